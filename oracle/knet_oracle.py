@@ -1,0 +1,253 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product package.
+
+CPU restatement (plain `torch`, functional, fp32 or fp64) of Video K-Net's kernel-update hot path,
+written from the reference's behaviour, each function citing the reference file:line it follows
+(paths relative to the upstream repo lxtGH/Video-K-Net).  Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import this module, and only as the checker / CPU baseline.
+
+Pinning status: the reference ships NO tests and NO golden vectors.  This oracle
+is pinned against outputs of the reference's own Python (imported unmodified in the build container
+through `oracle/standins/`, see `oracle/gen_golden.py`) committed under `tests/golden/`.  The mmcv
+wrapper semantics (`MultiheadAttention`, `FFN`, `ConvModule`) are not in the reference tree and mmcv is
+not installable offline; they are restated from mmcv 1.3-1.7 — that part of the pin is conditional on
+the restatement (flagged in DESIGN.md).
+
+It uses the same ATen op sequence as the reference (1x1 `conv2d`, `sigmoid > thr`, `einsum`, linear,
+`layer_norm`, softmax attention, per-image `conv2d`, bilinear `interpolate`) so that it also serves as the
+"port" CPU baseline in bench.py.
+"""
+import math
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class HeadCfg:
+    """The subset of KernelUpdateHead / KernelIterHead ctor kwargs that changes forward arithmetic
+    (knet/det/kernel_update_head.py:19-65, knet/det/kernel_iter_head.py:14-46)."""
+    num_stages: int = 3
+    in_channels: int = 256
+    num_heads: int = 8
+    num_classes: int = 19
+    num_ffn_fcs: int = 2
+    num_cls_fcs: int = 1
+    num_mask_fcs: int = 1
+    conv_kernel_size: int = 1
+    hard_mask_thr: float = 0.5
+    mask_upsample_stride: int = 2
+    with_ffn: bool = True
+    feat_transform: bool = True
+    use_sigmoid_cls: bool = True
+    feat_channels: int = 256      # KernelUpdator.feat_channels (== in_channels in every shipped cfg)
+    previous_type: str = ''       # 'ffn' for the shipped video head (knet/video/kernel_update_head.py:173-190)
+    ln_eps: float = 1e-5
+    extra: dict = field(default_factory=dict)
+
+
+def _ln(sd, pfx, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[pfx + '.weight'], sd[pfx + '.bias'], eps)
+
+
+def _linear(sd, pfx, x, bias=True):
+    return F.linear(x, sd[pfx + '.weight'], sd[pfx + '.bias'] if bias else None)
+
+
+def kernel_updator(sd, pfx, update_feature, input_feature, cfg: HeadCfg):
+    """knet/kernel_updator.py:56-93 with the shipped flags gate_sigmoid=True, gate_norm_act=False,
+    activate_out=False (:15-17).  update_feature [B,N,C]; input_feature [B,N,K*K,C] -> [B*N,K*K,C]."""
+    Cin, Cf = cfg.in_channels, cfg.feat_channels
+    u = update_feature.reshape(-1, Cin)                                   # :57
+    n = u.size(0)
+    params = _linear(sd, pfx + '.dynamic_layer', u)                       # :59
+    param_in, param_out = params[:, :Cf], params[:, -Cf:]                 # :60-63
+    feats = _linear(sd, pfx + '.input_layer', input_feature.reshape(n, -1, Cf))   # :65-66
+    input_in, input_out = feats[..., :Cf], feats[..., -Cf:]               # :67-68
+    gate = input_in * param_in.unsqueeze(-2)                              # :70
+    input_gate = _ln(sd, pfx + '.input_norm_in', _linear(sd, pfx + '.input_gate', gate), cfg.ln_eps).sigmoid()   # :74,76-77
+    update_gate = _ln(sd, pfx + '.norm_in', _linear(sd, pfx + '.update_gate', gate), cfg.ln_eps).sigmoid()       # :75,78
+    param_out = _ln(sd, pfx + '.norm_out', param_out, cfg.ln_eps)         # :79
+    input_out = _ln(sd, pfx + '.input_norm_out', input_out, cfg.ln_eps)   # :80
+    feats = update_gate * param_out.unsqueeze(-2) + input_gate * input_out     # :87-88
+    feats = _linear(sd, pfx + '.fc_layer', feats)                         # :90
+    return F.relu(_ln(sd, pfx + '.fc_norm', feats, cfg.ln_eps))           # :91-92
+
+
+def multihead_attention(sd, pfx, query, key, value, identity, num_heads):
+    """mmcv `MultiheadAttention.forward` (identity + attn(q,k,v)[0], dropout 0, seq-first [L,B,E]) wrapping
+    `torch.nn.MultiheadAttention` (packed in_proj, scaled dot-product softmax attention, out_proj).
+    Call sites: knet/det/kernel_update_head.py:100-101,206; knet/video/kernel_update_head.py:174-178,404-411."""
+    L, B, E = query.shape
+    S = key.shape[0]
+    hd = E // num_heads
+    w, b = sd[pfx + '.attn.in_proj_weight'], sd[pfx + '.attn.in_proj_bias']
+    q = F.linear(query, w[:E], b[:E])
+    k = F.linear(key, w[E:2 * E], b[E:2 * E])
+    v = F.linear(value, w[2 * E:], b[2 * E:])
+    q = q.reshape(L, B * num_heads, hd).transpose(0, 1)      # [B*h, L, hd]
+    k = k.reshape(S, B * num_heads, hd).transpose(0, 1)
+    v = v.reshape(S, B * num_heads, hd).transpose(0, 1)
+    attn = torch.softmax(torch.bmm(q * (1.0 / math.sqrt(hd)), k.transpose(1, 2)), dim=-1)
+    out = torch.bmm(attn, v).transpose(0, 1).reshape(L, B, E)
+    out = F.linear(out, sd[pfx + '.attn.out_proj.weight'], sd[pfx + '.attn.out_proj.bias'])
+    return identity + out
+
+
+def ffn(sd, pfx, x, num_fcs):
+    """mmcv `FFN.forward` = x + layers(x), layers = Seq(Seq(Linear,ReLU,Drop)x(num_fcs-1), Linear, Drop), dropout 0.
+    Call sites: knet/det/kernel_update_head.py:119-126,215."""
+    h = x
+    for i in range(num_fcs - 1):
+        h = F.relu(_linear(sd, f'{pfx}.layers.{i}.0', h))
+    h = _linear(sd, f'{pfx}.layers.{num_fcs - 1}', h)
+    return x + h
+
+
+def binarize(mask_logits, thr):
+    """knet/det/kernel_update_head.py:190-192: (sigmoid(z) > hard_mask_thr).float()."""
+    return (mask_logits.sigmoid() > thr).to(mask_logits.dtype)
+
+
+def mask_gather(x, m):
+    """knet/det/kernel_update_head.py:195: einsum('bnhw,bchw->bnc')."""
+    return torch.einsum('bnhw,bchw->bnc', m, x)
+
+
+def mask_decode(x, mask_feat, K):
+    """knet/det/kernel_update_head.py:247-260: per-image F.conv2d(x[i:i+1], mask_feat[i], padding=K//2)."""
+    B = x.shape[0]
+    outs = [F.conv2d(x[i:i + 1], mask_feat[i], padding=int(K // 2)) for i in range(B)]
+    return torch.cat(outs, dim=0)
+
+
+def update_head_stage(sd, pfx, x, proposal_feat, mask_preds, cfg: HeadCfg, previous_obj_feats=None, trace=None):
+    """One `KernelUpdateHead.forward` (knet/det/kernel_update_head.py:170-277) / `VideoKernelUpdateHead.forward`
+    with previous_type='ffn', previous_link=None (knet/video/kernel_update_head.py:281-541).
+    Returns (cls_score [B,N,ncls], new_mask_preds [B,N,H,W], obj_feat [B,N,C,K,K], x_feat [B,N,C], track or None)."""
+    B, N = proposal_feat.shape[:2]
+    C, K = cfg.in_channels, cfg.conv_kernel_size
+    if cfg.feat_transform:                                                 # :179-180 (ConvModule: conv only, bias, no norm/act)
+        x = F.conv2d(x, sd[pfx + '.feat_transform.conv.weight'], sd[pfx + '.feat_transform.conv.bias'])
+    H, W = x.shape[-2:]
+    if mask_preds.shape[-2:] != (H, W):                                    # :183-186
+        gather_mask = F.interpolate(mask_preds, (H, W), align_corners=False, mode='bilinear')
+    else:
+        gather_mask = mask_preds
+    m = binarize(gather_mask, cfg.hard_mask_thr)                           # :190-192
+    x_feat = mask_gather(x, m)                                             # :195
+    pf = proposal_feat.reshape(B, N, C, -1).permute(0, 1, 3, 2)            # :198-200  [B,N,K*K,C]
+    obj = kernel_updator(sd, pfx + '.kernel_update_conv', x_feat, pf, cfg)  # :201
+    obj = obj.reshape(B, N, -1).permute(1, 0, 2)                           # :204-205  [N,B,K*K*C]
+    obj_att = multihead_attention(sd, pfx + '.attention', obj, obj, obj, obj, cfg.num_heads)
+    obj = _ln(sd, pfx + '.attention_norm', obj_att, cfg.ln_eps)            # :206
+    obj = obj.permute(1, 0, 2).reshape(B, N, -1, C)                        # :208-211
+    if cfg.with_ffn:                                                       # :214-215
+        obj = _ln(sd, pfx + '.ffn_norm', ffn(sd, pfx + '.ffn', obj, cfg.num_ffn_fcs), cfg.ln_eps)
+    track = None
+    if previous_obj_feats is not None and cfg.previous_type == 'ffn':      # video :394-415
+        prev = previous_obj_feats.reshape(B, N, C * K * K).permute(1, 0, 2)
+        cur = obj.reshape(B, N, C * K * K).permute(1, 0, 2)
+        t = multihead_attention(sd, pfx + '.attention_previous', cur, prev, prev, cur, 8)   # _num_head = 8, :165
+        t = _ln(sd, pfx + '.attention_previous_norm', t, cfg.ln_eps)
+        t = t.permute(1, 0, 2).reshape(B, N, -1, C)
+        t = _ln(sd, pfx + '.link_ffn_norm', ffn(sd, pfx + '.link_ffn', t, cfg.num_ffn_fcs), cfg.ln_eps)
+        track = t.permute(0, 1, 3, 2).reshape(B, N, C, K, K)               # :536-538
+    cls_feat = obj.sum(-2)                                                 # :217
+    mask_feat = obj
+    for i in range(cfg.num_cls_fcs):                                       # :220-221  Linear(no bias) + LN + ReLU
+        cls_feat = F.relu(_ln(sd, f'{pfx}.cls_fcs.{3 * i + 1}', _linear(sd, f'{pfx}.cls_fcs.{3 * i}', cls_feat, bias=False), cfg.ln_eps))
+    for i in range(cfg.num_mask_fcs):                                      # :222-223
+        mask_feat = F.relu(_ln(sd, f'{pfx}.mask_fcs.{3 * i + 1}', _linear(sd, f'{pfx}.mask_fcs.{3 * i}', mask_feat, bias=False), cfg.ln_eps))
+    cls_score = _linear(sd, pfx + '.fc_cls', cls_feat).view(B, N, -1)      # :225
+    mask_feat = _linear(sd, pfx + '.fc_mask', mask_feat).permute(0, 1, 3, 2)   # :227
+    mask_feat = mask_feat.reshape(B, N, C, K, K)                           # :244-246
+    new_mask_preds = mask_decode(x, mask_feat, K).reshape(B, N, H, W)      # :247-260
+    obj_out = obj.permute(0, 1, 3, 2).reshape(B, N, C, K, K)               # :275-277
+    if trace is not None:
+        trace.update(dict(x_t=x, bin_mask=m, x_feat=x_feat, cls_score=cls_score, mask_feat=mask_feat.reshape(B, N, C * K * K),
+                          new_mask_preds=new_mask_preds, obj_feat=obj_out))
+    return cls_score, new_mask_preds, obj_out, x_feat, track
+
+
+def iter_head_mask_preds(sd, x, proposal_feats, mask_preds, cfg: HeadCfg, previous_obj_feats=None, traces=None,
+                         prefix='mask_head'):
+    """`KernelIterHead.simple_test_mask_preds` (knet/det/kernel_iter_head.py:285-311) and the video
+    `simple_test_mask_preds_plus_previous` (knet/video/kernel_iter_head.py:529-564): S stages, bilinear
+    x`mask_upsample_stride` on the last stage (`_mask_forward` :118-137), then cls activation (:307-310).
+    `previous_obj_feats` is passed to the LAST stage only (video :544-546).
+    Returns (object_feats, cls_score, mask_preds, scaled_mask_preds, object_feats_track or None)."""
+    obj, cls, track = proposal_feats, None, None
+    scaled = mask_preds
+    for s in range(cfg.num_stages):
+        prev = previous_obj_feats if s == cfg.num_stages - 1 else None
+        tr = {} if traces is not None else None
+        cls, mask_preds, obj, _xf, track = update_head_stage(sd, f'{prefix}.{s}', x, obj, mask_preds, cfg, prev, tr)
+        if traces is not None:
+            traces.append(tr)
+        if cfg.mask_upsample_stride > 1 and s == cfg.num_stages - 1:
+            scaled = F.interpolate(mask_preds, scale_factor=cfg.mask_upsample_stride, align_corners=False, mode='bilinear')
+        else:
+            scaled = mask_preds
+    cls = cls.sigmoid() if cfg.use_sigmoid_cls else cls.softmax(-1)[..., :-1]
+    return obj, cls, mask_preds, scaled, track
+
+
+def stage_param_shapes(cfg: HeadCfg):
+    """{state-dict key (without the `mask_head.{s}.` prefix): shape} of one stage — SURVEY.md §8(b)."""
+    C, Cf, ncls = cfg.in_channels, cfg.feat_channels, cfg.num_classes
+    E = C * cfg.conv_kernel_size ** 2
+    sh = {}
+
+    def lin(name, o, i, bias=True):
+        sh[name + '.weight'] = (o, i)
+        if bias:
+            sh[name + '.bias'] = (o,)
+
+    def ln(name, n):
+        sh[name + '.weight'] = (n,)
+        sh[name + '.bias'] = (n,)
+
+    def mha(name):
+        sh[name + '.attn.in_proj_weight'] = (3 * E, E)
+        sh[name + '.attn.in_proj_bias'] = (3 * E,)
+        lin(name + '.attn.out_proj', E, E)
+
+    def ffn_(name):
+        ff = cfg.extra.get('feedforward_channels', 2048)
+        i = C
+        for k in range(cfg.num_ffn_fcs - 1):
+            lin(f'{name}.layers.{k}.0', ff, i)
+            i = ff
+        lin(f'{name}.layers.{cfg.num_ffn_fcs - 1}', C, i)
+
+    mha('attention'); ln('attention_norm', E)
+    ku = 'kernel_update_conv'
+    lin(ku + '.dynamic_layer', 2 * Cf, C); lin(ku + '.input_layer', 2 * Cf, C)
+    lin(ku + '.input_gate', Cf, C); lin(ku + '.update_gate', Cf, C)
+    for n_ in ('norm_in', 'norm_out', 'input_norm_in', 'input_norm_out'):
+        ln(f'{ku}.{n_}', Cf)
+    lin(ku + '.fc_layer', C, Cf); ln(ku + '.fc_norm', C)
+    if cfg.feat_transform:
+        sh['feat_transform.conv.weight'] = (C, C, 1, 1)
+        sh['feat_transform.conv.bias'] = (C,)
+    if cfg.with_ffn:
+        ffn_('ffn'); ln('ffn_norm', C)
+    for i in range(cfg.num_cls_fcs):
+        lin(f'cls_fcs.{3 * i}', C, C, bias=False); ln(f'cls_fcs.{3 * i + 1}', C)
+    lin('fc_cls', ncls if cfg.use_sigmoid_cls else ncls + 1, C)
+    for i in range(cfg.num_mask_fcs):
+        lin(f'mask_fcs.{3 * i}', C, C, bias=False); ln(f'mask_fcs.{3 * i + 1}', C)
+    lin('fc_mask', C, C)
+    if cfg.previous_type == 'ffn':
+        mha('attention_previous'); ln('attention_previous_norm', E)
+        ffn_('link_ffn'); ln('link_ffn_norm', C)
+    return sh
+
+
+def head_param_shapes(cfg: HeadCfg, prefix='mask_head'):
+    out = {}
+    for s in range(cfg.num_stages):
+        for k, v in stage_param_shapes(cfg).items():
+            out[f'{prefix}.{s}.{k}'] = v
+    return out

@@ -1,0 +1,75 @@
+"""Deterministic synthetic tensors for goldens and parity tests — TEST INFRASTRUCTURE ONLY.
+
+Values come from an integer hash (splitmix64 finaliser) of the flat element index, so they are
+bit-reproducible on any machine without relying on a framework RNG stream.  Used by
+`oracle/gen_golden.py` (build container) and by `tests/` (build container and GPU box) to regenerate
+the *inputs* of a golden case; only the reference's *outputs* are stored in `tests/golden/`.
+"""
+import math
+
+import numpy as np
+
+_M64 = (1 << 64) - 1
+
+
+def _splitmix(idx: np.ndarray, salt: int) -> np.ndarray:
+    with np.errstate(over='ignore'):
+        z = idx.astype(np.uint64) + np.uint64((salt * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & _M64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform(shape, salt: int, lo=-1.0, hi=1.0) -> np.ndarray:
+    """float32 tensor, U[lo,hi) from the hash of the flat index (24 random mantissa bits)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    z = _splitmix(np.arange(n, dtype=np.uint64), salt)
+    u = (z >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def normalish(shape, salt: int, std=1.0) -> np.ndarray:
+    """Sum of four uniforms (Irwin-Hall), variance-normalised: smooth bell-shaped, bounded."""
+    acc = np.zeros(shape, dtype=np.float64)
+    for k in range(4):
+        acc += uniform(shape, salt * 4 + k + 1000003, -1.0, 1.0).astype(np.float64)
+    return (acc * (std / math.sqrt(4.0 / 3.0))).astype(np.float32)
+
+
+def _key_salt(key: str, seed: int) -> int:
+    h = 1469598103934665603
+    for ch in key.encode():
+        h = ((h ^ ch) * 1099511628211) & _M64
+    return (h ^ (seed * 0x9E3779B97F4A7C15)) & 0x7FFFFFFF
+
+
+def state_dict_like(shapes: dict, seed: int = 0) -> dict:
+    """Weights for a {key: shape} map, mirroring the reference init *distribution*
+    (knet/det/kernel_update_head.py:151-168: xavier-uniform on dim>1, fc_cls.bias = -log 99) but with
+    non-trivial LayerNorm affine and biases so that every parameter influences the outputs."""
+    out = {}
+    for key, shape in shapes.items():
+        shape = tuple(shape)
+        salt = _key_salt(key, seed)
+        if len(shape) > 1:
+            rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+            fan_in, fan_out = shape[1] * rf, shape[0] * rf
+            b = math.sqrt(6.0 / (fan_in + fan_out))
+            out[key] = uniform(shape, salt, -b, b)
+        elif key.endswith('weight'):
+            # every 1-D `weight` on the path is a LayerNorm gain: ~ 1 +- 0.2
+            out[key] = uniform(shape, salt, 0.8, 1.2)
+        elif key.endswith('fc_cls.bias'):
+            out[key] = (uniform(shape, salt, -0.2, 0.2) - math.log(99.0)).astype(np.float32)
+        else:
+            out[key] = uniform(shape, salt, -0.1, 0.1)
+    return out
+
+
+def head_inputs(B, N, C, H, W, seed=0, mask_scale=4.0):
+    """x [B,C,H,W], proposal_feats [B,N,C,1,1], mask_preds [B,N,H,W]."""
+    x = normalish((B, C, H, W), 11 + 7 * seed, 1.0)
+    pf = normalish((B, N, C, 1, 1), 12 + 7 * seed, 1.0)
+    mp = normalish((B, N, H, W), 13 + 7 * seed, mask_scale)
+    return x, pf, mp

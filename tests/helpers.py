@@ -1,0 +1,48 @@
+"""Shared test helpers: golden loading, formula weights/inputs, oracle runs.  Imports oracle/ (allowed in tests/)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import synth
+from oracle.knet_oracle import HeadCfg, head_param_shapes, iter_head_mask_preds
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CASE_FIELDS = ('C', 'heads', 'ffn', 'ncls', 'n_thing', 'n_stuff', 'S', 'up', 'nprop', 'N', 'H', 'W', 'B', 'seed', 'video')
+
+
+def load_golden(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+    case = dict(zip(CASE_FIELDS, (int(v) for v in g['case'])))
+    return g, case
+
+
+def cfg_of(case) -> HeadCfg:
+    return HeadCfg(num_stages=case['S'], in_channels=case['C'], num_heads=case['heads'], num_classes=case['ncls'],
+                   mask_upsample_stride=case['up'], feat_channels=case['C'],
+                   previous_type='ffn' if case['video'] else '', extra=dict(feedforward_channels=case['ffn']))
+
+
+def make_case(case, dtype=torch.float32):
+    """(cfg, state_dict, x, proposal_feats, mask_preds, previous_obj_feats|None) regenerated from the hash formulas."""
+    cfg = cfg_of(case)
+    shapes = head_param_shapes(cfg)
+    sd = {k: torch.from_numpy(v).to(dtype) for k, v in synth.state_dict_like(shapes, case['seed']).items()}
+    x, pf, mp = (torch.from_numpy(a).to(dtype) for a in
+                 synth.head_inputs(case['B'], case['N'], case['C'], case['H'], case['W'], case['seed']))
+    prev = None
+    if case['video']:
+        prev = torch.from_numpy(synth.normalish((case['B'], case['N'], case['C'], 1, 1), 99 + case['seed'], 1.0)).to(dtype)
+    return cfg, sd, x, pf, mp, prev
+
+
+def run_oracle(case, dtype=torch.float32, traces=None):
+    cfg, sd, x, pf, mp, prev = make_case(case, dtype)
+    with torch.no_grad():
+        return iter_head_mask_preds(sd, x, pf, mp, cfg, previous_obj_feats=prev, traces=traces)
+
+
+def maxabs(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b))) if a.size else 0.0

@@ -1,0 +1,79 @@
+"""CPU: the oracle (oracle/knet_oracle.py) against golden vectors captured from the reference's own Python
+(oracle/gen_golden.py).  This is what pins the oracle (the reference has no tests of its own)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, cfg_of, load_golden, maxabs, run_oracle
+from oracle.knet_oracle import binarize, head_param_shapes
+
+TOL = 2e-5   # same ATen ops, same machine class: summation-order noise only (|logit| up to ~60)
+
+
+@pytest.mark.parametrize('name', ['det_tiny', 'det_odd', 'det_cfg', 'video_tiny', 'video_cfg'])
+def test_oracle_matches_reference_golden(name):
+    g, case = load_golden(name)
+    traces = []
+    obj, cls, masks, scaled, track = run_oracle(case, traces=traces)
+    assert maxabs(obj, g['object_feats']) < TOL
+    assert maxabs(cls, g['cls_score']) < TOL
+    assert maxabs(masks, g['mask_preds']) < 5 * TOL
+    for s, tr in enumerate(traces):
+        assert maxabs(tr['cls_score'], g[f's{s}_cls']) < TOL
+        assert maxabs(tr['obj_feat'], g[f's{s}_obj']) < TOL
+        if f's{s}_mask' in g:
+            assert maxabs(tr['new_mask_preds'], g[f's{s}_mask']) < 5 * TOL
+    if 'scaled_mask_preds' in g:
+        assert maxabs(scaled, g['scaled_mask_preds']) < 5 * TOL
+    else:
+        rs = scaled.double().sum(dim=(-1, -2)).numpy()
+        assert np.max(np.abs(rs - g['scaled_rowsum']) / (1.0 + np.abs(g['scaled_rowsum']))) < 1e-4
+    if case['video']:
+        assert track is not None and maxabs(track, g['track']) < TOL
+    else:
+        assert track is None
+
+
+def test_oracle_matches_reference_golden_cfg1_size():
+    g, case = load_golden('det_cfg_big')
+    obj, cls, masks, scaled, _ = run_oracle(case)
+    assert maxabs(obj, g['object_feats']) < TOL
+    assert maxabs(cls, g['cls_score']) < TOL
+    flat = masks.reshape(-1)
+    assert maxabs(flat[torch.from_numpy(g['sample_idx'])], g['sample_val']) < 1e-4
+    rs = masks.double().sum(dim=(-1, -2)).numpy()
+    assert np.max(np.abs(rs - g['mask_rowsum'])) < 1e-4 * np.max(g['mask_rowabs'])
+    bits = np.packbits(flat.numpy() > 0)
+    valid = g['sign_valid']
+    assert np.all((bits ^ g['sign_bits']) & valid == 0), 'sign of a logit with |logit|>2e-3 differs from the reference'
+
+
+def test_state_dict_keys_match_reference():
+    for name in ('det_cfg', 'video_cfg'):
+        g, case = load_golden(name)
+        shapes = head_param_shapes(cfg_of(case))
+        assert sorted(shapes) == list(g['keys'])
+        assert [str(tuple(shapes[k])) for k in sorted(shapes)] == list(g['shapes'])
+    g, case = load_golden('det_cfg')
+    assert len([k for k in g['keys'] if k.startswith('mask_head.0.')]) == 44
+    n = sum(int(np.prod(eval(s))) for k, s in zip(g['keys'], g['shapes']) if k.startswith('mask_head.0.'))
+    assert n == 2046739
+
+
+def test_threshold_kat():
+    g = np.load(os.path.join(GOLDEN, 'thr_kat.npz'))
+    z = torch.from_numpy(g['z'])
+    assert np.array_equal(binarize(z, 0.5).numpy() > 0, g['bit'])
+    assert float(g['flip']) == pytest.approx(8.94069742685133e-08, rel=0, abs=0)
+    # not "z > 0": strictly positive logits below the flip point stay OFF
+    assert not bool(binarize(torch.tensor([5e-8]), 0.5)[0]) and bool(binarize(torch.tensor([1e-7]), 0.5)[0])
+
+
+def test_oracle_fp64_headroom():
+    """fp32 oracle vs the same code in fp64: documents the tolerance budget."""
+    _, case = load_golden('det_cfg')
+    o32 = run_oracle(case, torch.float32)
+    o64 = run_oracle(case, torch.float64)
+    assert maxabs(o32[2], o64[2]) < 1e-3
