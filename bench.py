@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of the Video K-Net kernel-update head on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one pass of the hot path over one clip of `--frames` synthetic 1024x2048 frames per GPU:
+`VideoKernelIterHead` (S=3 stages of gather -> kernel update + interaction -> decode, N = 100 proposals + 17 stuff kernels,
+C = 256) + the last stage's tracking link (previous_type="ffn") + the x4 bilinear upsample of the final logits
+(`_mask_forward`), i.e. everything `simple_test_mask_preds_plus_previous` does per frame; inputs are
+resident in HBM before the timed region.  Frames of a clip are sharded over the ranks in contiguous blocks (weak scaling:
+`--frames` per GPU); the only cross-rank data is the [N x C] kernel set of a block's last frame, which the next rank's first
+frame needs for its tracking embedding (RCCL all_gather, 120 KB per rank, inside the timed region).
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (mask-decode kernel, HIP-event timed, algorithmic bytes / time
+vs 8 TB/s HBM), "cpu_baseline" (the torch CPU oracle timed on this host, rank 0 / N=1 only), "breakdown".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+CFG2 = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256)
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def build_head(vkn, device, seed=0):
+    from test_host_logic import _cfg
+    head = vkn.build_head(_cfg(True, C=CFG2['C'], heads=CFG2['heads'], ffn=CFG2['ffn'], ncls=CFG2['ncls'],
+                               n_thing=CFG2['n_thing'], n_stuff=CFG2['n_stuff'], S=CFG2['S'], up=CFG2['up'],
+                               nprop=CFG2['nprop']))
+    torch.manual_seed(seed)
+    head.init_weights()                      # xavier-uniform, fc_cls.bias = -log 99 (reference init; no checkpoints offline)
+    return head.to(device).eval()
+
+
+def synth_inputs(B, device, seed):
+    g = torch.Generator(device='cpu').manual_seed(1234 + seed)
+    x = torch.randn(B, CFG2['C'], CFG2['H'], CFG2['W'], generator=g)
+    pf = torch.randn(B, CFG2['N'], CFG2['C'], 1, 1, generator=g)
+    mp = torch.randn(B, CFG2['N'], CFG2['H'], CFG2['W'], generator=g) * 4.0
+    return x.to(device), pf.to(device), mp.to(device)
+
+
+def cpu_baseline(head_sd, sample_frames=1, runs=6):
+    """The CPU oracle (same ATen op sequence as the reference) on this host's cores — kind 'port'."""
+    from oracle.knet_oracle import HeadCfg, iter_head_mask_preds
+    cfg = HeadCfg(num_stages=CFG2['S'], in_channels=CFG2['C'], num_heads=CFG2['heads'], num_classes=CFG2['ncls'],
+                  mask_upsample_stride=CFG2['up'], feat_channels=CFG2['C'], previous_type='ffn',
+                  extra=dict(feedforward_channels=CFG2['ffn']))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in head_sd.items()}
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(sample_frames, CFG2['C'], CFG2['H'], CFG2['W'], generator=g)
+    pf = torch.randn(sample_frames, CFG2['N'], CFG2['C'], 1, 1, generator=g)
+    mp = torch.randn(sample_frames, CFG2['N'], CFG2['H'], CFG2['W'], generator=g) * 4.0
+    prev = torch.randn(sample_frames, CFG2['N'], CFG2['C'], 1, 1, generator=g)
+    ts = []
+    with torch.no_grad():
+        for i in range(2 + runs):
+            t0 = time.perf_counter()
+            iter_head_mask_preds(sd, x, pf, mp, cfg, previous_obj_feats=prev)
+            if i >= 2:
+                ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return dict(value=round(sample_frames / med, 4), unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{runs} timed runs (2 warm-up) of {sample_frames} frame(s), same workload, fp32, median; '
+                       f'min {sample_frames / ts[-1]:.3f} max {sample_frames / ts[0]:.3f} frames/s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--frames', type=int, default=8, help='frames of the clip per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=device)
+
+    import vkn_import
+    vkn = vkn_import.load()
+    head = build_head(vkn, device)
+    B = args.frames
+    x, pf, mp = synth_inputs(B, device, rank)
+    N, C = CFG2['N'], CFG2['C']
+    last = head.mask_head[-1]
+    dims = last.make_dims(B, N, CFG2['H'], CFG2['W'])
+    packs = [h.stage_pack(device) for h in head.mask_head]
+    gather_buf = torch.empty(world, N, C, device=device) if world > 1 else None
+    first_prev = torch.zeros(1, N, C, device=device)
+    up = 1 if args.no_upsample else CFG2['up']
+
+    def step():
+        # all frames of this rank's block: S stages + upsample (one C-ABI call) ...
+        obj, cls, masks, scaled, _ = vkn.ops.head_forward(dims, packs, x, pf.reshape(B, N, C), mp, None, up)
+        cur = obj
+        # ... then the tracking link: prev[b] = obj[b-1]; frame 0 takes the previous rank's last frame
+        if world > 1:
+            dist.all_gather_into_tensor(gather_buf, cur[-1].contiguous())
+            p0 = gather_buf[(rank - 1) % world].unsqueeze(0)
+        else:
+            p0 = first_prev
+        prev = torch.cat([p0, cur[:-1]], 0)
+        track = vkn.ops.track_link(dims, packs[-1], cur, prev)
+        return obj, cls, masks, scaled, track
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames = world * B * args.steps
+    ms_per_step = dt / args.steps * 1e3
+
+    extra = {}
+    if rank == 0:
+        with torch.no_grad():
+            # ---- roofline of the dominant kernel: k_decode_mfma alone, HIP events on the launch stream
+            P = CFG2['H'] * CFG2['W']
+            kern = torch.randn(B, N, C, device=device)
+            hi, lo = vkn.ops.split_planes(kern)
+            kb = torch.randn(B, N, device=device)
+            outm = torch.empty(B, N, CFG2['H'], CFG2['W'], device=device)
+            for _ in range(3):
+                vkn.ops.mask_decode_planes(x, hi, lo, N, kb, outm)
+            reps = 20
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                vkn.ops.mask_decode_planes(x, hi, lo, N, kb, outm)
+            e1.record()
+            torch.cuda.synchronize()
+            dec_ms = e0.elapsed_time(e1) / reps
+            alg = B * P * (C * 4 + N * 4)                      # read x once + write the logits once
+            ach = alg / (dec_ms * 1e-3) / 1e9
+            extra['roofline'] = dict(kernel='k_decode_mfma', bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+                                     unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                                     algorithmic_bytes_per_launch=alg, avg_launch_ms=round(dec_ms, 4),
+                                     frames_per_launch=B)
+            # gather kernel (+ its partial reduce), same accounting: read x once + read the logits once
+            for _ in range(3):
+                vkn.ops.mask_gather(x, mp)
+            e0.record()
+            for _ in range(reps):
+                vkn.ops.mask_gather(x, mp)
+            e1.record()
+            torch.cuda.synchronize()
+            ga_ms = e0.elapsed_time(e1) / reps
+            # head without the x4 upsample output, and the upsample alone
+            e0.record()
+            for _ in range(5):
+                vkn.ops.head_forward(dims, packs, x, pf.reshape(B, N, C), mp, None, 1)
+            e1.record()
+            torch.cuda.synchronize()
+            head_ms = e0.elapsed_time(e1) / 5
+            e0.record()
+            for _ in range(5):
+                vkn.ops.upsample_bilinear(outm, CFG2['up'])
+            e1.record()
+            torch.cuda.synchronize()
+            up_ms = e0.elapsed_time(e1) / 5
+            extra['breakdown'] = dict(decode_ms=round(dec_ms, 4), gather_plus_reduce_ms=round(ga_ms, 4),
+                                      gather_GBps=round(alg / (ga_ms * 1e-3) / 1e9, 1),
+                                      head_3stages_no_upsample_ms=round(head_ms, 4),
+                                      upsample_x4_ms=round(up_ms, 4),
+                                      upsample_write_GBps=round(B * N * P * 16 * 4 / (up_ms * 1e-3) / 1e9, 1),
+                                      frames_per_s_no_upsample=round(B / (head_ms * 1e-3), 1))
+        if world == 1 and not args.no_cpu_baseline:
+            extra['cpu_baseline'] = cpu_baseline(head.state_dict())
+
+    if rank == 0:
+        line = dict(metric='frames/sec (S=3, N=100, 1024x2048)', value=round(frames / dt, 2), unit='frames/s',
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    config=dict(workload='cfg2 video_knet_s3_r50: VideoKernelIterHead S=3, N=100 proposals + 17 stuff = 117 '
+                                         'kernels, C=256, 1024x2048 frame -> 128x256 stride-8 features, ffn tracking link, '
+                                         'x4 bilinear upsample of the final logits' + (' [SKIPPED]' if args.no_upsample else ''),
+                                frames_per_gpu_per_step=B, parallelism=f'frame-sharded dp{world}',
+                                arithmetic='fp32 storage; gather/decode on f16 hi+lo split MFMA with fp32 accumulate; '
+                                           '[N x C] GEMMs exact-fp32 MFMA; random-init weights'),
+                    **extra)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,157 @@
+/* vkn.h — C ABI of libvkn.so: MI355X (gfx950) kernels for Video K-Net's kernel-update head.
+ *
+ * The reference (lxtGH/Video-K-Net) is 100 % Python and has NO FFI of its own; its boundary for this path is
+ * the call signature of three Python methods.  Each entry point below states the reference interface it replaces (file:line,
+ * relative to the upstream repo).  The reference-side binding is a `ctypes` stub — see INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - `extern "C"`, plain pointers and sizes; every pointer is a DEVICE pointer into caller-owned, contiguous memory
+ *     (16-byte aligned); nothing is allocated or freed inside; work is enqueued asynchronously on `stream`
+ *     (a `hipStream_t`, passed as void*; NULL = the default stream); no host synchronisation.
+ *   - return value: 0 = VKN_OK, < 0 = error (vkn_strerror); never throws, never aborts.
+ *   - re-entrant and thread-safe: no global mutable state; scratch memory is the caller's `ws` buffer
+ *     (size from vkn_stage_workspace_bytes / vkn_head_workspace_bytes).
+ *   - layouts: x [B][C][P] fp32 (NCHW, P = H*W); mask logits [B][N][P] fp32; kernels / object features [B][N][C] fp32
+ *     (the reference's [B,N,C,1,1] with conv_kernel_size K = 1, the only value in any shipped config).
+ *   - arithmetic: fp32 storage; gather / decode contract on MFMA with an f16 hi+lo operand split and fp32 accumulation
+ *     (2^-22 relative operand error, requires |x| < 65504); every [N x C] GEMM is exact-fp32 MFMA.
+ *     flags & VKN_FLAG_REF_KERNELS selects plain fp32 FMA kernels for gather / decode (slow, exact; debugging).
+ */
+#ifndef VKN_H
+#define VKN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VKN_VERSION 0x000100 /* 0.1.0 */
+
+#define VKN_OK 0
+#define VKN_E_ARG (-1)       /* null pointer / non-positive size */
+#define VKN_E_SHAPE (-2)     /* shape outside the supported envelope (see vkn_strerror text) */
+#define VKN_E_WORKSPACE (-3) /* ws too small or NULL */
+#define VKN_E_LAUNCH (-4)    /* HIP launch error */
+#define VKN_E_ALIGN (-5)     /* pointer not 16-byte aligned */
+
+#define VKN_FLAG_REF_KERNELS 1u /* exact-fp32 FMA gather/decode kernels instead of the MFMA ones */
+
+#define VKN_MAX_FCS 4
+
+/* Problem dimensions shared by the stage / head entry points. */
+typedef struct VknDims {
+    int B;      /* frames in this call */
+    int N;      /* kernels per frame (num_proposals + num_stuff_classes at inference, knet/det/kernel_head.py:256-263) */
+    int C;      /* in_channels == feat_channels == out_channels (256 in every shipped config); C % 32 == 0, C <= 256 */
+    int H, W;   /* feature-map size (stride 8 of the frame); P = H*W */
+    int heads;  /* num_heads of `attention` (8) */
+    int ff;     /* feedforward_channels (2048); ff % 32 == 0 */
+    int ncls;   /* fc_cls outputs (num_classes with sigmoid focal loss, knet/det/kernel_update_head.py:136-139) */
+    int n_cls_fcs, n_mask_fcs; /* num_cls_fcs / num_mask_fcs (1 / 1 in shipped configs), <= VKN_MAX_FCS */
+    float thr_logit; /* smallest fp32 z with sigmoid(z) > hard_mask_thr (8.940697e-08 for 0.5); bit = (z >= thr_logit) */
+    float ln_eps;    /* LayerNorm eps (1e-5) */
+} VknDims;
+
+/* One stage's parameters, torch layouts (Linear weight = [out][in]), fp32 device pointers.  Names follow the reference
+ * state-dict keys `mask_head.{s}.<...>`.  `ft_wT` is the only derived tensor: the transpose of
+ * feat_transform.conv.weight[:, :, 0, 0], prepared once by the host (weight folding). */
+typedef struct VknStageWeights {
+    const float *ft_w, *ft_b, *ft_wT;                 /* feat_transform.conv.{weight,bias}; all NULL if feat_transform is None */
+    const float *dyn_w, *dyn_b;                       /* kernel_update_conv.dynamic_layer   [2C][C] */
+    const float *inp_w, *inp_b;                       /* kernel_update_conv.input_layer     [2C][C] */
+    const float *ig_w, *ig_b, *ug_w, *ug_b;           /* kernel_update_conv.{input_gate,update_gate} [C][C] */
+    const float *norm_in_w, *norm_in_b;               /* kernel_update_conv.norm_in        (LN of update_gate) */
+    const float *norm_out_w, *norm_out_b;             /* kernel_update_conv.norm_out       (LN of param_out) */
+    const float *inorm_in_w, *inorm_in_b;             /* kernel_update_conv.input_norm_in  (LN of input_gate) */
+    const float *inorm_out_w, *inorm_out_b;           /* kernel_update_conv.input_norm_out (LN of input_out) */
+    const float *fc_w, *fc_b, *fc_norm_w, *fc_norm_b; /* kernel_update_conv.{fc_layer,fc_norm} */
+    const float *attn_in_w, *attn_in_b;               /* attention.attn.in_proj_{weight,bias} [3C][C] */
+    const float *attn_out_w, *attn_out_b;             /* attention.attn.out_proj */
+    const float *attn_norm_w, *attn_norm_b;           /* attention_norm */
+    const float *ffn1_w, *ffn1_b;                     /* ffn.layers.0.0 [ff][C] */
+    const float *ffn2_w, *ffn2_b;                     /* ffn.layers.1   [C][ff] */
+    const float *ffn_norm_w, *ffn_norm_b;             /* ffn_norm */
+    const float *cls_fc_w[VKN_MAX_FCS], *cls_ln_w[VKN_MAX_FCS], *cls_ln_b[VKN_MAX_FCS];    /* cls_fcs.{3i},{3i+1} */
+    const float *fc_cls_w, *fc_cls_b;                 /* fc_cls [ncls][C] */
+    const float *mask_fc_w[VKN_MAX_FCS], *mask_ln_w[VKN_MAX_FCS], *mask_ln_b[VKN_MAX_FCS]; /* mask_fcs.{3i},{3i+1} */
+    const float *fc_mask_w, *fc_mask_b;               /* fc_mask [C][C] */
+    /* video tracking link, previous_type == "ffn" (knet/video/kernel_update_head.py:173-190); all NULL for the image head */
+    const float *pa_in_w, *pa_in_b, *pa_out_w, *pa_out_b, *pa_norm_w, *pa_norm_b; /* attention_previous(.attn), _norm */
+    const float *lffn1_w, *lffn1_b, *lffn2_w, *lffn2_b, *lffn_norm_w, *lffn_norm_b; /* link_ffn, link_ffn_norm */
+} VknStageWeights;
+
+int vkn_version(void);
+const char* vkn_strerror(int code);
+/* sizeof(VknDims) / sizeof(VknStageWeights) as compiled — lets a foreign-language binding verify its struct mirror */
+size_t vkn_sizeof_dims(void);
+size_t vkn_sizeof_stage_weights(void);
+
+/* ---- op (i): mask gather.  Replaces `sigmoid_masks = (mask_preds.sigmoid() > hard_mask_thr).float();
+ *      x_feat = torch.einsum('bnhw,bchw->bnc', sigmoid_masks, x)`  knet/det/kernel_update_head.py:190-195
+ *      (same op at knet/video/kernel_iter_head.py:566-571, knet/det/kernel_head.py:248).
+ *      xraw_out [B][N][C], cnt_out [B][N] (number of ON pixels, may be NULL).  ws: vkn_gather_workspace_bytes. */
+size_t vkn_gather_workspace_bytes(int B, int N, int C, int P);
+int vkn_mask_gather_f32(const float* x, const float* mask_logits, float thr_logit, float* xraw_out, float* cnt_out, int B,
+                        int N, int C, int P, void* ws, size_t ws_bytes, unsigned flags, void* stream);
+
+/* ---- op (iii): mask decode.  Replaces the per-image loop `F.conv2d(mask_x[i:i+1], mask_feat[i], padding=K//2)`, K = 1
+ *      knet/det/kernel_update_head.py:247-260.   out[b][n][p] = sum_c kernels[b][n][c] x[b][c][p] + bias[b][n]
+ *      kernels [B][N][C] fp32, bias [B][N] or NULL, out [B][N][P].  ws: vkn_decode_workspace_bytes (f16 planes). */
+size_t vkn_decode_workspace_bytes(int B, int N, int C);
+int vkn_mask_decode_f32(const float* x, const float* kernels, const float* bias, float* out, int B, int N, int C, int P,
+                        void* ws, size_t ws_bytes, unsigned flags, void* stream);
+
+/* ---- the same decode on PRE-SPLIT kernels: kf_hi / kf_lo are f16 planes [B][roundup(N,32)][C] with hi + lo ~= K (rows >= N
+ *      are ignored), exactly what the update kernels hand to the decode inside a stage.  Launches the MFMA kernel only
+ *      (bench.py times it with HIP events for the roofline figure).  vkn_split_planes_f32 produces the planes. */
+int vkn_split_planes_f32(const float* kernels, void* kf_hi, void* kf_lo, int B, int N, int C, void* stream);
+int vkn_mask_decode_planes_f32(const float* x, const void* kf_hi, const void* kf_lo, const float* bias, float* out, int B,
+                               int N, int C, int P, void* stream);
+
+/* ---- `F.interpolate(mask_preds, scale_factor=S, mode='bilinear', align_corners=False)`
+ *      knet/det/kernel_iter_head.py:122-130.  in [planes][H][W] -> out [planes][H*S][W*S]. */
+int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, int W, int S, void* stream);
+
+/* ---- the gated kernel update alone.  Replaces `KernelUpdator.forward(update_feature, input_feature)`
+ *      knet/kernel_updator.py:56-93 (gate_sigmoid=True, gate_norm_act=False, activate_out=False — the defaults, :15-17).
+ *      update_feature [B][N][C] (= x_feat), input_feature [B][N][C] (= kernels, K*K = 1) -> out [B][N][C].
+ *      Only the kernel_update_conv.* members of `w` are read.  ws: vkn_stage_workspace_bytes. */
+int vkn_kernel_updator_f32(const VknDims* d, const VknStageWeights* w, const float* update_feature,
+                           const float* input_feature, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- one refinement stage.  Replaces `KernelUpdateHead.forward(x, proposal_feat, mask_preds)`
+ *      knet/det/kernel_update_head.py:170-277 and `VideoKernelUpdateHead.forward(..., previous_obj_feats=...)`
+ *      knet/video/kernel_update_head.py:281-541 (previous_type="ffn", previous_link=None).
+ *      in : x [B][C][P], obj_in [B][N][C] (= proposal_feat), masks_in [B][N][P], prev_obj [B][N][C] or NULL
+ *      out: cls_logits [B][N][ncls], masks_out [B][N][P], obj_out [B][N][C],
+ *           x_feat_out [B][N][C] or NULL (4th output of the video head), track_out [B][N][C] or NULL (5th; needs prev_obj). */
+size_t vkn_stage_workspace_bytes(const VknDims* d);
+int vkn_stage_forward_f32(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in,
+                          const float* masks_in, const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out,
+                          float* x_feat_out, float* track_out, void* ws, size_t ws_bytes, unsigned flags, void* stream);
+
+/* ---- the video tracking link alone (previous_type == "ffn"):
+ *      track = link_ffn_norm(link_ffn(attention_previous_norm(attention_previous(q=cur, k=v=prev, identity=cur))))
+ *      knet/video/kernel_update_head.py:394-415.  cur = this frame's final object features [B][N][C], prev = the previous
+ *      frame's [B][N][C].  Lets a clip be processed as one batch: all frames' masks first (they do not depend on the
+ *      previous frame), then one link call with prev[b] = cur[b-1].  ws: vkn_stage_workspace_bytes. */
+int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* cur_obj, const float* prev_obj,
+                       float* track_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- the S-stage loop.  Replaces `KernelIterHead.simple_test_mask_preds` knet/det/kernel_iter_head.py:285-311 and
+ *      `VideoKernelIterHead.simple_test_mask_preds_plus_previous` knet/video/kernel_iter_head.py:529-564
+ *      (stage loop + last-stage bilinear upsample `_mask_forward` :118-137 + cls sigmoid :307-308).
+ *      prev_obj is given to the LAST stage only (video :544-546).
+ *      out: obj_out [B][N][C], cls_prob [B][N][ncls] (sigmoid applied), mask_preds_out [B][N][P],
+ *           scaled_out [B][N][H*up][W*up] or NULL (skipped), track_out [B][N][C] or NULL. */
+size_t vkn_head_workspace_bytes(const VknDims* d);
+int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const float* x,
+                         const float* proposal_feats, const float* mask_preds_in, const float* prev_obj, float* obj_out,
+                         float* cls_prob, float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out,
+                         void* ws, size_t ws_bytes, unsigned flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKN_H */

@@ -16,4 +16,7 @@ def pytest_configure(config):
 def vkn():
     """The product package (directory `video-k-net_amd/`, imported as `video_k_net_amd`)."""
     import vkn_import
-    return vkn_import.load()
+    mod = vkn_import.load()
+    if not os.path.exists(mod._lib.LIBPATH) or os.environ.get('VKN_REBUILD') == '1':
+        mod.build(force=True)          # hipcc cross-compiles gfx950 without a GPU (same recipe as __graft_entry__.build)
+    return mod

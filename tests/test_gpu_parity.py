@@ -1,0 +1,273 @@
+"""GPU (-m gpu): parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs, against the
+golden vectors captured from the reference, and — at BASELINE cfg2 size — through size-independent properties.
+
+Tolerances (north_star): mask logits within 1e-3 (fp32); integer artefacts (binary masks, pixel counts) bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import GOLDEN, cfg_of, load_golden, make_case, maxabs, run_oracle
+from oracle import knet_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL_LOGIT = 1e-3
+
+
+def _cuda(*ts):
+    return [t.to(DEV) if t is not None else None for t in ts]
+
+
+def _rand(shape, salt, std=1.0):
+    return torch.from_numpy(synth.normalish(shape, salt, std))
+
+
+SHAPES = [  # B, N, C, H, W
+    (2, 15, 64, 8, 16),      # tiny
+    (1, 21, 64, 9, 15),      # ragged P = 135 (scalar-load path, pixel tail)
+    (2, 117, 256, 16, 32),   # config channels / kernels
+    (1, 117, 256, 64, 128),  # BASELINE cfg1 size
+    (1, 166, 256, 23, 40),   # VIP-Seg kernel count: two n-chunks (128 + 64 rows), P % 32 != 0
+    (3, 100, 32, 4, 8),      # one channel block, one pixel tile
+]
+
+
+def test_library_loaded_and_gpu_visible(vkn):
+    assert torch.cuda.is_available()
+    assert os.path.exists(vkn._lib.LIBPATH)
+    assert vkn._lib.lib().vkn_version() == 0x000100
+
+
+@pytest.mark.parametrize('flags', [0, 1], ids=['mfma', 'refkernels'])
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_mask_gather_vs_oracle(vkn, shape, flags):
+    B, N, C, H, W = shape
+    x, m = _rand((B, C, H, W), 101), _rand((B, N, H, W), 102, 4.0)
+    xraw, cnt = vkn.ops.mask_gather(x.to(DEV), m.to(DEV), 0.5, flags)
+    bits = O.binarize(m, 0.5)
+    ref = O.mask_gather(x.double(), bits.double())
+    assert torch.equal(cnt.cpu(), bits.sum(dim=(-1, -2))), 'ON-pixel counts must be bit-exact'
+    scale = float(ref.abs().max()) + 1.0
+    assert maxabs(xraw, ref) < 3e-6 * scale * max(1.0, np.sqrt(H * W) / 8)
+    # and against the fp32 oracle op itself
+    assert maxabs(xraw, O.mask_gather(x, bits)) < 2e-5 * scale
+
+
+def test_threshold_bits_are_bit_exact(vkn):
+    """(sigmoid(z) > 0.5) of the reference (torch CPU fp32) for every z of the KAT sweep, incl. 0, +-5e-8, 8.9e-8, +-1e-7."""
+    g = np.load(os.path.join(GOLDEN, 'thr_kat.npz'))
+    z, bit = g['z'], g['bit']
+    n = len(z)
+    rows = 256
+    B = (n + rows - 1) // rows
+    zz = np.full(B * rows, -1.0, dtype=np.float32)
+    zz[:n] = z
+    m = torch.from_numpy(zz).reshape(B, rows, 1, 1).expand(B, rows, 4, 8).contiguous()
+    x = torch.ones(B, 32, 4, 8)
+    _, cnt = vkn.ops.mask_gather(x.to(DEV), m.to(DEV), 0.5)
+    got = (cnt.cpu().reshape(-1)[:n] == 32).numpy()
+    assert set(np.unique(cnt.cpu().numpy())) <= {0.0, 32.0}
+    assert np.array_equal(got, bit)
+
+
+@pytest.mark.parametrize('flags', [0, 1], ids=['mfma', 'refkernels'])
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_mask_decode_vs_oracle(vkn, shape, flags):
+    B, N, C, H, W = shape
+    x, k, bias = _rand((B, C, H, W), 201), _rand((B, N, C), 202, 0.7), _rand((B, N), 203)
+    out = vkn.ops.mask_decode(x.to(DEV), k.to(DEV), bias.to(DEV), flags)
+    ref = O.mask_decode(x.double(), k.double().reshape(B, N, C, 1, 1), 1) + bias.double()[:, :, None, None]
+    assert maxabs(out, ref) < 1e-4, 'decode logits (|logit| ~ 30) must stay far inside the 1e-3 budget'
+    out0 = vkn.ops.mask_decode(x.to(DEV), k.to(DEV), None, flags)
+    assert maxabs(out0, ref - bias.double()[:, :, None, None]) < 1e-4
+
+
+def test_decode_planes_entry_matches(vkn):
+    B, N, C, H, W = 2, 117, 256, 16, 32
+    x, k = _rand((B, C, H, W), 211).to(DEV), _rand((B, N, C), 212, 0.7).to(DEV)
+    hi, lo = vkn.ops.split_planes(k)
+    assert maxabs(hi.float() + lo.float(), torch.cat([k, torch.zeros(B, 128 - N, C, device=DEV)], 1)) < 2e-6
+    assert torch.equal(vkn.ops.mask_decode_planes(x, hi, lo, N), vkn.ops.mask_decode(x, k))
+
+
+@pytest.mark.parametrize('scale', [2, 4])
+def test_upsample_vs_torch(vkn, scale):
+    m = _rand((2, 7, 9, 15), 301, 5.0)
+    out = vkn.ops.upsample_bilinear(m.to(DEV), scale)
+    ref = F.interpolate(m, scale_factor=scale, mode='bilinear', align_corners=False)
+    assert out.shape == ref.shape and maxabs(out, ref) < 2e-5
+
+
+def test_kernel_updator_vs_oracle(vkn):
+    C, M = 64, 30
+    ku = vkn.build_transformer_layer(dict(type='KernelUpdator', in_channels=C, feat_channels=C, out_channels=C))
+    shapes = {k: tuple(v.shape) for k, v in ku.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, 7).items()}
+    ku.load_state_dict(sd)
+    ku = ku.to(DEV).eval()
+    u, k = _rand((2, 15, C), 401, 20.0), _rand((2, 15, 1, C), 402)
+    with torch.no_grad():
+        out = ku(u.to(DEV), k.to(DEV))
+    ref = O.kernel_updator({'ku.' + n: v for n, v in sd.items()}, 'ku', u, k, O.HeadCfg(in_channels=C, feat_channels=C))
+    assert out.shape == ref.shape and maxabs(out, ref) < 2e-5
+
+
+def _build_head(vkn, case):
+    from test_host_logic import _cfg
+    head = vkn.build_head(_cfg(bool(case['video']), C=case['C'], heads=case['heads'], ffn=case['ffn'], ncls=case['ncls'],
+                               n_thing=case['n_thing'], n_stuff=case['n_stuff'], S=case['S'], up=case['up'],
+                               nprop=case['nprop']))
+    cfg, sd, x, pf, mp, prev = make_case(case)
+    head.load_state_dict(sd, strict=True)
+    return head.to(DEV).eval(), (x, pf, mp, prev)
+
+
+@pytest.mark.parametrize('name', ['det_tiny', 'det_odd', 'det_cfg', 'video_tiny', 'video_cfg'])
+def test_stage_by_stage_vs_oracle_and_reference(vkn, name):
+    """`_mask_forward` per stage (the reference's own per-stage API) against the oracle trace AND the reference goldens."""
+    g, case = load_golden(name)
+    head, (x, pf, mp, prev) = _build_head(vkn, case)
+    traces = []
+    run_oracle(case, traces=traces)
+    xd, obj, masks, prevd = _cuda(x, pf, mp, prev)
+    with torch.no_grad():
+        for s in range(case['S']):
+            kw = {}
+            if case['video'] and s == case['S'] - 1:
+                kw = dict(previous_obj_feats=prevd)
+            r = head._mask_forward(s, xd, obj, masks, [dict()] * case['B'], **kw)
+            obj, masks = r['object_feats'], r['mask_preds']
+            tr = traces[s]
+            assert maxabs(r['cls_score'], tr['cls_score']) < 1e-4, f'stage {s} cls'
+            assert maxabs(obj, tr['obj_feat']) < 1e-4, f'stage {s} obj'
+            assert maxabs(masks, tr['new_mask_preds']) < TOL_LOGIT, f'stage {s} masks'
+            assert maxabs(r['cls_score'], g[f's{s}_cls']) < 1e-4 and maxabs(obj, g[f's{s}_obj']) < 1e-4
+            if 'x_feats' in r:
+                assert maxabs(r['x_feats'], tr['x_feat']) < 1e-3 * (1 + float(tr['x_feat'].abs().max()))
+        if case['video']:
+            assert maxabs(r['object_feats_track'], g['track']) < 1e-4
+
+
+@pytest.mark.parametrize('flags', [0, 1], ids=['mfma', 'refkernels'])
+@pytest.mark.parametrize('name', ['det_tiny', 'det_odd', 'det_cfg', 'video_tiny', 'video_cfg'])
+def test_head_vs_reference_golden(vkn, name, flags):
+    """The fused S-stage call (`simple_test_mask_preds[_plus_previous]`) against the REFERENCE's own outputs."""
+    g, case = load_golden(name)
+    head, (x, pf, mp, prev) = _build_head(vkn, case)
+    xd, pfd, mpd, prevd = _cuda(x, pf, mp, prev)
+    with torch.no_grad():
+        obj, cls, masks, scaled, track = head._head_forward(xd, pfd, mpd, prevd if case['video'] else None,
+                                                            want_track=bool(case['video']), flags=flags)
+    assert maxabs(obj, g['object_feats']) < 1e-4
+    assert maxabs(cls, g['cls_score']) < 1e-5
+    assert maxabs(masks, g['mask_preds']) < TOL_LOGIT
+    ref_bits = g['mask_preds'] > 0
+    margin = np.abs(g['mask_preds']) > 2e-3
+    assert np.array_equal((masks.cpu().numpy() > 0)[margin], ref_bits[margin]), 'binary masks must be bit-exact'
+    up = case['up']
+    assert tuple(scaled.shape[-2:]) == (case['H'] * up, case['W'] * up)
+    if 'scaled_mask_preds' in g:
+        assert maxabs(scaled, g['scaled_mask_preds']) < TOL_LOGIT
+    else:
+        rs = scaled.double().sum(dim=(-1, -2)).cpu().numpy()
+        assert np.max(np.abs(rs - g['scaled_rowsum']) / (1.0 + np.abs(g['scaled_rowsum']))) < 1e-3
+    if case['video']:
+        assert maxabs(track, g['track']) < 1e-4
+    # public API returns
+    with torch.no_grad():
+        if case['video']:
+            out = head.simple_test_mask_preds_plus_previous(xd, pfd, mpd, None, [dict()] * case['B'], previous_obj_feats=prevd)
+        else:
+            out = head.simple_test_mask_preds(xd, pfd, mpd, None, [dict()] * case['B'])
+    assert len(out) == 4 and tuple(out[0].shape) == (case['B'], case['N'], case['C'], 1, 1)
+    if flags == 0:
+        assert torch.equal(out[2], masks), 'same inputs -> bit-identical outputs (deterministic kernels)'
+
+
+def test_head_cfg1_size_vs_reference_golden(vkn):
+    g, case = load_golden('det_cfg_big')
+    head, (x, pf, mp, _) = _build_head(vkn, case)
+    with torch.no_grad():
+        obj, cls, masks, scaled = head.simple_test_mask_preds(*_cuda(x, pf, mp), None, [dict()])
+    assert maxabs(obj, g['object_feats']) < 1e-4 and maxabs(cls, g['cls_score']) < 1e-5
+    flat = masks.reshape(-1).cpu()
+    assert maxabs(flat[torch.from_numpy(g['sample_idx'])], g['sample_val']) < TOL_LOGIT
+    rs = masks.double().sum(dim=(-1, -2)).cpu().numpy()
+    assert np.max(np.abs(rs - g['mask_rowsum'])) < 1e-4 * np.max(g['mask_rowabs'])
+    bits = np.packbits(flat.numpy() > 0)
+    assert np.all((bits ^ g['sign_bits']) & g['sign_valid'] == 0), 'binary masks (|logit| > 2e-3) must be bit-exact'
+
+
+def test_clip_forward_matches_frame_by_frame(vkn):
+    g, case = load_golden('video_tiny')
+    head, (x, pf, mp, prev) = _build_head(vkn, case)
+    xd, pfd, mpd, prevd = _cuda(x, pf, mp, prev)
+    with torch.no_grad():
+        obj, cls, masks, scaled, track = head.clip_forward(xd, pfd, mpd, first_previous_obj_feats=prevd[:1])
+        # frame-by-frame with explicit previous = previous frame's final kernels
+        chain = torch.cat([prevd[:1], obj[:-1]], 0)
+        o2, c2, m2, s2, t2 = head._head_forward(xd, pfd, mpd, chain, want_track=True)
+    assert torch.equal(masks, m2) and torch.equal(obj, o2) and maxabs(track, t2) < 1e-6
+    # and the oracle agrees on the tracking embedding of frame 1 given frame 0's kernels
+    cfg, sd, *_ = make_case(case)
+    _, _, _, _, tr = O.iter_head_mask_preds(sd, x, pf, mp, cfg, previous_obj_feats=chain.cpu())
+    assert maxabs(track, tr) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE cfg2 size
+CFG2 = dict(B=2, N=117, C=256, H=128, W=256)
+
+
+def test_cfg2_size_properties(vkn):
+    """1024x2048 frame -> 128x256 features: properties that need no CPU restatement at full size."""
+    B, N, C, H, W = (CFG2[k] for k in 'BNCHW')
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g).to(DEV)
+    k1, k2 = torch.randn(B, N, C, generator=g).to(DEV), torch.randn(B, N, C, generator=g).to(DEV)
+    d1, d2, d12 = vkn.ops.mask_decode(x, k1), vkn.ops.mask_decode(x, k2), vkn.ops.mask_decode(x, k1 + k2)
+    assert maxabs(d1 + d2, d12) < 2e-4, 'decode is linear in the kernels'
+    assert torch.equal(d1, vkn.ops.mask_decode(x, k1)), 'deterministic'
+    # selecting kernels reproduce feature channels: K[n] = e_{c(n)}
+    sel = torch.zeros(B, N, C, device=DEV)
+    idx = (torch.arange(N) * 2) % C
+    sel[:, torch.arange(N), idx] = 1.0
+    assert maxabs(vkn.ops.mask_decode(x, sel), x[:, idx]) < 2e-6
+    # gather: all-ON mask = per-channel pixel sum and P counts; all-OFF = zeros; one-hot pixel masks pick x[:, :, p]
+    on = torch.full((B, N, H, W), 3.0, device=DEV)
+    xr, cnt = vkn.ops.mask_gather(x, on)
+    ref = x.double().sum(dim=(-1, -2)).cpu()
+    assert torch.all(cnt == H * W) and maxabs(xr[:, 0], ref) < 1e-3 and maxabs(xr[:, -1], ref) < 1e-3
+    xr, cnt = vkn.ops.mask_gather(x, -on)
+    assert float(xr.abs().max()) == 0.0 and float(cnt.abs().max()) == 0.0
+    hot = torch.full((B, N, H * W), -5.0, device=DEV)
+    pix = (torch.arange(N) * 277 + 13) % (H * W)
+    hot[:, torch.arange(N), pix] = 5.0
+    xr, cnt = vkn.ops.mask_gather(x, hot.reshape(B, N, H, W))
+    assert torch.all(cnt == 1) and maxabs(xr, x.reshape(B, C, -1)[:, :, pix].transpose(1, 2)) < 2e-6
+    # gather is the adjoint of decode:  <decode(x,K), M> == <K, gather(x,M)>  for binary M
+    mlog = torch.randn(B, N, H, W, generator=g).to(DEV)
+    xr, _ = vkn.ops.mask_gather(x, mlog)
+    lhs = (d1.double() * (mlog >= vkn.ops.thr_logit(0.5)).double()).sum()
+    rhs = (k1.double() * xr.double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-6 * float(lhs.abs() + rhs.abs() + 1)
+
+
+def test_cfg2_size_head_vs_oracle(vkn):
+    """One 1024x2048 frame through the video head (S=3, N=117, link + x4 upsample) against the CPU oracle."""
+    case = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256,
+                B=1, seed=11, video=1)
+    head, (x, pf, mp, prev) = _build_head(vkn, case)
+    obj_r, cls_r, masks_r, scaled_r, track_r = run_oracle(case)
+    with torch.no_grad():
+        obj, cls, masks, scaled, track = head._head_forward(*_cuda(x, pf, mp, prev), want_track=True)
+    assert maxabs(obj, obj_r) < 1e-4 and maxabs(cls, cls_r) < 1e-5 and maxabs(track, track_r) < 1e-4
+    assert maxabs(masks, masks_r) < TOL_LOGIT
+    assert maxabs(scaled, scaled_r) < TOL_LOGIT
+    mr = masks_r.numpy()
+    margin = np.abs(mr) > 2e-3
+    assert np.array_equal((masks.cpu().numpy() > 0)[margin], (mr > 0)[margin])

@@ -1,0 +1,132 @@
+"""CPU (-m "not gpu"): registry / config build, state-dict drop-in, C-ABI export surface, host-side helpers.
+No compute kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(video, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=2, nprop=100):
+    """The roi_head dict of configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:79-138 (det) /
+    configs/det/video_knet_kitti_step/video_knet_s3_r50_*_link_ffn_joint_train.py:78-137 (video), train_cfg=None."""
+    import copy
+    mh = dict(type='VideoKernelUpdateHead' if video else 'KernelUpdateHead', num_classes=ncls,
+              num_thing_classes=n_thing, num_stuff_classes=n_stuff, num_ffn_fcs=2, num_heads=heads, num_cls_fcs=1,
+              num_mask_fcs=1, feedforward_channels=ffn, in_channels=C, out_channels=C, dropout=0.0, mask_thr=0.5,
+              conv_kernel_size=1, mask_upsample_stride=up, ffn_act_cfg=dict(type='ReLU', inplace=True), with_ffn=True,
+              feat_transform_cfg=dict(conv_cfg=dict(type='Conv2d'), act_cfg=None),
+              kernel_updator_cfg=dict(type='KernelUpdator', in_channels=C, feat_channels=C, out_channels=C,
+                                      input_feat_shape=3, act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN')),
+              loss_rank=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=0.1),
+              loss_mask=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+              loss_dice=dict(type='DiceLoss', loss_weight=4.0),
+              loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0))
+    if video:
+        mh.update(previous='placeholder', previous_type='ffn')
+    cfg = dict(type='VideoKernelIterHead' if video else 'KernelIterHead', num_thing_classes=n_thing,
+               num_stuff_classes=n_stuff, num_stages=S, stage_loss_weights=[1] * S, proposal_feature_channel=C,
+               num_proposals=nprop, mask_head=[copy.deepcopy(mh) for _ in range(S)])
+    cfg.update(dict(with_track=True, merge_joint=True) if video else dict(do_panoptic=True))
+    return cfg
+
+
+@pytest.mark.parametrize('video', [False, True])
+def test_reference_config_builds_and_state_dict_matches_reference(vkn, video):
+    head = vkn.build_head(_cfg(video))
+    assert type(head).__name__ == ('VideoKernelIterHead' if video else 'KernelIterHead')
+    g, _ = load_golden('video_cfg' if video else 'det_cfg')
+    sd = head.state_dict()
+    assert sorted(sd) == list(g['keys'])                                   # same 44(+16) keys per stage as the reference
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == list(g['shapes'])
+    head.init_weights()
+    assert float(head.mask_head[0].fc_cls.bias.detach()[0]) == pytest.approx(-np.log(99.0), rel=1e-6)   # bias_init_with_prob(0.01)
+    # a reference-shaped checkpoint loads strictly
+    head.load_state_dict({k: torch.zeros(tuple(v.shape)) for k, v in sd.items()}, strict=True)
+
+
+def test_registry_surface(vkn):
+    for name in ('KernelIterHead', 'KernelUpdateHead', 'VideoKernelIterHead', 'VideoKernelUpdateHead'):
+        assert vkn.HEADS.get(name) is not None
+    assert vkn.TRANSFORMER_LAYER.get('KernelUpdator') is vkn.KernelUpdator
+    ku = vkn.build_transformer_layer(dict(type='KernelUpdator', in_channels=64, feat_channels=64, out_channels=64))
+    assert sorted(n for n, _ in ku.named_parameters())[0] == 'dynamic_layer.bias'
+    with pytest.raises(KeyError):
+        vkn.build_head(dict(type='NoSuchHead'))
+    # feat_transform_cfg.pop('kernel_size') mutates the caller's dict exactly like the reference (kernel_update_head.py:108)
+    cfg = _cfg(False, C=64, ffn=128, S=1)
+    cfg['mask_head'][0]['feat_transform_cfg']['kernel_size'] = 1
+    vkn.build_head(cfg)
+    assert 'kernel_size' not in cfg['mask_head'][0]['feat_transform_cfg']
+
+
+def test_unsupported_variants_fail_loudly(vkn):
+    bad = _cfg(False, C=64, ffn=128, S=1)
+    bad['mask_head'][0]['conv_kernel_size'] = 3
+    with pytest.raises(NotImplementedError):
+        vkn.build_head(bad)
+    bad = _cfg(True, C=64, ffn=128, S=1)
+    bad['mask_head'][0]['previous_type'] = 'update'
+    with pytest.raises(NotImplementedError):
+        vkn.build_head(bad)
+    with pytest.raises(NotImplementedError):
+        vkn.build_head(dict(_cfg(False, C=64, ffn=128, S=1), train_cfg=[dict(assigner=dict(type='MaskHungarianAssigner'))]))
+
+
+def test_no_cpu_fallback(vkn):
+    head = vkn.build_head(_cfg(False, C=64, heads=8, ffn=128, ncls=5, S=1)).eval()
+    x, pf, mp = torch.zeros(1, 64, 4, 8), torch.zeros(1, 6, 64, 1, 1), torch.zeros(1, 6, 4, 8)
+    with pytest.raises(vkn.VknLibraryError):
+        head.simple_test_mask_preds(x, pf, mp, None, [dict()])
+    with pytest.raises(vkn.VknLibraryError):
+        vkn.ops.mask_gather(x, mp)
+    with pytest.raises(vkn.VknLibraryError):
+        vkn.ops.mask_decode(x, pf)
+
+
+def test_library_exports_every_declared_symbol(vkn):
+    hdr = open(os.path.join(ROOT, 'include', 'vkn.h')).read()
+    declared = sorted(set(re.findall(r'\b(vkn_[a-z0-9_]+)\s*\(', hdr)))
+    assert declared == sorted(vkn._lib.SYMBOLS)
+    L = ctypes.CDLL(vkn._lib.LIBPATH)
+    for sym in declared:
+        assert getattr(L, sym) is not None
+    L2 = vkn._lib.lib()
+    assert L2.vkn_version() == 0x000100
+    assert L2.vkn_strerror(0) == b'ok' and b'workspace' in L2.vkn_strerror(-3)
+    assert L2.vkn_sizeof_dims() == ctypes.sizeof(vkn._lib.VknDims)
+    assert L2.vkn_sizeof_stage_weights() == ctypes.sizeof(vkn._lib.VknStageWeights)
+
+
+def test_workspace_queries_are_pure_host(vkn):
+    L = vkn._lib.lib()
+    d = vkn.ops.make_dims(8, 117, 256, 128, 256, 8, 2048, 19, 1, 1)
+    stage, head = L.vkn_stage_workspace_bytes(ctypes.byref(d)), L.vkn_head_workspace_bytes(ctypes.byref(d))
+    assert 0 < stage < head < (1 << 31)
+    assert head - stage >= 8 * 117 * 128 * 256 * 4                         # the mask ping-pong buffer
+    bad = vkn.ops.make_dims(1, 117, 250, 8, 8, 8, 2048, 19, 1, 1)          # C % 32 != 0
+    assert L.vkn_stage_workspace_bytes(ctypes.byref(bad)) == 0
+    assert L.vkn_gather_workspace_bytes(8, 117, 256, 32768) > 0 and L.vkn_decode_workspace_bytes(8, 117, 256) > 0
+    # argument errors are reported, never crash (null pointers, no GPU touched)
+    assert L.vkn_mask_gather_f32(None, None, 0.0, None, None, 1, 1, 32, 32, None, 0, 0, None) == -1
+    assert L.vkn_mask_decode_f32(None, None, None, None, 1, 1, 32, 32, None, 0, 0, None) == -1
+    assert L.vkn_upsample_bilinear_f32(None, None, 1, 1, 1, 2, None) == -1
+    assert L.vkn_stage_forward_f32(ctypes.byref(bad), None, *([None] * 9), None, 0, 0, None) == -2
+
+
+def test_threshold_logit_matches_reference_flip_point(vkn):
+    g = np.load(os.path.join(GOLDEN, 'thr_kat.npz'))
+    t = vkn.ops.thr_logit(0.5)
+    assert np.float32(t) == np.float32(g['flip'])                          # 8.940697e-08, not 0
+    assert np.array_equal(g['z'] >= np.float32(t), g['bit'])               # z >= thr_logit  <=>  sigmoid(z) > 0.5 (bit-exact)
+    # other thresholds: bisection agrees with torch on a dense neighbourhood
+    for thr in (0.3, 0.7):
+        tz = np.float32(vkn.ops.thr_logit(thr))
+        z = (tz.view(np.uint32).astype(np.int64) + np.arange(-64, 64)).astype(np.uint32).view(np.float32)
+        assert np.array_equal(z >= tz, (torch.from_numpy(z).sigmoid() > thr).numpy())

@@ -1,0 +1,146 @@
+"""ctypes binding of libvkn.so (C ABI in include/vkn.h) + the hipcc build recipe.
+
+The library is built IN-TREE (`video-k-net_amd/lib/libvkn.so`) so that it travels with the repo snapshot to the GPU
+box; there is no CPU fallback: if the library is missing every op raises `VknLibraryError`.
+"""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_api.hip')
+MAX_FCS = 4
+
+# every symbol include/vkn.h declares
+SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_weights', 'vkn_gather_workspace_bytes', 'vkn_mask_gather_f32',
+           'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
+           'vkn_track_link_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
+           'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32')
+
+
+class VknLibraryError(RuntimeError):
+    pass
+
+
+class VknError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'libvkn error {code}: {msg}')
+        self.code = code
+
+
+_fp = ctypes.c_void_p  # device pointers travel as integers
+
+
+class VknDims(ctypes.Structure):
+    _fields_ = [('B', ctypes.c_int), ('N', ctypes.c_int), ('C', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int),
+                ('heads', ctypes.c_int), ('ff', ctypes.c_int), ('ncls', ctypes.c_int), ('n_cls_fcs', ctypes.c_int),
+                ('n_mask_fcs', ctypes.c_int), ('thr_logit', ctypes.c_float), ('ln_eps', ctypes.c_float)]
+
+
+_W_SCALAR_1 = ['ft_w', 'ft_b', 'ft_wT', 'dyn_w', 'dyn_b', 'inp_w', 'inp_b', 'ig_w', 'ig_b', 'ug_w', 'ug_b',
+               'norm_in_w', 'norm_in_b', 'norm_out_w', 'norm_out_b', 'inorm_in_w', 'inorm_in_b', 'inorm_out_w',
+               'inorm_out_b', 'fc_w', 'fc_b', 'fc_norm_w', 'fc_norm_b', 'attn_in_w', 'attn_in_b', 'attn_out_w',
+               'attn_out_b', 'attn_norm_w', 'attn_norm_b', 'ffn1_w', 'ffn1_b', 'ffn2_w', 'ffn2_b', 'ffn_norm_w',
+               'ffn_norm_b']
+_W_TAIL = ['pa_in_w', 'pa_in_b', 'pa_out_w', 'pa_out_b', 'pa_norm_w', 'pa_norm_b', 'lffn1_w', 'lffn1_b', 'lffn2_w',
+           'lffn2_b', 'lffn_norm_w', 'lffn_norm_b']
+
+
+class VknStageWeights(ctypes.Structure):
+    """Field order mirrors `struct VknStageWeights` in include/vkn.h exactly."""
+    _fields_ = ([(n, _fp) for n in _W_SCALAR_1]
+                + [('cls_fc_w', _fp * MAX_FCS), ('cls_ln_w', _fp * MAX_FCS), ('cls_ln_b', _fp * MAX_FCS),
+                   ('fc_cls_w', _fp), ('fc_cls_b', _fp),
+                   ('mask_fc_w', _fp * MAX_FCS), ('mask_ln_w', _fp * MAX_FCS), ('mask_ln_b', _fp * MAX_FCS),
+                   ('fc_mask_w', _fp), ('fc_mask_b', _fp)]
+                + [(n, _fp) for n in _W_TAIL])
+
+
+def hipcc_command(out=LIBPATH, extra=()):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    return [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', *extra,
+            *[os.path.join(CSRC, s) for s in SOURCES], '-o', out]
+
+
+def _stale():
+    if not os.path.exists(LIBPATH):
+        return True
+    t = os.path.getmtime(LIBPATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), 'include', 'vkn.h')]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into lib/libvkn.so (cross-compiles without a GPU)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not force and not _stale():
+        return LIBPATH
+    cmd = hipcc_command()
+    if verbose:
+        print(' '.join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise VknLibraryError('hipcc failed:\n' + r.stdout + r.stderr)
+    return LIBPATH
+
+
+_LIB = None
+
+
+def lib():
+    """The loaded library (ctypes.CDLL) with argtypes set.  Raises VknLibraryError when it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIBPATH):
+        raise VknLibraryError(f'{LIBPATH} is missing — run `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(there is deliberately no CPU fallback)')
+    L = ctypes.CDLL(LIBPATH)
+    c_int, c_size, c_uint, c_float = ctypes.c_int, ctypes.c_size_t, ctypes.c_uint, ctypes.c_float
+    pD, pW = ctypes.POINTER(VknDims), ctypes.POINTER(VknStageWeights)
+    L.vkn_version.restype = c_int
+    L.vkn_version.argtypes = []
+    L.vkn_strerror.restype = ctypes.c_char_p
+    L.vkn_strerror.argtypes = [c_int]
+    L.vkn_sizeof_dims.restype = c_size
+    L.vkn_sizeof_dims.argtypes = []
+    L.vkn_sizeof_stage_weights.restype = c_size
+    L.vkn_sizeof_stage_weights.argtypes = []
+    if L.vkn_sizeof_dims() != ctypes.sizeof(VknDims) or L.vkn_sizeof_stage_weights() != ctypes.sizeof(VknStageWeights):
+        raise VknLibraryError('ctypes mirror of include/vkn.h structs is out of date (size mismatch)')
+    L.vkn_gather_workspace_bytes.restype = c_size
+    L.vkn_gather_workspace_bytes.argtypes = [c_int] * 4
+    L.vkn_mask_gather_f32.restype = c_int
+    L.vkn_mask_gather_f32.argtypes = [_fp, _fp, c_float, _fp, _fp, c_int, c_int, c_int, c_int, _fp, c_size, c_uint, _fp]
+    L.vkn_decode_workspace_bytes.restype = c_size
+    L.vkn_decode_workspace_bytes.argtypes = [c_int] * 3
+    L.vkn_mask_decode_f32.restype = c_int
+    L.vkn_mask_decode_f32.argtypes = [_fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp, c_size, c_uint, _fp]
+    L.vkn_split_planes_f32.restype = c_int
+    L.vkn_split_planes_f32.argtypes = [_fp, _fp, _fp, c_int, c_int, c_int, _fp]
+    L.vkn_mask_decode_planes_f32.restype = c_int
+    L.vkn_mask_decode_planes_f32.argtypes = [_fp, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp]
+    L.vkn_track_link_f32.restype = c_int
+    L.vkn_track_link_f32.argtypes = [pD, pW, _fp, _fp, _fp, _fp, c_size, _fp]
+    L.vkn_upsample_bilinear_f32.restype = c_int
+    L.vkn_upsample_bilinear_f32.argtypes = [_fp, _fp, c_int, c_int, c_int, c_int, _fp]
+    L.vkn_kernel_updator_f32.restype = c_int
+    L.vkn_kernel_updator_f32.argtypes = [pD, pW, _fp, _fp, _fp, _fp, c_size, _fp]
+    L.vkn_stage_workspace_bytes.restype = c_size
+    L.vkn_stage_workspace_bytes.argtypes = [pD]
+    L.vkn_stage_forward_f32.restype = c_int
+    L.vkn_stage_forward_f32.argtypes = [pD, pW] + [_fp] * 9 + [_fp, c_size, c_uint, _fp]
+    L.vkn_head_workspace_bytes.restype = c_size
+    L.vkn_head_workspace_bytes.argtypes = [pD]
+    L.vkn_head_forward_f32.restype = c_int
+    L.vkn_head_forward_f32.argtypes = [pD, c_int, pW] + [_fp] * 8 + [c_int, _fp, _fp, c_size, c_uint, _fp]
+    _LIB = L
+    return L
+
+
+def check(code):
+    if code != 0:
+        raise VknError(code, lib().vkn_strerror(code).decode())

@@ -1,0 +1,442 @@
+// vkn_api.hip — the C ABI of libvkn.so (include/vkn.h): argument checking, workspace carving and the launch sequence of
+// one stage / of the S-stage loop.  Host code only; every kernel lives in vkn_gather / vkn_update / vkn_decode.
+#include "../../include/vkn.h"
+#include "vkn_common.h"
+#include "vkn_launch.h"
+
+namespace {
+
+struct Carver {
+    char* base;
+    size_t off;
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int npt_of(int N) { return (N + 31) / 32 * 32; }
+
+struct StageWs {
+    float *part, *cntp, *xraw, *cnt, *xfeat, *params, *inputf, *ig, *ug, *f, *obj1, *qkv, *ao, *obj2, *h, *partial, *t1, *t2,
+        *maskfeat, *kb, *kern32, *lq, *lkv;
+    _Float16 *kfh, *kfl;
+};
+
+int ffn_ksplit(int M, int K) {
+    const int rt = (M + 31) / 32, ktiles = K / 32;
+    int ks = 256 / (rt > 0 ? rt : 1);
+    if (ks > 16) ks = 16;
+    if (ks > ktiles) ks = ktiles;
+    if (ks < 1) ks = 1;
+    return ks;
+}
+
+size_t carve_stage(const VknDims* d, char* base, StageWs* s) {
+    Carver c{base, 0};
+    const size_t B = d->B, N = d->N, C = d->C, P = (size_t)d->H * d->W, M = B * N, FF = d->ff;
+    const size_t G = vkn_gather_groups(d->B, (int)P), NPT = npt_of(d->N);
+    s->part = c.take<float>(B * G * NPT * C);
+    s->cntp = c.take<float>(B * G * NPT);
+    s->xraw = c.take<float>(M * C);
+    s->cnt = c.take<float>(M);
+    s->xfeat = c.take<float>(M * C);
+    s->params = c.take<float>(M * 2 * C);
+    s->inputf = c.take<float>(M * 2 * C);
+    s->ig = c.take<float>(M * C);
+    s->ug = c.take<float>(M * C);
+    s->f = c.take<float>(M * C);
+    s->obj1 = c.take<float>(M * C);
+    s->qkv = c.take<float>(M * 3 * C);
+    s->ao = c.take<float>(M * C);
+    s->obj2 = c.take<float>(M * C);
+    s->h = c.take<float>(M * FF);
+    s->partial = c.take<float>((size_t)ffn_ksplit((int)M, (int)FF) * M * C);
+    s->t1 = c.take<float>(M * C);
+    s->t2 = c.take<float>(M * C);
+    s->maskfeat = c.take<float>(M * C);
+    s->kb = c.take<float>(M);
+    s->kern32 = c.take<float>(M * C);
+    s->lq = c.take<float>(M * C);
+    s->lkv = c.take<float>(M * 2 * C);
+    s->kfh = c.take<_Float16>(B * NPT * C);
+    s->kfl = c.take<_Float16>(B * NPT * C);
+    return (c.off + 255) & ~(size_t)255;
+}
+
+int check_dims(const VknDims* d) {
+    if (!d) return VKN_E_ARG;
+    if (d->B <= 0 || d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0 || d->heads <= 0 || d->ff <= 0 || d->ncls <= 0)
+        return VKN_E_ARG;
+    if (d->C % 32 != 0 || d->C > 256) return VKN_E_SHAPE;
+    if (d->C % d->heads != 0 || d->C / d->heads > 64 || (d->C % 8) != 0 || d->C / 8 > 64) return VKN_E_SHAPE;
+    if (d->ff % 32 != 0) return VKN_E_SHAPE;
+    if (d->N > 256) return VKN_E_SHAPE;
+    if (d->ncls > 256) return VKN_E_SHAPE;
+    if (d->n_cls_fcs < 0 || d->n_cls_fcs > VKN_MAX_FCS || d->n_mask_fcs < 0 || d->n_mask_fcs > VKN_MAX_FCS) return VKN_E_SHAPE;
+    return VKN_OK;
+}
+
+VknEpi mk_epi(const VknDims* d) {
+    VknEpi e{};
+    e.eps = d->ln_eps;
+    return e;
+}
+
+#define VKN_TRY(expr)             \
+    do {                          \
+        const int rc_ = (expr);   \
+        if (rc_ != VKN_OK) return rc_; \
+    } while (0)
+
+// FFN: out = LN(in + W2 relu(W1 in + b1) + b2)        (mmcv FFN + following LayerNorm)
+int run_ffn(const VknDims* d, const StageWs& s, const float* in, const float* w1, const float* b1, const float* w2,
+            const float* b2, const float* nw, const float* nb, float* out, hipStream_t st) {
+    const int M = d->B * d->N, C = d->C, FF = d->ff;
+    VknEpi e = mk_epi(d);
+    e.bias = b1; e.act = 1; e.out = s.h; e.ldo = FF;
+    VKN_TRY(vkn_launch_gemm(in, nullptr, C, w1, M, C, FF, 1, nullptr, e, st));
+    e = mk_epi(d);
+    e.bias = b2; e.resid = in; e.ldr = C; e.ln_w = nw; e.ln_b = nb; e.out = out; e.ldo = C;
+    return vkn_launch_gemm(s.h, nullptr, FF, w2, M, FF, C, ffn_ksplit(M, FF), s.partial, e, st);
+}
+
+// attention block: out = LN(identity + out_proj(softmax(q k^T / sqrt(hd)) v)); q from `qsrc`, k/v from `kvsrc`
+int run_attention(const VknDims* d, const StageWs& s, const float* qsrc, const float* kvsrc, int heads, const float* in_w,
+                  const float* in_b, const float* out_w, const float* out_b, const float* nw, const float* nb, float* out,
+                  hipStream_t st) {
+    const int M = d->B * d->N, C = d->C, hd = C / heads;
+    VknEpi e = mk_epi(d);
+    if (qsrc == kvsrc) {  // self-attention: one packed in_proj GEMM
+        e.bias = in_b; e.out = s.qkv; e.ldo = 3 * C;
+        VKN_TRY(vkn_launch_gemm(qsrc, nullptr, C, in_w, M, C, 3 * C, 1, nullptr, e, st));
+        VKN_TRY(vkn_launch_attn(s.qkv, 3 * C, s.qkv + C, s.qkv + 2 * C, 3 * C, s.ao, C, d->B, d->N, d->N, heads, hd, st));
+    } else {
+        e.bias = in_b; e.out = s.lq; e.ldo = C;
+        VKN_TRY(vkn_launch_gemm(qsrc, nullptr, C, in_w, M, C, C, 1, nullptr, e, st));
+        e = mk_epi(d);
+        e.bias = in_b + C; e.out = s.lkv; e.ldo = 2 * C;
+        VKN_TRY(vkn_launch_gemm(kvsrc, nullptr, C, in_w + (size_t)C * C, M, C, 2 * C, 1, nullptr, e, st));
+        VKN_TRY(vkn_launch_attn(s.lq, C, s.lkv, s.lkv + C, 2 * C, s.ao, C, d->B, d->N, d->N, heads, hd, st));
+    }
+    e = mk_epi(d);
+    e.bias = out_b; e.resid = qsrc; e.ldr = C; e.ln_w = nw; e.ln_b = nb; e.out = out; e.ldo = C;
+    return vkn_launch_gemm(s.ao, nullptr, C, out_w, M, C, C, 1, nullptr, e, st);
+}
+
+// KernelUpdator.forward                                        knet/kernel_updator.py:56-93
+int run_updator(const VknDims* d, const VknStageWeights* w, const float* xfeat, const float* obj_in, float* out,
+                const StageWs& s, hipStream_t st) {
+    const int C = d->C, M = d->B * d->N;
+    VknEpi e = mk_epi(d); e.bias = w->dyn_b; e.out = s.params; e.ldo = 2 * C;
+    VKN_TRY(vkn_launch_gemm(xfeat, nullptr, C, w->dyn_w, M, C, 2 * C, 1, nullptr, e, st));          // :59
+    e = mk_epi(d); e.bias = w->inp_b; e.out = s.inputf; e.ldo = 2 * C;
+    VKN_TRY(vkn_launch_gemm(obj_in, nullptr, C, w->inp_w, M, C, 2 * C, 1, nullptr, e, st));        // :65-66
+    // gate = input_in * param_in (:70) as the GEMM's A prologue; gates = sigmoid(LN(linear(gate)))  (:74-78)
+    e = mk_epi(d); e.bias = w->ig_b; e.ln_w = w->inorm_in_w; e.ln_b = w->inorm_in_b; e.act = 2; e.out = s.ig; e.ldo = C;
+    VKN_TRY(vkn_launch_gemm(s.inputf, s.params, 2 * C, w->ig_w, M, C, C, 1, nullptr, e, st));
+    e = mk_epi(d); e.bias = w->ug_b; e.ln_w = w->norm_in_w; e.ln_b = w->norm_in_b; e.act = 2; e.out = s.ug; e.ldo = C;
+    VKN_TRY(vkn_launch_gemm(s.inputf, s.params, 2 * C, w->ug_w, M, C, C, 1, nullptr, e, st));
+    VKN_TRY(vkn_launch_ku_mix(s.params, s.inputf, s.ig, s.ug, w->norm_out_w, w->norm_out_b, w->inorm_out_w, w->inorm_out_b,
+                              d->ln_eps, s.f, M, C, st));                                          // :79-88
+    e = mk_epi(d); e.bias = w->fc_b; e.ln_w = w->fc_norm_w; e.ln_b = w->fc_norm_b; e.act = 1; e.out = out; e.ldo = C;
+    return vkn_launch_gemm(s.f, nullptr, C, w->fc_w, M, C, C, 1, nullptr, e, st);                  // :90-92
+}
+
+// video tracking link, previous_type == "ffn"                 knet/video/kernel_update_head.py:394-415
+int run_link(const VknDims* d, const VknStageWeights* w, const float* cur, const float* prev, float* track_out,
+             const StageWs& s, hipStream_t st) {
+    if (!w->pa_in_w || !w->lffn1_w) return VKN_E_ARG;
+    VKN_TRY(run_attention(d, s, cur, prev, 8, w->pa_in_w, w->pa_in_b, w->pa_out_w, w->pa_out_b, w->pa_norm_w, w->pa_norm_b,
+                          s.t1, st));                                             // _num_head = 8 (:165)
+    return run_ffn(d, s, s.t1, w->lffn1_w, w->lffn1_b, w->lffn2_w, w->lffn2_b, w->lffn_norm_w, w->lffn_norm_b, track_out, st);
+}
+
+int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in, const float* masks_in,
+              const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out, float* x_feat_out,
+              float* track_out, const StageWs& s, unsigned flags, hipStream_t st) {
+    const int B = d->B, N = d->N, C = d->C, P = d->H * d->W, M = B * N;
+    const bool ref = (flags & VKN_FLAG_REF_KERNELS) != 0;
+    const bool has_ft = w->ft_w != nullptr;
+
+    // (i) mask gather                                        knet/det/kernel_update_head.py:190-195
+    if (ref)
+        VKN_TRY(vkn_launch_gather_ref(x, masks_in, d->thr_logit, s.xraw, s.cnt, B, N, C, P, st));
+    else
+        VKN_TRY(vkn_launch_gather(x, masks_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
+
+    // folded feat_transform: x_feat = xraw . W_ft^T + cnt (x) b_ft             (:179-180 folded)
+    float* xfeat = x_feat_out ? x_feat_out : s.xfeat;
+    VknEpi e = mk_epi(d);
+    if (has_ft) {
+        e.bias = w->ft_b; e.rowscale = s.cnt; e.out = xfeat; e.ldo = C;
+        VKN_TRY(vkn_launch_gemm(s.xraw, nullptr, C, w->ft_w, M, C, C, 1, nullptr, e, st));
+    } else {
+        if (hipMemcpyAsync(xfeat, s.xraw, (size_t)M * C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return VKN_E_LAUNCH;
+    }
+
+    // (ii-a) KernelUpdator                                    knet/kernel_updator.py:56-93
+    VKN_TRY(run_updator(d, w, xfeat, obj_in, s.obj1, s, st));
+
+    // (ii-b) kernel interaction: MHA + LN, FFN + LN           knet/det/kernel_update_head.py:204-215
+    VKN_TRY(run_attention(d, s, s.obj1, s.obj1, d->heads, w->attn_in_w, w->attn_in_b, w->attn_out_w, w->attn_out_b,
+                          w->attn_norm_w, w->attn_norm_b, s.obj2, st));
+    const float* obj3 = s.obj2;
+    if (w->ffn1_w) {
+        VKN_TRY(run_ffn(d, s, s.obj2, w->ffn1_w, w->ffn1_b, w->ffn2_w, w->ffn2_b, w->ffn_norm_w, w->ffn_norm_b, obj_out, st));
+        obj3 = obj_out;
+    } else {
+        if (hipMemcpyAsync(obj_out, s.obj2, (size_t)M * C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return VKN_E_LAUNCH;
+        obj3 = obj_out;
+    }
+
+    // cls branch                                              :217-225
+    const float* t = obj3;
+    for (int i = 0; i < d->n_cls_fcs; ++i) {
+        float* dst = (t == s.t1) ? s.t2 : s.t1;
+        e = mk_epi(d); e.ln_w = w->cls_ln_w[i]; e.ln_b = w->cls_ln_b[i]; e.act = 1; e.out = dst; e.ldo = C;
+        VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->cls_fc_w[i], M, C, C, 1, nullptr, e, st));
+        t = dst;
+    }
+    e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
+    VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->fc_cls_w, M, C, d->ncls, 1, nullptr, e, st));
+
+    // mask branch                                             :218-227
+    t = obj3;
+    for (int i = 0; i < d->n_mask_fcs; ++i) {
+        float* dst = (t == s.t1) ? s.t2 : s.t1;
+        e = mk_epi(d); e.ln_w = w->mask_ln_w[i]; e.ln_b = w->mask_ln_b[i]; e.act = 1; e.out = dst; e.ldo = C;
+        VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->mask_fc_w[i], M, C, C, 1, nullptr, e, st));
+        t = dst;
+    }
+    // mask_feat = fc_mask(.)  (+ folded decode bias kb = mask_feat . b_ft)
+    e = mk_epi(d); e.bias = w->fc_mask_b; e.out = s.maskfeat; e.ldo = C;
+    if (has_ft) { e.dot_vec = w->ft_b; e.dot_out = s.kb; }
+    VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->fc_mask_w, M, C, C, 1, nullptr, e, st));
+
+    // (iii) mask decode with the folded kernels  Kf = mask_feat . W_ft   :247-260
+    const float* kb = has_ft ? s.kb : nullptr;
+    if (ref) {
+        const float* kern = s.maskfeat;
+        if (has_ft) {
+            e = mk_epi(d); e.out = s.kern32; e.ldo = C;
+            VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, M, C, C, 1, nullptr, e, st));
+            kern = s.kern32;
+        }
+        VKN_TRY(vkn_launch_decode_ref(x, kern, kb, masks_out, B, N, C, P, st));
+    } else {
+        if (has_ft) {
+            e = mk_epi(d); e.plane_hi = s.kfh; e.plane_lo = s.kfl; e.ldo = C; e.rows_per_frame = N; e.NPT = npt_of(N);
+            VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, M, C, C, 1, nullptr, e, st));
+        } else {
+            VKN_TRY(vkn_launch_split_planes(s.maskfeat, s.kfh, s.kfl, B, N, C, st));
+        }
+        VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
+    }
+
+    if (prev_obj && track_out) VKN_TRY(run_link(d, w, obj3, prev_obj, track_out, s, st));
+    return VKN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vkn_version(void) { return VKN_VERSION; }
+size_t vkn_sizeof_dims(void) { return sizeof(VknDims); }
+size_t vkn_sizeof_stage_weights(void) { return sizeof(VknStageWeights); }
+
+const char* vkn_strerror(int code) {
+    switch (code) {
+        case VKN_OK: return "ok";
+        case VKN_E_ARG: return "invalid argument (null pointer or non-positive size)";
+        case VKN_E_SHAPE:
+            return "unsupported shape (need C % 32 == 0, C <= 256, N <= 256, head_dim <= 64, ff % 32 == 0, ncls <= 256, "
+                   "conv_kernel_size == 1)";
+        case VKN_E_WORKSPACE: return "workspace missing or too small";
+        case VKN_E_LAUNCH: return "HIP launch failed";
+        case VKN_E_ALIGN: return "pointer not 16-byte aligned";
+        default: return "unknown error";
+    }
+}
+
+size_t vkn_gather_workspace_bytes(int B, int N, int C, int P) {
+    if (B <= 0 || N <= 0 || C <= 0 || P <= 0) return 0;
+    const size_t G = vkn_gather_groups(B, P), NPT = npt_of(N);
+    Carver c{nullptr, 0};
+    c.take<float>((size_t)B * G * NPT * C);
+    c.take<float>((size_t)B * G * NPT);
+    c.take<float>((size_t)B * N);
+    return (c.off + 255) & ~(size_t)255;
+}
+
+int vkn_mask_gather_f32(const float* x, const float* mask_logits, float thr_logit, float* xraw_out, float* cnt_out, int B,
+                        int N, int C, int P, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    if (!x || !mask_logits || !xraw_out || B <= 0 || N <= 0 || C <= 0 || P <= 0) return VKN_E_ARG;
+    if (!aligned16(x) || !aligned16(mask_logits) || !aligned16(xraw_out)) return VKN_E_ALIGN;
+    if (C % 32 != 0 || C > 256 || N > 256) return VKN_E_SHAPE;
+    if (!ws || ws_bytes < vkn_gather_workspace_bytes(B, N, C, P)) return VKN_E_WORKSPACE;
+    const size_t G = vkn_gather_groups(B, P), NPT = npt_of(N);
+    Carver c{static_cast<char*>(ws), 0};
+    float* part = c.take<float>((size_t)B * G * NPT * C);
+    float* cntp = c.take<float>((size_t)B * G * NPT);
+    float* cnt = c.take<float>((size_t)B * N);
+    if (cnt_out) cnt = cnt_out;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & VKN_FLAG_REF_KERNELS) return vkn_launch_gather_ref(x, mask_logits, thr_logit, xraw_out, cnt, B, N, C, P, st);
+    return vkn_launch_gather(x, mask_logits, thr_logit, xraw_out, cnt, part, cntp, B, N, C, P, st);
+}
+
+size_t vkn_decode_workspace_bytes(int B, int N, int C) {
+    if (B <= 0 || N <= 0 || C <= 0) return 0;
+    Carver c{nullptr, 0};
+    c.take<_Float16>((size_t)B * npt_of(N) * C);
+    c.take<_Float16>((size_t)B * npt_of(N) * C);
+    return (c.off + 255) & ~(size_t)255;
+}
+
+int vkn_mask_decode_f32(const float* x, const float* kernels, const float* bias, float* out, int B, int N, int C, int P,
+                        void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    if (!x || !kernels || !out || B <= 0 || N <= 0 || C <= 0 || P <= 0) return VKN_E_ARG;
+    if (!aligned16(x) || !aligned16(kernels) || !aligned16(out)) return VKN_E_ALIGN;
+    if (C % 32 != 0 || C > 256 || N > 256) return VKN_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & VKN_FLAG_REF_KERNELS) return vkn_launch_decode_ref(x, kernels, bias, out, B, N, C, P, st);
+    if (!ws || ws_bytes < vkn_decode_workspace_bytes(B, N, C)) return VKN_E_WORKSPACE;
+    Carver c{static_cast<char*>(ws), 0};
+    _Float16* kfh = c.take<_Float16>((size_t)B * npt_of(N) * C);
+    _Float16* kfl = c.take<_Float16>((size_t)B * npt_of(N) * C);
+    VKN_TRY(vkn_launch_split_planes(kernels, kfh, kfl, B, N, C, st));
+    return vkn_launch_decode(x, kfh, kfl, bias, out, B, N, C, P, st);
+}
+
+int vkn_split_planes_f32(const float* kernels, void* kf_hi, void* kf_lo, int B, int N, int C, void* stream) {
+    if (!kernels || !kf_hi || !kf_lo || B <= 0 || N <= 0 || C <= 0) return VKN_E_ARG;
+    if (!aligned16(kf_hi) || !aligned16(kf_lo)) return VKN_E_ALIGN;
+    return vkn_launch_split_planes(kernels, static_cast<_Float16*>(kf_hi), static_cast<_Float16*>(kf_lo), B, N, C,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int vkn_mask_decode_planes_f32(const float* x, const void* kf_hi, const void* kf_lo, const float* bias, float* out, int B,
+                               int N, int C, int P, void* stream) {
+    if (!x || !kf_hi || !kf_lo || !out || B <= 0 || N <= 0 || C <= 0 || P <= 0) return VKN_E_ARG;
+    if (!aligned16(x) || !aligned16(kf_hi) || !aligned16(kf_lo) || !aligned16(out)) return VKN_E_ALIGN;
+    if (C % 32 != 0 || C > 256 || N > 256) return VKN_E_SHAPE;
+    return vkn_launch_decode(x, static_cast<const _Float16*>(kf_hi), static_cast<const _Float16*>(kf_lo), bias, out, B, N, C,
+                             P, static_cast<hipStream_t>(stream));
+}
+
+int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* cur_obj, const float* prev_obj,
+                       float* track_out, void* ws, size_t ws_bytes, void* stream) {
+    VKN_TRY(check_dims(d));
+    if (!w || !cur_obj || !prev_obj || !track_out) return VKN_E_ARG;
+    if (!aligned16(cur_obj) || !aligned16(prev_obj) || !aligned16(track_out)) return VKN_E_ALIGN;
+    StageWs s;
+    const size_t need = carve_stage(d, nullptr, &s);
+    if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
+    carve_stage(d, static_cast<char*>(ws), &s);
+    return run_link(d, w, cur_obj, prev_obj, track_out, s, static_cast<hipStream_t>(stream));
+}
+
+int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, int W, int S, void* stream) {
+    if (!in || !out || planes <= 0 || H <= 0 || W <= 0) return VKN_E_ARG;
+    if (!aligned16(in) || !aligned16(out)) return VKN_E_ALIGN;
+    return vkn_launch_upsample(in, out, planes, H, W, S, static_cast<hipStream_t>(stream));
+}
+
+int vkn_kernel_updator_f32(const VknDims* d, const VknStageWeights* w, const float* update_feature,
+                           const float* input_feature, float* out, void* ws, size_t ws_bytes, void* stream) {
+    VKN_TRY(check_dims(d));
+    if (!w || !update_feature || !input_feature || !out) return VKN_E_ARG;
+    if (!aligned16(update_feature) || !aligned16(input_feature) || !aligned16(out)) return VKN_E_ALIGN;
+    StageWs s;
+    const size_t need = carve_stage(d, nullptr, &s);
+    if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
+    carve_stage(d, static_cast<char*>(ws), &s);
+    return run_updator(d, w, update_feature, input_feature, out, s, static_cast<hipStream_t>(stream));
+}
+
+size_t vkn_stage_workspace_bytes(const VknDims* d) {
+    if (check_dims(d) != VKN_OK) return 0;
+    StageWs s;
+    return carve_stage(d, nullptr, &s);
+}
+
+int vkn_stage_forward_f32(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in,
+                          const float* masks_in, const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out,
+                          float* x_feat_out, float* track_out, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    VKN_TRY(check_dims(d));
+    if (!w || !x || !obj_in || !masks_in || !cls_logits || !masks_out || !obj_out) return VKN_E_ARG;
+    if (!aligned16(x) || !aligned16(obj_in) || !aligned16(masks_in) || !aligned16(masks_out) || !aligned16(obj_out))
+        return VKN_E_ALIGN;
+    if (masks_in == masks_out) return VKN_E_ARG;
+    StageWs s;
+    const size_t need = carve_stage(d, nullptr, &s);
+    if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
+    carve_stage(d, static_cast<char*>(ws), &s);
+    return run_stage(d, w, x, obj_in, masks_in, prev_obj, cls_logits, masks_out, obj_out, x_feat_out, track_out, s, flags,
+                     static_cast<hipStream_t>(stream));
+}
+
+static size_t carve_head(const VknDims* d, char* base, StageWs* s, float** mtmp, float** otmp, float** ctmp) {
+    const size_t stage_bytes = carve_stage(d, base, s);
+    Carver c{base, stage_bytes};
+    const size_t M = (size_t)d->B * d->N, P = (size_t)d->H * d->W;
+    *mtmp = c.take<float>(M * P);
+    *otmp = c.take<float>(M * d->C);
+    *ctmp = c.take<float>(M * d->ncls);
+    return (c.off + 255) & ~(size_t)255;
+}
+
+size_t vkn_head_workspace_bytes(const VknDims* d) {
+    if (check_dims(d) != VKN_OK) return 0;
+    StageWs s;
+    float *a, *b, *c;
+    return carve_head(d, nullptr, &s, &a, &b, &c);
+}
+
+int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const float* x,
+                         const float* proposal_feats, const float* mask_preds_in, const float* prev_obj, float* obj_out,
+                         float* cls_prob, float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out,
+                         void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    VKN_TRY(check_dims(d));
+    if (num_stages <= 0 || !stages || !x || !proposal_feats || !mask_preds_in || !obj_out || !cls_prob || !mask_preds_out)
+        return VKN_E_ARG;
+    if (!aligned16(x) || !aligned16(proposal_feats) || !aligned16(mask_preds_in) || !aligned16(obj_out) ||
+        !aligned16(mask_preds_out) || (scaled_out && !aligned16(scaled_out)))
+        return VKN_E_ALIGN;
+    if (mask_preds_in == mask_preds_out || proposal_feats == obj_out) return VKN_E_ARG;
+    StageWs s;
+    float *mtmp, *otmp, *ctmp;
+    const size_t need = carve_head(d, nullptr, &s, &mtmp, &otmp, &ctmp);
+    if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
+    carve_head(d, static_cast<char*>(ws), &s, &mtmp, &otmp, &ctmp);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    const float* m_in = mask_preds_in;
+    const float* o_in = proposal_feats;
+    for (int sidx = 0; sidx < num_stages; ++sidx) {
+        const bool last = (sidx == num_stages - 1);
+        // alternate so that the LAST stage writes the caller's buffers
+        const bool to_out = ((num_stages - 1 - sidx) & 1) == 0;
+        float* m_out = to_out ? mask_preds_out : mtmp;
+        float* o_out = to_out ? obj_out : otmp;
+        const float* prev = (last && track_out) ? prev_obj : nullptr;   // knet/video/kernel_iter_head.py:544-546
+        VKN_TRY(run_stage(d, &stages[sidx], x, o_in, m_in, prev, ctmp, m_out, o_out, nullptr, prev ? track_out : nullptr, s,
+                          flags, st));
+        m_in = m_out;
+        o_in = o_out;
+    }
+    VKN_TRY(vkn_launch_sigmoid(ctmp, cls_prob, d->B * d->N * d->ncls, st));               // knet/det/kernel_iter_head.py:307-308
+    if (scaled_out && upsample_stride > 1)                                                // :122-130
+        VKN_TRY(vkn_launch_upsample(mask_preds_out, scaled_out, d->B * d->N, d->H, d->W, upsample_stride, st));
+    return VKN_OK;
+}
+
+}  // extern "C"

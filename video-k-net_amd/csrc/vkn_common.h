@@ -1,0 +1,47 @@
+// vkn_common.h — shared device helpers for the MI355X (gfx950 / CDNA4) kernel-update-head kernels.
+// wave = 64 lanes; MFMA 32x32 fragments; no CUDA-compat paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define VKN_WAVE 64
+
+// ---- MFMA 32x32 C/D fragment map (dtype independent on gfx950): lane l, register r ->
+//      col = l & 31 ; row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+__device__ __forceinline__ int vkn_cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// f16 two-term split: v ~= hi + lo with |v - hi - lo| <= 2^-22 |v| (RNE both), products hi*hi, hi*lo, lo*hi
+// are exact in the fp32 MFMA accumulator.  Valid for |v| < 65504.
+__device__ __forceinline__ void vkn_split_f16(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+__device__ __forceinline__ float vkn_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float vkn_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// host-side error codes (see include/vkn.h)
+#define VKN_OK 0
+#define VKN_E_ARG (-1)
+#define VKN_E_SHAPE (-2)
+#define VKN_E_WORKSPACE (-3)
+#define VKN_E_LAUNCH (-4)
+#define VKN_E_ALIGN (-5)
+
+#define VKN_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        if (hipGetLastError() != hipSuccess) return VKN_E_LAUNCH; \
+    } while (0)

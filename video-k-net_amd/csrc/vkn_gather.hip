@@ -1,0 +1,311 @@
+// vkn_gather.hip — mask gather ("group feature assembling"):
+//     xraw[b][n][c] = sum_p bit(mask_logits[b][n][p]) * x[b][c][p],   cnt[b][n] = sum_p bit(...)
+// with bit(z) = (z >= thr_logit)  <=>  the reference's  (sigmoid(z) > hard_mask_thr).float()
+// (knet/det/kernel_update_head.py:190-195 `einsum('bnhw,bchw->bnc')`; thr_logit is the smallest fp32 z for which the
+// fp32 sigmoid exceeds the threshold — 8.940697e-08 for 0.5, found by the host by bisection, see ops.py).
+// The per-stage `feat_transform` 1x1 conv is folded AFTER the gather by the update kernels:
+//     x_feat = xraw . W_ft^T + cnt (x) b_ft          (SURVEY.md §7 "Folding feat_transform")
+//
+// MI355X design: HBM-bound stream of x and of the mask logits, each read once.
+//   * contraction index = pixel (contiguous in memory), so fragments need a [row][pixel] transpose: tiles of 32 pixels are
+//     loaded with coalesced dwordx4 (8 lanes per 128-B row segment), split to f16 hi/lo (x) or binarised to f16 {0,1}
+//     (mask) in registers and written to a padded LDS image (row stride 80 B -> conflict-free ds_read_b128);
+//   * wave w owns channel block w (32 channels) x all n-blocks: 2 MFMA (m*x_hi + m*x_lo, exact products) per
+//     (n-block, 16 px); waves 0..NB-1 also run one MFMA against an all-ones fragment to count pixels per kernel;
+//   * LDS double-buffered, next tile's global loads in flight during the MFMAs, one barrier per tile;
+//   * each workgroup walks a contiguous pixel range of one frame and writes one [NPT][C] fp32 partial; partials are
+//     summed in fixed order by k_gather_reduce (deterministic, no atomics).
+#include "vkn_common.h"
+#include "vkn_launch.h"
+
+#define GA_THREADS 512
+#define GA_WAVES 8
+#define GA_PT 32   // pixels per tile
+#define GA_LDR 40  // halfs per LDS row (32 + 8 pad)
+
+template <int NB>
+__global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __restrict__ x,
+                                                               const float* __restrict__ masks, float thr,
+                                                               float* __restrict__ part, float* __restrict__ cntp, int N,
+                                                               int NPT, int n0, int C, int P, int px_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // per buffer: xh [C][40], xl [C][40], mk [NB*32][40]
+    const int rows_buf = 2 * C + NB * 32;
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);
+
+    const int b = blockIdx.y, gidx = blockIdx.x, G = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+    const int g = lane >> 5, li = lane & 31;
+
+    const int p_begin = gidx * px_per_wg;
+    const int p_end = min(P, p_begin + px_per_wg);
+    const int ntiles = (p_end > p_begin) ? (p_end - p_begin + GA_PT - 1) / GA_PT : 0;
+
+    const float* xb = x + (size_t)b * C * P;
+    const float* mb = masks + (size_t)b * N * P;
+    const bool vec_ok = ((P & 3) == 0);
+
+    const int nxch = C * 8;        // 16-B chunks in an x tile
+    const int nmch = NB * 32 * 8;  // 16-B chunks in a mask tile
+    f32x4 xr[4];
+    f32x4 mr[2];
+
+    const int XI = (nxch + GA_THREADS - 1) / GA_THREADS;  // uniform trip counts (<= 4, <= 2)
+    const int MI = (nmch + GA_THREADS - 1) / GA_THREADS;
+    const f32x4 neg_inf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // "off" for padded rows / pixels
+
+    auto issue = [&](int t) {
+        const int p0 = p_begin + t * GA_PT;
+        const bool fast = vec_ok && (p0 + GA_PT <= p_end);  // uniform: whole tile in range, rows 16-B aligned
+        if (fast) {
+            // branch-free body: addresses are clamped, out-of-range lanes are masked by selects / by commit()
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < XI) {
+                    const int idc = min(tid + i * GA_THREADS, nxch - 1);
+                    xr[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i < MI) {
+                    const int idc = min(tid + i * GA_THREADS, nmch - 1);
+                    const int n = n0 + (idc >> 3);
+                    // raw load only (no use here: the value must stay in flight across the MFMAs); rows >= N are
+                    // switched off in commit()
+                    mr[i] = *reinterpret_cast<const f32x4*>(mb + (size_t)min(n, N - 1) * P + p0 + ((idc & 7) << 2));
+                }
+            }
+        } else {
+            // ragged tile (frame tail) or P % 4 != 0: guarded scalar loads
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + i * GA_THREADS;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (idx < nxch) {
+                    const int p = p0 + ((idx & 7) << 2);
+                    const float* src = xb + (size_t)(idx >> 3) * P + p;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (p + k < p_end) v[k] = src[k];
+                }
+                xr[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * GA_THREADS;
+                f32x4 v = neg_inf;
+                if (idx < nmch) {
+                    const int n = n0 + (idx >> 3), p = p0 + ((idx & 7) << 2);
+                    if (n < N) {
+                        const float* src = mb + (size_t)n * P + p;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (p + k < p_end) v[k] = src[k];
+                    }
+                }
+                mr[i] = v;
+            }
+        }
+    };
+
+    auto commit = [&](int buf) {
+        _Float16* xh = lds + (size_t)buf * rows_buf * GA_LDR;
+        _Float16* xl = xh + C * GA_LDR;
+        _Float16* mk = xl + C * GA_LDR;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * GA_THREADS;
+            if (idx < nxch) {
+                half4 h, l;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    _Float16 hh, ll;
+                    vkn_split_f16(xr[i][k], hh, ll);
+                    h[k] = hh;
+                    l[k] = ll;
+                }
+                const int off = (idx >> 3) * GA_LDR + ((idx & 7) << 2);
+                *reinterpret_cast<half4*>(xh + off) = h;
+                *reinterpret_cast<half4*>(xl + off) = l;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * GA_THREADS;
+            if (idx < nmch) {
+                const bool row_ok = (n0 + (idx >> 3)) < N;
+                half4 m;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = (row_ok && mr[i][k] >= thr) ? (_Float16)1.f : (_Float16)0.f;
+                *reinterpret_cast<half4*>(mk + (idx >> 3) * GA_LDR + ((idx & 7) << 2)) = m;
+            }
+        }
+    };
+
+    f32x16 acc[NB];
+    f32x16 accc;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accc[r] = 0.f;
+    half8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.f;
+
+    const bool has_cb = (wave * 32 < C);  // this wave owns channel block `wave` (uniform)
+    const bool has_cnt = (wave < NB);     // this wave counts pixels of n-block `wave`
+
+    if (ntiles > 0) {
+        issue(0);
+        commit(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) issue(t + 1);
+        {
+            const _Float16* xh = lds + (size_t)buf * rows_buf * GA_LDR;
+            const _Float16* xl = xh + C * GA_LDR;
+            const _Float16* mk = xl + C * GA_LDR;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = (ks << 4) + (g << 3);
+                if (has_cb) {
+                    const half8 bh = *reinterpret_cast<const half8*>(xh + (wave * 32 + li) * GA_LDR + off);
+                    const half8 bl = *reinterpret_cast<const half8*>(xl + (wave * 32 + li) * GA_LDR + off);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const half8 a = *reinterpret_cast<const half8*>(mk + (nb * 32 + li) * GA_LDR + off);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
+                    }
+                }
+                if (has_cnt) {
+                    const half8 a = *reinterpret_cast<const half8*>(mk + (wave * 32 + li) * GA_LDR + off);
+                    accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accc, 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < ntiles) commit(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- write this workgroup's partial (rows of the n-chunk, zero when the range was empty)
+    float* pp = part + ((size_t)b * G + gidx) * NPT * C;
+    if (has_cb) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + nb * 32 + vkn_cd_row(r, lane);
+                pp[(size_t)n * C + wave * 32 + li] = acc[nb][r];
+            }
+    }
+    if (has_cnt && li == 0) {
+        float* cp = cntp + ((size_t)b * G + gidx) * NPT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cp[n0 + wave * 32 + vkn_cd_row(r, lane)] = accc[r];
+    }
+}
+
+// xraw[b][n][c] = sum_g part[b][g][n][c] (g ascending -> deterministic), cnt[b][n] likewise.
+__global__ __launch_bounds__(256) void k_gather_reduce(const float* __restrict__ part, const float* __restrict__ cntp,
+                                                       float* __restrict__ xraw, float* __restrict__ cnt, int N, int NPT,
+                                                       int C, int G) {
+    const int row = blockIdx.x;  // b*N + n
+    const int b = row / N, n = row - b * N;
+    const float* pp = part + ((size_t)b * G * NPT + n) * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int gi = 0; gi < G; ++gi) s += pp[(size_t)gi * NPT * C + c];
+        xraw[(size_t)row * C + c] = s;
+    }
+    if (threadIdx.x == 0) {
+        const float* cp = cntp + (size_t)b * G * NPT + n;
+        float s = 0.f;
+        for (int gi = 0; gi < G; ++gi) s += cp[(size_t)gi * NPT];
+        cnt[row] = s;
+    }
+}
+
+// Exact-fp32 debug / fallback: one workgroup per (b, n), threads over channels, p-ordered accumulation.
+__global__ __launch_bounds__(256) void k_gather_ref(const float* __restrict__ x, const float* __restrict__ masks,
+                                                    float thr, float* __restrict__ xraw, float* __restrict__ cnt, int N,
+                                                    int C, int P) {
+    const int n = blockIdx.x, b = blockIdx.y;
+    const float* mp = masks + ((size_t)b * N + n) * P;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float* xp = x + ((size_t)b * C + c) * P;
+        float s = 0.f;
+        for (int p = 0; p < P; ++p)
+            if (mp[p] >= thr) s += xp[p];
+        xraw[((size_t)b * N + n) * C + c] = s;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int p = 0; p < P; ++p)
+            if (mp[p] >= thr) s += 1.f;
+        cnt[(size_t)b * N + n] = s;
+    }
+}
+
+static int ga_set_lds(const void* fn, size_t bytes) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+}
+
+// number of per-frame partials the launcher will produce for (B, P) — workspace sizing
+int vkn_gather_groups(int B, int P) {
+    int wg_per_frame = 256 / (B > 0 ? B : 1);
+    if (wg_per_frame < 1) wg_per_frame = 1;
+    int px_per_wg = (P + wg_per_frame - 1) / wg_per_frame;
+    px_per_wg = (px_per_wg + GA_PT - 1) / GA_PT * GA_PT;
+    return (P + px_per_wg - 1) / px_per_wg;
+}
+
+// part: [B][G][NPT][C] f32, cntp: [B][G][NPT] f32 (workspace); xraw [B][N][C], cnt [B][N] outputs.
+int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
+                      int B, int N, int C, int P, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || P <= 0) return VKN_E_ARG;
+    if (C % 32 != 0 || C > 256) return VKN_E_SHAPE;
+    const int NPT = (N + 31) / 32 * 32;
+    int wg_per_frame = 256 / B;
+    if (wg_per_frame < 1) wg_per_frame = 1;
+    int px_per_wg = (P + wg_per_frame - 1) / wg_per_frame;
+    px_per_wg = (px_per_wg + GA_PT - 1) / GA_PT * GA_PT;
+    const int G = (P + px_per_wg - 1) / px_per_wg;
+    for (int n0 = 0; n0 < NPT; n0 += 128) {
+        const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
+        const size_t lds = (size_t)2 * (2 * C + nb * 32) * GA_LDR * sizeof(_Float16);
+        dim3 grid(G, B, 1), block(GA_THREADS);
+#define GA_CASE(NBV)                                                                                             \
+    case NBV:                                                                                                    \
+        if (ga_set_lds((const void*)k_gather_mfma<NBV>, lds)) return VKN_E_LAUNCH;                               \
+        hipLaunchKernelGGL(k_gather_mfma<NBV>, grid, block, lds, stream, x, masks, thr, part, cntp, N, NPT, n0, C, P, \
+                           px_per_wg);                                                                           \
+        break;
+        switch (nb) {
+            GA_CASE(1)
+            GA_CASE(2)
+            GA_CASE(3)
+            GA_CASE(4)
+            default:
+                return VKN_E_SHAPE;
+        }
+#undef GA_CASE
+        VKN_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, NPT, C, G);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_launch_gather_ref(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
+                          int P, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gather_ref, dim3(N, B), dim3(256), 0, stream, x, masks, thr, xraw, cnt, N, C, P);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}

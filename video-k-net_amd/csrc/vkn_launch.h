@@ -1,0 +1,44 @@
+// vkn_launch.h — internal host-side launcher prototypes shared by the .hip translation units of libvkn.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// Row-wise epilogue descriptor of k_gemm / k_rowepi (vkn_update.hip).
+struct VknEpi {
+    const float* bias;      // [Nout] or null
+    const float* rowscale;  // [M] or null: bias is multiplied by rowscale[row] (pixel count of the folded feat_transform bias)
+    const float* resid;     // [M][ldr] or null, added before LN
+    int ldr;
+    const float* ln_w;  // [Nout] or null -> LayerNorm over the row
+    const float* ln_b;
+    float eps;
+    int act;     // 0 none, 1 relu, 2 sigmoid
+    float* out;  // [M][ldo] or null
+    int ldo;
+    const float* dot_vec;  // [Nout] or null: dot_out[row] = sum_col result(row,col) * dot_vec[col]
+    float* dot_out;
+    _Float16* plane_hi;  // or null: f16 split planes [B][NPT][ldo]; row r = b*N+n -> plane row b*NPT+n
+    _Float16* plane_lo;
+    int rows_per_frame;  // N
+    int NPT;
+};
+
+int vkn_gather_groups(int B, int P);
+int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
+                      int B, int N, int C, int P, hipStream_t stream);
+int vkn_launch_gather_ref(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
+                          int P, hipStream_t stream);
+int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
+                      int C, int P, hipStream_t stream);
+int vkn_launch_decode_ref(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
+                          hipStream_t stream);
+int vkn_launch_split_planes(const float* kern, _Float16* kfh, _Float16* kfl, int B, int N, int C, hipStream_t stream);
+int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, int M, int K, int Nout, int ksplit,
+                    float* partial, const VknEpi& epi, hipStream_t stream);
+int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig, const float* ug, const float* no_w,
+                      const float* no_b, const float* ino_w, const float* ino_b, float eps, float* f, int M, int C,
+                      hipStream_t stream);
+int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* out, int ldo, int B, int Nq,
+                    int Nk, int heads, int hd, hipStream_t stream);
+int vkn_launch_sigmoid(const float* in, float* out, int n, hipStream_t stream);
+int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream);

@@ -1,0 +1,451 @@
+// vkn_update.hip — the [B*N, C] "kernel update + interaction" block of one stage, plus the final bilinear upsample.
+//
+// Covers (reference file:line):
+//   KernelUpdator.forward                      knet/kernel_updator.py:56-93
+//   attention + attention_norm                 knet/det/kernel_update_head.py:204-208   (mmcv MultiheadAttention)
+//   ffn + ffn_norm                             knet/det/kernel_update_head.py:214-215   (mmcv FFN)
+//   cls_fcs / fc_cls / mask_fcs / fc_mask      knet/det/kernel_update_head.py:217-227
+//   video tracking link (previous_type="ffn")  knet/video/kernel_update_head.py:394-415
+//   F.interpolate(x mask_upsample_stride)      knet/det/kernel_iter_head.py:122-130
+//
+// Building blocks:
+//   k_gemm      out = epi(A . W^T): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), 32-row x 256-col tile per
+//               512-thread workgroup (wave w = column block w), A/W tiles staged in padded LDS with register prefetch of the
+//               next K-tile, optional split-K over blockIdx.z; optional elementwise-product A prologue (the updator's gate).
+//               The accumulator tile goes through LDS to a row-wise epilogue (one wave per row).
+//   row epilogue  + bias (optionally scaled per row: the folded feat_transform bias x pixel count) + residual -> LayerNorm
+//               -> ReLU/sigmoid -> store; optional dot-product side output (folded decode bias) and f16 hi/lo plane output
+//               (the decode kernels' LDS image).  Shared by k_gemm (fused) and k_rowepi (after split-K).
+//   k_ku_mix    f = ug * LN(param_out) + ig * LN(input_out)              (knet/kernel_updator.py:79-88)
+//   k_attn      softmax(q k^T / sqrt(d)) v per (frame, head), one wave per query row.
+//   k_upsample  bilinear, align_corners=False, integer scale.
+#include "vkn_common.h"
+#include "vkn_launch.h"
+
+
+#define GM_THREADS 512
+#define GM_BM 32
+#define GM_BN 256
+#define GM_KT 32
+#define GM_LDA 33
+#define GM_LDT 260
+
+// Per-lane column constants of the row epilogue (lane owns columns lane + 64*q): loaded ONCE per wave with clamped
+// addresses and no per-lane branches, so the loads issue back-to-back instead of one L2 round trip each.
+struct VknEpiCols {
+    float bias[4], lnw[4], lnb[4], dot[4];
+    int cidx[4];  // clamped absolute column
+    bool ok[4];
+};
+
+__device__ __forceinline__ void vkn_epi_load_cols(const VknEpi& e, int ncols, int col0, int lane, VknEpiCols& c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int cl = lane + 64 * q;
+        c.ok[q] = cl < ncols;
+        c.cidx[q] = col0 + min(cl, ncols - 1);
+        c.bias[q] = 0.f; c.lnw[q] = 1.f; c.lnb[q] = 0.f; c.dot[q] = 0.f;
+    }
+    if (e.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c.bias[q] = e.bias[c.cidx[q]];
+    }
+    if (e.ln_w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c.lnw[q] = e.ln_w[c.cidx[q]]; c.lnb[q] = e.ln_b[c.cidx[q]]; }
+    }
+    if (e.dot_vec) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c.dot[q] = e.dot_vec[c.cidx[q]];
+    }
+}
+
+// Row-wise epilogue executed by ONE wave for ONE row.  v[q] = accumulated value at column lane + 64*q.
+__device__ __forceinline__ void vkn_row_epilogue(const VknEpi& e, const VknEpiCols& c, int row, int ncols, int lane,
+                                                 float (&v)[4]) {
+    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e.resid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[q] = e.resid[(size_t)row * e.ldr + c.cidx[q]];
+    }
+    const float bs = (e.bias && e.rowscale) ? e.rowscale[row] : 1.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = c.ok[q] ? (v[q] + c.bias[q] * bs + rv[q]) : 0.f;
+    if (e.ln_w) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += v[q];
+        const float mean = vkn_wave_sum(s) / (float)ncols;
+        float d2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float d = c.ok[q] ? (v[q] - mean) : 0.f;
+            d2 += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(vkn_wave_sum(d2) / (float)ncols + e.eps);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (v[q] - mean) * rstd * c.lnw[q] + c.lnb[q];
+    }
+    if (e.act == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+    } else if (e.act == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = 1.0f / (1.0f + expf(-v[q]));
+    }
+    if (e.out) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c.ok[q]) e.out[(size_t)row * e.ldo + c.cidx[q]] = v[q];
+    }
+    if (e.dot_vec) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += c.ok[q] ? v[q] * c.dot[q] : 0.f;
+        s = vkn_wave_sum(s);
+        if (lane == 0) e.dot_out[row] = s;
+    }
+    if (e.plane_hi) {
+        const int b = row / e.rows_per_frame, n = row - b * e.rows_per_frame;
+        const size_t base = ((size_t)b * e.NPT + n) * e.ldo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c.ok[q]) {
+                _Float16 h, l;
+                vkn_split_f16(v[q], h, l);
+                e.plane_hi[base + c.cidx[q]] = h;
+                e.plane_lo[base + c.cidx[q]] = l;
+            }
+    }
+}
+
+// out[M][Nout] (tile 32 x 256) = A[M][K] . W[Nout][K]^T ; A2 != null: A := A (.) A2 elementwise.
+// gridDim = (ceil(Nout/256), ceil(M/32), ksplit).  ksplit > 1: raw partial sums to `partial` [ks][M][Nout].
+__global__ __launch_bounds__(GM_THREADS, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ A2, int lda,
+                                                        const float* __restrict__ W, int M, int K, int Nout,
+                                                        float* __restrict__ partial, VknEpi epi) {
+    __shared__ __attribute__((aligned(16))) float smem[GM_BM * GM_LDA + GM_BN * GM_LDA];
+    float* As = smem;                   // [32][33]
+    float* Ws = smem + GM_BM * GM_LDA;  // [256][33]; reused as the [32][260] output tile (8320 <= 8448 floats)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+    const int g = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+    const int ksplit = gridDim.z;
+    const int ktiles = K / GM_KT;
+    const int kt_per = (ktiles + ksplit - 1) / ksplit;
+    const int kt_begin = blockIdx.z * kt_per;
+    const int kt_end = min(ktiles, kt_begin + kt_per);
+
+    // staging roles: thread -> (row = tid>>5 [+16*i], k = tid&31)
+    const int sk = tid & 31, sr = tid >> 5;  // sr in 0..15
+    // Prefetch loads are unconditional on clamped rows (no per-lane branches) and nothing is consumed before the
+    // stash, so a whole K-tile (20 loads per thread) stays in flight behind the MFMAs of the previous tile.
+    const float* A2p = A2 ? A2 : A;
+    const bool mul = (A2 != nullptr);
+    float ra0, ra1, rb0, rb1;
+    float rw[16];
+    const size_t aoff0 = (size_t)min(m0 + sr, M - 1) * lda + sk;
+    const size_t aoff1 = (size_t)min(m0 + sr + 16, M - 1) * lda + sk;
+    const bool aok0 = (m0 + sr) < M, aok1 = (m0 + sr + 16) < M;
+
+#define GM_FETCH(KT)                                                                             \
+    do {                                                                                         \
+        const int kof_ = (KT) * GM_KT;                                                           \
+        ra0 = A[aoff0 + kof_];                                                                   \
+        ra1 = A[aoff1 + kof_];                                                                   \
+        rb0 = A2p[aoff0 + kof_];                                                                 \
+        rb1 = A2p[aoff1 + kof_];                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                           \
+            rw[i] = W[(size_t)min(n0 + sr + 16 * i, Nout - 1) * K + kof_ + sk];                  \
+    } while (0)
+
+#define GM_STASH()                                                                               \
+    do {                                                                                         \
+        As[sr * GM_LDA + sk] = aok0 ? (mul ? ra0 * rb0 : ra0) : 0.f;                             \
+        As[(sr + 16) * GM_LDA + sk] = aok1 ? (mul ? ra1 * rb1 : ra1) : 0.f;                      \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                           \
+            Ws[(sr + 16 * i) * GM_LDA + sk] = (n0 + sr + 16 * i < Nout) ? rw[i] : 0.f;           \
+    } while (0)
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool active = (n0 + wave * 32) < Nout;  // this wave's column block has at least one real column (uniform)
+
+    if (kt_begin < kt_end) GM_FETCH(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        GM_STASH();
+        __syncthreads();
+        if (kt + 1 < kt_end) GM_FETCH(kt + 1);
+        if (active) {
+            const float* ap = As + li * GM_LDA + g;
+            const float* bp = Ws + (wave * 32 + li) * GM_LDA + g;
+#pragma unroll
+            for (int kk = 0; kk < GM_KT / 2; ++kk)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bp[2 * kk], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef GM_FETCH
+#undef GM_STASH
+
+    if (ksplit > 1) {
+        // raw partial tile -> global [ks][M][Nout]; lanes 0..31 write 128 contiguous bytes
+        float* pz = partial + (size_t)blockIdx.z * M * Nout;
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + vkn_cd_row(r, lane), col = n0 + wave * 32 + li;
+                if (row < M && col < Nout) pz[(size_t)row * Nout + col] = acc[r];
+            }
+        }
+        return;
+    }
+
+    // ---- fused epilogue: accumulators -> LDS tile [32][260] -> one wave per row
+    float* T = Ws;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li] = active ? acc[r] : 0.f;
+    __syncthreads();
+    const int ncols = min(GM_BN, Nout - n0);
+    VknEpiCols cols;
+    vkn_epi_load_cols(epi, ncols, n0, lane, cols);
+#pragma unroll
+    for (int i = 0; i < GM_BM / 8; ++i) {
+        const int rl = wave * (GM_BM / 8) + i, row = m0 + rl;
+        if (row < M) {  // uniform
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = T[rl * GM_LDT + lane + 64 * q];
+            vkn_row_epilogue(epi, cols, row, ncols, lane, v);
+        }
+    }
+}
+
+// Row epilogue after a split-K GEMM: sums `ks` partials [ks][M][Nout] and applies the epilogue.  One wave per row, Nout <= 256.
+__global__ __launch_bounds__(256) void k_rowepi(const float* __restrict__ partial, int ks, int M, int Nout, VknEpi epi) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= M) return;
+    VknEpiCols cols;
+    vkn_epi_load_cols(epi, Nout, 0, lane, cols);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < ks; ++z) {  // fixed order -> deterministic
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += partial[((size_t)z * M + row) * Nout + cols.cidx[q]];
+    }
+    vkn_row_epilogue(epi, cols, row, Nout, lane, v);
+}
+
+// f[row] = ug * LN(params[:, C:2C]; norm_out) + ig * LN(inputf[:, C:2C]; input_norm_out)   (knet/kernel_updator.py:79-88)
+__global__ __launch_bounds__(256) void k_ku_mix(const float* __restrict__ params, const float* __restrict__ inputf,
+                                                const float* __restrict__ ig, const float* __restrict__ ug,
+                                                const float* __restrict__ no_w, const float* __restrict__ no_b,
+                                                const float* __restrict__ ino_w, const float* __restrict__ ino_b,
+                                                float eps, float* __restrict__ f, int M, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= M) return;
+    float po[4], io[4];
+    bool ok[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        ok[q] = c < C;
+        po[q] = ok[q] ? params[(size_t)row * 2 * C + C + c] : 0.f;
+        io[q] = ok[q] ? inputf[(size_t)row * 2 * C + C + c] : 0.f;
+        s1 += po[q];
+        s2 += io[q];
+    }
+    const float m1 = vkn_wave_sum(s1) / (float)C, m2 = vkn_wave_sum(s2) / (float)C;
+    float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (ok[q]) {
+            d1 += (po[q] - m1) * (po[q] - m1);
+            d2 += (io[q] - m2) * (io[q] - m2);
+        }
+    const float r1 = 1.0f / sqrtf(vkn_wave_sum(d1) / (float)C + eps), r2 = 1.0f / sqrtf(vkn_wave_sum(d2) / (float)C + eps);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (ok[q]) {
+            const int c = lane + 64 * q;
+            const float a = (po[q] - m1) * r1 * no_w[c] + no_b[c];
+            const float bb = (io[q] - m2) * r2 * ino_w[c] + ino_b[c];
+            f[(size_t)row * C + c] = ug[(size_t)row * C + c] * a + ig[(size_t)row * C + c] * bb;
+        }
+}
+
+// Scaled-dot-product attention over the kernels of one frame: grid (heads, B), 4 waves, one wave per query row.
+// q rows: Q[(b*Nq + i)*ldq + h*hd + d]; k/v rows: K[(b*Nk + j)*ldkv + h*hd + d]; out[(b*Nq+i)*ldo + h*hd + d].
+// Nk <= 256, hd <= 64.
+__global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
+                                              const float* __restrict__ Vp, int ldkv, float* __restrict__ out, int ldo,
+                                              int Nq, int Nk, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int ldh = hd + 1;
+    float* Ks = smem;             // [Nk][hd+1]
+    float* Vs = Ks + Nk * ldh;    // [Nk][hd+1]
+    float* qs = Vs + Nk * ldh;    // [4][64]
+    float* ps = qs + 4 * 64;      // [4][256]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+    for (int i = tid; i < Nk * hd; i += 256) {
+        const int j = i / hd, d = i - j * hd;
+        Ks[j * ldh + d] = Kp[((size_t)b * Nk + j) * ldkv + h * hd + d];
+        Vs[j * ldh + d] = Vp[((size_t)b * Nk + j) * ldkv + h * hd + d];
+    }
+    __syncthreads();
+    // lanes are grouped hdp-wide for the P.V product (hdp = pow2 >= hd)
+    int hdp = 1;
+    while (hdp < hd) hdp <<= 1;
+    const int ngrp = 64 / hdp, grp = lane / hdp, dl = lane - grp * hdp;
+    float* myq = qs + wave * 64;
+    float* myp = ps + wave * 256;
+    for (int i = wave; i < Nq; i += 4) {
+        if (lane < hd) myq[lane] = Q[((size_t)b * Nq + i) * ldq + h * hd + lane] * scale;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave visible to its own reads
+        float s[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = lane + 64 * jj;
+            float a = -INFINITY;
+            if (j < Nk) {
+                a = 0.f;
+                for (int d = 0; d < hd; ++d) a = fmaf(myq[d], Ks[j * ldh + d], a);
+            }
+            s[jj] = a;
+            mx = fmaxf(mx, a);
+        }
+        mx = vkn_wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = lane + 64 * jj;
+            const float ev = (j < Nk) ? expf(s[jj] - mx) : 0.f;
+            s[jj] = ev;
+            sum += ev;
+        }
+        sum = vkn_wave_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = lane + 64 * jj;
+            if (j < Nk) myp[j] = s[jj] * inv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        float o = 0.f;
+        if (dl < hd)
+            for (int j = grp; j < Nk; j += ngrp) o = fmaf(myp[j], Vs[j * ldh + dl], o);
+        for (int off = hdp; off < 64; off <<= 1) o += __shfl_xor(o, off, 64);
+        if (grp == 0 && dl < hd) out[((size_t)b * Nq + i) * ldo + h * hd + dl] = o;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// out = sigmoid(in) elementwise (cls activation after the stage loop, knet/det/kernel_iter_head.py:307-308)
+__global__ __launch_bounds__(256) void k_sigmoid(const float* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = 1.0f / (1.0f + expf(-in[i]));
+}
+
+// Bilinear upsample by integer factor S, align_corners=False (F.interpolate(scale_factor=S, mode='bilinear')):
+// src = (dst + 0.5) / S - 0.5 clamped at 0; neighbours clamped at the border.  One thread = 4 consecutive output x.
+__global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                  int S) {
+    const int OW = W * S, OH = H * S;
+    const int ox4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int oy = blockIdx.y, plane = blockIdx.z;
+    if (ox4 >= OW) return;
+    const float rs = 1.0f / (float)S;
+    const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f);
+    const int y0 = (int)sy;
+    const int y1 = min(y0 + 1, H - 1);
+    const float ly = sy - (float)y0, hy = 1.f - ly;
+    const float* r0 = in + ((size_t)plane * H + y0) * W;
+    const float* r1 = in + ((size_t)plane * H + y1) * W;
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ox = ox4 + k;
+        const float sx = fmaxf(((float)ox + 0.5f) * rs - 0.5f, 0.f);
+        const int x0 = min((int)sx, W - 1);
+        const int x1 = min(x0 + 1, W - 1);
+        const float lx = sx - (float)x0, hx = 1.f - lx;
+        o[k] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+    }
+    float* op = out + ((size_t)plane * OH + oy) * OW + ox4;
+    if (ox4 + 3 < OW && ((OW & 3) == 0)) {
+        *reinterpret_cast<f32x4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
+    } else {
+        for (int k = 0; k < 4 && ox4 + k < OW; ++k) op[k] = o[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host launchers
+int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, int M, int K, int Nout, int ksplit,
+                    float* partial, const VknEpi& epi, hipStream_t stream) {
+    if (M <= 0 || K <= 0 || Nout <= 0 || K % GM_KT != 0) return VKN_E_SHAPE;
+    const bool rowwise = epi.ln_w || epi.dot_vec;  // needs the whole row in one tile
+    if (rowwise && Nout > GM_BN) return VKN_E_SHAPE;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > 1 && (Nout > GM_BN || !partial)) return VKN_E_SHAPE;
+    dim3 grid((Nout + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, ksplit);
+    hipLaunchKernelGGL(k_gemm, grid, dim3(GM_THREADS), 0, stream, A, A2, lda, W, M, K, Nout, partial, epi);
+    VKN_CHECK_LAUNCH();
+    if (ksplit > 1) {
+        hipLaunchKernelGGL(k_rowepi, dim3((M + 3) / 4), dim3(256), 0, stream, partial, ksplit, M, Nout, epi);
+        VKN_CHECK_LAUNCH();
+    }
+    return VKN_OK;
+}
+
+int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig, const float* ug, const float* no_w,
+                      const float* no_b, const float* ino_w, const float* ino_b, float eps, float* f, int M, int C,
+                      hipStream_t stream) {
+    if (C > 256) return VKN_E_SHAPE;
+    hipLaunchKernelGGL(k_ku_mix, dim3((M + 3) / 4), dim3(256), 0, stream, params, inputf, ig, ug, no_w, no_b, ino_w, ino_b,
+                       eps, f, M, C);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* out, int ldo, int B, int Nq,
+                    int Nk, int heads, int hd, hipStream_t stream) {
+    if (Nk > 256 || hd > 64 || hd < 1) return VKN_E_SHAPE;
+    const size_t lds = ((size_t)2 * Nk * (hd + 1) + 4 * 64 + 4 * 256) * sizeof(float);
+    if (lds > 64 * 1024) return VKN_E_SHAPE;
+    hipLaunchKernelGGL(k_attn, dim3(heads, B), dim3(256), lds, stream, Q, ldq, K, V, ldkv, out, ldo, Nq, Nk, hd,
+                       1.0f / sqrtf((float)hd));
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_launch_sigmoid(const float* in, float* out, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sigmoid, dim3((n + 255) / 256), dim3(256), 0, stream, in, out, n);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream) {
+    if (S < 1 || H * S > 65535) return VKN_E_SHAPE;
+    const int OW = W * S;
+    int done = 0;
+    while (done < planes) {  // gridDim.z <= 65535
+        const int chunk = (planes - done > 32768) ? 32768 : planes - done;
+        dim3 grid((OW / 4 + 256) / 256, H * S, chunk);
+        hipLaunchKernelGGL(k_upsample, grid, dim3(256), 0, stream, in + (size_t)done * H * W,
+                           out + (size_t)done * H * S * W * S, H, W, S);
+        VKN_CHECK_LAUNCH();
+        done += chunk;
+    }
+    return VKN_OK;
+}

@@ -1,0 +1,224 @@
+"""`KernelIterHead` / `VideoKernelIterHead` — drop-ins for the reference's S-stage iteration
+(knet/det/kernel_iter_head.py:11-311, knet/video/kernel_iter_head.py:10-564): same `HEADS` registration, ctor kwargs,
+`mask_head.{s}.*` module tree and call signatures.  The stage loop itself is ONE C-ABI call (`vkn_head_forward_f32`) when
+every stage is one of our heads on a GPU tensor; `_mask_forward` exposes the per-stage path exactly like the reference.
+
+Train-time assignment / sampling / losses (`forward_train`) and the post-head panoptic merge (`simple_test`'s
+`get_panoptic`) are "next" rows of SURVEY.md §8(f) and raise NotImplementedError here.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .kernel_update_head import KernelUpdateHead, VideoKernelUpdateHead
+from .registry import BaseRoIHead, build_head, register_head
+
+
+@register_head
+class KernelIterHead(BaseRoIHead):
+
+    def __init__(self, num_stages=6, recursive=False, assign_stages=5, stage_loss_weights=(1, 1, 1, 1, 1, 1),
+                 proposal_feature_channel=256, merge_cls_scores=False, do_panoptic=False, post_assign=False,
+                 hard_target=False, merge_joint=False, num_proposals=100, num_thing_classes=80, num_stuff_classes=53,
+                 mask_assign_stride=4, ignore_label=255, thing_label_in_seg=0,
+                 mask_head=dict(type='KernelUpdateHead', num_classes=80, num_fcs=2, num_heads=8, num_cls_fcs=1,
+                                num_reg_fcs=3, feedforward_channels=2048, hidden_channels=256, dropout=0.0,
+                                roi_feat_size=7, ffn_act_cfg=dict(type='ReLU', inplace=True)),
+                 mask_out_stride=4, train_cfg=None, test_cfg=None, **kwargs):
+        assert mask_head is not None
+        assert len(stage_loss_weights) == num_stages
+        self.num_stages = num_stages
+        self.stage_loss_weights = stage_loss_weights
+        self.proposal_feature_channel = proposal_feature_channel
+        self.merge_cls_scores = merge_cls_scores
+        self.recursive = recursive
+        self.post_assign = post_assign
+        self.mask_out_stride = mask_out_stride
+        self.hard_target = hard_target
+        self.assign_stages = assign_stages
+        self.do_panoptic = do_panoptic
+        self.merge_joint = merge_joint
+        self.num_thing_classes = num_thing_classes
+        self.num_stuff_classes = num_stuff_classes
+        self.num_classes = self.num_thing_classes + self.num_stuff_classes
+        self.mask_assign_stride = mask_assign_stride
+        self.thing_label_in_seg = thing_label_in_seg
+        self.num_proposals = num_proposals
+        self.ignore_label = ignore_label
+        self._init_extra(kwargs)
+        super().__init__(mask_head=mask_head, train_cfg=train_cfg, test_cfg=test_cfg, **kwargs)
+
+    def _init_extra(self, kwargs):
+        pass
+
+    # ---- BaseRoIHead contract (reference :76-116)
+    def init_bbox_head(self, mask_roi_extractor, mask_head):
+        pass
+
+    def init_assigner_sampler(self):
+        self.mask_assigner = []
+        self.mask_sampler = []
+        if self.train_cfg is not None:
+            raise NotImplementedError('train-time assigner/sampler (reference :85-95) is a "next" row — SURVEY.md §8(f); '
+                                      'build with train_cfg=None for inference')
+
+    def init_weights(self):
+        for i in range(self.num_stages):
+            self.mask_head[i].init_weights()
+
+    def init_mask_head(self, mask_roi_extractor, mask_head):
+        self.mask_head = nn.ModuleList()
+        if not isinstance(mask_head, list):
+            mask_head = [mask_head for _ in range(self.num_stages)]
+        assert len(mask_head) == self.num_stages
+        for head in mask_head:
+            self.mask_head.append(build_head(head))
+        if self.recursive:
+            for i in range(self.num_stages):
+                self.mask_head[i] = self.mask_head[0]
+
+    # ---- per-stage path (reference :118-137)
+    def _mask_forward(self, stage, x, object_feats, mask_preds, img_metas):
+        mask_head = self.mask_head[stage]
+        cls_score, mask_preds, object_feats = mask_head(x, object_feats, mask_preds, img_metas=img_metas)
+        if mask_head.mask_upsample_stride > 1 and (stage == self.num_stages - 1 or self.training):
+            scaled_mask_preds = ops.upsample_bilinear(mask_preds, mask_head.mask_upsample_stride)
+        else:
+            scaled_mask_preds = mask_preds
+        return dict(cls_score=cls_score, mask_preds=mask_preds, scaled_mask_preds=scaled_mask_preds,
+                    object_feats=object_feats)
+
+    # ---- fused S-stage loop
+    def _fused_ok(self, x):
+        return (x.is_cuda and not self.training
+                and all(isinstance(h, KernelUpdateHead) for h in self.mask_head)
+                and len({(h.in_channels, h.num_heads, h.feedforward_channels, h.fc_cls.out_features, h.num_cls_fcs,
+                          h.num_mask_fcs, h.hard_mask_thr, h.with_ffn, h.feat_transform is None) for h in self.mask_head}) == 1)
+
+    def _head_forward(self, x, proposal_feats, mask_preds, previous_obj_feats=None, want_track=False, flags=0):
+        h0, hl = self.mask_head[0], self.mask_head[-1]
+        for h in self.mask_head:
+            h._check_inputs(x, proposal_feats, mask_preds, None)
+        B, N = proposal_feats.shape[:2]
+        C, K = h0.in_channels, h0.conv_kernel_size
+        H, W = x.shape[-2:]
+        dims = h0.make_dims(B, N, H, W)
+        packs = [h.stage_pack(x.device) for h in self.mask_head]
+        prev = previous_obj_feats.reshape(B, N, C) if previous_obj_feats is not None else None
+        obj, cls, masks, scaled, track = ops.head_forward(dims, packs, x, proposal_feats.reshape(B, N, C), mask_preds, prev,
+                                                          hl.mask_upsample_stride, want_track=want_track, flags=flags)
+        if not hl.loss_cls.use_sigmoid:
+            raise NotImplementedError('softmax cls activation (reference :309-310): every shipped config uses sigmoid')
+        obj = obj.reshape(B, N, C, K, K)
+        if track is not None:
+            track = track.reshape(B, N, C, K, K)
+        return obj, cls, masks, scaled, track
+
+    def simple_test_mask_preds(self, x, proposal_feats, mask_preds, cls_score, img_metas, imgs_whwh=None, rescale=False):
+        """-> (object_feats, cls_score.sigmoid(), mask_preds, scaled_mask_preds)            reference :285-311"""
+        if self._fused_ok(x):
+            return self._head_forward(x, proposal_feats, mask_preds)[:4]
+        object_feats = proposal_feats
+        for stage in range(self.num_stages):
+            r = self._mask_forward(stage, x, object_feats, mask_preds, img_metas)
+            object_feats, cls_score = r['object_feats'], r['cls_score']
+            mask_preds, scaled_mask_preds = r['mask_preds'], r['scaled_mask_preds']
+        if self.mask_head[-1].loss_cls.use_sigmoid:
+            cls_score = cls_score.sigmoid()
+        else:
+            cls_score = cls_score.softmax(-1)[..., :-1]
+        return object_feats, cls_score, mask_preds, scaled_mask_preds
+
+    def forward_dummy(self, x, proposal_boxes, proposal_feats, img_metas):
+        """FLOPs-counting harness of the reference (:316-330)."""
+        num_imgs = len(img_metas)
+        C = x.shape[1]
+        mask_preds = ops.mask_decode(x, proposal_feats.reshape(num_imgs, -1, C))
+        object_feats, out = proposal_feats, []
+        for stage in range(self.num_stages):
+            r = self._mask_forward(stage, x, object_feats, mask_preds, img_metas)
+            out.append(r)
+        return out
+
+    def forward_train(self, *a, **k):
+        raise NotImplementedError('forward_train (assign/sample/loss per stage, reference :139-231) is a "next" row')
+
+    def simple_test(self, *a, **k):
+        raise NotImplementedError('simple_test = simple_test_mask_preds + panoptic merge (reference :233-283, 332-370, '
+                                  '467-524); the merge is "next" row 1 of SURVEY.md §8(f) — call simple_test_mask_preds')
+
+    def aug_test(self, features, proposal_list, img_metas, rescale=False):
+        raise NotImplementedError('SparseMask does not support `aug_test`')
+
+
+@register_head
+class VideoKernelIterHead(KernelIterHead):
+    """knet/video/kernel_iter_head.py:10-564 (with_track + previous-frame link in the last stage only)."""
+
+    def _init_extra(self, kwargs):
+        self.with_track = kwargs.pop('with_track', False)
+
+    def _mask_forward(self, stage, x, object_feats, mask_preds, img_metas, previous_obj_feats=None,
+                      previous_mask_preds=None, previous_x_feats=None):
+        mask_head = self.mask_head[stage]
+        cls_score, mask_preds, object_feats, x_feats, object_feats_track = mask_head(
+            x, object_feats, mask_preds, img_metas=img_metas, previous_obj_feats=previous_obj_feats,
+            previous_mask_preds=previous_mask_preds, previous_x_feats=previous_x_feats)
+        if mask_head.mask_upsample_stride > 1 and (stage == self.num_stages - 1 or self.training):
+            scaled_mask_preds = ops.upsample_bilinear(mask_preds, mask_head.mask_upsample_stride)
+        else:
+            scaled_mask_preds = mask_preds
+        return dict(cls_score=cls_score, mask_preds=mask_preds, scaled_mask_preds=scaled_mask_preds,
+                    object_feats=object_feats, object_feats_track=object_feats_track, x_feats=x_feats)
+
+    def simple_test_mask_preds(self, x, proposal_feats, mask_preds, cls_score, img_metas):
+        """reference :508-527"""
+        return self.simple_test_mask_preds_plus_previous(x, proposal_feats, mask_preds, cls_score, img_metas)
+
+    def simple_test_mask_preds_plus_previous(self, x, proposal_feats, mask_preds, cls_score, img_metas,
+                                             previous_obj_feats=None, previous_mask_preds=None, previous_x_feats=None,
+                                             return_track=False):
+        """-> (object_feats, cls_score.sigmoid(), mask_preds, scaled_mask_preds)                   reference :529-564
+        `previous_*` reach the LAST stage only (:544-546).  `return_track=True` (an extension: the reference computes the
+        tracking embedding and drops it here) appends object_feats_track."""
+        if self._fused_ok(x) and all(isinstance(h, VideoKernelUpdateHead) for h in self.mask_head):
+            link = previous_obj_feats is not None and self.mask_head[-1].previous is not None
+            out = self._head_forward(x, proposal_feats, mask_preds, previous_obj_feats if link else None, want_track=link)
+            return out if return_track else out[:4]
+        object_feats, track = proposal_feats, None
+        for stage in range(self.num_stages):
+            last = stage == self.num_stages - 1
+            r = self._mask_forward(stage, x, object_feats, mask_preds, img_metas,
+                                   previous_obj_feats=previous_obj_feats if last else None,
+                                   previous_mask_preds=previous_mask_preds if last else None,
+                                   previous_x_feats=previous_x_feats if last else None)
+            object_feats, cls_score = r['object_feats'], r['cls_score']
+            mask_preds, scaled_mask_preds, track = r['mask_preds'], r['scaled_mask_preds'], r['object_feats_track']
+        cls_score = cls_score.sigmoid() if self.mask_head[-1].loss_cls.use_sigmoid else cls_score.softmax(-1)[..., :-1]
+        out = (object_feats, cls_score, mask_preds, scaled_mask_preds)
+        return out + (track,) if return_track else out
+
+    def clip_forward(self, x, proposal_feats, mask_preds, first_previous_obj_feats=None, want_scaled=True):
+        """Clip-batched inference (an MI355X extension; the reference walks a video one frame per call,
+        knet/video/knet_quansi_dense_embed_fc_joint_train.py:472-612).  x [T,C,H,W] are T CONSECUTIVE frames.  Masks, cls and
+        kernels of frame t do not depend on frame t-1, so all T frames run as one batch; only the tracking
+        embedding does: track[t] = link(cur = obj[t], prev = obj[t-1]) with obj[-1] = `first_previous_obj_feats`
+        (None = first frame of the video: the reference then uses object_feats as the tracking feature, :474-475).
+        -> (object_feats [T,N,C,1,1], cls [T,N,ncls], mask_preds, scaled_mask_preds, object_feats_track [T,N,C,1,1])"""
+        obj, cls, masks, scaled, _ = self._head_forward(x, proposal_feats, mask_preds)
+        last = self.mask_head[-1]
+        T, N = obj.shape[:2]
+        C = last.in_channels
+        cur = obj.reshape(T, N, C)
+        if getattr(last, 'previous', None) is None:
+            return obj, cls, masks, scaled, obj
+        prev0 = cur[:1] if first_previous_obj_feats is None else first_previous_obj_feats.reshape(1, N, C)
+        prev = torch.cat([prev0, cur[:-1]], dim=0)
+        track = ops.track_link(last.make_dims(T, N, x.shape[-2], x.shape[-1]), last.stage_pack(x.device), cur, prev)
+        if first_previous_obj_feats is None:
+            track[0] = cur[0]
+        return obj, cls, masks, scaled, track.reshape(obj.shape)
+
+    def simple_test_with_previous(self, *a, **k):
+        raise NotImplementedError('simple_test_with_previous = the stage loop + panoptic merge/tracking results '
+                                  '(reference :435-506): merge is a "next" row — call simple_test_mask_preds_plus_previous')

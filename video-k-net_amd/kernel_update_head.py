@@ -1,0 +1,253 @@
+"""`KernelUpdateHead` / `VideoKernelUpdateHead` — drop-ins for one refinement stage of the reference
+(knet/det/kernel_update_head.py:16-277, knet/video/kernel_update_head.py:17-541): same `HEADS` registration, same ctor kwargs,
+same module tree (=> the same 44 (+16 video) state-dict keys per stage), same call signature and returns.
+The forward arithmetic is one C-ABI call into libvkn.so (gather -> update -> decode HIP kernels).
+
+Sub-modules whose arithmetic lives in third-party mmcv in the reference (`MultiheadAttention`, `FFN`, `ConvModule`) are
+parameter containers here with the same attribute nesting, so the key names match (`attention.attn.in_proj_weight`,
+`ffn.layers.0.0.weight`, `feat_transform.conv.weight`, ...).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import build_loss, build_transformer_layer, register_head
+
+
+class _MHAParams(nn.Module):
+    """mmcv `MultiheadAttention(embed_dims, num_heads, attn_drop)` as a parameter container: `.attn` is a real
+    `nn.MultiheadAttention` so parameter names, shapes and default init are torch's own."""
+
+    def __init__(self, embed_dims, num_heads, dropout=0.0):
+        super().__init__()
+        if dropout != 0.0:
+            raise NotImplementedError('dropout must be 0.0 (every shipped config)')
+        self.embed_dims, self.num_heads = embed_dims, num_heads
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, dropout)
+
+
+class _FFNParams(nn.Module):
+    """mmcv `FFN(embed_dims, feedforward_channels, num_fcs, act_cfg, dropout)` as a parameter container
+    (`layers = Seq(Seq(Linear, ReLU, Dropout) x (num_fcs-1), Linear, Dropout)`)."""
+
+    def __init__(self, embed_dims, feedforward_channels, num_fcs=2, dropout=0.0):
+        super().__init__()
+        if num_fcs != 2:
+            raise NotImplementedError('num_ffn_fcs must be 2 (every shipped config)')
+        if dropout != 0.0:
+            raise NotImplementedError('dropout must be 0.0 (every shipped config)')
+        self.layers = nn.Sequential(
+            nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(dropout)),
+            nn.Linear(feedforward_channels, embed_dims), nn.Dropout(dropout))
+
+
+class _ConvParams(nn.Module):
+    """mmcv `ConvModule(C, C, 1, conv_cfg=Conv2d, act_cfg=None)`: a biased 1x1 conv, no norm, no activation."""
+
+    def __init__(self, channels, kernel_size):
+        super().__init__()
+        if kernel_size != 1:
+            raise NotImplementedError('feat_transform kernel_size must be 1 (every shipped config)')
+        self.conv = nn.Conv2d(channels, channels, 1)
+
+
+@register_head
+class KernelUpdateHead(nn.Module):
+
+    def __init__(self, num_classes=80, num_ffn_fcs=2, num_heads=8, num_cls_fcs=1, num_mask_fcs=3,
+                 feedforward_channels=2048, in_channels=256, out_channels=256, dropout=0.0, mask_thr=0.5,
+                 act_cfg=dict(type='ReLU', inplace=True), ffn_act_cfg=dict(type='ReLU', inplace=True),
+                 conv_kernel_size=3, feat_transform_cfg=None, hard_mask_thr=0.5, kernel_init=False, with_ffn=True,
+                 mask_out_stride=4, relative_coors=False, relative_coors_off=False, feat_gather_stride=1,
+                 mask_transform_stride=1, mask_upsample_stride=1, num_thing_classes=80, num_stuff_classes=53,
+                 mask_assign_stride=4, ignore_label=255, thing_label_in_seg=0,
+                 kernel_updator_cfg=dict(type='DynamicConv', in_channels=256, feat_channels=64, out_channels=256,
+                                         input_feat_shape=1, act_cfg=dict(type='ReLU', inplace=True),
+                                         norm_cfg=dict(type='LN')),
+                 loss_rank=None,
+                 loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0),
+                 loss_dice=dict(type='DiceLoss', loss_weight=3.0),
+                 loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0),
+                 **video_kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_mask = build_loss(loss_mask)
+        self.loss_dice = build_loss(loss_dice)
+        self.loss_rank = build_loss(loss_rank) if loss_rank is not None else loss_rank
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.mask_thr = mask_thr
+        self.fp16_enabled = False
+        self.dropout = dropout
+        self.num_heads = num_heads
+        self.hard_mask_thr = hard_mask_thr
+        self.kernel_init = kernel_init
+        self.with_ffn = with_ffn
+        self.mask_out_stride = mask_out_stride
+        self.relative_coors = relative_coors
+        self.relative_coors_off = relative_coors_off
+        self.conv_kernel_size = conv_kernel_size
+        self.feat_gather_stride = feat_gather_stride
+        self.mask_transform_stride = mask_transform_stride
+        self.mask_upsample_stride = mask_upsample_stride
+        self.num_thing_classes = num_thing_classes
+        self.num_stuff_classes = num_stuff_classes
+        self.mask_assign_stride = mask_assign_stride
+        self.ignore_label = ignore_label
+        self.thing_label_in_seg = thing_label_in_seg
+        self.feedforward_channels = feedforward_channels
+        self.num_cls_fcs, self.num_mask_fcs = num_cls_fcs, num_mask_fcs
+
+        if conv_kernel_size != 1:
+            raise NotImplementedError('conv_kernel_size must be 1: every shipped config sets it '
+                                      '(configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:3)')
+        if in_channels != out_channels:
+            raise NotImplementedError('in_channels == out_channels (every shipped config)')
+        if feat_gather_stride != 1 or mask_transform_stride != 1:
+            raise NotImplementedError('feat_gather_stride / mask_transform_stride must be 1 (dead branches in shipped cfgs)')
+        if max(num_cls_fcs, num_mask_fcs) > 4:
+            raise NotImplementedError('at most 4 cls/mask fcs')
+
+        E = in_channels * conv_kernel_size ** 2
+        self.attention = _MHAParams(E, num_heads, dropout)
+        self.attention_norm = nn.LayerNorm(E)
+        self.kernel_update_conv = build_transformer_layer(kernel_updator_cfg)
+        if feat_transform_cfg is not None:
+            kernel_size = feat_transform_cfg.pop('kernel_size', 1)      # mutates the cfg dict like the reference (:108)
+            if feat_transform_cfg.get('act_cfg', None) is not None or feat_transform_cfg.get('norm_cfg', None) is not None:
+                raise NotImplementedError('feat_transform must be a bare conv (act_cfg=None, no norm; every shipped config)')
+            self.feat_transform = _ConvParams(in_channels, kernel_size)
+        else:
+            self.feat_transform = None
+        if self.with_ffn:
+            self.ffn = _FFNParams(in_channels, feedforward_channels, num_ffn_fcs, dropout)
+            self.ffn_norm = nn.LayerNorm(in_channels)
+        self.cls_fcs = nn.ModuleList()
+        for _ in range(num_cls_fcs):
+            self.cls_fcs.append(nn.Linear(in_channels, in_channels, bias=False))
+            self.cls_fcs.append(nn.LayerNorm(in_channels))
+            self.cls_fcs.append(nn.ReLU(inplace=True))
+        if self.loss_cls.use_sigmoid:
+            self.fc_cls = nn.Linear(in_channels, self.num_classes)
+        else:
+            self.fc_cls = nn.Linear(in_channels, self.num_classes + 1)
+        self.mask_fcs = nn.ModuleList()
+        for _ in range(num_mask_fcs):
+            self.mask_fcs.append(nn.Linear(in_channels, in_channels, bias=False))
+            self.mask_fcs.append(nn.LayerNorm(in_channels))
+            self.mask_fcs.append(nn.ReLU(inplace=True))
+        self.fc_mask = nn.Linear(in_channels, out_channels)
+        self._init_video(num_ffn_fcs=num_ffn_fcs, **video_kwargs)
+        self._pack = None
+        self._pack_sig = None
+
+    def _init_video(self, **kw):
+        extra = {k: v for k, v in kw.items() if k != 'num_ffn_fcs'}
+        if extra:
+            raise TypeError(f'unexpected keyword arguments {sorted(extra)}')
+        self.previous = None
+        self.previous_type = None
+
+    # ---- reference: knet/det/kernel_update_head.py:151-168
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        if self.loss_cls.use_sigmoid:
+            nn.init.constant_(self.fc_cls.bias, float(-math.log((1 - 0.01) / 0.01)))   # bias_init_with_prob(0.01)
+        if self.kernel_init:
+            nn.init.normal_(self.fc_mask.weight, mean=0, std=0.01)
+
+    # ---- C-ABI plumbing
+    def stage_pack(self, device):
+        named = dict(self.named_parameters())
+        sig = ops.StagePack.signature(named, device)
+        if self._pack is None or sig != self._pack_sig:
+            self._pack = ops.StagePack(named, device)
+            self._pack_sig = sig
+        return self._pack
+
+    def make_dims(self, B, N, H, W):
+        return ops.make_dims(B, N, self.in_channels, H, W, self.num_heads, self.feedforward_channels,
+                             self.fc_cls.out_features, self.num_cls_fcs, self.num_mask_fcs, self.hard_mask_thr,
+                             self.attention_norm.eps)
+
+    def _check_inputs(self, x, proposal_feat, mask_preds, mask_shape):
+        if not self.with_ffn:
+            pass  # handled by the library (ffn pointers NULL)
+        if x.dim() != 4 or mask_preds.dim() != 4:
+            raise ValueError('x must be [B,C,H,W] and mask_preds [B,N,H,W]')
+        if tuple(mask_preds.shape[-2:]) != tuple(x.shape[-2:]):
+            raise NotImplementedError('mask_preds at a different resolution than x (bilinear pre-resize, reference :183-186) '
+                                      'never happens in shipped configs and is not built')
+        if mask_shape is not None and mask_shape[0] != x.shape[-2]:
+            raise NotImplementedError('mask_shape resize (reference :268-273) is dead in shipped configs and is not built')
+        if torch.is_grad_enabled() and (x.requires_grad or proposal_feat.requires_grad or
+                                        any(p.requires_grad for p in self.parameters()) and self.training):
+            raise NotImplementedError('backward of the MI355X head is a later round (SURVEY.md §8(f)); call under '
+                                      'torch.no_grad() / eval()')
+
+    def _run(self, x, proposal_feat, mask_preds, previous_obj_feats=None, flags=0):
+        B, N = proposal_feat.shape[:2]
+        C, K = self.in_channels, self.conv_kernel_size
+        H, W = x.shape[-2:]
+        dims = self.make_dims(B, N, H, W)
+        obj_in = proposal_feat.reshape(B, N, C)
+        prev = previous_obj_feats.reshape(B, N, C) if previous_obj_feats is not None else None
+        cls, masks, obj, xfeat, track = ops.stage_forward(dims, self.stage_pack(x.device), x, obj_in, mask_preds, prev,
+                                                          want_track=prev is not None, flags=flags)
+        obj = obj.reshape(B, N, C, K, K)
+        if track is not None:
+            track = track.reshape(B, N, C, K, K)
+        return cls, masks, obj, xfeat, track
+
+    def forward(self, x, proposal_feat, mask_preds, prev_cls_score=None, mask_shape=None, img_metas=None):
+        """-> (cls_score [B,N,ncls], new_mask_preds [B,N,H,W], obj_feat [B,N,C,K,K])   reference :170-277"""
+        self._check_inputs(x, proposal_feat, mask_preds, mask_shape)
+        cls, masks, obj, _, _ = self._run(x, proposal_feat, mask_preds)
+        return cls, masks, obj
+
+    def loss(self, *a, **k):
+        raise NotImplementedError('training loss/targets (reference :279-441) are a "next" row — SURVEY.md §8(f)')
+
+    get_targets = loss
+
+
+@register_head
+class VideoKernelUpdateHead(KernelUpdateHead):
+    """knet/video/kernel_update_head.py:17-541 with `previous_type='ffn'`, `previous_link=None` (the shipped video config,
+    configs/det/video_knet_kitti_step/video_knet_s3_r50_*_link_ffn_joint_train.py:86-89)."""
+
+    def __init__(self, *args, previous=None, previous_type='ffn', previous_link=None, previous_x_feat=None,
+                 previous_detach=False, previous_detach_link=False, previous_link_detach=False, **kwargs):
+        self._video_cfg = dict(previous=previous, previous_type=previous_type, previous_link=previous_link,
+                               previous_x_feat=previous_x_feat, previous_detach=previous_detach,
+                               previous_detach_link=previous_detach_link, previous_link_detach=previous_link_detach)
+        super().__init__(*args, **kwargs)
+
+    def _init_video(self, num_ffn_fcs=2, **kw):
+        if kw:
+            raise TypeError(f'unexpected keyword arguments {sorted(kw)}')
+        for k, v in self._video_cfg.items():
+            setattr(self, k, v)
+        if self.previous is not None:
+            if self.previous_type != 'ffn' or self.previous_link is not None:
+                raise NotImplementedError("only previous_type='ffn', previous_link=None (the shipped video config) is built; "
+                                          "the reference marks 'update'/'update_obj' as 'not work' (:417,:446)")
+            E = self.in_channels * self.conv_kernel_size ** 2
+            self.attention_previous = _MHAParams(E, 8, 0.0)            # _num_head = 8, _dropout = 0. (:165-166)
+            self.attention_previous_norm = nn.LayerNorm(E)
+            self.link_ffn = _FFNParams(self.in_channels, self.feedforward_channels, num_ffn_fcs, self.dropout)
+            self.link_ffn_norm = nn.LayerNorm(self.in_channels)
+
+    def forward(self, x, proposal_feat, mask_preds, prev_cls_score=None, mask_shape=None, img_metas=None,
+                previous_obj_feats=None, previous_mask_preds=None, previous_x_feats=None):
+        """-> (cls_score, new_mask_preds, obj_feat, x_feat [B,N,C], object_feats_track [B,N,C,K,K] | None)  reference :281-541"""
+        self._check_inputs(x, proposal_feat, mask_preds, mask_shape)
+        if previous_obj_feats is not None and self.previous is None:
+            previous_obj_feats = None      # no link modules were built (reference would fail on attribute access)
+        cls, masks, obj, xfeat, track = self._run(x, proposal_feat, mask_preds, previous_obj_feats)
+        return cls, masks, obj, xfeat, track

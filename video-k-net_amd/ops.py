@@ -1,0 +1,308 @@
+"""Python <-> C-ABI glue for the kernel-update head ops: torch is used only for device memory and streams.
+
+Every function enqueues HIP kernels of libvkn.so on the CURRENT torch stream, on the tensors' device, and returns
+torch tensors.  Inputs must be CUDA(=HIP) fp32 tensors; there is no CPU path here by design — the CPU restatement
+lives in `oracle/` and is test infrastructure only.
+"""
+import ctypes
+import struct
+import threading
+
+import torch
+
+from . import _lib
+from ._lib import VknDims, VknStageWeights, check
+
+FLAG_REF_KERNELS = 1
+
+_tls = threading.local()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name):
+    if not torch.is_tensor(t) or not t.is_cuda:
+        raise _lib.VknLibraryError(f'{name}: expected a CUDA/HIP tensor — the MI355X path has no CPU fallback')
+    if t.dtype != torch.float32:
+        raise TypeError(f'{name}: expected float32, got {t.dtype}')
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-(thread, device) scratch buffer handed to the C ABI (the library never allocates)."""
+    cache = getattr(_tls, 'ws', None)
+    if cache is None:
+        cache = _tls.ws = {}
+    buf = cache.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        cache[device] = buf
+    return buf
+
+
+_THR_CACHE = {}
+
+
+def thr_logit(hard_mask_thr=0.5):
+    """Smallest fp32 z with `torch.sigmoid(z) > hard_mask_thr` as ATen's CPU fp32 sigmoid evaluates it — the reference's
+    `(mask_preds.sigmoid() > hard_mask_thr)` (knet/det/kernel_update_head.py:190-191) becomes `z >= thr_logit`.
+    For 0.5 this is 8.940697e-08, NOT 0 (1/(1+exp(-z)) rounds to exactly 0.5 for smaller positive z).
+    Found by bisection over the ordered fp32 bit patterns (sigmoid is monotone)."""
+    key = float(hard_mask_thr)
+    if key in _THR_CACHE:
+        return _THR_CACHE[key]
+    if not 0.0 < key < 1.0:
+        raise ValueError('hard_mask_thr must be in (0, 1)')
+
+    def f2o(f):  # float -> monotone integer key
+        u = struct.unpack('<I', struct.pack('<f', f))[0]
+        return u ^ 0xFFFFFFFF if u & 0x80000000 else u | 0x80000000
+
+    def o2f(o):
+        u = o & 0x7FFFFFFF if o & 0x80000000 else o ^ 0xFFFFFFFF
+        return struct.unpack('<f', struct.pack('<I', u & 0xFFFFFFFF))[0]
+
+    def on(o):
+        # evaluate through a padded vector so the vectorised kernel (not only the scalar tail) is exercised
+        t = torch.full((16,), o2f(o), dtype=torch.float32)
+        return bool((t.sigmoid() > key)[0])
+
+    lo, hi = f2o(-200.0), f2o(200.0)
+    assert not on(lo) and on(hi)
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if on(mid):
+            hi = mid
+        else:
+            lo = mid
+    _THR_CACHE[key] = o2f(hi)
+    return _THR_CACHE[key]
+
+
+def mask_gather(x, mask_logits, hard_mask_thr=0.5, flags=0):
+    """(xraw [B,N,C], cnt [B,N]) = sum_p bit(mask)[b,n,p] * x[b,c,p] and the ON-pixel count.
+    Replaces `einsum('bnhw,bchw->bnc', (mask.sigmoid() > thr).float(), x)` (knet/det/kernel_update_head.py:190-195)."""
+    x, m = _req(x, 'x'), _req(mask_logits, 'mask_logits')
+    B, C = x.shape[0], x.shape[1]
+    N = m.shape[1]
+    P = x[0, 0].numel()
+    if m.shape[0] != B or m[0, 0].numel() != P:
+        raise ValueError('x and mask_logits disagree on batch or spatial size')
+    L = _lib.lib()
+    xraw = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+    cnt = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    nb = L.vkn_gather_workspace_bytes(B, N, C, P)
+    ws = _workspace(nb, x.device)
+    with torch.cuda.device(x.device):
+        check(L.vkn_mask_gather_f32(_ptr(x), _ptr(m), thr_logit(hard_mask_thr), _ptr(xraw), _ptr(cnt), B, N, C, P, _ptr(ws),
+                                    ws.numel(), flags, _stream()))
+    return xraw, cnt
+
+
+def mask_decode(x, kernels, bias=None, flags=0):
+    """out[b,n,h,w] = sum_c kernels[b,n,c] x[b,c,h,w] (+ bias[b,n]).
+    Replaces the per-image `F.conv2d(x[i:i+1], mask_feat[i])`, K=1 (knet/det/kernel_update_head.py:247-260)."""
+    x, k = _req(x, 'x'), _req(kernels.reshape(kernels.shape[0], kernels.shape[1], -1), 'kernels')
+    B, C, H, W = x.shape
+    N = k.shape[1]
+    if k.shape[0] != B or k.shape[2] != C:
+        raise ValueError('kernels must be [B, N, C] (conv_kernel_size == 1)')
+    bias = _req(bias, 'bias') if bias is not None else None
+    L = _lib.lib()
+    out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
+    nb = L.vkn_decode_workspace_bytes(B, N, C)
+    ws = _workspace(nb, x.device)
+    with torch.cuda.device(x.device):
+        check(L.vkn_mask_decode_f32(_ptr(x), _ptr(k), _ptr(bias), _ptr(out), B, N, C, H * W, _ptr(ws), ws.numel(), flags,
+                                    _stream()))
+    return out
+
+
+def upsample_bilinear(masks, scale):
+    """`F.interpolate(masks, scale_factor=scale, mode='bilinear', align_corners=False)` (knet/det/kernel_iter_head.py:122-130)."""
+    m = _req(masks, 'masks')
+    B, N, H, W = m.shape
+    out = torch.empty((B, N, H * scale, W * scale), dtype=torch.float32, device=m.device)
+    with torch.cuda.device(m.device):
+        check(_lib.lib().vkn_upsample_bilinear_f32(_ptr(m), _ptr(out), B * N, H, W, int(scale), _stream()))
+    return out
+
+
+class StagePack:
+    """Device pointers of one stage's parameters in the C-ABI struct, plus the derived folded tensor `ft_wT`.
+    Holds references to every tensor it points to.  Rebuilt when any parameter is replaced or modified in place
+    (tracked through `Tensor._version` and `data_ptr`)."""
+
+    def __init__(self, named: dict, device):
+        self.keep = []
+        self.w = VknStageWeights()
+        self.sig = None
+
+        def P(key):
+            t = named.get(key)
+            if t is None:
+                return 0
+            t = t.detach()
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.to(device=device, dtype=torch.float32).contiguous()
+            self.keep.append(t)
+            return t.data_ptr()
+
+        w = self.w
+        if 'feat_transform.conv.weight' in named:
+            ft = named['feat_transform.conv.weight'].detach().to(device=device, dtype=torch.float32)
+            ft2 = ft.reshape(ft.shape[0], ft.shape[1]).contiguous()
+            ftT = ft2.t().contiguous()
+            self.keep += [ft2, ftT]
+            w.ft_w, w.ft_wT = ft2.data_ptr(), ftT.data_ptr()
+            w.ft_b = P('feat_transform.conv.bias')
+        ku = 'kernel_update_conv.'
+        w.dyn_w, w.dyn_b = P(ku + 'dynamic_layer.weight'), P(ku + 'dynamic_layer.bias')
+        w.inp_w, w.inp_b = P(ku + 'input_layer.weight'), P(ku + 'input_layer.bias')
+        w.ig_w, w.ig_b = P(ku + 'input_gate.weight'), P(ku + 'input_gate.bias')
+        w.ug_w, w.ug_b = P(ku + 'update_gate.weight'), P(ku + 'update_gate.bias')
+        w.norm_in_w, w.norm_in_b = P(ku + 'norm_in.weight'), P(ku + 'norm_in.bias')
+        w.norm_out_w, w.norm_out_b = P(ku + 'norm_out.weight'), P(ku + 'norm_out.bias')
+        w.inorm_in_w, w.inorm_in_b = P(ku + 'input_norm_in.weight'), P(ku + 'input_norm_in.bias')
+        w.inorm_out_w, w.inorm_out_b = P(ku + 'input_norm_out.weight'), P(ku + 'input_norm_out.bias')
+        w.fc_w, w.fc_b = P(ku + 'fc_layer.weight'), P(ku + 'fc_layer.bias')
+        w.fc_norm_w, w.fc_norm_b = P(ku + 'fc_norm.weight'), P(ku + 'fc_norm.bias')
+        w.attn_in_w, w.attn_in_b = P('attention.attn.in_proj_weight'), P('attention.attn.in_proj_bias')
+        w.attn_out_w, w.attn_out_b = P('attention.attn.out_proj.weight'), P('attention.attn.out_proj.bias')
+        w.attn_norm_w, w.attn_norm_b = P('attention_norm.weight'), P('attention_norm.bias')
+        w.ffn1_w, w.ffn1_b = P('ffn.layers.0.0.weight'), P('ffn.layers.0.0.bias')
+        w.ffn2_w, w.ffn2_b = P('ffn.layers.1.weight'), P('ffn.layers.1.bias')
+        w.ffn_norm_w, w.ffn_norm_b = P('ffn_norm.weight'), P('ffn_norm.bias')
+        i = 0
+        while f'cls_fcs.{3 * i}.weight' in named:
+            w.cls_fc_w[i] = P(f'cls_fcs.{3 * i}.weight')
+            w.cls_ln_w[i], w.cls_ln_b[i] = P(f'cls_fcs.{3 * i + 1}.weight'), P(f'cls_fcs.{3 * i + 1}.bias')
+            i += 1
+        self.n_cls_fcs = i
+        i = 0
+        while f'mask_fcs.{3 * i}.weight' in named:
+            w.mask_fc_w[i] = P(f'mask_fcs.{3 * i}.weight')
+            w.mask_ln_w[i], w.mask_ln_b[i] = P(f'mask_fcs.{3 * i + 1}.weight'), P(f'mask_fcs.{3 * i + 1}.bias')
+            i += 1
+        self.n_mask_fcs = i
+        w.fc_cls_w, w.fc_cls_b = P('fc_cls.weight'), P('fc_cls.bias')
+        w.fc_mask_w, w.fc_mask_b = P('fc_mask.weight'), P('fc_mask.bias')
+        pa = 'attention_previous.attn.'
+        w.pa_in_w, w.pa_in_b = P(pa + 'in_proj_weight'), P(pa + 'in_proj_bias')
+        w.pa_out_w, w.pa_out_b = P(pa + 'out_proj.weight'), P(pa + 'out_proj.bias')
+        w.pa_norm_w, w.pa_norm_b = P('attention_previous_norm.weight'), P('attention_previous_norm.bias')
+        w.lffn1_w, w.lffn1_b = P('link_ffn.layers.0.0.weight'), P('link_ffn.layers.0.0.bias')
+        w.lffn2_w, w.lffn2_b = P('link_ffn.layers.1.weight'), P('link_ffn.layers.1.bias')
+        w.lffn_norm_w, w.lffn_norm_b = P('link_ffn_norm.weight'), P('link_ffn_norm.bias')
+        self.has_link = bool(w.pa_in_w and w.lffn1_w)
+
+    @staticmethod
+    def signature(named: dict, device):
+        return (str(device),) + tuple((k, t.data_ptr(), t._version) for k, t in sorted(named.items()))
+
+
+def make_dims(B, N, C, H, W, heads, ff, ncls, n_cls_fcs, n_mask_fcs, hard_mask_thr=0.5, ln_eps=1e-5):
+    return VknDims(B, N, C, H, W, heads, ff, ncls, n_cls_fcs, n_mask_fcs, thr_logit(hard_mask_thr), ln_eps)
+
+
+def stage_forward(dims: VknDims, pack: StagePack, x, obj_in, masks_in, prev_obj=None, want_track=False, flags=0):
+    """One `KernelUpdateHead.forward` on the GPU.  Returns (cls_logits [B,N,ncls], masks [B,N,H,W], obj [B,N,C],
+    x_feat [B,N,C], track [B,N,C] | None)."""
+    x, obj_in, masks_in = _req(x, 'x'), _req(obj_in, 'proposal_feat'), _req(masks_in, 'mask_preds')
+    B, N, C, H, W = dims.B, dims.N, dims.C, dims.H, dims.W
+    dev = x.device
+    L = _lib.lib()
+    cls = torch.empty((B, N, dims.ncls), dtype=torch.float32, device=dev)
+    masks = torch.empty((B, N, H, W), dtype=torch.float32, device=dev)
+    obj = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    xfeat = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    track = None
+    if prev_obj is not None and want_track:
+        prev_obj = _req(prev_obj, 'previous_obj_feats')
+        track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    else:
+        prev_obj = None
+    nb = L.vkn_stage_workspace_bytes(ctypes.byref(dims))  # 0 for unsupported dims: the call below reports the reason
+    ws = _workspace(max(nb, 256), dev)
+    with torch.cuda.device(dev):
+        check(L.vkn_stage_forward_f32(ctypes.byref(dims), ctypes.byref(pack.w), _ptr(x), _ptr(obj_in), _ptr(masks_in),
+                                      _ptr(prev_obj), _ptr(cls), _ptr(masks), _ptr(obj), _ptr(xfeat), _ptr(track),
+                                      _ptr(ws), ws.numel(), flags, _stream()))
+    return cls, masks, obj, xfeat, track
+
+
+def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=None, upsample_stride=1, want_track=False,
+                 want_scaled=True, flags=0):
+    """The S-stage loop in one C call.  Returns (obj [B,N,C], cls_prob [B,N,ncls], mask_preds [B,N,H,W],
+    scaled_mask_preds [B,N,H*s,W*s] | None, track [B,N,C] | None)."""
+    x, pf, mp = _req(x, 'x'), _req(proposal_feats, 'proposal_feats'), _req(mask_preds, 'mask_preds')
+    B, N, C, H, W = dims.B, dims.N, dims.C, dims.H, dims.W
+    dev = x.device
+    L = _lib.lib()
+    S = len(packs)
+    arr = (VknStageWeights * S)(*[p.w for p in packs])
+    obj = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    cls = torch.empty((B, N, dims.ncls), dtype=torch.float32, device=dev)
+    masks = torch.empty((B, N, H, W), dtype=torch.float32, device=dev)
+    scaled = None
+    if want_scaled and upsample_stride > 1:
+        scaled = torch.empty((B, N, H * upsample_stride, W * upsample_stride), dtype=torch.float32, device=dev)
+    track = None
+    if prev_obj is not None and want_track:
+        prev_obj = _req(prev_obj, 'previous_obj_feats')
+        track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    else:
+        prev_obj = None
+    nb = L.vkn_head_workspace_bytes(ctypes.byref(dims))
+    ws = _workspace(max(nb, 256), dev)
+    with torch.cuda.device(dev):
+        check(L.vkn_head_forward_f32(ctypes.byref(dims), S, arr, _ptr(x), _ptr(pf), _ptr(mp), _ptr(prev_obj), _ptr(obj),
+                                     _ptr(cls), _ptr(masks), _ptr(scaled), int(upsample_stride), _ptr(track), _ptr(ws),
+                                     ws.numel(), flags, _stream()))
+    return obj, cls, masks, (scaled if scaled is not None else masks), track
+
+
+def split_planes(kernels):
+    """fp32 kernels [B,N,C] -> (hi, lo) f16 planes [B, roundup(N,32), C] with hi + lo ~= kernels (2^-22 relative)."""
+    k = _req(kernels.reshape(kernels.shape[0], kernels.shape[1], -1), 'kernels')
+    B, N, C = k.shape
+    npt = (N + 31) // 32 * 32
+    hi = torch.zeros((B, npt, C), dtype=torch.float16, device=k.device)
+    lo = torch.zeros((B, npt, C), dtype=torch.float16, device=k.device)
+    with torch.cuda.device(k.device):
+        check(_lib.lib().vkn_split_planes_f32(_ptr(k), _ptr(hi), _ptr(lo), B, N, C, _stream()))
+    return hi, lo
+
+
+def mask_decode_planes(x, hi, lo, N, bias=None, out=None):
+    """The MFMA decode kernel alone on pre-split kernel planes (what runs inside a stage); `out` may be preallocated."""
+    x = _req(x, 'x')
+    B, C, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().vkn_mask_decode_planes_f32(_ptr(x), _ptr(hi), _ptr(lo), _ptr(bias), _ptr(out), B, N, C, H * W,
+                                                    _stream()))
+    return out
+
+
+def track_link(dims: VknDims, pack: StagePack, cur_obj, prev_obj):
+    """Tracking embedding of the video head's last stage for a batch of (cur, prev) kernel sets:
+    knet/video/kernel_update_head.py:394-415.  cur_obj, prev_obj [B,N,C] -> [B,N,C]."""
+    cur, prev = _req(cur_obj, 'cur_obj'), _req(prev_obj, 'prev_obj')
+    L = _lib.lib()
+    out = torch.empty_like(cur)
+    ws = _workspace(max(L.vkn_stage_workspace_bytes(ctypes.byref(dims)), 256), cur.device)
+    with torch.cuda.device(cur.device):
+        check(L.vkn_track_link_f32(ctypes.byref(dims), ctypes.byref(pack.w), _ptr(cur), _ptr(prev), _ptr(out), _ptr(ws),
+                                   ws.numel(), _stream()))
+    return out

@@ -1,0 +1,106 @@
+"""Registry surface of the reference.
+
+The reference registers `KernelIterHead` / `KernelUpdateHead` / `VideoKernel*Head` in mmdet's `HEADS` (= `MODELS` in mmdet 2.18;
+knet/det/kernel_iter_head.py:5,11, knet/det/kernel_update_head.py:9,16, knet/video/*.py) and `KernelUpdator` in mmcv's
+`TRANSFORMER_LAYER` (knet/kernel_updator.py:4,7), and builds them from config dicts with `build_head` /
+`build_transformer_layer` / `build_loss`.  When mmdet/mmcv are importable our classes register THERE (force=True, so that
+`custom_imports=['video_k_net_amd']` replaces the reference classes under the unchanged configs); otherwise a bundled
+registry with the same `register_module()/build(cfg)` behaviour is used.
+"""
+import copy
+
+import torch.nn as nn
+
+
+class Registry:
+    """mmcv.utils.Registry look-alike: `@R.register_module()` and `R.build(cfg)` with `type=` dispatch."""
+
+    def __init__(self, name):
+        self.name = name
+        self._module_dict = {}
+
+    def get(self, key):
+        return self._module_dict.get(key)
+
+    def __contains__(self, key):
+        return key in self._module_dict
+
+    def register_module(self, name=None, force=False, module=None):
+        def _reg(cls):
+            key = name or cls.__name__
+            if key in self._module_dict and not force:
+                raise KeyError(f'{key} is already registered in {self.name}')
+            self._module_dict[key] = cls
+            return cls
+        return _reg(module) if module is not None else _reg
+
+    def build(self, cfg, default_args=None):
+        if not isinstance(cfg, dict) or 'type' not in cfg:
+            raise TypeError(f'cfg must be a dict with a "type" key, got {cfg!r}')
+        args = copy.copy(dict(cfg))
+        for k, v in (default_args or {}).items():
+            args.setdefault(k, v)
+        typ = args.pop('type')
+        cls = self.get(typ) if isinstance(typ, str) else typ
+        if cls is None:
+            raise KeyError(f'{typ} is not in the {self.name} registry')
+        return cls(**args)
+
+
+try:  # real mmdet / mmcv present: be a plug-in of the reference's own registries
+    from mmcv.cnn.bricks.transformer import TRANSFORMER_LAYER, build_transformer_layer  # type: ignore
+    from mmdet.models.builder import HEADS, build_head, build_loss  # type: ignore
+    from mmdet.models.roi_heads import BaseRoIHead  # type: ignore
+    HAVE_MM = True
+except Exception:  # noqa: BLE001  (mmcv/mmdet are not installed in the build image)
+    HAVE_MM = False
+    HEADS = Registry('models')
+    TRANSFORMER_LAYER = Registry('transformerLayer')
+    LOSSES = Registry('loss')
+
+    def build_head(cfg):
+        return HEADS.build(cfg)
+
+    def build_transformer_layer(cfg, default_args=None):
+        return TRANSFORMER_LAYER.build(cfg, default_args)
+
+    class _LossShell(nn.Module):
+        """The forward path only reads `.use_sigmoid` (knet/det/kernel_update_head.py:136-139); loss arithmetic is a
+        'next' row (training) and lives in mmdet."""
+
+        def __init__(self, use_sigmoid=False, **kwargs):
+            super().__init__()
+            self.use_sigmoid = use_sigmoid
+            self.cfg = kwargs
+
+        def forward(self, *a, **k):
+            raise NotImplementedError('training losses need mmdet; the MI355X build covers the inference hot path')
+
+    for _n in ('FocalLoss', 'CrossEntropyLoss', 'DiceLoss'):
+        LOSSES.register_module(name=_n, module=type(_n, (_LossShell,), {}))
+
+    def build_loss(cfg):
+        return LOSSES.build(cfg)
+
+    class BaseRoIHead(nn.Module):
+        """Ctor contract of mmdet 2.18 `BaseRoIHead` (init_bbox_head / init_mask_head / init_assigner_sampler order,
+        knet/det/kernel_iter_head.py:67-68,85-116)."""
+
+        def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
+                     shared_head=None, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None):
+            super().__init__()
+            self.train_cfg = train_cfg
+            self.test_cfg = test_cfg
+            if bbox_head is not None:
+                self.init_bbox_head(bbox_roi_extractor, bbox_head)
+            if mask_head is not None:
+                self.init_mask_head(mask_roi_extractor, mask_head)
+            self.init_assigner_sampler()
+
+
+def register_head(cls):
+    return HEADS.register_module(force=True)(cls)
+
+
+def register_transformer_layer(cls):
+    return TRANSFORMER_LAYER.register_module(force=True)(cls)
