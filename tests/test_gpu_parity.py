@@ -174,8 +174,10 @@ def test_head_vs_reference_golden(vkn, name, flags):
     if 'scaled_mask_preds' in g:
         assert maxabs(scaled, g['scaled_mask_preds']) < TOL_LOGIT
     else:
+        # row sums of the upsampled logits, tolerance relative to the row's ABSOLUTE mass (sums themselves cancel to ~0)
         rs = scaled.double().sum(dim=(-1, -2)).cpu().numpy()
-        assert np.max(np.abs(rs - g['scaled_rowsum']) / (1.0 + np.abs(g['scaled_rowsum']))) < 1e-3
+        mass = np.abs(g['mask_preds']).sum(axis=(-1, -2)) * up * up
+        assert np.max(np.abs(rs - g['scaled_rowsum']) / mass) < 1e-5
     if case['video']:
         assert maxabs(track, g['track']) < 1e-4
     # public API returns
@@ -249,25 +251,60 @@ def test_cfg2_size_properties(vkn):
     hot[:, torch.arange(N), pix] = 5.0
     xr, cnt = vkn.ops.mask_gather(x, hot.reshape(B, N, H, W))
     assert torch.all(cnt == 1) and maxabs(xr, x.reshape(B, C, -1)[:, :, pix].transpose(1, 2)) < 2e-6
-    # gather is the adjoint of decode:  <decode(x,K), M> == <K, gather(x,M)>  for binary M
+    # gather is the adjoint of decode:  <decode(x,K), M> == <K, gather(x,M)>  for binary M.  Tolerance: fp32-level
+    # relative error on the ABSOLUTE mass of the two sums (the sums themselves are random-sign and cancel).
     mlog = torch.randn(B, N, H, W, generator=g).to(DEV)
-    xr, _ = vkn.ops.mask_gather(x, mlog)
-    lhs = (d1.double() * (mlog >= vkn.ops.thr_logit(0.5)).double()).sum()
-    rhs = (k1.double() * xr.double()).sum()
-    assert abs(float(lhs - rhs)) < 1e-6 * float(lhs.abs() + rhs.abs() + 1)
+    xr, cnt = vkn.ops.mask_gather(x, mlog)
+    M = (mlog >= vkn.ops.thr_logit(0.5)).double()
+    assert torch.equal(cnt.double(), M.sum(dim=(-1, -2)))
+    lhs, rhs = (d1.double() * M).sum(), (k1.double() * xr.double()).sum()
+    mass = float((k1.double().abs() * xr.double().abs()).sum())
+    assert abs(float(lhs - rhs)) < 2e-6 * mass
+    # full-size element-wise check against fp64 on the device (property check; the CPU oracle covers the small sizes)
+    ref = torch.bmm(M.reshape(B, N, -1), x.double().reshape(B, C, -1).transpose(1, 2))
+    assert maxabs(xr, ref) < 2e-5 * float(ref.abs().max())
+    refd = torch.bmm(k1.double(), x.double().reshape(B, C, -1)).reshape(B, N, H, W)
+    assert maxabs(d1, refd) < 2e-4
 
 
 def test_cfg2_size_head_vs_oracle(vkn):
-    """One 1024x2048 frame through the video head (S=3, N=117, link + x4 upsample) against the CPU oracle."""
+    """One 1024x2048 frame through the video head (S=3, N=117, link + x4 upsample) against the CPU oracle.
+
+    At this size (3.8 M logits per stage) a few logits lie within 1e-5 of the binarisation flip point, and ANY change of
+    fp32 summation order flips them (SURVEY.md §7 'Threshold semantics'; with i.i.d. random features one flipped pixel moves
+    that kernel's x_feat by ~1 %).  So parity is checked TEACHER-FORCED: every stage gets the oracle's previous-stage outputs
+    as inputs (identical fp32 mask logits => bit-identical binary masks), and the fused 3-stage call is then checked to be
+    bit-identical to the GPU's own stage-by-stage path."""
     case = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256,
                 B=1, seed=11, video=1)
     head, (x, pf, mp, prev) = _build_head(vkn, case)
-    obj_r, cls_r, masks_r, scaled_r, track_r = run_oracle(case)
+    traces = []
+    obj_r, cls_r, masks_r, scaled_r, track_r = run_oracle(case, traces=traces)
+    xd, prevd = _cuda(x, prev)
+    obj_in, m_in = pf, mp
     with torch.no_grad():
+        for s in range(3):
+            kw = dict(previous_obj_feats=prevd) if s == 2 else {}
+            r = head._mask_forward(s, xd, obj_in.to(DEV), m_in.to(DEV), [dict()], **kw)
+            tr = traces[s]
+            cnt_ref = tr['bin_mask'].sum(dim=(-1, -2))
+            assert maxabs(r['x_feats'], tr['x_feat']) < 2e-5 * float(tr['x_feat'].abs().max()), f'stage {s} x_feat'
+            assert maxabs(r['object_feats'], tr['obj_feat']) < 1e-4, f'stage {s} obj'
+            assert maxabs(r['cls_score'], tr['cls_score']) < 1e-4, f'stage {s} cls'
+            assert maxabs(r['mask_preds'], tr['new_mask_preds']) < TOL_LOGIT, f'stage {s} mask logits'
+            mr = tr['new_mask_preds'].numpy()
+            margin = np.abs(mr) > 2e-3
+            assert np.array_equal((r['mask_preds'].cpu().numpy() > 0)[margin], (mr > 0)[margin]), f'stage {s} binary masks'
+            assert cnt_ref.shape == (1, 117)
+            obj_in, m_in = tr['obj_feat'], tr['new_mask_preds']                 # teacher forcing
+        assert maxabs(r['object_feats_track'], track_r) < 1e-4
+        assert maxabs(r['scaled_mask_preds'], scaled_r) < TOL_LOGIT
+        # fused call == the GPU's own stage-by-stage path, bit for bit
         obj, cls, masks, scaled, track = head._head_forward(*_cuda(x, pf, mp, prev), want_track=True)
-    assert maxabs(obj, obj_r) < 1e-4 and maxabs(cls, cls_r) < 1e-5 and maxabs(track, track_r) < 1e-4
-    assert maxabs(masks, masks_r) < TOL_LOGIT
-    assert maxabs(scaled, scaled_r) < TOL_LOGIT
-    mr = masks_r.numpy()
-    margin = np.abs(mr) > 2e-3
-    assert np.array_equal((masks.cpu().numpy() > 0)[margin], (mr > 0)[margin])
+        o2, m2 = pf.to(DEV), mp.to(DEV)
+        for s in range(3):
+            kw = dict(previous_obj_feats=prevd) if s == 2 else {}
+            r = head._mask_forward(s, xd, o2, m2, [dict()], **kw)
+            o2, m2 = r['object_feats'], r['mask_preds']
+    assert torch.equal(masks, m2) and torch.equal(obj, o2) and torch.equal(scaled, r['scaled_mask_preds'])
+    assert torch.equal(track, r['object_feats_track']) and torch.equal(cls, r['cls_score'].sigmoid())
