@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): kernel trace + HBM counters of bench.py; outputs under gpurun_out/.
+# usage: tools/gpu_profile.sh <tag> [bench args...]
+set -u
+TAG=${1:-r01}; shift || true
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py $ARGS > $OUT/bench_trace.log 2>&1
+# counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with sys-trace)
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python $R/bench.py $ARGS > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python $R/bench.py $ARGS > $OUT/bench_write.log 2>&1
+python $R/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt | head -60
