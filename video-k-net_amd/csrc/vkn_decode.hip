@@ -10,7 +10,7 @@
 //   * each wave owns 32-pixel strips: B operand = x, loaded straight from global into MFMA fragments
 //     (lane = pixel -> 128-B coalesced segments per channel), split to f16 hi/lo in registers;
 //     A operand = kernels from LDS; 3 x v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi) per (n-block, 16 ch);
-//   * 3-deep register ring of x fragments (2 k-steps in flight per wave) across strip boundaries;
+//   * 6-deep register ring of x fragments (5 k-steps = 10 KB in flight per wave) across strip boundaries;
 //   * output D[n][px]: lanes 0..31 store 128 contiguous bytes of one mask row.
 #include "vkn_common.h"
 #include "vkn_launch.h"
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     float* ob = out + (size_t)b * N * P;
 
     f32x16 acc[NB];
-    float r0[8], r1[8], r2[8];
+    float r0[8], r1[8], r2[8], r3[8], r4[8], r5[8];
     int ld_ks = 0, ld_sl = 0, ld_cnt = 0;  // next fragment to load
     int c_ks = 0, c_sl = 0;                // next fragment to consume
 
@@ -128,10 +128,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
         }                                                                                                 \
     } while (0)
 
+    // 6-deep register ring: 5 fragments (40 dword loads = 10 KB per wave, 80 KB per CU) in flight behind the MFMAs
     DEC_LOAD(r0);
     DEC_LOAD(r1);
-    for (int f = 0; f < total; f += 3) {
-        DEC_LOAD(r2);
+    DEC_LOAD(r2);
+    DEC_LOAD(r3);
+    DEC_LOAD(r4);
+    for (int f = 0; f < total; f += 6) {
+        DEC_LOAD(r5);
         DEC_COMPUTE(r0);
         if (f + 1 >= total) break;
         DEC_LOAD(r0);
@@ -139,6 +143,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
         if (f + 2 >= total) break;
         DEC_LOAD(r1);
         DEC_COMPUTE(r2);
+        if (f + 3 >= total) break;
+        DEC_LOAD(r2);
+        DEC_COMPUTE(r3);
+        if (f + 4 >= total) break;
+        DEC_LOAD(r3);
+        DEC_COMPUTE(r4);
+        if (f + 5 >= total) break;
+        DEC_LOAD(r4);
+        DEC_COMPUTE(r5);
     }
 #undef DEC_LOAD
 #undef DEC_COMPUTE

@@ -48,69 +48,62 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
 
     const int nxch = C * 8;        // 16-B chunks in an x tile
     const int nmch = NB * 32 * 8;  // 16-B chunks in a mask tile
-    f32x4 xr[4];
-    f32x4 mr[2];
+    f32x4 xrA[4], xrB[4];  // two register sets: tile t+2 is being loaded while tile t+1 waits to be committed
+    f32x4 mrA[2], mrB[2];
 
-    const int XI = (nxch + GA_THREADS - 1) / GA_THREADS;  // uniform trip counts (<= 4, <= 2)
-    const int MI = (nmch + GA_THREADS - 1) / GA_THREADS;
     const f32x4 neg_inf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // "off" for padded rows / pixels
 
-    auto issue = [&](int t) {
+    // Full tiles (all 32 px in range, rows 16-B aligned): branch-free, ALWAYS 4 + 2 dwordx4 loads per thread on clamped
+    // addresses (lanes past the tile are masked in commit()), nothing consumed here -> exact vmcnt counting in the pipeline.
+    auto issue = [&](int t, f32x4 (&xr)[4], f32x4 (&mr)[2]) {
         const int p0 = p_begin + t * GA_PT;
-        const bool fast = vec_ok && (p0 + GA_PT <= p_end);  // uniform: whole tile in range, rows 16-B aligned
-        if (fast) {
-            // branch-free body: addresses are clamped, out-of-range lanes are masked by selects / by commit()
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < XI) {
-                    const int idc = min(tid + i * GA_THREADS, nxch - 1);
-                    xr[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2));
-                }
+        for (int i = 0; i < 4; ++i) {
+            const int idc = min(tid + i * GA_THREADS, nxch - 1);
+            xr[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idc = min(tid + i * GA_THREADS, nmch - 1);
+            const int n = min(n0 + (idc >> 3), N - 1);
+            mr[i] = *reinterpret_cast<const f32x4*>(mb + (size_t)n * P + p0 + ((idc & 7) << 2));
+        }
+    };
+
+    // Ragged tile (frame tail) or P % 4 != 0: guarded scalar loads, not pipelined.
+    auto issue_slow = [&](int t, f32x4 (&xr)[4], f32x4 (&mr)[2]) {
+        const int p0 = p_begin + t * GA_PT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * GA_THREADS;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < nxch) {
+                const int p = p0 + ((idx & 7) << 2);
+                const float* src = xb + (size_t)(idx >> 3) * P + p;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (p + k < p_end) v[k] = src[k];
             }
+            xr[i] = v;
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i < MI) {
-                    const int idc = min(tid + i * GA_THREADS, nmch - 1);
-                    const int n = n0 + (idc >> 3);
-                    // raw load only (no use here: the value must stay in flight across the MFMAs); rows >= N are
-                    // switched off in commit()
-                    mr[i] = *reinterpret_cast<const f32x4*>(mb + (size_t)min(n, N - 1) * P + p0 + ((idc & 7) << 2));
-                }
-            }
-        } else {
-            // ragged tile (frame tail) or P % 4 != 0: guarded scalar loads
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = tid + i * GA_THREADS;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (idx < nxch) {
-                    const int p = p0 + ((idx & 7) << 2);
-                    const float* src = xb + (size_t)(idx >> 3) * P + p;
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * GA_THREADS;
+            f32x4 v = neg_inf;
+            if (idx < nmch) {
+                const int n = n0 + (idx >> 3), p = p0 + ((idx & 7) << 2);
+                if (n < N) {
+                    const float* src = mb + (size_t)n * P + p;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (p + k < p_end) v[k] = src[k];
                 }
-                xr[i] = v;
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + i * GA_THREADS;
-                f32x4 v = neg_inf;
-                if (idx < nmch) {
-                    const int n = n0 + (idx >> 3), p = p0 + ((idx & 7) << 2);
-                    if (n < N) {
-                        const float* src = mb + (size_t)n * P + p;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (p + k < p_end) v[k] = src[k];
-                    }
-                }
-                mr[i] = v;
-            }
+            mr[i] = v;
         }
     };
 
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, const f32x4 (&xr)[4], const f32x4 (&mr)[2]) {
         _Float16* xh = lds + (size_t)buf * rows_buf * GA_LDR;
         _Float16* xl = xh + C * GA_LDR;
         _Float16* mk = xl + C * GA_LDR;
@@ -159,38 +152,56 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     const bool has_cb = (wave * 32 < C);  // this wave owns channel block `wave` (uniform)
     const bool has_cnt = (wave < NB);     // this wave counts pixels of n-block `wave`
 
-    if (ntiles > 0) {
-        issue(0);
-        commit(0);
-    }
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) issue(t + 1);
-        {
-            const _Float16* xh = lds + (size_t)buf * rows_buf * GA_LDR;
-            const _Float16* xl = xh + C * GA_LDR;
-            const _Float16* mk = xl + C * GA_LDR;
+    auto compute = [&](int buf) {
+        const _Float16* xh = lds + (size_t)buf * rows_buf * GA_LDR;
+        const _Float16* xl = xh + C * GA_LDR;
+        const _Float16* mk = xl + C * GA_LDR;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int off = (ks << 4) + (g << 3);
-                if (has_cb) {
-                    const half8 bh = *reinterpret_cast<const half8*>(xh + (wave * 32 + li) * GA_LDR + off);
-                    const half8 bl = *reinterpret_cast<const half8*>(xl + (wave * 32 + li) * GA_LDR + off);
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = (ks << 4) + (g << 3);
+            if (has_cb) {
+                const half8 bh = *reinterpret_cast<const half8*>(xh + (wave * 32 + li) * GA_LDR + off);
+                const half8 bl = *reinterpret_cast<const half8*>(xl + (wave * 32 + li) * GA_LDR + off);
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const half8 a = *reinterpret_cast<const half8*>(mk + (nb * 32 + li) * GA_LDR + off);
-                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[nb], 0, 0, 0);
-                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
-                    }
-                }
-                if (has_cnt) {
-                    const half8 a = *reinterpret_cast<const half8*>(mk + (wave * 32 + li) * GA_LDR + off);
-                    accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accc, 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) {
+                    const half8 a = *reinterpret_cast<const half8*>(mk + (nb * 32 + li) * GA_LDR + off);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
                 }
             }
+            if (has_cnt) {
+                const half8 a = *reinterpret_cast<const half8*>(mk + (wave * 32 + li) * GA_LDR + off);
+                accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accc, 0, 0, 0);
+            }
         }
-        if (t + 1 < ntiles) commit(buf ^ 1);
+    };
+
+    // pipeline over the FULL tiles: tile t computes from LDS[t&1]; tile t+1 sits in one register set and is committed to
+    // LDS[(t+1)&1] after the MFMAs; tile t+2 is issued into the other register set before them (two tiles = 96 KB per CU in
+    // flight).  Issues past the end re-read the last full tile (clamped) so every iteration has the same 6 loads.
+    const int nfull = vec_ok ? (p_end - p_begin) / GA_PT : 0;
+    if (nfull > 0) {
+        issue(0, xrA, mrA);
+        issue(min(1, nfull - 1), xrB, mrB);
+        commit(0, xrA, mrA);
+        __syncthreads();
+        for (int t = 0; t < nfull; t += 2) {
+            issue(min(t + 2, nfull - 1), xrA, mrA);
+            compute(0);
+            if (t + 1 < nfull) commit(1, xrB, mrB);
+            __syncthreads();
+            if (t + 1 >= nfull) break;
+            issue(min(t + 3, nfull - 1), xrB, mrB);
+            compute(1);
+            if (t + 2 < nfull) commit(0, xrA, mrA);
+            __syncthreads();
+        }
+    }
+    for (int t = nfull; t < ntiles; ++t) {  // ragged / unaligned tiles
+        issue_slow(t, xrA, mrA);
+        commit(0, xrA, mrA);
+        __syncthreads();
+        compute(0);
         __syncthreads();
     }
 

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_ku_mix(const float* __restrict__ params
         }
 }
 
-// Scaled-dot-product attention over the kernels of one frame: grid (heads, B), 4 waves, one wave per query row.
+// Scaled-dot-product attention over the kernels of one frame: grid (heads, B, ceil(Nq/16)), 4 waves, one wave per query row.
 // q rows: Q[(b*Nq + i)*ldq + h*hd + d]; k/v rows: K[(b*Nk + j)*ldkv + h*hd + d]; out[(b*Nq+i)*ldo + h*hd + d].
 // Nk <= 256, hd <= 64.
 __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
@@ -307,7 +307,10 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int l
     const int ngrp = 64 / hdp, grp = lane / hdp, dl = lane - grp * hdp;
     float* myq = qs + wave * 64;
     float* myp = ps + wave * 256;
-    for (int i = wave; i < Nq; i += 4) {
+    // blockIdx.z owns 16 consecutive query rows, 4 per wave: (heads x B x ceil(Nq/16)) workgroups
+    const int i_begin = blockIdx.z * 16 + wave * 4;
+    const int i_end = min(Nq, i_begin + 4);
+    for (int i = i_begin; i < i_end; ++i) {
         if (lane < hd) myq[lane] = Q[((size_t)b * Nq + i) * ldq + h * hd + lane] * scale;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave visible to its own reads
@@ -358,35 +361,47 @@ __global__ __launch_bounds__(256) void k_sigmoid(const float* __restrict__ in, f
 }
 
 // Bilinear upsample by integer factor S, align_corners=False (F.interpolate(scale_factor=S, mode='bilinear')):
-// src = (dst + 0.5) / S - 0.5 clamped at 0; neighbours clamped at the border.  One thread = 4 consecutive output x.
+// src = (dst + 0.5) / S - 0.5 clamped at 0; neighbours clamped at the border.
+// Write-bound (S*S outputs per input): one workgroup = one input row of one plane -> its S output rows; a thread owns 4
+// consecutive output x (x-weights computed once, reused for the S rows) and streams them out with 16-B non-temporal stores.
 __global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ in, float* __restrict__ out, int H, int W,
                                                   int S) {
     const int OW = W * S, OH = H * S;
-    const int ox4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int oy = blockIdx.y, plane = blockIdx.z;
-    if (ox4 >= OW) return;
+    const int y = blockIdx.x, plane = blockIdx.y;
     const float rs = 1.0f / (float)S;
-    const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f);
-    const int y0 = (int)sy;
-    const int y1 = min(y0 + 1, H - 1);
-    const float ly = sy - (float)y0, hy = 1.f - ly;
-    const float* r0 = in + ((size_t)plane * H + y0) * W;
-    const float* r1 = in + ((size_t)plane * H + y1) * W;
-    float o[4];
+    const float* ip = in + (size_t)plane * H * W;
+    const bool vec = ((OW & 3) == 0);
+    for (int ox4 = threadIdx.x * 4; ox4 < OW; ox4 += 1024) {
+        int x0[4], x1[4];
+        float lx[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int ox = ox4 + k;
-        const float sx = fmaxf(((float)ox + 0.5f) * rs - 0.5f, 0.f);
-        const int x0 = min((int)sx, W - 1);
-        const int x1 = min(x0 + 1, W - 1);
-        const float lx = sx - (float)x0, hx = 1.f - lx;
-        o[k] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
-    }
-    float* op = out + ((size_t)plane * OH + oy) * OW + ox4;
-    if (ox4 + 3 < OW && ((OW & 3) == 0)) {
-        *reinterpret_cast<f32x4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
-    } else {
-        for (int k = 0; k < 4 && ox4 + k < OW; ++k) op[k] = o[k];
+        for (int k = 0; k < 4; ++k) {
+            const float sx = fmaxf(((float)(ox4 + k) + 0.5f) * rs - 0.5f, 0.f);
+            x0[k] = min((int)sx, W - 1);
+            x1[k] = min(x0[k] + 1, W - 1);
+            lx[k] = sx - (float)x0[k];
+        }
+        for (int j = 0; j < S; ++j) {
+            const int oy = y * S + j;
+            const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f);
+            const int y0 = (int)sy;
+            const int y1 = min(y0 + 1, H - 1);
+            const float ly = sy - (float)y0, hy = 1.f - ly;
+            const float* r0 = ip + (size_t)y0 * W;
+            const float* r1 = ip + (size_t)y1 * W;
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float hx = 1.f - lx[k];
+                o[k] = hy * (hx * r0[x0[k]] + lx[k] * r0[x1[k]]) + ly * (hx * r1[x0[k]] + lx[k] * r1[x1[k]]);
+            }
+            float* op = out + ((size_t)plane * OH + oy) * OW + ox4;
+            if (vec && ox4 + 3 < OW) {
+                __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(op));
+            } else {
+                for (int k = 0; k < 4 && ox4 + k < OW; ++k) op[k] = o[k];
+            }
+        }
     }
 }
 
@@ -423,7 +438,7 @@ int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int
     if (Nk > 256 || hd > 64 || hd < 1) return VKN_E_SHAPE;
     const size_t lds = ((size_t)2 * Nk * (hd + 1) + 4 * 64 + 4 * 256) * sizeof(float);
     if (lds > 64 * 1024) return VKN_E_SHAPE;
-    hipLaunchKernelGGL(k_attn, dim3(heads, B), dim3(256), lds, stream, Q, ldq, K, V, ldkv, out, ldo, Nq, Nk, hd,
+    hipLaunchKernelGGL(k_attn, dim3(heads, B, (Nq + 15) / 16), dim3(256), lds, stream, Q, ldq, K, V, ldkv, out, ldo, Nq, Nk, hd,
                        1.0f / sqrtf((float)hd));
     VKN_CHECK_LAUNCH();
     return VKN_OK;
@@ -436,13 +451,11 @@ int vkn_launch_sigmoid(const float* in, float* out, int n, hipStream_t stream) {
 }
 
 int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream) {
-    if (S < 1 || H * S > 65535) return VKN_E_SHAPE;
-    const int OW = W * S;
+    if (S < 1) return VKN_E_SHAPE;
     int done = 0;
-    while (done < planes) {  // gridDim.z <= 65535
+    while (done < planes) {  // gridDim.y <= 65535
         const int chunk = (planes - done > 32768) ? 32768 : planes - done;
-        dim3 grid((OW / 4 + 256) / 256, H * S, chunk);
-        hipLaunchKernelGGL(k_upsample, grid, dim3(256), 0, stream, in + (size_t)done * H * W,
+        hipLaunchKernelGGL(k_upsample, dim3(H, chunk), dim3(256), 0, stream, in + (size_t)done * H * W,
                            out + (size_t)done * H * S * W * S, H, W, S);
         VKN_CHECK_LAUNCH();
         done += chunk;
