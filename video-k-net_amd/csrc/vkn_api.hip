@@ -161,6 +161,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
               float* track_out, const StageWs& s, unsigned flags, hipStream_t st) {
     const int B = d->B, N = d->N, C = d->C, P = d->H * d->W, M = B * N;
     const bool ref = (flags & VKN_FLAG_REF_KERNELS) != 0;
+    const bool ref_decode = ref || (P & 1);  // odd H*W: mask rows are not 8-byte aligned -> exact-fp32 FMA decode kernel
     const bool has_ft = w->ft_w != nullptr;
 
     // (i) mask gather                                        knet/det/kernel_update_head.py:190-195
@@ -222,7 +223,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
 
     // (iii) mask decode with the folded kernels  Kf = mask_feat . W_ft   :247-260
     const float* kb = has_ft ? s.kb : nullptr;
-    if (ref) {
+    if (ref_decode) {
         const float* kern = s.maskfeat;
         if (has_ft) {
             e = mk_epi(d); e.out = s.kern32; e.ldo = C;
@@ -307,7 +308,7 @@ int vkn_mask_decode_f32(const float* x, const float* kernels, const float* bias,
     if (!aligned16(x) || !aligned16(kernels) || !aligned16(out)) return VKN_E_ALIGN;
     if (C % 32 != 0 || C > 256 || N > 256) return VKN_E_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (flags & VKN_FLAG_REF_KERNELS) return vkn_launch_decode_ref(x, kernels, bias, out, B, N, C, P, st);
+    if ((flags & VKN_FLAG_REF_KERNELS) || (P & 1)) return vkn_launch_decode_ref(x, kernels, bias, out, B, N, C, P, st);
     if (!ws || ws_bytes < vkn_decode_workspace_bytes(B, N, C)) return VKN_E_WORKSPACE;
     Carver c{static_cast<char*>(ws), 0};
     _Float16* kfh = c.take<_Float16>((size_t)B * npt_of(N) * C);

@@ -7,18 +7,27 @@
 // MI355X design: HBM-bound stream of x (read once) and of the logits (written once).
 //   * one persistent 512-thread workgroup per CU; the frame's N decode kernels live in LDS as two f16 planes
 //     (hi/lo split of the fp32 values, 2^-22 relative), padded rows -> conflict-free ds_read_b128;
-//   * each wave owns 32-pixel strips: B operand = x, loaded straight from global into MFMA fragments
-//     (lane = pixel -> 128-B coalesced segments per channel), split to f16 hi/lo in registers;
-//     A operand = kernels from LDS; 3 x v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi) per (n-block, 16 ch);
-//   * 6-deep register ring of x fragments (5 k-steps = 10 KB in flight per wave) across strip boundaries;
-//   * output D[n][px]: lanes 0..31 store 128 contiguous bytes of one mask row.
+//   * each wave owns 64-pixel tiles = two interleaved 32-column MFMA strips (even / odd pixels): B operand = x, loaded
+//     straight from global into MFMA fragments with 8-byte buffer loads (lane = pixel pair -> 256-B coalesced segments per
+//     channel row, descriptor + SGPR row offsets, no VALU address math), split to f16 hi/lo in registers;
+//     A operand = kernels from LDS, each fragment reused for both strips; 3 x v_mfma_f32_32x32x16_f16
+//     (hi*hi + hi*lo + lo*hi) per (strip, n-block, 16 channels), the two strips' accumulators alternating;
+//   * 3-deep register ring of x fragments (2 k-steps = 8 KB in flight per wave) across tile boundaries;
+//   * output D[n][px]: 8-byte stores, lanes 0..31 write 256 contiguous bytes of one mask row.
 #include "vkn_common.h"
 #include "vkn_launch.h"
+#include <stdlib.h>
 
 #define DEC_THREADS 512
 #define DEC_WAVES 8
+#define DEC_TILE 64  // pixels per wave tile: two interleaved 32-column MFMA strips (even / odd pixels)
 
-template <int NB>
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ABL (ablation, debugging only; selected by env VKN_DECODE_ABL): 0 = the real kernel, 1 = no MFMA, 2 = no x loads,
+// 3 = no output stores.  Variants 1-3 produce WRONG results by construction and exist to attribute time.
+template <int NB, int ABL>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     const float* __restrict__ x, const _Float16* __restrict__ kfh, const _Float16* __restrict__ kfl,
     const float* __restrict__ kb, float* __restrict__ out, int N, int NPT, int n0, int C, int P, int px_per_wg) {
@@ -58,84 +67,132 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
 
     const int p_begin = blockIdx.x * px_per_wg;
     const int p_end = min(P, p_begin + px_per_wg);
-    const int nstrips = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
-    const int my = (nstrips > wave) ? (nstrips - wave + DEC_WAVES - 1) / DEC_WAVES : 0;
+    const int ntile = (p_end > p_begin) ? (p_end - p_begin + DEC_TILE - 1) / DEC_TILE : 0;
+    const int my = (ntile > wave) ? (ntile - wave + DEC_WAVES - 1) / DEC_WAVES : 0;
     const int KS = C >> 4;
     const int total = my * KS;
     if (total == 0) return;
 
-    const float* xb = x + (size_t)b * C * P;
-    float* ob = out + (size_t)b * N * P;
+    // Buffer descriptors built from uniform values only: loads/stores are `buffer_* v, v_off, s[rsrc], s_off offen` with ONE
+    // per-lane VGPR offset and every row / tile offset in the SGPR operand (no per-load VALU address arithmetic).
+    // NOTE: hipcc (ROCm 7.2) miscompiles `__builtin_bit_cast(T, vec[i])` on an ext_vector ELEMENT (always yields element 0,
+    // tools/scratch/buftest.hip) — elements are copied to scalars first and converted with __uint_as_float / __float_as_uint.
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * N * P, 0, N * P * 4, 0x00020000);
 
-    f32x16 acc[NB];
-    float r0[8], r1[8], r2[8], r3[8], r4[8], r5[8];
+    f32x16 acc[2][NB];
+    u32x2 r0[8], r1[8], r2[8];
     int ld_ks = 0, ld_sl = 0, ld_cnt = 0;  // next fragment to load
     int c_ks = 0, c_sl = 0;                // next fragment to consume
 
-#define DEC_LOAD(REG)                                                                       \
-    do { /* unconditional: past the end it re-reads the last fragment (keeps vmcnt counting exact) */ \
-        int px_ = p_begin + ((wave + DEC_WAVES * ld_sl) << 5) + li;                         \
-        px_ = min(px_, P - 1);                                                              \
-        const float* p_ = xb + (size_t)((ld_ks << 4) + (g << 3)) * P + px_;                 \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) REG[e] = p_[(size_t)e * P];           \
-        const bool adv_ = (ld_cnt + 1 < total);                                             \
-        const bool wrap_ = (ld_ks + 1 == KS);                                               \
-        ld_cnt += adv_ ? 1 : 0;                                                             \
-        ld_sl += (adv_ && wrap_) ? 1 : 0;                                                   \
-        ld_ks = adv_ ? (wrap_ ? 0 : ld_ks + 1) : ld_ks;                                     \
+    // lane (g, li) of a tile at pixel p0: pixels p0 + 2*li (+1), channels ks*16 + 8*g + e.  Near the frame end the pixel pair
+    // is clamped into the row (such lanes are never stored).
+#define DEC_LOAD(REG)                                                                                            \
+    do { /* unconditional: past the end it re-reads the last fragment (keeps vmcnt counting exact) */            \
+        const int p0_ = p_begin + (wave + DEC_WAVES * ld_sl) * DEC_TILE;                                         \
+        const int voff_ = (((g << 3) * P + min(2 * li, max(P - 2 - p0_, 0))) << 2);                              \
+        const int soff_ = ((ld_ks << 4) * P + p0_) << 2;                                                         \
+        if (ABL == 2) {                                                                                          \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) REG[e] = u32x2{(unsigned)(voff_ + e), (unsigned)soff_}; \
+        } else {                                                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                        \
+                REG[e] = __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 0);            \
+        }                                                                                                        \
+        const bool adv_ = (ld_cnt + 1 < total);                                                                  \
+        const bool wrap_ = (ld_ks + 1 == KS);                                                                    \
+        ld_cnt += adv_ ? 1 : 0;                                                                                  \
+        ld_sl += (adv_ && wrap_) ? 1 : 0;                                                                        \
+        ld_ks = adv_ ? (wrap_ ? 0 : ld_ks + 1) : ld_ks;                                                          \
     } while (0)
 
-#define DEC_COMPUTE(REG)                                                                                  \
-    do {                                                                                                  \
-        if (c_ks == 0) {                                                                                  \
-            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                             \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[nb][r] = kbs[nb * 32 + vkn_cd_row(r, lane)]; \
-        }                                                                                                 \
-        half8 bh, bl;                                                                                     \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
-            _Float16 h_, l_;                                                                              \
-            vkn_split_f16(REG[e], h_, l_);                                                                \
-            bh[e] = h_;                                                                                   \
-            bl[e] = l_;                                                                                   \
-        }                                                                                                 \
-        const int cb_ = (c_ks << 4) + (g << 3);                                                           \
-        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                               \
-            const _Float16* ap_ = ldsH + (nb * 32 + li) * LDK + cb_;                                      \
-            const half8 ah = *reinterpret_cast<const half8*>(ap_);                                        \
-            const half8 al = *reinterpret_cast<const half8*>(ap_ + NB * 32 * LDK);                        \
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[nb], 0, 0, 0);                   \
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[nb], 0, 0, 0);                   \
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[nb], 0, 0, 0);                   \
-        }                                                                                                 \
-        if (++c_ks == KS) {                                                                               \
-            const int px_ = p_begin + ((wave + DEC_WAVES * c_sl) << 5) + li;                              \
-            if (px_ < p_end) {                                                                            \
-                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                       \
-                    float* o_ = ob + (size_t)(n0 + nb * 32 + 4 * g) * P + px_;                            \
-                    if (n0 + nb * 32 + 32 <= N) { /* full block: no per-row guard (uniform branch) */     \
-                        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                    \
-                            o_[(size_t)((r & 3) + 8 * (r >> 2)) * P] = acc[nb][r];                        \
-                    } else {                                                                              \
-                        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                  \
-                            const int n_ = n0 + nb * 32 + vkn_cd_row(r, lane);                            \
-                            if (n_ < N) o_[(size_t)((r & 3) + 8 * (r >> 2)) * P] = acc[nb][r];            \
-                        }                                                                                 \
-                    }                                                                                     \
-                }                                                                                         \
-            }                                                                                             \
-            c_ks = 0;                                                                                     \
-            ++c_sl;                                                                                       \
-        }                                                                                                 \
+#define DEC_COMPUTE(REG)                                                                                          \
+    do {                                                                                                          \
+        if (c_ks == 0) {                                                                                          \
+            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                     \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
+                    const float kb_ = kbs[nb * 32 + vkn_cd_row(r, lane)];                                         \
+                    acc[0][nb][r] = kb_;                                                                          \
+                    acc[1][nb][r] = kb_;                                                                          \
+                }                                                                                                 \
+        }                                                                                                         \
+        half8 bh0, bl0, bh1, bl1;                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                           \
+            _Float16 h_, l_;                                                                                      \
+            const unsigned u0_ = REG[e][0], u1_ = REG[e][1];                                                      \
+            vkn_split_f16(__uint_as_float(u0_), h_, l_);                                                                  \
+            bh0[e] = h_;                                                                                          \
+            bl0[e] = l_;                                                                                          \
+            vkn_split_f16(__uint_as_float(u1_), h_, l_);                                                                  \
+            bh1[e] = h_;                                                                                          \
+            bl1[e] = l_;                                                                                          \
+        }                                                                                                         \
+        const int cb_ = (c_ks << 4) + (g << 3);                                                                   \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                       \
+            const _Float16* ap_ = ldsH + (nb * 32 + li) * LDK + cb_;                                              \
+            const half8 ah = *reinterpret_cast<const half8*>(ap_);                                                \
+            const half8 al = *reinterpret_cast<const half8*>(ap_ + NB * 32 * LDK);                                \
+            if (ABL == 1) {                                                                                       \
+                asm volatile("" ::"v"(ah), "v"(al), "v"(bh0), "v"(bl0), "v"(bh1), "v"(bl1));                      \
+            } else { /* alternate the two accumulators so dependent MFMAs are never back to back */               \
+                acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, acc[0][nb], 0, 0, 0);                \
+                acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh1, acc[1][nb], 0, 0, 0);                \
+                acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, acc[0][nb], 0, 0, 0);                \
+                acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl1, acc[1][nb], 0, 0, 0);                \
+                acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh0, acc[0][nb], 0, 0, 0);                \
+                acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh1, acc[1][nb], 0, 0, 0);                \
+            }                                                                                                     \
+        }                                                                                                         \
+        if (++c_ks == KS) {                                                                                       \
+            const int p0_ = p_begin + (wave + DEC_WAVES * c_sl) * DEC_TILE;                                       \
+            const int px_ = p0_ + 2 * li;                                                                         \
+            const int vst_ = ((4 * g) * P + 2 * li) << 2;                                                         \
+            if (ABL != 3 || acc[0][0][0] == 12345.678f) {                                                         \
+                if (p0_ + DEC_TILE <= p_end) { /* whole tile in range (uniform): 8-byte stores, 256 B per row */  \
+                    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                           \
+                        if (n0 + nb * 32 + 32 <= N) { /* full n-block (uniform): no per-row guard */              \
+                            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
+                                const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                           \
+                                const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
+                                const u32x2 v_ = {__float_as_uint(a0_), __float_as_uint(a1_)};                    \
+                                __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * P + p0_) << 2, 0);   \
+                            }                                                                                     \
+                        } else {                                                                                  \
+                            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
+                                const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                           \
+                                const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
+                                const u32x2 v_ = {__float_as_uint(a0_), __float_as_uint(a1_)};                    \
+                                if (row_ + 4 * g < N)                                                             \
+                                    __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * P + p0_) << 2, 0); \
+                            }                                                                                     \
+                        }                                                                                         \
+                    }                                                                                             \
+                } else { /* ragged tile at the end of the range: per-pixel guards, 4-byte buffer stores */        \
+                    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                           \
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
+                            const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                               \
+                            const int so_ = (row_ * P + p0_) << 2;                                                \
+                            if (row_ + 4 * g < N) {                                                               \
+                                const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
+                                if (px_ < p_end)                                                                  \
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a0_), ors, vst_, so_, 0); \
+                                if (px_ + 1 < p_end)                                                              \
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a1_), ors, vst_ + 4, so_, 0); \
+                            }                                                                                     \
+                        }                                                                                         \
+                    }                                                                                             \
+                }                                                                                                 \
+            }                                                                                                     \
+            c_ks = 0;                                                                                             \
+            ++c_sl;                                                                                               \
+        }                                                                                                         \
     } while (0)
 
-    // 6-deep register ring: 5 fragments (40 dword loads = 10 KB per wave, 80 KB per CU) in flight behind the MFMAs
+    // 3-deep register ring: 2 fragments (16 dwordx2 loads = 8 KB per wave, 64 KB per CU) in flight behind the MFMAs
     DEC_LOAD(r0);
     DEC_LOAD(r1);
-    DEC_LOAD(r2);
-    DEC_LOAD(r3);
-    DEC_LOAD(r4);
-    for (int f = 0; f < total; f += 6) {
-        DEC_LOAD(r5);
+    for (int f = 0; f < total; f += 3) {
+        DEC_LOAD(r2);
         DEC_COMPUTE(r0);
         if (f + 1 >= total) break;
         DEC_LOAD(r0);
@@ -143,15 +200,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
         if (f + 2 >= total) break;
         DEC_LOAD(r1);
         DEC_COMPUTE(r2);
-        if (f + 3 >= total) break;
-        DEC_LOAD(r2);
-        DEC_COMPUTE(r3);
-        if (f + 4 >= total) break;
-        DEC_LOAD(r3);
-        DEC_COMPUTE(r4);
-        if (f + 5 >= total) break;
-        DEC_LOAD(r4);
-        DEC_COMPUTE(r5);
     }
 #undef DEC_LOAD
 #undef DEC_COMPUTE
@@ -193,23 +241,40 @@ static int dec_set_lds(const void* fn, size_t bytes) {
 int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B,
                       int N, int C, int P, hipStream_t stream) {
     if (B <= 0 || N <= 0 || P <= 0) return VKN_E_ARG;
-    if (C % 16 != 0 || C > 512) return VKN_E_SHAPE;
+    if (C % 16 != 0 || C > 512 || P < 2 || (P & 1)) return VKN_E_SHAPE;  // odd P: rows not 8-byte aligned (use the ref kernel)
+    if ((size_t)C * P * 4 >= ((size_t)1 << 31) || (size_t)N * P * 4 >= ((size_t)1 << 31)) return VKN_E_SHAPE;  // 32-bit buffer offsets
     const int NPT = (N + 31) / 32 * 32;
     // persistent grid: ~1 workgroup per CU over the whole batch, >= 256 px (8 strips) per workgroup
-    int wg_per_frame = 256 / B;
+    // 512 px (one 64-px tile per wave) per workgroup measured best on MI355X (tools/decode_ablation.py: 95 us vs 108 us at
+    // 1024 px, B = 8, cfg2); fewer, larger workgroups only when the batch alone already oversubscribes the chip.
+    int wg_per_frame = 2048 / B;
     if (wg_per_frame < 1) wg_per_frame = 1;
     int px_per_wg = (P + wg_per_frame - 1) / wg_per_frame;
-    px_per_wg = (px_per_wg + 255) / 256 * 256;
+    px_per_wg = (px_per_wg + 511) / 512 * 512;  // 8 waves x 64-px tiles
     const int G = (P + px_per_wg - 1) / px_per_wg;
+    (void)G;
+    const char* abl_env = getenv("VKN_DECODE_ABL");  // debugging: time-attribution variants (wrong results)
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    const char* ppw_env = getenv("VKN_DECODE_PXWG");  // debugging: override pixels per workgroup
+    if (ppw_env && atoi(ppw_env) >= 512) px_per_wg = atoi(ppw_env) / 512 * 512;
+    const int G2 = (P + px_per_wg - 1) / px_per_wg;
     for (int n0 = 0; n0 < NPT; n0 += 128) {
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
         const size_t lds = (size_t)2 * nb * 32 * (C + 8) * sizeof(_Float16) + (size_t)nb * 32 * sizeof(float);
-        dim3 grid(G, B, 1), block(DEC_THREADS);
-#define DEC_CASE(NBV)                                                                                          \
-    case NBV:                                                                                                  \
-        if (dec_set_lds((const void*)k_decode_mfma<NBV>, lds)) return VKN_E_LAUNCH;                            \
-        hipLaunchKernelGGL(k_decode_mfma<NBV>, grid, block, lds, stream, x, kfh, kfl, kb, out, N, NPT, n0, C, P, \
-                           px_per_wg);                                                                         \
+        dim3 grid(G2, B, 1), block(DEC_THREADS);
+#define DEC_LAUNCH(NBV, ABLV)                                                                                  \
+    do {                                                                                                       \
+        if (dec_set_lds((const void*)k_decode_mfma<NBV, ABLV>, lds)) return VKN_E_LAUNCH;                      \
+        hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV>), grid, block, lds, stream, x, kfh, kfl, kb, out, N, NPT, n0, C, \
+                           P, px_per_wg);                                                                      \
+    } while (0)
+#define DEC_CASE(NBV)                    \
+    case NBV:                            \
+        if (abl == 0) DEC_LAUNCH(NBV, 0); \
+        else if (NBV == 4 && abl == 1) DEC_LAUNCH(4, 1); \
+        else if (NBV == 4 && abl == 2) DEC_LAUNCH(4, 2); \
+        else if (NBV == 4 && abl == 3) DEC_LAUNCH(4, 3); \
+        else DEC_LAUNCH(NBV, 0);         \
         break;
         switch (nb) {
             DEC_CASE(1)
@@ -220,6 +285,7 @@ int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, 
                 return VKN_E_SHAPE;
         }
 #undef DEC_CASE
+#undef DEC_LAUNCH
         VKN_CHECK_LAUNCH();
     }
     return VKN_OK;
