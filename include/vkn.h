@@ -14,7 +14,8 @@
  *   - layouts: x [B][C][P] fp32 (NCHW, P = H*W); mask logits [B][N][P] fp32; kernels / object features [B][N][C] fp32
  *     (the reference's [B,N,C,1,1] with conv_kernel_size K = 1, the only value in any shipped config).
  *   - arithmetic: fp32 storage; gather / decode contract on MFMA with an f16 hi+lo operand split and fp32 accumulation
- *     (2^-22 relative operand error, requires |x| < 65504); every [N x C] GEMM is exact-fp32 MFMA.
+ *     (2^-22 relative operand error, requires |x| < 65504); the [N x C] GEMMs are exact-fp32 MFMA, or bf16 MFMA on a
+ *     three-term operand split (2^-24 relative, full fp32 range) when pre-split weights are supplied (VknStageWeights.prepared).
  *     flags & VKN_FLAG_REF_KERNELS selects plain fp32 FMA kernels for gather / decode (slow, exact; debugging).
  */
 #ifndef VKN_H
@@ -36,6 +37,7 @@ extern "C" {
 #define VKN_E_ALIGN (-5)     /* pointer not 16-byte aligned */
 
 #define VKN_FLAG_REF_KERNELS 1u /* exact-fp32 FMA gather/decode kernels instead of the MFMA ones */
+#define VKN_FLAG_EXACT_GEMM 2u  /* exact-fp32 MFMA for the [N x C] GEMMs even when pre-split weights are supplied */
 
 #define VKN_MAX_FCS 4
 
@@ -79,6 +81,12 @@ typedef struct VknStageWeights {
     /* video tracking link, previous_type == "ffn" (knet/video/kernel_update_head.py:173-190); all NULL for the image head */
     const float *pa_in_w, *pa_in_b, *pa_out_w, *pa_out_b, *pa_norm_w, *pa_norm_b; /* attention_previous(.attn), _norm */
     const float *lffn1_w, *lffn1_b, *lffn2_w, *lffn2_b, *lffn_norm_w, *lffn_norm_b; /* link_ffn, link_ffn_norm */
+    /* Optional: every Linear weight above pre-split into three bf16 terms (vkn_prepare_stage_f32 fills a caller-owned buffer of
+     * vkn_prepared_bytes).  When set (and VKN_FLAG_EXACT_GEMM is not), the [N x C] GEMMs run on bf16 MFMA with six cross
+     * products (2^-24 relative, full fp32 range) instead of exact-fp32 MFMA: ~2.7x faster, fp32-class accuracy.
+     * Must be regenerated whenever a weight changes. */
+    const void* prepared;
+    size_t prepared_bytes;
 } VknStageWeights;
 
 int vkn_version(void);
@@ -112,6 +120,12 @@ int vkn_mask_decode_planes_f32(const float* x, const void* kf_hi, const void* kf
 /* ---- `F.interpolate(mask_preds, scale_factor=S, mode='bilinear', align_corners=False)`
  *      knet/det/kernel_iter_head.py:122-130.  in [planes][H][W] -> out [planes][H*S][W*S]. */
 int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, int W, int S, void* stream);
+
+/* ---- weight preparation for the bf16x3 split-MFMA GEMMs: splits every non-NULL Linear weight of `w` (w->prepared is ignored)
+ *      into `prepared` (device buffer, >= vkn_prepared_bytes(d, w) bytes, 256-B aligned).  Afterwards set
+ *      w->prepared = prepared, w->prepared_bytes = bytes. */
+size_t vkn_prepared_bytes(const VknDims* d, const VknStageWeights* w);
+int vkn_prepare_stage_f32(const VknDims* d, const VknStageWeights* w, void* prepared, size_t bytes, void* stream);
 
 /* ---- the gated kernel update alone.  Replaces `KernelUpdator.forward(update_feature, input_feature)`
  *      knet/kernel_updator.py:56-93 (gate_sigmoid=True, gate_norm_act=False, activate_out=False — the defaults, :15-17).

@@ -153,7 +153,7 @@ def test_stage_by_stage_vs_oracle_and_reference(vkn, name):
             assert maxabs(r['object_feats_track'], g['track']) < 1e-4
 
 
-@pytest.mark.parametrize('flags', [0, 1], ids=['mfma', 'refkernels'])
+@pytest.mark.parametrize('flags', [0, 1, 2, 3], ids=['mfma', 'refkernels', 'exactgemm', 'allexact'])
 @pytest.mark.parametrize('name', ['det_tiny', 'det_odd', 'det_cfg', 'video_tiny', 'video_cfg'])
 def test_head_vs_reference_golden(vkn, name, flags):
     """The fused S-stage call (`simple_test_mask_preds[_plus_previous]`) against the REFERENCE's own outputs."""

@@ -27,6 +27,49 @@ struct StageWs {
     _Float16 *kfh, *kfl;
 };
 
+// pre-split (bf16x3) copies of the Linear weights, carved from VknStageWeights.prepared in a fixed order
+struct PrepW {
+    const void *ft, *ftT, *dyn, *inp, *ig, *ug, *fc, *attn_in, *attn_out, *ffn1, *ffn2, *cls_fc[VKN_MAX_FCS], *fc_cls,
+        *mask_fc[VKN_MAX_FCS], *fc_mask, *pa_in, *pa_out, *lffn1, *lffn2;
+};
+
+struct PrepItem {
+    const float* src;
+    int nout, k;
+    const void** dst;
+};
+
+// enumerates (weight, shape, slot) in carve order; returns the number of items
+int prep_items(const VknDims* d, const VknStageWeights* w, PrepW* p, PrepItem* it) {
+    const int C = d->C, FF = d->ff;
+    int n = 0;
+    auto add = [&](const float* src, int nout, int k, const void** dst) {
+        *dst = nullptr;
+        if (src) it[n++] = PrepItem{src, nout, k, dst};
+    };
+    add(w->ft_w, C, C, &p->ft); add(w->ft_wT, C, C, &p->ftT);
+    add(w->dyn_w, 2 * C, C, &p->dyn); add(w->inp_w, 2 * C, C, &p->inp);
+    add(w->ig_w, C, C, &p->ig); add(w->ug_w, C, C, &p->ug); add(w->fc_w, C, C, &p->fc);
+    add(w->attn_in_w, 3 * C, C, &p->attn_in); add(w->attn_out_w, C, C, &p->attn_out);
+    add(w->ffn1_w, FF, C, &p->ffn1); add(w->ffn2_w, C, FF, &p->ffn2);
+    for (int i = 0; i < VKN_MAX_FCS; ++i) add(i < d->n_cls_fcs ? w->cls_fc_w[i] : nullptr, C, C, &p->cls_fc[i]);
+    add(w->fc_cls_w, d->ncls, C, &p->fc_cls);
+    for (int i = 0; i < VKN_MAX_FCS; ++i) add(i < d->n_mask_fcs ? w->mask_fc_w[i] : nullptr, C, C, &p->mask_fc[i]);
+    add(w->fc_mask_w, C, C, &p->fc_mask);
+    add(w->pa_in_w, 3 * C, C, &p->pa_in); add(w->pa_out_w, C, C, &p->pa_out);
+    add(w->lffn1_w, FF, C, &p->lffn1); add(w->lffn2_w, C, FF, &p->lffn2);
+    return n;
+}
+
+// assigns slots inside `base` (may be null: size query); returns total bytes
+size_t carve_prepared(const VknDims* d, const VknStageWeights* w, char* base, PrepW* p, PrepItem* it, int* n_out) {
+    const int n = prep_items(d, w, p, it);
+    Carver c{base, 0};
+    for (int i = 0; i < n; ++i) *it[i].dst = c.take<uint16_t>((size_t)it[i].nout * it[i].k * 3);
+    if (n_out) *n_out = n;
+    return (c.off + 255) & ~(size_t)255;
+}
+
 int ffn_ksplit(int M, int K) {
     const int rt = (M + 31) / 32, ktiles = K / 32;
     int ks = 256 / (rt > 0 ? rt : 1);
@@ -94,66 +137,69 @@ VknEpi mk_epi(const VknDims* d) {
     } while (0)
 
 // FFN: out = LN(in + W2 relu(W1 in + b1) + b2)        (mmcv FFN + following LayerNorm)
-int run_ffn(const VknDims* d, const StageWs& s, const float* in, const float* w1, const float* b1, const float* w2,
-            const float* b2, const float* nw, const float* nb, float* out, hipStream_t st) {
+int run_ffn(const VknDims* d, const StageWs& s, const float* in, const float* w1, const void* w1s, const float* b1,
+            const float* w2, const void* w2s, const float* b2, const float* nw, const float* nb, float* out, hipStream_t st) {
     const int M = d->B * d->N, C = d->C, FF = d->ff;
     VknEpi e = mk_epi(d);
     e.bias = b1; e.act = 1; e.out = s.h; e.ldo = FF;
-    VKN_TRY(vkn_launch_gemm(in, nullptr, C, w1, M, C, FF, 1, nullptr, e, st));
+    VKN_TRY(vkn_launch_gemm(in, nullptr, C, w1, w1s, M, C, FF, 1, nullptr, e, st));
     e = mk_epi(d);
     e.bias = b2; e.resid = in; e.ldr = C; e.ln_w = nw; e.ln_b = nb; e.out = out; e.ldo = C;
-    return vkn_launch_gemm(s.h, nullptr, FF, w2, M, FF, C, ffn_ksplit(M, FF), s.partial, e, st);
+    return vkn_launch_gemm(s.h, nullptr, FF, w2, w2s, M, FF, C, ffn_ksplit(M, FF), s.partial, e, st);
 }
 
 // attention block: out = LN(identity + out_proj(softmax(q k^T / sqrt(hd)) v)); q from `qsrc`, k/v from `kvsrc`
 int run_attention(const VknDims* d, const StageWs& s, const float* qsrc, const float* kvsrc, int heads, const float* in_w,
-                  const float* in_b, const float* out_w, const float* out_b, const float* nw, const float* nb, float* out,
-                  hipStream_t st) {
+                  const void* in_ws, const float* in_b, const float* out_w, const void* out_ws, const float* out_b,
+                  const float* nw, const float* nb, float* out, hipStream_t st) {
     const int M = d->B * d->N, C = d->C, hd = C / heads;
     VknEpi e = mk_epi(d);
     if (qsrc == kvsrc) {  // self-attention: one packed in_proj GEMM
         e.bias = in_b; e.out = s.qkv; e.ldo = 3 * C;
-        VKN_TRY(vkn_launch_gemm(qsrc, nullptr, C, in_w, M, C, 3 * C, 1, nullptr, e, st));
+        VKN_TRY(vkn_launch_gemm(qsrc, nullptr, C, in_w, in_ws, M, C, 3 * C, 1, nullptr, e, st));
         VKN_TRY(vkn_launch_attn(s.qkv, 3 * C, s.qkv + C, s.qkv + 2 * C, 3 * C, s.ao, C, d->B, d->N, d->N, heads, hd, st));
     } else {
         e.bias = in_b; e.out = s.lq; e.ldo = C;
-        VKN_TRY(vkn_launch_gemm(qsrc, nullptr, C, in_w, M, C, C, 1, nullptr, e, st));
+        VKN_TRY(vkn_launch_gemm(qsrc, nullptr, C, in_w, in_ws, M, C, C, 1, nullptr, e, st));
         e = mk_epi(d);
         e.bias = in_b + C; e.out = s.lkv; e.ldo = 2 * C;
-        VKN_TRY(vkn_launch_gemm(kvsrc, nullptr, C, in_w + (size_t)C * C, M, C, 2 * C, 1, nullptr, e, st));
+        // rows C..3C of the packed in_proj: the split layout is row-major too (3*C bf16 per row)
+        const void* kv_ws = in_ws ? static_cast<const void*>(static_cast<const uint16_t*>(in_ws) + (size_t)C * C * 3) : nullptr;
+        VKN_TRY(vkn_launch_gemm(kvsrc, nullptr, C, in_w + (size_t)C * C, kv_ws, M, C, 2 * C, 1, nullptr, e, st));
         VKN_TRY(vkn_launch_attn(s.lq, C, s.lkv, s.lkv + C, 2 * C, s.ao, C, d->B, d->N, d->N, heads, hd, st));
     }
     e = mk_epi(d);
     e.bias = out_b; e.resid = qsrc; e.ldr = C; e.ln_w = nw; e.ln_b = nb; e.out = out; e.ldo = C;
-    return vkn_launch_gemm(s.ao, nullptr, C, out_w, M, C, C, 1, nullptr, e, st);
+    return vkn_launch_gemm(s.ao, nullptr, C, out_w, out_ws, M, C, C, 1, nullptr, e, st);
 }
 
 // KernelUpdator.forward                                        knet/kernel_updator.py:56-93
-int run_updator(const VknDims* d, const VknStageWeights* w, const float* xfeat, const float* obj_in, float* out,
-                const StageWs& s, hipStream_t st) {
+int run_updator(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* xfeat, const float* obj_in,
+                float* out, const StageWs& s, hipStream_t st) {
     const int C = d->C, M = d->B * d->N;
     VknEpi e = mk_epi(d); e.bias = w->dyn_b; e.out = s.params; e.ldo = 2 * C;
-    VKN_TRY(vkn_launch_gemm(xfeat, nullptr, C, w->dyn_w, M, C, 2 * C, 1, nullptr, e, st));          // :59
+    VKN_TRY(vkn_launch_gemm(xfeat, nullptr, C, w->dyn_w, pw.dyn, M, C, 2 * C, 1, nullptr, e, st));          // :59
     e = mk_epi(d); e.bias = w->inp_b; e.out = s.inputf; e.ldo = 2 * C;
-    VKN_TRY(vkn_launch_gemm(obj_in, nullptr, C, w->inp_w, M, C, 2 * C, 1, nullptr, e, st));        // :65-66
+    VKN_TRY(vkn_launch_gemm(obj_in, nullptr, C, w->inp_w, pw.inp, M, C, 2 * C, 1, nullptr, e, st));        // :65-66
     // gate = input_in * param_in (:70) as the GEMM's A prologue; gates = sigmoid(LN(linear(gate)))  (:74-78)
     e = mk_epi(d); e.bias = w->ig_b; e.ln_w = w->inorm_in_w; e.ln_b = w->inorm_in_b; e.act = 2; e.out = s.ig; e.ldo = C;
-    VKN_TRY(vkn_launch_gemm(s.inputf, s.params, 2 * C, w->ig_w, M, C, C, 1, nullptr, e, st));
+    VKN_TRY(vkn_launch_gemm(s.inputf, s.params, 2 * C, w->ig_w, pw.ig, M, C, C, 1, nullptr, e, st));
     e = mk_epi(d); e.bias = w->ug_b; e.ln_w = w->norm_in_w; e.ln_b = w->norm_in_b; e.act = 2; e.out = s.ug; e.ldo = C;
-    VKN_TRY(vkn_launch_gemm(s.inputf, s.params, 2 * C, w->ug_w, M, C, C, 1, nullptr, e, st));
+    VKN_TRY(vkn_launch_gemm(s.inputf, s.params, 2 * C, w->ug_w, pw.ug, M, C, C, 1, nullptr, e, st));
     VKN_TRY(vkn_launch_ku_mix(s.params, s.inputf, s.ig, s.ug, w->norm_out_w, w->norm_out_b, w->inorm_out_w, w->inorm_out_b,
                               d->ln_eps, s.f, M, C, st));                                          // :79-88
     e = mk_epi(d); e.bias = w->fc_b; e.ln_w = w->fc_norm_w; e.ln_b = w->fc_norm_b; e.act = 1; e.out = out; e.ldo = C;
-    return vkn_launch_gemm(s.f, nullptr, C, w->fc_w, M, C, C, 1, nullptr, e, st);                  // :90-92
+    return vkn_launch_gemm(s.f, nullptr, C, w->fc_w, pw.fc, M, C, C, 1, nullptr, e, st);           // :90-92
 }
 
 // video tracking link, previous_type == "ffn"                 knet/video/kernel_update_head.py:394-415
-int run_link(const VknDims* d, const VknStageWeights* w, const float* cur, const float* prev, float* track_out,
-             const StageWs& s, hipStream_t st) {
+int run_link(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* cur, const float* prev,
+             float* track_out, const StageWs& s, hipStream_t st) {
     if (!w->pa_in_w || !w->lffn1_w) return VKN_E_ARG;
-    VKN_TRY(run_attention(d, s, cur, prev, 8, w->pa_in_w, w->pa_in_b, w->pa_out_w, w->pa_out_b, w->pa_norm_w, w->pa_norm_b,
-                          s.t1, st));                                             // _num_head = 8 (:165)
-    return run_ffn(d, s, s.t1, w->lffn1_w, w->lffn1_b, w->lffn2_w, w->lffn2_b, w->lffn_norm_w, w->lffn_norm_b, track_out, st);
+    VKN_TRY(run_attention(d, s, cur, prev, 8, w->pa_in_w, pw.pa_in, w->pa_in_b, w->pa_out_w, pw.pa_out, w->pa_out_b,
+                          w->pa_norm_w, w->pa_norm_b, s.t1, st));                                             // _num_head = 8 (:165)
+    return run_ffn(d, s, s.t1, w->lffn1_w, pw.lffn1, w->lffn1_b, w->lffn2_w, pw.lffn2, w->lffn2_b, w->lffn_norm_w,
+                   w->lffn_norm_b, track_out, st);
 }
 
 int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in, const float* masks_in,
@@ -163,6 +209,12 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     const bool ref = (flags & VKN_FLAG_REF_KERNELS) != 0;
     const bool ref_decode = ref || (P & 1);  // odd H*W: mask rows are not 8-byte aligned -> exact-fp32 FMA decode kernel
     const bool has_ft = w->ft_w != nullptr;
+    PrepW pw{};
+    if (w->prepared && !(flags & VKN_FLAG_EXACT_GEMM)) {
+        PrepItem items[40];
+        if (carve_prepared(d, w, static_cast<char*>(const_cast<void*>(w->prepared)), &pw, items, nullptr) > w->prepared_bytes)
+            return VKN_E_WORKSPACE;
+    }
 
     // (i) mask gather                                        knet/det/kernel_update_head.py:190-195
     if (ref)
@@ -175,21 +227,22 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     VknEpi e = mk_epi(d);
     if (has_ft) {
         e.bias = w->ft_b; e.rowscale = s.cnt; e.out = xfeat; e.ldo = C;
-        VKN_TRY(vkn_launch_gemm(s.xraw, nullptr, C, w->ft_w, M, C, C, 1, nullptr, e, st));
+        VKN_TRY(vkn_launch_gemm(s.xraw, nullptr, C, w->ft_w, pw.ft, M, C, C, 1, nullptr, e, st));
     } else {
         if (hipMemcpyAsync(xfeat, s.xraw, (size_t)M * C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
             return VKN_E_LAUNCH;
     }
 
     // (ii-a) KernelUpdator                                    knet/kernel_updator.py:56-93
-    VKN_TRY(run_updator(d, w, xfeat, obj_in, s.obj1, s, st));
+    VKN_TRY(run_updator(d, w, pw, xfeat, obj_in, s.obj1, s, st));
 
     // (ii-b) kernel interaction: MHA + LN, FFN + LN           knet/det/kernel_update_head.py:204-215
-    VKN_TRY(run_attention(d, s, s.obj1, s.obj1, d->heads, w->attn_in_w, w->attn_in_b, w->attn_out_w, w->attn_out_b,
-                          w->attn_norm_w, w->attn_norm_b, s.obj2, st));
+    VKN_TRY(run_attention(d, s, s.obj1, s.obj1, d->heads, w->attn_in_w, pw.attn_in, w->attn_in_b, w->attn_out_w,
+                          pw.attn_out, w->attn_out_b, w->attn_norm_w, w->attn_norm_b, s.obj2, st));
     const float* obj3 = s.obj2;
     if (w->ffn1_w) {
-        VKN_TRY(run_ffn(d, s, s.obj2, w->ffn1_w, w->ffn1_b, w->ffn2_w, w->ffn2_b, w->ffn_norm_w, w->ffn_norm_b, obj_out, st));
+        VKN_TRY(run_ffn(d, s, s.obj2, w->ffn1_w, pw.ffn1, w->ffn1_b, w->ffn2_w, pw.ffn2, w->ffn2_b, w->ffn_norm_w,
+                        w->ffn_norm_b, obj_out, st));
         obj3 = obj_out;
     } else {
         if (hipMemcpyAsync(obj_out, s.obj2, (size_t)M * C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -202,24 +255,24 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     for (int i = 0; i < d->n_cls_fcs; ++i) {
         float* dst = (t == s.t1) ? s.t2 : s.t1;
         e = mk_epi(d); e.ln_w = w->cls_ln_w[i]; e.ln_b = w->cls_ln_b[i]; e.act = 1; e.out = dst; e.ldo = C;
-        VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->cls_fc_w[i], M, C, C, 1, nullptr, e, st));
+        VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->cls_fc_w[i], pw.cls_fc[i], M, C, C, 1, nullptr, e, st));
         t = dst;
     }
     e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
-    VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->fc_cls_w, M, C, d->ncls, 1, nullptr, e, st));
+    VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->fc_cls_w, pw.fc_cls, M, C, d->ncls, 1, nullptr, e, st));
 
     // mask branch                                             :218-227
     t = obj3;
     for (int i = 0; i < d->n_mask_fcs; ++i) {
         float* dst = (t == s.t1) ? s.t2 : s.t1;
         e = mk_epi(d); e.ln_w = w->mask_ln_w[i]; e.ln_b = w->mask_ln_b[i]; e.act = 1; e.out = dst; e.ldo = C;
-        VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->mask_fc_w[i], M, C, C, 1, nullptr, e, st));
+        VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->mask_fc_w[i], pw.mask_fc[i], M, C, C, 1, nullptr, e, st));
         t = dst;
     }
     // mask_feat = fc_mask(.)  (+ folded decode bias kb = mask_feat . b_ft)
     e = mk_epi(d); e.bias = w->fc_mask_b; e.out = s.maskfeat; e.ldo = C;
     if (has_ft) { e.dot_vec = w->ft_b; e.dot_out = s.kb; }
-    VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->fc_mask_w, M, C, C, 1, nullptr, e, st));
+    VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->fc_mask_w, pw.fc_mask, M, C, C, 1, nullptr, e, st));
 
     // (iii) mask decode with the folded kernels  Kf = mask_feat . W_ft   :247-260
     const float* kb = has_ft ? s.kb : nullptr;
@@ -227,21 +280,21 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         const float* kern = s.maskfeat;
         if (has_ft) {
             e = mk_epi(d); e.out = s.kern32; e.ldo = C;
-            VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, M, C, C, 1, nullptr, e, st));
+            VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, pw.ftT, M, C, C, 1, nullptr, e, st));
             kern = s.kern32;
         }
         VKN_TRY(vkn_launch_decode_ref(x, kern, kb, masks_out, B, N, C, P, st));
     } else {
         if (has_ft) {
             e = mk_epi(d); e.plane_hi = s.kfh; e.plane_lo = s.kfl; e.ldo = C; e.rows_per_frame = N; e.NPT = npt_of(N);
-            VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, M, C, C, 1, nullptr, e, st));
+            VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, pw.ftT, M, C, C, 1, nullptr, e, st));
         } else {
             VKN_TRY(vkn_launch_split_planes(s.maskfeat, s.kfh, s.kfl, B, N, C, st));
         }
         VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
     }
 
-    if (prev_obj && track_out) VKN_TRY(run_link(d, w, obj3, prev_obj, track_out, s, st));
+    if (prev_obj && track_out) VKN_TRY(run_link(d, w, pw, obj3, prev_obj, track_out, s, st));
     return VKN_OK;
 }
 
@@ -342,13 +395,40 @@ int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* 
     const size_t need = carve_stage(d, nullptr, &s);
     if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
     carve_stage(d, static_cast<char*>(ws), &s);
-    return run_link(d, w, cur_obj, prev_obj, track_out, s, static_cast<hipStream_t>(stream));
+    PrepW pw{};
+    if (w->prepared) {
+        PrepItem items[40];
+        if (carve_prepared(d, w, static_cast<char*>(const_cast<void*>(w->prepared)), &pw, items, nullptr) > w->prepared_bytes)
+            return VKN_E_WORKSPACE;
+    }
+    return run_link(d, w, pw, cur_obj, prev_obj, track_out, s, static_cast<hipStream_t>(stream));
 }
 
 int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, int W, int S, void* stream) {
     if (!in || !out || planes <= 0 || H <= 0 || W <= 0) return VKN_E_ARG;
     if (!aligned16(in) || !aligned16(out)) return VKN_E_ALIGN;
     return vkn_launch_upsample(in, out, planes, H, W, S, static_cast<hipStream_t>(stream));
+}
+
+size_t vkn_prepared_bytes(const VknDims* d, const VknStageWeights* w) {
+    if (check_dims(d) != VKN_OK || !w) return 0;
+    PrepW pw;
+    PrepItem items[40];
+    return carve_prepared(d, w, nullptr, &pw, items, nullptr);
+}
+
+int vkn_prepare_stage_f32(const VknDims* d, const VknStageWeights* w, void* prepared, size_t bytes, void* stream) {
+    VKN_TRY(check_dims(d));
+    if (!w || !prepared) return VKN_E_ARG;
+    if (!aligned16(prepared)) return VKN_E_ALIGN;
+    PrepW pw;
+    PrepItem items[40];
+    int n = 0;
+    if (carve_prepared(d, w, static_cast<char*>(prepared), &pw, items, &n) > bytes) return VKN_E_WORKSPACE;
+    for (int i = 0; i < n; ++i)
+        VKN_TRY(vkn_launch_split_w3(items[i].src, const_cast<void*>(*items[i].dst), items[i].nout, items[i].k,
+                                    static_cast<hipStream_t>(stream)));
+    return VKN_OK;
 }
 
 int vkn_kernel_updator_f32(const VknDims* d, const VknStageWeights* w, const float* update_feature,
@@ -360,7 +440,13 @@ int vkn_kernel_updator_f32(const VknDims* d, const VknStageWeights* w, const flo
     const size_t need = carve_stage(d, nullptr, &s);
     if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
     carve_stage(d, static_cast<char*>(ws), &s);
-    return run_updator(d, w, update_feature, input_feature, out, s, static_cast<hipStream_t>(stream));
+    PrepW pw{};
+    if (w->prepared) {
+        PrepItem items[40];
+        if (carve_prepared(d, w, static_cast<char*>(const_cast<void*>(w->prepared)), &pw, items, nullptr) > w->prepared_bytes)
+            return VKN_E_WORKSPACE;
+    }
+    return run_updator(d, w, pw, update_feature, input_feature, out, s, static_cast<hipStream_t>(stream));
 }
 
 size_t vkn_stage_workspace_bytes(const VknDims* d) {

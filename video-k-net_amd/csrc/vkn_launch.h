@@ -33,8 +33,9 @@ int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, 
 int vkn_launch_decode_ref(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
                           hipStream_t stream);
 int vkn_launch_split_planes(const float* kern, _Float16* kfh, _Float16* kfl, int B, int N, int C, hipStream_t stream);
-int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, int M, int K, int Nout, int ksplit,
-                    float* partial, const VknEpi& epi, hipStream_t stream);
+int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, const void* Wsplit, int M, int K, int Nout,
+                    int ksplit, float* partial, const VknEpi& epi, hipStream_t stream);
+int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream);
 int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig, const float* ug, const float* no_w,
                       const float* no_b, const float* ino_w, const float* ino_b, float eps, float* f, int M, int C,
                       hipStream_t stream);

@@ -224,6 +224,169 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16x3 split GEMM
+// Same tile geometry, epilogue and split-K protocol as k_gemm, but the contraction runs on v_mfma_f32_32x32x16_bf16 with
+// BOTH operands split into three bf16 terms (x = h + m + l exactly to 2^-24: full fp32 range, unlike f16) and the six
+// significant cross products accumulated in fp32:  h*h + h*m + m*h + m*m + h*l + l*h   (dropped terms <= 2^-24 relative).
+// 6 MFMAs per 16 k at the bf16 rate = 2.7x the fp32-MFMA rate at fp32-class accuracy.
+//   A [M][lda] fp32 is split while it is staged into LDS; W comes PRE-SPLIT (k_split_w3, once per weight update) in the
+//   layout Wp[Nout][K/32][3][32] bf16, so one (row, K-tile) is 192 contiguous bytes = 12 x 16-B pieces.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define GS_LDR 40  // bf16 per LDS row: 32 + 8 pad (80 B: conflict-free ds_read_b128)
+
+__device__ __forceinline__ void vkn_split_bf16x3(float v, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+__global__ __launch_bounds__(256) void k_split_w3(const float* __restrict__ W, __bf16* __restrict__ Wp, int Nout, int K) {
+    const int row = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        __bf16 h, m, l;
+        vkn_split_bf16x3(W[(size_t)row * K + k], h, m, l);
+        __bf16* dst = Wp + ((size_t)row * (K >> 5) + (k >> 5)) * 96 + (k & 31);
+        dst[0] = h;
+        dst[32] = m;
+        dst[64] = l;
+    }
+}
+
+__global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(const float* __restrict__ A, const float* __restrict__ A2, int lda,
+                                                           const __bf16* __restrict__ Wp, int M, int K, int Nout,
+                                                           float* __restrict__ partial, VknEpi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem_s3[];
+    __bf16* Al = reinterpret_cast<__bf16*>(smem_s3);  // [3][32][40]
+    __bf16* Wl = Al + 3 * GM_BM * GS_LDR;             // [3][256][40]; reused as the fp32 [32][260] output tile
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+    const int ksplit = gridDim.z;
+    const int ktiles = K >> 5;
+    const int kt_per = (ktiles + ksplit - 1) / ksplit;
+    const int kt_begin = blockIdx.z * kt_per;
+    const int kt_end = min(ktiles, kt_begin + kt_per);
+
+    // ---- staging roles.  A: threads 0..255 own one float4 (row = tid>>3, k = 4*(tid&7)).  W: every thread owns 6 of the
+    // 3072 16-byte pieces of the K-tile: piece idx -> (row = idx/12, plane = (idx%12)/4, q = idx%4).
+    const bool a_role = tid < 256;
+    const int ar = (tid >> 3) & 31, aq = tid & 7;
+    const size_t aoff = (size_t)min(m0 + ar, M - 1) * lda + 4 * aq;
+    const float* A2p = A2 ? A2 : A;
+    const bool mul = (A2 != nullptr);
+    size_t wsrc[6];
+    int wdst[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int idx = tid + i * GM_THREADS;
+        const int row = idx / 12, rem = idx - row * 12;
+        const int plane = rem >> 2, q = rem & 3;
+        wsrc[i] = (size_t)min(n0 + row, Nout - 1) * ktiles * 96 + plane * 32 + q * 8;
+        wdst[i] = (plane * GM_BN + row) * GS_LDR + q * 8;
+    }
+    f32x4 ra, rb;
+    bf16x8 rw[6];
+
+#define GS_FETCH(KT)                                                                                  \
+    do {                                                                                              \
+        if (a_role) {                                                                                 \
+            ra = *reinterpret_cast<const f32x4*>(A + aoff + (size_t)(KT) * 32);                       \
+            rb = *reinterpret_cast<const f32x4*>(A2p + aoff + (size_t)(KT) * 32);                     \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                 \
+            rw[i] = *reinterpret_cast<const bf16x8*>(Wp + wsrc[i] + (size_t)(KT) * 96);               \
+    } while (0)
+
+#define GS_STASH()                                                                                    \
+    do {                                                                                              \
+        if (a_role) {                                                                                 \
+            bf16x4 h_, m_, l_;                                                                        \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
+                const float v_ = mul ? ra[e] * rb[e] : ra[e];                                         \
+                __bf16 hh_, mm_, ll_;                                                                 \
+                vkn_split_bf16x3(v_, hh_, mm_, ll_);                                                  \
+                h_[e] = hh_;                                                                          \
+                m_[e] = mm_;                                                                          \
+                l_[e] = ll_;                                                                          \
+            }                                                                                         \
+            __bf16* d_ = Al + ar * GS_LDR + 4 * aq;                                                   \
+            *reinterpret_cast<bf16x4*>(d_) = h_;                                                      \
+            *reinterpret_cast<bf16x4*>(d_ + GM_BM * GS_LDR) = m_;                                     \
+            *reinterpret_cast<bf16x4*>(d_ + 2 * GM_BM * GS_LDR) = l_;                                 \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) *reinterpret_cast<bf16x8*>(Wl + wdst[i]) = rw[i]; \
+    } while (0)
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool active = (n0 + wave * 32) < Nout;
+
+    if (kt_begin < kt_end) GS_FETCH(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        GS_STASH();
+        __syncthreads();
+        if (kt + 1 < kt_end) GS_FETCH(kt + 1);
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = (ks << 4) + (g << 3);
+                const __bf16* ap = Al + li * GS_LDR + off;
+                const __bf16* bp = Wl + (wave * 32 + li) * GS_LDR + off;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + GM_BN * GS_LDR);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * GM_BN * GS_LDR);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);  // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#undef GS_FETCH
+#undef GS_STASH
+
+    if (ksplit > 1) {
+        float* pz = partial + (size_t)blockIdx.z * M * Nout;
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + vkn_cd_row(r, lane), col = n0 + wave * 32 + li;
+                if (row < M && col < Nout) pz[(size_t)row * Nout + col] = acc[r];
+            }
+        }
+        return;
+    }
+
+    float* T = reinterpret_cast<float*>(Wl);  // [32][260] fp32 = 33,280 B <= 61,440 B
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li] = active ? acc[r] : 0.f;
+    __syncthreads();
+    const int ncols = min(GM_BN, Nout - n0);
+    VknEpiCols cols;
+    vkn_epi_load_cols(epi, ncols, n0, lane, cols);
+#pragma unroll
+    for (int i = 0; i < GM_BM / 8; ++i) {
+        const int rl = wave * (GM_BM / 8) + i, row = m0 + rl;
+        if (row < M) {  // uniform
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = T[rl * GM_LDT + lane + 64 * q];
+            vkn_row_epilogue(epi, cols, row, ncols, lane, v);
+        }
+    }
+}
+
 // Row epilogue after a split-K GEMM: sums `ks` partials [ks][M][Nout] and applies the epilogue.  One wave per row, Nout <= 256.
 __global__ __launch_bounds__(256) void k_rowepi(const float* __restrict__ partial, int ks, int M, int Nout, VknEpi epi) {
     const int lane = threadIdx.x & 63;
@@ -406,20 +569,36 @@ __global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ in, 
 }
 
 // ------------------------------------------------------------------------------------------------ host launchers
-int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, int M, int K, int Nout, int ksplit,
-                    float* partial, const VknEpi& epi, hipStream_t stream) {
+int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, const void* Wsplit, int M, int K, int Nout,
+                    int ksplit, float* partial, const VknEpi& epi, hipStream_t stream) {
     if (M <= 0 || K <= 0 || Nout <= 0 || K % GM_KT != 0) return VKN_E_SHAPE;
     const bool rowwise = epi.ln_w || epi.dot_vec;  // needs the whole row in one tile
     if (rowwise && Nout > GM_BN) return VKN_E_SHAPE;
     if (ksplit < 1) ksplit = 1;
     if (ksplit > 1 && (Nout > GM_BN || !partial)) return VKN_E_SHAPE;
     dim3 grid((Nout + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, ksplit);
-    hipLaunchKernelGGL(k_gemm, grid, dim3(GM_THREADS), 0, stream, A, A2, lda, W, M, K, Nout, partial, epi);
+    if (Wsplit && (lda % 4) == 0) {  // bf16x3 split-MFMA path (pre-split weights); A rows must be 16-B aligned
+        const size_t lds = (size_t)(3 * GM_BM + 3 * GM_BN) * GS_LDR * sizeof(__bf16);
+        if (hipFuncSetAttribute((const void*)k_gemm_s3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return VKN_E_LAUNCH;
+        hipLaunchKernelGGL(k_gemm_s3, grid, dim3(GM_THREADS), lds, stream, A, A2, lda, static_cast<const __bf16*>(Wsplit), M, K,
+                           Nout, partial, epi);
+    } else {
+        hipLaunchKernelGGL(k_gemm, grid, dim3(GM_THREADS), 0, stream, A, A2, lda, W, M, K, Nout, partial, epi);
+    }
     VKN_CHECK_LAUNCH();
     if (ksplit > 1) {
         hipLaunchKernelGGL(k_rowepi, dim3((M + 3) / 4), dim3(256), 0, stream, partial, ksplit, M, Nout, epi);
         VKN_CHECK_LAUNCH();
     }
+    return VKN_OK;
+}
+
+// fp32 W [Nout][K] -> bf16x3 planes Wp [Nout][K/32][3][32]  (K % 32 == 0)
+int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream) {
+    if (Nout <= 0 || K <= 0 || K % 32 != 0) return VKN_E_SHAPE;
+    hipLaunchKernelGGL(k_split_w3, dim3(Nout), dim3(256), 0, stream, W, static_cast<__bf16*>(Wp), Nout, K);
+    VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
 

@@ -70,6 +70,7 @@ class KernelUpdator(nn.Module):
         for r0 in range(0, M, 256):
             r1 = min(M, r0 + 256)
             dims = ops.make_dims(1, r1 - r0, C, 1, 1, 8, 32, 1, 0, 0, ln_eps=self.fc_norm.eps)
+            pack.ensure_prepared(dims)
             ws = ops._workspace(L.vkn_stage_workspace_bytes(ctypes.byref(dims)), u.device)
             with torch.cuda.device(u.device):
                 _lib.check(L.vkn_kernel_updator_f32(ctypes.byref(dims), ctypes.byref(pack.w), ops._ptr(u[r0:r1]),

@@ -14,6 +14,7 @@ from . import _lib
 from ._lib import VknDims, VknStageWeights, check
 
 FLAG_REF_KERNELS = 1
+FLAG_EXACT_GEMM = 2
 
 _tls = threading.local()
 
@@ -204,6 +205,26 @@ class StagePack:
         w.lffn2_w, w.lffn2_b = P('link_ffn.layers.1.weight'), P('link_ffn.layers.1.bias')
         w.lffn_norm_w, w.lffn_norm_b = P('link_ffn_norm.weight'), P('link_ffn_norm.bias')
         self.has_link = bool(w.pa_in_w and w.lffn1_w)
+        self.device = device
+        self._prep = None
+        self._prep_key = None
+
+    def ensure_prepared(self, dims):
+        """Pre-split every Linear weight into three bf16 terms (vkn_prepare_stage_f32) once per (pack, shape): the
+        [N x C] GEMMs then run on bf16 MFMA with fp32-class accuracy instead of exact-fp32 MFMA."""
+        key = (dims.C, dims.ff, dims.ncls, dims.n_cls_fcs, dims.n_mask_fcs)
+        if self._prep is not None and self._prep_key == key:
+            return
+        L = _lib.lib()
+        self.w.prepared, self.w.prepared_bytes = None, 0
+        nb = L.vkn_prepared_bytes(ctypes.byref(dims), ctypes.byref(self.w))
+        if nb == 0:
+            return
+        buf = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(L.vkn_prepare_stage_f32(ctypes.byref(dims), ctypes.byref(self.w), _ptr(buf), nb, _stream()))
+        self._prep, self._prep_key = buf, key
+        self.w.prepared, self.w.prepared_bytes = buf.data_ptr(), nb
 
     @staticmethod
     def signature(named: dict, device):
@@ -231,6 +252,7 @@ def stage_forward(dims: VknDims, pack: StagePack, x, obj_in, masks_in, prev_obj=
         track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
     else:
         prev_obj = None
+    pack.ensure_prepared(dims)
     nb = L.vkn_stage_workspace_bytes(ctypes.byref(dims))  # 0 for unsupported dims: the call below reports the reason
     ws = _workspace(max(nb, 256), dev)
     with torch.cuda.device(dev):
@@ -249,6 +271,8 @@ def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=N
     dev = x.device
     L = _lib.lib()
     S = len(packs)
+    for p in packs:
+        p.ensure_prepared(dims)
     arr = (VknStageWeights * S)(*[p.w for p in packs])
     obj = torch.empty((B, N, C), dtype=torch.float32, device=dev)
     cls = torch.empty((B, N, dims.ncls), dtype=torch.float32, device=dev)
@@ -300,6 +324,7 @@ def track_link(dims: VknDims, pack: StagePack, cur_obj, prev_obj):
     knet/video/kernel_update_head.py:394-415.  cur_obj, prev_obj [B,N,C] -> [B,N,C]."""
     cur, prev = _req(cur_obj, 'cur_obj'), _req(prev_obj, 'prev_obj')
     L = _lib.lib()
+    pack.ensure_prepared(dims)
     out = torch.empty_like(cur)
     ws = _workspace(max(L.vkn_stage_workspace_bytes(ctypes.byref(dims)), 256), cur.device)
     with torch.cuda.device(cur.device):
