@@ -98,6 +98,9 @@ def main():
     ap.add_argument('--frames', type=int, default=8, help='frames of the clip per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='frame groups of the clip processed on separate HIP streams (the latency-bound [N x C] chain of one '
+                         'group overlaps the HBM-bound gather/decode/upsample of the other)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -125,11 +128,32 @@ def main():
     first_prev = torch.zeros(1, N, C, device=device)
     up = 1 if args.no_upsample else CFG2['up']
 
+    NS = max(1, min(args.streams, B))
+    bounds = [(B * i) // NS for i in range(NS + 1)]
+    groups = [(bounds[i], bounds[i + 1]) for i in range(NS)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(NS)] if NS > 1 else [torch.cuda.current_stream(device)]
+    gdims = [last.make_dims(b1 - b0, N, CFG2['H'], CFG2['W']) for b0, b1 in groups]
+    xs = [x[b0:b1] for b0, b1 in groups]
+    pfs = [pf[b0:b1].reshape(b1 - b0, N, C) for b0, b1 in groups]
+    mps = [mp[b0:b1] for b0, b1 in groups]
+    for p in packs:
+        p.ensure_prepared(dims)
+
     def step():
-        # all frames of this rank's block: S stages + upsample (one C-ABI call) ...
-        obj, cls, masks, scaled, _ = vkn.ops.head_forward(dims, packs, x, pf.reshape(B, N, C), mp, None, up)
-        cur = obj
-        # ... then the tracking link: prev[b] = obj[b-1]; frame 0 takes the previous rank's last frame
+        # every group of frames: S stages + upsample (one C-ABI call per group, each on its own stream) ...
+        main = torch.cuda.current_stream(device)
+        outs = []
+        for gi in range(NS):
+            st = streams[gi]
+            if NS > 1:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(vkn.ops.head_forward(gdims[gi], packs, xs[gi], pfs[gi], mps[gi], None, up))
+        if NS > 1:
+            for st in streams:
+                main.wait_stream(st)
+        cur = torch.cat([o[0] for o in outs], 0) if NS > 1 else outs[0][0]
+        # ... then the tracking link over the whole block: prev[b] = obj[b-1]; frame 0 takes the previous rank's last frame
         if world > 1:
             dist.all_gather_into_tensor(gather_buf, cur[-1].contiguous())
             p0 = gather_buf[(rank - 1) % world].unsqueeze(0)
@@ -137,7 +161,7 @@ def main():
             p0 = first_prev
         prev = torch.cat([p0, cur[:-1]], 0)
         track = vkn.ops.track_link(dims, packs[-1], cur, prev)
-        return obj, cls, masks, scaled, track
+        return outs, track
 
     def barrier():
         if world > 1:
@@ -223,7 +247,7 @@ def main():
                     config=dict(workload='cfg2 video_knet_s3_r50: VideoKernelIterHead S=3, N=100 proposals + 17 stuff = 117 '
                                          'kernels, C=256, 1024x2048 frame -> 128x256 stride-8 features, ffn tracking link, '
                                          'x4 bilinear upsample of the final logits' + (' [SKIPPED]' if args.no_upsample else ''),
-                                frames_per_gpu_per_step=B, parallelism=f'frame-sharded dp{world}',
+                                frames_per_gpu_per_step=B, streams_per_gpu=NS, parallelism=f'frame-sharded dp{world}',
                                 arithmetic='fp32 storage; gather/decode on f16 hi+lo split MFMA with fp32 accumulate; '
                                            '[N x C] GEMMs exact-fp32 MFMA; random-init weights'),
                     **extra)

@@ -127,6 +127,13 @@ int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, in
 size_t vkn_prepared_bytes(const VknDims* d, const VknStageWeights* w);
 int vkn_prepare_stage_f32(const VknDims* d, const VknStageWeights* w, void* prepared, size_t bytes, void* stream);
 
+/* ---- building block (unit tests, micro-benchmarks): out[M][Nout] = act(A[M][K] . W[Nout][K]^T + bias), act 0 none / 1 relu.
+ *      w_split = NULL: exact-fp32 MFMA; else the bf16x3 planes of W produced by vkn_split_weight_f32
+ *      (3 * Nout * K bf16, K % 32 == 0).  ksplit > 1 splits K over workgroups (needs ws >= ksplit*M*Nout*4 bytes, Nout <= 256). */
+int vkn_split_weight_f32(const float* W, void* w_split, int Nout, int K, void* stream);
+int vkn_linear_f32(const float* A, const float* W, const void* w_split, const float* bias, float* out, int M, int K, int Nout,
+                   int act, int ksplit, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- the gated kernel update alone.  Replaces `KernelUpdator.forward(update_feature, input_feature)`
  *      knet/kernel_updator.py:56-93 (gate_sigmoid=True, gate_norm_act=False, activate_out=False — the defaults, :15-17).
  *      update_feature [B][N][C] (= x_feat), input_feature [B][N][C] (= kernels, K*K = 1) -> out [B][N][C].

@@ -17,7 +17,7 @@ MAX_FCS = 4
 # every symbol include/vkn.h declares
 SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_weights', 'vkn_gather_workspace_bytes', 'vkn_mask_gather_f32',
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
-           'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
+           'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
            'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32')
 
 
@@ -132,6 +132,10 @@ def lib():
     L.vkn_prepared_bytes.argtypes = [pD, pW]
     L.vkn_prepare_stage_f32.restype = c_int
     L.vkn_prepare_stage_f32.argtypes = [pD, pW, _fp, c_size, _fp]
+    L.vkn_split_weight_f32.restype = c_int
+    L.vkn_split_weight_f32.argtypes = [_fp, _fp, c_int, c_int, _fp]
+    L.vkn_linear_f32.restype = c_int
+    L.vkn_linear_f32.argtypes = [_fp, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _fp, c_size, _fp]
     L.vkn_kernel_updator_f32.restype = c_int
     L.vkn_kernel_updator_f32.argtypes = [pD, pW, _fp, _fp, _fp, _fp, c_size, _fp]
     L.vkn_stage_workspace_bytes.restype = c_size

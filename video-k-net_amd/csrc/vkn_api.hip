@@ -177,15 +177,19 @@ int run_attention(const VknDims* d, const StageWs& s, const float* qsrc, const f
 int run_updator(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* xfeat, const float* obj_in,
                 float* out, const StageWs& s, hipStream_t st) {
     const int C = d->C, M = d->B * d->N;
+    // dynamic_layer(x_feat) and input_layer(kernels) are independent: one grouped launch                     (:59, :65-66)
+    VknGemmProb pr[2];
     VknEpi e = mk_epi(d); e.bias = w->dyn_b; e.out = s.params; e.ldo = 2 * C;
-    VKN_TRY(vkn_launch_gemm(xfeat, nullptr, C, w->dyn_w, pw.dyn, M, C, 2 * C, 1, nullptr, e, st));          // :59
+    pr[0] = VknGemmProb{xfeat, nullptr, C, w->dyn_w, pw.dyn, 2 * C, e};
     e = mk_epi(d); e.bias = w->inp_b; e.out = s.inputf; e.ldo = 2 * C;
-    VKN_TRY(vkn_launch_gemm(obj_in, nullptr, C, w->inp_w, pw.inp, M, C, 2 * C, 1, nullptr, e, st));        // :65-66
-    // gate = input_in * param_in (:70) as the GEMM's A prologue; gates = sigmoid(LN(linear(gate)))  (:74-78)
+    pr[1] = VknGemmProb{obj_in, nullptr, C, w->inp_w, pw.inp, 2 * C, e};
+    VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
+    // gate = input_in * param_in (:70) as the GEMM's A prologue; both gates = sigmoid(LN(linear(gate))) in one launch (:74-78)
     e = mk_epi(d); e.bias = w->ig_b; e.ln_w = w->inorm_in_w; e.ln_b = w->inorm_in_b; e.act = 2; e.out = s.ig; e.ldo = C;
-    VKN_TRY(vkn_launch_gemm(s.inputf, s.params, 2 * C, w->ig_w, pw.ig, M, C, C, 1, nullptr, e, st));
+    pr[0] = VknGemmProb{s.inputf, s.params, 2 * C, w->ig_w, pw.ig, C, e};
     e = mk_epi(d); e.bias = w->ug_b; e.ln_w = w->norm_in_w; e.ln_b = w->norm_in_b; e.act = 2; e.out = s.ug; e.ldo = C;
-    VKN_TRY(vkn_launch_gemm(s.inputf, s.params, 2 * C, w->ug_w, pw.ug, M, C, C, 1, nullptr, e, st));
+    pr[1] = VknGemmProb{s.inputf, s.params, 2 * C, w->ug_w, pw.ug, C, e};
+    VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
     VKN_TRY(vkn_launch_ku_mix(s.params, s.inputf, s.ig, s.ug, w->norm_out_w, w->norm_out_b, w->inorm_out_w, w->inorm_out_b,
                               d->ln_eps, s.f, M, C, st));                                          // :79-88
     e = mk_epi(d); e.bias = w->fc_b; e.ln_w = w->fc_norm_w; e.ln_b = w->fc_norm_b; e.act = 1; e.out = out; e.ldo = C;
@@ -250,29 +254,37 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         obj3 = obj_out;
     }
 
-    // cls branch                                              :217-225
-    const float* t = obj3;
-    for (int i = 0; i < d->n_cls_fcs; ++i) {
-        float* dst = (t == s.t1) ? s.t2 : s.t1;
-        e = mk_epi(d); e.ln_w = w->cls_ln_w[i]; e.ln_b = w->cls_ln_b[i]; e.act = 1; e.out = dst; e.ldo = C;
-        VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->cls_fc_w[i], pw.cls_fc[i], M, C, C, 1, nullptr, e, st));
-        t = dst;
+    // cls and mask branches (:217-227) are independent: layer i of both runs as one grouped launch, then fc_cls + fc_mask
+    // (the latter also emits the folded decode bias kb = mask_feat . b_ft).
+    const float* tc = obj3;
+    const float* tm = obj3;
+    const int nl = d->n_cls_fcs > d->n_mask_fcs ? d->n_cls_fcs : d->n_mask_fcs;
+    for (int i = 0; i < nl; ++i) {
+        VknGemmProb pr[2];
+        int np = 0;
+        if (i < d->n_cls_fcs) {
+            float* dst = (i & 1) ? s.t2 : s.t1;
+            e = mk_epi(d); e.ln_w = w->cls_ln_w[i]; e.ln_b = w->cls_ln_b[i]; e.act = 1; e.out = dst; e.ldo = C;
+            pr[np++] = VknGemmProb{tc, nullptr, C, w->cls_fc_w[i], pw.cls_fc[i], C, e};
+            tc = dst;
+        }
+        if (i < d->n_mask_fcs) {
+            float* dst = (i & 1) ? s.lq : s.kern32;   // scratch not otherwise live here
+            e = mk_epi(d); e.ln_w = w->mask_ln_w[i]; e.ln_b = w->mask_ln_b[i]; e.act = 1; e.out = dst; e.ldo = C;
+            pr[np++] = VknGemmProb{tm, nullptr, C, w->mask_fc_w[i], pw.mask_fc[i], C, e};
+            tm = dst;
+        }
+        VKN_TRY(vkn_launch_gemm_group(pr, np, M, C, 1, nullptr, st));
     }
-    e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
-    VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->fc_cls_w, pw.fc_cls, M, C, d->ncls, 1, nullptr, e, st));
-
-    // mask branch                                             :218-227
-    t = obj3;
-    for (int i = 0; i < d->n_mask_fcs; ++i) {
-        float* dst = (t == s.t1) ? s.t2 : s.t1;
-        e = mk_epi(d); e.ln_w = w->mask_ln_w[i]; e.ln_b = w->mask_ln_b[i]; e.act = 1; e.out = dst; e.ldo = C;
-        VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->mask_fc_w[i], pw.mask_fc[i], M, C, C, 1, nullptr, e, st));
-        t = dst;
+    {
+        VknGemmProb pr[2];
+        e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
+        pr[0] = VknGemmProb{tc, nullptr, C, w->fc_cls_w, pw.fc_cls, d->ncls, e};
+        e = mk_epi(d); e.bias = w->fc_mask_b; e.out = s.maskfeat; e.ldo = C;
+        if (has_ft) { e.dot_vec = w->ft_b; e.dot_out = s.kb; }
+        pr[1] = VknGemmProb{tm, nullptr, C, w->fc_mask_w, pw.fc_mask, C, e};
+        VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
     }
-    // mask_feat = fc_mask(.)  (+ folded decode bias kb = mask_feat . b_ft)
-    e = mk_epi(d); e.bias = w->fc_mask_b; e.out = s.maskfeat; e.ldo = C;
-    if (has_ft) { e.dot_vec = w->ft_b; e.dot_out = s.kb; }
-    VKN_TRY(vkn_launch_gemm(t, nullptr, C, w->fc_mask_w, pw.fc_mask, M, C, C, 1, nullptr, e, st));
 
     // (iii) mask decode with the folded kernels  Kf = mask_feat . W_ft   :247-260
     const float* kb = has_ft ? s.kb : nullptr;
@@ -429,6 +441,22 @@ int vkn_prepare_stage_f32(const VknDims* d, const VknStageWeights* w, void* prep
         VKN_TRY(vkn_launch_split_w3(items[i].src, const_cast<void*>(*items[i].dst), items[i].nout, items[i].k,
                                     static_cast<hipStream_t>(stream)));
     return VKN_OK;
+}
+
+int vkn_split_weight_f32(const float* W, void* w_split, int Nout, int K, void* stream) {
+    if (!W || !w_split) return VKN_E_ARG;
+    return vkn_launch_split_w3(W, w_split, Nout, K, static_cast<hipStream_t>(stream));
+}
+
+int vkn_linear_f32(const float* A, const float* W, const void* w_split, const float* bias, float* out, int M, int K, int Nout,
+                   int act, int ksplit, void* ws, size_t ws_bytes, void* stream) {
+    if (!A || !W || !out || M <= 0 || K <= 0 || Nout <= 0) return VKN_E_ARG;
+    if (K % 32 != 0) return VKN_E_SHAPE;
+    if (ksplit > 1 && (!ws || ws_bytes < (size_t)ksplit * M * Nout * sizeof(float))) return VKN_E_WORKSPACE;
+    VknEpi e{};
+    e.bias = bias; e.act = act; e.out = out; e.ldo = Nout; e.eps = 1e-5f;
+    return vkn_launch_gemm(A, nullptr, K, W, w_split, M, K, Nout, ksplit, static_cast<float*>(ws), e,
+                           static_cast<hipStream_t>(stream));
 }
 
 int vkn_kernel_updator_f32(const VknDims* d, const VknStageWeights* w, const float* update_feature,

@@ -23,6 +23,17 @@ struct VknEpi {
     int NPT;
 };
 
+// One GEMM problem out = epi(A (.*A2) . W^T) for vkn_launch_gemm_group
+struct VknGemmProb {
+    const float* A;
+    const float* A2;  // or null: elementwise factor of A (same lda)
+    int lda;
+    const float* W;      // fp32 [Nout][K]
+    const void* Wsplit;  // or null: bf16x3 planes of W (k_split_w3)
+    int Nout;
+    VknEpi epi;
+};
+
 int vkn_gather_groups(int B, int P);
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
                       int B, int N, int C, int P, hipStream_t stream);
@@ -35,6 +46,7 @@ int vkn_launch_decode_ref(const float* x, const float* kern, const float* kb, fl
 int vkn_launch_split_planes(const float* kern, _Float16* kfh, _Float16* kfl, int B, int N, int C, hipStream_t stream);
 int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, const void* Wsplit, int M, int K, int Nout,
                     int ksplit, float* partial, const VknEpi& epi, hipStream_t stream);
+int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int ksplit, float* partial, hipStream_t stream);
 int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream);
 int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig, const float* ug, const float* no_w,
                       const float* no_b, const float* ino_w, const float* ino_b, float eps, float* f, int M, int C,

@@ -21,6 +21,7 @@
 //   k_upsample  bilinear, align_corners=False, integer scale.
 #include "vkn_common.h"
 #include "vkn_launch.h"
+#include <stdlib.h>
 
 
 #define GM_THREADS 512
@@ -254,9 +255,18 @@ __global__ __launch_bounds__(256) void k_split_w3(const float* __restrict__ W, _
     }
 }
 
-__global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(const float* __restrict__ A, const float* __restrict__ A2, int lda,
-                                                           const __bf16* __restrict__ Wp, int M, int K, int Nout,
-                                                           float* __restrict__ partial, VknEpi epi) {
+// Up to two independent problems (same M, K) run as ONE launch, selected by blockIdx.z when ksplit == 1: the kernel-update
+// chain is a sequence of short dependent kernels, so pairing independent layers (dynamic/input layer, the two gates, the
+// cls/mask branches) removes whole launch + prologue + epilogue latencies from the critical path.
+__global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGemmProb p1, int nprob, int M, int K,
+                                                           float* __restrict__ partial, int abl) {
+    const bool second = (nprob > 1) && (blockIdx.z == 1);
+    const float* __restrict__ A = second ? p1.A : p0.A;
+    const float* __restrict__ A2 = second ? p1.A2 : p0.A2;
+    const int lda = second ? p1.lda : p0.lda;
+    const __bf16* __restrict__ Wp = static_cast<const __bf16*>(second ? p1.Wsplit : p0.Wsplit);
+    const int Nout = second ? p1.Nout : p0.Nout;
+    const VknEpi epi = second ? p1.epi : p0.epi;
     extern __shared__ __attribute__((aligned(16))) char smem_s3[];
     __bf16* Al = reinterpret_cast<__bf16*>(smem_s3);  // [3][32][40]
     __bf16* Wl = Al + 3 * GM_BM * GS_LDR;             // [3][256][40]; reused as the fp32 [32][260] output tile
@@ -265,10 +275,12 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(const float* __restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
     const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
-    const int ksplit = gridDim.z;
+    if (n0 >= Nout) return;  // grouped launch: the grid is sized for the wider problem (uniform exit before any barrier)
+    const int ksplit = (nprob > 1) ? 1 : gridDim.z;
+    const int kz = (nprob > 1) ? 0 : blockIdx.z;
     const int ktiles = K >> 5;
     const int kt_per = (ktiles + ksplit - 1) / ksplit;
-    const int kt_begin = blockIdx.z * kt_per;
+    const int kt_begin = kz * kt_per;
     const int kt_end = min(ktiles, kt_begin + kt_per);
 
     // ---- staging roles.  A: threads 0..255 own one float4 (row = tid>>3, k = 4*(tid&7)).  W: every thread owns 6 of the
@@ -288,25 +300,29 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(const float* __restri
         wsrc[i] = (size_t)min(n0 + row, Nout - 1) * ktiles * 96 + plane * 32 + q * 8;
         wdst[i] = (plane * GM_BN + row) * GS_LDR + q * 8;
     }
-    f32x4 ra, rb;
-    bf16x8 rw[6];
+    // Four register sets = four K-tiles in flight: a K-tile is only ~400 MFMA cycles of work per wave, far less than one
+    // L2/HBM round trip, so the loop is latency-bound unless several tiles' loads overlap (16.8 us -> see profiles/).
+    // Loads are unconditional on a clamped tile index (exact vmcnt counting, nothing consumed before its stash).
+    f32x4 ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3;
+    bf16x8 rw0[6], rw1[6], rw2[6], rw3[6];
 
-#define GS_FETCH(KT)                                                                                  \
+#define GS_FETCH(RA, RB, RW, KT)                                                                      \
     do {                                                                                              \
-        if (a_role) {                                                                                 \
-            ra = *reinterpret_cast<const f32x4*>(A + aoff + (size_t)(KT) * 32);                       \
-            rb = *reinterpret_cast<const f32x4*>(A2p + aoff + (size_t)(KT) * 32);                     \
-        }                                                                                             \
+        const size_t kt_ = (size_t)min((KT), kt_end - 1);                                             \
+        /* unconditional for all 512 threads (the upper half re-reads the lower half's pieces): a conditional load */ \
+        /* makes the compiler fall back to vmcnt(0) at the join and drains the whole prefetch ring every tile      */ \
+        RA = *reinterpret_cast<const f32x4*>(A + aoff + kt_ * 32);                                    \
+        RB = *reinterpret_cast<const f32x4*>(A2p + aoff + kt_ * 32);                                  \
         _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                 \
-            rw[i] = *reinterpret_cast<const bf16x8*>(Wp + wsrc[i] + (size_t)(KT) * 96);               \
+            RW[i] = *reinterpret_cast<const bf16x8*>(Wp + wsrc[i] + kt_ * 96);                        \
     } while (0)
 
-#define GS_STASH()                                                                                    \
+#define GS_STASH(RA, RB, RW)                                                                          \
     do {                                                                                              \
         if (a_role) {                                                                                 \
             bf16x4 h_, m_, l_;                                                                        \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
-                const float v_ = mul ? ra[e] * rb[e] : ra[e];                                         \
+                const float v_ = mul ? RA[e] * RB[e] : RA[e];                                         \
                 __bf16 hh_, mm_, ll_;                                                                 \
                 vkn_split_bf16x3(v_, hh_, mm_, ll_);                                                  \
                 h_[e] = hh_;                                                                          \
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(const float* __restri
             *reinterpret_cast<bf16x4*>(d_ + GM_BM * GS_LDR) = m_;                                     \
             *reinterpret_cast<bf16x4*>(d_ + 2 * GM_BM * GS_LDR) = l_;                                 \
         }                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 6; ++i) *reinterpret_cast<bf16x8*>(Wl + wdst[i]) = rw[i]; \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) *reinterpret_cast<bf16x8*>(Wl + wdst[i]) = RW[i]; \
     } while (0)
 
     f32x16 acc;
@@ -326,38 +342,60 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(const float* __restri
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool active = (n0 + wave * 32) < Nout;
 
-    if (kt_begin < kt_end) GS_FETCH(kt_begin);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        GS_STASH();
-        __syncthreads();
-        if (kt + 1 < kt_end) GS_FETCH(kt + 1);
-        if (active) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int off = (ks << 4) + (g << 3);
-                const __bf16* ap = Al + li * GS_LDR + off;
-                const __bf16* bp = Wl + (wave * 32 + li) * GS_LDR + off;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-                const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
-                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + GM_BN * GS_LDR);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * GM_BN * GS_LDR);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);  // smallest terms first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-            }
+#define GS_COMPUTE()                                                                                  \
+    do {                                                                                              \
+        if (active) {                                                                                 \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                        \
+                const int off = (ks << 4) + (g << 3);                                                 \
+                const __bf16* ap = Al + li * GS_LDR + off;                                            \
+                const __bf16* bp = Wl + (wave * 32 + li) * GS_LDR + off;                              \
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);                               \
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);              \
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);          \
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);                               \
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + GM_BN * GS_LDR);              \
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * GM_BN * GS_LDR);          \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0); /* smallest first */ \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);                  \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+
+#define GS_STEP(RA, RB, RW, KT)                           \
+    do {                                                  \
+        if (abl != 2) GS_STASH(RA, RB, RW);               \
+        if (abl != 4) __syncthreads();                    \
+        if (abl != 3) GS_FETCH(RA, RB, RW, (KT) + 4);     \
+        if (abl != 1) GS_COMPUTE();                       \
+        if (abl != 4) __syncthreads();                    \
+    } while (0)
+
+    if (kt_begin < kt_end) {
+        GS_FETCH(ra0, rb0, rw0, kt_begin);
+        GS_FETCH(ra1, rb1, rw1, kt_begin + 1);
+        GS_FETCH(ra2, rb2, rw2, kt_begin + 2);
+        GS_FETCH(ra3, rb3, rw3, kt_begin + 3);
+        for (int kt = kt_begin; kt < kt_end; kt += 4) {
+            GS_STEP(ra0, rb0, rw0, kt);
+            if (kt + 1 >= kt_end) break;
+            GS_STEP(ra1, rb1, rw1, kt + 1);
+            if (kt + 2 >= kt_end) break;
+            GS_STEP(ra2, rb2, rw2, kt + 2);
+            if (kt + 3 >= kt_end) break;
+            GS_STEP(ra3, rb3, rw3, kt + 3);
         }
-        __syncthreads();
     }
 #undef GS_FETCH
 #undef GS_STASH
+#undef GS_COMPUTE
+#undef GS_STEP
 
     if (ksplit > 1) {
-        float* pz = partial + (size_t)blockIdx.z * M * Nout;
+        float* pz = partial + (size_t)kz * M * Nout;
         if (active) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -569,29 +607,61 @@ __global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ in, 
 }
 
 // ------------------------------------------------------------------------------------------------ host launchers
-int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, const void* Wsplit, int M, int K, int Nout,
-                    int ksplit, float* partial, const VknEpi& epi, hipStream_t stream) {
-    if (M <= 0 || K <= 0 || Nout <= 0 || K % GM_KT != 0) return VKN_E_SHAPE;
-    const bool rowwise = epi.ln_w || epi.dot_vec;  // needs the whole row in one tile
-    if (rowwise && Nout > GM_BN) return VKN_E_SHAPE;
+static int gemm_check(const VknGemmProb& p, int M, int K, int ksplit, const float* partial) {
+    if (M <= 0 || K <= 0 || p.Nout <= 0 || K % GM_KT != 0) return VKN_E_SHAPE;
+    const bool rowwise = p.epi.ln_w || p.epi.dot_vec;  // needs the whole row in one tile
+    if (rowwise && p.Nout > GM_BN) return VKN_E_SHAPE;
+    if (ksplit > 1 && (p.Nout > GM_BN || !partial)) return VKN_E_SHAPE;
+    return VKN_OK;
+}
+
+static int gemm_one_exact(const VknGemmProb& p, int M, int K, int ksplit, float* partial, hipStream_t stream) {
+    dim3 grid((p.Nout + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, ksplit);
+    hipLaunchKernelGGL(k_gemm, grid, dim3(GM_THREADS), 0, stream, p.A, p.A2, p.lda, p.W, M, K, p.Nout, partial, p.epi);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+// One or two independent GEMMs (same M, K).  Split (bf16x3) path: a single launch; exact path: one launch each.
+int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int ksplit, float* partial,
+                          hipStream_t stream) {
+    if (nprob < 1 || nprob > 2) return VKN_E_ARG;
     if (ksplit < 1) ksplit = 1;
-    if (ksplit > 1 && (Nout > GM_BN || !partial)) return VKN_E_SHAPE;
-    dim3 grid((Nout + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, ksplit);
-    if (Wsplit && (lda % 4) == 0) {  // bf16x3 split-MFMA path (pre-split weights); A rows must be 16-B aligned
+    if (nprob > 1 && ksplit > 1) return VKN_E_ARG;
+    bool split = true;
+    for (int i = 0; i < nprob; ++i) {
+        const int rc = gemm_check(probs[i], M, K, ksplit, partial);
+        if (rc != VKN_OK) return rc;
+        split = split && probs[i].Wsplit && (probs[i].lda % 4) == 0;
+    }
+    if (split) {
+        static const int abl = getenv("VKN_GEMM_ABL") ? atoi(getenv("VKN_GEMM_ABL")) : 0;  // debugging: time attribution
         const size_t lds = (size_t)(3 * GM_BM + 3 * GM_BN) * GS_LDR * sizeof(__bf16);
         if (hipFuncSetAttribute((const void*)k_gemm_s3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VKN_E_LAUNCH;
-        hipLaunchKernelGGL(k_gemm_s3, grid, dim3(GM_THREADS), lds, stream, A, A2, lda, static_cast<const __bf16*>(Wsplit), M, K,
-                           Nout, partial, epi);
+        int nmax = probs[0].Nout;
+        if (nprob > 1 && probs[1].Nout > nmax) nmax = probs[1].Nout;
+        dim3 grid((nmax + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, nprob > 1 ? nprob : ksplit);
+        hipLaunchKernelGGL(k_gemm_s3, grid, dim3(GM_THREADS), lds, stream, probs[0], probs[nprob > 1 ? 1 : 0], nprob, M, K,
+                           partial, abl);
+        VKN_CHECK_LAUNCH();
     } else {
-        hipLaunchKernelGGL(k_gemm, grid, dim3(GM_THREADS), 0, stream, A, A2, lda, W, M, K, Nout, partial, epi);
+        for (int i = 0; i < nprob; ++i) {
+            const int rc = gemm_one_exact(probs[i], M, K, ksplit, partial, stream);
+            if (rc != VKN_OK) return rc;
+        }
     }
-    VKN_CHECK_LAUNCH();
     if (ksplit > 1) {
-        hipLaunchKernelGGL(k_rowepi, dim3((M + 3) / 4), dim3(256), 0, stream, partial, ksplit, M, Nout, epi);
+        hipLaunchKernelGGL(k_rowepi, dim3((M + 3) / 4), dim3(256), 0, stream, partial, ksplit, M, probs[0].Nout, probs[0].epi);
         VKN_CHECK_LAUNCH();
     }
     return VKN_OK;
+}
+
+int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, const void* Wsplit, int M, int K, int Nout,
+                    int ksplit, float* partial, const VknEpi& epi, hipStream_t stream) {
+    VknGemmProb p{A, A2, lda, W, Wsplit, Nout, epi};
+    return vkn_launch_gemm_group(&p, 1, M, K, ksplit, partial, stream);
 }
 
 // fp32 W [Nout][K] -> bf16x3 planes Wp [Nout][K/32][3][32]  (K % 32 == 0)

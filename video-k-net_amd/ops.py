@@ -39,14 +39,16 @@ def _req(t, name):
 
 
 def _workspace(nbytes, device):
-    """Grow-only per-(thread, device) scratch buffer handed to the C ABI (the library never allocates)."""
+    """Grow-only per-(thread, device, stream) scratch buffer handed to the C ABI (the library never allocates).  Keyed by the
+    current stream so that calls enqueued on different streams never share scratch memory."""
     cache = getattr(_tls, 'ws', None)
     if cache is None:
         cache = _tls.ws = {}
-    buf = cache.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        cache[device] = buf
+        cache[key] = buf
     return buf
 
 
@@ -330,4 +332,27 @@ def track_link(dims: VknDims, pack: StagePack, cur_obj, prev_obj):
     with torch.cuda.device(cur.device):
         check(L.vkn_track_link_f32(ctypes.byref(dims), ctypes.byref(pack.w), _ptr(cur), _ptr(prev), _ptr(out), _ptr(ws),
                                    ws.numel(), _stream()))
+    return out
+
+
+def split_weight(W):
+    """fp32 Linear weight [Nout, K] -> bf16x3 planes (opaque uint8 buffer of 6*Nout*K bytes) for `linear(..., w_split=...)`."""
+    W = _req(W, 'W')
+    Nout, K = W.shape
+    buf = torch.empty(6 * Nout * K, dtype=torch.uint8, device=W.device)
+    with torch.cuda.device(W.device):
+        check(_lib.lib().vkn_split_weight_f32(_ptr(W), _ptr(buf), Nout, K, _stream()))
+    return buf
+
+
+def linear(A, W, bias=None, w_split=None, act=0, ksplit=1):
+    """act(A @ W.T + bias) through the library's GEMM kernel (exact-fp32 MFMA, or bf16x3 split MFMA when `w_split` is given)."""
+    A, W = _req(A, 'A'), _req(W, 'W')
+    M, K = A.shape
+    Nout = W.shape[0]
+    out = torch.empty((M, Nout), dtype=torch.float32, device=A.device)
+    ws = _workspace(max(ksplit * M * Nout * 4, 256), A.device)
+    with torch.cuda.device(A.device):
+        check(_lib.lib().vkn_linear_f32(_ptr(A), _ptr(W), _ptr(w_split), _ptr(bias), _ptr(out), M, K, Nout, int(act), int(ksplit),
+                                        _ptr(ws), ws.numel(), _stream()))
     return out
