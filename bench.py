@@ -117,6 +117,8 @@ def main():
 
     import vkn_import
     vkn = vkn_import.load()
+    from importlib import import_module
+    vkn_dist = import_module('video_k_net_amd.dist')
     head = build_head(vkn, device)
     B = args.frames
     x, pf, mp = synth_inputs(B, device, rank)
@@ -124,7 +126,6 @@ def main():
     last = head.mask_head[-1]
     dims = last.make_dims(B, N, CFG2['H'], CFG2['W'])
     packs = [h.stage_pack(device) for h in head.mask_head]
-    gather_buf = torch.empty(world, N, C, device=device) if world > 1 else None
     first_prev = torch.zeros(1, N, C, device=device)
     up = 1 if args.no_upsample else CFG2['up']
 
@@ -154,12 +155,8 @@ def main():
                 main.wait_stream(st)
         cur = torch.cat([o[0] for o in outs], 0) if NS > 1 else outs[0][0]
         # ... then the tracking link over the whole block: prev[b] = obj[b-1]; frame 0 takes the previous rank's last frame
-        if world > 1:
-            dist.all_gather_into_tensor(gather_buf, cur[-1].contiguous())
-            p0 = gather_buf[(rank - 1) % world].unsqueeze(0)
-        else:
-            p0 = first_prev
-        prev = torch.cat([p0, cur[:-1]], 0)
+        # (one small RCCL all_gather, 120 KB per rank — the only cross-rank traffic of the clip)
+        prev = vkn_dist.previous_kernels_for_block(cur, first_previous=first_prev)
         track = vkn.ops.track_link(dims, packs[-1], cur, prev)
         return outs, track
 

@@ -1,0 +1,69 @@
+"""CPU, world_size 2 on gloo: the frame sharding + neighbour exchange of the clip path."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, T, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import vkn_import
+    vkn = vkn_import.load()
+    from importlib import import_module
+    d = import_module('video_k_net_amd.dist')
+    N, C = 5, 8
+    frames = torch.arange(T, dtype=torch.float32).reshape(T, 1, 1).expand(T, N, C) + 100.0      # kernels of frame t == 100 + t
+    b0, b1 = d.shard_bounds(T, world, rank)
+    first_prev = torch.full((1, N, C), -1.0)
+    prev = d.previous_kernels_for_block(frames[b0:b1].contiguous(), first_previous=first_prev)
+    q.put((rank, b0, b1, prev[:, 0, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+    assert vkn is not None
+
+
+def _run(T, world=2):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+def test_clip_is_sharded_contiguously_and_previous_kernels_cross_ranks():
+    out = _run(T=8)
+    covered = []
+    for rank, b0, b1, prev in out:
+        covered += list(range(b0, b1))
+        want = [(-1.0 if t == 0 else 100.0 + t - 1) for t in range(b0, b1)]          # prev of frame t = kernels of frame t-1
+        assert prev == want, (rank, prev, want)
+    assert covered == list(range(8))
+
+
+def test_uneven_and_tiny_clips():
+    out = _run(T=3)
+    assert [o[1:3] for o in out] == [(0, 1), (1, 3)]
+    assert out[1][3] == [100.0, 101.0]
+    out = _run(T=1)                      # rank 0 owns nothing, rank 1 owns frame 0 and must fall back to first_previous
+    assert out[0][1:3] == (0, 0) and out[1][1:3] == (0, 1) and out[1][3] == [-1.0]
