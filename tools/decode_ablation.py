@@ -40,11 +40,11 @@ if only:       # used under rocprofv3 --pmc: just run the kernel a few times
     torch.cuda.synchronize()
     sys.exit(0)
 
-for abl in ('0', '1', '2', '3'):
+for abl in ('0', '1', '2', '3', '4', '5', '6'):
     os.environ['VKN_DECODE_ABL'] = abl
     ms = timeit(lambda: vkn.ops.mask_decode_planes(x, hi, lo, N, kb, out))
-    print(f'ABL={abl} ({["real", "no-mfma", "no-loads", "no-stores"][int(abl)]}): {ms*1e3:8.1f} us  -> {alg/ms/1e6:7.1f} GB/s algorithmic')
-os.environ['VKN_DECODE_ABL'] = '0'
+    print(f'ABL={abl} ({["real", "no-mfma", "no-loads", "no-stores", "nt-loads", "nt-stores", "nt-both"][int(abl)]}): {ms*1e3:8.1f} us  -> {alg/ms/1e6:7.1f} GB/s algorithmic')
+os.environ.pop('VKN_DECODE_ABL')
 for ppw in (256, 512, 1024, 2048, 4096):
     os.environ['VKN_DECODE_PXWG'] = str(ppw)
     ms = timeit(lambda: vkn.ops.mask_decode_planes(x, hi, lo, N, kb, out))

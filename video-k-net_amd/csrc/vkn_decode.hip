@@ -97,7 +97,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
             _Pragma("unroll") for (int e = 0; e < 8; ++e) REG[e] = u32x2{(unsigned)(voff_ + e), (unsigned)soff_}; \
         } else {                                                                                                 \
             _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                        \
-                REG[e] = __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 0);            \
+                /* aux = 2 (nt): x is streamed once per launch; measured +9 % (92 -> 84 us, cfg2 B = 8).  ABL 4 = plain */ \
+                REG[e] = (ABL == 4)                                                                              \
+                             ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 0)       \
+                             : __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 2);      \
         }                                                                                                        \
         const bool adv_ = (ld_cnt + 1 < total);                                                                  \
         const bool wrap_ = (ld_ks + 1 == KS);                                                                    \
@@ -155,7 +158,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
                                 const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                           \
                                 const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
                                 const u32x2 v_ = {__float_as_uint(a0_), __float_as_uint(a1_)};                    \
-                                __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * P + p0_) << 2, 0);   \
+                                if (ABL == 5)                                                                     \
+                                    __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * P + p0_) << 2, 2); \
+                                else                                                                              \
+                                    __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * P + p0_) << 2, 0); \
                             }                                                                                     \
                         } else {                                                                                  \
                             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
@@ -204,6 +210,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
 #undef DEC_LOAD
 #undef DEC_COMPUTE
 }
+
+// NOTE (negative result, round 1): a software-pipelined variant that parked a finished strip's accumulators in a second
+// register set and issued its stores a few per k-step during the next strip (so loads, MFMAs and stores interleave inside
+// every wave) was built and validated, and measured SLOWER (113 us vs 94 us at cfg2, B = 8): the read and write streams
+// already share the memory system at ~4.2 TB/s combined whatever their interleaving (tools/decode_ablation.py).
 
 // Exact-fp32 debug / fallback kernel: one thread per (n, px), k-ordered fmaf chain.
 __global__ __launch_bounds__(256) void k_decode_ref(const float* __restrict__ x, const float* __restrict__ kern,
@@ -274,6 +285,8 @@ int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, 
         else if (NBV == 4 && abl == 1) DEC_LAUNCH(4, 1); \
         else if (NBV == 4 && abl == 2) DEC_LAUNCH(4, 2); \
         else if (NBV == 4 && abl == 3) DEC_LAUNCH(4, 3); \
+        else if (NBV == 4 && abl == 4) DEC_LAUNCH(4, 4); \
+        else if (NBV == 4 && abl == 5) DEC_LAUNCH(4, 5); \
         else DEC_LAUNCH(NBV, 0);         \
         break;
         switch (nb) {

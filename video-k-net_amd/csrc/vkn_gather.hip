@@ -60,7 +60,8 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idc = min(tid + i * GA_THREADS, nxch - 1);
-            xr[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2));
+            // non-temporal: x is streamed once per launch (same +9 % as in the decode kernel)
+            xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2)));
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -223,19 +224,28 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     }
 }
 
-// xraw[b][n][c] = sum_g part[b][g][n][c] (g ascending -> deterministic), cnt[b][n] likewise.
-__global__ __launch_bounds__(256) void k_gather_reduce(const float* __restrict__ part, const float* __restrict__ cntp,
+// xraw[b][n][c] = sum_g part[b][g][n][c], cnt[b][n] likewise.  Fixed summation tree (four interleaved running sums over g,
+// combined in a fixed order) -> deterministic; float4 per thread and 4 independent loads in flight per step.
+__global__ __launch_bounds__(64) void k_gather_reduce(const float* __restrict__ part, const float* __restrict__ cntp,
                                                        float* __restrict__ xraw, float* __restrict__ cnt, int N, int NPT,
                                                        int C, int G) {
     const int row = blockIdx.x;  // b*N + n
     const int b = row / N, n = row - b * N;
+    const size_t gstride = (size_t)NPT * C;
     const float* pp = part + ((size_t)b * G * NPT + n) * C;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (int gi = 0; gi < G; ++gi) s += pp[(size_t)gi * NPT * C + c];
-        xraw[(size_t)row * C + c] = s;
+    for (int c4 = threadIdx.x * 4; c4 < C; c4 += 256) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        int gi = 0;
+        for (; gi + 3 < G; gi += 4) {
+            s0 += *reinterpret_cast<const f32x4*>(pp + (size_t)(gi + 0) * gstride + c4);
+            s1 += *reinterpret_cast<const f32x4*>(pp + (size_t)(gi + 1) * gstride + c4);
+            s2 += *reinterpret_cast<const f32x4*>(pp + (size_t)(gi + 2) * gstride + c4);
+            s3 += *reinterpret_cast<const f32x4*>(pp + (size_t)(gi + 3) * gstride + c4);
+        }
+        for (; gi < G; ++gi) s0 += *reinterpret_cast<const f32x4*>(pp + (size_t)gi * gstride + c4);
+        *reinterpret_cast<f32x4*>(xraw + (size_t)row * C + c4) = (s0 + s1) + (s2 + s3);
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 63) {  // counts are small integers: any order is exact
         const float* cp = cntp + (size_t)b * G * NPT + n;
         float s = 0.f;
         for (int gi = 0; gi < G; ++gi) s += cp[(size_t)gi * NPT];
@@ -309,7 +319,7 @@ int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw
 #undef GA_CASE
         VKN_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, NPT, C, G);
+    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(64), 0, stream, part, cntp, xraw, cnt, N, NPT, C, G);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
