@@ -129,7 +129,7 @@ int vkn_prepare_stage_f32(const VknDims* d, const VknStageWeights* w, void* prep
 
 /* ---- building block (unit tests, micro-benchmarks): out[M][Nout] = act(A[M][K] . W[Nout][K]^T + bias), act 0 none / 1 relu.
  *      w_split = NULL: exact-fp32 MFMA; else the bf16x3 planes of W produced by vkn_split_weight_f32
- *      (3 * Nout * K bf16, K % 32 == 0).  ksplit > 1 splits K over workgroups (needs ws >= ksplit*M*Nout*4 bytes, Nout <= 256). */
+ *      (6 * roundup(Nout, 256) * K bytes: LDS tile images, K % 32 == 0).  ksplit > 1 splits K over workgroups (needs ws >= ksplit*M*Nout*4 bytes, Nout <= 256). */
 int vkn_split_weight_f32(const float* W, void* w_split, int Nout, int K, void* stream);
 int vkn_linear_f32(const float* A, const float* W, const void* w_split, const float* bias, float* out, int M, int K, int Nout,
                    int act, int ksplit, void* ws, size_t ws_bytes, void* stream);

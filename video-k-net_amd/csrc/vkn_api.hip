@@ -30,7 +30,7 @@ struct StageWs {
 // pre-split (bf16x3) copies of the Linear weights, carved from VknStageWeights.prepared in a fixed order
 struct PrepW {
     const void *ft, *ftT, *dyn, *inp, *ig, *ug, *fc, *attn_in, *attn_out, *ffn1, *ffn2, *cls_fc[VKN_MAX_FCS], *fc_cls,
-        *mask_fc[VKN_MAX_FCS], *fc_mask, *pa_in, *pa_out, *lffn1, *lffn2;
+        *mask_fc[VKN_MAX_FCS], *fc_mask, *pa_in, *pa_in_kv, *pa_out, *lffn1, *lffn2;
 };
 
 struct PrepItem {
@@ -56,7 +56,9 @@ int prep_items(const VknDims* d, const VknStageWeights* w, PrepW* p, PrepItem* i
     add(w->fc_cls_w, d->ncls, C, &p->fc_cls);
     for (int i = 0; i < VKN_MAX_FCS; ++i) add(i < d->n_mask_fcs ? w->mask_fc_w[i] : nullptr, C, C, &p->mask_fc[i]);
     add(w->fc_mask_w, C, C, &p->fc_mask);
-    add(w->pa_in_w, 3 * C, C, &p->pa_in); add(w->pa_out_w, C, C, &p->pa_out);
+    // cross-attention: q rows and k/v rows of the packed in_proj are separate GEMMs -> separate tile images
+    add(w->pa_in_w, C, C, &p->pa_in); add(w->pa_in_w ? w->pa_in_w + (size_t)C * C : nullptr, 2 * C, C, &p->pa_in_kv);
+    add(w->pa_out_w, C, C, &p->pa_out);
     add(w->lffn1_w, FF, C, &p->lffn1); add(w->lffn2_w, C, FF, &p->lffn2);
     return n;
 }
@@ -65,7 +67,7 @@ int prep_items(const VknDims* d, const VknStageWeights* w, PrepW* p, PrepItem* i
 size_t carve_prepared(const VknDims* d, const VknStageWeights* w, char* base, PrepW* p, PrepItem* it, int* n_out) {
     const int n = prep_items(d, w, p, it);
     Carver c{base, 0};
-    for (int i = 0; i < n; ++i) *it[i].dst = c.take<uint16_t>((size_t)it[i].nout * it[i].k * 3);
+    for (int i = 0; i < n; ++i) *it[i].dst = c.take<char>(vkn_split_w3_bytes(it[i].nout, it[i].k));
     if (n_out) *n_out = n;
     return (c.off + 255) & ~(size_t)255;
 }
@@ -150,7 +152,7 @@ int run_ffn(const VknDims* d, const StageWs& s, const float* in, const float* w1
 
 // attention block: out = LN(identity + out_proj(softmax(q k^T / sqrt(hd)) v)); q from `qsrc`, k/v from `kvsrc`
 int run_attention(const VknDims* d, const StageWs& s, const float* qsrc, const float* kvsrc, int heads, const float* in_w,
-                  const void* in_ws, const float* in_b, const float* out_w, const void* out_ws, const float* out_b,
+                  const void* in_ws, const void* in_kv_ws, const float* in_b, const float* out_w, const void* out_ws, const float* out_b,
                   const float* nw, const float* nb, float* out, hipStream_t st) {
     const int M = d->B * d->N, C = d->C, hd = C / heads;
     VknEpi e = mk_epi(d);
@@ -163,9 +165,7 @@ int run_attention(const VknDims* d, const StageWs& s, const float* qsrc, const f
         VKN_TRY(vkn_launch_gemm(qsrc, nullptr, C, in_w, in_ws, M, C, C, 1, nullptr, e, st));
         e = mk_epi(d);
         e.bias = in_b + C; e.out = s.lkv; e.ldo = 2 * C;
-        // rows C..3C of the packed in_proj: the split layout is row-major too (3*C bf16 per row)
-        const void* kv_ws = in_ws ? static_cast<const void*>(static_cast<const uint16_t*>(in_ws) + (size_t)C * C * 3) : nullptr;
-        VKN_TRY(vkn_launch_gemm(kvsrc, nullptr, C, in_w + (size_t)C * C, kv_ws, M, C, 2 * C, 1, nullptr, e, st));
+        VKN_TRY(vkn_launch_gemm(kvsrc, nullptr, C, in_w + (size_t)C * C, in_kv_ws, M, C, 2 * C, 1, nullptr, e, st));
         VKN_TRY(vkn_launch_attn(s.lq, C, s.lkv, s.lkv + C, 2 * C, s.ao, C, d->B, d->N, d->N, heads, hd, st));
     }
     e = mk_epi(d);
@@ -200,7 +200,7 @@ int run_updator(const VknDims* d, const VknStageWeights* w, const PrepW& pw, con
 int run_link(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* cur, const float* prev,
              float* track_out, const StageWs& s, hipStream_t st) {
     if (!w->pa_in_w || !w->lffn1_w) return VKN_E_ARG;
-    VKN_TRY(run_attention(d, s, cur, prev, 8, w->pa_in_w, pw.pa_in, w->pa_in_b, w->pa_out_w, pw.pa_out, w->pa_out_b,
+    VKN_TRY(run_attention(d, s, cur, prev, 8, w->pa_in_w, pw.pa_in, pw.pa_in_kv, w->pa_in_b, w->pa_out_w, pw.pa_out, w->pa_out_b,
                           w->pa_norm_w, w->pa_norm_b, s.t1, st));                                             // _num_head = 8 (:165)
     return run_ffn(d, s, s.t1, w->lffn1_w, pw.lffn1, w->lffn1_b, w->lffn2_w, pw.lffn2, w->lffn2_b, w->lffn_norm_w,
                    w->lffn_norm_b, track_out, st);
@@ -241,7 +241,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     VKN_TRY(run_updator(d, w, pw, xfeat, obj_in, s.obj1, s, st));
 
     // (ii-b) kernel interaction: MHA + LN, FFN + LN           knet/det/kernel_update_head.py:204-215
-    VKN_TRY(run_attention(d, s, s.obj1, s.obj1, d->heads, w->attn_in_w, pw.attn_in, w->attn_in_b, w->attn_out_w,
+    VKN_TRY(run_attention(d, s, s.obj1, s.obj1, d->heads, w->attn_in_w, pw.attn_in, nullptr, w->attn_in_b, w->attn_out_w,
                           pw.attn_out, w->attn_out_b, w->attn_norm_w, w->attn_norm_b, s.obj2, st));
     const float* obj3 = s.obj2;
     if (w->ffn1_w) {

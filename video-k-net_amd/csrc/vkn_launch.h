@@ -47,6 +47,7 @@ int vkn_launch_split_planes(const float* kern, _Float16* kfh, _Float16* kfl, int
 int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, const void* Wsplit, int M, int K, int Nout,
                     int ksplit, float* partial, const VknEpi& epi, hipStream_t stream);
 int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int ksplit, float* partial, hipStream_t stream);
+size_t vkn_split_w3_bytes(int Nout, int K);
 int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream);
 int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig, const float* ug, const float* no_w,
                       const float* no_b, const float* ino_w, const float* ino_b, float eps, float* f, int M, int C,

@@ -230,11 +230,21 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm(const float* __restrict_
 // BOTH operands split into three bf16 terms (x = h + m + l exactly to 2^-24: full fp32 range, unlike f16) and the six
 // significant cross products accumulated in fp32:  h*h + h*m + m*h + m*m + h*l + l*h   (dropped terms <= 2^-24 relative).
 // 6 MFMAs per 16 k at the bf16 rate = 2.7x the fp32-MFMA rate at fp32-class accuracy.
-//   A [M][lda] fp32 is split while it is staged into LDS; W comes PRE-SPLIT (k_split_w3, once per weight update) in the
-//   layout Wp[Nout][K/32][3][32] bf16, so one (row, K-tile) is 192 contiguous bytes = 12 x 16-B pieces.
+//
+// The kernel-update chain is a sequence of short dependent kernels on M ~ 10^3 rows, so what matters is the serial latency of
+// one launch.  tools/gemm_trace.sh showed the per-K-tile phases {L1 fill of the 48 KB weight tile, LDS write, LDS read + MFMA,
+// two barriers} each cost 0.3-0.5 us and serialised (1.2 us per K-tile).  This version overlaps them:
+//   * weights are PRE-SPLIT (k_split_w3, once per weight update) into the exact LDS image of a (256-column, 32-k) tile —
+//     Wp[col tile][k tile][plane 3][q 4][row 256][8 bf16], 48 KB contiguous — and stream global -> LDS with
+//     `global_load_lds_dwordx4` (no VGPR round trip, no ds_write); a fragment read (fixed plane/q, 32 consecutive rows) is
+//     32 consecutive 16-B slots: conflict-free;
+//   * A [M][lda] fp32 is split in registers while it is staged (4 KB per tile);
+//   * LDS is double-buffered: the DMA + A loads of tile t+1 are issued before the MFMAs of tile t; ONE barrier per tile.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-#define GS_LDR 40  // bf16 per LDS row: 32 + 8 pad (80 B: conflict-free ds_read_b128)
+#define GS_LDR 40                   // bf16 per LDS row of the A image: 32 + 8 pad (80 B: conflict-free ds_read_b128)
+#define GS_WTILE (3 * 4 * 256 * 8)  // bf16 elements of one weight tile image (48 KB)
+#define GS_ATILE (3 * GM_BM * GS_LDR)
 
 __device__ __forceinline__ void vkn_split_bf16x3(float v, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)v;
@@ -243,23 +253,26 @@ __device__ __forceinline__ void vkn_split_bf16x3(float v, __bf16& h, __bf16& m, 
     l = (__bf16)(r1 - (float)m);
 }
 
+// fp32 W [Nout][K] -> tile images Wp[ceil(Nout/256)][K/32][3][4][256][8] (rows >= Nout zero).  grid = (K/32, ceil(Nout/256)).
 __global__ __launch_bounds__(256) void k_split_w3(const float* __restrict__ W, __bf16* __restrict__ Wp, int Nout, int K) {
-    const int row = blockIdx.x;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        __bf16 h, m, l;
-        vkn_split_bf16x3(W[(size_t)row * K + k], h, m, l);
-        __bf16* dst = Wp + ((size_t)row * (K >> 5) + (k >> 5)) * 96 + (k & 31);
-        dst[0] = h;
-        dst[32] = m;
-        dst[64] = l;
+    const int kt = blockIdx.x, nt = blockIdx.y;
+    __bf16* dst = Wp + ((size_t)nt * gridDim.x + kt) * GS_WTILE;
+    const int row = threadIdx.x, n = nt * 256 + row;
+    for (int k = 0; k < 32; ++k) {
+        __bf16 h = (__bf16)0.f, m = (__bf16)0.f, l = (__bf16)0.f;
+        if (n < Nout) vkn_split_bf16x3(W[(size_t)n * K + kt * 32 + k], h, m, l);
+        const int q = k >> 3, e = k & 7;
+        dst[((0 * 4 + q) * 256 + row) * 8 + e] = h;
+        dst[((1 * 4 + q) * 256 + row) * 8 + e] = m;
+        dst[((2 * 4 + q) * 256 + row) * 8 + e] = l;
     }
 }
 
-// Up to two independent problems (same M, K) run as ONE launch, selected by blockIdx.z when ksplit == 1: the kernel-update
-// chain is a sequence of short dependent kernels, so pairing independent layers (dynamic/input layer, the two gates, the
-// cls/mask branches) removes whole launch + prologue + epilogue latencies from the critical path.
+// Up to two independent problems (same M, K) run as ONE launch, selected by blockIdx.z when ksplit == 1: pairing independent
+// layers (dynamic/input layer, the two gates, the cls/mask branches) removes whole launch + prologue + epilogue latencies
+// from the critical path of the chain.
 __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGemmProb p1, int nprob, int M, int K,
-                                                           float* __restrict__ partial, int abl) {
+                                                           float* __restrict__ partial) {
     const bool second = (nprob > 1) && (blockIdx.z == 1);
     const float* __restrict__ A = second ? p1.A : p0.A;
     const float* __restrict__ A2 = second ? p1.A2 : p0.A2;
@@ -268,8 +281,8 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     const int Nout = second ? p1.Nout : p0.Nout;
     const VknEpi epi = second ? p1.epi : p0.epi;
     extern __shared__ __attribute__((aligned(16))) char smem_s3[];
-    __bf16* Al = reinterpret_cast<__bf16*>(smem_s3);  // [3][32][40]
-    __bf16* Wl = Al + 3 * GM_BM * GS_LDR;             // [3][256][40]; reused as the fp32 [32][260] output tile
+    __bf16* Wl = reinterpret_cast<__bf16*>(smem_s3);  // [2][GS_WTILE]; buffer 0 is reused as the fp32 [32][260] output tile
+    __bf16* Al = Wl + 2 * GS_WTILE;                   // [2][3][32][40]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,58 +296,50 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     const int kt_begin = kz * kt_per;
     const int kt_end = min(ktiles, kt_begin + kt_per);
 
-    // ---- staging roles.  A: threads 0..255 own one float4 (row = tid>>3, k = 4*(tid&7)).  W: every thread owns 6 of the
-    // 3072 16-byte pieces of the K-tile: piece idx -> (row = idx/12, plane = (idx%12)/4, q = idx%4).
+    // A staging role: thread -> one float4 (row = (tid>>3)&31, k = 4*(tid&7)); the upper 256 threads duplicate the loads of
+    // the lower 256 (unconditional loads keep the compiler's vmcnt accounting exact) and only the lower half writes LDS.
     const bool a_role = tid < 256;
     const int ar = (tid >> 3) & 31, aq = tid & 7;
     const size_t aoff = (size_t)min(m0 + ar, M - 1) * lda + 4 * aq;
     const float* A2p = A2 ? A2 : A;
     const bool mul = (A2 != nullptr);
-    size_t wsrc[6];
-    int wdst[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int idx = tid + i * GM_THREADS;
-        const int row = idx / 12, rem = idx - row * 12;
-        const int plane = rem >> 2, q = rem & 3;
-        wsrc[i] = (size_t)min(n0 + row, Nout - 1) * ktiles * 96 + plane * 32 + q * 8;
-        wdst[i] = (plane * GM_BN + row) * GS_LDR + q * 8;
-    }
-    // Four register sets = four K-tiles in flight: a K-tile is only ~400 MFMA cycles of work per wave, far less than one
-    // L2/HBM round trip, so the loop is latency-bound unless several tiles' loads overlap (16.8 us -> see profiles/).
-    // Loads are unconditional on a clamped tile index (exact vmcnt counting, nothing consumed before its stash).
-    f32x4 ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3;
-    bf16x8 rw0[6], rw1[6], rw2[6], rw3[6];
+    const __bf16* wtile0 = Wp + (size_t)blockIdx.x * ktiles * GS_WTILE;  // this column tile's images, K-tile major
+    f32x4 ra, rb;
 
-#define GS_FETCH(RA, RB, RW, KT)                                                                      \
-    do {                                                                                              \
-        const size_t kt_ = (size_t)min((KT), kt_end - 1);                                             \
-        /* unconditional for all 512 threads (the upper half re-reads the lower half's pieces): a conditional load */ \
-        /* makes the compiler fall back to vmcnt(0) at the join and drains the whole prefetch ring every tile      */ \
-        RA = *reinterpret_cast<const f32x4*>(A + aoff + kt_ * 32);                                    \
-        RB = *reinterpret_cast<const f32x4*>(A2p + aoff + kt_ * 32);                                  \
-        _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                 \
-            RW[i] = *reinterpret_cast<const bf16x8*>(Wp + wsrc[i] + kt_ * 96);                        \
+    // weight tile KT -> LDS buffer BUF: 3072 x 16 B, 6 DMA instructions per thread; piece index = i*512 + tid, so every
+    // wave writes 64 consecutive slots (the DMA's LDS address is wave base + lane*16) from 1 KB of contiguous global memory
+#define GS_DMA(KT, BUF)                                                                                               \
+    do {                                                                                                              \
+        const char* gsrc_ = reinterpret_cast<const char*>(wtile0 + (size_t)(KT) * GS_WTILE) + (size_t)tid * 16;       \
+        char* ldst_ = reinterpret_cast<char*>(Wl + (size_t)(BUF) * GS_WTILE) + (size_t)wave * 1024;                   \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                                 \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_ + i * 8192),       \
+                                             (__attribute__((address_space(3))) void*)(ldst_ + i * 8192), 16, 0, 0);  \
     } while (0)
 
-#define GS_STASH(RA, RB, RW)                                                                          \
+#define GS_AFETCH(KT)                                                              \
+    do {                                                                           \
+        ra = *reinterpret_cast<const f32x4*>(A + aoff + (size_t)(KT) * 32);        \
+        rb = *reinterpret_cast<const f32x4*>(A2p + aoff + (size_t)(KT) * 32);      \
+    } while (0)
+
+#define GS_ASTASH(BUF)                                                                                \
     do {                                                                                              \
         if (a_role) {                                                                                 \
             bf16x4 h_, m_, l_;                                                                        \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
-                const float v_ = mul ? RA[e] * RB[e] : RA[e];                                         \
+                const float v_ = mul ? ra[e] * rb[e] : ra[e];                                         \
                 __bf16 hh_, mm_, ll_;                                                                 \
                 vkn_split_bf16x3(v_, hh_, mm_, ll_);                                                  \
                 h_[e] = hh_;                                                                          \
                 m_[e] = mm_;                                                                          \
                 l_[e] = ll_;                                                                          \
             }                                                                                         \
-            __bf16* d_ = Al + ar * GS_LDR + 4 * aq;                                                   \
+            __bf16* d_ = Al + (size_t)(BUF) * GS_ATILE + ar * GS_LDR + 4 * aq;                        \
             *reinterpret_cast<bf16x4*>(d_) = h_;                                                      \
             *reinterpret_cast<bf16x4*>(d_ + GM_BM * GS_LDR) = m_;                                     \
             *reinterpret_cast<bf16x4*>(d_ + 2 * GM_BM * GS_LDR) = l_;                                 \
         }                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 6; ++i) *reinterpret_cast<bf16x8*>(Wl + wdst[i]) = RW[i]; \
     } while (0)
 
     f32x16 acc;
@@ -342,57 +347,46 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool active = (n0 + wave * 32) < Nout;
 
-#define GS_COMPUTE()                                                                                  \
-    do {                                                                                              \
-        if (active) {                                                                                 \
-            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                        \
-                const int off = (ks << 4) + (g << 3);                                                 \
-                const __bf16* ap = Al + li * GS_LDR + off;                                            \
-                const __bf16* bp = Wl + (wave * 32 + li) * GS_LDR + off;                              \
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);                               \
-                const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);              \
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);          \
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);                               \
-                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + GM_BN * GS_LDR);              \
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * GM_BN * GS_LDR);          \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0); /* smallest first */ \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);                  \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);                  \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);                  \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);                  \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);                  \
-            }                                                                                         \
-        }                                                                                             \
-    } while (0)
-
-#define GS_STEP(RA, RB, RW, KT)                           \
-    do {                                                  \
-        if (abl != 2) GS_STASH(RA, RB, RW);               \
-        if (abl != 4) __syncthreads();                    \
-        if (abl != 3) GS_FETCH(RA, RB, RW, (KT) + 4);     \
-        if (abl != 1) GS_COMPUTE();                       \
-        if (abl != 4) __syncthreads();                    \
-    } while (0)
-
     if (kt_begin < kt_end) {
-        GS_FETCH(ra0, rb0, rw0, kt_begin);
-        GS_FETCH(ra1, rb1, rw1, kt_begin + 1);
-        GS_FETCH(ra2, rb2, rw2, kt_begin + 2);
-        GS_FETCH(ra3, rb3, rw3, kt_begin + 3);
-        for (int kt = kt_begin; kt < kt_end; kt += 4) {
-            GS_STEP(ra0, rb0, rw0, kt);
-            if (kt + 1 >= kt_end) break;
-            GS_STEP(ra1, rb1, rw1, kt + 1);
-            if (kt + 2 >= kt_end) break;
-            GS_STEP(ra2, rb2, rw2, kt + 2);
-            if (kt + 3 >= kt_end) break;
-            GS_STEP(ra3, rb3, rw3, kt + 3);
+        GS_DMA(kt_begin, 0);
+        GS_AFETCH(kt_begin);
+        GS_ASTASH(0);
+        __syncthreads();  // (the compiler waits vmcnt(0) for the in-flight DMA before the barrier)
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int cur = (kt - kt_begin) & 1;
+            const bool more = (kt + 1 < kt_end);  // uniform
+            if (more) {
+                GS_DMA(kt + 1, cur ^ 1);
+                GS_AFETCH(kt + 1);
+            }
+            if (active) {
+                const __bf16* Ab = Al + (size_t)cur * GS_ATILE;
+                const __bf16* Wb = Wl + (size_t)cur * GS_WTILE;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const __bf16* ap = Ab + li * GS_LDR + (ks << 4) + (g << 3);
+                    const __bf16* bp = Wb + (((ks << 1) + g) * 256 + wave * 32 + li) * 8;  // plane 0, q = 2*ks + g
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
+                    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + 4 * 256 * 8);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 8 * 256 * 8);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);  // smallest terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                }
+            }
+            if (more) GS_ASTASH(cur ^ 1);
+            __syncthreads();  // tile kt+1 landed (DMA + A image) and every wave is done reading tile kt
         }
     }
-#undef GS_FETCH
-#undef GS_STASH
-#undef GS_COMPUTE
-#undef GS_STEP
+#undef GS_DMA
+#undef GS_AFETCH
+#undef GS_ASTASH
 
     if (ksplit > 1) {
         float* pz = partial + (size_t)kz * M * Nout;
@@ -406,7 +400,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
         return;
     }
 
-    float* T = reinterpret_cast<float*>(Wl);  // [32][260] fp32 = 33,280 B <= 61,440 B
+    float* T = reinterpret_cast<float*>(Wl);  // [32][260] fp32 = 33,280 B <= 49,152 B (weight buffer 0; all reads are done)
 #pragma unroll
     for (int r = 0; r < 16; ++r) T[vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li] = active ? acc[r] : 0.f;
     __syncthreads();
@@ -635,15 +629,14 @@ int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int
         split = split && probs[i].Wsplit && (probs[i].lda % 4) == 0;
     }
     if (split) {
-        static const int abl = getenv("VKN_GEMM_ABL") ? atoi(getenv("VKN_GEMM_ABL")) : 0;  // debugging: time attribution
-        const size_t lds = (size_t)(3 * GM_BM + 3 * GM_BN) * GS_LDR * sizeof(__bf16);
+        const size_t lds = (size_t)(2 * GS_WTILE + 2 * GS_ATILE) * sizeof(__bf16);
         if (hipFuncSetAttribute((const void*)k_gemm_s3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VKN_E_LAUNCH;
         int nmax = probs[0].Nout;
         if (nprob > 1 && probs[1].Nout > nmax) nmax = probs[1].Nout;
         dim3 grid((nmax + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, nprob > 1 ? nprob : ksplit);
         hipLaunchKernelGGL(k_gemm_s3, grid, dim3(GM_THREADS), lds, stream, probs[0], probs[nprob > 1 ? 1 : 0], nprob, M, K,
-                           partial, abl);
+                           partial);
         VKN_CHECK_LAUNCH();
     } else {
         for (int i = 0; i < nprob; ++i) {
@@ -664,10 +657,13 @@ int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, co
     return vkn_launch_gemm_group(&p, 1, M, K, ksplit, partial, stream);
 }
 
-// fp32 W [Nout][K] -> bf16x3 planes Wp [Nout][K/32][3][32]  (K % 32 == 0)
+// bytes of the pre-split tile images of a [Nout][K] weight
+size_t vkn_split_w3_bytes(int Nout, int K) { return (size_t)((Nout + 255) / 256) * (K / 32) * GS_WTILE * sizeof(__bf16); }
+
+// fp32 W [Nout][K] -> tile images (K % 32 == 0)
 int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream) {
     if (Nout <= 0 || K <= 0 || K % 32 != 0) return VKN_E_SHAPE;
-    hipLaunchKernelGGL(k_split_w3, dim3(Nout), dim3(256), 0, stream, W, static_cast<__bf16*>(Wp), Nout, K);
+    hipLaunchKernelGGL(k_split_w3, dim3(K / 32, (Nout + 255) / 256), dim3(256), 0, stream, W, static_cast<__bf16*>(Wp), Nout, K);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -336,10 +336,11 @@ def track_link(dims: VknDims, pack: StagePack, cur_obj, prev_obj):
 
 
 def split_weight(W):
-    """fp32 Linear weight [Nout, K] -> bf16x3 planes (opaque uint8 buffer of 6*Nout*K bytes) for `linear(..., w_split=...)`."""
+    """fp32 Linear weight [Nout, K] -> bf16x3 tile images (opaque uint8 buffer, 6 * roundup(Nout,256) * K bytes) for
+    `linear(..., w_split=...)`."""
     W = _req(W, 'W')
     Nout, K = W.shape
-    buf = torch.empty(6 * Nout * K, dtype=torch.uint8, device=W.device)
+    buf = torch.empty(6 * ((Nout + 255) // 256 * 256) * K, dtype=torch.uint8, device=W.device)   # 256-row tile images
     with torch.cuda.device(W.device):
         check(_lib.lib().vkn_split_weight_f32(_ptr(W), _ptr(buf), Nout, K, _stream()))
     return buf
