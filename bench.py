@@ -98,9 +98,8 @@ def main():
     ap.add_argument('--frames', type=int, default=8, help='frames of the clip per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
-    ap.add_argument('--streams', type=int, default=2,
-                    help='frame groups of the clip processed on separate HIP streams (the latency-bound [N x C] chain of one '
-                         'group overlaps the HBM-bound gather/decode/upsample of the other)')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='frame groups of the clip processed on separate HIP streams (measured: no gain, 1 is fastest)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -202,8 +201,17 @@ def main():
             dec_ms = e0.elapsed_time(e1) / reps
             alg = B * P * (C * 4 + N * 4)                      # read x once + write the logits once
             ach = alg / (dec_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the committed PMC profile of this same command (tools/gpu_profile.sh ->
+            # profiles/r01_pmc.json); null when the sidecar is absent or was taken at another batch size
+            traffic = None
+            try:
+                side = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
+                if B == 8:
+                    traffic = side['k_decode_mfma']['hbm_bytes_per_launch']
+            except Exception:  # noqa: BLE001
+                pass
             extra['roofline'] = dict(kernel='k_decode_mfma', bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS,
-                                     unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                                     unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                                      algorithmic_bytes_per_launch=alg, avg_launch_ms=round(dec_ms, 4),
                                      frames_per_launch=B)
             # gather kernel (+ its partial reduce), same accounting: read x once + read the logits once

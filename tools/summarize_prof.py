@@ -41,24 +41,22 @@ if con:
     print(f'{"kernel":48s} {"calls":>6s} {"avg_us":>9s} {"total_ms":>9s} {"pct":>6s}')
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
         print(f'{k:48s} {c:6d} {t / c / 1e3:9.2f} {t / 1e6:9.3f} {100 * t / tot:6.1f}')
-    ups = [i for i, r in enumerate(rows) if 'k_upsample' in r[0]]
-    if len(ups) >= 3:
-        i0, i1 = ups[-2] + 1, ups[-1] + 1
-        # a step = everything after the previous upsample's link kernels .. find first gather after ups[-2]
-        g = [i for i in range(ups[-2], ups[-1]) if 'k_gather_mfma' in rows[i][0]]
-        i0 = g[0] if g else i0
+    G = [i for i, r in enumerate(rows) if 'k_gather_mfma' in r[0]]
+    if len(G) >= 13:
+        # bench.py: every step = one head call = 3 gathers; take the 4th head call (a timed one)
+        i0, j = G[9], G[12]
         t0 = rows[i0][1]
-        print('\n== timeline of one timed step (us) ==')
+        print('\n== timeline of one timed step (us): start, duration, gap to previous kernel ==')
         prev = None
-        j = i0
-        while j < len(rows) and (j <= ups[-1] or 'k_gather_mfma' not in rows[j][0]):
-            n, s, e = rows[j]
+        gaps = 0.0
+        for n, s, e in rows[i0:j]:
             gap = (s - prev) / 1e3 if prev else 0.0
+            gaps += max(gap, 0.0)
             print(f'{short(n):32s} t={(s - t0) / 1e3:9.1f} dur={(e - s) / 1e3:8.1f} gap={gap:6.1f}')
             prev = e
-            j += 1
-        print(f'step span: {(prev - t0) / 1e3:.1f} us')
+        print(f'step span: {(prev - t0) / 1e3:.1f} us, of which gaps {gaps:.1f} us, kernels {j - i0}')
 
+pmc = {}
 for tag, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
     con = db(tag)
     print(f'\n== {ctr} per kernel launch (KB as reported by rocprofv3 --pmc {ctr}) ==')
@@ -68,3 +66,20 @@ for tag, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
     for n, c, avg, mx in con.execute('select name, count(*), avg(counter_value), max(counter_value) from pmc_events '
                                      'where counter_name = ? group by name order by avg(counter_value) desc limit 10', (ctr,)):
         print(f'{short(n):48s} n={c:5d} mean_KB={avg:14.1f} max_KB={mx:14.1f}')
+        pmc.setdefault(short(n), {})[ctr + '_KB'] = avg
+
+# sidecar for bench.py's roofline.traffic (committed under profiles/): HBM bytes per launch of the dominant kernels.
+# Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
+# coalesced streaming read -> doubled; WRITE_SIZE taken as reported (it equals the output tensor size exactly here).
+if len(sys.argv) > 2 and pmc:
+    import json
+    side = {}
+    for k in ('k_decode_mfma', 'k_gather_mfma<4>', 'k_upsample'):
+        if k in pmc and 'FETCH_SIZE_KB' in pmc[k] and 'WRITE_SIZE_KB' in pmc[k]:
+            side[k] = dict(fetch_size_kb=pmc[k]['FETCH_SIZE_KB'], write_size_kb=pmc[k]['WRITE_SIZE_KB'],
+                           hbm_bytes_per_launch=int((2 * pmc[k]['FETCH_SIZE_KB'] + pmc[k]['WRITE_SIZE_KB']) * 1024))
+    side['_note'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 2`, '
+                     'mean per launch (B = 8 frames); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per the gfx950 note in '
+                     'MI355X_MICROARCH.md')
+    json.dump(side, open(sys.argv[2], 'w'), indent=1)
+
