@@ -253,8 +253,8 @@ def main():
                                          'kernels, C=256, 1024x2048 frame -> 128x256 stride-8 features, ffn tracking link, '
                                          'x4 bilinear upsample of the final logits' + (' [SKIPPED]' if args.no_upsample else ''),
                                 frames_per_gpu_per_step=B, streams_per_gpu=NS, parallelism=f'frame-sharded dp{world}',
-                                arithmetic='fp32 storage; gather/decode on f16 hi+lo split MFMA with fp32 accumulate; '
-                                           '[N x C] GEMMs exact-fp32 MFMA; random-init weights'),
+                                arithmetic='fp32 storage; gather/decode on f16 hi+lo split MFMA, [N x C] GEMMs on bf16x3 split MFMA, '
+                                           'fp32 accumulate everywhere (fp32-class accuracy, DESIGN.md §3); random-init weights'),
                     **extra)
         print(json.dumps(line))
     if world > 1:

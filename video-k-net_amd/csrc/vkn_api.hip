@@ -119,6 +119,10 @@ int check_dims(const VknDims* d) {
         return VKN_E_ARG;
     if (d->C % 32 != 0 || d->C > 256) return VKN_E_SHAPE;
     if (d->C % d->heads != 0 || d->C / d->heads > 64 || (d->C % 8) != 0 || d->C / 8 > 64) return VKN_E_SHAPE;
+    {
+        const int hd = d->C / d->heads, hd8 = d->C / 8;  // head dims of `attention` and of the link attention (8 heads)
+        if (hd < 4 || (hd & (hd - 1)) || hd8 < 4 || (hd8 & (hd8 - 1))) return VKN_E_SHAPE;
+    }
     if (d->ff % 32 != 0) return VKN_E_SHAPE;
     if (d->N > 256) return VKN_E_SHAPE;
     if (d->ncls > 256) return VKN_E_SHAPE;
@@ -323,7 +327,7 @@ const char* vkn_strerror(int code) {
         case VKN_OK: return "ok";
         case VKN_E_ARG: return "invalid argument (null pointer or non-positive size)";
         case VKN_E_SHAPE:
-            return "unsupported shape (need C % 32 == 0, C <= 256, N <= 256, head_dim <= 64, ff % 32 == 0, ncls <= 256, "
+            return "unsupported shape (need C % 32 == 0, C <= 256, N <= 256, head_dim a power of two in [4, 64], ff % 32 == 0, ncls <= 256, "
                    "conv_kernel_size == 1)";
         case VKN_E_WORKSPACE: return "workspace missing or too small";
         case VKN_E_LAUNCH: return "HIP launch failed";

@@ -476,39 +476,63 @@ __global__ __launch_bounds__(256) void k_ku_mix(const float* __restrict__ params
 
 // Scaled-dot-product attention over the kernels of one frame: grid (heads, B, ceil(Nq/16)), 4 waves, one wave per query row.
 // q rows: Q[(b*Nq + i)*ldq + h*hd + d]; k/v rows: K[(b*Nk + j)*ldkv + h*hd + d]; out[(b*Nq+i)*ldo + h*hd + d].
-// Nk <= 256, hd <= 64.
+// Nk <= 256, hd <= 64, hd % 4 == 0.  The kernel is LDS-bandwidth bound (45 KB of LDS reads per query row with scalar reads),
+// so every LDS access is 16 bytes: K/V rows padded to hd+4 floats (conflict-free ds_read_b128), the query row is held in
+// registers, the P.V product gives each lane 4 output channels and splits the keys over 64/(hd/4) lane groups.
+template <int HD4>  // hd / 4
 __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
                                               const float* __restrict__ Vp, int ldkv, float* __restrict__ out, int ldo,
-                                              int Nq, int Nk, int hd, float scale) {
+                                              int Nq, int Nk, float scale) {
+    constexpr int hd = HD4 * 4, ldh = hd + 4;
+    constexpr int NGRP = 64 / HD4;  // lane groups of the P.V product (HD4 is a power of two <= 16)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
-    const int ldh = hd + 1;
-    float* Ks = smem;             // [Nk][hd+1]
-    float* Vs = Ks + Nk * ldh;    // [Nk][hd+1]
-    float* qs = Vs + Nk * ldh;    // [4][64]
-    float* ps = qs + 4 * 64;      // [4][256]
+    float* Ks = smem;             // [Nk][hd+4]
+    float* Vs = Ks + Nk * ldh;    // [Nk][hd+4]
+    float* qs = Vs + Nk * ldh;    // [16][hd]  (pre-scaled query rows of this workgroup)
+    float* ps = qs + 16 * hd;     // [4][256]
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
-    for (int i = tid; i < Nk * hd; i += 256) {
-        const int j = i / hd, d = i - j * hd;
-        Ks[j * ldh + d] = Kp[((size_t)b * Nk + j) * ldkv + h * hd + d];
-        Vs[j * ldh + d] = Vp[((size_t)b * Nk + j) * ldkv + h * hd + d];
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.z * 16;
+    // K/V staging: one float4 per thread per step, 4 steps batched (8 independent 16-B loads in flight before the LDS writes)
+    const int nvec = Nk * HD4;
+    for (int i0 = tid; i0 < nvec; i0 += 256 * 4) {
+        f32x4 kv[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * 256, nvec - 1);
+            const int j = i / HD4, q4 = i - j * HD4;
+            const size_t off = ((size_t)b * Nk + j) * ldkv + h * hd + 4 * q4;
+            kv[u] = *reinterpret_cast<const f32x4*>(Kp + off);
+            vv[u] = *reinterpret_cast<const f32x4*>(Vp + off);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            if (i < nvec) {
+                const int j = i / HD4, q4 = i - j * HD4;
+                *reinterpret_cast<f32x4*>(Ks + j * ldh + 4 * q4) = kv[u];
+                *reinterpret_cast<f32x4*>(Vs + j * ldh + 4 * q4) = vv[u];
+            }
+        }
+    }
+    for (int i = tid; i < 16 * HD4; i += 256) {
+        const int r = i / HD4, q4 = i - r * HD4;
+        if (row0 + r < Nq) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Q + ((size_t)b * Nq + row0 + r) * ldq + h * hd + 4 * q4);
+            *reinterpret_cast<f32x4*>(qs + r * hd + 4 * q4) = v * scale;
+        }
     }
     __syncthreads();
-    // lanes are grouped hdp-wide for the P.V product (hdp = pow2 >= hd)
-    int hdp = 1;
-    while (hdp < hd) hdp <<= 1;
-    const int ngrp = 64 / hdp, grp = lane / hdp, dl = lane - grp * hdp;
-    float* myq = qs + wave * 64;
+    const int grp = lane / HD4, dl4 = lane - grp * HD4;
     float* myp = ps + wave * 256;
-    // blockIdx.z owns 16 consecutive query rows, 4 per wave: (heads x B x ceil(Nq/16)) workgroups
-    const int i_begin = blockIdx.z * 16 + wave * 4;
+    const int i_begin = row0 + wave * 4;
     const int i_end = min(Nq, i_begin + 4);
     for (int i = i_begin; i < i_end; ++i) {
-        if (lane < hd) myq[lane] = Q[((size_t)b * Nq + i) * ldq + h * hd + lane] * scale;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave visible to its own reads
+        f32x4 qv[HD4];
+#pragma unroll
+        for (int u = 0; u < HD4; ++u) qv[u] = *reinterpret_cast<const f32x4*>(qs + (i - row0) * hd + 4 * u);  // broadcast reads
         float s[4];
         float mx = -INFINITY;
 #pragma unroll
@@ -516,8 +540,10 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int l
             const int j = lane + 64 * jj;
             float a = -INFINITY;
             if (j < Nk) {
-                a = 0.f;
-                for (int d = 0; d < hd; ++d) a = fmaf(myq[d], Ks[j * ldh + d], a);
+                f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < HD4; ++u) acc4 += qv[u] * *reinterpret_cast<const f32x4*>(Ks + j * ldh + 4 * u);
+                a = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
             }
             s[jj] = a;
             mx = fmaxf(mx, a);
@@ -539,12 +565,18 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int l
             if (j < Nk) myp[j] = s[jj] * inv;
         }
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        float o = 0.f;
-        if (dl < hd)
-            for (int j = grp; j < Nk; j += ngrp) o = fmaf(myp[j], Vs[j * ldh + dl], o);
-        for (int off = hdp; off < 64; off <<= 1) o += __shfl_xor(o, off, 64);
-        if (grp == 0 && dl < hd) out[((size_t)b * Nq + i) * ldo + h * hd + dl] = o;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int j = grp; j < Nk; j += NGRP) o += myp[j] * *reinterpret_cast<const f32x4*>(Vs + j * ldh + 4 * dl4);
+#pragma unroll
+        for (int off = HD4; off < 64; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = o[e];
+                o[e] = t + __shfl_xor(t, off, 64);
+            }
+        }
+        if (grp == 0) *reinterpret_cast<f32x4*>(out + ((size_t)b * Nq + i) * ldo + h * hd + 4 * dl4) = o;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -680,11 +712,20 @@ int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig,
 
 int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* out, int ldo, int B, int Nq,
                     int Nk, int heads, int hd, hipStream_t stream) {
-    if (Nk > 256 || hd > 64 || hd < 1) return VKN_E_SHAPE;
-    const size_t lds = ((size_t)2 * Nk * (hd + 1) + 4 * 64 + 4 * 256) * sizeof(float);
+    if (Nk > 256 || hd > 64 || hd < 4 || (hd & (hd - 1)) != 0 || (ldq % 4) || (ldkv % 4) || (ldo % 4)) return VKN_E_SHAPE;
+    const size_t lds = ((size_t)2 * Nk * (hd + 4) + 16 * hd + 4 * 256) * sizeof(float);
     if (lds > 64 * 1024) return VKN_E_SHAPE;
-    hipLaunchKernelGGL(k_attn, dim3(heads, B, (Nq + 15) / 16), dim3(256), lds, stream, Q, ldq, K, V, ldkv, out, ldo, Nq, Nk, hd,
-                       1.0f / sqrtf((float)hd));
+    dim3 grid(heads, B, (Nq + 15) / 16);
+    const float scale = 1.0f / sqrtf((float)hd);
+#define ATT_CASE(H4)                                                                                                      \
+    case H4:                                                                                                              \
+        hipLaunchKernelGGL(k_attn<H4>, grid, dim3(256), lds, stream, Q, ldq, K, V, ldkv, out, ldo, Nq, Nk, scale);        \
+        break;
+    switch (hd / 4) {
+        ATT_CASE(1) ATT_CASE(2) ATT_CASE(4) ATT_CASE(8) ATT_CASE(16)
+        default: return VKN_E_SHAPE;
+    }
+#undef ATT_CASE
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
