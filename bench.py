@@ -189,9 +189,9 @@ def main():
             hi, lo = vkn.ops.split_planes(kern)
             kb = torch.randn(B, N, device=device)
             outm = torch.empty(B, N, CFG2['H'], CFG2['W'], device=device)
-            for _ in range(3):
+            for _ in range(10):
                 vkn.ops.mask_decode_planes(x, hi, lo, N, kb, outm)
-            reps = 20
+            reps = 50
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):

@@ -12,8 +12,6 @@ import vkn_import  # noqa: E402
 vkn = vkn_import.load()
 dev = 'cuda:0'
 shapes = [(32, 32, 256), (936, 32, 256), (32, 256, 256), (936, 256, 256), (936, 64, 256), (936, 128, 256), (936, 256, 32)]
-if os.environ.get('VKN_GEMM_ABL'):
-    shapes = [(32, 256, 256), (936, 256, 256)]
 for (M, K, N) in shapes:
     A = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev) / K ** 0.5

@@ -3,11 +3,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/gemm_trace
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for abl in 0 1 2 3 4; do
-export VKN_GEMM_ABL=$abl
-rm -rf $OUT/t
 rocprofv3 --kernel-trace -d $OUT/t -o t -- python $R/tools/gemm_trace.py > $OUT/log.txt 2>&1
-echo "ABL=$abl (1 no-mfma/ldsread, 2 no-stash, 3 no-fetch, 4 no-barriers)"
 python - <<PY
 import sqlite3, glob
 con = sqlite3.connect(glob.glob('$OUT/t/**/*_results.db', recursive=True)[0])
@@ -19,4 +15,3 @@ for n,s,e,gx,gy in rows:
         print('gemm_s3 x%d: %s  (grid %s)' % (len(cur), ' '.join('%.1f' % v for v in cur), ''))
         cur = []
 PY
-done

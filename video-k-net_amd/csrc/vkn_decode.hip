@@ -30,7 +30,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NB, int ABL>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     const float* __restrict__ x, const _Float16* __restrict__ kfh, const _Float16* __restrict__ kfl,
-    const float* __restrict__ kb, float* __restrict__ out, int N, int NPT, int n0, int C, int P, int px_per_wg) {
+    const float* __restrict__ kb, float* __restrict__ out, int N, int NPT, int n0, int C, int P, int px_per_wg,
+    int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LDK = C + 8;  // halfs per LDS row; (C+8)*2 B = odd multiple of 16 B -> b128 reads conflict-free
     _Float16* ldsH = reinterpret_cast<_Float16*>(smem);
@@ -65,7 +66,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     }
     __syncthreads();
 
-    const int p_begin = blockIdx.x * px_per_wg;
+    // XCD-aware pixel ranges (workgroup id % 8 = XCD, observed): `xcd_remap` gives each XCD a contiguous 1/8 of the frame
+    int gx = blockIdx.x;
+    if (xcd_remap && (gridDim.x % 8) == 0) gx = (gx % 8) * (gridDim.x / 8) + gx / 8;
+    const int p_begin = gx * px_per_wg;
     const int p_end = min(P, p_begin + px_per_wg);
     const int ntile = (p_end > p_begin) ? (p_end - p_begin + DEC_TILE - 1) / DEC_TILE : 0;
     const int my = (ntile > wave) ? (ntile - wave + DEC_WAVES - 1) / DEC_WAVES : 0;
@@ -98,9 +102,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
         } else {                                                                                                 \
             _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                        \
                 /* aux = 2 (nt): x is streamed once per launch; measured +9 % (92 -> 84 us, cfg2 B = 8).  ABL 4 = plain */ \
-                REG[e] = (ABL == 4)                                                                              \
-                             ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 0)       \
-                             : __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 2);      \
+                /* cache policy aux = 3 (sc0 | nt): x is streamed once per launch.  tools/decode_sweep.py, cfg2 B = 8:        */ \
+                /* plain 88.7-94.6 us, nt 81.9-86.2 us, sc0|nt 78.3-82.7 us.  ABL 4 = plain, ABL 6 = nt only (A/B)     */ \
+                REG[e] = (ABL == 4)   ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 0) \
+                         : (ABL == 6) ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 2) \
+                                      : __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 3); \
         }                                                                                                        \
         const bool adv_ = (ld_cnt + 1 < total);                                                                  \
         const bool wrap_ = (ld_ks + 1 == KS);                                                                    \
@@ -269,6 +275,7 @@ int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, 
     const char* ppw_env = getenv("VKN_DECODE_PXWG");  // debugging: override pixels per workgroup
     if (ppw_env && atoi(ppw_env) >= 512) px_per_wg = atoi(ppw_env) / 512 * 512;
     const int G2 = (P + px_per_wg - 1) / px_per_wg;
+    const int xcd = getenv("VKN_DECODE_XCD") ? atoi(getenv("VKN_DECODE_XCD")) : 1;  // measured +1 % (tools/decode_sweep.py)
     for (int n0 = 0; n0 < NPT; n0 += 128) {
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
         const size_t lds = (size_t)2 * nb * 32 * (C + 8) * sizeof(_Float16) + (size_t)nb * 32 * sizeof(float);
@@ -277,7 +284,7 @@ int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, 
     do {                                                                                                       \
         if (dec_set_lds((const void*)k_decode_mfma<NBV, ABLV>, lds)) return VKN_E_LAUNCH;                      \
         hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV>), grid, block, lds, stream, x, kfh, kfl, kb, out, N, NPT, n0, C, \
-                           P, px_per_wg);                                                                      \
+                           P, px_per_wg, xcd);                                                                    \
     } while (0)
 #define DEC_CASE(NBV)                    \
     case NBV:                            \
@@ -287,6 +294,7 @@ int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, 
         else if (NBV == 4 && abl == 3) DEC_LAUNCH(4, 3); \
         else if (NBV == 4 && abl == 4) DEC_LAUNCH(4, 4); \
         else if (NBV == 4 && abl == 5) DEC_LAUNCH(4, 5); \
+        else if (NBV == 4 && abl == 6) DEC_LAUNCH(4, 6); \
         else DEC_LAUNCH(NBV, 0);         \
         break;
         switch (nb) {

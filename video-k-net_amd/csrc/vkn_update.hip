@@ -591,10 +591,11 @@ __global__ __launch_bounds__(256) void k_sigmoid(const float* __restrict__ in, f
 // src = (dst + 0.5) / S - 0.5 clamped at 0; neighbours clamped at the border.
 // Write-bound (S*S outputs per input): one workgroup = one input row of one plane -> its S output rows; a thread owns 4
 // consecutive output x (x-weights computed once, reused for the S rows) and streams them out with 16-B non-temporal stores.
+template <int NT, int ROWS>  // NT: non-temporal stores; ROWS: input rows per workgroup
 __global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ in, float* __restrict__ out, int H, int W,
                                                   int S) {
     const int OW = W * S, OH = H * S;
-    const int y = blockIdx.x, plane = blockIdx.y;
+    const int plane = blockIdx.y;
     const float rs = 1.0f / (float)S;
     const float* ip = in + (size_t)plane * H * W;
     const bool vec = ((OW & 3) == 0);
@@ -608,25 +609,32 @@ __global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ in, 
             x1[k] = min(x0[k] + 1, W - 1);
             lx[k] = sx - (float)x0[k];
         }
-        for (int j = 0; j < S; ++j) {
-            const int oy = y * S + j;
-            const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f);
-            const int y0 = (int)sy;
-            const int y1 = min(y0 + 1, H - 1);
-            const float ly = sy - (float)y0, hy = 1.f - ly;
-            const float* r0 = ip + (size_t)y0 * W;
-            const float* r1 = ip + (size_t)y1 * W;
-            float o[4];
+        for (int yy = 0; yy < ROWS; ++yy) {
+            const int y = blockIdx.x * ROWS + yy;
+            if (y >= H) break;
+            for (int j = 0; j < S; ++j) {
+                const int oy = y * S + j;
+                const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f);
+                const int y0 = (int)sy;
+                const int y1 = min(y0 + 1, H - 1);
+                const float ly = sy - (float)y0, hy = 1.f - ly;
+                const float* r0 = ip + (size_t)y0 * W;
+                const float* r1 = ip + (size_t)y1 * W;
+                float o[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float hx = 1.f - lx[k];
-                o[k] = hy * (hx * r0[x0[k]] + lx[k] * r0[x1[k]]) + ly * (hx * r1[x0[k]] + lx[k] * r1[x1[k]]);
-            }
-            float* op = out + ((size_t)plane * OH + oy) * OW + ox4;
-            if (vec && ox4 + 3 < OW) {
-                __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(op));
-            } else {
-                for (int k = 0; k < 4 && ox4 + k < OW; ++k) op[k] = o[k];
+                for (int k = 0; k < 4; ++k) {
+                    const float hx = 1.f - lx[k];
+                    o[k] = hy * (hx * r0[x0[k]] + lx[k] * r0[x1[k]]) + ly * (hx * r1[x0[k]] + lx[k] * r1[x1[k]]);
+                }
+                float* op = out + ((size_t)plane * OH + oy) * OW + ox4;
+                if (vec && ox4 + 3 < OW) {
+                    if (NT)
+                        __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(op));
+                    else
+                        *reinterpret_cast<f32x4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
+                } else {
+                    for (int k = 0; k < 4 && ox4 + k < OW; ++k) op[k] = o[k];
+                }
             }
         }
     }
@@ -741,8 +749,11 @@ int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, i
     int done = 0;
     while (done < planes) {  // gridDim.y <= 65535
         const int chunk = (planes - done > 32768) ? 32768 : planes - done;
-        hipLaunchKernelGGL(k_upsample, dim3(H, chunk), dim3(256), 0, stream, in + (size_t)done * H * W,
-                           out + (size_t)done * H * S * W * S, H, W, S);
+        const float* ip = in + (size_t)done * H * W;
+        float* op = out + (size_t)done * H * S * W * S;
+        // non-temporal stores, 4 input rows (16 output rows at S = 4) per workgroup: best of the measured variants
+        // (tools/upsample_ab.py: plain stores 650-690 us, nt 1 row 517 us, nt 4 rows 478 us, nt 16 rows 492 us)
+        hipLaunchKernelGGL((k_upsample<1, 4>), dim3((H + 3) / 4, chunk), dim3(256), 0, stream, ip, op, H, W, S);
         VKN_CHECK_LAUNCH();
         done += chunk;
     }
