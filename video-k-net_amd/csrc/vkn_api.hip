@@ -31,7 +31,17 @@ struct StageWs {
 struct PrepW {
     const void *ft, *ftT, *dyn, *inp, *ig, *ug, *fc, *attn_in, *attn_out, *ffn1, *ffn2, *cls_fc[VKN_MAX_FCS], *fc_cls,
         *mask_fc[VKN_MAX_FCS], *fc_mask, *pa_in, *pa_in_kv, *pa_out, *lffn1, *lffn2;
+    // composite weights (feat_transform folded into its consumers, computed once in vkn_prepare_stage_f32):
+    //   dynft = W_dyn.W_ft [2C][C], bcnt = W_dyn.b_ft [2C]       -> dynamic_layer(x_feat) straight from the raw gather
+    //   dec = W_ft^T.W_fm [C][C], decb = W_ft^T.b_fm [C]          -> decode kernels straight from the last mask_fcs output
+    //   dvec = W_fm^T.b_ft [C], kb0 = b_fm.b_ft                   -> decode bias
+    const void *dynft, *dec;
+    float *dynft32, *bcnt, *dec32, *decb, *dvec, *kb0, *fmT;
 };
+
+inline bool has_composites(const VknDims* d, const VknStageWeights* w) {
+    return w->ft_w && w->ft_wT && w->ft_b && w->dyn_w && w->dyn_b && w->fc_mask_w && w->fc_mask_b && d->n_mask_fcs > 0;
+}
 
 struct PrepItem {
     const float* src;
@@ -68,6 +78,20 @@ size_t carve_prepared(const VknDims* d, const VknStageWeights* w, char* base, Pr
     const int n = prep_items(d, w, p, it);
     Carver c{base, 0};
     for (int i = 0; i < n; ++i) *it[i].dst = c.take<char>(vkn_split_w3_bytes(it[i].nout, it[i].k));
+    p->dynft = p->dec = nullptr;
+    p->dynft32 = p->bcnt = p->dec32 = p->decb = p->dvec = p->kb0 = p->fmT = nullptr;
+    if (has_composites(d, w)) {
+        const size_t C = d->C;
+        p->dynft = c.take<char>(vkn_split_w3_bytes(2 * d->C, d->C));
+        p->dec = c.take<char>(vkn_split_w3_bytes(d->C, d->C));
+        p->dynft32 = c.take<float>(2 * C * C);
+        p->bcnt = c.take<float>(2 * C);
+        p->dec32 = c.take<float>(C * C);
+        p->decb = c.take<float>(C);
+        p->dvec = c.take<float>(C);
+        p->kb0 = c.take<float>(4);
+        p->fmT = c.take<float>(C * C);
+    }
     if (n_out) *n_out = n;
     return (c.off + 255) & ~(size_t)255;
 }
@@ -92,7 +116,7 @@ size_t carve_stage(const VknDims* d, char* base, StageWs* s) {
     s->xfeat = c.take<float>(M * C);
     s->params = c.take<float>(M * 2 * C);
     s->inputf = c.take<float>(M * 2 * C);
-    s->ig = c.take<float>(M * C);
+    s->ig = c.take<float>(M * 2 * C);  // fused path: [M][2C] = input gate | update gate
     s->ug = c.take<float>(M * C);
     s->f = c.take<float>(M * C);
     s->obj1 = c.take<float>(M * C);
@@ -178,25 +202,45 @@ int run_attention(const VknDims* d, const StageWs& s, const float* qsrc, const f
 }
 
 // KernelUpdator.forward                                        knet/kernel_updator.py:56-93
-int run_updator(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* xfeat, const float* obj_in,
-                float* out, const StageWs& s, hipStream_t st) {
+// `xraw`/`cnt` non-null (and composites prepared): dynamic_layer consumes the raw gather through W_dyn.W_ft (+ cnt (x) W_dyn.b_ft).
+int run_updator(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* xfeat, const float* xraw,
+                const float* cnt, const float* obj_in, float* out, const StageWs& s, hipStream_t st) {
     const int C = d->C, M = d->B * d->N;
+    // with C == 256 param_out / input_out are exactly the second 256-column tile of their GEMM: their LayerNorms (:79-80) run
+    // in that tile's epilogue, and the mix (:83-88) becomes the A prologue of fc_layer -> no standalone mix kernel.
+    const bool fuse = (C == 256);
     // dynamic_layer(x_feat) and input_layer(kernels) are independent: one grouped launch                     (:59, :65-66)
     VknGemmProb pr[2];
-    VknEpi e = mk_epi(d); e.bias = w->dyn_b; e.out = s.params; e.ldo = 2 * C;
-    pr[0] = VknGemmProb{xfeat, nullptr, C, w->dyn_w, pw.dyn, 2 * C, e};
+    VknEpi e = mk_epi(d); e.out = s.params; e.ldo = 2 * C;
+    if (fuse) { e.ln_w = w->norm_out_w; e.ln_b = w->norm_out_b; e.ln_from_col = C; }
+    if (xraw && pw.dynft) {
+        e.bias = pw.bcnt; e.rowscale = cnt; e.bias2 = w->dyn_b;
+        pr[0] = VknGemmProb{xraw, nullptr, nullptr, nullptr, C, pw.dynft32, pw.dynft, 2 * C, e};
+    } else {
+        e.bias = w->dyn_b;
+        pr[0] = VknGemmProb{xfeat, nullptr, nullptr, nullptr, C, w->dyn_w, pw.dyn, 2 * C, e};
+    }
     e = mk_epi(d); e.bias = w->inp_b; e.out = s.inputf; e.ldo = 2 * C;
-    pr[1] = VknGemmProb{obj_in, nullptr, C, w->inp_w, pw.inp, 2 * C, e};
+    if (fuse) { e.ln_w = w->inorm_out_w; e.ln_b = w->inorm_out_b; e.ln_from_col = C; }
+    pr[1] = VknGemmProb{obj_in, nullptr, nullptr, nullptr, C, w->inp_w, pw.inp, 2 * C, e};
     VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
     // gate = input_in * param_in (:70) as the GEMM's A prologue; both gates = sigmoid(LN(linear(gate))) in one launch (:74-78)
-    e = mk_epi(d); e.bias = w->ig_b; e.ln_w = w->inorm_in_w; e.ln_b = w->inorm_in_b; e.act = 2; e.out = s.ig; e.ldo = C;
-    pr[0] = VknGemmProb{s.inputf, s.params, 2 * C, w->ig_w, pw.ig, C, e};
-    e = mk_epi(d); e.bias = w->ug_b; e.ln_w = w->norm_in_w; e.ln_b = w->norm_in_b; e.act = 2; e.out = s.ug; e.ldo = C;
-    pr[1] = VknGemmProb{s.inputf, s.params, 2 * C, w->ug_w, pw.ug, C, e};
+    float* ig = s.ig;
+    float* ug = fuse ? s.ig + C : s.ug;
+    const int ldg = fuse ? 2 * C : C;
+    e = mk_epi(d); e.bias = w->ig_b; e.ln_w = w->inorm_in_w; e.ln_b = w->inorm_in_b; e.act = 2; e.out = ig; e.ldo = ldg;
+    pr[0] = VknGemmProb{s.inputf, s.params, nullptr, nullptr, 2 * C, w->ig_w, pw.ig, C, e};
+    e = mk_epi(d); e.bias = w->ug_b; e.ln_w = w->norm_in_w; e.ln_b = w->norm_in_b; e.act = 2; e.out = ug; e.ldo = ldg;
+    pr[1] = VknGemmProb{s.inputf, s.params, nullptr, nullptr, 2 * C, w->ug_w, pw.ug, C, e};
     VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
-    VKN_TRY(vkn_launch_ku_mix(s.params, s.inputf, s.ig, s.ug, w->norm_out_w, w->norm_out_b, w->inorm_out_w, w->inorm_out_b,
-                              d->ln_eps, s.f, M, C, st));                                          // :79-88
     e = mk_epi(d); e.bias = w->fc_b; e.ln_w = w->fc_norm_w; e.ln_b = w->fc_norm_b; e.act = 1; e.out = out; e.ldo = C;
+    if (fuse) {
+        // features = update_gate * norm_out(param_out) + input_gate * input_norm_out(input_out)            (:83-88)
+        pr[0] = VknGemmProb{ug, s.params + C, ig, s.inputf + C, 2 * C, w->fc_w, pw.fc, C, e};
+        return vkn_launch_gemm_group(pr, 1, M, C, 1, nullptr, st);                                  // :90-92
+    }
+    VKN_TRY(vkn_launch_ku_mix(s.params, s.inputf, ig, ug, w->norm_out_w, w->norm_out_b, w->inorm_out_w, w->inorm_out_b,
+                              d->ln_eps, s.f, M, C, st));                                          // :79-88
     return vkn_launch_gemm(s.f, nullptr, C, w->fc_w, pw.fc, M, C, C, 1, nullptr, e, st);           // :90-92
 }
 
@@ -230,19 +274,23 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     else
         VKN_TRY(vkn_launch_gather(x, masks_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
 
-    // folded feat_transform: x_feat = xraw . W_ft^T + cnt (x) b_ft             (:179-180 folded)
+    // folded feat_transform: x_feat = xraw . W_ft^T + cnt (x) b_ft             (:179-180 folded).  With the
+    // composite weights x_feat itself is only materialised when the caller asks for it.
+    const bool comp = pw.dynft != nullptr;
     float* xfeat = x_feat_out ? x_feat_out : s.xfeat;
     VknEpi e = mk_epi(d);
     if (has_ft) {
-        e.bias = w->ft_b; e.rowscale = s.cnt; e.out = xfeat; e.ldo = C;
-        VKN_TRY(vkn_launch_gemm(s.xraw, nullptr, C, w->ft_w, pw.ft, M, C, C, 1, nullptr, e, st));
+        if (!comp || x_feat_out) {
+            e.bias = w->ft_b; e.rowscale = s.cnt; e.out = xfeat; e.ldo = C;
+            VKN_TRY(vkn_launch_gemm(s.xraw, nullptr, C, w->ft_w, pw.ft, M, C, C, 1, nullptr, e, st));
+        }
     } else {
         if (hipMemcpyAsync(xfeat, s.xraw, (size_t)M * C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
             return VKN_E_LAUNCH;
     }
 
     // (ii-a) KernelUpdator                                    knet/kernel_updator.py:56-93
-    VKN_TRY(run_updator(d, w, pw, xfeat, obj_in, s.obj1, s, st));
+    VKN_TRY(run_updator(d, w, pw, xfeat, comp ? s.xraw : nullptr, s.cnt, obj_in, s.obj1, s, st));
 
     // (ii-b) kernel interaction: MHA + LN, FFN + LN           knet/det/kernel_update_head.py:204-215
     VKN_TRY(run_attention(d, s, s.obj1, s.obj1, d->heads, w->attn_in_w, pw.attn_in, nullptr, w->attn_in_b, w->attn_out_w,
@@ -269,45 +317,59 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         if (i < d->n_cls_fcs) {
             float* dst = (i & 1) ? s.t2 : s.t1;
             e = mk_epi(d); e.ln_w = w->cls_ln_w[i]; e.ln_b = w->cls_ln_b[i]; e.act = 1; e.out = dst; e.ldo = C;
-            pr[np++] = VknGemmProb{tc, nullptr, C, w->cls_fc_w[i], pw.cls_fc[i], C, e};
+            pr[np++] = VknGemmProb{tc, nullptr, nullptr, nullptr, C, w->cls_fc_w[i], pw.cls_fc[i], C, e};
             tc = dst;
         }
         if (i < d->n_mask_fcs) {
-            float* dst = (i & 1) ? s.lq : s.kern32;   // scratch not otherwise live here
+            float* dst = (i & 1) ? s.lq : s.f;   // scratch not otherwise live here
             e = mk_epi(d); e.ln_w = w->mask_ln_w[i]; e.ln_b = w->mask_ln_b[i]; e.act = 1; e.out = dst; e.ldo = C;
-            pr[np++] = VknGemmProb{tm, nullptr, C, w->mask_fc_w[i], pw.mask_fc[i], C, e};
+            if (comp && i == d->n_mask_fcs - 1) { e.dot_vec = pw.dvec; e.dot_bias = pw.kb0; e.dot_out = s.kb; }  // decode bias
+            pr[np++] = VknGemmProb{tm, nullptr, nullptr, nullptr, C, w->mask_fc_w[i], pw.mask_fc[i], C, e};
             tm = dst;
         }
         VKN_TRY(vkn_launch_gemm_group(pr, np, M, C, 1, nullptr, st));
     }
-    {
+    const float* kb = has_ft ? s.kb : nullptr;
+    if (comp) {
+        // fc_cls, and the decode kernels Kf = fc_mask(.) . W_ft in ONE GEMM from the composite weight          (:221, :227, :247)
         VknGemmProb pr[2];
         e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
-        pr[0] = VknGemmProb{tc, nullptr, C, w->fc_cls_w, pw.fc_cls, d->ncls, e};
-        e = mk_epi(d); e.bias = w->fc_mask_b; e.out = s.maskfeat; e.ldo = C;
-        if (has_ft) { e.dot_vec = w->ft_b; e.dot_out = s.kb; }
-        pr[1] = VknGemmProb{tm, nullptr, C, w->fc_mask_w, pw.fc_mask, C, e};
+        pr[0] = VknGemmProb{tc, nullptr, nullptr, nullptr, C, w->fc_cls_w, pw.fc_cls, d->ncls, e};
+        e = mk_epi(d); e.bias = pw.decb; e.ldo = C;
+        if (ref_decode) e.out = s.kern32;
+        else { e.plane_hi = s.kfh; e.plane_lo = s.kfl; e.rows_per_frame = N; e.NPT = npt_of(N); }
+        pr[1] = VknGemmProb{tm, nullptr, nullptr, nullptr, C, pw.dec32, pw.dec, C, e};
         VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
-    }
-
-    // (iii) mask decode with the folded kernels  Kf = mask_feat . W_ft   :247-260
-    const float* kb = has_ft ? s.kb : nullptr;
-    if (ref_decode) {
-        const float* kern = s.maskfeat;
-        if (has_ft) {
-            e = mk_epi(d); e.out = s.kern32; e.ldo = C;
-            VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, pw.ftT, M, C, C, 1, nullptr, e, st));
-            kern = s.kern32;
-        }
-        VKN_TRY(vkn_launch_decode_ref(x, kern, kb, masks_out, B, N, C, P, st));
+        if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
+        else VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
     } else {
-        if (has_ft) {
-            e = mk_epi(d); e.plane_hi = s.kfh; e.plane_lo = s.kfl; e.ldo = C; e.rows_per_frame = N; e.NPT = npt_of(N);
-            VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, pw.ftT, M, C, C, 1, nullptr, e, st));
-        } else {
-            VKN_TRY(vkn_launch_split_planes(s.maskfeat, s.kfh, s.kfl, B, N, C, st));
+        {
+            VknGemmProb pr[2];
+            e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
+            pr[0] = VknGemmProb{tc, nullptr, nullptr, nullptr, C, w->fc_cls_w, pw.fc_cls, d->ncls, e};
+            e = mk_epi(d); e.bias = w->fc_mask_b; e.out = s.maskfeat; e.ldo = C;
+            if (has_ft) { e.dot_vec = w->ft_b; e.dot_out = s.kb; }
+            pr[1] = VknGemmProb{tm, nullptr, nullptr, nullptr, C, w->fc_mask_w, pw.fc_mask, C, e};
+            VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
         }
-        VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
+        // (iii) mask decode with the folded kernels  Kf = mask_feat . W_ft   :247-260
+        if (ref_decode) {
+            const float* kern = s.maskfeat;
+            if (has_ft) {
+                e = mk_epi(d); e.out = s.kern32; e.ldo = C;
+                VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, pw.ftT, M, C, C, 1, nullptr, e, st));
+                kern = s.kern32;
+            }
+            VKN_TRY(vkn_launch_decode_ref(x, kern, kb, masks_out, B, N, C, P, st));
+        } else {
+            if (has_ft) {
+                e = mk_epi(d); e.plane_hi = s.kfh; e.plane_lo = s.kfl; e.ldo = C; e.rows_per_frame = N; e.NPT = npt_of(N);
+                VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, pw.ftT, M, C, C, 1, nullptr, e, st));
+            } else {
+                VKN_TRY(vkn_launch_split_planes(s.maskfeat, s.kfh, s.kfl, B, N, C, st));
+            }
+            VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
+        }
     }
 
     if (prev_obj && track_out) VKN_TRY(run_link(d, w, pw, obj3, prev_obj, track_out, s, st));
@@ -441,9 +503,27 @@ int vkn_prepare_stage_f32(const VknDims* d, const VknStageWeights* w, void* prep
     PrepItem items[40];
     int n = 0;
     if (carve_prepared(d, w, static_cast<char*>(prepared), &pw, items, &n) > bytes) return VKN_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     for (int i = 0; i < n; ++i)
-        VKN_TRY(vkn_launch_split_w3(items[i].src, const_cast<void*>(*items[i].dst), items[i].nout, items[i].k,
-                                    static_cast<hipStream_t>(stream)));
+        VKN_TRY(vkn_launch_split_w3(items[i].src, const_cast<void*>(*items[i].dst), items[i].nout, items[i].k, st));
+    if (pw.dynft) {
+        // composite weights, exact-fp32 GEMMs (out[m][n] = sum_k A[m][k] W[n][k])
+        const int C = d->C;
+        auto mm = [&](const float* A, const float* W, float* out, int M, int Nout) {
+            VknEpi e{};
+            e.eps = d->ln_eps; e.out = out; e.ldo = Nout;
+            return vkn_launch_gemm(A, nullptr, C, W, nullptr, M, C, Nout, 1, nullptr, e, st);
+        };
+        VKN_TRY(mm(w->dyn_w, w->ft_wT, pw.dynft32, 2 * C, C));       // (W_dyn.W_ft)[j][c] = sum_k W_dyn[j][k] W_ft[k][c]
+        VKN_TRY(mm(w->dyn_w, w->ft_b, pw.bcnt, 2 * C, 1));           // W_dyn.b_ft
+        VKN_TRY(vkn_launch_transpose(w->fc_mask_w, pw.fmT, C, C, st));
+        VKN_TRY(mm(w->ft_wT, pw.fmT, pw.dec32, C, C));               // (W_ft^T.W_fm)[c][k] = sum_j W_ft[j][c] W_fm[j][k]
+        VKN_TRY(mm(w->ft_wT, w->fc_mask_b, pw.decb, C, 1));          // W_ft^T.b_fm
+        VKN_TRY(mm(pw.fmT, w->ft_b, pw.dvec, C, 1));                 // W_fm^T.b_ft
+        VKN_TRY(mm(w->fc_mask_b, w->ft_b, pw.kb0, 1, 1));            // b_fm.b_ft
+        VKN_TRY(vkn_launch_split_w3(pw.dynft32, const_cast<void*>(pw.dynft), 2 * C, C, st));
+        VKN_TRY(vkn_launch_split_w3(pw.dec32, const_cast<void*>(pw.dec), C, C, st));
+    }
     return VKN_OK;
 }
 
@@ -478,7 +558,7 @@ int vkn_kernel_updator_f32(const VknDims* d, const VknStageWeights* w, const flo
         if (carve_prepared(d, w, static_cast<char*>(const_cast<void*>(w->prepared)), &pw, items, nullptr) > w->prepared_bytes)
             return VKN_E_WORKSPACE;
     }
-    return run_updator(d, w, pw, update_feature, input_feature, out, s, static_cast<hipStream_t>(stream));
+    return run_updator(d, w, pw, update_feature, nullptr, nullptr, input_feature, out, s, static_cast<hipStream_t>(stream));
 }
 
 size_t vkn_stage_workspace_bytes(const VknDims* d) {

@@ -7,15 +7,18 @@
 struct VknEpi {
     const float* bias;      // [Nout] or null
     const float* rowscale;  // [M] or null: bias is multiplied by rowscale[row] (pixel count of the folded feat_transform bias)
+    const float* bias2;     // [Nout] or null: second, unscaled bias (used together with a rowscale'd `bias`)
     const float* resid;     // [M][ldr] or null, added before LN
     int ldr;
-    const float* ln_w;  // [Nout] or null -> LayerNorm over the row
+    const float* ln_w;  // [ncols of a tile] or null -> LayerNorm over the row (of the column tile)
     const float* ln_b;
+    int ln_from_col;    // LayerNorm only in column tiles with n0 >= ln_from_col (weights indexed from there); 0 = whole row
     float eps;
     int act;     // 0 none, 1 relu, 2 sigmoid
     float* out;  // [M][ldo] or null
     int ldo;
-    const float* dot_vec;  // [Nout] or null: dot_out[row] = sum_col result(row,col) * dot_vec[col]
+    const float* dot_vec;   // [Nout] or null: dot_out[row] = sum_col result(row,col) * dot_vec[col] (+ *dot_bias)
+    const float* dot_bias;  // device scalar or null
     float* dot_out;
     _Float16* plane_hi;  // or null: f16 split planes [B][NPT][ldo]; row r = b*N+n -> plane row b*NPT+n
     _Float16* plane_lo;
@@ -27,6 +30,8 @@ struct VknEpi {
 struct VknGemmProb {
     const float* A;
     const float* A2;  // or null: elementwise factor of A (same lda)
+    const float* A3;  // or null: second product term, the effective operand is A*A2 + A3*A4 (same lda)
+    const float* A4;
     int lda;
     const float* W;      // fp32 [Nout][K]
     const void* Wsplit;  // or null: bf16x3 planes of W (k_split_w3)
@@ -48,6 +53,7 @@ int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, co
                     int ksplit, float* partial, const VknEpi& epi, hipStream_t stream);
 int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int ksplit, float* partial, hipStream_t stream);
 size_t vkn_split_w3_bytes(int Nout, int K);
+int vkn_launch_transpose(const float* src, float* dst, int R, int Cc, hipStream_t st);  // dst[c][r] = src[r][c]
 int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream);
 int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig, const float* ug, const float* no_w,
                       const float* no_b, const float* ino_w, const float* ino_b, float eps, float* f, int M, int C,

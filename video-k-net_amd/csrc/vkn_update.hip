@@ -34,9 +34,10 @@
 // Per-lane column constants of the row epilogue (lane owns columns lane + 64*q): loaded ONCE per wave with clamped
 // addresses and no per-lane branches, so the loads issue back-to-back instead of one L2 round trip each.
 struct VknEpiCols {
-    float bias[4], lnw[4], lnb[4], dot[4];
+    float bias[4], bias2[4], lnw[4], lnb[4], dot[4];
     int cidx[4];  // clamped absolute column
     bool ok[4];
+    bool do_ln;
 };
 
 __device__ __forceinline__ void vkn_epi_load_cols(const VknEpi& e, int ncols, int col0, int lane, VknEpiCols& c) {
@@ -45,15 +46,23 @@ __device__ __forceinline__ void vkn_epi_load_cols(const VknEpi& e, int ncols, in
         const int cl = lane + 64 * q;
         c.ok[q] = cl < ncols;
         c.cidx[q] = col0 + min(cl, ncols - 1);
-        c.bias[q] = 0.f; c.lnw[q] = 1.f; c.lnb[q] = 0.f; c.dot[q] = 0.f;
+        c.bias[q] = 0.f; c.bias2[q] = 0.f; c.lnw[q] = 1.f; c.lnb[q] = 0.f; c.dot[q] = 0.f;
     }
     if (e.bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) c.bias[q] = e.bias[c.cidx[q]];
     }
-    if (e.ln_w) {
+    if (e.bias2) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { c.lnw[q] = e.ln_w[c.cidx[q]]; c.lnb[q] = e.ln_b[c.cidx[q]]; }
+        for (int q = 0; q < 4; ++q) c.bias2[q] = e.bias2[c.cidx[q]];
+    }
+    c.do_ln = (e.ln_w != nullptr) && (col0 >= e.ln_from_col);
+    if (c.do_ln) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c.lnw[q] = e.ln_w[c.cidx[q] - e.ln_from_col];
+            c.lnb[q] = e.ln_b[c.cidx[q] - e.ln_from_col];
+        }
     }
     if (e.dot_vec) {
 #pragma unroll
@@ -71,8 +80,8 @@ __device__ __forceinline__ void vkn_row_epilogue(const VknEpi& e, const VknEpiCo
     }
     const float bs = (e.bias && e.rowscale) ? e.rowscale[row] : 1.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = c.ok[q] ? (v[q] + c.bias[q] * bs + rv[q]) : 0.f;
-    if (e.ln_w) {
+    for (int q = 0; q < 4; ++q) v[q] = c.ok[q] ? (v[q] + c.bias[q] * bs + c.bias2[q] + rv[q]) : 0.f;
+    if (c.do_ln) {
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) s += v[q];
@@ -104,7 +113,7 @@ __device__ __forceinline__ void vkn_row_epilogue(const VknEpi& e, const VknEpiCo
 #pragma unroll
         for (int q = 0; q < 4; ++q) s += c.ok[q] ? v[q] * c.dot[q] : 0.f;
         s = vkn_wave_sum(s);
-        if (lane == 0) e.dot_out[row] = s;
+        if (lane == 0) e.dot_out[row] = s + (e.dot_bias ? *e.dot_bias : 0.f);
     }
     if (e.plane_hi) {
         const int b = row / e.rows_per_frame, n = row - b * e.rows_per_frame;
@@ -122,7 +131,8 @@ __device__ __forceinline__ void vkn_row_epilogue(const VknEpi& e, const VknEpiCo
 
 // out[M][Nout] (tile 32 x 256) = A[M][K] . W[Nout][K]^T ; A2 != null: A := A (.) A2 elementwise.
 // gridDim = (ceil(Nout/256), ceil(M/32), ksplit).  ksplit > 1: raw partial sums to `partial` [ks][M][Nout].
-__global__ __launch_bounds__(GM_THREADS, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ A2, int lda,
+__global__ __launch_bounds__(GM_THREADS, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ A2,
+                                                        const float* __restrict__ A3, const float* __restrict__ A4, int lda,
                                                         const float* __restrict__ W, int M, int K, int Nout,
                                                         float* __restrict__ partial, VknEpi epi) {
     __shared__ __attribute__((aligned(16))) float smem[GM_BM * GM_LDA + GM_BN * GM_LDA];
@@ -144,8 +154,10 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm(const float* __restrict_
     // Prefetch loads are unconditional on clamped rows (no per-lane branches) and nothing is consumed before the
     // stash, so a whole K-tile (20 loads per thread) stays in flight behind the MFMAs of the previous tile.
     const float* A2p = A2 ? A2 : A;
-    const bool mul = (A2 != nullptr);
-    float ra0, ra1, rb0, rb1;
+    const float* A3p = A3 ? A3 : A;
+    const float* A4p = A4 ? A4 : A;
+    const bool mul = (A2 != nullptr), two = (A3 != nullptr);
+    float ra0, ra1, rb0, rb1, rc0, rc1, rd0, rd1;
     float rw[16];
     const size_t aoff0 = (size_t)min(m0 + sr, M - 1) * lda + sk;
     const size_t aoff1 = (size_t)min(m0 + sr + 16, M - 1) * lda + sk;
@@ -158,14 +170,18 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm(const float* __restrict_
         ra1 = A[aoff1 + kof_];                                                                   \
         rb0 = A2p[aoff0 + kof_];                                                                 \
         rb1 = A2p[aoff1 + kof_];                                                                 \
+        rc0 = A3p[aoff0 + kof_];                                                                 \
+        rc1 = A3p[aoff1 + kof_];                                                                 \
+        rd0 = A4p[aoff0 + kof_];                                                                 \
+        rd1 = A4p[aoff1 + kof_];                                                                 \
         _Pragma("unroll") for (int i = 0; i < 16; ++i)                                           \
             rw[i] = W[(size_t)min(n0 + sr + 16 * i, Nout - 1) * K + kof_ + sk];                  \
     } while (0)
 
 #define GM_STASH()                                                                               \
     do {                                                                                         \
-        As[sr * GM_LDA + sk] = aok0 ? (mul ? ra0 * rb0 : ra0) : 0.f;                             \
-        As[(sr + 16) * GM_LDA + sk] = aok1 ? (mul ? ra1 * rb1 : ra1) : 0.f;                      \
+        As[sr * GM_LDA + sk] = aok0 ? ((mul ? ra0 * rb0 : ra0) + (two ? rc0 * rd0 : 0.f)) : 0.f; \
+        As[(sr + 16) * GM_LDA + sk] = aok1 ? ((mul ? ra1 * rb1 : ra1) + (two ? rc1 * rd1 : 0.f)) : 0.f; \
         _Pragma("unroll") for (int i = 0; i < 16; ++i)                                           \
             Ws[(sr + 16 * i) * GM_LDA + sk] = (n0 + sr + 16 * i < Nout) ? rw[i] : 0.f;           \
     } while (0)
@@ -276,6 +292,8 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     const bool second = (nprob > 1) && (blockIdx.z == 1);
     const float* __restrict__ A = second ? p1.A : p0.A;
     const float* __restrict__ A2 = second ? p1.A2 : p0.A2;
+    const float* __restrict__ A3 = second ? p1.A3 : p0.A3;
+    const float* __restrict__ A4 = second ? p1.A4 : p0.A4;
     const int lda = second ? p1.lda : p0.lda;
     const __bf16* __restrict__ Wp = static_cast<const __bf16*>(second ? p1.Wsplit : p0.Wsplit);
     const int Nout = second ? p1.Nout : p0.Nout;
@@ -302,9 +320,11 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     const int ar = (tid >> 3) & 31, aq = tid & 7;
     const size_t aoff = (size_t)min(m0 + ar, M - 1) * lda + 4 * aq;
     const float* A2p = A2 ? A2 : A;
-    const bool mul = (A2 != nullptr);
+    const float* A3p = A3 ? A3 : A;
+    const float* A4p = A4 ? A4 : A;
+    const bool mul = (A2 != nullptr), two = (A3 != nullptr);
     const __bf16* wtile0 = Wp + (size_t)blockIdx.x * ktiles * GS_WTILE;  // this column tile's images, K-tile major
-    f32x4 ra, rb;
+    f32x4 ra, rb, rc, rd;
 
     // weight tile KT -> LDS buffer BUF: 3072 x 16 B, 6 DMA instructions per thread; piece index = i*512 + tid, so every
     // wave writes 64 consecutive slots (the DMA's LDS address is wave base + lane*16) from 1 KB of contiguous global memory
@@ -321,6 +341,8 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     do {                                                                           \
         ra = *reinterpret_cast<const f32x4*>(A + aoff + (size_t)(KT) * 32);        \
         rb = *reinterpret_cast<const f32x4*>(A2p + aoff + (size_t)(KT) * 32);      \
+        rc = *reinterpret_cast<const f32x4*>(A3p + aoff + (size_t)(KT) * 32);      \
+        rd = *reinterpret_cast<const f32x4*>(A4p + aoff + (size_t)(KT) * 32);      \
     } while (0)
 
 #define GS_ASTASH(BUF)                                                                                \
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
         if (a_role) {                                                                                 \
             bf16x4 h_, m_, l_;                                                                        \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
-                const float v_ = mul ? ra[e] * rb[e] : ra[e];                                         \
+                const float v_ = (mul ? ra[e] * rb[e] : ra[e]) + (two ? rc[e] * rd[e] : 0.f);         \
                 __bf16 hh_, mm_, ll_;                                                                 \
                 vkn_split_bf16x3(v_, hh_, mm_, ll_);                                                  \
                 h_[e] = hh_;                                                                          \
@@ -643,15 +665,16 @@ __global__ __launch_bounds__(256) void k_upsample(const float* __restrict__ in, 
 // ------------------------------------------------------------------------------------------------ host launchers
 static int gemm_check(const VknGemmProb& p, int M, int K, int ksplit, const float* partial) {
     if (M <= 0 || K <= 0 || p.Nout <= 0 || K % GM_KT != 0) return VKN_E_SHAPE;
-    const bool rowwise = p.epi.ln_w || p.epi.dot_vec;  // needs the whole row in one tile
-    if (rowwise && p.Nout > GM_BN) return VKN_E_SHAPE;
+    // LayerNorm / dot side output need the whole (sub-)row in one 256-column tile
+    if (p.epi.dot_vec && p.Nout > GM_BN) return VKN_E_SHAPE;
+    if (p.epi.ln_w && (p.Nout - p.epi.ln_from_col > GM_BN || p.epi.ln_from_col % GM_BN != 0)) return VKN_E_SHAPE;
     if (ksplit > 1 && (p.Nout > GM_BN || !partial)) return VKN_E_SHAPE;
     return VKN_OK;
 }
 
 static int gemm_one_exact(const VknGemmProb& p, int M, int K, int ksplit, float* partial, hipStream_t stream) {
     dim3 grid((p.Nout + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, ksplit);
-    hipLaunchKernelGGL(k_gemm, grid, dim3(GM_THREADS), 0, stream, p.A, p.A2, p.lda, p.W, M, K, p.Nout, partial, p.epi);
+    hipLaunchKernelGGL(k_gemm, grid, dim3(GM_THREADS), 0, stream, p.A, p.A2, p.A3, p.A4, p.lda, p.W, M, K, p.Nout, partial, p.epi);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
@@ -693,12 +716,26 @@ int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int
 
 int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, const void* Wsplit, int M, int K, int Nout,
                     int ksplit, float* partial, const VknEpi& epi, hipStream_t stream) {
-    VknGemmProb p{A, A2, lda, W, Wsplit, Nout, epi};
+    VknGemmProb p{A, A2, nullptr, nullptr, lda, W, Wsplit, Nout, epi};
     return vkn_launch_gemm_group(&p, 1, M, K, ksplit, partial, stream);
 }
 
 // bytes of the pre-split tile images of a [Nout][K] weight
 size_t vkn_split_w3_bytes(int Nout, int K) { return (size_t)((Nout + 255) / 256) * (K / 32) * GS_WTILE * sizeof(__bf16); }
+
+__global__ void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * Cc) return;
+    const int r = i / Cc, c = i - r * Cc;
+    dst[(size_t)c * R + r] = src[i];
+}
+
+int vkn_launch_transpose(const float* src, float* dst, int R, int Cc, hipStream_t st) {
+    const int n = R * Cc;
+    hipLaunchKernelGGL(k_transpose, dim3((n + 255) / 256), dim3(256), 0, st, src, dst, R, Cc);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
 
 // fp32 W [Nout][K] -> tile images (K % 32 == 0)
 int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream) {
