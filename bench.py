@@ -167,10 +167,10 @@ def main():
     with torch.no_grad():
         # untimed settle phase before the W warm-up steps: a step is < 2 ms, so a handful of warm-up steps alone would leave the
         # caching allocator, the clocks and the lazily loaded code objects cold on a fresh box
-        t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < 1.0:
+        # (fixed count, not wall time: step() holds a collective when world > 1, so every rank must run the same number)
+        for _ in range(300):
             step()
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
         barrier()
