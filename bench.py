@@ -95,6 +95,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--settle', type=int, default=300, help='untimed settle steps before the warm-up (profiling runs use few)')
     ap.add_argument('--frames', type=int, default=8, help='frames of the clip per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
@@ -168,7 +169,7 @@ def main():
         # untimed settle phase before the W warm-up steps: a step is < 2 ms, so a handful of warm-up steps alone would leave the
         # caching allocator, the clocks and the lazily loaded code objects cold on a fresh box
         # (fixed count, not wall time: step() holds a collective when world > 1, so every rank must run the same number)
-        for _ in range(300):
+        for _ in range(args.settle):
             step()
         torch.cuda.synchronize()
         for _ in range(args.warmup):
