@@ -172,6 +172,27 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
                          float* cls_prob, float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out,
                          void* ws, size_t ws_bytes, unsigned flags, void* stream);
 
+/* ---- kernel initialisation ("pass 0").  Replaces `ConvKernelHead._decode_init_proposals` AFTER its loc / seg convs
+ *      (knet/det/kernel_head.py:204-263; `simple_test_rpn` :506-508), i.e. everything between the localization FPN's two feature
+ *      maps and the first `KernelUpdateHead`:
+ *        mask_preds[:, :Np]  = init_kernels(loc_feats)                     1x1 conv, no bias, frame-shared kernels   (:222)
+ *        seg_preds           = conv_seg(sem_feats)                         1x1 conv + bias                           (:231-234)
+ *        x_feats             = sem_feats + loc_feats                                                                (:238-241)
+ *        obj_feats           = einsum('bnhw,bchw->bnc', (sigmoid(mask_preds) > 0.5).float(), x_feats)  (use_binary) (:243-250)
+ *        proposal_feats      = init_kernels.weight + obj_feats                                                      (:234, :252-254)
+ *        cat_stuff (eval):     mask_preds[:, Np:] = seg_preds[:, num_thing_classes:],
+ *                              proposal_feats[:, Np:] = conv_seg.weight[num_thing_classes:]                         (:255-263)
+ *      in : loc_feats, sem_feats [B][C][P] (sem_feats NULL: semantic_fpn=False, then x_feats = loc_feats);
+ *           init_w [Np][C]; seg_w [ncls][C], seg_b [ncls]; with_obj = proposal_feats_with_obj; thr_logit as in VknDims.
+ *      out: x_feats [B][C][P]; mask_preds [B][N][P] and proposal_feats [B][N][C] with N = Np + (cat_stuff ? ncls -
+ *           num_thing_classes : 0); seg_preds [B][ncls][P] or NULL (kept in the workspace).
+ *      `use_binary=False` (soft weights) is not provided: every shipped config sets use_binary=True. */
+size_t vkn_kernel_init_workspace_bytes(int B, int Np, int ncls, int C, int P);
+int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const float* init_w, const float* seg_w,
+                        const float* seg_b, int num_thing_classes, int cat_stuff, int with_obj, float thr_logit, float* x_feats,
+                        float* mask_preds, float* seg_preds, float* proposal_feats, int B, int Np, int ncls, int C, int P,
+                        void* ws, size_t ws_bytes, unsigned flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,8 @@ import knet.det.kernel_update_head  # noqa: E402,F401
 import knet.det.kernel_iter_head  # noqa: E402,F401
 import knet.video.kernel_update_head  # noqa: E402,F401
 import knet.video.kernel_iter_head  # noqa: E402,F401
-from mmdet.models.builder import build_head  # noqa: E402
+import knet.det.kernel_head  # noqa: E402,F401  (ConvKernelHead: the kernel-initialisation pass)
+from mmdet.models.builder import NECKS, build_head  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
 
@@ -159,6 +160,82 @@ def run_case(name, p):
     print(f'{name}: ok  max|mask|={float(m.abs().max()):.2f}')
 
 
+@NECKS.register_module()
+class PassThroughNeck(torch.nn.Module):
+    """Test plumbing: stands where `SemanticFPNWrapper` sits and hands the two feature maps straight through, so that
+    `ConvKernelHead._decode_init_proposals` runs exactly the part SURVEY.md §8(f)-2 scopes (no loc/seg convs)."""
+
+    def forward(self, feats):
+        return [feats[0], feats[1]] if len(feats) == 2 else feats[0]
+
+
+INIT_CASES = {
+    'init_tiny': dict(C=64, nprop=12, ncls=5, n_thing=2, H=8, W=16, B=2, seed=21, sem=True, cat=True),
+    'init_odd': dict(C=64, nprop=21, ncls=0, n_thing=0, H=9, W=15, B=1, seed=22, sem=False, cat=False),
+    'init_cfg': dict(C=256, nprop=100, ncls=19, n_thing=2, H=16, W=32, B=2, seed=23, sem=True, cat=True),
+}
+
+
+def init_inputs(p):
+    """loc / semantic features and the ConvKernelHead weights of an init case (hash-formula, regenerated by the tests)."""
+    B, C, H, W, seed = p['B'], p['C'], p['H'], p['W'], p['seed']
+    loc = synth.normalish((B, C, H, W), 31 + 7 * seed, 1.0)
+    sem = synth.normalish((B, C, H, W), 32 + 7 * seed, 1.0) if p['sem'] else None
+    shapes = {'init_kernels.weight': (p['nprop'], C, 1, 1)}
+    if p['sem']:
+        shapes['conv_seg.weight'] = (p['ncls'], C, 1, 1)
+        shapes['conv_seg.bias'] = (p['ncls'],)
+    return loc, sem, shapes
+
+
+def run_init_case(name, p):
+    """ConvKernelHead.simple_test_rpn of the reference (knet/det/kernel_head.py:506-508) behind a pass-through neck."""
+    cfg = dict(type='ConvKernelHead', num_proposals=p['nprop'], in_channels=p['C'], out_channels=p['C'], num_loc_convs=0,
+               num_seg_convs=0, localization_fpn=dict(type='PassThroughNeck'), conv_kernel_size=1, semantic_fpn=p['sem'],
+               num_classes=max(p['ncls'], 1), use_binary=True, proposal_feats_with_obj=True, feat_downsample_stride=1,
+               num_thing_classes=p['n_thing'], num_stuff_classes=p['ncls'] - p['n_thing'], cat_stuff_mask=p['cat'])
+    head = build_head(cfg)
+    head.eval()
+    loc, sem, shapes = init_inputs(p)
+    assert {k: tuple(v.shape) for k, v in head.state_dict().items()} == shapes, head.state_dict().keys()
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, p['seed']).items()}
+    head.load_state_dict(sd, strict=True)
+    feats = (torch.from_numpy(loc), torch.from_numpy(sem)) if p['sem'] else (torch.from_numpy(loc),)
+    with torch.no_grad():
+        prop, x_feats, masks, cls, seg = head.simple_test_rpn(feats, [dict() for _ in range(p['B'])])
+    assert cls is None
+    out = dict(case=np.array([p['C'], p['nprop'], p['ncls'], p['n_thing'], p['H'], p['W'], p['B'], p['seed'], int(p['sem']),
+                              int(p['cat'])], dtype=np.int64),
+               keys=np.array(sorted(shapes)), shapes=np.array([str(shapes[k]) for k in sorted(shapes)]),
+               proposal_feats=prop.numpy(), mask_preds=masks.numpy())
+    if p['C'] <= 64:
+        out['x_feats'] = x_feats.numpy()
+    else:
+        out['x_feats_rowsum'] = x_feats.double().sum(dim=(-1, -2)).numpy()
+    if seg is not None:
+        out['seg_preds'] = seg.numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    frac = float((masks[:, :p['nprop']] > 0).float().mean())
+    print(f'{name}: ok  N={masks.shape[1]} on-fraction={frac:.3f} max|prop|={float(prop.abs().max()):.1f}')
+
+
+def init_keys():
+    """state-dict keys / shapes of the reference's ConvKernelHead under the shipped rpn_head kwargs
+    (configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:29-61; neck replaced by the pass-through), plus the
+    feat_refine=True variant that adds ins_downsample / seg_downsample."""
+    out = {}
+    for tag, refine in (('kitti', False), ('refine', True)):
+        cfg = dict(type='ConvKernelHead', num_classes=19, num_thing_classes=2, num_stuff_classes=17, cat_stuff_mask=True,
+                   conv_kernel_size=1, feat_downsample_stride=2, feat_refine_stride=1, feat_refine=refine, use_binary=True,
+                   num_loc_convs=1, num_seg_convs=1, conv_normal_init=True, localization_fpn=dict(type='PassThroughNeck'),
+                   num_proposals=100, proposal_feats_with_obj=True, xavier_init_kernel=False, kernel_init_std=1)
+        sd = build_head(cfg).state_dict()
+        out[tag + '_keys'] = np.array(sorted(sd))
+        out[tag + '_shapes'] = np.array([str(tuple(sd[k].shape)) for k in sorted(sd)])
+    np.savez_compressed(os.path.join(OUT, 'init_keys.npz'), **out)
+    print('init_keys: ok', len(out['kitti_keys']), len(out['refine_keys']))
+
+
 def thr_kat():
     """(sigmoid(z) > 0.5) as the reference computes it (knet/det/kernel_update_head.py:190-191) — torch CPU fp32.
     The flip point is not z=0: it depends on the fp32 sigmoid (SURVEY.md §7 'Threshold semantics')."""
@@ -190,5 +267,10 @@ if __name__ == '__main__':
     for name, p in CASES.items():
         if not only or name in only:
             run_case(name, p)
+    for name, p in INIT_CASES.items():
+        if not only or name in only:
+            run_init_case(name, p)
+    if not only or 'init_keys' in only:
+        init_keys()
     if not only or 'thr_kat' in only:
         thr_kat()

@@ -251,3 +251,27 @@ def head_param_shapes(cfg: HeadCfg, prefix='mask_head'):
         for k, v in stage_param_shapes(cfg).items():
             out[f'{prefix}.{s}.{k}'] = v
     return out
+
+
+def kernel_init(init_w, loc_feats, semantic_feats=None, seg_w=None, seg_b=None, num_thing_classes=0, cat_stuff_mask=False,
+                proposal_feats_with_obj=True, use_binary=True):
+    """ConvKernelHead._decode_init_proposals after the loc / seg convs, eval mode        knet/det/kernel_head.py:204-263
+    init_w [Np,C,1,1] = init_kernels.weight; seg_w [ncls,C,1,1], seg_b [ncls] = conv_seg.
+    Returns (proposal_feats [B,N,C,1,1], x_feats, mask_preds [B,N,H,W], seg_preds | None)."""
+    B = loc_feats.shape[0]
+    Np, C = init_w.shape[0], init_w.shape[1]
+    mask_preds = F.conv2d(loc_feats, init_w)                                                       # :222
+    seg_preds = F.conv2d(semantic_feats, seg_w, seg_b) if semantic_feats is not None else None     # :231-234
+    proposal_feats = init_w[None].expand(B, *init_w.shape)                                         # :234-236
+    x_feats = semantic_feats + loc_feats if semantic_feats is not None else loc_feats              # :238-241
+    if proposal_feats_with_obj:
+        sig = mask_preds.sigmoid()                                                                 # :243-250
+        nz = sig > 0.5
+        w = nz.float() if use_binary else nz.float() * sig
+        obj = torch.einsum('bnhw,bchw->bnc', w, x_feats)
+        proposal_feats = proposal_feats + obj.view(B, Np, C, 1, 1)                                 # :252-254
+    if cat_stuff_mask:                                                                             # :255-263 (eval)
+        mask_preds = torch.cat([mask_preds, seg_preds[:, num_thing_classes:]], dim=1)
+        stuff = seg_w[num_thing_classes:]
+        proposal_feats = torch.cat([proposal_feats, stuff[None].expand(B, *stuff.shape)], dim=1)
+    return proposal_feats, x_feats, mask_preds, seg_preds

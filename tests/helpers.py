@@ -46,3 +46,25 @@ def maxabs(a, b):
     a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
     b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+INIT_FIELDS = ('C', 'nprop', 'ncls', 'n_thing', 'H', 'W', 'B', 'seed', 'sem', 'cat')
+
+
+def load_init_golden(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+    return g, dict(zip(INIT_FIELDS, (int(v) for v in g['case'])))
+
+
+def make_init_case(case):
+    """(loc, sem|None, init_w, seg_w|None, seg_b|None) of a kernel-initialisation golden, from the hash formulas
+    (same recipe as oracle/gen_golden.py:init_inputs)."""
+    B, C, H, W, seed = case['B'], case['C'], case['H'], case['W'], case['seed']
+    loc = torch.from_numpy(synth.normalish((B, C, H, W), 31 + 7 * seed, 1.0))
+    sem = torch.from_numpy(synth.normalish((B, C, H, W), 32 + 7 * seed, 1.0)) if case['sem'] else None
+    shapes = {'init_kernels.weight': (case['nprop'], C, 1, 1)}
+    if case['sem']:
+        shapes['conv_seg.weight'] = (case['ncls'], C, 1, 1)
+        shapes['conv_seg.bias'] = (case['ncls'],)
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, seed).items()}
+    return loc, sem, sd['init_kernels.weight'], sd.get('conv_seg.weight'), sd.get('conv_seg.bias')

@@ -308,3 +308,110 @@ def test_cfg2_size_head_vs_oracle(vkn):
             o2, m2 = r['object_feats'], r['mask_preds']
     assert torch.equal(masks, m2) and torch.equal(obj, o2) and torch.equal(scaled, r['scaled_mask_preds'])
     assert torch.equal(track, r['object_feats_track']) and torch.equal(cls, r['cls_score'].sigmoid())
+
+
+# ------------------------------------------------------------------------------------------ kernel initialisation ("pass 0")
+def _init_rows_off_threshold(masks_golden, nprop, thr, margin=1e-4):
+    """rows (b, n) of the thing masks without any logit within `margin` of the binarisation threshold: their object features are
+    insensitive to fp32 summation order of the decode."""
+    m = torch.from_numpy(masks_golden[:, :nprop])
+    return ((m - thr).abs().flatten(2).min(dim=2).values > margin)
+
+
+@pytest.mark.parametrize('flags', [0, 1], ids=['mfma', 'refkernels'])
+@pytest.mark.parametrize('name', ['init_tiny', 'init_odd', 'init_cfg'])
+def test_kernel_init_vs_oracle_and_reference(vkn, name, flags):
+    """vkn_kernel_init_f32 vs the reference's ConvKernelHead.simple_test_rpn (golden) and vs the oracle."""
+    from helpers import load_init_golden, make_init_case
+    g, case = load_init_golden(name)
+    loc, sem, iw, sw, sb = make_init_case(case)
+    dl, ds, diw, dsw, dsb = _cuda(loc, sem, iw, sw, sb)
+    prop, xf, masks, seg = vkn.ops.kernel_init(dl, ds, diw, dsw, dsb, case['n_thing'], bool(case['cat']), True, flags=flags)
+    torch.cuda.synchronize()
+    nprop = case['nprop']
+    assert tuple(masks.shape) == g['mask_preds'].shape and tuple(prop.shape) == g['proposal_feats'].shape[:3]
+    assert maxabs(masks, g['mask_preds']) < TOL_LOGIT * 0.1
+    if seg is not None:
+        assert maxabs(seg, g['seg_preds']) < TOL_LOGIT * 0.1
+        # the concatenated stuff rows are the seg_preds rows, bit for bit
+        assert torch.equal(masks[:, nprop:], seg[:, case['n_thing']:])
+    # x_feats = sem + loc: one fp32 add per element -> bit-exact
+    if sem is not None:
+        assert torch.equal(xf.cpu(), sem + loc)
+    else:
+        assert xf.data_ptr() == dl.data_ptr()
+    # proposal_feats: (a) teacher-forced through the oracle's einsum on the GPU's own logits -> tight
+    thr = vkn.ops.thr_logit(0.5)
+    bits = (masks[:, :nprop].cpu() >= thr).float()
+    obj = torch.einsum('bnhw,bchw->bnc', bits.double(), (xf.cpu()).double())
+    want = iw.reshape(1, nprop, -1).double() + obj
+    got = prop[:, :nprop].cpu().double()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < 2e-5 * max(scale, 1.0)
+    # (b) against the reference golden on every row whose logits stay clear of the threshold
+    ok = _init_rows_off_threshold(g['mask_preds'], nprop, thr)
+    assert float(ok.float().mean()) > 0.3
+    gp = torch.from_numpy(g['proposal_feats']).reshape(prop.shape).double()
+    err = (prop.cpu().double() - gp)[:, :nprop][ok]
+    assert float(err.abs().max()) < 2e-4 * max(scale, 1.0)
+    if case['cat']:
+        # stuff kernels are copies of conv_seg.weight[num_thing:]
+        assert torch.equal(prop[:, nprop:].cpu(), sw[case['n_thing']:].reshape(1, -1, case['C']).expand(case['B'], -1, -1))
+
+
+def test_kernel_init_feeds_the_head(vkn):
+    """pass 0 -> S-stage head on the GPU equals the oracle chain fed with the same (GPU) pass-0 outputs."""
+    from helpers import load_init_golden, make_init_case
+    g, icase = load_init_golden('init_tiny')
+    loc, sem, iw, sw, sb = make_init_case(icase)
+    prop, xf, masks, _ = vkn.ops.kernel_init(*_cuda(loc, sem, iw, sw, sb), icase['n_thing'], True, True)
+    _, hcase = load_golden('det_tiny')   # same C / N / H / W as init_tiny
+    assert hcase['N'] == masks.shape[1] and hcase['C'] == icase['C']
+    cfg, sd, *_ = make_case(hcase)
+    head, _ = _build_head(vkn, hcase)
+    o, c, m, sc = head.simple_test_mask_preds(xf, prop.reshape(*prop.shape, 1, 1), masks, None, [dict()] * icase['B'])
+    with torch.no_grad():
+        ro, rc, rm, rsc, _ = O.iter_head_mask_preds(sd, xf.cpu(), prop.cpu().reshape(*prop.shape, 1, 1), masks.cpu(), cfg)
+    assert maxabs(m, rm) < TOL_LOGIT and maxabs(c, rc) < 1e-4 and maxabs(o.reshape(ro.shape), ro) < 1e-3
+
+
+def test_kernel_init_cfg2_size(vkn):
+    """BASELINE cfg2 size: shared-kernel decode + strided gather at B = 2, 128x256, against fp64 on the device."""
+    B, Np, ncls, nth, C, H, W = 2, 100, 19, 2, 256, 128, 256
+    loc, sem = _rand((B, C, H, W), 501).to(DEV), _rand((B, C, H, W), 502).to(DEV)
+    iw = (_rand((Np, C, 1, 1), 503, 0.05)).to(DEV)
+    sw, sb = _rand((ncls, C, 1, 1), 504, 0.05).to(DEV), _rand((ncls,), 505).to(DEV)
+    prop, xf, masks, seg = vkn.ops.kernel_init(loc, sem, iw, sw, sb, nth, True, True)
+    assert torch.equal(xf, sem + loc)
+    want_m = torch.einsum('nc,bchw->bnhw', iw.reshape(Np, C).double(), loc.double())
+    want_s = torch.einsum('nc,bchw->bnhw', sw.reshape(ncls, C).double(), sem.double()) + sb.double().view(1, -1, 1, 1)
+    assert maxabs(masks[:, :Np], want_m) < 1e-4 and maxabs(seg, want_s) < 1e-4
+    assert torch.equal(masks[:, Np:], seg[:, nth:])
+    bits = (masks[:, :Np] >= vkn.ops.thr_logit(0.5)).double()
+    want_p = iw.reshape(1, Np, C).double() + torch.einsum('bnhw,bchw->bnc', bits, xf.double())
+    assert maxabs(prop[:, :Np], want_p) < 2e-5 * float(want_p.abs().max())
+
+
+def test_conv_kernel_head_class_matches_reference_golden(vkn):
+    """The registry class end to end: a pass-through neck, reference-shaped checkpoint, `simple_test_rpn` 5-tuple."""
+    from helpers import load_init_golden, make_init_case
+    g, case = load_init_golden('init_cfg')
+    loc, sem, iw, sw, sb = make_init_case(case)
+
+    class Neck(torch.nn.Module):
+        def forward(self, feats):
+            return [feats[0], feats[1]]
+
+    head = vkn.build_head(dict(type='ConvKernelHead', num_proposals=case['nprop'], in_channels=case['C'], out_channels=case['C'],
+                               num_loc_convs=0, num_seg_convs=0, localization_fpn=Neck(), semantic_fpn=True,
+                               num_classes=case['ncls'], use_binary=True, proposal_feats_with_obj=True,
+                               num_thing_classes=case['n_thing'], num_stuff_classes=case['ncls'] - case['n_thing'],
+                               cat_stuff_mask=True))
+    head.load_state_dict({'init_kernels.weight': iw, 'conv_seg.weight': sw, 'conv_seg.bias': sb}, strict=True)
+    head = head.to(DEV).eval()
+    prop, xf, masks, cls, seg = head.simple_test_rpn((loc.to(DEV), sem.to(DEV)), [dict()] * case['B'])
+    assert cls is None and tuple(prop.shape) == g['proposal_feats'].shape
+    assert maxabs(masks, g['mask_preds']) < TOL_LOGIT * 0.1 and maxabs(seg, g['seg_preds']) < TOL_LOGIT * 0.1
+    ok = _init_rows_off_threshold(g['mask_preds'], case['nprop'], vkn.ops.thr_logit(0.5))
+    err = (prop.cpu() - torch.from_numpy(g['proposal_feats']))[:, :case['nprop']].flatten(2)[ok]
+    assert float(err.abs().max()) < 2e-4 * float(np.abs(g['proposal_feats']).max())

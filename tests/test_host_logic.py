@@ -130,3 +130,25 @@ def test_threshold_logit_matches_reference_flip_point(vkn):
         tz = np.float32(vkn.ops.thr_logit(thr))
         z = (tz.view(np.uint32).astype(np.int64) + np.arange(-64, 64)).astype(np.uint32).view(np.float32)
         assert np.array_equal(z >= tz, (torch.from_numpy(z).sigmoid() > thr).numpy())
+
+
+@pytest.mark.parametrize('tag,refine', [('kitti', False), ('refine', True)])
+def test_conv_kernel_head_state_dict_matches_reference(vkn, tag, refine):
+    """ConvKernelHead under the shipped rpn_head kwargs (configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:29-61): same
+    state-dict keys and shapes as the reference (captured by oracle/gen_golden.py:init_keys)."""
+    g = dict(np.load(os.path.join(GOLDEN, 'init_keys.npz'), allow_pickle=False))
+    head = vkn.build_head(dict(type='ConvKernelHead', num_classes=19, num_thing_classes=2, num_stuff_classes=17,
+                               cat_stuff_mask=True, conv_kernel_size=1, feat_downsample_stride=2, feat_refine_stride=1,
+                               feat_refine=refine, use_binary=True, num_loc_convs=1, num_seg_convs=1, conv_normal_init=True,
+                               localization_fpn=None, num_proposals=100, proposal_feats_with_obj=True,
+                               xavier_init_kernel=False, kernel_init_std=1))
+    sd = head.state_dict()
+    assert sorted(sd) == list(g[tag + '_keys'])
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == list(g[tag + '_shapes'])
+    head.init_weights()
+    with pytest.raises(NotImplementedError):
+        vkn.build_head(dict(type='ConvKernelHead', proposal_feats_with_obj=True, use_binary=False))
+    with pytest.raises(NotImplementedError):
+        vkn.build_head(dict(type='ConvKernelHead', conv_kernel_size=3))
+    with pytest.raises(vkn.VknLibraryError):   # CPU tensors: no fallback
+        head.eval().decode_init_proposals_from_feats(torch.zeros(1, 256, 4, 8), torch.zeros(1, 256, 4, 8))

@@ -77,3 +77,23 @@ def test_oracle_fp64_headroom():
     o32 = run_oracle(case, torch.float32)
     o64 = run_oracle(case, torch.float64)
     assert maxabs(o32[2], o64[2]) < 1e-3
+
+
+@pytest.mark.parametrize('name', ['init_tiny', 'init_odd', 'init_cfg'])
+def test_kernel_init_oracle_matches_reference_golden(name):
+    """oracle.kernel_init == the reference's ConvKernelHead.simple_test_rpn (behind a pass-through neck)."""
+    from helpers import load_init_golden, make_init_case
+    from oracle.knet_oracle import kernel_init
+    g, case = load_init_golden(name)
+    loc, sem, iw, sw, sb = make_init_case(case)
+    with torch.no_grad():
+        prop, xf, masks, seg = kernel_init(iw, loc, sem, sw, sb, case['n_thing'], bool(case['cat']))
+    assert tuple(prop.shape) == g['proposal_feats'].shape and tuple(masks.shape) == g['mask_preds'].shape
+    assert maxabs(masks, g['mask_preds']) < 1e-5
+    assert maxabs(prop, g['proposal_feats']) < 2e-4     # sums of ~P/2 unit-variance features
+    if 'x_feats' in g:
+        assert maxabs(xf, g['x_feats']) == 0.0
+    else:
+        assert maxabs(xf.double().sum(dim=(-1, -2)), g['x_feats_rowsum']) < 1e-9
+    if seg is not None:
+        assert maxabs(seg, g['seg_preds']) < 1e-5

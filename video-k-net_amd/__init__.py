@@ -1,7 +1,7 @@
 """video_k_net_amd — MI355X-native kernel-update head for Video K-Net (directory `video-k-net_amd/`).
 
 Importing this package registers `KernelUpdator` (TRANSFORMER_LAYER) and `KernelUpdateHead`, `VideoKernelUpdateHead`,
-`KernelIterHead`, `VideoKernelIterHead` (HEADS) — into mmcv/mmdet's registries when they are importable, else into the bundled
+`KernelIterHead`, `VideoKernelIterHead`, `ConvKernelHead` (HEADS) — into mmcv/mmdet's registries when they are importable, else into the bundled
 ones — so the reference's config dicts build these classes unchanged.  All arithmetic runs in
 `lib/libvkn.so` (hand-written HIP for gfx950, C ABI in include/vkn.h); there is no CPU fallback.
 """
@@ -10,8 +10,9 @@ from ._lib import VknError, VknLibraryError, build  # noqa: F401
 from .kernel_updator import KernelUpdator  # noqa: F401
 from .kernel_update_head import KernelUpdateHead, VideoKernelUpdateHead  # noqa: F401
 from .kernel_iter_head import KernelIterHead, VideoKernelIterHead  # noqa: F401
+from .kernel_head import ConvKernelHead  # noqa: F401
 from .registry import HEADS, TRANSFORMER_LAYER, build_head, build_transformer_layer  # noqa: F401
 
-__all__ = ['KernelUpdator', 'KernelUpdateHead', 'VideoKernelUpdateHead', 'KernelIterHead', 'VideoKernelIterHead',
+__all__ = ['KernelUpdator', 'KernelUpdateHead', 'VideoKernelUpdateHead', 'KernelIterHead', 'VideoKernelIterHead', 'ConvKernelHead',
            'HEADS', 'TRANSFORMER_LAYER', 'build_head', 'build_transformer_layer', 'ops', 'build', 'VknError',
            'VknLibraryError']

@@ -11,14 +11,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
-SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_api.hip')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_init.hip', 'vkn_api.hip')
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares
 SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_weights', 'vkn_gather_workspace_bytes', 'vkn_mask_gather_f32',
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
            'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
-           'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32')
+           'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32',
+           'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32')
 
 
 class VknLibraryError(RuntimeError):
@@ -146,6 +147,10 @@ def lib():
     L.vkn_head_workspace_bytes.argtypes = [pD]
     L.vkn_head_forward_f32.restype = c_int
     L.vkn_head_forward_f32.argtypes = [pD, c_int, pW] + [_fp] * 8 + [c_int, _fp, _fp, c_size, c_uint, _fp]
+    L.vkn_kernel_init_workspace_bytes.restype = c_size
+    L.vkn_kernel_init_workspace_bytes.argtypes = [c_int] * 5
+    L.vkn_kernel_init_f32.restype = c_int
+    L.vkn_kernel_init_f32.argtypes = [_fp] * 5 + [c_int, c_int, c_int, c_float] + [_fp] * 4 + [c_int] * 5 + [_fp, c_size, c_uint, _fp]
     _LIB = L
     return L
 

@@ -376,6 +376,26 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     return VKN_OK;
 }
 
+// workspace of the kernel-initialisation pass
+struct InitWs {
+    _Float16 *ih, *il, *sh, *sl;
+    float *part, *cntp, *cnt, *obj, *seg;
+};
+size_t carve_init(int B, int Np, int ncls, int C, int P, bool need_seg, char* base, InitWs* s) {
+    Carver c{base, 0};
+    const size_t G = vkn_gather_groups(B, P), NPTp = npt_of(Np), NPTs = npt_of(ncls > 0 ? ncls : 1);
+    s->ih = c.take<_Float16>(NPTp * C);
+    s->il = c.take<_Float16>(NPTp * C);
+    s->sh = c.take<_Float16>(NPTs * C);
+    s->sl = c.take<_Float16>(NPTs * C);
+    s->part = c.take<float>((size_t)B * G * NPTp * C);
+    s->cntp = c.take<float>((size_t)B * G * NPTp);
+    s->cnt = c.take<float>((size_t)B * Np);
+    s->obj = c.take<float>((size_t)B * Np * C);
+    s->seg = need_seg ? c.take<float>((size_t)B * ncls * P) : nullptr;
+    return (c.off + 255) & ~(size_t)255;
+}
+
 }  // namespace
 
 extern "C" {
@@ -486,6 +506,75 @@ int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, in
     if (!in || !out || planes <= 0 || H <= 0 || W <= 0) return VKN_E_ARG;
     if (!aligned16(in) || !aligned16(out)) return VKN_E_ALIGN;
     return vkn_launch_upsample(in, out, planes, H, W, S, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------- kernel initialisation
+size_t vkn_kernel_init_workspace_bytes(int B, int Np, int ncls, int C, int P) {
+    if (B <= 0 || Np <= 0 || C <= 0 || P <= 0 || ncls < 0) return 0;
+    InitWs s;
+    return carve_init(B, Np, ncls, C, P, true, nullptr, &s);
+}
+
+int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const float* init_w, const float* seg_w,
+                        const float* seg_b, int num_thing_classes, int cat_stuff, int with_obj, float thr_logit, float* x_feats,
+                        float* mask_preds, float* seg_preds, float* proposal_feats, int B, int Np, int ncls, int C, int P,
+                        void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    if (!loc_feats || !init_w || !mask_preds || !proposal_feats || B <= 0 || Np <= 0 || C <= 0 || P <= 0) return VKN_E_ARG;
+    const bool sem = sem_feats != nullptr;
+    if (sem && (!seg_w || ncls <= 0 || !x_feats)) return VKN_E_ARG;
+    if (cat_stuff && (!sem || num_thing_classes < 0 || num_thing_classes > ncls)) return VKN_E_ARG;
+    if (!aligned16(loc_feats) || !aligned16(sem_feats) || !aligned16(mask_preds) || !aligned16(x_feats) || !aligned16(seg_preds) ||
+        !aligned16(proposal_feats) || !aligned16(init_w) || !aligned16(seg_w))
+        return VKN_E_ALIGN;
+    const int nstuff = cat_stuff ? ncls - num_thing_classes : 0, N = Np + nstuff;
+    if (C % 32 != 0 || C > 256 || Np > 256 || ncls > 256) return VKN_E_SHAPE;
+    InitWs s;
+    const size_t need = carve_init(B, Np, ncls, C, P, sem && !seg_preds, nullptr, &s);
+    if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
+    carve_init(B, Np, ncls, C, P, sem && !seg_preds, static_cast<char*>(ws), &s);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool ref = (flags & VKN_FLAG_REF_KERNELS) != 0, ref_decode = ref || (P & 1);
+
+    // mask_preds[:, :Np] = init_kernels(loc_feats): 1x1 conv, no bias, the same kernels for every frame          (:222)
+    if (ref_decode) {
+        VKN_TRY(vkn_launch_decode_ref_ex(loc_feats, init_w, nullptr, mask_preds, B, Np, C, P, 1, N, st));
+    } else {
+        VKN_TRY(vkn_launch_split_planes(init_w, s.ih, s.il, 1, Np, C, st));
+        VKN_TRY(vkn_launch_decode_ex(loc_feats, s.ih, s.il, nullptr, mask_preds, B, Np, C, P, 1, N, st));
+    }
+    const float* xf = loc_feats;
+    if (sem) {
+        // seg_preds = conv_seg(semantic_feats)                                                                   (:231-234)
+        float* seg = seg_preds ? seg_preds : s.seg;
+        if (ref_decode) {
+            VKN_TRY(vkn_launch_decode_ref_ex(sem_feats, seg_w, seg_b, seg, B, ncls, C, P, 1, ncls, st));
+        } else {
+            VKN_TRY(vkn_launch_split_planes(seg_w, s.sh, s.sl, 1, ncls, C, st));
+            VKN_TRY(vkn_launch_decode_ex(sem_feats, s.sh, s.sl, seg_b, seg, B, ncls, C, P, 1, ncls, st));
+        }
+        // mask_preds[:, Np:] = seg_preds[:, num_thing_classes:]  (cat_stuff_mask, inference)                      (:255-257)
+        if (nstuff > 0) {
+            if (hipMemcpy2DAsync(mask_preds + (size_t)Np * P, (size_t)N * P * sizeof(float), seg + (size_t)num_thing_classes * P,
+                                 (size_t)ncls * P * sizeof(float), (size_t)nstuff * P * sizeof(float), B,
+                                 hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return VKN_E_LAUNCH;
+        }
+        // x_feats = semantic_feats + loc_feats                                                                   (:238-241)
+        VKN_TRY(vkn_launch_add2(sem_feats, loc_feats, x_feats, (size_t)B * C * P, st));
+        xf = x_feats;
+    } else if (x_feats && x_feats != loc_feats) {
+        if (hipMemcpyAsync(x_feats, loc_feats, (size_t)B * C * P * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return VKN_E_LAUNCH;
+    }
+    // obj_feats = einsum('bnhw,bchw->bnc', (sigmoid(mask_preds) > 0.5).float(), x_feats)   (use_binary)           (:243-250)
+    const float* obj = nullptr;
+    if (with_obj) {
+        if (ref) VKN_TRY(vkn_launch_gather_ref_ex(xf, mask_preds, thr_logit, s.obj, s.cnt, B, Np, C, P, N, st));
+        else VKN_TRY(vkn_launch_gather_ex(xf, mask_preds, thr_logit, s.obj, s.cnt, s.part, s.cntp, B, Np, C, P, N, st));
+        obj = s.obj;
+    }
+    // proposal_feats = init_kernels.weight (+ obj_feats), then the stuff kernels conv_seg.weight[num_thing:]      (:234-263)
+    return vkn_launch_init_finish(init_w, obj, seg_w, proposal_feats, B, Np, N, num_thing_classes, C, st);
 }
 
 size_t vkn_prepared_bytes(const VknDims* d, const VknStageWeights* w) {

@@ -31,7 +31,7 @@ template <int NB, int ABL>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     const float* __restrict__ x, const _Float16* __restrict__ kfh, const _Float16* __restrict__ kfl,
     const float* __restrict__ kb, float* __restrict__ out, int N, int NPT, int n0, int C, int P, int px_per_wg,
-    int xcd_remap) {
+    int xcd_remap, VknDecodeStrides fs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LDK = C + 8;  // halfs per LDS row; (C+8)*2 B = odd multiple of 16 B -> b128 reads conflict-free
     _Float16* ldsH = reinterpret_cast<_Float16*>(smem);
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
 
     // ---- stage this frame's kernels (rows n0 .. n0+NB*32) into LDS
     {
-        const _Float16* gh = kfh + ((size_t)b * NPT + n0) * C;
-        const _Float16* gl = kfl + ((size_t)b * NPT + n0) * C;
+        const _Float16* gh = kfh + (size_t)b * fs.plane + (size_t)n0 * C;
+        const _Float16* gl = kfl + (size_t)b * fs.plane + (size_t)n0 * C;
         const int cpr = C >> 3;
         for (int i = threadIdx.x; i < NB * 32 * cpr; i += DEC_THREADS) {
             const int r = i / cpr, q = i - r * cpr;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     float* kbs = reinterpret_cast<float*>(ldsL + NB * 32 * LDK);
     if (threadIdx.x < NB * 32) {
         const int n = n0 + threadIdx.x;
-        kbs[threadIdx.x] = (kb && n < N) ? kb[(size_t)b * N + n] : 0.f;
+        kbs[threadIdx.x] = (kb && n < N) ? kb[(size_t)b * fs.kb + n] : 0.f;
     }
     __syncthreads();
 
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     // tools/scratch/buftest.hip) — elements are copied to scalars first and converted with __uint_as_float / __float_as_uint.
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * N * P, 0, N * P * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * fs.out, 0, N * P * 4, 0x00020000);
 
     f32x16 acc[2][NB];
     u32x2 r0[8], r1[8], r2[8];
@@ -225,15 +225,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
 // Exact-fp32 debug / fallback kernel: one thread per (n, px), k-ordered fmaf chain.
 __global__ __launch_bounds__(256) void k_decode_ref(const float* __restrict__ x, const float* __restrict__ kern,
                                                     const float* __restrict__ kb, float* __restrict__ out, int N,
-                                                    int C, int P) {
+                                                    int C, int P, VknDecodeStrides fs) {
     const int px = blockIdx.x * 256 + threadIdx.x;
     const int n = blockIdx.y, b = blockIdx.z;
     if (px >= P) return;
     const float* xp = x + (size_t)b * C * P + px;
-    const float* kp = kern + ((size_t)b * N + n) * C;
+    const float* kp = kern + (size_t)b * fs.plane + (size_t)n * C;  // fs.plane: fp32 kernel elements per frame here
     float acc = 0.f;
     for (int c = 0; c < C; ++c) acc = fmaf(kp[c], xp[(size_t)c * P], acc);
-    out[((size_t)b * N + n) * P + px] = acc + (kb ? kb[(size_t)b * N + n] : 0.f);
+    out[(size_t)b * fs.out + (size_t)n * P + px] = acc + (kb ? kb[(size_t)b * fs.kb + n] : 0.f);
 }
 
 // fp32 kernels [B][N][C] -> two f16 planes [B][NPT][C] (rows >= N zero).  Used by the stand-alone decode entry
@@ -257,10 +257,18 @@ static int dec_set_lds(const void* fn, size_t bytes) {
 // host launcher.  kfh/kfl: [B][NPT][C] f16, NPT = roundup(N,32).  Returns VKN_* code.
 int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B,
                       int N, int C, int P, hipStream_t stream) {
-    if (B <= 0 || N <= 0 || P <= 0) return VKN_E_ARG;
+    return vkn_launch_decode_ex(x, kfh, kfl, kb, out, B, N, C, P, 0, N, stream);
+}
+
+// shared != 0: ONE set of kernels / bias for every frame (planes [NPT][C], kb [N]); out_rows: rows per frame of the output
+// tensor the N decoded rows are written into (>= N: the caller points `out` at the first of its rows).
+int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B,
+                         int N, int C, int P, int shared, int out_rows, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || P <= 0 || out_rows < N) return VKN_E_ARG;
     if (C % 16 != 0 || C > 512 || P < 2 || (P & 1)) return VKN_E_SHAPE;  // odd P: rows not 8-byte aligned (use the ref kernel)
     if ((size_t)C * P * 4 >= ((size_t)1 << 31) || (size_t)N * P * 4 >= ((size_t)1 << 31)) return VKN_E_SHAPE;  // 32-bit buffer offsets
     const int NPT = (N + 31) / 32 * 32;
+    const VknDecodeStrides fs{shared ? 0 : (long long)NPT * C, shared ? 0 : (long long)N, (long long)out_rows * P};
     // persistent grid: ~1 workgroup per CU over the whole batch, >= 256 px (8 strips) per workgroup
     // 512 px (one 64-px tile per wave) per workgroup measured best on MI355X (tools/decode_ablation.py: 95 us vs 108 us at
     // 1024 px, B = 8, cfg2); fewer, larger workgroups only when the batch alone already oversubscribes the chip.
@@ -284,7 +292,7 @@ int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, 
     do {                                                                                                       \
         if (dec_set_lds((const void*)k_decode_mfma<NBV, ABLV>, lds)) return VKN_E_LAUNCH;                      \
         hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV>), grid, block, lds, stream, x, kfh, kfl, kb, out, N, NPT, n0, C, \
-                           P, px_per_wg, xcd);                                                                    \
+                           P, px_per_wg, xcd, fs);                                                                 \
     } while (0)
 #define DEC_CASE(NBV)                    \
     case NBV:                            \
@@ -314,8 +322,15 @@ int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, 
 
 int vkn_launch_decode_ref(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
                           hipStream_t stream) {
+    return vkn_launch_decode_ref_ex(x, kern, kb, out, B, N, C, P, 0, N, stream);
+}
+
+int vkn_launch_decode_ref_ex(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
+                             int shared, int out_rows, hipStream_t stream) {
+    if (out_rows < N) return VKN_E_ARG;
+    const VknDecodeStrides fs{shared ? 0 : (long long)N * C, shared ? 0 : (long long)N, (long long)out_rows * P};
     dim3 grid((P + 255) / 256, N, B);
-    hipLaunchKernelGGL(k_decode_ref, grid, dim3(256), 0, stream, x, kern, kb, out, N, C, P);
+    hipLaunchKernelGGL(k_decode_ref, grid, dim3(256), 0, stream, x, kern, kb, out, N, C, P, fs);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -27,7 +27,8 @@ template <int NB>
 __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __restrict__ x,
                                                                const float* __restrict__ masks, float thr,
                                                                float* __restrict__ part, float* __restrict__ cntp, int N,
-                                                               int NPT, int n0, int C, int P, int px_per_wg) {
+                                                               int NPT, int n0, int C, int P, int px_per_wg,
+                                                               long long mask_fs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // per buffer: xh [C][40], xl [C][40], mk [NB*32][40]
     const int rows_buf = 2 * C + NB * 32;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     const int ntiles = (p_end > p_begin) ? (p_end - p_begin + GA_PT - 1) / GA_PT : 0;
 
     const float* xb = x + (size_t)b * C * P;
-    const float* mb = masks + (size_t)b * N * P;
+    const float* mb = masks + (size_t)b * mask_fs;  // mask_fs = rows per frame of the logits tensor * P (>= N * P)
     const bool vec_ok = ((P & 3) == 0);
 
     const int nxch = C * 8;        // 16-B chunks in an x tile
@@ -256,9 +257,9 @@ __global__ __launch_bounds__(64) void k_gather_reduce(const float* __restrict__ 
 // Exact-fp32 debug / fallback: one workgroup per (b, n), threads over channels, p-ordered accumulation.
 __global__ __launch_bounds__(256) void k_gather_ref(const float* __restrict__ x, const float* __restrict__ masks,
                                                     float thr, float* __restrict__ xraw, float* __restrict__ cnt, int N,
-                                                    int C, int P) {
+                                                    int C, int P, long long mask_fs) {
     const int n = blockIdx.x, b = blockIdx.y;
-    const float* mp = masks + ((size_t)b * N + n) * P;
+    const float* mp = masks + (size_t)b * mask_fs + (size_t)n * P;
     for (int c = threadIdx.x; c < C; c += 256) {
         const float* xp = x + ((size_t)b * C + c) * P;
         float s = 0.f;
@@ -290,7 +291,14 @@ int vkn_gather_groups(int B, int P) {
 // part: [B][G][NPT][C] f32, cntp: [B][G][NPT] f32 (workspace); xraw [B][N][C], cnt [B][N] outputs.
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
                       int B, int N, int C, int P, hipStream_t stream) {
-    if (B <= 0 || N <= 0 || P <= 0) return VKN_E_ARG;
+    return vkn_launch_gather_ex(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, N, stream);
+}
+
+// mask_rows: rows per frame of the logits tensor the N gathered rows live in (>= N; `masks` points at the first of them)
+int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
+                         int B, int N, int C, int P, int mask_rows, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || P <= 0 || mask_rows < N) return VKN_E_ARG;
+    const long long mask_fs = (long long)mask_rows * P;
     if (C % 32 != 0 || C > 256) return VKN_E_SHAPE;
     const int NPT = (N + 31) / 32 * 32;
     int wg_per_frame = 256 / B;
@@ -306,7 +314,7 @@ int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw
     case NBV:                                                                                                    \
         if (ga_set_lds((const void*)k_gather_mfma<NBV>, lds)) return VKN_E_LAUNCH;                               \
         hipLaunchKernelGGL(k_gather_mfma<NBV>, grid, block, lds, stream, x, masks, thr, part, cntp, N, NPT, n0, C, P, \
-                           px_per_wg);                                                                           \
+                           px_per_wg, mask_fs);                                                                     \
         break;
         switch (nb) {
             GA_CASE(1)
@@ -326,7 +334,14 @@ int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw
 
 int vkn_launch_gather_ref(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                           int P, hipStream_t stream) {
-    hipLaunchKernelGGL(k_gather_ref, dim3(N, B), dim3(256), 0, stream, x, masks, thr, xraw, cnt, N, C, P);
+    return vkn_launch_gather_ref_ex(x, masks, thr, xraw, cnt, B, N, C, P, N, stream);
+}
+
+int vkn_launch_gather_ref_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
+                             int P, int mask_rows, hipStream_t stream) {
+    if (mask_rows < N) return VKN_E_ARG;
+    hipLaunchKernelGGL(k_gather_ref, dim3(N, B), dim3(256), 0, stream, x, masks, thr, xraw, cnt, N, C, P,
+                       (long long)mask_rows * P);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

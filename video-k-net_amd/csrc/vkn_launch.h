@@ -40,10 +40,24 @@ struct VknGemmProb {
 };
 
 int vkn_gather_groups(int B, int P);
+int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
+                         int B, int N, int C, int P, int mask_rows, hipStream_t stream);
+int vkn_launch_gather_ref_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
+                             int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
                       int B, int N, int C, int P, hipStream_t stream);
 int vkn_launch_gather_ref(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                           int P, hipStream_t stream);
+// per-frame element strides of the decode operands (shared kernels: 0)
+struct VknDecodeStrides {
+    long long plane;  // kernel planes (f16 elements) / fp32 kernels (ref kernel) per frame
+    long long kb;     // bias elements per frame
+    long long out;    // output elements per frame
+};
+int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
+                         int C, int P, int shared, int out_rows, hipStream_t stream);
+int vkn_launch_decode_ref_ex(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
+                             int shared, int out_rows, hipStream_t stream);
 int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
                       int C, int P, hipStream_t stream);
 int vkn_launch_decode_ref(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
@@ -53,6 +67,9 @@ int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, co
                     int ksplit, float* partial, const VknEpi& epi, hipStream_t stream);
 int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int ksplit, float* partial, hipStream_t stream);
 size_t vkn_split_w3_bytes(int Nout, int K);
+int vkn_launch_add2(const float* a, const float* b, float* out, size_t n, hipStream_t st);
+int vkn_launch_init_finish(const float* init_w, const float* obj, const float* seg_w, float* out, int B, int Np, int N, int nth,
+                           int C, hipStream_t st);
 int vkn_launch_transpose(const float* src, float* dst, int R, int Cc, hipStream_t st);  // dst[c][r] = src[r][c]
 int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream);
 int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig, const float* ug, const float* no_w,

@@ -357,3 +357,44 @@ def linear(A, W, bias=None, w_split=None, act=0, ksplit=1):
         check(_lib.lib().vkn_linear_f32(_ptr(A), _ptr(W), _ptr(w_split), _ptr(bias), _ptr(out), M, K, Nout, int(act), int(ksplit),
                                         _ptr(ws), ws.numel(), _stream()))
     return out
+
+
+def kernel_init(loc_feats, semantic_feats, init_w, seg_w=None, seg_b=None, num_thing_classes=0, cat_stuff_mask=False,
+                proposal_feats_with_obj=True, hard_mask_thr=0.5, want_seg_preds=True, flags=0):
+    """Kernel initialisation ("pass 0"), `ConvKernelHead._decode_init_proposals` after its loc / seg convs
+    (knet/det/kernel_head.py:204-263), use_binary semantics.  Returns (proposal_feats [B,N,C], x_feats [B,C,H,W],
+    mask_preds [B,N,H,W], seg_preds [B,ncls,H,W] | None)."""
+    loc = _req(loc_feats, 'loc_feats')
+    B, C, H, W = loc.shape
+    P = H * W
+    dev = loc.device
+    iw = _req(init_w.reshape(init_w.shape[0], -1), 'init_kernels.weight')
+    Np = iw.shape[0]
+    if iw.shape[1] != C:
+        raise ValueError('init_kernels.weight must be [num_proposals, C, 1, 1] (conv_kernel_size == 1)')
+    sem = sw = sb = None
+    ncls = 0
+    if semantic_feats is not None:
+        sem = _req(semantic_feats, 'semantic_feats')
+        if sem.shape != loc.shape:
+            raise ValueError('semantic_feats and loc_feats must have the same shape')
+        sw = _req(seg_w.reshape(seg_w.shape[0], -1), 'conv_seg.weight')
+        sb = _req(seg_b, 'conv_seg.bias') if seg_b is not None else None
+        ncls = sw.shape[0]
+    elif cat_stuff_mask:
+        raise ValueError('cat_stuff_mask needs the semantic branch')
+    nstuff = ncls - num_thing_classes if cat_stuff_mask else 0
+    N = Np + nstuff
+    L = _lib.lib()
+    x_feats = torch.empty_like(loc) if sem is not None else loc
+    masks = torch.empty((B, N, H, W), dtype=torch.float32, device=dev)
+    seg = torch.empty((B, ncls, H, W), dtype=torch.float32, device=dev) if (sem is not None and want_seg_preds) else None
+    prop = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    nb = L.vkn_kernel_init_workspace_bytes(B, Np, ncls, C, P)
+    ws = _workspace(max(nb, 256), dev)
+    with torch.cuda.device(dev):
+        check(L.vkn_kernel_init_f32(_ptr(loc), _ptr(sem), _ptr(iw), _ptr(sw), _ptr(sb), int(num_thing_classes),
+                                    int(bool(cat_stuff_mask)), int(bool(proposal_feats_with_obj)), thr_logit(hard_mask_thr),
+                                    _ptr(x_feats), _ptr(masks), _ptr(seg), _ptr(prop), B, Np, ncls, C, P, _ptr(ws), ws.numel(),
+                                    flags, _stream()))
+    return prop, x_feats, masks, seg
