@@ -193,6 +193,37 @@ int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const fl
                         float* mask_preds, float* seg_preds, float* proposal_feats, int B, int Np, int ncls, int C, int P,
                         void* ws, size_t ws_bytes, unsigned flags, void* stream);
 
+/* ---- post-head mask pipeline: joint panoptic merge of one batch of frames, straight from the head's LOW-RES mask logits.
+ *      Replaces, per image, `KernelIterHead.get_panoptic` + `merge_stuff_thing_stuff_joint` (knet/det/kernel_iter_head.py:332-370,
+ *      467-524; video: knet/video/kernel_iter_head.py:591-640, 832-905) including `KernelUpdateHead.rescale_masks`
+ *      (knet/det/kernel_update_head.py:443-458) and the last-stage x`up` interpolate of `_mask_forward` (:122-130): no
+ *      [K, ori_h, ori_w] tensor is ever materialised.  `merge_joint=True` semantics (every shipped panoptic config).
+ *      All frames of the call share one geometry (img_meta).  Ties between exactly equal scores are broken by the lower index
+ *      (torch leaves them unspecified). */
+typedef struct VknPanopticCfg {
+    int num_proposals;        /* thing kernels = rows [0, num_proposals); stuff kernels = the remaining N - num_proposals rows */
+    int num_thing_classes;
+    int max_per_img;          /* test_cfg.max_per_img: top-k over (proposal, thing class) pairs */
+    float instance_score_thr; /* test_cfg.merge_stuff_thing.instance_score_thr (compared in fp32, as torch does) */
+    double overlap_thr;       /* test_cfg.merge_stuff_thing.overlap_thr (compared in fp64, as Python does) */
+    int up;                   /* mask_upsample_stride applied to mask_logits first (1: logits are already `scaled_mask_preds`) */
+    int Hm, Wm;               /* mask_logits spatial size */
+    int Hb, Wb;               /* img_meta['batch_input_shape'] */
+    int h, w;                 /* img_meta['img_shape'][:2]   (crop of the batch input) */
+    int Ho, Wo;               /* img_meta['ori_shape'][:2]   (output size) */
+} VknPanopticCfg;
+#define VKN_PANOPTIC_INFO_FIELDS 6
+size_t vkn_sizeof_panoptic_cfg(void);
+size_t vkn_panoptic_workspace_bytes(const VknPanopticCfg* cfg, int B, int N);
+/*      in : cls_prob [B][N][ncls] (sigmoid applied: the head's 2nd output), mask_logits [B][N][Hm][Wm]
+ *      out: panoptic_seg int32 [B][Ho][Wo] (0 = void, 1.. = segment ids in creation order);
+ *           info int32 [B][K][6], K = max_per_img + (N - num_proposals), one entry per selected kernel k in the reference's
+ *           `total_*` order: {mask row, joint label (< num_thing_classes: thing class; else num_thing_classes + stuff index),
+ *           segment id or 0, area (#pixels won), original area (#pixels with prob >= 0.5), score bits (fp32)};
+ *           nseg int32 [B] = number of segments (-1: internal capacity error, results invalid). */
+int vkn_panoptic_joint_f32(const VknPanopticCfg* cfg, const float* cls_prob, const float* mask_logits, int B, int N, int ncls,
+                           int* panoptic_seg, int* info, int* nseg, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

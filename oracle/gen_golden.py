@@ -30,6 +30,7 @@ sys.path.insert(2, ROOT)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
 from oracle import synth  # noqa: E402
 
@@ -236,6 +237,55 @@ def init_keys():
     print('init_keys: ok', len(out['kitti_keys']), len(out['refine_keys']))
 
 
+class AttrDict(dict):
+    """mmcv.Config-style attribute access for test_cfg (the reference reads `test_cfg.max_per_img`, `merge_cfg.overlap_thr`)."""
+    __getattr__ = dict.__getitem__
+
+
+PAN_CASES = {
+    # three resampling levels: x2, -> batch input, crop, -> ori (up-scaling by 1.5)
+    'pan_tiny': dict(B=2, N=15, Np=12, T=2, ncls=5, Hm=8, Wm=16, up=2, bis=(64, 128), img=(60, 120), ori=(90, 180), seed=31),
+    # last resize is the identity (Cityscapes-style: ori == img == batch input)
+    'pan_ident': dict(B=2, N=15, Np=12, T=2, ncls=5, Hm=8, Wm=16, up=4, bis=(64, 128), img=(64, 128), ori=(64, 128), seed=32),
+    # config kernel count, down-scaling last level, odd crop
+    'pan_cfg': dict(B=1, N=117, Np=100, T=2, ncls=19, Hm=32, Wm=64, up=4, bis=(256, 512), img=(250, 499), ori=(125, 250), seed=33),
+    # KITTI-like odd sizes, already-scaled logits (up = 1), crop only
+    'pan_kitti': dict(B=1, N=117, Np=100, T=2, ncls=19, Hm=48, Wm=156, up=1, bis=(96, 312), img=(94, 311), ori=(94, 311), seed=34),
+}
+
+
+def run_pan_case(name, p):
+    """KernelIterHead.get_panoptic of the reference (merge_joint=True) on structured synthetic logits."""
+    test_cfg = AttrDict(max_per_img=p['Np'], mask_thr=0.5, stuff_score_thr=0.05,
+                        merge_stuff_thing=AttrDict(overlap_thr=0.6, iou_thr=0.5, stuff_max_area=4096, instance_score_thr=0.25))
+    cfg = head_cfg(False, C=32, heads=8, ffn=64, ncls=p['ncls'], n_thing=p['T'], n_stuff=p['ncls'] - p['T'], S=1, up=p['up'],
+                   nprop=p['Np'])
+    cfg.update(do_panoptic=True, merge_joint=True, test_cfg=test_cfg)
+    head = build_head(cfg)
+    head.eval()
+    cls, logits = (torch.from_numpy(a) for a in synth.panoptic_inputs(p['B'], p['N'], p['Np'], p['ncls'], p['Hm'], p['Wm'], p['seed']))
+    meta = dict(img_shape=(*p['img'], 3), batch_input_shape=tuple(p['bis']), ori_shape=(*p['ori'], 3))
+    segs, infos = [], []
+    with torch.no_grad():
+        scaled = logits
+        if p['up'] > 1:   # the last stage's upsample, exactly as _mask_forward does it (knet/det/kernel_iter_head.py:122-130)
+            scaled = F.interpolate(logits, scale_factor=p['up'], align_corners=False, mode='bilinear')
+        for b in range(p['B']):
+            _, _, (pan, info) = head.get_panoptic(cls[b], scaled[b], head.test_cfg, meta)
+            segs.append(pan)
+            # id, isthing, category_id, instance_id (-1 for stuff), score (nan for stuff), area (-1 for things)
+            infos.append(np.array([[s['id'], int(s['isthing']), s['category_id'], s.get('instance_id', -1),
+                                    s.get('score', float('nan')), s.get('area', -1)] for s in info], dtype=np.float64).reshape(-1, 6))
+    out = dict(case=np.array([p['B'], p['N'], p['Np'], p['T'], p['ncls'], p['Hm'], p['Wm'], p['up'], *p['bis'], *p['img'], *p['ori'],
+                              p['seed']], dtype=np.int64),
+               panoptic_seg=np.stack(segs).astype(np.int32), nseg=np.array([len(i) for i in infos], dtype=np.int64))
+    for b, i in enumerate(infos):
+        out[f'info{b}'] = i
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(f'{name}: ok  segments per frame = {[len(i) for i in infos]}  void fraction = '
+          f'{float((np.stack(segs) == 0).mean()):.3f}')
+
+
 def thr_kat():
     """(sigmoid(z) > 0.5) as the reference computes it (knet/det/kernel_update_head.py:190-191) — torch CPU fp32.
     The flip point is not z=0: it depends on the fp32 sigmoid (SURVEY.md §7 'Threshold semantics')."""
@@ -270,6 +320,9 @@ if __name__ == '__main__':
     for name, p in INIT_CASES.items():
         if not only or name in only:
             run_init_case(name, p)
+    for name, p in PAN_CASES.items():
+        if not only or name in only:
+            run_pan_case(name, p)
     if not only or 'init_keys' in only:
         init_keys()
     if not only or 'thr_kat' in only:

@@ -275,3 +275,74 @@ def kernel_init(init_w, loc_feats, semantic_feats=None, seg_w=None, seg_b=None, 
         stuff = seg_w[num_thing_classes:]
         proposal_feats = torch.cat([proposal_feats, stuff[None].expand(B, *stuff.shape)], dim=1)
     return proposal_feats, x_feats, mask_preds, seg_preds
+
+
+def rescale_masks(masks_per_img, img_meta):
+    """KernelUpdateHead.rescale_masks                                             knet/det/kernel_update_head.py:443-458"""
+    h, w = img_meta['img_shape'][:2]
+    m = F.interpolate(masks_per_img.unsqueeze(0).sigmoid(), size=tuple(img_meta['batch_input_shape']), mode='bilinear',
+                      align_corners=False)
+    m = m[:, :, :h, :w]
+    return F.interpolate(m, size=tuple(img_meta['ori_shape'][:2]), mode='bilinear', align_corners=False).squeeze(0)
+
+
+def panoptic_joint(cls_scores, mask_logits, num_proposals, num_thing_classes, max_per_img, instance_score_thr, overlap_thr,
+                   img_meta, upsample_stride=1):
+    """One image: the last-stage upsample of `_mask_forward` (knet/det/kernel_iter_head.py:122-130), then `get_panoptic`
+    (:332-370) with merge_joint=True and `merge_stuff_thing_stuff_joint` (:467-524).
+    cls_scores [N,ncls] (sigmoid applied), mask_logits [N,Hm,Wm].  Returns a dict with the reference's outputs
+    (`panoptic_seg` int32, `segments_info`) and the intermediates the parity tests compare."""
+    T = num_thing_classes
+    scaled = mask_logits
+    if upsample_stride > 1:
+        scaled = F.interpolate(mask_logits[None], scale_factor=upsample_stride, align_corners=False, mode='bilinear')[0]
+    thing_scores = cls_scores[:num_proposals][:, :T]
+    thing_scores, topk_indices = thing_scores.flatten(0, 1).topk(max_per_img, sorted=True)            # :337-338
+    mask_indices = topk_indices // T
+    thing_labels = topk_indices % T
+    thing_masks = rescale_masks(scaled[:num_proposals][mask_indices], img_meta)                       # :341-342
+    stuff_scores = cls_scores[num_proposals:][:, T:].diag()                                           # :349-350
+    stuff_scores, stuff_inds = torch.sort(stuff_scores, descending=True)
+    stuff_masks = rescale_masks(scaled[num_proposals:][stuff_inds], img_meta)
+    stuff_labels = stuff_inds + T                                                                     # :359
+    total_masks = torch.cat([thing_masks, stuff_masks], dim=0)                                        # :480-482
+    total_scores = torch.cat([thing_scores, stuff_scores], dim=0)
+    total_labels = torch.cat([thing_labels, stuff_labels], dim=0)
+    rows = torch.cat([mask_indices, stuff_inds + num_proposals], dim=0)
+    cur_prob_masks = total_scores.view(-1, 1, 1) * total_masks
+    cur_mask_ids = cur_prob_masks.argmax(0)                                                           # :486
+    H, W = total_masks.shape[-2:]
+    panoptic_seg = torch.zeros((H, W), dtype=torch.int32)
+    segments_info = []
+    K = total_masks.shape[0]
+    area = torch.zeros(K, dtype=torch.int64)
+    orig = torch.zeros(K, dtype=torch.int64)
+    seg_of = torch.zeros(K, dtype=torch.int64)
+    current_segment_id = 0
+    for k in torch.argsort(-total_scores):                                                            # :489-522
+        k = int(k)
+        pred_class = int(total_labels[k])
+        isthing = pred_class < T
+        mask = cur_mask_ids == k
+        area[k] = int(mask.sum())
+        orig[k] = int((total_masks[k] >= 0.5).sum())
+        if isthing and total_scores[k] < instance_score_thr:
+            continue
+        mask_area, original_area = int(area[k]), int(orig[k])
+        if mask_area > 0 and original_area > 0:
+            if mask_area / original_area < overlap_thr:
+                continue
+            current_segment_id += 1
+            panoptic_seg[mask] = current_segment_id
+            seg_of[k] = current_segment_id
+            if isthing:
+                segments_info.append(dict(id=current_segment_id, isthing=True, score=float(total_scores[k]),
+                                          category_id=pred_class, instance_id=k))
+            else:
+                segments_info.append(dict(id=current_segment_id, isthing=False, category_id=pred_class - T + 1,
+                                          area=mask_area))
+    top2 = cur_prob_masks.topk(2, dim=0).values if K > 1 else None
+    margin = (top2[0] - top2[1]) if top2 is not None else torch.full((H, W), float('inf'))
+    return dict(panoptic_seg=panoptic_seg, segments_info=segments_info, cur_mask_ids=cur_mask_ids, total_scores=total_scores,
+                total_labels=total_labels, rows=rows, area=area, orig=orig, seg_of=seg_of, margin=margin,
+                total_masks=total_masks)

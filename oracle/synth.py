@@ -73,3 +73,25 @@ def head_inputs(B, N, C, H, W, seed=0, mask_scale=4.0):
     pf = normalish((B, N, C, 1, 1), 12 + 7 * seed, 1.0)
     mp = normalish((B, N, H, W), 13 + 7 * seed, mask_scale)
     return x, pf, mp
+
+
+def panoptic_inputs(B, N, Np, ncls, Hm, Wm, seed):
+    """Structured inputs of the post-head pipeline: cls probabilities [B,N,ncls] in (0,1) and low-res mask logits [B,N,Hm,Wm]
+    that look like segmentation (one soft elliptic blob per thing kernel, one horizontal band per stuff kernel, plus noise), so
+    that the joint merge accepts some kernels and rejects others (i.i.d. noise would reject everything)."""
+    cls = uniform((B, N, ncls), 41 + 13 * seed, 0.02, 0.98)
+    noise = normalish((B, N, Hm, Wm), 42 + 13 * seed, 0.7)
+    cx = uniform((B, N), 43 + 13 * seed, 0.05, 0.95).astype(np.float64)
+    cy = uniform((B, N), 44 + 13 * seed, 0.05, 0.95).astype(np.float64)
+    r0 = float(np.sqrt(0.5 / max(Np, 1)))   # blobs shrink with the kernel count so that they overlap only partly
+    rx = uniform((B, N), 45 + 13 * seed, 0.5 * r0, 1.5 * r0).astype(np.float64)
+    ry = uniform((B, N), 46 + 13 * seed, 0.5 * r0, 1.5 * r0).astype(np.float64)
+    ys = ((np.arange(Hm) + 0.5) / Hm)[None, None, :, None]
+    xs = ((np.arange(Wm) + 0.5) / Wm)[None, None, None, :]
+    d = np.sqrt(((xs - cx[..., None, None]) / rx[..., None, None]) ** 2 + ((ys - cy[..., None, None]) / ry[..., None, None]) ** 2)
+    logits = np.clip(6.0 * (1.0 - d), -6.0, 6.0)
+    ns = N - Np
+    for j in range(ns):  # stuff: band j of ns
+        inside = (ys >= j / ns) & (ys < (j + 1) / ns)
+        logits[:, Np + j] = np.where(np.broadcast_to(inside[:, 0], (B, Hm, Wm)), 4.0, -4.0)
+    return cls.astype(np.float32), (logits + noise).astype(np.float32)

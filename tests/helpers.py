@@ -68,3 +68,32 @@ def make_init_case(case):
         shapes['conv_seg.bias'] = (case['ncls'],)
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, seed).items()}
     return loc, sem, sd['init_kernels.weight'], sd.get('conv_seg.weight'), sd.get('conv_seg.bias')
+
+
+PAN_FIELDS = ('B', 'N', 'Np', 'T', 'ncls', 'Hm', 'Wm', 'up', 'Hb', 'Wb', 'h', 'w', 'Ho', 'Wo', 'seed')
+PAN_CFG = dict(instance_score_thr=0.25, overlap_thr=0.6)   # test_cfg.merge_stuff_thing of the shipped configs
+
+
+def load_pan_golden(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+    return g, dict(zip(PAN_FIELDS, (int(v) for v in g['case'])))
+
+
+def make_pan_case(case):
+    cls, logits = synth.panoptic_inputs(case['B'], case['N'], case['Np'], case['ncls'], case['Hm'], case['Wm'], case['seed'])
+    meta = dict(img_shape=(case['h'], case['w'], 3), batch_input_shape=(case['Hb'], case['Wb']), ori_shape=(case['Ho'], case['Wo'], 3))
+    return torch.from_numpy(cls), torch.from_numpy(logits), meta
+
+
+def run_pan_oracle(case, b):
+    from oracle.knet_oracle import panoptic_joint
+    cls, logits, meta = make_pan_case(case)
+    with torch.no_grad():
+        return panoptic_joint(cls[b], logits[b], case['Np'], case['T'], case['Np'], PAN_CFG['instance_score_thr'],
+                              PAN_CFG['overlap_thr'], meta, upsample_stride=case['up'])
+
+
+def pan_info_rows(segments_info):
+    """segments_info (list of dicts) -> the golden's [id, isthing, category_id, instance_id|-1, score|nan, area|-1] rows."""
+    return np.array([[s['id'], int(s['isthing']), s['category_id'], s.get('instance_id', -1), s.get('score', float('nan')),
+                      s.get('area', -1)] for s in segments_info], dtype=np.float64).reshape(-1, 6)

@@ -415,3 +415,73 @@ def test_conv_kernel_head_class_matches_reference_golden(vkn):
     ok = _init_rows_off_threshold(g['mask_preds'], case['nprop'], vkn.ops.thr_logit(0.5))
     err = (prop.cpu() - torch.from_numpy(g['proposal_feats']))[:, :case['nprop']].flatten(2)[ok]
     assert float(err.abs().max()) < 2e-4 * float(np.abs(g['proposal_feats']).max())
+
+
+# --------------------------------------------------------------------------------------- post-head pipeline: joint panoptic merge
+def _pan_gpu(vkn, case):
+    from helpers import PAN_CFG, make_pan_case
+    cls, logits, meta = make_pan_case(case)
+    seg, info, nseg = vkn.ops.panoptic_joint(cls.to(DEV), logits.to(DEV), case['Np'], case['T'], case['Np'],
+                                             PAN_CFG['instance_score_thr'], PAN_CFG['overlap_thr'], meta['img_shape'][:2],
+                                             meta['batch_input_shape'], meta['ori_shape'][:2], upsample_stride=case['up'])
+    torch.cuda.synchronize()
+    return seg.cpu().numpy(), info.cpu().numpy(), nseg.cpu().numpy()
+
+
+@pytest.mark.parametrize('name', ['pan_tiny', 'pan_ident', 'pan_cfg', 'pan_kitti'])
+def test_panoptic_joint_vs_oracle_and_reference(vkn, name):
+    """Integer artefacts of the post-head pipeline: selection (rows / labels / scores) and segment decisions bit-exact; the
+    panoptic map bit-exact except where the reference's own arg-max is decided by < 1e-6 (fp32 resampling noise)."""
+    from helpers import load_pan_golden, run_pan_oracle
+    g, case = load_pan_golden(name)
+    seg, info, nseg = _pan_gpu(vkn, case)
+    for b in range(case['B']):
+        r = run_pan_oracle(case, b)
+        assert int(nseg[b]) == len(r['segments_info']) == int(g['nseg'][b])
+        assert np.array_equal(info[b, :, 0], r['rows'].numpy()) and np.array_equal(info[b, :, 1], r['total_labels'].numpy())
+        assert np.array_equal(info[b, :, 5].view(np.float32), r['total_scores'].numpy())       # score bits
+        assert np.array_equal(info[b, :, 2], r['seg_of'].numpy())                              # accept / reject + ids
+        near = (r['margin'].numpy() < 1e-6)
+        assert float(near.mean()) < 2e-3
+        n_near = int(near.sum())
+        assert np.abs(info[b, :, 3] - r['area'].numpy()).sum() <= 2 * n_near                   # pixels won
+        near_half = int(((r['total_masks'] - 0.5).abs() < 1e-6).sum())
+        assert np.abs(info[b, :, 4] - r['orig'].numpy()).sum() <= near_half                    # pixels with prob >= 0.5
+        diff = seg[b] != g['panoptic_seg'][b]
+        assert not (diff & ~near).any()
+        assert int(diff.sum()) <= n_near
+
+
+def test_panoptic_joint_cfg2_size(vkn):
+    """BASELINE cfg2 geometry (128x256 logits, x4, 1024x2048 output, K = 117): consistency of the integer outputs and
+    agreement with a straightforward torch evaluation of the same chain on the device (which materialises K x Ho x Wo)."""
+    B, N, Np, T, ncls, Hm, Wm, up = 1, 117, 100, 2, 19, 128, 256, 4
+    cls_np, logit_np = synth.panoptic_inputs(B, N, Np, ncls, Hm, Wm, 77)
+    cls, logits = torch.from_numpy(cls_np).to(DEV), torch.from_numpy(logit_np).to(DEV)
+    shape = (1024, 2048)
+    seg, info, nseg = vkn.ops.panoptic_joint(cls, logits, Np, T, Np, 0.25, 0.6, shape, shape, shape, upsample_stride=up)
+    torch.cuda.synchronize()
+    info = info[0].cpu().numpy()
+    K = info.shape[0]
+    assert int(nseg[0]) > 5 and int(nseg[0]) == int((info[:, 2] > 0).sum())
+    assert int(info[:, 3].sum()) == shape[0] * shape[1]                      # every pixel is won by exactly one kernel
+    # torch chain on the device
+    rows = torch.from_numpy(info[:, 0]).long().to(DEV)
+    scores = torch.from_numpy(info[:, 5].view(np.float32).copy()).to(DEV)
+    scaled = F.interpolate(logits[0][None], scale_factor=up, mode='bilinear', align_corners=False)[0]
+    tm = F.interpolate(scaled[rows][None].sigmoid(), size=shape, mode='bilinear', align_corners=False)[0]
+    prob = scores.view(-1, 1, 1) * tm
+    top2 = prob.topk(2, dim=0)
+    near = (top2.values[0] - top2.values[1]) < 1e-6
+    ids = top2.indices[0]
+    seg_of = torch.from_numpy(info[:, 2]).to(DEV)
+    want = seg_of[ids].int()
+    diff = seg[0] != want
+    assert not bool((diff & ~near).any()) and float(near.float().mean()) < 2e-3
+    area = torch.bincount(ids.flatten(), minlength=K).cpu().numpy()
+    assert np.abs(area - info[:, 3]).sum() <= 2 * int(near.sum())
+    orig = (tm >= 0.5).flatten(1).sum(1).cpu().numpy()
+    assert np.abs(orig - info[:, 4]).sum() <= int(((tm - 0.5).abs() < 1e-6).sum())
+    # determinism
+    seg2, info2, _ = vkn.ops.panoptic_joint(cls, logits, Np, T, Np, 0.25, 0.6, shape, shape, shape, upsample_stride=up)
+    assert torch.equal(seg, seg2) and np.array_equal(info, info2[0].cpu().numpy())

@@ -97,3 +97,17 @@ def test_kernel_init_oracle_matches_reference_golden(name):
         assert maxabs(xf.double().sum(dim=(-1, -2)), g['x_feats_rowsum']) < 1e-9
     if seg is not None:
         assert maxabs(seg, g['seg_preds']) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['pan_tiny', 'pan_ident', 'pan_cfg', 'pan_kitti'])
+def test_panoptic_oracle_matches_reference_golden(name):
+    """oracle.panoptic_joint == the reference's KernelIterHead.get_panoptic (merge_joint=True): the integer panoptic map and the
+    segments_info list, bit for bit (same ATen ops on the same machine class)."""
+    from helpers import load_pan_golden, pan_info_rows, run_pan_oracle
+    g, case = load_pan_golden(name)
+    for b in range(case['B']):
+        r = run_pan_oracle(case, b)
+        assert np.array_equal(r['panoptic_seg'].numpy(), g['panoptic_seg'][b])
+        rows, want = pan_info_rows(r['segments_info']), g[f'info{b}']
+        assert rows.shape == want.shape and int(g['nseg'][b]) == len(r['segments_info']) > 0
+        assert np.array_equal(np.nan_to_num(rows, nan=-7.0), np.nan_to_num(want, nan=-7.0))

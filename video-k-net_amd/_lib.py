@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
-SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_init.hip', 'vkn_api.hip')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_api.hip')
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares
@@ -19,7 +19,16 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_w
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
            'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
            'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32',
-           'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32')
+           'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32',
+           'vkn_sizeof_panoptic_cfg', 'vkn_panoptic_workspace_bytes', 'vkn_panoptic_joint_f32')
+
+
+class VknPanopticCfg(ctypes.Structure):
+    """Mirror of include/vkn.h: VknPanopticCfg."""
+    _fields_ = [('num_proposals', ctypes.c_int), ('num_thing_classes', ctypes.c_int), ('max_per_img', ctypes.c_int),
+                ('instance_score_thr', ctypes.c_float), ('overlap_thr', ctypes.c_double), ('up', ctypes.c_int),
+                ('Hm', ctypes.c_int), ('Wm', ctypes.c_int), ('Hb', ctypes.c_int), ('Wb', ctypes.c_int),
+                ('h', ctypes.c_int), ('w', ctypes.c_int), ('Ho', ctypes.c_int), ('Wo', ctypes.c_int)]
 
 
 class VknLibraryError(RuntimeError):
@@ -151,6 +160,15 @@ def lib():
     L.vkn_kernel_init_workspace_bytes.argtypes = [c_int] * 5
     L.vkn_kernel_init_f32.restype = c_int
     L.vkn_kernel_init_f32.argtypes = [_fp] * 5 + [c_int, c_int, c_int, c_float] + [_fp] * 4 + [c_int] * 5 + [_fp, c_size, c_uint, _fp]
+    pP = ctypes.POINTER(VknPanopticCfg)
+    L.vkn_sizeof_panoptic_cfg.restype = c_size
+    L.vkn_sizeof_panoptic_cfg.argtypes = []
+    if L.vkn_sizeof_panoptic_cfg() != ctypes.sizeof(VknPanopticCfg):
+        raise VknLibraryError('ctypes mirror of VknPanopticCfg is out of date (size mismatch)')
+    L.vkn_panoptic_workspace_bytes.restype = c_size
+    L.vkn_panoptic_workspace_bytes.argtypes = [pP, c_int, c_int]
+    L.vkn_panoptic_joint_f32.restype = c_int
+    L.vkn_panoptic_joint_f32.argtypes = [pP, _fp, _fp, c_int, c_int, c_int, _fp, _fp, _fp, _fp, c_size, _fp]
     _LIB = L
     return L
 

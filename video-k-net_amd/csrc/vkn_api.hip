@@ -577,6 +577,21 @@ int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const fl
     return vkn_launch_init_finish(init_w, obj, seg_w, proposal_feats, B, Np, N, num_thing_classes, C, st);
 }
 
+size_t vkn_sizeof_panoptic_cfg(void) { return sizeof(VknPanopticCfg); }
+
+size_t vkn_panoptic_workspace_bytes(const VknPanopticCfg* cfg, int B, int N) {
+    if (!cfg || B <= 0 || N <= 0 || cfg->num_proposals > N || cfg->max_per_img <= 0) return 0;
+    return vkn_panoptic_ws_bytes(B, cfg->max_per_img + (N - cfg->num_proposals));
+}
+
+int vkn_panoptic_joint_f32(const VknPanopticCfg* cfg, const float* cls_prob, const float* mask_logits, int B, int N, int ncls,
+                           int* panoptic_seg, int* info, int* nseg, void* ws, size_t ws_bytes, void* stream) {
+    if (!cfg || !cls_prob || !mask_logits || !panoptic_seg || !info || !nseg || B <= 0 || N <= 0 || ncls <= 0) return VKN_E_ARG;
+    if (!ws || !aligned16(ws)) return VKN_E_WORKSPACE;
+    return vkn_launch_panoptic_joint(cfg, cls_prob, mask_logits, B, N, ncls, panoptic_seg, info, nseg, ws, ws_bytes,
+                                     static_cast<hipStream_t>(stream));
+}
+
 size_t vkn_prepared_bytes(const VknDims* d, const VknStageWeights* w) {
     if (check_dims(d) != VKN_OK || !w) return 0;
     PrepW pw;

@@ -79,3 +79,9 @@ int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int
                     int Nk, int heads, int hd, hipStream_t stream);
 int vkn_launch_sigmoid(const float* in, float* out, int n, hipStream_t stream);
 int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream);
+
+// post-head joint panoptic merge (vkn_panoptic.hip); VknPanopticCfg is declared in include/vkn.h
+struct VknPanopticCfg;
+size_t vkn_panoptic_ws_bytes(int B, int K);
+int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const float* masks, int B, int N, int ncls,
+                              int* panoptic_seg, int* info, int* nseg, void* ws, size_t ws_bytes, hipStream_t st);

@@ -1,0 +1,356 @@
+// vkn_panoptic.hip — post-head mask pipeline, joint panoptic merge.
+//
+// Reference (per image): KernelIterHead.get_panoptic + merge_stuff_thing_stuff_joint (knet/det/kernel_iter_head.py:332-370,
+// 467-524; video: knet/video/kernel_iter_head.py:591-640, 832-905) with KernelUpdateHead.rescale_masks
+// (knet/det/kernel_update_head.py:443-458) and the last-stage F.interpolate of _mask_forward (knet/det/kernel_iter_head.py:122-130):
+//
+//   scaled      = interpolate(mask_logits, scale_factor=up)                      [N, Hm*up, Wm*up]
+//   thing rows  = top-`max_per_img` of cls[:Np, :T].flatten()  -> (score, row = idx // T, label = idx % T)
+//   stuff rows  = sort(diag(cls[Np:, T:]), descending)         -> (score, row = Np + j, label = T + j)
+//   total_masks = interpolate(interpolate(sigmoid(scaled[rows]), size=batch_input_shape)[:, :h, :w], size=ori_shape)
+//   cur_mask_ids = argmax_k(score_k * total_masks[k]);  area_k = #(ids == k);  orig_k = #(total_masks[k] >= 0.5)
+//   in score order: skip things below instance_score_thr; keep k iff area_k > 0, orig_k > 0, area_k / orig_k >= overlap_thr;
+//   panoptic_seg[ids == k] = running segment id.
+//
+// The reference materialises K x Ho x Wo fp32 (981 MB per 1024x2048 frame) three times.  Here nothing of that size exists:
+// one kernel walks 64x8 output tiles, and for a batch of kernels k resamples the tile's footprint level by level through LDS
+// (low-res logits -> x`up` + sigmoid -> batch-input size -> ori size), keeping the running arg-max and the two pixel counts; the
+// only full-size array is the int32 id map, which the relabel pass turns into panoptic_seg in place.  Integer counts use integer
+// atomics (order-independent => deterministic).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/vkn.h"
+#include "vkn_common.h"
+#include "vkn_launch.h"
+
+#define PAN_TW 64
+#define PAN_TH 8
+#define PAN_THREADS 256
+#define PAN_KB 4
+
+// ATen's linear-interpolation coefficients, align_corners=False (aten/src/ATen/native/UpSample.h:
+// area_pixel_compute_source_index + guard_index_and_lambda), fp32 opmath.
+__device__ __forceinline__ void pan_coef(float scale, int dst, int in_size, int& i0, int& i1, float& lam) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = min((int)floorf(src), in_size - 1);
+    lam = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+}
+
+// value of one output pixel of a level from its input region in LDS (row pitch `pitch`), ATen's evaluation order:
+// x first, then y; each as v0*w0 + v1*w1.
+__device__ __forceinline__ float pan_lerp(const float* __restrict__ src, int pitch, int y0, int y1, float ly, int x0, int x1,
+                                          float lx) {
+    const float wx0 = 1.f - lx, wy0 = 1.f - ly;
+    const float r0 = src[y0 * pitch + x0] * wx0 + src[y0 * pitch + x1] * lx;
+    const float r1 = src[y1 * pitch + x0] * wx0 + src[y1 * pitch + x1] * lx;
+    return r0 * wy0 + r1 * ly;
+}
+
+// ------------------------------------------------------------------------------------------------ selection
+// One workgroup per frame.  Ranks by (score descending, index ascending) — torch.topk / sort / argsort leave the order of exact
+// ties unspecified; this is the stable choice.  sel_* [B][K], K = Kt + nstuff; order[B][K] = merge order (indices into sel).
+__global__ __launch_bounds__(256) void k_pan_select(const float* __restrict__ cls, int N, int ncls, int Np, int T, int Kt,
+                                                    int nstuff, int* __restrict__ sel_row, int* __restrict__ sel_label,
+                                                    float* __restrict__ sel_score, int* __restrict__ order) {
+    const int b = blockIdx.x, K = Kt + nstuff;
+    const float* c = cls + (size_t)b * N * ncls;
+    int* row = sel_row + (size_t)b * K;
+    int* lab = sel_label + (size_t)b * K;
+    float* sc = sel_score + (size_t)b * K;
+    const int nth = Np * T;
+    // things: candidate i = (proposal i / T, class i % T)                                knet/det/kernel_iter_head.py:334-340
+    for (int i = threadIdx.x; i < nth; i += 256) {
+        const float s = c[(size_t)(i / T) * ncls + (i % T)];
+        int rank = 0;
+        for (int j = 0; j < nth; ++j) {
+            const float t = c[(size_t)(j / T) * ncls + (j % T)];
+            rank += (t > s) || (t == s && j < i);
+        }
+        if (rank < Kt) {
+            row[rank] = i / T;
+            lab[rank] = i % T;
+            sc[rank] = s;
+        }
+    }
+    // stuff: score j = cls[Np + j][T + j], sorted descending; joint labels = T + j         :349-352, :359
+    for (int i = threadIdx.x; i < nstuff; i += 256) {
+        const float s = c[(size_t)(Np + i) * ncls + (T + i)];
+        int rank = 0;
+        for (int j = 0; j < nstuff; ++j) {
+            const float t = c[(size_t)(Np + j) * ncls + (T + j)];
+            rank += (t > s) || (t == s && j < i);
+        }
+        row[Kt + rank] = Np + i;
+        lab[Kt + rank] = T + i;
+        sc[Kt + rank] = s;
+    }
+    __syncthreads();
+    __threadfence_block();
+    // merge order: argsort(-total_scores)                                                  :489
+    for (int i = threadIdx.x; i < K; i += 256) {
+        const float s = sc[i];
+        int rank = 0;
+        for (int j = 0; j < K; ++j) {
+            const float t = sc[j];
+            rank += (t > s) || (t == s && j < i);
+        }
+        order[(size_t)b * K + rank] = i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused resample + arg-max
+struct PanLevel {
+    int in_h, in_w;  // size of the level's input image
+    float sy, sx;    // output -> input coordinate scale
+};
+struct PanGeom {
+    int Hm, Wm;       // low-res logits
+    PanLevel lv[3];   // [0] x`up` of the logits (sigmoid applied to its output), [1] -> batch_input_shape, [2] crop -> ori_shape
+    int nlev;         // 3, or 2 when the last resize is the identity (ori_shape == img_shape)
+    int Ho, Wo;       // output size
+    int cap_w[3], cap_h[3];  // LDS capacity of the INPUT region of level i
+};
+
+struct PanTab {  // per-level coefficient tables in LDS (local indices into the level's input region)
+    int *x0, *x1, *y0, *y1;
+    float *lx, *ly;
+};
+
+__global__ __launch_bounds__(PAN_THREADS) void k_pan_argmax(PanGeom g, const float* __restrict__ masks,
+                                                            const int* __restrict__ sel_row,
+                                                            const float* __restrict__ sel_score, int K, int N,
+                                                            int* __restrict__ ids, int* __restrict__ area,
+                                                            int* __restrict__ orig, int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int rx0[3], ry0[3], rw[3], rh[3];  // input region of each level (absolute origin, extent)
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int X0 = blockIdx.x * PAN_TW, Y0 = blockIdx.y * PAN_TH;
+    const int nl = g.nlev;
+    const int tw = min(PAN_TW, g.Wo - X0), th = min(PAN_TH, g.Ho - Y0);
+
+    // ---- carve LDS: tables, counters, region buffers
+    char* p = smem;
+    auto take_i = [&](int n) { int* r = reinterpret_cast<int*>(p); p += (size_t)n * 4; return r; };
+    auto take_f = [&](int n) { float* r = reinterpret_cast<float*>(p); p += (size_t)n * 4; return r; };
+    PanTab tab[3] = {};
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        if (l >= nl) break;
+        const int nw = (l == nl - 1) ? PAN_TW : g.cap_w[l + 1], nh = (l == nl - 1) ? PAN_TH : g.cap_h[l + 1];
+        tab[l].x0 = take_i(nw); tab[l].x1 = take_i(nw); tab[l].lx = take_f(nw);
+        tab[l].y0 = take_i(nh); tab[l].y1 = take_i(nh); tab[l].ly = take_f(nh);
+    }
+    int* area_s = take_i(K);
+    int* orig_s = take_i(K);
+    float* buf[3] = {nullptr, nullptr, nullptr};
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+        if (l < nl) buf[l] = take_f(PAN_KB * g.cap_w[l] * g.cap_h[l]);
+
+    for (int i = tid; i < K; i += PAN_THREADS) { area_s[i] = 0; orig_s[i] = 0; }
+
+    // ---- coefficient tables, from the output tile back to the logits (once per tile)
+#pragma unroll
+    for (int l = 2; l >= 0; --l) {
+        if (l >= nl) continue;
+        const int ox0 = (l == nl - 1) ? X0 : rx0[l + 1], oy0 = (l == nl - 1) ? Y0 : ry0[l + 1];
+        const int ow = (l == nl - 1) ? tw : rw[l + 1], oh = (l == nl - 1) ? th : rh[l + 1];
+        for (int i = tid; i < ow; i += PAN_THREADS) pan_coef(g.lv[l].sx, ox0 + i, g.lv[l].in_w, tab[l].x0[i], tab[l].x1[i], tab[l].lx[i]);
+        for (int i = tid; i < oh; i += PAN_THREADS) pan_coef(g.lv[l].sy, oy0 + i, g.lv[l].in_h, tab[l].y0[i], tab[l].y1[i], tab[l].ly[i]);
+        __syncthreads();
+        if (tid == 0) {
+            rx0[l] = tab[l].x0[0]; rw[l] = tab[l].x1[ow - 1] - tab[l].x0[0] + 1;
+            ry0[l] = tab[l].y0[0]; rh[l] = tab[l].y1[oh - 1] - tab[l].y0[0] + 1;
+            if (rw[l] > g.cap_w[l] || rh[l] > g.cap_h[l]) atomicExch(err, 1);
+        }
+        __syncthreads();
+        if (rw[l] > g.cap_w[l] || rh[l] > g.cap_h[l]) return;  // capacity bug: reported through `err`, never silent
+        for (int i = tid; i < ow; i += PAN_THREADS) { tab[l].x0[i] -= rx0[l]; tab[l].x1[i] -= rx0[l]; }
+        for (int i = tid; i < oh; i += PAN_THREADS) { tab[l].y0[i] -= ry0[l]; tab[l].y1[i] -= ry0[l]; }
+        __syncthreads();
+    }
+
+    // this thread's two output pixels: (fx, fy) and (fx, fy + 4)
+    const int fx = tid & 63, fy = tid >> 6;
+    const bool okx = fx < tw, ok0 = okx && fy < th, ok1 = okx && (fy + 4) < th;
+    const PanTab tf = (nl == 3) ? tab[2] : tab[1];
+    const int fx0 = tf.x0[okx ? fx : 0], fx1 = tf.x1[okx ? fx : 0];
+    const float flx = tf.lx[okx ? fx : 0];
+    const int fya0 = tf.y0[ok0 ? fy : 0], fya1 = tf.y1[ok0 ? fy : 0], fyb0 = tf.y0[ok1 ? fy + 4 : 0], fyb1 = tf.y1[ok1 ? fy + 4 : 0];
+    const float flya = tf.ly[ok0 ? fy : 0], flyb = tf.ly[ok1 ? fy + 4 : 0];
+    float best0 = -INFINITY, best1 = -INFINITY;
+    int id0 = 0, id1 = 0;
+
+    const int lw = rw[0], lh = rh[0], lp = g.cap_w[0], ln = g.cap_w[0] * g.cap_h[0];
+    const float* mb = masks + (size_t)b * N * g.Hm * g.Wm;
+    const int* rowp = sel_row + (size_t)b * K;
+    const float* scp = sel_score + (size_t)b * K;
+
+    for (int k0 = 0; k0 < K; k0 += PAN_KB) {
+        const int nk = min(PAN_KB, K - k0);
+        // ---- logits footprint of nk kernels -> LDS
+        for (int i = tid; i < nk * lh * lw; i += PAN_THREADS) {
+            const int kk = i / (lh * lw), r = i - kk * lh * lw, yy = r / lw, xx = r - yy * lw;
+            buf[0][kk * ln + yy * lp + xx] = mb[((size_t)rowp[k0 + kk] * g.Hm + ry0[0] + yy) * g.Wm + rx0[0] + xx];
+        }
+        __syncthreads();
+        // ---- intermediate levels: buf[l] -> buf[l+1]; level 0's output goes through the sigmoid (rescale_masks :446)
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (l >= nl - 1) break;
+            const int ow = rw[l + 1], oh = rh[l + 1], ip = g.cap_w[l], in = g.cap_w[l] * g.cap_h[l];
+            const int op = g.cap_w[l + 1], on = g.cap_w[l + 1] * g.cap_h[l + 1];
+            const PanTab& t = tab[l];
+            for (int i = tid; i < nk * oh * ow; i += PAN_THREADS) {
+                const int kk = i / (oh * ow), r = i - kk * oh * ow, yy = r / ow, xx = r - yy * ow;
+                float v = pan_lerp(buf[l] + kk * in, ip, t.y0[yy], t.y1[yy], t.ly[yy], t.x0[xx], t.x1[xx], t.lx[xx]);
+                if (l == 0) v = 1.0f / (1.0f + expf(-v));
+                buf[l + 1][kk * on + yy * op + xx] = v;
+            }
+            __syncthreads();
+        }
+        // ---- last level per output pixel + score-weighted arg-max + ">= 0.5" count                      :484-486, :499
+        {
+            const int ip = (nl == 3) ? g.cap_w[2] : g.cap_w[1], in = ip * ((nl == 3) ? g.cap_h[2] : g.cap_h[1]);
+            const float* last = (nl == 3) ? buf[2] : buf[1];
+            for (int kk = 0; kk < nk; ++kk) {
+                const float* src = last + kk * in;
+                const float v0 = pan_lerp(src, ip, fya0, fya1, flya, fx0, fx1, flx);
+                const float v1 = pan_lerp(src, ip, fyb0, fyb1, flyb, fx0, fx1, flx);
+                const float s = scp[k0 + kk];
+                const float p0 = s * v0, p1 = s * v1;
+                if (p0 > best0) { best0 = p0; id0 = k0 + kk; }
+                if (p1 > best1) { best1 = p1; id1 = k0 + kk; }
+                const int c = __popcll(__ballot(ok0 && v0 >= 0.5f)) + __popcll(__ballot(ok1 && v1 >= 0.5f));
+                if ((tid & 63) == 0 && c) atomicAdd(&orig_s[k0 + kk], c);
+            }
+        }
+        __syncthreads();
+    }
+
+    int* idp = ids + (size_t)b * g.Ho * g.Wo;
+    if (ok0) { idp[(size_t)(Y0 + fy) * g.Wo + X0 + fx] = id0; atomicAdd(&area_s[id0], 1); }
+    if (ok1) { idp[(size_t)(Y0 + fy + 4) * g.Wo + X0 + fx] = id1; atomicAdd(&area_s[id1], 1); }
+    __syncthreads();
+    for (int i = tid; i < K; i += PAN_THREADS) {
+        if (area_s[i]) atomicAdd(&area[(size_t)b * K + i], area_s[i]);
+        if (orig_s[i]) atomicAdd(&orig[(size_t)b * K + i], orig_s[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sequential merge
+// One thread per frame: the score-ordered accept / reject loop                       knet/det/kernel_iter_head.py:492-522
+// info[B][K][6] = {mask row, joint label, segment id (0 = rejected), area, original area, score bits}
+__global__ void k_pan_merge(const int* __restrict__ sel_row, const int* __restrict__ sel_label,
+                            const float* __restrict__ sel_score, const int* __restrict__ order, const int* __restrict__ area,
+                            const int* __restrict__ orig, int B, int K, int T, float inst_thr, double overlap_thr,
+                            int* __restrict__ seg_of, int* __restrict__ info, int* __restrict__ nseg,
+                            const int* __restrict__ err) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int cur = 0;
+    for (int r = 0; r < K; ++r) {
+        const int k = order[(size_t)b * K + r];
+        const size_t kk = (size_t)b * K + k;
+        const bool isthing = sel_label[kk] < T;
+        int sid = 0;
+        if (!(isthing && sel_score[kk] < inst_thr)) {
+            const int a = area[kk], o = orig[kk];
+            if (a > 0 && o > 0 && !((double)a / (double)o < overlap_thr)) sid = ++cur;
+        }
+        seg_of[kk] = sid;
+        int* e = info + kk * 6;
+        e[0] = sel_row[kk]; e[1] = sel_label[kk]; e[2] = sid; e[3] = area[kk]; e[4] = orig[kk];
+        e[5] = __float_as_int(sel_score[kk]);
+    }
+    nseg[b] = *err ? -1 : cur;  // -1: the arg-max kernel hit an LDS capacity bug (never silent)
+}
+
+// panoptic_seg[p] = segment id of the kernel that won pixel p (in place over the id map)                :503
+__global__ __launch_bounds__(256) void k_pan_relabel(int* __restrict__ seg, const int* __restrict__ seg_of, int K, size_t npx) {
+    const int b = blockIdx.y;
+    const int* tbl = seg_of + (size_t)b * K;
+    int* s = seg + (size_t)b * npx;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (size_t)gridDim.x * 256) s[i] = tbl[s[i]];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int cap_of(int out_extent, float scale, int in_size) {
+    // n consecutive outputs span (n-1)*scale input coordinates -> at most that + 3 input indices
+    long long c = (long long)ceil((double)(out_extent > 0 ? out_extent - 1 : 0) * (double)scale) + 3;
+    if (c > in_size) c = in_size;
+    return (int)(c < 1 ? 1 : c);
+}
+
+size_t vkn_panoptic_ws_bytes(int B, int K) {
+    // sel_row, sel_label, order, area, orig, seg_of (int) + sel_score (float) + err
+    return ((size_t)B * K * 7 * 4 + 256 + 255) & ~(size_t)255;
+}
+
+int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const float* masks, int B, int N, int ncls,
+                              int* panoptic_seg, int* info, int* nseg, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int Np = c->num_proposals, T = c->num_thing_classes, Kt = c->max_per_img;
+    const int nstuff = N - Np, K = Kt + nstuff;
+    if (Np <= 0 || Np > N || T < 0 || Kt <= 0 || Kt > Np * T || nstuff < 0 || T + nstuff > ncls) return VKN_E_ARG;
+    if (c->up < 1 || c->Hm <= 0 || c->Wm <= 0 || c->Hb <= 0 || c->Wb <= 0 || c->h <= 0 || c->w <= 0 || c->Ho <= 0 || c->Wo <= 0)
+        return VKN_E_ARG;
+    if (c->h > c->Hb || c->w > c->Wb) return VKN_E_ARG;  // img_shape is a crop of batch_input_shape
+    if (ws_bytes < vkn_panoptic_ws_bytes(B, K)) return VKN_E_WORKSPACE;
+    int* wsi = static_cast<int*>(ws);
+    int* sel_row = wsi;
+    int* sel_label = sel_row + (size_t)B * K;
+    int* order = sel_label + (size_t)B * K;
+    int* area = order + (size_t)B * K;
+    int* orig = area + (size_t)B * K;
+    int* seg_of = orig + (size_t)B * K;
+    float* sel_score = reinterpret_cast<float*>(seg_of + (size_t)B * K);
+    int* err = reinterpret_cast<int*>(sel_score + (size_t)B * K);
+    if (hipMemsetAsync(area, 0, (size_t)B * K * 2 * sizeof(int), st) != hipSuccess) return VKN_E_LAUNCH;
+    if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) return VKN_E_LAUNCH;
+
+    hipLaunchKernelGGL(k_pan_select, dim3(B), dim3(256), 0, st, cls, N, ncls, Np, T, Kt, nstuff, sel_row, sel_label, sel_score, order);
+    VKN_CHECK_LAUNCH();
+
+    PanGeom g{};
+    g.Hm = c->Hm; g.Wm = c->Wm;
+    const int Ha = c->Hm * c->up, Wa = c->Wm * c->up;
+    // F.interpolate(scale_factor=up): ATen maps coordinates with 1/scale_factor; size= : with in/out (both in fp32)
+    g.lv[0] = PanLevel{c->Hm, c->Wm, (float)(1.0 / (double)c->up), (float)(1.0 / (double)c->up)};
+    g.lv[1] = PanLevel{Ha, Wa, (float)Ha / (float)c->Hb, (float)Wa / (float)c->Wb};
+    g.lv[2] = PanLevel{c->h, c->w, (float)c->h / (float)c->Ho, (float)c->w / (float)c->Wo};
+    g.nlev = (c->h == c->Ho && c->w == c->Wo) ? 2 : 3;
+    g.Ho = c->Ho; g.Wo = c->Wo;
+    // input-region capacities, from the output tile back
+    int ow = PAN_TW, oh = PAN_TH;
+    for (int l = g.nlev - 1; l >= 0; --l) {
+        g.cap_w[l] = cap_of(ow, g.lv[l].sx, g.lv[l].in_w);
+        g.cap_h[l] = cap_of(oh, g.lv[l].sy, g.lv[l].in_h);
+        ow = g.cap_w[l]; oh = g.cap_h[l];
+    }
+    size_t lds = 0;
+    for (int l = 0; l < g.nlev; ++l) {
+        const int nw = (l == g.nlev - 1) ? PAN_TW : g.cap_w[l + 1], nh = (l == g.nlev - 1) ? PAN_TH : g.cap_h[l + 1];
+        lds += (size_t)(3 * nw + 3 * nh) * 4;
+        lds += (size_t)PAN_KB * g.cap_w[l] * g.cap_h[l] * 4;
+    }
+    lds += (size_t)2 * K * 4;
+    if (lds > 150 * 1024) return VKN_E_SHAPE;  // extreme down-scaling: footprint of one tile does not fit LDS
+    if (hipFuncSetAttribute((const void*)k_pan_argmax, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VKN_E_LAUNCH;
+    dim3 grid((c->Wo + PAN_TW - 1) / PAN_TW, (c->Ho + PAN_TH - 1) / PAN_TH, B);
+    hipLaunchKernelGGL(k_pan_argmax, grid, dim3(PAN_THREADS), lds, st, g, masks, sel_row, sel_score, K, N, panoptic_seg, area, orig, err);
+    VKN_CHECK_LAUNCH();
+
+    hipLaunchKernelGGL(k_pan_merge, dim3((B + 63) / 64), dim3(64), 0, st, sel_row, sel_label, sel_score, order, area, orig, B, K, T,
+                       c->instance_score_thr, c->overlap_thr, seg_of, info, nseg, err);
+    VKN_CHECK_LAUNCH();
+    const size_t npx = (size_t)c->Ho * c->Wo;
+    size_t blocks = (npx + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_pan_relabel, dim3((unsigned)blocks, B), dim3(256), 0, st, panoptic_seg, seg_of, K, npx);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}

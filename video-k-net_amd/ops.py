@@ -398,3 +398,31 @@ def kernel_init(loc_feats, semantic_feats, init_w, seg_w=None, seg_b=None, num_t
                                     _ptr(x_feats), _ptr(masks), _ptr(seg), _ptr(prop), B, Np, ncls, C, P, _ptr(ws), ws.numel(),
                                     flags, _stream()))
     return prop, x_feats, masks, seg
+
+
+def panoptic_joint(cls_prob, mask_logits, num_proposals, num_thing_classes, max_per_img, instance_score_thr, overlap_thr,
+                   img_shape, batch_input_shape, ori_shape, upsample_stride=1):
+    """Joint panoptic merge of a batch of frames sharing one img_meta, straight from the head's low-res mask logits
+    (`get_panoptic` + `merge_stuff_thing_stuff_joint` + `rescale_masks`, knet/det/kernel_iter_head.py:332-370, 467-524).
+    Returns device tensors (panoptic_seg int32 [B,Ho,Wo], info int32 [B,K,6], nseg int32 [B]); see include/vkn.h."""
+    cls, m = _req(cls_prob, 'cls_prob'), _req(mask_logits, 'mask_logits')
+    B, N, ncls = cls.shape
+    if m.shape[0] != B or m.shape[1] != N:
+        raise ValueError('cls_prob [B,N,ncls] and mask_logits [B,N,Hm,Wm] disagree')
+    Hm, Wm = int(m.shape[2]), int(m.shape[3])
+    cfg = _lib.VknPanopticCfg(int(num_proposals), int(num_thing_classes), int(max_per_img), float(instance_score_thr),
+                              float(overlap_thr), int(upsample_stride), Hm, Wm, int(batch_input_shape[0]),
+                              int(batch_input_shape[1]), int(img_shape[0]), int(img_shape[1]), int(ori_shape[0]),
+                              int(ori_shape[1]))
+    K = int(max_per_img) + (N - int(num_proposals))
+    dev = cls.device
+    L = _lib.lib()
+    seg = torch.empty((B, cfg.Ho, cfg.Wo), dtype=torch.int32, device=dev)
+    info = torch.empty((B, K, 6), dtype=torch.int32, device=dev)
+    nseg = torch.empty((B,), dtype=torch.int32, device=dev)
+    nb = L.vkn_panoptic_workspace_bytes(ctypes.byref(cfg), B, N)
+    ws = _workspace(max(nb, 256), dev)
+    with torch.cuda.device(dev):
+        check(L.vkn_panoptic_joint_f32(ctypes.byref(cfg), _ptr(cls), _ptr(m), B, N, ncls, seg.data_ptr(), info.data_ptr(),
+                                       nseg.data_ptr(), _ptr(ws), ws.numel(), _stream()))
+    return seg, info, nseg
