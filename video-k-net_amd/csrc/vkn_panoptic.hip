@@ -19,6 +19,7 @@
 // atomics (order-independent => deterministic).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/vkn.h"
 #include "vkn_common.h"
@@ -119,19 +120,33 @@ struct PanTab {  // per-level coefficient tables in LDS (local indices into the 
     float *lx, *ly;
 };
 
+// Workgroup = one 64x8 output tile of one frame.
+//  1. coefficient tables of every level for this tile, from the output back to the logits;
+//  2. the logits footprint of ALL K kernels -> LDS in one burst (one global-latency exposure per tile), and per kernel the
+//     footprint's max / min logit.  Bilinear resampling and the sigmoid are monotone convex combinations, so every output value
+//     of kernel k in this tile lies in [sigmoid(min_k), sigmoid(max_k)]:  k can neither win a pixel nor reach prob 0.5 here if
+//         score_k * sigmoid(max_k) < LB := max_j score_j * sigmoid(min_j)   and   sigmoid(max_k) < 0.5
+//     (bounds padded by 1e-5 relative: fp32 rounding of the logits moves a probability by <= 2e-6 relative).  Only the surviving kernels — typically a handful per tile for real
+//     segmentation masks — are resampled; the result is identical to visiting all K;
+//  3. per batch of PAN_KB survivors: wave kk resamples kernel kk's footprint level by level through LDS; then every thread
+//     evaluates the last level at its two output pixels, keeps the running arg-max (strict >, ascending k: first maximum wins,
+//     as torch.argmax) and counts prob >= 0.5.
 __global__ __launch_bounds__(PAN_THREADS) void k_pan_argmax(PanGeom g, const float* __restrict__ masks,
                                                             const int* __restrict__ sel_row,
                                                             const float* __restrict__ sel_score, int K, int N,
                                                             int* __restrict__ ids, int* __restrict__ area,
-                                                            int* __restrict__ orig, int* __restrict__ err) {
+                                                            int* __restrict__ orig, int* __restrict__ err, int prune, int KC) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int rx0[3], ry0[3], rw[3], rh[3];  // input region of each level (absolute origin, extent)
-    const int tid = threadIdx.x, b = blockIdx.z;
+    __shared__ int nact_s;
+    __shared__ float lbw[PAN_THREADS / 64];
+    const int tid = threadIdx.x, b = blockIdx.z, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int X0 = blockIdx.x * PAN_TW, Y0 = blockIdx.y * PAN_TH;
     const int nl = g.nlev;
     const int tw = min(PAN_TW, g.Wo - X0), th = min(PAN_TH, g.Ho - Y0);
 
-    // ---- carve LDS: tables, counters, region buffers
+    // ---- carve LDS: tables, per-kernel scalars, region buffers
     char* p = smem;
     auto take_i = [&](int n) { int* r = reinterpret_cast<int*>(p); p += (size_t)n * 4; return r; };
     auto take_f = [&](int n) { float* r = reinterpret_cast<float*>(p); p += (size_t)n * 4; return r; };
@@ -145,14 +160,20 @@ __global__ __launch_bounds__(PAN_THREADS) void k_pan_argmax(PanGeom g, const flo
     }
     int* area_s = take_i(K);
     int* orig_s = take_i(K);
+    int* list = take_i(K);     // surviving kernels, ascending
+    float* khi = take_f(K);    // score * sigmoid(max logit)  (padded up)
+    float* klo = take_f(K);    // score * sigmoid(min logit)  (padded down)
+    float* kpm = take_f(K);    // sigmoid(max logit)          (padded up)
+    const int ln = g.cap_w[0] * g.cap_h[0], lp = g.cap_w[0];
+    float* Ls = take_f(KC * ln);  // logits footprints: of every kernel when KC == K, else of one chunk / one batch at a time
     float* buf[3] = {nullptr, nullptr, nullptr};
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
+    for (int l = 1; l < 3; ++l)
         if (l < nl) buf[l] = take_f(PAN_KB * g.cap_w[l] * g.cap_h[l]);
 
     for (int i = tid; i < K; i += PAN_THREADS) { area_s[i] = 0; orig_s[i] = 0; }
 
-    // ---- coefficient tables, from the output tile back to the logits (once per tile)
+    // ---- 1. coefficient tables, from the output tile back to the logits (once per tile)
 #pragma unroll
     for (int l = 2; l >= 0; --l) {
         if (l >= nl) continue;
@@ -173,6 +194,75 @@ __global__ __launch_bounds__(PAN_THREADS) void k_pan_argmax(PanGeom g, const flo
         __syncthreads();
     }
 
+    // ---- 2. logits footprint of all K kernels -> LDS, bounds, survivor list
+    const int lw = rw[0], lh = rh[0], lwh = lw * lh;
+    const float inv_lw = 1.0f / (float)lw;
+    const float* mb = masks + (size_t)b * N * g.Hm * g.Wm;
+    const int* rowp = sel_row + (size_t)b * K;
+    const float* scp = sel_score + (size_t)b * K;
+    const float* lbase = mb + (size_t)ry0[0] * g.Wm + rx0[0];
+    const size_t plane = (size_t)g.Hm * g.Wm;
+    const bool all_fit = KC >= K;
+    float lb_part = 0.f;
+    for (int c0 = 0; c0 < K; c0 += KC) {
+        const int nc = min(KC, K - c0);
+        {
+            const float inv_lwh = 1.0f / (float)lwh;
+            const int total = nc * lwh;
+            for (int i0 = tid; i0 < total; i0 += PAN_THREADS * 4) {  // 4 independent loads in flight per thread
+                float v[4];
+                int dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(i0 + u * PAN_THREADS, total - 1);
+                    const int k = (int)(((float)i + 0.5f) * inv_lwh), r = i - k * lwh;
+                    const int yy = (int)(((float)r + 0.5f) * inv_lw), xx = r - yy * lw;
+                    dst[u] = k * ln + yy * lp + xx;
+                    v[u] = lbase[(size_t)rowp[c0 + k] * plane + (size_t)yy * g.Wm + xx];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * PAN_THREADS < total) Ls[dst[u]] = v[u];
+            }
+        }
+        __syncthreads();
+        for (int kc = wave; kc < nc; kc += PAN_THREADS / 64) {
+            const int k = c0 + kc;
+            float mx = -INFINITY, mn = INFINITY;
+            for (int r = lane; r < lwh; r += 64) {
+                const int yy = (int)(((float)r + 0.5f) * inv_lw), xx = r - yy * lw;
+                const float v = Ls[kc * ln + yy * lp + xx];
+                mx = fmaxf(mx, v);
+                mn = fminf(mn, v);
+            }
+            mx = vkn_wave_max(mx);
+            mn = -vkn_wave_max(-mn);
+            const float s = scp[k];
+            const float pm = 1.0f / (1.0f + expf(-mx)), pn = 1.0f / (1.0f + expf(-mn));
+            const float hi = s * pm * (1.0f + 1e-5f) + 1e-30f, lo = s * pn * (1.0f - 1e-5f);
+            if (lane == 0) { khi[k] = hi; klo[k] = lo; kpm[k] = pm * (1.0f + 1e-5f); }
+            lb_part = fmaxf(lb_part, lo);
+        }
+        if (!all_fit) __syncthreads();  // the next chunk overwrites Ls
+    }
+    if (lane == 0) lbw[wave] = lb_part;
+    __syncthreads();
+    if (wave == 0) {
+        float LB = 0.f;
+        for (int w = 0; w < PAN_THREADS / 64; ++w) LB = fmaxf(LB, lbw[w]);
+        int cnt = 0;
+        for (int base = 0; base < K; base += 64) {
+            const int k = base + lane;
+            const bool act = k < K && (!prune || khi[k] >= LB || kpm[k] >= 0.5f);
+            const unsigned long long m = __ballot(act);
+            if (act) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = k;
+            cnt += __popcll(m);
+        }
+        if (lane == 0) nact_s = cnt;
+    }
+    __syncthreads();
+    const int nact = nact_s;
+
     // this thread's two output pixels: (fx, fy) and (fx, fy + 4)
     const int fx = tid & 63, fy = tid >> 6;
     const bool okx = fx < tw, ok0 = okx && fy < th, ok1 = okx && (fy + 4) < th;
@@ -184,48 +274,61 @@ __global__ __launch_bounds__(PAN_THREADS) void k_pan_argmax(PanGeom g, const flo
     float best0 = -INFINITY, best1 = -INFINITY;
     int id0 = 0, id1 = 0;
 
-    const int lw = rw[0], lh = rh[0], lp = g.cap_w[0], ln = g.cap_w[0] * g.cap_h[0];
-    const float* mb = masks + (size_t)b * N * g.Hm * g.Wm;
-    const int* rowp = sel_row + (size_t)b * K;
-    const float* scp = sel_score + (size_t)b * K;
-
-    for (int k0 = 0; k0 < K; k0 += PAN_KB) {
-        const int nk = min(PAN_KB, K - k0);
-        // ---- logits footprint of nk kernels -> LDS
-        for (int i = tid; i < nk * lh * lw; i += PAN_THREADS) {
-            const int kk = i / (lh * lw), r = i - kk * lh * lw, yy = r / lw, xx = r - yy * lw;
-            buf[0][kk * ln + yy * lp + xx] = mb[((size_t)rowp[k0 + kk] * g.Hm + ry0[0] + yy) * g.Wm + rx0[0] + xx];
+    // ---- 3. survivors, PAN_KB at a time: wave kk resamples kernel list[a0 + kk] through the intermediate levels
+    for (int a0 = 0; a0 < nact; a0 += PAN_KB) {
+        const int nk = min(PAN_KB, nact - a0);
+        if (wave < nk) {
+            const int k = list[a0 + wave];
+            if (!all_fit) {  // footprints did not all fit: this wave re-stages its kernel's footprint (slot = wave)
+                for (int r = lane; r < lwh; r += 64) {
+                    const int yy = (int)(((float)r + 0.5f) * inv_lw), xx = r - yy * lw;
+                    Ls[wave * ln + yy * lp + xx] = lbase[(size_t)rowp[k] * plane + (size_t)yy * g.Wm + xx];
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+            {   // level 0: logits footprint -> x up -> sigmoid                                     (rescale_masks :446)
+                const int ow = rw[1], oh = rh[1], op = g.cap_w[1];
+                const float inv_ow = 1.0f / (float)ow;
+                const float* src = Ls + (all_fit ? k : wave) * ln;
+                float* dst = buf[1] + wave * (g.cap_w[1] * g.cap_h[1]);
+                const PanTab& t = tab[0];
+                for (int r = lane; r < ow * oh; r += 64) {
+                    const int yy = (int)(((float)r + 0.5f) * inv_ow), xx = r - yy * ow;
+                    const float v = pan_lerp(src, lp, t.y0[yy], t.y1[yy], t.ly[yy], t.x0[xx], t.x1[xx], t.lx[xx]);
+                    dst[yy * op + xx] = 1.0f / (1.0f + expf(-v));
+                }
+            }
+            if (nl == 3) {  // level 1: -> batch_input_shape (the crop is the domain of level 2)
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+                __builtin_amdgcn_wave_barrier();
+                const int ow = rw[2], oh = rh[2], op = g.cap_w[2], ip = g.cap_w[1];
+                const float inv_ow = 1.0f / (float)ow;
+                const float* src = buf[1] + wave * (g.cap_w[1] * g.cap_h[1]);
+                float* dst = buf[2] + wave * (g.cap_w[2] * g.cap_h[2]);
+                const PanTab& t = tab[1];
+                for (int r = lane; r < ow * oh; r += 64) {
+                    const int yy = (int)(((float)r + 0.5f) * inv_ow), xx = r - yy * ow;
+                    dst[yy * op + xx] = pan_lerp(src, ip, t.y0[yy], t.y1[yy], t.ly[yy], t.x0[xx], t.x1[xx], t.lx[xx]);
+                }
+            }
         }
         __syncthreads();
-        // ---- intermediate levels: buf[l] -> buf[l+1]; level 0's output goes through the sigmoid (rescale_masks :446)
-#pragma unroll
-        for (int l = 0; l < 2; ++l) {
-            if (l >= nl - 1) break;
-            const int ow = rw[l + 1], oh = rh[l + 1], ip = g.cap_w[l], in = g.cap_w[l] * g.cap_h[l];
-            const int op = g.cap_w[l + 1], on = g.cap_w[l + 1] * g.cap_h[l + 1];
-            const PanTab& t = tab[l];
-            for (int i = tid; i < nk * oh * ow; i += PAN_THREADS) {
-                const int kk = i / (oh * ow), r = i - kk * oh * ow, yy = r / ow, xx = r - yy * ow;
-                float v = pan_lerp(buf[l] + kk * in, ip, t.y0[yy], t.y1[yy], t.ly[yy], t.x0[xx], t.x1[xx], t.lx[xx]);
-                if (l == 0) v = 1.0f / (1.0f + expf(-v));
-                buf[l + 1][kk * on + yy * op + xx] = v;
-            }
-            __syncthreads();
-        }
         // ---- last level per output pixel + score-weighted arg-max + ">= 0.5" count                      :484-486, :499
         {
             const int ip = (nl == 3) ? g.cap_w[2] : g.cap_w[1], in = ip * ((nl == 3) ? g.cap_h[2] : g.cap_h[1]);
             const float* last = (nl == 3) ? buf[2] : buf[1];
             for (int kk = 0; kk < nk; ++kk) {
+                const int k = list[a0 + kk];
                 const float* src = last + kk * in;
                 const float v0 = pan_lerp(src, ip, fya0, fya1, flya, fx0, fx1, flx);
                 const float v1 = pan_lerp(src, ip, fyb0, fyb1, flyb, fx0, fx1, flx);
-                const float s = scp[k0 + kk];
+                const float s = scp[k];
                 const float p0 = s * v0, p1 = s * v1;
-                if (p0 > best0) { best0 = p0; id0 = k0 + kk; }
-                if (p1 > best1) { best1 = p1; id1 = k0 + kk; }
+                if (p0 > best0) { best0 = p0; id0 = k; }
+                if (p1 > best1) { best1 = p1; id1 = k; }
                 const int c = __popcll(__ballot(ok0 && v0 >= 0.5f)) + __popcll(__ballot(ok1 && v1 >= 0.5f));
-                if ((tid & 63) == 0 && c) atomicAdd(&orig_s[k0 + kk], c);
+                if (lane == 0 && c) atomicAdd(&orig_s[k], c);
             }
         }
         __syncthreads();
@@ -334,14 +437,21 @@ int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const f
     for (int l = 0; l < g.nlev; ++l) {
         const int nw = (l == g.nlev - 1) ? PAN_TW : g.cap_w[l + 1], nh = (l == g.nlev - 1) ? PAN_TH : g.cap_h[l + 1];
         lds += (size_t)(3 * nw + 3 * nh) * 4;
-        lds += (size_t)PAN_KB * g.cap_w[l] * g.cap_h[l] * 4;
+        if (l > 0) lds += (size_t)PAN_KB * g.cap_w[l] * g.cap_h[l] * 4;
     }
-    lds += (size_t)2 * K * 4;
+    // logits footprints: all K kernels when they fit 64 KB, else chunks (bounds pass) / one per wave (resampling pass)
+    const size_t ln_bytes = (size_t)g.cap_w[0] * g.cap_h[0] * 4;
+    int KC = (int)((size_t)65536 / ln_bytes);
+    if (KC >= K) KC = K;
+    if (KC < PAN_KB) KC = PAN_KB;
+    lds += (size_t)KC * ln_bytes;
+    lds += (size_t)6 * K * 4;
     if (lds > 150 * 1024) return VKN_E_SHAPE;  // extreme down-scaling: footprint of one tile does not fit LDS
     if (hipFuncSetAttribute((const void*)k_pan_argmax, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VKN_E_LAUNCH;
     dim3 grid((c->Wo + PAN_TW - 1) / PAN_TW, (c->Ho + PAN_TH - 1) / PAN_TH, B);
-    hipLaunchKernelGGL(k_pan_argmax, grid, dim3(PAN_THREADS), lds, st, g, masks, sel_row, sel_score, K, N, panoptic_seg, area, orig, err);
+    hipLaunchKernelGGL(k_pan_argmax, grid, dim3(PAN_THREADS), lds, st, g, masks, sel_row, sel_score, K, N, panoptic_seg, area, orig, err,
+                       getenv("VKN_PAN_NOPRUNE") ? 0 : 1, KC);  // debugging knob: visit all K kernels in every tile
     VKN_CHECK_LAUNCH();
 
     hipLaunchKernelGGL(k_pan_merge, dim3((B + 63) / 64), dim3(64), 0, st, sel_row, sel_label, sel_score, order, area, orig, B, K, T,
