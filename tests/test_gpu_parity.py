@@ -485,3 +485,82 @@ def test_panoptic_joint_cfg2_size(vkn):
     # determinism
     seg2, info2, _ = vkn.ops.panoptic_joint(cls, logits, Np, T, Np, 0.25, 0.6, shape, shape, shape, upsample_stride=up)
     assert torch.equal(seg, seg2) and np.array_equal(info, info2[0].cpu().numpy())
+
+
+_TEST_CFG = dict(max_per_img=12, mask_thr=0.5, stuff_score_thr=0.05,
+                 merge_stuff_thing=dict(overlap_thr=0.6, iou_thr=0.5, stuff_max_area=4096, instance_score_thr=0.25))
+
+
+def _pan_compare(seg, segments_info, r):
+    """GPU (panoptic_seg ndarray, segments_info) vs an oracle.panoptic_joint result, modulo arg-max near-ties."""
+    from helpers import pan_info_rows
+    near = r['margin'].numpy() < 1e-6
+    diff = seg != r['panoptic_seg'].numpy()
+    assert not (diff & ~near).any() and float(near.mean()) < 5e-3
+    a, b = pan_info_rows(segments_info), pan_info_rows(r['segments_info'])
+    assert a.shape == b.shape
+    assert np.array_equal(np.nan_to_num(a[:, :5], nan=-7.0), np.nan_to_num(b[:, :5], nan=-7.0))      # ids, classes, scores
+    assert np.abs(a[:, 5] - b[:, 5]).sum() <= 2 * int(near.sum())                                        # stuff areas
+
+
+def test_simple_test_panoptic_path(vkn):
+    """KernelIterHead.simple_test (do_panoptic, merge_joint): stage loop + fused post-head pipeline from the low-res logits.
+    Checked against the oracle's panoptic_joint fed with the GPU head's own cls / mask outputs, and against the reference's
+    route through the materialised `scaled_mask_preds` (get_panoptic signature)."""
+    from test_host_logic import _cfg
+    _, case = load_golden('det_tiny')
+    cfg = _cfg(False, C=case['C'], heads=case['heads'], ffn=case['ffn'], ncls=case['ncls'], n_thing=case['n_thing'],
+               n_stuff=case['n_stuff'], S=case['S'], up=case['up'], nprop=case['nprop'])
+    cfg.update(do_panoptic=True, merge_joint=True, test_cfg=_TEST_CFG)
+    head = vkn.build_head(cfg)
+    _, sd, x, pf, mp, _ = make_case(case)
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV).eval()
+    H, W, up = case['H'], case['W'], case['up']
+    meta = dict(img_shape=(H * 8 - 3, W * 8 - 5, 3), batch_input_shape=(H * 8, W * 8), ori_shape=(H * 6, W * 6, 3))
+    metas = [meta] * case['B']
+    dx, dpf, dmp = _cuda(x, pf, mp)
+    res = head.simple_test(dx, dpf, dmp, None, metas)
+    o, c, m, sc = head.simple_test_mask_preds(dx, dpf, dmp, None, metas)
+    assert len(res) == case['B']
+    for b in range(case['B']):
+        bbox, segm, (seg, info) = res[b]
+        assert bbox is None and segm is None and seg.dtype == np.int32 and seg.shape == (H * 6, W * 6)
+        with torch.no_grad():
+            r = O.panoptic_joint(c[b].cpu(), m[b].cpu(), case['nprop'], case['n_thing'], 12, 0.25, 0.6, meta, upsample_stride=up)
+        _pan_compare(seg, info, r)
+        # the reference's own route: get_panoptic on the materialised scaled masks
+        _, _, (seg2, info2) = head.get_panoptic(c[b], sc[b], head.test_cfg, meta)
+        _pan_compare(seg2, info2, r)
+
+
+def test_video_simple_test_with_previous(vkn):
+    """VideoKernelIterHead.simple_test_with_previous: results + tracking embeddings of the accepted thing segments."""
+    from test_host_logic import _cfg
+    _, case = load_golden('video_tiny')
+    cfg = _cfg(True, C=case['C'], heads=case['heads'], ffn=case['ffn'], ncls=case['ncls'], n_thing=case['n_thing'],
+               n_stuff=case['n_stuff'], S=case['S'], up=case['up'], nprop=case['nprop'])
+    cfg.update(do_panoptic=True, merge_joint=True, with_track=True, test_cfg=_TEST_CFG)
+    head = vkn.build_head(cfg)
+    _, sd, x, pf, mp, prev = make_case(case)
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV).eval()
+    H, W = case['H'], case['W']
+    meta = dict(img_shape=(H * 8, W * 8, 3), batch_input_shape=(H * 8, W * 8), ori_shape=(H * 8, W * 8, 3))
+    metas = [meta] * case['B']
+    dx, dpf, dmp, dprev = _cuda(x, pf, mp, prev)
+    results, obj, cls, masks, scaled = head.simple_test_with_previous(dx, dpf, dmp, None, metas, previous_obj_feats=dprev)
+    o2, c2, m2, s2, track = head.simple_test_mask_preds_plus_previous(dx, dpf, dmp, None, metas, previous_obj_feats=dprev,
+                                                                      return_track=True)
+    assert torch.equal(masks, m2) and torch.equal(cls, c2) and torch.equal(scaled, s2)
+    for b in range(case['B']):
+        bbox, segm, tmask, (seg, info), tfeat = results[b]
+        with torch.no_grad():
+            r = O.panoptic_joint(cls[b].cpu(), masks[b].cpu(), case['nprop'], case['n_thing'], 12, 0.25, 0.6, meta,
+                                 upsample_stride=case['up'])
+        _pan_compare(seg, info, r)
+        things = [s for s in info if s['isthing']]
+        assert tfeat.shape[0] == len(things)
+        rows = r['rows'].numpy()
+        for j, s_ in enumerate(things):
+            assert torch.equal(tfeat[j], track[b, int(rows[s_['instance_id']])])

@@ -3,9 +3,12 @@
 `mask_head.{s}.*` module tree and call signatures.  The stage loop itself is ONE C-ABI call (`vkn_head_forward_f32`) when
 every stage is one of our heads on a GPU tensor; `_mask_forward` exposes the per-stage path exactly like the reference.
 
-Train-time assignment / sampling / losses (`forward_train`) and the post-head panoptic merge (`simple_test`'s
-`get_panoptic`) are "next" rows of SURVEY.md §8(f) and raise NotImplementedError here.
+The post-head panoptic path (`simple_test` with do_panoptic + merge_joint, `get_panoptic`) runs the fused
+`vkn_panoptic_joint_f32` pipeline straight from the low-res mask logits (no [K, H, W] full-resolution tensor is materialised).
+Train-time assignment / sampling / losses (`forward_train`), the thing-first merge variant and the instance-only
+`get_seg_masks` path are later rows of SURVEY.md §8(f) and raise NotImplementedError here.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -95,7 +98,8 @@ class KernelIterHead(BaseRoIHead):
                 and len({(h.in_channels, h.num_heads, h.feedforward_channels, h.fc_cls.out_features, h.num_cls_fcs,
                           h.num_mask_fcs, h.hard_mask_thr, h.with_ffn, h.feat_transform is None) for h in self.mask_head}) == 1)
 
-    def _head_forward(self, x, proposal_feats, mask_preds, previous_obj_feats=None, want_track=False, flags=0):
+    def _head_forward(self, x, proposal_feats, mask_preds, previous_obj_feats=None, want_track=False, flags=0,
+                      want_scaled=True):
         h0, hl = self.mask_head[0], self.mask_head[-1]
         for h in self.mask_head:
             h._check_inputs(x, proposal_feats, mask_preds, None)
@@ -106,7 +110,8 @@ class KernelIterHead(BaseRoIHead):
         packs = [h.stage_pack(x.device) for h in self.mask_head]
         prev = previous_obj_feats.reshape(B, N, C) if previous_obj_feats is not None else None
         obj, cls, masks, scaled, track = ops.head_forward(dims, packs, x, proposal_feats.reshape(B, N, C), mask_preds, prev,
-                                                          hl.mask_upsample_stride, want_track=want_track, flags=flags)
+                                                          hl.mask_upsample_stride, want_track=want_track, want_scaled=want_scaled,
+                                                          flags=flags)
         if not hl.loss_cls.use_sigmoid:
             raise NotImplementedError('softmax cls activation (reference :309-310): every shipped config uses sigmoid')
         obj = obj.reshape(B, N, C, K, K)
@@ -143,9 +148,78 @@ class KernelIterHead(BaseRoIHead):
     def forward_train(self, *a, **k):
         raise NotImplementedError('forward_train (assign/sample/loss per stage, reference :139-231) is a "next" row')
 
-    def simple_test(self, *a, **k):
-        raise NotImplementedError('simple_test = simple_test_mask_preds + panoptic merge (reference :233-283, 332-370, '
-                                  '467-524); the merge is "next" row 1 of SURVEY.md §8(f) — call simple_test_mask_preds')
+    # ---- post-head pipeline (reference :233-283, 332-370, 467-524)
+    @staticmethod
+    def _cfg(cfg, key):
+        return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
+
+    @staticmethod
+    def _meta_geometry(meta):
+        return tuple(meta['img_shape'][:2]), tuple(meta['batch_input_shape'][:2]), tuple(meta['ori_shape'][:2])
+
+    def _panoptic_joint(self, cls_score, mask_logits, test_cfg, img_meta, upsample_stride):
+        """Frames [B] sharing one img_meta -> device tensors (panoptic_seg [B,Ho,Wo] int32, info [B,K,6], nseg [B])."""
+        if not self.merge_joint:
+            raise NotImplementedError('the thing-first merge (merge_stuff_thing, reference :385-465) is not provided: every '
+                                      'shipped panoptic config sets merge_joint=True')
+        merge_cfg = self._cfg(test_cfg, 'merge_stuff_thing')
+        img, bis, ori = self._meta_geometry(img_meta)
+        return ops.panoptic_joint(cls_score, mask_logits, self.num_proposals, self.num_thing_classes,
+                                  self._cfg(test_cfg, 'max_per_img'), self._cfg(merge_cfg, 'instance_score_thr'),
+                                  self._cfg(merge_cfg, 'overlap_thr'), img, bis, ori, upsample_stride=upsample_stride)
+
+    def _segments_info(self, info_b):
+        """info [K,6] (host numpy) -> the reference's segments_info list, in segment-id order (reference :505-521)."""
+        out = []
+        acc = np.nonzero(info_b[:, 2] > 0)[0]
+        for k in acc[np.argsort(info_b[acc, 2], kind='stable')]:
+            label, sid = int(info_b[k, 1]), int(info_b[k, 2])
+            if label < self.num_thing_classes:
+                out.append(dict(id=sid, isthing=True, score=float(info_b[k, 5:6].view(np.float32)[0]), category_id=label,
+                                instance_id=int(k)))
+            else:
+                out.append(dict(id=sid, isthing=False, category_id=label - self.num_thing_classes + 1, area=int(info_b[k, 3])))
+        return out
+
+    def get_panoptic(self, cls_scores, mask_preds, test_cfg, img_meta):
+        """One image, the reference's signature (:332-370): `mask_preds` are the (already up-scaled) `scaled_mask_preds[img]`.
+        Returns `(bbox_result, segm_result, (panoptic_seg int32 ndarray, segments_info))`; the first two are None: they are
+        the K full-resolution thing masks as host arrays (`segm2result`), which this pipeline exists to NOT materialise."""
+        seg, info, nseg = self._panoptic_joint(cls_scores[None], mask_preds[None], test_cfg, img_meta, 1)
+        info_h = info[0].cpu().numpy()
+        if int(nseg[0]) < 0:
+            raise RuntimeError('vkn_panoptic_joint_f32: internal LDS capacity error')
+        return None, None, (seg[0].cpu().numpy(), self._segments_info(info_h))
+
+    def _panoptic_results(self, cls_score, mask_preds, img_metas, upsample_stride):
+        """All frames of a batch: one fused call per group of frames with identical geometry (normally one group)."""
+        groups = {}
+        for i, m in enumerate(img_metas):
+            groups.setdefault(self._meta_geometry(m), []).append(i)
+        results = [None] * len(img_metas)
+        for idx in groups.values():
+            sel = torch.as_tensor(idx, device=cls_score.device)
+            whole = len(idx) == len(img_metas)
+            seg, info, nseg = self._panoptic_joint(cls_score if whole else cls_score[sel], mask_preds if whole else mask_preds[sel],
+                                                   self.test_cfg, img_metas[idx[0]], upsample_stride)
+            seg_h, info_h, nseg_h = seg.cpu().numpy(), info.cpu().numpy(), nseg.cpu().numpy()   # the only host sync
+            if (nseg_h < 0).any():
+                raise RuntimeError('vkn_panoptic_joint_f32: internal LDS capacity error')
+            for j, i in enumerate(idx):
+                results[i] = (seg_h[j], self._segments_info(info_h[j]), info_h[j])
+        return results
+
+    def simple_test(self, x, proposal_feats, mask_preds, cls_score, img_metas, imgs_whwh=None, rescale=False):
+        """Stage loop + panoptic results per image (reference :233-283): a list of
+        `(bbox_result, segm_result, (panoptic_seg, segments_info))` with bbox/segm results None (see get_panoptic)."""
+        if not self.do_panoptic:
+            raise NotImplementedError('instance-only results (get_seg_masks, reference :265-281) need the K full-resolution '
+                                      'masks on the host; not provided')
+        if not self._fused_ok(x):
+            raise NotImplementedError('simple_test needs the fused GPU head (eval mode, CUDA tensors)')
+        _, cls, masks, _, _ = self._head_forward(x, proposal_feats, mask_preds, want_scaled=False)
+        up = self.mask_head[-1].mask_upsample_stride
+        return [(None, None, (seg, info)) for seg, info, _ in self._panoptic_results(cls, masks, img_metas, up)]
 
     def aug_test(self, features, proposal_list, img_metas, rescale=False):
         raise NotImplementedError('SparseMask does not support `aug_test`')
@@ -219,6 +293,44 @@ class VideoKernelIterHead(KernelIterHead):
             track[0] = cur[0]
         return obj, cls, masks, scaled, track.reshape(obj.shape)
 
-    def simple_test_with_previous(self, *a, **k):
-        raise NotImplementedError('simple_test_with_previous = the stage loop + panoptic merge/tracking results '
-                                  '(reference :435-506): merge is a "next" row — call simple_test_mask_preds_plus_previous')
+    def get_panoptic(self, cls_scores, mask_preds, test_cfg, img_meta, obj_feat=None):
+        """Video signature (knet/video/kernel_iter_head.py:591-640): 5-tuple
+        `(bbox_result, segm_result, thing_mask_preds, panoptic_result, thing_obj_feat)`.  The first three (boxes and the K
+        full-resolution thing masks for the tracker) are None — see KernelIterHead.get_panoptic; `thing_obj_feat` are the
+        tracking embeddings of the accepted thing segments in segment order (`sort_obj_fea[things_ids]`, :903)."""
+        seg, info, nseg = self._panoptic_joint(cls_scores[None], mask_preds[None], test_cfg, img_meta, 1)
+        info_h = info[0].cpu().numpy()
+        if int(nseg[0]) < 0:
+            raise RuntimeError('vkn_panoptic_joint_f32: internal LDS capacity error')
+        return None, None, None, (seg[0].cpu().numpy(), self._segments_info(info_h)), self._thing_obj_feat(info_h, obj_feat)
+
+    def _thing_obj_feat(self, info_b, obj_feat):
+        if obj_feat is None:
+            return None
+        acc = np.nonzero((info_b[:, 2] > 0) & (info_b[:, 1] < self.num_thing_classes))[0]
+        acc = acc[np.argsort(info_b[acc, 2], kind='stable')]
+        rows = torch.as_tensor(info_b[acc, 0].astype(np.int64), device=obj_feat.device)
+        return obj_feat[rows]
+
+    def simple_test_with_previous(self, x, proposal_feats, mask_preds, cls_score, img_metas, previous_obj_feats=None,
+                                  previous_mask_preds=None, previous_x_feats=None, is_first=False):
+        """Stage loop with the last-stage tracking link + panoptic results per image
+        (knet/video/kernel_iter_head.py:435-506).  `results[i]` is the 5-tuple of `get_panoptic`; with `with_track` the
+        reference's `(results, object_feats, cls_score, mask_preds, scaled_mask_preds)` is returned."""
+        if not self.do_panoptic:
+            raise NotImplementedError('instance-only results (get_seg_masks) need the K full-resolution masks on the host')
+        if not (self._fused_ok(x) and all(isinstance(h, VideoKernelUpdateHead) for h in self.mask_head)):
+            raise NotImplementedError('simple_test_with_previous needs the fused GPU head (eval mode, CUDA tensors)')
+        link = previous_obj_feats is not None and self.mask_head[-1].previous is not None
+        obj, cls, masks, scaled, track = self._head_forward(x, proposal_feats, mask_preds,
+                                                            previous_obj_feats if link else None, want_track=link,
+                                                            want_scaled=self.with_track)
+        if is_first or track is None:
+            track = obj                                                                                   # :474-475
+        up = self.mask_head[-1].mask_upsample_stride
+        results = []
+        for i, (seg, seg_info, info_h) in enumerate(self._panoptic_results(cls, masks, img_metas, up)):
+            results.append((None, None, None, (seg, seg_info), self._thing_obj_feat(info_h, track[i])))
+        if self.with_track:
+            return results, obj, cls, masks, scaled
+        return results
