@@ -49,6 +49,25 @@ def synth_inputs(B, device, seed):
     return x.to(device), pf.to(device), mp.to(device)
 
 
+def panoptic_inputs(B, N, Np, ncls, H, W, device, seed=7):
+    """cls probabilities and segmentation-like mask logits for the post-head timing: one soft elliptic blob per thing kernel,
+    one horizontal band per stuff kernel, plus noise (i.i.d. noise would be rejected wholesale by the merge)."""
+    g = torch.Generator(device='cpu').manual_seed(4321 + seed)
+    cls = torch.rand(B, N, ncls, generator=g) * 0.96 + 0.02
+    cx, cy = torch.rand(B, N, 1, 1, generator=g), torch.rand(B, N, 1, 1, generator=g)
+    r0 = (0.5 / Np) ** 0.5
+    rx, ry = (torch.rand(B, N, 1, 1, generator=g) + 0.5) * r0, (torch.rand(B, N, 1, 1, generator=g) + 0.5) * r0
+    ys = ((torch.arange(H) + 0.5) / H).view(1, 1, H, 1)
+    xs = ((torch.arange(W) + 0.5) / W).view(1, 1, 1, W)
+    logits = (6.0 * (1.0 - torch.sqrt(((xs - cx) / rx) ** 2 + ((ys - cy) / ry) ** 2))).clamp(-6.0, 6.0)
+    ns = N - Np
+    for j in range(ns):
+        inside = ((ys >= j / ns) & (ys < (j + 1) / ns)).expand(B, 1, H, W)[:, 0]
+        logits[:, Np + j] = torch.where(inside, torch.tensor(4.0), torch.tensor(-4.0))
+    logits = logits + 0.7 * torch.randn(B, N, H, W, generator=g)
+    return cls.to(device), logits.to(device)
+
+
 def cpu_baseline(head_sd, sample_frames=1, runs=6):
     """The CPU oracle (same ATen op sequence as the reference) on this host's cores — kind 'port'."""
     from oracle.knet_oracle import HeadCfg, iter_head_mask_preds
@@ -243,7 +262,33 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             up_ms = e0.elapsed_time(e1) / 5
+            # the two widened rows, timed for the record; they are NOT part of `value`
+            P0 = CFG2['N'] - 17
+            loc, sem = x, torch.roll(x, 1, 0)
+            iw = torch.randn(P0, C, 1, 1, device=device) * 0.05
+            sw, sb = torch.randn(19, C, 1, 1, device=device) * 0.05, torch.zeros(19, device=device)
+            for _ in range(2):
+                vkn.ops.kernel_init(loc, sem, iw, sw, sb, 2, True, True)
+            e0.record()
+            for _ in range(5):
+                vkn.ops.kernel_init(loc, sem, iw, sw, sb, 2, True, True)
+            e1.record()
+            torch.cuda.synchronize()
+            init_ms = e0.elapsed_time(e1) / 5
+            full = (CFG2['H'] * 8, CFG2['W'] * 8)
+            # post-head: structured logits (blobs / bands) — the arg-max kernel's footprint pruning is data dependent
+            pc, pl = panoptic_inputs(B, N, P0, 19, CFG2['H'], CFG2['W'], device)
+            pan = lambda: vkn.ops.panoptic_joint(pc, pl, P0, 2, P0, 0.25, 0.6, full, full, full, upsample_stride=CFG2['up'])  # noqa: E731
+            for _ in range(2):
+                pan()
+            e0.record()
+            for _ in range(5):
+                pan()
+            e1.record()
+            torch.cuda.synchronize()
+            pan_ms = e0.elapsed_time(e1) / 5
             extra['breakdown'] = dict(decode_ms=round(dec_ms, 4), gather_plus_reduce_ms=round(ga_ms, 4),
+                                      kernel_init_pass0_ms=round(init_ms, 4), panoptic_joint_1024x2048_ms=round(pan_ms, 4),
                                       gather_GBps=round(alg / (ga_ms * 1e-3) / 1e9, 1),
                                       head_3stages_no_upsample_ms=round(head_ms, 4),
                                       upsample_x4_ms=round(up_ms, 4),
