@@ -27,7 +27,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ABL (ablation, debugging only; selected by env VKN_DECODE_ABL): 0 = the real kernel, 1 = no MFMA, 2 = no x loads,
 // 3 = no output stores.  Variants 1-3 produce WRONG results by construction and exist to attribute time.
-template <int NB, int ABL>
+template <int NB, int ABL, int RING>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     const float* __restrict__ x, const _Float16* __restrict__ kfh, const _Float16* __restrict__ kfl,
     const float* __restrict__ kb, float* __restrict__ out, int N, int NPT, int n0, int C, int P, int px_per_wg,
@@ -200,18 +200,38 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
         }                                                                                                         \
     } while (0)
 
-    // 3-deep register ring: 2 fragments (16 dwordx2 loads = 8 KB per wave, 64 KB per CU) in flight behind the MFMAs
-    DEC_LOAD(r0);
-    DEC_LOAD(r1);
-    for (int f = 0; f < total; f += 3) {
-        DEC_LOAD(r2);
-        DEC_COMPUTE(r0);
-        if (f + 1 >= total) break;
+    // register ring: RING - 1 fragments (8 dwordx2 loads = 4 KB per wave each) in flight behind the MFMAs
+    if constexpr (RING == 3) {
         DEC_LOAD(r0);
-        DEC_COMPUTE(r1);
-        if (f + 2 >= total) break;
         DEC_LOAD(r1);
-        DEC_COMPUTE(r2);
+        for (int f = 0; f < total; f += 3) {
+            DEC_LOAD(r2);
+            DEC_COMPUTE(r0);
+            if (f + 1 >= total) break;
+            DEC_LOAD(r0);
+            DEC_COMPUTE(r1);
+            if (f + 2 >= total) break;
+            DEC_LOAD(r1);
+            DEC_COMPUTE(r2);
+        }
+    } else {
+        u32x2 r3[8];
+        DEC_LOAD(r0);
+        DEC_LOAD(r1);
+        DEC_LOAD(r2);
+        for (int f = 0; f < total; f += 4) {
+            DEC_LOAD(r3);
+            DEC_COMPUTE(r0);
+            if (f + 1 >= total) break;
+            DEC_LOAD(r0);
+            DEC_COMPUTE(r1);
+            if (f + 2 >= total) break;
+            DEC_LOAD(r1);
+            DEC_COMPUTE(r2);
+            if (f + 3 >= total) break;
+            DEC_LOAD(r2);
+            DEC_COMPUTE(r3);
+        }
     }
 #undef DEC_LOAD
 #undef DEC_COMPUTE
@@ -283,27 +303,31 @@ int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kf
     const char* ppw_env = getenv("VKN_DECODE_PXWG");  // debugging: override pixels per workgroup
     if (ppw_env && atoi(ppw_env) >= 512) px_per_wg = atoi(ppw_env) / 512 * 512;
     const int G2 = (P + px_per_wg - 1) / px_per_wg;
+    const int ring = getenv("VKN_DECODE_RING") ? atoi(getenv("VKN_DECODE_RING")) : 3;  // debugging: ring depth A/B
     const int xcd = getenv("VKN_DECODE_XCD") ? atoi(getenv("VKN_DECODE_XCD")) : 1;  // measured +1 % (tools/decode_sweep.py)
     for (int n0 = 0; n0 < NPT; n0 += 128) {
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
         const size_t lds = (size_t)2 * nb * 32 * (C + 8) * sizeof(_Float16) + (size_t)nb * 32 * sizeof(float);
         dim3 grid(G2, B, 1), block(DEC_THREADS);
-#define DEC_LAUNCH(NBV, ABLV)                                                                                  \
+#define DEC_LAUNCH(NBV, ABLV, RINGV)                                                                           \
     do {                                                                                                       \
-        if (dec_set_lds((const void*)k_decode_mfma<NBV, ABLV>, lds)) return VKN_E_LAUNCH;                      \
-        hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV>), grid, block, lds, stream, x, kfh, kfl, kb, out, N, NPT, n0, C, \
-                           P, px_per_wg, xcd, fs);                                                                 \
+        if (dec_set_lds((const void*)k_decode_mfma<NBV, ABLV, RINGV>, lds)) return VKN_E_LAUNCH;               \
+        hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV, RINGV>), grid, block, lds, stream, x, kfh, kfl, kb, out, N, NPT, n0, C, \
+                           P, px_per_wg, xcd, fs);                                                             \
     } while (0)
-#define DEC_CASE(NBV)                    \
-    case NBV:                            \
-        if (abl == 0) DEC_LAUNCH(NBV, 0); \
-        else if (NBV == 4 && abl == 1) DEC_LAUNCH(4, 1); \
-        else if (NBV == 4 && abl == 2) DEC_LAUNCH(4, 2); \
-        else if (NBV == 4 && abl == 3) DEC_LAUNCH(4, 3); \
-        else if (NBV == 4 && abl == 4) DEC_LAUNCH(4, 4); \
-        else if (NBV == 4 && abl == 5) DEC_LAUNCH(4, 5); \
-        else if (NBV == 4 && abl == 6) DEC_LAUNCH(4, 6); \
-        else DEC_LAUNCH(NBV, 0);         \
+#define DEC_CASE(NBV)                                        \
+    case NBV:                                                \
+        if (abl == 0) {                                      \
+            if (ring == 3) DEC_LAUNCH(NBV, 0, 3);            \
+            else DEC_LAUNCH(NBV, 0, 4);                      \
+        }                                                    \
+        else if (NBV == 4 && abl == 1) DEC_LAUNCH(4, 1, 3);  \
+        else if (NBV == 4 && abl == 2) DEC_LAUNCH(4, 2, 3);  \
+        else if (NBV == 4 && abl == 3) DEC_LAUNCH(4, 3, 3);  \
+        else if (NBV == 4 && abl == 4) DEC_LAUNCH(4, 4, 3);  \
+        else if (NBV == 4 && abl == 5) DEC_LAUNCH(4, 5, 3);  \
+        else if (NBV == 4 && abl == 6) DEC_LAUNCH(4, 6, 3);  \
+        else DEC_LAUNCH(NBV, 0, 3);                          \
         break;
         switch (nb) {
             DEC_CASE(1)
