@@ -781,6 +781,110 @@ int vkn_launch_sigmoid(const float* in, float* out, int n, hipStream_t stream) {
     return VKN_OK;
 }
 
+// Register-staged variant for S = 2 and S = 4 (every shipped config): the generic kernel issues 16 gather loads per 16-byte store
+// and reaches 4.6 TB/s of writes where a plain fill reaches 6.9 TB/s (tools/write_ceiling.py).  Here a thread owns one quad of
+// 4 consecutive output columns for UP_ROWS input rows: it loads the UP_ROWS + 2 input rows x (4 / S + 2) input columns its
+// quad can touch ONCE (coalesced across the workgroup), interpolates them horizontally once, and then only blends two of
+// those values per output pixel.  Coefficients come from the same clamped source-index formula as the generic kernel, taps are
+// selected from the staged registers -> the same values enter the same expression.
+#define UP_ROWS 4
+template <int S, int NT, int SUBS>  // SUBS consecutive groups of UP_ROWS input rows per workgroup (contiguous S*UP_ROWS*SUBS output rows)
+__global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in, float* __restrict__ out, int H, int W) {
+    constexpr int NTAP = 4 / S + 2;  // input columns a quad can touch: jb - 1 .. jb + 4 / S
+    const int OW = W * S, OH = H * S;
+    const int plane = blockIdx.y;
+    const int yb0 = blockIdx.x * UP_ROWS * SUBS;  // first input row of this workgroup
+    const float rs = 1.0f / (float)S;
+    const float* ip = in + (size_t)plane * H * W;
+    float* op = out + (size_t)plane * OH * OW;
+    for (int q = threadIdx.x; q * 4 < OW; q += 256) {
+        const int jb = (q * 4) / S;  // first input column under the quad
+        // horizontal coefficients of the quad's 4 output columns, local tap indices
+        int t0[4], t1[4], cx[NTAP];
+        float lx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sx = fmaxf(((float)(q * 4 + k) + 0.5f) * rs - 0.5f, 0.f);
+            const int x0 = min((int)sx, W - 1), x1 = min(x0 + 1, W - 1);
+            lx[k] = sx - (float)x0;
+            t0[k] = x0 - (jb - 1);
+            t1[k] = x1 - (jb - 1);
+        }
+#pragma unroll
+        for (int i = 0; i < NTAP; ++i) cx[i] = min(max(jb - 1 + i, 0), W - 1);
+        auto hinterp = [&](const float (&v)[NTAP], float (&h)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = v[0], b2 = v[0];
+#pragma unroll
+                for (int i = 1; i < NTAP; ++i) {
+                    a = (t0[k] == i) ? v[i] : a;
+                    b2 = (t1[k] == i) ? v[i] : b2;
+                }
+                h[k] = (1.f - lx[k]) * a + lx[k] * b2;
+            }
+        };
+        // rows yb - 1 .. yb + UP_ROWS (clamped) of the current group, interpolated horizontally: hrow[r][k]
+        float hrow[UP_ROWS + 2][4];
+#pragma unroll
+        for (int r = 0; r < UP_ROWS + 2; ++r) {
+            const int y = min(max(yb0 - 1 + r, 0), H - 1);
+            float v[NTAP];
+#pragma unroll
+            for (int i = 0; i < NTAP; ++i) v[i] = ip[(size_t)y * W + cx[i]];
+            hinterp(v, hrow[r]);
+        }
+#pragma unroll
+        for (int sub = 0; sub < SUBS; ++sub) {
+            const int yb = yb0 + sub * UP_ROWS;
+            if (yb >= H) break;
+            // the next group's UP_ROWS new input rows are requested BEFORE this group's 16 stores: vector memory operations
+            // retire in order, so loads issued behind a store burst would wait for it
+            float nv[UP_ROWS][NTAP];
+            if (sub + 1 < SUBS) {
+#pragma unroll
+                for (int r = 0; r < UP_ROWS; ++r) {
+                    const int y = min(yb + UP_ROWS + 1 + r, H - 1);
+#pragma unroll
+                    for (int i = 0; i < NTAP; ++i) nv[r][i] = ip[(size_t)y * W + cx[i]];
+                }
+            }
+            // vertical blend + store: output rows S * yb .. S * (yb + UP_ROWS) - 1
+#pragma unroll
+            for (int i = 0; i < UP_ROWS; ++i) {
+#pragma unroll
+                for (int j = 0; j < S; ++j) {
+                    const int oy = (yb + i) * S + j;
+                    if (oy >= OH) continue;
+                    const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f);
+                    const int y0 = min((int)sy, H - 1);
+                    const float ly = sy - (float)y0, hy = 1.f - ly;
+                    // y0 is yb + i - 1 for the upper half of the S output rows, yb + i for the lower (clamped rows coincide)
+                    const bool low = (y0 - (yb - 1)) > i;
+                    float o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float top = low ? hrow[i + 1][k] : hrow[i][k];
+                        const float bot = low ? hrow[i + 2][k] : hrow[i + 1][k];
+                        o[k] = hy * top + ly * bot;
+                    }
+                    float* dst = op + (size_t)oy * OW + q * 4;
+                    if (NT)
+                        __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(dst));
+                    else
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+                }
+            }
+            if (sub + 1 < SUBS) {  // slide the window: the last two rows stay, UP_ROWS new ones come in
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { hrow[0][k] = hrow[UP_ROWS][k]; hrow[1][k] = hrow[UP_ROWS + 1][k]; }
+#pragma unroll
+                for (int r = 0; r < UP_ROWS; ++r) hinterp(nv[r], hrow[2 + r]);
+            }
+        }
+    }
+}
+
 int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream) {
     if (S < 1) return VKN_E_SHAPE;
     int done = 0;
@@ -788,9 +892,31 @@ int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, i
         const int chunk = (planes - done > 32768) ? 32768 : planes - done;
         const float* ip = in + (size_t)done * H * W;
         float* op = out + (size_t)done * H * S * W * S;
-        // non-temporal stores, 4 input rows (16 output rows at S = 4) per workgroup: best of the measured variants
-        // (tools/upsample_ab.py: plain stores 650-690 us, nt 1 row 517 us, nt 4 rows 478 us, nt 16 rows 492 us)
-        hipLaunchKernelGGL((k_upsample<1, 4>), dim3((H + 3) / 4, chunk), dim3(256), 0, stream, ip, op, H, W, S);
+        const char* ue = getenv("VKN_UPSAMPLE");  // debugging: 0 = generic kernel; 1x/2x = staged nt/plain stores, x = 1|4 groups
+        const int mode = ue ? atoi(ue) : 14;
+        const bool staged = mode != 0 && (S == 2 || S == 4) && ((W * S) % 4) == 0 && (reinterpret_cast<uintptr_t>(op) & 15) == 0;
+        if (staged) {
+            const bool nt = mode / 10 != 2;
+            const int subs = (mode % 10 == 1) ? 1 : 4;
+            dim3 grid((H + UP_ROWS * subs - 1) / (UP_ROWS * subs), chunk);
+#define UP_LAUNCH(SV, NTV, SUBV) hipLaunchKernelGGL((k_upsample_s<SV, NTV, SUBV>), grid, dim3(256), 0, stream, ip, op, H, W)
+            if (S == 4) {
+                if (nt && subs == 4) UP_LAUNCH(4, 1, 4);
+                else if (nt) UP_LAUNCH(4, 1, 1);
+                else if (subs == 4) UP_LAUNCH(4, 0, 4);
+                else UP_LAUNCH(4, 0, 1);
+            } else {
+                if (nt && subs == 4) UP_LAUNCH(2, 1, 4);
+                else if (nt) UP_LAUNCH(2, 1, 1);
+                else if (subs == 4) UP_LAUNCH(2, 0, 4);
+                else UP_LAUNCH(2, 0, 1);
+            }
+#undef UP_LAUNCH
+        } else {
+            // generic scale: non-temporal stores, 4 input rows per workgroup (tools/upsample_ab.py: plain stores 650-690 us,
+            // nt 1 row 517 us, nt 4 rows 478 us, nt 16 rows 492 us at cfg2)
+            hipLaunchKernelGGL((k_upsample<1, 4>), dim3((H + 3) / 4, chunk), dim3(256), 0, stream, ip, op, H, W, S);
+        }
         VKN_CHECK_LAUNCH();
         done += chunk;
     }
