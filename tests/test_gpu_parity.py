@@ -564,3 +564,22 @@ def test_video_simple_test_with_previous(vkn):
         rows = r['rows'].numpy()
         for j, s_ in enumerate(things):
             assert torch.equal(tfeat[j], track[b, int(rows[s_['instance_id']])])
+
+
+@pytest.mark.parametrize('name', ['det_cfg', 'video_cfg', 'det_tiny'])
+def test_bit_packed_stage_handoff_is_exact(vkn, name):
+    """The fused head hands stage s -> s+1 the binarised masks as bit words (decode's bit-packed epilogue -> gather's bit
+    operand) when H*W % 64 == 0.  VKN_FLAG_LOGITS_HANDOFF (4) keeps the fp32 logits path: every output must be bit-identical."""
+    g, case = load_golden(name)
+    head, (x, pf, mp, prev) = _build_head(vkn, case)
+    assert (case['H'] * case['W']) % 64 == 0
+    B, N, C = case['B'], case['N'], case['C']
+    dims = head.mask_head[0].make_dims(B, N, case['H'], case['W'])
+    packs = [h.stage_pack(torch.device(DEV)) for h in head.mask_head]
+    dx, dpf, dmp = _cuda(x, pf.reshape(B, N, C), mp)
+    a = vkn.ops.head_forward(dims, packs, dx, dpf, dmp, None, case['up'], flags=0)
+    b = vkn.ops.head_forward(dims, packs, dx, dpf, dmp, None, case['up'], flags=4)
+    torch.cuda.synchronize()
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u, v)
+    assert maxabs(a[2], g['mask_preds']) < TOL_LOGIT

@@ -256,7 +256,10 @@ int run_link(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const 
 
 int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in, const float* masks_in,
               const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out, float* x_feat_out,
-              float* track_out, const StageWs& s, unsigned flags, hipStream_t st) {
+              float* track_out, const StageWs& s, unsigned flags, hipStream_t st, const unsigned* bits_in = nullptr,
+              unsigned* bits_out = nullptr) {
+    // bits_in / bits_out (fused head only): the stage hand-off as bit words instead of fp32 logits — the gather consumes
+    // nothing but bit(logit >= thr), so intermediate stages never write the 15.3 MB / frame of logits
     const int B = d->B, N = d->N, C = d->C, P = d->H * d->W, M = B * N;
     const bool ref = (flags & VKN_FLAG_REF_KERNELS) != 0;
     const bool ref_decode = ref || (P & 1);  // odd H*W: mask rows are not 8-byte aligned -> exact-fp32 FMA decode kernel
@@ -271,6 +274,8 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     // (i) mask gather                                        knet/det/kernel_update_head.py:190-195
     if (ref)
         VKN_TRY(vkn_launch_gather_ref(x, masks_in, d->thr_logit, s.xraw, s.cnt, B, N, C, P, st));
+    else if (bits_in)
+        VKN_TRY(vkn_launch_gather_bits(x, bits_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
     else
         VKN_TRY(vkn_launch_gather(x, masks_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
 
@@ -341,6 +346,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         pr[1] = VknGemmProb{tm, nullptr, nullptr, nullptr, C, pw.dec32, pw.dec, C, e};
         VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
         if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
+        else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st));
         else VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
     } else {
         {
@@ -368,7 +374,8 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             } else {
                 VKN_TRY(vkn_launch_split_planes(s.maskfeat, s.kfh, s.kfl, B, N, C, st));
             }
-            VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
+            if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st));
+            else VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
         }
     }
 
@@ -687,13 +694,16 @@ int vkn_stage_forward_f32(const VknDims* d, const VknStageWeights* w, const floa
                      static_cast<hipStream_t>(stream));
 }
 
-static size_t carve_head(const VknDims* d, char* base, StageWs* s, float** mtmp, float** otmp, float** ctmp) {
+static size_t carve_head(const VknDims* d, char* base, StageWs* s, float** mtmp, float** otmp, float** ctmp, unsigned** bits) {
     const size_t stage_bytes = carve_stage(d, base, s);
     Carver c{base, stage_bytes};
     const size_t M = (size_t)d->B * d->N, P = (size_t)d->H * d->W;
     *mtmp = c.take<float>(M * P);
     *otmp = c.take<float>(M * d->C);
     *ctmp = c.take<float>(M * d->ncls);
+    const size_t nw = (size_t)d->B * ((P + 31) / 32) * npt_of(d->N);  // bit-packed stage hand-off, two buffers
+    bits[0] = c.take<unsigned>(nw);
+    bits[1] = c.take<unsigned>(nw);
     return (c.off + 255) & ~(size_t)255;
 }
 
@@ -701,7 +711,8 @@ size_t vkn_head_workspace_bytes(const VknDims* d) {
     if (check_dims(d) != VKN_OK) return 0;
     StageWs s;
     float *a, *b, *c;
-    return carve_head(d, nullptr, &s, &a, &b, &c);
+    unsigned* bits[2];
+    return carve_head(d, nullptr, &s, &a, &b, &c, bits);
 }
 
 int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const float* x,
@@ -717,10 +728,14 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
     if (mask_preds_in == mask_preds_out || proposal_feats == obj_out) return VKN_E_ARG;
     StageWs s;
     float *mtmp, *otmp, *ctmp;
-    const size_t need = carve_head(d, nullptr, &s, &mtmp, &otmp, &ctmp);
+    unsigned* bits[2];
+    const size_t need = carve_head(d, nullptr, &s, &mtmp, &otmp, &ctmp, bits);
     if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
-    carve_head(d, static_cast<char*>(ws), &s, &mtmp, &otmp, &ctmp);
+    carve_head(d, static_cast<char*>(ws), &s, &mtmp, &otmp, &ctmp, bits);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // stage s -> s+1 hand-off as bit words (the only thing the next gather reads) unless the exact-fp32 kernels are asked for,
+    // the spatial size is not a multiple of the 64-px decode tile, or the caller wants the logits path (A/B)
+    const bool use_bits = !(flags & (VKN_FLAG_REF_KERNELS | VKN_FLAG_LOGITS_HANDOFF)) && ((d->H * d->W) % 64) == 0;
 
     const float* m_in = mask_preds_in;
     const float* o_in = proposal_feats;
@@ -731,8 +746,10 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
         float* m_out = to_out ? mask_preds_out : mtmp;
         float* o_out = to_out ? obj_out : otmp;
         const float* prev = (last && track_out) ? prev_obj : nullptr;   // knet/video/kernel_iter_head.py:544-546
+        const unsigned* b_in = (use_bits && sidx > 0) ? bits[(sidx - 1) & 1] : nullptr;
+        unsigned* b_out = (use_bits && !last) ? bits[sidx & 1] : nullptr;
         VKN_TRY(run_stage(d, &stages[sidx], x, o_in, m_in, prev, ctmp, m_out, o_out, nullptr, prev ? track_out : nullptr, s,
-                          flags, st));
+                          flags, st, b_in, b_out));
         m_in = m_out;
         o_in = o_out;
     }

@@ -25,13 +25,58 @@
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// ---- bit-packed output (intermediate stages of the fused head): instead of the logits, emit bit(z >= thr) — all the next
+// stage's gather consumes — as words[B][P/32][NPT]: word (tile t, row n) bit i = pixel 32 t + i.  A 64-px decode tile holds the
+// even pixels in strip 0 and the odd ones in strip 1, so the two ballots are interleaved on the scalar unit, collected lane =
+// row with selects and stored as 256-B rows.  Cuts the stage hand-off from 2 x 15.3 MB to 2 x 0.5 MB per frame.
+__device__ __forceinline__ unsigned long long dec_spread(unsigned x) {  // bit i -> bit 2 i
+    unsigned long long v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+
+template <int NB>
+__device__ __forceinline__ void dec_emit_bits(const f32x16 (&acc)[2][NB], float thr, unsigned* __restrict__ wbase, int NPT,
+                                              int lane) {
+    constexpr int NH = (NB * 32 + 63) / 64;
+    int w[2][NH];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) w[t][h] = 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned long long m0 = __ballot(acc[0][nb][r] >= thr);  // even pixels: bit 32 g + li
+            const unsigned long long m1 = __ballot(acc[1][nb][r] >= thr);  // odd pixels
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const unsigned long long full = dec_spread((unsigned)(m0 >> (32 * g))) | (dec_spread((unsigned)(m1 >> (32 * g))) << 1);
+                const int row = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;  // compile-time
+                const bool mine = lane == (row & 63);  // lane <- its row's words (the values are wave-uniform)
+                w[0][row >> 6] = mine ? (int)(unsigned)full : w[0][row >> 6];
+                w[1][row >> 6] = mine ? (int)(unsigned)(full >> 32) : w[1][row >> 6];
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            if (h * 64 + lane < NB * 32) wbase[(size_t)t * NPT + h * 64 + lane] = (unsigned)w[t][h];
+}
+
 // ABL (ablation, debugging only; selected by env VKN_DECODE_ABL): 0 = the real kernel, 1 = no MFMA, 2 = no x loads,
 // 3 = no output stores.  Variants 1-3 produce WRONG results by construction and exist to attribute time.
-template <int NB, int ABL, int RING>
+template <int NB, int ABL, int RING, int BITS>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     const float* __restrict__ x, const _Float16* __restrict__ kfh, const _Float16* __restrict__ kfl,
     const float* __restrict__ kb, float* __restrict__ out, int N, int NPT, int n0, int C, int P, int px_per_wg,
-    int xcd_remap, VknDecodeStrides fs) {
+    int xcd_remap, VknDecodeStrides fs, unsigned* __restrict__ bits_out, float thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LDK = C + 8;  // halfs per LDS row; (C+8)*2 B = odd multiple of 16 B -> b128 reads conflict-free
     _Float16* ldsH = reinterpret_cast<_Float16*>(smem);
@@ -156,7 +201,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
             const int p0_ = p_begin + (wave + DEC_WAVES * c_sl) * DEC_TILE;                                       \
             const int px_ = p0_ + 2 * li;                                                                         \
             const int vst_ = ((4 * g) * P + 2 * li) << 2;                                                         \
-            if (ABL != 3 || acc[0][0][0] == 12345.678f) {                                                         \
+            if (BITS) { /* P % 64 == 0 (launcher): every tile is whole */                                        \
+                dec_emit_bits<NB>(acc, thr, bits_out + ((size_t)b * (P >> 5) + (p0_ >> 5)) * NPT + n0, NPT, lane);   \
+            } else if (ABL != 3 || acc[0][0][0] == 12345.678f) {                                                  \
                 if (p0_ + DEC_TILE <= p_end) { /* whole tile in range (uniform): 8-byte stores, 256 B per row */  \
                     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                           \
                         if (n0 + nb * 32 + 32 <= N) { /* full n-block (uniform): no per-row guard */              \
@@ -282,8 +329,23 @@ int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, 
 
 // shared != 0: ONE set of kernels / bias for every frame (planes [NPT][C], kb [N]); out_rows: rows per frame of the output
 // tensor the N decoded rows are written into (>= N: the caller points `out` at the first of its rows).
+static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
+                         int C, int P, int shared, int out_rows, unsigned* bits_out, float thr, hipStream_t stream);
+
 int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B,
                          int N, int C, int P, int shared, int out_rows, hipStream_t stream) {
+    return decode_launch(x, kfh, kfl, kb, out, B, N, C, P, shared, out_rows, nullptr, 0.f, stream);
+}
+
+// bit-packed variant: words [B][P/32][roundup(N,32)] of bit(logit >= thr) instead of the logits (P % 64 == 0)
+int vkn_launch_decode_bits(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, unsigned* bits_out,
+                           float thr, int B, int N, int C, int P, hipStream_t stream) {
+    if (!bits_out || (P % 64) != 0) return VKN_E_SHAPE;
+    return decode_launch(x, kfh, kfl, kb, nullptr, B, N, C, P, 0, N, bits_out, thr, stream);
+}
+
+static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
+                         int C, int P, int shared, int out_rows, unsigned* bits_out, float thr, hipStream_t stream) {
     if (B <= 0 || N <= 0 || P <= 0 || out_rows < N) return VKN_E_ARG;
     if (C % 16 != 0 || C > 512 || P < 2 || (P & 1)) return VKN_E_SHAPE;  // odd P: rows not 8-byte aligned (use the ref kernel)
     if ((size_t)C * P * 4 >= ((size_t)1 << 31) || (size_t)N * P * 4 >= ((size_t)1 << 31)) return VKN_E_SHAPE;  // 32-bit buffer offsets
@@ -309,25 +371,26 @@ int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kf
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
         const size_t lds = (size_t)2 * nb * 32 * (C + 8) * sizeof(_Float16) + (size_t)nb * 32 * sizeof(float);
         dim3 grid(G2, B, 1), block(DEC_THREADS);
-#define DEC_LAUNCH(NBV, ABLV, RINGV)                                                                           \
+#define DEC_LAUNCH(NBV, ABLV, RINGV, BITSV)                                                                    \
     do {                                                                                                       \
-        if (dec_set_lds((const void*)k_decode_mfma<NBV, ABLV, RINGV>, lds)) return VKN_E_LAUNCH;               \
-        hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV, RINGV>), grid, block, lds, stream, x, kfh, kfl, kb, out, N, NPT, n0, C, \
-                           P, px_per_wg, xcd, fs);                                                             \
+        if (dec_set_lds((const void*)k_decode_mfma<NBV, ABLV, RINGV, BITSV>, lds)) return VKN_E_LAUNCH;        \
+        hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV, RINGV, BITSV>), grid, block, lds, stream, x, kfh, kfl, kb, out, N, NPT, \
+                           n0, C, P, px_per_wg, xcd, fs, bits_out, thr);                                       \
     } while (0)
-#define DEC_CASE(NBV)                                        \
-    case NBV:                                                \
-        if (abl == 0) {                                      \
-            if (ring == 3) DEC_LAUNCH(NBV, 0, 3);            \
-            else DEC_LAUNCH(NBV, 0, 4);                      \
-        }                                                    \
-        else if (NBV == 4 && abl == 1) DEC_LAUNCH(4, 1, 3);  \
-        else if (NBV == 4 && abl == 2) DEC_LAUNCH(4, 2, 3);  \
-        else if (NBV == 4 && abl == 3) DEC_LAUNCH(4, 3, 3);  \
-        else if (NBV == 4 && abl == 4) DEC_LAUNCH(4, 4, 3);  \
-        else if (NBV == 4 && abl == 5) DEC_LAUNCH(4, 5, 3);  \
-        else if (NBV == 4 && abl == 6) DEC_LAUNCH(4, 6, 3);  \
-        else DEC_LAUNCH(NBV, 0, 3);                          \
+#define DEC_CASE(NBV)                                           \
+    case NBV:                                                   \
+        if (bits_out) DEC_LAUNCH(NBV, 0, 3, 1);                 \
+        else if (abl == 0) {                                    \
+            if (ring == 3) DEC_LAUNCH(NBV, 0, 3, 0);            \
+            else DEC_LAUNCH(NBV, 0, 4, 0);                      \
+        }                                                       \
+        else if (NBV == 4 && abl == 1) DEC_LAUNCH(4, 1, 3, 0);  \
+        else if (NBV == 4 && abl == 2) DEC_LAUNCH(4, 2, 3, 0);  \
+        else if (NBV == 4 && abl == 3) DEC_LAUNCH(4, 3, 3, 0);  \
+        else if (NBV == 4 && abl == 4) DEC_LAUNCH(4, 4, 3, 0);  \
+        else if (NBV == 4 && abl == 5) DEC_LAUNCH(4, 5, 3, 0);  \
+        else if (NBV == 4 && abl == 6) DEC_LAUNCH(4, 6, 3, 0);  \
+        else DEC_LAUNCH(NBV, 0, 3, 0);                          \
         break;
         switch (nb) {
             DEC_CASE(1)

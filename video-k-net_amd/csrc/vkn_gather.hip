@@ -23,7 +23,9 @@
 #define GA_PT 32   // pixels per tile
 #define GA_LDR 40  // halfs per LDS row (32 + 8 pad)
 
-template <int NB>
+// BITS: `masks` are the bit words [B][P/32][NPT] written by the decode kernel's bit-packed epilogue (fused head, stages > 0)
+// instead of logits; fragments of the binary operand come from a 256-entry byte -> half8 table in LDS.
+template <int NB, int BITS>
 __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __restrict__ x,
                                                                const float* __restrict__ masks, float thr,
                                                                float* __restrict__ part, float* __restrict__ cntp, int N,
@@ -45,7 +47,18 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
 
     const float* xb = x + (size_t)b * C * P;
     const float* mb = masks + (size_t)b * mask_fs;  // mask_fs = rows per frame of the logits tensor * P (>= N * P)
+    const unsigned* wb = reinterpret_cast<const unsigned*>(masks) + (size_t)b * (P >> 5) * NPT + n0;  // BITS: words of this frame / n-chunk
     const bool vec_ok = ((P & 3) == 0);
+    // BITS: byte -> 8 halfs {0,1} (bit e of the byte = pixel e of the 8-px group), behind the two tile buffers
+    half8* lut = reinterpret_cast<half8*>(lds + (size_t)2 * rows_buf * GA_LDR);
+    if (BITS) {
+        for (int v = tid; v < 256; v += GA_THREADS) {
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = ((v >> e) & 1) ? (_Float16)1.f : (_Float16)0.f;
+            lut[v] = h;
+        }
+    }
 
     const int nxch = C * 8;        // 16-B chunks in an x tile
     const int nmch = NB * 32 * 8;  // 16-B chunks in a mask tile
@@ -64,11 +77,16 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
             // non-temporal: x is streamed once per launch (same +9 % as in the decode kernel)
             xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2)));
         }
+        if (BITS) {  // one word per row of the n-chunk and 32-px tile (clamped: every thread loads)
+            const unsigned w = wb[(size_t)(p0 >> 5) * NPT + min(tid, NB * 32 - 1)];
+            mr[0][0] = __uint_as_float(w);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idc = min(tid + i * GA_THREADS, nmch - 1);
-            const int n = min(n0 + (idc >> 3), N - 1);
-            mr[i] = *reinterpret_cast<const f32x4*>(mb + (size_t)n * P + p0 + ((idc & 7) << 2));
+            for (int i = 0; i < 2; ++i) {
+                const int idc = min(tid + i * GA_THREADS, nmch - 1);
+                const int n = min(n0 + (idc >> 3), N - 1);
+                mr[i] = *reinterpret_cast<const f32x4*>(mb + (size_t)n * P + p0 + ((idc & 7) << 2));
+            }
         }
     };
 
@@ -126,6 +144,10 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                 *reinterpret_cast<half4*>(xl + off) = l;
             }
         }
+        if (BITS) {
+            const float w0 = mr[0][0];
+            if (tid < NB * 32) reinterpret_cast<unsigned*>(mk)[tid] = __float_as_uint(w0);
+        } else
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * GA_THREADS;
@@ -166,13 +188,25 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                 const half8 bl = *reinterpret_cast<const half8*>(xl + (wave * 32 + li) * GA_LDR + off);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const half8 a = *reinterpret_cast<const half8*>(mk + (nb * 32 + li) * GA_LDR + off);
+                    half8 a;
+                    if (BITS) {
+                        const unsigned w = reinterpret_cast<const unsigned*>(mk)[nb * 32 + li];
+                        a = lut[(w >> (8 * (2 * ks + g))) & 0xFFu];
+                    } else {
+                        a = *reinterpret_cast<const half8*>(mk + (nb * 32 + li) * GA_LDR + off);
+                    }
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[nb], 0, 0, 0);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
                 }
             }
             if (has_cnt) {
-                const half8 a = *reinterpret_cast<const half8*>(mk + (wave * 32 + li) * GA_LDR + off);
+                half8 a;
+                if (BITS) {
+                    const unsigned w = reinterpret_cast<const unsigned*>(mk)[wave * 32 + li];
+                    a = lut[(w >> (8 * (2 * ks + g))) & 0xFFu];
+                } else {
+                    a = *reinterpret_cast<const half8*>(mk + (wave * 32 + li) * GA_LDR + off);
+                }
                 accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accc, 0, 0, 0);
             }
         }
@@ -295,8 +329,23 @@ int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw
 }
 
 // mask_rows: rows per frame of the logits tensor the N gathered rows live in (>= N; `masks` points at the first of them)
+static int gather_launch(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
+                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream);
+
 int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
                          int B, int N, int C, int P, int mask_rows, hipStream_t stream) {
+    return gather_launch(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 0, stream);
+}
+
+// binary operand given as bit words [B][P/32][roundup(N,32)] (vkn_launch_decode_bits); P % 32 == 0
+int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
+                           int C, int P, hipStream_t stream) {
+    if ((P % 32) != 0) return VKN_E_SHAPE;
+    return gather_launch(x, reinterpret_cast<const float*>(bits), 0.f, xraw, cnt, part, cntp, B, N, C, P, N, 1, stream);
+}
+
+static int gather_launch(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
+                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream) {
     if (B <= 0 || N <= 0 || P <= 0 || mask_rows < N) return VKN_E_ARG;
     const long long mask_fs = (long long)mask_rows * P;
     if (C % 32 != 0 || C > 256) return VKN_E_SHAPE;
@@ -308,13 +357,18 @@ int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* x
     const int G = (P + px_per_wg - 1) / px_per_wg;
     for (int n0 = 0; n0 < NPT; n0 += 128) {
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
-        const size_t lds = (size_t)2 * (2 * C + nb * 32) * GA_LDR * sizeof(_Float16);
+        const size_t lds = (size_t)2 * (2 * C + nb * 32) * GA_LDR * sizeof(_Float16) + (bits ? 4096 : 0);
         dim3 grid(G, B, 1), block(GA_THREADS);
-#define GA_CASE(NBV)                                                                                             \
-    case NBV:                                                                                                    \
-        if (ga_set_lds((const void*)k_gather_mfma<NBV>, lds)) return VKN_E_LAUNCH;                               \
-        hipLaunchKernelGGL(k_gather_mfma<NBV>, grid, block, lds, stream, x, masks, thr, part, cntp, N, NPT, n0, C, P, \
-                           px_per_wg, mask_fs);                                                                     \
+#define GA_LAUNCH(NBV, BV)                                                                                       \
+    do {                                                                                                         \
+        if (ga_set_lds((const void*)k_gather_mfma<NBV, BV>, lds)) return VKN_E_LAUNCH;                           \
+        hipLaunchKernelGGL((k_gather_mfma<NBV, BV>), grid, block, lds, stream, x, masks, thr, part, cntp, N, NPT, n0, C, P, \
+                           px_per_wg, mask_fs);                                                                  \
+    } while (0)
+#define GA_CASE(NBV)                       \
+    case NBV:                              \
+        if (bits) GA_LAUNCH(NBV, 1);       \
+        else GA_LAUNCH(NBV, 0);            \
         break;
         switch (nb) {
             GA_CASE(1)
@@ -325,6 +379,7 @@ int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* x
                 return VKN_E_SHAPE;
         }
 #undef GA_CASE
+#undef GA_LAUNCH
         VKN_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(64), 0, stream, part, cntp, xraw, cnt, N, NPT, C, G);

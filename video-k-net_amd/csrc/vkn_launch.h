@@ -44,6 +44,8 @@ int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* x
                          int B, int N, int C, int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_ref_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                              int P, int mask_rows, hipStream_t stream);
+int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
+                           int C, int P, hipStream_t stream);
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
                       int B, int N, int C, int P, hipStream_t stream);
 int vkn_launch_gather_ref(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
@@ -58,6 +60,8 @@ int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kf
                          int C, int P, int shared, int out_rows, hipStream_t stream);
 int vkn_launch_decode_ref_ex(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
                              int shared, int out_rows, hipStream_t stream);
+int vkn_launch_decode_bits(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, unsigned* bits_out,
+                           float thr, int B, int N, int C, int P, hipStream_t stream);
 int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
                       int C, int P, hipStream_t stream);
 int vkn_launch_decode_ref(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
