@@ -26,24 +26,17 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- bit-packed output (intermediate stages of the fused head): instead of the logits, emit bit(z >= thr) — all the next
-// stage's gather consumes — as words[B][P/32][NPT]: word (tile t, row n) bit i = pixel 32 t + i.  A 64-px decode tile holds the
-// even pixels in strip 0 and the odd ones in strip 1, so the two ballots are interleaved on the scalar unit, collected lane =
-// row with selects and stored as 256-B rows.  Cuts the stage hand-off from 2 x 15.3 MB to 2 x 0.5 MB per frame.
-__device__ __forceinline__ unsigned long long dec_spread(unsigned x) {  // bit i -> bit 2 i
-    unsigned long long v = x;
-    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
-    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    v = (v | (v << 2)) & 0x3333333333333333ull;
-    v = (v | (v << 1)) & 0x5555555555555555ull;
-    return v;
-}
-
+// stage's gather consumes — as words[B][P/64][2][NPT]: for 64-px tile T and row n, word [T][0][n] bit i = pixel 64 T + 2 i
+// (even pixels = MFMA strip 0) and word [T][1][n] bit i = pixel 64 T + 2 i + 1 (strip 1).  That is exactly what the two ballots of
+// a C/D register deliver, so the epilogue is 2 v_cmp + 4 selects per register pair and four 256-B row stores per tile (a first
+// version that interleaved the two ballots into pixel order on the scalar unit cost as much as the logits stores it replaced:
+// one SALU serves the whole CU).  The gather's byte -> fragment table absorbs the even/odd split.
+// Cuts the stage hand-off from 2 x 15.3 MB to 2 x 0.5 MB per frame.
 template <int NB>
 __device__ __forceinline__ void dec_emit_bits(const f32x16 (&acc)[2][NB], float thr, unsigned* __restrict__ wbase, int NPT,
                                               int lane) {
     constexpr int NH = (NB * 32 + 63) / 64;
-    int w[2][NH];
+    int w[2][NH];  // [even | odd pixels][row half]: lane = row & 63
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -56,11 +49,10 @@ __device__ __forceinline__ void dec_emit_bits(const f32x16 (&acc)[2][NB], float 
             const unsigned long long m1 = __ballot(acc[1][nb][r] >= thr);  // odd pixels
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const unsigned long long full = dec_spread((unsigned)(m0 >> (32 * g))) | (dec_spread((unsigned)(m1 >> (32 * g))) << 1);
                 const int row = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;  // compile-time
-                const bool mine = lane == (row & 63);  // lane <- its row's words (the values are wave-uniform)
-                w[0][row >> 6] = mine ? (int)(unsigned)full : w[0][row >> 6];
-                w[1][row >> 6] = mine ? (int)(unsigned)(full >> 32) : w[1][row >> 6];
+                const bool mine = lane == (row & 63);                      // lane <- its row's words (values are wave-uniform)
+                w[0][row >> 6] = mine ? (int)(unsigned)(m0 >> (32 * g)) : w[0][row >> 6];
+                w[1][row >> 6] = mine ? (int)(unsigned)(m1 >> (32 * g)) : w[1][row >> 6];
             }
         }
 #pragma unroll
@@ -202,7 +194,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
             const int px_ = p0_ + 2 * li;                                                                         \
             const int vst_ = ((4 * g) * P + 2 * li) << 2;                                                         \
             if (BITS) { /* P % 64 == 0 (launcher): every tile is whole */                                        \
-                dec_emit_bits<NB>(acc, thr, bits_out + ((size_t)b * (P >> 5) + (p0_ >> 5)) * NPT + n0, NPT, lane);   \
+                dec_emit_bits<NB>(acc, thr, bits_out + ((size_t)b * (P >> 5) + ((p0_ >> 6) << 1)) * NPT + n0, NPT, lane);   \
             } else if (ABL != 3 || acc[0][0][0] == 12345.678f) {                                                  \
                 if (p0_ + DEC_TILE <= p_end) { /* whole tile in range (uniform): 8-byte stores, 256 B per row */  \
                     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                           \
@@ -337,7 +329,8 @@ int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kf
     return decode_launch(x, kfh, kfl, kb, out, B, N, C, P, shared, out_rows, nullptr, 0.f, stream);
 }
 
-// bit-packed variant: words [B][P/32][roundup(N,32)] of bit(logit >= thr) instead of the logits (P % 64 == 0)
+// bit-packed variant: words [B][P/64][2][roundup(N,32)] (even / odd pixels of each 64-px tile) of bit(logit >= thr)
+// instead of the logits (P % 64 == 0)
 int vkn_launch_decode_bits(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, unsigned* bits_out,
                            float thr, int B, int N, int C, int P, hipStream_t stream) {
     if (!bits_out || (P % 64) != 0) return VKN_E_SHAPE;

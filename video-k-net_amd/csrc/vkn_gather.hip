@@ -23,8 +23,9 @@
 #define GA_PT 32   // pixels per tile
 #define GA_LDR 40  // halfs per LDS row (32 + 8 pad)
 
-// BITS: `masks` are the bit words [B][P/32][NPT] written by the decode kernel's bit-packed epilogue (fused head, stages > 0)
-// instead of logits; fragments of the binary operand come from a 256-entry byte -> half8 table in LDS.
+// BITS: `masks` are the bit words [B][P/64][2][NPT] (even / odd pixels of each 64-px tile) written by the decode kernel's
+// bit-packed epilogue (fused head, stages > 0) instead of logits; fragments of the binary operand come from a 256-entry
+// (even nibble, odd nibble) -> half8 table in LDS.
 template <int NB, int BITS>
 __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __restrict__ x,
                                                                const float* __restrict__ masks, float thr,
@@ -49,13 +50,14 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     const float* mb = masks + (size_t)b * mask_fs;  // mask_fs = rows per frame of the logits tensor * P (>= N * P)
     const unsigned* wb = reinterpret_cast<const unsigned*>(masks) + (size_t)b * (P >> 5) * NPT + n0;  // BITS: words of this frame / n-chunk
     const bool vec_ok = ((P & 3) == 0);
-    // BITS: byte -> 8 halfs {0,1} (bit e of the byte = pixel e of the 8-px group), behind the two tile buffers
+    // BITS: (even nibble | odd nibble << 4) -> 8 halfs {0,1}: pixel e of the 8-px group = bit e/2 of the even (e even) or odd
+    // (e odd) nibble; behind the two tile buffers
     half8* lut = reinterpret_cast<half8*>(lds + (size_t)2 * rows_buf * GA_LDR);
     if (BITS) {
         for (int v = tid; v < 256; v += GA_THREADS) {
             half8 h;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) h[e] = ((v >> e) & 1) ? (_Float16)1.f : (_Float16)0.f;
+            for (int e = 0; e < 8; ++e) h[e] = ((v >> ((e >> 1) + 4 * (e & 1))) & 1) ? (_Float16)1.f : (_Float16)0.f;
             lut[v] = h;
         }
     }
@@ -77,9 +79,11 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
             // non-temporal: x is streamed once per launch (same +9 % as in the decode kernel)
             xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2)));
         }
-        if (BITS) {  // one word per row of the n-chunk and 32-px tile (clamped: every thread loads)
-            const unsigned w = wb[(size_t)(p0 >> 5) * NPT + min(tid, NB * 32 - 1)];
-            mr[0][0] = __uint_as_float(w);
+        if (BITS) {  // even- and odd-pixel word of this row for the 64-px tile holding p0 (clamped: every thread loads)
+            const unsigned* wp = wb + (size_t)((p0 >> 6) << 1) * NPT + min(tid, NB * 32 - 1);
+            const unsigned we = wp[0], wo = wp[NPT];
+            mr[0][0] = __uint_as_float(we);
+            mr[0][1] = __uint_as_float(wo);
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -145,8 +149,11 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
             }
         }
         if (BITS) {
-            const float w0 = mr[0][0];
-            if (tid < NB * 32) reinterpret_cast<unsigned*>(mk)[tid] = __float_as_uint(w0);
+            const float w0 = mr[0][0], w1 = mr[0][1];
+            if (tid < NB * 32) {
+                reinterpret_cast<unsigned*>(mk)[tid] = __float_as_uint(w0);
+                reinterpret_cast<unsigned*>(mk)[NB * 32 + tid] = __float_as_uint(w1);
+            }
         } else
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -176,13 +183,15 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     const bool has_cb = (wave * 32 < C);  // this wave owns channel block `wave` (uniform)
     const bool has_cnt = (wave < NB);     // this wave counts pixels of n-block `wave`
 
-    auto compute = [&](int buf) {
+    // `odd32`: the 32-px tile is the second half of its 64-px tile (BITS: selects bits 16.. of the even / odd words)
+    auto compute = [&](int buf, int odd32) {
         const _Float16* xh = lds + (size_t)buf * rows_buf * GA_LDR;
         const _Float16* xl = xh + C * GA_LDR;
         const _Float16* mk = xl + C * GA_LDR;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int off = (ks << 4) + (g << 3);
+            const int bsh = 16 * odd32 + 8 * ks + 4 * g;  // pixels 16 ks + 8 g + e  <->  bit bsh + e / 2 of the even (e even) / odd word
             if (has_cb) {
                 const half8 bh = *reinterpret_cast<const half8*>(xh + (wave * 32 + li) * GA_LDR + off);
                 const half8 bl = *reinterpret_cast<const half8*>(xl + (wave * 32 + li) * GA_LDR + off);
@@ -190,8 +199,9 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                 for (int nb = 0; nb < NB; ++nb) {
                     half8 a;
                     if (BITS) {
-                        const unsigned w = reinterpret_cast<const unsigned*>(mk)[nb * 32 + li];
-                        a = lut[(w >> (8 * (2 * ks + g))) & 0xFFu];
+                        const unsigned we = reinterpret_cast<const unsigned*>(mk)[nb * 32 + li];
+                        const unsigned wo = reinterpret_cast<const unsigned*>(mk)[NB * 32 + nb * 32 + li];
+                        a = lut[((we >> bsh) & 0xFu) | (((wo >> bsh) & 0xFu) << 4)];
                     } else {
                         a = *reinterpret_cast<const half8*>(mk + (nb * 32 + li) * GA_LDR + off);
                     }
@@ -202,8 +212,9 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
             if (has_cnt) {
                 half8 a;
                 if (BITS) {
-                    const unsigned w = reinterpret_cast<const unsigned*>(mk)[wave * 32 + li];
-                    a = lut[(w >> (8 * (2 * ks + g))) & 0xFFu];
+                    const unsigned we = reinterpret_cast<const unsigned*>(mk)[wave * 32 + li];
+                    const unsigned wo = reinterpret_cast<const unsigned*>(mk)[NB * 32 + wave * 32 + li];
+                    a = lut[((we >> bsh) & 0xFu) | (((wo >> bsh) & 0xFu) << 4)];
                 } else {
                     a = *reinterpret_cast<const half8*>(mk + (wave * 32 + li) * GA_LDR + off);
                 }
@@ -223,12 +234,12 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
         __syncthreads();
         for (int t = 0; t < nfull; t += 2) {
             issue(min(t + 2, nfull - 1), xrA, mrA);
-            compute(0);
+            compute(0, ((p_begin >> 5) + t) & 1);
             if (t + 1 < nfull) commit(1, xrB, mrB);
             __syncthreads();
             if (t + 1 >= nfull) break;
             issue(min(t + 3, nfull - 1), xrB, mrB);
-            compute(1);
+            compute(1, ((p_begin >> 5) + t + 1) & 1);
             if (t + 2 < nfull) commit(0, xrA, mrA);
             __syncthreads();
         }
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
         issue_slow(t, xrA, mrA);
         commit(0, xrA, mrA);
         __syncthreads();
-        compute(0);
+        compute(0, 0);
         __syncthreads();
     }
 
@@ -337,10 +348,10 @@ int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* x
     return gather_launch(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 0, stream);
 }
 
-// binary operand given as bit words [B][P/32][roundup(N,32)] (vkn_launch_decode_bits); P % 32 == 0
+// binary operand given as bit words [B][P/64][2][roundup(N,32)] (vkn_launch_decode_bits); P % 64 == 0
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
                            int C, int P, hipStream_t stream) {
-    if ((P % 32) != 0) return VKN_E_SHAPE;
+    if ((P % 64) != 0) return VKN_E_SHAPE;
     return gather_launch(x, reinterpret_cast<const float*>(bits), 0.f, xraw, cnt, part, cntp, B, N, C, P, N, 1, stream);
 }
 
