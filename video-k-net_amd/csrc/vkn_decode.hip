@@ -54,6 +54,7 @@ __device__ __forceinline__ void dec_emit_bits(const f32x16 (&acc)[2][NB], float 
                 w[0][row >> 6] = mine ? (int)(unsigned)(m0 >> (32 * g)) : w[0][row >> 6];
                 w[1][row >> 6] = mine ? (int)(unsigned)(m1 >> (32 * g)) : w[1][row >> 6];
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep each pair of ballots next to its selects (else 128 masks spill SGPRs)
         }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
