@@ -17,7 +17,13 @@ out = sys.argv[1]
 def short(n):
     n = n.replace('void ', '')
     if n.startswith('_Z'):
-        for key in ('k_decode_mfma', 'k_split_planes', 'k_gemm_s3'):
+        if 'k_decode_mfma' in n:  # template <NB, ABL, RING, BITS>: the bit-packed hand-off variant is a different kernel
+            import re
+            m = re.search(r'k_decode_mfmaILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', n)
+            if m and m.group(1) != '4':  # few-row launches (e.g. conv_seg of the kernel-init pass): not the roofline kernel
+                return f'k_decode_mfma<NB={m.group(1)}>'
+            return 'k_decode_mfma<bits>' if (m and m.group(4) == '1') else 'k_decode_mfma'
+        for key in ('k_split_planes', 'k_gemm_s3'):
             if key in n:
                 return key
     return n.split('(')[0][:48]
