@@ -17,6 +17,7 @@
 //     summed in fixed order by k_gather_reduce (deterministic, no atomics).
 #include "vkn_common.h"
 #include "vkn_launch.h"
+#include <stdlib.h>
 
 #define GA_THREADS 512
 #define GA_WAVES 8
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                                                                const float* __restrict__ masks, float thr,
                                                                float* __restrict__ part, float* __restrict__ cntp, int N,
                                                                int NPT, int n0, int C, int P, int px_per_wg,
-                                                               long long mask_fs) {
+                                                               long long mask_fs, int ileave) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // per buffer: xh [C][40], xl [C][40], mk [NB*32][40]
     const int rows_buf = 2 * C + NB * 32;
@@ -42,9 +43,15 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
     const int g = lane >> 5, li = lane & 31;
 
-    const int p_begin = gidx * px_per_wg;
-    const int p_end = min(P, p_begin + px_per_wg);
-    const int ntiles = (p_end > p_begin) ? (p_end - p_begin + GA_PT - 1) / GA_PT : 0;
+    // Pixel ranges.  ileave == 0: workgroup g walks the contiguous range [g, g+1) * px_per_wg.  ileave == 1 (P % 64 == 0): it walks
+    // the 64-px super-tiles j * G + g, j = 0, 1, ... — at any moment the G workgroups of a frame read ADJACENT 256-byte pieces of
+    // every channel row (DRAM page locality across CUs) instead of G pieces 4 KB apart.  Both gather kernels visit the 32-px
+    // tiles of a workgroup in the same order, so their partial sums are bit-identical.
+    const int p_begin = ileave ? 0 : gidx * px_per_wg;
+    const int p_end = ileave ? 0 : min(P, p_begin + px_per_wg);
+    const int nsup_i = ileave ? (((P >> 6) - gidx + G - 1) / G) : 0;
+    const int ntiles = ileave ? 2 * nsup_i : ((p_end > p_begin) ? (p_end - p_begin + GA_PT - 1) / GA_PT : 0);
+    auto tile_p0 = [&](int t) { return ileave ? ((((t >> 1) * G + gidx) << 6) + ((t & 1) << 5)) : p_begin + t * GA_PT; };
 
     const float* xb = x + (size_t)b * C * P;
     const float* mb = masks + (size_t)b * mask_fs;  // mask_fs = rows per frame of the logits tensor * P (>= N * P)
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     // Full tiles (all 32 px in range, rows 16-B aligned): branch-free, ALWAYS 4 + 2 dwordx4 loads per thread on clamped
     // addresses (lanes past the tile are masked in commit()), nothing consumed here -> exact vmcnt counting in the pipeline.
     auto issue = [&](int t, f32x4 (&xr)[4], f32x4 (&mr)[2]) {
-        const int p0 = p_begin + t * GA_PT;
+        const int p0 = tile_p0(t);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idc = min(tid + i * GA_THREADS, nxch - 1);
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
 
     // Ragged tile (frame tail) or P % 4 != 0: guarded scalar loads, not pipelined.
     auto issue_slow = [&](int t, f32x4 (&xr)[4], f32x4 (&mr)[2]) {
-        const int p0 = p_begin + t * GA_PT;
+        const int p0 = tile_p0(t);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + i * GA_THREADS;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     // pipeline over the FULL tiles: tile t computes from LDS[t&1]; tile t+1 sits in one register set and is committed to
     // LDS[(t+1)&1] after the MFMAs; tile t+2 is issued into the other register set before them (two tiles = 96 KB per CU in
     // flight).  Issues past the end re-read the last full tile (clamped) so every iteration has the same 6 loads.
-    const int nfull = vec_ok ? (p_end - p_begin) / GA_PT : 0;
+    const int nfull = ileave ? ntiles : (vec_ok ? (p_end - p_begin) / GA_PT : 0);
     if (nfull > 0) {
         issue(0, xrA, mrA);
         issue(min(1, nfull - 1), xrB, mrB);
@@ -234,12 +241,12 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
         __syncthreads();
         for (int t = 0; t < nfull; t += 2) {
             issue(min(t + 2, nfull - 1), xrA, mrA);
-            compute(0, ((p_begin >> 5) + t) & 1);
+            compute(0, (tile_p0(t) >> 5) & 1);
             if (t + 1 < nfull) commit(1, xrB, mrB);
             __syncthreads();
             if (t + 1 >= nfull) break;
             issue(min(t + 3, nfull - 1), xrB, mrB);
-            compute(1, ((p_begin >> 5) + t + 1) & 1);
+            compute(1, (tile_p0(t + 1) >> 5) & 1);
             if (t + 2 < nfull) commit(0, xrA, mrA);
             __syncthreads();
         }
@@ -268,6 +275,157 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) cp[n0 + wave * 32 + vkn_cd_row(r, lane)] = accc[r];
     }
+}
+
+// ---- wave-independent variant for the bit-word operand (stages > 0 of the fused head).
+// k_gather_mfma synchronises its 8 waves once per 32-px tile, so all of them split/write LDS at the same time and then all run
+// MFMAs at the same time (PMC: waves wait 54 % of their cycles, MFMA pipe 5 % busy).  With the binary operand available as words
+// nothing has to be shared between waves: wave w streams ONLY its 32 channels of x (4 KB per 32-px tile), transposes them through
+// a PRIVATE LDS tile and takes the mask fragments from the (even nibble, odd nibble) table.  No workgroup barrier in the loop
+// (LDS operations of one wave execute in order), waves drift apart and their load / VALU / MFMA phases overlap.
+// Work unit = one 64-px super-tile (both 32-px halves share the even / odd words).  Same partial layout as k_gather_mfma.
+template <int NB>
+__global__ __launch_bounds__(GA_THREADS, 2) void k_gather_bits_w(const float* __restrict__ x, const unsigned* __restrict__ bits,
+                                                                  float* __restrict__ part, float* __restrict__ cntp, int N,
+                                                                  int NPT, int n0, int C, int P, int px_per_wg, int ileave) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WTILE = 2 * 32 * GA_LDR;  // halfs of one private tile: hi [32][40] + lo [32][40]
+    const int b = blockIdx.y, gidx = blockIdx.x, G = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    _Float16* wl = reinterpret_cast<_Float16*>(smem) + (size_t)wave * 2 * WTILE;  // two tiles (the halves of a super-tile)
+    half8* lut = reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(smem) + (size_t)GA_WAVES * 2 * WTILE);
+    for (int v = tid; v < 256; v += GA_THREADS) {
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = ((v >> ((e >> 1) + 4 * (e & 1))) & 1) ? (_Float16)1.f : (_Float16)0.f;
+        lut[v] = h;
+    }
+    __syncthreads();  // the only workgroup barrier
+
+    // super-tile s of this workgroup starts at pixel sup_p0(s) (same two mappings as k_gather_mfma)
+    const int p_begin = gidx * px_per_wg;
+    const int p_end = min(P, p_begin + px_per_wg);
+    const int nsup = ileave ? (((P >> 6) - gidx + G - 1) / G)
+                            : ((p_end > p_begin) ? (p_end - p_begin) >> 6 : 0);  // launcher: P % 64 == 0, px_per_wg % 64 == 0
+    auto sup_p0 = [&](int s) { return ileave ? ((s * G + gidx) << 6) : p_begin + (s << 6); };
+    const bool has_cb = (wave * 32 < C);
+    const bool has_cnt = (wave < NB);
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    unsigned cnt_i = 0;  // ON pixels of row (n-block `wave`, row li): popcount of its words (exact; no ones-MFMA needed here)
+
+    if (has_cb && nsup > 0) {
+        const float* xw = x + ((size_t)b * C + wave * 32) * P;
+        const unsigned* wb = bits + (size_t)b * (P >> 5) * NPT + n0 + li;
+        // lane's slots in a 32-channel x 32-px tile: rows (lane >> 3) + 8 i, 16-byte chunk lane & 7
+        const int lrow = lane >> 3, lchk = lane & 7;
+        f32x4 xa[8], xb[8];        // a super-tile = 2 tiles x 4 dwordx4 per lane
+        unsigned wa[2 * NB], wv[2 * NB];
+
+        auto issue = [&](int s, f32x4 (&xr)[8], unsigned (&wr)[2 * NB]) {
+            const int p0 = sup_p0(s);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    xr[h * 4 + i] = __builtin_nontemporal_load(
+                        reinterpret_cast<const f32x4*>(xw + (size_t)(lrow + 8 * i) * P + p0 + 32 * h + (lchk << 2)));
+            const unsigned* wp = wb + (size_t)((p0 >> 6) << 1) * NPT;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                wr[nb] = wp[nb * 32];
+                wr[NB + nb] = wp[NPT + nb * 32];
+            }
+        };
+        auto commit = [&](const f32x4 (&xr)[8]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                _Float16* xh = wl + h * WTILE;
+                _Float16* xl = xh + 32 * GA_LDR;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    half4 hh, ll;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        _Float16 a, c2;
+                        vkn_split_f16(xr[h * 4 + i][k], a, c2);
+                        hh[k] = a;
+                        ll[k] = c2;
+                    }
+                    const int off = (lrow + 8 * i) * GA_LDR + (lchk << 2);
+                    *reinterpret_cast<half4*>(xh + off) = hh;
+                    *reinterpret_cast<half4*>(xl + off) = ll;
+                }
+            }
+        };
+        auto compute = [&](const unsigned (&wr)[2 * NB]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const _Float16* xh = wl + h * WTILE;
+                const _Float16* xl = xh + 32 * GA_LDR;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int off = (ks << 4) + (g << 3);
+                    const int bsh = 16 * h + 8 * ks + 4 * g;
+                    const half8 bh = *reinterpret_cast<const half8*>(xh + li * GA_LDR + off);
+                    const half8 bl = *reinterpret_cast<const half8*>(xl + li * GA_LDR + off);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const half8 a = lut[((wr[nb] >> bsh) & 0xFu) | (((wr[NB + nb] >> bsh) & 0xFu) << 4)];
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        auto lds_fence = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes / reads have completed
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        const int last = nsup - 1;  // two register sets (a third one spills: 141 us instead of 71)
+        issue(0, xa, wa);
+        for (int s = 0; s < nsup; s += 2) {
+            issue(min(s + 1, last), xb, wv);
+            commit(xa);
+            lds_fence();
+            compute(wa);
+            lds_fence();
+            if (s + 1 >= nsup) break;
+            issue(min(s + 2, last), xa, wa);
+            commit(xb);
+            lds_fence();
+            compute(wv);
+            lds_fence();
+        }
+    }
+
+    if (has_cnt) {  // wave w < NB: ON-pixel count of the rows of n-block w over this workgroup's range
+        const unsigned* wc = bits + (size_t)b * (P >> 5) * NPT + n0 + wave * 32 + li;
+        for (int s2 = 0; s2 < nsup; ++s2) {
+            const unsigned* wp = wc + (size_t)((sup_p0(s2) >> 6) << 1) * NPT;
+            cnt_i += __popc(wp[0]) + __popc(wp[NPT]);
+        }
+    }
+
+    // ---- write this workgroup's partial (rows of the n-chunk, zero when the range was empty)
+    float* pp = part + ((size_t)b * G + gidx) * NPT * C;
+    if (has_cb) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + nb * 32 + vkn_cd_row(r, lane);
+                pp[(size_t)n * C + wave * 32 + li] = acc[nb][r];
+            }
+    }
+    if (has_cnt && g == 0) cntp[((size_t)b * G + gidx) * NPT + n0 + wave * 32 + li] = (float)cnt_i;
 }
 
 // xraw[b][n][c] = sum_g part[b][g][n][c], cnt[b][n] likewise.  Fixed summation tree (four interleaved running sums over g,
@@ -366,15 +524,38 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
     int px_per_wg = (P + wg_per_frame - 1) / wg_per_frame;
     px_per_wg = (px_per_wg + GA_PT - 1) / GA_PT * GA_PT;
     const int G = (P + px_per_wg - 1) / px_per_wg;
+    const int ileave = ((P % 64) == 0 && !(getenv("VKN_GATHER_ILEAVE") && atoi(getenv("VKN_GATHER_ILEAVE")) == 0)) ? 1 : 0;
+    const bool wave_indep = bits && !(getenv("VKN_GATHER_BITS_W") && atoi(getenv("VKN_GATHER_BITS_W")) == 0) && (C % 32) == 0 &&
+                            (px_per_wg % 64) == 0;
     for (int n0 = 0; n0 < NPT; n0 += 128) {
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
-        const size_t lds = (size_t)2 * (2 * C + nb * 32) * GA_LDR * sizeof(_Float16) + (bits ? 4096 : 0);
         dim3 grid(G, B, 1), block(GA_THREADS);
+        if (wave_indep) {
+            const size_t ldsw = (size_t)GA_WAVES * 2 * 2 * 32 * GA_LDR * sizeof(_Float16) + 4096;
+            const unsigned* bw = reinterpret_cast<const unsigned*>(masks);
+#define GA_WLAUNCH(NBV)                                                                                              \
+    case NBV:                                                                                                        \
+        if (ga_set_lds((const void*)k_gather_bits_w<NBV>, ldsw)) return VKN_E_LAUNCH;                               \
+        hipLaunchKernelGGL(k_gather_bits_w<NBV>, grid, block, ldsw, stream, x, bw, part, cntp, N, NPT, n0, C, P, px_per_wg, ileave); \
+        break;
+            switch (nb) {
+                GA_WLAUNCH(1)
+                GA_WLAUNCH(2)
+                GA_WLAUNCH(3)
+                GA_WLAUNCH(4)
+                default:
+                    return VKN_E_SHAPE;
+            }
+#undef GA_WLAUNCH
+            VKN_CHECK_LAUNCH();
+            continue;
+        }
+        const size_t lds = (size_t)2 * (2 * C + nb * 32) * GA_LDR * sizeof(_Float16) + (bits ? 4096 : 0);
 #define GA_LAUNCH(NBV, BV)                                                                                       \
     do {                                                                                                         \
         if (ga_set_lds((const void*)k_gather_mfma<NBV, BV>, lds)) return VKN_E_LAUNCH;                           \
         hipLaunchKernelGGL((k_gather_mfma<NBV, BV>), grid, block, lds, stream, x, masks, thr, part, cntp, N, NPT, n0, C, P, \
-                           px_per_wg, mask_fs);                                                                  \
+                           px_per_wg, mask_fs, ileave);                                                          \
     } while (0)
 #define GA_CASE(NBV)                       \
     case NBV:                              \
