@@ -152,3 +152,23 @@ def test_conv_kernel_head_state_dict_matches_reference(vkn, tag, refine):
         vkn.build_head(dict(type='ConvKernelHead', conv_kernel_size=3))
     with pytest.raises(vkn.VknLibraryError):   # CPU tensors: no fallback
         head.eval().decode_init_proposals_from_feats(torch.zeros(1, 256, 4, 8), torch.zeros(1, 256, 4, 8))
+
+
+def test_widened_entry_points_validate_on_the_host(vkn):
+    """Argument / shape validation of the kernel-init and panoptic entry points happens before any launch (no GPU needed)."""
+    L = vkn._lib.lib()
+    assert L.vkn_kernel_init_workspace_bytes(2, 100, 19, 256, 32768) > 0
+    assert L.vkn_kernel_init_workspace_bytes(0, 100, 19, 256, 32768) == 0
+    cfg = vkn._lib.VknPanopticCfg(100, 2, 100, 0.25, 0.6, 4, 128, 256, 1024, 2048, 1024, 2048, 1024, 2048)
+    assert L.vkn_sizeof_panoptic_cfg() == ctypes.sizeof(cfg)
+    nb = L.vkn_panoptic_workspace_bytes(ctypes.byref(cfg), 8, 117)
+    assert nb >= 8 * 117 * 7 * 4
+    # null pointers / bad geometry are rejected with an error code, never a crash
+    assert L.vkn_panoptic_joint_f32(ctypes.byref(cfg), None, None, 8, 117, 19, None, None, None, None, 0, None) == -1
+    assert L.vkn_kernel_init_f32(None, None, None, None, None, 2, 1, 1, 0.0, None, None, None, None, 2, 100, 19, 256, 1024,
+                                 None, 0, 0, None) == -1
+    assert vkn._lib.lib().vkn_strerror(-2).decode().startswith('unsupported shape')
+    with pytest.raises(vkn.VknLibraryError):   # CPU tensors: no fallback
+        vkn.ops.panoptic_joint(torch.zeros(1, 15, 5), torch.zeros(1, 15, 8, 16), 12, 2, 12, 0.25, 0.6, (64, 128), (64, 128), (64, 128))
+    with pytest.raises(vkn.VknLibraryError):
+        vkn.ops.kernel_init(torch.zeros(1, 64, 8, 16), None, torch.zeros(12, 64, 1, 1))
