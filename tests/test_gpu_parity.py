@@ -583,3 +583,34 @@ def test_bit_packed_stage_handoff_is_exact(vkn, name):
     for u, v in zip(a[:4], b[:4]):
         assert torch.equal(u, v)
     assert maxabs(a[2], g['mask_preds']) < TOL_LOGIT
+
+
+@pytest.mark.parametrize('hw', [(24, 40), (23, 40)], ids=['bits_handoff', 'logits_handoff'])
+def test_head_vipseg_kernel_count_vs_oracle(vkn, hw):
+    """VIP-Seg-like dims (N = 166 kernels -> two n-chunks of 128 + 64 rows, 124 classes), S = 2: the fused head against the oracle,
+    with the bit-packed hand-off (H*W % 64 == 0) and with the fp32 logits hand-off (H*W = 920)."""
+    from test_host_logic import _cfg
+    H, W = hw
+    case = dict(C=64, heads=8, ffn=128, ncls=124, n_thing=58, n_stuff=66, S=2, up=2, nprop=100, N=166, H=H, W=W, B=2, seed=41,
+                video=0)
+    head = vkn.build_head(_cfg(False, C=64, heads=8, ffn=128, ncls=124, n_thing=58, n_stuff=66, S=2, up=2, nprop=100))
+    cfg, sd, x, pf, mp, _ = make_case(case)
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV).eval()
+    o, c, m, sc = head.simple_test_mask_preds(*_cuda(x, pf, mp), None, [dict()] * 2)
+    with torch.no_grad():
+        traces = []
+        ro, rc, rm, rsc, _ = O.iter_head_mask_preds(sd, x, pf, mp, cfg, traces=traces)
+    # the stage-0 masks decide stage 1's gather: compare where the oracle's stage-0 logits are not within 1e-4 of the threshold
+    assert maxabs(c, rc) < 1e-3 and maxabs(m, rm) < 5e-2   # loose end-to-end bound (a flipped pixel moves a kernel slightly)
+    dims = head.mask_head[0].make_dims(2, 166, H, W)
+    packs = [h.stage_pack(torch.device(DEV)) for h in head.mask_head]
+    a = vkn.ops.head_forward(dims, packs, *_cuda(x, pf.reshape(2, 166, 64), mp), None, 2, flags=0)
+    b = vkn.ops.head_forward(dims, packs, *_cuda(x, pf.reshape(2, 166, 64), mp), None, 2, flags=4)
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u, v)
+    # teacher-forced last stage: feed the oracle's stage-0 outputs to the GPU stage 1 -> tight
+    t0 = traces[0]
+    cls1, m1, o1, _, _ = vkn.ops.stage_forward(dims, packs[1], x.to(DEV), t0['obj_feat'].reshape(2, 166, 64).to(DEV),
+                                                t0['new_mask_preds'].to(DEV))
+    assert maxabs(m1, rm) < TOL_LOGIT and maxabs(cls1, traces[1]['cls_score']) < 1e-4
