@@ -47,7 +47,7 @@ if con:
     print(f'{"kernel":48s} {"calls":>6s} {"avg_us":>9s} {"total_ms":>9s} {"pct":>6s}')
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
         print(f'{k:48s} {c:6d} {t / c / 1e3:9.2f} {t / 1e6:9.3f} {100 * t / tot:6.1f}')
-    G = [i for i, r in enumerate(rows) if 'k_gather_mfma' in r[0]]
+    G = [i for i, r in enumerate(rows) if 'k_gather_mfma' in r[0] or 'k_gather_bits_w' in r[0]]
     if len(G) >= 13:
         # bench.py: every step = one head call = 3 gathers; take the 4th head call (a timed one)
         i0, j = G[9], G[12]
@@ -84,8 +84,14 @@ if len(sys.argv) > 2 and pmc:
         if k in pmc and 'FETCH_SIZE_KB' in pmc[k] and 'WRITE_SIZE_KB' in pmc[k]:
             side[k] = dict(fetch_size_kb=pmc[k]['FETCH_SIZE_KB'], write_size_kb=pmc[k]['WRITE_SIZE_KB'],
                            hbm_bytes_per_launch=int((2 * pmc[k]['FETCH_SIZE_KB'] + pmc[k]['WRITE_SIZE_KB']) * 1024))
+    try:  # frames per launch of the profiled run, from the bench line rocprofv3 passed through
+        import re
+        log = open(os.path.join(out, 'bench_trace.log')).read()
+        side['_frames_per_launch'] = int(re.search(r'"frames_per_gpu_per_step": (\d+)', log).group(1))
+    except Exception:  # noqa: BLE001
+        side['_frames_per_launch'] = None
     side['_note'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 2`, '
-                     'mean per launch (B = 8 frames); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per the gfx950 note in '
+                     'mean per launch (B = _frames_per_launch frames); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per the gfx950 note in '
                      'MI355X_MICROARCH.md')
     json.dump(side, open(sys.argv[2], 'w'), indent=1)
 
