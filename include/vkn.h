@@ -225,6 +225,29 @@ size_t vkn_panoptic_workspace_bytes(const VknPanopticCfg* cfg, int B, int N);
 int vkn_panoptic_joint_f32(const VknPanopticCfg* cfg, const float* cls_prob, const float* mask_logits, int B, int N, int ncls,
                            int* panoptic_seg, int* info, int* nseg, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- train-time one-to-one assignment, one image.  Replaces `MaskHungarianAssigner.assign`
+ *      (knet/det/mask_hungarian_assigner.py:160-274; call site knet/det/kernel_iter_head.py:193-207) with the shipped costs
+ *      FocalLossCost (mmdet 2.18) + DiceCost (pred_act, :37-74) + MaskCost (pred_act, :87-113):
+ *        cost[n][g] = cls_weight * focal(cls_logits)[n][gt_labels[g]] + dice_weight * dice(n, g) + mask_weight * maskcost(n, g)
+ *      vkn_assign_costs_f32 computes the cost matrix on the GPU (the two [N x P].[P x G] contractions run on the gather kernel);
+ *      vkn_lsap_f32 is a HOST function: scipy.optimize.linear_sum_assignment's algorithm (same scan order and tie rule).
+ *      in : mask_logits [N][P] (the kernels' mask predictions at the assign resolution), cls_logits [N][ncls] or NULL,
+ *           gt_masks [G][P] with values 0 / 1, gt_labels int32 [G]; N <= 128, G <= 256.
+ *      out: cost [N][G] fp32 (device).  The caller copies it to the host, runs vkn_lsap_f32 and sets
+ *           assigned_gt_inds[row] = col + 1 (0 = background), as the reference does (:262-271). */
+typedef struct VknAssignCfg {
+    float cls_weight, dice_weight, mask_weight; /* the three `weight=` of train_cfg.assigner */
+    float focal_alpha, focal_gamma, focal_eps;  /* FocalLossCost defaults: 0.25, 2, 1e-12 */
+    float dice_eps;                             /* DiceCost eps: 1e-3 */
+} VknAssignCfg;
+size_t vkn_sizeof_assign_cfg(void);
+size_t vkn_assign_workspace_bytes(int N, int G, int P);
+int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, const float* cls_logits, const float* gt_masks,
+                         const int* gt_labels, int N, int G, int ncls, int P, float* cost_out, void* ws, size_t ws_bytes,
+                         void* stream);
+/*      cost: HOST fp32 [nr][nc]; writes min(nr, nc) (row, col) pairs sorted by row; returns their number or a negative code */
+int vkn_lsap_f32(const float* cost, int nr, int nc, int* row_ind, int* col_ind);
+
 #ifdef __cplusplus
 }
 #endif

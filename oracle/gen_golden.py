@@ -40,6 +40,7 @@ import knet.det.kernel_iter_head  # noqa: E402,F401
 import knet.video.kernel_update_head  # noqa: E402,F401
 import knet.video.kernel_iter_head  # noqa: E402,F401
 import knet.det.kernel_head  # noqa: E402,F401  (ConvKernelHead: the kernel-initialisation pass)
+import knet.det.mask_hungarian_assigner  # noqa: E402,F401  (MaskHungarianAssigner, DiceCost, MaskCost)
 from mmdet.models.builder import NECKS, build_head  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
@@ -286,6 +287,31 @@ def run_pan_case(name, p):
           f'{float((np.stack(segs) == 0).mean()):.3f}')
 
 
+ASSIGN_CASES = {
+    'assign_tiny': dict(N=12, G=5, ncls=2, H=16, W=32, seed=51),
+    'assign_cfg': dict(N=100, G=23, ncls=2, H=64, W=128, seed=52),       # 100 thing kernels, the shipped costs, 1/4-res masks
+    'assign_odd': dict(N=21, G=30, ncls=7, H=9, W=15, seed=53),          # more ground truths than kernels, ragged P
+}
+
+
+def run_assign_case(name, p):
+    """MaskHungarianAssigner.assign of the reference with the shipped train_cfg costs
+    (configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:143-148)."""
+    from mmdet.core import build_assigner
+    assigner = build_assigner(dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                   dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                   mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)))
+    logits, cls, gt, labels = (torch.from_numpy(a) for a in synth.assign_inputs(p['N'], p['G'], p['ncls'], p['H'], p['W'], p['seed']))
+    with torch.no_grad():
+        res = assigner.assign(logits, cls, gt, labels)
+        # the cost matrix itself, through the reference's own cost objects (what assign() sums at :222-241)
+        cost = assigner.cls_cost(cls, labels) + assigner.mask_cost(logits, gt) + assigner.dice_cost(logits, gt)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'),
+                        case=np.array([p['N'], p['G'], p['ncls'], p['H'], p['W'], p['seed']], dtype=np.int64),
+                        gt_inds=res.gt_inds.numpy(), labels=res.labels.numpy(), cost=cost.numpy())
+    print(f'{name}: ok  matched {int((res.gt_inds > 0).sum())} of {p["N"]} kernels to {p["G"]} ground truths')
+
+
 def thr_kat():
     """(sigmoid(z) > 0.5) as the reference computes it (knet/det/kernel_update_head.py:190-191) — torch CPU fp32.
     The flip point is not z=0: it depends on the fp32 sigmoid (SURVEY.md §7 'Threshold semantics')."""
@@ -323,6 +349,9 @@ if __name__ == '__main__':
     for name, p in PAN_CASES.items():
         if not only or name in only:
             run_pan_case(name, p)
+    for name, p in ASSIGN_CASES.items():
+        if not only or name in only:
+            run_assign_case(name, p)
     if not only or 'init_keys' in only:
         init_keys()
     if not only or 'thr_kat' in only:

@@ -346,3 +346,38 @@ def panoptic_joint(cls_scores, mask_logits, num_proposals, num_thing_classes, ma
     return dict(panoptic_seg=panoptic_seg, segments_info=segments_info, cur_mask_ids=cur_mask_ids, total_scores=total_scores,
                 total_labels=total_labels, rows=rows, area=area, orig=orig, seg_of=seg_of, margin=margin,
                 total_masks=total_masks)
+
+
+def assign_costs(mask_preds, cls_pred, gt_masks, gt_labels, cls_weight=2.0, dice_weight=4.0, mask_weight=1.0,
+                 focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3):
+    """Cost matrix of MaskHungarianAssigner.assign (knet/det/mask_hungarian_assigner.py:222-241) with FocalLossCost
+    (mmdet 2.18, restated), DiceCost(pred_act=True) (:37-74) and MaskCost(pred_act=True) (:87-113).  -> [N, G] fp32."""
+    p = cls_pred.sigmoid()                                                                            # FocalLossCost
+    neg = -(1 - p + focal_eps).log() * (1 - focal_alpha) * p.pow(focal_gamma)
+    pos = -(p + focal_eps).log() * focal_alpha * (1 - p).pow(focal_gamma)
+    cls_cost = (pos[:, gt_labels] - neg[:, gt_labels]) * cls_weight
+    mp = mask_preds.sigmoid().clamp(min=0.01, max=1.0)                                                # MaskCost :104-113
+    H, W = gt_masks.shape[-2:]
+    pos_c = torch.einsum('nhw,mhw->nm', mp, gt_masks)
+    neg_c = torch.einsum('nhw,mhw->nm', 1 - mp, 1 - gt_masks)
+    reg_cost = -(pos_c + neg_c) / (H * W) * mask_weight
+    dp = mask_preds.sigmoid().clamp(min=0.001, max=1.0)                                               # DiceCost :48-74
+    inp = dp.reshape(dp.shape[0], -1)
+    tgt = gt_masks.reshape(gt_masks.shape[0], -1).float()
+    a = torch.einsum('nh,mh->nm', inp, tgt)
+    b = torch.sum(inp * inp, 1) + dice_eps
+    c = torch.sum(tgt * tgt, 1) + dice_eps
+    dice_cost = -((2 * a) / (b[:, None] + c[None, ...])) * dice_weight
+    return cls_cost + reg_cost + dice_cost                                                            # :241
+
+
+def hungarian_assign(cost, gt_labels):
+    """Steps 3-4 of MaskHungarianAssigner.assign (:244-274): scipy LSAP on the host, 1-based gt indices, 0 = background."""
+    from scipy.optimize import linear_sum_assignment
+    rows, cols = linear_sum_assignment(cost.detach().cpu())
+    n = cost.shape[0]
+    gt_inds = torch.zeros(n, dtype=torch.long)
+    labels = torch.full((n,), -1, dtype=torch.long)
+    gt_inds[torch.from_numpy(rows)] = torch.from_numpy(cols) + 1
+    labels[torch.from_numpy(rows)] = gt_labels[torch.from_numpy(cols)]
+    return gt_inds, labels

@@ -21,3 +21,17 @@ def multi_apply(func, *args, **kwargs):
 
 def reduce_mean(tensor):
     return tensor
+
+
+class AssignResult:
+    """mmdet.core.AssignResult (fields only): what `MaskHungarianAssigner.assign` returns."""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts = num_gts
+        self.gt_inds = gt_inds
+        self.max_overlaps = max_overlaps
+        self.labels = labels
+
+
+class BaseAssigner:
+    """mmdet.core.BaseAssigner: abstract base, no behaviour."""

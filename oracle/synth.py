@@ -95,3 +95,15 @@ def panoptic_inputs(B, N, Np, ncls, Hm, Wm, seed):
         inside = (ys >= j / ns) & (ys < (j + 1) / ns)
         logits[:, Np + j] = np.where(np.broadcast_to(inside[:, 0], (B, Hm, Wm)), 4.0, -4.0)
     return cls.astype(np.float32), (logits + noise).astype(np.float32)
+
+
+def assign_inputs(N, G, ncls, H, W, seed):
+    """Inputs of the train-time assignment for one image: mask logits [N,H,W] (blobs + noise), class logits [N,ncls],
+    ground-truth masks [G,H,W] in {0,1} (G of the blobs, thresholded, so that a good matching exists) and labels [G]."""
+    _, logits = panoptic_inputs(1, N, N, 1, H, W, 100 + seed)
+    logits = logits[0]
+    cls = normalish((N, ncls), 61 + 13 * seed, 2.0)
+    pick = (uniform((G,), 62 + 13 * seed, 0.0, 1.0).astype(np.float64) * N).astype(np.int64)
+    gt = (logits[pick] + normalish((G, H, W), 63 + 13 * seed, 1.0) > 0.5).astype(np.float32)
+    labels = (uniform((G,), 64 + 13 * seed, 0.0, 1.0).astype(np.float64) * ncls).astype(np.int64)
+    return logits.astype(np.float32), cls.astype(np.float32), gt, labels

@@ -97,3 +97,15 @@ def pan_info_rows(segments_info):
     """segments_info (list of dicts) -> the golden's [id, isthing, category_id, instance_id|-1, score|nan, area|-1] rows."""
     return np.array([[s['id'], int(s['isthing']), s['category_id'], s.get('instance_id', -1), s.get('score', float('nan')),
                       s.get('area', -1)] for s in segments_info], dtype=np.float64).reshape(-1, 6)
+
+
+ASSIGN_FIELDS = ('N', 'G', 'ncls', 'H', 'W', 'seed')
+
+
+def load_assign_golden(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+    return g, dict(zip(ASSIGN_FIELDS, (int(v) for v in g['case'])))
+
+
+def make_assign_case(case):
+    return tuple(torch.from_numpy(a) for a in synth.assign_inputs(case['N'], case['G'], case['ncls'], case['H'], case['W'], case['seed']))

@@ -614,3 +614,53 @@ def test_head_vipseg_kernel_count_vs_oracle(vkn, hw):
     cls1, m1, o1, _, _ = vkn.ops.stage_forward(dims, packs[1], x.to(DEV), t0['obj_feat'].reshape(2, 166, 64).to(DEV),
                                                 t0['new_mask_preds'].to(DEV))
     assert maxabs(m1, rm) < TOL_LOGIT and maxabs(cls1, traces[1]['cls_score']) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ train-time assignment
+@pytest.mark.parametrize('name', ['assign_tiny', 'assign_cfg', 'assign_odd'])
+def test_assignment_vs_reference(vkn, name):
+    """MaskHungarianAssigner on the GPU: cost matrix vs the reference's (fp32 class accuracy), integer assignment bit-exact."""
+    from helpers import load_assign_golden, make_assign_case
+    g, case = load_assign_golden(name)
+    logits, cls, gt, labels = make_assign_case(case)
+    a = vkn.MaskHungarianAssigner(cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                  dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                  mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    dl, dc, dg, dlab = logits.to(DEV), cls.to(DEV), gt.to(DEV), labels.to(DEV)
+    cost = a.cost_matrix(dl, dc, dg, dlab)
+    assert maxabs(cost, g['cost']) < 2e-5
+    res = a.assign(dl, dc, dg, dlab)
+    assert res.num_gts == case['G']
+    assert np.array_equal(res.gt_inds.cpu().numpy(), g['gt_inds'])          # integer kernel assignments: bit-exact
+    assert np.array_equal(res.labels.cpu().numpy(), g['labels'])
+    # the margin of the optimum: the second-best assignment is farther than the cost error, so the match is not luck
+    from scipy.optimize import linear_sum_assignment
+    c64 = g['cost'].astype(np.float64)
+    r0, c0 = linear_sum_assignment(c64)
+    best = c64[r0, c0].sum()
+    got = cost.cpu().numpy().astype(np.float64)
+    assert abs(got[r0, c0].sum() - best) < 1e-3
+
+
+def test_assignment_full_resolution(vkn):
+    """cfg2 assign resolution (1024x2048 / mask_assign_stride 4 = 256x512, 100 kernels, 40 ground truths) vs fp64 on the device."""
+    N, G, ncls, H, W = 100, 40, 2, 256, 512
+    lo, cl, gt, lab = (torch.from_numpy(a).to(DEV) for a in synth.assign_inputs(N, G, ncls, H, W, 9))
+    a = vkn.MaskHungarianAssigner(cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                  dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                  mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    cost = a.cost_matrix(lo, cl, gt, lab)
+    p = lo.double().sigmoid()
+    p1, p2, gd = p.clamp(0.001, 1.0).flatten(1), p.clamp(0.01, 1.0).flatten(1), gt.double().flatten(1)
+    dice = -(2 * p1 @ gd.t()) / ((p1 * p1).sum(1, keepdim=True) + 1e-3 + gd.sum(1)[None] + 1e-3)
+    mcost = -(p2 @ gd.t() + (1 - p2) @ (1 - gd).t()) / (H * W)
+    pc = cl.double().sigmoid()
+    foc = (-(pc + 1e-12).log() * 0.25 * (1 - pc) ** 2 + (1 - pc + 1e-12).log() * 0.75 * pc ** 2)[:, lab]
+    want = 2.0 * foc + 4.0 * dice + mcost
+    assert maxabs(cost, want) < 2e-5
+    res = a.assign(lo, cl, gt, lab)
+    from scipy.optimize import linear_sum_assignment
+    r0, c0 = linear_sum_assignment(want.cpu().numpy())
+    inds = np.zeros(N, dtype=np.int64)
+    inds[r0] = c0 + 1
+    assert np.array_equal(res.gt_inds.cpu().numpy(), inds)

@@ -172,3 +172,38 @@ def test_widened_entry_points_validate_on_the_host(vkn):
         vkn.ops.panoptic_joint(torch.zeros(1, 15, 5), torch.zeros(1, 15, 8, 16), 12, 2, 12, 0.25, 0.6, (64, 128), (64, 128), (64, 128))
     with pytest.raises(vkn.VknLibraryError):
         vkn.ops.kernel_init(torch.zeros(1, 64, 8, 16), None, torch.zeros(12, 64, 1, 1))
+
+
+def test_lsap_matches_scipy(vkn):
+    """libvkn's host LSAP (shortest augmenting path, scipy's scan order and tie rule) == scipy.optimize.linear_sum_assignment,
+    including rectangular inputs in both orientations and integer matrices full of ties."""
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        nr, nc = int(rng.integers(1, 48)), int(rng.integers(1, 48))
+        c = (rng.integers(0, 4, size=(nr, nc)) if trial % 3 == 0 else rng.standard_normal((nr, nc))).astype(np.float32)
+        r, cc = vkn.ops.lsap(c)
+        r0, c0 = linear_sum_assignment(c)
+        assert np.array_equal(r, r0) and np.array_equal(cc, c0)
+    g = np.load(os.path.join(GOLDEN, 'assign_cfg.npz'))     # the reference's own cost matrix -> the reference's assignment
+    r, cc = vkn.ops.lsap(g['cost'])
+    inds = np.zeros(g['cost'].shape[0], dtype=np.int64)
+    inds[r] = cc + 1
+    assert np.array_equal(inds, g['gt_inds'])
+    with pytest.raises(vkn.VknError):
+        vkn.ops.lsap(np.full((3, 3), np.nan, dtype=np.float32))
+
+
+def test_mask_hungarian_assigner_surface(vkn):
+    A = vkn.MaskHungarianAssigner
+    a = A(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+          mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    assert a.cls['weight'] == 2.0 and a.dice['eps'] == 1e-3
+    with pytest.raises(NotImplementedError):
+        A()                                                # the class defaults name costs no shipped config uses
+    with pytest.raises(NotImplementedError):
+        A(cls_cost=dict(type='FocalLossCost'), dice_cost=dict(type='DiceCost', pred_act=False), mask_cost=dict(type='MaskCost', pred_act=True))
+    with pytest.raises(vkn.VknLibraryError):               # CPU tensors: no fallback
+        a.assign(torch.zeros(4, 8, 8), torch.zeros(4, 2), torch.zeros(2, 8, 8), torch.zeros(2, dtype=torch.long))
+    r = a.assign(torch.zeros(4, 8, 8), torch.zeros(4, 2), torch.zeros(0, 8, 8), torch.zeros(0, dtype=torch.long))
+    assert r.num_gts == 0 and (r.gt_inds == 0).all()

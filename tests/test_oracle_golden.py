@@ -111,3 +111,18 @@ def test_panoptic_oracle_matches_reference_golden(name):
         rows, want = pan_info_rows(r['segments_info']), g[f'info{b}']
         assert rows.shape == want.shape and int(g['nseg'][b]) == len(r['segments_info']) > 0
         assert np.array_equal(np.nan_to_num(rows, nan=-7.0), np.nan_to_num(want, nan=-7.0))
+
+
+@pytest.mark.parametrize('name', ['assign_tiny', 'assign_cfg', 'assign_odd'])
+def test_assign_oracle_matches_reference_golden(name):
+    """oracle.assign_costs / hungarian_assign == the reference's MaskHungarianAssigner with the shipped costs: the cost matrix
+    to fp32 rounding, the integer assignment bit-exact."""
+    from helpers import load_assign_golden, make_assign_case
+    from oracle.knet_oracle import assign_costs, hungarian_assign
+    g, case = load_assign_golden(name)
+    logits, cls, gt, labels = make_assign_case(case)
+    with torch.no_grad():
+        cost = assign_costs(logits, cls, gt, labels)
+        gt_inds, lab = hungarian_assign(cost, labels)
+    assert maxabs(cost, g['cost']) < 1e-6
+    assert np.array_equal(gt_inds.numpy(), g['gt_inds']) and np.array_equal(lab.numpy(), g['labels'])

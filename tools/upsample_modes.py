@@ -12,8 +12,9 @@ import vkn_import  # noqa: E402
 
 vkn = vkn_import.load()
 dev = 'cuda:0'
-m = torch.randn(8, 117, 128, 256, device=dev)
-big = torch.empty(8, 117, 512, 1024, device=dev)
+B = int(os.environ.get("B", 8))
+m = torch.randn(B, 117, 128, 256, device=dev)
+big = torch.empty(B, 117, 512, 1024, device=dev)
 nbytes = big.numel() * 4
 
 

@@ -11,8 +11,9 @@ from .kernel_updator import KernelUpdator  # noqa: F401
 from .kernel_update_head import KernelUpdateHead, VideoKernelUpdateHead  # noqa: F401
 from .kernel_iter_head import KernelIterHead, VideoKernelIterHead  # noqa: F401
 from .kernel_head import ConvKernelHead  # noqa: F401
+from .mask_hungarian_assigner import MaskHungarianAssigner  # noqa: F401
 from .registry import HEADS, TRANSFORMER_LAYER, build_head, build_transformer_layer  # noqa: F401
 
-__all__ = ['KernelUpdator', 'KernelUpdateHead', 'VideoKernelUpdateHead', 'KernelIterHead', 'VideoKernelIterHead', 'ConvKernelHead',
+__all__ = ['KernelUpdator', 'KernelUpdateHead', 'VideoKernelUpdateHead', 'KernelIterHead', 'VideoKernelIterHead', 'ConvKernelHead', 'MaskHungarianAssigner',
            'HEADS', 'TRANSFORMER_LAYER', 'build_head', 'build_transformer_layer', 'ops', 'build', 'VknError',
            'VknLibraryError']

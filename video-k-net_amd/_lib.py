@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
-SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_api.hip')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_assign.hip', 'vkn_api.hip')
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares
@@ -20,7 +20,8 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_w
            'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
            'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32',
            'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32',
-           'vkn_sizeof_panoptic_cfg', 'vkn_panoptic_workspace_bytes', 'vkn_panoptic_joint_f32')
+           'vkn_sizeof_panoptic_cfg', 'vkn_panoptic_workspace_bytes', 'vkn_panoptic_joint_f32',
+           'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_lsap_f32')
 
 
 class VknPanopticCfg(ctypes.Structure):
@@ -29,6 +30,13 @@ class VknPanopticCfg(ctypes.Structure):
                 ('instance_score_thr', ctypes.c_float), ('overlap_thr', ctypes.c_double), ('up', ctypes.c_int),
                 ('Hm', ctypes.c_int), ('Wm', ctypes.c_int), ('Hb', ctypes.c_int), ('Wb', ctypes.c_int),
                 ('h', ctypes.c_int), ('w', ctypes.c_int), ('Ho', ctypes.c_int), ('Wo', ctypes.c_int)]
+
+
+class VknAssignCfg(ctypes.Structure):
+    """Mirror of include/vkn.h: VknAssignCfg."""
+    _fields_ = [('cls_weight', ctypes.c_float), ('dice_weight', ctypes.c_float), ('mask_weight', ctypes.c_float),
+                ('focal_alpha', ctypes.c_float), ('focal_gamma', ctypes.c_float), ('focal_eps', ctypes.c_float),
+                ('dice_eps', ctypes.c_float)]
 
 
 class VknLibraryError(RuntimeError):
@@ -169,6 +177,17 @@ def lib():
     L.vkn_panoptic_workspace_bytes.argtypes = [pP, c_int, c_int]
     L.vkn_panoptic_joint_f32.restype = c_int
     L.vkn_panoptic_joint_f32.argtypes = [pP, _fp, _fp, c_int, c_int, c_int, _fp, _fp, _fp, _fp, c_size, _fp]
+    pA = ctypes.POINTER(VknAssignCfg)
+    L.vkn_sizeof_assign_cfg.restype = c_size
+    L.vkn_sizeof_assign_cfg.argtypes = []
+    if L.vkn_sizeof_assign_cfg() != ctypes.sizeof(VknAssignCfg):
+        raise VknLibraryError('ctypes mirror of VknAssignCfg is out of date (size mismatch)')
+    L.vkn_assign_workspace_bytes.restype = c_size
+    L.vkn_assign_workspace_bytes.argtypes = [c_int] * 3
+    L.vkn_assign_costs_f32.restype = c_int
+    L.vkn_assign_costs_f32.argtypes = [pA, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp, _fp, c_size, _fp]
+    L.vkn_lsap_f32.restype = c_int
+    L.vkn_lsap_f32.argtypes = [_fp, c_int, c_int, _fp, _fp]
     _LIB = L
     return L
 

@@ -1,0 +1,224 @@
+// vkn_assign.hip — train-time one-to-one assignment of kernels to ground-truth masks.
+//
+// Reference, per image: MaskHungarianAssigner.assign (knet/det/mask_hungarian_assigner.py:160-274) with the shipped costs
+// (configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:143-160):
+//     cost[n][g] = w_cls  * FocalLossCost(cls_logits)[n][label_g]                       (mmdet 2.18 match cost, restated below)
+//                + w_dice * DiceCost  = -2 a / (sum_p p1^2 + eps + sum_p g^2 + eps),   a = sum_p p1 g,  p1 = clamp(sigmoid z, 1e-3, 1)   (:37-74)
+//                + w_mask * MaskCost  = -(sum_p p2 g + sum_p (1 - p2)(1 - g)) / (H W),                p2 = clamp(sigmoid z, 1e-2, 1)   (:87-113)
+// then scipy.optimize.linear_sum_assignment on the host and assigned_gt_inds[row] = col + 1                                  (:244-271).
+//
+// The two [N x P] . [P x G] contractions are the gather kernel with the roles swapped: the binary operand is the ground truth
+// (rows g, "logit" = the 0/1 mask, threshold 0.5), the streamed real operand holds the activated predictions as channels —
+// p1 rows in channels [0, Npad), p2 rows in [Npad, 2 Npad) — so ONE launch of k_gather_mfma yields both sums and sum_p g (its
+// pixel count).  k_assign_act writes the activations (+ fixed-order partial row sums of p1^2 and p2), k_assign_cost combines
+// everything in fp64.  The LSAP itself is the shortest-augmenting-path algorithm scipy uses, in C++ on the host (vkn_lsap_f32).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include <limits>
+#include <vector>
+
+#include "../../include/vkn.h"
+#include "vkn_common.h"
+#include "vkn_launch.h"
+
+#define AS_CHUNK 4096  // pixels per workgroup of k_assign_act
+
+// act[0 .. Npad) = p1 rows, act[Npad .. 2 Npad) = p2 rows (rows >= N zero); rowsum[n][chunk][2] = partial (sum p1^2, sum p2)
+__global__ __launch_bounds__(256) void k_assign_act(const float* __restrict__ logits, float* __restrict__ act,
+                                                    float* __restrict__ rowsum, int N, int Npad, int P, int nchunk) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.y, ck = blockIdx.x;
+    const int p_lo = ck * AS_CHUNK, p_hi = min(P, p_lo + AS_CHUNK);
+    float s1 = 0.f, s2 = 0.f;
+    float* a1 = act + (size_t)n * P;
+    float* a2 = act + (size_t)(Npad + n) * P;
+    if (n < N) {
+        const float* z = logits + (size_t)n * P;
+        for (int p = p_lo + threadIdx.x; p < p_hi; p += 256) {
+            const float s = 1.0f / (1.0f + expf(-z[p]));
+            const float p1 = fminf(fmaxf(s, 0.001f), 1.0f), p2 = fminf(fmaxf(s, 0.01f), 1.0f);
+            a1[p] = p1;
+            a2[p] = p2;
+            s1 += p1 * p1;
+            s2 += p2;
+        }
+    } else {
+        for (int p = p_lo + threadIdx.x; p < p_hi; p += 256) { a1[p] = 0.f; a2[p] = 0.f; }
+    }
+    s1 = vkn_wave_sum(s1);
+    s2 = vkn_wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0 && n < N) {
+        rowsum[((size_t)n * nchunk + ck) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        rowsum[((size_t)n * nchunk + ck) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// S [G][2 Npad] from the gather (S[g][n] = sum p1 g, S[g][Npad + n] = sum p2 g), cnt [G] = sum g -> cost [N][G]
+__global__ __launch_bounds__(256) void k_assign_cost(VknAssignCfg c, const float* __restrict__ S, const float* __restrict__ cnt,
+                                                     const float* __restrict__ rowsum, const float* __restrict__ cls,
+                                                     const int* __restrict__ labels, int N, int Npad, int G, int ncls, int P,
+                                                     int nchunk, float* __restrict__ cost) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * G) return;
+    const int n = i / G, g = i - n * G;
+    double sp1sq = 0.0, sp2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {  // fixed order -> deterministic
+        sp1sq += (double)rowsum[((size_t)n * nchunk + k) * 2 + 0];
+        sp2 += (double)rowsum[((size_t)n * nchunk + k) * 2 + 1];
+    }
+    const double sg = (double)cnt[g];
+    double total = 0.0;
+    if (c.dice_weight != 0.f) {
+        const double a = (double)S[(size_t)g * 2 * Npad + n];
+        total += (double)c.dice_weight * (-(2.0 * a) / ((sp1sq + (double)c.dice_eps) + (sg + (double)c.dice_eps)));
+    }
+    if (c.mask_weight != 0.f) {
+        const double pos = (double)S[(size_t)g * 2 * Npad + Npad + n];
+        const double neg = (double)P - sp2 - sg + pos;  // sum (1 - p2)(1 - g)
+        total += (double)c.mask_weight * (-(pos + neg) / (double)P);
+    }
+    if (c.cls_weight != 0.f && cls) {
+        // mmdet FocalLossCost: p = sigmoid(logit); neg = -log(1 - p + eps) (1 - alpha) p^gamma; pos = -log(p + eps) alpha (1 - p)^gamma
+        const float z = cls[(size_t)n * ncls + labels[g]];
+        const float p = 1.0f / (1.0f + expf(-z));
+        const float negc = -logf(1.f - p + c.focal_eps) * (1.f - c.focal_alpha) * powf(p, c.focal_gamma);
+        const float posc = -logf(p + c.focal_eps) * c.focal_alpha * powf(1.f - p, c.focal_gamma);
+        total += (double)c.cls_weight * (double)(posc - negc);
+    }
+    cost[i] = (float)total;
+}
+
+namespace {
+struct AssignWs {
+    float *act, *rowsum, *S, *cnt, *part, *cntp;
+};
+size_t carve_assign(int N, int G, int P, char* base, AssignWs* w) {
+    const size_t Npad = (size_t)(N + 31) / 32 * 32, nchunk = (size_t)(P + AS_CHUNK - 1) / AS_CHUNK;
+    const size_t Gg = vkn_gather_groups(1, P), GPT = (size_t)(G + 31) / 32 * 32, C2 = 2 * Npad;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        float* r = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off = (off + n * sizeof(float) + 255) & ~(size_t)255;
+        return r;
+    };
+    w->act = take(C2 * P);
+    w->rowsum = take((size_t)N * nchunk * 2);
+    w->S = take((size_t)G * C2);
+    w->cnt = take(G);
+    w->part = take(Gg * GPT * C2);
+    w->cntp = take(Gg * GPT);
+    return off;
+}
+}  // namespace
+
+extern "C" {
+
+size_t vkn_sizeof_assign_cfg(void) { return sizeof(VknAssignCfg); }
+
+size_t vkn_assign_workspace_bytes(int N, int G, int P) {
+    if (N <= 0 || G <= 0 || P <= 0) return 0;
+    AssignWs w;
+    return carve_assign(N, G, P, nullptr, &w);
+}
+
+int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, const float* cls_logits, const float* gt_masks,
+                         const int* gt_labels, int N, int G, int ncls, int P, float* cost_out, void* ws, size_t ws_bytes,
+                         void* stream) {
+    if (!cfg || !mask_logits || !gt_masks || !cost_out || N <= 0 || G <= 0 || P <= 0) return VKN_E_ARG;
+    if (cfg->cls_weight != 0.f && cls_logits && (!gt_labels || ncls <= 0)) return VKN_E_ARG;
+    const int Npad = (N + 31) / 32 * 32;
+    if (2 * Npad > 256 || G > 256) return VKN_E_SHAPE;  // both activations ride one gather launch as 2 Npad channels
+    if ((reinterpret_cast<uintptr_t>(mask_logits) | reinterpret_cast<uintptr_t>(gt_masks) | reinterpret_cast<uintptr_t>(ws)) & 15)
+        return VKN_E_ALIGN;
+    AssignWs w;
+    if (!ws || ws_bytes < carve_assign(N, G, P, nullptr, &w)) return VKN_E_WORKSPACE;
+    carve_assign(N, G, P, static_cast<char*>(ws), &w);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nchunk = (P + AS_CHUNK - 1) / AS_CHUNK;
+    hipLaunchKernelGGL(k_assign_act, dim3(nchunk, Npad), dim3(256), 0, st, mask_logits, w.act, w.rowsum, N, Npad, P, nchunk);
+    VKN_CHECK_LAUNCH();
+    // "x" = the activations [1][2 Npad][P], "masks" = the ground truth [G][P] binarised at 0.5
+    const int rc = vkn_launch_gather(w.act, gt_masks, 0.5f, w.S, w.cnt, w.part, w.cntp, 1, G, 2 * Npad, P, st);
+    if (rc != VKN_OK) return rc;
+    hipLaunchKernelGGL(k_assign_cost, dim3((N * G + 255) / 256), dim3(256), 0, st, *cfg, w.S, w.cnt, w.rowsum, cls_logits, gt_labels,
+                       N, Npad, G, ncls, P, nchunk, cost_out);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+// Rectangular linear sum assignment (minimisation), HOST function: the shortest augmenting path algorithm of
+// scipy.optimize.linear_sum_assignment (Crouse 2016), including its scan order (`remaining` filled in reverse) and its tie rule
+// (prefer a column that is still free), so that degenerate cost matrices resolve the same way.  cost: host fp32 [nr][nc] row-major
+// (converted to fp64 as scipy does).  Writes min(nr, nc) pairs sorted by row; returns the number of pairs or a negative error.
+int vkn_lsap_f32(const float* cost, int nr, int nc, int* row_ind, int* col_ind) {
+    if (!cost || !row_ind || !col_ind || nr < 0 || nc < 0) return VKN_E_ARG;
+    if (nr == 0 || nc == 0) return 0;
+    const bool transpose = nc < nr;
+    const int R = transpose ? nc : nr, Cn = transpose ? nr : nc;  // R <= Cn
+    std::vector<double> c((size_t)R * Cn);
+    for (int i = 0; i < nr; ++i)
+        for (int j = 0; j < nc; ++j) {
+            const double v = (double)cost[(size_t)i * nc + j];
+            if (v != v || v == -std::numeric_limits<double>::infinity()) return VKN_E_ARG;  // scipy: "matrix contains invalid numeric entries"
+            if (transpose) c[(size_t)j * Cn + i] = v;
+            else c[(size_t)i * Cn + j] = v;
+        }
+    const double INF = std::numeric_limits<double>::infinity();
+    std::vector<double> u(R, 0.0), v(Cn, 0.0), spc(Cn);
+    std::vector<int> path(Cn, -1), col4row(R, -1), row4col(Cn, -1), remaining(Cn);
+    std::vector<char> SR(R), SC(Cn);
+    for (int cur = 0; cur < R; ++cur) {
+        double minVal = 0.0;
+        int num_remaining = Cn;
+        for (int it = 0; it < Cn; ++it) remaining[it] = Cn - it - 1;
+        std::fill(SR.begin(), SR.end(), 0);
+        std::fill(SC.begin(), SC.end(), 0);
+        std::fill(spc.begin(), spc.end(), INF);
+        int sink = -1, i = cur;
+        while (sink == -1) {
+            int index = -1;
+            double lowest = INF;
+            SR[i] = 1;
+            for (int it = 0; it < num_remaining; ++it) {
+                const int j = remaining[it];
+                const double r = minVal + c[(size_t)i * Cn + j] - u[i] - v[j];
+                if (r < spc[j]) { path[j] = i; spc[j] = r; }
+                if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+            }
+            minVal = lowest;
+            if (minVal == INF) return VKN_E_ARG;  // infeasible
+            const int j = remaining[index];
+            if (row4col[j] == -1) sink = j;
+            else i = row4col[j];
+            SC[j] = 1;
+            remaining[index] = remaining[--num_remaining];
+        }
+        u[cur] += minVal;
+        for (int r2 = 0; r2 < R; ++r2)
+            if (SR[r2] && r2 != cur) u[r2] += minVal - spc[col4row[r2]];
+        for (int j = 0; j < Cn; ++j)
+            if (SC[j]) v[j] -= minVal - spc[j];
+        int j = sink;
+        while (true) {
+            const int r2 = path[j];
+            row4col[j] = r2;
+            const int t = col4row[r2];
+            col4row[r2] = j;
+            j = t;
+            if (r2 == cur) break;
+        }
+    }
+    int n = 0;
+    if (!transpose) {
+        for (int r2 = 0; r2 < R; ++r2) { row_ind[n] = r2; col_ind[n] = col4row[r2]; ++n; }
+    } else {  // rows of the original matrix are the columns here: emit sorted by original row
+        for (int j = 0; j < Cn; ++j)
+            if (row4col[j] != -1) { row_ind[n] = j; col_ind[n] = row4col[j]; ++n; }
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -426,3 +426,41 @@ def panoptic_joint(cls_prob, mask_logits, num_proposals, num_thing_classes, max_
         check(L.vkn_panoptic_joint_f32(ctypes.byref(cfg), _ptr(cls), _ptr(m), B, N, ncls, seg.data_ptr(), info.data_ptr(),
                                        nseg.data_ptr(), _ptr(ws), ws.numel(), _stream()))
     return seg, info, nseg
+
+
+def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, dice_weight=4.0, mask_weight=1.0,
+                 focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3):
+    """Cost matrix [N, G] of `MaskHungarianAssigner.assign` (knet/det/mask_hungarian_assigner.py:222-241) on the GPU."""
+    m = _req(mask_logits.reshape(mask_logits.shape[0], -1), 'mask_preds')
+    g = _req(gt_masks.reshape(gt_masks.shape[0], -1).float(), 'gt_masks')
+    N, P = m.shape
+    G = g.shape[0]
+    if g.shape[1] != P:
+        raise ValueError('mask_preds and gt_masks must have the same spatial size')
+    cls = _req(cls_logits, 'cls_pred') if cls_logits is not None else None
+    ncls = cls.shape[1] if cls is not None else 0
+    lab = gt_labels.to(device=m.device, dtype=torch.int32).contiguous()
+    cfg = _lib.VknAssignCfg(float(cls_weight), float(dice_weight), float(mask_weight), float(focal_alpha), float(focal_gamma),
+                            float(focal_eps), float(dice_eps))
+    L = _lib.lib()
+    cost = torch.empty((N, G), dtype=torch.float32, device=m.device)
+    nb = L.vkn_assign_workspace_bytes(N, G, P)
+    ws = _workspace(max(nb, 256), m.device)
+    with torch.cuda.device(m.device):
+        check(L.vkn_assign_costs_f32(ctypes.byref(cfg), _ptr(m), _ptr(cls), _ptr(g), lab.data_ptr(), N, G, ncls, P, _ptr(cost),
+                                     _ptr(ws), ws.numel(), _stream()))
+    return cost
+
+
+def lsap(cost):
+    """`scipy.optimize.linear_sum_assignment(cost)` on a host fp32 matrix through libvkn's C++ solver -> (row_ind, col_ind)
+    int64 numpy arrays (knet/det/mask_hungarian_assigner.py:244-251)."""
+    import numpy as np
+    c = np.ascontiguousarray(cost.detach().cpu().numpy() if torch.is_tensor(cost) else cost, dtype=np.float32)
+    nr, nc = c.shape
+    k = min(nr, nc)
+    rows, cols = np.empty(k, dtype=np.int32), np.empty(k, dtype=np.int32)
+    n = _lib.lib().vkn_lsap_f32(c.ctypes.data, nr, nc, rows.ctypes.data, cols.ctypes.data)
+    if n < 0:
+        check(n)
+    return rows[:n].astype(np.int64), cols[:n].astype(np.int64)
