@@ -103,7 +103,18 @@ def cpu_baseline(head_sd, sample_frames=1, runs=6):
                 ts.append(time.perf_counter() - t0)
     ts.sort()
     med = ts[len(ts) // 2]
+    # the same head at BASELINE cfg1 size (512x1024 frame -> 64x128 features), for the record
+    x1, mp1 = x[:, :, :64, :128].contiguous(), mp[:, :, :64, :128].contiguous()
+    t1 = []
+    with torch.no_grad():
+        for i in range(5):
+            t0 = time.perf_counter()
+            iter_head_mask_preds(sd, x1, pf, mp1, cfg, previous_obj_feats=prev)
+            if i >= 1:
+                t1.append(time.perf_counter() - t0)
+    t1.sort()
     return dict(value=round(sample_frames / med, 4), unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                cfg1_size_value=round(sample_frames / t1[len(t1) // 2], 4),
                 sample=f'{runs} timed runs (2 warm-up) of {sample_frames} frame(s) of the same workload, fp32, median, '
                        f'{best} intra-op threads (fastest of 8/16/32/64 on {ncpu} logical CPUs); '
                        f'min {sample_frames / ts[-1]:.3f} max {sample_frames / ts[0]:.3f} frames/s')

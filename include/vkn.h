@@ -166,7 +166,10 @@ int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* 
  *      (stage loop + last-stage bilinear upsample `_mask_forward` :118-137 + cls sigmoid :307-308).
  *      prev_obj is given to the LAST stage only (video :544-546).
  *      out: obj_out [B][N][C], cls_prob [B][N][ncls] (sigmoid applied), mask_preds_out [B][N][P],
- *           scaled_out [B][N][H*up][W*up] or NULL (skipped), track_out [B][N][C] or NULL. */
+ *           scaled_out [B][N][H*up][W*up] or NULL (skipped), track_out [B][N][C] or NULL.
+ *      Between stages only the binarised masks are handed over (bit words, 1/32 of the logits' bytes) when H*W % 64 == 0:
+ *      the next stage's gather reads nothing else, so every output is bit-identical to the logits hand-off
+ *      (VKN_FLAG_LOGITS_HANDOFF keeps the latter for A/B); intermediate stages' logits are not materialised. */
 size_t vkn_head_workspace_bytes(const VknDims* d);
 int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const float* x,
                          const float* proposal_feats, const float* mask_preds_in, const float* prev_obj, float* obj_out,
