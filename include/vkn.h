@@ -224,9 +224,12 @@ size_t vkn_panoptic_workspace_bytes(const VknPanopticCfg* cfg, int B, int N);
  *           info int32 [B][K][6], K = max_per_img + (N - num_proposals), one entry per selected kernel k in the reference's
  *           `total_*` order: {mask row, joint label (< num_thing_classes: thing class; else num_thing_classes + stuff index),
  *           segment id or 0, area (#pixels won), original area (#pixels with prob >= 0.5), score bits (fp32)};
- *           nseg int32 [B] = number of segments (-1: internal capacity error, results invalid). */
+ *           nseg int32 [B] = number of segments (-1: internal capacity error, results invalid);
+ *           bbox int32 [B][K][4] or NULL: (xmin, ymin, xmax, ymax) of `panoptic_seg == id` for accepted entries, else (-1,-1,10,10)
+ *           = `tensor_mask2box` (unitrack/utils/mask.py:80-90) on the segment masks, what the video detector hands its tracker
+ *           (knet/video/knet_quansi_dense_embed_fc_joint_train.py:541-584). */
 int vkn_panoptic_joint_f32(const VknPanopticCfg* cfg, const float* cls_prob, const float* mask_logits, int B, int N, int ncls,
-                           int* panoptic_seg, int* info, int* nseg, void* ws, size_t ws_bytes, void* stream);
+                           int* panoptic_seg, int* info, int* nseg, int* bbox, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- train-time one-to-one assignment, one image.  Replaces `MaskHungarianAssigner.assign`
  *      (knet/det/mask_hungarian_assigner.py:160-274; call site knet/det/kernel_iter_head.py:193-207) with the shipped costs

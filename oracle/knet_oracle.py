@@ -381,3 +381,20 @@ def hungarian_assign(cost, gt_labels):
     gt_inds[torch.from_numpy(rows)] = torch.from_numpy(cols) + 1
     labels[torch.from_numpy(rows)] = gt_labels[torch.from_numpy(cols)]
     return gt_inds, labels
+
+
+def things_for_tracking(panoptic_seg, segments_info):
+    """`get_things_id_for_tracking` (knet/video/knet_quansi_dense_embed_fc_joint_train.py:673-685) followed by
+    `tensor_mask2box` (unitrack/utils/mask.py:41-46, 80-90) on the segment masks `panoptic_seg == id`:
+    -> (instance ids, labels, boxes [n,4] = (xmin, ymin, xmax, ymax), scores) of the thing segments."""
+    idxs, labels, boxes, scores = [], [], [], []
+    seg = torch.as_tensor(panoptic_seg)
+    for s in segments_info:
+        if s['isthing']:
+            m = (seg == s['id']).nonzero().float()          # rows of (y, x)
+            if m.numel() > 0:                                # coords2bbox_all: (min col1, min col0, max col1, max col0)
+                box = (m[:, 1].min().item(), m[:, 0].min().item(), m[:, 1].max().item(), m[:, 0].max().item())
+            else:
+                box = (-1, -1, 10, 10)
+            idxs.append(s['instance_id']); labels.append(s['category_id']); boxes.append(box); scores.append(s['score'])
+    return idxs, labels, boxes, scores

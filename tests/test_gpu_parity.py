@@ -664,3 +664,35 @@ def test_assignment_full_resolution(vkn):
     inds = np.zeros(N, dtype=np.int64)
     inds[r0] = c0 + 1
     assert np.array_equal(res.gt_inds.cpu().numpy(), inds)
+
+
+@pytest.mark.parametrize('name', ['pan_tiny', 'pan_cfg'])
+def test_segment_boxes_for_tracking(vkn, name):
+    """bbox output of the panoptic pipeline == tensor_mask2box(panoptic_seg == id) on the reference's panoptic map for every
+    thing segment (the tracker's input), integer-exact wherever the GPU map equals the reference map."""
+    from helpers import PAN_CFG, load_pan_golden, make_pan_case, run_pan_oracle
+    g, case = load_pan_golden(name)
+    cls, logits, meta = make_pan_case(case)
+    seg, info, nseg, bbox = vkn.ops.panoptic_joint(cls.to(DEV), logits.to(DEV), case['Np'], case['T'], case['Np'],
+                                                   PAN_CFG['instance_score_thr'], PAN_CFG['overlap_thr'], meta['img_shape'][:2],
+                                                   meta['batch_input_shape'], meta['ori_shape'][:2], upsample_stride=case['up'],
+                                                   want_bbox=True)
+    torch.cuda.synchronize()
+    seg, info, bbox = seg.cpu().numpy(), info.cpu().numpy(), bbox.cpu().numpy()
+    head_like = type('H', (), dict(num_thing_classes=case['T']))()
+    from importlib import import_module
+    KIH = import_module('video_k_net_amd.kernel_iter_head').KernelIterHead
+    for b in range(case['B']):
+        r = run_pan_oracle(case, b)
+        # boxes of the GPU's own map, through the oracle's restatement of get_things_id_for_tracking + tensor_mask2box
+        infos = KIH._segments_info(head_like, info[b])
+        want = O.things_for_tracking(seg[b], infos)
+        got = KIH.things_for_tracking(head_like, info[b], bbox[b])
+        assert got[0] == want[0] and got[1] == want[1] and len(got[0]) > 0
+        assert np.array_equal(got[2], np.asarray(want[2], dtype=np.float32))
+        assert np.allclose(got[3], want[3], rtol=0, atol=0)
+        if np.array_equal(seg[b], g['panoptic_seg'][b]):     # identical maps -> identical boxes as the reference's map gives
+            ref = O.things_for_tracking(g['panoptic_seg'][b], r['segments_info'])
+            assert np.array_equal(got[2], np.asarray(ref[2], dtype=np.float32))
+        rej = info[b, :, 2] == 0
+        assert (bbox[b][rej] == np.array([-1, -1, 10, 10])).all()

@@ -164,7 +164,7 @@ def test_widened_entry_points_validate_on_the_host(vkn):
     nb = L.vkn_panoptic_workspace_bytes(ctypes.byref(cfg), 8, 117)
     assert nb >= 8 * 117 * 7 * 4
     # null pointers / bad geometry are rejected with an error code, never a crash
-    assert L.vkn_panoptic_joint_f32(ctypes.byref(cfg), None, None, 8, 117, 19, None, None, None, None, 0, None) == -1
+    assert L.vkn_panoptic_joint_f32(ctypes.byref(cfg), None, None, 8, 117, 19, None, None, None, None, None, 0, None) == -1
     assert L.vkn_kernel_init_f32(None, None, None, None, None, 2, 1, 1, 0.0, None, None, None, None, 2, 100, 19, 256, 1024,
                                  None, 0, 0, None) == -1
     assert vkn._lib.lib().vkn_strerror(-2).decode().startswith('unsupported shape')

@@ -176,7 +176,7 @@ def lib():
     L.vkn_panoptic_workspace_bytes.restype = c_size
     L.vkn_panoptic_workspace_bytes.argtypes = [pP, c_int, c_int]
     L.vkn_panoptic_joint_f32.restype = c_int
-    L.vkn_panoptic_joint_f32.argtypes = [pP, _fp, _fp, c_int, c_int, c_int, _fp, _fp, _fp, _fp, c_size, _fp]
+    L.vkn_panoptic_joint_f32.argtypes = [pP, _fp, _fp, c_int, c_int, c_int, _fp, _fp, _fp, _fp, _fp, c_size, _fp]
     pA = ctypes.POINTER(VknAssignCfg)
     L.vkn_sizeof_assign_cfg.restype = c_size
     L.vkn_sizeof_assign_cfg.argtypes = []

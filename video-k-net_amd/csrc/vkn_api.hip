@@ -592,10 +592,10 @@ size_t vkn_panoptic_workspace_bytes(const VknPanopticCfg* cfg, int B, int N) {
 }
 
 int vkn_panoptic_joint_f32(const VknPanopticCfg* cfg, const float* cls_prob, const float* mask_logits, int B, int N, int ncls,
-                           int* panoptic_seg, int* info, int* nseg, void* ws, size_t ws_bytes, void* stream) {
+                           int* panoptic_seg, int* info, int* nseg, int* bbox, void* ws, size_t ws_bytes, void* stream) {
     if (!cfg || !cls_prob || !mask_logits || !panoptic_seg || !info || !nseg || B <= 0 || N <= 0 || ncls <= 0) return VKN_E_ARG;
     if (!ws || !aligned16(ws)) return VKN_E_WORKSPACE;
-    return vkn_launch_panoptic_joint(cfg, cls_prob, mask_logits, B, N, ncls, panoptic_seg, info, nseg, ws, ws_bytes,
+    return vkn_launch_panoptic_joint(cfg, cls_prob, mask_logits, B, N, ncls, panoptic_seg, info, nseg, bbox, ws, ws_bytes,
                                      static_cast<hipStream_t>(stream));
 }
 

@@ -389,7 +389,8 @@ __global__ __launch_bounds__(64) void k_pan_merge(const int* __restrict__ sel_ro
                                                   const float* __restrict__ sel_score, const int* __restrict__ order,
                                                   const int* __restrict__ area, const int* __restrict__ orig, int K, int T,
                                                   float inst_thr, double overlap_thr, int* __restrict__ seg_of,
-                                                  int* __restrict__ info, int* __restrict__ nseg, const int* __restrict__ err) {
+                                                  int* __restrict__ info, int* __restrict__ nseg, const int* __restrict__ err,
+                                                  int* __restrict__ bbox) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;  // one wave per frame: stage the K-entry tables in LDS, then one lane walks them in score order
     int* ord = reinterpret_cast<int*>(smem);
@@ -422,15 +423,45 @@ __global__ __launch_bounds__(64) void k_pan_merge(const int* __restrict__ sel_ro
         seg_of[kk] = sid_s[i];
         int* e = info + kk * 6;
         e[0] = sel_row[kk]; e[1] = lab[i]; e[2] = sid_s[i]; e[3] = ar[i]; e[4] = og[i]; e[5] = __float_as_int(scs[i]);
+        if (bbox) {  // accepted: identity of min / max, filled by the relabel pass; rejected: unitrack's empty box (-1, -1, 10, 10)
+            int* bb = bbox + kk * 4;
+            const bool acc = sid_s[i] > 0;
+            bb[0] = acc ? 0x7fffffff : -1; bb[1] = acc ? 0x7fffffff : -1; bb[2] = acc ? -1 : 10; bb[3] = acc ? -1 : 10;
+        }
     }
 }
 
 // panoptic_seg[p] = segment id of the kernel that won pixel p (in place over the id map)                :503
-__global__ __launch_bounds__(256) void k_pan_relabel(int* __restrict__ seg, const int* __restrict__ seg_of, int K, size_t npx) {
+// bbox != NULL: also the bounding box (xmin, ymin, xmax, ymax) of every accepted segment = `tensor_mask2box(panoptic_seg == id)`
+// (unitrack/utils/mask.py:41-46, 80-90; what the video detector feeds its tracker,
+// knet/video/knet_quansi_dense_embed_fc_joint_train.py:541-584), by integer min / max atomics (order-independent).
+__global__ __launch_bounds__(256) void k_pan_relabel(int* __restrict__ seg, const int* __restrict__ seg_of, int K, int Wo, size_t npx,
+                                                     int* __restrict__ bbox) {
+    extern __shared__ int bbs[];  // [K][4]
     const int b = blockIdx.y;
     const int* tbl = seg_of + (size_t)b * K;
     int* s = seg + (size_t)b * npx;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (size_t)gridDim.x * 256) s[i] = tbl[s[i]];
+    if (bbox)
+        for (int i = threadIdx.x; i < K; i += 256) { bbs[4 * i] = 0x7fffffff; bbs[4 * i + 1] = 0x7fffffff; bbs[4 * i + 2] = -1; bbs[4 * i + 3] = -1; }
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (size_t)gridDim.x * 256) {
+        const int k = s[i];
+        const int sid = tbl[k];
+        s[i] = sid;
+        if (bbox && sid > 0) {
+            const int y = (int)(i / (size_t)Wo), x = (int)(i - (size_t)y * Wo);
+            atomicMin(&bbs[4 * k], x); atomicMin(&bbs[4 * k + 1], y);
+            atomicMax(&bbs[4 * k + 2], x); atomicMax(&bbs[4 * k + 3], y);
+        }
+    }
+    if (!bbox) return;
+    __syncthreads();
+    int* gb = bbox + (size_t)b * K * 4;
+    for (int i = threadIdx.x; i < K; i += 256)
+        if (bbs[4 * i + 2] >= 0) {
+            atomicMin(&gb[4 * i], bbs[4 * i]); atomicMin(&gb[4 * i + 1], bbs[4 * i + 1]);
+            atomicMax(&gb[4 * i + 2], bbs[4 * i + 2]); atomicMax(&gb[4 * i + 3], bbs[4 * i + 3]);
+        }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -447,7 +478,7 @@ size_t vkn_panoptic_ws_bytes(int B, int K) {
 }
 
 int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const float* masks, int B, int N, int ncls,
-                              int* panoptic_seg, int* info, int* nseg, void* ws, size_t ws_bytes, hipStream_t st) {
+                              int* panoptic_seg, int* info, int* nseg, int* bbox, void* ws, size_t ws_bytes, hipStream_t st) {
     const int Np = c->num_proposals, T = c->num_thing_classes, Kt = c->max_per_img;
     const int nstuff = N - Np, K = Kt + nstuff;
     if (Np <= 0 || Np > N || T < 0 || Kt <= 0 || Kt > Np * T || nstuff < 0 || T + nstuff > ncls) return VKN_E_ARG;
@@ -512,12 +543,12 @@ int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const f
     VKN_CHECK_LAUNCH();
 
     hipLaunchKernelGGL(k_pan_merge, dim3(B), dim3(64), (size_t)K * 6 * 4, st, sel_row, sel_label, sel_score, order, area, orig, K, T,
-                       c->instance_score_thr, c->overlap_thr, seg_of, info, nseg, err);
+                       c->instance_score_thr, c->overlap_thr, seg_of, info, nseg, err, bbox);
     VKN_CHECK_LAUNCH();
     const size_t npx = (size_t)c->Ho * c->Wo;
     size_t blocks = (npx + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_pan_relabel, dim3((unsigned)blocks, B), dim3(256), 0, st, panoptic_seg, seg_of, K, npx);
+    hipLaunchKernelGGL(k_pan_relabel, dim3((unsigned)blocks, B), dim3(256), (size_t)K * 16, st, panoptic_seg, seg_of, K, c->Wo, npx, bbox);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -157,8 +157,8 @@ class KernelIterHead(BaseRoIHead):
     def _meta_geometry(meta):
         return tuple(meta['img_shape'][:2]), tuple(meta['batch_input_shape'][:2]), tuple(meta['ori_shape'][:2])
 
-    def _panoptic_joint(self, cls_score, mask_logits, test_cfg, img_meta, upsample_stride):
-        """Frames [B] sharing one img_meta -> device tensors (panoptic_seg [B,Ho,Wo] int32, info [B,K,6], nseg [B])."""
+    def _panoptic_joint(self, cls_score, mask_logits, test_cfg, img_meta, upsample_stride, want_bbox=False):
+        """Frames [B] sharing one img_meta -> device tensors (panoptic_seg [B,Ho,Wo] int32, info [B,K,6], nseg [B][, bbox])."""
         if not self.merge_joint:
             raise NotImplementedError('the thing-first merge (merge_stuff_thing, reference :385-465) is not provided: every '
                                       'shipped panoptic config sets merge_joint=True')
@@ -166,7 +166,8 @@ class KernelIterHead(BaseRoIHead):
         img, bis, ori = self._meta_geometry(img_meta)
         return ops.panoptic_joint(cls_score, mask_logits, self.num_proposals, self.num_thing_classes,
                                   self._cfg(test_cfg, 'max_per_img'), self._cfg(merge_cfg, 'instance_score_thr'),
-                                  self._cfg(merge_cfg, 'overlap_thr'), img, bis, ori, upsample_stride=upsample_stride)
+                                  self._cfg(merge_cfg, 'overlap_thr'), img, bis, ori, upsample_stride=upsample_stride,
+                                  want_bbox=want_bbox)
 
     def _segments_info(self, info_b):
         """info [K,6] (host numpy) -> the reference's segments_info list, in segment-id order (reference :505-521)."""
@@ -180,6 +181,15 @@ class KernelIterHead(BaseRoIHead):
             else:
                 out.append(dict(id=sid, isthing=False, category_id=label - self.num_thing_classes + 1, area=int(info_b[k, 3])))
         return out
+
+    def things_for_tracking(self, info_b, bbox_b):
+        """Host arrays of one frame (info [K,6], bbox [K,4]) -> what the video detector hands its tracker
+        (`get_things_id_for_tracking` + `tensor_mask2box`, knet/video/knet_quansi_dense_embed_fc_joint_train.py:541-584,
+        673-685): (instance ids, thing labels, boxes [n,4] (xmin, ymin, xmax, ymax), scores) in segment order."""
+        acc = np.nonzero((info_b[:, 2] > 0) & (info_b[:, 1] < self.num_thing_classes))[0]
+        acc = acc[np.argsort(info_b[acc, 2], kind='stable')]
+        return (acc.tolist(), info_b[acc, 1].tolist(), bbox_b[acc].astype(np.float32),
+                info_b[acc, 5:6].copy().view(np.float32)[:, 0].tolist())
 
     def get_panoptic(self, cls_scores, mask_preds, test_cfg, img_meta):
         """One image, the reference's signature (:332-370): `mask_preds` are the (already up-scaled) `scaled_mask_preds[img]`.

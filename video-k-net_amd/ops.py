@@ -401,10 +401,11 @@ def kernel_init(loc_feats, semantic_feats, init_w, seg_w=None, seg_b=None, num_t
 
 
 def panoptic_joint(cls_prob, mask_logits, num_proposals, num_thing_classes, max_per_img, instance_score_thr, overlap_thr,
-                   img_shape, batch_input_shape, ori_shape, upsample_stride=1):
+                   img_shape, batch_input_shape, ori_shape, upsample_stride=1, want_bbox=False):
     """Joint panoptic merge of a batch of frames sharing one img_meta, straight from the head's low-res mask logits
     (`get_panoptic` + `merge_stuff_thing_stuff_joint` + `rescale_masks`, knet/det/kernel_iter_head.py:332-370, 467-524).
-    Returns device tensors (panoptic_seg int32 [B,Ho,Wo], info int32 [B,K,6], nseg int32 [B]); see include/vkn.h."""
+    Returns device tensors (panoptic_seg int32 [B,Ho,Wo], info int32 [B,K,6], nseg int32 [B]) and, with `want_bbox`, a fourth
+    one: bbox int32 [B,K,4] = (xmin, ymin, xmax, ymax) of every accepted segment (what the tracker consumes); see include/vkn.h."""
     cls, m = _req(cls_prob, 'cls_prob'), _req(mask_logits, 'mask_logits')
     B, N, ncls = cls.shape
     if m.shape[0] != B or m.shape[1] != N:
@@ -420,12 +421,13 @@ def panoptic_joint(cls_prob, mask_logits, num_proposals, num_thing_classes, max_
     seg = torch.empty((B, cfg.Ho, cfg.Wo), dtype=torch.int32, device=dev)
     info = torch.empty((B, K, 6), dtype=torch.int32, device=dev)
     nseg = torch.empty((B,), dtype=torch.int32, device=dev)
+    bbox = torch.empty((B, K, 4), dtype=torch.int32, device=dev) if want_bbox else None
     nb = L.vkn_panoptic_workspace_bytes(ctypes.byref(cfg), B, N)
     ws = _workspace(max(nb, 256), dev)
     with torch.cuda.device(dev):
         check(L.vkn_panoptic_joint_f32(ctypes.byref(cfg), _ptr(cls), _ptr(m), B, N, ncls, seg.data_ptr(), info.data_ptr(),
-                                       nseg.data_ptr(), _ptr(ws), ws.numel(), _stream()))
-    return seg, info, nseg
+                                       nseg.data_ptr(), bbox.data_ptr() if want_bbox else None, _ptr(ws), ws.numel(), _stream()))
+    return (seg, info, nseg, bbox) if want_bbox else (seg, info, nseg)
 
 
 def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, dice_weight=4.0, mask_weight=1.0,
