@@ -696,3 +696,22 @@ def test_segment_boxes_for_tracking(vkn, name):
             assert np.array_equal(got[2], np.asarray(ref[2], dtype=np.float32))
         rej = info[b, :, 2] == 0
         assert (bbox[b][rej] == np.array([-1, -1, 10, 10])).all()
+
+
+def test_batch_invariance(vkn):
+    """Frames are independent: a 19-frame call gives, bit for bit, what single-frame calls give (and the x`up` output is the
+    stand-alone upsample of the final logits)."""
+    _, case = load_golden('video_tiny')
+    head, (x, pf, mp, prev) = _build_head(vkn, case)
+    B, N, C, H, W = 19, case['N'], case['C'], case['H'], case['W']
+    xs = _rand((B, C, H, W), 901).to(DEV)
+    pfs = _rand((B, N, C), 902).to(DEV)
+    mps = _rand((B, N, H, W), 903, 4.0).to(DEV)
+    dims = head.mask_head[0].make_dims(B, N, H, W)
+    packs = [h.stage_pack(torch.device(DEV)) for h in head.mask_head]
+    obj, cls, masks, scaled, _ = vkn.ops.head_forward(dims, packs, xs, pfs, mps, None, case['up'])
+    assert torch.equal(scaled, vkn.ops.upsample_bilinear(masks, case['up']))
+    d1 = head.mask_head[0].make_dims(1, N, H, W)
+    for b in (0, 7, 8, 18):
+        o1, c1, m1, s1, _ = vkn.ops.head_forward(d1, packs, xs[b:b + 1], pfs[b:b + 1], mps[b:b + 1], None, case['up'])
+        assert torch.equal(m1[0], masks[b]) and torch.equal(s1[0], scaled[b]) and torch.equal(c1[0], cls[b])
