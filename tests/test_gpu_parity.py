@@ -715,3 +715,22 @@ def test_batch_invariance(vkn):
     for b in (0, 7, 8, 18):
         o1, c1, m1, s1, _ = vkn.ops.head_forward(d1, packs, xs[b:b + 1], pfs[b:b + 1], mps[b:b + 1], None, case['up'])
         assert torch.equal(m1[0], masks[b]) and torch.equal(s1[0], scaled[b]) and torch.equal(c1[0], cls[b])
+
+
+def test_panoptic_selection_many_thing_classes(vkn):
+    """VIP-Seg-like class layout (58 thing classes, 100 proposals -> 5800 (proposal, class) candidates, 66 stuff kernels): the
+    top-k / sort / merge-order kernels against the oracle's torch.topk / sort / argsort, bit-exact."""
+    N, Np, T, ncls, Hm, Wm = 166, 100, 58, 124, 16, 24
+    cls_np, logit_np = synth.panoptic_inputs(1, N, Np, ncls, Hm, Wm, 321)
+    meta = dict(img_shape=(64, 96, 3), batch_input_shape=(64, 96), ori_shape=(64, 96, 3))
+    seg, info, nseg = vkn.ops.panoptic_joint(torch.from_numpy(cls_np).to(DEV), torch.from_numpy(logit_np).to(DEV), Np, T, 100, 0.25,
+                                             0.6, (64, 96), (64, 96), (64, 96), upsample_stride=4)
+    with torch.no_grad():
+        r = O.panoptic_joint(torch.from_numpy(cls_np)[0], torch.from_numpy(logit_np)[0], Np, T, 100, 0.25, 0.6, meta,
+                             upsample_stride=4)
+    info = info[0].cpu().numpy()
+    assert np.array_equal(info[:, 0], r['rows'].numpy()) and np.array_equal(info[:, 1], r['total_labels'].numpy())
+    assert np.array_equal(info[:, 5].view(np.float32), r['total_scores'].numpy())
+    assert np.array_equal(info[:, 2], r['seg_of'].numpy()) and int(nseg[0]) == len(r['segments_info'])
+    near = r['margin'].numpy() < 1e-6
+    assert not ((seg[0].cpu().numpy() != r['panoptic_seg'].numpy()) & ~near).any()

@@ -57,25 +57,26 @@ __device__ __forceinline__ float pan_lerp(const float* __restrict__ ldsf, int ba
 }
 
 // ------------------------------------------------------------------------------------------------ selection
-// One workgroup per frame.  Ranks by (score descending, index ascending) — torch.topk / sort / argsort leave the order of exact
-// ties unspecified; this is the stable choice.  sel_* [B][K], K = Kt + nstuff; order[B][K] = merge order (indices into sel).
+// Ranks by (score descending, index ascending) — torch.topk / sort / argsort leave the order of exact
+// ties unspecified; this is the stable choice.  sel_* [B][K], K = Kt + nstuff (the merge order is ranked in k_pan_merge).
+// grid (chunks, B): every workgroup stages all candidates of its frame in LDS and ranks its own slice of them (rank = number of
+// candidates that sort before it) — O(n^2 / workgroups) per workgroup, n = Np * T up to 8000 (COCO: 100 proposals x 80 classes).
 __global__ __launch_bounds__(256) void k_pan_select(const float* __restrict__ cls, int N, int ncls, int Np, int T, int Kt,
                                                     int nstuff, int* __restrict__ sel_row, int* __restrict__ sel_label,
-                                                    float* __restrict__ sel_score, int* __restrict__ order) {
+                                                    float* __restrict__ sel_score) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x, K = Kt + nstuff;
+    const int b = blockIdx.y, K = Kt + nstuff;
     const float* c = cls + (size_t)b * N * ncls;
     int* row = sel_row + (size_t)b * K;
     int* lab = sel_label + (size_t)b * K;
     float* sc = sel_score + (size_t)b * K;
     const int nth = Np * T;
     float* cand = reinterpret_cast<float*>(smem);  // [nth] thing candidates, then [nstuff] stuff candidates
-    float* tot = cand + nth + nstuff;              // [K] selected scores
     for (int i = threadIdx.x; i < nth; i += 256) cand[i] = c[(size_t)(i / T) * ncls + (i % T)];
     for (int i = threadIdx.x; i < nstuff; i += 256) cand[nth + i] = c[(size_t)(Np + i) * ncls + (T + i)];
     __syncthreads();
     // things: candidate i = (proposal i / T, class i % T)                                knet/det/kernel_iter_head.py:334-340
-    for (int i = threadIdx.x; i < nth; i += 256) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nth; i += gridDim.x * 256) {
         const float s = cand[i];
         int rank = 0;
         for (int j = 0; j < nth; ++j) {
@@ -86,11 +87,10 @@ __global__ __launch_bounds__(256) void k_pan_select(const float* __restrict__ cl
             row[rank] = i / T;
             lab[rank] = i % T;
             sc[rank] = s;
-            tot[rank] = s;
         }
     }
     // stuff: score j = cls[Np + j][T + j], sorted descending; joint labels = T + j         :349-352, :359
-    for (int i = threadIdx.x; i < nstuff; i += 256) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nstuff; i += gridDim.x * 256) {
         const float s = cand[nth + i];
         int rank = 0;
         for (int j = 0; j < nstuff; ++j) {
@@ -100,18 +100,6 @@ __global__ __launch_bounds__(256) void k_pan_select(const float* __restrict__ cl
         row[Kt + rank] = Np + i;
         lab[Kt + rank] = T + i;
         sc[Kt + rank] = s;
-        tot[Kt + rank] = s;
-    }
-    __syncthreads();
-    // merge order: argsort(-total_scores)                                                  :489
-    for (int i = threadIdx.x; i < K; i += 256) {
-        const float s = tot[i];
-        int rank = 0;
-        for (int j = 0; j < K; ++j) {
-            const float t = tot[j];
-            rank += (t > s) || (t == s && j < i);
-        }
-        order[(size_t)b * K + rank] = i;
     }
 }
 
@@ -386,7 +374,7 @@ __global__ __launch_bounds__(PAN_THREADS) void k_pan_argmax(PanGeom g, const flo
 // One thread per frame: the score-ordered accept / reject loop                       knet/det/kernel_iter_head.py:492-522
 // info[B][K][6] = {mask row, joint label, segment id (0 = rejected), area, original area, score bits}
 __global__ __launch_bounds__(64) void k_pan_merge(const int* __restrict__ sel_row, const int* __restrict__ sel_label,
-                                                  const float* __restrict__ sel_score, const int* __restrict__ order,
+                                                  const float* __restrict__ sel_score, int* __restrict__ order,
                                                   const int* __restrict__ area, const int* __restrict__ orig, int K, int T,
                                                   float inst_thr, double overlap_thr, int* __restrict__ seg_of,
                                                   int* __restrict__ info, int* __restrict__ nseg, const int* __restrict__ err,
@@ -401,7 +389,19 @@ __global__ __launch_bounds__(64) void k_pan_merge(const int* __restrict__ sel_ro
     float* scs = reinterpret_cast<float*>(sid_s + K);
     for (int i = threadIdx.x; i < K; i += 64) {
         const size_t kk = (size_t)b * K + i;
-        ord[i] = order[kk]; lab[i] = sel_label[kk]; ar[i] = area[kk]; og[i] = orig[kk]; scs[i] = sel_score[kk];
+        lab[i] = sel_label[kk]; ar[i] = area[kk]; og[i] = orig[kk]; scs[i] = sel_score[kk];
+    }
+    __syncthreads();
+    // merge order: argsort(-total_scores), ties by index                                                    :489
+    for (int i = threadIdx.x; i < K; i += 64) {
+        const float s = scs[i];
+        int rank = 0;
+        for (int j = 0; j < K; ++j) {
+            const float t = scs[j];
+            rank += (t > s) || (t == s && j < i);
+        }
+        ord[rank] = i;
+        order[(size_t)b * K + rank] = i;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -499,7 +499,12 @@ int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const f
     if (hipMemsetAsync(area, 0, (size_t)B * K * 2 * sizeof(int), st) != hipSuccess) return VKN_E_LAUNCH;
     if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) return VKN_E_LAUNCH;
 
-    hipLaunchKernelGGL(k_pan_select, dim3(B), dim3(256), (size_t)(Np * T + nstuff + K) * 4, st, cls, N, ncls, Np, T, Kt, nstuff, sel_row, sel_label, sel_score, order);
+    {
+        int chunks = (Np * T + 2047) / 2048;  // ~8 candidates per thread
+        if (chunks < 1) chunks = 1;
+        hipLaunchKernelGGL(k_pan_select, dim3(chunks, B), dim3(256), (size_t)(Np * T + nstuff) * 4, st, cls, N, ncls, Np, T, Kt, nstuff,
+                           sel_row, sel_label, sel_score);
+    }
     VKN_CHECK_LAUNCH();
 
     PanGeom g{};
