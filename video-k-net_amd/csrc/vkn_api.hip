@@ -257,7 +257,7 @@ int run_link(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const 
 int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in, const float* masks_in,
               const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out, float* x_feat_out,
               float* track_out, const StageWs& s, unsigned flags, hipStream_t st, const unsigned* bits_in = nullptr,
-              unsigned* bits_out = nullptr) {
+              unsigned* bits_out = nullptr, bool cls_sigmoid = false) {
     // bits_in / bits_out (fused head only): the stage hand-off as bit words instead of fp32 logits — the gather consumes
     // nothing but bit(logit >= thr), so intermediate stages never write the 15.3 MB / frame of logits
     const int B = d->B, N = d->N, C = d->C, P = d->H * d->W, M = B * N;
@@ -339,6 +339,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         // fc_cls, and the decode kernels Kf = fc_mask(.) . W_ft in ONE GEMM from the composite weight          (:221, :227, :247)
         VknGemmProb pr[2];
         e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
+        if (cls_sigmoid) e.act = 2;  // fused head, last stage: the caller wants cls_score.sigmoid() (knet/det/kernel_iter_head.py:307-308)
         pr[0] = VknGemmProb{tc, nullptr, nullptr, nullptr, C, w->fc_cls_w, pw.fc_cls, d->ncls, e};
         e = mk_epi(d); e.bias = pw.decb; e.ldo = C;
         if (ref_decode) e.out = s.kern32;
@@ -352,6 +353,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         {
             VknGemmProb pr[2];
             e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
+            if (cls_sigmoid) e.act = 2;
             pr[0] = VknGemmProb{tc, nullptr, nullptr, nullptr, C, w->fc_cls_w, pw.fc_cls, d->ncls, e};
             e = mk_epi(d); e.bias = w->fc_mask_b; e.out = s.maskfeat; e.ldo = C;
             if (has_ft) { e.dot_vec = w->ft_b; e.dot_out = s.kb; }
@@ -748,12 +750,12 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
         const float* prev = (last && track_out) ? prev_obj : nullptr;   // knet/video/kernel_iter_head.py:544-546
         const unsigned* b_in = (use_bits && sidx > 0) ? bits[(sidx - 1) & 1] : nullptr;
         unsigned* b_out = (use_bits && !last) ? bits[sidx & 1] : nullptr;
-        VKN_TRY(run_stage(d, &stages[sidx], x, o_in, m_in, prev, ctmp, m_out, o_out, nullptr, prev ? track_out : nullptr, s,
-                          flags, st, b_in, b_out));
+        // the last stage's fc_cls epilogue applies the sigmoid and writes the caller's cls_prob directly
+        VKN_TRY(run_stage(d, &stages[sidx], x, o_in, m_in, prev, last ? cls_prob : ctmp, m_out, o_out, nullptr,
+                          prev ? track_out : nullptr, s, flags, st, b_in, b_out, last));
         m_in = m_out;
         o_in = o_out;
     }
-    VKN_TRY(vkn_launch_sigmoid(ctmp, cls_prob, d->B * d->N * d->ncls, st));               // knet/det/kernel_iter_head.py:307-308
     if (scaled_out && upsample_stride > 1)                                                // :122-130
         VKN_TRY(vkn_launch_upsample(mask_preds_out, scaled_out, d->B * d->N, d->H, d->W, upsample_stride, st));
     return VKN_OK;

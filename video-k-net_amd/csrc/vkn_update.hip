@@ -603,12 +603,6 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int l
     }
 }
 
-// out = sigmoid(in) elementwise (cls activation after the stage loop, knet/det/kernel_iter_head.py:307-308)
-__global__ __launch_bounds__(256) void k_sigmoid(const float* __restrict__ in, float* __restrict__ out, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = 1.0f / (1.0f + expf(-in[i]));
-}
-
 // Bilinear upsample by integer factor S, align_corners=False (F.interpolate(scale_factor=S, mode='bilinear')):
 // src = (dst + 0.5) / S - 0.5 clamped at 0; neighbours clamped at the border.
 // Write-bound (S*S outputs per input): one workgroup = one input row of one plane -> its S output rows; a thread owns 4
@@ -771,12 +765,6 @@ int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int
         default: return VKN_E_SHAPE;
     }
 #undef ATT_CASE
-    VKN_CHECK_LAUNCH();
-    return VKN_OK;
-}
-
-int vkn_launch_sigmoid(const float* in, float* out, int n, hipStream_t stream) {
-    hipLaunchKernelGGL(k_sigmoid, dim3((n + 255) / 256), dim3(256), 0, stream, in, out, n);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
