@@ -3,6 +3,7 @@
 #include "../../include/vkn.h"
 #include "vkn_common.h"
 #include "vkn_launch.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -96,6 +97,15 @@ size_t carve_prepared(const VknDims* d, const VknStageWeights* w, char* base, Pr
     return (c.off + 255) & ~(size_t)255;
 }
 
+// hidden splits of the fused FFN: enough workgroups to fill the chip, each with whole 256-wide hidden chunks; 0 = not applicable
+int ffn_hsplit(int M, int FF) {
+    if (FF % 256 != 0) return 0;
+    const int chunks = FF / 256, rt = (M + 31) / 32;
+    int hs = 1;
+    while (hs < chunks && rt * hs < 256 && chunks % (hs * 2) == 0) hs *= 2;
+    return hs;
+}
+
 int ffn_ksplit(int M, int K) {
     const int rt = (M + 31) / 32, ktiles = K / 32;
     int ks = 256 / (rt > 0 ? rt : 1);
@@ -124,7 +134,10 @@ size_t carve_stage(const VknDims* d, char* base, StageWs* s) {
     s->ao = c.take<float>(M * C);
     s->obj2 = c.take<float>(M * C);
     s->h = c.take<float>(M * FF);
-    s->partial = c.take<float>((size_t)ffn_ksplit((int)M, (int)FF) * M * C);
+    {
+        const size_t ks = (size_t)ffn_ksplit((int)M, (int)FF), hs = (size_t)ffn_hsplit((int)M, (int)FF);
+        s->partial = c.take<float>((ks > hs ? ks : hs) * M * C);
+    }
     s->t1 = c.take<float>(M * C);
     s->t2 = c.take<float>(M * C);
     s->maskfeat = c.take<float>(M * C);
@@ -171,6 +184,12 @@ int run_ffn(const VknDims* d, const StageWs& s, const float* in, const float* w1
             const float* w2, const void* w2s, const float* b2, const float* nw, const float* nb, float* out, hipStream_t st) {
     const int M = d->B * d->N, C = d->C, FF = d->ff;
     VknEpi e = mk_epi(d);
+    // both Linears in one kernel (hidden activations stay on chip) when the weights are pre-split and the shape allows it
+    const int hsplit = ffn_hsplit(M, FF);
+    if (w1s && w2s && C == 256 && hsplit > 0 && !(getenv("VKN_FFN_FUSED") && atoi(getenv("VKN_FFN_FUSED")) == 0)) {
+        e.bias = b2; e.resid = in; e.ldr = C; e.ln_w = nw; e.ln_b = nb; e.out = out; e.ldo = C;
+        return vkn_launch_ffn_fused(in, C, w1s, b1, w2s, M, C, FF, hsplit, s.partial, e, st);
+    }
     e.bias = b1; e.act = 1; e.out = s.h; e.ldo = FF;
     VKN_TRY(vkn_launch_gemm(in, nullptr, C, w1, w1s, M, C, FF, 1, nullptr, e, st));
     e = mk_epi(d);

@@ -74,6 +74,8 @@ size_t vkn_split_w3_bytes(int Nout, int K);
 int vkn_launch_add2(const float* a, const float* b, float* out, size_t n, hipStream_t st);
 int vkn_launch_init_finish(const float* init_w, const float* obj, const float* seg_w, float* out, int B, int Np, int N, int nth,
                            int C, hipStream_t st);
+int vkn_launch_ffn_fused(const float* X, int ldx, const void* W1s, const float* b1, const void* W2s, int M, int C, int FF, int HS,
+                         float* partial, const VknEpi& epi2, hipStream_t stream);
 int vkn_launch_transpose(const float* src, float* dst, int R, int Cc, hipStream_t st);  // dst[c][r] = src[r][c]
 int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream);
 int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig, const float* ug, const float* no_w,

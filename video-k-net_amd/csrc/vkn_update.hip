@@ -441,6 +441,182 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused FFN
+// partial[hs] = relu(X . W1[hidden range hs]^T + b1) . W2[:, hidden range hs]^T         (mmcv FFN, both Linears in one kernel)
+// The [M x 2048] hidden activations never leave the chip: workgroup (row tile, hidden split hs) walks its 256-wide hidden chunks;
+// per chunk it runs GEMM 1 (K = C, tile images of W1's column tile = the chunk) exactly like k_gemm_s3, turns the accumulators
+// into ReLU(. + b1) split to bf16x3 straight into an LDS image, and uses that image as the A operand of GEMM 2 (K = the chunk's 256
+// hidden units = 8 K-tiles of W2's images), accumulating the [32 x C] output over its chunks.  The hidden splits are summed in
+// fixed order by k_rowepi (+ b2, residual, LayerNorm).  Replaces two launches, the M x 2048 round trip through HBM and half of the
+// split-K partial traffic.  C == 256, FF % (256 * HS) == 0.
+#define FF_HLD 256  // bf16 per row of the hidden image.  No padding (LDS is full: 96 + 15 + 48 KB); instead the 16-byte chunk j of row
+                    // r lives at chunk j ^ (r & 31), so the 32 rows of a fragment read hit 32 different chunks
+#define FF_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt(0): this wave's LDS DMA has landed (a barrier does not imply it)
+__global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __restrict__ X, int ldx, const __bf16* __restrict__ W1p,
+                                                             const float* __restrict__ b1, const __bf16* __restrict__ W2p, int M,
+                                                             int C, int FF, int HS, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem_ff[];
+    __bf16* Wl = reinterpret_cast<__bf16*>(smem_ff);  // [2][GS_WTILE]
+    __bf16* Al = Wl + 2 * GS_WTILE;                   // [2][3][32][40]
+    __bf16* Hl = Al + 2 * GS_ATILE;                   // [3][32][FF_HLD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.y * GM_BM, hs = blockIdx.x;
+    const int kt1 = C >> 5;                    // K-tiles of GEMM 1
+    const int cps = (FF >> 8) / HS;            // hidden chunks of this split
+    const bool a_role = tid < 256;
+    const int ar = (tid >> 3) & 31, aq = tid & 7;
+    const size_t aoff = (size_t)min(m0 + ar, M - 1) * ldx + 4 * aq;
+    f32x4 ra;
+
+#define FF_DMA(SRC, BUF)                                                                                              \
+    do {                                                                                                              \
+        const char* gsrc_ = reinterpret_cast<const char*>(SRC) + (size_t)tid * 16;                                    \
+        char* ldst_ = reinterpret_cast<char*>(Wl + (size_t)(BUF) * GS_WTILE) + (size_t)wave * 1024;                   \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                                 \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_ + i * 8192),       \
+                                             (__attribute__((address_space(3))) void*)(ldst_ + i * 8192), 16, 0, 0);  \
+    } while (0)
+#define FF_ASTASH(BUF)                                                                                \
+    do {                                                                                              \
+        if (a_role) {                                                                                 \
+            bf16x4 h_, m_, l_;                                                                        \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
+                __bf16 hh_, mm_, ll_;                                                                 \
+                vkn_split_bf16x3(ra[e], hh_, mm_, ll_);                                               \
+                h_[e] = hh_;                                                                          \
+                m_[e] = mm_;                                                                          \
+                l_[e] = ll_;                                                                          \
+            }                                                                                         \
+            __bf16* d_ = Al + (size_t)(BUF) * GS_ATILE + ar * GS_LDR + 4 * aq;                        \
+            *reinterpret_cast<bf16x4*>(d_) = h_;                                                      \
+            *reinterpret_cast<bf16x4*>(d_ + GM_BM * GS_LDR) = m_;                                     \
+            *reinterpret_cast<bf16x4*>(d_ + 2 * GM_BM * GS_LDR) = l_;                                 \
+        }                                                                                             \
+    } while (0)
+#define FF_MFMA6(ACC, AH, AM, AL, BP)                                                                 \
+    do {                                                                                              \
+        const bf16x8 bh_ = *reinterpret_cast<const bf16x8*>(BP);                                      \
+        const bf16x8 bm_ = *reinterpret_cast<const bf16x8*>((BP) + 4 * 256 * 8);                      \
+        const bf16x8 bl_ = *reinterpret_cast<const bf16x8*>((BP) + 8 * 256 * 8);                      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, bl_, ACC, 0, 0, 0);                         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, bh_, ACC, 0, 0, 0);                         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, bm_, ACC, 0, 0, 0);                         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, bm_, ACC, 0, 0, 0);                         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, bh_, ACC, 0, 0, 0);                         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, bh_, ACC, 0, 0, 0);                         \
+    } while (0)
+
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+
+    for (int cc = 0; cc < cps; ++cc) {
+        const int c = hs * cps + cc;  // hidden chunk = column tile of W1 = K-tiles 8c .. 8c+7 of W2
+        // ---- GEMM 1: acc1 [32 x 256 hidden] = X tile . W1[chunk]^T
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+        const __bf16* w1t = W1p + (size_t)c * kt1 * GS_WTILE;
+        FF_DMA(w1t, 0);
+        ra = *reinterpret_cast<const f32x4*>(X + aoff);
+        FF_ASTASH(0);
+        __syncthreads();
+        for (int kt = 0; kt < kt1; ++kt) {
+            const int cur = kt & 1;
+            const bool more = (kt + 1 < kt1);
+            if (more) {
+                FF_DMA(w1t + (size_t)(kt + 1) * GS_WTILE, cur ^ 1);
+                ra = *reinterpret_cast<const f32x4*>(X + aoff + (size_t)(kt + 1) * 32);
+            }
+            {
+                const __bf16* Ab = Al + (size_t)cur * GS_ATILE;
+                const __bf16* Wb = Wl + (size_t)cur * GS_WTILE;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const __bf16* ap = Ab + li * GS_LDR + (ks << 4) + (g << 3);
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);
+                    const __bf16* bp = Wb + (((ks << 1) + g) * 256 + wave * 32 + li) * 8;
+                    FF_MFMA6(acc1, ah, am, al, bp);
+                }
+            }
+            if (more) FF_ASTASH(cur ^ 1);
+            __syncthreads();
+        }
+        // ---- hidden = ReLU(acc1 + b1) -> bf16x3 image [3][32 rows][256 k]; this wave owns hidden columns wave*32 + li
+        {
+            const float bias = b1[c * 256 + wave * 32 + li];
+            const int col = wave * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = fmaxf(acc1[r] + bias, 0.f);
+                __bf16 hh, mm, ll;
+                vkn_split_bf16x3(v, hh, mm, ll);
+                const int row = vkn_cd_row(r, lane);
+                __bf16* d = Hl + row * FF_HLD + ((((col >> 3) ^ row) & 31) << 3) + (col & 7);
+                d[0] = hh;
+                d[GM_BM * FF_HLD] = mm;
+                d[2 * GM_BM * FF_HLD] = ll;
+            }
+        }
+        // ---- GEMM 2: acc2 [32 x C] += hidden [32 x 256] . W2[:, chunk]^T   (the barrier below also publishes the hidden image)
+        const __bf16* w2t = W2p + (size_t)c * 8 * GS_WTILE;
+        FF_DMA(w2t, 0);
+        FF_VMCNT0();
+        __syncthreads();
+        for (int kt = 0; kt < 8; ++kt) {
+            const int cur = kt & 1;
+            const bool more = (kt + 1 < 8);
+            if (more) FF_DMA(w2t + (size_t)(kt + 1) * GS_WTILE, cur ^ 1);
+            {
+                const __bf16* Wb = Wl + (size_t)cur * GS_WTILE;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const __bf16* ap = Hl + li * FF_HLD + (((((kt << 2) + (ks << 1) + g) ^ li) & 31) << 3);
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * FF_HLD);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * FF_HLD);
+                    const __bf16* bp = Wb + (((ks << 1) + g) * 256 + wave * 32 + li) * 8;
+                    FF_MFMA6(acc2, ah, am, al, bp);
+                }
+            }
+            FF_VMCNT0();
+            __syncthreads();
+        }
+    }
+#undef FF_DMA
+#undef FF_ASTASH
+#undef FF_MFMA6
+#undef FF_VMCNT0
+
+    float* pz = partial + (size_t)hs * M * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + vkn_cd_row(r, lane), col = wave * 32 + li;
+        if (row < M && col < C) pz[(size_t)row * C + col] = acc2[r];
+    }
+}
+
+__global__ void k_rowepi(const float* __restrict__ partial, int ks, int M, int Nout, VknEpi epi);
+
+// out = LN(X + FFN(X)): k_ffn_fused + k_rowepi.  W1s / W2s: pre-split tile images of W1 [FF][C] and W2 [C][FF].
+int vkn_launch_ffn_fused(const float* X, int ldx, const void* W1s, const float* b1, const void* W2s, int M, int C, int FF, int HS,
+                         float* partial, const VknEpi& epi2, hipStream_t stream) {
+    if (C != 256 || FF % (256 * HS) != 0 || HS < 1 || (ldx % 4) != 0) return VKN_E_SHAPE;
+    const size_t lds = (size_t)(2 * GS_WTILE + 2 * GS_ATILE + 3 * GM_BM * FF_HLD) * sizeof(__bf16);
+    if (hipFuncSetAttribute((const void*)k_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VKN_E_LAUNCH;
+    hipLaunchKernelGGL(k_ffn_fused, dim3(HS, (M + GM_BM - 1) / GM_BM), dim3(GM_THREADS), lds, stream, X, ldx,
+                       static_cast<const __bf16*>(W1s), b1, static_cast<const __bf16*>(W2s), M, C, FF, HS, partial);
+    VKN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_rowepi, dim3((M + 3) / 4), dim3(256), 0, stream, partial, HS, M, C, epi2);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
 // Row epilogue after a split-K GEMM: sums `ks` partials [ks][M][Nout] and applies the epilogue.  One wave per row, Nout <= 256.
 __global__ __launch_bounds__(256) void k_rowepi(const float* __restrict__ partial, int ks, int M, int Nout, VknEpi epi) {
     const int lane = threadIdx.x & 63;
