@@ -48,6 +48,32 @@ __global__ __launch_bounds__(128) void kD(float* out) {
     }
 }
 
+// E: persistent grid — each block walks chunks of ROWS x 4 KB, block-strided
+template <int NT, int ROWS>
+__global__ __launch_bounds__(256) void kE(float* out, size_t nchunks) {
+    const f32x4 v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        f32x4* p = reinterpret_cast<f32x4*>(out) + c * ROWS * 256 + threadIdx.x;
+        for (int i = 0; i < ROWS; ++i) {
+            if (NT) __builtin_nontemporal_store(v, p + i * 256);
+            else p[i * 256] = v;
+        }
+    }
+}
+// F: persistent, each thread 4 consecutive float4 (64 B), wave writes 4 KB contiguous
+template <int NT>
+__global__ __launch_bounds__(256) void kF(float* out, size_t nchunks) {
+    const f32x4 v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        f32x4* p = reinterpret_cast<f32x4*>(out) + c * 4096 + threadIdx.x * 4;
+        for (int r = 0; r < 4; ++r)
+            for (int i = 0; i < 4; ++i) {
+                if (NT) __builtin_nontemporal_store(v, p + r * 1024 + i);
+                else p[r * 1024 + i] = v;
+            }
+    }
+}
+
 int main() {
     const size_t planes = 936, rows = 512, n = planes * rows * 1024;  // floats (1.96 GB)
     float* out;
@@ -73,6 +99,11 @@ int main() {
         run("B 64 rows plain", [&] { hipLaunchKernelGGL((kB<0, 64>), dim3(n / 65536), dim3(256), 0, 0, out); });
         run("C 2-D grid 16 rows plain", [&] { hipLaunchKernelGGL((kC<0, 16>), dim3(rows / 16, planes), dim3(256), 0, 0, out, (int)rows); });
         run("C 2-D grid 16 rows nt", [&] { hipLaunchKernelGGL((kC<1, 16>), dim3(rows / 16, planes), dim3(256), 0, 0, out, (int)rows); });
+        run("E persistent 2048 blocks 16 rows plain", [&] { hipLaunchKernelGGL((kE<0, 16>), dim3(2048), dim3(256), 0, 0, out, n / 16384); });
+        run("E persistent 2048 blocks 16 rows nt", [&] { hipLaunchKernelGGL((kE<1, 16>), dim3(2048), dim3(256), 0, 0, out, n / 16384); });
+        run("E persistent 1024 blocks 64 rows plain", [&] { hipLaunchKernelGGL((kE<0, 64>), dim3(1024), dim3(256), 0, 0, out, n / 65536); });
+        run("E persistent 4096 blocks 4 rows plain", [&] { hipLaunchKernelGGL((kE<0, 4>), dim3(4096), dim3(256), 0, 0, out, n / 4096); });
+        run("F persistent 64 B/thread plain", [&] { hipLaunchKernelGGL(kF<0>, dim3(2048), dim3(256), 0, 0, out, n / 16384); });
         run("D 32 B/thread 128 thr plain", [&] { hipLaunchKernelGGL(kD<0>, dim3(n / 16384), dim3(128), 0, 0, out); });
         run("D 32 B/thread 128 thr nt", [&] { hipLaunchKernelGGL(kD<1>, dim3(n / 16384), dim3(128), 0, 0, out); });
     }
