@@ -39,6 +39,8 @@ extern "C" {
 #define VKN_FLAG_REF_KERNELS 1u /* exact-fp32 FMA gather/decode kernels instead of the MFMA ones */
 #define VKN_FLAG_EXACT_GEMM 2u  /* exact-fp32 MFMA for the [N x C] GEMMs even when pre-split weights are supplied */
 #define VKN_FLAG_LOGITS_HANDOFF 4u /* vkn_head_forward_f32: keep fp32 logits between stages instead of bit words (A/B; same results) */
+#define VKN_FLAG_CLIP_LINK 8u      /* vkn_head_forward_f32: the B frames are CONSECUTIVE frames of one video: prev_obj is [1][N][C] (the
+                                      kernels of the frame before frame 0) and frame b > 0 links to this call's own frame b - 1 */
 
 #define VKN_MAX_FCS 4
 

@@ -734,3 +734,26 @@ def test_panoptic_selection_many_thing_classes(vkn):
     assert np.array_equal(info[:, 2], r['seg_of'].numpy()) and int(nseg[0]) == len(r['segments_info'])
     near = r['margin'].numpy() < 1e-6
     assert not ((seg[0].cpu().numpy() != r['panoptic_seg'].numpy()) & ~near).any()
+
+
+def test_clip_link_in_one_call(vkn):
+    """VKN_FLAG_CLIP_LINK: frame b links to frame b - 1 of the same call, frame 0 to the given previous kernels — identical to the
+    two-step path (head, then track_link on the shifted kernels)."""
+    _, case = load_golden('video_cfg')
+    head, (x, pf, mp, prev) = _build_head(vkn, case)
+    T, N, C = 5, case['N'], case['C']
+    xs = _rand((T, C, case['H'], case['W']), 931).to(DEV)
+    pfs = _rand((T, N, C), 932).to(DEV)
+    mps = _rand((T, N, case['H'], case['W']), 933, 4.0).to(DEV)
+    first = _rand((1, N, C), 934).to(DEV)
+    dims = head.mask_head[0].make_dims(T, N, case['H'], case['W'])
+    packs = [h.stage_pack(torch.device(DEV)) for h in head.mask_head]
+    a = vkn.ops.head_forward(dims, packs, xs, pfs, mps, None, case['up'], clip_first_prev=first)
+    b = vkn.ops.head_forward(dims, packs, xs, pfs, mps, None, case['up'])
+    prevs = torch.cat([first, b[0][:-1]], 0)
+    track = vkn.ops.track_link(dims, packs[-1], b[0], prevs)
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u, v)
+    assert torch.equal(a[4], track)
+    o = head.clip_forward(xs, pfs.reshape(T, N, C, 1, 1), mps, first_previous_obj_feats=first.reshape(1, N, C, 1, 1))
+    assert torch.equal(o[4].reshape(T, N, C), track) and torch.equal(o[2], b[2])

@@ -767,6 +767,8 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
         float* m_out = to_out ? mask_preds_out : mtmp;
         float* o_out = to_out ? obj_out : otmp;
         const float* prev = (last && track_out) ? prev_obj : nullptr;   // knet/video/kernel_iter_head.py:544-546
+        const bool clip = prev && (flags & VKN_FLAG_CLIP_LINK);
+        if (clip) prev = nullptr;  // the link needs this call's own kernels: it runs after the stage (below)
         const unsigned* b_in = (use_bits && sidx > 0) ? bits[(sidx - 1) & 1] : nullptr;
         unsigned* b_out = (use_bits && !last) ? bits[sidx & 1] : nullptr;
         // the last stage's fc_cls epilogue applies the sigmoid and writes the caller's cls_prob directly
@@ -774,6 +776,23 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
                           prev ? track_out : nullptr, s, flags, st, b_in, b_out, last));
         m_in = m_out;
         o_in = o_out;
+        if (clip) {
+            // clip mode: prev[0] = the caller's previous-frame kernels, prev[b] = this call's frame b - 1          
+            const size_t fr = (size_t)d->N * d->C;
+            float* pv = otmp;  // [B][N][C] scratch: the last stage wrote the caller's obj_out, otmp is free
+            if (hipMemcpyAsync(pv, prev_obj, fr * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return VKN_E_LAUNCH;
+            if (d->B > 1 && hipMemcpyAsync(pv + fr, obj_out, (size_t)(d->B - 1) * fr * sizeof(float), hipMemcpyDeviceToDevice, st) !=
+                                hipSuccess)
+                return VKN_E_LAUNCH;
+            PrepW pw{};
+            const VknStageWeights* w = &stages[sidx];
+            if (w->prepared && !(flags & VKN_FLAG_EXACT_GEMM)) {
+                PrepItem items[40];
+                if (carve_prepared(d, w, static_cast<char*>(const_cast<void*>(w->prepared)), &pw, items, nullptr) > w->prepared_bytes)
+                    return VKN_E_WORKSPACE;
+            }
+            VKN_TRY(run_link(d, w, pw, obj_out, pv, track_out, s, st));
+        }
     }
     if (scaled_out && upsample_stride > 1)                                                // :122-130
         VKN_TRY(vkn_launch_upsample(mask_preds_out, scaled_out, d->B * d->N, d->H, d->W, upsample_stride, st));

@@ -99,7 +99,7 @@ class KernelIterHead(BaseRoIHead):
                           h.num_mask_fcs, h.hard_mask_thr, h.with_ffn, h.feat_transform is None) for h in self.mask_head}) == 1)
 
     def _head_forward(self, x, proposal_feats, mask_preds, previous_obj_feats=None, want_track=False, flags=0,
-                      want_scaled=True):
+                      want_scaled=True, clip_first_prev=None):
         h0, hl = self.mask_head[0], self.mask_head[-1]
         for h in self.mask_head:
             h._check_inputs(x, proposal_feats, mask_preds, None)
@@ -111,7 +111,7 @@ class KernelIterHead(BaseRoIHead):
         prev = previous_obj_feats.reshape(B, N, C) if previous_obj_feats is not None else None
         obj, cls, masks, scaled, track = ops.head_forward(dims, packs, x, proposal_feats.reshape(B, N, C), mask_preds, prev,
                                                           hl.mask_upsample_stride, want_track=want_track, want_scaled=want_scaled,
-                                                          flags=flags)
+                                                          flags=flags, clip_first_prev=clip_first_prev)
         if not hl.loss_cls.use_sigmoid:
             raise NotImplementedError('softmax cls activation (reference :309-310): every shipped config uses sigmoid')
         obj = obj.reshape(B, N, C, K, K)
@@ -289,8 +289,13 @@ class VideoKernelIterHead(KernelIterHead):
         embedding does: track[t] = link(cur = obj[t], prev = obj[t-1]) with obj[-1] = `first_previous_obj_feats`
         (None = first frame of the video: the reference then uses object_feats as the tracking feature, :474-475).
         -> (object_feats [T,N,C,1,1], cls [T,N,ncls], mask_preds, scaled_mask_preds, object_feats_track [T,N,C,1,1])"""
-        obj, cls, masks, scaled, _ = self._head_forward(x, proposal_feats, mask_preds)
         last = self.mask_head[-1]
+        if first_previous_obj_feats is not None and getattr(last, 'previous', None) is not None:
+            # the whole clip, link included, in one C call (VKN_FLAG_CLIP_LINK)
+            obj, cls, masks, scaled, track = self._head_forward(x, proposal_feats, mask_preds, want_scaled=want_scaled,
+                                                                clip_first_prev=first_previous_obj_feats)
+            return obj, cls, masks, scaled, track
+        obj, cls, masks, scaled, _ = self._head_forward(x, proposal_feats, mask_preds)
         T, N = obj.shape[:2]
         C = last.in_channels
         cur = obj.reshape(T, N, C)

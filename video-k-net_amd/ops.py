@@ -265,7 +265,7 @@ def stage_forward(dims: VknDims, pack: StagePack, x, obj_in, masks_in, prev_obj=
 
 
 def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=None, upsample_stride=1, want_track=False,
-                 want_scaled=True, flags=0):
+                 want_scaled=True, flags=0, clip_first_prev=None):
     """The S-stage loop in one C call.  Returns (obj [B,N,C], cls_prob [B,N,ncls], mask_preds [B,N,H,W],
     scaled_mask_preds [B,N,H*s,W*s] | None, track [B,N,C] | None)."""
     x, pf, mp = _req(x, 'x'), _req(proposal_feats, 'proposal_feats'), _req(mask_preds, 'mask_preds')
@@ -283,7 +283,13 @@ def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=N
     if want_scaled and upsample_stride > 1:
         scaled = torch.empty((B, N, H * upsample_stride, W * upsample_stride), dtype=torch.float32, device=dev)
     track = None
-    if prev_obj is not None and want_track:
+    if clip_first_prev is not None:
+        # the B frames are consecutive frames of one video: frame b links to frame b - 1 of this call, frame 0 to `clip_first_prev`
+        # [1,N,C] (VKN_FLAG_CLIP_LINK) — the whole clip step is one C call
+        prev_obj = _req(clip_first_prev.reshape(1, N, C), 'clip_first_prev')
+        track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        flags |= 8
+    elif prev_obj is not None and want_track:
         prev_obj = _req(prev_obj, 'previous_obj_feats')
         track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
     else:
