@@ -192,7 +192,7 @@ def main():
         cur = torch.cat([o[0] for o in outs], 0) if NS > 1 else outs[0][0]
         # ... then the tracking link over the whole block: prev[b] = obj[b-1]; frame 0 takes the previous rank's last frame
         # (one small RCCL all_gather, 120 KB per rank — the only cross-rank traffic of the clip)
-        prev = vkn_dist.previous_kernels_for_block(cur, first_previous=first_prev)
+        prev = vkn_dist.previous_kernels_for_block(cur, first_previous=first_prev, all_nonempty=True)
         track = vkn.ops.track_link(dims, packs[-1], cur, prev)
         return outs, track
 

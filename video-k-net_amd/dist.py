@@ -14,11 +14,13 @@ def shard_bounds(num_frames: int, world: int, rank: int):
     return (num_frames * rank) // world, (num_frames * (rank + 1)) // world
 
 
-def previous_kernels_for_block(block_kernels: torch.Tensor, first_previous=None, group=None):
+def previous_kernels_for_block(block_kernels: torch.Tensor, first_previous=None, group=None, all_nonempty=False):
     """`block_kernels` [T_r, N, C] = final kernels of this rank's frames.  Returns prev [T_r, N, C] with
     prev[i] = kernels of the frame BEFORE frame i of the block: the previous rank's last frame for i = 0
     (rank 0: `first_previous` [1,N,C], or its own frame 0 when the clip starts the video), own frame i-1 otherwise.
-    One all_gather of [N, C] per rank; ranks with an empty block contribute zeros and are skipped by their successor."""
+    One all_gather of [N, C] per rank; ranks with an empty block contribute zeros and are skipped by their successor.
+    `all_nonempty=True` (every rank is known to own frames, e.g. an even split): the predecessor is simply rank - 1 and no
+    device -> host read of the has-frames flags is needed (keeps the step free of host synchronisation)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     T = block_kernels.shape[0]
@@ -30,10 +32,14 @@ def previous_kernels_for_block(block_kernels: torch.Tensor, first_previous=None,
         got = [torch.empty_like(payload) for _ in range(world)]
         dist.all_gather(got, payload, group=group)
         p0 = None
-        for r in range(rank - 1, -1, -1):            # nearest predecessor that owns at least one frame
-            if float(got[r][-1]) > 0:
-                p0 = got[r][:-1].reshape(1, N, C)
-                break
+        if all_nonempty:
+            if rank > 0:
+                p0 = got[rank - 1][:-1].reshape(1, N, C)
+        else:
+            for r in range(rank - 1, -1, -1):        # nearest predecessor that owns at least one frame
+                if float(got[r][-1]) > 0:
+                    p0 = got[r][:-1].reshape(1, N, C)
+                    break
     else:
         p0 = None
     if p0 is None:
