@@ -250,6 +250,8 @@ PAN_CASES = {
     'pan_ident': dict(B=2, N=15, Np=12, T=2, ncls=5, Hm=8, Wm=16, up=4, bis=(64, 128), img=(64, 128), ori=(64, 128), seed=32),
     # config kernel count, down-scaling last level, odd crop
     'pan_cfg': dict(B=1, N=117, Np=100, T=2, ncls=19, Hm=32, Wm=64, up=4, bis=(256, 512), img=(250, 499), ori=(125, 250), seed=33),
+    # VIP-Seg class layout: 58 thing classes (5800 (proposal, class) candidates for the top-k), 66 stuff kernels
+    'pan_vipseg': dict(B=1, N=166, Np=100, T=58, ncls=124, Hm=24, Wm=40, up=4, bis=(192, 320), img=(184, 320), ori=(184, 320), seed=35),
     # KITTI-like odd sizes, already-scaled logits (up = 1), crop only
     'pan_kitti': dict(B=1, N=117, Np=100, T=2, ncls=19, Hm=48, Wm=156, up=1, bis=(96, 312), img=(94, 311), ori=(94, 311), seed=34),
 }

@@ -428,7 +428,7 @@ def _pan_gpu(vkn, case):
     return seg.cpu().numpy(), info.cpu().numpy(), nseg.cpu().numpy()
 
 
-@pytest.mark.parametrize('name', ['pan_tiny', 'pan_ident', 'pan_cfg', 'pan_kitti'])
+@pytest.mark.parametrize('name', ['pan_tiny', 'pan_ident', 'pan_cfg', 'pan_kitti', 'pan_vipseg'])
 def test_panoptic_joint_vs_oracle_and_reference(vkn, name):
     """Integer artefacts of the post-head pipeline: selection (rows / labels / scores) and segment decisions bit-exact; the
     panoptic map bit-exact except where the reference's own arg-max is decided by < 1e-6 (fp32 resampling noise)."""

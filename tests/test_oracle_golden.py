@@ -99,7 +99,7 @@ def test_kernel_init_oracle_matches_reference_golden(name):
         assert maxabs(seg, g['seg_preds']) < 1e-5
 
 
-@pytest.mark.parametrize('name', ['pan_tiny', 'pan_ident', 'pan_cfg', 'pan_kitti'])
+@pytest.mark.parametrize('name', ['pan_tiny', 'pan_ident', 'pan_cfg', 'pan_kitti', 'pan_vipseg'])
 def test_panoptic_oracle_matches_reference_golden(name):
     """oracle.panoptic_joint == the reference's KernelIterHead.get_panoptic (merge_joint=True): the integer panoptic map and the
     segments_info list, bit for bit (same ATen ops on the same machine class)."""
