@@ -120,10 +120,65 @@ def t_assign():
     assert float((cost.cpu() - want).abs().max()) < 5e-5, ('assign', N, G, ncls, H, W)
 
 
+def t_kernel_init():
+    B, Np, C = int(rng.integers(1, 3)), int(rng.integers(1, 120)), int(rng.choice([32, 64, 256]))
+    H, W = int(rng.integers(1, 30)), int(rng.integers(2, 30))
+    nth = int(rng.integers(0, 4))
+    ncls = nth + int(rng.integers(1, 20))
+    sem_on = bool(rng.integers(0, 2))
+    loc = torch.randn(B, C, H, W)
+    sem = torch.randn(B, C, H, W) if sem_on else None
+    iw = torch.randn(Np, C, 1, 1) * 0.2
+    sw = torch.randn(ncls, C, 1, 1) * 0.2 if sem_on else None
+    sb = torch.randn(ncls) if sem_on else None
+    cat = sem_on and bool(rng.integers(0, 2))
+    d = lambda t: t.to(dev) if t is not None else None  # noqa: E731
+    prop, xf, masks, seg = vkn.ops.kernel_init(d(loc), d(sem), d(iw), d(sw), d(sb), nth, cat, True)
+    rp, rx, rm, rs = O.kernel_init(iw, loc, sem, sw, sb, nth, cat)
+    tag = ('kernel_init', B, Np, C, H, W, nth, ncls, sem_on, cat)
+    assert float((masks.cpu() - rm).abs().max()) < 1e-4, tag
+    if sem_on:
+        assert torch.equal(xf.cpu(), rx), tag
+    bits = (masks[:, :Np].cpu() >= vkn.ops.thr_logit(0.5)).double()
+    want = iw.reshape(1, Np, C).double() + torch.einsum('bnhw,bchw->bnc', bits, xf.cpu().double())
+    assert float((prop[:, :Np].cpu().double() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max())), tag
+
+
+def t_head_c256():
+    from test_host_logic import _cfg
+    N = int(rng.integers(2, 170))
+    B = int(rng.integers(1, 5))
+    H, W = int(rng.choice([4, 8, 12])), int(rng.choice([8, 16]))
+    video = bool(rng.integers(0, 2))
+    key = ('h256', video)
+    if key not in _heads:
+        h = vkn.build_head(_cfg(video, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=1, up=2, nprop=100))
+        h.init_weights()
+        _heads[key] = h.to(dev).eval()
+    head = _heads[key]
+    x, pf = torch.randn(B, 256, H, W, device=dev), torch.randn(B, N, 256, device=dev)
+    mp = torch.randn(B, N, H, W, device=dev) * 3
+    first = torch.randn(1, N, 256, device=dev)
+    dims = head.mask_head[0].make_dims(B, N, H, W)
+    packs = [h.stage_pack(torch.device(dev)) for h in head.mask_head]
+    kw = dict(clip_first_prev=first) if video else {}
+    a = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, **kw)                 # bf16x3 GEMMs, fused FFN, composite weights
+    e = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=2, **kw)        # exact-fp32 GEMMs, plain chain
+    tag = ('head256', video, B, N, H, W)
+    # one stage (no intermediate binarisation): the two GEMM paths must agree to fp32 rounding on every output
+    assert float((a[1] - e[1]).abs().max()) < 1e-5, tag                                                   # cls probabilities
+    assert float((a[0] - e[0]).abs().max()) < 1e-4 * max(1.0, float(e[0].abs().max())), tag              # kernels
+    assert float((a[2] - e[2]).abs().max()) < 1e-3 * max(1.0, float(e[2].abs().max()) / 50), tag          # mask logits
+    if video:
+        assert float((a[4] - e[4]).abs().max()) < 1e-4 * max(1.0, float(e[4].abs().max())), tag
+
+
+_heads = {}
 only = sys.argv[2:]
 with torch.no_grad():
     for name, fn in (('gather / decode', t_gather_decode), ('upsample', t_upsample), ('panoptic joint', t_panoptic),
-                     ('head bit vs logits hand-off', t_head_handoff), ('assignment costs', t_assign)):
+                     ('head bit vs logits hand-off', t_head_handoff), ('assignment costs', t_assign),
+                     ('kernel init', t_kernel_init), ('head C=256 split vs exact GEMMs', t_head_c256)):
         if not only or any(o in name for o in only):
             section(name, fn)
 print('soak: OK')
