@@ -25,15 +25,13 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 CFG2 = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
 def build_head(vkn, device, seed=0):
-    from test_host_logic import _cfg
-    head = vkn.build_head(_cfg(True, C=CFG2['C'], heads=CFG2['heads'], ffn=CFG2['ffn'], ncls=CFG2['ncls'],
+    head = vkn.build_head(vkn.configs.roi_head_cfg(True, C=CFG2['C'], heads=CFG2['heads'], ffn=CFG2['ffn'], ncls=CFG2['ncls'],
                                n_thing=CFG2['n_thing'], n_stuff=CFG2['n_stuff'], S=CFG2['S'], up=CFG2['up'],
                                nprop=CFG2['nprop']))
     torch.manual_seed(seed)

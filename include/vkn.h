@@ -39,6 +39,8 @@ extern "C" {
 #define VKN_FLAG_REF_KERNELS 1u /* exact-fp32 FMA gather/decode kernels instead of the MFMA ones */
 #define VKN_FLAG_EXACT_GEMM 2u  /* exact-fp32 MFMA for the [N x C] GEMMs even when pre-split weights are supplied */
 #define VKN_FLAG_LOGITS_HANDOFF 4u /* vkn_head_forward_f32: keep fp32 logits between stages instead of bit words (A/B; same results) */
+#define VKN_FLAG_BITS_HANDOFF 16u  /* vkn_head_forward_f32: stage hand-off as bit words through two kernels (decode-bits, gather-bits)
+                                      instead of the fused decode -> gather pass over x (A/B; same results) */
 #define VKN_FLAG_CLIP_LINK 8u      /* vkn_head_forward_f32: the B frames are CONSECUTIVE frames of one video: prev_obj is [1][N][C] (the
                                       kernels of the frame before frame 0) and frame b > 0 links to this call's own frame b - 1 */
 
@@ -120,6 +122,17 @@ int vkn_split_planes_f32(const float* kernels, void* kf_hi, void* kf_lo, int B, 
 int vkn_mask_decode_planes_f32(const float* x, const void* kf_hi, const void* kf_lo, const float* bias, float* out, int B,
                                int N, int C, int P, void* stream);
 
+/* ---- ops (iii) of stage s and (i) of stage s + 1 as ONE pass over x (k_fused_dg, csrc/vkn_fused.hip): the decode
+ *      `F.conv2d(mask_x[i:i+1], mask_feat[i])` knet/det/kernel_update_head.py:247-260, the next stage's binarisation
+ *      `sigmoid(mask_preds) > hard_mask_thr` :190-192 and its gather `einsum('bnhw,bchw->bnc')` :195.
+ *          xraw[b][n][c] = sum_p [ bias[b][n] + sum_c' K[b][n][c'] x[b][c'][p]  >=  thr_logit ] * x[b][c][p],  cnt = the ON count
+ *      kf_hi / kf_lo: pre-split kernels as for vkn_mask_decode_planes_f32.  Results are bit-identical to
+ *      vkn_mask_decode_planes_f32 followed by vkn_mask_gather_f32.  Needs P % 64 == 0 and C in {64, 128, 256}
+ *      (vkn_decode_gather_supported), else VKN_E_SHAPE.  ws: vkn_gather_workspace_bytes. */
+int vkn_decode_gather_supported(int C, int P);
+int vkn_decode_gather_f32(const float* x, const void* kf_hi, const void* kf_lo, const float* bias, float thr_logit,
+                          float* xraw_out, float* cnt_out, int B, int N, int C, int P, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- `F.interpolate(mask_preds, scale_factor=S, mode='bilinear', align_corners=False)`
  *      knet/det/kernel_iter_head.py:122-130.  in [planes][H][W] -> out [planes][H*S][W*S]. */
 int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, int W, int S, void* stream);
@@ -169,9 +182,10 @@ int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* 
  *      prev_obj is given to the LAST stage only (video :544-546).
  *      out: obj_out [B][N][C], cls_prob [B][N][ncls] (sigmoid applied), mask_preds_out [B][N][P],
  *           scaled_out [B][N][H*up][W*up] or NULL (skipped), track_out [B][N][C] or NULL.
- *      Between stages only the binarised masks are handed over (bit words, 1/32 of the logits' bytes) when H*W % 64 == 0:
- *      the next stage's gather reads nothing else, so every output is bit-identical to the logits hand-off
- *      (VKN_FLAG_LOGITS_HANDOFF keeps the latter for A/B); intermediate stages' logits are not materialised. */
+ *      Stage hand-off when H*W % 64 == 0 (and C in {64, 128, 256}): stage s's mask decode and stage s+1's mask gather run as ONE
+ *      pass over x (k_fused_dg) — the next gather reads nothing but bit(logit >= thr), so intermediate logits are never
+ *      materialised and every output is bit-identical to the other two paths kept for A/B: VKN_FLAG_BITS_HANDOFF (two kernels,
+ *      bit words of 1/32 of the logits' bytes in between) and VKN_FLAG_LOGITS_HANDOFF (fp32 logits in between). */
 size_t vkn_head_workspace_bytes(const VknDims* d);
 int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const float* x,
                          const float* proposal_feats, const float* mask_preds_in, const float* prev_obj, float* obj_out,

@@ -34,6 +34,8 @@ SHAPES = [  # B, N, C, H, W
     (1, 117, 256, 64, 128),  # BASELINE cfg1 size
     (1, 166, 256, 23, 40),   # VIP-Seg kernel count: two n-chunks (128 + 64 rows), P % 32 != 0
     (3, 100, 32, 4, 8),      # one channel block, one pixel tile
+    (2, 40, 64, 16, 16),     # P % 128 == 0, C % 64 == 0: the 16-byte decode kernel (k_decode4), two n-blocks
+    (1, 166, 128, 8, 32),    # k_decode4 / fused pass with two n-chunks (128 + 64 rows), C = 128
 ]
 
 
@@ -93,6 +95,25 @@ def test_decode_planes_entry_matches(vkn):
     hi, lo = vkn.ops.split_planes(k)
     assert maxabs(hi.float() + lo.float(), torch.cat([k, torch.zeros(B, 128 - N, C, device=DEV)], 1)) < 2e-6
     assert torch.equal(vkn.ops.mask_decode_planes(x, hi, lo, N), vkn.ops.mask_decode(x, k))
+
+
+@pytest.mark.parametrize('shape', [(2, 40, 64, 16, 16), (1, 166, 128, 8, 32), (2, 117, 256, 16, 32), (3, 117, 256, 24, 40)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_fused_decode_gather_is_decode_then_gather(vkn, shape):
+    """k_fused_dg (stage s decode + stage s+1 gather in one pass over x) == k_decode* followed by k_gather*, BIT for bit:
+    same per-element MFMA sequence for the logits, same tile order / partial sums / fixed-order reduce for the gather."""
+    B, N, C, H, W = shape
+    x, k, bias = _rand((B, C, H, W), 221).to(DEV), _rand((B, N, C), 222, 0.25).to(DEV), _rand((B, N), 223).to(DEV)
+    hi, lo = vkn.ops.split_planes(k)
+    logits = vkn.ops.mask_decode_planes(x, hi, lo, N, bias)
+    xr_ref, cnt_ref = vkn.ops.mask_gather(x, logits)
+    xr, cnt = vkn.ops.decode_gather(x, hi, lo, N, bias)
+    assert torch.equal(cnt, cnt_ref) and torch.equal(xr, xr_ref)
+    assert 0.05 < float((cnt > 0).float().mean())  # not a vacuous case
+    # and against fp64 on the device
+    M = (logits >= vkn.ops.thr_logit(0.5)).double()
+    ref = torch.bmm(M.reshape(B, N, -1), x.double().reshape(B, C, -1).transpose(1, 2))
+    assert maxabs(xr, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize('scale', [2, 4])
@@ -577,11 +598,12 @@ def test_bit_packed_stage_handoff_is_exact(vkn, name):
     dims = head.mask_head[0].make_dims(B, N, case['H'], case['W'])
     packs = [h.stage_pack(torch.device(DEV)) for h in head.mask_head]
     dx, dpf, dmp = _cuda(x, pf.reshape(B, N, C), mp)
-    a = vkn.ops.head_forward(dims, packs, dx, dpf, dmp, None, case['up'], flags=0)
-    b = vkn.ops.head_forward(dims, packs, dx, dpf, dmp, None, case['up'], flags=4)
+    a = vkn.ops.head_forward(dims, packs, dx, dpf, dmp, None, case['up'], flags=0)     # fused decode -> gather pass (C in {64,128,256})
+    b = vkn.ops.head_forward(dims, packs, dx, dpf, dmp, None, case['up'], flags=4)     # fp32 logits hand-off
+    c = vkn.ops.head_forward(dims, packs, dx, dpf, dmp, None, case['up'], flags=16)    # bit words through two kernels
     torch.cuda.synchronize()
-    for u, v in zip(a[:4], b[:4]):
-        assert torch.equal(u, v)
+    for u, v, w in zip(a[:4], b[:4], c[:4]):
+        assert torch.equal(u, v) and torch.equal(u, w)
     assert maxabs(a[2], g['mask_preds']) < TOL_LOGIT
 
 
@@ -607,8 +629,9 @@ def test_head_vipseg_kernel_count_vs_oracle(vkn, hw):
     packs = [h.stage_pack(torch.device(DEV)) for h in head.mask_head]
     a = vkn.ops.head_forward(dims, packs, *_cuda(x, pf.reshape(2, 166, 64), mp), None, 2, flags=0)
     b = vkn.ops.head_forward(dims, packs, *_cuda(x, pf.reshape(2, 166, 64), mp), None, 2, flags=4)
-    for u, v in zip(a[:4], b[:4]):
-        assert torch.equal(u, v)
+    c = vkn.ops.head_forward(dims, packs, *_cuda(x, pf.reshape(2, 166, 64), mp), None, 2, flags=16)
+    for u, v, w in zip(a[:4], b[:4], c[:4]):
+        assert torch.equal(u, v) and torch.equal(u, w)
     # teacher-forced last stage: feed the oracle's stage-0 outputs to the GPU stage 1 -> tight
     t0 = traces[0]
     cls1, m1, o1, _, _ = vkn.ops.stage_forward(dims, packs[1], x.to(DEV), t0['obj_feat'].reshape(2, 166, 64).to(DEV),

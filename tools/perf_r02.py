@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Round-2 kernel A/B on one MI355X (debug library: reads VKN_* knobs).  Prints one line per measurement.
+
+    python tools/perf_r02.py [--frames 8,32] [--what decode,fused,head,upsample]
+
+decode:   k_decode_mfma (8-byte accesses, VKN_DECODE4=0) vs k_decode4 (16-byte accesses), logits output, cfg2 shape
+fused:    stages' hand-off through the fused decode->gather pass vs bit words (flag 16) vs logits (flag 4): whole head, no upsample
+head:     whole bench step (S = 3 + link + x4 upsample) at B = 1 / 8 / 32
+upsample: x4 bilinear upsample alone
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timeit(fn, reps=20, warm=5):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3   # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frames', default='8,32')
+    ap.add_argument('--what', default='decode,fused,head,upsample')
+    ap.add_argument('--release', action='store_true', help='use the release library (no env knobs)')
+    args = ap.parse_args()
+    import vkn_import
+    vkn = vkn_import.load()
+    if not args.release:
+        vkn._lib.build_debug()
+        vkn._lib.use_debug()
+    import bench
+    dev = torch.device('cuda', 0)
+    what = args.what.split(',')
+    N, C, H, W = 117, 256, 128, 256
+    P = H * W
+    head = bench.build_head(vkn, dev)
+    for B in [int(v) for v in args.frames.split(',')]:
+        x, pf, mp = bench.synth_inputs(B, dev, 0)
+        alg = B * P * (C + N) * 4
+        if 'decode' in what:
+            kern = torch.randn(B, N, C, device=dev)
+            hi, lo = vkn.ops.split_planes(kern)
+            kb = torch.randn(B, N, device=dev)
+            out = torch.empty(B, N, H, W, device=dev)
+            res = {}
+            os.environ['VKN_DECODE4'] = '0'
+            for opt in (0, 1, 2, 4, 5, 7, 0):
+                os.environ['VKN_DECODE_OPT'] = str(opt)
+                t = timeit(lambda: vkn.ops.mask_decode_planes(x, hi, lo, N, kb, out), reps=40)
+                res[opt] = out.clone()
+                print(f'decode B={B} k_decode_mfma OPT={opt}: {t:8.1f} us  {alg / t / 1e6:7.3f} TB/s  frac {alg / t / 1e6 / 8:.3f}'
+                      f'  bit-identical to OPT=0: {torch.equal(res[0], res[opt])}', flush=True)
+            os.environ['VKN_DECODE_OPT'] = '0'
+            os.environ['VKN_DECODE4'] = '1'
+            t = timeit(lambda: vkn.ops.mask_decode_planes(x, hi, lo, N, kb, out), reps=40)
+            print(f'decode B={B} k_decode4: {t:8.1f} us  {alg / t / 1e6:7.3f} TB/s  bit-identical: {torch.equal(res[0], out)}', flush=True)
+            os.environ['VKN_DECODE4'] = '0'
+            # the fused decode -> gather pass alone: one-wave-per-SIMD (VKN_FUSED8=0) vs two (1); bytes = x only
+            xb = B * P * C * 4
+            ref = None
+            for f8 in ('0', '1'):
+                os.environ['VKN_FUSED8'] = f8
+                t = timeit(lambda: vkn.ops.decode_gather(x, hi, lo, N, kb), reps=20)
+                r = vkn.ops.decode_gather(x, hi, lo, N, kb)
+                same = True if ref is None else (torch.equal(r[0], ref[0]) and torch.equal(r[1], ref[1]))
+                ref = r if ref is None else ref
+                print(f'fused decode->gather B={B} eight_waves={f8}: {t:8.1f} us  {xb / t / 1e6:7.3f} TB/s of x  same: {same}', flush=True)
+            os.environ['VKN_FUSED8'] = '1'
+            t = timeit(lambda: vkn.ops.mask_gather(x, mp), reps=30)
+            print(f'gather(logits)+reduce B={B}: {t:8.1f} us  {alg / t / 1e6:7.3f} TB/s', flush=True)
+            del out, res
+        last = head.mask_head[-1]
+        dims = last.make_dims(B, N, H, W)
+        packs = [h.stage_pack(dev) for h in head.mask_head]
+        pfr = pf.reshape(B, N, C)
+        if 'fused' in what:
+            outs = {}
+            for name, fl in (('fused', 0), ('bits', 16), ('logits', 4)):
+                t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, flags=fl), reps=10, warm=3)
+                outs[name] = vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, flags=fl)
+                print(f'head(no upsample, no link) B={B} handoff={name}: {t:8.1f} us  {B / t * 1e6:9.1f} frames/s', flush=True)
+            same = all(torch.equal(a, b) for a, b in zip(outs['fused'][:3], outs['bits'][:3]))
+            same2 = all(torch.equal(a, b) for a, b in zip(outs['fused'][:3], outs['logits'][:3]))
+            print(f'head B={B}: fused == bits: {same}; fused == logits: {same2}', flush=True)
+            del outs
+        if 'head' in what:
+            fp = torch.zeros(1, N, C, device=dev)
+            t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 4, clip_first_prev=fp), reps=10, warm=3)
+            print(f'bench step (S=3 + link + x4) B={B}: {t:8.1f} us  {B / t * 1e6:9.1f} frames/s', flush=True)
+            t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
+            print(f'bench step without x4 upsample B={B}: {t:8.1f} us  {B / t * 1e6:9.1f} frames/s', flush=True)
+        if 'upsample' in what:
+            m = torch.randn(B, N, H, W, device=dev)
+            t = timeit(lambda: vkn.ops.upsample_bilinear(m, 4), reps=10, warm=3)
+            wb = B * N * P * 16 * 4
+            print(f'upsample x4 B={B}: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s of writes', flush=True)
+            if not args.release:
+                for mode in (24, 11):
+                    os.environ['VKN_UPSAMPLE'] = str(mode)
+                    t = timeit(lambda: vkn.ops.upsample_bilinear(m, 4), reps=10, warm=3)
+                    print(f'upsample x4 B={B} mode={mode}: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s of writes', flush=True)
+                os.environ.pop('VKN_UPSAMPLE')
+            o = torch.empty(B, N, H * 4, W * 4, device=dev)
+            t = timeit(lambda: o.fill_(1.0), reps=10, warm=3)
+            print(f'torch fill_ of the same bytes B={B}: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s', flush=True)
+            del o, m
+        del x, pf, mp
+        torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    main()

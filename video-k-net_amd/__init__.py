@@ -5,7 +5,7 @@ Importing this package registers `KernelUpdator` (TRANSFORMER_LAYER) and `Kernel
 ones — so the reference's config dicts build these classes unchanged.  All arithmetic runs in
 `lib/libvkn.so` (hand-written HIP for gfx950, C ABI in include/vkn.h); there is no CPU fallback.
 """
-from . import _lib, ops, registry  # noqa: F401
+from . import _lib, configs, ops, registry  # noqa: F401
 from ._lib import VknError, VknLibraryError, build  # noqa: F401
 from .kernel_updator import KernelUpdator  # noqa: F401
 from .kernel_update_head import KernelUpdateHead, VideoKernelUpdateHead  # noqa: F401

@@ -11,12 +11,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
-SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_assign.hip', 'vkn_api.hip')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_assign.hip', 'vkn_api.hip')
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares
 SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_weights', 'vkn_gather_workspace_bytes', 'vkn_mask_gather_f32',
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
+           'vkn_decode_gather_supported', 'vkn_decode_gather_f32',
            'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
            'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32',
            'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32',
@@ -84,10 +85,14 @@ def hipcc_command(out=LIBPATH, extra=()):
             *[os.path.join(CSRC, s) for s in SOURCES], '-o', out]
 
 
-def _stale():
-    if not os.path.exists(LIBPATH):
+DEBUG_LIBPATH = os.path.join(LIBDIR, 'libvkn_debug.so')
+
+
+def _stale(path=None):
+    path = path or LIBPATH
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIBPATH)
+    t = os.path.getmtime(path)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), 'include', 'vkn.h')]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
@@ -106,7 +111,28 @@ def build(force=False, verbose=False):
     return LIBPATH
 
 
+def build_debug(force=False):
+    """The same sources with -DVKN_DEBUG -> lib/libvkn_debug.so: the ONLY build that reads VKN_* environment knobs and contains
+    the time-attribution kernel variants (tools/ only; never loaded by the package unless `use_debug()` is called first)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not force and not _stale(DEBUG_LIBPATH):
+        return DEBUG_LIBPATH
+    r = subprocess.run(hipcc_command(out=DEBUG_LIBPATH, extra=('-DVKN_DEBUG',)), capture_output=True, text=True)
+    if r.returncode != 0:
+        raise VknLibraryError('hipcc failed:\n' + r.stdout + r.stderr)
+    return DEBUG_LIBPATH
+
+
 _LIB = None
+_USE_DEBUG = False
+
+
+def use_debug():
+    """Measurement tools: load lib/libvkn_debug.so instead of the release library (must be called before the first op)."""
+    global _USE_DEBUG
+    if _LIB is not None:
+        raise VknLibraryError('use_debug() must be called before the library is first used')
+    _USE_DEBUG = True
 
 
 def lib():
@@ -114,10 +140,11 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIBPATH):
-        raise VknLibraryError(f'{LIBPATH} is missing — run `python -c "import __graft_entry__ as g; g.build()"` '
+    path = DEBUG_LIBPATH if _USE_DEBUG else LIBPATH
+    if not os.path.exists(path):
+        raise VknLibraryError(f'{path} is missing — run `python -c "import __graft_entry__ as g; g.build()"` '
                               '(there is deliberately no CPU fallback)')
-    L = ctypes.CDLL(LIBPATH)
+    L = ctypes.CDLL(path)
     c_int, c_size, c_uint, c_float = ctypes.c_int, ctypes.c_size_t, ctypes.c_uint, ctypes.c_float
     pD, pW = ctypes.POINTER(VknDims), ctypes.POINTER(VknStageWeights)
     L.vkn_version.restype = c_int
@@ -142,6 +169,10 @@ def lib():
     L.vkn_split_planes_f32.argtypes = [_fp, _fp, _fp, c_int, c_int, c_int, _fp]
     L.vkn_mask_decode_planes_f32.restype = c_int
     L.vkn_mask_decode_planes_f32.argtypes = [_fp, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp]
+    L.vkn_decode_gather_supported.restype = c_int
+    L.vkn_decode_gather_supported.argtypes = [c_int, c_int]
+    L.vkn_decode_gather_f32.restype = c_int
+    L.vkn_decode_gather_f32.argtypes = [_fp, _fp, _fp, _fp, c_float, _fp, _fp, c_int, c_int, c_int, c_int, _fp, c_size, _fp]
     L.vkn_track_link_f32.restype = c_int
     L.vkn_track_link_f32.argtypes = [pD, pW, _fp, _fp, _fp, _fp, c_size, _fp]
     L.vkn_upsample_bilinear_f32.restype = c_int

@@ -3,7 +3,6 @@
 #include "../../include/vkn.h"
 #include "vkn_common.h"
 #include "vkn_launch.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -186,7 +185,7 @@ int run_ffn(const VknDims* d, const StageWs& s, const float* in, const float* w1
     VknEpi e = mk_epi(d);
     // both Linears in one kernel (hidden activations stay on chip) when the weights are pre-split and the shape allows it
     const int hsplit = ffn_hsplit(M, FF);
-    if (w1s && w2s && C == 256 && hsplit > 0 && !(getenv("VKN_FFN_FUSED") && atoi(getenv("VKN_FFN_FUSED")) == 0)) {
+    if (w1s && w2s && C == 256 && hsplit > 0 && vkn_dbg_env("VKN_FFN_FUSED", 1) != 0) {
         e.bias = b2; e.resid = in; e.ldr = C; e.ln_w = nw; e.ln_b = nb; e.out = out; e.ldo = C;
         return vkn_launch_ffn_fused(in, C, w1s, b1, w2s, M, C, FF, hsplit, s.partial, e, st);
     }
@@ -276,9 +275,12 @@ int run_link(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const 
 int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in, const float* masks_in,
               const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out, float* x_feat_out,
               float* track_out, const StageWs& s, unsigned flags, hipStream_t st, const unsigned* bits_in = nullptr,
-              unsigned* bits_out = nullptr, bool cls_sigmoid = false) {
+              unsigned* bits_out = nullptr, bool cls_sigmoid = false, bool gathered_in = false, bool gather_out = false) {
     // bits_in / bits_out (fused head only): the stage hand-off as bit words instead of fp32 logits — the gather consumes
-    // nothing but bit(logit >= thr), so intermediate stages never write the 15.3 MB / frame of logits
+    // nothing but bit(logit >= thr), so intermediate stages never write the 15.3 MB / frame of logits.
+    // gather_out / gathered_in (fused head, default): the hand-off is the NEXT stage's gather itself — this stage's decode and the
+    // next stage's gather run as one pass over x (vkn_fused.hip) that leaves xraw / cnt in the shared workspace, where the next
+    // stage (gathered_in) finds them; neither logits nor bit words exist.
     const int B = d->B, N = d->N, C = d->C, P = d->H * d->W, M = B * N;
     const bool ref = (flags & VKN_FLAG_REF_KERNELS) != 0;
     const bool ref_decode = ref || (P & 1);  // odd H*W: mask rows are not 8-byte aligned -> exact-fp32 FMA decode kernel
@@ -291,7 +293,9 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     }
 
     // (i) mask gather                                        knet/det/kernel_update_head.py:190-195
-    if (ref)
+    if (gathered_in) {
+        // s.xraw / s.cnt were produced by the previous stage's fused decode -> gather pass
+    } else if (ref)
         VKN_TRY(vkn_launch_gather_ref(x, masks_in, d->thr_logit, s.xraw, s.cnt, B, N, C, P, st));
     else if (bits_in)
         VKN_TRY(vkn_launch_gather_bits(x, bits_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
@@ -366,6 +370,8 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         pr[1] = VknGemmProb{tm, nullptr, nullptr, nullptr, C, pw.dec32, pw.dec, C, e};
         VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
         if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
+        else if (gather_out)
+            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
         else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st));
         else VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
     } else {
@@ -395,7 +401,10 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             } else {
                 VKN_TRY(vkn_launch_split_planes(s.maskfeat, s.kfh, s.kfl, B, N, C, st));
             }
-            if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st));
+            if (gather_out)
+                VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P,
+                                                       st));
+            else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st));
             else VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
         }
     }
@@ -510,6 +519,22 @@ int vkn_mask_decode_planes_f32(const float* x, const void* kf_hi, const void* kf
     if (C % 32 != 0 || C > 256 || N > 256) return VKN_E_SHAPE;
     return vkn_launch_decode(x, static_cast<const _Float16*>(kf_hi), static_cast<const _Float16*>(kf_lo), bias, out, B, N, C,
                              P, static_cast<hipStream_t>(stream));
+}
+
+int vkn_decode_gather_supported(int C, int P) { return vkn_fused_supported(C, P); }
+
+int vkn_decode_gather_f32(const float* x, const void* kf_hi, const void* kf_lo, const float* bias, float thr_logit,
+                          float* xraw_out, float* cnt_out, int B, int N, int C, int P, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !kf_hi || !kf_lo || !xraw_out || !cnt_out || B <= 0 || N <= 0 || C <= 0 || P <= 0) return VKN_E_ARG;
+    if (!aligned16(x) || !aligned16(kf_hi) || !aligned16(kf_lo) || !aligned16(xraw_out)) return VKN_E_ALIGN;
+    if (N > 256 || !vkn_fused_supported(C, P)) return VKN_E_SHAPE;
+    if (!ws || ws_bytes < vkn_gather_workspace_bytes(B, N, C, P)) return VKN_E_WORKSPACE;
+    const size_t G = vkn_gather_groups(B, P), NPT = npt_of(N);
+    Carver c{static_cast<char*>(ws), 0};
+    float* part = c.take<float>((size_t)B * G * NPT * C);
+    float* cntp = c.take<float>((size_t)B * G * NPT);
+    return vkn_launch_fused_decode_gather(x, static_cast<const _Float16*>(kf_hi), static_cast<const _Float16*>(kf_lo), bias,
+                                          thr_logit, xraw_out, cnt_out, part, cntp, B, N, C, P, static_cast<hipStream_t>(stream));
 }
 
 int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* cur_obj, const float* prev_obj,
@@ -757,6 +782,9 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
     // stage s -> s+1 hand-off as bit words (the only thing the next gather reads) unless the exact-fp32 kernels are asked for,
     // the spatial size is not a multiple of the 64-px decode tile, or the caller wants the logits path (A/B)
     const bool use_bits = !(flags & (VKN_FLAG_REF_KERNELS | VKN_FLAG_LOGITS_HANDOFF)) && ((d->H * d->W) % 64) == 0;
+    // ... and by default not even those: decode(s) and gather(s + 1) are ONE pass over x (vkn_fused.hip); VKN_FLAG_BITS_HANDOFF
+    // keeps the two-kernel bit-word path (A/B; bit-identical results)
+    const bool use_fused = use_bits && !(flags & VKN_FLAG_BITS_HANDOFF) && vkn_fused_supported(d->C, d->H * d->W);
 
     const float* m_in = mask_preds_in;
     const float* o_in = proposal_feats;
@@ -769,11 +797,11 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
         const float* prev = (last && track_out) ? prev_obj : nullptr;   // knet/video/kernel_iter_head.py:544-546
         const bool clip = prev && (flags & VKN_FLAG_CLIP_LINK);
         if (clip) prev = nullptr;  // the link needs this call's own kernels: it runs after the stage (below)
-        const unsigned* b_in = (use_bits && sidx > 0) ? bits[(sidx - 1) & 1] : nullptr;
-        unsigned* b_out = (use_bits && !last) ? bits[sidx & 1] : nullptr;
+        const unsigned* b_in = (use_bits && !use_fused && sidx > 0) ? bits[(sidx - 1) & 1] : nullptr;
+        unsigned* b_out = (use_bits && !use_fused && !last) ? bits[sidx & 1] : nullptr;
         // the last stage's fc_cls epilogue applies the sigmoid and writes the caller's cls_prob directly
         VKN_TRY(run_stage(d, &stages[sidx], x, o_in, m_in, prev, last ? cls_prob : ctmp, m_out, o_out, nullptr,
-                          prev ? track_out : nullptr, s, flags, st, b_in, b_out, last));
+                          prev ? track_out : nullptr, s, flags, st, b_in, b_out, last, use_fused && sidx > 0, use_fused && !last));
         m_in = m_out;
         o_in = o_out;
         if (clip) {

@@ -7,11 +7,15 @@
 //                + w_mask * MaskCost  = -(sum_p p2 g + sum_p (1 - p2)(1 - g)) / (H W),                p2 = clamp(sigmoid z, 1e-2, 1)   (:87-113)
 // then scipy.optimize.linear_sum_assignment on the host and assigned_gt_inds[row] = col + 1                                  (:244-271).
 //
-// The two [N x P] . [P x G] contractions are the gather kernel with the roles swapped: the binary operand is the ground truth
-// (rows g, "logit" = the 0/1 mask, threshold 0.5), the streamed real operand holds the activated predictions as channels —
-// p1 rows in channels [0, Npad), p2 rows in [Npad, 2 Npad) — so ONE launch of k_gather_mfma yields both sums and sum_p g (its
-// pixel count).  k_assign_act writes the activations (+ fixed-order partial row sums of p1^2 and p2), k_assign_cost combines
-// everything in fp64.  The LSAP itself is the shortest-augmenting-path algorithm scipy uses, in C++ on the host (vkn_lsap_f32).
+// The two [N x P] . [P x G] contractions are the gather kernel with the roles swapped: the left operand is the ground truth
+// (rows g) as a REAL-valued operand — the reference down-samples gt masks bilinearly to the assign stride
+// (knet/det/knet.py:131) and `hard_target` defaults to False, so their borders are soft; DiceCost / MaskCost use the real
+// values (`einsum(pred, target)`, `sum(target * target)`, `1 - target`) —, the streamed operand holds the activated
+// predictions as channels — p1 rows in channels [0, Npad), p2 rows in [Npad, 2 Npad) — so ONE launch of k_gather_mfma<., 2>
+// yields both sums and sum_p g.  k_assign_act writes the activations (+ fixed-order partial row sums of p1^2 and p2),
+// k_assign_gtsq the fixed-order partial sums of g^2, k_assign_cost combines everything in fp64.  (0/1 masks split exactly
+// into hi = g, lo = 0: for them the results are those of the binary-operand kernel bit for bit.)
+// The LSAP itself is the shortest-augmenting-path algorithm scipy uses, in C++ on the host (vkn_lsap_f32).
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -56,11 +60,25 @@ __global__ __launch_bounds__(256) void k_assign_act(const float* __restrict__ lo
     }
 }
 
+// gsq[g][chunk] = partial sum_p g^2 (fixed order)
+__global__ __launch_bounds__(256) void k_assign_gtsq(const float* __restrict__ gt, float* __restrict__ gsq, int P, int nchunk) {
+    __shared__ float red[4];
+    const int g = blockIdx.y, ck = blockIdx.x;
+    const int p_lo = ck * AS_CHUNK, p_hi = min(P, p_lo + AS_CHUNK);
+    const float* z = gt + (size_t)g * P;
+    float s = 0.f;
+    for (int p = p_lo + threadIdx.x; p < p_hi; p += 256) s += z[p] * z[p];
+    s = vkn_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) gsq[(size_t)g * nchunk + ck] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // S [G][2 Npad] from the gather (S[g][n] = sum p1 g, S[g][Npad + n] = sum p2 g), cnt [G] = sum g -> cost [N][G]
 __global__ __launch_bounds__(256) void k_assign_cost(VknAssignCfg c, const float* __restrict__ S, const float* __restrict__ cnt,
-                                                     const float* __restrict__ rowsum, const float* __restrict__ cls,
-                                                     const int* __restrict__ labels, int N, int Npad, int G, int ncls, int P,
-                                                     int nchunk, float* __restrict__ cost) {
+                                                     const float* __restrict__ rowsum, const float* __restrict__ gsq,
+                                                     const float* __restrict__ cls, const int* __restrict__ labels, int N,
+                                                     int Npad, int G, int ncls, int P, int nchunk, float* __restrict__ cost) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * G) return;
     const int n = i / G, g = i - n * G;
@@ -70,10 +88,12 @@ __global__ __launch_bounds__(256) void k_assign_cost(VknAssignCfg c, const float
         sp2 += (double)rowsum[((size_t)n * nchunk + k) * 2 + 1];
     }
     const double sg = (double)cnt[g];
+    double sgsq = 0.0;
+    for (int k = 0; k < nchunk; ++k) sgsq += (double)gsq[(size_t)g * nchunk + k];
     double total = 0.0;
     if (c.dice_weight != 0.f) {
         const double a = (double)S[(size_t)g * 2 * Npad + n];
-        total += (double)c.dice_weight * (-(2.0 * a) / ((sp1sq + (double)c.dice_eps) + (sg + (double)c.dice_eps)));
+        total += (double)c.dice_weight * (-(2.0 * a) / ((sp1sq + (double)c.dice_eps) + (sgsq + (double)c.dice_eps)));
     }
     if (c.mask_weight != 0.f) {
         const double pos = (double)S[(size_t)g * 2 * Npad + Npad + n];
@@ -82,7 +102,8 @@ __global__ __launch_bounds__(256) void k_assign_cost(VknAssignCfg c, const float
     }
     if (c.cls_weight != 0.f && cls) {
         // mmdet FocalLossCost: p = sigmoid(logit); neg = -log(1 - p + eps) (1 - alpha) p^gamma; pos = -log(p + eps) alpha (1 - p)^gamma
-        const float z = cls[(size_t)n * ncls + labels[g]];
+        const int lab = min(max(labels[g], 0), ncls - 1);  // the host wrapper rejects labels outside [0, ncls); never read out of bounds
+        const float z = cls[(size_t)n * ncls + lab];
         const float p = 1.0f / (1.0f + expf(-z));
         const float negc = -logf(1.f - p + c.focal_eps) * (1.f - c.focal_alpha) * powf(p, c.focal_gamma);
         const float posc = -logf(p + c.focal_eps) * c.focal_alpha * powf(1.f - p, c.focal_gamma);
@@ -93,7 +114,7 @@ __global__ __launch_bounds__(256) void k_assign_cost(VknAssignCfg c, const float
 
 namespace {
 struct AssignWs {
-    float *act, *rowsum, *S, *cnt, *part, *cntp;
+    float *act, *rowsum, *gsq, *S, *cnt, *part, *cntp;
 };
 size_t carve_assign(int N, int G, int P, char* base, AssignWs* w) {
     const size_t Npad = (size_t)(N + 31) / 32 * 32, nchunk = (size_t)(P + AS_CHUNK - 1) / AS_CHUNK;
@@ -106,6 +127,7 @@ size_t carve_assign(int N, int G, int P, char* base, AssignWs* w) {
     };
     w->act = take(C2 * P);
     w->rowsum = take((size_t)N * nchunk * 2);
+    w->gsq = take((size_t)G * nchunk);
     w->S = take((size_t)G * C2);
     w->cnt = take(G);
     w->part = take(Gg * GPT * C2);
@@ -140,17 +162,24 @@ int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, cons
     const int nchunk = (P + AS_CHUNK - 1) / AS_CHUNK;
     hipLaunchKernelGGL(k_assign_act, dim3(nchunk, Npad), dim3(256), 0, st, mask_logits, w.act, w.rowsum, N, Npad, P, nchunk);
     VKN_CHECK_LAUNCH();
-    // "x" = the activations [1][2 Npad][P], "masks" = the ground truth [G][P] binarised at 0.5
-    const int rc = vkn_launch_gather(w.act, gt_masks, 0.5f, w.S, w.cnt, w.part, w.cntp, 1, G, 2 * Npad, P, st);
+    hipLaunchKernelGGL(k_assign_gtsq, dim3(nchunk, G), dim3(256), 0, st, gt_masks, w.gsq, P, nchunk);
+    VKN_CHECK_LAUNCH();
+    // "x" = the activations [1][2 Npad][P], left operand = the (possibly soft) ground truth [G][P]
+    const int rc = vkn_launch_gather_real(w.act, gt_masks, w.S, w.cnt, w.part, w.cntp, 1, G, 2 * Npad, P, G, st);
     if (rc != VKN_OK) return rc;
-    hipLaunchKernelGGL(k_assign_cost, dim3((N * G + 255) / 256), dim3(256), 0, st, *cfg, w.S, w.cnt, w.rowsum, cls_logits, gt_labels,
-                       N, Npad, G, ncls, P, nchunk, cost_out);
+    hipLaunchKernelGGL(k_assign_cost, dim3((N * G + 255) / 256), dim3(256), 0, st, *cfg, w.S, w.cnt, w.rowsum, w.gsq, cls_logits,
+                       gt_labels, N, Npad, G, ncls, P, nchunk, cost_out);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
 
 // Rectangular linear sum assignment (minimisation), HOST function: the shortest augmenting path algorithm of
-// scipy.optimize.linear_sum_assignment (Crouse 2016), including its scan order (`remaining` filled in reverse) and its tie rule
+// scipy.optimize.linear_sum_assignment (D. F. Crouse, "On implementing 2D rectangular assignment algorithms", IEEE TAES 2016).
+// ATTRIBUTION: this function restates scipy/optimize/rectangular_lsap/rectangular_lsap.cpp (SciPy 1.x; Copyright (c) 2019,
+// PM Larsen and SciPy developers; BSD 3-Clause License — "Redistribution and use in source and binary forms, with or without
+// modification, are permitted provided that the above copyright notice, this list of conditions and the disclaimer are retained";
+// the full text is in LICENSES/SCIPY-BSD-3-Clause.txt) closely — same variable roles (u, v, path, col4row, row4col, SR, SC,
+// remaining) — because identical tie-breaking requires the identical scan order.  It follows scipy's algorithm including its scan order (`remaining` filled in reverse) and its tie rule
 // (prefer a column that is still free), so that degenerate cost matrices resolve the same way.  cost: host fp32 [nr][nc] row-major
 // (converted to fp64 as scipy does).  Writes min(nr, nc) pairs sorted by row; returns the number of pairs or a negative error.
 int vkn_lsap_f32(const float* cost, int nr, int nc, int* row_ind, int* col_ind) {

@@ -11,6 +11,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define VKN_WAVE 64
 
+// Debug knobs: the release library reads NO environment variable and contains no ablation variant; a build with -DVKN_DEBUG
+// (tools/ only, `_lib.build_debug()` -> lib/libvkn_debug.so) turns `vkn_dbg_env(name, default)` into a getenv read.
+#ifdef VKN_DEBUG
+#include <stdlib.h>
+static inline int vkn_dbg_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+#define vkn_dbg_env(name, dflt) (dflt)
+#endif
+
 // ---- MFMA 32x32 C/D fragment map (dtype independent on gfx950): lane l, register r ->
 //      col = l & 31 ; row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
 __device__ __forceinline__ int vkn_cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
@@ -40,6 +52,25 @@ __device__ __forceinline__ float vkn_wave_max(float v) {
 #define VKN_E_WORKSPACE (-3)
 #define VKN_E_LAUNCH (-4)
 #define VKN_E_ALIGN (-5)
+
+// Raise a kernel's dynamic-LDS limit to the whole 160 KB ONCE per (process, device) instead of on every launch.
+static inline int vkn_allow_full_lds(const void* fn, unsigned long long* done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return 0;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return -1;
+    const int dyn = 160 * 1024 - (int)fa.sharedSizeBytes;  // static __shared__ of the kernel counts against the same 160 KB
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) return -1;
+    __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+    return 0;
+}
+#define VKN_ALLOW_FULL_LDS(fn)                                                        \
+    do {                                                                              \
+        static unsigned long long lds_done_ = 0;                                      \
+        if (vkn_allow_full_lds((const void*)(fn), &lds_done_)) return VKN_E_LAUNCH;   \
+    } while (0)
 
 #define VKN_CHECK_LAUNCH()                                  \
     do {                                                    \

@@ -16,13 +16,14 @@
 //   * output D[n][px]: 8-byte stores, lanes 0..31 write 256 contiguous bytes of one mask row.
 #include "vkn_common.h"
 #include "vkn_launch.h"
-#include <stdlib.h>
 
 #define DEC_THREADS 512
 #define DEC_WAVES 8
 #define DEC_TILE 64  // pixels per wave tile: two interleaved 32-column MFMA strips (even / odd pixels)
+#define DEC_OPT_DEFAULT 0  // round-2 variants of k_decode_mfma compiled into the release library (see OPT below)
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- bit-packed output (intermediate stages of the fused head): instead of the logits, emit bit(z >= thr) — all the next
@@ -65,7 +66,11 @@ __device__ __forceinline__ void dec_emit_bits(const f32x16 (&acc)[2][NB], float 
 
 // ABL (ablation, debugging only; selected by env VKN_DECODE_ABL): 0 = the real kernel, 1 = no MFMA, 2 = no x loads,
 // 3 = no output stores.  Variants 1-3 produce WRONG results by construction and exist to attribute time.
-template <int NB, int ABL, int RING, int BITS>
+// OPT (bit mask, round-2 variants measured with tools/perf_r02.py): 1 = request the first x fragments BEFORE staging the kernel
+// planes (the prologue overlaps their latency); 2 = static `s_setprio 1` for the younger half of the workgroup (waves 4-7);
+// 4 = 16-byte stores: adjacent lanes exchange half of their pixel pairs (DPP quad_perm) so that a lane stores 4 consecutive
+// pixels of ONE row — half the store instructions, same 256-byte row segments.
+template <int NB, int ABL, int RING, int BITS, int OPT>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     const float* __restrict__ x, const _Float16* __restrict__ kfh, const _Float16* __restrict__ kfl,
     const float* __restrict__ kb, float* __restrict__ out, int N, int NPT, int n0, int C, int P, int px_per_wg,
@@ -80,29 +85,32 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> scalar control flow
     const int g = lane >> 5, li = lane & 31;
 
-    // ---- stage this frame's kernels (rows n0 .. n0+NB*32) into LDS
-    {
-        const _Float16* gh = kfh + (size_t)b * fs.plane + (size_t)n0 * C;
-        const _Float16* gl = kfl + (size_t)b * fs.plane + (size_t)n0 * C;
-        const int cpr = C >> 3;
-        for (int i = threadIdx.x; i < NB * 32 * cpr; i += DEC_THREADS) {
-            const int r = i / cpr, q = i - r * cpr;
-            half8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (n0 + r < N) {  // rows >= N of the planes are never written by the producer: treat as zero
-                vh = *reinterpret_cast<const half8*>(gh + (size_t)r * C + q * 8);
-                vl = *reinterpret_cast<const half8*>(gl + (size_t)r * C + q * 8);
-            }
-            *reinterpret_cast<half8*>(ldsH + r * LDK + q * 8) = vh;
-            *reinterpret_cast<half8*>(ldsL + r * LDK + q * 8) = vl;
-        }
-    }
-    // folded decode bias of the chunk's rows -> LDS (accumulators start from it)
     float* kbs = reinterpret_cast<float*>(ldsL + NB * 32 * LDK);
-    if (threadIdx.x < NB * 32) {
-        const int n = n0 + threadIdx.x;
-        kbs[threadIdx.x] = (kb && n < N) ? kb[(size_t)b * fs.kb + n] : 0.f;
-    }
-    __syncthreads();
+    auto stage_planes = [&]() {
+        // ---- stage this frame's kernels (rows n0 .. n0+NB*32) into LDS
+        {
+            const _Float16* gh = kfh + (size_t)b * fs.plane + (size_t)n0 * C;
+            const _Float16* gl = kfl + (size_t)b * fs.plane + (size_t)n0 * C;
+            const int cpr = C >> 3;
+            for (int i = threadIdx.x; i < NB * 32 * cpr; i += DEC_THREADS) {
+                const int r = i / cpr, q = i - r * cpr;
+                half8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (n0 + r < N) {  // rows >= N of the planes are never written by the producer: treat as zero
+                    vh = *reinterpret_cast<const half8*>(gh + (size_t)r * C + q * 8);
+                    vl = *reinterpret_cast<const half8*>(gl + (size_t)r * C + q * 8);
+                }
+                *reinterpret_cast<half8*>(ldsH + r * LDK + q * 8) = vh;
+                *reinterpret_cast<half8*>(ldsL + r * LDK + q * 8) = vl;
+            }
+        }
+        // folded decode bias of the chunk's rows -> LDS (accumulators start from it)
+        if (threadIdx.x < NB * 32) {
+            const int n = n0 + threadIdx.x;
+            kbs[threadIdx.x] = (kb && n < N) ? kb[(size_t)b * fs.kb + n] : 0.f;
+        }
+        __syncthreads();
+    };
+    if (!(OPT & 1)) stage_planes();
 
     // XCD-aware pixel ranges (workgroup id % 8 = XCD, observed): `xcd_remap` gives each XCD a contiguous 1/8 of the frame
     int gx = blockIdx.x;
@@ -113,7 +121,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     const int my = (ntile > wave) ? (ntile - wave + DEC_WAVES - 1) / DEC_WAVES : 0;
     const int KS = C >> 4;
     const int total = my * KS;
-    if (total == 0) return;
+    if (total == 0) {
+        if (OPT & 1) stage_planes();  // every wave takes part in the staging barrier
+        return;
+    }
+    if ((OPT & 2) && wave >= 4) __builtin_amdgcn_s_setprio(1);  // `wave` is provably uniform: a scalar branch around one s_setprio
 
     // Buffer descriptors built from uniform values only: loads/stores are `buffer_* v, v_off, s[rsrc], s_off offen` with ONE
     // per-lane VGPR offset and every row / tile offset in the SGPR operand (no per-load VALU address arithmetic).
@@ -199,7 +211,25 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
             } else if (ABL != 3 || acc[0][0][0] == 12345.678f) {                                                  \
                 if (p0_ + DEC_TILE <= p_end) { /* whole tile in range (uniform): 8-byte stores, 256 B per row */  \
                     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                           \
-                        if (n0 + nb * 32 + 32 <= N) { /* full n-block (uniform): no per-row guard */              \
+                        if ((OPT & 4) && n0 + nb * 32 + 32 <= N) { /* 16-byte stores: lanes 2j / 2j+1 swap halves */ \
+                            const int q_ = li & 1;                                                                \
+                            const int vw_ = ((4 * g + q_) * P + 2 * (li - q_)) << 2;                              \
+                            _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                   \
+                                const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2); /* even lanes: row_, odd: row_ + 1 */ \
+                                const float e0_ = acc[0][nb][r], e1_ = acc[1][nb][r];         /* row_     : this lane's px pair */ \
+                                const float o0_ = acc[0][nb][r + 1], o1_ = acc[1][nb][r + 1]; /* row_ + 1 */      \
+                                /* send what the partner stores: the even lane its row_+1 pair, the odd lane its row_ pair */ \
+                                const int s0_ = __float_as_int(q_ ? e0_ : o0_), s1_ = __float_as_int(q_ ? e1_ : o1_); \
+                                const int t0_ = __builtin_amdgcn_mov_dpp(s0_, 0xB1, 0xF, 0xF, true); /* quad_perm [1,0,3,2] */ \
+                                const int t1_ = __builtin_amdgcn_mov_dpp(s1_, 0xB1, 0xF, 0xF, true);              \
+                                u32x4w v_;                                                                        \
+                                v_[0] = q_ ? (unsigned)t0_ : __float_as_uint(e0_);                                \
+                                v_[1] = q_ ? (unsigned)t1_ : __float_as_uint(e1_);                                \
+                                v_[2] = q_ ? __float_as_uint(o0_) : (unsigned)t0_;                                \
+                                v_[3] = q_ ? __float_as_uint(o1_) : (unsigned)t1_;                                \
+                                __builtin_amdgcn_raw_buffer_store_b128(v_, ors, vw_, (row_ * P + p0_) << 2, 0);   \
+                            }                                                                                     \
+                        } else if (n0 + nb * 32 + 32 <= N) { /* full n-block (uniform): no per-row guard */       \
                             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
                                 const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                           \
                                 const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
@@ -244,6 +274,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     if constexpr (RING == 3) {
         DEC_LOAD(r0);
         DEC_LOAD(r1);
+        if (OPT & 1) stage_planes();
         for (int f = 0; f < total; f += 3) {
             DEC_LOAD(r2);
             DEC_COMPUTE(r0);
@@ -259,6 +290,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
         DEC_LOAD(r0);
         DEC_LOAD(r1);
         DEC_LOAD(r2);
+        if (OPT & 1) stage_planes();
         for (int f = 0; f < total; f += 4) {
             DEC_LOAD(r3);
             DEC_COMPUTE(r0);
@@ -281,6 +313,180 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
 // register set and issued its stores a few per k-step during the next strip (so loads, MFMAs and stores interleave inside
 // every wave) was built and validated, and measured SLOWER (113 us vs 94 us at cfg2, B = 8): the read and write streams
 // already share the memory system at ~4.2 TB/s combined whatever their interleaving (tools/decode_ablation.py).
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_decode4 — the same contraction with 16-BYTE global accesses (round 2).
+//
+// Why: k_decode_mfma moves every byte of x and of the logits with 8-byte-per-lane instructions (lane = pixel pair).  The CU's
+// vector-memory front end retires lanes, not bytes: an 8-byte access costs what a 16-byte one costs (MI355X_MICROARCH.md:
+// "8-B accesses 0.54-0.70x the 16-B rate"), and the round-1 ablations fit that model — loads alone 52 us, stores alone 52 us,
+// both 80-95 us at cfg2 / B = 8, with the MFMAs removed changing nothing.  Here a lane owns FOUR consecutive pixels:
+//   * x fragments: `buffer_load_dwordx4` (32 lanes x 16 B = 512-B row segments, two channel rows per instruction);
+//   * a wave tile is 128 px = four interleaved 32-column MFMA strips (pixel 4 li + s -> strip s); every A fragment read from
+//     LDS feeds 12 MFMAs instead of 6 (half the LDS traffic per pixel);
+//   * logits: `buffer_store_dwordx4`, 512 B per mask row per instruction, half the store instructions;
+//   * 4 strips x NB n-blocks = up to 256 accumulator registers per lane -> ONE wave per SIMD (256-thread workgroups,
+//     `__launch_bounds__(256, 1)`, 512 registers per lane); the 4-deep fragment ring (3 x 8 KB in flight per wave) hides the
+//     HBM latency that a second wave per SIMD used to hide.
+// Per output element the MFMA sequence is the one of k_decode_mfma (kb, then per 16 channels hi*hi, hi*lo, lo*hi), so both
+// kernels produce bit-identical logits.  Needs P % 128 == 0 and C % 64 == 0 (every shipped config); other shapes use k_decode_mfma.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define D4_THREADS 256
+#define D4_WAVES 4
+#define D4_TILE 128
+
+template <int NB>
+__global__ __launch_bounds__(D4_THREADS, 1) void k_decode4(const float* __restrict__ x, const _Float16* __restrict__ kfh,
+                                                           const _Float16* __restrict__ kfl, const float* __restrict__ kb,
+                                                           float* __restrict__ out, int N, int NPT, int n0, int C, int P,
+                                                           int px_per_wg, int xcd_remap, VknDecodeStrides fs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int LDK = C + 8;
+    _Float16* ldsH = reinterpret_cast<_Float16*>(smem);
+    _Float16* ldsL = ldsH + NB * 32 * LDK;
+    float* kbs = reinterpret_cast<float*>(ldsL + NB * 32 * LDK);
+
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 5, li = lane & 31;
+
+    int gx = blockIdx.x;
+    if (xcd_remap && (gridDim.x % 8) == 0) gx = (gx % 8) * (gridDim.x / 8) + gx / 8;
+    const int p_begin = gx * px_per_wg;
+    const int p_end = min(P, p_begin + px_per_wg);
+    const int ntile = (p_end > p_begin) ? (p_end - p_begin) / D4_TILE : 0;  // launcher: P % 128 == 0, px_per_wg % 512 == 0
+    const int my = (ntile > wave) ? (ntile - wave + D4_WAVES - 1) / D4_WAVES : 0;
+    const int KS = C >> 4;
+    const int total = my * KS;
+
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * fs.out, 0, N * P * 4, 0x00020000);
+
+    // 4-deep fragment ring (3 fragments = 24 KB per wave in flight).  C % 64 == 0 (launcher), so the ring phase is the same at
+    // every tile start: the tile loop is explicit, accumulators are loop-carried through the MFMAs only (they stay in AGPRs).
+    u32x4 r0[8], r1[8], r2[8], r3[8];
+    int ld_ks = 0, ld_sl = 0, ld_cnt = 0;  // next fragment to load
+    const int voff = (((g << 3) * P + 4 * li) << 2);  // lane (g, li): channels 8 g + e, pixels 4 li .. 4 li + 3 of the tile
+
+#define D4_LOAD(REG)                                                                                   \
+    do { /* unconditional: past the end it re-reads the last fragment (exact vmcnt counting) */        \
+        const int p0_ = p_begin + (wave + D4_WAVES * ld_sl) * D4_TILE;                                 \
+        const int soff_ = ((ld_ks << 4) * P + p0_) << 2;                                               \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                  \
+            REG[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, soff_ + ((e * P) << 2), 3); /* sc0 | nt: streamed once */ \
+        const bool adv_ = (ld_cnt + 1 < total);                                                        \
+        const bool wrap_ = (ld_ks + 1 == KS);                                                          \
+        ld_cnt += adv_ ? 1 : 0;                                                                        \
+        ld_sl += (adv_ && wrap_) ? 1 : 0;                                                              \
+        ld_ks = adv_ ? (wrap_ ? 0 : ld_ks + 1) : ld_ks;                                                \
+    } while (0)
+
+    // the first three fragments are requested BEFORE the kernel planes are staged: the workgroup's prologue overlaps their latency
+    if (total > 0) {
+        D4_LOAD(r0);
+        D4_LOAD(r1);
+        D4_LOAD(r2);
+    }
+
+    // ---- stage this frame's kernels (rows n0 .. n0 + NB*32) and the folded bias into LDS
+    {
+        const _Float16* gh = kfh + (size_t)b * fs.plane + (size_t)n0 * C;
+        const _Float16* gl = kfl + (size_t)b * fs.plane + (size_t)n0 * C;
+        const int cpr = C >> 3;
+        for (int i = threadIdx.x; i < NB * 32 * cpr; i += D4_THREADS) {
+            const int r = i / cpr, q = i - r * cpr;
+            half8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (n0 + r < N) {
+                vh = *reinterpret_cast<const half8*>(gh + (size_t)r * C + q * 8);
+                vl = *reinterpret_cast<const half8*>(gl + (size_t)r * C + q * 8);
+            }
+            *reinterpret_cast<half8*>(ldsH + r * LDK + q * 8) = vh;
+            *reinterpret_cast<half8*>(ldsL + r * LDK + q * 8) = vl;
+        }
+        if (threadIdx.x < NB * 32) {
+            const int n = n0 + threadIdx.x;
+            kbs[threadIdx.x] = (kb && n < N) ? kb[(size_t)b * fs.kb + n] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (total == 0) return;
+
+    f32x16 acc[4][NB];
+
+#define D4_COMPUTE(REG, KSV)                                                                                  \
+    do {                                                                                                      \
+        half8 bh[4], bl[4];                                                                                   \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                       \
+            const unsigned u0_ = REG[e][0], u1_ = REG[e][1], u2_ = REG[e][2], u3_ = REG[e][3];               \
+            _Float16 h_, l_;                                                                                  \
+            vkn_split_f16(__uint_as_float(u0_), h_, l_); bh[0][e] = h_; bl[0][e] = l_;                        \
+            vkn_split_f16(__uint_as_float(u1_), h_, l_); bh[1][e] = h_; bl[1][e] = l_;                        \
+            vkn_split_f16(__uint_as_float(u2_), h_, l_); bh[2][e] = h_; bl[2][e] = l_;                        \
+            vkn_split_f16(__uint_as_float(u3_), h_, l_); bh[3][e] = h_; bl[3][e] = l_;                        \
+        }                                                                                                     \
+        const int cb_ = ((KSV) << 4) + (g << 3);                                                              \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                   \
+            const _Float16* ap_ = ldsH + (nb * 32 + li) * LDK + cb_;                                          \
+            const half8 ah = *reinterpret_cast<const half8*>(ap_);                                            \
+            const half8 al = *reinterpret_cast<const half8*>(ap_ + NB * 32 * LDK);                            \
+            /* per accumulator: hi*hi, hi*lo, lo*hi (the order of k_decode_mfma); four independent chains interleaved */ \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                     \
+                acc[s][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc[s][nb], 0, 0, 0);          \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                     \
+                acc[s][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc[s][nb], 0, 0, 0);          \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                     \
+                acc[s][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc[s][nb], 0, 0, 0);          \
+        }                                                                                                     \
+    } while (0)
+
+    for (int t = 0; t < my; ++t) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float kb_ = kbs[nb * 32 + vkn_cd_row(r, lane)];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[s][nb][r] = kb_;
+            }
+        for (int ks = 0; ks < KS; ks += 4) {
+            D4_LOAD(r3);
+            D4_COMPUTE(r0, ks);
+            D4_LOAD(r0);
+            D4_COMPUTE(r1, ks + 1);
+            D4_LOAD(r1);
+            D4_COMPUTE(r2, ks + 2);
+            D4_LOAD(r2);
+            D4_COMPUTE(r3, ks + 3);
+        }
+        const int p0 = p_begin + (wave + D4_WAVES * t) * D4_TILE;
+        const int vst = ((4 * g) * P + 4 * li) << 2;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (n0 + nb * 32 + 32 <= N) {  // full n-block (uniform): no per-row guard
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);
+                    const float a0 = acc[0][nb][r], a1 = acc[1][nb][r], a2 = acc[2][nb][r], a3 = acc[3][nb][r];
+                    const u32x4 v = {__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), __float_as_uint(a3)};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ors, vst, (row * P + p0) << 2, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);
+                    const float a0 = acc[0][nb][r], a1 = acc[1][nb][r], a2 = acc[2][nb][r], a3 = acc[3][nb][r];
+                    const u32x4 v = {__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), __float_as_uint(a3)};
+                    if (row + 4 * g < N) __builtin_amdgcn_raw_buffer_store_b128(v, ors, vst, (row * P + p0) << 2, 0);
+                }
+            }
+        }
+    }
+#undef D4_LOAD
+#undef D4_COMPUTE
+}
 
 // Exact-fp32 debug / fallback kernel: one thread per (n, px), k-ordered fmaf chain.
 __global__ __launch_bounds__(256) void k_decode_ref(const float* __restrict__ x, const float* __restrict__ kern,
@@ -308,10 +514,6 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
         kfh[(size_t)row * C + c] = h;
         kfl[(size_t)row * C + c] = l;
     }
-}
-
-static int dec_set_lds(const void* fn, size_t bytes) {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
 }
 
 // host launcher.  kfh/kfl: [B][NPT][C] f16, NPT = roundup(N,32).  Returns VKN_* code.
@@ -345,32 +547,70 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
     if ((size_t)C * P * 4 >= ((size_t)1 << 31) || (size_t)N * P * 4 >= ((size_t)1 << 31)) return VKN_E_SHAPE;  // 32-bit buffer offsets
     const int NPT = (N + 31) / 32 * 32;
     const VknDecodeStrides fs{shared ? 0 : (long long)NPT * C, shared ? 0 : (long long)N, (long long)out_rows * P};
-    // persistent grid: ~1 workgroup per CU over the whole batch, >= 256 px (8 strips) per workgroup
-    // 512 px (one 64-px tile per wave) per workgroup measured best on MI355X (tools/decode_ablation.py: 95 us vs 108 us at
-    // 1024 px, B = 8, cfg2); fewer, larger workgroups only when the batch alone already oversubscribes the chip.
+    // ~2048 workgroups per launch, 512 px (one tile per wave) each: measured best on MI355X (tools/decode_ablation.py: 95 us vs
+    // 108 us at 1024 px, B = 8, cfg2); fewer, larger workgroups only when the batch alone already oversubscribes the chip.
     int wg_per_frame = 2048 / B;
     if (wg_per_frame < 1) wg_per_frame = 1;
     int px_per_wg = (P + wg_per_frame - 1) / wg_per_frame;
-    px_per_wg = (px_per_wg + 511) / 512 * 512;  // 8 waves x 64-px tiles
-    const int G = (P + px_per_wg - 1) / px_per_wg;
-    (void)G;
-    const char* abl_env = getenv("VKN_DECODE_ABL");  // debugging: time-attribution variants (wrong results)
-    const int abl = abl_env ? atoi(abl_env) : 0;
-    const char* ppw_env = getenv("VKN_DECODE_PXWG");  // debugging: override pixels per workgroup
-    if (ppw_env && atoi(ppw_env) >= 512) px_per_wg = atoi(ppw_env) / 512 * 512;
+    px_per_wg = (px_per_wg + 511) / 512 * 512;  // 8 waves x 64-px tiles = 4 waves x 128-px tiles
+    const int ppw_dbg = vkn_dbg_env("VKN_DECODE_PXWG", 0);  // debug build only: override pixels per workgroup
+    if (ppw_dbg >= 512) px_per_wg = ppw_dbg / 512 * 512;
     const int G2 = (P + px_per_wg - 1) / px_per_wg;
-    const int ring = getenv("VKN_DECODE_RING") ? atoi(getenv("VKN_DECODE_RING")) : 3;  // debugging: ring depth A/B
-    const int xcd = getenv("VKN_DECODE_XCD") ? atoi(getenv("VKN_DECODE_XCD")) : 1;  // measured +1 % (tools/decode_sweep.py)
+    const int xcd = vkn_dbg_env("VKN_DECODE_XCD", 1);  // measured +1 % (tools/decode_sweep.py)
+    // 16-byte variant: whole 128-px tiles and 16-byte aligned rows; the logits output only (the bit-packed hand-off lives in the
+    // fused decode -> gather kernel, vkn_fused.hip)
+    const bool wide = !bits_out && (P % D4_TILE) == 0 && (C % 64) == 0 && vkn_dbg_env("VKN_DECODE4", 0) != 0 &&
+                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     for (int n0 = 0; n0 < NPT; n0 += 128) {
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
         const size_t lds = (size_t)2 * nb * 32 * (C + 8) * sizeof(_Float16) + (size_t)nb * 32 * sizeof(float);
-        dim3 grid(G2, B, 1), block(DEC_THREADS);
-#define DEC_LAUNCH(NBV, ABLV, RINGV, BITSV)                                                                    \
+        dim3 grid(G2, B, 1);
+        if (wide) {
+#define D4_CASE(NBV)                                                                                                       \
+    case NBV: {                                                                                                            \
+        VKN_ALLOW_FULL_LDS(k_decode4<NBV>);                                                                                \
+        hipLaunchKernelGGL((k_decode4<NBV>), grid, dim3(D4_THREADS), lds, stream, x, kfh, kfl, kb, out, N, NPT, n0, C, P, \
+                           px_per_wg, xcd, fs);                                                                            \
+    } break;
+            switch (nb) {
+                D4_CASE(1)
+                D4_CASE(2)
+                D4_CASE(3)
+                D4_CASE(4)
+                default:
+                    return VKN_E_SHAPE;
+            }
+#undef D4_CASE
+            VKN_CHECK_LAUNCH();
+            continue;
+        }
+        dim3 block(DEC_THREADS);
+#define DEC_LAUNCH_O(NBV, ABLV, RINGV, BITSV, OPTV)                                                            \
     do {                                                                                                       \
-        if (dec_set_lds((const void*)k_decode_mfma<NBV, ABLV, RINGV, BITSV>, lds)) return VKN_E_LAUNCH;        \
-        hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV, RINGV, BITSV>), grid, block, lds, stream, x, kfh, kfl, kb, out, N, NPT, \
-                           n0, C, P, px_per_wg, xcd, fs, bits_out, thr);                                       \
+        VKN_ALLOW_FULL_LDS((k_decode_mfma<NBV, ABLV, RINGV, BITSV, OPTV>));                                    \
+        hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV, RINGV, BITSV, OPTV>), grid, block, lds, stream, x, kfh, kfl, kb, out, N, \
+                           NPT, n0, C, P, px_per_wg, xcd, fs, bits_out, thr);                                  \
     } while (0)
+#ifdef VKN_DEBUG
+        const int opt = vkn_dbg_env("VKN_DECODE_OPT", DEC_OPT_DEFAULT);
+#define DEC_LAUNCH(NBV, ABLV, RINGV, BITSV)                                              \
+    do {                                                                                 \
+        if (ABLV != 0 || RINGV != 3 || BITSV != 0 || NBV != 4) DEC_LAUNCH_O(NBV, ABLV, RINGV, BITSV, DEC_OPT_DEFAULT); \
+        else if (opt == 0) DEC_LAUNCH_O(4, 0, 3, 0, 0);                                  \
+        else if (opt == 1) DEC_LAUNCH_O(4, 0, 3, 0, 1);                                  \
+        else if (opt == 2) DEC_LAUNCH_O(4, 0, 3, 0, 2);                                  \
+        else if (opt == 3) DEC_LAUNCH_O(4, 0, 3, 0, 3);                                  \
+        else if (opt == 4) DEC_LAUNCH_O(4, 0, 3, 0, 4);                                  \
+        else if (opt == 5) DEC_LAUNCH_O(4, 0, 3, 0, 5);                                  \
+        else if (opt == 6) DEC_LAUNCH_O(4, 0, 3, 0, 6);                                  \
+        else DEC_LAUNCH_O(4, 0, 3, 0, 7);                                                \
+    } while (0)
+#else
+#define DEC_LAUNCH(NBV, ABLV, RINGV, BITSV) DEC_LAUNCH_O(NBV, ABLV, RINGV, BITSV, DEC_OPT_DEFAULT)
+#endif
+#ifdef VKN_DEBUG
+        // time-attribution variants (WRONG results by construction) and the ring-depth A/B exist in the debug build only
+        const int abl = vkn_dbg_env("VKN_DECODE_ABL", 0), ring = vkn_dbg_env("VKN_DECODE_RING", 3);
 #define DEC_CASE(NBV)                                           \
     case NBV:                                                   \
         if (bits_out) DEC_LAUNCH(NBV, 0, 3, 1);                 \
@@ -386,6 +626,13 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
         else if (NBV == 4 && abl == 6) DEC_LAUNCH(4, 6, 3, 0);  \
         else DEC_LAUNCH(NBV, 0, 3, 0);                          \
         break;
+#else
+#define DEC_CASE(NBV)                           \
+    case NBV:                                   \
+        if (bits_out) DEC_LAUNCH(NBV, 0, 3, 1); \
+        else DEC_LAUNCH(NBV, 0, 3, 0);          \
+        break;
+#endif
         switch (nb) {
             DEC_CASE(1)
             DEC_CASE(2)
@@ -396,6 +643,7 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
         }
 #undef DEC_CASE
 #undef DEC_LAUNCH
+#undef DEC_LAUNCH_O
         VKN_CHECK_LAUNCH();
     }
     return VKN_OK;

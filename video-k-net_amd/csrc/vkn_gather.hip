@@ -17,14 +17,15 @@
 //     summed in fixed order by k_gather_reduce (deterministic, no atomics).
 #include "vkn_common.h"
 #include "vkn_launch.h"
-#include <stdlib.h>
 
 #define GA_THREADS 512
 #define GA_WAVES 8
 #define GA_PT 32   // pixels per tile
 #define GA_LDR 40  // halfs per LDS row (32 + 8 pad)
 
-// BITS: `masks` are the bit words [B][P/64][2][NPT] (even / odd pixels of each 64-px tile) written by the decode kernel's
+// BITS == 2: `masks` is a REAL-valued left operand a[b][n][p] (soft gather weights, soft ground-truth masks): out = sum_p a x,
+// `cnt` = sum_p a; both operands f16 hi / lo split, a_hi x_hi + a_hi x_lo + a_lo x_hi (|a|, |x| < 65504; absolute resolution of a: 6e-8).
+// BITS == 1: `masks` are the bit words [B][P/64][2][NPT] (even / odd pixels of each 64-px tile) written by the decode kernel's
 // bit-packed epilogue (fused head, stages > 0) instead of logits; fragments of the binary operand come from a 256-entry
 // (even nibble, odd nibble) -> half8 table in LDS.
 template <int NB, int BITS>
@@ -34,8 +35,9 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                                                                int NPT, int n0, int C, int P, int px_per_wg,
                                                                long long mask_fs, int ileave) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // per buffer: xh [C][40], xl [C][40], mk [NB*32][40]
-    const int rows_buf = 2 * C + NB * 32;
+    // per buffer: xh [C][40], xl [C][40], mk [NB*32][40] (+ ml [NB*32][40]: low half of a REAL mask operand, BITS == 2)
+    constexpr bool REAL = (BITS == 2);
+    const int rows_buf = 2 * C + (REAL ? 2 : 1) * NB * 32;
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
 
     const int b = blockIdx.y, gidx = blockIdx.x, G = gridDim.x;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     // BITS: (even nibble | odd nibble << 4) -> 8 halfs {0,1}: pixel e of the 8-px group = bit e/2 of the even (e even) or odd
     // (e odd) nibble; behind the two tile buffers
     half8* lut = reinterpret_cast<half8*>(lds + (size_t)2 * rows_buf * GA_LDR);
-    if (BITS) {
+    if (BITS == 1) {
         for (int v = tid; v < 256; v += GA_THREADS) {
             half8 h;
 #pragma unroll
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     f32x4 xrA[4], xrB[4];  // two register sets: tile t+2 is being loaded while tile t+1 waits to be committed
     f32x4 mrA[2], mrB[2];
 
-    const f32x4 neg_inf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // "off" for padded rows / pixels
+    const float off_v = REAL ? 0.f : -INFINITY;  // "off" for padded rows / pixels
+    const f32x4 neg_inf = {off_v, off_v, off_v, off_v};
 
     // Full tiles (all 32 px in range, rows 16-B aligned): branch-free, ALWAYS 4 + 2 dwordx4 loads per thread on clamped
     // addresses (lanes past the tile are masked in commit()), nothing consumed here -> exact vmcnt counting in the pipeline.
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
             // non-temporal: x is streamed once per launch (same +9 % as in the decode kernel)
             xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2)));
         }
-        if (BITS) {  // even- and odd-pixel word of this row for the 64-px tile holding p0 (clamped: every thread loads)
+        if (BITS == 1) {  // even- and odd-pixel word of this row for the 64-px tile holding p0 (clamped: every thread loads)
             const unsigned* wp = wb + (size_t)((p0 >> 6) << 1) * NPT + min(tid, NB * 32 - 1);
             const unsigned we = wp[0], wo = wp[NPT];
             mr[0][0] = __uint_as_float(we);
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                 *reinterpret_cast<half4*>(xl + off) = l;
             }
         }
-        if (BITS) {
+        if (BITS == 1) {
             const float w0 = mr[0][0], w1 = mr[0][1];
             if (tid < NB * 32) {
                 reinterpret_cast<unsigned*>(mk)[tid] = __float_as_uint(w0);
@@ -167,10 +170,20 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
             const int idx = tid + i * GA_THREADS;
             if (idx < nmch) {
                 const bool row_ok = (n0 + (idx >> 3)) < N;
-                half4 m;
+                half4 m, ml;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) m[k] = (row_ok && mr[i][k] >= thr) ? (_Float16)1.f : (_Float16)0.f;
+                for (int k = 0; k < 4; ++k) {
+                    if (REAL) {  // real-valued left operand: f16 hi / lo split like x
+                        _Float16 hh, ll;
+                        vkn_split_f16(row_ok ? mr[i][k] : 0.f, hh, ll);
+                        m[k] = hh;
+                        ml[k] = ll;
+                    } else {
+                        m[k] = (row_ok && mr[i][k] >= thr) ? (_Float16)1.f : (_Float16)0.f;
+                    }
+                }
                 *reinterpret_cast<half4*>(mk + (idx >> 3) * GA_LDR + ((idx & 7) << 2)) = m;
+                if (REAL) *reinterpret_cast<half4*>(mk + (NB * 32 + (idx >> 3)) * GA_LDR + ((idx & 7) << 2)) = ml;
             }
         }
     };
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     half8 a;
-                    if (BITS) {
+                    if (BITS == 1) {
                         const unsigned we = reinterpret_cast<const unsigned*>(mk)[nb * 32 + li];
                         const unsigned wo = reinterpret_cast<const unsigned*>(mk)[NB * 32 + nb * 32 + li];
                         a = lut[((we >> bsh) & 0xFu) | (((wo >> bsh) & 0xFu) << 4)];
@@ -214,11 +227,15 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                     }
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[nb], 0, 0, 0);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
+                    if (REAL) {  // a = a_hi here: + a_lo * x_hi (a_lo * x_lo is below fp32 resolution)
+                        const half8 al = *reinterpret_cast<const half8*>(mk + (NB * 32 + nb * 32 + li) * GA_LDR + off);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[nb], 0, 0, 0);
+                    }
                 }
             }
             if (has_cnt) {
                 half8 a;
-                if (BITS) {
+                if (BITS == 1) {
                     const unsigned we = reinterpret_cast<const unsigned*>(mk)[wave * 32 + li];
                     const unsigned wo = reinterpret_cast<const unsigned*>(mk)[NB * 32 + wave * 32 + li];
                     a = lut[((we >> bsh) & 0xFu) | (((wo >> bsh) & 0xFu) << 4)];
@@ -226,6 +243,10 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                     a = *reinterpret_cast<const half8*>(mk + (wave * 32 + li) * GA_LDR + off);
                 }
                 accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accc, 0, 0, 0);
+                if (REAL) {  // `cnt` = sum_p a (hi + lo)
+                    const half8 al = *reinterpret_cast<const half8*>(mk + (NB * 32 + wave * 32 + li) * GA_LDR + off);
+                    accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ones, accc, 0, 0, 0);
+                }
             }
         }
     };
@@ -478,8 +499,11 @@ __global__ __launch_bounds__(256) void k_gather_ref(const float* __restrict__ x,
     }
 }
 
-static int ga_set_lds(const void* fn, size_t bytes) {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+int vkn_launch_gather_reduce(const float* part, const float* cntp, float* xraw, float* cnt, int B, int N, int C, int G,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(64), 0, stream, part, cntp, xraw, cnt, N, (N + 31) / 32 * 32, C, G);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
 }
 
 // number of per-frame partials the launcher will produce for (B, P) — workspace sizing
@@ -506,6 +530,12 @@ int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* x
     return gather_launch(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 0, stream);
 }
 
+// REAL-valued left operand a [B][mask_rows][P] (first N rows used): xraw = sum_p a x, cnt = sum_p a
+int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C,
+                           int P, int mask_rows, hipStream_t stream) {
+    return gather_launch(x, a, 0.f, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 2, stream);
+}
+
 // binary operand given as bit words [B][P/64][2][roundup(N,32)] (vkn_launch_decode_bits); P % 64 == 0
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
                            int C, int P, hipStream_t stream) {
@@ -524,8 +554,8 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
     int px_per_wg = (P + wg_per_frame - 1) / wg_per_frame;
     px_per_wg = (px_per_wg + GA_PT - 1) / GA_PT * GA_PT;
     const int G = (P + px_per_wg - 1) / px_per_wg;
-    const int ileave = ((P % 64) == 0 && !(getenv("VKN_GATHER_ILEAVE") && atoi(getenv("VKN_GATHER_ILEAVE")) == 0)) ? 1 : 0;
-    const bool wave_indep = bits && !(getenv("VKN_GATHER_BITS_W") && atoi(getenv("VKN_GATHER_BITS_W")) == 0) && (C % 32) == 0 &&
+    const int ileave = ((P % 64) == 0 && vkn_dbg_env("VKN_GATHER_ILEAVE", 1) != 0) ? 1 : 0;
+    const bool wave_indep = bits == 1 && vkn_dbg_env("VKN_GATHER_BITS_W", 1) != 0 && (C % 32) == 0 &&
                             (px_per_wg % 64) == 0;
     for (int n0 = 0; n0 < NPT; n0 += 128) {
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
@@ -535,7 +565,7 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
             const unsigned* bw = reinterpret_cast<const unsigned*>(masks);
 #define GA_WLAUNCH(NBV)                                                                                              \
     case NBV:                                                                                                        \
-        if (ga_set_lds((const void*)k_gather_bits_w<NBV>, ldsw)) return VKN_E_LAUNCH;                               \
+        VKN_ALLOW_FULL_LDS(k_gather_bits_w<NBV>);                                                                    \
         hipLaunchKernelGGL(k_gather_bits_w<NBV>, grid, block, ldsw, stream, x, bw, part, cntp, N, NPT, n0, C, P, px_per_wg, ileave); \
         break;
             switch (nb) {
@@ -550,16 +580,17 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
             VKN_CHECK_LAUNCH();
             continue;
         }
-        const size_t lds = (size_t)2 * (2 * C + nb * 32) * GA_LDR * sizeof(_Float16) + (bits ? 4096 : 0);
+        const size_t lds = (size_t)2 * (2 * C + (bits == 2 ? 2 : 1) * nb * 32) * GA_LDR * sizeof(_Float16) + (bits == 1 ? 4096 : 0);
 #define GA_LAUNCH(NBV, BV)                                                                                       \
     do {                                                                                                         \
-        if (ga_set_lds((const void*)k_gather_mfma<NBV, BV>, lds)) return VKN_E_LAUNCH;                           \
+        VKN_ALLOW_FULL_LDS((k_gather_mfma<NBV, BV>));                                                            \
         hipLaunchKernelGGL((k_gather_mfma<NBV, BV>), grid, block, lds, stream, x, masks, thr, part, cntp, N, NPT, n0, C, P, \
                            px_per_wg, mask_fs, ileave);                                                          \
     } while (0)
 #define GA_CASE(NBV)                       \
     case NBV:                              \
-        if (bits) GA_LAUNCH(NBV, 1);       \
+        if (bits == 2) GA_LAUNCH(NBV, 2);  \
+        else if (bits) GA_LAUNCH(NBV, 1);  \
         else GA_LAUNCH(NBV, 0);            \
         break;
         switch (nb) {

@@ -44,8 +44,17 @@ int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* x
                          int B, int N, int C, int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_ref_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                              int P, int mask_rows, hipStream_t stream);
+int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C,
+                           int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
                            int C, int P, hipStream_t stream);
+int vkn_launch_gather_reduce(const float* part, const float* cntp, float* xraw, float* cnt, int B, int N, int C, int G,
+                             hipStream_t stream);
+// stage s decode fused with the stage s + 1 gather (vkn_fused.hip)
+int vkn_fused_supported(int C, int P);
+int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float thr,
+                                   float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C, int P,
+                                   hipStream_t stream);
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
                       int B, int N, int C, int P, hipStream_t stream);
 int vkn_launch_gather_ref(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,

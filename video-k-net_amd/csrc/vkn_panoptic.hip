@@ -19,7 +19,6 @@
 // atomics (order-independent => deterministic).
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include <stdlib.h>
 
 #include "../../include/vkn.h"
 #include "vkn_common.h"
@@ -540,11 +539,10 @@ int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const f
     int KC = (int)(budget / ln_bytes);
     if (KC >= K) KC = K;
     lds += (size_t)KC * ln_bytes;
-    if (hipFuncSetAttribute((const void*)k_pan_argmax, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return VKN_E_LAUNCH;
+    VKN_ALLOW_FULL_LDS(k_pan_argmax);
     dim3 grid((c->Wo + PAN_TW - 1) / PAN_TW, (c->Ho + PAN_TH - 1) / PAN_TH, B);
     hipLaunchKernelGGL(k_pan_argmax, grid, dim3(PAN_THREADS), lds, st, g, masks, sel_row, sel_score, K, N, panoptic_seg, area, orig, err,
-                       getenv("VKN_PAN_NOPRUNE") ? 0 : 1, KC);  // debugging knob: visit all K kernels in every tile
+                       vkn_dbg_env("VKN_PAN_NOPRUNE", 0) ? 0 : 1, KC);  // debug build only: visit all K kernels in every tile
     VKN_CHECK_LAUNCH();
 
     hipLaunchKernelGGL(k_pan_merge, dim3(B), dim3(64), (size_t)K * 6 * 4, st, sel_row, sel_label, sel_score, order, area, orig, K, T,

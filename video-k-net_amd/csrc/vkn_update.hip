@@ -21,7 +21,6 @@
 //   k_upsample  bilinear, align_corners=False, integer scale.
 #include "vkn_common.h"
 #include "vkn_launch.h"
-#include <stdlib.h>
 
 
 #define GM_THREADS 512
@@ -607,8 +606,7 @@ int vkn_launch_ffn_fused(const float* X, int ldx, const void* W1s, const float* 
                          float* partial, const VknEpi& epi2, hipStream_t stream) {
     if (C != 256 || FF % (256 * HS) != 0 || HS < 1 || (ldx % 4) != 0) return VKN_E_SHAPE;
     const size_t lds = (size_t)(2 * GS_WTILE + 2 * GS_ATILE + 3 * GM_BM * FF_HLD) * sizeof(__bf16);
-    if (hipFuncSetAttribute((const void*)k_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return VKN_E_LAUNCH;
+    VKN_ALLOW_FULL_LDS(k_ffn_fused);
     hipLaunchKernelGGL(k_ffn_fused, dim3(HS, (M + GM_BM - 1) / GM_BM), dim3(GM_THREADS), lds, stream, X, ldx,
                        static_cast<const __bf16*>(W1s), b1, static_cast<const __bf16*>(W2s), M, C, FF, HS, partial);
     VKN_CHECK_LAUNCH();
@@ -863,8 +861,7 @@ int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int
     }
     if (split) {
         const size_t lds = (size_t)(2 * GS_WTILE + 2 * GS_ATILE) * sizeof(__bf16);
-        if (hipFuncSetAttribute((const void*)k_gemm_s3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return VKN_E_LAUNCH;
+        VKN_ALLOW_FULL_LDS(k_gemm_s3);
         int nmax = probs[0].Nout;
         if (nprob > 1 && probs[1].Nout > nmax) nmax = probs[1].Nout;
         dim3 grid((nmax + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, nprob > 1 ? nprob : ksplit);
@@ -1056,8 +1053,7 @@ int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, i
         const int chunk = (planes - done > 32768) ? 32768 : planes - done;
         const float* ip = in + (size_t)done * H * W;
         float* op = out + (size_t)done * H * S * W * S;
-        const char* ue = getenv("VKN_UPSAMPLE");  // debugging: 0 = generic kernel; 1x/2x = staged nt/plain stores, x = 1|4 groups
-        const int mode = ue ? atoi(ue) : 14;
+        const int mode = vkn_dbg_env("VKN_UPSAMPLE", 14);  // debug build only: 0 = generic kernel; 1x/2x = staged nt/plain stores, x = 1|4 groups
         const bool staged = mode != 0 && (S == 2 || S == 4) && ((W * S) % 4) == 0 && (reinterpret_cast<uintptr_t>(op) & 15) == 0;
         if (staged) {
             const bool nt = mode / 10 != 2;

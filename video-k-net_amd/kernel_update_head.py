@@ -170,6 +170,22 @@ class KernelUpdateHead(nn.Module):
             self._pack_sig = sig
         return self._pack
 
+    def invalidate_pack(self):
+        """Drop the cached C-ABI weight pack (pre-split bf16x3 images, composite weights).  The cache is keyed on every
+        parameter's (data_ptr, _version); in-place writes through `param.data` (EMA hooks, some optimizers) bump neither — call
+        this after such writes.  `load_state_dict` and `train()` / `eval()` transitions call it automatically."""
+        self._pack = None
+        self._pack_sig = None
+
+    def train(self, mode=True):
+        if mode != self.training:
+            self.invalidate_pack()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_pack()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def make_dims(self, B, N, H, W):
         return ops.make_dims(B, N, self.in_channels, H, W, self.num_heads, self.feedforward_channels,
                              self.fc_cls.out_features, self.num_cls_fcs, self.num_mask_fcs, self.hard_mask_thr,

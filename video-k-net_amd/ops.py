@@ -210,12 +210,15 @@ class StagePack:
         self.device = device
         self._prep = None
         self._prep_key = None
+        self._ready = None      # event recorded after vkn_prepare_stage_f32: other streams wait on it before using `prepared`
 
     def ensure_prepared(self, dims):
         """Pre-split every Linear weight into three bf16 terms (vkn_prepare_stage_f32) once per (pack, shape): the
         [N x C] GEMMs then run on bf16 MFMA with fp32-class accuracy instead of exact-fp32 MFMA."""
         key = (dims.C, dims.ff, dims.ncls, dims.n_cls_fcs, dims.n_mask_fcs)
         if self._prep is not None and self._prep_key == key:
+            if self._ready is not None and not self._ready.query():
+                torch.cuda.current_stream(self.device).wait_event(self._ready)   # prepared on another stream, still in flight
             return
         L = _lib.lib()
         self.w.prepared, self.w.prepared_bytes = None, 0
@@ -225,6 +228,8 @@ class StagePack:
         buf = torch.empty(nb, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
             check(L.vkn_prepare_stage_f32(ctypes.byref(dims), ctypes.byref(self.w), _ptr(buf), nb, _stream()))
+            self._ready = torch.cuda.Event()
+            self._ready.record(torch.cuda.current_stream(self.device))
         self._prep, self._prep_key = buf, key
         self.w.prepared, self.w.prepared_bytes = buf.data_ptr(), nb
 
@@ -325,6 +330,22 @@ def mask_decode_planes(x, hi, lo, N, bias=None, out=None):
         check(_lib.lib().vkn_mask_decode_planes_f32(_ptr(x), _ptr(hi), _ptr(lo), _ptr(bias), _ptr(out), B, N, C, H * W,
                                                     _stream()))
     return out
+
+
+def decode_gather(x, hi, lo, N, bias=None, hard_mask_thr=0.5):
+    """Stage s decode fused with the stage s + 1 gather, one pass over x: (xraw [B,N,C], cnt [B,N]) of the masks
+    `bias + K.x >= thr` without materialising them (bit-identical to mask_decode_planes + mask_gather)."""
+    x = _req(x, 'x')
+    B, C, H, W = x.shape
+    P = H * W
+    L = _lib.lib()
+    xraw = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+    cnt = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    ws = _workspace(L.vkn_gather_workspace_bytes(B, N, C, P), x.device)
+    with torch.cuda.device(x.device):
+        check(L.vkn_decode_gather_f32(_ptr(x), _ptr(hi), _ptr(lo), _ptr(bias), thr_logit(hard_mask_thr), _ptr(xraw), _ptr(cnt),
+                                      B, N, C, P, _ptr(ws), ws.numel(), _stream()))
+    return xraw, cnt
 
 
 def track_link(dims: VknDims, pack: StagePack, cur_obj, prev_obj):
@@ -448,6 +469,10 @@ def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, d
     cls = _req(cls_logits, 'cls_pred') if cls_logits is not None else None
     ncls = cls.shape[1] if cls is not None else 0
     lab = gt_labels.to(device=m.device, dtype=torch.int32).contiguous()
+    if cls is not None and lab.numel() and (int(lab.min()) < 0 or int(lab.max()) >= ncls):
+        # the reference's `cls_pred[:, gt_labels]` raises an IndexError for such labels (ignore label 255, stuff label against
+        # thing-only logits); an unchecked device read would silently produce garbage costs
+        raise IndexError(f'gt_labels outside [0, {ncls}): {int(lab.min())} .. {int(lab.max())}')
     cfg = _lib.VknAssignCfg(float(cls_weight), float(dice_weight), float(mask_weight), float(focal_alpha), float(focal_gamma),
                             float(focal_eps), float(dice_eps))
     L = _lib.lib()
