@@ -20,7 +20,7 @@
 #define DEC_THREADS 512
 #define DEC_WAVES 8
 #define DEC_TILE 64  // pixels per wave tile: two interleaved 32-column MFMA strips (even / odd pixels)
-#define DEC_OPT_DEFAULT 0  // round-2 variants of k_decode_mfma compiled into the release library (see OPT below)
+#define DEC_OPT_DEFAULT 1  // round-2 variants of k_decode_mfma compiled into the release library (see OPT below)
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
 // every wave) was built and validated, and measured SLOWER (113 us vs 94 us at cfg2, B = 8): the read and write streams
 // already share the memory system at ~4.2 TB/s combined whatever their interleaving (tools/decode_ablation.py).
 
+#ifdef VKN_DEBUG
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_decode4 — the same contraction with 16-BYTE global accesses (round 2).
 //
@@ -330,6 +331,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
 //     HBM latency that a second wave per SIMD used to hide.
 // Per output element the MFMA sequence is the one of k_decode_mfma (kb, then per 16 channels hi*hi, hi*lo, lo*hi), so both
 // kernels produce bit-identical logits.  Needs P % 128 == 0 and C % 64 == 0 (every shipped config); other shapes use k_decode_mfma.
+//
+// MEASURED (tools/perf_r02.py, cfg2, 32 frames per launch): 366-404 us against 326-345 us for k_decode_mfma — the lane-rate model
+// above does NOT hold for this kernel, and one wave per SIMD cannot overlap its own VALU split with its MFMAs.  Negative result:
+// compiled into the DEBUG library only (VKN_DECODE4=1), for the record and for further experiments.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define D4_THREADS 256
@@ -451,35 +456,40 @@ __global__ __launch_bounds__(D4_THREADS, 1) void k_decode4(const float* __restri
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc[s][nb][r] = kb_;
             }
+        // sched_barrier: with registers to spare the machine scheduler renames the ring and hoists all four loads to the top of
+        // the unrolled body (then drains to vmcnt(0) at its end); pinned, every compute waits with vmcnt(24) = 3 fragments in flight
         for (int ks = 0; ks < KS; ks += 4) {
             D4_LOAD(r3);
+            __builtin_amdgcn_sched_barrier(0);
             D4_COMPUTE(r0, ks);
+            __builtin_amdgcn_sched_barrier(0);
             D4_LOAD(r0);
+            __builtin_amdgcn_sched_barrier(0);
             D4_COMPUTE(r1, ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
             D4_LOAD(r1);
+            __builtin_amdgcn_sched_barrier(0);
             D4_COMPUTE(r2, ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
             D4_LOAD(r2);
+            __builtin_amdgcn_sched_barrier(0);
             D4_COMPUTE(r3, ks + 3);
+            __builtin_amdgcn_sched_barrier(0);
         }
         const int p0 = p_begin + (wave + D4_WAVES * t) * D4_TILE;
         const int vst = ((4 * g) * P + 4 * li) << 2;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            if (n0 + nb * 32 + 32 <= N) {  // full n-block (uniform): no per-row guard
+            {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);
                     const float a0 = acc[0][nb][r], a1 = acc[1][nb][r], a2 = acc[2][nb][r], a3 = acc[3][nb][r];
                     const u32x4 v = {__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), __float_as_uint(a3)};
-                    __builtin_amdgcn_raw_buffer_store_b128(v, ors, vst, (row * P + p0) << 2, 0);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);
-                    const float a0 = acc[0][nb][r], a1 = acc[1][nb][r], a2 = acc[2][nb][r], a3 = acc[3][nb][r];
-                    const u32x4 v = {__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), __float_as_uint(a3)};
-                    if (row + 4 * g < N) __builtin_amdgcn_raw_buffer_store_b128(v, ors, vst, (row * P + p0) << 2, 0);
+                    // rows >= N: the lane's offset is pushed past num_records (N * P * 4 < 2^31) -> the hardware drops the store;
+                    // branch-free on purpose (per-row exec branches made hipcc route every store vector through scratch)
+                    const int vo = (row + 4 * g < N) ? vst : 0x7FFFFFF0;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ors, vo, (row * P + p0) << 2, 0);
                 }
             }
         }
@@ -487,6 +497,8 @@ __global__ __launch_bounds__(D4_THREADS, 1) void k_decode4(const float* __restri
 #undef D4_LOAD
 #undef D4_COMPUTE
 }
+
+#endif  // VKN_DEBUG (k_decode4)
 
 // Exact-fp32 debug / fallback kernel: one thread per (n, px), k-ordered fmaf chain.
 __global__ __launch_bounds__(256) void k_decode_ref(const float* __restrict__ x, const float* __restrict__ kern,
@@ -557,14 +569,16 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
     if (ppw_dbg >= 512) px_per_wg = ppw_dbg / 512 * 512;
     const int G2 = (P + px_per_wg - 1) / px_per_wg;
     const int xcd = vkn_dbg_env("VKN_DECODE_XCD", 1);  // measured +1 % (tools/decode_sweep.py)
-    // 16-byte variant: whole 128-px tiles and 16-byte aligned rows; the logits output only (the bit-packed hand-off lives in the
-    // fused decode -> gather kernel, vkn_fused.hip)
+    // (debug build) 16-byte variant k_decode4: whole 128-px tiles and 16-byte aligned rows; the logits output only
+#ifdef VKN_DEBUG
     const bool wide = !bits_out && (P % D4_TILE) == 0 && (C % 64) == 0 && vkn_dbg_env("VKN_DECODE4", 0) != 0 &&
                       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+#endif
     for (int n0 = 0; n0 < NPT; n0 += 128) {
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
         const size_t lds = (size_t)2 * nb * 32 * (C + 8) * sizeof(_Float16) + (size_t)nb * 32 * sizeof(float);
         dim3 grid(G2, B, 1);
+#ifdef VKN_DEBUG
         if (wide) {
 #define D4_CASE(NBV)                                                                                                       \
     case NBV: {                                                                                                            \
@@ -584,6 +598,7 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
             VKN_CHECK_LAUNCH();
             continue;
         }
+#endif
         dim3 block(DEC_THREADS);
 #define DEC_LAUNCH_O(NBV, ABLV, RINGV, BITSV, OPTV)                                                            \
     do {                                                                                                       \
