@@ -108,6 +108,16 @@ size_t vkn_gather_workspace_bytes(int B, int N, int C, int P);
 int vkn_mask_gather_f32(const float* x, const float* mask_logits, float thr_logit, float* xraw_out, float* cnt_out, int B,
                         int N, int C, int P, void* ws, size_t ws_bytes, unsigned flags, void* stream);
 
+/* ---- op (i) with a REAL-valued left operand:  out[b][n][c] = sum_p a[b][n][p] x[b][c][p],  asum[b][n] = sum_p a[b][n][p].
+ *      Same kernel as vkn_mask_gather_f32 with the mask operand split hi/lo in f16 like x (k_gather_mfma<., 2>).  Three users:
+ *      (1) the BACKWARD of the mask decode w.r.t. the kernels, dK = dM . x^T (SURVEY.md §8(a) footnote; the autograd of
+ *      `F.conv2d(mask_x, mask_feat)` knet/det/kernel_update_head.py:247-260), asum = the bias gradient; (2) soft ground-truth
+ *      masks in the assignment costs (knet/det/mask_hungarian_assigner.py:44-54,100-108); (3) `use_binary=False` gather weights
+ *      in the kernel-initialisation pass (knet/det/kernel_head.py:243-250).  Requires |a|, |x| < 65504; absolute resolution of a is
+ *      6e-8 (f16 subnormal): callers with tiny operands (gradients) scale by a power of two first.  ws: vkn_gather_workspace_bytes. */
+int vkn_mask_gather_real_f32(const float* x, const float* a, float* out, float* asum_out, int B, int N, int C, int P, void* ws,
+                             size_t ws_bytes, void* stream);
+
 /* ---- op (iii): mask decode.  Replaces the per-image loop `F.conv2d(mask_x[i:i+1], mask_feat[i], padding=K//2)`, K = 1
  *      knet/det/kernel_update_head.py:247-260.   out[b][n][p] = sum_c kernels[b][n][c] x[b][c][p] + bias[b][n]
  *      kernels [B][N][C] fp32, bias [B][N] or NULL, out [B][N][P].  ws: vkn_decode_workspace_bytes (f16 planes). */

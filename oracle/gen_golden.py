@@ -41,6 +41,8 @@ import knet.video.kernel_update_head  # noqa: E402,F401
 import knet.video.kernel_iter_head  # noqa: E402,F401
 import knet.det.kernel_head  # noqa: E402,F401  (ConvKernelHead: the kernel-initialisation pass)
 import knet.det.mask_hungarian_assigner  # noqa: E402,F401  (MaskHungarianAssigner, DiceCost, MaskCost)
+import knet.det.mask_pseudo_sampler  # noqa: E402,F401  (MaskPseudoSampler)
+import knet.cross_entropy_loss  # noqa: E402,F401  (the reference's own CrossEntropyLoss, registered with force=True)
 from mmdet.models.builder import NECKS, build_head  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
@@ -314,6 +316,123 @@ def run_assign_case(name, p):
     print(f'{name}: ok  matched {int((res.gt_inds > 0).sum())} of {p["N"]} kernels to {p["G"]} ground truths')
 
 
+TRAIN_CASES = {
+    # det head, panoptic targets (thing gt + stuff sem targets), soft-edged gt masks
+    'train_tiny': dict(video=False, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=3, up=2, nprop=12, N=15, H=8, W=16, B=2,
+                       seed=71),
+    # video head: last-stage link to the previous frame's kernels (forward_train_with_previous), x4 upsample
+    'train_video': dict(video=True, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=4, nprop=12, N=15, H=8, W=16, B=2,
+                        seed=72),
+    # config channels / kernel count
+    'train_cfg': dict(video=False, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=2, nprop=100, N=117, H=16, W=32,
+                      B=2, seed=73),
+}
+TRAIN_GRAD_KEYS = ('mask_head.0.feat_transform.conv.weight', 'mask_head.0.feat_transform.conv.bias',
+                   'mask_head.0.kernel_update_conv.dynamic_layer.weight', 'mask_head.0.attention.attn.in_proj_weight',
+                   'mask_head.0.ffn.layers.1.weight', 'mask_head.1.fc_mask.weight', 'mask_head.1.fc_cls.bias',
+                   'mask_head.1.kernel_update_conv.fc_norm.weight', 'mask_head.1.mask_fcs.0.weight')
+
+
+def run_train_case(name, p):
+    """`forward_train` / `forward_train_with_previous` of the reference (knet/det/kernel_iter_head.py:139-231,
+    knet/video/kernel_iter_head.py:255-376) with the shipped train_cfg: per-stage losses, the assignments, and the gradients
+    of the summed loss w.r.t. x, proposal_feats and a sample of the parameters."""
+    p = dict(p)
+    N, H, W, B, seed = (p.pop(k) for k in ('N', 'H', 'W', 'B', 'seed'))
+    video = p['video']
+    cfg = head_cfg(**p)
+    cfg['train_cfg'] = [AttrDict(assigner=dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                               dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                               mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)),
+                                 sampler=dict(type='MaskPseudoSampler'), pos_weight=1) for _ in range(p['S'])]
+    head = build_head(cfg)
+    head.train()
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    load_formula_weights(head, shapes, seed)
+    x, pf, mp = (torch.from_numpy(a) for a in synth.head_inputs(B, N, p['C'], H, W, seed))
+    x.requires_grad_(True)
+    pf.requires_grad_(True)
+    tg = synth.train_targets(B, p['n_thing'], p['n_stuff'], H * p['up'], W * p['up'], seed)
+    gt_masks = [torch.from_numpy(t['gt_masks']) for t in tg]
+    gt_labels = [torch.from_numpy(t['gt_labels']) for t in tg]
+    gt_sem_seg = [torch.from_numpy(t['gt_sem_seg']) for t in tg]
+    gt_sem_cls = [torch.from_numpy(t['gt_sem_cls']) for t in tg]
+    metas = [dict() for _ in range(B)]
+    # record the assignment of every stage
+    assigned = []
+    for a in head.mask_assigner:
+        orig = a.assign
+
+        def rec(*args, _orig=orig, **kw):
+            r = _orig(*args, **kw)
+            assigned.append(r.gt_inds.clone())
+            return r
+        a.assign = rec
+    if video:
+        prev = torch.from_numpy(synth.normalish((B, N, p['C'], 1, 1), 99 + seed, 1.0))
+        out = head.forward_train_with_previous(x, pf, mp, None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                               gt_sem_cls=gt_sem_cls, previous_obj_feats=prev)
+        losses, track = out[0], out[5]
+    else:
+        losses = head.forward_train(x, pf, mp, None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+        track = None
+    total = sum(v for k, v in losses.items() if 'loss' in k)
+    if track is not None:
+        total = total + 0.01 * (track ** 2).sum()     # makes the link's parameters part of the graph
+    total.backward()
+    out = dict(case=np.array([p['C'], p['heads'], p['ffn'], p['ncls'], p['n_thing'], p['n_stuff'], p['S'], p['up'], p['nprop'], N, H,
+                              W, B, seed, int(video)], dtype=np.int64),
+               loss_keys=np.array(sorted(losses)), loss_vals=np.array([float(losses[k]) for k in sorted(losses)], dtype=np.float64),
+               total=np.float64(float(total)), assigned=torch.stack(assigned).numpy())
+    big = p['C'] > 64
+
+    def put(tag, t):
+        """full tensor for the small cases; 4096 sampled elements + the norm for the config-size case"""
+        t = t.detach()
+        if not big or t.numel() <= 8192:
+            out[tag] = t.numpy()
+        else:
+            idx = (synth.uniform((4096,), 5151 + len(tag), 0.0, 1.0).astype(np.float64) * t.numel()).astype(np.int64)
+            out[tag + '_idx'], out[tag + '_val'] = idx, t.reshape(-1)[idx].numpy()
+            out[tag + '_norm'] = np.float64(float(t.double().norm()))
+    put('grad_x', x.grad)
+    put('grad_pf', pf.grad)
+    named = dict(head.named_parameters())
+    gk = [k for k in TRAIN_GRAD_KEYS if k in named]
+    if video:
+        gk += ['mask_head.%d.attention_previous.attn.in_proj_weight' % (p['S'] - 1), 'mask_head.%d.link_ffn.layers.1.weight' % (p['S'] - 1)]
+    out['grad_keys'] = np.array(gk)
+    for i, k in enumerate(gk):
+        put(f'grad_{i}', named[k].grad)
+    # every parameter's gradient norm (cheap completeness check)
+    out['all_keys'] = np.array(sorted(named))
+    out['all_gnorm'] = np.array([float(named[k].grad.double().norm()) if named[k].grad is not None else -1.0 for k in sorted(named)])
+    if track is not None:
+        out['track'] = track.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(f'{name}: ok  total={float(total):.5f}  ' + ' '.join(f'{k}={float(v):.4f}' for k, v in sorted(losses.items())[:6]))
+
+
+def run_assign_soft():
+    """MaskHungarianAssigner with SOFT ground-truth masks (bilinearly down-sampled, knet/det/knet.py:131): the costs use the real
+    values of the targets, not their binarisation."""
+    from mmdet.core import build_assigner
+    assigner = build_assigner(dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                   dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                   mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)))
+    N, G, ncls, H, W, seed = 30, 9, 3, 32, 64, 54
+    logits, cls, gt, labels = (torch.from_numpy(a) for a in synth.assign_inputs(N, G, ncls, 2 * H, 2 * W, seed))
+    logits = F.interpolate(logits[None], size=(H, W), mode='bilinear', align_corners=False)[0]
+    gt = F.interpolate(gt[None], size=(H, W), mode='bilinear', align_corners=False)[0]      # soft borders: values in {0, .25, .5, .75, 1}
+    with torch.no_grad():
+        res = assigner.assign(logits, cls, gt, labels)
+        cost = assigner.cls_cost(cls, labels) + assigner.mask_cost(logits, gt) + assigner.dice_cost(logits, gt)
+    np.savez_compressed(os.path.join(OUT, 'assign_soft.npz'), case=np.array([N, G, ncls, H, W, seed], dtype=np.int64),
+                        gt_inds=res.gt_inds.numpy(), labels=res.labels.numpy(), cost=cost.numpy(),
+                        soft_fraction=np.float64(float(((gt > 0) & (gt < 1)).float().mean())))
+    print(f'assign_soft: ok  soft pixels {float(((gt > 0) & (gt < 1)).float().mean()):.3f}')
+
+
 def thr_kat():
     """(sigmoid(z) > 0.5) as the reference computes it (knet/det/kernel_update_head.py:190-191) — torch CPU fp32.
     The flip point is not z=0: it depends on the fp32 sigmoid (SURVEY.md §7 'Threshold semantics')."""
@@ -354,6 +473,11 @@ if __name__ == '__main__':
     for name, p in ASSIGN_CASES.items():
         if not only or name in only:
             run_assign_case(name, p)
+    for name, p in TRAIN_CASES.items():
+        if not only or name in only:
+            run_train_case(name, p)
+    if not only or 'assign_soft' in only:
+        run_assign_soft()
     if not only or 'init_keys' in only:
         init_keys()
     if not only or 'thr_kat' in only:

@@ -31,6 +31,10 @@ class AssignResult:
         self.gt_inds = gt_inds
         self.max_overlaps = max_overlaps
         self.labels = labels
+        self._extra_properties = {}
+
+    def set_extra_property(self, key, value):
+        self._extra_properties[key] = value
 
 
 class BaseAssigner:

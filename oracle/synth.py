@@ -107,3 +107,33 @@ def assign_inputs(N, G, ncls, H, W, seed):
     gt = (logits[pick] + normalish((G, H, W), 63 + 13 * seed, 1.0) > 0.5).astype(np.float32)
     labels = (uniform((G,), 64 + 13 * seed, 0.0, 1.0).astype(np.float64) * ncls).astype(np.int64)
     return logits.astype(np.float32), cls.astype(np.float32), gt, labels
+
+
+def train_targets(B, n_thing, n_stuff, Hs, Ws, seed, gmin=2, gmax=5, soft=True):
+    """Ground truth of one training batch at the resolution of the up-scaled mask predictions: per image a list entry with
+    thing masks [G_i, Hs, Ws] (elliptic blobs; `soft` leaves bilinear-like soft borders, values in [0, 1], as the reference's
+    down-sampled gt masks have — knet/det/knet.py:131), thing labels [G_i], and the stuff targets gt_sem_cls [S_i] (labels in
+    [n_thing, n_thing + n_stuff)) with band masks gt_sem_seg [S_i, Hs, Ws]."""
+    out = []
+    ys = ((np.arange(Hs) + 0.5) / Hs)[None, :, None]
+    xs = ((np.arange(Ws) + 0.5) / Ws)[None, None, :]
+    for b in range(B):
+        sd = 7001 + 131 * seed + 17 * b
+        G = gmin + int(uniform((1,), sd, 0.0, 1.0)[0] * (gmax - gmin + 1) * 0.999)
+        cx = uniform((G, 1, 1), sd + 1, 0.15, 0.85).astype(np.float64)
+        cy = uniform((G, 1, 1), sd + 2, 0.15, 0.85).astype(np.float64)
+        rx = uniform((G, 1, 1), sd + 3, 0.08, 0.3).astype(np.float64)
+        ry = uniform((G, 1, 1), sd + 4, 0.08, 0.3).astype(np.float64)
+        d = np.sqrt(((xs - cx) / rx) ** 2 + ((ys - cy) / ry) ** 2)
+        gt = np.clip((1.0 - d) * (4.0 if soft else 1e6) + 0.5, 0.0, 1.0).astype(np.float32)
+        labels = (uniform((G,), sd + 5, 0.0, 1.0).astype(np.float64) * n_thing).astype(np.int64)
+        sem_cls, sem_seg = np.zeros((0,), np.int64), np.zeros((0, Hs, Ws), np.float32)
+        if n_stuff > 0:
+            present = uniform((n_stuff,), sd + 6, 0.0, 1.0) < 0.7
+            present[0] = True
+            idx = np.nonzero(present)[0]
+            sem_cls = (idx + n_thing).astype(np.int64)
+            sem_seg = np.stack([((ys[0] >= j / n_stuff) & (ys[0] < (j + 1) / n_stuff)).astype(np.float32).repeat(Ws, axis=1)
+                                for j in idx])
+        out.append(dict(gt_masks=gt, gt_labels=labels, gt_sem_cls=sem_cls, gt_sem_seg=sem_seg))
+    return out

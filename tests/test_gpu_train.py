@@ -1,0 +1,143 @@
+"""GPU (-m gpu): the TRAINING path — `forward_train` losses, assignments and gradients of the MI355X head against goldens captured
+from the reference's own `forward_train` (oracle/gen_golden.py: TRAIN_CASES), and the backward passes of the two x-streaming
+HIP ops against fp64 autograd on the device.
+
+Tolerances: losses 1e-4 relative (fp32 reductions over [num_pos, H, W]); assignments bit-exact; gradients 2e-3 of the tensor's
+max-abs (the forward's binarised masks are identical to the reference's on these cases, so gradients agree to fp32 accuracy).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, make_case, maxabs
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _rand(shape, salt, std=1.0):
+    return torch.from_numpy(synth.normalish(shape, salt, std))
+
+
+@pytest.mark.parametrize('shape', [(2, 15, 64, 8, 16), (1, 117, 256, 16, 32), (1, 166, 128, 8, 32)], ids=lambda s: 'x'.join(map(str, s)))
+def test_gather_decode_backward_vs_fp64_autograd(vkn, shape):
+    """dx, dK, dkb of `Z = K x + kb` and dx of `xraw = M x^T` from the HIP kernels (transposed-operand launches) vs torch fp64."""
+    B, N, C, H, W = shape
+    x = _rand((B, C, H, W), 501).to(DEV).requires_grad_(True)
+    k = _rand((B, N, C), 502, 0.3).to(DEV).requires_grad_(True)
+    kb = _rand((B, N), 503).to(DEV).requires_grad_(True)
+    gz = (_rand((B, N, H, W), 504) * 1e-4).to(DEV)               # small like a real mean-reduced loss gradient
+    z = vkn.autograd.mask_decode(x, k, kb)
+    z.backward(gz)
+    xd, kd, kbd = x.detach().double().requires_grad_(True), k.detach().double().requires_grad_(True), kb.detach().double().requires_grad_(True)
+    zr = torch.einsum('bnc,bchw->bnhw', kd, xd) + kbd[:, :, None, None]
+    zr.backward(gz.double())
+    assert maxabs(z, zr) < 1e-4
+    for got, ref in ((x.grad, xd.grad), (k.grad, kd.grad), (kb.grad, kbd.grad)):
+        assert maxabs(got, ref) < 2e-5 * float(ref.abs().max())
+    # gather: differentiable w.r.t. x only (the binarised mask carries no gradient, knet/det/kernel_update_head.py:191-192)
+    x2 = x.detach().clone().requires_grad_(True)
+    m = _rand((B, N, H, W), 505, 2.0).to(DEV).requires_grad_(True)
+    gx = (_rand((B, N, C), 506) * 1e-3).to(DEV)
+    xraw, cnt = vkn.autograd.mask_gather(x2, m, 0.5)
+    xraw.backward(gx)
+    bits = (m.detach() >= vkn.ops.thr_logit(0.5)).double()
+    ref = torch.einsum('bnhw,bnc->bchw', bits, gx.double())
+    assert maxabs(x2.grad, ref) < 2e-5 * float(ref.abs().max())
+    assert m.grad is None and not cnt.requires_grad
+
+
+def _train_case(vkn, name):
+    g = dict(np.load(f'{__import__("helpers").GOLDEN}/{name}.npz', allow_pickle=False))
+    from helpers import CASE_FIELDS
+    case = dict(zip(CASE_FIELDS, (int(v) for v in g['case'])))
+    cfgd = vkn.configs.roi_head_cfg(bool(case['video']), C=case['C'], heads=case['heads'], ffn=case['ffn'], ncls=case['ncls'],
+                                    n_thing=case['n_thing'], n_stuff=case['n_stuff'], S=case['S'], up=case['up'],
+                                    nprop=case['nprop'], train_cfg=vkn.configs.rcnn_train_cfg(case['S']))
+    head = vkn.build_head(cfgd)
+    _, sd, x, pf, mp, prev = make_case(case)
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV).train()
+    tg = synth.train_targets(case['B'], case['n_thing'], case['n_stuff'], case['H'] * case['up'], case['W'] * case['up'], case['seed'])
+    t = lambda key: [torch.from_numpy(e[key]).to(DEV) for e in tg]  # noqa: E731
+    return g, case, head, (x, pf, mp, prev), (t('gt_masks'), t('gt_labels'), t('gt_sem_seg'), t('gt_sem_cls'))
+
+
+def _check_grad(g, tag, got, tol=2e-3):
+    got = got.detach().cpu()
+    if tag in g:
+        ref = torch.from_numpy(g[tag])
+        assert maxabs(got, ref) < tol * max(float(ref.abs().max()), 1e-12), tag
+    else:
+        idx, val = torch.from_numpy(g[tag + '_idx']), torch.from_numpy(g[tag + '_val'])
+        assert maxabs(got.reshape(-1)[idx], val) < tol * max(float(val.abs().max()), 1e-12), tag
+        assert abs(float(got.double().norm()) - float(g[tag + '_norm'])) < tol * float(g[tag + '_norm']), tag
+
+
+@pytest.mark.parametrize('name', ['train_tiny', 'train_video', 'train_cfg'])
+def test_forward_train_vs_reference_golden(vkn, name):
+    """Losses (every `s{stage}_*` key), per-stage assignments and gradients vs the reference's forward_train."""
+    g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, name)
+    xd = x.to(DEV).requires_grad_(True)
+    pfd = pf.to(DEV).requires_grad_(True)
+    metas = [dict() for _ in range(case['B'])]
+    # record the assignments
+    assigned = []
+    for a in head.mask_assigner:
+        orig = a.assign
+
+        def rec(*args, _orig=orig, **kw):
+            r = _orig(*args, **kw)
+            assigned.append(r.gt_inds.clone())
+            return r
+        a.assign = rec
+    track = None
+    if case['video']:
+        out = head.forward_train_with_previous(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                               gt_sem_cls=gt_sem_cls, previous_obj_feats=prev.to(DEV))
+        losses, track = out[0], out[5]
+    else:
+        losses = head.forward_train(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                    gt_sem_cls=gt_sem_cls)
+    assert sorted(losses) == list(g['loss_keys'])
+    assert np.array_equal(torch.stack(assigned).cpu().numpy(), g['assigned']), 'Hungarian assignments must be bit-exact'
+    for k, ref in zip(g['loss_keys'], g['loss_vals']):
+        assert abs(float(losses[k]) - ref) < 1e-4 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
+    total = sum(v for k, v in losses.items() if 'loss' in k)
+    if track is not None:
+        assert maxabs(track, g['track']) < 1e-3
+        total = total + 0.01 * (track ** 2).sum()
+    assert abs(float(total) - float(g['total'])) < 1e-4 * abs(float(g['total']))
+    total.backward()
+    _check_grad(g, 'grad_x', xd.grad)
+    _check_grad(g, 'grad_pf', pfd.grad)
+    named = dict(head.named_parameters())
+    for i, k in enumerate(g['grad_keys']):
+        _check_grad(g, f'grad_{i}', named[str(k)].grad)
+    # every parameter received a gradient of the reference's norm
+    for k, ref in zip(g['all_keys'], g['all_gnorm']):
+        p = named[str(k)]
+        if ref < 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert p.grad is not None and abs(float(p.grad.double().norm()) - ref) < 5e-3 * max(ref, 1e-6), (k, ref)
+
+
+def test_soft_gt_assignment_vs_reference(vkn):
+    """Soft (bilinearly down-sampled) ground-truth masks: DiceCost / MaskCost use the REAL target values."""
+    g = dict(np.load(f'{__import__("helpers").GOLDEN}/assign_soft.npz', allow_pickle=False))
+    N, G, ncls, H, W, seed = (int(v) for v in g['case'])
+    import torch.nn.functional as F
+    logits, cls, gt, labels = (torch.from_numpy(a) for a in synth.assign_inputs(N, G, ncls, 2 * H, 2 * W, seed))
+    logits = F.interpolate(logits[None], size=(H, W), mode='bilinear', align_corners=False)[0]
+    gt = F.interpolate(gt[None], size=(H, W), mode='bilinear', align_corners=False)[0]
+    assert float(((gt > 0) & (gt < 1)).float().mean()) > 0.02
+    a = vkn.MaskHungarianAssigner(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                  mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    cost = a.cost_matrix(logits.to(DEV), cls.to(DEV), gt.to(DEV), labels.to(DEV))
+    assert maxabs(cost, g['cost']) < 2e-5
+    res = a.assign(logits.to(DEV), cls.to(DEV), gt.to(DEV), labels.to(DEV))
+    assert np.array_equal(res.gt_inds.cpu().numpy(), g['gt_inds']) and np.array_equal(res.labels.cpu().numpy(), g['labels'])
+    with pytest.raises(IndexError):
+        a.cost_matrix(logits.to(DEV), cls.to(DEV), gt.to(DEV), torch.full_like(labels, 255).to(DEV))

@@ -15,7 +15,7 @@ SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip'
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares
-SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_weights', 'vkn_gather_workspace_bytes', 'vkn_mask_gather_f32',
+SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_weights', 'vkn_gather_workspace_bytes', 'vkn_mask_gather_f32', 'vkn_mask_gather_real_f32',
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
            'vkn_decode_gather_supported', 'vkn_decode_gather_f32',
            'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
@@ -161,6 +161,8 @@ def lib():
     L.vkn_gather_workspace_bytes.argtypes = [c_int] * 4
     L.vkn_mask_gather_f32.restype = c_int
     L.vkn_mask_gather_f32.argtypes = [_fp, _fp, c_float, _fp, _fp, c_int, c_int, c_int, c_int, _fp, c_size, c_uint, _fp]
+    L.vkn_mask_gather_real_f32.restype = c_int
+    L.vkn_mask_gather_real_f32.argtypes = [_fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp, c_size, _fp]
     L.vkn_decode_workspace_bytes.restype = c_size
     L.vkn_decode_workspace_bytes.argtypes = [c_int] * 3
     L.vkn_mask_decode_f32.restype = c_int

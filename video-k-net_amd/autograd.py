@@ -1,0 +1,97 @@
+"""Differentiable wrappers of the two x-streaming HIP ops (training, BASELINE cfg3; SURVEY.md §8(a) footnote).
+
+The binarised mask carries no gradient (`.float()` of a bool, knet/det/kernel_update_head.py:191-192), so
+  * gather  xraw = M x^T           is differentiable w.r.t. x only:   dx  = M^T dxraw            (decode-shaped)
+  * decode  Z = K x + kb           w.r.t. both operands:              dK  = dZ x^T, dkb = sum dZ (gather-shaped, real operand)
+                                                                      dx  = K^T dZ              (decode-shaped)
+i.e. the backward passes are the SAME two kernel shapes with transposed operands: `vkn_mask_decode_f32` with the roles of
+channels and kernels swapped, and `vkn_mask_gather_real_f32`.  Gradient operands are scaled by a power of two into the f16
+hi/lo split's range first (exact in fp32) and the result is scaled back.
+"""
+import torch
+
+from . import ops
+
+
+def _pow2_scale(t, target=1024.0):
+    """Power of two s (device scalar tensor) with max|t| * s in [target / 2, target]; 1 for an all-zero tensor."""
+    m = t.detach().abs().amax()
+    e = torch.floor(torch.log2(torch.clamp(m, min=1e-30)))
+    s = torch.exp2(torch.clamp(torch.floor(torch.log2(torch.tensor(target, device=t.device))) - e, -100.0, 100.0))
+    return torch.where(m > 0, s, torch.ones_like(s))
+
+
+def _pad_rows(t, mult):
+    """[B, R, ...] -> rows padded with zeros to a multiple of `mult`."""
+    r = t.shape[1]
+    rp = (r + mult - 1) // mult * mult
+    if rp == r:
+        return t.contiguous()
+    pad = t.new_zeros((t.shape[0], rp - r) + tuple(t.shape[2:]))
+    return torch.cat([t, pad], dim=1).contiguous()
+
+
+def _decode_transposed(rows, kern_t):
+    """out[b, c, p] = sum_n kern_t[b, c, n] rows[b, n, p]: the decode kernel with `rows` [B, R, H, W] as its feature map
+    (R padded to the kernel's 16-channel contraction step) and `kern_t` [B, C, R] as its kernels."""
+    rows_p = _pad_rows(rows, 32)
+    k = kern_t
+    if rows_p.shape[1] != kern_t.shape[2]:
+        k = torch.cat([kern_t, kern_t.new_zeros(kern_t.shape[0], kern_t.shape[1], rows_p.shape[1] - kern_t.shape[2])], dim=2)
+    return ops.mask_decode(rows_p, k.contiguous())
+
+
+class MaskGatherFn(torch.autograd.Function):
+    """(xraw, cnt) = gather(x, bit(mask_logits)); backward: dx = bit^T dxraw."""
+
+    @staticmethod
+    def forward(ctx, x, mask_logits, hard_mask_thr):
+        xraw, cnt = ops.mask_gather(x, mask_logits, hard_mask_thr)
+        ctx.save_for_backward(mask_logits)
+        ctx.thr = ops.thr_logit(hard_mask_thr)
+        ctx.need_dx = x.requires_grad
+        ctx.mark_non_differentiable(cnt)
+        return xraw, cnt
+
+    @staticmethod
+    def backward(ctx, dxraw, _dcnt):
+        if not ctx.need_dx:
+            return None, None, None
+        (mask_logits,) = ctx.saved_tensors
+        bits = (mask_logits >= ctx.thr).to(torch.float32)              # [B, N, H, W], exactly {0, 1}
+        s = _pow2_scale(dxraw)
+        dx = _decode_transposed(bits, (dxraw * s).transpose(1, 2)) / s  # [B, C, H, W]
+        return dx, None, None
+
+
+class MaskDecodeFn(torch.autograd.Function):
+    """Z = decode(x, K, kb); backward: dK = dZ x^T, dkb = sum_p dZ, dx = K^T dZ."""
+
+    @staticmethod
+    def forward(ctx, x, kernels, bias):
+        out = ops.mask_decode(x, kernels, bias)
+        ctx.save_for_backward(x, kernels)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, kernels = ctx.saved_tensors
+        dz = dz.contiguous()
+        s = _pow2_scale(dz)
+        dzs = dz * s
+        dk = dkb = dx = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dk, dkb = ops.mask_gather_real(x, dzs)
+            dk, dkb = dk / s, dkb / s
+        if ctx.needs_input_grad[0]:
+            dx = _decode_transposed(dzs, kernels.transpose(1, 2)) / s
+        return dx, dk if ctx.needs_input_grad[1] else None, dkb if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+
+
+def mask_gather(x, mask_logits, hard_mask_thr=0.5):
+    return MaskGatherFn.apply(x, mask_logits, hard_mask_thr)
+
+
+def mask_decode(x, kernels, bias=None):
+    return MaskDecodeFn.apply(x, kernels, bias)

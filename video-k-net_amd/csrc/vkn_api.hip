@@ -482,6 +482,21 @@ int vkn_mask_gather_f32(const float* x, const float* mask_logits, float thr_logi
     return vkn_launch_gather(x, mask_logits, thr_logit, xraw_out, cnt, part, cntp, B, N, C, P, st);
 }
 
+int vkn_mask_gather_real_f32(const float* x, const float* a, float* out, float* asum_out, int B, int N, int C, int P, void* ws,
+                             size_t ws_bytes, void* stream) {
+    if (!x || !a || !out || B <= 0 || N <= 0 || C <= 0 || P <= 0) return VKN_E_ARG;
+    if (!aligned16(x) || !aligned16(a) || !aligned16(out)) return VKN_E_ALIGN;
+    if (C % 32 != 0 || C > 256 || N > 256) return VKN_E_SHAPE;
+    if (!ws || ws_bytes < vkn_gather_workspace_bytes(B, N, C, P)) return VKN_E_WORKSPACE;
+    const size_t G = vkn_gather_groups(B, P), NPT = npt_of(N);
+    Carver c{static_cast<char*>(ws), 0};
+    float* part = c.take<float>((size_t)B * G * NPT * C);
+    float* cntp = c.take<float>((size_t)B * G * NPT);
+    float* asum = c.take<float>((size_t)B * N);
+    if (asum_out) asum = asum_out;
+    return vkn_launch_gather_real(x, a, out, asum, part, cntp, B, N, C, P, N, static_cast<hipStream_t>(stream));
+}
+
 size_t vkn_decode_workspace_bytes(int B, int N, int C) {
     if (B <= 0 || N <= 0 || C <= 0) return 0;
     Carver c{nullptr, 0};

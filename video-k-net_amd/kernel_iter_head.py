@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from .kernel_update_head import KernelUpdateHead, VideoKernelUpdateHead
-from .registry import BaseRoIHead, build_head, register_head
+from .registry import BaseRoIHead, build_assigner, build_head, build_sampler, register_head
 
 
 @register_head
@@ -59,11 +59,14 @@ class KernelIterHead(BaseRoIHead):
         pass
 
     def init_assigner_sampler(self):
+        """One assigner + sampler per stage from `train_cfg` (a list of per-stage dicts; reference :85-95)."""
         self.mask_assigner = []
         self.mask_sampler = []
         if self.train_cfg is not None:
-            raise NotImplementedError('train-time assigner/sampler (reference :85-95) is a "next" row — SURVEY.md §8(f); '
-                                      'build with train_cfg=None for inference')
+            for idx, rcnn_train_cfg in enumerate(self.train_cfg):
+                self.mask_assigner.append(build_assigner(self._cfg(rcnn_train_cfg, 'assigner')))
+                self.current_stage = idx
+                self.mask_sampler.append(build_sampler(self._cfg(rcnn_train_cfg, 'sampler'), context=self))
 
     def init_weights(self):
         for i in range(self.num_stages):
@@ -85,14 +88,25 @@ class KernelIterHead(BaseRoIHead):
         mask_head = self.mask_head[stage]
         cls_score, mask_preds, object_feats = mask_head(x, object_feats, mask_preds, img_metas=img_metas)
         if mask_head.mask_upsample_stride > 1 and (stage == self.num_stages - 1 or self.training):
-            scaled_mask_preds = ops.upsample_bilinear(mask_preds, mask_head.mask_upsample_stride)
+            scaled_mask_preds = self._upsample(mask_preds, mask_head.mask_upsample_stride)
         else:
             scaled_mask_preds = mask_preds
         return dict(cls_score=cls_score, mask_preds=mask_preds, scaled_mask_preds=scaled_mask_preds,
                     object_feats=object_feats)
 
+    @staticmethod
+    def _upsample(mask_preds, stride):
+        """`F.interpolate(mask_preds, scale_factor=stride, bilinear, align_corners=False)` (reference :122-130): the HIP kernel at
+        inference; under autograd torch's own op (its backward is needed, the upsample is write-bound either way)."""
+        if mask_preds.requires_grad and torch.is_grad_enabled():
+            return torch.nn.functional.interpolate(mask_preds, scale_factor=stride, mode='bilinear', align_corners=False)
+        return ops.upsample_bilinear(mask_preds, stride)
+
     # ---- fused S-stage loop
     def _fused_ok(self, x):
+        # the `simple_test*` entry points are INFERENCE APIs: in eval() mode they take the fused C-ABI path and their outputs are
+        # detached from autograd whatever the grad mode (mmdet calls them under no_grad); gradients flow through `forward_train`
+        # and through the stage modules' `forward` (KernelUpdateHead._needs_grad)
         return (x.is_cuda and not self.training
                 and all(isinstance(h, KernelUpdateHead) for h in self.mask_head)
                 and len({(h.in_channels, h.num_heads, h.feedforward_channels, h.fc_cls.out_features, h.num_cls_fcs,
@@ -145,8 +159,59 @@ class KernelIterHead(BaseRoIHead):
             out.append(r)
         return out
 
-    def forward_train(self, *a, **k):
-        raise NotImplementedError('forward_train (assign/sample/loss per stage, reference :139-231) is a "next" row')
+    def _train_stages(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, imgs_whwh=None,
+                      gt_sem_seg=None, gt_sem_cls=None, stage_kwargs=None):
+        """The per-stage assign -> sample -> targets -> loss loop shared by `forward_train` (reference :139-231) and the video
+        head's `forward_train[_with_previous]` (knet/video/kernel_iter_head.py:150-376).  Assignment runs on the GPU cost kernels
+        + the C++ LSAP (`MaskHungarianAssigner`), losses in torch autograd, the stage forward through the HIP kernels' autograd
+        wrappers.  `stage_kwargs(stage)` gives extra keyword arguments of `_mask_forward` (the last stage's previous-frame link)."""
+        if not self.mask_assigner:
+            raise RuntimeError('forward_train needs train_cfg (one dict per stage with assigner / sampler / pos_weight)')
+        import torch.nn.functional as F
+        num_imgs = len(img_metas)
+        up = self.mask_head[0].mask_upsample_stride
+        prev_mask_preds = (F.interpolate(mask_preds.detach(), scale_factor=up, mode='bilinear', align_corners=False)
+                           if up > 1 else mask_preds.detach())
+        prev_cls_score = cls_score.detach() if cls_score is not None else [None] * num_imgs
+        if self.hard_target:
+            gt_masks = [g.bool().float() for g in gt_masks]
+        object_feats = proposal_feats
+        all_stage_loss, assign_results, mask_results = {}, [], None
+        for stage in range(self.num_stages):
+            extra = stage_kwargs(stage) if stage_kwargs is not None else {}
+            mask_results = self._mask_forward(stage, x, object_feats, mask_preds, img_metas, **extra)
+            mask_preds = mask_results['mask_preds']
+            scaled_mask_preds = mask_results['scaled_mask_preds']
+            cls_score = mask_results['cls_score']
+            object_feats = mask_results['object_feats']
+            if self.post_assign:
+                prev_mask_preds, prev_cls_score = scaled_mask_preds.detach(), cls_score.detach()
+            sampling_results = []
+            if stage < self.assign_stages:
+                assign_results = []
+            for i in range(num_imgs):
+                if stage < self.assign_stages:
+                    mask_for_assign = prev_mask_preds[i][:self.num_proposals]
+                    cls_for_assign = (prev_cls_score[i][:self.num_proposals, :self.num_thing_classes]
+                                      if prev_cls_score[i] is not None else None)
+                    assign_results.append(self.mask_assigner[stage].assign(mask_for_assign, cls_for_assign, gt_masks[i],
+                                                                           gt_labels[i], img_meta=img_metas[i]))
+                sampling_results.append(self.mask_sampler[stage].sample(assign_results[i], scaled_mask_preds[i], gt_masks[i]))
+            mask_targets = self.mask_head[stage].get_targets(sampling_results, gt_masks, gt_labels, self.train_cfg[stage], True,
+                                                             gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+            single_stage_loss = self.mask_head[stage].loss(object_feats, cls_score, scaled_mask_preds, *mask_targets,
+                                                           imgs_whwh=imgs_whwh)
+            for key, value in single_stage_loss.items():
+                all_stage_loss[f's{stage}_{key}'] = value * self.stage_loss_weights[stage]
+            if not self.post_assign:
+                prev_mask_preds, prev_cls_score = scaled_mask_preds.detach(), cls_score.detach()
+        return all_stage_loss, mask_results
+
+    def forward_train(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, gt_bboxes_ignore=None,
+                      imgs_whwh=None, gt_bboxes=None, gt_sem_seg=None, gt_sem_cls=None):
+        """-> dict of `s{stage}_loss_cls / loss_mask / loss_dice / loss_rank / pos_acc`          reference :139-231"""
+        return self._train_stages(x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, imgs_whwh,
+                                  gt_sem_seg, gt_sem_cls)[0]
 
     # ---- post-head pipeline (reference :233-283, 332-370, 467-524)
     @staticmethod
@@ -249,11 +314,39 @@ class VideoKernelIterHead(KernelIterHead):
             x, object_feats, mask_preds, img_metas=img_metas, previous_obj_feats=previous_obj_feats,
             previous_mask_preds=previous_mask_preds, previous_x_feats=previous_x_feats)
         if mask_head.mask_upsample_stride > 1 and (stage == self.num_stages - 1 or self.training):
-            scaled_mask_preds = ops.upsample_bilinear(mask_preds, mask_head.mask_upsample_stride)
+            scaled_mask_preds = self._upsample(mask_preds, mask_head.mask_upsample_stride)
         else:
             scaled_mask_preds = mask_preds
         return dict(cls_score=cls_score, mask_preds=mask_preds, scaled_mask_preds=scaled_mask_preds,
                     object_feats=object_feats, object_feats_track=object_feats_track, x_feats=x_feats)
+
+    def forward_train(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, gt_pids=None,
+                      gt_bboxes_ignore=None, imgs_whwh=None, gt_bboxes=None, gt_sem_seg=None, gt_sem_cls=None):
+        """knet/video/kernel_iter_head.py:150-253: losses, and with `with_track` also the last stage's outputs."""
+        losses, r = self._train_stages(x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, imgs_whwh,
+                                       gt_sem_seg, gt_sem_cls)
+        if self.with_track:
+            return losses, r['object_feats'], r['cls_score'], r['mask_preds'], r['scaled_mask_preds']
+        return losses
+
+    def forward_train_with_previous(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, gt_pids=None,
+                                    gt_bboxes_ignore=None, imgs_whwh=None, gt_bboxes=None, gt_sem_seg=None, gt_sem_cls=None,
+                                    previous_obj_feats=None, previous_mask_preds=None, previous_x_feats=None):
+        """knet/video/kernel_iter_head.py:255-376: the previous frame's kernels reach the LAST stage only (:300-303)."""
+        last = self.num_stages - 1
+
+        def kw(stage):
+            on = stage == last
+            return dict(previous_obj_feats=previous_obj_feats if on else None,
+                        previous_mask_preds=previous_mask_preds if on else None,
+                        previous_x_feats=previous_x_feats if on else None)
+
+        losses, r = self._train_stages(x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, imgs_whwh,
+                                       gt_sem_seg, gt_sem_cls, stage_kwargs=kw)
+        if self.with_track:
+            return (losses, r['object_feats'], r['cls_score'], r['mask_preds'], r['scaled_mask_preds'],
+                    r['object_feats_track'])
+        return losses
 
     def simple_test_mask_preds(self, x, proposal_feats, mask_preds, cls_score, img_metas):
         """reference :508-527"""

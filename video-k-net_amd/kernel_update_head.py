@@ -12,7 +12,9 @@ import math
 import torch
 import torch.nn as nn
 
+from . import autograd as vag
 from . import ops
+from .losses import accuracy, reduce_mean
 from .registry import build_loss, build_transformer_layer, register_head
 
 
@@ -201,10 +203,63 @@ class KernelUpdateHead(nn.Module):
                                       'never happens in shipped configs and is not built')
         if mask_shape is not None and mask_shape[0] != x.shape[-2]:
             raise NotImplementedError('mask_shape resize (reference :268-273) is dead in shipped configs and is not built')
-        if torch.is_grad_enabled() and (x.requires_grad or proposal_feat.requires_grad or
-                                        any(p.requires_grad for p in self.parameters()) and self.training):
-            raise NotImplementedError('backward of the MI355X head is a later round (SURVEY.md §8(f)); call under '
-                                      'torch.no_grad() / eval()')
+
+    def _needs_grad(self, x, proposal_feat):
+        """Autograd is wanted whenever grad mode is on and an input or any parameter requires grad — in train() AND eval() mode
+        (a frozen / eval head inside a fine-tuned model still has to pass gradients to x and the kernels)."""
+        return torch.is_grad_enabled() and (x.requires_grad or proposal_feat.requires_grad
+                                            or any(p.requires_grad for p in self.parameters()))
+
+    def _mha(self, mod, query, key=None, identity=None):
+        """mmcv `MultiheadAttention.forward` (seq-first): identity + attn(q, k, v)[0], key = value, dropout 0."""
+        key = query if key is None else key
+        identity = query if identity is None else identity
+        return identity + mod.attn(query, key, key, need_weights=False)[0]
+
+    def _forward_autograd(self, x, proposal_feat, mask_preds, previous_obj_feats=None):
+        """Differentiable stage (training): the two x-streaming ops are the HIP kernels behind autograd Functions
+        (video-k-net_amd/autograd.py: their backward passes are the same kernels with transposed operands), the [B*N, C] chain
+        runs as torch ops on this module's own parameters.  `feat_transform` stays folded: x_feat = xraw W^T + cnt b,
+        Z = (mask_feat W) x + mask_feat . b — its weight / bias gradients come out of the two small matmuls.
+        Line-by-line counterpart of knet/det/kernel_update_head.py:170-277 (video: knet/video/kernel_update_head.py:281-541)."""
+        B, N = proposal_feat.shape[:2]
+        C, K = self.in_channels, self.conv_kernel_size
+        xraw, cnt = vag.mask_gather(x, mask_preds.detach(), self.hard_mask_thr)                        # :190-195
+        if self.feat_transform is not None:
+            w_ft = self.feat_transform.conv.weight.reshape(C, C)
+            b_ft = self.feat_transform.conv.bias
+            x_feat = xraw @ w_ft.t() + cnt.unsqueeze(-1) * b_ft                                         # :179-180 folded
+        else:
+            x_feat = xraw
+        pf = proposal_feat.reshape(B, N, C, -1).permute(0, 1, 3, 2)                                     # :198-199
+        obj_feat = self.kernel_update_conv.forward_autograd(x_feat, pf)                                 # :200
+        obj_feat = obj_feat.reshape(B, N, -1).permute(1, 0, 2)                                          # :203-205
+        obj_feat = self.attention_norm(self._mha(self.attention, obj_feat))                             # :206
+        obj_feat = obj_feat.permute(1, 0, 2).reshape(B, N, -1, C)                                       # :208-211
+        if self.with_ffn:
+            obj_feat = self.ffn_norm(obj_feat + self.ffn.layers(obj_feat))                              # :214-215
+        track = None
+        if previous_obj_feats is not None and self.previous is not None:                                # video :394-415
+            prev = previous_obj_feats.reshape(B, N, C * K * K).permute(1, 0, 2)
+            cur = obj_feat.reshape(B, N, C * K * K).permute(1, 0, 2)
+            t = self.attention_previous_norm(self._mha(self.attention_previous, cur, prev, cur)).permute(1, 0, 2)
+            t = t.reshape(B, N, -1, C)
+            t = self.link_ffn_norm(t + self.link_ffn.layers(t))
+            track = t.permute(0, 1, 3, 2).reshape(B, N, C, K, K)
+        cls_feat = obj_feat.sum(-2)                                                                     # :217-221
+        mask_feat = obj_feat
+        for layer in self.cls_fcs:
+            cls_feat = layer(cls_feat)
+        cls_score = self.fc_cls(cls_feat).view(B, N, -1)
+        for layer in self.mask_fcs:                                                                     # :223-227
+            mask_feat = layer(mask_feat)
+        mask_feat = self.fc_mask(mask_feat).reshape(B, N, C)
+        if self.feat_transform is not None:
+            kern, kb = mask_feat @ w_ft, mask_feat @ b_ft                                               # K (W x + b) = (K W) x + K.b
+        else:
+            kern, kb = mask_feat, None
+        new_mask_preds = vag.mask_decode(x, kern, kb)                                                   # :247-260
+        return cls_score, new_mask_preds, obj_feat.permute(0, 1, 3, 2).reshape(B, N, C, K, K), x_feat, track
 
     def _run(self, x, proposal_feat, mask_preds, previous_obj_feats=None, flags=0):
         B, N = proposal_feat.shape[:2]
@@ -223,13 +278,97 @@ class KernelUpdateHead(nn.Module):
     def forward(self, x, proposal_feat, mask_preds, prev_cls_score=None, mask_shape=None, img_metas=None):
         """-> (cls_score [B,N,ncls], new_mask_preds [B,N,H,W], obj_feat [B,N,C,K,K])   reference :170-277"""
         self._check_inputs(x, proposal_feat, mask_preds, mask_shape)
+        if self._needs_grad(x, proposal_feat):
+            cls, masks, obj, _, _ = self._forward_autograd(x, proposal_feat, mask_preds)
+            return cls, masks, obj
         cls, masks, obj, _, _ = self._run(x, proposal_feat, mask_preds)
         return cls, masks, obj
 
-    def loss(self, *a, **k):
-        raise NotImplementedError('training loss/targets (reference :279-441) are a "next" row — SURVEY.md §8(f)')
+    # ---- training: knet/det/kernel_update_head.py:279-441
+    def loss(self, object_feats, cls_score, mask_pred, labels, label_weights, mask_targets, mask_weights, imgs_whwh=None,
+             reduction_override=None, **kwargs):
+        losses = dict()
+        bg_class_ind = self.num_classes
+        pos_inds = (labels >= 0) & (labels < bg_class_ind)
+        num_pos = pos_inds.sum().float()
+        avg_factor = reduce_mean(num_pos).clamp_(min=1.0)
+        num_preds = mask_pred.shape[0] * mask_pred.shape[1]
+        assert mask_pred.shape[0] == cls_score.shape[0] and mask_pred.shape[1] == cls_score.shape[1]
+        if cls_score is not None and cls_score.numel() > 0:
+            losses['loss_cls'] = self.loss_cls(cls_score.view(num_preds, -1), labels, label_weights, avg_factor=avg_factor,
+                                               reduction_override=reduction_override)
+            losses['pos_acc'] = accuracy(cls_score.view(num_preds, -1)[pos_inds], labels[pos_inds])
+        if mask_pred is not None:
+            bool_pos_inds = pos_inds.type(torch.bool)
+            H, W = mask_pred.shape[-2:]
+            if pos_inds.any():
+                pos_mask_pred = mask_pred.reshape(num_preds, H, W)[bool_pos_inds]
+                pos_mask_targets = mask_targets[bool_pos_inds]
+                losses['loss_mask'] = self.loss_mask(pos_mask_pred, pos_mask_targets)
+                losses['loss_dice'] = self.loss_dice(pos_mask_pred, pos_mask_targets)
+                if self.loss_rank is not None:
+                    batch_size = mask_pred.size(0)
+                    rank_target = mask_targets.new_full((batch_size, H, W), self.ignore_label, dtype=torch.long)
+                    rank_inds = pos_inds.view(batch_size, -1).nonzero(as_tuple=False)
+                    batch_mask_targets = mask_targets.view(batch_size, -1, H, W).bool()
+                    for i in range(batch_size):
+                        curr_rank = rank_inds[:, 1][rank_inds[:, 0] == i]
+                        for j in curr_rank:
+                            rank_target[i][batch_mask_targets[i][j]] = j
+                    losses['loss_rank'] = self.loss_rank(mask_pred, rank_target, ignore_index=self.ignore_label)
+            else:
+                losses['loss_mask'] = mask_pred.sum() * 0
+                losses['loss_dice'] = mask_pred.sum() * 0
+                if self.loss_rank is not None:
+                    losses['loss_rank'] = mask_pred.sum() * 0
+        return losses
 
-    get_targets = loss
+    def _get_target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls,
+                           cfg):
+        num_pos, num_neg = pos_mask.size(0), neg_mask.size(0)
+        num_samples = num_pos + num_neg
+        H, W = pos_mask.shape[-2:]
+        labels = pos_mask.new_full((num_samples,), self.num_classes, dtype=torch.long)
+        label_weights = pos_mask.new_zeros((num_samples, self.num_classes))
+        mask_targets = pos_mask.new_zeros(num_samples, H, W)
+        mask_weights = pos_mask.new_zeros(num_samples, H, W)
+        if num_pos > 0:
+            labels[pos_inds] = pos_gt_labels
+            pw = cfg['pos_weight'] if isinstance(cfg, dict) else cfg.pos_weight
+            label_weights[pos_inds] = 1.0 if pw <= 0 else pw
+            mask_targets[pos_inds, ...] = pos_gt_mask
+            mask_weights[pos_inds, ...] = 1
+        if num_neg > 0:
+            label_weights[neg_inds] = 1.0
+        if gt_sem_cls is not None and gt_sem_seg is not None:
+            S, T = self.num_stuff_classes, self.num_thing_classes
+            sem_labels = pos_mask.new_full((S,), self.num_classes, dtype=torch.long)
+            sem_targets = pos_mask.new_zeros(S, H, W)
+            sem_weights = pos_mask.new_zeros(S, H, W)
+            sem_label_weights = torch.cat([pos_mask.new_zeros((S, T)), torch.eye(S, device=pos_mask.device)], dim=-1)
+            if len(gt_sem_cls > 0):
+                sem_inds = (gt_sem_cls - T).long()
+                sem_labels[sem_inds] = gt_sem_cls.long()
+                sem_targets[sem_inds] = gt_sem_seg
+                sem_weights[sem_inds] = 1
+            label_weights[:, T:] = 0
+            labels = torch.cat([labels, sem_labels])
+            label_weights = torch.cat([label_weights, sem_label_weights])
+            mask_targets = torch.cat([mask_targets, sem_targets])
+            mask_weights = torch.cat([mask_weights, sem_weights])
+        return labels, label_weights, mask_targets, mask_weights
+
+    def get_targets(self, sampling_results, gt_mask, gt_labels, rcnn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None):
+        n = len(sampling_results)
+        if gt_sem_seg is None:
+            gt_sem_seg, gt_sem_cls = [None] * n, [None] * n      # (the reference hard-codes 2 here, :417-418: batch of 2 only)
+        out = [self._get_target_single(r.pos_inds, r.neg_inds, r.pos_masks, r.neg_masks, r.pos_gt_masks, r.pos_gt_labels,
+                                       gt_sem_seg[i], gt_sem_cls[i], rcnn_train_cfg) for i, r in enumerate(sampling_results)]
+        labels, label_weights, mask_targets, mask_weights = (list(t) for t in zip(*out))
+        if concat:
+            labels, label_weights = torch.cat(labels, 0), torch.cat(label_weights, 0)
+            mask_targets, mask_weights = torch.cat(mask_targets, 0), torch.cat(mask_weights, 0)
+        return labels, label_weights, mask_targets, mask_weights
 
 
 @register_head
@@ -265,5 +404,7 @@ class VideoKernelUpdateHead(KernelUpdateHead):
         self._check_inputs(x, proposal_feat, mask_preds, mask_shape)
         if previous_obj_feats is not None and self.previous is None:
             previous_obj_feats = None      # no link modules were built (reference would fail on attribute access)
+        if self._needs_grad(x, proposal_feat):
+            return self._forward_autograd(x, proposal_feat, mask_preds, previous_obj_feats)
         cls, masks, obj, xfeat, track = self._run(x, proposal_feat, mask_preds, previous_obj_feats)
         return cls, masks, obj, xfeat, track

@@ -1,0 +1,46 @@
+"""`MaskPseudoSampler` / `MaskSamplingResult` — knet/det/mask_pseudo_sampler.py:15-191 (same `BBOX_SAMPLERS` name, same fields):
+no sampling happens, the one-to-one assignment is only repackaged as (pos, neg) index sets with the matched ground truth."""
+import torch
+
+
+class MaskSamplingResult:
+    """knet/det/mask_pseudo_sampler.py:15-170."""
+
+    def __init__(self, pos_inds, neg_inds, masks, gt_masks, assign_result, gt_flags):
+        self.pos_inds = pos_inds
+        self.neg_inds = neg_inds
+        self.pos_masks = masks[pos_inds]
+        self.neg_masks = masks[neg_inds]
+        self.pos_is_gt = gt_flags[pos_inds]
+        self.num_gts = gt_masks.shape[0]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        if gt_masks.numel() == 0:
+            assert self.pos_assigned_gt_inds.numel() == 0
+            self.pos_gt_masks = torch.empty_like(gt_masks)
+        else:
+            self.pos_gt_masks = gt_masks[self.pos_assigned_gt_inds, :]
+        self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
+        extra = getattr(assign_result, '_extra_properties', {})
+        self.pos_gt_pids = extra['pids'][pos_inds] if 'pids' in extra else None
+
+    @property
+    def masks(self):
+        return torch.cat([self.pos_masks, self.neg_masks])
+
+    @property
+    def info(self):
+        return dict(pos_inds=self.pos_inds, neg_inds=self.neg_inds, pos_masks=self.pos_masks, neg_masks=self.neg_masks,
+                    pos_is_gt=self.pos_is_gt, num_gts=self.num_gts, pos_assigned_gt_inds=self.pos_assigned_gt_inds)
+
+
+class MaskPseudoSampler:
+    """knet/det/mask_pseudo_sampler.py:173-205."""
+
+    def __init__(self, **kwargs):
+        pass
+
+    def sample(self, assign_result, masks, gt_masks, **kwargs):
+        pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        gt_flags = masks.new_zeros(masks.shape[0], dtype=torch.uint8)
+        return MaskSamplingResult(pos_inds, neg_inds, masks, gt_masks, assign_result, gt_flags)

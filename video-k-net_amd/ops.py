@@ -111,6 +111,24 @@ def mask_gather(x, mask_logits, hard_mask_thr=0.5, flags=0):
     return xraw, cnt
 
 
+def mask_gather_real(x, a):
+    """(out [B,N,C], asum [B,N]) = sum_p a[b,n,p] * x[b,c,p] and sum_p a — the gather with a REAL-valued left operand
+    (`einsum('bnhw,bchw->bnc', a, x)`): decode backward w.r.t. the kernels, soft gather weights, soft ground-truth masks."""
+    x, a = _req(x, 'x'), _req(a, 'a')
+    B, C = x.shape[0], x.shape[1]
+    N = a.shape[1]
+    P = x[0, 0].numel()
+    if a.shape[0] != B or a[0, 0].numel() != P:
+        raise ValueError('x and a disagree on batch or spatial size')
+    L = _lib.lib()
+    out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+    asum = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    ws = _workspace(L.vkn_gather_workspace_bytes(B, N, C, P), x.device)
+    with torch.cuda.device(x.device):
+        check(L.vkn_mask_gather_real_f32(_ptr(x), _ptr(a), _ptr(out), _ptr(asum), B, N, C, P, _ptr(ws), ws.numel(), _stream()))
+    return out, asum
+
+
 def mask_decode(x, kernels, bias=None, flags=0):
     """out[b,n,h,w] = sum_c kernels[b,n,c] x[b,c,h,w] (+ bias[b,n]).
     Replaces the per-image `F.conv2d(x[i:i+1], mask_feat[i])`, K=1 (knet/det/kernel_update_head.py:247-260)."""

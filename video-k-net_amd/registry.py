@@ -51,33 +51,28 @@ try:  # real mmdet / mmcv present: be a plug-in of the reference's own registrie
     from mmcv.cnn.bricks.transformer import TRANSFORMER_LAYER, build_transformer_layer  # type: ignore
     from mmdet.models.builder import HEADS, build_head, build_loss  # type: ignore
     from mmdet.models.roi_heads import BaseRoIHead  # type: ignore
+    from mmdet.core import build_assigner, build_sampler  # type: ignore
     HAVE_MM = True
 except Exception:  # noqa: BLE001  (mmcv/mmdet are not installed in the build image)
     HAVE_MM = False
     HEADS = Registry('models')
     TRANSFORMER_LAYER = Registry('transformerLayer')
     LOSSES = Registry('loss')
+    BBOX_ASSIGNERS = Registry('bbox_assigner')
+    BBOX_SAMPLERS = Registry('bbox_sampler')
+
+    def build_assigner(cfg, **default_args):
+        return BBOX_ASSIGNERS.build(cfg, default_args)
+
+    def build_sampler(cfg, **default_args):
+        default_args.pop('context', None)      # mmdet passes the head as `context`; the pseudo sampler ignores it
+        return BBOX_SAMPLERS.build(cfg, default_args)
 
     def build_head(cfg):
         return HEADS.build(cfg)
 
     def build_transformer_layer(cfg, default_args=None):
         return TRANSFORMER_LAYER.build(cfg, default_args)
-
-    class _LossShell(nn.Module):
-        """The forward path only reads `.use_sigmoid` (knet/det/kernel_update_head.py:136-139); loss arithmetic is a
-        'next' row (training) and lives in mmdet."""
-
-        def __init__(self, use_sigmoid=False, **kwargs):
-            super().__init__()
-            self.use_sigmoid = use_sigmoid
-            self.cfg = kwargs
-
-        def forward(self, *a, **k):
-            raise NotImplementedError('training losses need mmdet; the MI355X build covers the inference hot path')
-
-    for _n in ('FocalLoss', 'CrossEntropyLoss', 'DiceLoss'):
-        LOSSES.register_module(name=_n, module=type(_n, (_LossShell,), {}))
 
     def build_loss(cfg):
         return LOSSES.build(cfg)
@@ -96,6 +91,20 @@ except Exception:  # noqa: BLE001  (mmcv/mmdet are not installed in the build im
             if mask_head is not None:
                 self.init_mask_head(mask_roi_extractor, mask_head)
             self.init_assigner_sampler()
+
+
+def _register_training_components():
+    """Losses / assigner / sampler of the training path into the bundled registries (with mmdet present its own are used; the
+    reference's `knet/cross_entropy_loss.py` and assigner / sampler modules register themselves there)."""
+    if HAVE_MM:
+        return
+    from . import losses
+    from .mask_hungarian_assigner import MaskHungarianAssigner
+    from .mask_pseudo_sampler import MaskPseudoSampler
+    for cls in (losses.FocalLoss, losses.CrossEntropyLoss, losses.DiceLoss):
+        LOSSES.register_module(force=True)(cls)
+    BBOX_ASSIGNERS.register_module(force=True)(MaskHungarianAssigner)
+    BBOX_SAMPLERS.register_module(force=True)(MaskPseudoSampler)
 
 
 def register_head(cls):
