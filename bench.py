@@ -12,7 +12,12 @@ resident in HBM before the timed region.  Frames of a clip are sharded over the 
 frame needs for its tracking embedding (RCCL all_gather, 120 KB per rank, inside the timed region).
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (mask-decode kernel, HIP-event timed, algorithmic bytes / time
-vs 8 TB/s HBM), "cpu_baseline" (the torch CPU oracle timed on this host, rank 0 / N=1 only), "breakdown".
+vs 8 TB/s HBM), "cpu_baseline" (the torch CPU oracle timed on this host, rank 0 / N=1 only), "breakdown" (incl. the whole step at
+1 / 8 / 32 frames per call: the reference walks a video one frame per call).
+
+`--train` (BASELINE cfg3, not the headline): one step = `forward_train_with_previous` of the same head on `--frames` frames per GPU
+(losses, Hungarian assignment, backward through the HIP kernels' autograd wrappers), bucketed RCCL all-reduce of the head's
+gradients overlapped with backward, SGD update; prints training frames/s.
 """
 import argparse
 import json
@@ -28,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 CFG2 = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PMC_SIDECAR = 'profiles/r02_pmc.json'   # HBM counters of this same command (tools/gpu_profile.sh); `roofline.traffic` is read from it
 
 
 def build_head(vkn, device, seed=0):
@@ -118,6 +124,80 @@ def cpu_baseline(head_sd, sample_frames=1, runs=6):
                        f'min {sample_frames / ts[-1]:.3f} max {sample_frames / ts[0]:.3f} frames/s')
 
 
+def train_main(args, vkn, vkn_dist, device, world, rank):
+    """BASELINE cfg3: the clip's frames sharded over the ranks, head trained data-parallel (see the module docstring)."""
+    B = args.frames if args.frames != 32 else 4            # frames per GPU per step (the inference default of 32 is not a training batch)
+    N, C, H, W, up = CFG2['N'], CFG2['C'], CFG2['H'], CFG2['W'], 2
+    cfg = vkn.configs.roi_head_cfg(True, C=C, heads=CFG2['heads'], ffn=CFG2['ffn'], ncls=CFG2['ncls'], n_thing=CFG2['n_thing'],
+                                   n_stuff=CFG2['n_stuff'], S=CFG2['S'], up=up, nprop=CFG2['nprop'],
+                                   train_cfg=vkn.configs.rcnn_train_cfg(CFG2['S']))
+    head = vkn.build_head(cfg)
+    torch.manual_seed(0)                                   # identical replicas
+    head.init_weights()
+    head = head.to(device).train()
+    reducer = vkn_dist.BucketedGradAllReducer(head)
+    opt = torch.optim.SGD(head.parameters(), lr=1e-4, momentum=0.9)
+    x, pf, mp = synth_inputs(B, device, rank)
+    x.requires_grad_(True)                                 # gradients flow on into the backbone in the real model
+    g = torch.Generator(device='cpu').manual_seed(4321 + rank)
+    Hs, Ws = H * up, W * up
+    gt_masks, gt_labels, gt_sem_seg, gt_sem_cls = [], [], [], []
+    ys, xs = torch.arange(Hs).view(1, Hs, 1), torch.arange(Ws).view(1, 1, Ws)
+    for _ in range(B):                                     # 8 rectangular "things" + the 17 stuff bands per frame
+        cy, cx = torch.rand(8, 1, 1, generator=g) * Hs, torch.rand(8, 1, 1, generator=g) * Ws
+        hh, ww = torch.rand(8, 1, 1, generator=g) * Hs / 4 + 4, torch.rand(8, 1, 1, generator=g) * Ws / 4 + 4
+        gt_masks.append((((ys - cy).abs() < hh) & ((xs - cx).abs() < ww)).float().to(device))
+        gt_labels.append(torch.randint(0, CFG2['n_thing'], (8,), generator=g).to(device))
+        band = (ys * CFG2['n_stuff'] // Hs).expand(1, Hs, Ws)
+        gt_sem_cls.append((torch.arange(CFG2['n_stuff']) + CFG2['n_thing']).to(device))
+        gt_sem_seg.append((band == torch.arange(CFG2['n_stuff']).view(-1, 1, 1)).float().to(device))
+    prev = torch.randn(B, N, C, 1, 1, generator=g).to(device)
+    metas = [dict() for _ in range(B)]
+
+    def step():
+        reducer.zero_grad()
+        if x.grad is not None:
+            x.grad = None
+        out = head.forward_train_with_previous(x, pf, mp, None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                               gt_sem_cls=gt_sem_cls, previous_obj_feats=prev)
+        loss = sum(v for k, v in out[0].items() if 'loss' in k) + 1e-3 * (out[5] ** 2).mean()
+        loss.backward()                                    # per-stage buckets are all-reduced (RCCL) as backward produces them
+        reducer.finalize()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 3)):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        nparam = sum(p.numel() for p in head.parameters())
+        print(json.dumps(dict(metric='training frames/sec (S=3, N=100, 1024x2048, head only)', value=round(world * B * args.steps / dt, 2),
+                              unit='frames/s', n_gpus=world, steps=args.steps, warmup=max(args.warmup, 3),
+                              ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
+                              dtype='f32', data='synthetic',
+                              config=dict(workload='cfg3 video_knet_s3_r50 head training: forward_train_with_previous (losses, GPU '
+                                                   'cost matrices + host LSAP), backward through the HIP gather / decode kernels, '
+                                                   'per-stage bucketed RCCL gradient all-reduce overlapped with backward, SGD step',
+                                          frames_per_gpu_per_step=B, parallelism=f'frame-sharded dp{world}',
+                                          head_parameters=nparam, last_loss=round(float(loss), 4)))))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -130,6 +210,7 @@ def main():
     ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
     ap.add_argument('--streams', type=int, default=1,
                     help='frame groups of the clip processed on separate HIP streams (measured: no gain, 1 is fastest)')
+    ap.add_argument('--train', action='store_true', help='training step (cfg3) instead of the inference headline; see the docstring')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -148,6 +229,8 @@ def main():
     vkn = vkn_import.load()
     from importlib import import_module
     vkn_dist = import_module('video_k_net_amd.dist')
+    if args.train:
+        return train_main(args, vkn, vkn_dist, device, world, rank)
     head = build_head(vkn, device)
     B = args.frames
     x, pf, mp = synth_inputs(B, device, rank)
@@ -169,11 +252,11 @@ def main():
     for p in packs:
         p.ensure_prepared(dims)
 
-    def step():
+    def step(events=None):
         if world == 1 and NS == 1:
             # single process: the whole clip step — S stages, x4 upsample, tracking link of every frame to its predecessor — is
             # ONE C-ABI call (VKN_FLAG_CLIP_LINK), so the host side of a step is a handful of allocations
-            out = vkn.ops.head_forward(dims, packs, x, pfs[0], mp, None, up, clip_first_prev=first_prev)
+            out = vkn.ops.head_forward(dims, packs, x, pfs[0], mp, None, up, clip_first_prev=first_prev, decode_events=events)
             return out, out[4]
         # every group of frames: S stages + upsample (one C-ABI call per group, each on its own stream) ...
         main = torch.cuda.current_stream(device)
@@ -183,7 +266,8 @@ def main():
             if NS > 1:
                 st.wait_stream(main)
             with torch.cuda.stream(st):
-                outs.append(vkn.ops.head_forward(gdims[gi], packs, xs[gi], pfs[gi], mps[gi], None, up))
+                outs.append(vkn.ops.head_forward(gdims[gi], packs, xs[gi], pfs[gi], mps[gi], None, up,
+                                                 decode_events=events if gi == 0 else None))
         if NS > 1:
             for st in streams:
                 main.wait_stream(st)
@@ -226,12 +310,19 @@ def main():
                 break
         for _ in range(args.warmup):
             out = step()
+        # one HIP-event pair per timed step, recorded by the library around the LAST stage's mask-decode launch on the launch
+        # stream (vkn_head_forward_prof_f32): the roofline kernel is timed live, inside the timed region
+        dec_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for e0_, e1_ in dec_events:      # the first record creates the underlying hipEvent_t
+            e0_.record(streams[0])
+            e1_.record(streams[0])
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
+        for i in range(args.steps):
+            out = step(dec_events[i])
         barrier()
         dt = time.perf_counter() - t0
+        dec_live_ms = sorted(e0_.elapsed_time(e1_) for e0_, e1_ in dec_events)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -242,7 +333,9 @@ def main():
     extra = {}
     if rank == 0:
         with torch.no_grad():
-            # ---- roofline of the dominant kernel: k_decode_mfma alone, HIP events on the launch stream
+            # ---- roofline of the dominant x-streaming kernel with an HBM-bound design: k_decode_mfma (last stage), timed LIVE
+            # inside the timed steps above (mean of the per-step HIP-event pairs); `isolated_*` = the same kernel in a
+            # back-to-back loop of 50 launches (sustained HBM load: lower clocks, what round 1 reported)
             P = CFG2['H'] * CFG2['W']
             kern = torch.randn(B, N, C, device=device)
             hi, lo = vkn.ops.split_planes(kern)
@@ -257,22 +350,42 @@ def main():
                 vkn.ops.mask_decode_planes(x, hi, lo, N, kb, outm)
             e1.record()
             torch.cuda.synchronize()
-            dec_ms = e0.elapsed_time(e1) / reps
-            alg = B * P * (C * 4 + N * 4)                      # read x once + write the logits once
+            dec_iso_ms = e0.elapsed_time(e1) / reps
+            Bl = B // NS if NS > 1 else B                      # frames of the launch the events bracket
+            dec_ms = sum(dec_live_ms) / len(dec_live_ms)
+            alg = Bl * P * (C * 4 + N * 4)                     # read x once + write the logits once
             ach = alg / (dec_ms * 1e-3) / 1e9
             # HBM bytes per launch from the committed PMC profile of this same command (tools/gpu_profile.sh ->
             # profiles/r01_pmc.json); null when the sidecar is absent or was taken at another batch size
             traffic = None
             try:
-                side = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
-                if B == side.get('_frames_per_launch'):
+                side = json.load(open(os.path.join(ROOT, PMC_SIDECAR)))
+                if Bl == side.get('_frames_per_launch'):
                     traffic = side['k_decode_mfma']['hbm_bytes_per_launch']
             except Exception:  # noqa: BLE001
                 pass
             extra['roofline'] = dict(kernel='k_decode_mfma', bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                                      unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
+                                     traffic_source=(PMC_SIDECAR if traffic is not None else None),
                                      algorithmic_bytes_per_launch=alg, avg_launch_ms=round(dec_ms, 4),
-                                     frames_per_launch=B)
+                                     min_launch_ms=round(dec_live_ms[0], 4), max_launch_ms=round(dec_live_ms[-1], 4),
+                                     timed='HIP events recorded by the library around the launch, one pair per timed step',
+                                     isolated_loop_launch_ms=round(dec_iso_ms, 4),
+                                     isolated_loop_frac=round(B * P * (C + N) * 4 / (dec_iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     frames_per_launch=Bl)
+            # the fused decode(s) -> gather(s+1) pass alone (k_fused_dgs + reduce): it reads x once; reported both against the
+            # bytes it actually moves and against the algorithmic bytes of the two ops it replaces (decode: x + logits written,
+            # gather: x + logits read — SURVEY.md §8(d)); co-bound by the matrix pipe, see DESIGN.md
+            for _ in range(5):
+                vkn.ops.decode_gather(x, hi, lo, N, kb)
+            e0.record()
+            for _ in range(reps):
+                vkn.ops.decode_gather(x, hi, lo, N, kb)
+            e1.record()
+            torch.cuda.synchronize()
+            fu_ms = e0.elapsed_time(e1) / reps
+            alg = B * P * (C * 4 + N * 4)
+            dec_ms = dec_iso_ms                                 # the breakdown below lists isolated-loop timings
             # gather kernel (+ its partial reduce), same accounting: read x once + read the logits once
             for _ in range(3):
                 vkn.ops.mask_gather(x, mp)
@@ -320,7 +433,27 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             pan_ms = e0.elapsed_time(e1) / 5
-            extra['breakdown'] = dict(decode_ms=round(dec_ms, 4), gather_plus_reduce_ms=round(ga_ms, 4),
+            # the whole step (S stages + link + x4 upsample, one C call) at 1 / 8 frames per call — the reference walks a video one
+            # frame per call; `value` above is at `--frames` per call
+            per_call = {}
+            for b_ in (1, 8):
+                if b_ >= B:
+                    continue
+                dims_b = last.make_dims(b_, N, CFG2['H'], CFG2['W'])
+                xb, pfb, mpb = x[:b_], pf[:b_].reshape(b_, N, C), mp[:b_]
+                for _ in range(5):
+                    vkn.ops.head_forward(dims_b, packs, xb, pfb, mpb, None, up, clip_first_prev=first_prev)
+                e0.record()
+                for _ in range(30):
+                    vkn.ops.head_forward(dims_b, packs, xb, pfb, mpb, None, up, clip_first_prev=first_prev)
+                e1.record()
+                torch.cuda.synchronize()
+                per_call[f'frames_per_s_at_{b_}_frames_per_call'] = round(b_ / (e0.elapsed_time(e1) / 30 * 1e-3), 1)
+            per_call[f'frames_per_s_at_{B}_frames_per_call'] = round(frames / dt, 1)
+            extra['breakdown'] = dict(**per_call, fused_decode_gather_ms=round(fu_ms, 4),
+                                      fused_x_GBps=round(B * P * C * 4 / (fu_ms * 1e-3) / 1e9, 1),
+                                      fused_replaces_algorithmic_GBps=round(2 * alg / (fu_ms * 1e-3) / 1e9, 1),
+                                      decode_ms=round(dec_ms, 4), gather_plus_reduce_ms=round(ga_ms, 4),
                                       kernel_init_pass0_ms=round(init_ms, 4), panoptic_joint_1024x2048_ms=round(pan_ms, 4),
                                       gather_GBps=round(alg / (ga_ms * 1e-3) / 1e9, 1),
                                       head_3stages_no_upsample_ms=round(head_ms, 4),

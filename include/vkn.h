@@ -202,6 +202,15 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
                          float* cls_prob, float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out,
                          void* ws, size_t ws_bytes, unsigned flags, void* stream);
 
+/* ---- the same call with two caller-owned hipEvent_t recorded on `stream` immediately before / after the LAST stage's mask-decode
+ *      launch (either may be NULL): lets a benchmark time the dominant kernel live, inside its timed steps, instead of in a
+ *      separate loop (bench.py `roofline`). */
+int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const float* x,
+                              const float* proposal_feats, const float* mask_preds_in, const float* prev_obj, float* obj_out,
+                              float* cls_prob, float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out,
+                              void* ws, size_t ws_bytes, unsigned flags, void* stream, void* ev_decode_start,
+                              void* ev_decode_stop);
+
 /* ---- kernel initialisation ("pass 0").  Replaces `ConvKernelHead._decode_init_proposals` AFTER its loc / seg convs
  *      (knet/det/kernel_head.py:204-263; `simple_test_rpn` :506-508), i.e. everything between the localization FPN's two feature
  *      maps and the first `KernelUpdateHead`:

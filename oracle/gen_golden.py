@@ -102,6 +102,13 @@ CASES = {
     'det_cfg_big': dict(video=False, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=2, nprop=100, N=117, H=64, W=128, B=1, seed=4),
     'video_tiny': dict(video=True, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=3, up=4, nprop=12, N=15, H=8, W=16, B=2, seed=5),
     'video_cfg': dict(video=True, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=16, W=32, B=1, seed=6),
+    # BASELINE cfg5 at its real size: video_knet_s3_swinb VIP-Seg, 720p -> 92x160 stride-8 features, 100 + 66 kernels, 124 classes, x4
+    'video_vipseg_big': dict(video=True, C=256, heads=8, ffn=2048, ncls=124, n_thing=58, n_stuff=66, S=3, up=4, nprop=100, N=166, H=92, W=160,
+                             B=1, seed=8),
+    # BASELINE cfg4 per-frame shape (YouTube-VIS 640x360 -> 48x80): N = 100, 40 thing classes, no stuff, x2 — through the knet head
+    # (the knet_vis copy of the stage is the same arithmetic; its registry names are pinned by oracle/gen_golden_vis.py)
+    'det_ytvis': dict(video=False, C=256, heads=8, ffn=2048, ncls=40, n_thing=40, n_stuff=0, S=3, up=2, nprop=100, N=100, H=48, W=80, B=2,
+                      seed=9),
 }
 
 
@@ -137,7 +144,11 @@ def run_case(name, p):
         else:
             o, c, m, sc = head.simple_test_mask_preds(x, pf, mp, None, metas)
     assert torch.equal(per_stage[-1][1], m)
-    big = name.endswith('_big')
+    # per (stage, frame, kernel): the smallest |logit - flip point| of the mask that stage hands to the next gather — a kernel whose
+    # margins all exceed the fp32 noise of a different summation order cannot flip a bit (free-running parity at large sizes)
+    flip = 8.940697e-08
+    out['row_margin'] = np.stack([(ms - flip).abs().flatten(2).min(dim=2).values.numpy() for _, ms, _ in per_stage[:-1]])
+    big = name.endswith('_big') or name == 'det_ytvis'
     out['object_feats'] = o.numpy()
     out['cls_score'] = c.numpy()
     if not big:
@@ -257,6 +268,37 @@ PAN_CASES = {
     # KITTI-like odd sizes, already-scaled logits (up = 1), crop only
     'pan_kitti': dict(B=1, N=117, Np=100, T=2, ncls=19, Hm=48, Wm=156, up=1, bis=(96, 312), img=(94, 311), ori=(94, 311), seed=34),
 }
+
+
+def run_pan_video_case(name, p):
+    """VideoKernelIterHead.get_panoptic of the reference (knet/video/kernel_iter_head.py:591-640, merge_stuff_thing_stuff_joint
+    :832-905): the 5-tuple incl. `thing_obj_feat = sort_obj_fea[things_ids]` — the tracking embeddings of the accepted things."""
+    test_cfg = AttrDict(max_per_img=p['Np'], mask_thr=0.5, stuff_score_thr=0.05,
+                        merge_stuff_thing=AttrDict(overlap_thr=0.6, iou_thr=0.5, stuff_max_area=4096, instance_score_thr=0.25))
+    C = 32
+    cfg = head_cfg(True, C=C, heads=8, ffn=64, ncls=p['ncls'], n_thing=p['T'], n_stuff=p['ncls'] - p['T'], S=1, up=p['up'], nprop=p['Np'])
+    cfg.update(with_track=True, merge_joint=True, test_cfg=test_cfg)
+    head = build_head(cfg)
+    head.eval()
+    cls, logits = (torch.from_numpy(a) for a in synth.panoptic_inputs(p['B'], p['N'], p['Np'], p['ncls'], p['Hm'], p['Wm'], p['seed']))
+    obj = torch.from_numpy(synth.normalish((p['B'], p['N'], C), 77 + p['seed'], 1.0))
+    meta = dict(img_shape=(*p['img'], 3), batch_input_shape=tuple(p['bis']), ori_shape=(*p['ori'], 3))
+    out = dict(case=np.array([p['B'], p['N'], p['Np'], p['T'], p['ncls'], p['Hm'], p['Wm'], p['up'], *p['bis'], *p['img'], *p['ori'],
+                              p['seed']], dtype=np.int64))
+    with torch.no_grad():
+        scaled = F.interpolate(logits, scale_factor=p['up'], align_corners=False, mode='bilinear') if p['up'] > 1 else logits
+        segs, nseg = [], []
+        for b in range(p['B']):
+            bboxes, _, _, (pan, info), tfeat = head.get_panoptic(cls[b], scaled[b], head.test_cfg, meta, obj_feat=obj[b])
+            segs.append(pan)
+            nseg.append(len(info))
+            out[f'info{b}'] = np.array([[s_['id'], int(s_['isthing']), s_['category_id'], s_.get('instance_id', -1),
+                                         s_.get('score', float('nan')), s_.get('area', -1)] for s_ in info], dtype=np.float64).reshape(-1, 6)
+            out[f'thing_obj_feat{b}'] = tfeat.numpy()
+    out['panoptic_seg'] = np.stack(segs).astype(np.int32)
+    out['nseg'] = np.array(nseg, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(f'{name}: ok  segments per frame = {nseg}  things with embeddings = {[out[f"thing_obj_feat{b}"].shape[0] for b in range(p["B"])]}')
 
 
 def run_pan_case(name, p):
@@ -470,6 +512,8 @@ if __name__ == '__main__':
     for name, p in PAN_CASES.items():
         if not only or name in only:
             run_pan_case(name, p)
+    if not only or 'pan_video' in only:
+        run_pan_video_case('pan_video', PAN_CASES['pan_tiny'])
     for name, p in ASSIGN_CASES.items():
         if not only or name in only:
             run_assign_case(name, p)

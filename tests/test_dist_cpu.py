@@ -70,3 +70,60 @@ def test_uneven_and_tiny_clips():
     assert out[1][3] == [100.0, 101.0]
     out = _run(T=1)                      # rank 0 owns nothing, rank 1 owns frame 0 and must fall back to first_previous
     assert out[0][1:3] == (0, 0) and out[1][1:3] == (0, 1) and out[1][3] == [-1.0]
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import vkn_import
+    vkn = vkn_import.load()
+    from importlib import import_module
+    d = import_module('video_k_net_amd.dist')
+    torch.manual_seed(0)                                    # identical replicas
+    C, rows = 32, 16
+    net = torch.nn.ModuleDict({'mask_head': torch.nn.ModuleList(
+        [vkn.KernelUpdator(in_channels=C, feat_channels=C, out_channels=C) for _ in range(3)])})
+    red = d.BucketedGradAllReducer(net)
+    assert sorted(b['key'] for b in red.buckets) == ['stage0', 'stage1', 'stage2']
+    g = torch.Generator().manual_seed(7)
+    u, k = torch.randn(world * rows, C, generator=g), torch.randn(world * rows, 1, C, generator=g)
+
+    def loss_of(u_, k_):
+        h = k_
+        for m in net['mask_head']:                           # the head's own torch chain (KernelUpdator.forward_autograd), CPU
+            h = m.forward_autograd(u_, h)
+        return (h ** 2).mean()
+
+    for _ in range(2):                                       # two steps: zero_grad re-arms the hooks
+        red.zero_grad()
+        loss_of(u[rank * rows:(rank + 1) * rows], k[rank * rows:(rank + 1) * rows]).backward()
+        red.finalize()
+    got = {n: p.grad.clone() for n, p in net.named_parameters()}
+    if rank == 0:                                            # single-process reference on the whole batch
+        ref_net = torch.nn.ModuleDict({'mask_head': torch.nn.ModuleList(
+            [vkn.KernelUpdator(in_channels=C, feat_channels=C, out_channels=C) for _ in range(3)])})
+        ref_net.load_state_dict(net.state_dict())
+        h = k
+        for m in ref_net['mask_head']:
+            h = m.forward_autograd(u, h)
+        (h ** 2).mean().backward()
+        err = max(float((got[n] - p.grad).abs().max() / (p.grad.abs().max() + 1e-12)) for n, p in ref_net.named_parameters())
+        q.put(err)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_equals_full_batch_gradients():
+    """2 ranks x half the rows, per-stage buckets reduced asynchronously from backward hooks == 1 rank x all rows."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert err < 1e-5, err

@@ -226,6 +226,78 @@ def test_head_cfg1_size_vs_reference_golden(vkn):
     assert np.all((bits ^ g['sign_bits']) & g['sign_valid'] == 0), 'binary masks (|logit| > 2e-3) must be bit-exact'
 
 
+@pytest.mark.parametrize('name', ['video_vipseg_big', 'det_ytvis'])
+def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name):
+    """BASELINE cfg5 at its real size (video_knet_s3_swinb VIP-Seg: N = 166 = 100 + 66 kernels -> two n-chunks, C = 256, 92x160
+    features, 124 classes, x4, tracking link) and the cfg4 per-frame shape (YouTube-VIS: N = 100, 48x80, 40 thing classes, no
+    stuff, x2, 2 frames): the free-running 3-stage fused head against the REFERENCE's own outputs."""
+    g, case = load_golden(name)
+    head, (x, pf, mp, prev) = _build_head(vkn, case)
+    metas = [dict()] * case['B']
+    B, N, P = case['B'], case['N'], case['H'] * case['W']
+    # kernels whose hand-over masks stay clear of the binarisation threshold in EVERY stage of the reference cannot flip a bit under
+    # a different fp32 summation order (golden `row_margin`); the few others may (chaos note, DESIGN.md §2) and get a loose bound
+    stable = torch.from_numpy((g['row_margin'] > 5e-5).all(axis=0))          # [B, N]
+    assert float(stable.float().mean()) > 0.8
+    with torch.no_grad():
+        if case['video']:
+            obj, cls, masks, scaled, track = head.simple_test_mask_preds_plus_previous(
+                *_cuda(x, pf, mp), None, metas, previous_obj_feats=prev.to(DEV), return_track=True)
+            d = (track.cpu() - torch.from_numpy(g['track'])).abs().reshape(B, N, -1).amax(-1)
+            assert float(d[stable].max()) < 2e-4 and float(d.max()) < 5e-2
+        else:
+            obj, cls, masks, scaled = head.simple_test_mask_preds(*_cuda(x, pf, mp), None, metas)
+    d = (obj.cpu() - torch.from_numpy(g['object_feats'])).abs().reshape(B, N, -1).amax(-1)
+    assert float(d[stable].max()) < 2e-4 and float(d.max()) < 5e-2
+    d = (cls.cpu() - torch.from_numpy(g['cls_score'])).abs().amax(-1)
+    assert float(d[stable].max()) < 1e-5 and float(d.max()) < 1e-2
+    flat = masks.reshape(-1).cpu()
+    idx = torch.from_numpy(g['sample_idx'])
+    srow = stable.reshape(-1)[idx // P]                                        # the (frame, kernel) row of each sampled logit
+    d = (flat[idx] - torch.from_numpy(g['sample_val'])).abs()
+    assert float(d[srow].max()) < TOL_LOGIT and float(d.max()) < 0.5
+    rs = masks.double().sum(dim=(-1, -2)).cpu()
+    drs = (rs - torch.from_numpy(g['mask_rowsum'])).abs()
+    assert float(drs[stable].max()) < 1e-4 * np.max(g['mask_rowabs'])
+    bits = np.unpackbits(np.packbits(flat.numpy() > 0) ^ g['sign_bits'])[:flat.numel()] & np.unpackbits(g['sign_valid'])[:flat.numel()]
+    wrong = torch.from_numpy(bits.astype(bool)).reshape(B, N, P)
+    assert not bool(wrong[stable].any()), 'binary masks (|logit| > 2e-3) of the stable kernels must be bit-exact'
+    assert float(wrong.float().mean()) < 1e-4
+
+
+def test_cfg2_size_free_running_vs_oracle_flip_budget(vkn):
+    """The FREE-RUNNING 3-stage head at BASELINE cfg2 size against the free-running oracle, with the chaos argument measured
+    instead of assumed: per stage, the binarised masks may differ from the oracle's only where the oracle's logit
+    is within 1e-4 of the threshold, at most 64 of the 3.8 M bits flip, and every kernel row whose mask has no flipped bit
+    stays within 1e-3 (logits) / 2e-4 (kernels) of the oracle."""
+    case = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256,
+                B=1, seed=12, video=0)
+    head, (x, pf, mp, _) = _build_head(vkn, case)
+    traces = []
+    run_oracle(case, traces=traces)
+    thr = vkn.ops.thr_logit(0.5)
+    xd, o, m = x.to(DEV), pf.to(DEV), mp.to(DEV)
+    clean = torch.ones(117, dtype=torch.bool)            # rows whose gather input never differed from the oracle's
+    total_flips = 0
+    with torch.no_grad():
+        for s in range(3):
+            r = head._mask_forward(s, xd, o, m, [dict()])
+            tr = traces[s]
+            o, m = r['object_feats'], r['mask_preds']
+            got, ref = m[0].cpu(), tr['new_mask_preds'][0]
+            assert maxabs(r['object_feats'][0].reshape(117, -1).cpu()[clean], tr['obj_feat'][0].reshape(117, -1)[clean]) < 2e-4, s
+            assert maxabs(got[clean], ref[clean]) < TOL_LOGIT, f'stage {s}: logits of kernels with unflipped masks'
+            flip = (got >= thr) != (ref >= thr)
+            fc = flip[clean]                              # kernels that entered this stage with oracle-identical masks
+            nflip = int(fc.sum())
+            total_flips += nflip
+            assert nflip <= 64, f'stage {s}: {nflip} flipped bits in clean kernels'
+            if nflip:
+                assert float((ref[clean][fc] - thr).abs().max()) < 1e-4, 'only near-threshold logits may flip'
+            clean = clean & ~flip.flatten(1).any(dim=1)   # the next stage gathers with these masks
+    assert int(clean.sum()) >= 100, f'{int(clean.sum())} clean rows, {total_flips} flips'
+
+
 def test_clip_forward_matches_frame_by_frame(vkn):
     g, case = load_golden('video_tiny')
     head, (x, pf, mp, prev) = _build_head(vkn, case)
@@ -585,6 +657,29 @@ def test_video_simple_test_with_previous(vkn):
         rows = r['rows'].numpy()
         for j, s_ in enumerate(things):
             assert torch.equal(tfeat[j], track[b, int(rows[s_['instance_id']])])
+
+
+def test_video_get_panoptic_vs_reference_golden(vkn):
+    """VideoKernelIterHead.get_panoptic (knet/video/kernel_iter_head.py:591-640): panoptic map, segments and `thing_obj_feat` —
+    the tracking embeddings of the accepted things in segment order — against the reference's own video head."""
+    from helpers import load_pan_golden, make_pan_case, pan_info_rows
+    g, case = load_pan_golden('pan_video')
+    cls, logits, meta = make_pan_case(case)
+    obj = torch.from_numpy(synth.normalish((case['B'], case['N'], 32), 77 + case['seed'], 1.0))
+    cfg = vkn.configs.roi_head_cfg(True, C=32, heads=8, ffn=64, ncls=case['ncls'], n_thing=case['T'], n_stuff=case['ncls'] - case['T'],
+                                   S=1, up=case['up'], nprop=case['Np'])
+    cfg['test_cfg'] = dict(max_per_img=case['Np'], mask_thr=0.5, merge_stuff_thing=dict(overlap_thr=0.6, instance_score_thr=0.25))
+    head = vkn.build_head(cfg).to(DEV).eval()
+    scaled = F.interpolate(logits, scale_factor=case['up'], align_corners=False, mode='bilinear') if case['up'] > 1 else logits
+    for b in range(case['B']):
+        bbox, segm, tmask, (seg, info), tfeat = head.get_panoptic(cls[b].to(DEV), scaled[b].to(DEV), head.test_cfg, meta,
+                                                                   obj_feat=obj[b].to(DEV))
+        rows = pan_info_rows(info)
+        ref = g[f'info{b}']
+        assert rows.shape == ref.shape and np.array_equal(rows[:, :4], ref[:, :4])
+        assert np.allclose(rows[:, 4], ref[:, 4], rtol=0, atol=1e-6, equal_nan=True)
+        assert np.mean(seg != g['panoptic_seg'][b]) < 2e-3          # arg-max ties under fp32 resampling noise only
+        assert torch.equal(tfeat.cpu(), torch.from_numpy(g[f'thing_obj_feat{b}'])), 'thing_obj_feat = obj_feat[things], exact'
 
 
 @pytest.mark.parametrize('name', ['det_cfg', 'video_cfg', 'det_tiny'])

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (via gpurun): kernel trace + HBM counters of bench.py; outputs under gpurun_out/.
 # usage: tools/gpu_profile.sh <tag> [bench args...]
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -12,5 +12,6 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py $A
 # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with sys-trace)
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python $R/bench.py $ARGS > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python $R/bench.py $ARGS > $OUT/bench_write.log 2>&1
-python $R/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o mfma -- python $R/bench.py $ARGS > $OUT/bench_mfma.log 2>&1
+python $R/tools/summarize_prof.py $OUT $OUT/pmc.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt | head -60

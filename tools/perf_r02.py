@@ -64,6 +64,12 @@ def main():
                 res[opt] = out.clone()
                 print(f'decode B={B} k_decode_mfma OPT={opt}: {t:8.1f} us  {alg / t / 1e6:7.3f} TB/s  frac {alg / t / 1e6 / 8:.3f}'
                       f'  bit-identical to OPT=0: {torch.equal(res[0], res[opt])}', flush=True)
+            os.environ['VKN_DECODE_OPT'] = '1'
+            for ppw in (1024, 2048, 4096, 8192, 512):
+                os.environ['VKN_DECODE_PXWG'] = str(ppw)
+                t = timeit(lambda: vkn.ops.mask_decode_planes(x, hi, lo, N, kb, out), reps=40)
+                print(f'decode B={B} k_decode_mfma OPT=1 px/wg={ppw}: {t:8.1f} us  {alg / t / 1e6:7.3f} TB/s  frac {alg / t / 1e6 / 8:.3f}', flush=True)
+            os.environ.pop('VKN_DECODE_PXWG')
             os.environ['VKN_DECODE_OPT'] = '0'
             os.environ['VKN_DECODE4'] = '1'
             t = timeit(lambda: vkn.ops.mask_decode_planes(x, hi, lo, N, kb, out), reps=40)

@@ -23,7 +23,7 @@ def short(n):
             if m and m.group(1) != '4':  # few-row launches (e.g. conv_seg of the kernel-init pass): not the roofline kernel
                 return f'k_decode_mfma<NB={m.group(1)}>'
             return 'k_decode_mfma<bits>' if (m and m.group(4) == '1') else 'k_decode_mfma'
-        for key in ('k_split_planes', 'k_gemm_s3'):
+        for key in ('k_split_planes', 'k_gemm_s3', 'k_fused_dgs', 'k_ffn_fused', 'k_gather_bits_w'):
             if key in n:
                 return key
     return n.split('(')[0][:48]
@@ -37,6 +37,14 @@ def db(tag):
 con = db('trace')
 if con:
     rows = con.execute('select name, start, end from kernels order by start').fetchall()
+    # the x-streaming kernels by frames per launch (grid_y): bench.py's breakdown also launches them at 1 / 8 frames
+    print('== x-streaming kernels by frames per launch (grid_y) ==')
+    for n, gy, c, avg, mn, mx in con.execute(
+            "select name, grid_y, count(*), avg(end - start), min(end - start), max(end - start) from kernels where name like "
+            "'%k_decode_mfma%' or name like '%k_fused_dgs%' or name like '%k_gather_mfma%' or name like '%k_upsample_s%' "
+            "group by name, grid_y order by name, grid_y"):
+        print(f'{short(n):28s} frames/launch={gy:5d} calls={c:4d} avg_us={avg / 1e3:9.2f} min_us={mn / 1e3:9.2f} max_us={mx / 1e3:9.2f}')
+    print()
     agg = defaultdict(lambda: [0, 0.0])
     for n, s, e in rows:
         a = agg[short(n)]
@@ -47,10 +55,11 @@ if con:
     print(f'{"kernel":48s} {"calls":>6s} {"avg_us":>9s} {"total_ms":>9s} {"pct":>6s}')
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
         print(f'{k:48s} {c:6d} {t / c / 1e3:9.2f} {t / 1e6:9.3f} {100 * t / tot:6.1f}')
-    G = [i for i, r in enumerate(rows) if 'k_gather_mfma' in r[0] or 'k_gather_bits_w' in r[0]]
-    if len(G) >= 13:
-        # bench.py: every step = one head call = 3 gathers; take the 4th head call (a timed one)
-        i0, j = G[9], G[12]
+    G = [i for i, r in enumerate(rows) if 'k_gather_mfma' in r[0]]
+    if len(G) >= 5:
+        # bench.py: every step = one head call = ONE logits gather (stage 0; stages 1.. gather inside the fused pass);
+        # take the 4th head call (a timed one)
+        i0, j = G[3], G[4]
         t0 = rows[i0][1]
         print('\n== timeline of one timed step (us): start, duration, gap to previous kernel ==')
         prev = None
@@ -62,6 +71,21 @@ if con:
             prev = e
         print(f'step span: {(prev - t0) / 1e3:.1f} us, of which gaps {gaps:.1f} us, kernels {j - i0}')
 
+# MFMA utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 32 SIMDs per shader engine) — the
+# counters are reported per shader engine (8 CUs = 32 SIMDs each); ROCm 7.2 has no gfx950 derived-metric section
+con = db('pmc_mfma')
+print('\n== MFMA utilisation per kernel (SQ_VALU_MFMA_BUSY_CYCLES / (32 SIMDs x GRBM_GUI_ACTIVE), per shader engine) ==')
+if not con:
+    print('not collected')
+else:
+    vals = defaultdict(dict)
+    for n, ctr, avg in con.execute('select name, counter_name, avg(counter_value) from pmc_events group by name, counter_name'):
+        vals[short(n)][ctr] = vals[short(n)].get(ctr, 0.0) + avg
+    for k, v in sorted(vals.items(), key=lambda kv: -kv[1].get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0))[:12]:
+        if v.get('GRBM_GUI_ACTIVE'):
+            print(f'{k:48s} MfmaUtil={v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (32.0 * v["GRBM_GUI_ACTIVE"]):6.3f}  '
+                  f'SQ_BUSY/GUI_ACTIVE={v.get("SQ_BUSY_CYCLES", 0.0) / v["GRBM_GUI_ACTIVE"]:5.2f}')
+
 pmc = {}
 for tag, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
     con = db(tag)
@@ -71,8 +95,11 @@ for tag, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         continue
     for n, c, avg, mx in con.execute('select name, count(*), avg(counter_value), max(counter_value) from pmc_events '
                                      'where counter_name = ? group by name order by avg(counter_value) desc limit 10', (ctr,)):
-        print(f'{short(n):48s} n={c:5d} mean_KB={avg:14.1f} max_KB={mx:14.1f}')
-        pmc.setdefault(short(n), {})[ctr + '_KB'] = avg
+        # launches of the full batch only (bench.py also launches the kernels at 1 / 8 frames): values within 10 % of the maximum
+        full = con.execute('select count(*), avg(counter_value) from pmc_events where counter_name = ? and name = ? and '
+                           'counter_value >= ?', (ctr, n, 0.9 * mx)).fetchone()
+        print(f'{short(n):48s} n={c:5d} mean_KB={avg:14.1f} max_KB={mx:14.1f}  full-batch launches: n={full[0]} mean_KB={full[1]:14.1f}')
+        pmc.setdefault(short(n), {})[ctr + '_KB'] = full[1]
 
 # sidecar for bench.py's roofline.traffic (committed under profiles/): HBM bytes per launch of the dominant kernels.
 # Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
@@ -80,7 +107,7 @@ for tag, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
 if len(sys.argv) > 2 and pmc:
     import json
     side = {}
-    for k in ('k_decode_mfma', 'k_gather_mfma<4>', 'k_upsample'):
+    for k in ('k_decode_mfma', 'k_fused_dgs', 'k_gather_mfma<4>', 'k_upsample'):
         if k in pmc and 'FETCH_SIZE_KB' in pmc[k] and 'WRITE_SIZE_KB' in pmc[k]:
             side[k] = dict(fetch_size_kb=pmc[k]['FETCH_SIZE_KB'], write_size_kb=pmc[k]['WRITE_SIZE_KB'],
                            hbm_bytes_per_launch=int((2 * pmc[k]['FETCH_SIZE_KB'] + pmc[k]['WRITE_SIZE_KB']) * 1024))

@@ -275,7 +275,8 @@ int run_link(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const 
 int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in, const float* masks_in,
               const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out, float* x_feat_out,
               float* track_out, const StageWs& s, unsigned flags, hipStream_t st, const unsigned* bits_in = nullptr,
-              unsigned* bits_out = nullptr, bool cls_sigmoid = false, bool gathered_in = false, bool gather_out = false) {
+              unsigned* bits_out = nullptr, bool cls_sigmoid = false, bool gathered_in = false, bool gather_out = false,
+              hipEvent_t prof0 = nullptr, hipEvent_t prof1 = nullptr) {
     // bits_in / bits_out (fused head only): the stage hand-off as bit words instead of fp32 logits — the gather consumes
     // nothing but bit(logit >= thr), so intermediate stages never write the 15.3 MB / frame of logits.
     // gather_out / gathered_in (fused head, default): the hand-off is the NEXT stage's gather itself — this stage's decode and the
@@ -373,7 +374,11 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         else if (gather_out)
             VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
         else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st));
-        else VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
+        else {
+            if (prof0 && hipEventRecord(prof0, st) != hipSuccess) return VKN_E_LAUNCH;  // vkn_head_forward_prof_f32: the decode kernel alone
+            VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
+            if (prof1 && hipEventRecord(prof1, st) != hipSuccess) return VKN_E_LAUNCH;
+        }
     } else {
         {
             VknGemmProb pr[2];
@@ -405,7 +410,11 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
                 VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P,
                                                        st));
             else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st));
-            else VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
+            else {
+                if (prof0 && hipEventRecord(prof0, st) != hipSuccess) return VKN_E_LAUNCH;
+                VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
+                if (prof1 && hipEventRecord(prof1, st) != hipSuccess) return VKN_E_LAUNCH;
+            }
         }
     }
 
@@ -780,6 +789,16 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
                          const float* proposal_feats, const float* mask_preds_in, const float* prev_obj, float* obj_out,
                          float* cls_prob, float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out,
                          void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    return vkn_head_forward_prof_f32(d, num_stages, stages, x, proposal_feats, mask_preds_in, prev_obj, obj_out, cls_prob,
+                                     mask_preds_out, scaled_out, upsample_stride, track_out, ws, ws_bytes, flags, stream, nullptr,
+                                     nullptr);
+}
+
+int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const float* x,
+                              const float* proposal_feats, const float* mask_preds_in, const float* prev_obj, float* obj_out,
+                              float* cls_prob, float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out,
+                              void* ws, size_t ws_bytes, unsigned flags, void* stream, void* ev_decode_start,
+                              void* ev_decode_stop) {
     VKN_TRY(check_dims(d));
     if (num_stages <= 0 || !stages || !x || !proposal_feats || !mask_preds_in || !obj_out || !cls_prob || !mask_preds_out)
         return VKN_E_ARG;
@@ -816,7 +835,9 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
         unsigned* b_out = (use_bits && !use_fused && !last) ? bits[sidx & 1] : nullptr;
         // the last stage's fc_cls epilogue applies the sigmoid and writes the caller's cls_prob directly
         VKN_TRY(run_stage(d, &stages[sidx], x, o_in, m_in, prev, last ? cls_prob : ctmp, m_out, o_out, nullptr,
-                          prev ? track_out : nullptr, s, flags, st, b_in, b_out, last, use_fused && sidx > 0, use_fused && !last));
+                          prev ? track_out : nullptr, s, flags, st, b_in, b_out, last, use_fused && sidx > 0, use_fused && !last,
+                          last ? static_cast<hipEvent_t>(ev_decode_start) : nullptr,
+                          last ? static_cast<hipEvent_t>(ev_decode_stop) : nullptr));
         m_in = m_out;
         o_in = o_out;
         if (clip) {

@@ -559,12 +559,14 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
     if ((size_t)C * P * 4 >= ((size_t)1 << 31) || (size_t)N * P * 4 >= ((size_t)1 << 31)) return VKN_E_SHAPE;  // 32-bit buffer offsets
     const int NPT = (N + 31) / 32 * 32;
     const VknDecodeStrides fs{shared ? 0 : (long long)NPT * C, shared ? 0 : (long long)N, (long long)out_rows * P};
-    // ~2048 workgroups per launch, 512 px (one tile per wave) each: measured best on MI355X (tools/decode_ablation.py: 95 us vs
-    // 108 us at 1024 px, B = 8, cfg2); fewer, larger workgroups only when the batch alone already oversubscribes the chip.
-    int wg_per_frame = 2048 / B;
-    if (wg_per_frame < 1) wg_per_frame = 1;
-    int px_per_wg = (P + wg_per_frame - 1) / wg_per_frame;
-    px_per_wg = (px_per_wg + 511) / 512 * 512;  // 8 waves x 64-px tiles = 4 waves x 128-px tiles
+    // ONE workgroup per CU over the whole batch whenever the batch is large enough (round 2, tools/perf_r02.py, cfg2, early x loads):
+    // a persistent workgroup stages the kernel planes once and its fragment ring runs on across tiles, while every workgroup
+    // boundary costs a store drain + plane staging + first-load latency.  Measured px / workgroup -> us: B = 32: 512 -> 329,
+    // 2048 -> 332, 4096 (256 WGs) -> 309; B = 16: 512 -> 161, 2048 (256 WGs) -> 153; B = 8: 512 -> 87, 1024 (256 WGs) -> 88;
+    // B <= 4: 512 is best (fewer than 256 WGs either way).  Intermediate sizes (2-4 WGs per CU in sequence) are the slowest.
+    long long ppx = ((long long)B * P + 255) / 256;
+    int px_per_wg = (int)((ppx + 511) / 512 * 512);  // 8 waves x 64-px tiles
+    if (px_per_wg < 512) px_per_wg = 512;
     const int ppw_dbg = vkn_dbg_env("VKN_DECODE_PXWG", 0);  // debug build only: override pixels per workgroup
     if (ppw_dbg >= 512) px_per_wg = ppw_dbg / 512 * 512;
     const int G2 = (P + px_per_wg - 1) / px_per_wg;

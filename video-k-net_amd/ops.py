@@ -288,7 +288,7 @@ def stage_forward(dims: VknDims, pack: StagePack, x, obj_in, masks_in, prev_obj=
 
 
 def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=None, upsample_stride=1, want_track=False,
-                 want_scaled=True, flags=0, clip_first_prev=None):
+                 want_scaled=True, flags=0, clip_first_prev=None, decode_events=None):
     """The S-stage loop in one C call.  Returns (obj [B,N,C], cls_prob [B,N,ncls], mask_preds [B,N,H,W],
     scaled_mask_preds [B,N,H*s,W*s] | None, track [B,N,C] | None)."""
     x, pf, mp = _req(x, 'x'), _req(proposal_feats, 'proposal_feats'), _req(mask_preds, 'mask_preds')
@@ -320,9 +320,18 @@ def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=N
     nb = L.vkn_head_workspace_bytes(ctypes.byref(dims))
     ws = _workspace(max(nb, 256), dev)
     with torch.cuda.device(dev):
-        check(L.vkn_head_forward_f32(ctypes.byref(dims), S, arr, _ptr(x), _ptr(pf), _ptr(mp), _ptr(prev_obj), _ptr(obj),
-                                     _ptr(cls), _ptr(masks), _ptr(scaled), int(upsample_stride), _ptr(track), _ptr(ws),
-                                     ws.numel(), flags, _stream()))
+        if decode_events is not None:
+            # (start, stop) torch.cuda.Event(enable_timing=True) pair, each recorded once before (that creates the HIP event): the
+            # library records them around the last stage's mask-decode launch on the current stream
+            e0, e1 = decode_events
+            check(L.vkn_head_forward_prof_f32(ctypes.byref(dims), S, arr, _ptr(x), _ptr(pf), _ptr(mp), _ptr(prev_obj), _ptr(obj),
+                                              _ptr(cls), _ptr(masks), _ptr(scaled), int(upsample_stride), _ptr(track), _ptr(ws),
+                                              ws.numel(), flags, _stream(), ctypes.c_void_p(e0.cuda_event),
+                                              ctypes.c_void_p(e1.cuda_event)))
+        else:
+            check(L.vkn_head_forward_f32(ctypes.byref(dims), S, arr, _ptr(x), _ptr(pf), _ptr(mp), _ptr(prev_obj), _ptr(obj),
+                                         _ptr(cls), _ptr(masks), _ptr(scaled), int(upsample_stride), _ptr(track), _ptr(ws),
+                                         ws.numel(), flags, _stream()))
     return obj, cls, masks, (scaled if scaled is not None else masks), track
 
 
