@@ -186,6 +186,16 @@ int vkn_stage_forward_f32(const VknDims* d, const VknStageWeights* w, const floa
 int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* cur_obj, const float* prev_obj,
                        float* track_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the [B*N, C] chain of one stage ALONE (ops ii-a, ii-b and the cls / mask FC branches of vkn_stage_forward_f32, no gather,
+ *      no decode): x_feat [B][N][C] is given (already feat-transformed), the folded fp32 decode kernels Kf = fc_mask(.) . W_ft
+ *      [B][N][C] and bias kb = fc_mask(.) . b_ft [B][N] are returned.  For heads whose gather output is post-processed before the
+ *      update — the clip-level VIS heads average x_feat over the frames of a clip (`query_merge_method='mean'`,
+ *      knet_vis/tracker/kernel_update_head.py:240-243) and decode every frame with the SAME kernels (:318-330).  cls_logits may be
+ *      NULL (stages built with with_cls=False have no classification branch, :133-146).  d->H, d->W are ignored. */
+int vkn_stage_chain_f32(const VknDims* d, const VknStageWeights* w, const float* x_feat, const float* obj_in, float* cls_logits,
+                        float* kernels_out, float* kb_out, float* obj_out, void* ws, size_t ws_bytes, unsigned flags,
+                        void* stream);
+
 /* ---- the S-stage loop.  Replaces `KernelIterHead.simple_test_mask_preds` knet/det/kernel_iter_head.py:285-311 and
  *      `VideoKernelIterHead.simple_test_mask_preds_plus_previous` knet/video/kernel_iter_head.py:529-564
  *      (stage loop + last-stage bilinear upsample `_mask_forward` :118-137 + cls sigmoid :307-308).
@@ -222,10 +232,11 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
  *        cat_stuff (eval):     mask_preds[:, Np:] = seg_preds[:, num_thing_classes:],
  *                              proposal_feats[:, Np:] = conv_seg.weight[num_thing_classes:]                         (:255-263)
  *      in : loc_feats, sem_feats [B][C][P] (sem_feats NULL: semantic_fpn=False, then x_feats = loc_feats);
- *           init_w [Np][C]; seg_w [ncls][C], seg_b [ncls]; with_obj = proposal_feats_with_obj; thr_logit as in VknDims.
+ *           init_w [Np][C]; seg_w [ncls][C], seg_b [ncls]; with_obj: 0 = proposal_feats_with_obj off, 1 = on with
+ *           use_binary=True, 2 = on with use_binary=False (weights (sigmoid(z) > 0.5) * sigmoid(z), :246-247); thr_logit as in VknDims.
  *      out: x_feats [B][C][P]; mask_preds [B][N][P] and proposal_feats [B][N][C] with N = Np + (cat_stuff ? ncls -
  *           num_thing_classes : 0); seg_preds [B][ncls][P] or NULL (kept in the workspace).
- *      `use_binary=False` (soft weights) is not provided: every shipped config sets use_binary=True. */
+ */
 size_t vkn_kernel_init_workspace_bytes(int B, int Np, int ncls, int C, int P);
 int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const float* init_w, const float* seg_w,
                         const float* seg_b, int num_thing_classes, int cat_stuff, int with_obj, float thr_logit, float* x_feats,

@@ -188,6 +188,8 @@ INIT_CASES = {
     'init_tiny': dict(C=64, nprop=12, ncls=5, n_thing=2, H=8, W=16, B=2, seed=21, sem=True, cat=True),
     'init_odd': dict(C=64, nprop=21, ncls=0, n_thing=0, H=9, W=15, B=1, seed=22, sem=False, cat=False),
     'init_cfg': dict(C=256, nprop=100, ncls=19, n_thing=2, H=16, W=32, B=2, seed=23, sem=True, cat=True),
+    # use_binary=False: gather weights (sigmoid(z) > 0.5) * sigmoid(z)  (knet/det/kernel_head.py:246-247)
+    'init_soft': dict(C=64, nprop=12, ncls=5, n_thing=2, H=8, W=16, B=2, seed=24, sem=True, cat=True, soft=True),
 }
 
 
@@ -207,7 +209,7 @@ def run_init_case(name, p):
     """ConvKernelHead.simple_test_rpn of the reference (knet/det/kernel_head.py:506-508) behind a pass-through neck."""
     cfg = dict(type='ConvKernelHead', num_proposals=p['nprop'], in_channels=p['C'], out_channels=p['C'], num_loc_convs=0,
                num_seg_convs=0, localization_fpn=dict(type='PassThroughNeck'), conv_kernel_size=1, semantic_fpn=p['sem'],
-               num_classes=max(p['ncls'], 1), use_binary=True, proposal_feats_with_obj=True, feat_downsample_stride=1,
+               num_classes=max(p['ncls'], 1), use_binary=not p.get('soft', False), proposal_feats_with_obj=True, feat_downsample_stride=1,
                num_thing_classes=p['n_thing'], num_stuff_classes=p['ncls'] - p['n_thing'], cat_stuff_mask=p['cat'])
     head = build_head(cfg)
     head.eval()
@@ -455,6 +457,33 @@ def run_train_case(name, p):
     print(f'{name}: ok  total={float(total):.5f}  ' + ' '.join(f'{k}={float(v):.4f}' for k, v in sorted(losses.items())[:6]))
 
 
+def run_instance_case():
+    """Instance-only results (do_panoptic=False): KernelIterHead.simple_test -> top-k -> get_seg_masks / segm2result
+    (knet/det/kernel_iter_head.py:270-281, knet/det/kernel_update_head.py:443-481), YouTube-VIS-like class layout (things only)."""
+    p = dict(video=False, C=64, heads=8, ffn=128, ncls=7, n_thing=7, n_stuff=0, S=2, up=2, nprop=20)
+    N, H, W, B, seed = 20, 8, 16, 2, 81
+    cfg = head_cfg(**p)
+    cfg.update(do_panoptic=False, test_cfg=AttrDict(max_per_img=10, mask_thr=0.5))
+    head = build_head(cfg)
+    head.eval()
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    load_formula_weights(head, shapes, seed)
+    x, pf, mp = (torch.from_numpy(a) for a in synth.head_inputs(B, N, p['C'], H, W, seed))
+    meta = dict(img_shape=(60, 120, 3), batch_input_shape=(64, 128), ori_shape=(90, 180, 3))
+    with torch.no_grad():
+        res = head.simple_test(x, pf, mp, None, [meta] * B)
+    out = dict(case=np.array([p['C'], p['heads'], p['ffn'], p['ncls'], p['n_thing'], p['n_stuff'], p['S'], p['up'], p['nprop'], N, H, W,
+                              B, seed, 0], dtype=np.int64))
+    for b, (bbox_result, segm_result) in enumerate(res):
+        out[f'scores{b}'] = np.concatenate([bb[:, 4] for bb in bbox_result])            # class-major, score order within a class
+        out[f'labels{b}'] = np.concatenate([np.full(len(bb), c) for c, bb in enumerate(bbox_result)]).astype(np.int64)
+        masks = [m for per_cls in segm_result for m in per_cls]
+        out[f'masks{b}'] = np.packbits(np.stack(masks).astype(bool)) if masks else np.zeros(0, np.uint8)
+        out[f'nmask{b}'] = np.int64(len(masks))
+    np.savez_compressed(os.path.join(OUT, 'inst_tiny.npz'), **out)
+    print('inst_tiny: ok  instances per image =', [int(out[f'nmask{b}']) for b in range(B)])
+
+
 def run_assign_soft():
     """MaskHungarianAssigner with SOFT ground-truth masks (bilinearly down-sampled, knet/det/knet.py:131): the costs use the real
     values of the targets, not their binarisation."""
@@ -522,6 +551,8 @@ if __name__ == '__main__':
             run_train_case(name, p)
     if not only or 'assign_soft' in only:
         run_assign_soft()
+    if not only or 'inst_tiny' in only:
+        run_instance_case()
     if not only or 'init_keys' in only:
         init_keys()
     if not only or 'thr_kat' in only:

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Goldens of the YouTube-VIS model family (`knet_vis/`, BASELINE cfg4) from the REFERENCE ITSELF — build container only.
+
+A separate process from oracle/gen_golden.py: `knet_vis` registers heads under the SAME registry names as `knet`
+(`KernelUpdateHead`, ...).  The reference's files are imported unmodified through oracle/standins/ (plus the `mmtrack.transform`
+and `mmdet.datasets.coco_panoptic` stand-ins).  Only outputs are stored.
+
+    python oracle/gen_golden_vis.py        # writes tests/golden/vis_*.npz
+
+  vis_tiny   KernelIterHeadVideo (per-frame roi head, instance results + features) -> KernelFrameIterHeadVideo (clip-level tracker:
+             query fusion 'mean', 3 stages with assign_stages = 2: two clip-level `with_cls` stages, one per-frame stage)
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get('VKN_REFERENCE', '/root/reference')
+sys.path.insert(0, os.path.join(HERE, 'standins'))
+sys.path.insert(1, REF)
+sys.path.insert(2, ROOT)
+
+import copy  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import synth  # noqa: E402
+
+import knet_vis.kernel_updator  # noqa: E402,F401
+import knet_vis.det.kernel_update_head  # noqa: E402,F401
+import knet_vis.tracker.kernel_iter_head  # noqa: E402,F401
+import knet_vis.tracker.kernel_update_head  # noqa: E402,F401
+import knet_vis.tracker.kernel_frame_iter_head  # noqa: E402,F401
+import knet.cross_entropy_loss  # noqa: E402,F401
+from mmdet.models.builder import build_head  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+
+def stage_cfg(typ, C, heads, ffn, ncls, up, **extra):
+    d = dict(type=typ, num_classes=ncls, num_thing_classes=ncls, num_stuff_classes=0, num_ffn_fcs=2, num_heads=heads, num_cls_fcs=1,
+             num_mask_fcs=1, feedforward_channels=ffn, in_channels=C, out_channels=C, dropout=0.0, mask_thr=0.5, conv_kernel_size=1,
+             mask_upsample_stride=up, ffn_act_cfg=dict(type='ReLU', inplace=True), with_ffn=True,
+             feat_transform_cfg=dict(conv_cfg=dict(type='Conv2d'), act_cfg=None),
+             kernel_updator_cfg=dict(type='KernelUpdator', in_channels=C, feat_channels=C, out_channels=C, input_feat_shape=3,
+                                     act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN')),
+             loss_mask=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0), loss_dice=dict(type='DiceLoss', loss_weight=4.0),
+             loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0))
+    d.update(extra)
+    return d
+
+
+def pack_masks(mask_results):
+    masks = [m for per_cls in mask_results for m in per_cls]
+    return (np.packbits(np.stack(masks).astype(bool)), len(masks)) if masks else (np.zeros(0, np.uint8), 0)
+
+
+def run(name, C, heads, ffn, ncls, N, H, W, up, S, bs, nf, seed, kmax):
+    test_cfg = AttrDict(max_per_img=kmax, mask_thr=0.5)
+    roi = build_head(dict(type='KernelIterHeadVideo', num_stages=S, stage_loss_weights=[1] * S, proposal_feature_channel=C,
+                          num_thing_classes=ncls, num_stuff_classes=0, num_proposals=N, test_cfg=test_cfg,
+                          mask_head=[stage_cfg('KernelUpdateHead', C, heads, ffn, ncls, up) for _ in range(S)]))
+    trk = build_head(dict(type='KernelFrameIterHeadVideo', num_proposals=N, num_stages=3, assign_stages=2, proposal_feature_channel=C,
+                          stage_loss_weights=(1., 1., 1.), num_thing_classes=ncls, num_stuff_classes=0, test_cfg=test_cfg,
+                          mask_head=stage_cfg('KernelUpdateHeadVideo', C, heads, ffn, ncls, up, num_proposals=N)))
+    roi.eval()
+    trk.eval()
+    out = dict(case=np.array([C, heads, ffn, ncls, N, H, W, up, S, bs, nf, seed, kmax], dtype=np.int64))
+    for tag, mod, sd_seed in (('roi', roi, seed), ('trk', trk, seed + 1)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, sd_seed).items()}, strict=True)
+        out[tag + '_keys'] = np.array(sorted(shapes))
+        out[tag + '_shapes'] = np.array([str(shapes[k]) for k in sorted(shapes)])
+    B = bs * nf
+    x, pf, mp = (torch.from_numpy(a) for a in synth.head_inputs(B, N, C, H, W, seed))
+    meta = dict(img_shape=(H * 8 - 4, W * 8 - 8, 3), batch_input_shape=(H * 8, W * 8), ori_shape=(H * 6, W * 6, 3))
+    img_metas = [meta] * bs
+    ref_img_metas = [[meta] * nf for _ in range(bs)]
+    with torch.no_grad():
+        res, feats = roi.simple_test(x, pf, mp, None, img_metas, ref_img_metas, rescale=True)
+        tres, tfeats = trk.simple_test(x=feats['x_feats'], img_metas=img_metas, ref_img_metas=ref_img_metas, cls_scores=feats['cls_scores'],
+                                       masks=feats['masks'], obj_feats=feats['obj_feats'])
+    for k in ('obj_feats', 'cls_scores', 'masks'):
+        out['roi_' + k] = feats[k].numpy()
+        out['trk_' + k] = tfeats[k].numpy()
+    for i, (bbox_result, segm_result) in enumerate(res):
+        out[f'roi_scores{i}'] = np.concatenate([bb[:, 4] for bb in bbox_result])
+        out[f'roi_labels{i}'] = np.concatenate([np.full(len(bb), c) for c, bb in enumerate(bbox_result)]).astype(np.int64)
+        out[f'roi_masks{i}'], out[f'roi_nmask{i}'] = pack_masks(segm_result)
+    for b in range(bs):
+        for f in range(nf):
+            bbox_results, mask_results = tres[b][f]
+            out[f'trk_rows{b}_{f}'] = np.concatenate([np.concatenate([r, np.full((len(r), 1), c)], axis=1) for c, r in enumerate(bbox_results)])
+            out[f'trk_masks{b}_{f}'], out[f'trk_nmask{b}_{f}'] = pack_masks(mask_results)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(f'{name}: ok  roi instances/frame = {[int(out[f"roi_nmask{i}"]) for i in range(B)]}, tracker instances = {int(out["trk_nmask0_0"])}')
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    run('vis_tiny', C=64, heads=8, ffn=128, ncls=7, N=20, H=8, W=16, up=2, S=2, bs=2, nf=3, seed=91, kmax=10)
+    run('vis_cfg', C=256, heads=8, ffn=2048, ncls=40, N=100, H=12, W=20, up=2, S=3, bs=1, nf=2, seed=93, kmax=10)

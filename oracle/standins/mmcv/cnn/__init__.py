@@ -67,3 +67,9 @@ class ConvModule(nn.Module):
         if self.with_activation:
             x = self.activate(x)
         return x
+
+
+def build_model_from_cfg(cfg, registry, default_args=None):
+    """mmcv.cnn.build_model_from_cfg: registry build (plumbing)."""
+    from mmcv.registry import build_from_cfg
+    return build_from_cfg(cfg, registry, default_args)

@@ -137,3 +137,34 @@ def train_targets(B, n_thing, n_stuff, Hs, Ws, seed, gmin=2, gmax=5, soft=True):
                                 for j in idx])
         out.append(dict(gt_masks=gt, gt_labels=labels, gt_sem_cls=sem_cls, gt_sem_seg=sem_seg))
     return out
+
+
+def tracker_sequence(T, n_obj, emb, n_cls, seed):
+    """A synthetic video for the quasi-dense tracker: `n_obj` objects drift over T frames (some disappear / reappear), each frame
+    lists detections in shuffled order: boxes [n,5] (x1,y1,x2,y2,score), labels [n], embeddings [n,emb] = object code + noise, plus
+    a few low-score duplicates and clutter.  Returns a list of (bboxes, labels, embeds, true_object_index)."""
+    codes = normalish((n_obj, emb), 900 + seed, 1.0) * 3.0
+    cls = (uniform((n_obj,), 901 + seed, 0.0, 1.0).astype(np.float64) * n_cls).astype(np.int64)
+    c0 = uniform((n_obj, 2), 902 + seed, 40.0, 600.0).astype(np.float64)
+    vel = uniform((n_obj, 2), 903 + seed, -12.0, 12.0).astype(np.float64)
+    size = uniform((n_obj, 2), 904 + seed, 20.0, 90.0).astype(np.float64)
+    frames = []
+    for t in range(T):
+        vis = uniform((n_obj,), 910 + 31 * seed + t, 0.0, 1.0) < 0.85
+        rows, labs, embs, who = [], [], [], []
+        for o in (int(v) for v in np.nonzero(vis)[0]):
+            c = c0[o] + vel[o] * t
+            sc = float(uniform((1,), 920 + 97 * seed + 13 * t + o, 0.25, 0.99)[0])
+            rows.append([c[0] - size[o, 0], c[1] - size[o, 1], c[0] + size[o, 0], c[1] + size[o, 1], sc])
+            labs.append(cls[o])
+            embs.append(codes[o] + normalish((emb,), 930 + 101 * seed + 17 * t + o, 0.3))
+            who.append(o)
+            if (o + t) % 4 == 0:      # a low-score near-duplicate of the same object
+                rows.append([c[0] - size[o, 0] + 3, c[1] - size[o, 1] + 2, c[0] + size[o, 0] + 3, c[1] + size[o, 1] + 2, sc * 0.4])
+                labs.append(cls[o])
+                embs.append(codes[o] + normalish((emb,), 940 + 101 * seed + 17 * t + o, 0.3))
+                who.append(o)
+        order = np.argsort(uniform((len(rows),), 950 + seed * 7 + t, 0.0, 1.0))
+        frames.append((np.asarray(rows, np.float32)[order], np.asarray(labs, np.int64)[order],
+                       np.stack(embs).astype(np.float32)[order], np.asarray(who, np.int64)[order]))
+    return frames

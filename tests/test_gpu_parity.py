@@ -268,7 +268,7 @@ def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name):
 def test_cfg2_size_free_running_vs_oracle_flip_budget(vkn):
     """The FREE-RUNNING 3-stage head at BASELINE cfg2 size against the free-running oracle, with the chaos argument measured
     instead of assumed: per stage, the binarised masks may differ from the oracle's only where the oracle's logit
-    is within 1e-4 of the threshold, at most 64 of the 3.8 M bits flip, and every kernel row whose mask has no flipped bit
+    is within 5e-4 of the threshold (half the 1e-3 logit budget), at most 64 of the 3.8 M bits flip, and every kernel row whose mask has no flipped bit
     stays within 1e-3 (logits) / 2e-4 (kernels) of the oracle."""
     case = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256,
                 B=1, seed=12, video=0)
@@ -293,7 +293,7 @@ def test_cfg2_size_free_running_vs_oracle_flip_budget(vkn):
             total_flips += nflip
             assert nflip <= 64, f'stage {s}: {nflip} flipped bits in clean kernels'
             if nflip:
-                assert float((ref[clean][fc] - thr).abs().max()) < 1e-4, 'only near-threshold logits may flip'
+                assert float((ref[clean][fc] - thr).abs().max()) < 5e-4, 'only near-threshold logits (within half the 1e-3 budget) may flip'
             clean = clean & ~flip.flatten(1).any(dim=1)   # the next stage gathers with these masks
     assert int(clean.sum()) >= 100, f'{int(clean.sum())} clean rows, {total_flips} flips'
 
@@ -450,6 +450,28 @@ def test_kernel_init_vs_oracle_and_reference(vkn, name, flags):
     if case['cat']:
         # stuff kernels are copies of conv_seg.weight[num_thing:]
         assert torch.equal(prop[:, nprop:].cpu(), sw[case['n_thing']:].reshape(1, -1, case['C']).expand(case['B'], -1, -1))
+
+
+def test_kernel_init_soft_weights_vs_reference(vkn):
+    """`use_binary=False`: gather weights (sigmoid(z) > 0.5) * sigmoid(z) (knet/det/kernel_head.py:246-247), real-valued left
+    operand of k_gather_mfma<., 3>: vs the reference golden (rows clear of the threshold) and teacher-forced vs fp64."""
+    from helpers import load_init_golden, make_init_case
+    g, case = load_init_golden('init_soft')
+    loc, sem, iw, sw, sb = make_init_case(case)
+    prop, xf, masks, seg = vkn.ops.kernel_init(*_cuda(loc, sem, iw, sw, sb), case['n_thing'], bool(case['cat']), True, use_binary=False)
+    nprop = case['nprop']
+    assert maxabs(masks, g['mask_preds']) < TOL_LOGIT * 0.1
+    z = masks[:, :nprop].cpu().double()
+    w = (z >= vkn.ops.thr_logit(0.5)).double() * torch.sigmoid(masks[:, :nprop].cpu()).double()
+    want = iw.reshape(1, nprop, -1).double() + torch.einsum('bnhw,bchw->bnc', w, xf.cpu().double())
+    scale = float(want.abs().max())
+    assert float((prop[:, :nprop].cpu().double() - want).abs().max()) < 2e-5 * scale
+    ok = _init_rows_off_threshold(g['mask_preds'], nprop, vkn.ops.thr_logit(0.5))
+    gp = torch.from_numpy(g['proposal_feats']).reshape(prop.shape).double()
+    assert float((prop.cpu().double() - gp)[:, :nprop][ok].abs().max()) < 2e-4 * scale
+    # and it is NOT the binary gather
+    pb = vkn.ops.kernel_init(*_cuda(loc, sem, iw, sw, sb), case['n_thing'], bool(case['cat']), True)[0]
+    assert float((pb - prop)[:, :nprop].abs().max()) > 1e-2 * scale
 
 
 def test_kernel_init_feeds_the_head(vkn):
@@ -657,6 +679,30 @@ def test_video_simple_test_with_previous(vkn):
         rows = r['rows'].numpy()
         for j, s_ in enumerate(things):
             assert torch.equal(tfeat[j], track[b, int(rows[s_['instance_id']])])
+
+
+def test_instance_only_results_vs_reference_golden(vkn):
+    """do_panoptic=False (BASELINE cfg4's result path): `simple_test` -> per image (bbox_result, segm_result) — scores, labels and
+    the full-resolution boolean masks against the reference's own simple_test (knet/det/kernel_iter_head.py:270-281)."""
+    g, case = load_golden('inst_tiny')
+    cfg = vkn.configs.roi_head_cfg(False, C=case['C'], heads=case['heads'], ffn=case['ffn'], ncls=case['ncls'], n_thing=case['n_thing'],
+                                   n_stuff=case['n_stuff'], S=case['S'], up=case['up'], nprop=case['nprop'], do_panoptic=False,
+                                   test_cfg=dict(max_per_img=10, mask_thr=0.5))
+    head = vkn.build_head(cfg)
+    _, sd, x, pf, mp, _ = make_case(case)
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV).eval()
+    meta = dict(img_shape=(60, 120, 3), batch_input_shape=(64, 128), ori_shape=(90, 180, 3))
+    with torch.no_grad():
+        res = head.simple_test(*_cuda(x, pf, mp), None, [meta] * case['B'])
+    for b, (bbox_result, segm_result) in enumerate(res):
+        assert len(bbox_result) == case['ncls'] and len(segm_result) == case['ncls']
+        scores = np.concatenate([bb[:, 4] for bb in bbox_result])
+        labels = np.concatenate([np.full(len(bb), c) for c, bb in enumerate(bbox_result)])
+        assert np.array_equal(labels, g[f'labels{b}']) and np.max(np.abs(scores - g[f'scores{b}'])) < 1e-5
+        masks = np.stack([m for per_cls in segm_result for m in per_cls]).astype(bool)
+        ref = np.unpackbits(g[f'masks{b}'])[:masks.size].reshape(masks.shape).astype(bool)
+        assert masks.shape == (int(g[f'nmask{b}']), 90, 180) and np.mean(masks != ref) < 1e-3
 
 
 def test_video_get_panoptic_vs_reference_golden(vkn):

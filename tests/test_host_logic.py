@@ -128,8 +128,7 @@ def test_conv_kernel_head_state_dict_matches_reference(vkn, tag, refine):
     assert sorted(sd) == list(g[tag + '_keys'])
     assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == list(g[tag + '_shapes'])
     head.init_weights()
-    with pytest.raises(NotImplementedError):
-        vkn.build_head(dict(type='ConvKernelHead', proposal_feats_with_obj=True, use_binary=False))
+    assert vkn.build_head(dict(type='ConvKernelHead', proposal_feats_with_obj=True, use_binary=False)).use_binary is False   # soft weights: built
     with pytest.raises(NotImplementedError):
         vkn.build_head(dict(type='ConvKernelHead', conv_kernel_size=3))
     with pytest.raises(vkn.VknLibraryError):   # CPU tensors: no fallback
@@ -189,3 +188,20 @@ def test_mask_hungarian_assigner_surface(vkn):
         a.assign(torch.zeros(4, 8, 8), torch.zeros(4, 2), torch.zeros(2, 8, 8), torch.zeros(2, dtype=torch.long))
     r = a.assign(torch.zeros(4, 8, 8), torch.zeros(4, 2), torch.zeros(0, 8, 8), torch.zeros(0, dtype=torch.long))
     assert r.num_gts == 0 and (r.gt_inds == 0).all()
+
+
+def test_quasi_dense_tracker_ids_bit_exact_vs_reference(vkn):
+    """QuasiDenseEmbedTracker.match over synthetic videos: kept detections, labels and ids per frame equal the reference's own
+    tracker (oracle/gen_golden_tracker.py), for the three match metrics."""
+    from oracle import synth
+    g = dict(np.load(os.path.join(GOLDEN, 'qd_tracker.npz'), allow_pickle=False))
+    cfg = dict(type='QuasiDenseEmbedTracker', init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5,
+               memo_backdrop_frames=1, memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7,
+               with_cats=True)
+    for name in ('trk_a', 'trk_b', 'trk_c', 'trk_d'):
+        T, n_obj, emb, n_cls, seed = (int(v) for v in g[name + '_case'])
+        trk = vkn.build_tracker(dict(cfg, match_metric=str(g[name + '_metric'])))
+        for t, (bb, lab, em, _) in enumerate(synth.tracker_sequence(T, n_obj, emb, n_cls, seed)):
+            b, l_, ids = trk.match(bboxes=torch.from_numpy(bb), labels=torch.from_numpy(lab), track_feats=torch.from_numpy(em), frame_id=t)
+            assert np.array_equal(ids.numpy(), g[f'{name}_ids{t}']), (name, t)
+            assert np.array_equal(l_.numpy(), g[f'{name}_labels{t}']) and np.array_equal(b.numpy(), g[f'{name}_bboxes{t}'])

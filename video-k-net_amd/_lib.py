@@ -19,7 +19,7 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_w
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
            'vkn_decode_gather_supported', 'vkn_decode_gather_f32',
            'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
-           'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32',
+           'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_stage_chain_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32',
            'vkn_head_forward_prof_f32',
            'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32',
            'vkn_sizeof_panoptic_cfg', 'vkn_panoptic_workspace_bytes', 'vkn_panoptic_joint_f32',
@@ -194,6 +194,8 @@ def lib():
     L.vkn_stage_workspace_bytes.argtypes = [pD]
     L.vkn_stage_forward_f32.restype = c_int
     L.vkn_stage_forward_f32.argtypes = [pD, pW] + [_fp] * 9 + [_fp, c_size, c_uint, _fp]
+    L.vkn_stage_chain_f32.restype = c_int
+    L.vkn_stage_chain_f32.argtypes = [pD, pW] + [_fp] * 6 + [_fp, c_size, c_uint, _fp]
     L.vkn_head_workspace_bytes.restype = c_size
     L.vkn_head_workspace_bytes.argtypes = [pD]
     L.vkn_head_forward_f32.restype = c_int

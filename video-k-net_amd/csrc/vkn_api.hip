@@ -276,7 +276,11 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
               const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out, float* x_feat_out,
               float* track_out, const StageWs& s, unsigned flags, hipStream_t st, const unsigned* bits_in = nullptr,
               unsigned* bits_out = nullptr, bool cls_sigmoid = false, bool gathered_in = false, bool gather_out = false,
-              hipEvent_t prof0 = nullptr, hipEvent_t prof1 = nullptr) {
+              hipEvent_t prof0 = nullptr, hipEvent_t prof1 = nullptr, const float* xfeat_in = nullptr, float* kern_out = nullptr,
+              float* kb_out = nullptr) {
+    // xfeat_in / kern_out / kb_out (vkn_stage_chain_f32): the [B*N, C] chain alone — the caller supplies x_feat (already
+    // feat-transformed and, for the clip-level VIS heads, merged over the frames of a clip) and receives the folded fp32 decode
+    // kernels + bias instead of decoded masks; no gather and no decode are launched, x / masks_in / masks_out are unused.
     // bits_in / bits_out (fused head only): the stage hand-off as bit words instead of fp32 logits — the gather consumes
     // nothing but bit(logit >= thr), so intermediate stages never write the 15.3 MB / frame of logits.
     // gather_out / gathered_in (fused head, default): the hand-off is the NEXT stage's gather itself — this stage's decode and the
@@ -284,7 +288,9 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     // stage (gathered_in) finds them; neither logits nor bit words exist.
     const int B = d->B, N = d->N, C = d->C, P = d->H * d->W, M = B * N;
     const bool ref = (flags & VKN_FLAG_REF_KERNELS) != 0;
-    const bool ref_decode = ref || (P & 1);  // odd H*W: mask rows are not 8-byte aligned -> exact-fp32 FMA decode kernel
+    const bool chain_only = kern_out != nullptr;
+    const bool ref_decode = ref || (P & 1) || chain_only;  // odd H*W: mask rows are not 8-byte aligned -> exact-fp32 FMA decode kernel
+                                                           // (chain_only: fp32 folded kernels are the output)
     const bool has_ft = w->ft_w != nullptr;
     PrepW pw{};
     if (w->prepared && !(flags & VKN_FLAG_EXACT_GEMM)) {
@@ -294,8 +300,8 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     }
 
     // (i) mask gather                                        knet/det/kernel_update_head.py:190-195
-    if (gathered_in) {
-        // s.xraw / s.cnt were produced by the previous stage's fused decode -> gather pass
+    if (gathered_in || xfeat_in) {
+        // s.xraw / s.cnt were produced by the previous stage's fused decode -> gather pass (or x_feat is given)
     } else if (ref)
         VKN_TRY(vkn_launch_gather_ref(x, masks_in, d->thr_logit, s.xraw, s.cnt, B, N, C, P, st));
     else if (bits_in)
@@ -308,7 +314,9 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     const bool comp = pw.dynft != nullptr;
     float* xfeat = x_feat_out ? x_feat_out : s.xfeat;
     VknEpi e = mk_epi(d);
-    if (has_ft) {
+    if (xfeat_in) {
+        xfeat = const_cast<float*>(xfeat_in);
+    } else if (has_ft) {
         if (!comp || x_feat_out) {
             e.bias = w->ft_b; e.rowscale = s.cnt; e.out = xfeat; e.ldo = C;
             VKN_TRY(vkn_launch_gemm(s.xraw, nullptr, C, w->ft_w, pw.ft, M, C, C, 1, nullptr, e, st));
@@ -319,7 +327,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     }
 
     // (ii-a) KernelUpdator                                    knet/kernel_updator.py:56-93
-    VKN_TRY(run_updator(d, w, pw, xfeat, comp ? s.xraw : nullptr, s.cnt, obj_in, s.obj1, s, st));
+    VKN_TRY(run_updator(d, w, pw, xfeat, (comp && !xfeat_in) ? s.xraw : nullptr, s.cnt, obj_in, s.obj1, s, st));
 
     // (ii-b) kernel interaction: MHA + LN, FFN + LN           knet/det/kernel_update_head.py:204-215
     VKN_TRY(run_attention(d, s, s.obj1, s.obj1, d->heads, w->attn_in_w, pw.attn_in, nullptr, w->attn_in_b, w->attn_out_w,
@@ -362,15 +370,21 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     if (comp) {
         // fc_cls, and the decode kernels Kf = fc_mask(.) . W_ft in ONE GEMM from the composite weight          (:221, :227, :247)
         VknGemmProb pr[2];
-        e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
-        if (cls_sigmoid) e.act = 2;  // fused head, last stage: the caller wants cls_score.sigmoid() (knet/det/kernel_iter_head.py:307-308)
-        pr[0] = VknGemmProb{tc, nullptr, nullptr, nullptr, C, w->fc_cls_w, pw.fc_cls, d->ncls, e};
+        int np = 0;
+        if (w->fc_cls_w && cls_logits) {  // heads without a classification branch (knet_vis tracker stages with with_cls=False)
+            e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
+            if (cls_sigmoid) e.act = 2;  // fused head, last stage: the caller wants cls_score.sigmoid() (knet/det/kernel_iter_head.py:307-308)
+            pr[np++] = VknGemmProb{tc, nullptr, nullptr, nullptr, C, w->fc_cls_w, pw.fc_cls, d->ncls, e};
+        }
         e = mk_epi(d); e.bias = pw.decb; e.ldo = C;
-        if (ref_decode) e.out = s.kern32;
+        if (ref_decode) e.out = chain_only ? kern_out : s.kern32;
         else { e.plane_hi = s.kfh; e.plane_lo = s.kfl; e.rows_per_frame = N; e.NPT = npt_of(N); }
-        pr[1] = VknGemmProb{tm, nullptr, nullptr, nullptr, C, pw.dec32, pw.dec, C, e};
-        VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
-        if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
+        pr[np++] = VknGemmProb{tm, nullptr, nullptr, nullptr, C, pw.dec32, pw.dec, C, e};
+        VKN_TRY(vkn_launch_gemm_group(pr, np, M, C, 1, nullptr, st));
+        if (chain_only) {
+            if (kb_out && hipMemcpyAsync(kb_out, s.kb, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return VKN_E_LAUNCH;
+        } else if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
         else if (gather_out)
             VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
         else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st));
@@ -382,16 +396,28 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     } else {
         {
             VknGemmProb pr[2];
-            e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
-            if (cls_sigmoid) e.act = 2;
-            pr[0] = VknGemmProb{tc, nullptr, nullptr, nullptr, C, w->fc_cls_w, pw.fc_cls, d->ncls, e};
-            e = mk_epi(d); e.bias = w->fc_mask_b; e.out = s.maskfeat; e.ldo = C;
+            int np = 0;
+            if (w->fc_cls_w && cls_logits) {
+                e = mk_epi(d); e.bias = w->fc_cls_b; e.out = cls_logits; e.ldo = d->ncls;
+                if (cls_sigmoid) e.act = 2;
+                pr[np++] = VknGemmProb{tc, nullptr, nullptr, nullptr, C, w->fc_cls_w, pw.fc_cls, d->ncls, e};
+            }
+            e = mk_epi(d); e.bias = w->fc_mask_b; e.out = (chain_only && !has_ft) ? kern_out : s.maskfeat; e.ldo = C;
             if (has_ft) { e.dot_vec = w->ft_b; e.dot_out = s.kb; }
-            pr[1] = VknGemmProb{tm, nullptr, nullptr, nullptr, C, w->fc_mask_w, pw.fc_mask, C, e};
-            VKN_TRY(vkn_launch_gemm_group(pr, 2, M, C, 1, nullptr, st));
+            pr[np++] = VknGemmProb{tm, nullptr, nullptr, nullptr, C, w->fc_mask_w, pw.fc_mask, C, e};
+            VKN_TRY(vkn_launch_gemm_group(pr, np, M, C, 1, nullptr, st));
         }
         // (iii) mask decode with the folded kernels  Kf = mask_feat . W_ft   :247-260
-        if (ref_decode) {
+        if (chain_only) {
+            if (has_ft) {
+                e = mk_epi(d); e.out = kern_out; e.ldo = C;
+                VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, pw.ftT, M, C, C, 1, nullptr, e, st));
+                if (kb_out && hipMemcpyAsync(kb_out, s.kb, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return VKN_E_LAUNCH;
+            } else if (kb_out && hipMemsetAsync(kb_out, 0, (size_t)M * sizeof(float), st) != hipSuccess) {
+                return VKN_E_LAUNCH;
+            }
+        } else if (ref_decode) {
             const float* kern = s.maskfeat;
             if (has_ft) {
                 e = mk_epi(d); e.out = s.kern32; e.ldo = C;
@@ -646,7 +672,10 @@ int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const fl
     // obj_feats = einsum('bnhw,bchw->bnc', (sigmoid(mask_preds) > 0.5).float(), x_feats)   (use_binary)           (:243-250)
     const float* obj = nullptr;
     if (with_obj) {
-        if (ref) VKN_TRY(vkn_launch_gather_ref_ex(xf, mask_preds, thr_logit, s.obj, s.cnt, B, Np, C, P, N, st));
+        if (with_obj == 2) {  // use_binary=False: weights (sigmoid(z) > 0.5) * sigmoid(z)
+            if (ref) return VKN_E_SHAPE;  // no exact-fp32 reference kernel for the soft weights
+            VKN_TRY(vkn_launch_gather_soft(xf, mask_preds, thr_logit, s.obj, s.cnt, s.part, s.cntp, B, Np, C, P, N, st));
+        } else if (ref) VKN_TRY(vkn_launch_gather_ref_ex(xf, mask_preds, thr_logit, s.obj, s.cnt, B, Np, C, P, N, st));
         else VKN_TRY(vkn_launch_gather_ex(xf, mask_preds, thr_logit, s.obj, s.cnt, s.part, s.cntp, B, Np, C, P, N, st));
         obj = s.obj;
     }
@@ -752,7 +781,8 @@ int vkn_stage_forward_f32(const VknDims* d, const VknStageWeights* w, const floa
                           const float* masks_in, const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out,
                           float* x_feat_out, float* track_out, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
     VKN_TRY(check_dims(d));
-    if (!w || !x || !obj_in || !masks_in || !cls_logits || !masks_out || !obj_out) return VKN_E_ARG;
+    if (!w || !x || !obj_in || !masks_in || !masks_out || !obj_out) return VKN_E_ARG;
+    if (w->fc_cls_w && !cls_logits) return VKN_E_ARG;  // cls_logits may be NULL only for stages without a classification branch
     if (!aligned16(x) || !aligned16(obj_in) || !aligned16(masks_in) || !aligned16(masks_out) || !aligned16(obj_out))
         return VKN_E_ALIGN;
     if (masks_in == masks_out) return VKN_E_ARG;
@@ -762,6 +792,21 @@ int vkn_stage_forward_f32(const VknDims* d, const VknStageWeights* w, const floa
     carve_stage(d, static_cast<char*>(ws), &s);
     return run_stage(d, w, x, obj_in, masks_in, prev_obj, cls_logits, masks_out, obj_out, x_feat_out, track_out, s, flags,
                      static_cast<hipStream_t>(stream));
+}
+
+int vkn_stage_chain_f32(const VknDims* d, const VknStageWeights* w, const float* x_feat, const float* obj_in, float* cls_logits,
+                        float* kernels_out, float* kb_out, float* obj_out, void* ws, size_t ws_bytes, unsigned flags,
+                        void* stream) {
+    VKN_TRY(check_dims(d));
+    if (!w || !x_feat || !obj_in || !kernels_out || !obj_out) return VKN_E_ARG;
+    if (!aligned16(x_feat) || !aligned16(obj_in) || !aligned16(kernels_out) || !aligned16(obj_out)) return VKN_E_ALIGN;
+    StageWs s;
+    const size_t need = carve_stage(d, nullptr, &s);
+    if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
+    carve_stage(d, static_cast<char*>(ws), &s);
+    return run_stage(d, w, nullptr, obj_in, nullptr, nullptr, cls_logits, nullptr, obj_out, nullptr, nullptr, s, flags,
+                     static_cast<hipStream_t>(stream), nullptr, nullptr, false, false, false, nullptr, nullptr, x_feat, kernels_out,
+                     kb_out);
 }
 
 static size_t carve_head(const VknDims* d, char* base, StageWs* s, float** mtmp, float** otmp, float** ctmp, unsigned** bits) {

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                                                                long long mask_fs, int ileave) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // per buffer: xh [C][40], xl [C][40], mk [NB*32][40] (+ ml [NB*32][40]: low half of a REAL mask operand, BITS == 2)
-    constexpr bool REAL = (BITS == 2);
+    constexpr bool REAL = (BITS == 2 || BITS == 3);  // 3: real operand = bit(z) * sigmoid(z), activated on the fly
     const int rows_buf = 2 * C + (REAL ? 2 : 1) * NB * 32;
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
 
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     f32x4 xrA[4], xrB[4];  // two register sets: tile t+2 is being loaded while tile t+1 waits to be committed
     f32x4 mrA[2], mrB[2];
 
-    const float off_v = REAL ? 0.f : -INFINITY;  // "off" for padded rows / pixels
+    const float off_v = (BITS == 2) ? 0.f : -INFINITY;  // "off" for padded rows / pixels
     const f32x4 neg_inf = {off_v, off_v, off_v, off_v};
 
     // Full tiles (all 32 px in range, rows 16-B aligned): branch-free, ALWAYS 4 + 2 dwordx4 loads per thread on clamped
@@ -175,7 +175,10 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                 for (int k = 0; k < 4; ++k) {
                     if (REAL) {  // real-valued left operand: f16 hi / lo split like x
                         _Float16 hh, ll;
-                        vkn_split_f16(row_ok ? mr[i][k] : 0.f, hh, ll);
+                        float av = row_ok ? mr[i][k] : 0.f;
+                        if (BITS == 3)  // soft gather weights (sigmoid(z) > thr) * sigmoid(z)   knet/det/kernel_head.py:243-249
+                            av = (row_ok && mr[i][k] >= thr) ? 1.0f / (1.0f + expf(-mr[i][k])) : 0.f;
+                        vkn_split_f16(av, hh, ll);
                         m[k] = hh;
                         ml[k] = ll;
                     } else {
@@ -536,6 +539,12 @@ int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* c
     return gather_launch(x, a, 0.f, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 2, stream);
 }
 
+// soft gather weights: xraw = sum_p [z >= thr] sigmoid(z) x, cnt = the sum of the weights (use_binary=False, knet/det/kernel_head.py:243-249)
+int vkn_launch_gather_soft(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
+                           int N, int C, int P, int mask_rows, hipStream_t stream) {
+    return gather_launch(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 3, stream);
+}
+
 // binary operand given as bit words [B][P/64][2][roundup(N,32)] (vkn_launch_decode_bits); P % 64 == 0
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
                            int C, int P, hipStream_t stream) {
@@ -580,7 +589,7 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
             VKN_CHECK_LAUNCH();
             continue;
         }
-        const size_t lds = (size_t)2 * (2 * C + (bits == 2 ? 2 : 1) * nb * 32) * GA_LDR * sizeof(_Float16) + (bits == 1 ? 4096 : 0);
+        const size_t lds = (size_t)2 * (2 * C + (bits >= 2 ? 2 : 1) * nb * 32) * GA_LDR * sizeof(_Float16) + (bits == 1 ? 4096 : 0);
 #define GA_LAUNCH(NBV, BV)                                                                                       \
     do {                                                                                                         \
         VKN_ALLOW_FULL_LDS((k_gather_mfma<NBV, BV>));                                                            \
@@ -589,7 +598,8 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
     } while (0)
 #define GA_CASE(NBV)                       \
     case NBV:                              \
-        if (bits == 2) GA_LAUNCH(NBV, 2);  \
+        if (bits == 3) GA_LAUNCH(NBV, 3);  \
+        else if (bits == 2) GA_LAUNCH(NBV, 2);  \
         else if (bits) GA_LAUNCH(NBV, 1);  \
         else GA_LAUNCH(NBV, 0);            \
         break;

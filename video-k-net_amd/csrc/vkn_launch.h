@@ -46,6 +46,8 @@ int vkn_launch_gather_ref_ex(const float* x, const float* masks, float thr, floa
                              int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C,
                            int P, int mask_rows, hipStream_t stream);
+int vkn_launch_gather_soft(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
+                           int N, int C, int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
                            int C, int P, hipStream_t stream);
 int vkn_launch_gather_reduce(const float* part, const float* cntp, float* xraw, float* cnt, int B, int N, int C, int G,

@@ -47,9 +47,6 @@ class ConvKernelHead(nn.Module):
         super().__init__()
         if conv_kernel_size != 1:
             raise NotImplementedError('conv_kernel_size must be 1 (every shipped config)')
-        if proposal_feats_with_obj and not use_binary:
-            raise NotImplementedError('proposal_feats_with_obj needs use_binary=True (every shipped config); the soft-weight '
-                                      'variant is not provided by libvkn')
         if cat_stuff_mask and not semantic_fpn:
             raise ValueError('cat_stuff_mask needs semantic_fpn=True')
         self.num_proposals = num_proposals
@@ -163,7 +160,8 @@ class ConvKernelHead(nn.Module):
         prop, x_feats, mask_preds, seg_preds = ops.kernel_init(
             loc_feats, semantic_feats if self.semantic_fpn else None, self.init_kernels.weight,
             self.conv_seg.weight if self.semantic_fpn else None, self.conv_seg.bias if self.semantic_fpn else None,
-            num_thing_classes=self.num_thing_classes, cat_stuff_mask=cat, proposal_feats_with_obj=self.proposal_feats_with_obj)
+            num_thing_classes=self.num_thing_classes, cat_stuff_mask=cat, proposal_feats_with_obj=self.proposal_feats_with_obj,
+            use_binary=self.use_binary)
         return prop.reshape(*prop.shape, 1, 1), x_feats, mask_preds, None, seg_preds
 
     def _decode_init_proposals(self, img, img_metas):

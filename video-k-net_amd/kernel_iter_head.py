@@ -287,14 +287,25 @@ class KernelIterHead(BaseRoIHead):
     def simple_test(self, x, proposal_feats, mask_preds, cls_score, img_metas, imgs_whwh=None, rescale=False):
         """Stage loop + panoptic results per image (reference :233-283): a list of
         `(bbox_result, segm_result, (panoptic_seg, segments_info))` with bbox/segm results None (see get_panoptic)."""
-        if not self.do_panoptic:
-            raise NotImplementedError('instance-only results (get_seg_masks, reference :265-281) need the K full-resolution '
-                                      'masks on the host; not provided')
         if not self._fused_ok(x):
             raise NotImplementedError('simple_test needs the fused GPU head (eval mode, CUDA tensors)')
+        if not self.do_panoptic:
+            # instance-only results (reference :270-281): top-`max_per_img` (kernel, class) pairs -> their up-scaled masks ->
+            # rescale / threshold (`get_seg_masks`).  Selection and resampling run on the device, one D2H copy of K bool masks.
+            _, cls, _, scaled, _ = self._head_forward(x, proposal_feats, mask_preds)
+            return [self._instance_result(cls[i], scaled[i], img_metas[i]) for i in range(len(img_metas))]
         _, cls, masks, _, _ = self._head_forward(x, proposal_feats, mask_preds, want_scaled=False)
         up = self.mask_head[-1].mask_upsample_stride
         return [(None, None, (seg, info)) for seg, info, _ in self._panoptic_results(cls, masks, img_metas, up)]
+
+    def _instance_topk(self, cls_score_per_img):
+        num_classes = self.mask_head[-1].num_classes
+        scores, topk = cls_score_per_img.flatten(0, 1).topk(self._cfg(self.test_cfg, 'max_per_img'), sorted=True)
+        return scores, topk // num_classes, topk % num_classes
+
+    def _instance_result(self, cls_score_per_img, scaled_mask_preds_per_img, img_meta):
+        scores, mask_indices, labels = self._instance_topk(cls_score_per_img)
+        return self.mask_head[-1].get_seg_masks(scaled_mask_preds_per_img[mask_indices], labels, scores, self.test_cfg, img_meta)
 
     def aug_test(self, features, proposal_list, img_metas, rescale=False):
         raise NotImplementedError('SparseMask does not support `aug_test`')
@@ -426,7 +437,7 @@ class VideoKernelIterHead(KernelIterHead):
         (knet/video/kernel_iter_head.py:435-506).  `results[i]` is the 5-tuple of `get_panoptic`; with `with_track` the
         reference's `(results, object_feats, cls_score, mask_preds, scaled_mask_preds)` is returned."""
         if not self.do_panoptic:
-            raise NotImplementedError('instance-only results (get_seg_masks) need the K full-resolution masks on the host')
+            raise NotImplementedError('the video head is panoptic-only in every shipped config (do_panoptic / merge_joint)')
         if not (self._fused_ok(x) and all(isinstance(h, VideoKernelUpdateHead) for h in self.mask_head)):
             raise NotImplementedError('simple_test_with_previous needs the fused GPU head (eval mode, CUDA tensors)')
         link = previous_obj_feats is not None and self.mask_head[-1].previous is not None

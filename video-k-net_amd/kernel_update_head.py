@@ -284,6 +284,42 @@ class KernelUpdateHead(nn.Module):
         cls, masks, obj, _, _ = self._run(x, proposal_feat, mask_preds)
         return cls, masks, obj
 
+    # ---- instance-only results: knet/det/kernel_update_head.py:443-481 (result formatting: K <= max_per_img masks per image)
+    @staticmethod
+    def _meta(cfg, key):
+        return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
+
+    def rescale_masks(self, masks_per_img, img_meta):
+        """sigmoid -> bilinear to batch_input_shape -> crop to img_shape -> bilinear to ori_shape (:443-458), on the masks' device
+        (the K selected masks only; the panoptic path never materialises them — vkn_panoptic_joint_f32)."""
+        import torch.nn.functional as F
+        h, w = img_meta['img_shape'][:2]
+        m = F.interpolate(masks_per_img.unsqueeze(0).sigmoid(), size=tuple(img_meta['batch_input_shape']), mode='bilinear',
+                          align_corners=False)
+        m = m[:, :, :h, :w]
+        return F.interpolate(m, size=tuple(img_meta['ori_shape'][:2]), mode='bilinear', align_corners=False).squeeze(0)
+
+    def get_seg_masks(self, masks_per_img, labels_per_img, scores_per_img, test_cfg, img_meta):
+        """-> (bbox_result, segm_result) of mmdet's instance-segmentation format (:460-466)."""
+        seg_masks = self.rescale_masks(masks_per_img, img_meta) > self._meta(test_cfg, 'mask_thr')
+        return self.segm2result(seg_masks, labels_per_img, scores_per_img)
+
+    def segm2result(self, mask_preds, det_labels, cls_scores):
+        """One D2H copy of the K boolean masks; per-class lists exactly as the reference builds them (:468-481)."""
+        import numpy as np
+        num_classes = self.num_classes
+        segm_result = [[] for _ in range(num_classes)]
+        mask_preds = mask_preds.cpu().numpy()
+        det_labels = det_labels.cpu().numpy()
+        cls_scores = cls_scores.cpu().numpy()
+        num_ins = mask_preds.shape[0]
+        bboxes = np.zeros((num_ins, 5), dtype=np.float32)       # fake boxes: only the score column is filled
+        bboxes[:, -1] = cls_scores
+        bbox_result = [bboxes[det_labels == i, :] for i in range(num_classes)]
+        for idx in range(num_ins):
+            segm_result[det_labels[idx]].append(mask_preds[idx])
+        return bbox_result, segm_result
+
     # ---- training: knet/det/kernel_update_head.py:279-441
     def loss(self, object_feats, cls_score, mask_pred, labels, label_weights, mask_targets, mask_weights, imgs_whwh=None,
              reduction_override=None, **kwargs):

@@ -1,0 +1,249 @@
+"""The YouTube-VIS model family's heads (BASELINE cfg4, `configs/video_knet_vis/_base_/models/knet_track_r50.py`) — SURVEY.md §8(f)-4:
+
+* `KernelIterHeadVideo`       knet_vis/tracker/kernel_iter_head.py:13-330   per-frame roi head: S stages on bs * num_frames frames,
+                                                                           instance-only results, `features` for the tracker
+* `KernelUpdateHeadVideo`     knet_vis/tracker/kernel_update_head.py:20-380 clip-level stage: 5-D gather over the frames of a clip,
+                                                                           kernels shared by the frames (`with_cls`) or per frame
+* `KernelFrameIterHeadVideo`  knet_vis/tracker/kernel_frame_iter_head.py:15-383  the "tracker": query fusion + S clip-level stages
+
+Same registry names, ctor kwargs and state-dict keys as the reference.  They are compositions of the same three HIP ops: the 5-D
+gather `einsum('bfnhw,bfchw->bfnc')` is `vkn_mask_gather_f32` on B * F frames, the update runs through `vkn_stage_chain_f32`
+(`query_merge_method='mean'`: x_feat averaged over the clip first) or the whole per-frame `vkn_stage_forward_f32`, the decode
+`F.conv2d(mask_x[i], mask_feat[i])` with clip-shared kernels is `vkn_mask_decode_f32` with the kernels repeated per frame.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .kernel_iter_head import KernelIterHead
+from .kernel_update_head import KernelUpdateHead
+from .registry import BaseRoIHead, build_head, register_head
+
+
+@register_head
+class KernelUpdateHeadVideo(KernelUpdateHead):
+
+    def __init__(self, with_cls=True, num_proposals=100, query_merge_method='mean', **kwargs):
+        super().__init__(**kwargs)
+        self.with_cls = with_cls
+        self.num_proposals = num_proposals
+        self.query_merge_method = query_merge_method
+        if query_merge_method != 'mean' and with_cls:
+            raise NotImplementedError("query_merge_method must be 'mean' (the shipped knet_track configs); the attention merge "
+                                      '(knet_vis/tracker/kernel_update_head.py:244-263) is not built')
+        if not with_cls:                       # the reference builds no classification branch then (:133-146): same state dict
+            del self.cls_fcs
+            del self.fc_cls
+            self.num_cls_fcs = 0
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        if self.with_cls and self.loss_cls.use_sigmoid:
+            nn.init.constant_(self.fc_cls.bias, -4.59511985013459)       # bias_init_with_prob(0.01) = -log(99)
+        if self.kernel_init:
+            nn.init.normal_(self.fc_mask.weight, mean=0, std=0.01)
+
+    def make_dims(self, B, N, H, W):
+        ncls = self.fc_cls.out_features if self.with_cls else 1
+        return ops.make_dims(B, N, self.in_channels, H, W, self.num_heads, self.feedforward_channels, ncls, self.num_cls_fcs,
+                             self.num_mask_fcs, self.hard_mask_thr, self.attention_norm.eps)
+
+    def forward(self, x, proposal_feat, mask_preds, prev_cls_score=None, mask_shape=None, img_metas=None, pos=None):
+        """x [B,F,C,H,W], mask_preds [B,F,N,H,W]; proposal_feat [B,N,C,1,1] (clip-level kernels, `with_cls` stages) or
+        [B,F,N,C,1,1] (per-frame kernels) -> (cls_score | None, new_mask_preds [B,F,N,H,W], obj_feat)      reference :209-374"""
+        B, F, C, H, W = x.shape
+        if mask_preds.shape[-2:] != (H, W):
+            raise NotImplementedError('mask_preds at another resolution than x is dead in shipped configs (:227-231)')
+        if proposal_feat.dim() == 6:
+            assert not self.with_cls
+            N = proposal_feat.shape[2]
+            assert self.num_proposals == N
+            self._check_inputs(x.reshape(B * F, C, H, W), proposal_feat.reshape(B * F, N, C, 1, 1), mask_preds.reshape(B * F, N, H, W), None)
+            _, masks, obj, _, _ = self._run(x.reshape(B * F, C, H, W), proposal_feat.reshape(B * F, N, C, 1, 1),
+                                            mask_preds.reshape(B * F, N, H, W))
+            return None, masks.reshape(B, F, N, H, W), obj.reshape(B, F, N, C, 1, 1)
+        assert self.with_cls
+        N = proposal_feat.shape[1]
+        assert self.num_proposals == N
+        xf, mf = x.reshape(B * F, C, H, W), mask_preds.reshape(B * F, N, H, W)
+        self._check_inputs(xf, proposal_feat, mf, None)
+        xraw, cnt = ops.mask_gather(xf, mf, self.hard_mask_thr)                                # einsum('bfnhw,bfchw->bfnc') :242
+        if self.feat_transform is not None:                                                    # folded: x_feat = xraw W^T + cnt b
+            w_ft = self.feat_transform.conv.weight.detach().reshape(C, C)
+            x_feat = ops.linear(xraw.reshape(-1, C), w_ft).reshape(B * F, N, C)
+            x_feat = x_feat + cnt.unsqueeze(-1) * self.feat_transform.conv.bias.detach()
+        else:
+            x_feat = xraw
+        x_feat = x_feat.reshape(B, F, N, C).mean(1)                                            # query_merge_method == 'mean' :243
+        dims = self.make_dims(B, N, H, W)
+        cls, kern, kb, obj = ops.stage_chain(dims, self.stage_pack(x.device), x_feat, proposal_feat.reshape(B, N, C))
+        # every frame of a clip is decoded with the clip's kernels (:318-330)
+        masks = ops.mask_decode(xf, kern.repeat_interleave(F, dim=0), kb.repeat_interleave(F, dim=0))
+        return cls, masks.reshape(B, F, N, H, W), obj.reshape(B, N, C, 1, 1)
+
+    def get_seg_masks_tracking(self, masks_per_img, labels_per_img, scores_per_img, ids_per_img, test_cfg, img_meta):
+        """knet_vis/det/kernel_update_head.py:484-500: masks + mmtrack's `outs2results` packing (ids instead of boxes)."""
+        seg_masks = self.rescale_masks(masks_per_img, img_meta) > self._meta(test_cfg, 'mask_thr')
+        bboxes = torch.zeros((masks_per_img.shape[0], 5), dtype=torch.float32)
+        bboxes[:, -1] = scores_per_img.cpu()
+        tracks = outs2results(bboxes=bboxes, labels=labels_per_img, masks=seg_masks, ids=ids_per_img, num_classes=self.num_classes)
+        return tracks['bbox_results'], tracks['mask_results']
+
+
+KernelUpdateHead.get_seg_masks_tracking = KernelUpdateHeadVideo.get_seg_masks_tracking   # the per-frame head has it too (:484)
+
+
+def outs2results(bboxes=None, labels=None, masks=None, ids=None, num_classes=None, **kwargs):
+    """mmtrack.core `outs2results` (third-party, mmtrack 0.x; restated): per-class lists; with `ids` the box rows are
+    [id, x1, y1, x2, y2, score] and detections with id < 0 are dropped."""
+    import numpy as np
+    assert labels is not None and num_classes is not None
+    results = dict()
+    labels = labels.cpu().numpy() if torch.is_tensor(labels) else np.asarray(labels)
+    if ids is not None:
+        ids = ids.cpu().numpy() if torch.is_tensor(ids) else np.asarray(ids)
+        valid = ids > -1
+        ids, labels = ids[valid], labels[valid]
+    else:
+        valid = np.ones(len(labels), dtype=bool)
+    if bboxes is not None:
+        bb = (bboxes.cpu().numpy() if torch.is_tensor(bboxes) else np.asarray(bboxes))[valid]
+        if ids is None:
+            results['bbox_results'] = [bb[labels == i, :] for i in range(num_classes)]
+        else:
+            rows = np.concatenate([ids[:, None].astype(bb.dtype), bb], axis=1) if bb.shape[0] else np.zeros((0, 6), dtype=np.float32)
+            results['bbox_results'] = [rows[labels == i, :] for i in range(num_classes)]
+    if masks is not None:
+        mm = (masks.cpu().numpy() if torch.is_tensor(masks) else np.asarray(masks))[valid]
+        mask_results = [[] for _ in range(num_classes)]
+        for i in range(mm.shape[0]):
+            mask_results[labels[i]].append(mm[i])
+        results['mask_results'] = mask_results
+    return results
+
+
+@register_head
+class KernelIterHeadVideo(KernelIterHead):
+    """knet_vis/tracker/kernel_iter_head.py: the per-frame roi head of the VIS model.  x holds bs * num_frames frames."""
+
+    def simple_test(self, x, proposal_feats, mask_preds, cls_score, img_metas, ref_img_metas, imgs_whwh=None, rescale=False):
+        """-> (results: per frame `(bbox_result, segm_result)`, features: the tracker's inputs)            reference :243-313"""
+        if self.do_panoptic:
+            raise NotImplementedError  # as the reference (:287-288)
+        if not self._fused_ok(x):
+            raise NotImplementedError('simple_test needs the fused GPU head (eval mode, CUDA tensors)')
+        num_imgs, num_frames = len(ref_img_metas), len(ref_img_metas[0])
+        obj, cls, masks, scaled, _ = self._head_forward(x, proposal_feats, mask_preds)
+        bs_nf, nq, c, k1, k2 = obj.shape
+        h, w = x.shape[-2:]
+        assert bs_nf == num_imgs * num_frames == x.shape[0] and c == x.shape[1]
+        features = dict(obj_feats=obj.reshape(num_imgs, num_frames, nq, c, k1, k2), x_feats=x.reshape(num_imgs, num_frames, c, h, w),
+                        cls_scores=cls.reshape(num_imgs, num_frames, nq, self.num_classes),
+                        masks=masks.reshape(num_imgs, num_frames, nq, h, w))
+        results = []
+        for img_id in range(num_imgs):
+            for frame_id in range(num_frames):
+                i = img_id * num_frames + frame_id
+                results.append(self._instance_result(cls[i], scaled[i], img_metas[img_id]))
+        return results, features
+
+
+@register_head
+class KernelFrameIterHeadVideo(BaseRoIHead):
+    """knet_vis/tracker/kernel_frame_iter_head.py:15-383 (inference; `query_merge_method='mean'`, `with_mask_init` optional)."""
+
+    def __init__(self, mask_head=None, with_mask_init=False, num_stages=3, stage_loss_weights=(1, 1, 1), proposal_feature_channel=256,
+                 assign_stages=5, num_proposals=100, num_thing_classes=80, num_stuff_classes=53, query_merge_method='mean',
+                 train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None, **kwargs):
+        assert len(stage_loss_weights) == num_stages
+        self.num_stages = num_stages
+        self.stage_loss_weights = stage_loss_weights
+        self.assign_stages = assign_stages
+        self.num_proposals = num_proposals
+        self.num_thing_classes = num_thing_classes
+        self.num_stuff_classes = num_stuff_classes
+        self.query_merge_method = query_merge_method
+        self.proposal_feature_channel = proposal_feature_channel
+        if query_merge_method != 'mean':
+            raise NotImplementedError("query_merge_method must be 'mean' (the shipped knet_track configs)")
+        super().__init__(mask_head=mask_head, train_cfg=train_cfg, test_cfg=test_cfg, **kwargs)
+        self.with_mask_init = with_mask_init
+        if self.with_mask_init:
+            self.fc_mask = nn.Linear(proposal_feature_channel, proposal_feature_channel)
+
+    def init_mask_head(self, bbox_roi_extractor=None, mask_head=None):
+        assert bbox_roi_extractor is None
+        self.mask_head = nn.ModuleList()
+        if not isinstance(mask_head, list):
+            mask_head = [mask_head for _ in range(self.num_stages)]
+        assert len(mask_head) == self.num_stages
+        for idx, head in enumerate(mask_head):
+            head = dict(head)
+            head.update(with_cls=(idx < self.assign_stages))                                   # reference :100
+            self.mask_head.append(build_head(head))
+
+    def init_assigner_sampler(self):
+        self.mask_assigner, self.mask_sampler = [], []
+        if self.train_cfg is not None:
+            raise NotImplementedError('training of the clip-level tracker head (MaskHungarianAssignerVideo) is not built')
+
+    def init_bbox_head(self, mask_roi_extractor, mask_head):
+        raise NotImplementedError
+
+    def init_weights(self):
+        for h in self.mask_head:
+            h.init_weights()
+
+    def _mask_forward(self, stage, x, object_feats, mask_preds):
+        mask_head = self.mask_head[stage]
+        cls_score, mask_preds, object_feats = mask_head(x, object_feats, mask_preds, img_metas=None)
+        if mask_head.mask_upsample_stride > 1 and (stage == self.num_stages - 1 or self.training):
+            B, F, N, H, W = mask_preds.shape
+            s = mask_head.mask_upsample_stride
+            scaled = ops.upsample_bilinear(mask_preds.reshape(B * F, N, H, W), s).reshape(B, F, N, H * s, W * s)   # :121-130
+        else:
+            scaled = mask_preds
+        return dict(cls_score=cls_score, mask_preds=mask_preds, scaled_mask_preds=scaled, object_feats=object_feats)
+
+    def _query_fusion(self, obj_feats, num_imgs, num_frames):
+        return obj_feats.mean(1)                                                               # :140-141
+
+    def _mask_init(self, object_feats, x_feats, num_imgs):
+        """:163-178: mask_preds = conv2d(x_feats[i], fc_mask(object_feats)[i]) for all frames of clip i."""
+        B, F, C, H, W = x_feats.shape
+        N = object_feats.shape[1]
+        k = ops.linear(object_feats.reshape(B * N, C), self.fc_mask.weight.detach(), self.fc_mask.bias.detach()).reshape(B, N, C)
+        return ops.mask_decode(x_feats.reshape(B * F, C, H, W), k.repeat_interleave(F, dim=0)).reshape(B, F, N, H, W)
+
+    @staticmethod
+    def _cfg(cfg, key):
+        return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
+
+    def simple_test(self, x, img_metas, ref_img_metas, cls_scores, masks, obj_feats, **kwargs):
+        """-> (results[img][frame] = (bbox_results with ids, mask_results), features)                      reference :313-372"""
+        num_imgs, num_frames = len(ref_img_metas), len(ref_img_metas[0])
+        object_feats = self._query_fusion(obj_feats, num_imgs, num_frames) if obj_feats.dim() == 6 else obj_feats
+        mask_preds = self._mask_init(object_feats, x, num_imgs) if self.with_mask_init else masks
+        cls_score = None
+        with torch.no_grad():
+            for stage in range(self.num_stages):
+                if stage == self.assign_stages:
+                    object_feats = object_feats[:, None].repeat(1, num_frames, 1, 1, 1, 1)
+                r = self._mask_forward(stage, x, object_feats, mask_preds)
+                mask_preds, scaled_mask_preds = r['mask_preds'], r['scaled_mask_preds']
+                cls_score = r['cls_score'] if r['cls_score'] is not None else cls_score
+                object_feats = r['object_feats']
+        last = self.mask_head[-1]
+        num_classes = last.num_classes
+        cls_score = cls_score.sigmoid() if last.loss_cls.use_sigmoid else cls_score.softmax(-1)[..., :-1]
+        k = self._cfg(self.test_cfg, 'max_per_img')
+        results = []
+        for img_id in range(num_imgs):
+            scores, topk = cls_score[img_id].flatten(0, 1).topk(k, sorted=True)
+            mask_indices, labels = topk // num_classes, topk % num_classes
+            results.append([last.get_seg_masks_tracking(scaled_mask_preds[img_id][f][mask_indices], labels, scores, torch.arange(k),
+                                                        self.test_cfg, img_metas[img_id]) for f in range(num_frames)])
+        features = dict(obj_feats=object_feats, x_feats=x, cls_scores=cls_score, masks=mask_preds)
+        return results, features

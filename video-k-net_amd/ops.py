@@ -287,6 +287,25 @@ def stage_forward(dims: VknDims, pack: StagePack, x, obj_in, masks_in, prev_obj=
     return cls, masks, obj, xfeat, track
 
 
+def stage_chain(dims: VknDims, pack: StagePack, x_feat, obj_in, want_cls=True, flags=0):
+    """The [B*N, C] chain of one stage alone (no gather, no decode): x_feat [B,N,C] (feat-transformed), obj_in [B,N,C] ->
+    (cls_logits [B,N,ncls] | None, folded decode kernels [B,N,C], decode bias [B,N], obj [B,N,C])."""
+    xf, obj_in = _req(x_feat, 'x_feat'), _req(obj_in, 'proposal_feat')
+    B, N, C = dims.B, dims.N, dims.C
+    dev = xf.device
+    L = _lib.lib()
+    cls = torch.empty((B, N, dims.ncls), dtype=torch.float32, device=dev) if want_cls else None
+    kern = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    kb = torch.empty((B, N), dtype=torch.float32, device=dev)
+    obj = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    pack.ensure_prepared(dims)
+    ws = _workspace(max(L.vkn_stage_workspace_bytes(ctypes.byref(dims)), 256), dev)
+    with torch.cuda.device(dev):
+        check(L.vkn_stage_chain_f32(ctypes.byref(dims), ctypes.byref(pack.w), _ptr(xf), _ptr(obj_in), _ptr(cls), _ptr(kern), _ptr(kb),
+                                    _ptr(obj), _ptr(ws), ws.numel(), flags, _stream()))
+    return cls, kern, kb, obj
+
+
 def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=None, upsample_stride=1, want_track=False,
                  want_scaled=True, flags=0, clip_first_prev=None, decode_events=None):
     """The S-stage loop in one C call.  Returns (obj [B,N,C], cls_prob [B,N,ncls], mask_preds [B,N,H,W],
@@ -414,7 +433,7 @@ def linear(A, W, bias=None, w_split=None, act=0, ksplit=1):
 
 
 def kernel_init(loc_feats, semantic_feats, init_w, seg_w=None, seg_b=None, num_thing_classes=0, cat_stuff_mask=False,
-                proposal_feats_with_obj=True, hard_mask_thr=0.5, want_seg_preds=True, flags=0):
+                proposal_feats_with_obj=True, hard_mask_thr=0.5, want_seg_preds=True, flags=0, use_binary=True):
     """Kernel initialisation ("pass 0"), `ConvKernelHead._decode_init_proposals` after its loc / seg convs
     (knet/det/kernel_head.py:204-263), use_binary semantics.  Returns (proposal_feats [B,N,C], x_feats [B,C,H,W],
     mask_preds [B,N,H,W], seg_preds [B,ncls,H,W] | None)."""
@@ -448,7 +467,8 @@ def kernel_init(loc_feats, semantic_feats, init_w, seg_w=None, seg_b=None, num_t
     ws = _workspace(max(nb, 256), dev)
     with torch.cuda.device(dev):
         check(L.vkn_kernel_init_f32(_ptr(loc), _ptr(sem), _ptr(iw), _ptr(sw), _ptr(sb), int(num_thing_classes),
-                                    int(bool(cat_stuff_mask)), int(bool(proposal_feats_with_obj)), thr_logit(hard_mask_thr),
+                                    int(bool(cat_stuff_mask)), (1 if use_binary else 2) if proposal_feats_with_obj else 0,
+                                    thr_logit(hard_mask_thr),
                                     _ptr(x_feats), _ptr(masks), _ptr(seg), _ptr(prop), B, Np, ncls, C, P, _ptr(ws), ws.numel(),
                                     flags, _stream()))
     return prop, x_feats, masks, seg
