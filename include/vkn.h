@@ -277,6 +277,22 @@ size_t vkn_panoptic_workspace_bytes(const VknPanopticCfg* cfg, int B, int N);
 int vkn_panoptic_joint_f32(const VknPanopticCfg* cfg, const float* cls_prob, const float* mask_logits, int B, int N, int ncls,
                            int* panoptic_seg, int* info, int* nseg, int* bbox, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- post-head pipeline, THING-FIRST merge (`merge_joint=False`): `KernelIterHead.merge_stuff_thing`
+ *      knet/det/kernel_iter_head.py:385-465 and `VideoKernelIterHead.merge_stuff_thing_thing_first`
+ *      knet/video/kernel_iter_head.py:656-742.  Boolean full-resolution masks (1 byte per pixel, [K][HW]) are pasted in score order:
+ *      things (order = argsort(-thing_scores); stop at the first score < instance_score_thr; skip empty masks and masks whose
+ *      overlap with the painted area exceeds iou_thr of their own area; paint the still-empty part), then stuff (order = the
+ *      distinct labels by descending score, one OR-ed mask per label; painted where still empty if that area >= stuff_max_area).
+ *      All on the device (2 launches per mask, no host synchronisation); out: panoptic_seg [HW] int32 (0 = void),
+ *      info [(Kt + Ks)][5] = per step {segment id or 0, kind 0 thing / 1 stuff, label, instance index (things) or area (stuff),
+ *      score bits (things)}, nseg = number of segments.  ws: vkn_merge_workspace_bytes(Kt, Ks). */
+size_t vkn_merge_workspace_bytes(int Kt, int Ks);
+int vkn_panoptic_thing_first_u8(const unsigned char* thing_masks, const float* thing_scores, const int* thing_labels,
+                                const int* thing_order, int Kt, const unsigned char* stuff_masks, const int* stuff_labels,
+                                const int* stuff_order, int Ks, int HW, double instance_score_thr, double iou_thr,
+                                int stuff_max_area, int* panoptic_seg, int* info, int* nseg, void* ws, size_t ws_bytes,
+                                void* stream);
+
 /* ---- train-time one-to-one assignment, one image.  Replaces `MaskHungarianAssigner.assign`
  *      (knet/det/mask_hungarian_assigner.py:160-274; call site knet/det/kernel_iter_head.py:193-207) with the shipped costs
  *      FocalLossCost (mmdet 2.18) + DiceCost (pred_act, :37-74) + MaskCost (pred_act, :87-113):

@@ -303,6 +303,34 @@ def run_pan_video_case(name, p):
     print(f'{name}: ok  segments per frame = {nseg}  things with embeddings = {[out[f"thing_obj_feat{b}"].shape[0] for b in range(p["B"])]}')
 
 
+def run_pan_thing_first(name, p):
+    """KernelIterHead.get_panoptic with merge_joint=False -> merge_stuff_thing (knet/det/kernel_iter_head.py:332-370, 385-465)."""
+    test_cfg = AttrDict(max_per_img=p['Np'], mask_thr=0.5, stuff_score_thr=0.05,
+                        merge_stuff_thing=AttrDict(overlap_thr=0.6, iou_thr=0.5, stuff_max_area=p.get('sma', 64), instance_score_thr=0.25))
+    cfg = head_cfg(False, C=32, heads=8, ffn=64, ncls=p['ncls'], n_thing=p['T'], n_stuff=p['ncls'] - p['T'], S=1, up=p['up'], nprop=p['Np'])
+    cfg.update(do_panoptic=True, merge_joint=False, test_cfg=test_cfg)
+    head = build_head(cfg)
+    head.eval()
+    cls, logits = (torch.from_numpy(a) for a in synth.panoptic_inputs(p['B'], p['N'], p['Np'], p['ncls'], p['Hm'], p['Wm'], p['seed']))
+    meta = dict(img_shape=(*p['img'], 3), batch_input_shape=tuple(p['bis']), ori_shape=(*p['ori'], 3))
+    out = dict(case=np.array([p['B'], p['N'], p['Np'], p['T'], p['ncls'], p['Hm'], p['Wm'], p['up'], *p['bis'], *p['img'], *p['ori'],
+                              p['seed']], dtype=np.int64), stuff_max_area=np.int64(p.get('sma', 64)))
+    segs, nseg = [], []
+    with torch.no_grad():
+        scaled = F.interpolate(logits, scale_factor=p['up'], align_corners=False, mode='bilinear') if p['up'] > 1 else logits
+        for b in range(p['B']):
+            bbox_result, segm_result, (pan, info) = head.get_panoptic(cls[b], scaled[b], head.test_cfg, meta)
+            segs.append(pan)
+            nseg.append(len(info))
+            out[f'info{b}'] = np.array([[s_['id'], int(s_['isthing']), s_['category_id'], s_.get('instance_id', -1),
+                                         s_.get('score', float('nan')), s_.get('area', -1)] for s_ in info], dtype=np.float64).reshape(-1, 6)
+            out[f'nmask{b}'] = np.int64(sum(len(m) for m in segm_result))
+    out['panoptic_seg'] = np.stack(segs).astype(np.int32)
+    out['nseg'] = np.array(nseg, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(f'{name}: ok  segments per frame = {nseg}  void = {float((np.stack(segs) == 0).mean()):.3f}')
+
+
 def run_pan_case(name, p):
     """KernelIterHead.get_panoptic of the reference (merge_joint=True) on structured synthetic logits."""
     test_cfg = AttrDict(max_per_img=p['Np'], mask_thr=0.5, stuff_score_thr=0.05,
@@ -541,6 +569,9 @@ if __name__ == '__main__':
     for name, p in PAN_CASES.items():
         if not only or name in only:
             run_pan_case(name, p)
+    for nm, src in (('pan_tf_tiny', 'pan_tiny'), ('pan_tf_cfg', 'pan_cfg')):
+        if not only or nm in only:
+            run_pan_thing_first(nm, PAN_CASES[src])
     if not only or 'pan_video' in only:
         run_pan_video_case('pan_video', PAN_CASES['pan_tiny'])
     for name, p in ASSIGN_CASES.items():

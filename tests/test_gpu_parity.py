@@ -681,6 +681,31 @@ def test_video_simple_test_with_previous(vkn):
             assert torch.equal(tfeat[j], track[b, int(rows[s_['instance_id']])])
 
 
+@pytest.mark.parametrize('name', ['pan_tf_tiny', 'pan_tf_cfg'])
+def test_thing_first_merge_vs_reference_golden(vkn, name):
+    """merge_joint=False: `get_panoptic` -> `merge_stuff_thing` (knet/det/kernel_iter_head.py:385-465) on the device: segment list
+    (ids, kinds, labels, instance indices, scores) equal, stuff areas and the map equal up to the few pixels whose rescaled
+    probability sits on the 0.5 threshold."""
+    from helpers import load_pan_golden, make_pan_case, pan_info_rows
+    g, case = load_pan_golden(name)
+    cls, logits, meta = make_pan_case(case)
+    cfg = vkn.configs.roi_head_cfg(False, C=32, heads=8, ffn=64, ncls=case['ncls'], n_thing=case['T'], n_stuff=case['ncls'] - case['T'],
+                                   S=1, up=case['up'], nprop=case['Np'], merge_joint=False)
+    cfg['test_cfg'] = dict(max_per_img=case['Np'], mask_thr=0.5,
+                           merge_stuff_thing=dict(overlap_thr=0.6, iou_thr=0.5, stuff_max_area=int(g['stuff_max_area']), instance_score_thr=0.25))
+    head = vkn.build_head(cfg).to(DEV).eval()
+    scaled = F.interpolate(logits, scale_factor=case['up'], align_corners=False, mode='bilinear') if case['up'] > 1 else logits
+    for b in range(case['B']):
+        bbox_result, segm_result, (seg, info) = head.get_panoptic(cls[b].to(DEV), scaled[b].to(DEV), head.test_cfg, meta)
+        rows, ref = pan_info_rows(info), g[f'info{b}']
+        assert rows.shape == ref.shape and np.array_equal(rows[:, :4], ref[:, :4])
+        assert np.allclose(rows[:, 4], ref[:, 4], rtol=0, atol=1e-6, equal_nan=True)
+        stuff = ref[:, 1] == 0
+        assert np.all(np.abs(rows[stuff, 5] - ref[stuff, 5]) <= 0.002 * ref[stuff, 5] + 8)
+        assert np.mean(seg != g['panoptic_seg'][b]) < 2e-3
+        assert sum(len(m) for m in segm_result) == int(g[f'nmask{b}'])
+
+
 def test_instance_only_results_vs_reference_golden(vkn):
     """do_panoptic=False (BASELINE cfg4's result path): `simple_test` -> per image (bbox_result, segm_result) — scores, labels and
     the full-resolution boolean masks against the reference's own simple_test (knet/det/kernel_iter_head.py:270-281)."""

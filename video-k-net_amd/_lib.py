@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
-SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_assign.hip', 'vkn_api.hip')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_api.hip')
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares
@@ -23,6 +23,7 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_w
            'vkn_head_forward_prof_f32',
            'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32',
            'vkn_sizeof_panoptic_cfg', 'vkn_panoptic_workspace_bytes', 'vkn_panoptic_joint_f32',
+           'vkn_merge_workspace_bytes', 'vkn_panoptic_thing_first_u8',
            'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_lsap_f32')
 
 
@@ -215,6 +216,11 @@ def lib():
     L.vkn_panoptic_workspace_bytes.argtypes = [pP, c_int, c_int]
     L.vkn_panoptic_joint_f32.restype = c_int
     L.vkn_panoptic_joint_f32.argtypes = [pP, _fp, _fp, c_int, c_int, c_int, _fp, _fp, _fp, _fp, _fp, c_size, _fp]
+    L.vkn_merge_workspace_bytes.restype = c_size
+    L.vkn_merge_workspace_bytes.argtypes = [c_int, c_int]
+    L.vkn_panoptic_thing_first_u8.restype = c_int
+    L.vkn_panoptic_thing_first_u8.argtypes = [_fp, _fp, _fp, _fp, c_int, _fp, _fp, _fp, c_int, c_int, ctypes.c_double, ctypes.c_double,
+                                              c_int, _fp, _fp, _fp, _fp, c_size, _fp]
     pA = ctypes.POINTER(VknAssignCfg)
     L.vkn_sizeof_assign_cfg.restype = c_size
     L.vkn_sizeof_assign_cfg.argtypes = []

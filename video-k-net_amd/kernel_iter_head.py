@@ -5,8 +5,9 @@ every stage is one of our heads on a GPU tensor; `_mask_forward` exposes the per
 
 The post-head panoptic path (`simple_test` with do_panoptic + merge_joint, `get_panoptic`) runs the fused
 `vkn_panoptic_joint_f32` pipeline straight from the low-res mask logits (no [K, H, W] full-resolution tensor is materialised).
-Train-time assignment / sampling / losses (`forward_train`), the thing-first merge variant and the instance-only
-`get_seg_masks` path are later rows of SURVEY.md §8(f) and raise NotImplementedError here.
+The thing-first merge (`merge_joint=False`: `merge_stuff_thing`, on the device through `vkn_panoptic_thing_first_u8`), the
+instance-only `get_seg_masks` path (`do_panoptic=False`) and training (`forward_train`: GPU assignment costs + C++ LSAP, torch
+losses, autograd through the HIP gather / decode kernels) are provided as well.
 """
 import numpy as np
 import torch
@@ -225,8 +226,7 @@ class KernelIterHead(BaseRoIHead):
     def _panoptic_joint(self, cls_score, mask_logits, test_cfg, img_meta, upsample_stride, want_bbox=False):
         """Frames [B] sharing one img_meta -> device tensors (panoptic_seg [B,Ho,Wo] int32, info [B,K,6], nseg [B][, bbox])."""
         if not self.merge_joint:
-            raise NotImplementedError('the thing-first merge (merge_stuff_thing, reference :385-465) is not provided: every '
-                                      'shipped panoptic config sets merge_joint=True')
+            raise RuntimeError('_panoptic_joint is the merge_joint=True pipeline; merge_joint=False goes through get_panoptic')
         merge_cfg = self._cfg(test_cfg, 'merge_stuff_thing')
         img, bis, ori = self._meta_geometry(img_meta)
         return ops.panoptic_joint(cls_score, mask_logits, self.num_proposals, self.num_thing_classes,
@@ -256,10 +256,55 @@ class KernelIterHead(BaseRoIHead):
         return (acc.tolist(), info_b[acc, 1].tolist(), bbox_b[acc].astype(np.float32),
                 info_b[acc, 5:6].copy().view(np.float32)[:, 0].tolist())
 
+    # ---- thing-first merge (merge_joint=False): reference :385-465
+    def merge_stuff_thing(self, thing_masks, thing_labels, thing_scores, stuff_masks, stuff_labels, stuff_scores, merge_cfg=None):
+        """Boolean masks pasted in score order, things first (reference :385-465) — on the device (`vkn_panoptic_thing_first_u8`),
+        one D2H copy of the map and a [K, 5] table.  -> (panoptic_seg int32 ndarray, segments_info)."""
+        dev = thing_masks.device
+        thing_order = torch.argsort(-thing_scores)
+        sorted_inds = torch.argsort(-stuff_scores)
+        lab_sorted = stuff_labels[sorted_inds].cpu().tolist()
+        if len(set(lab_sorted)) == len(lab_sorted):
+            sm, sl, so = stuff_masks, stuff_labels, sorted_inds
+        else:   # several masks per label: OR them, one entry per distinct label in first-occurrence (score) order (:440-448)
+            uniq = list(dict.fromkeys(lab_sorted))
+            sm = torch.stack([stuff_masks[stuff_labels == u].bool().any(0) for u in uniq])
+            sl = torch.tensor(uniq, device=dev)
+            so = torch.arange(len(uniq), device=dev)
+        seg, info, nseg = ops.panoptic_thing_first(thing_masks, thing_scores, thing_labels, thing_order, sm, sl, so,
+                                                   self._cfg(merge_cfg, 'instance_score_thr'), self._cfg(merge_cfg, 'iou_thr'),
+                                                   self._cfg(merge_cfg, 'stuff_max_area'))
+        info_h = info.cpu().numpy()
+        segments_info = []
+        for row in info_h[info_h[:, 0] > 0]:
+            if row[1] == 0:
+                segments_info.append(dict(id=int(row[0]), isthing=True, score=float(row[4:5].view(np.float32)[0]), category_id=int(row[2]),
+                                          instance_id=int(row[3])))
+            else:
+                segments_info.append(dict(id=int(row[0]), isthing=False, category_id=int(row[2]), area=int(row[3])))
+        return seg.cpu().numpy(), segments_info
+
+    def _get_panoptic_thing_first(self, cls_scores, mask_preds, test_cfg, img_meta):
+        """reference :332-370 with merge_joint=False: top-k things and score-sorted stuff, rescaled and thresholded, then merged."""
+        Np, T = self.num_proposals, self.num_thing_classes
+        last = self.mask_head[-1]
+        thing_scores, topk = cls_scores[:Np][:, :T].flatten(0, 1).topk(self._cfg(self.test_cfg, 'max_per_img'), sorted=True)
+        mask_indices, thing_labels = topk // T, topk % T
+        thr = self._cfg(test_cfg, 'mask_thr')
+        thing_masks = last.rescale_masks(mask_preds[:Np][mask_indices], img_meta) > thr
+        bbox_result, segm_result = last.segm2result(thing_masks, thing_labels, thing_scores)
+        stuff_scores, stuff_inds = torch.sort(cls_scores[Np:][:, T:].diag(), descending=True)
+        stuff_masks = last.rescale_masks(mask_preds[Np:][stuff_inds], img_meta) > thr
+        pan = self.merge_stuff_thing(thing_masks, thing_labels, thing_scores, stuff_masks, stuff_inds + 1, stuff_scores,
+                                     self._cfg(test_cfg, 'merge_stuff_thing'))
+        return bbox_result, segm_result, pan
+
     def get_panoptic(self, cls_scores, mask_preds, test_cfg, img_meta):
         """One image, the reference's signature (:332-370): `mask_preds` are the (already up-scaled) `scaled_mask_preds[img]`.
         Returns `(bbox_result, segm_result, (panoptic_seg int32 ndarray, segments_info))`; the first two are None: they are
         the K full-resolution thing masks as host arrays (`segm2result`), which this pipeline exists to NOT materialise."""
+        if not self.merge_joint:
+            return self._get_panoptic_thing_first(cls_scores, mask_preds, test_cfg, img_meta)
         seg, info, nseg = self._panoptic_joint(cls_scores[None], mask_preds[None], test_cfg, img_meta, 1)
         info_h = info[0].cpu().numpy()
         if int(nseg[0]) < 0:
@@ -294,6 +339,9 @@ class KernelIterHead(BaseRoIHead):
             # rescale / threshold (`get_seg_masks`).  Selection and resampling run on the device, one D2H copy of K bool masks.
             _, cls, _, scaled, _ = self._head_forward(x, proposal_feats, mask_preds)
             return [self._instance_result(cls[i], scaled[i], img_metas[i]) for i in range(len(img_metas))]
+        if not self.merge_joint:   # thing-first merge: needs the K rescaled boolean masks (reference :263-269, 332-370)
+            _, cls, _, scaled, _ = self._head_forward(x, proposal_feats, mask_preds)
+            return [self.get_panoptic(cls[i], scaled[i], self.test_cfg, img_metas[i]) for i in range(len(img_metas))]
         _, cls, masks, _, _ = self._head_forward(x, proposal_feats, mask_preds, want_scaled=False)
         up = self.mask_head[-1].mask_upsample_stride
         return [(None, None, (seg, info)) for seg, info, _ in self._panoptic_results(cls, masks, img_metas, up)]

@@ -504,6 +504,33 @@ def panoptic_joint(cls_prob, mask_logits, num_proposals, num_thing_classes, max_
     return (seg, info, nseg, bbox) if want_bbox else (seg, info, nseg)
 
 
+def panoptic_thing_first(thing_masks, thing_scores, thing_labels, thing_order, stuff_masks, stuff_labels, stuff_order,
+                         instance_score_thr, iou_thr, stuff_max_area):
+    """Thing-first panoptic merge of ONE image on the device (`merge_stuff_thing`, knet/det/kernel_iter_head.py:385-465).
+    thing_masks [Kt,H,W] / stuff_masks [Ks,H,W] bool, scores fp32, labels / orders int; `*_order` = the paste order (indices into
+    the mask arrays).  Returns device tensors (panoptic_seg int32 [H,W], info int32 [Kt+Ks,5], nseg int32 [1]); see include/vkn.h."""
+    dev = thing_masks.device
+    if not thing_masks.is_cuda:
+        raise _lib.VknLibraryError('panoptic_thing_first: expected CUDA/HIP tensors — the MI355X path has no CPU fallback')
+    H, W = thing_masks.shape[-2:]
+    HW = H * W
+    Kt, Ks = thing_masks.shape[0], stuff_masks.shape[0]
+    tm = thing_masks.to(torch.uint8).contiguous()
+    sm = stuff_masks.to(torch.uint8).contiguous()
+    i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()  # noqa: E731
+    ts, tl, to, sl, so = thing_scores.float().contiguous(), i32(thing_labels), i32(thing_order), i32(stuff_labels), i32(stuff_order)
+    L = _lib.lib()
+    seg = torch.empty((H, W), dtype=torch.int32, device=dev)
+    info = torch.zeros((Kt + Ks, 5), dtype=torch.int32, device=dev)
+    nseg = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = _workspace(max(L.vkn_merge_workspace_bytes(Kt, Ks), 256), dev)
+    with torch.cuda.device(dev):
+        check(L.vkn_panoptic_thing_first_u8(_ptr(tm), _ptr(ts), tl.data_ptr(), to.data_ptr(), Kt, _ptr(sm), sl.data_ptr(), so.data_ptr(),
+                                            Ks, HW, float(instance_score_thr), float(iou_thr), int(stuff_max_area), seg.data_ptr(),
+                                            info.data_ptr(), nseg.data_ptr(), _ptr(ws), ws.numel(), _stream()))
+    return seg, info, nseg
+
+
 def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, dice_weight=4.0, mask_weight=1.0,
                  focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3):
     """Cost matrix [N, G] of `MaskHungarianAssigner.assign` (knet/det/mask_hungarian_assigner.py:222-241) on the GPU."""
