@@ -465,6 +465,18 @@ class VideoKernelIterHead(KernelIterHead):
         `(bbox_result, segm_result, thing_mask_preds, panoptic_result, thing_obj_feat)`.  The first three (boxes and the K
         full-resolution thing masks for the tracker) are None — see KernelIterHead.get_panoptic; `thing_obj_feat` are the
         tracking embeddings of the accepted thing segments in segment order (`sort_obj_fea[things_ids]`, :903)."""
+        if not self.merge_joint:
+            # merge_stuff_thing_thing_first (:656-742): the det head's thing-first merge + the accepted things' embeddings, which
+            # the reference indexes in SCORE-SORTED order: thing_obj_feat[sorted_inds][instance_ids] (:676, :742)
+            Np, T = self.num_proposals, self.num_thing_classes
+            bbox_result, segm_result, pan = self._get_panoptic_thing_first(cls_scores, mask_preds, test_cfg, img_meta)
+            tfeat = None
+            if obj_feat is not None:
+                thing_scores, topk = cls_scores[:Np][:, :T].flatten(0, 1).topk(self._cfg(self.test_cfg, 'max_per_img'), sorted=True)
+                sel = obj_feat[:Np][topk // T][torch.argsort(-thing_scores)]
+                ids = [s_['instance_id'] for s_ in pan[1] if s_['isthing']]
+                tfeat = sel[torch.as_tensor(ids, dtype=torch.long, device=sel.device)]
+            return bbox_result, segm_result, None, pan, tfeat
         seg, info, nseg = self._panoptic_joint(cls_scores[None], mask_preds[None], test_cfg, img_meta, 1)
         info_h = info[0].cpu().numpy()
         if int(nseg[0]) < 0:
