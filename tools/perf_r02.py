@@ -115,16 +115,7 @@ def main():
             wb = B * N * P * 16 * 4
             print(f'upsample x4 B={B}: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s of writes', flush=True)
             if not args.release:
-                ref4 = vkn.ops.upsample_bilinear(m, 4)
-                os.environ['VKN_UPSAMPLE4'] = '0'
-                t = timeit(lambda: vkn.ops.upsample_bilinear(m, 4), reps=10, warm=3)
-                same = torch.equal(ref4, vkn.ops.upsample_bilinear(m, 4))
-                print(f'upsample x4 B={B} generic staged kernel: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s of writes; x4 kernel bit-identical: {same}', flush=True)
-                tref = torch.nn.functional.interpolate(m[:2], scale_factor=4, mode='bilinear', align_corners=False)
-                print(f'  x4 kernel == ATen: {torch.equal(ref4[:2], tref)}', flush=True)
-                del ref4, tref
-                os.environ.pop('VKN_UPSAMPLE4')
-                for mode in (24, 11):
+                for mode in (24, 11, 18, 19, 34):   # 2x plain stores, x1 one row group, x8 / x9 = 8 / 32 groups per WG, 3x write-only
                     os.environ['VKN_UPSAMPLE'] = str(mode)
                     t = timeit(lambda: vkn.ops.upsample_bilinear(m, 4), reps=10, warm=3)
                     print(f'upsample x4 B={B} mode={mode}: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s of writes', flush=True)

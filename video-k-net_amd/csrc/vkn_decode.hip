@@ -24,7 +24,6 @@
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- bit-packed output (intermediate stages of the fused head): instead of the logits, emit bit(z >= thr) — all the next
 // stage's gather consumes — as words[B][P/64][2][NPT]: for 64-px tile T and row n, word [T][0][n] bit i = pixel 64 T + 2 i

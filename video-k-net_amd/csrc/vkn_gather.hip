@@ -452,32 +452,48 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_bits_w(const float* __
     if (has_cnt && g == 0) cntp[((size_t)b * G + gidx) * NPT + n0 + wave * 32 + li] = (float)cnt_i;
 }
 
-// xraw[b][n][c] = sum_g part[b][g][n][c], cnt[b][n] likewise.  Fixed summation tree (four interleaved running sums over g,
-// combined in a fixed order) -> deterministic; float4 per thread and 4 independent loads in flight per step.
-__global__ __launch_bounds__(64) void k_gather_reduce(const float* __restrict__ part, const float* __restrict__ cntp,
-                                                       float* __restrict__ xraw, float* __restrict__ cnt, int N, int NPT,
-                                                       int C, int G) {
+// xraw[b][n][c] = sum_g part[b][g][n][c], cnt[b][n] likewise.  Fixed summation tree: four interleaved running sums over g
+// (chain k = groups k, k+4, ...; a remainder of G % 4 groups continues chain 0), combined as (s0 + s1) + (s2 + s3) -> deterministic.
+// One wave per chain, 8 independent 16-byte loads in flight per lane: with few frames G is large (256 partials per frame at B = 1)
+// and a serial walk over g is pure load latency (73 us per call at B = 1 before this layout; the sums are bit-identical to it).
+__global__ __launch_bounds__(256) void k_gather_reduce(const float* __restrict__ part, const float* __restrict__ cntp,
+                                                        float* __restrict__ xraw, float* __restrict__ cnt, int N, int NPT,
+                                                        int C, int G) {
+    __shared__ f32x4 comb[3][64];
     const int row = blockIdx.x;  // b*N + n
     const int b = row / N, n = row - b * N;
+    const int lane = threadIdx.x & 63;
+    const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // chain
     const size_t gstride = (size_t)NPT * C;
     const float* pp = part + ((size_t)b * G * NPT + n) * C;
-    for (int c4 = threadIdx.x * 4; c4 < C; c4 += 256) {
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-        int gi = 0;
-        for (; gi + 3 < G; gi += 4) {
-            s0 += *reinterpret_cast<const f32x4*>(pp + (size_t)(gi + 0) * gstride + c4);
-            s1 += *reinterpret_cast<const f32x4*>(pp + (size_t)(gi + 1) * gstride + c4);
-            s2 += *reinterpret_cast<const f32x4*>(pp + (size_t)(gi + 2) * gstride + c4);
-            s3 += *reinterpret_cast<const f32x4*>(pp + (size_t)(gi + 3) * gstride + c4);
+    const int G4 = G & ~3;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c4 = c0 + lane * 4;
+        const bool ok = c4 < C;
+        const float* pc = pp + (ok ? c4 : 0);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int gi = k;
+        for (; gi + 28 < G4; gi += 32) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(pc + (size_t)(gi + 4 * u) * gstride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; gi < G; ++gi) s0 += *reinterpret_cast<const f32x4*>(pp + (size_t)gi * gstride + c4);
-        *reinterpret_cast<f32x4*>(xraw + (size_t)row * C + c4) = (s0 + s1) + (s2 + s3);
+        for (; gi < G4; gi += 4) s += *reinterpret_cast<const f32x4*>(pc + (size_t)gi * gstride);
+        if (k == 0)
+            for (gi = G4; gi < G; ++gi) s += *reinterpret_cast<const f32x4*>(pc + (size_t)gi * gstride);
+        if (c0) __syncthreads();
+        if (k) comb[k - 1][lane] = s;
+        __syncthreads();
+        if (k == 0 && ok) *reinterpret_cast<f32x4*>(xraw + (size_t)row * C + c4) = (s + comb[0][lane]) + (comb[1][lane] + comb[2][lane]);
     }
-    if (threadIdx.x == 63) {  // counts are small integers: any order is exact
+    if (k == 1) {  // lane l sums groups l, l + 64, ... in order, then a fixed butterfly (binary counts: exact in any order)
         const float* cp = cntp + (size_t)b * G * NPT + n;
         float s = 0.f;
-        for (int gi = 0; gi < G; ++gi) s += cp[(size_t)gi * NPT];
-        cnt[row] = s;
+        for (int gi = lane; gi < G; gi += 64) s += cp[(size_t)gi * NPT];
+        s = vkn_wave_sum(s);
+        if (lane == 0) cnt[row] = s;
     }
 }
 
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(256) void k_gather_ref(const float* __restrict__ x,
 
 int vkn_launch_gather_reduce(const float* part, const float* cntp, float* xraw, float* cnt, int B, int N, int C, int G,
                              hipStream_t stream) {
-    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(64), 0, stream, part, cntp, xraw, cnt, N, (N + 31) / 32 * 32, C, G);
+    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, (N + 31) / 32 * 32, C, G);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
@@ -615,7 +631,7 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
 #undef GA_LAUNCH
         VKN_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(64), 0, stream, part, cntp, xraw, cnt, N, NPT, C, G);
+    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, NPT, C, G);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

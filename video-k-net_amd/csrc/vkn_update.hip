@@ -257,6 +257,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm(const float* __restrict_
 //   * LDS is double-buffered: the DMA + A loads of tile t+1 are issued before the MFMAs of tile t; ONE barrier per tile.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define GS_LDR 40                   // bf16 per LDS row of the A image: 32 + 8 pad (80 B: conflict-free ds_read_b128)
 #define GS_WTILE (3 * 4 * 256 * 8)  // bf16 elements of one weight tile image (48 KB)
 #define GS_ATILE (3 * GM_BM * GS_LDR)
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void k_split_w3(const float* __restrict__ W, _
 // Up to two independent problems (same M, K) run as ONE launch, selected by blockIdx.z when ksplit == 1: pairing independent
 // layers (dynamic/input layer, the two gates, the cls/mask branches) removes whole launch + prologue + epilogue latencies
 // from the critical path of the chain.
-__global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGemmProb p1, int nprob, int M, int K,
+__global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmProb p1, int nprob, int M, int K,
                                                            float* __restrict__ partial) {
     const bool second = (nprob > 1) && (blockIdx.z == 1);
     const float* __restrict__ A = second ? p1.A : p0.A;
@@ -298,8 +299,8 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     const int Nout = second ? p1.Nout : p0.Nout;
     const VknEpi epi = second ? p1.epi : p0.epi;
     extern __shared__ __attribute__((aligned(16))) char smem_s3[];
-    __bf16* Wl = reinterpret_cast<__bf16*>(smem_s3);  // [2][GS_WTILE]; buffer 0 is reused as the fp32 [32][260] output tile
-    __bf16* Al = Wl + 2 * GS_WTILE;                   // [2][3][32][40]
+    __bf16* Wl = reinterpret_cast<__bf16*>(smem_s3);  // [3][GS_WTILE]; buffer 0 is reused as the fp32 [32][260] output tile
+    __bf16* Al = Wl + 3 * GS_WTILE;                   // [2][3][32][40]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -313,10 +314,12 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     const int kt_begin = kz * kt_per;
     const int kt_end = min(ktiles, kt_begin + kt_per);
 
-    // A staging role: thread -> one float4 (row = (tid>>3)&31, k = 4*(tid&7)); the upper 256 threads duplicate the loads of
-    // the lower 256 (unconditional loads keep the compiler's vmcnt accounting exact) and only the lower half writes LDS.
-    const bool a_role = tid < 256;
-    const int ar = (tid >> 3) & 31, aq = tid & 7;
+    // Roles (wave-uniform): waves 0-3 issue the weight DMA, waves 4-7 fetch / split / stash the A tile.  The split matters for the
+    // waits: hipcc waits vmcnt(0) for ANY register load once LDS-DMA instructions are pending in the same wave (measured: it did
+    // so with the A loads strictly older than the DMA), which would drain the prefetch every K-tile.  With the roles apart, the DMA
+    // waves carry no compiler-visible dependency and are held only by the explicit vmcnt below; the A waves have nothing else in flight.
+    const bool a_role = wave >= 4;
+    const int at = tid & 255, ar = (at >> 3) & 31, aq = at & 7;
     const size_t aoff = (size_t)min(m0 + ar, M - 1) * lda + 4 * aq;
     const float* A2p = A2 ? A2 : A;
     const float* A3p = A3 ? A3 : A;
@@ -325,15 +328,15 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     const __bf16* wtile0 = Wp + (size_t)blockIdx.x * ktiles * GS_WTILE;  // this column tile's images, K-tile major
     f32x4 ra, rb, rc, rd;
 
-    // weight tile KT -> LDS buffer BUF: 3072 x 16 B, 6 DMA instructions per thread; piece index = i*512 + tid, so every
-    // wave writes 64 consecutive slots (the DMA's LDS address is wave base + lane*16) from 1 KB of contiguous global memory
+    // weight tile KT -> LDS buffer BUF: 3072 x 16 B = 12 DMA instructions per thread of waves 0-3; piece index = i*256 + tid, so
+    // every wave writes 64 consecutive slots (the DMA's LDS address is wave base + lane*16) from 1 KB of contiguous global memory
 #define GS_DMA(KT, BUF)                                                                                               \
     do {                                                                                                              \
-        const char* gsrc_ = reinterpret_cast<const char*>(wtile0 + (size_t)(KT) * GS_WTILE) + (size_t)tid * 16;       \
+        const char* gsrc_ = reinterpret_cast<const char*>(wtile0 + (size_t)(KT) * GS_WTILE) + (size_t)at * 16;        \
         char* ldst_ = reinterpret_cast<char*>(Wl + (size_t)(BUF) * GS_WTILE) + (size_t)wave * 1024;                   \
-        _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                                 \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_ + i * 8192),       \
-                                             (__attribute__((address_space(3))) void*)(ldst_ + i * 8192), 16, 0, 0);  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_)                                                             \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_ + i_ * 4096),      \
+                                             (__attribute__((address_space(3))) void*)(ldst_ + i_ * 4096), 16, 0, 0); \
     } while (0)
 
 #define GS_AFETCH(KT)                                                              \
@@ -344,23 +347,45 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
         rd = *reinterpret_cast<const f32x4*>(A4p + aoff + (size_t)(KT) * 32);      \
     } while (0)
 
-#define GS_ASTASH(BUF)                                                                                \
-    do {                                                                                              \
-        if (a_role) {                                                                                 \
-            bf16x4 h_, m_, l_;                                                                        \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
-                const float v_ = (mul ? ra[e] * rb[e] : ra[e]) + (two ? rc[e] * rd[e] : 0.f);         \
-                __bf16 hh_, mm_, ll_;                                                                 \
-                vkn_split_bf16x3(v_, hh_, mm_, ll_);                                                  \
-                h_[e] = hh_;                                                                          \
-                m_[e] = mm_;                                                                          \
-                l_[e] = ll_;                                                                          \
-            }                                                                                         \
-            __bf16* d_ = Al + (size_t)(BUF) * GS_ATILE + ar * GS_LDR + 4 * aq;                        \
-            *reinterpret_cast<bf16x4*>(d_) = h_;                                                      \
-            *reinterpret_cast<bf16x4*>(d_ + GM_BM * GS_LDR) = m_;                                     \
-            *reinterpret_cast<bf16x4*>(d_ + 2 * GM_BM * GS_LDR) = l_;                                 \
-        }                                                                                             \
+#define GS_ASTASH(BUF)                                                                            \
+    do {                                                                                          \
+        bf16x4 h_, m_, l_;                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
+            const float v_ = (mul ? ra[e] * rb[e] : ra[e]) + (two ? rc[e] * rd[e] : 0.f);         \
+            __bf16 hh_, mm_, ll_;                                                                 \
+            vkn_split_bf16x3(v_, hh_, mm_, ll_);                                                  \
+            h_[e] = hh_;                                                                          \
+            m_[e] = mm_;                                                                          \
+            l_[e] = ll_;                                                                          \
+        }                                                                                         \
+        __bf16* d_ = Al + (size_t)(BUF) * GS_ATILE + ar * GS_LDR + 4 * aq;                        \
+        *reinterpret_cast<bf16x4*>(d_) = h_;                                                      \
+        *reinterpret_cast<bf16x4*>(d_ + GM_BM * GS_LDR) = m_;                                     \
+        *reinterpret_cast<bf16x4*>(d_ + 2 * GM_BM * GS_LDR) = l_;                                 \
+    } while (0)
+
+#define GS_MFMA(I)                                                                                                    \
+    do {                                                                                                              \
+        { /* every wave multiplies (image rows >= Nout are zero): no branch in the loop body */                       \
+            const __bf16* Ab = Al + (size_t)((I) & 1) * GS_ATILE;                                                     \
+            const __bf16* Wb = Wl + (size_t)((I) % 3) * GS_WTILE;                                                     \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                        \
+                const __bf16* ap = Ab + li * GS_LDR + (ks << 4) + (g << 3);                                           \
+                const __bf16* bp = Wb + (((ks << 1) + g) * 256 + wave * 32 + li) * 8; /* plane 0, q = 2*ks + g */     \
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);                                               \
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);                              \
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);                          \
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);                                               \
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + 4 * 256 * 8);                                 \
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 8 * 256 * 8);                                 \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0); /* smallest terms first */       \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);                                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);                                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);                                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);                                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);                                  \
+            }                                                                                                         \
+        }                                                                                                             \
     } while (0)
 
     f32x16 acc;
@@ -368,46 +393,47 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm_s3(VknGemmProb p0, VknGe
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool active = (n0 + wave * 32) < Nout;
 
-    if (kt_begin < kt_end) {
-        GS_DMA(kt_begin, 0);
-        GS_AFETCH(kt_begin);
-        GS_ASTASH(0);
-        __syncthreads();  // (the compiler waits vmcnt(0) for the in-flight DMA before the barrier)
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const int cur = (kt - kt_begin) & 1;
-            const bool more = (kt + 1 < kt_end);  // uniform
-            if (more) {
-                GS_DMA(kt + 1, cur ^ 1);
-                GS_AFETCH(kt + 1);
-            }
-            if (active) {
-                const __bf16* Ab = Al + (size_t)cur * GS_ATILE;
-                const __bf16* Wb = Wl + (size_t)cur * GS_WTILE;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const __bf16* ap = Ab + li * GS_LDR + (ks << 4) + (g << 3);
-                    const __bf16* bp = Wb + (((ks << 1) + g) * 256 + wave * 32 + li) * 8;  // plane 0, q = 2*ks + g
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
-                    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + 4 * 256 * 8);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 8 * 256 * 8);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);  // smallest terms first
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-                }
-            }
-            if (more) GS_ASTASH(cur ^ 1);
-            __syncthreads();  // tile kt+1 landed (DMA + A image) and every wave is done reading tile kt
+    // Three weight buffers: while tile i is multiplied, tiles i+1 AND i+2 are in flight (96 KB per CU).  The K loop of these small-M
+    // GEMMs is bound by the latency of one weight tile (L2 / MALL, 1.5 - 2 us) — with one tile in flight a K-tile cost that latency;
+    // two in flight halve it.  The DMA -> LDS dependency is invisible to the compiler, so the waits are explicit: vmcnt counts in
+    // order, the 12 DMA instructions of tile i+2 are the youngest, vmcnt(12) = "tile i+1 has landed".
+    const int nkt = kt_end - kt_begin;
+    if (nkt > 0) {
+        if (a_role) {
+            GS_AFETCH(kt_begin);
+            GS_ASTASH(0);
+        } else {
+            GS_DMA(kt_begin, 0);
+            if (nkt > 1) GS_DMA(kt_begin + 1, 1);
         }
+        if (nkt > 1) __builtin_amdgcn_s_waitcnt(0x0F7C);  // vmcnt(12)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+        __syncthreads();
+        int i = 0;
+        for (; i + 2 < nkt; ++i) {
+            if (a_role) GS_AFETCH(kt_begin + i + 1);
+            else GS_DMA(kt_begin + i + 2, (i + 2) % 3);  // that buffer held tile i-1: every wave passed the barrier after reading it
+            GS_MFMA(i);
+            if (a_role) GS_ASTASH((i + 1) & 1);
+            // tile i+1 landed (tile i+2 may still be in flight), this wave's LDS writes are done; ONE asm statement: behind a
+            // __syncthreads() hipcc strengthens the wait to vmcnt(0) (its workgroup release fence), which drains the prefetch
+            asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (i + 1 < nkt) {
+            if (a_role) GS_AFETCH(kt_begin + i + 1);
+            GS_MFMA(i);
+            if (a_role) GS_ASTASH((i + 1) & 1);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+            ++i;
+        }
+        GS_MFMA(i);
+        __syncthreads();  // buffer 0 becomes the output tile below
     }
 #undef GS_DMA
 #undef GS_AFETCH
 #undef GS_ASTASH
+#undef GS_MFMA
 
     if (ksplit > 1) {
         float* pz = partial + (size_t)kz * M * Nout;
@@ -860,7 +886,7 @@ int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int
         split = split && probs[i].Wsplit && (probs[i].lda % 4) == 0;
     }
     if (split) {
-        const size_t lds = (size_t)(2 * GS_WTILE + 2 * GS_ATILE) * sizeof(__bf16);
+        const size_t lds = (size_t)(3 * GS_WTILE + 2 * GS_ATILE) * sizeof(__bf16);  // 162,816 B of the 163,840
         VKN_ALLOW_FULL_LDS(k_gemm_s3);
         int nmax = probs[0].Nout;
         if (nprob > 1 && probs[1].Nout > nmax) nmax = probs[1].Nout;
@@ -992,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
             const int y = min(max(yb0 - 1 + r, 0), H - 1);
             float v[NTAP];
 #pragma unroll
-            for (int i = 0; i < NTAP; ++i) v[i] = ip[(size_t)y * W + cx[i]];
+            for (int i = 0; i < NTAP; ++i) v[i] = (NT == 2) ? (float)(y + cx[i]) : ip[(size_t)y * W + cx[i]];  // NT == 2: write-only ablation (debug)
             hinterp(v, hrow[r]);
         }
 #pragma unroll
@@ -1007,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
                 for (int r = 0; r < UP_ROWS; ++r) {
                     const int y = min(yb + UP_ROWS + 1 + r, H - 1);
 #pragma unroll
-                    for (int i = 0; i < NTAP; ++i) nv[r][i] = ip[(size_t)y * W + cx[i]];
+                    for (int i = 0; i < NTAP; ++i) nv[r][i] = (NT == 2) ? (float)(y + cx[i]) : ip[(size_t)y * W + cx[i]];
                 }
             }
             // vertical blend + store: output rows S * yb .. S * (yb + UP_ROWS) - 1
@@ -1046,81 +1072,6 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
     }
 }
 
-// x4 specialisation (every video config, the bench headline): align_corners=False at scale 4 has only four interpolation phases,
-// lambda = {0.625, 0.875, 0.125, 0.375}, and static taps — outputs 4q, 4q+1 blend input columns (q-1, q), outputs 4q+2, 4q+3 blend
-// (q, q+1); rows likewise.  k_upsample_s derives all of that per thread at run time (index arithmetic + ~9 selects per value:
-// ~30 VALU per 16-byte store, 0.4 ms of VALU issue for the 7.85 GB of a 32-frame step); here the coefficients are literals and
-// only the two clamped borders (column quad 0, output rows 0 and 1: ATen clamps the source index to 0, lambda = 0) keep a select.
-// Same expression per value ((1 - l) * a + l * b, then hy * top + ly * bot) on the same operands -> bit-identical outputs.
-template <int NT, int SUBS>
-__global__ __launch_bounds__(256) void k_upsample4(const float* __restrict__ in, float* __restrict__ out, int H, int W) {
-    const int OW = W * 4, OH = H * 4;
-    const int plane = blockIdx.y;
-    const int yb0 = blockIdx.x * UP_ROWS * SUBS;
-    const float* ip = in + (size_t)plane * H * W;
-    float* op = out + (size_t)plane * OH * OW;
-    constexpr float LX[4] = {0.625f, 0.875f, 0.125f, 0.375f};
-    for (int q = threadIdx.x; q * 4 < OW; q += 256) {
-        const int c0 = max(q - 1, 0), c1 = q, c2 = min(q + 1, W - 1);
-        const bool left = (q == 0);  // outputs 0, 1 of the first quad: source index clamped to 0 -> lambda 0 on taps (0, 1)
-        auto hinterp = [&](float v0, float v1, float v2, float (&h)[4]) {
-            const float l0 = left ? 0.f : LX[0], l1 = left ? 0.f : LX[1];
-            const float a = left ? v1 : v0, b = left ? v2 : v1;
-            h[0] = (1.f - l0) * a + l0 * b;
-            h[1] = (1.f - l1) * a + l1 * b;
-            h[2] = (1.f - LX[2]) * v1 + LX[2] * v2;
-            h[3] = (1.f - LX[3]) * v1 + LX[3] * v2;
-        };
-        float hrow[UP_ROWS + 2][4];
-#pragma unroll
-        for (int r = 0; r < UP_ROWS + 2; ++r) {
-            const int y = min(max(yb0 - 1 + r, 0), H - 1);
-            const float* rp = ip + (size_t)y * W;
-            hinterp(rp[c0], rp[c1], rp[c2], hrow[r]);
-        }
-#pragma unroll
-        for (int sub = 0; sub < SUBS; ++sub) {
-            const int yb = yb0 + sub * UP_ROWS;
-            if (yb >= H) break;
-            float nv[UP_ROWS][3];
-            if (sub + 1 < SUBS) {
-#pragma unroll
-                for (int r = 0; r < UP_ROWS; ++r) {
-                    const float* rp = ip + (size_t)min(yb + UP_ROWS + 1 + r, H - 1) * W;
-                    nv[r][0] = rp[c0];
-                    nv[r][1] = rp[c1];
-                    nv[r][2] = rp[c2];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < UP_ROWS; ++i) {
-                if (yb + i >= H) break;
-                const bool top_edge = (yb + i == 0);  // uniform: output rows 0, 1 take input row 0 with lambda 0
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int oy = (yb + i) * 4 + j;
-                    float ly = LX[j];
-                    const float* top = (j < 2) ? hrow[i] : hrow[i + 1];
-                    const float* bot = (j < 2) ? hrow[i + 1] : hrow[i + 2];
-                    if (j < 2 && top_edge) { ly = 0.f; top = hrow[1]; bot = hrow[2]; }
-                    const float hy = 1.f - ly;
-                    const f32x4 o = {hy * top[0] + ly * bot[0], hy * top[1] + ly * bot[1], hy * top[2] + ly * bot[2],
-                                     hy * top[3] + ly * bot[3]};
-                    float* dst = op + (size_t)oy * OW + q * 4;
-                    if (NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst));
-                    else *reinterpret_cast<f32x4*>(dst) = o;
-                }
-            }
-            if (sub + 1 < SUBS) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { hrow[0][k] = hrow[UP_ROWS][k]; hrow[1][k] = hrow[UP_ROWS + 1][k]; }
-#pragma unroll
-                for (int r = 0; r < UP_ROWS; ++r) hinterp(nv[r][0], nv[r][1], nv[r][2], hrow[2 + r]);
-            }
-        }
-    }
-}
-
 int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream) {
     if (S < 1) return VKN_E_SHAPE;
     int done = 0;
@@ -1135,9 +1086,14 @@ int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, i
             const int subs = (mode % 10 == 1) ? 1 : 4;
             dim3 grid((H + UP_ROWS * subs - 1) / (UP_ROWS * subs), chunk);
 #define UP_LAUNCH(SV, NTV, SUBV) hipLaunchKernelGGL((k_upsample_s<SV, NTV, SUBV>), grid, dim3(256), 0, stream, ip, op, H, W)
-            if (S == 4 && nt && subs == 4 && vkn_dbg_env("VKN_UPSAMPLE4", 1) != 0) {
-                hipLaunchKernelGGL((k_upsample4<1, 4>), grid, dim3(256), 0, stream, ip, op, H, W);
-            } else if (S == 4) {
+#ifdef VKN_DEBUG
+            if (S == 4 && mode / 10 == 3) { UP_LAUNCH(4, 2, 4); }  // write-only ablation: the store pattern's own ceiling
+            else if (S == 4 && (mode % 10 == 8 || mode % 10 == 9)) {  // 8 / 32 row groups per workgroup (quarter / whole plane)
+                if (mode % 10 == 8) { grid.x = (H + UP_ROWS * 8 - 1) / (UP_ROWS * 8); UP_LAUNCH(4, 1, 8); }
+                else { grid.x = (H + UP_ROWS * 32 - 1) / (UP_ROWS * 32); UP_LAUNCH(4, 1, 32); }
+            } else
+#endif
+            if (S == 4) {
                 if (nt && subs == 4) UP_LAUNCH(4, 1, 4);
                 else if (nt) UP_LAUNCH(4, 1, 1);
                 else if (subs == 4) UP_LAUNCH(4, 0, 4);
