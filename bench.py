@@ -210,6 +210,8 @@ def main():
     ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
     ap.add_argument('--streams', type=int, default=1,
                     help='frame groups of the clip processed on separate HIP streams (measured: no gain, 1 is fastest)')
+    ap.add_argument('--x-storage', default='fp32', choices=['fp32', 'fp16', 'bf16'],
+                    help='storage type of the feature map x (the head computes in fp32 either way; fp32 = the parity-exact headline)')
     ap.add_argument('--train', action='store_true', help='training step (cfg3) instead of the inference headline; see the docstring')
     args = ap.parse_args()
 
@@ -234,6 +236,9 @@ def main():
     head = build_head(vkn, device)
     B = args.frames
     x, pf, mp = synth_inputs(B, device, rank)
+    XDT = {'fp32': torch.float32, 'fp16': torch.float16, 'bf16': torch.bfloat16}
+    x = x.to(XDT[args.x_storage])
+    xeb = x.element_size()
     N, C = CFG2['N'], CFG2['C']
     last = head.mask_head[-1]
     dims = last.make_dims(B, N, CFG2['H'], CFG2['W'])
@@ -353,14 +358,14 @@ def main():
             dec_iso_ms = e0.elapsed_time(e1) / reps
             Bl = B // NS if NS > 1 else B                      # frames of the launch the events bracket
             dec_ms = sum(dec_live_ms) / len(dec_live_ms)
-            alg = Bl * P * (C * 4 + N * 4)                     # read x once + write the logits once
+            alg = Bl * P * (C * xeb + N * 4)                   # read x once + write the logits once
             ach = alg / (dec_ms * 1e-3) / 1e9
             # HBM bytes per launch from the committed PMC profile of this same command (tools/gpu_profile.sh ->
             # profiles/r01_pmc.json); null when the sidecar is absent or was taken at another batch size
             traffic = None
             try:
                 side = json.load(open(os.path.join(ROOT, PMC_SIDECAR)))
-                if Bl == side.get('_frames_per_launch'):
+                if Bl == side.get('_frames_per_launch') and xeb == 4:
                     traffic = side['k_decode_mfma']['hbm_bytes_per_launch']
             except Exception:  # noqa: BLE001
                 pass
@@ -371,7 +376,7 @@ def main():
                                      min_launch_ms=round(dec_live_ms[0], 4), max_launch_ms=round(dec_live_ms[-1], 4),
                                      timed='HIP events recorded by the library around the launch, one pair per timed step',
                                      isolated_loop_launch_ms=round(dec_iso_ms, 4),
-                                     isolated_loop_frac=round(B * P * (C + N) * 4 / (dec_iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     isolated_loop_frac=round(B * P * (C * xeb + N * 4) / (dec_iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      frames_per_launch=Bl)
             # the fused decode(s) -> gather(s+1) pass alone (k_fused_dgs + reduce): it reads x once; reported both against the
             # bytes it actually moves and against the algorithmic bytes of the two ops it replaces (decode: x + logits written,
@@ -384,7 +389,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             fu_ms = e0.elapsed_time(e1) / reps
-            alg = B * P * (C * 4 + N * 4)
+            alg = B * P * (C * xeb + N * 4)
             dec_ms = dec_iso_ms                                 # the breakdown below lists isolated-loop timings
             # gather kernel (+ its partial reduce), same accounting: read x once + read the logits once
             for _ in range(3):
@@ -410,7 +415,8 @@ def main():
             up_ms = e0.elapsed_time(e1) / 5
             # the two widened rows, timed for the record; they are NOT part of `value`
             P0 = CFG2['N'] - 17
-            loc, sem = x, torch.roll(x, 1, 0)
+            loc = x if xeb == 4 else x.float()   # the kernel-initialisation pass reads fp32 features
+            sem = torch.roll(loc, 1, 0)
             iw = torch.randn(P0, C, 1, 1, device=device) * 0.05
             sw, sb = torch.randn(19, C, 1, 1, device=device) * 0.05, torch.zeros(19, device=device)
             for _ in range(2):
@@ -450,8 +456,35 @@ def main():
                 torch.cuda.synchronize()
                 per_call[f'frames_per_s_at_{b_}_frames_per_call'] = round(b_ / (e0.elapsed_time(e1) / 30 * 1e-3), 1)
             per_call[f'frames_per_s_at_{B}_frames_per_call'] = round(frames / dt, 1)
+            # the same step with x STORED as fp16 / bf16 (VKN_FLAG_X_F16 / _BF16: fp32 compute, half the x bytes; bit-identical to
+            # the fp32 path on the rounded x, tests/test_gpu_xhalf.py) — reported next to the fp32 headline, never as `value`
+            variants = {}
+            if xeb == 4 and world == 1 and NS == 1:
+                del loc, sem
+                for nm in ('fp16', 'bf16'):
+                    xh = x.to(XDT[nm])
+                    for _ in range(5):
+                        o_ = vkn.ops.head_forward(dims, packs, xh, pfs[0], mp, None, up, clip_first_prev=first_prev)
+                    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+                    for a_, b_ in ev:
+                        a_.record()
+                        b_.record()
+                    torch.cuda.synchronize()
+                    th = time.perf_counter()
+                    for a_, b_ in ev:
+                        o_ = vkn.ops.head_forward(dims, packs, xh, pfs[0], mp, None, up, clip_first_prev=first_prev,
+                                                  decode_events=(a_, b_))
+                    torch.cuda.synchronize()
+                    th = (time.perf_counter() - th) / len(ev)
+                    dh = sum(a_.elapsed_time(b_) for a_, b_ in ev) / len(ev)
+                    algh = B * P * (C * 2 + N * 4)
+                    variants[nm] = dict(ms_per_step=round(th * 1e3, 4), frames_per_s=round(B / th, 1), decode_launch_ms=round(dh, 4),
+                                        decode_frac_of_hbm_peak=round(algh / (dh * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        decode_algorithmic_bytes=algh)
+                    del xh, o_
+            per_call['x_storage_variants'] = variants
             extra['breakdown'] = dict(**per_call, fused_decode_gather_ms=round(fu_ms, 4),
-                                      fused_x_GBps=round(B * P * C * 4 / (fu_ms * 1e-3) / 1e9, 1),
+                                      fused_x_GBps=round(B * P * C * xeb / (fu_ms * 1e-3) / 1e9, 1),
                                       fused_replaces_algorithmic_GBps=round(2 * alg / (fu_ms * 1e-3) / 1e9, 1),
                                       decode_ms=round(dec_ms, 4), gather_plus_reduce_ms=round(ga_ms, 4),
                                       kernel_init_pass0_ms=round(init_ms, 4), panoptic_joint_1024x2048_ms=round(pan_ms, 4),
@@ -471,7 +504,8 @@ def main():
                                          'kernels, C=256, 1024x2048 frame -> 128x256 stride-8 features, ffn tracking link, '
                                          'x4 bilinear upsample of the final logits' + (' [SKIPPED]' if args.no_upsample else ''),
                                 frames_per_gpu_per_step=B, streams_per_gpu=NS, parallelism=f'frame-sharded dp{world}',
-                                arithmetic='fp32 storage; gather/decode on f16 hi+lo split MFMA, [N x C] GEMMs on bf16x3 split MFMA, '
+                                x_storage=args.x_storage,
+                                arithmetic=('fp32' if xeb == 4 else args.x_storage + ' x,') + ' fp32 everything else storage; gather/decode on f16 hi+lo split MFMA, [N x C] GEMMs on bf16x3 split MFMA, '
                                            'fp32 accumulate everywhere (fp32-class accuracy, DESIGN.md §3); random-init weights'),
                     **extra)
         print(json.dumps(line))

@@ -41,6 +41,20 @@ extern "C" {
 #define VKN_FLAG_LOGITS_HANDOFF 4u /* vkn_head_forward_f32: keep fp32 logits between stages instead of bit words (A/B; same results) */
 #define VKN_FLAG_BITS_HANDOFF 16u  /* vkn_head_forward_f32: stage hand-off as bit words through two kernels (decode-bits, gather-bits)
                                       instead of the fused decode -> gather pass over x (A/B; same results) */
+/* Storage type of the feature map x.  The head computes in fp32 whatever the storage; with a 2-byte x the x-streaming kernels
+ * (gather, fused decode->gather, decode) read half the bytes and drop every MFMA against the (zero) low half of x.  fp16 enters
+ * the f16 MFMAs as is; bf16 is converted to f16 on the fly (exact for 2^-14 <= |x| < 65504).  On x' = float(half(x)) the fp32
+ * path returns the SAME BITS as the half path on half(x) (tests/test_gpu_xhalf.py), i.e. the only deviation from the fp32
+ * reference is the rounding of x itself: |dx / x| <= 2^-11 (fp16) / 2^-8 (bf16) — stated tolerance on mask logits 5e-3 / 4e-2 of
+ * the logit scale (tests), not the 1e-3 of the fp32 path.  The reference has no reduced-precision mode.
+ * Needs H*W % 64 == 0; not available with VKN_FLAG_REF_KERNELS.  With the flags below `x` points at 2-byte elements. */
+#define VKN_X_F32 0
+#define VKN_X_F16 1
+#define VKN_X_BF16 2
+#define VKN_FLAG_X_F16 64u    /* x is [B][C][H*W] fp16 */
+#define VKN_FLAG_X_BF16 128u  /* x is [B][C][H*W] bf16 */
+#define VKN_FLAG_SERIAL_LINK 32u   /* vkn_head_forward_f32: run the tracking link on the caller's stream instead of the library's side
+                                    * stream (A/B, or callers that must see ONE stream; same results) */
 #define VKN_FLAG_CLIP_LINK 8u      /* vkn_head_forward_f32: the B frames are CONSECUTIVE frames of one video: prev_obj is [1][N][C] (the
                                       kernels of the frame before frame 0) and frame b > 0 links to this call's own frame b - 1 */
 
@@ -131,6 +145,9 @@ int vkn_mask_decode_f32(const float* x, const float* kernels, const float* bias,
 int vkn_split_planes_f32(const float* kernels, void* kf_hi, void* kf_lo, int B, int N, int C, void* stream);
 int vkn_mask_decode_planes_f32(const float* x, const void* kf_hi, const void* kf_lo, const float* bias, float* out, int B,
                                int N, int C, int P, void* stream);
+/*      ... with x stored as x_dtype (VKN_X_F32 / VKN_X_F16 / VKN_X_BF16; see the note at VKN_FLAG_X_F16) */
+int vkn_mask_decode_planes_x(const void* x, int x_dtype, const void* kf_hi, const void* kf_lo, const float* bias, float* out, int B,
+                             int N, int C, int P, void* stream);
 
 /* ---- ops (iii) of stage s and (i) of stage s + 1 as ONE pass over x (k_fused_dg, csrc/vkn_fused.hip): the decode
  *      `F.conv2d(mask_x[i:i+1], mask_feat[i])` knet/det/kernel_update_head.py:247-260, the next stage's binarisation
@@ -142,6 +159,8 @@ int vkn_mask_decode_planes_f32(const float* x, const void* kf_hi, const void* kf
 int vkn_decode_gather_supported(int C, int P);
 int vkn_decode_gather_f32(const float* x, const void* kf_hi, const void* kf_lo, const float* bias, float thr_logit,
                           float* xraw_out, float* cnt_out, int B, int N, int C, int P, void* ws, size_t ws_bytes, void* stream);
+int vkn_decode_gather_x(const void* x, int x_dtype, const void* kf_hi, const void* kf_lo, const float* bias, float thr_logit,
+                        float* xraw_out, float* cnt_out, int B, int N, int C, int P, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- `F.interpolate(mask_preds, scale_factor=S, mode='bilinear', align_corners=False)`
  *      knet/det/kernel_iter_head.py:122-130.  in [planes][H][W] -> out [planes][H*S][W*S]. */

@@ -946,3 +946,28 @@ def test_clip_link_in_one_call(vkn):
     assert torch.equal(a[4], track)
     o = head.clip_forward(xs, pfs.reshape(T, N, C, 1, 1), mps, first_previous_obj_feats=first.reshape(1, N, C, 1, 1))
     assert torch.equal(o[4].reshape(T, N, C), track) and torch.equal(o[2], b[2])
+
+
+def test_side_stream_link_equals_serial_link(vkn):
+    """The fused head runs the tracking link on the library's side stream (forked where the last stage's kernels are final,
+    joined before the call returns); VKN_FLAG_SERIAL_LINK keeps it on the caller's stream.  Same kernels on the same operands
+    -> every output bit-identical, in clip mode and with a per-frame previous tensor, repeated to catch ordering races."""
+    _, case = load_golden('video_cfg')
+    head, (x, pf, mp, prev) = _build_head(vkn, case)
+    T, N, C = 6, case['N'], case['C']
+    xs = _rand((T, C, case['H'], case['W']), 941).to(DEV)
+    pfs = _rand((T, N, C), 942).to(DEV)
+    mps = _rand((T, N, case['H'], case['W']), 943, 4.0).to(DEV)
+    first = _rand((1, N, C), 944).to(DEV)
+    prevs = _rand((T, N, C), 945).to(DEV)
+    dims = head.mask_head[0].make_dims(T, N, case['H'], case['W'])
+    packs = [h.stage_pack(torch.device(DEV)) for h in head.mask_head]
+    for kw in ({'clip_first_prev': first}, {'prev_obj': prevs}):
+        ref = vkn.ops.head_forward(dims, packs, xs, pfs, mps, kw.get('prev_obj'), case['up'],
+                                   clip_first_prev=kw.get('clip_first_prev'), want_track=True, flags=vkn.ops.FLAG_SERIAL_LINK)
+        for _ in range(4):
+            out = vkn.ops.head_forward(dims, packs, xs, pfs, mps, kw.get('prev_obj'), case['up'],
+                                       clip_first_prev=kw.get('clip_first_prev'), want_track=True)
+            assert out[4] is not None
+            for u, v in zip(out, ref):
+                assert (u is None and v is None) or torch.equal(u, v)

@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--frames', default='8,32')
     ap.add_argument('--what', default='decode,fused,head,upsample')
     ap.add_argument('--release', action='store_true', help='use the release library (no env knobs)')
+    ap.add_argument('--xdtype', default='fp32', choices=['fp32', 'fp16', 'bf16'], help='storage type of the feature map x')
     args = ap.parse_args()
     import vkn_import
     vkn = vkn_import.load()
@@ -50,7 +51,9 @@ def main():
     head = bench.build_head(vkn, dev)
     for B in [int(v) for v in args.frames.split(',')]:
         x, pf, mp = bench.synth_inputs(B, dev, 0)
-        alg = B * P * (C + N) * 4
+        x = x.to({'fp32': torch.float32, 'fp16': torch.float16, 'bf16': torch.bfloat16}[args.xdtype])
+        xbytes = x.element_size()
+        alg = B * P * (C * xbytes + N * 4)
         if 'decode' in what:
             kern = torch.randn(B, N, C, device=dev)
             hi, lo = vkn.ops.split_planes(kern)
@@ -76,7 +79,7 @@ def main():
             print(f'decode B={B} k_decode4: {t:8.1f} us  {alg / t / 1e6:7.3f} TB/s  bit-identical: {torch.equal(res[0], out)}', flush=True)
             os.environ['VKN_DECODE4'] = '0'
             # the fused decode -> gather pass alone: one-wave-per-SIMD (VKN_FUSED8=0) vs two (1); bytes = x only
-            xb = B * P * C * 4
+            xb = B * P * C * xbytes
             ref = None
             for f8 in ('0', '1', '2', '2'):
                 os.environ['VKN_FUSED'] = f8
@@ -107,6 +110,8 @@ def main():
             fp = torch.zeros(1, N, C, device=dev)
             t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 4, clip_first_prev=fp), reps=10, warm=3)
             print(f'bench step (S=3 + link + x4) B={B}: {t:8.1f} us  {B / t * 1e6:9.1f} frames/s', flush=True)
+            t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 4, clip_first_prev=fp, flags=32), reps=10, warm=3)
+            print(f'bench step, link on the caller stream (flag 32) B={B}: {t:8.1f} us  {B / t * 1e6:9.1f} frames/s', flush=True)
             t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
             print(f'bench step without x4 upsample B={B}: {t:8.1f} us  {B / t * 1e6:9.1f} frames/s', flush=True)
         if 'upsample' in what:

@@ -17,7 +17,7 @@ MAX_FCS = 4
 # every symbol include/vkn.h declares
 SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_weights', 'vkn_gather_workspace_bytes', 'vkn_mask_gather_f32', 'vkn_mask_gather_real_f32',
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
-           'vkn_decode_gather_supported', 'vkn_decode_gather_f32',
+           'vkn_decode_gather_supported', 'vkn_decode_gather_f32', 'vkn_mask_decode_planes_x', 'vkn_decode_gather_x',
            'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
            'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_stage_chain_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32',
            'vkn_head_forward_prof_f32',
@@ -175,6 +175,10 @@ def lib():
     L.vkn_mask_decode_planes_f32.argtypes = [_fp, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp]
     L.vkn_decode_gather_supported.restype = c_int
     L.vkn_decode_gather_supported.argtypes = [c_int, c_int]
+    L.vkn_mask_decode_planes_x.restype = c_int
+    L.vkn_mask_decode_planes_x.argtypes = [_fp, c_int, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp]
+    L.vkn_decode_gather_x.restype = c_int
+    L.vkn_decode_gather_x.argtypes = [_fp, c_int, _fp, _fp, _fp, c_float, _fp, _fp, c_int, c_int, c_int, c_int, _fp, c_size, _fp]
     L.vkn_decode_gather_f32.restype = c_int
     L.vkn_decode_gather_f32.argtypes = [_fp, _fp, _fp, _fp, c_float, _fp, _fp, c_int, c_int, c_int, c_int, _fp, c_size, _fp]
     L.vkn_track_link_f32.restype = c_int

@@ -166,6 +166,9 @@ int check_dims(const VknDims* d) {
     return VKN_OK;
 }
 
+// storage type of x selected by the flags (0 fp32, 1 fp16, 2 bf16)
+inline int xdt_of(unsigned flags) { return (flags & VKN_FLAG_X_F16) ? 1 : ((flags & VKN_FLAG_X_BF16) ? 2 : 0); }
+
 VknEpi mk_epi(const VknDims* d) {
     VknEpi e{};
     e.eps = d->ln_eps;
@@ -277,7 +280,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
               float* track_out, const StageWs& s, unsigned flags, hipStream_t st, const unsigned* bits_in = nullptr,
               unsigned* bits_out = nullptr, bool cls_sigmoid = false, bool gathered_in = false, bool gather_out = false,
               hipEvent_t prof0 = nullptr, hipEvent_t prof1 = nullptr, const float* xfeat_in = nullptr, float* kern_out = nullptr,
-              float* kb_out = nullptr) {
+              float* kb_out = nullptr, hipEvent_t obj_ready = nullptr) {
     // xfeat_in / kern_out / kb_out (vkn_stage_chain_f32): the [B*N, C] chain alone — the caller supplies x_feat (already
     // feat-transformed and, for the clip-level VIS heads, merged over the frames of a clip) and receives the folded fp32 decode
     // kernels + bias instead of decoded masks; no gather and no decode are launched, x / masks_in / masks_out are unused.
@@ -292,6 +295,9 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     const bool ref_decode = ref || (P & 1) || chain_only;  // odd H*W: mask rows are not 8-byte aligned -> exact-fp32 FMA decode kernel
                                                            // (chain_only: fp32 folded kernels are the output)
     const bool has_ft = w->ft_w != nullptr;
+    const int xdt = xdt_of(flags);
+    // half-storage x: the MFMA kernels only (whole 64-px tiles); the exact-fp32 reference kernels read fp32
+    if (xdt && !chain_only && (ref || (P % 64) != 0)) return VKN_E_SHAPE;
     PrepW pw{};
     if (w->prepared && !(flags & VKN_FLAG_EXACT_GEMM)) {
         PrepItem items[40];
@@ -305,9 +311,9 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     } else if (ref)
         VKN_TRY(vkn_launch_gather_ref(x, masks_in, d->thr_logit, s.xraw, s.cnt, B, N, C, P, st));
     else if (bits_in)
-        VKN_TRY(vkn_launch_gather_bits(x, bits_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
+        VKN_TRY(vkn_launch_gather_bits(x, bits_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt));
     else
-        VKN_TRY(vkn_launch_gather(x, masks_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
+        VKN_TRY(vkn_launch_gather(x, masks_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt));
 
     // folded feat_transform: x_feat = xraw . W_ft^T + cnt (x) b_ft             (:179-180 folded).  With the
     // composite weights x_feat itself is only materialised when the caller asks for it.
@@ -342,6 +348,9 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             return VKN_E_LAUNCH;
         obj3 = obj_out;
     }
+
+    // obj_out is final here: the fused head forks the tracking link onto its side stream at this point
+    if (obj_ready && hipEventRecord(obj_ready, st) != hipSuccess) return VKN_E_LAUNCH;
 
     // cls and mask branches (:217-227) are independent: layer i of both runs as one grouped launch, then fc_cls + fc_mask
     // (the latter also emits the folded decode bias kb = mask_feat . b_ft).
@@ -386,11 +395,11 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
                 return VKN_E_LAUNCH;
         } else if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
         else if (gather_out)
-            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st));
-        else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st));
+            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt));
+        else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
         else {
             if (prof0 && hipEventRecord(prof0, st) != hipSuccess) return VKN_E_LAUNCH;  // vkn_head_forward_prof_f32: the decode kernel alone
-            VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
+            VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st, xdt));
             if (prof1 && hipEventRecord(prof1, st) != hipSuccess) return VKN_E_LAUNCH;
         }
     } else {
@@ -434,11 +443,11 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             }
             if (gather_out)
                 VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P,
-                                                       st));
-            else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st));
+                                                       st, xdt));
+            else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
             else {
                 if (prof0 && hipEventRecord(prof0, st) != hipSuccess) return VKN_E_LAUNCH;
-                VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st));
+                VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st, xdt));
                 if (prof1 && hipEventRecord(prof1, st) != hipSuccess) return VKN_E_LAUNCH;
             }
         }
@@ -513,8 +522,11 @@ int vkn_mask_gather_f32(const float* x, const float* mask_logits, float thr_logi
     float* cnt = c.take<float>((size_t)B * N);
     if (cnt_out) cnt = cnt_out;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (flags & VKN_FLAG_REF_KERNELS) return vkn_launch_gather_ref(x, mask_logits, thr_logit, xraw_out, cnt, B, N, C, P, st);
-    return vkn_launch_gather(x, mask_logits, thr_logit, xraw_out, cnt, part, cntp, B, N, C, P, st);
+    if (flags & VKN_FLAG_REF_KERNELS) {
+        if (xdt_of(flags)) return VKN_E_SHAPE;
+        return vkn_launch_gather_ref(x, mask_logits, thr_logit, xraw_out, cnt, B, N, C, P, st);
+    }
+    return vkn_launch_gather(x, mask_logits, thr_logit, xraw_out, cnt, part, cntp, B, N, C, P, st, xdt_of(flags));
 }
 
 int vkn_mask_gather_real_f32(const float* x, const float* a, float* out, float* asum_out, int B, int N, int C, int P, void* ws,
@@ -546,13 +558,16 @@ int vkn_mask_decode_f32(const float* x, const float* kernels, const float* bias,
     if (!aligned16(x) || !aligned16(kernels) || !aligned16(out)) return VKN_E_ALIGN;
     if (C % 32 != 0 || C > 256 || N > 256) return VKN_E_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if ((flags & VKN_FLAG_REF_KERNELS) || (P & 1)) return vkn_launch_decode_ref(x, kernels, bias, out, B, N, C, P, st);
+    if ((flags & VKN_FLAG_REF_KERNELS) || (P & 1)) {
+        if (xdt_of(flags)) return VKN_E_SHAPE;
+        return vkn_launch_decode_ref(x, kernels, bias, out, B, N, C, P, st);
+    }
     if (!ws || ws_bytes < vkn_decode_workspace_bytes(B, N, C)) return VKN_E_WORKSPACE;
     Carver c{static_cast<char*>(ws), 0};
     _Float16* kfh = c.take<_Float16>((size_t)B * npt_of(N) * C);
     _Float16* kfl = c.take<_Float16>((size_t)B * npt_of(N) * C);
     VKN_TRY(vkn_launch_split_planes(kernels, kfh, kfl, B, N, C, st));
-    return vkn_launch_decode(x, kfh, kfl, bias, out, B, N, C, P, st);
+    return vkn_launch_decode(x, kfh, kfl, bias, out, B, N, C, P, st, xdt_of(flags));
 }
 
 int vkn_split_planes_f32(const float* kernels, void* kf_hi, void* kf_lo, int B, int N, int C, void* stream) {
@@ -564,17 +579,29 @@ int vkn_split_planes_f32(const float* kernels, void* kf_hi, void* kf_lo, int B, 
 
 int vkn_mask_decode_planes_f32(const float* x, const void* kf_hi, const void* kf_lo, const float* bias, float* out, int B,
                                int N, int C, int P, void* stream) {
-    if (!x || !kf_hi || !kf_lo || !out || B <= 0 || N <= 0 || C <= 0 || P <= 0) return VKN_E_ARG;
+    return vkn_mask_decode_planes_x(x, VKN_X_F32, kf_hi, kf_lo, bias, out, B, N, C, P, stream);
+}
+
+int vkn_mask_decode_planes_x(const void* x, int x_dtype, const void* kf_hi, const void* kf_lo, const float* bias, float* out, int B,
+                             int N, int C, int P, void* stream) {
+    if (!x || !kf_hi || !kf_lo || !out || B <= 0 || N <= 0 || C <= 0 || P <= 0 || x_dtype < 0 || x_dtype > 2) return VKN_E_ARG;
     if (!aligned16(x) || !aligned16(kf_hi) || !aligned16(kf_lo) || !aligned16(out)) return VKN_E_ALIGN;
     if (C % 32 != 0 || C > 256 || N > 256) return VKN_E_SHAPE;
-    return vkn_launch_decode(x, static_cast<const _Float16*>(kf_hi), static_cast<const _Float16*>(kf_lo), bias, out, B, N, C,
-                             P, static_cast<hipStream_t>(stream));
+    return vkn_launch_decode(static_cast<const float*>(x), static_cast<const _Float16*>(kf_hi), static_cast<const _Float16*>(kf_lo),
+                             bias, out, B, N, C, P, static_cast<hipStream_t>(stream), x_dtype);
 }
 
 int vkn_decode_gather_supported(int C, int P) { return vkn_fused_supported(C, P); }
 
 int vkn_decode_gather_f32(const float* x, const void* kf_hi, const void* kf_lo, const float* bias, float thr_logit,
                           float* xraw_out, float* cnt_out, int B, int N, int C, int P, void* ws, size_t ws_bytes, void* stream) {
+    return vkn_decode_gather_x(x, VKN_X_F32, kf_hi, kf_lo, bias, thr_logit, xraw_out, cnt_out, B, N, C, P, ws, ws_bytes, stream);
+}
+
+int vkn_decode_gather_x(const void* xv, int x_dtype, const void* kf_hi, const void* kf_lo, const float* bias, float thr_logit,
+                        float* xraw_out, float* cnt_out, int B, int N, int C, int P, void* ws, size_t ws_bytes, void* stream) {
+    const float* x = static_cast<const float*>(xv);
+    if (x_dtype < 0 || x_dtype > 2) return VKN_E_ARG;
     if (!x || !kf_hi || !kf_lo || !xraw_out || !cnt_out || B <= 0 || N <= 0 || C <= 0 || P <= 0) return VKN_E_ARG;
     if (!aligned16(x) || !aligned16(kf_hi) || !aligned16(kf_lo) || !aligned16(xraw_out)) return VKN_E_ALIGN;
     if (N > 256 || !vkn_fused_supported(C, P)) return VKN_E_SHAPE;
@@ -584,7 +611,8 @@ int vkn_decode_gather_f32(const float* x, const void* kf_hi, const void* kf_lo, 
     float* part = c.take<float>((size_t)B * G * NPT * C);
     float* cntp = c.take<float>((size_t)B * G * NPT);
     return vkn_launch_fused_decode_gather(x, static_cast<const _Float16*>(kf_hi), static_cast<const _Float16*>(kf_lo), bias,
-                                          thr_logit, xraw_out, cnt_out, part, cntp, B, N, C, P, static_cast<hipStream_t>(stream));
+                                          thr_logit, xraw_out, cnt_out, part, cntp, B, N, C, P, static_cast<hipStream_t>(stream),
+                                          x_dtype);
 }
 
 int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* cur_obj, const float* prev_obj,
@@ -809,6 +837,29 @@ int vkn_stage_chain_f32(const VknDims* d, const VknStageWeights* w, const float*
                      kb_out);
 }
 
+// Side stream of the fused head: the tracking link (attention over the previous frame's kernels + FFN, a latency-bound [N x C]
+// chain) depends only on the last stage's updated kernels, while the main stream still has that stage's cls / mask branches, the
+// mask decode and the x4 upsample (HBM-bound) to run.  Fork at "obj_out final", join before the call returns control of the
+// workspace.  One side stream + two events per host thread and device, created on first use, never destroyed (process lifetime).
+struct SideStream {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int dev = -1;
+};
+static SideStream* side_stream() {
+    thread_local SideStream ss[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream* p = &ss[dev];
+    if (p->dev != dev) {
+        if (hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        p->dev = dev;
+    }
+    return p;
+}
+
 static size_t carve_head(const VknDims* d, char* base, StageWs* s, float** mtmp, float** otmp, float** ctmp, unsigned** bits) {
     const size_t stage_bytes = carve_stage(d, base, s);
     Carver c{base, stage_bytes};
@@ -867,6 +918,7 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
 
     const float* m_in = mask_preds_in;
     const float* o_in = proposal_feats;
+    SideStream* joined = nullptr;
     for (int sidx = 0; sidx < num_stages; ++sidx) {
         const bool last = (sidx == num_stages - 1);
         // alternate so that the LAST stage writes the caller's buffers
@@ -875,24 +927,42 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
         float* o_out = to_out ? obj_out : otmp;
         const float* prev = (last && track_out) ? prev_obj : nullptr;   // knet/video/kernel_iter_head.py:544-546
         const bool clip = prev && (flags & VKN_FLAG_CLIP_LINK);
-        if (clip) prev = nullptr;  // the link needs this call's own kernels: it runs after the stage (below)
+        // the link runs on the side stream (forked where obj_out is final) unless the caller asks for one stream
+        SideStream* side = (prev && !(flags & VKN_FLAG_SERIAL_LINK)) ? side_stream() : nullptr;
+        const bool link_after = clip || side;
+        const float* prev_in_stage = link_after ? nullptr : prev;
         const unsigned* b_in = (use_bits && !use_fused && sidx > 0) ? bits[(sidx - 1) & 1] : nullptr;
         unsigned* b_out = (use_bits && !use_fused && !last) ? bits[sidx & 1] : nullptr;
         // the last stage's fc_cls epilogue applies the sigmoid and writes the caller's cls_prob directly
-        VKN_TRY(run_stage(d, &stages[sidx], x, o_in, m_in, prev, last ? cls_prob : ctmp, m_out, o_out, nullptr,
-                          prev ? track_out : nullptr, s, flags, st, b_in, b_out, last, use_fused && sidx > 0, use_fused && !last,
-                          last ? static_cast<hipEvent_t>(ev_decode_start) : nullptr,
-                          last ? static_cast<hipEvent_t>(ev_decode_stop) : nullptr));
+        VKN_TRY(run_stage(d, &stages[sidx], x, o_in, m_in, prev_in_stage, last ? cls_prob : ctmp, m_out, o_out, nullptr,
+                          prev_in_stage ? track_out : nullptr, s, flags, st, b_in, b_out, last, use_fused && sidx > 0,
+                          use_fused && !last, last ? static_cast<hipEvent_t>(ev_decode_start) : nullptr,
+                          last ? static_cast<hipEvent_t>(ev_decode_stop) : nullptr, nullptr, nullptr, nullptr,
+                          (prev && side) ? side->fork : nullptr));
         m_in = m_out;
         o_in = o_out;
-        if (clip) {
-            // clip mode: prev[0] = the caller's previous-frame kernels, prev[b] = this call's frame b - 1          
-            const size_t fr = (size_t)d->N * d->C;
-            float* pv = otmp;  // [B][N][C] scratch: the last stage wrote the caller's obj_out, otmp is free
-            if (hipMemcpyAsync(pv, prev_obj, fr * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return VKN_E_LAUNCH;
-            if (d->B > 1 && hipMemcpyAsync(pv + fr, obj_out, (size_t)(d->B - 1) * fr * sizeof(float), hipMemcpyDeviceToDevice, st) !=
-                                hipSuccess)
-                return VKN_E_LAUNCH;
+        if (prev && link_after) {
+            hipStream_t ls = side ? side->st : st;
+            if (side && hipStreamWaitEvent(side->st, side->fork, 0) != hipSuccess) return VKN_E_LAUNCH;
+            // scratch of the link while the main stream is still inside the stage: the cls / mask branches own t1 / t2 / lq / f,
+            // so the link's q / kv projections live in the (finished) self-attention's qkv buffer and its attention output in obj1
+            StageWs sl = s;
+            if (side) {
+                sl.lq = s.qkv;
+                sl.lkv = s.qkv + (size_t)d->B * d->N * d->C;
+                sl.t1 = s.obj1;
+            }
+            const float* pv = prev;
+            if (clip) {
+                // clip mode: prev[0] = the caller's previous-frame kernels, prev[b] = this call's frame b - 1          
+                const size_t fr = (size_t)d->N * d->C;
+                float* pvb = otmp;  // [B][N][C] scratch: the last stage wrote the caller's obj_out and has read its obj_in (otmp)
+                if (hipMemcpyAsync(pvb, prev_obj, fr * sizeof(float), hipMemcpyDeviceToDevice, ls) != hipSuccess) return VKN_E_LAUNCH;
+                if (d->B > 1 &&
+                    hipMemcpyAsync(pvb + fr, obj_out, (size_t)(d->B - 1) * fr * sizeof(float), hipMemcpyDeviceToDevice, ls) != hipSuccess)
+                    return VKN_E_LAUNCH;
+                pv = pvb;
+            }
             PrepW pw{};
             const VknStageWeights* w = &stages[sidx];
             if (w->prepared && !(flags & VKN_FLAG_EXACT_GEMM)) {
@@ -900,11 +970,17 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
                 if (carve_prepared(d, w, static_cast<char*>(const_cast<void*>(w->prepared)), &pw, items, nullptr) > w->prepared_bytes)
                     return VKN_E_WORKSPACE;
             }
-            VKN_TRY(run_link(d, w, pw, obj_out, pv, track_out, s, st));
+            VKN_TRY(run_link(d, w, pw, obj_out, pv, track_out, sl, ls));
+            if (side) {
+                if (hipEventRecord(side->join, side->st) != hipSuccess) return VKN_E_LAUNCH;
+                joined = side;
+            }
         }
     }
     if (scaled_out && upsample_stride > 1)                                                // :122-130
         VKN_TRY(vkn_launch_upsample(mask_preds_out, scaled_out, d->B * d->N, d->H, d->W, upsample_stride, st));
+    // join: everything the call produced (and every use of the workspace) is ordered before later work on the caller's stream
+    if (joined && hipStreamWaitEvent(st, joined->join, 0) != hipSuccess) return VKN_E_LAUNCH;
     return VKN_OK;
 }
 

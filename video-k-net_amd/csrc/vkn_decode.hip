@@ -69,7 +69,11 @@ __device__ __forceinline__ void dec_emit_bits(const f32x16 (&acc)[2][NB], float 
 // planes (the prologue overlaps their latency); 2 = static `s_setprio 1` for the younger half of the workgroup (waves 4-7);
 // 4 = 16-byte stores: adjacent lanes exchange half of their pixel pairs (DPP quad_perm) so that a lane stores 4 consecutive
 // pixels of ONE row — half the store instructions, same 256-byte row segments.
-template <int NB, int ABL, int RING, int BITS, int OPT>
+// XH (x storage): 0 = fp32 (split to f16 hi / lo in registers, 3 MFMAs per operand pair); 1 = fp16, 2 = bf16 (converted to f16:
+// exact for 2^-14 <= |x| < 65504): x IS its own high half, the low half is zero — a lane loads its pixel pair as ONE dword, and the
+// two MFMAs against x_lo disappear.  The remaining sequence (K_hi x, K_lo x per pixel) is the fp32 kernel's with the zero terms
+// removed, so on x' = float(half(x)) both kernels return the same bits.
+template <int NB, int ABL, int RING, int BITS, int OPT, int XH = 0>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     const float* __restrict__ x, const _Float16* __restrict__ kfh, const _Float16* __restrict__ kfl,
     const float* __restrict__ kb, float* __restrict__ out, int N, int NPT, int n0, int C, int P, int px_per_wg,
@@ -131,7 +135,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     // NOTE: hipcc (ROCm 7.2) miscompiles `__builtin_bit_cast(T, vec[i])` on an ext_vector ELEMENT (always yields element 0,
     // tools/scratch/buftest.hip) — elements are copied to scalars first and converted with __uint_as_float / __float_as_uint.
     const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
+        XH ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P), 0,
+                                               C * P * 2, 0x00020000)
+           : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * fs.out, 0, N * P * 4, 0x00020000);
 
     f32x16 acc[2][NB];
@@ -144,9 +150,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
 #define DEC_LOAD(REG)                                                                                            \
     do { /* unconditional: past the end it re-reads the last fragment (keeps vmcnt counting exact) */            \
         const int p0_ = p_begin + (wave + DEC_WAVES * ld_sl) * DEC_TILE;                                         \
-        const int voff_ = (((g << 3) * P + min(2 * li, max(P - 2 - p0_, 0))) << 2);                              \
-        const int soff_ = ((ld_ks << 4) * P + p0_) << 2;                                                         \
-        if (ABL == 2) {                                                                                          \
+        const int voff_ = (((g << 3) * P + min(2 * li, max(P - 2 - p0_, 0))) << (XH ? 1 : 2));                   \
+        const int soff_ = ((ld_ks << 4) * P + p0_) << (XH ? 1 : 2);                                              \
+        if (XH) { /* half storage: the pixel pair is one dword */                                                \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                        \
+                REG[e] = u32x2{__builtin_amdgcn_raw_buffer_load_b32(xrs, voff_, soff_ + ((e * P) << 1), 3), 0u}; \
+        } else if (ABL == 2) {                                                                                          \
             _Pragma("unroll") for (int e = 0; e < 8; ++e) REG[e] = u32x2{(unsigned)(voff_ + e), (unsigned)soff_}; \
         } else {                                                                                                 \
             _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                        \
@@ -178,12 +187,20 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                           \
             _Float16 h_, l_;                                                                                      \
             const unsigned u0_ = REG[e][0], u1_ = REG[e][1];                                                      \
-            vkn_split_f16(__uint_as_float(u0_), h_, l_);                                                                  \
-            bh0[e] = h_;                                                                                          \
-            bl0[e] = l_;                                                                                          \
-            vkn_split_f16(__uint_as_float(u1_), h_, l_);                                                                  \
-            bh1[e] = h_;                                                                                          \
-            bl1[e] = l_;                                                                                          \
+            if (XH == 1) { /* fp16 pair: low half = even pixel */                                                 \
+                bh0[e] = __builtin_bit_cast(_Float16, (unsigned short)(u0_ & 0xFFFFu));                           \
+                bh1[e] = __builtin_bit_cast(_Float16, (unsigned short)(u0_ >> 16));                               \
+            } else if (XH == 2) { /* bf16 pair -> fp32 (exact) -> f16 */                                          \
+                bh0[e] = (_Float16)__uint_as_float(u0_ << 16);                                                    \
+                bh1[e] = (_Float16)__uint_as_float(u0_ & 0xFFFF0000u);                                            \
+            } else {                                                                                              \
+                vkn_split_f16(__uint_as_float(u0_), h_, l_);                                                      \
+                bh0[e] = h_;                                                                                      \
+                bl0[e] = l_;                                                                                      \
+                vkn_split_f16(__uint_as_float(u1_), h_, l_);                                                      \
+                bh1[e] = h_;                                                                                      \
+                bl1[e] = l_;                                                                                      \
+            }                                                                                                     \
         }                                                                                                         \
         const int cb_ = (c_ks << 4) + (g << 3);                                                                   \
         _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                       \
@@ -195,8 +212,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
             } else { /* alternate the two accumulators so dependent MFMAs are never back to back */               \
                 acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, acc[0][nb], 0, 0, 0);                \
                 acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh1, acc[1][nb], 0, 0, 0);                \
-                acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, acc[0][nb], 0, 0, 0);                \
-                acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl1, acc[1][nb], 0, 0, 0);                \
+                if (!XH) {                                                                                        \
+                    acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, acc[0][nb], 0, 0, 0);            \
+                    acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl1, acc[1][nb], 0, 0, 0);            \
+                }                                                                                                 \
                 acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh0, acc[0][nb], 0, 0, 0);                \
                 acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh1, acc[1][nb], 0, 0, 0);                \
             }                                                                                                     \
@@ -366,7 +385,9 @@ __global__ __launch_bounds__(D4_THREADS, 1) void k_decode4(const float* __restri
     const int total = my * KS;
 
     const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
+        XH ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P), 0,
+                                               C * P * 2, 0x00020000)
+           : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * fs.out, 0, N * P * 4, 0x00020000);
 
     // 4-deep fragment ring (3 fragments = 24 KB per wave in flight).  C % 64 == 0 (launcher), so the ring phase is the same at
@@ -529,31 +550,33 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
 
 // host launcher.  kfh/kfl: [B][NPT][C] f16, NPT = roundup(N,32).  Returns VKN_* code.
 int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B,
-                      int N, int C, int P, hipStream_t stream) {
-    return vkn_launch_decode_ex(x, kfh, kfl, kb, out, B, N, C, P, 0, N, stream);
+                      int N, int C, int P, hipStream_t stream, int xdt) {
+    return vkn_launch_decode_ex(x, kfh, kfl, kb, out, B, N, C, P, 0, N, stream, xdt);
 }
 
 // shared != 0: ONE set of kernels / bias for every frame (planes [NPT][C], kb [N]); out_rows: rows per frame of the output
 // tensor the N decoded rows are written into (>= N: the caller points `out` at the first of its rows).
 static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
-                         int C, int P, int shared, int out_rows, unsigned* bits_out, float thr, hipStream_t stream);
+                         int C, int P, int shared, int out_rows, unsigned* bits_out, float thr, hipStream_t stream, int xdt);
 
+// xdt: storage type of x (VKN_X_F32 / VKN_X_F16 / VKN_X_BF16); for the half types `x` points at 2-byte elements
 int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B,
-                         int N, int C, int P, int shared, int out_rows, hipStream_t stream) {
-    return decode_launch(x, kfh, kfl, kb, out, B, N, C, P, shared, out_rows, nullptr, 0.f, stream);
+                         int N, int C, int P, int shared, int out_rows, hipStream_t stream, int xdt) {
+    return decode_launch(x, kfh, kfl, kb, out, B, N, C, P, shared, out_rows, nullptr, 0.f, stream, xdt);
 }
 
 // bit-packed variant: words [B][P/64][2][roundup(N,32)] (even / odd pixels of each 64-px tile) of bit(logit >= thr)
 // instead of the logits (P % 64 == 0)
 int vkn_launch_decode_bits(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, unsigned* bits_out,
-                           float thr, int B, int N, int C, int P, hipStream_t stream) {
+                           float thr, int B, int N, int C, int P, hipStream_t stream, int xdt) {
     if (!bits_out || (P % 64) != 0) return VKN_E_SHAPE;
-    return decode_launch(x, kfh, kfl, kb, nullptr, B, N, C, P, 0, N, bits_out, thr, stream);
+    return decode_launch(x, kfh, kfl, kb, nullptr, B, N, C, P, 0, N, bits_out, thr, stream, xdt);
 }
 
 static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
-                         int C, int P, int shared, int out_rows, unsigned* bits_out, float thr, hipStream_t stream) {
+                         int C, int P, int shared, int out_rows, unsigned* bits_out, float thr, hipStream_t stream, int xdt) {
     if (B <= 0 || N <= 0 || P <= 0 || out_rows < N) return VKN_E_ARG;
+    if (xdt < 0 || xdt > 2) return VKN_E_ARG;
     if (C % 16 != 0 || C > 512 || P < 2 || (P & 1)) return VKN_E_SHAPE;  // odd P: rows not 8-byte aligned (use the ref kernel)
     if ((size_t)C * P * 4 >= ((size_t)1 << 31) || (size_t)N * P * 4 >= ((size_t)1 << 31)) return VKN_E_SHAPE;  // 32-bit buffer offsets
     const int NPT = (N + 31) / 32 * 32;
@@ -572,7 +595,7 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
     const int xcd = vkn_dbg_env("VKN_DECODE_XCD", 1);  // measured +1 % (tools/decode_sweep.py)
     // (debug build) 16-byte variant k_decode4: whole 128-px tiles and 16-byte aligned rows; the logits output only
 #ifdef VKN_DEBUG
-    const bool wide = !bits_out && (P % D4_TILE) == 0 && (C % 64) == 0 && vkn_dbg_env("VKN_DECODE4", 0) != 0 &&
+    const bool wide = xdt == 0 && !bits_out && (P % D4_TILE) == 0 && (C % 64) == 0 && vkn_dbg_env("VKN_DECODE4", 0) != 0 &&
                       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
 #endif
     for (int n0 = 0; n0 < NPT; n0 += 128) {
@@ -601,11 +624,19 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
         }
 #endif
         dim3 block(DEC_THREADS);
+#define DEC_LAUNCH_X(NBV, ABLV, RINGV, BITSV, OPTV, XHV)                                                       \
+    do {                                                                                                       \
+        VKN_ALLOW_FULL_LDS((k_decode_mfma<NBV, ABLV, RINGV, BITSV, OPTV, XHV>));                               \
+        hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV, RINGV, BITSV, OPTV, XHV>), grid, block, lds, stream, x, kfh, kfl, kb, out, \
+                           N, NPT, n0, C, P, px_per_wg, xcd, fs, bits_out, thr);                               \
+    } while (0)
+    // half-storage x: the shipped variant only (no ablations, ring 3, default OPT)
 #define DEC_LAUNCH_O(NBV, ABLV, RINGV, BITSV, OPTV)                                                            \
     do {                                                                                                       \
-        VKN_ALLOW_FULL_LDS((k_decode_mfma<NBV, ABLV, RINGV, BITSV, OPTV>));                                    \
-        hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV, RINGV, BITSV, OPTV>), grid, block, lds, stream, x, kfh, kfl, kb, out, N, \
-                           NPT, n0, C, P, px_per_wg, xcd, fs, bits_out, thr);                                  \
+        if (xdt == 0) DEC_LAUNCH_X(NBV, ABLV, RINGV, BITSV, OPTV, 0);                                          \
+        else if (ABLV != 0 || RINGV != 3 || OPTV != DEC_OPT_DEFAULT) return VKN_E_ARG;                         \
+        else if (xdt == 1) DEC_LAUNCH_X(NBV, 0, 3, BITSV, DEC_OPT_DEFAULT, 1);                                 \
+        else DEC_LAUNCH_X(NBV, 0, 3, BITSV, DEC_OPT_DEFAULT, 2);                                               \
     } while (0)
 #ifdef VKN_DEBUG
         const int opt = vkn_dbg_env("VKN_DECODE_OPT", DEC_OPT_DEFAULT);
@@ -660,6 +691,7 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
 #undef DEC_CASE
 #undef DEC_LAUNCH
 #undef DEC_LAUNCH_O
+#undef DEC_LAUNCH_X
         VKN_CHECK_LAUNCH();
     }
     return VKN_OK;

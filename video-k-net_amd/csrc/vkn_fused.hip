@@ -496,7 +496,10 @@ __global__ __launch_bounds__(FU8_THREADS, 2) void k_fused_dg8(const float* __res
 #define FS_THREADS 512
 #define FS_TILE 32
 
-template <int NB, int C>
+// XH (x storage): 0 = fp32; 1 = fp16, 2 = bf16 (converted to f16): the loader's pixel pair is one dword, only the hi plane of the
+// tile image is written / read and every MFMA against x_lo disappears (decode 3 -> 2, gather 2 -> 1 per operand pair).  On
+// x' = float(half(x)) the fp32 kernel returns the same bits.
+template <int NB, int C, int XH = 0>
 __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_dgs(const float* __restrict__ x, const _Float16* __restrict__ kfh,
                                                               const _Float16* __restrict__ kfl, const float* __restrict__ kb,
                                                               float thr, float* __restrict__ part, float* __restrict__ cntp,
@@ -540,17 +543,23 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_dgs(const float* __rest
     }
 
     const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
+        XH ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P), 0,
+                                               C * P * 2, 0x00020000)
+           : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
     // loader: lane (q, lp) = (lane >> 4, lane & 15): channels 4 q + e (e = 0..3) of the 16-channel fragment, pixels 2 lp, 2 lp + 1
     const int lq = lane >> 4, lp = lane & 15;
-    const int voff = (((lq << 2) * P + 2 * lp) << 2);
+    constexpr int XSH = XH ? 1 : 2;  // log2(bytes per stored element)
+    const int voff = (((lq << 2) * P + 2 * lp) << XSH);
     fu_u32x2 raw[NF][4];
     auto issue = [&](int t, int f) {
         const int ks = wave + 8 * f;
         if (ALLF || ks < KS) {
-            const int soff = ((ks << 4) * P + tile_p0(t)) << 2;
+            const int soff = ((ks << 4) * P + tile_p0(t)) << XSH;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) raw[f][e] = __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, soff + ((e * P) << 2), 3);
+            for (int e = 0; e < 4; ++e) {
+                if (XH) raw[f][e] = fu_u32x2{__builtin_amdgcn_raw_buffer_load_b32(xrs, voff, soff + ((e * P) << 1), 3), 0u};
+                else raw[f][e] = __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, soff + ((e * P) << 2), 3);
+            }
         }
     };
     auto commit = [&](int buf, int f) {  // rows lp (pixel 2 lp) and 16 + lp (pixel 2 lp + 1), columns 16 ks + 4 q .. + 4
@@ -561,18 +570,28 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_dgs(const float* __rest
             for (int e = 0; e < 4; ++e) {
                 const unsigned u0 = raw[f][e][0], u1 = raw[f][e][1];
                 _Float16 h, l;
-                vkn_split_f16(__uint_as_float(u0), h, l);
-                h0[e] = h;
-                l0[e] = l;
-                vkn_split_f16(__uint_as_float(u1), h, l);
-                h1[e] = h;
-                l1[e] = l;
+                if (XH == 1) {  // fp16 pair: low half = even pixel
+                    h0[e] = __builtin_bit_cast(_Float16, (unsigned short)(u0 & 0xFFFFu));
+                    h1[e] = __builtin_bit_cast(_Float16, (unsigned short)(u0 >> 16));
+                } else if (XH == 2) {  // bf16 pair -> fp32 (exact) -> f16
+                    h0[e] = (_Float16)__uint_as_float(u0 << 16);
+                    h1[e] = (_Float16)__uint_as_float(u0 & 0xFFFF0000u);
+                } else {
+                    vkn_split_f16(__uint_as_float(u0), h, l);
+                    h0[e] = h;
+                    l0[e] = l;
+                    vkn_split_f16(__uint_as_float(u1), h, l);
+                    h1[e] = h;
+                    l1[e] = l;
+                }
             }
             _Float16* dh = dimg + (size_t)buf * IMG + lp * LDK + (ks << 4) + (lq << 2);
             *reinterpret_cast<half4*>(dh) = h0;
-            *reinterpret_cast<half4*>(dh + PLANE) = l0;
             *reinterpret_cast<half4*>(dh + 16 * LDK) = h1;
-            *reinterpret_cast<half4*>(dh + 16 * LDK + PLANE) = l1;
+            if (!XH) {
+                *reinterpret_cast<half4*>(dh + PLANE) = l0;
+                *reinterpret_cast<half4*>(dh + 16 * LDK + PLANE) = l1;
+            }
         }
     };
 
@@ -618,9 +637,11 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_dgs(const float* __rest
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const half8 bh = *reinterpret_cast<const half8*>(bp + (ks << 4));
-                    const half8 bl = *reinterpret_cast<const half8*>(bp + (ks << 4) + PLANE);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], bl, acc, 0, 0, 0);
+                    if (!XH) {
+                        const half8 bl = *reinterpret_cast<const half8*>(bp + (ks << 4) + PLANE);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], bl, acc, 0, 0, 0);
+                    }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[ks], bh, acc, 0, 0, 0);
                 }
                 int wd = 0;
@@ -688,12 +709,12 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_dgs(const float* __rest
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 bh[e] = cp[((e >> 1) + 16 * (e & 1)) * LDK];
-                                bl[e] = cp[((e >> 1) + 16 * (e & 1)) * LDK + PLANE];
+                                if (!XH) bl[e] = cp[((e >> 1) + 16 * (e & 1)) * LDK + PLANE];
                             }
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb) {
                                 accg[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb], bh, accg[j][nb], 0, 0, 0);
-                                accg[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb], bl, accg[j][nb], 0, 0, 0);
+                                if (!XH) accg[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb], bl, accg[j][nb], 0, 0, 0);
                             }
                         }
                     }
@@ -741,8 +762,8 @@ int vkn_fused_supported(int C, int P) {
 // cnt [B][N]; part / cntp: the gather's workspace ([B][G][NPT][C], [B][G][NPT], G = vkn_gather_groups(B, P)).
 int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float thr,
                                    float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C, int P,
-                                   hipStream_t stream) {
-    if (B <= 0 || N <= 0 || P <= 0) return VKN_E_ARG;
+                                   hipStream_t stream, int xdt) {
+    if (B <= 0 || N <= 0 || P <= 0 || xdt < 0 || xdt > 2) return VKN_E_ARG;
     if (!vkn_fused_supported(C, P)) return VKN_E_SHAPE;
     const int NPT = (N + 31) / 32 * 32;
     const int G = vkn_gather_groups(B, P);
@@ -756,16 +777,22 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
     for (int n0 = 0; n0 < NPT; n0 += 128) {
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
         dim3 grid(G, B, 1);
-#define FU_LAUNCH_S(NBV, CV)                                                                                               \
-    do {                                                                                                                   \
-        VKN_ALLOW_FULL_LDS((k_fused_dgs<NBV, CV>));                                                                        \
-        hipLaunchKernelGGL((k_fused_dgs<NBV, CV>), grid, dim3(FS_THREADS), lds, stream, x, kfh, kfl, kb, thr, part, cntp,  \
-                           N, NPT, n0, P);                                                                                 \
+#define FU_LAUNCH_X(NBV, CV, XHV)                                                                                              \
+    do {                                                                                                                       \
+        VKN_ALLOW_FULL_LDS((k_fused_dgs<NBV, CV, XHV>));                                                                       \
+        hipLaunchKernelGGL((k_fused_dgs<NBV, CV, XHV>), grid, dim3(FS_THREADS), lds, stream, x, kfh, kfl, kb, thr, part, cntp, \
+                           N, NPT, n0, P);                                                                                     \
+    } while (0)
+#define FU_LAUNCH_S(NBV, CV)                        \
+    do {                                            \
+        if (xdt == 1) FU_LAUNCH_X(NBV, CV, 1);      \
+        else if (xdt == 2) FU_LAUNCH_X(NBV, CV, 2); \
+        else FU_LAUNCH_X(NBV, CV, 0);               \
     } while (0)
 #ifdef VKN_DEBUG
 #define FU_LAUNCH(NBV, CV)                                                                                                     \
     do {                                                                                                                       \
-        if (variant == 2) FU_LAUNCH_S(NBV, CV);                                                                                \
+        if (variant == 2 || xdt != 0) FU_LAUNCH_S(NBV, CV);                                                                    \
         else if (eight) {                                                                                                      \
             VKN_ALLOW_FULL_LDS((k_fused_dg8<NBV, CV>));                                                                        \
             hipLaunchKernelGGL((k_fused_dg8<NBV, CV>), grid, dim3(FU8_THREADS), lds, stream, x, kfh, kfl, kb, thr, part, cntp, \
@@ -796,6 +823,7 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
 #undef FU_CASE
 #undef FU_LAUNCH
 #undef FU_LAUNCH_S
+#undef FU_LAUNCH_X
         VKN_CHECK_LAUNCH();
     }
     return vkn_launch_gather_reduce(part, cntp, xraw, cnt, B, N, C, G, stream);  // the unfused path's fixed-order second pass

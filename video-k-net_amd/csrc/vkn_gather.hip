@@ -28,7 +28,10 @@
 // BITS == 1: `masks` are the bit words [B][P/64][2][NPT] (even / odd pixels of each 64-px tile) written by the decode kernel's
 // bit-packed epilogue (fused head, stages > 0) instead of logits; fragments of the binary operand come from a 256-entry
 // (even nibble, odd nibble) -> half8 table in LDS.
-template <int NB, int BITS>
+// XH (x storage, BITS 0 / 1 only): 0 = fp32; 1 = fp16, 2 = bf16 (converted to f16) — x is its own high half: a 16-byte chunk holds
+// 8 pixels (two chunks per thread and tile instead of four), only the hi image is written and the MFMA against x_lo disappears.
+// Needs P % 64 == 0 (whole, 16-byte aligned tiles).  On x' = float(half(x)) the fp32 kernel returns the same bits.
+template <int NB, int BITS, int XH = 0>
 __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __restrict__ x,
                                                                const float* __restrict__ masks, float thr,
                                                                float* __restrict__ part, float* __restrict__ cntp, int N,
@@ -37,6 +40,8 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // per buffer: xh [C][40], xl [C][40], mk [NB*32][40] (+ ml [NB*32][40]: low half of a REAL mask operand, BITS == 2)
     constexpr bool REAL = (BITS == 2 || BITS == 3);  // 3: real operand = bit(z) * sigmoid(z), activated on the fly
+    static_assert(!(XH && REAL), "half-storage x: binary operands only");
+    constexpr int XCH = XH ? 2 : 4;  // 16-byte x chunks per thread and tile (C = 256)
     const int rows_buf = 2 * C + (REAL ? 2 : 1) * NB * 32;
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
 
@@ -56,6 +61,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     auto tile_p0 = [&](int t) { return ileave ? ((((t >> 1) * G + gidx) << 6) + ((t & 1) << 5)) : p_begin + t * GA_PT; };
 
     const float* xb = x + (size_t)b * C * P;
+    const unsigned short* xb16 = reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P;  // XH
     const float* mb = masks + (size_t)b * mask_fs;  // mask_fs = rows per frame of the logits tensor * P (>= N * P)
     const unsigned* wb = reinterpret_cast<const unsigned*>(masks) + (size_t)b * (P >> 5) * NPT + n0;  // BITS: words of this frame / n-chunk
     const bool vec_ok = ((P & 3) == 0);
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
         }
     }
 
-    const int nxch = C * 8;        // 16-B chunks in an x tile
+    const int nxch = XH ? C * 4 : C * 8;  // 16-B chunks in an x tile
     const int nmch = NB * 32 * 8;  // 16-B chunks in a mask tile
     f32x4 xrA[4], xrB[4];  // two register sets: tile t+2 is being loaded while tile t+1 waits to be committed
     f32x4 mrA[2], mrB[2];
@@ -84,10 +90,13 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
     auto issue = [&](int t, f32x4 (&xr)[4], f32x4 (&mr)[2]) {
         const int p0 = tile_p0(t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < XCH; ++i) {
             const int idc = min(tid + i * GA_THREADS, nxch - 1);
             // non-temporal: x is streamed once per launch (same +9 % as in the decode kernel)
-            xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2)));
+            if (XH)
+                xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb16 + (size_t)(idc >> 2) * P + p0 + ((idc & 3) << 3)));
+            else
+                xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2)));
         }
         if (BITS == 1) {  // even- and odd-pixel word of this row for the 64-px tile holding p0 (clamped: every thread loads)
             const unsigned* wp = wb + (size_t)((p0 >> 6) << 1) * NPT + min(tid, NB * 32 - 1);
@@ -141,6 +150,26 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
         _Float16* xh = lds + (size_t)buf * rows_buf * GA_LDR;
         _Float16* xl = xh + C * GA_LDR;
         _Float16* mk = xl + C * GA_LDR;
+        if (XH) {
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                const int idx = tid + i * GA_THREADS;
+                if (idx < nxch) {
+                    f32x4 v = xr[i];
+                    if (XH == 2) {  // 8 bf16 -> 8 f16 (through fp32: exact for normal f16 range)
+                        half8 h;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned u = __float_as_uint(xr[i][k]);
+                            h[2 * k] = (_Float16)__uint_as_float(u << 16);
+                            h[2 * k + 1] = (_Float16)__uint_as_float(u & 0xFFFF0000u);
+                        }
+                        v = __builtin_bit_cast(f32x4, h);
+                    }
+                    *reinterpret_cast<f32x4*>(xh + (idx >> 2) * GA_LDR + ((idx & 3) << 3)) = v;
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + i * GA_THREADS;
@@ -229,7 +258,7 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                         a = *reinterpret_cast<const half8*>(mk + (nb * 32 + li) * GA_LDR + off);
                     }
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
+                    if (!XH) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
                     if (REAL) {  // a = a_hi here: + a_lo * x_hi (a_lo * x_lo is below fp32 resolution)
                         const half8 al = *reinterpret_cast<const half8*>(mk + (NB * 32 + nb * 32 + li) * GA_LDR + off);
                         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[nb], 0, 0, 0);
@@ -536,17 +565,17 @@ int vkn_gather_groups(int B, int P) {
 
 // part: [B][G][NPT][C] f32, cntp: [B][G][NPT] f32 (workspace); xraw [B][N][C], cnt [B][N] outputs.
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                      int B, int N, int C, int P, hipStream_t stream) {
-    return vkn_launch_gather_ex(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, N, stream);
+                      int B, int N, int C, int P, hipStream_t stream, int xdt) {
+    return vkn_launch_gather_ex(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, N, stream, xdt);
 }
 
 // mask_rows: rows per frame of the logits tensor the N gathered rows live in (>= N; `masks` points at the first of them)
 static int gather_launch(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
-                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream);
+                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt = 0);
 
 int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                         int B, int N, int C, int P, int mask_rows, hipStream_t stream) {
-    return gather_launch(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 0, stream);
+                         int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt) {
+    return gather_launch(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 0, stream, xdt);
 }
 
 // REAL-valued left operand a [B][mask_rows][P] (first N rows used): xraw = sum_p a x, cnt = sum_p a
@@ -563,14 +592,16 @@ int vkn_launch_gather_soft(const float* x, const float* masks, float thr, float*
 
 // binary operand given as bit words [B][P/64][2][roundup(N,32)] (vkn_launch_decode_bits); P % 64 == 0
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
-                           int C, int P, hipStream_t stream) {
+                           int C, int P, hipStream_t stream, int xdt) {
     if ((P % 64) != 0) return VKN_E_SHAPE;
-    return gather_launch(x, reinterpret_cast<const float*>(bits), 0.f, xraw, cnt, part, cntp, B, N, C, P, N, 1, stream);
+    return gather_launch(x, reinterpret_cast<const float*>(bits), 0.f, xraw, cnt, part, cntp, B, N, C, P, N, 1, stream, xdt);
 }
 
 static int gather_launch(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
-                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream) {
+                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt) {
     if (B <= 0 || N <= 0 || P <= 0 || mask_rows < N) return VKN_E_ARG;
+    if (xdt < 0 || xdt > 2) return VKN_E_ARG;
+    if (xdt && (bits >= 2 || (P % 64) != 0)) return VKN_E_SHAPE;  // half-storage x: binary operands, whole 16-byte aligned tiles
     const long long mask_fs = (long long)mask_rows * P;
     if (C % 32 != 0 || C > 256) return VKN_E_SHAPE;
     const int NPT = (N + 31) / 32 * 32;
@@ -580,7 +611,7 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
     px_per_wg = (px_per_wg + GA_PT - 1) / GA_PT * GA_PT;
     const int G = (P + px_per_wg - 1) / px_per_wg;
     const int ileave = ((P % 64) == 0 && vkn_dbg_env("VKN_GATHER_ILEAVE", 1) != 0) ? 1 : 0;
-    const bool wave_indep = bits == 1 && vkn_dbg_env("VKN_GATHER_BITS_W", 1) != 0 && (C % 32) == 0 &&
+    const bool wave_indep = bits == 1 && xdt == 0 && vkn_dbg_env("VKN_GATHER_BITS_W", 1) != 0 && (C % 32) == 0 &&
                             (px_per_wg % 64) == 0;
     for (int n0 = 0; n0 < NPT; n0 += 128) {
         const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
@@ -606,18 +637,22 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
             continue;
         }
         const size_t lds = (size_t)2 * (2 * C + (bits >= 2 ? 2 : 1) * nb * 32) * GA_LDR * sizeof(_Float16) + (bits == 1 ? 4096 : 0);
-#define GA_LAUNCH(NBV, BV)                                                                                       \
+#define GA_LAUNCH(NBV, BV, XHV)                                                                                  \
     do {                                                                                                         \
-        VKN_ALLOW_FULL_LDS((k_gather_mfma<NBV, BV>));                                                            \
-        hipLaunchKernelGGL((k_gather_mfma<NBV, BV>), grid, block, lds, stream, x, masks, thr, part, cntp, N, NPT, n0, C, P, \
+        VKN_ALLOW_FULL_LDS((k_gather_mfma<NBV, BV, XHV>));                                                       \
+        hipLaunchKernelGGL((k_gather_mfma<NBV, BV, XHV>), grid, block, lds, stream, x, masks, thr, part, cntp, N, NPT, n0, C, P, \
                            px_per_wg, mask_fs, ileave);                                                          \
     } while (0)
-#define GA_CASE(NBV)                       \
-    case NBV:                              \
-        if (bits == 3) GA_LAUNCH(NBV, 3);  \
-        else if (bits == 2) GA_LAUNCH(NBV, 2);  \
-        else if (bits) GA_LAUNCH(NBV, 1);  \
-        else GA_LAUNCH(NBV, 0);            \
+#define GA_CASE(NBV)                                 \
+    case NBV:                                        \
+        if (bits == 3) GA_LAUNCH(NBV, 3, 0);         \
+        else if (bits == 2) GA_LAUNCH(NBV, 2, 0);    \
+        else if (bits && xdt == 1) GA_LAUNCH(NBV, 1, 1); \
+        else if (bits && xdt == 2) GA_LAUNCH(NBV, 1, 2); \
+        else if (bits) GA_LAUNCH(NBV, 1, 0);         \
+        else if (xdt == 1) GA_LAUNCH(NBV, 0, 1);     \
+        else if (xdt == 2) GA_LAUNCH(NBV, 0, 2);     \
+        else GA_LAUNCH(NBV, 0, 0);                   \
         break;
         switch (nb) {
             GA_CASE(1)

@@ -41,7 +41,7 @@ struct VknGemmProb {
 
 int vkn_gather_groups(int B, int P);
 int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                         int B, int N, int C, int P, int mask_rows, hipStream_t stream);
+                         int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt = 0);
 int vkn_launch_gather_ref_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                              int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C,
@@ -49,16 +49,16 @@ int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* c
 int vkn_launch_gather_soft(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
                            int N, int C, int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
-                           int C, int P, hipStream_t stream);
+                           int C, int P, hipStream_t stream, int xdt = 0);
 int vkn_launch_gather_reduce(const float* part, const float* cntp, float* xraw, float* cnt, int B, int N, int C, int G,
                              hipStream_t stream);
 // stage s decode fused with the stage s + 1 gather (vkn_fused.hip)
 int vkn_fused_supported(int C, int P);
 int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float thr,
                                    float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C, int P,
-                                   hipStream_t stream);
+                                   hipStream_t stream, int xdt = 0);
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                      int B, int N, int C, int P, hipStream_t stream);
+                      int B, int N, int C, int P, hipStream_t stream, int xdt = 0);
 int vkn_launch_gather_ref(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                           int P, hipStream_t stream);
 // per-frame element strides of the decode operands (shared kernels: 0)
@@ -67,14 +67,16 @@ struct VknDecodeStrides {
     long long kb;     // bias elements per frame
     long long out;    // output elements per frame
 };
+// xdt (last argument of the x-streaming launchers): storage type of x — 0 fp32, 1 fp16, 2 bf16 (VKN_X_* in include/vkn.h); for the
+// half types `x` points at 2-byte elements
 int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
-                         int C, int P, int shared, int out_rows, hipStream_t stream);
+                         int C, int P, int shared, int out_rows, hipStream_t stream, int xdt = 0);
 int vkn_launch_decode_ref_ex(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
                              int shared, int out_rows, hipStream_t stream);
 int vkn_launch_decode_bits(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, unsigned* bits_out,
-                           float thr, int B, int N, int C, int P, hipStream_t stream);
+                           float thr, int B, int N, int C, int P, hipStream_t stream, int xdt = 0);
 int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
-                      int C, int P, hipStream_t stream);
+                      int C, int P, hipStream_t stream, int xdt = 0);
 int vkn_launch_decode_ref(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
                           hipStream_t stream);
 int vkn_launch_split_planes(const float* kern, _Float16* kfh, _Float16* kfl, int B, int N, int C, hipStream_t stream);

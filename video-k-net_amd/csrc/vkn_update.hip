@@ -393,6 +393,12 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool active = (n0 + wave * 32) < Nout;
 
+    // per-lane column constants of the row epilogue (bias / LayerNorm weights / dot vector): requested BEFORE the K loop, so their
+    // L2 round trips ride under it instead of sitting between the last MFMA and the first output row
+    const int ncols = min(GM_BN, Nout - n0);
+    VknEpiCols cols;
+    vkn_epi_load_cols(epi, ncols, n0, lane, cols);
+
     // Three weight buffers: while tile i is multiplied, tiles i+1 AND i+2 are in flight (96 KB per CU).  The K loop of these small-M
     // GEMMs is bound by the latency of one weight tile (L2 / MALL, 1.5 - 2 us) — with one tile in flight a K-tile cost that latency;
     // two in flight halve it.  The DMA -> LDS dependency is invisible to the compiler, so the waits are explicit: vmcnt counts in
@@ -451,9 +457,6 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
 #pragma unroll
     for (int r = 0; r < 16; ++r) T[vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li] = active ? acc[r] : 0.f;
     __syncthreads();
-    const int ncols = min(GM_BN, Nout - n0);
-    VknEpiCols cols;
-    vkn_epi_load_cols(epi, ncols, n0, lane, cols);
 #pragma unroll
     for (int i = 0; i < GM_BM / 8; ++i) {
         const int rl = wave * (GM_BM / 8) + i, row = m0 + rl;

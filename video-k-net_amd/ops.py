@@ -15,6 +15,9 @@ from ._lib import VknDims, VknStageWeights, check
 
 FLAG_REF_KERNELS = 1
 FLAG_EXACT_GEMM = 2
+FLAG_LOGITS_HANDOFF = 4
+FLAG_BITS_HANDOFF = 16
+FLAG_SERIAL_LINK = 32   # tracking link on the caller's stream instead of the library's side stream (A/B; same results)
 
 _tls = threading.local()
 
@@ -36,6 +39,22 @@ def _req(t, name):
     if t.data_ptr() % 16:
         t = t.clone(memory_format=torch.contiguous_format)
     return t
+
+
+_X_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+FLAG_X_F16, FLAG_X_BF16 = 64, 128
+
+
+def _req_x(t, name='x'):
+    """The feature map: fp32, or fp16 / bf16 STORAGE (VKN_X_*; the head still computes in fp32).  Returns (tensor, x_dtype code)."""
+    if not torch.is_tensor(t) or not t.is_cuda:
+        raise _lib.VknLibraryError(f'{name}: expected a CUDA/HIP tensor — the MI355X path has no CPU fallback')
+    if t.dtype not in _X_DTYPES:
+        raise TypeError(f'{name}: expected float32, float16 or bfloat16, got {t.dtype}')
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t, _X_DTYPES[t.dtype]
 
 
 def _workspace(nbytes, device):
@@ -94,7 +113,8 @@ def thr_logit(hard_mask_thr=0.5):
 def mask_gather(x, mask_logits, hard_mask_thr=0.5, flags=0):
     """(xraw [B,N,C], cnt [B,N]) = sum_p bit(mask)[b,n,p] * x[b,c,p] and the ON-pixel count.
     Replaces `einsum('bnhw,bchw->bnc', (mask.sigmoid() > thr).float(), x)` (knet/det/kernel_update_head.py:190-195)."""
-    x, m = _req(x, 'x'), _req(mask_logits, 'mask_logits')
+    (x, xdt), m = _req_x(x), _req(mask_logits, 'mask_logits')
+    flags |= (0, FLAG_X_F16, FLAG_X_BF16)[xdt]
     B, C = x.shape[0], x.shape[1]
     N = m.shape[1]
     P = x[0, 0].numel()
@@ -132,7 +152,8 @@ def mask_gather_real(x, a):
 def mask_decode(x, kernels, bias=None, flags=0):
     """out[b,n,h,w] = sum_c kernels[b,n,c] x[b,c,h,w] (+ bias[b,n]).
     Replaces the per-image `F.conv2d(x[i:i+1], mask_feat[i])`, K=1 (knet/det/kernel_update_head.py:247-260)."""
-    x, k = _req(x, 'x'), _req(kernels.reshape(kernels.shape[0], kernels.shape[1], -1), 'kernels')
+    (x, xdt), k = _req_x(x), _req(kernels.reshape(kernels.shape[0], kernels.shape[1], -1), 'kernels')
+    flags |= (0, FLAG_X_F16, FLAG_X_BF16)[xdt]
     B, C, H, W = x.shape
     N = k.shape[1]
     if k.shape[0] != B or k.shape[2] != C:
@@ -310,7 +331,8 @@ def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=N
                  want_scaled=True, flags=0, clip_first_prev=None, decode_events=None):
     """The S-stage loop in one C call.  Returns (obj [B,N,C], cls_prob [B,N,ncls], mask_preds [B,N,H,W],
     scaled_mask_preds [B,N,H*s,W*s] | None, track [B,N,C] | None)."""
-    x, pf, mp = _req(x, 'x'), _req(proposal_feats, 'proposal_feats'), _req(mask_preds, 'mask_preds')
+    (x, xdt), pf, mp = _req_x(x), _req(proposal_feats, 'proposal_feats'), _req(mask_preds, 'mask_preds')
+    flags |= (0, FLAG_X_F16, FLAG_X_BF16)[xdt]
     B, N, C, H, W = dims.B, dims.N, dims.C, dims.H, dims.W
     dev = x.device
     L = _lib.lib()
@@ -368,20 +390,20 @@ def split_planes(kernels):
 
 def mask_decode_planes(x, hi, lo, N, bias=None, out=None):
     """The MFMA decode kernel alone on pre-split kernel planes (what runs inside a stage); `out` may be preallocated."""
-    x = _req(x, 'x')
+    x, xdt = _req_x(x)
     B, C, H, W = x.shape
     if out is None:
         out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(_lib.lib().vkn_mask_decode_planes_f32(_ptr(x), _ptr(hi), _ptr(lo), _ptr(bias), _ptr(out), B, N, C, H * W,
-                                                    _stream()))
+        check(_lib.lib().vkn_mask_decode_planes_x(_ptr(x), xdt, _ptr(hi), _ptr(lo), _ptr(bias), _ptr(out), B, N, C, H * W,
+                                                  _stream()))
     return out
 
 
 def decode_gather(x, hi, lo, N, bias=None, hard_mask_thr=0.5):
     """Stage s decode fused with the stage s + 1 gather, one pass over x: (xraw [B,N,C], cnt [B,N]) of the masks
     `bias + K.x >= thr` without materialising them (bit-identical to mask_decode_planes + mask_gather)."""
-    x = _req(x, 'x')
+    x, xdt = _req_x(x)
     B, C, H, W = x.shape
     P = H * W
     L = _lib.lib()
@@ -389,8 +411,8 @@ def decode_gather(x, hi, lo, N, bias=None, hard_mask_thr=0.5):
     cnt = torch.empty((B, N), dtype=torch.float32, device=x.device)
     ws = _workspace(L.vkn_gather_workspace_bytes(B, N, C, P), x.device)
     with torch.cuda.device(x.device):
-        check(L.vkn_decode_gather_f32(_ptr(x), _ptr(hi), _ptr(lo), _ptr(bias), thr_logit(hard_mask_thr), _ptr(xraw), _ptr(cnt),
-                                      B, N, C, P, _ptr(ws), ws.numel(), _stream()))
+        check(L.vkn_decode_gather_x(_ptr(x), xdt, _ptr(hi), _ptr(lo), _ptr(bias), thr_logit(hard_mask_thr), _ptr(xraw), _ptr(cnt),
+                                    B, N, C, P, _ptr(ws), ws.numel(), _stream()))
     return xraw, cnt
 
 
