@@ -114,6 +114,13 @@ def main():
             print(f'bench step, link on the caller stream (flag 32) B={B}: {t:8.1f} us  {B / t * 1e6:9.1f} frames/s', flush=True)
             t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
             print(f'bench step without x4 upsample B={B}: {t:8.1f} us  {B / t * 1e6:9.1f} frames/s', flush=True)
+        if 'gemmabl' in what and not args.release:
+            fp = torch.zeros(1, N, C, device=dev)
+            for abl, nm in ((0, 'real'), (1, 'no K loop'), (2, 'no row epilogue'), (0, 'real')):
+                os.environ['VKN_GEMM_ABL'] = str(abl)
+                t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
+                print(f'head without upsample B={B}, k_gemm_s3 ablation {abl} ({nm}): {t:8.1f} us  (24 k_gemm_s3 launches per step)', flush=True)
+            os.environ.pop('VKN_GEMM_ABL')
         if 'upsample' in what:
             m = torch.randn(B, N, H, W, device=dev)
             t = timeit(lambda: vkn.ops.upsample_bilinear(m, 4), reps=10, warm=3)

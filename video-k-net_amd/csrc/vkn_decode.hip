@@ -385,9 +385,7 @@ __global__ __launch_bounds__(D4_THREADS, 1) void k_decode4(const float* __restri
     const int total = my * KS;
 
     const __amdgpu_buffer_rsrc_t xrs =
-        XH ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P), 0,
-                                               C * P * 2, 0x00020000)
-           : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * fs.out, 0, N * P * 4, 0x00020000);
 
     // 4-deep fragment ring (3 fragments = 24 KB per wave in flight).  C % 64 == 0 (launcher), so the ring phase is the same at

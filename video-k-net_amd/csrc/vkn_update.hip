@@ -287,6 +287,8 @@ __global__ __launch_bounds__(256) void k_split_w3(const float* __restrict__ W, _
 // Up to two independent problems (same M, K) run as ONE launch, selected by blockIdx.z when ksplit == 1: pairing independent
 // layers (dynamic/input layer, the two gates, the cls/mask branches) removes whole launch + prologue + epilogue latencies
 // from the critical path of the chain.
+// ABL (debug build, VKN_GEMM_ABL; WRONG results by construction, time attribution only): 1 = no K loop, 2 = no row epilogue
+template <int ABL>
 __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmProb p1, int nprob, int M, int K,
                                                            float* __restrict__ partial) {
     const bool second = (nprob > 1) && (blockIdx.z == 1);
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
     // GEMMs is bound by the latency of one weight tile (L2 / MALL, 1.5 - 2 us) — with one tile in flight a K-tile cost that latency;
     // two in flight halve it.  The DMA -> LDS dependency is invisible to the compiler, so the waits are explicit: vmcnt counts in
     // order, the 12 DMA instructions of tile i+2 are the youngest, vmcnt(12) = "tile i+1 has landed".
-    const int nkt = kt_end - kt_begin;
+    const int nkt = (ABL == 1) ? 0 : kt_end - kt_begin;
     if (nkt > 0) {
         if (a_role) {
             GS_AFETCH(kt_begin);
@@ -457,6 +459,10 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
 #pragma unroll
     for (int r = 0; r < 16; ++r) T[vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li] = active ? acc[r] : 0.f;
     __syncthreads();
+    if (ABL == 2) {
+        if (T[tid] == 12345.678f) partial[0] = cols.bias[0];  // keep the loads alive
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < GM_BM / 8; ++i) {
         const int rl = wave * (GM_BM / 8) + i, row = m0 + rl;
@@ -890,12 +896,23 @@ int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int
     }
     if (split) {
         const size_t lds = (size_t)(3 * GS_WTILE + 2 * GS_ATILE) * sizeof(__bf16);  // 162,816 B of the 163,840
-        VKN_ALLOW_FULL_LDS(k_gemm_s3);
         int nmax = probs[0].Nout;
         if (nprob > 1 && probs[1].Nout > nmax) nmax = probs[1].Nout;
         dim3 grid((nmax + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, nprob > 1 ? nprob : ksplit);
-        hipLaunchKernelGGL(k_gemm_s3, grid, dim3(GM_THREADS), lds, stream, probs[0], probs[nprob > 1 ? 1 : 0], nprob, M, K,
-                           partial);
+#define GS3_LAUNCH(ABLV)                                                                                                  \
+    do {                                                                                                                  \
+        VKN_ALLOW_FULL_LDS((k_gemm_s3<ABLV>));                                                                            \
+        hipLaunchKernelGGL((k_gemm_s3<ABLV>), grid, dim3(GM_THREADS), lds, stream, probs[0], probs[nprob > 1 ? 1 : 0], nprob, M, K, \
+                           partial);                                                                                      \
+    } while (0)
+#ifdef VKN_DEBUG
+        const int gabl = vkn_dbg_env("VKN_GEMM_ABL", 0);
+        if (gabl == 1) GS3_LAUNCH(1);
+        else if (gabl == 2) GS3_LAUNCH(2);
+        else
+#endif
+            GS3_LAUNCH(0);
+#undef GS3_LAUNCH
         VKN_CHECK_LAUNCH();
     } else {
         for (int i = 0; i < nprob; ++i) {
