@@ -69,15 +69,28 @@ __device__ __forceinline__ void vkn_epi_load_cols(const VknEpi& e, int ncols, in
     }
 }
 
-// Row-wise epilogue executed by ONE wave for ONE row.  v[q] = accumulated value at column lane + 64*q.
-__device__ __forceinline__ void vkn_row_epilogue(const VknEpi& e, const VknEpiCols& c, int row, int ncols, int lane,
-                                                 float (&v)[4]) {
-    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+// Per-row global operands of the epilogue (residual row, bias scale).  Loaded for ALL rows of a wave before the first row is
+// processed: inside the row loop they sit behind the previous row's stores (which may alias them as far as the compiler knows),
+// i.e. one L2 round trip per row on the critical path of every GEMM launch.
+struct VknEpiRow {
+    float rv[4];
+    float bs;
+};
+__device__ __forceinline__ void vkn_epi_load_row(const VknEpi& e, const VknEpiCols& c, int row, VknEpiRow& r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r.rv[q] = 0.f;
     if (e.resid) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rv[q] = e.resid[(size_t)row * e.ldr + c.cidx[q]];
+        for (int q = 0; q < 4; ++q) r.rv[q] = e.resid[(size_t)row * e.ldr + c.cidx[q]];
     }
-    const float bs = (e.bias && e.rowscale) ? e.rowscale[row] : 1.f;
+    r.bs = (e.bias && e.rowscale) ? e.rowscale[row] : 1.f;
+}
+
+// Row-wise epilogue executed by ONE wave for ONE row.  v[q] = accumulated value at column lane + 64*q.
+__device__ __forceinline__ void vkn_row_epilogue(const VknEpi& e, const VknEpiCols& c, int row, int ncols, int lane,
+                                                 float (&v)[4], const VknEpiRow& pre) {
+    const float (&rv)[4] = pre.rv;
+    const float bs = pre.bs;
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = c.ok[q] ? (v[q] + c.bias[q] * bs + c.bias2[q] + rv[q]) : 0.f;
     if (c.do_ln) {
@@ -228,6 +241,9 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm(const float* __restrict_
     const int ncols = min(GM_BN, Nout - n0);
     VknEpiCols cols;
     vkn_epi_load_cols(epi, ncols, n0, lane, cols);
+    VknEpiRow pre[GM_BM / 8];
+#pragma unroll
+    for (int i = 0; i < GM_BM / 8; ++i) vkn_epi_load_row(epi, cols, min(m0 + wave * (GM_BM / 8) + i, M - 1), pre[i]);
 #pragma unroll
     for (int i = 0; i < GM_BM / 8; ++i) {
         const int rl = wave * (GM_BM / 8) + i, row = m0 + rl;
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_gemm(const float* __restrict_
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = T[rl * GM_LDT + lane + 64 * q];
-            vkn_row_epilogue(epi, cols, row, ncols, lane, v);
+            vkn_row_epilogue(epi, cols, row, ncols, lane, v, pre[i]);
         }
     }
 }
@@ -328,7 +344,7 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
     const float* A4p = A4 ? A4 : A;
     const bool mul = (A2 != nullptr), two = (A3 != nullptr);
     const __bf16* wtile0 = Wp + (size_t)blockIdx.x * ktiles * GS_WTILE;  // this column tile's images, K-tile major
-    f32x4 ra, rb, rc, rd;
+    f32x4 S0[4], S1[4];  // two register sets of A fragments (tile i + 1 waiting to be stashed, tile i + 2 in flight)
 
     // weight tile KT -> LDS buffer BUF: 3072 x 16 B = 12 DMA instructions per thread of waves 0-3; piece index = i*256 + tid, so
     // every wave writes 64 consecutive slots (the DMA's LDS address is wave base + lane*16) from 1 KB of contiguous global memory
@@ -341,19 +357,19 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
                                              (__attribute__((address_space(3))) void*)(ldst_ + i_ * 4096), 16, 0, 0); \
     } while (0)
 
-#define GS_AFETCH(KT)                                                              \
-    do {                                                                           \
-        ra = *reinterpret_cast<const f32x4*>(A + aoff + (size_t)(KT) * 32);        \
-        rb = *reinterpret_cast<const f32x4*>(A2p + aoff + (size_t)(KT) * 32);      \
-        rc = *reinterpret_cast<const f32x4*>(A3p + aoff + (size_t)(KT) * 32);      \
-        rd = *reinterpret_cast<const f32x4*>(A4p + aoff + (size_t)(KT) * 32);      \
+#define GS_AFETCH(KT, S)                                                            \
+    do {                                                                            \
+        S[0] = *reinterpret_cast<const f32x4*>(A + aoff + (size_t)(KT) * 32);       \
+        S[1] = *reinterpret_cast<const f32x4*>(A2p + aoff + (size_t)(KT) * 32);     \
+        S[2] = *reinterpret_cast<const f32x4*>(A3p + aoff + (size_t)(KT) * 32);     \
+        S[3] = *reinterpret_cast<const f32x4*>(A4p + aoff + (size_t)(KT) * 32);     \
     } while (0)
 
-#define GS_ASTASH(BUF)                                                                            \
+#define GS_ASTASH(BUF, S)                                                                         \
     do {                                                                                          \
         bf16x4 h_, m_, l_;                                                                        \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
-            const float v_ = (mul ? ra[e] * rb[e] : ra[e]) + (two ? rc[e] * rd[e] : 0.f);         \
+            const float v_ = (mul ? S[0][e] * S[1][e] : S[0][e]) + (two ? S[2][e] * S[3][e] : 0.f); \
             __bf16 hh_, mm_, ll_;                                                                 \
             vkn_split_bf16x3(v_, hh_, mm_, ll_);                                                  \
             h_[e] = hh_;                                                                          \
@@ -400,44 +416,62 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
     const int ncols = min(GM_BN, Nout - n0);
     VknEpiCols cols;
     vkn_epi_load_cols(epi, ncols, n0, lane, cols);
+    VknEpiRow pre[GM_BM / 8];  // ... and so are the per-row operands (residual rows, bias scales) of this wave's four output rows
+#pragma unroll
+    for (int i = 0; i < GM_BM / 8; ++i) vkn_epi_load_row(epi, cols, min(m0 + wave * (GM_BM / 8) + i, M - 1), pre[i]);
 
-    // Three weight buffers: while tile i is multiplied, tiles i+1 AND i+2 are in flight (96 KB per CU).  The K loop of these small-M
-    // GEMMs is bound by the latency of one weight tile (L2 / MALL, 1.5 - 2 us) — with one tile in flight a K-tile cost that latency;
-    // two in flight halve it.  The DMA -> LDS dependency is invisible to the compiler, so the waits are explicit: vmcnt counts in
-    // order, the 12 DMA instructions of tile i+2 are the youngest, vmcnt(12) = "tile i+1 has landed".
+    // Three weight buffers: while tile i is multiplied, tiles i+1 AND i+2 are in flight (96 KB per CU); the A fragments run two
+    // tiles ahead as well (tile i+2 requested before the MFMAs of tile i, tile i+1 split and written after them).  Time attribution
+    // (debug build, VKN_GEMM_ABL, B = 1): the K loop cost 8.4 of a launch's 15 us with A one tile ahead — its L2 round trip
+    // (~0.7 us) did not fit under the 0.3 us of MFMAs of one tile — and the depth of the WEIGHT ring made no difference by itself.
+    // The DMA -> LDS dependency is invisible to the compiler, so the DMA waves' waits are explicit: vmcnt counts in order, the 12
+    // DMA instructions of tile i+2 are the youngest, vmcnt(12) = "tile i+1 has landed".  Both roles run the same number of barriers.
+    // BAR: this wave's LDS writes are done (lgkmcnt) + workgroup barrier, as ONE asm statement: behind a __syncthreads() hipcc
+    // strengthens the wait to vmcnt(0) (its workgroup release fence), which would drain the prefetch.
+#define GS_BAR(VM) asm volatile("s_waitcnt " VM "lgkmcnt(0)\n\ts_barrier" ::: "memory")
     const int nkt = (ABL == 1) ? 0 : kt_end - kt_begin;
     if (nkt > 0) {
+        const int klast = kt_end - 1;
         if (a_role) {
-            GS_AFETCH(kt_begin);
-            GS_ASTASH(0);
+            GS_AFETCH(kt_begin, S0);
+            GS_AFETCH(min(kt_begin + 1, klast), S1);
+            GS_ASTASH(0, S0);
+            GS_BAR("");
+            for (int j = 0; j + 1 < nkt; j += 2) {
+                GS_AFETCH(min(kt_begin + j + 2, klast), S0);  // past the end: re-reads the last tile, never stashed into a live buffer
+                GS_MFMA(j);
+                GS_ASTASH(1, S1);
+                GS_BAR("");
+                if (j + 2 < nkt) {
+                    GS_AFETCH(min(kt_begin + j + 3, klast), S1);
+                    GS_MFMA(j + 1);
+                    GS_ASTASH(0, S0);
+                    GS_BAR("");
+                }
+            }
         } else {
             GS_DMA(kt_begin, 0);
-            if (nkt > 1) GS_DMA(kt_begin + 1, 1);
+            if (nkt > 1) {
+                GS_DMA(kt_begin + 1, 1);
+                GS_BAR("vmcnt(12) ");
+            } else {
+                GS_BAR("vmcnt(0) ");
+            }
+            for (int i = 0; i + 1 < nkt; ++i) {
+                if (i + 2 < nkt) {
+                    GS_DMA(kt_begin + i + 2, (i + 2) % 3);  // that buffer held tile i-1: every wave passed the barrier after reading it
+                    GS_MFMA(i);
+                    GS_BAR("vmcnt(12) ");  // tile i+1 landed; tile i+2 may still be in flight
+                } else {
+                    GS_MFMA(i);
+                    GS_BAR("vmcnt(0) ");
+                }
+            }
         }
-        if (nkt > 1) __builtin_amdgcn_s_waitcnt(0x0F7C);  // vmcnt(12)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
-        __syncthreads();
-        int i = 0;
-        for (; i + 2 < nkt; ++i) {
-            if (a_role) GS_AFETCH(kt_begin + i + 1);
-            else GS_DMA(kt_begin + i + 2, (i + 2) % 3);  // that buffer held tile i-1: every wave passed the barrier after reading it
-            GS_MFMA(i);
-            if (a_role) GS_ASTASH((i + 1) & 1);
-            // tile i+1 landed (tile i+2 may still be in flight), this wave's LDS writes are done; ONE asm statement: behind a
-            // __syncthreads() hipcc strengthens the wait to vmcnt(0) (its workgroup release fence), which drains the prefetch
-            asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-        if (i + 1 < nkt) {
-            if (a_role) GS_AFETCH(kt_begin + i + 1);
-            GS_MFMA(i);
-            if (a_role) GS_ASTASH((i + 1) & 1);
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            __syncthreads();
-            ++i;
-        }
-        GS_MFMA(i);
+        GS_MFMA(nkt - 1);
         __syncthreads();  // buffer 0 becomes the output tile below
     }
+#undef GS_BAR
 #undef GS_DMA
 #undef GS_AFETCH
 #undef GS_ASTASH
@@ -470,7 +504,7 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = T[rl * GM_LDT + lane + 64 * q];
-            vkn_row_epilogue(epi, cols, row, ncols, lane, v);
+            vkn_row_epilogue(epi, cols, row, ncols, lane, v, pre[i]);
         }
     }
 }
@@ -657,12 +691,14 @@ __global__ __launch_bounds__(256) void k_rowepi(const float* __restrict__ partia
     if (row >= M) return;
     VknEpiCols cols;
     vkn_epi_load_cols(epi, Nout, 0, lane, cols);
+    VknEpiRow pre;
+    vkn_epi_load_row(epi, cols, row, pre);
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < ks; ++z) {  // fixed order -> deterministic
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += partial[((size_t)z * M + row) * Nout + cols.cidx[q]];
     }
-    vkn_row_epilogue(epi, cols, row, Nout, lane, v);
+    vkn_row_epilogue(epi, cols, row, Nout, lane, v, pre);
 }
 
 // f[row] = ug * LN(params[:, C:2C]; norm_out) + ig * LN(inputf[:, C:2C]; input_norm_out)   (knet/kernel_updator.py:79-88)
