@@ -17,12 +17,18 @@ out = sys.argv[1]
 def short(n):
     n = n.replace('void ', '')
     if n.startswith('_Z'):
-        if 'k_decode_mfma' in n:  # template <NB, ABL, RING, BITS>: the bit-packed hand-off variant is a different kernel
+        if 'k_decode_mfma' in n:  # template <NB, ABL, RING, BITS, OPT, XH>: the bit-packed hand-off variant is a different kernel
             import re
-            m = re.search(r'k_decode_mfmaILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', n)
+            m = re.search(r'k_decode_mfmaILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', n)
             if m and m.group(1) != '4':  # few-row launches (e.g. conv_seg of the kernel-init pass): not the roofline kernel
                 return f'k_decode_mfma<NB={m.group(1)}>'
+            if m and m.group(6) != '0':  # x stored as fp16 / bf16 (bench.py's x_storage_variants): its own row
+                return 'k_decode_mfma<x16>'
             return 'k_decode_mfma<bits>' if (m and m.group(4) == '1') else 'k_decode_mfma'
+        if 'k_fused_dgs' in n:
+            import re
+            m = re.search(r'k_fused_dgsILi(\d+)ELi(\d+)ELi(\d+)E', n)
+            return 'k_fused_dgs<x16>' if (m and m.group(3) != '0') else 'k_fused_dgs'
         for key in ('k_split_planes', 'k_gemm_s3', 'k_fused_dgs', 'k_ffn_fused', 'k_gather_bits_w'):
             if key in n:
                 return key
@@ -107,7 +113,7 @@ for tag, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
 if len(sys.argv) > 2 and pmc:
     import json
     side = {}
-    for k in ('k_decode_mfma', 'k_fused_dgs', 'k_gather_mfma<4>', 'k_upsample'):
+    for k in ('k_decode_mfma', 'k_decode_mfma<x16>', 'k_fused_dgs', 'k_fused_dgs<x16>', 'k_gather_mfma<4>', 'k_upsample'):
         if k in pmc and 'FETCH_SIZE_KB' in pmc[k] and 'WRITE_SIZE_KB' in pmc[k]:
             side[k] = dict(fetch_size_kb=pmc[k]['FETCH_SIZE_KB'], write_size_kb=pmc[k]['WRITE_SIZE_KB'],
                            hbm_bytes_per_launch=int((2 * pmc[k]['FETCH_SIZE_KB'] + pmc[k]['WRITE_SIZE_KB']) * 1024))
