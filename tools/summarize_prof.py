@@ -51,6 +51,17 @@ if con:
             "group by name, grid_y order by name, grid_y"):
         print(f'{short(n):28s} frames/launch={gy:5d} calls={c:4d} avg_us={avg / 1e3:9.2f} min_us={mn / 1e3:9.2f} max_us={mx / 1e3:9.2f}')
     print()
+    # the roofline kernel: launches inside head steps (the previous kernel on the timeline is a GEMM) vs bench.py's back-to-back loop
+    full_y = max([0] + [gy for n, gy in con.execute("select name, grid_y from kernels where name like '%k_decode_mfma%'")])
+    ordered = con.execute('select name, start, end, grid_y from kernels order by start').fetchall()
+    instep, loop = [], []
+    for i, (n, s0, e0, gy) in enumerate(ordered):
+        if short(n) == 'k_decode_mfma' and gy == full_y and i > 0:
+            (instep if 'k_decode_mfma' not in ordered[i - 1][0] else loop).append((e0 - s0) / 1e3)
+    if instep:
+        print(f'k_decode_mfma at {full_y} frames per launch: inside head steps n={len(instep)} avg_us={sum(instep) / len(instep):.2f} '
+              f'min={min(instep):.2f} max={max(instep):.2f}; back-to-back loop n={len(loop)} avg_us={sum(loop) / max(len(loop), 1):.2f}')
+        print()
     agg = defaultdict(lambda: [0, 0.0])
     for n, s, e in rows:
         a = agg[short(n)]
@@ -100,11 +111,14 @@ for tag, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         print('not collected')
         continue
     for n, c, avg, mx in con.execute('select name, count(*), avg(counter_value), max(counter_value) from pmc_events '
-                                     'where counter_name = ? group by name order by avg(counter_value) desc limit 10', (ctr,)):
+                                     'where counter_name = ? group by name order by avg(counter_value) desc limit 40', (ctr,)):
         # launches of the full batch only (bench.py also launches the kernels at 1 / 8 frames): values within 10 % of the maximum
         full = con.execute('select count(*), avg(counter_value) from pmc_events where counter_name = ? and name = ? and '
                            'counter_value >= ?', (ctr, n, 0.9 * mx)).fetchone()
-        print(f'{short(n):48s} n={c:5d} mean_KB={avg:14.1f} max_KB={mx:14.1f}  full-batch launches: n={full[0]} mean_KB={full[1]:14.1f}')
+        if short(n) in pmc and (ctr + '_KB') in pmc[short(n)]:
+            continue  # a second template instance with the same short name (fp16 / bf16): the first (larger) row stands
+        if len([1 for v in pmc.values() if (ctr + '_KB') in v]) < 18:
+            print(f'{short(n):48s} n={c:5d} mean_KB={avg:14.1f} max_KB={mx:14.1f}  full-batch launches: n={full[0]} mean_KB={full[1]:14.1f}')
         pmc.setdefault(short(n), {})[ctr + '_KB'] = full[1]
 
 # sidecar for bench.py's roofline.traffic (committed under profiles/): HBM bytes per launch of the dominant kernels.

@@ -557,7 +557,10 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_dgs(const float* __rest
             const int soff = ((ks << 4) * P + tile_p0(t)) << XSH;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (XH) raw[f][e] = fu_u32x2{__builtin_amdgcn_raw_buffer_load_b32(xrs, voff, soff + ((e * P) << 1), 3), 0u};
+                // half storage: a 32-px tile is HALF a 128-byte line of its channel row; the other half is the next tile of this same
+                // workgroup.  With the streaming hint (sc0 | nt) the line was fetched from HBM twice (PMC FETCH_SIZE = 2x the x bytes,
+                // profiles/r02n); default caching keeps it for the second half.
+                if (XH) raw[f][e] = fu_u32x2{__builtin_amdgcn_raw_buffer_load_b32(xrs, voff, soff + ((e * P) << 1), 0), 0u};
                 else raw[f][e] = __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, soff + ((e * P) << 2), 3);
             }
         }

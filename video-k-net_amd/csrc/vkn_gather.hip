@@ -93,8 +93,8 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
         for (int i = 0; i < XCH; ++i) {
             const int idc = min(tid + i * GA_THREADS, nxch - 1);
             // non-temporal: x is streamed once per launch (same +9 % as in the decode kernel)
-            if (XH)
-                xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb16 + (size_t)(idc >> 2) * P + p0 + ((idc & 3) << 3)));
+            if (XH)  // plain load: the 32-px tile is half a 128-byte line, the next tile of this workgroup takes the other half
+                xr[i] = *reinterpret_cast<const f32x4*>(xb16 + (size_t)(idc >> 2) * P + p0 + ((idc & 3) << 3));
             else
                 xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2)));
         }
