@@ -101,6 +101,30 @@ def test_half_x_head_matches_fp32_head_on_rounded_x_and_reference_within_toleran
     assert (ra[2] - rb[2]).abs().max().item() <= tol * scale, ((ra[2] - rb[2]).abs().max().item(), scale)
 
 
+def test_half_x_single_stage_and_class_api(vkn):
+    """`KernelUpdateHead.forward` (vkn_stage_forward_f32) and the class-level fused head take half-storage x as is."""
+    from test_gpu_parity import _build_head
+    _, case = load_golden('video_cfg')
+    head, _ = _build_head(vkn, case)
+    T, N, C, H, W = 2, case['N'], case['C'], case['H'], case['W']
+    xs = _clamp_tiny(_rand((T, C, H, W), 51)).to(DEV)
+    pfs = _rand((T, N, C, 1, 1), 52).to(DEV)
+    mps = _rand((T, N, H, W), 53, 4.0).to(DEV)
+    xh = xs.to(torch.bfloat16)
+    head.eval()
+    with torch.no_grad():
+        a = head.mask_head[0](xh, pfs, mps)
+        b = head.mask_head[0](xh.float(), pfs, mps)
+        for u, v in zip(a, b):
+            assert (u is None and v is None) or torch.equal(u, v)
+        a = head.simple_test_mask_preds(xh, pfs, mps, None, None)
+        b = head.simple_test_mask_preds(xh.float(), pfs, mps, None, None)
+        for u, v in zip(a, b):
+            assert (u is None and v is None) or torch.equal(u, v)
+    with pytest.raises(TypeError):   # the autograd (training) path reads fp32 features
+        head.mask_head[0](xh, pfs, mps)
+
+
 def test_half_x_rejected_by_reference_kernels_and_ragged_sizes(vkn):
     x = _rand((1, 64, 6, 10), 41).to(DEV).half()
     masks = _rand((1, 32, 6, 10), 42).to(DEV)

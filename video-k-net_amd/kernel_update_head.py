@@ -222,6 +222,8 @@ class KernelUpdateHead(nn.Module):
         runs as torch ops on this module's own parameters.  `feat_transform` stays folded: x_feat = xraw W^T + cnt b,
         Z = (mask_feat W) x + mask_feat . b — its weight / bias gradients come out of the two small matmuls.
         Line-by-line counterpart of knet/det/kernel_update_head.py:170-277 (video: knet/video/kernel_update_head.py:281-541)."""
+        if x.dtype != torch.float32:
+            raise TypeError('the autograd (training) path reads fp32 features; half-storage x is an inference option')
         B, N = proposal_feat.shape[:2]
         C, K = self.in_channels, self.conv_kernel_size
         xraw, cnt = vag.mask_gather(x, mask_preds.detach(), self.hard_mask_thr)                        # :190-195

@@ -284,7 +284,8 @@ def make_dims(B, N, C, H, W, heads, ff, ncls, n_cls_fcs, n_mask_fcs, hard_mask_t
 def stage_forward(dims: VknDims, pack: StagePack, x, obj_in, masks_in, prev_obj=None, want_track=False, flags=0):
     """One `KernelUpdateHead.forward` on the GPU.  Returns (cls_logits [B,N,ncls], masks [B,N,H,W], obj [B,N,C],
     x_feat [B,N,C], track [B,N,C] | None)."""
-    x, obj_in, masks_in = _req(x, 'x'), _req(obj_in, 'proposal_feat'), _req(masks_in, 'mask_preds')
+    (x, xdt), obj_in, masks_in = _req_x(x), _req(obj_in, 'proposal_feat'), _req(masks_in, 'mask_preds')
+    flags |= (0, FLAG_X_F16, FLAG_X_BF16)[xdt]
     B, N, C, H, W = dims.B, dims.N, dims.C, dims.H, dims.W
     dev = x.device
     L = _lib.lib()
