@@ -121,6 +121,20 @@ def main():
                 t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
                 print(f'head without upsample B={B}, k_gemm_s3 ablation {abl} ({nm}): {t:8.1f} us  (24 k_gemm_s3 launches per step)', flush=True)
             os.environ.pop('VKN_GEMM_ABL')
+        if 'ffnhs' in what and not args.release:
+            fp = torch.zeros(1, N, C, device=dev)
+            for hs in (0, 1, 2, 4, 0):
+                os.environ['VKN_FFN_HS'] = str(hs)
+                t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
+                print(f'head without upsample B={B}, FFN hidden split {hs} (0 = policy): {t:8.1f} us', flush=True)
+            os.environ.pop('VKN_FFN_HS')
+        if 'lastchunk' in what and not args.release:
+            fp = torch.zeros(1, N, C, device=dev)
+            for ch in (0, 16, 8, 4, 0):
+                os.environ['VKN_LAST_CHUNK'] = str(ch)
+                t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 4, clip_first_prev=fp), reps=10, warm=3)
+                print(f'bench step B={B}, last decode + upsample in chunks of {ch} frames (0 = whole batch): {t:8.1f} us', flush=True)
+            os.environ.pop('VKN_LAST_CHUNK')
         if 'upsample' in what:
             m = torch.randn(B, N, H, W, device=dev)
             t = timeit(lambda: vkn.ops.upsample_bilinear(m, 4), reps=10, warm=3)

@@ -187,7 +187,11 @@ int run_ffn(const VknDims* d, const StageWs& s, const float* in, const float* w1
     const int M = d->B * d->N, C = d->C, FF = d->ff;
     VknEpi e = mk_epi(d);
     // both Linears in one kernel (hidden activations stay on chip) when the weights are pre-split and the shape allows it
-    const int hsplit = ffn_hsplit(M, FF);
+    int hsplit = ffn_hsplit(M, FF);
+    {
+        const int hs_dbg = vkn_dbg_env("VKN_FFN_HS", 0);  // debug build: smaller hidden split (A/B)
+        if (hs_dbg > 0 && hs_dbg <= hsplit) hsplit = hs_dbg;
+    }
     if (w1s && w2s && C == 256 && hsplit > 0 && vkn_dbg_env("VKN_FFN_FUSED", 1) != 0) {
         e.bias = b2; e.resid = in; e.ldr = C; e.ln_w = nw; e.ln_b = nb; e.out = out; e.ldo = C;
         return vkn_launch_ffn_fused(in, C, w1s, b1, w2s, M, C, FF, hsplit, s.partial, e, st);
@@ -280,7 +284,8 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
               float* track_out, const StageWs& s, unsigned flags, hipStream_t st, const unsigned* bits_in = nullptr,
               unsigned* bits_out = nullptr, bool cls_sigmoid = false, bool gathered_in = false, bool gather_out = false,
               hipEvent_t prof0 = nullptr, hipEvent_t prof1 = nullptr, const float* xfeat_in = nullptr, float* kern_out = nullptr,
-              float* kb_out = nullptr, hipEvent_t obj_ready = nullptr) {
+              float* kb_out = nullptr, hipEvent_t obj_ready = nullptr, float* up_out = nullptr, int up_stride = 0, int up_chunk = 0,
+              bool* up_done = nullptr) {
     // xfeat_in / kern_out / kb_out (vkn_stage_chain_f32): the [B*N, C] chain alone — the caller supplies x_feat (already
     // feat-transformed and, for the clip-level VIS heads, merged over the frames of a clip) and receives the folded fp32 decode
     // kernels + bias instead of decoded masks; no gather and no decode are launched, x / masks_in / masks_out are unused.
@@ -296,6 +301,25 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
                                                            // (chain_only: fp32 folded kernels are the output)
     const bool has_ft = w->ft_w != nullptr;
     const int xdt = xdt_of(flags);
+    // the LAST stage's logits decode (+ the caller's xS up-scaled output when up_out is given): in chunks of up_chunk frames, each
+    // chunk's upsample right behind its decode, so the upsample reads logits that are still in the memory-side cache
+    auto decode_final = [&](const float* kb) -> int {
+        const int ch = (up_out && up_chunk > 0 && up_chunk < B) ? up_chunk : B;
+        const size_t NPTC = (size_t)npt_of(N) * C;
+        for (int b0 = 0; b0 < B; b0 += ch) {
+            const int bn = (B - b0 < ch) ? B - b0 : ch;
+            const float* xb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + (size_t)b0 * C * P * (xdt_of(flags) ? 2 : 4));
+            if (b0 == 0 && prof0 && hipEventRecord(prof0, st) != hipSuccess) return VKN_E_LAUNCH;  // the (first) decode launch alone
+            VKN_TRY(vkn_launch_decode(xb, s.kfh + b0 * NPTC, s.kfl + b0 * NPTC, kb ? kb + (size_t)b0 * N : nullptr,
+                                      masks_out + (size_t)b0 * N * P, bn, N, C, P, st, xdt_of(flags)));
+            if (b0 == 0 && prof1 && hipEventRecord(prof1, st) != hipSuccess) return VKN_E_LAUNCH;
+            if (ch < B)
+                VKN_TRY(vkn_launch_upsample(masks_out + (size_t)b0 * N * P, up_out + (size_t)b0 * N * P * up_stride * up_stride, bn * N,
+                                            d->H, d->W, up_stride, st));
+        }
+        if (ch < B && up_done) *up_done = true;
+        return VKN_OK;
+    };
     // half-storage x: the MFMA kernels only (whole 64-px tiles); the exact-fp32 reference kernels read fp32
     if (xdt && !chain_only && (ref || (P % 64) != 0)) return VKN_E_SHAPE;
     PrepW pw{};
@@ -397,11 +421,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         else if (gather_out)
             VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt));
         else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
-        else {
-            if (prof0 && hipEventRecord(prof0, st) != hipSuccess) return VKN_E_LAUNCH;  // vkn_head_forward_prof_f32: the decode kernel alone
-            VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st, xdt));
-            if (prof1 && hipEventRecord(prof1, st) != hipSuccess) return VKN_E_LAUNCH;
-        }
+        else VKN_TRY(decode_final(kb));
     } else {
         {
             VknGemmProb pr[2];
@@ -445,11 +465,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
                 VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P,
                                                        st, xdt));
             else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
-            else {
-                if (prof0 && hipEventRecord(prof0, st) != hipSuccess) return VKN_E_LAUNCH;
-                VKN_TRY(vkn_launch_decode(x, s.kfh, s.kfl, kb, masks_out, B, N, C, P, st, xdt));
-                if (prof1 && hipEventRecord(prof1, st) != hipSuccess) return VKN_E_LAUNCH;
-            }
+            else VKN_TRY(decode_final(kb));
         }
     }
 
@@ -919,6 +935,7 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
     const float* m_in = mask_preds_in;
     const float* o_in = proposal_feats;
     SideStream* joined = nullptr;
+    bool up_done = false;
     for (int sidx = 0; sidx < num_stages; ++sidx) {
         const bool last = (sidx == num_stages - 1);
         // alternate so that the LAST stage writes the caller's buffers
@@ -938,7 +955,8 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
                           prev_in_stage ? track_out : nullptr, s, flags, st, b_in, b_out, last, use_fused && sidx > 0,
                           use_fused && !last, last ? static_cast<hipEvent_t>(ev_decode_start) : nullptr,
                           last ? static_cast<hipEvent_t>(ev_decode_stop) : nullptr, nullptr, nullptr, nullptr,
-                          (prev && side) ? side->fork : nullptr));
+                          (prev && side) ? side->fork : nullptr, (last && scaled_out && upsample_stride > 1) ? scaled_out : nullptr,
+                          upsample_stride, vkn_dbg_env("VKN_LAST_CHUNK", 0), &up_done));
         m_in = m_out;
         o_in = o_out;
         if (prev && link_after) {
@@ -977,7 +995,7 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
             }
         }
     }
-    if (scaled_out && upsample_stride > 1)                                                // :122-130
+    if (scaled_out && upsample_stride > 1 && !up_done)                                    // :122-130
         VKN_TRY(vkn_launch_upsample(mask_preds_out, scaled_out, d->B * d->N, d->H, d->W, upsample_stride, st));
     // join: everything the call produced (and every use of the workspace) is ordered before later work on the caller's stream
     if (joined && hipStreamWaitEvent(st, joined->join, 0) != hipSuccess) return VKN_E_LAUNCH;
