@@ -345,14 +345,16 @@ class KernelUpdateHead(nn.Module):
                 losses['loss_mask'] = self.loss_mask(pos_mask_pred, pos_mask_targets)
                 losses['loss_dice'] = self.loss_dice(pos_mask_pred, pos_mask_targets)
                 if self.loss_rank is not None:
+                    # reference :311-322 paints, per image, the positive kernels' target masks into a label map in ASCENDING kernel
+                    # order (`for j in curr_rank: rank_target[i][mask_ij] = j`), i.e. every pixel ends up with the LARGEST positive
+                    # kernel index whose target covers it.  Same map without the per-instance host loop (hundreds of tiny
+                    # nonzero / index_put launches and a host sync each per step): a masked max over the kernel axis.
                     batch_size = mask_pred.size(0)
-                    rank_target = mask_targets.new_full((batch_size, H, W), self.ignore_label, dtype=torch.long)
-                    rank_inds = pos_inds.view(batch_size, -1).nonzero(as_tuple=False)
-                    batch_mask_targets = mask_targets.view(batch_size, -1, H, W).bool()
-                    for i in range(batch_size):
-                        curr_rank = rank_inds[:, 1][rank_inds[:, 0] == i]
-                        for j in curr_rank:
-                            rank_target[i][batch_mask_targets[i][j]] = j
+                    n = mask_targets.shape[0] // batch_size
+                    covered = mask_targets.view(batch_size, n, H, W).bool() & pos_inds.view(batch_size, n, 1, 1)
+                    idx = torch.arange(n, device=mask_targets.device, dtype=torch.int16).view(1, n, 1, 1)
+                    top = torch.where(covered, idx, idx.new_full((), -1)).amax(dim=1).long()
+                    rank_target = torch.where(top >= 0, top, top.new_full((), self.ignore_label))
                     losses['loss_rank'] = self.loss_rank(mask_pred, rank_target, ignore_index=self.ignore_label)
             else:
                 losses['loss_mask'] = mask_pred.sum() * 0
