@@ -257,7 +257,19 @@ def main():
     for p in packs:
         p.ensure_prepared(dims)
 
+    dims1 = last.make_dims(1, N, CFG2['H'], CFG2['W'])
+
     def step(events=None):
+        if world > 1 and NS == 1:
+            # one process per GPU, contiguous blocks of the clip: the whole block — S stages, x4 upsample, the tracking link of
+            # frames 1 .. B-1 to their predecessors (VKN_FLAG_CLIP_LINK) — is ONE C-ABI call, as on one GPU; only frame 0 of the
+            # block links across ranks: one neighbour hand-over of the previous rank's last [N x C] kernels (120 KB, point to
+            # point) and a one-frame link.  Rank 0's frame 0 links to the clip's `first_prev` inside the call.
+            out = vkn.ops.head_forward(dims, packs, x, pfs[0], mp, None, up, clip_first_prev=first_prev, decode_events=events)
+            p0 = vkn_dist.neighbour_last_kernels(out[0])
+            if p0 is not None:
+                out[4][0:1].copy_(vkn.ops.track_link(dims1, packs[-1], out[0][0:1], p0))
+            return out, out[4]
         if world == 1 and NS == 1:
             # single process: the whole clip step — S stages, x4 upsample, tracking link of every frame to its predecessor — is
             # ONE C-ABI call (VKN_FLAG_CLIP_LINK), so the host side of a step is a handful of allocations

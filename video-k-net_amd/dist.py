@@ -14,6 +14,27 @@ def shard_bounds(num_frames: int, world: int, rank: int):
     return (num_frames * rank) // world, (num_frames * (rank + 1)) // world
 
 
+def neighbour_last_kernels(block_kernels: torch.Tensor, group=None):
+    """Every rank owns >= 1 frame: hand this rank's LAST frame's kernels [N, C] to rank + 1 and return the previous rank's
+    ([1, N, C]; None on rank 0 or without a process group).  ONE point-to-point send / receive (120 KB at N = 117, C = 256) —
+    xGMI is point-to-point, a single send rides one link, no ring, no host synchronisation."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world <= 1:
+        return None
+    N, C = block_kernels.shape[1:]
+    last = block_kernels[-1].contiguous()
+    recv = torch.empty_like(last)
+    ops = []
+    if rank + 1 < world:
+        ops.append(dist.P2POp(dist.isend, last, rank + 1, group))
+    if rank > 0:
+        ops.append(dist.P2POp(dist.irecv, recv, rank - 1, group))
+    for req in (dist.batch_isend_irecv(ops) if ops else []):
+        req.wait()
+    return recv.reshape(1, N, C) if rank > 0 else None
+
+
 def previous_kernels_for_block(block_kernels: torch.Tensor, first_previous=None, group=None, all_nonempty=False):
     """`block_kernels` [T_r, N, C] = final kernels of this rank's frames.  Returns prev [T_r, N, C] with
     prev[i] = kernels of the frame BEFORE frame i of the block: the previous rank's last frame for i = 0
@@ -27,18 +48,7 @@ def previous_kernels_for_block(block_kernels: torch.Tensor, first_previous=None,
     T = block_kernels.shape[0]
     N, C = block_kernels.shape[1:]
     if world > 1 and all_nonempty:
-        # one neighbour hand-over (rank r -> r + 1, 120 KB at N = 117, C = 256) instead of an all_gather of world x 120 KB
-        # (xGMI is point-to-point: a single send rides one link, no ring)
-        last = block_kernels[-1].contiguous()
-        recv = torch.empty_like(last)
-        ops = []
-        if rank + 1 < world:
-            ops.append(dist.P2POp(dist.isend, last, rank + 1, group))
-        if rank > 0:
-            ops.append(dist.P2POp(dist.irecv, recv, rank - 1, group))
-        for req in (dist.batch_isend_irecv(ops) if ops else []):
-            req.wait()
-        p0 = recv.reshape(1, N, C) if rank > 0 else None
+        p0 = neighbour_last_kernels(block_kernels, group)
     elif world > 1:
         last = block_kernels[-1].contiguous() if T > 0 else block_kernels.new_zeros(N, C)
         has = torch.tensor([1.0 if T > 0 else 0.0], device=block_kernels.device)
