@@ -971,3 +971,31 @@ def test_side_stream_link_equals_serial_link(vkn):
             assert out[4] is not None
             for u, v in zip(out, ref):
                 assert (u is None and v is None) or torch.equal(u, v)
+
+
+def test_block_step_with_neighbour_link_equals_whole_clip(vkn):
+    """bench.py --gpus N: every rank runs its contiguous block of the clip as ONE call with the in-call clip link and re-links only
+    its frame 0 to the previous rank's last kernels (dist.neighbour_last_kernels).  Emulated on one GPU with two blocks: every
+    output of the two block steps equals the whole-clip call."""
+    _, case = load_golden('video_cfg')
+    head, _ = _build_head(vkn, case)
+    T, N, C, H, W = 6, case['N'], case['C'], case['H'], case['W']
+    xs = _rand((T, C, H, W), 951).to(DEV)
+    pfs = _rand((T, N, C), 952).to(DEV)
+    mps = _rand((T, N, H, W), 953, 4.0).to(DEV)
+    first = _rand((1, N, C), 954).to(DEV)
+    packs = [h.stage_pack(torch.device(DEV)) for h in head.mask_head]
+    mk = head.mask_head[0].make_dims
+    whole = vkn.ops.head_forward(mk(T, N, H, W), packs, xs, pfs, mps, None, case['up'], clip_first_prev=first)
+    h = T // 2
+    blocks = []
+    prev_last = None
+    for r, (b0, b1) in enumerate(((0, h), (h, T))):
+        out = vkn.ops.head_forward(mk(b1 - b0, N, H, W), packs, xs[b0:b1], pfs[b0:b1], mps[b0:b1], None, case['up'],
+                                   clip_first_prev=first)
+        if r > 0:   # what rank r does after the neighbour hand-over
+            out[4][0:1].copy_(vkn.ops.track_link(mk(1, N, H, W), packs[-1], out[0][0:1], prev_last))
+        prev_last = out[0][-1:].clone()
+        blocks.append(out)
+    for k in range(5):
+        assert torch.equal(torch.cat([b[k] for b in blocks], 0), whole[k]), k
