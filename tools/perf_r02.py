@@ -141,7 +141,7 @@ def main():
             wb = B * N * P * 16 * 4
             print(f'upsample x4 B={B}: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s of writes', flush=True)
             if not args.release:
-                for mode in (24, 11, 18, 19, 34):   # 2x plain stores, x1 one row group, x8 / x9 = 8 / 32 groups per WG, 3x write-only
+                for mode in (24, 11, 64, 74, 34):   # plain stores, one row group per WG, nontemporal input loads, all loads up front, write-only   # 2x plain stores, x1 one row group, x8 / x9 = 8 / 32 groups per WG, 3x write-only
                     os.environ['VKN_UPSAMPLE'] = str(mode)
                     t = timeit(lambda: vkn.ops.upsample_bilinear(m, 4), reps=10, warm=3)
                     print(f'upsample x4 B={B} mode={mode}: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s of writes', flush=True)

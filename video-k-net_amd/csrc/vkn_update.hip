@@ -1078,8 +1078,20 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
             const int y = min(max(yb0 - 1 + r, 0), H - 1);
             float v[NTAP];
 #pragma unroll
-            for (int i = 0; i < NTAP; ++i) v[i] = (NT == 2) ? (float)(y + cx[i]) : ip[(size_t)y * W + cx[i]];  // NT == 2: write-only ablation (debug)
+            for (int i = 0; i < NTAP; ++i) v[i] = (NT == 2) ? (float)(y + cx[i]) : (NT == 3) ? __builtin_nontemporal_load(ip + (size_t)y * W + cx[i]) : ip[(size_t)y * W + cx[i]];  // NT == 2: write-only ablation, 3: nontemporal input loads (debug A/B)
             hinterp(v, hrow[r]);
+        }
+        // NT == 4: ALL input rows of the workgroup are requested up front — no load sits between store bursts
+        float pre[NT == 4 ? SUBS : 1][UP_ROWS][NTAP];
+        if (NT == 4) {
+#pragma unroll
+            for (int sb = 0; sb + 1 < SUBS; ++sb)
+#pragma unroll
+                for (int r = 0; r < UP_ROWS; ++r) {
+                    const int y = min(yb0 + sb * UP_ROWS + UP_ROWS + 1 + r, H - 1);
+#pragma unroll
+                    for (int i = 0; i < NTAP; ++i) pre[sb][r][i] = ip[(size_t)y * W + cx[i]];
+                }
         }
 #pragma unroll
         for (int sub = 0; sub < SUBS; ++sub) {
@@ -1088,12 +1100,19 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
             // the next group's UP_ROWS new input rows are requested BEFORE this group's 16 stores: vector memory operations
             // retire in order, so loads issued behind a store burst would wait for it
             float nv[UP_ROWS][NTAP];
-            if (sub + 1 < SUBS) {
+            if (NT == 4) {
+                if (sub + 1 < SUBS) {
+#pragma unroll
+                    for (int r = 0; r < UP_ROWS; ++r)
+#pragma unroll
+                        for (int i = 0; i < NTAP; ++i) nv[r][i] = pre[sub][r][i];
+                }
+            } else if (sub + 1 < SUBS) {
 #pragma unroll
                 for (int r = 0; r < UP_ROWS; ++r) {
                     const int y = min(yb + UP_ROWS + 1 + r, H - 1);
 #pragma unroll
-                    for (int i = 0; i < NTAP; ++i) nv[r][i] = (NT == 2) ? (float)(y + cx[i]) : ip[(size_t)y * W + cx[i]];
+                    for (int i = 0; i < NTAP; ++i) nv[r][i] = (NT == 2) ? (float)(y + cx[i]) : (NT == 3) ? __builtin_nontemporal_load(ip + (size_t)y * W + cx[i]) : ip[(size_t)y * W + cx[i]];
                 }
             }
             // vertical blend + store: output rows S * yb .. S * (yb + UP_ROWS) - 1
@@ -1147,7 +1166,9 @@ int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, i
             dim3 grid((H + UP_ROWS * subs - 1) / (UP_ROWS * subs), chunk);
 #define UP_LAUNCH(SV, NTV, SUBV) hipLaunchKernelGGL((k_upsample_s<SV, NTV, SUBV>), grid, dim3(256), 0, stream, ip, op, H, W)
 #ifdef VKN_DEBUG
-            if (S == 4 && mode / 10 == 3) { UP_LAUNCH(4, 2, 4); }  // write-only ablation: the store pattern's own ceiling
+            if (S == 4 && mode / 10 == 6) { UP_LAUNCH(4, 3, 4); }  // nontemporal input loads (A/B)
+            else if (S == 4 && mode / 10 == 7) { UP_LAUNCH(4, 4, 4); }  // all input rows requested up front (A/B)
+            else if (S == 4 && mode / 10 == 3) { UP_LAUNCH(4, 2, 4); }  // write-only ablation: the store pattern's own ceiling
             else if (S == 4 && (mode % 10 == 8 || mode % 10 == 9)) {  // 8 / 32 row groups per workgroup (quarter / whole plane)
                 if (mode % 10 == 8) { grid.x = (H + UP_ROWS * 8 - 1) / (UP_ROWS * 8); UP_LAUNCH(4, 1, 8); }
                 else { grid.x = (H + UP_ROWS * 32 - 1) / (UP_ROWS * 32); UP_LAUNCH(4, 1, 32); }
