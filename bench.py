@@ -374,16 +374,18 @@ def main():
             ach = alg / (dec_ms * 1e-3) / 1e9
             # HBM bytes per launch from the committed PMC profile of this same command (tools/gpu_profile.sh ->
             # profiles/r01_pmc.json); null when the sidecar is absent or was taken at another batch size
-            traffic = None
+            traffic, mfma_util = None, None
             try:
                 side = json.load(open(os.path.join(ROOT, PMC_SIDECAR)))
                 if Bl == side.get('_frames_per_launch') and xeb == 4:
                     traffic = side['k_decode_mfma']['hbm_bytes_per_launch']
+                    mfma_util = side['k_decode_mfma'].get('mfma_util')
             except Exception:  # noqa: BLE001
                 pass
             extra['roofline'] = dict(kernel='k_decode_mfma', bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                                      unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                                      traffic_source=(PMC_SIDECAR if traffic is not None else None),
+                                     mfma_util=mfma_util,   # matrix-pipe busy fraction of this kernel, same sidecar
                                      algorithmic_bytes_per_launch=alg, avg_launch_ms=round(dec_ms, 4),
                                      min_launch_ms=round(dec_live_ms[0], 4), max_launch_ms=round(dec_live_ms[-1], 4),
                                      timed='HIP events recorded by the library around the launch, one pair per timed step',

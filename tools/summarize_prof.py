@@ -90,6 +90,7 @@ if con:
 
 # MFMA utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 32 SIMDs per shader engine) — the
 # counters are reported per shader engine (8 CUs = 32 SIMDs each); ROCm 7.2 has no gfx950 derived-metric section
+mfma_util = {}
 con = db('pmc_mfma')
 print('\n== MFMA utilisation per kernel (SQ_VALU_MFMA_BUSY_CYCLES / (32 SIMDs x GRBM_GUI_ACTIVE), per shader engine) ==')
 if not con:
@@ -98,6 +99,9 @@ else:
     vals = defaultdict(dict)
     for n, ctr, avg in con.execute('select name, counter_name, avg(counter_value) from pmc_events group by name, counter_name'):
         vals[short(n)][ctr] = vals[short(n)].get(ctr, 0.0) + avg
+    for k, v in vals.items():
+        if v.get('GRBM_GUI_ACTIVE'):
+            mfma_util[k] = v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (32.0 * v['GRBM_GUI_ACTIVE'])
     for k, v in sorted(vals.items(), key=lambda kv: -kv[1].get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0))[:12]:
         if v.get('GRBM_GUI_ACTIVE'):
             print(f'{k:48s} MfmaUtil={v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (32.0 * v["GRBM_GUI_ACTIVE"]):6.3f}  '
@@ -131,6 +135,8 @@ if len(sys.argv) > 2 and pmc:
         if k in pmc and 'FETCH_SIZE_KB' in pmc[k] and 'WRITE_SIZE_KB' in pmc[k]:
             side[k] = dict(fetch_size_kb=pmc[k]['FETCH_SIZE_KB'], write_size_kb=pmc[k]['WRITE_SIZE_KB'],
                            hbm_bytes_per_launch=int((2 * pmc[k]['FETCH_SIZE_KB'] + pmc[k]['WRITE_SIZE_KB']) * 1024))
+            if k in mfma_util:  # SQ_VALU_MFMA_BUSY_CYCLES / (32 SIMDs x GRBM_GUI_ACTIVE), all launches of the kernel
+                side[k]['mfma_util'] = round(mfma_util[k], 4)
     try:  # frames per launch of the profiled run, from the bench line rocprofv3 passed through
         import re
         log = open(os.path.join(out, 'bench_trace.log')).read()
