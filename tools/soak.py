@@ -173,12 +173,68 @@ def t_head_c256():
         assert float((a[4] - e[4]).abs().max()) < 1e-4 * max(1.0, float(e[4].abs().max())), tag
 
 
+def t_head_fused():
+    """fused decode->gather pass vs bit words vs fp32 logits between stages, side-stream vs serial link: bit-identical outputs."""
+    from test_host_logic import _cfg
+    C = int(rng.choice([64, 128, 256]))
+    N = int(rng.integers(3, 170))
+    H, W = int(rng.choice([8, 16, 32])), int(rng.choice([8, 16, 64]))   # H * W % 64 == 0: the fused pass is eligible
+    B = int(rng.integers(1, 6))
+    S = int(rng.integers(2, 4))
+    video = bool(rng.integers(0, 2))
+    key = ('fused', C, S, video)
+    if key not in _heads:
+        h = vkn.build_head(_cfg(video, C=C, heads=8, ffn=256 if C < 256 else 2048, ncls=7, n_thing=2, n_stuff=5, S=S, up=2, nprop=50))
+        h.init_weights()
+        _heads[key] = h.to(dev).eval()
+    head = _heads[key]
+    x, pf = torch.randn(B, C, H, W, device=dev), torch.randn(B, N, C, device=dev)
+    mp = torch.randn(B, N, H, W, device=dev) * 3
+    first = torch.randn(1, N, C, device=dev)
+    dims = head.mask_head[0].make_dims(B, N, H, W)
+    packs = [h.stage_pack(torch.device(dev)) for h in head.mask_head]
+    kw = dict(clip_first_prev=first) if video else {}
+    ref = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=4 | 32, **kw)      # fp32 logits hand-off, serial link
+    for fl in (0, 16, 32):
+        out = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=fl, **kw)
+        for u, v in zip(out, ref):
+            assert (u is None and v is None) or torch.equal(u, v), ('fused', fl, C, S, video, B, N, H, W)
+
+
+def t_xhalf():
+    """fp16 / bf16 storage of x: same bits as the fp32 kernels on the rounded x (gather, decode, fused pass, head)."""
+    from test_host_logic import _cfg
+    C = int(rng.choice([64, 128, 256]))
+    N = int(rng.integers(1, 200))
+    H, W = int(rng.choice([8, 16, 24])), int(rng.choice([8, 16, 40]))
+    if (H * W) % 64:
+        W = 16
+    B = int(rng.integers(1, 5))
+    dt = torch.float16 if rng.integers(0, 2) else torch.bfloat16
+    x = torch.randn(B, C, H, W, device=dev)
+    x = torch.where(x.abs() < 2.0 ** -13, torch.full_like(x, 2.0 ** -13), x)      # bf16 -> f16 exact in the normal range
+    xh = x.to(dt)
+    xr = xh.float()
+    m = torch.randn(B, N, H, W, device=dev) * 3
+    k = torch.randn(B, N, C, device=dev) * 0.2
+    kb = torch.randn(B, N, device=dev)
+    hi, lo = vkn.ops.split_planes(k)
+    tag = ('xhalf', str(dt), B, N, C, H, W)
+    a, b = vkn.ops.mask_gather(xh, m), vkn.ops.mask_gather(xr, m)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), tag
+    assert torch.equal(vkn.ops.mask_decode_planes(xh, hi, lo, N, kb), vkn.ops.mask_decode_planes(xr, hi, lo, N, kb)), tag
+    if vkn._lib.lib().vkn_decode_gather_supported(C, H * W):
+        a, b = vkn.ops.decode_gather(xh, hi, lo, N, kb), vkn.ops.decode_gather(xr, hi, lo, N, kb)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), tag
+
+
 _heads = {}
 only = sys.argv[2:]
 with torch.no_grad():
     for name, fn in (('gather / decode', t_gather_decode), ('upsample', t_upsample), ('panoptic joint', t_panoptic),
                      ('head bit vs logits hand-off', t_head_handoff), ('assignment costs', t_assign),
-                     ('kernel init', t_kernel_init), ('head C=256 split vs exact GEMMs', t_head_c256)):
+                     ('kernel init', t_kernel_init), ('head C=256 split vs exact GEMMs', t_head_c256),
+                     ('head fused / bits / logits / side stream', t_head_fused), ('half-storage x', t_xhalf)):
         if not only or any(o in name for o in only):
             section(name, fn)
 print('soak: OK')
