@@ -121,6 +121,13 @@ def main():
                 t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
                 print(f'head without upsample B={B}, k_gemm_s3 ablation {abl} ({nm}): {t:8.1f} us  (24 k_gemm_s3 launches per step)', flush=True)
             os.environ.pop('VKN_GEMM_ABL')
+        if 'ffnabl' in what and not args.release:
+            fp = torch.zeros(1, N, C, device=dev)
+            for abl in (0, 1, 2, 0):
+                os.environ['VKN_FFN_ABL'] = str(abl)
+                t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
+                print(f'head without upsample B={B}, k_ffn_fused ablation {abl} (1 = GEMM 2 without waits, 2 = no GEMM 2): {t:8.1f} us  (4 launches per step)', flush=True)
+            os.environ.pop('VKN_FFN_ABL')
         if 'ffnhs' in what and not args.release:
             fp = torch.zeros(1, N, C, device=dev)
             for hs in (0, 1, 2, 4, 0):

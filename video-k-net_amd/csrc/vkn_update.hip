@@ -520,6 +520,8 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
 #define FF_HLD 256  // bf16 per row of the hidden image.  No padding (LDS is full: 96 + 15 + 48 KB); instead the 16-byte chunk j of row
                     // r lives at chunk j ^ (r & 31), so the 32 rows of a fragment read hit 32 different chunks
 #define FF_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt(0): this wave's LDS DMA has landed (a barrier does not imply it)
+// ABL (debug build, VKN_FFN_ABL; WRONG results, time attribution): 1 = GEMM 2 does not wait for its weight tiles, 2 = no GEMM 2 loop
+template <int ABL>
 __global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __restrict__ X, int ldx, const __bf16* __restrict__ W1p,
                                                              const float* __restrict__ b1, const __bf16* __restrict__ W2p, int M,
                                                              int C, int FF, int HS, float* __restrict__ partial) {
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __rest
         FF_DMA(w2t, 0);
         FF_VMCNT0();
         __syncthreads();
-        for (int kt = 0; kt < 8; ++kt) {
+        for (int kt = 0; kt < (ABL == 2 ? 0 : 8); ++kt) {
             const int cur = kt & 1;
             const bool more = (kt + 1 < 8);
             if (more) FF_DMA(w2t + (size_t)(kt + 1) * GS_WTILE, cur ^ 1);
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __rest
                     FF_MFMA6(acc2, ah, am, al, bp);
                 }
             }
-            FF_VMCNT0();
+            if (ABL != 1) FF_VMCNT0();
             __syncthreads();
         }
     }
@@ -675,9 +677,20 @@ int vkn_launch_ffn_fused(const float* X, int ldx, const void* W1s, const float* 
                          float* partial, const VknEpi& epi2, hipStream_t stream) {
     if (C != 256 || FF % (256 * HS) != 0 || HS < 1 || (ldx % 4) != 0) return VKN_E_SHAPE;
     const size_t lds = (size_t)(2 * GS_WTILE + 2 * GS_ATILE + 3 * GM_BM * FF_HLD) * sizeof(__bf16);
-    VKN_ALLOW_FULL_LDS(k_ffn_fused);
-    hipLaunchKernelGGL(k_ffn_fused, dim3(HS, (M + GM_BM - 1) / GM_BM), dim3(GM_THREADS), lds, stream, X, ldx,
-                       static_cast<const __bf16*>(W1s), b1, static_cast<const __bf16*>(W2s), M, C, FF, HS, partial);
+#define FFN_LAUNCH(ABLV)                                                                                              \
+    do {                                                                                                              \
+        VKN_ALLOW_FULL_LDS(k_ffn_fused<ABLV>);                                                                        \
+        hipLaunchKernelGGL(k_ffn_fused<ABLV>, dim3(HS, (M + GM_BM - 1) / GM_BM), dim3(GM_THREADS), lds, stream, X, ldx, \
+                           static_cast<const __bf16*>(W1s), b1, static_cast<const __bf16*>(W2s), M, C, FF, HS, partial); \
+    } while (0)
+#ifdef VKN_DEBUG
+    const int fabl = vkn_dbg_env("VKN_FFN_ABL", 0);
+    if (fabl == 1) FFN_LAUNCH(1);
+    else if (fabl == 2) FFN_LAUNCH(2);
+    else
+#endif
+        FFN_LAUNCH(0);
+#undef FFN_LAUNCH
     VKN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_rowepi, dim3((M + 3) / 4), dim3(256), 0, stream, partial, HS, M, C, epi2);
     VKN_CHECK_LAUNCH();
