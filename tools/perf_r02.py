@@ -116,11 +116,22 @@ def main():
             print(f'bench step without x4 upsample B={B}: {t:8.1f} us  {B / t * 1e6:9.1f} frames/s', flush=True)
         if 'gemmabl' in what and not args.release:
             fp = torch.zeros(1, N, C, device=dev)
-            for abl, nm in ((0, 'real'), (1, 'no K loop'), (2, 'no row epilogue'), (0, 'real')):
+            for abl, nm in ((0, 'real'), (1, 'no K loop'), (2, 'no row epilogue'), (3, 'no MFMAs (k_gemm_r3)'), (4, 'no A path in the loop (r3)'), (5, 'no barriers in the loop (r3)'), (6, 'no weight loads in the loop (r3)'), (0, 'real')):
                 os.environ['VKN_GEMM_ABL'] = str(abl)
                 t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
                 print(f'head without upsample B={B}, k_gemm_s3 ablation {abl} ({nm}): {t:8.1f} us  (24 k_gemm_s3 launches per step)', flush=True)
             os.environ.pop('VKN_GEMM_ABL')
+        if 'gemmr3' in what and not args.release:
+            fp = torch.zeros(1, N, C, device=dev)
+            outs = {}
+            for r3 in (0, 1, 0, 1):
+                os.environ['VKN_GEMM_R3'] = str(r3)
+                t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
+                outs[r3] = vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp)
+                print(f'head without upsample B={B}, GEMM weights {"global -> registers (k_gemm_r3)" if r3 else "global -> LDS -> registers (k_gemm_s3)"}: {t:8.1f} us', flush=True)
+            same = all((a is None and b is None) or torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+            print(f'  every output bit-identical: {same}', flush=True)
+            os.environ.pop('VKN_GEMM_R3')
         if 'ffnabl' in what and not args.release:
             fp = torch.zeros(1, N, C, device=dev)
             for abl in (0, 1, 2, 0):
