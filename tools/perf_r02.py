@@ -121,6 +121,18 @@ def main():
                 t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
                 print(f'head without upsample B={B}, k_gemm_s3 ablation {abl} ({nm}): {t:8.1f} us  (24 k_gemm_s3 launches per step)', flush=True)
             os.environ.pop('VKN_GEMM_ABL')
+        if 'gemmx16' in what and not args.release:
+            fp = torch.zeros(1, N, C, device=dev)
+            one = [packs[0]]
+            outs = {}
+            for x16 in (0, 1, 0, 1):
+                os.environ['VKN_GEMM_X16'] = str(x16)
+                t = timeit(lambda: vkn.ops.head_forward(dims, packs, x, pfr, mp, None, 1, clip_first_prev=fp), reps=10, warm=3)
+                outs[x16] = vkn.ops.head_forward(dims, one, x, pfr, mp, None, 1)
+                print(f'head without upsample B={B}, GEMMs {"k_gemm_x16 (16 waves, intra-WG split-K)" if x16 else "k_gemm_s3"}: {t:8.1f} us', flush=True)
+            d = [float((a - b).abs().max()) for a, b in zip(outs[0][:3], outs[1][:3])]
+            print(f'  one stage, max |diff| of (kernels, cls, mask logits) between the two: {d}', flush=True)
+            os.environ.pop('VKN_GEMM_X16')
         if 'gemmr3' in what and not args.release:
             fp = torch.zeros(1, N, C, device=dev)
             outs = {}

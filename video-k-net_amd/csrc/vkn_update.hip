@@ -695,6 +695,166 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_r3(VknGemmProb p0, VknGemmP
     }
 }
 
+// k_gemm_x16 — k_gemm_r3 with SIXTEEN waves per workgroup: the K-tiles of the 32 x 256 output tile are split between two groups of
+// eight waves (group g takes tiles kt = g mod 2; group 1's accumulators are added to group 0's through LDS before the epilogue).
+// Why: VKN_GEMM_ABL shows the phases of a K-tile iteration (weight loads, A fetch / split / stash, barrier, LDS fragment reads,
+// MFMAs) running mostly one after the other inside the one workgroup a CU holds — four waves per SIMD instead of two, working on two
+// K-tiles per barrier, overlap them.  128 VGPRs per wave: weight ring of two tiles, epilogue operands loaded after the loop.
+// The sum order differs from k_gemm_s3 / r3 (two interleaved partial sums), so results differ in the last bits.
+template <int ABL>
+__global__ __launch_bounds__(1024) void k_gemm_x16(VknGemmProb p0, VknGemmProb p1, int nprob, int M, int K) {
+    const bool second = (nprob > 1) && (blockIdx.z == 1);
+    const float* __restrict__ A = second ? p1.A : p0.A;
+    const float* __restrict__ A2 = second ? p1.A2 : p0.A2;
+    const float* __restrict__ A3 = second ? p1.A3 : p0.A3;
+    const float* __restrict__ A4 = second ? p1.A4 : p0.A4;
+    const int lda = second ? p1.lda : p0.lda;
+    const __bf16* __restrict__ Wp = static_cast<const __bf16*>(second ? p1.Wsplit : p0.Wsplit);
+    const int Nout = second ? p1.Nout : p0.Nout;
+    const VknEpi epi = second ? p1.epi : p0.epi;
+    extern __shared__ __attribute__((aligned(16))) char smem_x16[];
+    __bf16* Al0 = reinterpret_cast<__bf16*>(smem_x16);             // [group 2][buffer 2][3][32][40]
+    float* T = reinterpret_cast<float*>(Al0 + 4 * GS_ATILE);       // [32][260] output tile (group 0) ...
+    float* T1 = T + GM_BM * GM_LDT;                                // ... and group 1's partial sums
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave16 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave16 >> 3, wave = wave16 & 7;
+    const int g = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+    if (n0 >= Nout) return;
+    const int ktiles = K >> 5;
+    __bf16* Al = Al0 + (size_t)grp * 2 * GS_ATILE;
+
+    const int tg = tid & 511, ar = tg >> 4, aq = tg & 15;
+    const size_t aoff = (size_t)min(m0 + ar, M - 1) * lda + 2 * aq;
+    const float* A2p = A2 ? A2 : A;
+    const float* A3p = A3 ? A3 : A;
+    const float* A4p = A4 ? A4 : A;
+    const bool mul = (A2 != nullptr), two = (A3 != nullptr);
+    const __bf16* wlane = Wp + (size_t)blockIdx.x * ktiles * GS_WTILE + (size_t)(g * 256 + wave * 32 + li) * 8;
+    bf16x8 Wr[2][2][3];
+    f32x2 S0[4], S1[4];
+
+#define X_WLOAD(KT, SLOT)                                                                                                    \
+    do {                                                                                                                     \
+        const __bf16* wt_ = wlane + (size_t)(KT) * GS_WTILE;                                                                 \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                                  \
+            _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)                                                                 \
+                Wr[SLOT][ks_][p_] = *reinterpret_cast<const bf16x8*>(wt_ + (size_t)((p_ * 4 + 2 * ks_) * 256) * 8);         \
+    } while (0)
+#define X_AFETCH(KT, S)                                                             \
+    do {                                                                            \
+        S[0] = *reinterpret_cast<const f32x2*>(A + aoff + (size_t)(KT) * 32);       \
+        S[1] = *reinterpret_cast<const f32x2*>(A2p + aoff + (size_t)(KT) * 32);     \
+        S[2] = *reinterpret_cast<const f32x2*>(A3p + aoff + (size_t)(KT) * 32);     \
+        S[3] = *reinterpret_cast<const f32x2*>(A4p + aoff + (size_t)(KT) * 32);     \
+    } while (0)
+#define X_ASTASH(BUF, S)                                                                          \
+    do {                                                                                          \
+        bf16x2 h_, m_, l_;                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                           \
+            const float v_ = (mul ? S[0][e] * S[1][e] : S[0][e]) + (two ? S[2][e] * S[3][e] : 0.f); \
+            __bf16 hh_, mm_, ll_;                                                                 \
+            vkn_split_bf16x3(v_, hh_, mm_, ll_);                                                  \
+            h_[e] = hh_;                                                                          \
+            m_[e] = mm_;                                                                          \
+            l_[e] = ll_;                                                                          \
+        }                                                                                         \
+        __bf16* d_ = Al + (size_t)(BUF) * GS_ATILE + ar * GS_LDR + 2 * aq;                        \
+        *reinterpret_cast<bf16x2*>(d_) = h_;                                                      \
+        *reinterpret_cast<bf16x2*>(d_ + GM_BM * GS_LDR) = m_;                                     \
+        *reinterpret_cast<bf16x2*>(d_ + 2 * GM_BM * GS_LDR) = l_;                                 \
+    } while (0)
+#define X_MFMA(ABUF, SLOT)                                                                                            \
+    do {                                                                                                              \
+        const __bf16* Ab = Al + (size_t)(ABUF) * GS_ATILE;                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
+            const __bf16* ap = Ab + li * GS_LDR + (ks << 4) + (g << 3);                                               \
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);                                                   \
+            const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);                                  \
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);                              \
+            const bf16x8 bh = Wr[SLOT][ks][0], bm = Wr[SLOT][ks][1], bl = Wr[SLOT][ks][2];                            \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);                                      \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);                                      \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);                                      \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);                                      \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);                                      \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);                                      \
+        }                                                                                                             \
+    } while (0)
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool active = (n0 + wave * 32) < Nout;
+
+    // group g: tiles grp, grp + 2, ...; both groups run jmax iterations (same number of barriers), a group past its last tile
+    // re-reads it and skips the MFMAs
+    const int ng = (ktiles - grp + 1) >> 1;
+    const int jmax = (ABL == 1) ? 0 : (ktiles + 1) >> 1;
+    if (jmax > 0) {
+        const int klast = max(grp + 2 * (ng - 1), 0);
+        auto tile = [&](int j) { return min(grp + 2 * j, klast); };
+        X_AFETCH(tile(0), S0);
+        X_WLOAD(tile(0), 0);
+        X_AFETCH(tile(1), S1);
+        __builtin_amdgcn_sched_barrier(0);
+        X_ASTASH(0, S0);
+        __syncthreads();
+#define X_ITER(J, SLOT, SNEXT, SFETCH, SSTASH)                                                        \
+    do {                                                                                              \
+        X_AFETCH(tile((J) + 2), SFETCH);                                                              \
+        X_WLOAD(tile((J) + 1), SNEXT);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if ((J) < ng) X_MFMA((J) & 1, SLOT);                                                          \
+        X_ASTASH(((J) + 1) & 1, SSTASH);                                                              \
+        __syncthreads();                                                                              \
+    } while (0)
+        for (int j = 0; j < jmax; j += 2) {
+            X_ITER(j, 0, 1, S0, S1);
+            if (j + 1 >= jmax) break;
+            X_ITER(j + 1, 1, 0, S1, S0);
+        }
+#undef X_ITER
+    }
+#undef X_WLOAD
+#undef X_AFETCH
+#undef X_ASTASH
+#undef X_MFMA
+
+    // group 1 -> LDS, group 0 adds (fixed order) and publishes the tile
+    if (grp == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T1[vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li] = acc[r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li;
+            T[o] = active ? acc[r] + T1[o] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (ABL == 2) return;
+    const int ncols = min(GM_BN, Nout - n0);
+    VknEpiCols cols;
+    vkn_epi_load_cols(epi, ncols, n0, lane, cols);
+#pragma unroll
+    for (int i = 0; i < GM_BM / 16; ++i) {
+        const int rl = wave16 * (GM_BM / 16) + i, row = m0 + rl;
+        if (row < M) {  // uniform
+            VknEpiRow pre;
+            vkn_epi_load_row(epi, cols, row, pre);
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = T[rl * GM_LDT + lane + 64 * q];
+            vkn_row_epilogue(epi, cols, row, ncols, lane, v, pre);
+        }
+    }
+}
+
 #endif  // VKN_DEBUG (k_gemm_r3)
 
 // ------------------------------------------------------------------------------------------------ fused FFN
@@ -1151,6 +1311,14 @@ int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int
                            K, partial);                                                                                   \
     } while (0)
         const bool r3 = vkn_dbg_env("VKN_GEMM_R3", 0) != 0;  // A/B: register-streamed weights (k_gemm_r3)
+        if (vkn_dbg_env("VKN_GEMM_X16", 0) != 0 && ksplit == 1) {  // A/B: 16 waves, intra-workgroup split-K (k_gemm_x16)
+            const size_t lds_x = (size_t)4 * GS_ATILE * sizeof(__bf16) + (size_t)2 * GM_BM * GM_LDT * sizeof(float);
+            const int xabl = vkn_dbg_env("VKN_GEMM_ABL", 0);
+            VKN_ALLOW_FULL_LDS((k_gemm_x16<0>));
+            VKN_ALLOW_FULL_LDS((k_gemm_x16<1>));
+            if (xabl == 1) hipLaunchKernelGGL((k_gemm_x16<1>), grid, dim3(1024), lds_x, stream, probs[0], probs[nprob > 1 ? 1 : 0], nprob, M, K);
+            else hipLaunchKernelGGL((k_gemm_x16<0>), grid, dim3(1024), lds_x, stream, probs[0], probs[nprob > 1 ? 1 : 0], nprob, M, K);
+        } else {
         const int gabl = vkn_dbg_env("VKN_GEMM_ABL", 0);
         if (gabl == 1) { if (r3) GR3_LAUNCH(1); else GS3_LAUNCH(1); }
         else if (gabl == 2) { if (r3) GR3_LAUNCH(2); else GS3_LAUNCH(2); }
@@ -1159,10 +1327,11 @@ int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int
         else if (gabl == 5) GR3_LAUNCH(5);
         else if (gabl == 6) GR3_LAUNCH(6);
         else if (r3) GR3_LAUNCH(0);
-        else
-#undef GR3_LAUNCH_DUMMY
+        else GS3_LAUNCH(0);
+        }
+#else
+        GS3_LAUNCH(0);
 #endif
-            GS3_LAUNCH(0);
 #undef GS3_LAUNCH
 #ifdef VKN_DEBUG
 #undef GR3_LAUNCH
