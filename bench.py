@@ -470,6 +470,24 @@ def main():
                 torch.cuda.synchronize()
                 per_call[f'frames_per_s_at_{b_}_frames_per_call'] = round(b_ / (e0.elapsed_time(e1) / 30 * 1e-3), 1)
             per_call[f'frames_per_s_at_{B}_frames_per_call'] = round(frames / dt, 1)
+            if world == 1 and NS == 1 and xeb == 4 and B == 32:
+                # ... and at twice the clip length per call (the update chain is latency-bound in M = B x N rows): for the record only
+                try:
+                    x2, pf2, mp2 = synth_inputs(2 * B, device, 1)
+                    dims2 = last.make_dims(2 * B, N, CFG2['H'], CFG2['W'])
+                    pf2 = pf2.reshape(2 * B, N, C)
+                    for _ in range(3):
+                        o2 = vkn.ops.head_forward(dims2, packs, x2, pf2, mp2, None, up, clip_first_prev=first_prev)
+                    e0.record()
+                    for _ in range(10):
+                        o2 = vkn.ops.head_forward(dims2, packs, x2, pf2, mp2, None, up, clip_first_prev=first_prev)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    per_call[f'frames_per_s_at_{2 * B}_frames_per_call'] = round(2 * B / (e0.elapsed_time(e1) / 10 * 1e-3), 1)
+                    del x2, pf2, mp2, o2
+                    torch.cuda.empty_cache()
+                except RuntimeError:   # out of memory on a shared box: skip the extra point
+                    pass
             # the same step with x STORED as fp16 / bf16 (VKN_FLAG_X_F16 / _BF16: fp32 compute, half the x bytes; bit-identical to
             # the fp32 path on the rounded x, tests/test_gpu_xhalf.py) — reported next to the fp32 headline, never as `value`
             variants = {}
