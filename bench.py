@@ -470,6 +470,29 @@ def main():
                 torch.cuda.synchronize()
                 per_call[f'frames_per_s_at_{b_}_frames_per_call'] = round(b_ / (e0.elapsed_time(e1) / 30 * 1e-3), 1)
             per_call[f'frames_per_s_at_{B}_frames_per_call'] = round(frames / dt, 1)
+            if world == 1 and NS == 1:
+                # several independent clips in flight (step i on HIP stream i % 4, e.g. one video per stream): the latency-bound update
+                # chain of one clip runs while another clip's HBM-bound kernels stream (tools/inflight_test.py: 1 / 3 / 4 / 6 streams ->
+                # 8.66 / 9.13 / 9.62 / 9.64 k frames/s).  For the record only: `value` is ONE step at a time on one stream, and the
+                # roofline kernel is timed without a concurrent clip.
+                sts = [torch.cuda.Stream(device=device) for _ in range(4)]
+                keep = [None] * 4
+                for st in sts:
+                    st.wait_stream(torch.cuda.current_stream(device))
+
+                def run_inflight(n):
+                    for i_ in range(n):
+                        with torch.cuda.stream(sts[i_ % 4]):
+                            keep[i_ % 4] = vkn.ops.head_forward(dims, packs, x, pfs[0], mp, None, up, clip_first_prev=first_prev)
+                run_inflight(12)
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                run_inflight(40)
+                torch.cuda.synchronize()
+                th = (time.perf_counter() - th) / 40
+                per_call[f'frames_per_s_at_{B}_frames_per_call_4_clips_in_flight'] = round(B / th, 1)
+                del keep, sts
+                torch.cuda.empty_cache()
             if world == 1 and NS == 1 and xeb == 4 and B == 32:
                 # ... and at twice the clip length per call (the update chain is latency-bound in M = B x N rows): for the record only
                 try:
