@@ -207,6 +207,8 @@ def main():
     ap.add_argument('--frames', type=int, default=32,
                     help='frames of the clip per GPU per step (throughput at 8 / 16 / 32 / 64: 5.3k / 6.7k / 7.7k / 8.4k frames/s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the extra data points of `breakdown` that launch other batch sizes / several clips (profiling runs)')
     ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
     ap.add_argument('--streams', type=int, default=1,
                     help='frame groups of the clip processed on separate HIP streams (measured: no gain, 1 is fastest)')
@@ -470,7 +472,7 @@ def main():
                 torch.cuda.synchronize()
                 per_call[f'frames_per_s_at_{b_}_frames_per_call'] = round(b_ / (e0.elapsed_time(e1) / 30 * 1e-3), 1)
             per_call[f'frames_per_s_at_{B}_frames_per_call'] = round(frames / dt, 1)
-            if world == 1 and NS == 1:
+            if world == 1 and NS == 1 and not args.no_extras:
                 # several independent clips in flight (step i on HIP stream i % 4, e.g. one video per stream): the latency-bound update
                 # chain of one clip runs while another clip's HBM-bound kernels stream (tools/inflight_test.py: 1 / 3 / 4 / 6 streams ->
                 # 8.66 / 9.13 / 9.62 / 9.64 k frames/s).  For the record only: `value` is ONE step at a time on one stream, and the
@@ -493,7 +495,7 @@ def main():
                 per_call[f'frames_per_s_at_{B}_frames_per_call_4_clips_in_flight'] = round(B / th, 1)
                 del keep, sts
                 torch.cuda.empty_cache()
-            if world == 1 and NS == 1 and xeb == 4 and B == 32:
+            if world == 1 and NS == 1 and xeb == 4 and B == 32 and not args.no_extras:
                 # ... and at twice the clip length per call (the update chain is latency-bound in M = B x N rows): for the record only
                 try:
                     x2, pf2, mp2 = synth_inputs(2 * B, device, 1)
