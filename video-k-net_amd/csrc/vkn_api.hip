@@ -374,7 +374,8 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     }
 
     // obj_out is final here: the fused head forks the tracking link onto its side stream at this point
-    if (obj_ready && hipEventRecord(obj_ready, st) != hipSuccess) return VKN_E_LAUNCH;
+    const bool fork_late = vkn_dbg_env("VKN_LINK_FORK_LATE", 0) != 0;  // debug A/B: 1 = fork the link behind the decode launch instead of at obj_out (measured: 8777 vs 8832 frames/s; the decode is equally fast either way)
+    if (obj_ready && !fork_late && hipEventRecord(obj_ready, st) != hipSuccess) return VKN_E_LAUNCH;
 
     // cls and mask branches (:217-227) are independent: layer i of both runs as one grouped launch, then fc_cls + fc_mask
     // (the latter also emits the folded decode bias kb = mask_feat . b_ft).
@@ -469,6 +470,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         }
     }
 
+    if (obj_ready && fork_late && hipEventRecord(obj_ready, st) != hipSuccess) return VKN_E_LAUNCH;
     if (prev_obj && track_out) VKN_TRY(run_link(d, w, pw, obj3, prev_obj, track_out, s, st));
     return VKN_OK;
 }
