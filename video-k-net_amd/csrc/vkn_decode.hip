@@ -152,7 +152,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
         const int p0_ = p_begin + (wave + DEC_WAVES * ld_sl) * DEC_TILE;                                         \
         const int voff_ = (((g << 3) * P + min(2 * li, max(P - 2 - p0_, 0))) << (XH ? 1 : 2));                   \
         const int soff_ = ((ld_ks << 4) * P + p0_) << (XH ? 1 : 2);                                              \
-        if (XH) { /* half storage: the pixel pair is one dword */                                                \
+        if (XH && (OPT & 8)) { /* half storage, paired lanes (debug A/B): lane li loads 4 px x 4 channels (8 B), see DEC_COMPUTE */ \
+            const int vp_ = ((((g << 3) + ((li & 1) << 2)) * P + min(4 * (li >> 1), max(P - 4 - p0_, 0))) << 1);  \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                        \
+                REG[e] = __builtin_amdgcn_raw_buffer_load_b64(xrs, vp_, soff_ + ((e * P) << 1), 3);              \
+        } else if (XH) { /* half storage: the pixel pair is one dword */                                         \
             _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                        \
                 REG[e] = u32x2{__builtin_amdgcn_raw_buffer_load_b32(xrs, voff_, soff_ + ((e * P) << 1), 3), 0u}; \
         } else if (ABL == 2) {                                                                                          \
@@ -186,7 +190,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
         half8 bh0, bl0, bh1, bl1;                                                                                 \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                           \
             _Float16 h_, l_;                                                                                      \
-            const unsigned u0_ = REG[e][0], u1_ = REG[e][1];                                                      \
+            unsigned u0_ = REG[e][0], u1_ = REG[e][1];                                                            \
+            if (XH && (OPT & 8)) { /* lanes 2j / 2j+1 hold channels 0-3 / 4-7 of pixels 4j..4j+3: swap halves via DPP */ \
+                const int e4_ = e & 3, odd_ = li & 1;                                                             \
+                const unsigned own0_ = REG[e4_][0], own1_ = REG[e4_][1];                                          \
+                const unsigned recv_ = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd_ ? own0_ : own1_), 0xB1, 0xF, 0xF, true); \
+                u0_ = (e < 4) ? (odd_ ? recv_ : own0_) : (odd_ ? own1_ : recv_);                                  \
+            }                                                                                                     \
             if (XH == 1) { /* fp16 pair: low half = even pixel */                                                 \
                 bh0[e] = __builtin_bit_cast(_Float16, (unsigned short)(u0_ & 0xFFFFu));                           \
                 bh1[e] = __builtin_bit_cast(_Float16, (unsigned short)(u0_ >> 16));                               \
@@ -628,11 +638,17 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
         hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV, RINGV, BITSV, OPTV, XHV>), grid, block, lds, stream, x, kfh, kfl, kb, out, \
                            N, NPT, n0, C, P, px_per_wg, xcd, fs, bits_out, thr);                               \
     } while (0)
+#ifdef VKN_DEBUG
+#define DEC_LAUNCH_XP() DEC_LAUNCH_X(4, 0, 3, 0, (DEC_OPT_DEFAULT | 8), 2)
+#else
+#define DEC_LAUNCH_XP() DEC_LAUNCH_X(4, 0, 3, 0, DEC_OPT_DEFAULT, 2)
+#endif
     // half-storage x: the shipped variant only (no ablations, ring 3, default OPT)
 #define DEC_LAUNCH_O(NBV, ABLV, RINGV, BITSV, OPTV)                                                            \
     do {                                                                                                       \
         if (xdt == 0) DEC_LAUNCH_X(NBV, ABLV, RINGV, BITSV, OPTV, 0);                                          \
         else if (ABLV != 0 || RINGV != 3 || OPTV != DEC_OPT_DEFAULT) return VKN_E_ARG;                         \
+        else if (NBV == 4 && BITSV == 0 && xdt == 2 && vkn_dbg_env("VKN_DECODE_XPAIR", 0) != 0) DEC_LAUNCH_XP();  \
         else if (xdt == 1) DEC_LAUNCH_X(NBV, 0, 3, BITSV, DEC_OPT_DEFAULT, 1);                                 \
         else DEC_LAUNCH_X(NBV, 0, 3, BITSV, DEC_OPT_DEFAULT, 2);                                               \
     } while (0)
@@ -690,6 +706,7 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
 #undef DEC_LAUNCH
 #undef DEC_LAUNCH_O
 #undef DEC_LAUNCH_X
+#undef DEC_LAUNCH_XP
         VKN_CHECK_LAUNCH();
     }
     return VKN_OK;
