@@ -6,6 +6,7 @@ shortest-augmenting-path solver (`vkn_lsap_f32`, the algorithm scipy uses) — s
 Supported: the costs every shipped config uses — `FocalLossCost` (mmdet 2.18 defaults), `DiceCost(pred_act=True)`,
 `MaskCost(pred_act=True)`, `topk=1`, no boundary cost.  Anything else raises NotImplementedError.
 """
+import numpy as np
 import torch
 
 from . import ops
@@ -19,6 +20,7 @@ class AssignResult:
         self.gt_inds = gt_inds
         self.max_overlaps = max_overlaps
         self.labels = labels
+        self.host_pos_inds = None   # sorted numpy array of the matched prediction indices when the assigner knows them on the host
 
 
 def _cost_cfg(cfg, kind, allowed, defaults):
@@ -71,12 +73,15 @@ class MaskHungarianAssigner:
             return AssignResult(num_gts, gt_inds, None, labels=labels)
         cost = self.cost_matrix(bbox_pred, cls_pred, gt_bboxes, gt_labels)
         rows, cols = ops.lsap(cost)                       # one D2H copy of [N, G] floats, C++ solver on the host
+        rows_host = rows
         rows = torch.from_numpy(rows).to(bbox_pred.device)
         cols = torch.from_numpy(cols).to(bbox_pred.device)
         gt_inds[:] = 0
         gt_inds[rows] = cols + 1
         labels[rows] = gt_labels[cols].to(labels.dtype)
-        return AssignResult(num_gts, gt_inds, None, labels=labels)
+        res = AssignResult(num_gts, gt_inds, None, labels=labels)
+        res.host_pos_inds = np.sort(np.asarray(rows_host, dtype=np.int64))   # the LSAP ran on the host: the sampler needs no device nonzero
+        return res
 
 
 try:  # register beside the reference's class when mmdet is importable (same `type` name, force=True)
