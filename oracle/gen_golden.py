@@ -45,10 +45,10 @@ import knet.det.mask_pseudo_sampler  # noqa: E402,F401  (MaskPseudoSampler)
 import knet.cross_entropy_loss  # noqa: E402,F401  (the reference's own CrossEntropyLoss, registered with force=True)
 from mmdet.models.builder import NECKS, build_head  # noqa: E402
 
-OUT = os.path.join(ROOT, 'tests', 'golden')
+OUT = os.environ.get('VKN_GOLDEN_OUT', os.path.join(ROOT, 'tests', 'golden'))   # tests/test_golden_regen.py regenerates into a tmp dir
 
 
-def head_cfg(video, C, heads, ffn, ncls, n_thing, n_stuff, S, up, nprop):
+def head_cfg(video, C, heads, ffn, ncls, n_thing, n_stuff, S, up, nprop, plink=None, ptype='ffn'):
     """Same dict layout as configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:79-138 (det) and
     configs/det/video_knet_kitti_step/video_knet_s3_r50_*_link_ffn_joint_train.py:78-137 (video)."""
     mh = dict(
@@ -64,7 +64,11 @@ def head_cfg(video, C, heads, ffn, ncls, n_thing, n_stuff, S, up, nprop):
         loss_dice=dict(type='DiceLoss', loss_weight=4.0),
         loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0))
     if video:
-        mh.update(previous='placeholder', previous_type='ffn')
+        # previous_link / previous_type: configs/det/video_knet_kitti_step/video_knet_s3_swin{b,l}_*_joint_update.py:98-100
+        # ('update_dynamic_cov' + 'update'), ..._update_conv_short_track_fc.py:95-97 ('update_dynamic_cov' + 'ffn')
+        mh.update(previous='placeholder', previous_type=ptype)
+        if plink is not None:
+            mh.update(previous_link=plink)
     import copy
     cfg = dict(type='VideoKernelIterHead' if video else 'KernelIterHead', num_thing_classes=n_thing,
                num_stuff_classes=n_stuff, num_stages=S, stage_loss_weights=[1] * S, proposal_feature_channel=C,
@@ -107,6 +111,18 @@ CASES = {
                              B=1, seed=8),
     # BASELINE cfg4 per-frame shape (YouTube-VIS 640x360 -> 48x80): N = 100, 40 thing classes, no stuff, x2 — through the knet head
     # (the knet_vis copy of the stage is the same arithmetic; its registry names are pinned by oracle/gen_golden_vis.py)
+    # the "update" video heads: the LAST stage's kernels are rewritten from the previous frame's kernels before the update
+    # (previous_link='update_dynamic_cov', knet/video/kernel_update_head.py:324-348), tracking embedding through a second
+    # KernelUpdator (previous_type='update', :417-445) or the plain attention link (previous_type='ffn')
+    'video_upd_tiny': dict(video=True, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=3, up=4, nprop=12, N=15, H=8, W=16, B=3, seed=11,
+                           plink='update_dynamic_cov', ptype='update'),
+    'video_updffn_tiny': dict(video=True, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=2, nprop=12, N=15, H=8, W=16, B=2,
+                              seed=12, plink='update_dynamic_cov', ptype='ffn'),
+    'video_upd_cfg': dict(video=True, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=16, W=32, B=2,
+                          seed=13, plink='update_dynamic_cov', ptype='update'),
+    # BASELINE cfg5 as literally worded: 150 proposals + 66 stuff kernels = 216 rows (the reference's VIP-Seg config has 100 + 66)
+    'video_vipseg_n216': dict(video=True, C=256, heads=8, ffn=2048, ncls=124, n_thing=58, n_stuff=66, S=3, up=4, nprop=150, N=216, H=46, W=80,
+                              B=1, seed=14),
     'det_ytvis': dict(video=False, C=256, heads=8, ffn=2048, ncls=40, n_thing=40, n_stuff=0, S=3, up=2, nprop=100, N=100, H=48, W=80, B=2,
                       seed=9),
 }
@@ -123,6 +139,8 @@ def run_case(name, p):
     out = dict(case=np.array([p['C'], p['heads'], p['ffn'], p['ncls'], p['n_thing'], p['n_stuff'], p['S'], p['up'],
                               p['nprop'], N, H, W, B, seed, int(video)], dtype=np.int64),
                keys=np.array(sorted(shapes)), shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
+    if p.get('plink') is not None:
+        out['plink'], out['ptype'] = np.array(p['plink']), np.array(p['ptype'])
     with torch.no_grad():
         # per-stage intermediates straight from the reference's stage modules
         obj, masks = pf, mp
@@ -141,14 +159,34 @@ def run_case(name, p):
                 obj2, masks2 = mr['object_feats'], mr['mask_preds']
             out['track'] = mr['object_feats_track'].numpy()
             assert torch.equal(masks2, m)
+            if p.get('plink') is not None:
+                # the B frames as CONSECUTIVE frames of one video, walked the way the detector does
+                # (knet/video/knet_quansi_dense_embed_fc_joint_train.py:505-525): frame 0 has no previous kernels, frame t > 0 gets
+                # frame t - 1's last-stage object_feats — with previous_link the masks of frame t depend on frame t - 1
+                memo = None
+                for t in range(B):
+                    obj3, masks3 = pf[t:t + 1], mp[t:t + 1]
+                    for s in range(p['S']):
+                        mr3 = head._mask_forward(s, x[t:t + 1], obj3, masks3, metas[:1],
+                                                 previous_obj_feats=memo if s == p['S'] - 1 else None)
+                        obj3, masks3 = mr3['object_feats'], mr3['mask_preds']
+                    memo = obj3
+                    out[f'clip_obj{t}'] = obj3.numpy()
+                    out[f'clip_cls{t}'] = mr3['cls_score'].sigmoid().numpy()
+                    if p['C'] <= 64:
+                        out[f'clip_mask{t}'] = masks3.numpy()
+                    else:
+                        out[f'clip_mask_rowsum{t}'] = masks3.double().sum(dim=(-1, -2)).numpy()
+                    if mr3['object_feats_track'] is not None:
+                        out[f'clip_track{t}'] = mr3['object_feats_track'].numpy()
         else:
             o, c, m, sc = head.simple_test_mask_preds(x, pf, mp, None, metas)
-    assert torch.equal(per_stage[-1][1], m)
+    assert p.get('plink') is not None or torch.equal(per_stage[-1][1], m)   # (previous_link rewrites the last stage's kernels)
     # per (stage, frame, kernel): the smallest |logit - flip point| of the mask that stage hands to the next gather — a kernel whose
     # margins all exceed the fp32 noise of a different summation order cannot flip a bit (free-running parity at large sizes)
     flip = 8.940697e-08
     out['row_margin'] = np.stack([(ms - flip).abs().flatten(2).min(dim=2).values.numpy() for _, ms, _ in per_stage[:-1]])
-    big = name.endswith('_big') or name == 'det_ytvis'
+    big = name.endswith('_big') or name in ('det_ytvis', 'video_vipseg_n216')
     out['object_feats'] = o.numpy()
     out['cls_score'] = c.numpy()
     if not big:
@@ -395,6 +433,9 @@ TRAIN_CASES = {
     # video head: last-stage link to the previous frame's kernels (forward_train_with_previous), x4 upsample
     'train_video': dict(video=True, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=4, nprop=12, N=15, H=8, W=16, B=2,
                         seed=72),
+    # the "update" video head in training: previous_link='update_dynamic_cov' rewrites the last stage's kernels, previous_type='update'
+    'train_video_upd': dict(video=True, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=4, nprop=12, N=15, H=8, W=16, B=2,
+                            seed=74, plink='update_dynamic_cov', ptype='update'),
     # config channels / kernel count
     'train_cfg': dict(video=False, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=2, nprop=100, N=117, H=16, W=32,
                       B=2, seed=73),
@@ -456,6 +497,8 @@ def run_train_case(name, p):
                               W, B, seed, int(video)], dtype=np.int64),
                loss_keys=np.array(sorted(losses)), loss_vals=np.array([float(losses[k]) for k in sorted(losses)], dtype=np.float64),
                total=np.float64(float(total)), assigned=torch.stack(assigned).numpy())
+    if p.get('plink') is not None:
+        out['plink'], out['ptype'] = np.array(p['plink']), np.array(p['ptype'])
     big = p['C'] > 64
 
     def put(tag, t):
@@ -471,7 +514,12 @@ def run_train_case(name, p):
     put('grad_pf', pf.grad)
     named = dict(head.named_parameters())
     gk = [k for k in TRAIN_GRAD_KEYS if k in named]
-    if video:
+    if video and p.get('plink') is not None:
+        gk += ['mask_head.%d.%s' % (p['S'] - 1, k) for k in (
+            'attention_previous_update_link.dynamic_layer.weight', 'attention_previous_link.attn.in_proj_weight',
+            'link_ffn_link.layers.1.weight', 'attention_previous_update_track.fc_layer.weight',
+            'attention_previous_track.attn.out_proj.weight', 'link_ffn_norm_track.weight')]
+    elif video:
         gk += ['mask_head.%d.attention_previous.attn.in_proj_weight' % (p['S'] - 1), 'mask_head.%d.link_ffn.layers.1.weight' % (p['S'] - 1)]
     out['grad_keys'] = np.array(gk)
     for i, k in enumerate(gk):

@@ -51,4 +51,4 @@ if __name__ == '__main__':
             b, l_, ids = trk.match(bboxes=torch.from_numpy(bb), labels=torch.from_numpy(lab), track_feats=torch.from_numpy(em), frame_id=t)
             out[f'{name}_bboxes{t}'], out[f'{name}_labels{t}'], out[f'{name}_ids{t}'] = b.numpy(), l_.numpy(), ids.numpy()
         print(name, 'ok  tracklets created:', int(trk.num_tracklets), ' last frame ids:', ids.tolist())
-    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'qd_tracker.npz'), **out)
+    np.savez_compressed(os.path.join(os.environ.get('VKN_GOLDEN_OUT', os.path.join(ROOT, 'tests', 'golden')), 'qd_tracker.npz'), **out)

@@ -36,7 +36,7 @@ import knet_vis.tracker.kernel_frame_iter_head  # noqa: E402,F401
 import knet.cross_entropy_loss  # noqa: E402,F401
 from mmdet.models.builder import build_head  # noqa: E402
 
-OUT = os.path.join(ROOT, 'tests', 'golden')
+OUT = os.environ.get('VKN_GOLDEN_OUT', os.path.join(ROOT, 'tests', 'golden'))   # tests/test_golden_regen.py regenerates into a tmp dir
 
 
 class AttrDict(dict):
