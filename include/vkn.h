@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VKN_VERSION 0x000100 /* 0.1.0 */
+#define VKN_VERSION 0x000200 /* 0.2.0 */
 
 #define VKN_OK 0
 #define VKN_E_ARG (-1)       /* null pointer / non-positive size */
@@ -205,6 +205,30 @@ int vkn_stage_forward_f32(const VknDims* d, const VknStageWeights* w, const floa
 int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* cur_obj, const float* prev_obj,
                        float* track_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- a previous-frame LINK BLOCK of the video head's last stage (knet/video/kernel_update_head.py:192-236, 324-476):
+ *        kv  = w has kernel_update_conv.* ? KernelUpdator_w(update_feature, prev) : prev
+ *        out = link_ffn_norm(link_ffn(attention_previous_norm(attention_previous(q = cur, k = v = kv, identity = cur))))   (8 heads)
+ *      `w` is a VknStageWeights holding ONLY the block's weights, in the members of the modules the block is made of:
+ *      kernel_update_conv.* (dyn_w .. fc_norm_b; NULL = no updator), attention_previous.* (pa_*), link_ffn.* (lffn*).
+ *      One primitive covers every variant the reference has:
+ *        previous_type "ffn"        cur = the stage's updated kernels, no updator                     -> tracking embedding (:394-415)
+ *        previous_type "update"     ... updator(update_feature = x_feat, prev)                        -> tracking embedding (:417-445)
+ *        previous_type "update_obj" ... updator(update_feature = the updated kernels, prev)           -> tracking embedding (:446-476)
+ *        previous_link "update_dynamic_cov"  cur = the stage's INCOMING kernels, updator(x_feat, prev) -> replaces them    (:324-348)
+ *        previous_link "link_atten"          cur = the stage's incoming kernels, no updator            -> replaces them    (:350-372)
+ *      update_feature, cur, prev, out: [B][N][C].  ws: vkn_stage_workspace_bytes. */
+int vkn_link_block_f32(const VknDims* d, const VknStageWeights* w, const float* update_feature, const float* cur,
+                       const float* prev, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- vkn_stage_forward_f32 for the heads with previous_link / previous_type = "update" | "update_obj"
+ *      (`VideoKernelUpdateHead.forward`, knet/video/kernel_update_head.py:281-541, all branches): link_pre (or NULL) rewrites obj_in
+ *      from prev_obj before the update, link_track (or NULL = the stage's own "ffn" link) produces track_out; track_src: update
+ *      feature of link_track's updator, 1 = x_feat ("update"), 2 = the updated kernels ("update_obj"). */
+int vkn_stage_forward_link_f32(const VknDims* d, const VknStageWeights* w, const VknStageWeights* link_pre,
+                               const VknStageWeights* link_track, int track_src, const float* x, const float* obj_in,
+                               const float* masks_in, const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out,
+                               float* x_feat_out, float* track_out, void* ws, size_t ws_bytes, unsigned flags, void* stream);
+
 /* ---- the [B*N, C] chain of one stage ALONE (ops ii-a, ii-b and the cls / mask FC branches of vkn_stage_forward_f32, no gather,
  *      no decode): x_feat [B][N][C] is given (already feat-transformed), the folded fp32 decode kernels Kf = fc_mask(.) . W_ft
  *      [B][N][C] and bias kb = fc_mask(.) . b_ft [B][N] are returned.  For heads whose gather output is post-processed before the
@@ -230,6 +254,18 @@ int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights
                          const float* proposal_feats, const float* mask_preds_in, const float* prev_obj, float* obj_out,
                          float* cls_prob, float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out,
                          void* ws, size_t ws_bytes, unsigned flags, void* stream);
+
+/* ---- vkn_head_forward_f32 for the "update" video heads (configs/det/video_knet_kitti_step/video_knet_s3_swin{b,l}_*_joint_update.py:
+ *      previous_link="update_dynamic_cov", previous_type="update"; ..._update_conv_short_track_fc.py: "update_dynamic_cov" + "ffn").
+ *      link_pre / link_track / track_src as in vkn_stage_forward_link_f32, applied in the LAST stage (knet/video/kernel_iter_head.py:
+ *      544-546).  With link_pre the masks of frame t depend on the FINAL kernels of frame t-1: under VKN_FLAG_CLIP_LINK (B consecutive
+ *      frames) the last stage's [N x C] chain runs frame by frame between the batched last gather and the batched last decode;
+ *      stages 0..S-2 and every pass over x stay batched.  Without the flag prev_obj is [B][N][C] and the frames are independent. */
+int vkn_head_forward_link_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const VknStageWeights* link_pre,
+                              const VknStageWeights* link_track, int track_src, const float* x, const float* proposal_feats,
+                              const float* mask_preds_in, const float* prev_obj, float* obj_out, float* cls_prob,
+                              float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out, void* ws,
+                              size_t ws_bytes, unsigned flags, void* stream);
 
 /* ---- the same call with two caller-owned hipEvent_t recorded on `stream` immediately before / after the LAST stage's mask-decode
  *      launch (either may be NULL): lets a benchmark time the dominant kernel live, inside its timed steps, instead of in a

@@ -41,7 +41,9 @@ class HeadCfg:
     feat_transform: bool = True
     use_sigmoid_cls: bool = True
     feat_channels: int = 256      # KernelUpdator.feat_channels (== in_channels in every shipped cfg)
-    previous_type: str = ''       # 'ffn' for the shipped video head (knet/video/kernel_update_head.py:173-190)
+    previous_type: str = ''       # tracking embedding: 'ffn' (r50 / VIP-Seg video configs), 'update', 'update_obj'
+                                  # (knet/video/kernel_update_head.py:173-214)
+    previous_link: str = ''       # 'update_dynamic_cov' (swin "update" configs), 'link_atten': rewrites the incoming kernels (:216-258)
     ln_eps: float = 1e-5
     extra: dict = field(default_factory=dict)
 
@@ -104,6 +106,22 @@ def ffn(sd, pfx, x, num_fcs):
     return x + h
 
 
+def link_block(sd, pfx, sfx, with_updator, update_feature, cur, prev, cfg: HeadCfg):
+    """The previous-frame blocks of `VideoKernelUpdateHead.forward` share one shape (knet/video/kernel_update_head.py):
+         prev' = attention_previous_update{sfx}(update_feature, prev)          (only the "update" flavours: :332, :422, :451)
+         t     = attention_previous_norm{sfx}(attention_previous{sfx}(query=cur, key=prev', value=prev', identity=cur))   (8 heads)
+         out   = link_ffn_norm{sfx}(link_ffn{sfx}(t))
+    sfx '' = previous_type 'ffn' (:394-415), '_track' = 'update' / 'update_obj' (:417-476), '_link' = previous_link (:324-372).
+    cur, prev [B,N,C] (K = 1) -> [B,N,C]."""
+    B, N, C = cur.shape
+    if with_updator:
+        prev = kernel_updator(sd, f'{pfx}.attention_previous_update{sfx}', update_feature, prev.reshape(B, N, 1, C), cfg).reshape(B, N, C)
+    q, kv = cur.permute(1, 0, 2), prev.permute(1, 0, 2)
+    t = multihead_attention(sd, f'{pfx}.attention_previous{sfx}', q, kv, kv, q, 8)                    # _num_head = 8 (:165, :219, :242)
+    t = _ln(sd, f'{pfx}.attention_previous_norm{sfx}', t, cfg.ln_eps).permute(1, 0, 2)
+    return _ln(sd, f'{pfx}.link_ffn_norm{sfx}', ffn(sd, f'{pfx}.link_ffn{sfx}', t, cfg.num_ffn_fcs), cfg.ln_eps)
+
+
 def binarize(mask_logits, thr):
     """knet/det/kernel_update_head.py:190-192: (sigmoid(z) > hard_mask_thr).float()."""
     return (mask_logits.sigmoid() > thr).to(mask_logits.dtype)
@@ -137,6 +155,9 @@ def update_head_stage(sd, pfx, x, proposal_feat, mask_preds, cfg: HeadCfg, previ
     m = binarize(gather_mask, cfg.hard_mask_thr)                           # :190-192
     x_feat = mask_gather(x, m)                                             # :195
     pf = proposal_feat.reshape(B, N, C, -1).permute(0, 1, 3, 2)            # :198-200  [B,N,K*K,C]
+    if previous_obj_feats is not None and cfg.previous_link:               # video :324-372: the incoming kernels are rewritten
+        pf = link_block(sd, pfx, '_link', cfg.previous_link == 'update_dynamic_cov', x_feat, pf.reshape(B, N, C),
+                        previous_obj_feats.reshape(B, N, C), cfg).reshape(B, N, 1, C)
     obj = kernel_updator(sd, pfx + '.kernel_update_conv', x_feat, pf, cfg)  # :201
     obj = obj.reshape(B, N, -1).permute(1, 0, 2)                           # :204-205  [N,B,K*K*C]
     obj_att = multihead_attention(sd, pfx + '.attention', obj, obj, obj, obj, cfg.num_heads)
@@ -153,6 +174,10 @@ def update_head_stage(sd, pfx, x, proposal_feat, mask_preds, cfg: HeadCfg, previ
         t = t.permute(1, 0, 2).reshape(B, N, -1, C)
         t = _ln(sd, pfx + '.link_ffn_norm', ffn(sd, pfx + '.link_ffn', t, cfg.num_ffn_fcs), cfg.ln_eps)
         track = t.permute(0, 1, 3, 2).reshape(B, N, C, K, K)               # :536-538
+    elif previous_obj_feats is not None and cfg.previous_type in ('update', 'update_obj'):   # video :417-476
+        uf = x_feat if cfg.previous_type == 'update' else obj.reshape(B, N, C)
+        track = link_block(sd, pfx, '_track', True, uf, obj.reshape(B, N, C), previous_obj_feats.reshape(B, N, C), cfg)
+        track = track.reshape(B, N, C, K, K)
     cls_feat = obj.sum(-2)                                                 # :217
     mask_feat = obj
     for i in range(cfg.num_cls_fcs):                                       # :220-221  Linear(no bias) + LN + ReLU
@@ -239,9 +264,25 @@ def stage_param_shapes(cfg: HeadCfg):
     for i in range(cfg.num_mask_fcs):
         lin(f'mask_fcs.{3 * i}', C, C, bias=False); ln(f'mask_fcs.{3 * i + 1}', C)
     lin('fc_mask', C, C)
+    def updator(ku):
+        lin(ku + '.dynamic_layer', 2 * Cf, C); lin(ku + '.input_layer', 2 * Cf, C)
+        lin(ku + '.input_gate', Cf, C); lin(ku + '.update_gate', Cf, C)
+        for n_ in ('norm_in', 'norm_out', 'input_norm_in', 'input_norm_out'):
+            ln(f'{ku}.{n_}', Cf)
+        lin(ku + '.fc_layer', C, Cf); ln(ku + '.fc_norm', C)
+
+    def block(sfx, with_updator):
+        if with_updator:
+            updator('attention_previous_update' + sfx)
+        mha('attention_previous' + sfx); ln('attention_previous_norm' + sfx, E)
+        ffn_('link_ffn' + sfx); ln('link_ffn_norm' + sfx, C)
+
     if cfg.previous_type == 'ffn':
-        mha('attention_previous'); ln('attention_previous_norm', E)
-        ffn_('link_ffn'); ln('link_ffn_norm', C)
+        block('', False)
+    elif cfg.previous_type in ('update', 'update_obj'):
+        block('_track', True)
+    if cfg.previous_link:
+        block('_link', cfg.previous_link == 'update_dynamic_cov')
     return sh
 
 

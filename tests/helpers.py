@@ -14,13 +14,16 @@ CASE_FIELDS = ('C', 'heads', 'ffn', 'ncls', 'n_thing', 'n_stuff', 'S', 'up', 'np
 def load_golden(name):
     g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
     case = dict(zip(CASE_FIELDS, (int(v) for v in g['case'])))
+    if 'plink' in g:   # the "update" video heads (previous_link / previous_type of the swin configs)
+        case['plink'], case['ptype'] = str(g['plink']), str(g['ptype'])
     return g, case
 
 
 def cfg_of(case) -> HeadCfg:
     return HeadCfg(num_stages=case['S'], in_channels=case['C'], num_heads=case['heads'], num_classes=case['ncls'],
                    mask_upsample_stride=case['up'], feat_channels=case['C'],
-                   previous_type='ffn' if case['video'] else '', extra=dict(feedforward_channels=case['ffn']))
+                   previous_type=case.get('ptype', 'ffn') if case['video'] else '', previous_link=case.get('plink', ''),
+                   extra=dict(feedforward_channels=case['ffn']))
 
 
 def make_case(case, dtype=torch.float32):

@@ -42,7 +42,7 @@ SHAPES = [  # B, N, C, H, W
 def test_library_loaded_and_gpu_visible(vkn):
     assert torch.cuda.is_available()
     assert os.path.exists(vkn._lib.LIBPATH)
-    assert vkn._lib.lib().vkn_version() == 0x000100
+    assert vkn._lib.lib().vkn_version() == 0x000200
 
 
 @pytest.mark.parametrize('flags', [0, 1], ids=['mfma', 'refkernels'])
@@ -140,9 +140,10 @@ def test_kernel_updator_vs_oracle(vkn):
 
 def _build_head(vkn, case):
     from test_host_logic import _cfg
+    over = dict(previous_link=case['plink'], previous_type=case['ptype']) if 'plink' in case else None
     head = vkn.build_head(_cfg(bool(case['video']), C=case['C'], heads=case['heads'], ffn=case['ffn'], ncls=case['ncls'],
                                n_thing=case['n_thing'], n_stuff=case['n_stuff'], S=case['S'], up=case['up'],
-                               nprop=case['nprop']))
+                               nprop=case['nprop'], mask_over=over))
     cfg, sd, x, pf, mp, prev = make_case(case)
     head.load_state_dict(sd, strict=True)
     return head.to(DEV).eval(), (x, pf, mp, prev)

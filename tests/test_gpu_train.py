@@ -52,9 +52,13 @@ def _train_case(vkn, name):
     g = dict(np.load(f'{__import__("helpers").GOLDEN}/{name}.npz', allow_pickle=False))
     from helpers import CASE_FIELDS
     case = dict(zip(CASE_FIELDS, (int(v) for v in g['case'])))
+    over = None
+    if 'plink' in g:
+        case['plink'], case['ptype'] = str(g['plink']), str(g['ptype'])
+        over = dict(previous_link=case['plink'], previous_type=case['ptype'])
     cfgd = vkn.configs.roi_head_cfg(bool(case['video']), C=case['C'], heads=case['heads'], ffn=case['ffn'], ncls=case['ncls'],
                                     n_thing=case['n_thing'], n_stuff=case['n_stuff'], S=case['S'], up=case['up'],
-                                    nprop=case['nprop'], train_cfg=vkn.configs.rcnn_train_cfg(case['S']))
+                                    nprop=case['nprop'], train_cfg=vkn.configs.rcnn_train_cfg(case['S']), mask_over=over)
     head = vkn.build_head(cfgd)
     _, sd, x, pf, mp, prev = make_case(case)
     head.load_state_dict(sd, strict=True)
@@ -75,7 +79,7 @@ def _check_grad(g, tag, got, tol=2e-3):
         assert abs(float(got.double().norm()) - float(g[tag + '_norm'])) < tol * float(g[tag + '_norm']), tag
 
 
-@pytest.mark.parametrize('name', ['train_tiny', 'train_video', 'train_cfg'])
+@pytest.mark.parametrize('name', ['train_tiny', 'train_video', 'train_video_upd', 'train_cfg'])
 def test_forward_train_vs_reference_golden(vkn, name):
     """Losses (every `s{stage}_*` key), per-stage assignments and gradients vs the reference's forward_train."""
     g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, name)

@@ -33,6 +33,21 @@ def test_reference_config_builds_and_state_dict_matches_reference(vkn, video):
     head.load_state_dict({k: torch.zeros(tuple(v.shape)) for k, v in sd.items()}, strict=True)
 
 
+@pytest.mark.parametrize('name', ['video_upd_tiny', 'video_updffn_tiny', 'video_upd_cfg'])
+def test_update_link_configs_build_and_state_dict_matches_reference(vkn, name):
+    """previous_link='update_dynamic_cov' + previous_type='update' | 'ffn' (three shipped swin configs): same module tree / keys."""
+    g, case = load_golden(name)
+    head = vkn.build_head(_cfg(True, C=case['C'], heads=case['heads'], ffn=case['ffn'], ncls=case['ncls'], n_thing=case['n_thing'],
+                               n_stuff=case['n_stuff'], S=case['S'], up=case['up'], nprop=case['nprop'],
+                               mask_over=dict(previous_link=case['plink'], previous_type=case['ptype'])))
+    sd = head.state_dict()
+    assert sorted(sd) == list(g['keys'])
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == list(g['shapes'])
+    last = head.mask_head[-1]
+    assert last._link_names('link')[0] == 'attention_previous_update_link'
+    assert (last._link_names('track')[0] is None) == (case['ptype'] == 'ffn')
+
+
 def test_registry_surface(vkn):
     for name in ('KernelIterHead', 'KernelUpdateHead', 'VideoKernelIterHead', 'VideoKernelUpdateHead'):
         assert vkn.HEADS.get(name) is not None
@@ -54,8 +69,8 @@ def test_unsupported_variants_fail_loudly(vkn):
     with pytest.raises(NotImplementedError):
         vkn.build_head(bad)
     bad = _cfg(True, C=64, ffn=128, S=1)
-    bad['mask_head'][0]['previous_type'] = 'update'
-    with pytest.raises(NotImplementedError):
+    bad['mask_head'][0]['previous_type'] = 'no_such_link'
+    with pytest.raises(ValueError):
         vkn.build_head(bad)
     with pytest.raises(NotImplementedError):
         vkn.build_head(dict(_cfg(False, C=64, ffn=128, S=1), train_cfg=[dict(assigner=dict(type='MaskHungarianAssigner'))]))
@@ -80,7 +95,7 @@ def test_library_exports_every_declared_symbol(vkn):
     for sym in declared:
         assert getattr(L, sym) is not None
     L2 = vkn._lib.lib()
-    assert L2.vkn_version() == 0x000100
+    assert L2.vkn_version() == 0x000200
     assert L2.vkn_strerror(0) == b'ok' and b'workspace' in L2.vkn_strerror(-3)
     assert L2.vkn_sizeof_dims() == ctypes.sizeof(vkn._lib.VknDims)
     assert L2.vkn_sizeof_stage_weights() == ctypes.sizeof(vkn._lib.VknStageWeights)

@@ -36,6 +36,31 @@ def test_oracle_matches_reference_golden(name):
         assert track is None
 
 
+@pytest.mark.parametrize('name', ['video_upd_tiny', 'video_updffn_tiny', 'video_upd_cfg'])
+def test_oracle_update_link_heads_match_reference_golden(name):
+    """previous_link='update_dynamic_cov' / previous_type='update' (knet/video/kernel_update_head.py:324-348, 417-445), incl. the
+    frame-by-frame walk of a video where frame t's last stage is linked to frame t-1's final kernels."""
+    from helpers import make_case
+    from oracle.knet_oracle import iter_head_mask_preds
+    g, case = load_golden(name)
+    shapes = head_param_shapes(cfg_of(case))
+    assert sorted(shapes) == list(g['keys']) and [str(tuple(shapes[k])) for k in sorted(shapes)] == list(g['shapes'])
+    obj, cls, masks, scaled, track = run_oracle(case)
+    assert maxabs(obj, g['object_feats']) < TOL and maxabs(cls, g['cls_score']) < TOL
+    assert maxabs(masks, g['mask_preds']) < 5 * TOL and maxabs(track, g['track']) < TOL
+    cfg, sd, x, pf, mp, _ = make_case(case)
+    memo = None
+    with torch.no_grad():
+        for t in range(case['B']):
+            o, c, m, _, tr = iter_head_mask_preds(sd, x[t:t + 1], pf[t:t + 1], mp[t:t + 1], cfg, previous_obj_feats=memo)
+            memo = o
+            assert maxabs(o, g[f'clip_obj{t}']) < 2 * TOL and maxabs(c, g[f'clip_cls{t}']) < TOL
+            if f'clip_mask{t}' in g:
+                assert maxabs(m, g[f'clip_mask{t}']) < 5 * TOL
+            if f'clip_track{t}' in g:
+                assert maxabs(tr, g[f'clip_track{t}']) < 2 * TOL
+
+
 def test_oracle_matches_reference_golden_cfg1_size():
     g, case = load_golden('det_cfg_big')
     obj, cls, masks, scaled, _ = run_oracle(case)

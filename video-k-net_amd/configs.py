@@ -25,9 +25,12 @@ def mask_head_cfg(video=False, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_s
 
 
 def roi_head_cfg(video=False, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=2, nprop=100, train_cfg=None,
-                 **over):
-    """`roi_head=dict(type='KernelIterHead' | 'VideoKernelIterHead', mask_head=[...] * S)`; `train_cfg=None` = test time."""
-    mh = mask_head_cfg(video, C, heads, ffn, ncls, n_thing, n_stuff, up)
+                 mask_over=None, **over):
+    """`roi_head=dict(type='KernelIterHead' | 'VideoKernelIterHead', mask_head=[...] * S)`; `train_cfg=None` = test time.
+    `mask_over`: overrides of every stage's mask_head dict — e.g. the "update" video configs
+    (configs/det/video_knet_kitti_step/video_knet_s3_swinb_*_joint_update.py:98-100):
+    `mask_over=dict(previous_link='update_dynamic_cov', previous_type='update')`."""
+    mh = mask_head_cfg(video, C, heads, ffn, ncls, n_thing, n_stuff, up, **(mask_over or {}))
     cfg = dict(type='VideoKernelIterHead' if video else 'KernelIterHead', num_thing_classes=n_thing,
                num_stuff_classes=n_stuff, num_stages=S, stage_loss_weights=[1] * S, proposal_feature_channel=C,
                num_proposals=nprop, mask_head=[copy.deepcopy(mh) for _ in range(S)])

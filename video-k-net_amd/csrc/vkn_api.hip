@@ -23,8 +23,23 @@ inline int npt_of(int N) { return (N + 31) / 32 * 32; }
 
 struct StageWs {
     float *part, *cntp, *xraw, *cnt, *xfeat, *params, *inputf, *ig, *ug, *f, *obj1, *qkv, *ao, *obj2, *h, *partial, *t1, *t2,
-        *maskfeat, *kb, *kern32, *lq, *lkv;
+        *maskfeat, *kb, *kern32, *lq, *lkv, *lobj, *lupd, *lf;
     _Float16 *kfh, *kfl;
+};
+
+// Optional previous-frame blocks of the video head's LAST stage (knet/video/kernel_update_head.py:192-236).  A "link block" is
+//   kv  = KernelUpdator_link(update_feature, prev)   (only when the block's weights carry an updator)
+//   out = LN(FFN(LN(cur + MHA_8(q = cur, k = v = kv))))
+// and is described by a VknStageWeights whose kernel_update_conv.* / attention_previous.* / link_ffn.* members hold the block's
+// weights (everything else NULL).  It covers previous_link = "update_dynamic_cov" | "link_atten" (cur = the stage's incoming kernels:
+// the result REPLACES them, :324-372) and previous_type = "ffn" | "update" | "update_obj" (cur = the stage's updated kernels: the
+// result is the tracking embedding, :394-476).
+struct StageOpts {
+    const VknStageWeights* link_pre = nullptr;    // previous_link block, applied to obj_in before the update
+    const float* prev_pre = nullptr;              // its previous-frame kernels [B][N][C]
+    const VknStageWeights* link_track = nullptr;  // previous_type "update" / "update_obj" block (NULL: the stage's own "ffn" link)
+    int track_src = 0;                            // update feature of link_track's updator: 1 = x_feat, 2 = the stage's obj_out
+    bool skip_decode = false;                     // stop after the decode kernels (planes / kern32, kb) are written
 };
 
 // pre-split (bf16x3) copies of the Linear weights, carved from VknStageWeights.prepared in a fixed order
@@ -134,8 +149,12 @@ size_t carve_stage(const VknDims* d, char* base, StageWs* s) {
     s->obj2 = c.take<float>(M * C);
     s->h = c.take<float>(M * FF);
     {
+        // split-K / hidden-split partials: for the whole batch, and for ONE frame (the frame-sequential last stage of the
+        // previous_link heads runs the chain with B = 1 inside a B-frame call, with that shape's own split factors)
         const size_t ks = (size_t)ffn_ksplit((int)M, (int)FF), hs = (size_t)ffn_hsplit((int)M, (int)FF);
-        s->partial = c.take<float>((ks > hs ? ks : hs) * M * C);
+        const size_t ks1 = (size_t)ffn_ksplit((int)N, (int)FF), hs1 = (size_t)ffn_hsplit((int)N, (int)FF);
+        const size_t a = (ks > hs ? ks : hs) * M * C, b1 = (ks1 > hs1 ? ks1 : hs1) * N * C;
+        s->partial = c.take<float>(a > b1 ? a : b1);
     }
     s->t1 = c.take<float>(M * C);
     s->t2 = c.take<float>(M * C);
@@ -144,6 +163,9 @@ size_t carve_stage(const VknDims* d, char* base, StageWs* s) {
     s->kern32 = c.take<float>(M * C);
     s->lq = c.take<float>(M * C);
     s->lkv = c.take<float>(M * 2 * C);
+    s->lobj = c.take<float>(M * C);
+    s->lupd = c.take<float>(M * C);
+    s->lf = c.take<float>(M * C);
     s->kfh = c.take<_Float16>(B * NPT * C);
     s->kfl = c.take<_Float16>(B * NPT * C);
     return (c.off + 255) & ~(size_t)255;
@@ -269,14 +291,59 @@ int run_updator(const VknDims* d, const VknStageWeights* w, const PrepW& pw, con
     return vkn_launch_gemm(s.f, nullptr, C, w->fc_w, pw.fc, M, C, C, 1, nullptr, e, st);           // :90-92
 }
 
-// video tracking link, previous_type == "ffn"                 knet/video/kernel_update_head.py:394-415
+// link block (see StageOpts): video tracking link, previous_type == "ffn"      knet/video/kernel_update_head.py:394-415
+//                                  previous_type == "update" / "update_obj"      :417-476   (updator on x_feat / on obj_feat)
+//                                  previous_link == "update_dynamic_cov"         :324-348   (updator on x_feat; out replaces obj_in)
+//                                  previous_link == "link_atten"                 :350-372
 int run_link(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* cur, const float* prev,
-             float* track_out, const StageWs& s, hipStream_t st) {
+             float* out, const StageWs& s, hipStream_t st, const float* update_feature = nullptr) {
     if (!w->pa_in_w || !w->lffn1_w) return VKN_E_ARG;
-    VKN_TRY(run_attention(d, s, cur, prev, 8, w->pa_in_w, pw.pa_in, pw.pa_in_kv, w->pa_in_b, w->pa_out_w, pw.pa_out, w->pa_out_b,
+    const float* kv = prev;
+    if (w->dyn_w) {
+        if (!update_feature) return VKN_E_ARG;
+        StageWs su = s;
+        su.f = s.lf;  // (C != 256: the unfused mix buffer; `f` itself is a cls / mask branch scratch of the main stream)
+        VKN_TRY(run_updator(d, w, pw, update_feature, nullptr, nullptr, prev, s.lupd, su, st));
+        kv = s.lupd;
+    }
+    VKN_TRY(run_attention(d, s, cur, kv, 8, w->pa_in_w, pw.pa_in, pw.pa_in_kv, w->pa_in_b, w->pa_out_w, pw.pa_out, w->pa_out_b,
                           w->pa_norm_w, w->pa_norm_b, s.t1, st));                                             // _num_head = 8 (:165)
     return run_ffn(d, s, s.t1, w->lffn1_w, pw.lffn1, w->lffn1_b, w->lffn2_w, pw.lffn2, w->lffn2_b, w->lffn_norm_w,
-                   w->lffn_norm_b, track_out, st);
+                   w->lffn_norm_b, out, st);
+}
+
+int carve_pw(const VknDims* d, const VknStageWeights* w, unsigned flags, PrepW* pw) {
+    *pw = PrepW{};
+    if (w->prepared && !(flags & VKN_FLAG_EXACT_GEMM)) {
+        PrepItem items[40];
+        if (carve_prepared(d, w, static_cast<char*>(const_cast<void*>(w->prepared)), pw, items, nullptr) > w->prepared_bytes)
+            return VKN_E_WORKSPACE;
+    }
+    return VKN_OK;
+}
+
+// The LAST stage's logits decode from the planes in `s` (+ the caller's xS up-scaled output when up_out is given): in chunks of
+// up_chunk frames, each chunk's upsample right behind its decode, so the upsample reads logits that are still in the memory-side
+// cache.  Odd H*W / VKN_FLAG_REF_KERNELS: the exact-fp32 kernel on s.kern32.
+int final_decode(const VknDims* d, const float* x, const StageWs& s, const float* kb, float* masks_out, unsigned flags,
+                 hipStream_t st, hipEvent_t prof0, hipEvent_t prof1, float* up_out, int up_stride, int up_chunk, bool* up_done) {
+    const int B = d->B, N = d->N, C = d->C, P = d->H * d->W;
+    if ((flags & VKN_FLAG_REF_KERNELS) || (P & 1)) return vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st);
+    const int ch = (up_out && up_chunk > 0 && up_chunk < B) ? up_chunk : B;
+    const size_t NPTC = (size_t)npt_of(N) * C;
+    for (int b0 = 0; b0 < B; b0 += ch) {
+        const int bn = (B - b0 < ch) ? B - b0 : ch;
+        const float* xb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + (size_t)b0 * C * P * (xdt_of(flags) ? 2 : 4));
+        if (b0 == 0 && prof0 && hipEventRecord(prof0, st) != hipSuccess) return VKN_E_LAUNCH;  // the (first) decode launch alone
+        VKN_TRY(vkn_launch_decode(xb, s.kfh + b0 * NPTC, s.kfl + b0 * NPTC, kb ? kb + (size_t)b0 * N : nullptr,
+                                  masks_out + (size_t)b0 * N * P, bn, N, C, P, st, xdt_of(flags)));
+        if (b0 == 0 && prof1 && hipEventRecord(prof1, st) != hipSuccess) return VKN_E_LAUNCH;
+        if (ch < B)
+            VKN_TRY(vkn_launch_upsample(masks_out + (size_t)b0 * N * P, up_out + (size_t)b0 * N * P * up_stride * up_stride, bn * N,
+                                        d->H, d->W, up_stride, st));
+    }
+    if (ch < B && up_done) *up_done = true;
+    return VKN_OK;
 }
 
 int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in, const float* masks_in,
@@ -285,7 +352,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
               unsigned* bits_out = nullptr, bool cls_sigmoid = false, bool gathered_in = false, bool gather_out = false,
               hipEvent_t prof0 = nullptr, hipEvent_t prof1 = nullptr, const float* xfeat_in = nullptr, float* kern_out = nullptr,
               float* kb_out = nullptr, hipEvent_t obj_ready = nullptr, float* up_out = nullptr, int up_stride = 0, int up_chunk = 0,
-              bool* up_done = nullptr) {
+              bool* up_done = nullptr, const StageOpts* so = nullptr) {
     // xfeat_in / kern_out / kb_out (vkn_stage_chain_f32): the [B*N, C] chain alone — the caller supplies x_feat (already
     // feat-transformed and, for the clip-level VIS heads, merged over the frames of a clip) and receives the folded fp32 decode
     // kernels + bias instead of decoded masks; no gather and no decode are launched, x / masks_in / masks_out are unused.
@@ -301,24 +368,11 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
                                                            // (chain_only: fp32 folded kernels are the output)
     const bool has_ft = w->ft_w != nullptr;
     const int xdt = xdt_of(flags);
-    // the LAST stage's logits decode (+ the caller's xS up-scaled output when up_out is given): in chunks of up_chunk frames, each
-    // chunk's upsample right behind its decode, so the upsample reads logits that are still in the memory-side cache
+    const bool skip_decode = so && so->skip_decode;
+    const bool pre_link = so && so->link_pre && so->prev_pre;
+    const bool need_xfeat = pre_link || (so && so->link_track && so->track_src == 1);  // (the link may run after the stage: side stream)
     auto decode_final = [&](const float* kb) -> int {
-        const int ch = (up_out && up_chunk > 0 && up_chunk < B) ? up_chunk : B;
-        const size_t NPTC = (size_t)npt_of(N) * C;
-        for (int b0 = 0; b0 < B; b0 += ch) {
-            const int bn = (B - b0 < ch) ? B - b0 : ch;
-            const float* xb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + (size_t)b0 * C * P * (xdt_of(flags) ? 2 : 4));
-            if (b0 == 0 && prof0 && hipEventRecord(prof0, st) != hipSuccess) return VKN_E_LAUNCH;  // the (first) decode launch alone
-            VKN_TRY(vkn_launch_decode(xb, s.kfh + b0 * NPTC, s.kfl + b0 * NPTC, kb ? kb + (size_t)b0 * N : nullptr,
-                                      masks_out + (size_t)b0 * N * P, bn, N, C, P, st, xdt_of(flags)));
-            if (b0 == 0 && prof1 && hipEventRecord(prof1, st) != hipSuccess) return VKN_E_LAUNCH;
-            if (ch < B)
-                VKN_TRY(vkn_launch_upsample(masks_out + (size_t)b0 * N * P, up_out + (size_t)b0 * N * P * up_stride * up_stride, bn * N,
-                                            d->H, d->W, up_stride, st));
-        }
-        if (ch < B && up_done) *up_done = true;
-        return VKN_OK;
+        return final_decode(d, x, s, kb, masks_out, flags, st, prof0, prof1, up_out, up_stride, up_chunk, up_done);
     };
     // half-storage x: the MFMA kernels only (whole 64-px tiles); the exact-fp32 reference kernels read fp32
     if (xdt && !chain_only && (ref || (P % 64) != 0)) return VKN_E_SHAPE;
@@ -347,13 +401,21 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     if (xfeat_in) {
         xfeat = const_cast<float*>(xfeat_in);
     } else if (has_ft) {
-        if (!comp || x_feat_out) {
+        if (!comp || x_feat_out || need_xfeat) {
             e.bias = w->ft_b; e.rowscale = s.cnt; e.out = xfeat; e.ldo = C;
             VKN_TRY(vkn_launch_gemm(s.xraw, nullptr, C, w->ft_w, pw.ft, M, C, C, 1, nullptr, e, st));
         }
     } else {
         if (hipMemcpyAsync(xfeat, s.xraw, (size_t)M * C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
             return VKN_E_LAUNCH;
+    }
+
+    // previous_link: the incoming kernels are rewritten from the previous frame's kernels first     knet/video/kernel_update_head.py:324-372
+    if (pre_link) {
+        PrepW pl;
+        VKN_TRY(carve_pw(d, so->link_pre, flags, &pl));
+        VKN_TRY(run_link(d, so->link_pre, pl, obj_in, so->prev_pre, s.lobj, s, st, xfeat));
+        obj_in = s.lobj;
     }
 
     // (ii-a) KernelUpdator                                    knet/kernel_updator.py:56-93
@@ -418,6 +480,8 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         if (chain_only) {
             if (kb_out && hipMemcpyAsync(kb_out, s.kb, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return VKN_E_LAUNCH;
+        } else if (skip_decode) {
+            // the caller decodes all frames at once (frame-sequential last stage)
         } else if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
         else if (gather_out)
             VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt));
@@ -453,8 +517,11 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
                 e = mk_epi(d); e.out = s.kern32; e.ldo = C;
                 VKN_TRY(vkn_launch_gemm(s.maskfeat, nullptr, C, w->ft_wT, pw.ftT, M, C, C, 1, nullptr, e, st));
                 kern = s.kern32;
+            } else if (skip_decode) {
+                if (hipMemcpyAsync(s.kern32, s.maskfeat, (size_t)M * C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return VKN_E_LAUNCH;
             }
-            VKN_TRY(vkn_launch_decode_ref(x, kern, kb, masks_out, B, N, C, P, st));
+            if (!skip_decode) VKN_TRY(vkn_launch_decode_ref(x, kern, kb, masks_out, B, N, C, P, st));
         } else {
             if (has_ft) {
                 e = mk_epi(d); e.plane_hi = s.kfh; e.plane_lo = s.kfl; e.ldo = C; e.rows_per_frame = N; e.NPT = npt_of(N);
@@ -462,7 +529,8 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             } else {
                 VKN_TRY(vkn_launch_split_planes(s.maskfeat, s.kfh, s.kfl, B, N, C, st));
             }
-            if (gather_out)
+            if (skip_decode) {
+            } else if (gather_out)
                 VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P,
                                                        st, xdt));
             else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
@@ -471,8 +539,27 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     }
 
     if (obj_ready && fork_late && hipEventRecord(obj_ready, st) != hipSuccess) return VKN_E_LAUNCH;
-    if (prev_obj && track_out) VKN_TRY(run_link(d, w, pw, obj3, prev_obj, track_out, s, st));
+    if (prev_obj && track_out) {
+        if (so && so->link_track) {   // previous_type "update" (updator on x_feat) / "update_obj" (on obj_feat)        :417-476
+            PrepW pt;
+            VKN_TRY(carve_pw(d, so->link_track, flags, &pt));
+            VKN_TRY(run_link(d, so->link_track, pt, obj3, prev_obj, track_out, s, st, so->track_src == 2 ? obj3 : xfeat));
+        } else {
+            VKN_TRY(run_link(d, w, pw, obj3, prev_obj, track_out, s, st));
+        }
+    }
     return VKN_OK;
+}
+
+// the per-row workspace of frame b alone (B = 1 sub-problem of a B-frame call; gather partials are not per-row: untouched)
+StageWs frame_ws(const StageWs& s, const VknDims* d, int b) {
+    StageWs r = s;
+    const size_t R = (size_t)b * d->N, C = d->C;
+    r.xraw += R * C; r.cnt += R; r.xfeat += R * C; r.params += R * 2 * C; r.inputf += R * 2 * C; r.ig += R * 2 * C; r.ug += R * C;
+    r.f += R * C; r.obj1 += R * C; r.qkv += R * 3 * C; r.ao += R * C; r.obj2 += R * C; r.h += R * d->ff; r.t1 += R * C; r.t2 += R * C;
+    r.maskfeat += R * C; r.kb += R; r.kern32 += R * C; r.lq += R * C; r.lkv += R * 2 * C; r.lobj += R * C; r.lupd += R * C; r.lf += R * C;
+    r.kfh += (size_t)b * npt_of(d->N) * C; r.kfl += (size_t)b * npt_of(d->N) * C;
+    return r;   // (partial: one frame at a time reuses the base)
 }
 
 // workspace of the kernel-initialisation pass
@@ -840,6 +927,46 @@ int vkn_stage_forward_f32(const VknDims* d, const VknStageWeights* w, const floa
                      static_cast<hipStream_t>(stream));
 }
 
+int vkn_stage_forward_link_f32(const VknDims* d, const VknStageWeights* w, const VknStageWeights* link_pre,
+                               const VknStageWeights* link_track, int track_src, const float* x, const float* obj_in,
+                               const float* masks_in, const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out,
+                               float* x_feat_out, float* track_out, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    VKN_TRY(check_dims(d));
+    if (!w || !x || !obj_in || !masks_in || !masks_out || !obj_out) return VKN_E_ARG;
+    if (w->fc_cls_w && !cls_logits) return VKN_E_ARG;
+    if (track_src < 0 || track_src > 2 || (link_track && track_src == 0) || ((link_pre || link_track) && !prev_obj)) return VKN_E_ARG;
+    if (!aligned16(x) || !aligned16(obj_in) || !aligned16(masks_in) || !aligned16(masks_out) || !aligned16(obj_out) ||
+        !aligned16(prev_obj))
+        return VKN_E_ALIGN;
+    if (masks_in == masks_out) return VKN_E_ARG;
+    StageWs s;
+    const size_t need = carve_stage(d, nullptr, &s);
+    if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
+    carve_stage(d, static_cast<char*>(ws), &s);
+    StageOpts so;
+    so.link_pre = link_pre;
+    so.prev_pre = link_pre ? prev_obj : nullptr;
+    so.link_track = track_out ? link_track : nullptr;
+    so.track_src = track_src;
+    return run_stage(d, w, x, obj_in, masks_in, prev_obj, cls_logits, masks_out, obj_out, x_feat_out, track_out, s, flags,
+                     static_cast<hipStream_t>(stream), nullptr, nullptr, false, false, false, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, 0, 0, nullptr, &so);
+}
+
+int vkn_link_block_f32(const VknDims* d, const VknStageWeights* w, const float* update_feature, const float* cur,
+                       const float* prev, float* out, void* ws, size_t ws_bytes, void* stream) {
+    VKN_TRY(check_dims(d));
+    if (!w || !cur || !prev || !out || (w->dyn_w && !update_feature)) return VKN_E_ARG;
+    if (!aligned16(cur) || !aligned16(prev) || !aligned16(out) || !aligned16(update_feature)) return VKN_E_ALIGN;
+    StageWs s;
+    const size_t need = carve_stage(d, nullptr, &s);
+    if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
+    carve_stage(d, static_cast<char*>(ws), &s);
+    PrepW pw;
+    VKN_TRY(carve_pw(d, w, 0, &pw));
+    return run_link(d, w, pw, cur, prev, out, s, static_cast<hipStream_t>(stream), update_feature);
+}
+
 int vkn_stage_chain_f32(const VknDims* d, const VknStageWeights* w, const float* x_feat, const float* obj_in, float* cls_logits,
                         float* kernels_out, float* kb_out, float* obj_out, void* ws, size_t ws_bytes, unsigned flags,
                         void* stream) {
@@ -899,13 +1026,19 @@ size_t vkn_head_workspace_bytes(const VknDims* d) {
     return carve_head(d, nullptr, &s, &a, &b, &c, bits);
 }
 
+static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWeights* stages, const VknStageWeights* link_pre,
+                             const VknStageWeights* link_track, int track_src, const float* x, const float* proposal_feats,
+                             const float* mask_preds_in, const float* prev_obj, float* obj_out, float* cls_prob,
+                             float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out, void* ws,
+                             size_t ws_bytes, unsigned flags, void* stream, void* ev_decode_start, void* ev_decode_stop);
+
 int vkn_head_forward_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const float* x,
                          const float* proposal_feats, const float* mask_preds_in, const float* prev_obj, float* obj_out,
                          float* cls_prob, float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out,
                          void* ws, size_t ws_bytes, unsigned flags, void* stream) {
-    return vkn_head_forward_prof_f32(d, num_stages, stages, x, proposal_feats, mask_preds_in, prev_obj, obj_out, cls_prob,
-                                     mask_preds_out, scaled_out, upsample_stride, track_out, ws, ws_bytes, flags, stream, nullptr,
-                                     nullptr);
+    return head_forward_impl(d, num_stages, stages, nullptr, nullptr, 0, x, proposal_feats, mask_preds_in, prev_obj, obj_out,
+                             cls_prob, mask_preds_out, scaled_out, upsample_stride, track_out, ws, ws_bytes, flags, stream, nullptr,
+                             nullptr);
 }
 
 int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const float* x,
@@ -913,6 +1046,27 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
                               float* cls_prob, float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out,
                               void* ws, size_t ws_bytes, unsigned flags, void* stream, void* ev_decode_start,
                               void* ev_decode_stop) {
+    return head_forward_impl(d, num_stages, stages, nullptr, nullptr, 0, x, proposal_feats, mask_preds_in, prev_obj, obj_out,
+                             cls_prob, mask_preds_out, scaled_out, upsample_stride, track_out, ws, ws_bytes, flags, stream,
+                             ev_decode_start, ev_decode_stop);
+}
+
+int vkn_head_forward_link_f32(const VknDims* d, int num_stages, const VknStageWeights* stages, const VknStageWeights* link_pre,
+                              const VknStageWeights* link_track, int track_src, const float* x, const float* proposal_feats,
+                              const float* mask_preds_in, const float* prev_obj, float* obj_out, float* cls_prob,
+                              float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out, void* ws,
+                              size_t ws_bytes, unsigned flags, void* stream) {
+    if (track_src < 0 || track_src > 2 || (link_track && track_src == 0)) return VKN_E_ARG;
+    return head_forward_impl(d, num_stages, stages, link_pre, link_track, track_src, x, proposal_feats, mask_preds_in, prev_obj,
+                             obj_out, cls_prob, mask_preds_out, scaled_out, upsample_stride, track_out, ws, ws_bytes, flags, stream,
+                             nullptr, nullptr);
+}
+
+static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWeights* stages, const VknStageWeights* link_pre,
+                             const VknStageWeights* link_track, int track_src, const float* x, const float* proposal_feats,
+                             const float* mask_preds_in, const float* prev_obj, float* obj_out, float* cls_prob,
+                             float* mask_preds_out, float* scaled_out, int upsample_stride, float* track_out, void* ws,
+                             size_t ws_bytes, unsigned flags, void* stream, void* ev_decode_start, void* ev_decode_stop) {
     VKN_TRY(check_dims(d));
     if (num_stages <= 0 || !stages || !x || !proposal_feats || !mask_preds_in || !obj_out || !cls_prob || !mask_preds_out)
         return VKN_E_ARG;
@@ -952,13 +1106,51 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
         const float* prev_in_stage = link_after ? nullptr : prev;
         const unsigned* b_in = (use_bits && !use_fused && sidx > 0) ? bits[(sidx - 1) & 1] : nullptr;
         unsigned* b_out = (use_bits && !use_fused && !last) ? bits[sidx & 1] : nullptr;
-        // the last stage's fc_cls epilogue applies the sigmoid and writes the caller's cls_prob directly
-        VKN_TRY(run_stage(d, &stages[sidx], x, o_in, m_in, prev_in_stage, last ? cls_prob : ctmp, m_out, o_out, nullptr,
-                          prev_in_stage ? track_out : nullptr, s, flags, st, b_in, b_out, last, use_fused && sidx > 0,
-                          use_fused && !last, last ? static_cast<hipEvent_t>(ev_decode_start) : nullptr,
-                          last ? static_cast<hipEvent_t>(ev_decode_stop) : nullptr, nullptr, nullptr, nullptr,
-                          (prev && side) ? side->fork : nullptr, (last && scaled_out && upsample_stride > 1) ? scaled_out : nullptr,
-                          upsample_stride, vkn_dbg_env("VKN_LAST_CHUNK", 0), &up_done));
+        // previous_link heads: the last stage's incoming kernels are rewritten from the previous frame's FINAL kernels
+        // (knet/video/kernel_update_head.py:324-348), so with consecutive frames in one call (clip mode) the last stage's [N x C]
+        // chain is frame-sequential: gather (all frames) -> per frame { link, update, interaction, FC branches } -> decode (all
+        // frames).  Everything that streams x stays batched; only ~15 small launches per frame are serialised.
+        const float* prev_pre = (last && link_pre) ? prev_obj : nullptr;
+        const bool seq = prev_pre && (flags & VKN_FLAG_CLIP_LINK) && d->B > 1;
+        StageOpts so;
+        so.link_pre = prev_pre ? link_pre : nullptr;
+        so.prev_pre = prev_pre;
+        so.link_track = (last && track_out) ? link_track : nullptr;
+        so.track_src = track_src;
+        hipEvent_t ev0 = last ? static_cast<hipEvent_t>(ev_decode_start) : nullptr;
+        hipEvent_t ev1 = last ? static_cast<hipEvent_t>(ev_decode_stop) : nullptr;
+        float* up_out = (last && scaled_out && upsample_stride > 1) ? scaled_out : nullptr;
+        if (!seq) {
+            // the last stage's fc_cls epilogue applies the sigmoid and writes the caller's cls_prob directly
+            VKN_TRY(run_stage(d, &stages[sidx], x, o_in, m_in, prev_in_stage, last ? cls_prob : ctmp, m_out, o_out, nullptr,
+                              prev_in_stage ? track_out : nullptr, s, flags, st, b_in, b_out, last, use_fused && sidx > 0,
+                              use_fused && !last, ev0, ev1, nullptr, nullptr, nullptr, (prev && side) ? side->fork : nullptr, up_out,
+                              upsample_stride, vkn_dbg_env("VKN_LAST_CHUNK", 0), &up_done, &so));
+        } else {
+            const VknStageWeights* w = &stages[sidx];
+            const int B = d->B, N = d->N, C = d->C, P = d->H * d->W;
+            if (!(use_fused && sidx > 0)) {  // the stage's gather for all frames (run_stage's step (i))
+                if (flags & VKN_FLAG_REF_KERNELS) VKN_TRY(vkn_launch_gather_ref(x, m_in, d->thr_logit, s.xraw, s.cnt, B, N, C, P, st));
+                else if (b_in) VKN_TRY(vkn_launch_gather_bits(x, b_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt_of(flags)));
+                else VKN_TRY(vkn_launch_gather(x, m_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt_of(flags)));
+            }
+            VknDims d1 = *d;
+            d1.B = 1;
+            so.skip_decode = true;
+            so.link_track = nullptr;  // the tracking link runs batched behind the loop (every frame's kernels are known then)
+            for (int b = 0; b < B; ++b) {
+                const size_t r = (size_t)b * N;
+                const StageWs sb = frame_ws(s, d, b);
+                so.prev_pre = b == 0 ? prev_obj : o_out + (r - N) * C;
+                VKN_TRY(run_stage(&d1, w, x, o_in + r * C, nullptr, nullptr, cls_prob + r * d->ncls, nullptr, o_out + r * C, nullptr,
+                                  nullptr, sb, flags, st, nullptr, nullptr, true, true, false, nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr, 0, 0, nullptr, &so));
+            }
+            if (prev && side && hipEventRecord(side->fork, st) != hipSuccess) return VKN_E_LAUNCH;
+            VKN_TRY(final_decode(d, x, s, w->ft_w ? s.kb : nullptr, m_out, flags, st, ev0, ev1, up_out, upsample_stride,
+                                 vkn_dbg_env("VKN_LAST_CHUNK", 0), &up_done));
+            so.link_track = (last && track_out) ? link_track : nullptr;
+        }
         m_in = m_out;
         o_in = o_out;
         if (prev && link_after) {
@@ -984,13 +1176,11 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
                 pv = pvb;
             }
             PrepW pw{};
-            const VknStageWeights* w = &stages[sidx];
-            if (w->prepared && !(flags & VKN_FLAG_EXACT_GEMM)) {
-                PrepItem items[40];
-                if (carve_prepared(d, w, static_cast<char*>(const_cast<void*>(w->prepared)), &pw, items, nullptr) > w->prepared_bytes)
-                    return VKN_E_WORKSPACE;
-            }
-            VKN_TRY(run_link(d, w, pw, obj_out, pv, track_out, sl, ls));
+            const VknStageWeights* w = so.link_track ? so.link_track : &stages[sidx];
+            VKN_TRY(carve_pw(d, w, flags, &pw));
+            // previous_type "update": the link's own KernelUpdator turns (x_feat, previous kernels) into the keys / values (:417-445);
+            // s.xfeat of the last stage is still intact (nothing after the stage's feat-transform GEMM writes it)
+            VKN_TRY(run_link(d, w, pw, obj_out, pv, track_out, sl, ls, so.link_track ? (track_src == 2 ? obj_out : s.xfeat) : nullptr));
             if (side) {
                 if (hipEventRecord(side->join, side->st) != hipSuccess) return VKN_E_LAUNCH;
                 joined = side;

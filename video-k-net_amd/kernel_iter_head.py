@@ -124,9 +124,12 @@ class KernelIterHead(BaseRoIHead):
         dims = h0.make_dims(B, N, H, W)
         packs = [h.stage_pack(x.device) for h in self.mask_head]
         prev = previous_obj_feats.reshape(B, N, C) if previous_obj_feats is not None else None
+        # previous_link / previous_type="update" blocks of the LAST stage (knet/video/kernel_iter_head.py:544-546)
+        link_pre, link_track, track_src = hl.link_packs(x.device) if (prev is not None or clip_first_prev is not None) else (None, None, 0)
         obj, cls, masks, scaled, track = ops.head_forward(dims, packs, x, proposal_feats.reshape(B, N, C), mask_preds, prev,
                                                           hl.mask_upsample_stride, want_track=want_track, want_scaled=want_scaled,
-                                                          flags=flags, clip_first_prev=clip_first_prev)
+                                                          flags=flags, clip_first_prev=clip_first_prev, link_pre=link_pre,
+                                                          link_track=link_track, track_src=track_src)
         if not hl.loss_cls.use_sigmoid:
             raise NotImplementedError('softmax cls activation (reference :309-310): every shipped config uses sigmoid')
         obj = obj.reshape(B, N, C, K, K)
@@ -418,8 +421,10 @@ class VideoKernelIterHead(KernelIterHead):
         `previous_*` reach the LAST stage only (:544-546).  `return_track=True` (an extension: the reference computes the
         tracking embedding and drops it here) appends object_feats_track."""
         if self._fused_ok(x) and all(isinstance(h, VideoKernelUpdateHead) for h in self.mask_head):
-            link = previous_obj_feats is not None and self.mask_head[-1].previous is not None
-            out = self._head_forward(x, proposal_feats, mask_preds, previous_obj_feats if link else None, want_track=link)
+            last = self.mask_head[-1]
+            link = previous_obj_feats is not None and last.previous is not None
+            out = self._head_forward(x, proposal_feats, mask_preds, previous_obj_feats if link else None,
+                                     want_track=link and last.previous_type is not None)
             return out if return_track else out[:4]
         object_feats, track = proposal_feats, None
         for stage in range(self.num_stages):
@@ -440,8 +445,21 @@ class VideoKernelIterHead(KernelIterHead):
         kernels of frame t do not depend on frame t-1, so all T frames run as one batch; only the tracking
         embedding does: track[t] = link(cur = obj[t], prev = obj[t-1]) with obj[-1] = `first_previous_obj_feats`
         (None = first frame of the video: the reference then uses object_feats as the tracking feature, :474-475).
+        Heads with `previous_link` ("update" configs): the LAST stage's incoming kernels of frame t are rewritten from frame t-1's
+        final kernels, so masks DO depend on the previous frame — the library then runs the last stage's [N x C] chain frame by
+        frame between the batched last gather and the batched last decode (vkn_head_forward_link_f32); the first frame of a video
+        (no previous kernels) runs without the link, exactly like the reference's first `simple_test_with_previous` call.
         -> (object_feats [T,N,C,1,1], cls [T,N,ncls], mask_preds, scaled_mask_preds, object_feats_track [T,N,C,1,1])"""
         last = self.mask_head[-1]
+        if getattr(last, 'previous', None) is not None and getattr(last, 'previous_link', None) is not None \
+                and first_previous_obj_feats is None:
+            # frame 0 has nothing to link to; frames 1.. form a clip whose first previous kernels are frame 0's
+            o0, c0, m0, s0, _ = self._head_forward(x[:1], proposal_feats[:1], mask_preds[:1], want_scaled=want_scaled)
+            if x.shape[0] == 1:
+                return o0, c0, m0, s0, o0
+            o1, c1, m1, s1, t1 = self._head_forward(x[1:], proposal_feats[1:], mask_preds[1:], want_scaled=want_scaled,
+                                                    clip_first_prev=o0)
+            return (torch.cat([o0, o1]), torch.cat([c0, c1]), torch.cat([m0, m1]), torch.cat([s0, s1]), torch.cat([o0, t1]))
         if first_previous_obj_feats is not None and getattr(last, 'previous', None) is not None:
             # the whole clip, link included, in one C call (VKN_FLAG_CLIP_LINK)
             obj, cls, masks, scaled, track = self._head_forward(x, proposal_feats, mask_preds, want_scaled=want_scaled,
@@ -500,9 +518,11 @@ class VideoKernelIterHead(KernelIterHead):
             raise NotImplementedError('the video head is panoptic-only in every shipped config (do_panoptic / merge_joint)')
         if not (self._fused_ok(x) and all(isinstance(h, VideoKernelUpdateHead) for h in self.mask_head)):
             raise NotImplementedError('simple_test_with_previous needs the fused GPU head (eval mode, CUDA tensors)')
-        link = previous_obj_feats is not None and self.mask_head[-1].previous is not None
+        last = self.mask_head[-1]
+        link = previous_obj_feats is not None and last.previous is not None
         obj, cls, masks, scaled, track = self._head_forward(x, proposal_feats, mask_preds,
-                                                            previous_obj_feats if link else None, want_track=link,
+                                                            previous_obj_feats if link else None,
+                                                            want_track=link and last.previous_type is not None,
                                                             want_scaled=self.with_track)
         if is_first or track is None:
             track = obj                                                                                   # :474-475

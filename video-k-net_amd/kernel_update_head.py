@@ -172,12 +172,17 @@ class KernelUpdateHead(nn.Module):
             self._pack_sig = sig
         return self._pack
 
+    def link_packs(self, device):
+        """(link_pre, link_track, track_src) `ops.link_pack`s of the previous-frame blocks (None for the plain heads)."""
+        return None, None, 0
+
     def invalidate_pack(self):
         """Drop the cached C-ABI weight pack (pre-split bf16x3 images, composite weights).  The cache is keyed on every
         parameter's (data_ptr, _version); in-place writes through `param.data` (EMA hooks, some optimizers) bump neither — call
         this after such writes.  `load_state_dict` and `train()` / `eval()` transitions call it automatically."""
         self._pack = None
         self._pack_sig = None
+        self._link_cache = None
 
     def train(self, mode=True):
         if mode != self.training:
@@ -234,6 +239,9 @@ class KernelUpdateHead(nn.Module):
         else:
             x_feat = xraw
         pf = proposal_feat.reshape(B, N, C, -1).permute(0, 1, 3, 2)                                     # :198-199
+        if previous_obj_feats is not None and getattr(self, 'previous_link', None) is not None:         # video :324-372
+            pf = self._link_autograd(self._link_names('link'), x_feat, pf.reshape(B, N, C), previous_obj_feats,
+                                     self.training and self.previous_detach_link).reshape(B, N, -1, C)
         obj_feat = self.kernel_update_conv.forward_autograd(x_feat, pf)                                 # :200
         obj_feat = obj_feat.reshape(B, N, -1).permute(1, 0, 2)                                          # :203-205
         obj_feat = self.attention_norm(self._mha(self.attention, obj_feat))                             # :206
@@ -241,13 +249,10 @@ class KernelUpdateHead(nn.Module):
         if self.with_ffn:
             obj_feat = self.ffn_norm(obj_feat + self.ffn.layers(obj_feat))                              # :214-215
         track = None
-        if previous_obj_feats is not None and self.previous is not None:                                # video :394-415
-            prev = previous_obj_feats.reshape(B, N, C * K * K).permute(1, 0, 2)
-            cur = obj_feat.reshape(B, N, C * K * K).permute(1, 0, 2)
-            t = self.attention_previous_norm(self._mha(self.attention_previous, cur, prev, cur)).permute(1, 0, 2)
-            t = t.reshape(B, N, -1, C)
-            t = self.link_ffn_norm(t + self.link_ffn.layers(t))
-            track = t.permute(0, 1, 3, 2).reshape(B, N, C, K, K)
+        if previous_obj_feats is not None and self.previous is not None and self.previous_type is not None:   # video :394-476
+            uf = {'ffn': None, 'update': x_feat, 'update_obj': obj_feat.reshape(B, N, C)}[self.previous_type]
+            t = self._link_autograd(self._link_names('track'), uf, obj_feat.reshape(B, N, C), previous_obj_feats, False)
+            track = t.reshape(B, N, C, K, K)
         cls_feat = obj_feat.sum(-2)                                                                     # :217-221
         mask_feat = obj_feat
         for layer in self.cls_fcs:
@@ -263,6 +268,22 @@ class KernelUpdateHead(nn.Module):
         new_mask_preds = vag.mask_decode(x, kern, kb)                                                   # :247-260
         return cls_score, new_mask_preds, obj_feat.permute(0, 1, 3, 2).reshape(B, N, C, K, K), x_feat, track
 
+    def _link_names(self, which):
+        raise NotImplementedError
+
+    def _link_autograd(self, names, update_feature, cur, prev, detach_prev):
+        """A link block in torch autograd (include/vkn.h: vkn_link_block_f32): cur, prev [B,N,C] -> [B,N,C]."""
+        upd, att, norm, ffn, ffn_norm = (getattr(self, n) if n is not None else None for n in names)
+        B, N, C = cur.shape
+        prev = prev.reshape(B, N, C)
+        if detach_prev:
+            prev = prev.detach()
+        if upd is not None:
+            prev = upd.forward_autograd(update_feature, prev.reshape(B, N, 1, C)).reshape(B, N, C)
+        q = cur.permute(1, 0, 2)
+        t = norm(self._mha(att, q, prev.permute(1, 0, 2), q)).permute(1, 0, 2)
+        return ffn_norm(t + ffn.layers(t))
+
     def _run(self, x, proposal_feat, mask_preds, previous_obj_feats=None, flags=0):
         B, N = proposal_feat.shape[:2]
         C, K = self.in_channels, self.conv_kernel_size
@@ -270,8 +291,10 @@ class KernelUpdateHead(nn.Module):
         dims = self.make_dims(B, N, H, W)
         obj_in = proposal_feat.reshape(B, N, C)
         prev = previous_obj_feats.reshape(B, N, C) if previous_obj_feats is not None else None
+        link_pre, link_track, track_src = self.link_packs(x.device) if prev is not None else (None, None, 0)
         cls, masks, obj, xfeat, track = ops.stage_forward(dims, self.stage_pack(x.device), x, obj_in, mask_preds, prev,
-                                                          want_track=prev is not None, flags=flags)
+                                                          want_track=prev is not None and self.previous_type is not None,
+                                                          flags=flags, link_pre=link_pre, link_track=link_track, track_src=track_src)
         obj = obj.reshape(B, N, C, K, K)
         if track is not None:
             track = track.reshape(B, N, C, K, K)
@@ -413,14 +436,21 @@ class KernelUpdateHead(nn.Module):
 
 @register_head
 class VideoKernelUpdateHead(KernelUpdateHead):
-    """knet/video/kernel_update_head.py:17-541 with `previous_type='ffn'`, `previous_link=None` (the shipped video config,
-    configs/det/video_knet_kitti_step/video_knet_s3_r50_*_link_ffn_joint_train.py:86-89)."""
+    """knet/video/kernel_update_head.py:17-541.  `previous_type` (tracking embedding): 'ffn' (the r50 / VIP-Seg video configs,
+    configs/det/video_knet_kitti_step/video_knet_s3_r50_*_link_ffn_joint_train.py:86-89), 'update', 'update_obj';
+    `previous_link` (rewrites the stage's incoming kernels from the previous frame's): None, 'update_dynamic_cov'
+    (configs/det/video_knet_kitti_step/video_knet_s3_swin{b,l}_*_joint_update.py:98-100, ..._update_conv_short_track_fc.py:95-97),
+    'link_atten'.  Every block is one `vkn_link_block_f32`."""
 
-    def __init__(self, *args, previous=None, previous_type='ffn', previous_link=None, previous_x_feat=None,
+    _TRACK_TYPES = (None, 'ffn', 'update', 'update_obj')
+    _LINK_TYPES = (None, 'update_dynamic_cov', 'link_atten')
+
+    def __init__(self, *args, previous=None, previous_type=None, previous_link=None, previous_x_feat=None,
                  previous_detach=False, previous_detach_link=False, previous_link_detach=False, **kwargs):
         self._video_cfg = dict(previous=previous, previous_type=previous_type, previous_link=previous_link,
                                previous_x_feat=previous_x_feat, previous_detach=previous_detach,
                                previous_detach_link=previous_detach_link, previous_link_detach=previous_link_detach)
+        self._updator_cfg = kwargs.get('kernel_updator_cfg')
         super().__init__(*args, **kwargs)
 
     def _init_video(self, num_ffn_fcs=2, **kw):
@@ -428,15 +458,52 @@ class VideoKernelUpdateHead(KernelUpdateHead):
             raise TypeError(f'unexpected keyword arguments {sorted(kw)}')
         for k, v in self._video_cfg.items():
             setattr(self, k, v)
-        if self.previous is not None:
-            if self.previous_type != 'ffn' or self.previous_link is not None:
-                raise NotImplementedError("only previous_type='ffn', previous_link=None (the shipped video config) is built; "
-                                          "the reference marks 'update'/'update_obj' as 'not work' (:417,:446)")
-            E = self.in_channels * self.conv_kernel_size ** 2
-            self.attention_previous = _MHAParams(E, 8, 0.0)            # _num_head = 8, _dropout = 0. (:165-166)
-            self.attention_previous_norm = nn.LayerNorm(E)
-            self.link_ffn = _FFNParams(self.in_channels, self.feedforward_channels, num_ffn_fcs, self.dropout)
-            self.link_ffn_norm = nn.LayerNorm(self.in_channels)
+        self._link_cache = None
+        if self.previous is None:
+            return
+        if self.previous_type not in self._TRACK_TYPES or self.previous_link not in self._LINK_TYPES:
+            raise ValueError(f'previous_type must be one of {self._TRACK_TYPES}, previous_link one of {self._LINK_TYPES}')
+        E = self.in_channels * self.conv_kernel_size ** 2
+
+        def block(sfx, updator):   # module names exactly as the reference builds them (:173-258)
+            if updator:
+                cfg = dict(self._updator_cfg) if self._updator_cfg is not None else dict(type='KernelUpdator')
+                setattr(self, 'attention_previous_update' + sfx, build_transformer_layer(cfg))
+            setattr(self, 'attention_previous' + sfx, _MHAParams(E, 8, 0.0))           # _num_head = 8, _dropout = 0. (:165-166)
+            setattr(self, 'attention_previous_norm' + sfx, nn.LayerNorm(E))
+            setattr(self, 'link_ffn' + sfx, _FFNParams(self.in_channels, self.feedforward_channels, num_ffn_fcs, self.dropout))
+            setattr(self, 'link_ffn_norm' + sfx, nn.LayerNorm(self.in_channels))
+
+        if self.previous_type == 'ffn':
+            block('', False)
+        elif self.previous_type in ('update', 'update_obj'):
+            block('_track', True)
+        if self.previous_link == 'update_dynamic_cov':
+            block('_link', True)
+        elif self.previous_link == 'link_atten':
+            block('_link', False)
+
+    def _link_names(self, which):
+        """(updator, attention, norm, ffn, ffn_norm) attribute names of the tracking ('track') / previous_link ('link') block."""
+        if which == 'link':
+            sfx, upd = '_link', self.previous_link == 'update_dynamic_cov'
+        else:
+            sfx, upd = ('', False) if self.previous_type == 'ffn' else ('_track', True)
+        return ('attention_previous_update' + sfx if upd else None, 'attention_previous' + sfx, 'attention_previous_norm' + sfx,
+                'link_ffn' + sfx, 'link_ffn_norm' + sfx)
+
+    def link_packs(self, device):
+        if self.previous is None:
+            return None, None, 0
+        named = dict(self.named_parameters())
+        sig = ops.StagePack.signature(named, device)
+        if self._link_cache is None or self._link_cache[0] != sig:
+            pre = ops.link_pack(named, device, *self._link_names('link')) if self.previous_link is not None else None
+            trk, src = None, 0
+            if self.previous_type in ('update', 'update_obj'):
+                trk, src = ops.link_pack(named, device, *self._link_names('track')), 1 if self.previous_type == 'update' else 2
+            self._link_cache = (sig, pre, trk, src)
+        return self._link_cache[1:]
 
     def forward(self, x, proposal_feat, mask_preds, prev_cls_score=None, mask_shape=None, img_metas=None,
                 previous_obj_feats=None, previous_mask_preds=None, previous_x_feats=None):
@@ -444,6 +511,8 @@ class VideoKernelUpdateHead(KernelUpdateHead):
         self._check_inputs(x, proposal_feat, mask_preds, mask_shape)
         if previous_obj_feats is not None and self.previous is None:
             previous_obj_feats = None      # no link modules were built (reference would fail on attribute access)
+        if previous_obj_feats is not None and self.training and self.previous_detach:
+            previous_obj_feats = previous_obj_feats.detach()                                               # :317-318
         if self._needs_grad(x, proposal_feat):
             return self._forward_autograd(x, proposal_feat, mask_preds, previous_obj_feats)
         cls, masks, obj, xfeat, track = self._run(x, proposal_feat, mask_preds, previous_obj_feats)

@@ -277,13 +277,52 @@ class StagePack:
         return (str(device),) + tuple((k, t.data_ptr(), t._version) for k, t in sorted(named.items()))
 
 
+def link_pack(named: dict, device, updator=None, attention='attention_previous', norm='attention_previous_norm', ffn='link_ffn',
+              ffn_norm='link_ffn_norm'):
+    """The weights of one previous-frame LINK BLOCK (include/vkn.h: vkn_link_block_f32) as a `StagePack`: `named` are the
+    owning stage's parameters, the arguments name the sub-modules the block is made of (`updator` None = no KernelUpdator).
+    E.g. previous_link="update_dynamic_cov": updator='attention_previous_update_link', attention='attention_previous_link',
+    norm='attention_previous_norm_link', ffn='link_ffn_link', ffn_norm='link_ffn_norm_link'
+    (knet/video/kernel_update_head.py:216-236)."""
+    remap = {}
+    for src, dst in ((updator, 'kernel_update_conv'), (attention, 'attention_previous'), (norm, 'attention_previous_norm'),
+                     (ffn, 'link_ffn'), (ffn_norm, 'link_ffn_norm')):
+        if src is None:
+            continue
+        for k, v in named.items():
+            if k.startswith(src + '.'):
+                remap[dst + k[len(src):]] = v
+    return StagePack(remap, device)
+
+
+def _pw(pack):
+    return ctypes.byref(pack.w) if pack is not None else None
+
+
+def link_block(dims: VknDims, pack: StagePack, cur, prev, update_feature=None):
+    """One link block on [B,N,C] kernel sets (see `link_pack`): out = LN(FFN(LN(cur + MHA(cur, kv)))), kv = prev or
+    KernelUpdator(update_feature, prev) when the pack carries an updator."""
+    cur, prev = _req(cur, 'cur'), _req(prev, 'prev')
+    uf = _req(update_feature, 'update_feature') if update_feature is not None else None
+    L = _lib.lib()
+    pack.ensure_prepared(dims)
+    out = torch.empty_like(cur)
+    ws = _workspace(max(L.vkn_stage_workspace_bytes(ctypes.byref(dims)), 256), cur.device)
+    with torch.cuda.device(cur.device):
+        check(L.vkn_link_block_f32(ctypes.byref(dims), ctypes.byref(pack.w), _ptr(uf), _ptr(cur), _ptr(prev), _ptr(out), _ptr(ws),
+                                   ws.numel(), _stream()))
+    return out
+
+
 def make_dims(B, N, C, H, W, heads, ff, ncls, n_cls_fcs, n_mask_fcs, hard_mask_thr=0.5, ln_eps=1e-5):
     return VknDims(B, N, C, H, W, heads, ff, ncls, n_cls_fcs, n_mask_fcs, thr_logit(hard_mask_thr), ln_eps)
 
 
-def stage_forward(dims: VknDims, pack: StagePack, x, obj_in, masks_in, prev_obj=None, want_track=False, flags=0):
+def stage_forward(dims: VknDims, pack: StagePack, x, obj_in, masks_in, prev_obj=None, want_track=False, flags=0, link_pre=None,
+                  link_track=None, track_src=0):
     """One `KernelUpdateHead.forward` on the GPU.  Returns (cls_logits [B,N,ncls], masks [B,N,H,W], obj [B,N,C],
-    x_feat [B,N,C], track [B,N,C] | None)."""
+    x_feat [B,N,C], track [B,N,C] | None).  link_pre / link_track: `link_pack`s of the previous_link / previous_type="update"
+    blocks (vkn_stage_forward_link_f32)."""
     (x, xdt), obj_in, masks_in = _req_x(x), _req(obj_in, 'proposal_feat'), _req(masks_in, 'mask_preds')
     flags |= (0, FLAG_X_F16, FLAG_X_BF16)[xdt]
     B, N, C, H, W = dims.B, dims.N, dims.C, dims.H, dims.W
@@ -294,18 +333,29 @@ def stage_forward(dims: VknDims, pack: StagePack, x, obj_in, masks_in, prev_obj=
     obj = torch.empty((B, N, C), dtype=torch.float32, device=dev)
     xfeat = torch.empty((B, N, C), dtype=torch.float32, device=dev)
     track = None
-    if prev_obj is not None and want_track:
+    if prev_obj is not None and (want_track or link_pre is not None):
         prev_obj = _req(prev_obj, 'previous_obj_feats')
-        track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        if want_track:
+            track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
     else:
         prev_obj = None
+        link_pre = link_track = None
     pack.ensure_prepared(dims)
+    for lp in (link_pre, link_track):
+        if lp is not None:
+            lp.ensure_prepared(dims)
     nb = L.vkn_stage_workspace_bytes(ctypes.byref(dims))  # 0 for unsupported dims: the call below reports the reason
     ws = _workspace(max(nb, 256), dev)
     with torch.cuda.device(dev):
-        check(L.vkn_stage_forward_f32(ctypes.byref(dims), ctypes.byref(pack.w), _ptr(x), _ptr(obj_in), _ptr(masks_in),
-                                      _ptr(prev_obj), _ptr(cls), _ptr(masks), _ptr(obj), _ptr(xfeat), _ptr(track),
-                                      _ptr(ws), ws.numel(), flags, _stream()))
+        if link_pre is not None or link_track is not None:
+            check(L.vkn_stage_forward_link_f32(ctypes.byref(dims), ctypes.byref(pack.w), _pw(link_pre), _pw(link_track),
+                                               int(track_src) if link_track is not None else 0, _ptr(x), _ptr(obj_in), _ptr(masks_in),
+                                               _ptr(prev_obj), _ptr(cls), _ptr(masks), _ptr(obj), _ptr(xfeat), _ptr(track),
+                                               _ptr(ws), ws.numel(), flags, _stream()))
+        else:
+            check(L.vkn_stage_forward_f32(ctypes.byref(dims), ctypes.byref(pack.w), _ptr(x), _ptr(obj_in), _ptr(masks_in),
+                                          _ptr(prev_obj), _ptr(cls), _ptr(masks), _ptr(obj), _ptr(xfeat), _ptr(track),
+                                          _ptr(ws), ws.numel(), flags, _stream()))
     return cls, masks, obj, xfeat, track
 
 
@@ -329,9 +379,10 @@ def stage_chain(dims: VknDims, pack: StagePack, x_feat, obj_in, want_cls=True, f
 
 
 def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=None, upsample_stride=1, want_track=False,
-                 want_scaled=True, flags=0, clip_first_prev=None, decode_events=None):
+                 want_scaled=True, flags=0, clip_first_prev=None, decode_events=None, link_pre=None, link_track=None, track_src=0):
     """The S-stage loop in one C call.  Returns (obj [B,N,C], cls_prob [B,N,ncls], mask_preds [B,N,H,W],
-    scaled_mask_preds [B,N,H*s,W*s] | None, track [B,N,C] | None)."""
+    scaled_mask_preds [B,N,H*s,W*s] | None, track [B,N,C] | None).  link_pre / link_track / track_src: the LAST stage's
+    previous_link / previous_type="update" blocks (`link_pack`; vkn_head_forward_link_f32) — they need prev_obj / clip_first_prev."""
     (x, xdt), pf, mp = _req_x(x), _req(proposal_feats, 'proposal_feats'), _req(mask_preds, 'mask_preds')
     flags |= (0, FLAG_X_F16, FLAG_X_BF16)[xdt]
     B, N, C, H, W = dims.B, dims.N, dims.C, dims.H, dims.W
@@ -354,15 +405,25 @@ def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=N
         prev_obj = _req(clip_first_prev.reshape(1, N, C), 'clip_first_prev')
         track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
         flags |= 8
-    elif prev_obj is not None and want_track:
+    elif prev_obj is not None and (want_track or link_pre is not None):
         prev_obj = _req(prev_obj, 'previous_obj_feats')
-        track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        if want_track:
+            track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
     else:
         prev_obj = None
+        link_pre = link_track = None
+    for lp in (link_pre, link_track):
+        if lp is not None:
+            lp.ensure_prepared(dims)
     nb = L.vkn_head_workspace_bytes(ctypes.byref(dims))
     ws = _workspace(max(nb, 256), dev)
     with torch.cuda.device(dev):
-        if decode_events is not None:
+        if link_pre is not None or link_track is not None:
+            check(L.vkn_head_forward_link_f32(ctypes.byref(dims), S, arr, _pw(link_pre), _pw(link_track),
+                                              int(track_src) if link_track is not None else 0, _ptr(x), _ptr(pf), _ptr(mp),
+                                              _ptr(prev_obj), _ptr(obj), _ptr(cls), _ptr(masks), _ptr(scaled), int(upsample_stride),
+                                              _ptr(track), _ptr(ws), ws.numel(), flags, _stream()))
+        elif decode_events is not None:
             # (start, stop) torch.cuda.Event(enable_timing=True) pair, each recorded once before (that creates the HIP event): the
             # library records them around the last stage's mask-decode launch on the current stream
             e0, e1 = decode_events
