@@ -371,6 +371,41 @@ int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, cons
 /*      cost: HOST fp32 [nr][nc]; writes min(nr, nc) (row, col) pairs sorted by row; returns their number or a negative code */
 int vkn_lsap_f32(const float* cost, int nr, int nc, int* row_ind, int* col_ind);
 
+/* ---- quasi-dense embedding association (the `tracker=dict(type='QuasiDenseEmbedTracker', ...)` of the video configs).  Replaces
+ *      `QuasiDenseEmbedTracker.match(bboxes, labels, track_feats, frame_id) -> (bboxes, labels, ids)` together with the `update_memo`
+ *      and `memo` it calls: knet/video/qdtrack/trackers/quasi_dense_embed_tracker.py:137-207, :47-103, :105-135 (ctor kwargs :11-38).
+ *      One single-workgroup kernel per frame over a device-resident memo (caller-owned `state`, reset once per video): score sort,
+ *      duplicate suppression by IoU, [n x m] bi-softmax / softmax / cosine similarity against tracklets + backdrops, the
+ *      order-dependent greedy assignment, births, momentum update of the matched tracks, backdrop memo, expiry.
+ *      in : bboxes [n][5] (x1, y1, x2, y2, score) fp32, labels [n] int64, embeds [n][embed_dim] fp32 — device pointers, n <= max_dets
+ *      out: out_bboxes [max_dets][5], out_labels [max_dets], out_ids [max_dets] — the SURVIVING detections in score order (the
+ *           reference returns exactly these rows), ids: >= 0 track id, -1 unmatched (kept as backdrop candidate), -2 suppressed;
+ *           out_count[0] = number of surviving detections, out_count[1] = status bits (1: tracklet table full, a birth was dropped).
+ *      Equal scores are ordered by input row (torch's unstable sort leaves that order unspecified).  memo_keep = float(1.0 -
+ *      double(memo_momentum)): Python evaluates `1 - self.memo_momentum` in double before it meets the fp32 tensor. */
+typedef struct VknTrackerCfg {
+    float init_score_thr, obj_score_thr, match_score_thr;
+    float memo_momentum, memo_keep;
+    float nms_conf_thr, nms_backdrop_iou_thr, nms_class_iou_thr;
+    int memo_tracklet_frames, memo_backdrop_frames;
+    int with_cats;      /* 0 / 1 */
+    int match_metric;   /* 0 bisoftmax, 1 softmax, 2 cosine */
+    int max_dets;       /* capacity: detections per frame (<= 256) */
+    int max_tracklets;  /* capacity of the tracklet table (max_tracklets + max(memo_backdrop_frames, 1) * max_dets <= 4096) */
+    int embed_dim;
+} VknTrackerCfg;
+size_t vkn_sizeof_tracker_cfg(void);
+size_t vkn_qd_tracker_state_bytes(const VknTrackerCfg* cfg);
+size_t vkn_qd_tracker_workspace_bytes(const VknTrackerCfg* cfg);
+/* byte offsets inside `state` of {header, id, label, last_frame, acc_frame, bbox[5], velocity[5], embed[E], backdrop count[F],
+ * backdrop label[F][D], backdrop bbox[F][D][5], backdrop embed[F][D][E]}; header ints: next id, live tracklets, backdrop frames,
+ * status, survivors of the last call, calls.  For introspection (`tracker.tracklets`) only. */
+int vkn_qd_tracker_state_layout(const VknTrackerCfg* cfg, size_t* offsets12);
+int vkn_qd_tracker_reset(const VknTrackerCfg* cfg, void* state, size_t state_bytes, void* stream);
+int vkn_qd_tracker_match_f32(const VknTrackerCfg* cfg, void* state, size_t state_bytes, const float* bboxes, const int64_t* labels,
+                             const float* embeds, int n, int frame_id, float* out_bboxes, int64_t* out_labels, int64_t* out_ids,
+                             int* out_count, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

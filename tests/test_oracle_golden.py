@@ -151,3 +151,20 @@ def test_assign_oracle_matches_reference_golden(name):
         gt_inds, lab = hungarian_assign(cost, labels)
     assert maxabs(cost, g['cost']) < 1e-6
     assert np.array_equal(gt_inds.numpy(), g['gt_inds']) and np.array_equal(lab.numpy(), g['labels'])
+
+
+def test_tracker_oracle_ids_bit_exact_vs_reference():
+    """oracle/tracker_oracle.py over the four synthetic videos: surviving detections, labels and ids per frame equal the
+    reference's own tracker class (oracle/gen_golden_tracker.py) for the three match metrics."""
+    from oracle import synth
+    from oracle.tracker_oracle import TrackerOracle
+    g = dict(np.load(os.path.join(GOLDEN, 'qd_tracker.npz'), allow_pickle=False))
+    cfg = dict(init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5, memo_backdrop_frames=1,
+               memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True)
+    for name in ('trk_a', 'trk_b', 'trk_c', 'trk_d'):
+        T, n_obj, emb, n_cls, seed = (int(v) for v in g[name + '_case'])
+        trk = TrackerOracle(**cfg, match_metric=str(g[name + '_metric']))
+        for t, (bb, lab, em, _) in enumerate(synth.tracker_sequence(T, n_obj, emb, n_cls, seed)):
+            b, l_, ids = trk.step(torch.from_numpy(bb), torch.from_numpy(lab), torch.from_numpy(em), t)
+            assert np.array_equal(ids.numpy(), g[f'{name}_ids{t}']), (name, t)
+            assert np.array_equal(l_.numpy(), g[f'{name}_labels{t}']) and np.array_equal(b.numpy(), g[f'{name}_bboxes{t}'])

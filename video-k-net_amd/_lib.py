@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
-SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_api.hip')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_tracker.hip', 'vkn_api.hip')
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares
@@ -24,7 +24,9 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_w
            'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32',
            'vkn_sizeof_panoptic_cfg', 'vkn_panoptic_workspace_bytes', 'vkn_panoptic_joint_f32',
            'vkn_merge_workspace_bytes', 'vkn_panoptic_thing_first_u8',
-           'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_lsap_f32')
+           'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_lsap_f32',
+           'vkn_sizeof_tracker_cfg', 'vkn_qd_tracker_state_bytes', 'vkn_qd_tracker_workspace_bytes', 'vkn_qd_tracker_state_layout',
+           'vkn_qd_tracker_reset', 'vkn_qd_tracker_match_f32')
 
 
 class VknPanopticCfg(ctypes.Structure):
@@ -40,6 +42,14 @@ class VknAssignCfg(ctypes.Structure):
     _fields_ = [('cls_weight', ctypes.c_float), ('dice_weight', ctypes.c_float), ('mask_weight', ctypes.c_float),
                 ('focal_alpha', ctypes.c_float), ('focal_gamma', ctypes.c_float), ('focal_eps', ctypes.c_float),
                 ('dice_eps', ctypes.c_float)]
+
+
+class VknTrackerCfg(ctypes.Structure):
+    """Mirror of include/vkn.h: VknTrackerCfg."""
+    _fields_ = ([(n, ctypes.c_float) for n in ('init_score_thr', 'obj_score_thr', 'match_score_thr', 'memo_momentum', 'memo_keep',
+                                               'nms_conf_thr', 'nms_backdrop_iou_thr', 'nms_class_iou_thr')]
+                + [(n, ctypes.c_int) for n in ('memo_tracklet_frames', 'memo_backdrop_frames', 'with_cats', 'match_metric', 'max_dets',
+                                               'max_tracklets', 'embed_dim')])
 
 
 class VknLibraryError(RuntimeError):
@@ -242,6 +252,20 @@ def lib():
     L.vkn_assign_costs_f32.argtypes = [pA, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp, _fp, c_size, _fp]
     L.vkn_lsap_f32.restype = c_int
     L.vkn_lsap_f32.argtypes = [_fp, c_int, c_int, _fp, _fp]
+    pT = ctypes.POINTER(VknTrackerCfg)
+    L.vkn_sizeof_tracker_cfg.restype = c_size
+    L.vkn_sizeof_tracker_cfg.argtypes = []
+    if L.vkn_sizeof_tracker_cfg() != ctypes.sizeof(VknTrackerCfg):
+        raise VknLibraryError('ctypes mirror of VknTrackerCfg is out of date (size mismatch)')
+    for fn in (L.vkn_qd_tracker_state_bytes, L.vkn_qd_tracker_workspace_bytes):
+        fn.restype = c_size
+        fn.argtypes = [pT]
+    L.vkn_qd_tracker_state_layout.restype = c_int
+    L.vkn_qd_tracker_state_layout.argtypes = [pT, ctypes.POINTER(ctypes.c_size_t)]
+    L.vkn_qd_tracker_reset.restype = c_int
+    L.vkn_qd_tracker_reset.argtypes = [pT, _fp, c_size, _fp]
+    L.vkn_qd_tracker_match_f32.restype = c_int
+    L.vkn_qd_tracker_match_f32.argtypes = [pT, _fp, c_size, _fp, _fp, _fp, c_int, c_int, _fp, _fp, _fp, _fp, _fp, c_size, _fp]
     _LIB = L
     return L
 
