@@ -124,7 +124,7 @@ def cpu_baseline(head_sd, sample_frames=1, runs=6):
                        f'min {sample_frames / ts[-1]:.3f} max {sample_frames / ts[0]:.3f} frames/s')
 
 
-def train_main(args, vkn, vkn_dist, device, world, rank):
+def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
     """BASELINE cfg3: the clip's frames sharded over the ranks, head trained data-parallel (see the module docstring)."""
     B = args.frames if args.frames != 32 else 4            # frames per GPU per step (the inference default of 32 is not a training batch)
     N, C, H, W, up = CFG2['N'], CFG2['C'], CFG2['H'], CFG2['W'], 2
@@ -135,7 +135,7 @@ def train_main(args, vkn, vkn_dist, device, world, rank):
     torch.manual_seed(0)                                   # identical replicas
     head.init_weights()
     head = head.to(device).train()
-    reducer = vkn_dist.BucketedGradAllReducer(head)
+    reducer = vkn_dist.BucketedGradAllReducer(head, force_collectives=dist_on)
     opt = torch.optim.SGD(head.parameters(), lr=1e-4, momentum=0.9)
     x, pf, mp = synth_inputs(B, device, rank)
     x.requires_grad_(True)                                 # gradients flow on into the backbone in the real model
@@ -167,7 +167,7 @@ def train_main(args, vkn, vkn_dist, device, world, rank):
         return loss
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -179,7 +179,7 @@ def train_main(args, vkn, vkn_dist, device, world, rank):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -194,7 +194,7 @@ def train_main(args, vkn, vkn_dist, device, world, rank):
                                                    'per-stage bucketed RCCL gradient all-reduce overlapped with backward, SGD step',
                                           frames_per_gpu_per_step=B, parallelism=f'frame-sharded dp{world}',
                                           head_parameters=nparam, last_loss=round(float(loss), 4)))))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
@@ -215,6 +215,9 @@ def main():
     ap.add_argument('--x-storage', default='fp32', choices=['fp32', 'fp16', 'bf16'],
                     help='storage type of the feature map x (the head computes in fp32 either way; fp32 = the parity-exact headline)')
     ap.add_argument('--train', action='store_true', help='training step (cfg3) instead of the inference headline; see the docstring')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise the RCCL process group and take the multi-rank code path even with ONE rank (tests/test_gpu_rccl.py: '
+                         'the distributed step on a 1-GPU box)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -225,16 +228,19 @@ def main():
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=device)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
 
     import vkn_import
     vkn = vkn_import.load()
     from importlib import import_module
     vkn_dist = import_module('video_k_net_amd.dist')
     if args.train:
-        return train_main(args, vkn, vkn_dist, device, world, rank)
+        return train_main(args, vkn, vkn_dist, device, world, rank, dist_on)
     head = build_head(vkn, device)
     B = args.frames
     x, pf, mp = synth_inputs(B, device, rank)
@@ -262,7 +268,7 @@ def main():
     dims1 = last.make_dims(1, N, CFG2['H'], CFG2['W'])
 
     def step(events=None):
-        if world > 1 and NS == 1:
+        if dist_on and NS == 1:
             # one process per GPU, contiguous blocks of the clip: the whole block — S stages, x4 upsample, the tracking link of
             # frames 1 .. B-1 to their predecessors (VKN_FLAG_CLIP_LINK) — is ONE C-ABI call, as on one GPU; only frame 0 of the
             # block links across ranks: one neighbour hand-over of the previous rank's last [N x C] kernels (120 KB, point to
@@ -298,7 +304,7 @@ def main():
         return outs, track
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -323,7 +329,7 @@ def main():
             prev_t = tb
             long_enough = (time.perf_counter() - t_settle) >= (2.0 if args.settle >= 300 else 0.0)
             done = torch.tensor([1 if (stable >= 2 and long_enough) else 0], device=device, dtype=torch.int32)
-            if world > 1:
+            if dist_on:
                 dist.all_reduce(done, op=dist.ReduceOp.MIN)
             if int(done.item()):
                 break
@@ -342,7 +348,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         dec_live_ms = sorted(e0_.elapsed_time(e1_) for e0_, e1_ in dec_events)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -566,7 +572,7 @@ def main():
                                            'fp32 accumulate everywhere (fp32-class accuracy, DESIGN.md §3); random-init weights'),
                     **extra)
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -127,3 +127,97 @@ def test_bucketed_gradient_allreduce_equals_full_batch_gradients():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert err < 1e-5, err
+
+
+def _robust_worker(rank, world, port, q):
+    """torch's default `zero_grad()` (set_to_none) must not cut the reducer off from the gradients; gradient
+    accumulation under `no_sync()`; buckets with never-used members overlap from the second step on; misuse raises."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import vkn_import
+    vkn_import.load()
+    from importlib import import_module
+    d = import_module('video_k_net_amd.dist')
+    torch.manual_seed(0)
+
+    class Stage(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.used = torch.nn.Linear(8, 8)
+            self.unused = torch.nn.Linear(8, 8)          # like the link modules of the non-last video stages
+
+    net = torch.nn.ModuleDict({'mask_head': torch.nn.ModuleList([Stage(), Stage()])})
+    red = d.BucketedGradAllReducer(net)
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    g = torch.Generator().manual_seed(3)
+    data = torch.randn(4, world * 6, 8, generator=g)       # 4 micro-batches of world * 6 rows
+
+    def loss_of(xb):
+        h = xb
+        for st in net['mask_head']:
+            h = torch.tanh(st.used(h))
+        return (h ** 2).sum()
+
+    def full_grads(batches):
+        ref = {n: torch.zeros_like(p) for n, p in net.named_parameters()}
+        for xb in batches:
+            gs = torch.autograd.grad(loss_of(xb), [p for n, p in net.named_parameters() if '.used.' in n])
+            for (n, _), gi in zip([(n, p) for n, p in net.named_parameters() if '.used.' in n], gs):
+                ref[n] += gi
+        return {n: v / world for n, v in ref.items()}
+
+    res = {}
+    mine = lambda xb: xb[rank * 6:(rank + 1) * 6]  # noqa: E731
+    # step 1: torch's DEFAULT zero_grad (drops the .grad views), one backward
+    opt.zero_grad()
+    assert all(p.grad is None for p in net.parameters())
+    loss_of(mine(data[0])).backward()
+    red.finalize()
+    ref = full_grads([data[0]])
+    res['default_zero_grad'] = max(float((p.grad - ref[n]).abs().max()) for n, p in net.named_parameters() if p.grad is not None)
+    assert all((p.grad is None) == ('.unused.' in n) for n, p in net.named_parameters())
+    assert all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for b in red.buckets for p, v in zip(b['params'], b['views']))
+    # step 2: buckets now know that `unused` never fires -> their all-reduce starts inside backward
+    red.zero_grad()
+    loss_of(mine(data[1])).backward()
+    res['overlap'] = all(b['handle'] is not None for b in red.buckets) if world > 1 else True
+    red.finalize()
+    ref = full_grads([data[1]])
+    res['step2'] = max(float((p.grad - ref[n]).abs().max()) for n, p in net.named_parameters())
+    # step 3: accumulation of two micro-batches, the first under no_sync(); default zero_grad again
+    opt.zero_grad()
+    with red.no_sync():
+        loss_of(mine(data[2])).backward()
+    loss_of(mine(data[3])).backward()
+    red.finalize()
+    ref = full_grads([data[2], data[3]])
+    res['accumulate'] = max(float((p.grad - ref[n]).abs().max()) for n, p in net.named_parameters() if p.grad is not None)
+    # misuse: a second synchronised backward before finalize() must raise, not corrupt an in-flight bucket
+    red.zero_grad()
+    loss_of(mine(data[0])).backward()
+    try:
+        loss_of(mine(data[1])).backward()
+        res['misuse_raises'] = world == 1
+    except RuntimeError:
+        res['misuse_raises'] = True
+    red.finalize()
+    if rank == 0:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_survives_default_zero_grad_accumulation_and_unused_members():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_robust_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res['default_zero_grad'] < 1e-5 and res['step2'] < 1e-5 and res['accumulate'] < 1e-5, res
+    assert res['overlap'] and res['misuse_raises'], res

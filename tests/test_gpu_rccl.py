@@ -1,0 +1,121 @@
+"""GPU (-m gpu): the RCCL path on ONE GPU.  `backend='nccl'` IS RCCL on ROCm; the multi-GPU runs are the driver's, but a process
+group of world_size 1 already goes through RCCL's communicator setup, its stream ordering against the compute stream, the async
+all-reduce handles of `BucketedGradAllReducer` and the batched point-to-point step of `neighbour_last_kernels` — everything except
+the xGMI transport itself.  Also: `bench.py` launched the way the driver launches the N-GPU runs (torch.distributed.run, one rank)
+prints the same metric as the plain run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope='module')
+def rccl_group():
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    yield
+    dist.destroy_process_group()
+
+
+def test_bucketed_reducer_through_rccl(vkn, rccl_group):
+    """Per-stage buckets all-reduced asynchronously from the backward hooks over RCCL (sum over ONE rank = identity): gradients of
+    the head's own torch chain are unchanged, the collectives really were issued, and the step order zero_grad -> backward ->
+    finalize -> optimizer works with torch's default zero_grad."""
+    from importlib import import_module
+    d = import_module('video_k_net_amd.dist')
+    torch.manual_seed(0)
+    C, rows = 64, 48
+    net = torch.nn.ModuleDict({'mask_head': torch.nn.ModuleList(
+        [vkn.KernelUpdator(in_channels=C, feat_channels=C, out_channels=C) for _ in range(3)])}).to(DEV)
+    red = d.BucketedGradAllReducer(net, force_collectives=True)
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    u, k = torch.randn(rows, C, device=DEV), torch.randn(rows, 1, C, device=DEV)
+
+    def loss_of():
+        h = k
+        for m in net['mask_head']:
+            h = m.forward_autograd(u, h)
+        return (h ** 2).mean()
+
+    ref = torch.autograd.grad(loss_of(), list(net.parameters()))
+    for zero in (red.zero_grad, opt.zero_grad, red.zero_grad):
+        zero()
+        loss_of().backward()
+        launched = [b['handle'] is not None for b in red.buckets]
+        red.finalize()
+        opt.step()
+        for p, g in zip(net.parameters(), ref):
+            assert torch.equal(p.grad, g)
+    assert all(launched), 'from the second step on every stage bucket starts its all-reduce inside backward'
+    t = torch.ones(1 << 20, device=DEV)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    assert float(t.sum()) == float(1 << 20)
+
+
+def test_neighbour_exchange_through_rccl(vkn, rccl_group):
+    """The 120 KB hand-over of a block's last kernels as ONE batched isend / irecv — with one rank the neighbour is the rank
+    itself (RCCL pairs the two within the group) — followed by the one-frame link on the compute stream."""
+    from importlib import import_module
+    d = import_module('video_k_net_amd.dist')
+    N, C = 117, 256
+    block = torch.randn(4, N, C, device=DEV)
+    assert d.neighbour_last_kernels(block) is None            # world 1: no neighbour
+    recv = torch.empty(N, C, device=DEV)
+    d.exchange(block[-1].contiguous(), recv, send_to=0, recv_from=0)
+    torch.cuda.synchronize()
+    assert torch.equal(recv, block[-1])
+    prev = d.previous_kernels_for_block(block, first_previous=torch.zeros(1, N, C, device=DEV))
+    assert torch.equal(prev[1:], block[:-1]) and float(prev[0].abs().max()) == 0.0
+
+
+def _bench(args, launcher=()):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('MASTER_PORT', None)
+    cmd = [sys.executable, *launcher, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '40', '--warmup', '10', '--settle', '60',
+           '--no-cpu-baseline', '--no-extras', *args]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+
+
+def test_bench_under_torchrun_one_rank_matches_plain_run():
+    """`python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1 --force-dist`: RCCL initialised, the multi-rank
+    step (clip link in the call + neighbour exchange + barrier + max-over-ranks all-reduce of the time) — same value as the plain
+    single-process run within run-to-run noise."""
+    plain = _bench([])
+    port = _free_port()
+    dist_line = _bench(['--force-dist'], launcher=['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                                                 '127.0.0.1', '--master-port', str(port)])
+    assert dist_line['n_gpus'] == 1 and dist_line['metric'] == plain['metric']
+    ratio = dist_line['value'] / plain['value']
+    print(f'plain {plain["value"]} frames/s, torchrun + RCCL (1 rank) {dist_line["value"]} frames/s, ratio {ratio:.3f}')
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'r03_rccl_one_rank.json'), 'w') as f:
+        json.dump(dict(plain=plain, torchrun_force_dist=dist_line, ratio=ratio), f, indent=1)
+    assert 0.93 < ratio < 1.07, (plain['value'], dist_line['value'])
+
+    train = _bench(['--train', '--force-dist', '--steps', '6', '--warmup', '3'],
+                   launcher=['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                             '--master-port', str(_free_port())])
+    assert train['n_gpus'] == 1 and train['value'] > 0

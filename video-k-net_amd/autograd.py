@@ -6,7 +6,9 @@ The binarised mask carries no gradient (`.float()` of a bool, knet/det/kernel_up
                                                                       dx  = K^T dZ              (decode-shaped)
 i.e. the backward passes are the SAME two kernel shapes with transposed operands: `vkn_mask_decode_f32` with the roles of
 channels and kernels swapped, and `vkn_mask_gather_real_f32`.  Gradient operands are scaled by a power of two into the f16
-hi/lo split's range first (exact in fp32) and the result is scaled back.
+hi/lo split's range first (exact in fp32) and the result is scaled back.  Dynamic range: ONE power-of-two scale per tensor puts
+max|g| at ~2^10; an element more than ~2^34 below the tensor's maximum falls under the smallest f16 subnormal of the low half
+(2^-24) and contributes zero — irrelevant for loss gradients (their spread inside one tensor is far smaller) but it is a limit.
 """
 import torch
 
@@ -47,9 +49,11 @@ class MaskGatherFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask_logits, hard_mask_thr):
         xraw, cnt = ops.mask_gather(x, mask_logits, hard_mask_thr)
-        ctx.save_for_backward(mask_logits)
-        ctx.thr = ops.thr_logit(hard_mask_thr)
         ctx.need_dx = x.requires_grad
+        if ctx.need_dx:
+            # backward needs nothing but bit(z >= thr): ONE byte per logit is kept for it instead of the fp32 logits
+            # (15 MB -> 3.8 MB per frame and stage at cfg2 size)
+            ctx.save_for_backward(mask_logits >= ops.thr_logit(hard_mask_thr))
         ctx.mark_non_differentiable(cnt)
         return xraw, cnt
 
@@ -57,10 +61,21 @@ class MaskGatherFn(torch.autograd.Function):
     def backward(ctx, dxraw, _dcnt):
         if not ctx.need_dx:
             return None, None, None
-        (mask_logits,) = ctx.saved_tensors
-        bits = (mask_logits >= ctx.thr).to(torch.float32)              # [B, N, H, W], exactly {0, 1}
+        (bits,) = ctx.saved_tensors                                     # [B, N, H, W] bool
+        B, N, H, W = bits.shape
         s = _pow2_scale(dxraw)
-        dx = _decode_transposed(bits, (dxraw * s).transpose(1, 2)) / s  # [B, C, H, W]
+        kt = (dxraw * s).transpose(1, 2)                                # [B, C, N]
+        if (H * W) % 64 == 0:
+            # the decode kernel with the bit rows as a HALF-STORAGE feature map (fp16 {0, 1} is exact, its low half is zero: one MFMA
+            # per operand pair instead of three, half the bytes of an fp32 bit tensor), rows padded to the 32-row contraction step
+            Np = (N + 31) // 32 * 32
+            rows = torch.zeros((B, Np, H, W), dtype=torch.float16, device=bits.device)
+            rows[:, :N] = bits
+            if Np != N:
+                kt = torch.cat([kt, kt.new_zeros(B, kt.shape[1], Np - N)], dim=2)
+            dx = ops.mask_decode(rows, kt.contiguous()) / s             # [B, C, H, W]
+        else:
+            dx = _decode_transposed(bits.to(torch.float32), kt) / s
         return dx, None, None
 
 

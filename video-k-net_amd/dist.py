@@ -14,6 +14,20 @@ def shard_bounds(num_frames: int, world: int, rank: int):
     return (num_frames * rank) // world, (num_frames * (rank + 1)) // world
 
 
+def exchange(send, recv, send_to=None, recv_from=None, group=None):
+    """One batched point-to-point step: `send` -> group rank `send_to`, `recv` <- group rank `recv_from` (either may be None).
+    P2POp peers are GLOBAL ranks: group-local ranks are translated (identical for the default group).  A rank may name itself
+    (RCCL pairs a send and a receive posted in one group): that is how a 1-GPU box exercises this path."""
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    ops = []
+    if send_to is not None:
+        ops.append(dist.P2POp(dist.isend, send, peer(send_to), group))
+    if recv_from is not None:
+        ops.append(dist.P2POp(dist.irecv, recv, peer(recv_from), group))
+    for req in (dist.batch_isend_irecv(ops) if ops else []):
+        req.wait()
+
+
 def neighbour_last_kernels(block_kernels: torch.Tensor, group=None):
     """Every rank owns >= 1 frame: hand this rank's LAST frame's kernels [N, C] to rank + 1 and return the previous rank's
     ([1, N, C]; None on rank 0 or without a process group).  ONE point-to-point send / receive (120 KB at N = 117, C = 256) —
@@ -25,13 +39,7 @@ def neighbour_last_kernels(block_kernels: torch.Tensor, group=None):
     N, C = block_kernels.shape[1:]
     last = block_kernels[-1].contiguous()
     recv = torch.empty_like(last)
-    ops = []
-    if rank + 1 < world:
-        ops.append(dist.P2POp(dist.isend, last, rank + 1, group))
-    if rank > 0:
-        ops.append(dist.P2POp(dist.irecv, recv, rank - 1, group))
-    for req in (dist.batch_isend_irecv(ops) if ops else []):
-        req.wait()
+    exchange(last, recv, rank + 1 if rank + 1 < world else None, rank - 1 if rank > 0 else None, group)
     return recv.reshape(1, N, C) if rank > 0 else None
 
 
@@ -76,16 +84,32 @@ class BucketedGradAllReducer:
 
     Parameters are grouped into buckets (default: one per `mask_head.{s}` stage + one for the rest).  Every parameter's `.grad` is
     a VIEW into its bucket's flat fp32 buffer, so a bucket is reduced in place with ONE collective and nothing is copied.  A
-    post-accumulate-grad hook counts the bucket's parameters as backward produces them; the bucket's `all_reduce(async_op=True)`
-    is launched the moment its last gradient lands — backward runs the stages in reverse, so stage S-1's 13 MB travel while stages
-    S-2 .. 0 are still being differentiated.  `finalize()` waits for the collectives and divides by the world size.
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large buckets keep every link busy with long messages instead of
-    hundreds of per-tensor rings.  With world_size 1 (or no process group) everything degenerates to plain local gradients."""
+    post-accumulate-grad hook marks the bucket's parameters as backward produces them; the bucket's `all_reduce(async_op=True)`
+    is launched the moment the last gradient it EXPECTS has landed — backward runs the stages in reverse, so stage S-1's 13 MB
+    travel while stages S-2 .. 0 are still being differentiated.  `finalize()` launches what is left, waits, and divides by the
+    world size.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large buckets keep every link busy with long
+    messages instead of hundreds of per-tensor rings.  With world_size 1 everything degenerates to plain local gradients.
 
-    def __init__(self, module, bucket_of=None, group=None):
+    Contract (the DDP one):
+    * one synchronised backward per step: `zero_grad -> backward -> finalize -> optimizer.step`.  Gradient accumulation: run the
+      earlier backward passes under `with reducer.no_sync():` — nothing is launched there, gradients just add up in the buckets.
+      A second backward outside `no_sync()` before `finalize()` would add to a buffer that is already being reduced: it raises.
+    * ANY `zero_grad` is fine.  `reducer.zero_grad()` zeroes the flat buffers.  torch's default `optimizer.zero_grad()` /
+      `module.zero_grad()` (set_to_none=True) DROPS the `.grad` views; the hook notices (`p.grad` is no longer the bucket's view),
+      copies the fresh gradient into the view and re-attaches it, so the collective always reduces the real gradients.
+    * parameters that take part in no backward (the video head builds its link modules in every stage but uses the last stage's
+      only) are learned during the first synchronised step: from the second step on a bucket waits only for the parameters that
+      did fire, so stage buckets with unused members also overlap with backward.  When the set of used parameters changes
+      (e.g. switching between `forward_train` and `forward_train_with_previous`), call `reset_usage()`; a gradient arriving in a
+      bucket that is already in flight raises instead of being silently lost."""
+
+    def __init__(self, module, bucket_of=None, group=None, force_collectives=False):
         import re
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # force_collectives: issue the all-reduces even in a ONE-rank group (a 1-GPU box still exercises the RCCL path)
+        self._coll = self.world > 1 or (force_collectives and dist.is_available() and dist.is_initialized())
+        self._sync = True
         if bucket_of is None:
             def bucket_of(name):
                 m = re.search(r'mask_head\.(\d+)\.', name)
@@ -98,40 +122,93 @@ class BucketedGradAllReducer:
             seen.add(id(p))
             groups.setdefault((bucket_of(name), p.device, p.dtype), []).append(p)
         self.buckets = []
-        self._handles = []
         for (key, dev, dt), params in groups.items():
             flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=dt)
-            b = dict(key=key, flat=flat, params=params, ready=0, handle=None)
+            b = dict(key=key, flat=flat, params=params, views=[], fired=set(), expect=None, handle=None, grew=False)
             off = 0
-            for p in params:
-                p.grad = flat[off:off + p.numel()].view_as(p)
+            for i, p in enumerate(params):
+                v = flat[off:off + p.numel()].view_as(p)
+                b['views'].append(v)
+                p.grad = v
                 off += p.numel()
-                p.register_post_accumulate_grad_hook(self._make_hook(b))
+                p.register_post_accumulate_grad_hook(self._make_hook(b, i))
             self.buckets.append(b)
 
-    def _make_hook(self, b):
-        def hook(_p):
-            b['ready'] += 1
-            if b['ready'] == len(b['params']) and self.world > 1:
-                b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    def _launch(self, b):
+        b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _make_hook(self, b, i):
+        def hook(p):
+            view = b['views'][i]
+            g = p.grad
+            if g is not view and (g is None or g.data_ptr() != view.data_ptr()):
+                # `zero_grad(set_to_none=True)` (torch's default) or an external `p.grad = ...` dropped the view
+                if g is not None:
+                    view.copy_(g)
+                p.grad = view
+            if b['handle'] is not None:
+                raise RuntimeError(f"BucketedGradAllReducer: a gradient arrived in bucket '{b['key']}' while its all-reduce is in "
+                                   'flight (a second backward before finalize() — wrap the earlier ones in no_sync() — or the set '
+                                   'of used parameters changed — call reset_usage())')
+            if not self._sync:
+                return
+            b['fired'].add(i)
+            if b['expect'] is not None and i not in b['expect']:
+                b['grew'] = True                                  # a parameter we did not expect: reduce this bucket in finalize()
+            want = b['expect'] if b['expect'] is not None else range(len(b['params']))
+            if self._coll and not b['grew'] and len(b['fired']) == len(want):
+                self._launch(b)
         return hook
 
+    class _NoSync:
+        def __init__(self, owner):
+            self.owner = owner
+
+        def __enter__(self):
+            self.prev, self.owner._sync = self.owner._sync, False
+
+        def __exit__(self, *exc):
+            self.owner._sync = self.prev
+            return False
+
+    def no_sync(self):
+        """Context manager for the non-final backward passes of a gradient-accumulation step (DDP's `no_sync`)."""
+        return self._NoSync(self)
+
+    def reset_usage(self):
+        """Forget which parameters take part in backward (re-learned during the next synchronised step)."""
+        for b in self.buckets:
+            b['expect'] = None
+
     def zero_grad(self):
-        """Zero the flat buffers (the parameters' `.grad` views stay attached) and re-arm the hooks."""
+        """Zero the flat buffers, (re-)attach the parameters' `.grad` views and re-arm the hooks."""
         for b in self.buckets:
             b['flat'].zero_()
-            b['ready'], b['handle'] = 0, None
+            for p, v in zip(b['params'], b['views']):
+                if p.grad is not v:
+                    p.grad = v
+            b['fired'], b['handle'], b['grew'] = set(), None, False
 
     def finalize(self):
-        """Wait for the in-flight collectives (buckets whose parameters did not all take part in this backward are reduced
-        now), then average.  Call after `loss.backward()` and before `optimizer.step()`."""
-        if self.world > 1:
+        """Launch the collectives of the buckets that are not in flight yet (first step, unused members, accumulation), wait for
+        all of them, then average.  Call after the step's last `backward()` and before `optimizer.step()`."""
+        for b in self.buckets:
+            for p, v in zip(b['params'], b['views']):
+                # `p.grad is None`: the parameter took no part in this step after a set_to_none zero_grad — it stays None (the
+                # optimizer skips it; whatever its slot of the flat buffer holds is reduced along and never read)
+                if p.grad is not None and p.grad is not v and p.grad.data_ptr() != v.data_ptr():
+                    if b['handle'] is not None:   # a gradient assigned behind the hooks' back
+                        raise RuntimeError(f"BucketedGradAllReducer: bucket '{b['key']}' was reduced without a member's gradient")
+                    v.copy_(p.grad)
+                    p.grad = v
+        if self._coll:
             for b in self.buckets:
                 if b['handle'] is None:
-                    b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self._launch(b)
             for b in self.buckets:
                 b['handle'].wait()
                 b['flat'].div_(self.world)
         for b in self.buckets:
-            b['ready'] = 0
-            b['handle'] = None
+            if self._sync and b['fired']:
+                b['expect'] = set(b['fired']) if b['expect'] is None else (b['expect'] | b['fired'])
+            b['fired'], b['handle'], b['grew'] = set(), None, False

@@ -627,10 +627,14 @@ def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, d
     cls = _req(cls_logits, 'cls_pred') if cls_logits is not None else None
     ncls = cls.shape[1] if cls is not None else 0
     lab = gt_labels.to(device=m.device, dtype=torch.int32).contiguous()
-    if cls is not None and lab.numel() and (int(lab.min()) < 0 or int(lab.max()) >= ncls):
-        # the reference's `cls_pred[:, gt_labels]` raises an IndexError for such labels (ignore label 255, stuff label against
-        # thing-only logits); an unchecked device read would silently produce garbage costs
-        raise IndexError(f'gt_labels outside [0, {ncls}): {int(lab.min())} .. {int(lab.max())}')
+    if cls is not None and lab.numel():
+        # the reference's `cls_pred[:, gt_labels]` raises an IndexError for labels outside the logits (ignore label 255, stuff label
+        # against thing-only logits); an unchecked device read would silently produce garbage costs.  Host labels are checked on the
+        # host; device labels cost ONE combined read (the cost matrix itself goes to the host for the LSAP right after)
+        src = gt_labels if not gt_labels.is_cuda else torch.stack(torch.aminmax(lab))
+        lo, hi = (int(v) for v in (src.min(), src.max())) if not gt_labels.is_cuda else (int(v) for v in src.tolist())
+        if lo < 0 or hi >= ncls:
+            raise IndexError(f'gt_labels outside [0, {ncls}): {lo} .. {hi}')
     cfg = _lib.VknAssignCfg(float(cls_weight), float(dice_weight), float(mask_weight), float(focal_alpha), float(focal_gamma),
                             float(focal_eps), float(dice_eps))
     L = _lib.lib()
