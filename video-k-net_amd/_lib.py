@@ -106,6 +106,9 @@ def _stale(path=None):
         return True
     t = os.path.getmtime(path)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), 'include', 'vkn.h')]
+    exp = os.path.join(os.path.dirname(HERE), 'tools', 'experiments')     # debug-only kernel variants (#include'd under VKN_DEBUG)
+    if path == DEBUG_LIBPATH and os.path.isdir(exp):
+        deps += [os.path.join(exp, f) for f in os.listdir(exp)]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

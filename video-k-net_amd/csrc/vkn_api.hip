@@ -299,8 +299,8 @@ int run_link(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const 
              float* out, const StageWs& s, hipStream_t st, const float* update_feature = nullptr) {
     if (!w->pa_in_w || !w->lffn1_w) return VKN_E_ARG;
     const float* kv = prev;
-    if (w->dyn_w) {
-        if (!update_feature) return VKN_E_ARG;
+    if (update_feature) {   // (the stage's OWN weights also carry an updator — the main one: only an update feature selects it)
+        if (!w->dyn_w) return VKN_E_ARG;
         StageWs su = s;
         su.f = s.lf;  // (C != 256: the unfused mix buffer; `f` itself is a cls / mask branch scratch of the main stream)
         VKN_TRY(run_updator(d, w, pw, update_feature, nullptr, nullptr, prev, s.lupd, su, st));
@@ -370,7 +370,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     const int xdt = xdt_of(flags);
     const bool skip_decode = so && so->skip_decode;
     const bool pre_link = so && so->link_pre && so->prev_pre;
-    const bool need_xfeat = pre_link || (so && so->link_track && so->track_src == 1);  // (the link may run after the stage: side stream)
+    const bool need_xfeat = (pre_link && so->link_pre->dyn_w) || (so && so->link_track && so->track_src == 1);  // (the link may run after the stage: side stream)
     auto decode_final = [&](const float* kb) -> int {
         return final_decode(d, x, s, kb, masks_out, flags, st, prof0, prof1, up_out, up_stride, up_chunk, up_done);
     };
@@ -414,7 +414,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     if (pre_link) {
         PrepW pl;
         VKN_TRY(carve_pw(d, so->link_pre, flags, &pl));
-        VKN_TRY(run_link(d, so->link_pre, pl, obj_in, so->prev_pre, s.lobj, s, st, xfeat));
+        VKN_TRY(run_link(d, so->link_pre, pl, obj_in, so->prev_pre, s.lobj, s, st, so->link_pre->dyn_w ? xfeat : nullptr));  // (link_atten: no updator)
         obj_in = s.lobj;
     }
 
@@ -956,7 +956,7 @@ int vkn_stage_forward_link_f32(const VknDims* d, const VknStageWeights* w, const
 int vkn_link_block_f32(const VknDims* d, const VknStageWeights* w, const float* update_feature, const float* cur,
                        const float* prev, float* out, void* ws, size_t ws_bytes, void* stream) {
     VKN_TRY(check_dims(d));
-    if (!w || !cur || !prev || !out || (w->dyn_w && !update_feature)) return VKN_E_ARG;
+    if (!w || !cur || !prev || !out || ((w->dyn_w != nullptr) != (update_feature != nullptr))) return VKN_E_ARG;
     if (!aligned16(cur) || !aligned16(prev) || !aligned16(out) || !aligned16(update_feature)) return VKN_E_ALIGN;
     StageWs s;
     const size_t need = carve_stage(d, nullptr, &s);

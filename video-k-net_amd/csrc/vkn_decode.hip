@@ -342,191 +342,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
 // every wave) was built and validated, and measured SLOWER (113 us vs 94 us at cfg2, B = 8): the read and write streams
 // already share the memory system at ~4.2 TB/s combined whatever their interleaving (tools/decode_ablation.py).
 
-#ifdef VKN_DEBUG
-// ---------------------------------------------------------------------------------------------------------------------------
-// k_decode4 — the same contraction with 16-BYTE global accesses (round 2).
-//
-// Why: k_decode_mfma moves every byte of x and of the logits with 8-byte-per-lane instructions (lane = pixel pair).  The CU's
-// vector-memory front end retires lanes, not bytes: an 8-byte access costs what a 16-byte one costs (MI355X_MICROARCH.md:
-// "8-B accesses 0.54-0.70x the 16-B rate"), and the round-1 ablations fit that model — loads alone 52 us, stores alone 52 us,
-// both 80-95 us at cfg2 / B = 8, with the MFMAs removed changing nothing.  Here a lane owns FOUR consecutive pixels:
-//   * x fragments: `buffer_load_dwordx4` (32 lanes x 16 B = 512-B row segments, two channel rows per instruction);
-//   * a wave tile is 128 px = four interleaved 32-column MFMA strips (pixel 4 li + s -> strip s); every A fragment read from
-//     LDS feeds 12 MFMAs instead of 6 (half the LDS traffic per pixel);
-//   * logits: `buffer_store_dwordx4`, 512 B per mask row per instruction, half the store instructions;
-//   * 4 strips x NB n-blocks = up to 256 accumulator registers per lane -> ONE wave per SIMD (256-thread workgroups,
-//     `__launch_bounds__(256, 1)`, 512 registers per lane); the 4-deep fragment ring (3 x 8 KB in flight per wave) hides the
-//     HBM latency that a second wave per SIMD used to hide.
-// Per output element the MFMA sequence is the one of k_decode_mfma (kb, then per 16 channels hi*hi, hi*lo, lo*hi), so both
-// kernels produce bit-identical logits.  Needs P % 128 == 0 and C % 64 == 0 (every shipped config); other shapes use k_decode_mfma.
-//
-// MEASURED (tools/perf_r02.py, cfg2, 32 frames per launch): 366-404 us against 326-345 us for k_decode_mfma — the lane-rate model
-// above does NOT hold for this kernel, and one wave per SIMD cannot overlap its own VALU split with its MFMAs.  Negative result:
-// compiled into the DEBUG library only (VKN_DECODE4=1), for the record and for further experiments.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-#define D4_THREADS 256
-#define D4_WAVES 4
-#define D4_TILE 128
-
-template <int NB>
-__global__ __launch_bounds__(D4_THREADS, 1) void k_decode4(const float* __restrict__ x, const _Float16* __restrict__ kfh,
-                                                           const _Float16* __restrict__ kfl, const float* __restrict__ kb,
-                                                           float* __restrict__ out, int N, int NPT, int n0, int C, int P,
-                                                           int px_per_wg, int xcd_remap, VknDecodeStrides fs) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int LDK = C + 8;
-    _Float16* ldsH = reinterpret_cast<_Float16*>(smem);
-    _Float16* ldsL = ldsH + NB * 32 * LDK;
-    float* kbs = reinterpret_cast<float*>(ldsL + NB * 32 * LDK);
-
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 5, li = lane & 31;
-
-    int gx = blockIdx.x;
-    if (xcd_remap && (gridDim.x % 8) == 0) gx = (gx % 8) * (gridDim.x / 8) + gx / 8;
-    const int p_begin = gx * px_per_wg;
-    const int p_end = min(P, p_begin + px_per_wg);
-    const int ntile = (p_end > p_begin) ? (p_end - p_begin) / D4_TILE : 0;  // launcher: P % 128 == 0, px_per_wg % 512 == 0
-    const int my = (ntile > wave) ? (ntile - wave + D4_WAVES - 1) / D4_WAVES : 0;
-    const int KS = C >> 4;
-    const int total = my * KS;
-
-    const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * fs.out, 0, N * P * 4, 0x00020000);
-
-    // 4-deep fragment ring (3 fragments = 24 KB per wave in flight).  C % 64 == 0 (launcher), so the ring phase is the same at
-    // every tile start: the tile loop is explicit, accumulators are loop-carried through the MFMAs only (they stay in AGPRs).
-    u32x4 r0[8], r1[8], r2[8], r3[8];
-    int ld_ks = 0, ld_sl = 0, ld_cnt = 0;  // next fragment to load
-    const int voff = (((g << 3) * P + 4 * li) << 2);  // lane (g, li): channels 8 g + e, pixels 4 li .. 4 li + 3 of the tile
-
-#define D4_LOAD(REG)                                                                                   \
-    do { /* unconditional: past the end it re-reads the last fragment (exact vmcnt counting) */        \
-        const int p0_ = p_begin + (wave + D4_WAVES * ld_sl) * D4_TILE;                                 \
-        const int soff_ = ((ld_ks << 4) * P + p0_) << 2;                                               \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                  \
-            REG[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, soff_ + ((e * P) << 2), 3); /* sc0 | nt: streamed once */ \
-        const bool adv_ = (ld_cnt + 1 < total);                                                        \
-        const bool wrap_ = (ld_ks + 1 == KS);                                                          \
-        ld_cnt += adv_ ? 1 : 0;                                                                        \
-        ld_sl += (adv_ && wrap_) ? 1 : 0;                                                              \
-        ld_ks = adv_ ? (wrap_ ? 0 : ld_ks + 1) : ld_ks;                                                \
-    } while (0)
-
-    // the first three fragments are requested BEFORE the kernel planes are staged: the workgroup's prologue overlaps their latency
-    if (total > 0) {
-        D4_LOAD(r0);
-        D4_LOAD(r1);
-        D4_LOAD(r2);
-    }
-
-    // ---- stage this frame's kernels (rows n0 .. n0 + NB*32) and the folded bias into LDS
-    {
-        const _Float16* gh = kfh + (size_t)b * fs.plane + (size_t)n0 * C;
-        const _Float16* gl = kfl + (size_t)b * fs.plane + (size_t)n0 * C;
-        const int cpr = C >> 3;
-        for (int i = threadIdx.x; i < NB * 32 * cpr; i += D4_THREADS) {
-            const int r = i / cpr, q = i - r * cpr;
-            half8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (n0 + r < N) {
-                vh = *reinterpret_cast<const half8*>(gh + (size_t)r * C + q * 8);
-                vl = *reinterpret_cast<const half8*>(gl + (size_t)r * C + q * 8);
-            }
-            *reinterpret_cast<half8*>(ldsH + r * LDK + q * 8) = vh;
-            *reinterpret_cast<half8*>(ldsL + r * LDK + q * 8) = vl;
-        }
-        if (threadIdx.x < NB * 32) {
-            const int n = n0 + threadIdx.x;
-            kbs[threadIdx.x] = (kb && n < N) ? kb[(size_t)b * fs.kb + n] : 0.f;
-        }
-    }
-    __syncthreads();
-    if (total == 0) return;
-
-    f32x16 acc[4][NB];
-
-#define D4_COMPUTE(REG, KSV)                                                                                  \
-    do {                                                                                                      \
-        half8 bh[4], bl[4];                                                                                   \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                       \
-            const unsigned u0_ = REG[e][0], u1_ = REG[e][1], u2_ = REG[e][2], u3_ = REG[e][3];               \
-            _Float16 h_, l_;                                                                                  \
-            vkn_split_f16(__uint_as_float(u0_), h_, l_); bh[0][e] = h_; bl[0][e] = l_;                        \
-            vkn_split_f16(__uint_as_float(u1_), h_, l_); bh[1][e] = h_; bl[1][e] = l_;                        \
-            vkn_split_f16(__uint_as_float(u2_), h_, l_); bh[2][e] = h_; bl[2][e] = l_;                        \
-            vkn_split_f16(__uint_as_float(u3_), h_, l_); bh[3][e] = h_; bl[3][e] = l_;                        \
-        }                                                                                                     \
-        const int cb_ = ((KSV) << 4) + (g << 3);                                                              \
-        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                   \
-            const _Float16* ap_ = ldsH + (nb * 32 + li) * LDK + cb_;                                          \
-            const half8 ah = *reinterpret_cast<const half8*>(ap_);                                            \
-            const half8 al = *reinterpret_cast<const half8*>(ap_ + NB * 32 * LDK);                            \
-            /* per accumulator: hi*hi, hi*lo, lo*hi (the order of k_decode_mfma); four independent chains interleaved */ \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                     \
-                acc[s][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc[s][nb], 0, 0, 0);          \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                     \
-                acc[s][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc[s][nb], 0, 0, 0);          \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                     \
-                acc[s][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc[s][nb], 0, 0, 0);          \
-        }                                                                                                     \
-    } while (0)
-
-    for (int t = 0; t < my; ++t) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float kb_ = kbs[nb * 32 + vkn_cd_row(r, lane)];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[s][nb][r] = kb_;
-            }
-        // sched_barrier: with registers to spare the machine scheduler renames the ring and hoists all four loads to the top of
-        // the unrolled body (then drains to vmcnt(0) at its end); pinned, every compute waits with vmcnt(24) = 3 fragments in flight
-        for (int ks = 0; ks < KS; ks += 4) {
-            D4_LOAD(r3);
-            __builtin_amdgcn_sched_barrier(0);
-            D4_COMPUTE(r0, ks);
-            __builtin_amdgcn_sched_barrier(0);
-            D4_LOAD(r0);
-            __builtin_amdgcn_sched_barrier(0);
-            D4_COMPUTE(r1, ks + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            D4_LOAD(r1);
-            __builtin_amdgcn_sched_barrier(0);
-            D4_COMPUTE(r2, ks + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            D4_LOAD(r2);
-            __builtin_amdgcn_sched_barrier(0);
-            D4_COMPUTE(r3, ks + 3);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const int p0 = p_begin + (wave + D4_WAVES * t) * D4_TILE;
-        const int vst = ((4 * g) * P + 4 * li) << 2;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);
-                    const float a0 = acc[0][nb][r], a1 = acc[1][nb][r], a2 = acc[2][nb][r], a3 = acc[3][nb][r];
-                    const u32x4 v = {__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), __float_as_uint(a3)};
-                    // rows >= N: the lane's offset is pushed past num_records (N * P * 4 < 2^31) -> the hardware drops the store;
-                    // branch-free on purpose (per-row exec branches made hipcc route every store vector through scratch)
-                    const int vo = (row + 4 * g < N) ? vst : 0x7FFFFFF0;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, ors, vo, (row * P + p0) << 2, 0);
-                }
-            }
-        }
-    }
-#undef D4_LOAD
-#undef D4_COMPUTE
-}
-
-#endif  // VKN_DEBUG (k_decode4)
+#ifdef VKN_DEBUG  // rejected / time-attribution variants live outside the product sources
+#include "../../tools/experiments/decode_variants.inc"
+#endif
 
 // Exact-fp32 debug / fallback kernel: one thread per (n, px), k-ordered fmaf chain.
 __global__ __launch_bounds__(256) void k_decode_ref(const float* __restrict__ x, const float* __restrict__ kern,

@@ -26,459 +26,9 @@
 
 typedef unsigned int fu_u32x2 __attribute__((ext_vector_type(2)));
 
-#ifdef VKN_DEBUG  // the two earlier variants: measured slower than k_fused_dgs, kept in the debug library for A/B (VKN_FUSED=0|1)
-template <int NB, int C>
-__global__ __launch_bounds__(FU_THREADS, 1) void k_fused_dg(const float* __restrict__ x, const _Float16* __restrict__ kfh,
-                                                            const _Float16* __restrict__ kfl, const float* __restrict__ kb,
-                                                            float thr, float* __restrict__ part, float* __restrict__ cntp,
-                                                            int N, int NPT, int n0, int P) {
-    constexpr int KS = C / 16;                          // 16-channel k-steps of the decode contraction
-    constexpr int NF = (KS + FU_WAVES - 1) / FU_WAVES;  // x fragments a wave loads per tile (k-steps w, w + 4, ...)
-    constexpr int NCB = C / 32;                         // 32-channel blocks of the gather output
-    constexpr int CBW = (NCB + FU_WAVES - 1) / FU_WAVES;
-    constexpr int LDK = C + 8;                          // halfs per LDS row: (C + 8) * 2 B = odd multiple of 16 B
-    constexpr int PLANE = FU_TILE * LDK;                // halfs of one plane of one tile image
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* dimg = reinterpret_cast<_Float16*>(smem);  // [2 buffers][hi | lo][64 rows][LDK]
-    half8* lut = reinterpret_cast<half8*>(dimg + 4 * PLANE);
-    unsigned* wbits = reinterpret_cast<unsigned*>(lut + 256);  // [2 (even | odd pixels)][128 rows]
-    float* kbs = reinterpret_cast<float*>(wbits + 256);        // [128]
-
-    const int b = blockIdx.y, gidx = blockIdx.x, G = gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 5, li = lane & 31;
-
-    // 64-px tiles s * G + gidx, s = 0, 1, ... (launcher: P % 64 == 0)
-    const int nsup = ((P >> 6) - gidx + G - 1) / G;
-
-    // (even nibble | odd nibble << 4) -> 8 halfs {0,1}: pixel e of an 8-px group = bit e/2 of the even (e even) / odd (e odd) nibble
-    for (int v = tid; v < 256; v += FU_THREADS) {
-        half8 h;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = ((v >> ((e >> 1) + 4 * (e & 1))) & 1) ? (_Float16)1.f : (_Float16)0.f;
-        lut[v] = h;
-    }
-    if (tid < 128) {
-        const int n = n0 + tid;
-        kbs[tid] = (kb && tid < NB * 32 && n < N) ? kb[(size_t)b * N + n] : 0.f;
-    }
-
-    const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
-    const int voff = (((g << 3) * P + 2 * li) << 2);  // lane (g, li): channels 8 g + e, pixels 2 li, 2 li + 1 of the tile
-
-    // ---- x fragments of the next tile(s), raw fp32 in registers
-    // NOTE on waits: vector loads return in order and the compiler's waitcnt insertion is exact only on branch-free code —
-    // every load below is unconditional when KS divides evenly (ALLF), and `sched_barrier`s pin commit -> issue order, else
-    // hipcc drains the prefetch (`s_waitcnt vmcnt(0)` right after the next tile's loads were issued: measured 2x slower).
-    constexpr bool ALLF = (KS % FU_WAVES) == 0;
-    fu_u32x2 raw[NF][8];
-    auto issue = [&](int s, int f) {  // fragment f of tile s: k-step wave + 4 f
-        const int ks = wave + FU_WAVES * f;
-        if (ALLF || ks < KS) {  // uniform
-            const int p0 = (s * G + gidx) << 6;
-            const int soff = ((ks << 4) * P + p0) << 2;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) raw[f][e] = __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, soff + ((e * P) << 2), 3);
-        }
-    };
-    // split fragment f and write it to tile image `buf`: rows li (even pixel) and 32 + li (odd pixel), columns 16 ks + 8 g ..
-    auto commit = [&](int buf, int f) {
-        const int ks = wave + FU_WAVES * f;
-        if (ALLF || ks < KS) {
-            half8 h0, l0, h1, l1;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned u0 = raw[f][e][0], u1 = raw[f][e][1];
-                _Float16 h, l;
-                vkn_split_f16(__uint_as_float(u0), h, l);
-                h0[e] = h;
-                l0[e] = l;
-                vkn_split_f16(__uint_as_float(u1), h, l);
-                h1[e] = h;
-                l1[e] = l;
-            }
-            _Float16* dh = dimg + (size_t)buf * 2 * PLANE + li * LDK + (ks << 4) + (g << 3);
-            *reinterpret_cast<half8*>(dh) = h0;
-            *reinterpret_cast<half8*>(dh + PLANE) = l0;
-            *reinterpret_cast<half8*>(dh + 32 * LDK) = h1;
-            *reinterpret_cast<half8*>(dh + 32 * LDK + PLANE) = l1;
-        }
-    };
-
-#pragma unroll
-    for (int f = 0; f < NF; ++f) issue(0, f);  // (tile gidx < P / 64 exists even when nsup == 0 only if G <= P / 64: launcher)
-
-    // ---- decode operand A: this wave's 32 kernel rows, stationary in registers
-    half8 Ah[KS], Al[KS];
-    {
-        const int n = n0 + wave * 32 + li;
-        const bool ok = (wave < NB) && (n < N);  // rows >= N of the planes are never written by the producer: zero
-        const size_t base = ((size_t)b * NPT + (ok ? n : 0)) * C + (g << 3);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            half8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) {
-                vh = *reinterpret_cast<const half8*>(kfh + base + (ks << 4));
-                vl = *reinterpret_cast<const half8*>(kfl + base + (ks << 4));
-            }
-            Ah[ks] = vh;
-            Al[ks] = vl;
-        }
-    }
-
-    f32x16 accg[CBW][NB];
-#pragma unroll
-    for (int j = 0; j < CBW; ++j)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accg[j][nb][r] = 0.f;
-    unsigned cnt_i = 0;  // lanes 0..31 of wave nb: ON pixels of row 32 nb + lane
-
-    {
-        const int last = max(nsup - 1, 0);  // (a workgroup without tiles converts / re-reads tile 0 of its frame: harmless)
-#pragma unroll
-        for (int f = 0; f < NF; ++f) commit(0, f);
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), UNCONDITIONALLY on the way into the loop: the prologue's loads (kernel
-        __builtin_amdgcn_sched_barrier(0);   // rows, first tile) are complete — inside the loop the only vector loads in flight
-#pragma unroll                               // are the next tile's, which no phase touches
-        for (int f = 0; f < NF; ++f) issue(min(1, last), f);
-    }
-    __syncthreads();
-
-    for (int s = 0; s < nsup; ++s) {
-        const int buf = s & 1;
-        const _Float16* dh = dimg + (size_t)buf * 2 * PLANE;
-        // ---------------- decode phase: wave = n-block
-        if (wave < NB) {
-            f32x16 acc0, acc1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float k0 = kbs[wave * 32 + vkn_cd_row(r, lane)];
-                acc0[r] = k0;
-                acc1[r] = k0;
-            }
-            const _Float16* bp = dh + li * LDK + (g << 3);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const half8 bh0 = *reinterpret_cast<const half8*>(bp + (ks << 4));
-                const half8 bl0 = *reinterpret_cast<const half8*>(bp + (ks << 4) + PLANE);
-                const half8 bh1 = *reinterpret_cast<const half8*>(bp + (ks << 4) + 32 * LDK);
-                const half8 bl1 = *reinterpret_cast<const half8*>(bp + (ks << 4) + 32 * LDK + PLANE);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], bh0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], bh1, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], bl0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], bl1, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[ks], bh0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[ks], bh1, acc1, 0, 0, 0);
-            }
-            // bit words of this wave's 32 rows: lane = row
-            int we = 0, wo = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned long long m0 = __ballot(acc0[r] >= thr);  // even pixels: bit 32 g' + li'
-                const unsigned long long m1 = __ballot(acc1[r] >= thr);  // odd pixels
-#pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * g2;  // compile-time
-                    const bool mine = lane == row;
-                    we = mine ? (int)(unsigned)(m0 >> (32 * g2)) : we;
-                    wo = mine ? (int)(unsigned)(m1 >> (32 * g2)) : wo;
-                }
-                __builtin_amdgcn_sched_barrier(0);  // keep each pair of ballots next to its selects (else the masks spill SGPRs)
-            }
-            if (lane < 32) {
-                wbits[wave * 32 + lane] = (unsigned)we;
-                wbits[128 + wave * 32 + lane] = (unsigned)wo;
-                cnt_i += __popc((unsigned)we) + __popc((unsigned)wo);
-            }
-        }
-        __syncthreads();  // A: the tile's bit words are visible; every wave has left the previous tile's gather phase
-
-        // ---------------- gather phase: wave = channel blocks wave + 4 j; the next tile is converted between the MFMA groups
-        unsigned wev[NB], wov[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            wev[nb] = wbits[nb * 32 + li];
-            wov[nb] = wbits[128 + nb * 32 + li];
-        }
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int bsh = 8 * ps + 4 * g;  // pixels 16 ps + 8 g + e  <->  bit bsh + e / 2 of the even (e even) / odd word
-            half8 a[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) a[nb] = lut[((wev[nb] >> bsh) & 0xFu) | (((wov[nb] >> bsh) & 0xFu) << 4)];
-#pragma unroll
-            for (int j = 0; j < CBW; ++j) {
-                const int cb = wave + FU_WAVES * j;
-                if (cb < NCB) {  // uniform
-                    // pixel 16 ps + 8 g + e lives in row (8 ps + 4 g + e / 2) + 32 (e & 1)
-                    const _Float16* cp = dh + (8 * ps + 4 * g) * LDK + cb * 32 + li;
-                    half8 bh, bl;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        bh[e] = cp[((e >> 1) + 32 * (e & 1)) * LDK];
-                        bl[e] = cp[((e >> 1) + 32 * (e & 1)) * LDK + PLANE];
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        accg[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb], bh, accg[j][nb], 0, 0, 0);
-                        accg[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb], bl, accg[j][nb], 0, 0, 0);
-                    }
-                }
-            }
-            if (ps < NF) {  // next tile: convert fragment ps (in flight since the previous tile), then request the tile after
-                __builtin_amdgcn_sched_barrier(0);
-                commit(buf ^ 1, ps);  // (past the last tile: a harmless re-conversion of the clamped re-read)
-                __builtin_amdgcn_sched_barrier(0);
-                issue(min(s + 2, nsup - 1), ps);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();  // B: the next tile's image is complete; this tile's image and bit words are free
-    }
-
-    // ---- this workgroup's partial (the layout of k_gather_mfma / k_gather_bits_w; rows of the n-chunk)
-    float* pp = part + ((size_t)b * G + gidx) * NPT * C;
-#pragma unroll
-    for (int j = 0; j < CBW; ++j) {
-        const int cb = wave + FU_WAVES * j;
-        if (cb < NCB) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + nb * 32 + vkn_cd_row(r, lane);
-                    pp[(size_t)n * C + cb * 32 + li] = accg[j][nb][r];
-                }
-        }
-    }
-    if (wave < NB && lane < 32) cntp[((size_t)b * G + gidx) * NPT + n0 + wave * 32 + lane] = (float)cnt_i;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// k_fused_dg8 — the same pass with TWO waves per SIMD (512 threads): measured on MI355X, the one-wave-per-SIMD kernel above
-// leaves every LDS round trip of its single instruction stream exposed (per tile ~15 k cycles for 5.1 k cycles of MFMA), so it
-// only ties with the two-kernel path.  With a partner wave on each SIMD the hardware overlaps one wave's LDS / VALU phases with
-// the other's MFMAs.  256 registers per lane instead of 512 -> only the HI plane of the wave's kernel rows stays in registers
-// (C / 4 registers); the LO plane lives in LDS (67.6 KB) and the x tile image is single-buffered (67.6 KB):
-//   decode role of wave w: n-block w & 3, strip w >> 2 (even / odd pixels)      48 MFMA per tile
-//   gather role of wave w: channel block w (all n-blocks)                       8 NB MFMA per tile
-//   loads: k-steps w, w + 8 of the NEXT tile in flight in registers while this tile is multiplied
-// Three workgroup barriers per tile (image complete / bit words complete / image free).  Results: bit-identical to k_fused_dg.
-#define FU8_THREADS 512
-#define FU8_WAVES 8
-
-template <int NB, int C>
-__global__ __launch_bounds__(FU8_THREADS, 2) void k_fused_dg8(const float* __restrict__ x, const _Float16* __restrict__ kfh,
-                                                              const _Float16* __restrict__ kfl, const float* __restrict__ kb,
-                                                              float thr, float* __restrict__ part, float* __restrict__ cntp,
-                                                              int N, int NPT, int n0, int P) {
-    constexpr int KS = C / 16;
-    constexpr int NF = (KS + FU8_WAVES - 1) / FU8_WAVES;
-    constexpr int NCB = C / 32;
-    constexpr int LDK = C + 8;
-    constexpr int PLANE = FU_TILE * LDK;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* dimg = reinterpret_cast<_Float16*>(smem);          // [hi | lo][64 rows][LDK]: the x tile
-    _Float16* alo = dimg + 2 * PLANE;                            // [128 rows][LDK]: LO plane of the frame's kernels
-    half8* lut = reinterpret_cast<half8*>(alo + 128 * LDK);
-    unsigned* wbits = reinterpret_cast<unsigned*>(lut + 256);    // [2 (even | odd pixels)][128 rows]
-    float* kbs = reinterpret_cast<float*>(wbits + 256);          // [128]
-    unsigned* cnt2 = reinterpret_cast<unsigned*>(kbs + 128);     // [128]: odd-pixel counts, added by the even-pixel waves at the end
-
-    const int b = blockIdx.y, gidx = blockIdx.x, G = gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 5, li = lane & 31;
-    const int dnb = wave & 3, dt = wave >> 2;  // decode role
-    const bool has_dec = dnb < NB;
-    const bool has_cb = wave < NCB;
-
-    const int nsup = ((P >> 6) - gidx + G - 1) / G;
-
-    for (int v = tid; v < 256; v += FU8_THREADS) {
-        half8 h;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = ((v >> ((e >> 1) + 4 * (e & 1))) & 1) ? (_Float16)1.f : (_Float16)0.f;
-        lut[v] = h;
-    }
-    if (tid < 128) {
-        const int n = n0 + tid;
-        kbs[tid] = (kb && tid < NB * 32 && n < N) ? kb[(size_t)b * N + n] : 0.f;
-        cnt2[tid] = 0u;
-    }
-    {  // LO plane of the chunk's kernel rows -> LDS (rows >= N: zero)
-        const _Float16* gl = kfl + ((size_t)b * NPT + n0) * C;
-        constexpr int cpr = C >> 3;
-        for (int i = tid; i < NB * 32 * cpr; i += FU8_THREADS) {
-            const int r = i / cpr, q = i - r * cpr;
-            half8 vl = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (n0 + r < N) vl = *reinterpret_cast<const half8*>(gl + (size_t)r * C + q * 8);
-            *reinterpret_cast<half8*>(alo + r * LDK + q * 8) = vl;
-        }
-    }
-
-    const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
-    const int voff = (((g << 3) * P + 2 * li) << 2);
-
-    constexpr bool ALLF = (KS % FU8_WAVES) == 0;  // see the note on waits in k_fused_dg
-    fu_u32x2 raw[NF][8];
-    auto issue = [&](int s, int f) {
-        const int ks = wave + FU8_WAVES * f;
-        if (ALLF || ks < KS) {
-            const int p0 = (s * G + gidx) << 6;
-            const int soff = ((ks << 4) * P + p0) << 2;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) raw[f][e] = __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, soff + ((e * P) << 2), 3);
-        }
-    };
-    auto commit = [&](int f) {
-        const int ks = wave + FU8_WAVES * f;
-        if (ALLF || ks < KS) {
-            half8 h0, l0, h1, l1;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned u0 = raw[f][e][0], u1 = raw[f][e][1];
-                _Float16 h, l;
-                vkn_split_f16(__uint_as_float(u0), h, l);
-                h0[e] = h;
-                l0[e] = l;
-                vkn_split_f16(__uint_as_float(u1), h, l);
-                h1[e] = h;
-                l1[e] = l;
-            }
-            _Float16* dh = dimg + li * LDK + (ks << 4) + (g << 3);
-            *reinterpret_cast<half8*>(dh) = h0;
-            *reinterpret_cast<half8*>(dh + PLANE) = l0;
-            *reinterpret_cast<half8*>(dh + 32 * LDK) = h1;
-            *reinterpret_cast<half8*>(dh + 32 * LDK + PLANE) = l1;
-        }
-    };
-
-#pragma unroll
-    for (int f = 0; f < NF; ++f) issue(0, f);
-
-    // HI plane of this wave's 32 kernel rows: stationary in registers
-    half8 Ah[KS];
-    {
-        const int n = n0 + dnb * 32 + li;
-        const bool ok = has_dec && (n < N);
-        const size_t base = ((size_t)b * NPT + (ok ? n : 0)) * C + (g << 3);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            half8 vh = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) vh = *reinterpret_cast<const half8*>(kfh + base + (ks << 4));
-            Ah[ks] = vh;
-        }
-    }
-
-    f32x16 accg[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accg[nb][r] = 0.f;
-    unsigned cnt_i = 0;
-
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): prologue loads complete (see k_fused_dg) — also the first tile's fragments
-    __builtin_amdgcn_sched_barrier(0);
-    for (int s = 0; s < nsup; ++s) {
-        // ---------------- the tile's image: split this wave's fragments (requested one tile ago), THEN request the next tile's
-#pragma unroll
-        for (int f = 0; f < NF; ++f) commit(f);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int f = 0; f < NF; ++f) issue(min(s + 1, nsup - 1), f);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();  // X: image complete (and, first tile, LO plane / table / bias staged)
-
-        // ---------------- decode phase: wave = (n-block, strip)
-        if (has_dec) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = kbs[dnb * 32 + vkn_cd_row(r, lane)];
-            const _Float16* bp = dimg + (32 * dt + li) * LDK + (g << 3);
-            const _Float16* ap = alo + (dnb * 32 + li) * LDK + (g << 3);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const half8 bh = *reinterpret_cast<const half8*>(bp + (ks << 4));
-                const half8 bl = *reinterpret_cast<const half8*>(bp + (ks << 4) + PLANE);
-                const half8 al = *reinterpret_cast<const half8*>(ap + (ks << 4));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-            }
-            int wd = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned long long m = __ballot(acc[r] >= thr);
-#pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * g2;
-                    wd = (lane == row) ? (int)(unsigned)(m >> (32 * g2)) : wd;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (lane < 32) {
-                wbits[dt * 128 + dnb * 32 + lane] = (unsigned)wd;
-                cnt_i += __popc((unsigned)wd);
-            }
-        }
-        __syncthreads();  // A: bit words complete
-
-        // ---------------- gather phase: wave = channel block
-        if (has_cb) {
-            unsigned wev[NB], wov[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                wev[nb] = wbits[nb * 32 + li];
-                wov[nb] = wbits[128 + nb * 32 + li];
-            }
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int bsh = 8 * ps + 4 * g;
-                const _Float16* cp = dimg + (8 * ps + 4 * g) * LDK + wave * 32 + li;
-                half8 bh, bl;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    bh[e] = cp[((e >> 1) + 32 * (e & 1)) * LDK];
-                    bl[e] = cp[((e >> 1) + 32 * (e & 1)) * LDK + PLANE];
-                }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const half8 a = lut[((wev[nb] >> bsh) & 0xFu) | (((wov[nb] >> bsh) & 0xFu) << 4)];
-                    accg[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, accg[nb], 0, 0, 0);
-                    accg[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, accg[nb], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();  // B: image and bit words are free
-    }
-
-    float* pp = part + ((size_t)b * G + gidx) * NPT * C;
-    if (has_cb) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + nb * 32 + vkn_cd_row(r, lane);
-                pp[(size_t)n * C + wave * 32 + li] = accg[nb][r];
-            }
-    }
-    // ON-pixel counts: the odd-pixel waves hand theirs over through LDS (integers: exact in any order)
-    if (has_dec && dt == 1 && lane < 32) cnt2[dnb * 32 + lane] = cnt_i;
-    __syncthreads();
-    if (has_dec && dt == 0 && lane < 32)
-        cntp[((size_t)b * G + gidx) * NPT + n0 + dnb * 32 + lane] = (float)(cnt_i + cnt2[dnb * 32 + lane]);
-}
-
-
-#endif  // VKN_DEBUG (k_fused_dg, k_fused_dg8)
+#ifdef VKN_DEBUG  // rejected / time-attribution variants live outside the product sources
+#include "../../tools/experiments/fused_variants.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_fused_dgs — the same pass with ROLE-SPECIALISED waves.  Measured (tools/perf_r02.py, cfg2, 32 frames): k_fused_dg 420 us,

@@ -509,353 +509,9 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
     }
 }
 
-#ifdef VKN_DEBUG
-// k_gemm_r3 — the same GEMM with the weight fragments streamed STRAIGHT FROM GLOBAL MEMORY INTO REGISTERS.
-// In k_gemm_s3 wave w is the only consumer of column block w of every weight tile, yet the tile takes the detour global -> LDS
-// (DMA) -> registers: per K-tile the LDS pipe moves 48 KB of DMA writes + 48 KB of weight-fragment reads + 48 KB of A-fragment
-// reads (0.48 us) against 0.32 us of MFMAs, and with one barrier per tile the two mostly add up (VKN_GEMM_ABL / VKN_FFN_ABL: the
-// K loops are LDS-bound, not DMA-latency-bound).  The pre-split tile image [plane][q][row 256][8] already IS the fragment layout:
-// lane (g, li) of wave w needs k = 16 ks + 8 g .. + 7 of column 32 w + li = the 16 bytes at ((plane * 4 + 2 ks + g) * 256 + 32 w + li)
-// * 16 — two 512-byte runs per wave and load.  So every wave loads its own six fragments per K-tile with plain 16-byte global loads
-// into a 4-deep register ring (three tiles = 18 KB per wave in flight, counted vmcnt, no DMA pessimism, plain barriers), the LDS
-// carries only the shared A image, and the footprint drops from 159 KB to 48 KB.  Same MFMA sequence per accumulator ->
-// bit-identical to k_gemm_s3.
-// MEASURED (tools/perf_r02.py --what gemmr3 / gemmabl, debug build): no faster — 580 vs 580 us per single-frame step, 2.27 - 2.39 vs
-// 2.31 - 2.42 ms at 32 frames.  The K loop is not bound by any one pipe: removing, one at a time, the MFMAs / the A path / the
-// barriers / the weight loads from the loop saves 1.1 / 1.5 / 0.7 / 1.8 us of its 7.7 us per launch (B = 1) — the phases of a
-// K-tile iteration mostly run one after the other inside the single resident workgroup of a CU, and 256 VGPRs (ring of four
-// tiles) rule out a second one.  Kept in the debug library only (VKN_GEMM_R3=1).
-template <int ABL>
-__global__ __launch_bounds__(GM_THREADS) void k_gemm_r3(VknGemmProb p0, VknGemmProb p1, int nprob, int M, int K,
-                                                           float* __restrict__ partial) {
-    const bool second = (nprob > 1) && (blockIdx.z == 1);
-    const float* __restrict__ A = second ? p1.A : p0.A;
-    const float* __restrict__ A2 = second ? p1.A2 : p0.A2;
-    const float* __restrict__ A3 = second ? p1.A3 : p0.A3;
-    const float* __restrict__ A4 = second ? p1.A4 : p0.A4;
-    const int lda = second ? p1.lda : p0.lda;
-    const __bf16* __restrict__ Wp = static_cast<const __bf16*>(second ? p1.Wsplit : p0.Wsplit);
-    const int Nout = second ? p1.Nout : p0.Nout;
-    const VknEpi epi = second ? p1.epi : p0.epi;
-    extern __shared__ __attribute__((aligned(16))) char smem_r3[];
-    __bf16* Al = reinterpret_cast<__bf16*>(smem_r3);                // [2][3][32][40]
-    float* T = reinterpret_cast<float*>(Al + 2 * GS_ATILE);         // [32][260] output tile
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 5, li = lane & 31;
-    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
-    if (n0 >= Nout) return;
-    const int ksplit = (nprob > 1) ? 1 : gridDim.z;
-    const int kz = (nprob > 1) ? 0 : blockIdx.z;
-    const int ktiles = K >> 5;
-    const int kt_per = (ktiles + ksplit - 1) / ksplit;
-    const int kt_begin = kz * kt_per;
-    const int kt_end = min(ktiles, kt_begin + kt_per);
-
-    // A staging: thread -> two consecutive floats of the 32 x 32 tile (row = tid >> 4, k = 2 * (tid & 15)), every thread, no branch
-    const int ar = tid >> 4, aq = tid & 15;
-    const size_t aoff = (size_t)min(m0 + ar, M - 1) * lda + 2 * aq;
-    const float* A2p = A2 ? A2 : A;
-    const float* A3p = A3 ? A3 : A;
-    const float* A4p = A4 ? A4 : A;
-    const bool mul = (A2 != nullptr), two = (A3 != nullptr);
-    // this lane's fragment address inside a tile image (plane 0, ks 0); + ((plane * 4 + 2 ks) * 256) * 8 elements per (plane, ks)
-    const __bf16* wlane = Wp + (size_t)blockIdx.x * ktiles * GS_WTILE + (size_t)(g * 256 + wave * 32 + li) * 8;
-    bf16x8 Wr[4][2][3];
-    f32x2 S0[4], S1[4];
-
-#define R3_WLOAD(KT, SLOT)                                                                                                   \
-    do {                                                                                                                     \
-        const __bf16* wt_ = wlane + (size_t)(KT) * GS_WTILE;                                                                 \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                                  \
-            _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)                                                                 \
-                Wr[SLOT][ks_][p_] = *reinterpret_cast<const bf16x8*>(wt_ + (size_t)((p_ * 4 + 2 * ks_) * 256) * 8);         \
-    } while (0)
-#define R3_AFETCH(KT, S)                                                            \
-    do {                                                                            \
-        S[0] = *reinterpret_cast<const f32x2*>(A + aoff + (size_t)(KT) * 32);       \
-        S[1] = *reinterpret_cast<const f32x2*>(A2p + aoff + (size_t)(KT) * 32);     \
-        S[2] = *reinterpret_cast<const f32x2*>(A3p + aoff + (size_t)(KT) * 32);     \
-        S[3] = *reinterpret_cast<const f32x2*>(A4p + aoff + (size_t)(KT) * 32);     \
-    } while (0)
-#define R3_ASTASH(BUF, S)                                                                         \
-    do {                                                                                          \
-        bf16x2 h_, m_, l_;                                                                        \
-        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                           \
-            const float v_ = (mul ? S[0][e] * S[1][e] : S[0][e]) + (two ? S[2][e] * S[3][e] : 0.f); \
-            __bf16 hh_, mm_, ll_;                                                                 \
-            vkn_split_bf16x3(v_, hh_, mm_, ll_);                                                  \
-            h_[e] = hh_;                                                                          \
-            m_[e] = mm_;                                                                          \
-            l_[e] = ll_;                                                                          \
-        }                                                                                         \
-        __bf16* d_ = Al + (size_t)(BUF) * GS_ATILE + ar * GS_LDR + 2 * aq;                        \
-        *reinterpret_cast<bf16x2*>(d_) = h_;                                                      \
-        *reinterpret_cast<bf16x2*>(d_ + GM_BM * GS_LDR) = m_;                                     \
-        *reinterpret_cast<bf16x2*>(d_ + 2 * GM_BM * GS_LDR) = l_;                                 \
-    } while (0)
-#define R3_MFMA(ABUF, SLOT)                                                                                           \
-    do {                                                                                                              \
-        const __bf16* Ab = Al + (size_t)(ABUF) * GS_ATILE;                                                            \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
-            const __bf16* ap = Ab + li * GS_LDR + (ks << 4) + (g << 3);                                               \
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);                                                   \
-            const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);                                  \
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);                              \
-            const bf16x8 bh = Wr[SLOT][ks][0], bm = Wr[SLOT][ks][1], bl = Wr[SLOT][ks][2];                            \
-            if (ABL == 3) { asm volatile("" ::"v"(ah), "v"(am), "v"(al), "v"(bh), "v"(bm), "v"(bl)); continue; }      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0); /* smallest terms first (as s3) */   \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);                                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);                                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);                                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);                                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);                                      \
-        }                                                                                                             \
-    } while (0)
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool active = (n0 + wave * 32) < Nout;
-
-    const int ncols = min(GM_BN, Nout - n0);
-    VknEpiCols cols;
-    vkn_epi_load_cols(epi, ncols, n0, lane, cols);
-    VknEpiRow pre[GM_BM / 8];
-#pragma unroll
-    for (int i = 0; i < GM_BM / 8; ++i) vkn_epi_load_row(epi, cols, min(m0 + wave * (GM_BM / 8) + i, M - 1), pre[i]);
-
-    const int nkt = (ABL == 1) ? 0 : kt_end - kt_begin;
-    if (nkt > 0) {
-        const int klast = kt_end - 1;
-        // loads past the end re-read the last tile (never consumed): every iteration issues the same loads, counted vmcnt
-        R3_AFETCH(kt_begin, S0);
-        R3_WLOAD(kt_begin, 0);
-        R3_AFETCH(min(kt_begin + 1, klast), S1);
-        R3_WLOAD(min(kt_begin + 1, klast), 1);
-        R3_WLOAD(min(kt_begin + 2, klast), 2);
-        __builtin_amdgcn_sched_barrier(0);
-        R3_ASTASH(0, S0);
-        __syncthreads();
-#define R3_ITER(I, SLOT, SNEXT, SFETCH, SSTASH)                                                       \
-    do {                                                                                              \
-        /* A first: vmcnt counts in order, so waiting for the (younger) A fetch would force every older weight load to  */ \
-        /* have landed as well and collapse the weight ring to one tile ahead                                          */ \
-        if (ABL != 4) R3_AFETCH(min(kt_begin + (I) + 2, klast), SFETCH);                              \
-        if (ABL != 6) R3_WLOAD(min(kt_begin + (I) + 3, klast), SNEXT);                                \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        R3_MFMA((I) & 1, SLOT);                                                                       \
-        if (ABL != 4) R3_ASTASH(((I) + 1) & 1, SSTASH);                                               \
-        if (ABL != 5) __syncthreads();                                                                \
-    } while (0)
-        for (int i = 0; i < nkt; i += 4) {
-            R3_ITER(i, 0, 3, S0, S1);
-            if (i + 1 >= nkt) break;
-            R3_ITER(i + 1, 1, 0, S1, S0);
-            if (i + 2 >= nkt) break;
-            R3_ITER(i + 2, 2, 1, S0, S1);
-            if (i + 3 >= nkt) break;
-            R3_ITER(i + 3, 3, 2, S1, S0);
-        }
-#undef R3_ITER
-    }
-#undef R3_WLOAD
-#undef R3_AFETCH
-#undef R3_ASTASH
-#undef R3_MFMA
-
-    if (ksplit > 1) {
-        float* pz = partial + (size_t)kz * M * Nout;
-        if (active) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + vkn_cd_row(r, lane), col = n0 + wave * 32 + li;
-                if (row < M && col < Nout) pz[(size_t)row * Nout + col] = acc[r];
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) T[vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li] = active ? acc[r] : 0.f;
-    __syncthreads();
-    if (ABL == 2) {
-        if (T[tid] == 12345.678f) partial[0] = cols.bias[0];
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < GM_BM / 8; ++i) {
-        const int rl = wave * (GM_BM / 8) + i, row = m0 + rl;
-        if (row < M) {  // uniform
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = T[rl * GM_LDT + lane + 64 * q];
-            vkn_row_epilogue(epi, cols, row, ncols, lane, v, pre[i]);
-        }
-    }
-}
-
-// k_gemm_x16 — k_gemm_r3 with SIXTEEN waves per workgroup: the K-tiles of the 32 x 256 output tile are split between two groups of
-// eight waves (group g takes tiles kt = g mod 2; group 1's accumulators are added to group 0's through LDS before the epilogue).
-// Why: VKN_GEMM_ABL shows the phases of a K-tile iteration (weight loads, A fetch / split / stash, barrier, LDS fragment reads,
-// MFMAs) running mostly one after the other inside the one workgroup a CU holds — four waves per SIMD instead of two, working on two
-// K-tiles per barrier, overlap them.  128 VGPRs per wave: weight ring of two tiles, epilogue operands loaded after the loop.
-// The sum order differs from k_gemm_s3 / r3 (two interleaved partial sums), so results differ in the last bits.
-template <int ABL>
-__global__ __launch_bounds__(1024) void k_gemm_x16(VknGemmProb p0, VknGemmProb p1, int nprob, int M, int K) {
-    const bool second = (nprob > 1) && (blockIdx.z == 1);
-    const float* __restrict__ A = second ? p1.A : p0.A;
-    const float* __restrict__ A2 = second ? p1.A2 : p0.A2;
-    const float* __restrict__ A3 = second ? p1.A3 : p0.A3;
-    const float* __restrict__ A4 = second ? p1.A4 : p0.A4;
-    const int lda = second ? p1.lda : p0.lda;
-    const __bf16* __restrict__ Wp = static_cast<const __bf16*>(second ? p1.Wsplit : p0.Wsplit);
-    const int Nout = second ? p1.Nout : p0.Nout;
-    const VknEpi epi = second ? p1.epi : p0.epi;
-    extern __shared__ __attribute__((aligned(16))) char smem_x16[];
-    __bf16* Al0 = reinterpret_cast<__bf16*>(smem_x16);             // [group 2][buffer 2][3][32][40]
-    float* T = reinterpret_cast<float*>(Al0 + 4 * GS_ATILE);       // [32][260] output tile (group 0) ...
-    float* T1 = T + GM_BM * GM_LDT;                                // ... and group 1's partial sums
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave16 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave16 >> 3, wave = wave16 & 7;
-    const int g = lane >> 5, li = lane & 31;
-    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
-    if (n0 >= Nout) return;
-    const int ktiles = K >> 5;
-    __bf16* Al = Al0 + (size_t)grp * 2 * GS_ATILE;
-
-    const int tg = tid & 511, ar = tg >> 4, aq = tg & 15;
-    const size_t aoff = (size_t)min(m0 + ar, M - 1) * lda + 2 * aq;
-    const float* A2p = A2 ? A2 : A;
-    const float* A3p = A3 ? A3 : A;
-    const float* A4p = A4 ? A4 : A;
-    const bool mul = (A2 != nullptr), two = (A3 != nullptr);
-    const __bf16* wlane = Wp + (size_t)blockIdx.x * ktiles * GS_WTILE + (size_t)(g * 256 + wave * 32 + li) * 8;
-    bf16x8 Wr[2][2][3];
-    f32x2 S0[4], S1[4];
-
-#define X_WLOAD(KT, SLOT)                                                                                                    \
-    do {                                                                                                                     \
-        const __bf16* wt_ = wlane + (size_t)(KT) * GS_WTILE;                                                                 \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                                  \
-            _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)                                                                 \
-                Wr[SLOT][ks_][p_] = *reinterpret_cast<const bf16x8*>(wt_ + (size_t)((p_ * 4 + 2 * ks_) * 256) * 8);         \
-    } while (0)
-#define X_AFETCH(KT, S)                                                             \
-    do {                                                                            \
-        S[0] = *reinterpret_cast<const f32x2*>(A + aoff + (size_t)(KT) * 32);       \
-        S[1] = *reinterpret_cast<const f32x2*>(A2p + aoff + (size_t)(KT) * 32);     \
-        S[2] = *reinterpret_cast<const f32x2*>(A3p + aoff + (size_t)(KT) * 32);     \
-        S[3] = *reinterpret_cast<const f32x2*>(A4p + aoff + (size_t)(KT) * 32);     \
-    } while (0)
-#define X_ASTASH(BUF, S)                                                                          \
-    do {                                                                                          \
-        bf16x2 h_, m_, l_;                                                                        \
-        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                           \
-            const float v_ = (mul ? S[0][e] * S[1][e] : S[0][e]) + (two ? S[2][e] * S[3][e] : 0.f); \
-            __bf16 hh_, mm_, ll_;                                                                 \
-            vkn_split_bf16x3(v_, hh_, mm_, ll_);                                                  \
-            h_[e] = hh_;                                                                          \
-            m_[e] = mm_;                                                                          \
-            l_[e] = ll_;                                                                          \
-        }                                                                                         \
-        __bf16* d_ = Al + (size_t)(BUF) * GS_ATILE + ar * GS_LDR + 2 * aq;                        \
-        *reinterpret_cast<bf16x2*>(d_) = h_;                                                      \
-        *reinterpret_cast<bf16x2*>(d_ + GM_BM * GS_LDR) = m_;                                     \
-        *reinterpret_cast<bf16x2*>(d_ + 2 * GM_BM * GS_LDR) = l_;                                 \
-    } while (0)
-#define X_MFMA(ABUF, SLOT)                                                                                            \
-    do {                                                                                                              \
-        const __bf16* Ab = Al + (size_t)(ABUF) * GS_ATILE;                                                            \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
-            const __bf16* ap = Ab + li * GS_LDR + (ks << 4) + (g << 3);                                               \
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);                                                   \
-            const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + GM_BM * GS_LDR);                                  \
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * GM_BM * GS_LDR);                              \
-            const bf16x8 bh = Wr[SLOT][ks][0], bm = Wr[SLOT][ks][1], bl = Wr[SLOT][ks][2];                            \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);                                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);                                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);                                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);                                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);                                      \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);                                      \
-        }                                                                                                             \
-    } while (0)
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool active = (n0 + wave * 32) < Nout;
-
-    // group g: tiles grp, grp + 2, ...; both groups run jmax iterations (same number of barriers), a group past its last tile
-    // re-reads it and skips the MFMAs
-    const int ng = (ktiles - grp + 1) >> 1;
-    const int jmax = (ABL == 1) ? 0 : (ktiles + 1) >> 1;
-    if (jmax > 0) {
-        const int klast = max(grp + 2 * (ng - 1), 0);
-        auto tile = [&](int j) { return min(grp + 2 * j, klast); };
-        X_AFETCH(tile(0), S0);
-        X_WLOAD(tile(0), 0);
-        X_AFETCH(tile(1), S1);
-        __builtin_amdgcn_sched_barrier(0);
-        X_ASTASH(0, S0);
-        __syncthreads();
-#define X_ITER(J, SLOT, SNEXT, SFETCH, SSTASH)                                                        \
-    do {                                                                                              \
-        X_AFETCH(tile((J) + 2), SFETCH);                                                              \
-        X_WLOAD(tile((J) + 1), SNEXT);                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        if ((J) < ng) X_MFMA((J) & 1, SLOT);                                                          \
-        X_ASTASH(((J) + 1) & 1, SSTASH);                                                              \
-        __syncthreads();                                                                              \
-    } while (0)
-        for (int j = 0; j < jmax; j += 2) {
-            X_ITER(j, 0, 1, S0, S1);
-            if (j + 1 >= jmax) break;
-            X_ITER(j + 1, 1, 0, S1, S0);
-        }
-#undef X_ITER
-    }
-#undef X_WLOAD
-#undef X_AFETCH
-#undef X_ASTASH
-#undef X_MFMA
-
-    // group 1 -> LDS, group 0 adds (fixed order) and publishes the tile
-    if (grp == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T1[vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li] = acc[r];
-    }
-    __syncthreads();
-    if (grp == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li;
-            T[o] = active ? acc[r] + T1[o] : 0.f;
-        }
-    }
-    __syncthreads();
-    if (ABL == 2) return;
-    const int ncols = min(GM_BN, Nout - n0);
-    VknEpiCols cols;
-    vkn_epi_load_cols(epi, ncols, n0, lane, cols);
-#pragma unroll
-    for (int i = 0; i < GM_BM / 16; ++i) {
-        const int rl = wave16 * (GM_BM / 16) + i, row = m0 + rl;
-        if (row < M) {  // uniform
-            VknEpiRow pre;
-            vkn_epi_load_row(epi, cols, row, pre);
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = T[rl * GM_LDT + lane + 64 * q];
-            vkn_row_epilogue(epi, cols, row, ncols, lane, v, pre);
-        }
-    }
-}
-
-#endif  // VKN_DEBUG (k_gemm_r3)
+#ifdef VKN_DEBUG  // rejected / time-attribution variants live outside the product sources
+#include "../../tools/experiments/gemm_variants.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------ fused FFN
 // partial[hs] = relu(X . W1[hidden range hs]^T + b1) . W2[:, hidden range hs]^T         (mmcv FFN, both Linears in one kernel)
