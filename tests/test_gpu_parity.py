@@ -227,9 +227,10 @@ def test_head_cfg1_size_vs_reference_golden(vkn):
     assert np.all((bits ^ g['sign_bits']) & g['sign_valid'] == 0), 'binary masks (|logit| > 2e-3) must be bit-exact'
 
 
-@pytest.mark.parametrize('name', ['video_vipseg_big', 'det_ytvis'])
+@pytest.mark.parametrize('name', ['video_vipseg_big', 'det_ytvis', 'video_vipseg_n216'])
 def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name):
-    """BASELINE cfg5 at its real size (video_knet_s3_swinb VIP-Seg: N = 166 = 100 + 66 kernels -> two n-chunks, C = 256, 92x160
+    """(`video_vipseg_n216`: BASELINE cfg5 as LITERALLY worded — 150 proposals + 66 stuff kernels = 216 rows, 46x80 features.)
+    BASELINE cfg5 at its real size (video_knet_s3_swinb VIP-Seg: N = 166 = 100 + 66 kernels -> two n-chunks, C = 256, 92x160
     features, 124 classes, x4, tracking link) and the cfg4 per-frame shape (YouTube-VIS: N = 100, 48x80, 40 thing classes, no
     stuff, x2, 2 frames): the free-running 3-stage fused head against the REFERENCE's own outputs."""
     g, case = load_golden(name)

@@ -101,6 +101,39 @@ def test_half_x_head_matches_fp32_head_on_rounded_x_and_reference_within_toleran
     assert (ra[2] - rb[2]).abs().max().item() <= tol * scale, ((ra[2] - rb[2]).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize('golden,dt,tol,H,W,T', [('video_cfg', torch.bfloat16, 4e-2, 128, 256, 2),          # BASELINE cfg2 "bf16": 1024x2048, N = 117
+                                                 ('video_vipseg_big', torch.float16, 5e-3, 92, 160, 2)],   # BASELINE cfg5 "fp16": 720p, N = 166
+                         ids=['cfg2_bf16_128x256_N117', 'cfg5_fp16_92x160_N166'])
+def test_half_x_head_at_the_sizes_that_name_it(vkn, golden, dt, tol, H, W, T):
+    """The two BASELINE configs that WORD a half type, at their own feature size and kernel count: the whole fused head (3 stages,
+    clip link, x4 upsample) on half-storage x is bit-identical to the fp32 head on the rounded x (all three stage hand-offs), and
+    the first stage's logits stay within the stated tolerance of the logit scale against the unrounded fp32 x."""
+    from test_gpu_parity import _build_head
+    _, case = load_golden(golden)
+    head, _ = _build_head(vkn, case)
+    N, C = case['N'], case['C']
+    xs = _clamp_tiny(_rand((T, C, H, W), 61)).to(DEV)
+    pfs = _rand((T, N, C), 62).to(DEV)
+    mps = _rand((T, N, H, W), 63, 4.0).to(DEV)
+    first = _rand((1, N, C), 64).to(DEV)
+    dims = head.mask_head[0].make_dims(T, N, H, W)
+    packs = [h.stage_pack(torch.device(DEV)) for h in head.mask_head]
+    xh = xs.to(dt)
+    a = vkn.ops.head_forward(dims, packs, xh, pfs, mps, None, case['up'], clip_first_prev=first)
+    b = vkn.ops.head_forward(dims, packs, xh.float(), pfs, mps, None, case['up'], clip_first_prev=first)
+    for u, v in zip(a, b):
+        assert (u is None and v is None) or torch.equal(u, v)
+    if (H * W) % 64 == 0:
+        c = vkn.ops.head_forward(dims, packs, xh, pfs, mps, None, case['up'], clip_first_prev=first, flags=vkn.ops.FLAG_BITS_HANDOFF)
+        for u, v in zip(a, c):
+            assert (u is None and v is None) or torch.equal(u, v)
+    one = [packs[0]]
+    ra = vkn.ops.head_forward(dims, one, xh, pfs, mps, None, 1)
+    rb = vkn.ops.head_forward(dims, one, xs, pfs, mps, None, 1)
+    scale = rb[2].abs().max().item()
+    assert (ra[2] - rb[2]).abs().max().item() <= tol * scale, ((ra[2] - rb[2]).abs().max().item(), scale)
+
+
 def test_half_x_single_stage_and_class_api(vkn):
     """`KernelUpdateHead.forward` (vkn_stage_forward_f32) and the class-level fused head take half-storage x as is."""
     from test_gpu_parity import _build_head
