@@ -59,7 +59,7 @@ def main():
             base = None
             for v in [int(t) for t in args.variants.split(',')]:
                 # v < 100: k_fused_dgs variant bits; 100 / 101 = k_fused_pp / its profile build; 200 / 201 = k_fused_pq (shipped) / its profile build
-                os.environ['VKN_FUSED'] = {100: '3', 101: '4', 200: '5', 201: '6', 202: '7', 203: '8', 204: '9'}.get(v, '2')
+                os.environ['VKN_FUSED'] = {100: '3', 101: '4', 200: '5', 201: '6', 202: '7', 203: '8', 204: '9', 300: '10', 301: '11'}.get(v, '2')
                 os.environ['VKN_FUSED_V'] = str(v)
                 out = vkn.ops.decode_gather(x, hi, lo, N, kb)
                 torch.cuda.synchronize()
@@ -70,18 +70,18 @@ def main():
                 t = timeit(lambda: vkn.ops.decode_gather(x, hi, lo, N, kb))
                 print(f'fused B={B} N={N} C={C} {H}x{W} V={v}: {t:8.1f} us  x-bytes {B * C * P * 4 / t / 1e6:6.2f} TB/s  '
                       f'bit-identical to V=first: {same0}, to decode->gather: {same_ref}', flush=True)
-            for pv in [t for t in args.variants.split(',') if t in ('15', '101', '201', '202', '203', '204')]:
+            for pv in [t for t in args.variants.split(',') if t in ('15', '101', '201', '202', '203', '204', '301')]:
                 import ctypes
                 L = vkn._lib.lib()
                 buf = (ctypes.c_ulonglong * 64)()
-                os.environ['VKN_FUSED'] = {'15': '2', '101': '4', '201': '6', '202': '7', '203': '8', '204': '9'}[pv]
+                os.environ['VKN_FUSED'] = {'15': '2', '101': '4', '201': '6', '202': '7', '203': '8', '204': '9', '301': '11'}[pv]
                 os.environ['VKN_FUSED_V'] = '15'
                 vkn.ops.decode_gather(x, hi, lo, N, kb)
                 torch.cuda.synchronize()
                 L.vkn_dbg_fused_prof.argtypes = [ctypes.c_void_p]
                 assert L.vkn_dbg_fused_prof(buf) == 0
                 ntile = 2 * (((P >> 6) + (256 // B if B <= 256 else 1) - 1) // max(256 // B, 1))
-                if pv == '15':
+                if pv in ('15', '301'):
                     print(f'k_fused_dgs: phase cycles per tile, workgroup (0,0), ~{ntile} tiles: [role work | wait loads | split+LDS write | issue | barrier]')
                     ns = 5
                 else:
@@ -100,7 +100,7 @@ def main():
                 head = bench.build_head(vkn, dev)
                 xx, pf, mp = bench.synth_inputs(B, dev, 0)
                 for v in [int(t) for t in args.variants.split(',')]:
-                    os.environ['VKN_FUSED'] = {100: '3', 101: '4', 200: '5', 201: '6', 202: '7', 203: '8', 204: '9'}.get(v, '2')
+                    os.environ['VKN_FUSED'] = {100: '3', 101: '4', 200: '5', 201: '6', 202: '7', 203: '8', 204: '9', 300: '10', 301: '11'}.get(v, '2')
                     os.environ['VKN_FUSED_V'] = str(v)
                     with torch.no_grad():
                         t = timeit(lambda: head._head_forward(xx, pf, mp, want_scaled=False), reps=20)

@@ -797,6 +797,409 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_pp(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// k_fused_il — k_fused_dgs with every wave's loader work INTERLEAVED INTO its own MFMA stream (round 3, the shipped variant).
+// What the phase stamps and ablations of k_fused_dgs / k_fused_pp / k_fused_pq established (profiles/r03_fused_phases_*.txt,
+// profiles/r03_mfma_issue_rate.txt):
+//   * one accumulator chain issues an MFMA every 52 cycles, two or more independent ones every 32; VALU instructions of the SAME wave
+//     between its MFMAs are free (32.1 cycles per MFMA with 4 conversions in every gap);
+//   * the partner wave of a SIMD gets almost no VALU issue while the other wave streams MFMAs (the same split + LDS-write code took
+//     900 cycles beside a gather stream and 4100 beside a decode stream) — "one wave computes while its partner loads" does not
+//     work here, ping-pong phases (k_fused_pp / k_fused_pq) were no faster than k_fused_dgs;
+//   * in k_fused_dgs both waves of a SIMD ran their MFMAs at the same time (good: the gather MFMAs fill the 20-cycle gaps of the
+//     decode wave's single dependent chain) and then BOTH did their loader work with the matrix pipe idle (bad: ~1300 of 4700
+//     cycles per tile), and loads were requested one tile (32 KB per CU) ahead of a ~4000-cycle loaded-HBM latency.
+// Here: same roles, same three images, one barrier per 32-px tile — but the split / LDS writes / load requests of a wave are
+// scheduled INTO the gaps of its own MFMA stream (sched_group_barrier pipelines), loads run two tiles ahead (two register sets),
+// and the ballot transposition is two asm blocks of 16 v_writelane.  Per-accumulator operation order is unchanged: bit-identical.
+template <int NB, int C, int XH = 0, int PF = 0>
+__global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restrict__ x, const _Float16* __restrict__ kfh,
+                                                             const _Float16* __restrict__ kfl, const float* __restrict__ kb,
+                                                             float thr, float* __restrict__ part, float* __restrict__ cntp,
+                                                             int N, int NPT, int n0, int P) {
+    constexpr int KS = C / 16;
+    // 16-channel fragments of a tile per loader wave: the decode waves (128 + 16 + 24 registers of operands) take NFD each, the gather
+    // waves (128 + 32 + 24) NFG — at C = 256 3 + 1 (with two tiles in flight: 48 + 16 registers), else all of them go to the decode waves
+    constexpr int NFG = KS / 16, NFD = KS / 4 - NFG, NF = NFD;
+    static_assert(KS % 4 == 0 && 4 * (NFD + NFG) == KS, "C must be a multiple of 64");
+    constexpr int NCB = C / 32;
+    constexpr int CBW = (NCB + 3) / 4;
+    constexpr int LDK = C + 8;
+    constexpr int PLANE = FS_TILE * LDK;
+    constexpr int IMG = 2 * PLANE;
+    constexpr int V = PF ? 8 : 0;  // (FS_STAMP)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* dimg = reinterpret_cast<_Float16*>(smem);         // [3 buffers][hi | lo][32 px][LDK]
+    half8* lut = reinterpret_cast<half8*>(dimg + 3 * IMG);
+    unsigned* wbits = reinterpret_cast<unsigned*>(lut + 256);   // [2 buffers][128 rows]
+    float* kbs = reinterpret_cast<float*>(wbits + 256);         // [128]
+
+    const int b = blockIdx.y, gidx = blockIdx.x, G = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    (void)prof; (void)tprev;
+
+    const int nsup = ((P >> 6) - gidx + G - 1) / G;
+    const int T = 2 * nsup;  // 32-px tiles (always an even count): halves of the 64-px super-tiles s * G + gidx
+    auto tile_p0 = [&](int t) { return (((t >> 1) * G + gidx) << 6) + ((t & 1) << 5); };
+
+    for (int v = tid; v < 256; v += FS_THREADS) {
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = ((v >> ((e >> 1) + 4 * (e & 1))) & 1) ? (_Float16)1.f : (_Float16)0.f;
+        lut[v] = h;
+    }
+    if (tid < 128) {
+        const int n = n0 + tid;
+        kbs[tid] = (kb && tid < NB * 32 && n < N) ? kb[(size_t)b * N + n] : 0.f;
+    }
+
+    const __amdgpu_buffer_rsrc_t xrs =
+        XH ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P), 0,
+                                               C * P * 2, 0x00020000)
+           : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
+    const int lq = lane >> 4, lp = lane & 15;
+    constexpr int XSH = XH ? 1 : 2;
+    const int voff = (((lq << 2) * P + 2 * lp) << XSH);
+    fu_u32x2 raw[2][NF][4];   // two tiles in flight
+    auto frag_ks = [&](int f) { return wave < 4 ? wave + 4 * f : 4 * NFD + (wave - 4) + 4 * f; };
+    auto issue = [&](int slot, int t, int f) {
+        const int ks = frag_ks(f);
+        {
+            const int soff = ((ks << 4) * P + tile_p0(t)) << XSH;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (XH) raw[slot][f][e] = fu_u32x2{__builtin_amdgcn_raw_buffer_load_b32(xrs, voff, soff + ((e * P) << 1), 0), 0u};
+                else raw[slot][f][e] = __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, soff + ((e * P) << 2), 3);
+            }
+        }
+    };
+    auto commit = [&](int slot, int buf, int f) {
+        const int ks = frag_ks(f);
+        {
+            half4 h0, l0, h1, l1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned u0 = raw[slot][f][e][0], u1 = raw[slot][f][e][1];
+                _Float16 h, l;
+                if (XH == 1) {
+                    h0[e] = __builtin_bit_cast(_Float16, (unsigned short)(u0 & 0xFFFFu));
+                    h1[e] = __builtin_bit_cast(_Float16, (unsigned short)(u0 >> 16));
+                } else if (XH == 2) {
+                    h0[e] = (_Float16)__uint_as_float(u0 << 16);
+                    h1[e] = (_Float16)__uint_as_float(u0 & 0xFFFF0000u);
+                } else {
+                    vkn_split_f16(__uint_as_float(u0), h, l);
+                    h0[e] = h;
+                    l0[e] = l;
+                    vkn_split_f16(__uint_as_float(u1), h, l);
+                    h1[e] = h;
+                    l1[e] = l;
+                }
+            }
+            _Float16* dh = dimg + (size_t)buf * IMG + lp * LDK + (ks << 4) + (lq << 2);
+            *reinterpret_cast<half4*>(dh) = h0;
+            *reinterpret_cast<half4*>(dh + 16 * LDK) = h1;
+            if (!XH) {
+                *reinterpret_cast<half4*>(dh + PLANE) = l0;
+                *reinterpret_cast<half4*>(dh + 16 * LDK + PLANE) = l1;
+            }
+        }
+    };
+    // the loader work of a tile in UNITS that the role loops place between their MFMAs: unit u of 2 * NF * 4 —
+    //   u < NF * 4:  fragment f = u / 4, channel e = u % 4: split the channel's pixel pair into the fragment's four half4 rows (and
+    //                write the four rows to the image after the fragment's last channel)
+    //   else:        request the same (f, e) of tile `tnext` into the register set just consumed
+    half4 ch0, cl0, ch1, cl1;
+    auto loader_unit = [&](int nf, int slot, int buf, int tnext, int u) {
+        const int NU = nf * 4;
+        if (u < NU) {
+            const int ff = u >> 2, e = u & 3, ks = frag_ks(ff);
+            {
+                const unsigned u0 = raw[slot][ff][e][0], u1 = raw[slot][ff][e][1];
+                _Float16 h, l;
+                if (XH == 1) {
+                    ch0[e] = __builtin_bit_cast(_Float16, (unsigned short)(u0 & 0xFFFFu));
+                    ch1[e] = __builtin_bit_cast(_Float16, (unsigned short)(u0 >> 16));
+                } else if (XH == 2) {
+                    ch0[e] = (_Float16)__uint_as_float(u0 << 16);
+                    ch1[e] = (_Float16)__uint_as_float(u0 & 0xFFFF0000u);
+                } else {
+                    vkn_split_f16(__uint_as_float(u0), h, l);
+                    ch0[e] = h;
+                    cl0[e] = l;
+                    vkn_split_f16(__uint_as_float(u1), h, l);
+                    ch1[e] = h;
+                    cl1[e] = l;
+                }
+                if (e == 3) {
+                    _Float16* dh = dimg + (size_t)buf * IMG + lp * LDK + (ks << 4) + (lq << 2);
+                    *reinterpret_cast<half4*>(dh) = ch0;
+                    *reinterpret_cast<half4*>(dh + 16 * LDK) = ch1;
+                    if (!XH) {
+                        *reinterpret_cast<half4*>(dh + PLANE) = cl0;
+                        *reinterpret_cast<half4*>(dh + 16 * LDK + PLANE) = cl1;
+                    }
+                }
+            }
+        } else if (u < 2 * NU) {
+            const int v = u - NU, ff = v >> 2, e = v & 3, ks = frag_ks(ff);
+            {
+                const int soff = ((ks << 4) * P + tile_p0(tnext)) << XSH;
+                if (XH) raw[slot][ff][e] = fu_u32x2{__builtin_amdgcn_raw_buffer_load_b32(xrs, voff, soff + ((e * P) << 1), 0), 0u};
+                else raw[slot][ff][e] = __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, soff + ((e * P) << 2), 3);
+            }
+        }
+    };
+    const int tlast = max(T - 1, 0);
+    float* pp = part + ((size_t)b * G + gidx) * NPT * C;
+
+    if (wave < 4) {
+        // =============================================================== decode role: n-block `wave`
+        const bool has_dec = wave < NB;
+        half8 Ah[KS], Al[KS];
+        {
+            const int n = n0 + wave * 32 + li;
+            const bool ok = has_dec && (n < N);
+            const size_t base = ((size_t)b * NPT + (ok ? n : 0)) * C + (g << 3);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                half8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) {
+                    vh = *reinterpret_cast<const half8*>(kfh + base + (ks << 4));
+                    vl = *reinterpret_cast<const half8*>(kfl + base + (ks << 4));
+                }
+                Ah[ks] = vh;
+                Al[ks] = vl;
+            }
+        }
+        unsigned cnt_i = 0;
+#pragma unroll
+        for (int f = 0; f < NFD; ++f) issue(0, 0, f);
+#pragma unroll
+        for (int f = 0; f < NFD; ++f) issue(1, min(1, tlast), f);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) once: the prologue's loads (kernel rows, tiles 0 and 1) are complete — from
+        __builtin_amdgcn_sched_barrier(0);   // here on the only vector loads in flight are the two tiles ahead
+#pragma unroll
+        for (int f = 0; f < NFD; ++f) commit(0, 0, f);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NFD; ++f) issue(0, min(2, tlast), f);
+        __syncthreads();
+#ifdef VKN_DEBUG
+        if constexpr (PF != 0) tprev = __builtin_amdgcn_s_memtime();
+#endif
+        for (int i0 = 0; i0 < T; i0 += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = i0 + u;
+                // the decode of tile i with this wave's loader units (tile i + 1 -> image (i + 1) % 3, request tile i + 3) in the gaps of
+                // its MFMA chain: one unit behind every k-step, fenced so that the scheduler cannot pull them back together
+                f32x16 acc;
+                const _Float16* bp = dimg + (size_t)(i % 3) * IMG + li * LDK + (g << 3);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = kbs[wave * 32 + vkn_cd_row(r, lane)];
+                {
+                    half8 rbh[3], rbl[3];
+                    auto ldb = [&](int slot, int ks) {
+                        rbh[slot] = *reinterpret_cast<const half8*>(bp + (ks << 4));
+                        if (!XH) rbl[slot] = *reinterpret_cast<const half8*>(bp + (ks << 4) + PLANE);
+                    };
+                    ldb(0, 0);
+                    if (KS > 1) ldb(1, 1);
+                    constexpr int NUNIT = 2 * NFD * 4;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if (ks + 2 < KS) ldb((ks + 2) % 3, ks + 2);
+                        if (has_dec) {
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], rbh[ks % 3], acc, 0, 0, 0);
+                            if (!XH) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], rbl[ks % 3], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[ks], rbh[ks % 3], acc, 0, 0, 0);
+                        }
+                        // units spread over the k-steps (KS = 16: one per k-step; fewer k-steps: several per k-step)
+#pragma unroll
+                        for (int uu = (ks * NUNIT) / KS; uu < ((ks + 1) * NUNIT) / KS; ++uu) loader_unit(NFD, u ^ 1, (i + 1) % 3, min(i + 3, tlast), uu);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (has_dec) {
+                    unsigned long long m[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[r] = __ballot(acc[r] >= thr);  // bit 32 g' + li' : row (r) + 4 g', image row li'
+                    __builtin_amdgcn_sched_barrier(0);   // (v_writelane right behind the v_cmp that wrote its SGPR reads a stale value)
+                    int wd = 0;
+#define FS_WL2(r) (int)(unsigned)m[r], (int)(unsigned)(m[r] >> 32)
+#define FS_WL8(wd, r0)                                                                                                              \
+    asm volatile("v_writelane_b32 %0, %1, %17\n\tv_writelane_b32 %0, %2, %18\n\tv_writelane_b32 %0, %3, %19\n\tv_writelane_b32 %0, %4, %20\n\t"   \
+                 "v_writelane_b32 %0, %5, %21\n\tv_writelane_b32 %0, %6, %22\n\tv_writelane_b32 %0, %7, %23\n\tv_writelane_b32 %0, %8, %24\n\t"   \
+                 "v_writelane_b32 %0, %9, %25\n\tv_writelane_b32 %0, %10, %26\n\tv_writelane_b32 %0, %11, %27\n\tv_writelane_b32 %0, %12, %28\n\t" \
+                 "v_writelane_b32 %0, %13, %29\n\tv_writelane_b32 %0, %14, %30\n\tv_writelane_b32 %0, %15, %31\n\tv_writelane_b32 %0, %16, %32"      \
+                 : "+v"(wd)                                                                                                         \
+                 : "s"((int)(unsigned)m[r0]), "s"((int)(unsigned)(m[r0] >> 32)), "s"((int)(unsigned)m[r0 + 1]),                     \
+                   "s"((int)(unsigned)(m[r0 + 1] >> 32)), "s"((int)(unsigned)m[r0 + 2]), "s"((int)(unsigned)(m[r0 + 2] >> 32)),      \
+                   "s"((int)(unsigned)m[r0 + 3]), "s"((int)(unsigned)(m[r0 + 3] >> 32)), "s"((int)(unsigned)m[r0 + 4]),              \
+                   "s"((int)(unsigned)(m[r0 + 4] >> 32)), "s"((int)(unsigned)m[r0 + 5]), "s"((int)(unsigned)(m[r0 + 5] >> 32)),      \
+                   "s"((int)(unsigned)m[r0 + 6]), "s"((int)(unsigned)(m[r0 + 6] >> 32)), "s"((int)(unsigned)m[r0 + 7]),              \
+                   "s"((int)(unsigned)(m[r0 + 7] >> 32)), "n"(FS_ROW(r0)), "n"(FS_ROW(r0) + 4), "n"(FS_ROW(r0 + 1)),                 \
+                   "n"(FS_ROW(r0 + 1) + 4), "n"(FS_ROW(r0 + 2)), "n"(FS_ROW(r0 + 2) + 4), "n"(FS_ROW(r0 + 3)), "n"(FS_ROW(r0 + 3) + 4), \
+                   "n"(FS_ROW(r0 + 4)), "n"(FS_ROW(r0 + 4) + 4), "n"(FS_ROW(r0 + 5)), "n"(FS_ROW(r0 + 5) + 4), "n"(FS_ROW(r0 + 6)),   \
+                   "n"(FS_ROW(r0 + 6) + 4), "n"(FS_ROW(r0 + 7)), "n"(FS_ROW(r0 + 7) + 4))
+#define FS_ROW(r) (((r)&3) + 8 * ((r) >> 2))
+                    FS_WL8(wd, 0);
+                    FS_WL8(wd, 8);
+                    if (lane < 32) {
+                        wbits[(i & 1) * 128 + wave * 32 + lane] = (unsigned)wd;
+                        cnt_i += __popc((unsigned)wd);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                FS_STAMP(4);
+                __syncthreads();
+                FS_STAMP(5);
+            }
+        }
+#ifdef VKN_DEBUG
+        if constexpr (PF != 0)
+            if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+                for (int k = 0; k < 8; ++k) g_fs_prof[wave][k] = prof[k];
+#endif
+        if (has_dec && lane < 32) cntp[((size_t)b * G + gidx) * NPT + n0 + wave * 32 + lane] = (float)cnt_i;
+    } else {
+        // =============================================================== gather role: channel blocks wave - 4 (+ 4)
+        const int gw = wave - 4;
+        f32x16 accg[CBW][NB];
+#pragma unroll
+        for (int j = 0; j < CBW; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accg[j][nb][r] = 0.f;
+#pragma unroll
+        for (int f = 0; f < NFG; ++f) issue(0, 0, f);
+#pragma unroll
+        for (int f = 0; f < NFG; ++f) issue(1, min(1, tlast), f);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NFG; ++f) commit(0, 0, f);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NFG; ++f) issue(0, min(2, tlast), f);
+        __syncthreads();
+        // operands of one tile: table rows a[ps][nb] (bit words -> 8 halfs {0, 1}) and a 3-deep ring of transposed x fragments
+        constexpr int NSTEP = 2 * CBW;   // (channel block j, 16-pixel half ps), j outer: every accumulator sees ps 0 (hi, lo), ps 1 (hi, lo)
+        half8 a[2][NB], fbh[3], fbl[3];
+        typedef __attribute__((address_space(3))) fs_short4 lds_s4;
+        // ds_read_b64_tr_b16 lane map (tools/micro/trprobe.hip): see k_fused_dgs
+        const int tg = lane >> 4, ta = (lane >> 2) & 3, tq = lane & 3;
+        const int toff = (4 * (tg >> 1) + (ta >> 1) + 16 * (ta & 1)) * LDK + 16 * (tg & 1) + 4 * tq;
+        auto ldf = [&](int slot, int st, const _Float16* dh) {
+            const int cb = gw + 4 * (st >> 1);
+            if (cb < NCB) {
+                const _Float16* cp = dh + toff + (8 * (st & 1)) * LDK + cb * 32;
+                const fs_short4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(cp));
+                const fs_short4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(cp + 2 * LDK));
+                fbh[slot] = __builtin_bit_cast(half8, (fs_short8)__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                if (!XH) {
+                    const fs_short4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(cp + PLANE));
+                    const fs_short4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(cp + PLANE + 2 * LDK));
+                    fbl[slot] = __builtin_bit_cast(half8, (fs_short8)__builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
+        };
+        auto prep = [&](int t) {   // tile t: its bit words are complete (written in phase A of iteration t, two barriers ago)
+            const _Float16* dh = dimg + (size_t)(t % 3) * IMG;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const unsigned wv = wbits[(t & 1) * 128 + nb * 32 + li];
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps)
+                    a[ps][nb] = lut[((wv >> (8 * ps + 4 * g)) & 0xFu) | (((wv >> (16 + 8 * ps + 4 * g)) & 0xFu) << 4)];
+            }
+            ldf(0, 0, dh);
+            if (NSTEP > 1) ldf(1, 1, dh);
+        };
+        auto gather = [&](int t) {
+            const _Float16* dh = dimg + (size_t)(t % 3) * IMG;
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                if (st + 2 < NSTEP) ldf((st + 2) % 3, st + 2, dh);
+                const int j = st >> 1, ps = st & 1, cb = gw + 4 * j;
+                if (cb < NCB) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        accg[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ps][nb], fbh[st % 3], accg[j][nb], 0, 0, 0);
+                        if (!XH) accg[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ps][nb], fbl[st % 3], accg[j][nb], 0, 0, 0);
+                    }
+                }
+            }
+        };
+#ifdef VKN_DEBUG
+        if constexpr (PF != 0) tprev = __builtin_amdgcn_s_memtime();
+#endif
+        for (int i0 = 0; i0 < T; i0 += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = i0 + u;
+                // the gather of tile i - 1 with this wave's loader units in the gaps of its MFMA stream (two units behind every group of
+                // four MFMAs), fenced against re-clustering
+                if (i >= 1) prep(i - 1);
+                {
+                    const _Float16* dh = dimg + (size_t)((i + 2) % 3) * IMG;   // image of tile i - 1
+                    constexpr int NUNIT = 2 * NFG * 4, NCH = NSTEP * (XH ? 1 : 2);
+                    int ch = 0;
+#pragma unroll
+                    for (int st = 0; st < NSTEP; ++st) {
+                        if (i >= 1 && st + 2 < NSTEP) ldf((st + 2) % 3, st + 2, dh);
+                        const int j = st >> 1, ps = st & 1, cb = gw + 4 * j;
+#pragma unroll
+                        for (int pl = 0; pl < (XH ? 1 : 2); ++pl) {
+                            if (i >= 1 && cb < NCB) {
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb)
+                                    accg[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ps][nb], pl ? fbl[st % 3] : fbh[st % 3], accg[j][nb], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int uu = (ch * NUNIT) / NCH; uu < ((ch + 1) * NUNIT) / NCH; ++uu) loader_unit(NFG, u ^ 1, (i + 1) % 3, min(i + 3, tlast), uu);
+                            ++ch;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                FS_STAMP(4);
+                __syncthreads();
+                FS_STAMP(5);
+            }
+        }
+        if (T >= 1) {   // the last tile (the decode waves are done)
+            prep(T - 1);
+            gather(T - 1);
+        }
+#ifdef VKN_DEBUG
+        if constexpr (PF != 0)
+            if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+                for (int k = 0; k < 8; ++k) g_fs_prof[wave][k] = prof[k];
+#endif
+#pragma unroll
+        for (int j = 0; j < CBW; ++j) {
+            const int cb = gw + 4 * j;
+            if (cb < NCB) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = n0 + nb * 32 + vkn_cd_row(r, lane);
+                        pp[(size_t)n * C + cb * 32 + li] = accg[j][nb][r];
+                    }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // k_fused_pq — ping-pong phases over 64-px PAIRS of strips (round 3, the shipped variant).  What the stamps of k_fused_pp added to
 // the picture: a wave's MFMAs on ONE accumulator issue every ~48 cycles, not 32 (2335 cycles for the 48 MFMAs of a strip) — the
 // dependent-accumulate latency of the 8-pass 32x32x16 MFMA; in k_fused_dgs the partner wave's MFMAs filled those gaps, in k_fused_pp
@@ -1168,7 +1571,7 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
     const int NPT = (N + 31) / 32 * 32;
     const int G = vkn_gather_groups(B, P);
 #ifdef VKN_DEBUG
-    const int variant = vkn_dbg_env("VKN_FUSED", 2);  // debug build A/B: 0 = k_fused_dg, 1 = k_fused_dg8, 2 = k_fused_dgs, 3 = k_fused_pp (4: profile), 5 = k_fused_pq (6: profile)
+    const int variant = vkn_dbg_env("VKN_FUSED", 10);  // debug build A/B: 0 = k_fused_dg, 1 = k_fused_dg8, 2 = k_fused_dgs, 3 = k_fused_pp (4: profile), 5 = k_fused_pq (6: profile), 10 = k_fused_il (shipped; 11: profile)
     const bool eight = variant == 1;
     const size_t lds = variant >= 2 ? fuseds_lds_bytes(C) : (eight ? fused8_lds_bytes(C) : fused_lds_bytes(C));
 #else
@@ -1189,6 +1592,12 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
         hipLaunchKernelGGL((k_fused_pq<NBV, CV, XHV, PFV>), grid, dim3(FS_THREADS), fusedq_lds_bytes(C), stream, x, kfh, kfl,  \
                            kb, thr, part, cntp, N, NPT, n0, P);                                                                \
     } while (0)
+#define FU_LAUNCH_IL(NBV, CV, XHV, PFV)                                                                                        \
+    do {                                                                                                                       \
+        VKN_ALLOW_FULL_LDS((k_fused_il<NBV, CV, XHV, PFV>));                                                                   \
+        hipLaunchKernelGGL((k_fused_il<NBV, CV, XHV, PFV>), grid, dim3(FS_THREADS), lds, stream, x, kfh, kfl, kb, thr, part,   \
+                           cntp, N, NPT, n0, P);                                                                               \
+    } while (0)
 #define FU_LAUNCH_PP(NBV, CV, XHV, PFV)                                                                                        \
     do {                                                                                                                       \
         VKN_ALLOW_FULL_LDS((k_fused_pp<NBV, CV, XHV, PFV>));                                                                   \
@@ -1206,6 +1615,8 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
         else if (variant == 8 && cfg2) FU_LAUNCH_PQ(4, 256, 0, 3);                         \
         else if (variant == 9 && cfg2) FU_LAUNCH_PQ(4, 256, 0, 4);                         \
         else if (variant == 3) FU_LAUNCH_PP(NBV, CV, XHV, 0);                              \
+        else if (variant == 10) FU_LAUNCH_IL(NBV, CV, XHV, 0);                             \
+        else if (variant == 11 && cfg2) FU_LAUNCH_IL(4, 256, 0, 1);                        \
         else if (variant == 5) FU_LAUNCH_PQ(NBV, CV, XHV, 0);                              \
         else if (cfg2 && vv != FS_V_DEFAULT) {                                             \
             switch (vv) {                                                                  \
@@ -1221,7 +1632,7 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
         } else FU_LAUNCH_XV(NBV, CV, XHV, FS_V_DEFAULT);                                   \
     } while (0)
 #else
-#define FU_LAUNCH_X(NBV, CV, XHV) FU_LAUNCH_XV(NBV, CV, XHV, FS_V_DEFAULT)
+#define FU_LAUNCH_X(NBV, CV, XHV) FU_LAUNCH_IL(NBV, CV, XHV, 0)
 #endif
 #define FU_LAUNCH_S(NBV, CV)                        \
     do {                                            \
@@ -1266,6 +1677,7 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
 #undef FU_LAUNCH_X
 #undef FU_LAUNCH_XV
 #undef FU_LAUNCH_PP
+#undef FU_LAUNCH_IL
 #undef FU_LAUNCH_PQ
         VKN_CHECK_LAUNCH();
     }

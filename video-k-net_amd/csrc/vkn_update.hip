@@ -1054,11 +1054,12 @@ int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int
     // per call: 36 us instead of 30 — the kernel is bound by the serial per-row chain of a wave, not by the staging
     const int rpw = 16;
     const size_t lds = ((size_t)2 * Nk * (hd + 4) + (size_t)rpw * hd + 4 * 256) * sizeof(float);
-    if (lds > 64 * 1024) return VKN_E_SHAPE;
+    if (lds > 160 * 1024) return VKN_E_SHAPE;   // (N = 216 kernels of 32-wide heads: 68 KB — beyond the 64 KB default limit)
     dim3 grid(heads, B, (Nq + rpw - 1) / rpw);
     const float scale = 1.0f / sqrtf((float)hd);
 #define ATT_CASE(H4)                                                                                                      \
     case H4:                                                                                                              \
+        if (lds > 64 * 1024) VKN_ALLOW_FULL_LDS(k_attn<H4>);                                                              \
         hipLaunchKernelGGL(k_attn<H4>, grid, dim3(256), lds, stream, Q, ldq, K, V, ldkv, out, ldo, Nq, Nk, scale, rpw);   \
         break;
     switch (hd / 4) {
