@@ -533,6 +533,71 @@ def run_train_case(name, p):
     print(f'{name}: ok  total={float(total):.5f}  ' + ' '.join(f'{k}={float(v):.4f}' for k, v in sorted(losses.items())[:6]))
 
 
+RPN_TRAIN_CASES = {
+    # the shipped rpn_head losses / train_cfg.rpn (configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:29-78, 143-150) behind the
+    # pass-through neck: x2 up-scaled predictions for assignment and losses, stuff kernels appended in training
+    'rpn_train_tiny': dict(C=64, nprop=12, ncls=5, n_thing=2, H=8, W=16, B=2, seed=91),
+    'rpn_train_cfg': dict(C=256, nprop=100, ncls=19, n_thing=2, H=16, W=32, B=2, seed=92),
+}
+
+
+def run_rpn_train_case(name, p):
+    """`ConvKernelHead.forward_train` of the reference (knet/det/kernel_head.py:267-336): losses, assignments, outputs handed to the
+    roi head, gradients of the summed loss w.r.t. both feature maps and every parameter."""
+    cfg = dict(type='ConvKernelHead', num_proposals=p['nprop'], in_channels=p['C'], out_channels=p['C'], num_loc_convs=0,
+               num_seg_convs=0, localization_fpn=dict(type='PassThroughNeck'), conv_kernel_size=1, semantic_fpn=True,
+               num_classes=p['ncls'], use_binary=True, proposal_feats_with_obj=True, feat_downsample_stride=2, feat_refine=False,
+               num_thing_classes=p['n_thing'], num_stuff_classes=p['ncls'] - p['n_thing'], cat_stuff_mask=True,
+               loss_rank=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=0.1),
+               loss_seg=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+               loss_mask=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+               loss_dice=dict(type='DiceLoss', loss_weight=4.0),
+               train_cfg=AttrDict(assigner=dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                                dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                                mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)),
+                                  sampler=dict(type='MaskPseudoSampler'), pos_weight=1))
+    head = build_head(cfg)
+    head.train()
+    loc, sem, shapes = init_inputs(dict(p, sem=True))
+    assert {k: tuple(v.shape) for k, v in head.state_dict().items()} == shapes
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, p['seed']).items()}, strict=True)
+    loc, sem = torch.from_numpy(loc).requires_grad_(True), torch.from_numpy(sem).requires_grad_(True)
+    tg = synth.train_targets(p['B'], p['n_thing'], p['ncls'] - p['n_thing'], 2 * p['H'], 2 * p['W'], p['seed'])
+    gt_masks = [torch.from_numpy(t['gt_masks']) for t in tg]
+    gt_labels = [torch.from_numpy(t['gt_labels']) for t in tg]
+    gt_sem_seg = [torch.from_numpy(t['gt_sem_seg']) for t in tg]
+    gt_sem_cls = [torch.from_numpy(t['gt_sem_cls']) for t in tg]
+    assigned = []
+    orig = head.assigner.assign
+
+    def rec(*args, **kw):
+        r = orig(*args, **kw)
+        assigned.append(r.gt_inds.clone())
+        return r
+    head.assigner.assign = rec
+    losses, prop, x_feats, masks, cls = head.forward_train((loc, sem), [dict() for _ in range(p['B'])], gt_masks, gt_labels,
+                                                           gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+    assert cls is None
+    total = sum(v for k, v in losses.items() if 'loss' in k) + 1e-3 * (prop ** 2).mean() + 1e-3 * (masks ** 2).mean()
+    total.backward()
+    named = dict(head.named_parameters())
+    out = dict(case=np.array([p['C'], p['nprop'], p['ncls'], p['n_thing'], p['H'], p['W'], p['B'], p['seed'], 1, 1], dtype=np.int64),
+               loss_keys=np.array(sorted(losses)), loss_vals=np.array([float(losses[k].detach()) for k in sorted(losses)], dtype=np.float64),
+               total=np.float64(float(total.detach())), assigned=torch.stack(assigned).numpy(),
+               proposal_feats=prop.detach().numpy(), mask_rowsum=masks.detach().double().sum(dim=(-1, -2)).numpy(),
+               grad_keys=np.array(sorted(named)))
+    big = p['C'] > 64
+    for tag, t in [('grad_loc', loc.grad), ('grad_sem', sem.grad)] + [(f'grad_{i}', named[k].grad) for i, k in enumerate(sorted(named))]:
+        if not big or t.numel() <= 8192:
+            out[tag] = t.numpy()
+        else:
+            idx = (synth.uniform((4096,), 6161 + len(tag), 0.0, 1.0).astype(np.float64) * t.numel()).astype(np.int64)
+            out[tag + '_idx'], out[tag + '_val'] = idx, t.reshape(-1)[idx].numpy()
+            out[tag + '_norm'] = np.float64(float(t.double().norm()))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(f'{name}: ok  total={float(total):.5f}  ' + ' '.join(f'{k}={float(v):.4f}' for k, v in sorted(losses.items())))
+
+
 def run_instance_case():
     """Instance-only results (do_panoptic=False): KernelIterHead.simple_test -> top-k -> get_seg_masks / segm2result
     (knet/det/kernel_iter_head.py:270-281, knet/det/kernel_update_head.py:443-481), YouTube-VIS-like class layout (things only)."""
@@ -628,6 +693,9 @@ if __name__ == '__main__':
     for name, p in TRAIN_CASES.items():
         if not only or name in only:
             run_train_case(name, p)
+    for name, p in RPN_TRAIN_CASES.items():
+        if not only or name in only:
+            run_rpn_train_case(name, p)
     if not only or 'assign_soft' in only:
         run_assign_soft()
     if not only or 'inst_tiny' in only:

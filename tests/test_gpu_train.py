@@ -145,3 +145,61 @@ def test_soft_gt_assignment_vs_reference(vkn):
     assert np.array_equal(res.gt_inds.cpu().numpy(), g['gt_inds']) and np.array_equal(res.labels.cpu().numpy(), g['labels'])
     with pytest.raises(IndexError):
         a.cost_matrix(logits.to(DEV), cls.to(DEV), gt.to(DEV), torch.full_like(labels, 255).to(DEV))
+
+
+@pytest.mark.parametrize('name', ['rpn_train_tiny', 'rpn_train_cfg'])
+def test_conv_kernel_head_forward_train_vs_reference_golden(vkn, name):
+    """`ConvKernelHead.forward_train` (knet/det/kernel_head.py:267-336) with the shipped rpn losses / train_cfg: losses, Hungarian
+    assignments, what it hands to the roi head, and gradients w.r.t. both feature maps and every parameter — against the
+    reference's own forward_train + autograd (oracle/gen_golden.py: RPN_TRAIN_CASES).  The two 1x1 convs and the object-feature
+    gather run (and back-propagate) through the HIP decode / gather kernels."""
+    from helpers import GOLDEN, INIT_FIELDS, make_init_case
+    g = dict(np.load(f'{GOLDEN}/{name}.npz', allow_pickle=False))
+    p = dict(zip(INIT_FIELDS, (int(v) for v in g['case'])))
+    loc, sem, iw, sw, sb = make_init_case(p)
+    head = vkn.build_head(dict(
+        type='ConvKernelHead', num_proposals=p['nprop'], in_channels=p['C'], out_channels=p['C'], num_loc_convs=0, num_seg_convs=0,
+        localization_fpn=None, conv_kernel_size=1, semantic_fpn=True, num_classes=p['ncls'], use_binary=True,
+        proposal_feats_with_obj=True, feat_downsample_stride=2, feat_refine=False, num_thing_classes=p['n_thing'],
+        num_stuff_classes=p['ncls'] - p['n_thing'], cat_stuff_mask=True,
+        loss_rank=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=0.1),
+        loss_seg=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+        loss_mask=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0), loss_dice=dict(type='DiceLoss', loss_weight=4.0),
+        train_cfg=dict(assigner=dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                     dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                     mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)),
+                       sampler=dict(type='MaskPseudoSampler'), pos_weight=1)))
+    head.load_state_dict({'init_kernels.weight': iw, 'conv_seg.weight': sw, 'conv_seg.bias': sb}, strict=True)
+    head = head.to(DEV).train()
+    head._upstream_feats = lambda img: img          # the pass-through neck of the golden: (loc_feats, semantic_feats) are the input
+    locd, semd = loc.to(DEV).requires_grad_(True), sem.to(DEV).requires_grad_(True)
+    tg = synth.train_targets(p['B'], p['n_thing'], p['ncls'] - p['n_thing'], 2 * p['H'], 2 * p['W'], p['seed'])
+    t = lambda key: [torch.from_numpy(e[key]).to(DEV) for e in tg]  # noqa: E731
+    assigned = []
+    orig = head.assigner.assign
+
+    def rec(*args, **kw):
+        r = orig(*args, **kw)
+        assigned.append(r.gt_inds.clone())
+        return r
+    head.assigner.assign = rec
+    losses, prop, x_feats, masks, cls = head.forward_train((locd, semd), [dict() for _ in range(p['B'])], t('gt_masks'), t('gt_labels'),
+                                                           gt_sem_seg=t('gt_sem_seg'), gt_sem_cls=t('gt_sem_cls'))
+    assert cls is None and sorted(losses) == list(g['loss_keys'])
+    assert np.array_equal(torch.stack(assigned).cpu().numpy(), g['assigned']), 'Hungarian assignments must be bit-exact'
+    for k, ref in zip(g['loss_keys'], g['loss_vals']):
+        assert abs(float(losses[k]) - ref) < 1e-4 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
+    N = p['nprop'] + p['ncls'] - p['n_thing']
+    assert tuple(prop.shape) == (p['B'], N, p['C'], 1, 1) and tuple(masks.shape) == (p['B'], N, p['H'], p['W'])
+    assert maxabs(prop, g['proposal_feats']) < 1e-3 * (1 + float(np.abs(g['proposal_feats']).max()))
+    rs = masks.detach().double().sum(dim=(-1, -2)).cpu().numpy()
+    assert np.max(np.abs(rs - g['mask_rowsum'])) < 1e-4 * p['H'] * p['W'] * 8
+    total = sum(v for k, v in losses.items() if 'loss' in k) + 1e-3 * (prop ** 2).mean() + 1e-3 * (masks ** 2).mean()
+    assert abs(float(total) - float(g['total'])) < 1e-4 * abs(float(g['total']))
+    total.backward()
+    _check_grad(g, 'grad_loc', locd.grad)
+    _check_grad(g, 'grad_sem', semd.grad)
+    named = dict(head.named_parameters())
+    assert sorted(named) == list(g['grad_keys'])
+    for i, k in enumerate(g['grad_keys']):
+        _check_grad(g, f'grad_{i}', named[str(k)].grad)

@@ -205,6 +205,28 @@ def test_mask_hungarian_assigner_surface(vkn):
     assert r.num_gts == 0 and (r.gt_inds == 0).all()
 
 
+def test_conv_kernel_head_training_surface(vkn):
+    """The shipped rpn_head dict (losses + train_cfg.rpn) builds: losses / assigner / sampler as the reference (knet/det/kernel_head.py:
+    90-120), no extra state-dict keys, the reference's loss / target helpers are present."""
+    g = dict(np.load(os.path.join(GOLDEN, 'init_keys.npz'), allow_pickle=False))
+    head = vkn.build_head(dict(
+        type='ConvKernelHead', num_classes=19, num_thing_classes=2, num_stuff_classes=17, cat_stuff_mask=True, conv_kernel_size=1,
+        feat_downsample_stride=2, feat_refine_stride=1, feat_refine=False, use_binary=True, num_loc_convs=1, num_seg_convs=1,
+        conv_normal_init=True, localization_fpn=None, num_proposals=100, proposal_feats_with_obj=True, xavier_init_kernel=False,
+        kernel_init_std=1, loss_rank=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=0.1),
+        loss_seg=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+        loss_mask=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0), loss_dice=dict(type='DiceLoss', loss_weight=4.0),
+        train_cfg=dict(assigner=dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                     dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                     mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)),
+                       sampler=dict(type='MaskPseudoSampler'), pos_weight=1)))
+    assert sorted(head.state_dict()) == list(g['kitti_keys'])
+    assert type(head.assigner).__name__ == 'MaskHungarianAssigner' and type(head.sampler).__name__ == 'MaskPseudoSampler'
+    assert head.loss_seg.use_sigmoid and head.loss_cls is None and head.loss_rank is not None
+    for m in ('forward_train', 'loss', 'get_targets', '_get_target_single', 'simple_test_rpn'):
+        assert callable(getattr(head, m))
+
+
 def test_quasi_dense_tracker_surface(vkn):
     """Registry name / ctor kwargs of the reference's tracker; no CPU path (the association runs in vkn_qd_tracker_match_f32)."""
     cfg = dict(type='QuasiDenseEmbedTracker', init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5,

@@ -11,9 +11,12 @@ end to end, and run on the GPU through PyTorch-ROCm.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from . import autograd as vag
 from . import ops
-from .registry import HAVE_MM, HEADS, register_head
+from .losses import accuracy, reduce_mean
+from .registry import HAVE_MM, HEADS, build_assigner, build_loss, build_sampler, register_head
 
 
 class _ConvGNReLU(nn.Module):
@@ -83,7 +86,17 @@ class ConvKernelHead(nn.Module):
         self.cat_stuff_mask = cat_stuff_mask
         self.loss_cfgs = dict(loss_mask=loss_mask, loss_seg=loss_seg, loss_cls=loss_cls, loss_dice=loss_dice, loss_rank=loss_rank)
         self.localization_fpn = self._build_neck(localization_fpn)
+        # losses, assigner and sampler exactly as the reference builds them (knet/det/kernel_head.py:90-120)
+        for key, cfg in self.loss_cfgs.items():
+            setattr(self, key, build_loss(dict(cfg)) if cfg is not None else None)
+        if self.train_cfg:
+            self.assigner = build_assigner(self._cfg(self.train_cfg, 'assigner'))
+            self.sampler = build_sampler(dict(type='MaskPseudoSampler'), context=self)     # `self.sampling` is False (:56, :113-117)
         self._init_layers()
+
+    @staticmethod
+    def _cfg(cfg, key):
+        return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
 
     @staticmethod
     def _build_neck(cfg):
@@ -154,9 +167,10 @@ class ConvKernelHead(nn.Module):
     def decode_init_proposals_from_feats(self, loc_feats, semantic_feats=None):
         """The hot part of `_decode_init_proposals` (knet/det/kernel_head.py:221-263) in one C-ABI call.
         Returns the reference's 5-tuple `(proposal_feats [B,N,C,1,1], x_feats, mask_preds, cls_scores=None, seg_preds)`."""
+        if torch.is_grad_enabled() and (loc_feats.requires_grad or (semantic_feats is not None and semantic_feats.requires_grad)
+                                        or any(p.requires_grad for p in (self.init_kernels.weight,))):
+            return self._decode_autograd(loc_feats, semantic_feats)
         cat = self.cat_stuff_mask and not self.training
-        if self.cat_stuff_mask and self.training:
-            raise NotImplementedError('training is a later row (SURVEY.md §8(f)); this build covers inference')
         prop, x_feats, mask_preds, seg_preds = ops.kernel_init(
             loc_feats, semantic_feats if self.semantic_fpn else None, self.init_kernels.weight,
             self.conv_seg.weight if self.semantic_fpn else None, self.conv_seg.bias if self.semantic_fpn else None,
@@ -177,6 +191,141 @@ class ConvKernelHead(nn.Module):
         """knet/det/kernel_head.py:510-515."""
         return self._decode_init_proposals(img, img_metas)
 
-    def forward_train(self, *args, **kwargs):
-        raise NotImplementedError('training (assignment + losses, knet/det/kernel_head.py:265-504) is a later row; this build '
-                                  'covers the inference hot path')
+    # ------------------------------------------------------------------------------------------------------------------ training
+    def _decode_autograd(self, loc_feats, semantic_feats):
+        """Differentiable `_decode_init_proposals` after the loc / seg convs (knet/det/kernel_head.py:221-263): the two 1x1 convs are
+        the HIP decode (frame-shared kernels; the expand's backward sums their gradient over the frames), the object features the
+        HIP gather — both through their autograd wrappers (video-k-net_amd/autograd.py).  The stuff concatenation is the eval
+        branch (:255-263); in training `forward_train` appends the stuff kernels itself (:326-334)."""
+        B, C = loc_feats.shape[:2]
+        Np = self.num_proposals
+        w = self.init_kernels.weight.reshape(Np, C)
+        mask_preds = vag.mask_decode(loc_feats, w[None].expand(B, Np, C))                                  # :222
+        seg_preds = None
+        if self.semantic_fpn:
+            sw = self.conv_seg.weight.reshape(self.num_classes, C)
+            seg_preds = vag.mask_decode(semantic_feats, sw[None].expand(B, self.num_classes, C),
+                                        self.conv_seg.bias[None].expand(B, self.num_classes))               # :231-234
+        proposal_feats = self.init_kernels.weight[None].expand(B, Np, C, 1, 1)                             # :234-236
+        x_feats = semantic_feats + loc_feats if semantic_feats is not None else loc_feats                  # :238-241
+        if self.proposal_feats_with_obj:
+            if not self.use_binary:
+                raise NotImplementedError('training with use_binary=False (soft gather weights) is not built (no shipped config)')
+            obj, _ = vag.mask_gather(x_feats, mask_preds.detach(), 0.5)                                    # :243-250 (bool mask: no grad)
+            proposal_feats = proposal_feats + obj.view(B, Np, C, 1, 1)                                     # :252-254
+        if self.cat_stuff_mask and not self.training:                                                       # :255-263
+            mask_preds = torch.cat([mask_preds, seg_preds[:, self.num_thing_classes:]], dim=1)
+            stuff = self.conv_seg.weight[self.num_thing_classes:].clone()
+            proposal_feats = torch.cat([proposal_feats, stuff[None].expand(B, *stuff.shape)], dim=1)
+        return proposal_feats, x_feats, mask_preds, None, seg_preds
+
+    def forward_train(self, img, img_metas, gt_masks, gt_labels, gt_sem_seg=None, gt_sem_cls=None):
+        """-> (losses, proposal_feats, x_feats, mask_preds, cls_scores)                           knet/det/kernel_head.py:267-336"""
+        if not self.train_cfg:
+            raise RuntimeError('forward_train needs train_cfg (assigner / pos_weight)')
+        num_imgs = len(img_metas)
+        proposal_feats, x_feats, mask_preds, cls_scores, seg_preds = self._decode_init_proposals(img, img_metas)
+        s_ = self.feat_downsample_stride
+        if s_ > 1:
+            scaled_mask_preds = F.interpolate(mask_preds, scale_factor=s_, mode='bilinear', align_corners=False)
+            scaled_seg_preds = (F.interpolate(seg_preds, scale_factor=s_, mode='bilinear', align_corners=False)
+                                if seg_preds is not None else None)
+        else:
+            scaled_mask_preds, scaled_seg_preds = mask_preds, seg_preds
+        if self.hard_target:
+            gt_masks = [g.bool().float() for g in gt_masks]
+        sampling_results = []
+        for i in range(num_imgs):
+            assign_result = self.assigner.assign(scaled_mask_preds[i].detach(), None, gt_masks[i], gt_labels[i], img_metas[i])
+            sampling_results.append(self.sampler.sample(assign_result, scaled_mask_preds[i], gt_masks[i]))
+        mask_targets = self.get_targets(sampling_results, gt_masks, self.train_cfg, True, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+        losses = self.loss(scaled_mask_preds, cls_scores, scaled_seg_preds, proposal_feats, *mask_targets)
+        if self.cat_stuff_mask and self.training:
+            mask_preds = torch.cat([mask_preds, seg_preds[:, self.num_thing_classes:]], dim=1)
+            stuff_kernels = self.conv_seg.weight[self.num_thing_classes:].clone()
+            proposal_feats = torch.cat([proposal_feats, stuff_kernels[None].expand(num_imgs, *stuff_kernels.size())], dim=1)
+        return losses, proposal_feats, x_feats, mask_preds, cls_scores
+
+    def loss(self, mask_pred, cls_scores, seg_preds, proposal_feats, labels, label_weights, mask_targets, mask_weights, seg_targets,
+             reduction_override=None, **kwargs):
+        """`loss_rpn_mask / _dice / _rank / _seg` (+ `_cls`, `rpn_pos_acc` when the head scores classes)      :338-425"""
+        losses = dict()
+        bg = self.num_classes
+        pos = (labels >= 0) & (labels < bg)
+        num_preds = mask_pred.shape[0] * mask_pred.shape[1]
+        if cls_scores is not None:
+            avg_factor = reduce_mean(pos.sum().float())
+            losses['loss_rpn_cls'] = self.loss_cls(cls_scores.view(num_preds, -1), labels, label_weights, avg_factor=avg_factor,
+                                                   reduction_override=reduction_override)
+            losses['rpn_pos_acc'] = accuracy(cls_scores.view(num_preds, -1)[pos], labels[pos])
+        H, W = mask_pred.shape[-2:]
+        if pos.any():
+            pos_mask_pred = mask_pred.reshape(num_preds, H, W)[pos]
+            pos_mask_targets = mask_targets[pos]
+            losses['loss_rpn_mask'] = self.loss_mask(pos_mask_pred, pos_mask_targets)
+            losses['loss_rpn_dice'] = self.loss_dice(pos_mask_pred, pos_mask_targets)
+            if self.loss_rank is not None:
+                # every pixel gets the LARGEST positive kernel index whose target covers it (the reference paints the targets in
+                # ascending kernel order, :375-386) — a masked max over the kernel axis instead of a per-instance host loop
+                B = mask_pred.size(0)
+                n = mask_targets.shape[0] // B
+                covered = mask_targets.view(B, n, H, W).bool() & pos.view(B, n, 1, 1)
+                idx = torch.arange(n, device=mask_targets.device, dtype=torch.int16).view(1, n, 1, 1)
+                top = torch.where(covered, idx, idx.new_full((), -1)).amax(dim=1).long()
+                rank_target = torch.where(top >= 0, top, top.new_full((), self.ignore_label))
+                losses['loss_rpn_rank'] = self.loss_rank(mask_pred, rank_target, ignore_index=self.ignore_label)
+        else:
+            losses['loss_rpn_mask'] = mask_pred.sum() * 0
+            losses['loss_rpn_dice'] = mask_pred.sum() * 0
+            if self.loss_rank is not None:
+                losses['loss_rank'] = mask_pred.sum() * 0                                     # (the reference's key, :393)
+        if seg_preds is not None:
+            ch = seg_preds.shape[1]
+            flat = seg_preds.view(-1, ch, H * W).permute(0, 2, 1).reshape(-1, ch)
+            tgt = seg_targets.view(-1)
+            if self.loss_seg.use_sigmoid:                                                       # focal (:397-410)
+                dense_pos = ((tgt >= 0) & (tgt < bg)).sum().float().clamp(min=1.0)
+                losses['loss_rpn_seg'] = self.loss_seg(flat, tgt, avg_factor=dense_pos)
+            else:                                                                               # ce (:412-418)
+                losses['loss_rpn_seg'] = self.loss_seg(flat, tgt, ignore_index=self.num_classes)
+        return losses
+
+    def _get_target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls, cfg):
+        """:427-466.  `seg_targets`: the dense semantic target — stuff classes first, then every positive instance's label painted
+        over its ground-truth mask in sample order."""
+        num_pos, num_neg = pos_mask.size(0), neg_mask.size(0)
+        n = num_pos + num_neg
+        H, W = pos_mask.shape[-2:]
+        labels = pos_mask.new_full((n,), self.num_classes, dtype=torch.long)
+        label_weights = pos_mask.new_zeros(n)
+        mask_targets = pos_mask.new_zeros(n, H, W)
+        mask_weights = pos_mask.new_zeros(n, H, W)
+        seg_targets = pos_mask.new_full((H, W), self.num_classes, dtype=torch.long)
+        if gt_sem_cls is not None and gt_sem_seg is not None:
+            for sem_mask, sem_cls in zip(gt_sem_seg.bool(), gt_sem_cls):
+                seg_targets[sem_mask] = sem_cls.long()
+        if num_pos > 0:
+            labels[pos_inds] = pos_gt_labels
+            pw = self._cfg(cfg, 'pos_weight')
+            label_weights[pos_inds] = 1.0 if pw <= 0 else pw
+            mask_targets[pos_inds, ...] = pos_gt_mask
+            mask_weights[pos_inds, ...] = 1
+            for i in range(num_pos):
+                seg_targets[pos_gt_mask[i].bool()] = pos_gt_labels[i]
+        if num_neg > 0:
+            label_weights[neg_inds] = 1.0
+        return labels, label_weights, mask_targets, mask_weights, seg_targets
+
+    def get_targets(self, sampling_results, gt_mask, rpn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None):
+        """:468-504"""
+        n = len(sampling_results)
+        if gt_sem_seg is None:
+            gt_sem_seg, gt_sem_cls = [None] * n, [None] * n      # (the reference hard-codes 2, :480-481)
+        out = [self._get_target_single(r.pos_inds, r.neg_inds, r.pos_masks, r.neg_masks, r.pos_gt_masks, r.pos_gt_labels,
+                                       gt_sem_seg[i], gt_sem_cls[i], rpn_train_cfg) for i, r in enumerate(sampling_results)]
+        labels, label_weights, mask_targets, mask_weights, seg_targets = (list(t) for t in zip(*out))
+        if concat:
+            labels, label_weights = torch.cat(labels, 0), torch.cat(label_weights, 0)
+            mask_targets, mask_weights = torch.cat(mask_targets, 0), torch.cat(mask_weights, 0)
+            seg_targets = torch.stack(seg_targets, 0)
+        return labels, label_weights, mask_targets, mask_weights, seg_targets
