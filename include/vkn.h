@@ -220,6 +220,19 @@ int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* 
 int vkn_link_block_f32(const VknDims* d, const VknStageWeights* w, const float* update_feature, const float* cur,
                        const float* prev, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- clip-level QUERY MERGE of the VIS heads, query_merge_method = "attention" | "attention_pos"
+ *      (knet_vis/tracker/kernel_frame_iter_head.py:142-160 on the per-frame object features;
+ *       knet_vis/tracker/kernel_update_head.py:244-263 on the per-frame gathers):
+ *        out = query_merge_ffn_norm(query_merge_ffn(query_merge_norm(
+ *                  query_merge_attn(query, key = value = keys, query_pos = pos, key_pos = pos repeated per frame))))      (8 heads)
+ *      d: B = clips, N = queries (= kernels) per clip, ff = the merge FFN's width (8 C in the reference).
+ *      query [B][N][C]; keys [B][num_frames * N][C] (frame-major: key f * N + n is kernel n of frame f); pos [N][C] or NULL;
+ *      out [B][N][C].  `w`: only pa_* (query_merge_attn.attn.*, query_merge_norm.*) and lffn* (query_merge_ffn.*, query_merge_ffn_norm.*).
+ *      num_frames * N may exceed 256 (up to 10240 keys).  ws: vkn_query_merge_workspace_bytes. */
+size_t vkn_query_merge_workspace_bytes(const VknDims* d, int num_frames);
+int vkn_query_merge_f32(const VknDims* d, int num_frames, const VknStageWeights* w, const float* query, const float* keys,
+                        const float* pos, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- vkn_stage_forward_f32 for the heads with previous_link / previous_type = "update" | "update_obj"
  *      (`VideoKernelUpdateHead.forward`, knet/video/kernel_update_head.py:281-541, all branches): link_pre (or NULL) rewrites obj_in
  *      from prev_obj before the update, link_track (or NULL = the stage's own "ffn" link) produces track_out; track_src: update

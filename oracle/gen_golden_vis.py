@@ -7,6 +7,7 @@ and `mmdet.datasets.coco_panoptic` stand-ins).  Only outputs are stored.
 
     python oracle/gen_golden_vis.py        # writes tests/golden/vis_*.npz
 
+  vis_attn_* the same pipeline with query_merge_method = 'attention' / 'attention_pos' in the tracker and its clip-level stages
   vis_tiny   KernelIterHeadVideo (per-frame roi head, instance results + features) -> KernelFrameIterHeadVideo (clip-level tracker:
              query fusion 'mean', 3 stages with assign_stages = 2: two clip-level `with_cls` stages, one per-frame stage)
 """
@@ -61,17 +62,20 @@ def pack_masks(mask_results):
     return (np.packbits(np.stack(masks).astype(bool)), len(masks)) if masks else (np.zeros(0, np.uint8), 0)
 
 
-def run(name, C, heads, ffn, ncls, N, H, W, up, S, bs, nf, seed, kmax):
+def run(name, C, heads, ffn, ncls, N, H, W, up, S, bs, nf, seed, kmax, merge='mean'):
     test_cfg = AttrDict(max_per_img=kmax, mask_thr=0.5)
     roi = build_head(dict(type='KernelIterHeadVideo', num_stages=S, stage_loss_weights=[1] * S, proposal_feature_channel=C,
                           num_thing_classes=ncls, num_stuff_classes=0, num_proposals=N, test_cfg=test_cfg,
                           mask_head=[stage_cfg('KernelUpdateHead', C, heads, ffn, ncls, up) for _ in range(S)]))
     trk = build_head(dict(type='KernelFrameIterHeadVideo', num_proposals=N, num_stages=3, assign_stages=2, proposal_feature_channel=C,
                           stage_loss_weights=(1., 1., 1.), num_thing_classes=ncls, num_stuff_classes=0, test_cfg=test_cfg,
-                          mask_head=stage_cfg('KernelUpdateHeadVideo', C, heads, ffn, ncls, up, num_proposals=N)))
+                          query_merge_method=merge,
+                          mask_head=stage_cfg('KernelUpdateHeadVideo', C, heads, ffn, ncls, up, num_proposals=N, query_merge_method=merge)))
     roi.eval()
     trk.eval()
     out = dict(case=np.array([C, heads, ffn, ncls, N, H, W, up, S, bs, nf, seed, kmax], dtype=np.int64))
+    if merge != 'mean':
+        out['merge'] = np.array(merge)
     for tag, mod, sd_seed in (('roi', roi, seed), ('trk', trk, seed + 1)):
         shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
         mod.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, sd_seed).items()}, strict=True)
@@ -86,6 +90,9 @@ def run(name, C, heads, ffn, ncls, N, H, W, up, S, bs, nf, seed, kmax):
         res, feats = roi.simple_test(x, pf, mp, None, img_metas, ref_img_metas, rescale=True)
         tres, tfeats = trk.simple_test(x=feats['x_feats'], img_metas=img_metas, ref_img_metas=ref_img_metas, cls_scores=feats['cls_scores'],
                                        masks=feats['masks'], obj_feats=feats['obj_feats'])
+    if merge != 'mean':   # the fused clip-level kernels alone (pins oracle.query_merge; tests/test_oracle_golden.py)
+        with torch.no_grad():
+            out['trk_query_fusion'] = trk._query_fusion(feats['obj_feats'], bs, nf).numpy()
     for k in ('obj_feats', 'cls_scores', 'masks'):
         out['roi_' + k] = feats[k].numpy()
         out['trk_' + k] = tfeats[k].numpy()
@@ -107,3 +114,7 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     run('vis_tiny', C=64, heads=8, ffn=128, ncls=7, N=20, H=8, W=16, up=2, S=2, bs=2, nf=3, seed=91, kmax=10)
     run('vis_cfg', C=256, heads=8, ffn=2048, ncls=40, N=100, H=12, W=20, up=2, S=3, bs=1, nf=2, seed=93, kmax=10)
+    # query_merge_method 'attention' / 'attention_pos' (no shipped config sets them; the classes build and run them)
+    run('vis_attn_tiny', C=64, heads=8, ffn=128, ncls=7, N=20, H=8, W=16, up=2, S=2, bs=2, nf=3, seed=95, kmax=10, merge='attention')
+    run('vis_attnpos_tiny', C=64, heads=8, ffn=128, ncls=7, N=20, H=8, W=16, up=2, S=2, bs=2, nf=3, seed=96, kmax=10, merge='attention_pos')
+    run('vis_attnpos_cfg', C=256, heads=8, ffn=2048, ncls=40, N=100, H=12, W=20, up=2, S=3, bs=1, nf=3, seed=97, kmax=10, merge='attention_pos')

@@ -122,6 +122,26 @@ def link_block(sd, pfx, sfx, with_updator, update_feature, cur, prev, cfg: HeadC
     return _ln(sd, f'{pfx}.link_ffn_norm{sfx}', ffn(sd, f'{pfx}.link_ffn{sfx}', t, cfg.num_ffn_fcs), cfg.ln_eps)
 
 
+def query_merge(sd, pfx, query, keys, pos=None, ln_eps=1e-5):
+    """Clip-level attention query merge of the VIS heads (knet_vis/tracker/kernel_frame_iter_head.py:142-160,
+    knet_vis/tracker/kernel_update_head.py:244-263):
+         t   = query_merge_norm(query_merge_attn(query=query, key=keys, value=keys, query_pos=pos, key_pos=pos per frame))   (8 heads)
+         out = query_merge_ffn_norm(query_merge_ffn(t))
+    mmcv's MultiheadAttention adds the positions to query / key only: value and the residual (identity) stay without them.
+    query [B,N,C], keys [B,F*N,C] (frame-major), pos [N,C] | None -> [B,N,C].  `pfx` '' or 'mask_head.0' etc."""
+    B, N, C = query.shape
+    F_ = keys.shape[1] // N
+    p = (pfx + '.') if pfx else ''
+    q, k = query, keys
+    if pos is not None:
+        q = query + pos[None]
+        k = keys + pos[None].repeat(1, F_, 1)
+    t = multihead_attention(sd, p + 'query_merge_attn', q.permute(1, 0, 2), k.permute(1, 0, 2), keys.permute(1, 0, 2),
+                            query.permute(1, 0, 2), 8).permute(1, 0, 2)
+    t = _ln(sd, p + 'query_merge_norm', t, ln_eps)
+    return _ln(sd, p + 'query_merge_ffn_norm', ffn(sd, p + 'query_merge_ffn', t, 2), ln_eps)
+
+
 def binarize(mask_logits, thr):
     """knet/det/kernel_update_head.py:190-192: (sigmoid(z) > hard_mask_thr).float()."""
     return (mask_logits.sigmoid() > thr).to(mask_logits.dtype)

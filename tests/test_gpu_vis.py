@@ -12,6 +12,7 @@ from helpers import GOLDEN, maxabs
 from oracle import synth
 
 DEV = 'cuda:0'
+VIS_CASES = ['vis_tiny', 'vis_cfg', 'vis_attn_tiny', 'vis_attnpos_tiny', 'vis_attnpos_cfg']
 VIS_FIELDS = ('C', 'heads', 'ffn', 'ncls', 'N', 'H', 'W', 'up', 'S', 'bs', 'nf', 'seed', 'kmax')
 
 
@@ -23,18 +24,19 @@ def _stage_cfg(vkn, typ, c, **extra):
 def _build(vkn, name):
     g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
     c = dict(zip(VIS_FIELDS, (int(v) for v in g['case'])))
+    merge = str(g['merge']) if 'merge' in g else 'mean'
     test_cfg = dict(max_per_img=c['kmax'], mask_thr=0.5)
     roi = vkn.build_head(dict(type='KernelIterHeadVideo', num_stages=c['S'], stage_loss_weights=[1] * c['S'],
                               proposal_feature_channel=c['C'], num_thing_classes=c['ncls'], num_stuff_classes=0, num_proposals=c['N'],
                               test_cfg=test_cfg, mask_head=[_stage_cfg(vkn, 'KernelUpdateHead', c) for _ in range(c['S'])]))
     trk = vkn.build_head(dict(type='KernelFrameIterHeadVideo', num_proposals=c['N'], num_stages=3, assign_stages=2,
                               proposal_feature_channel=c['C'], stage_loss_weights=(1., 1., 1.), num_thing_classes=c['ncls'],
-                              num_stuff_classes=0, test_cfg=test_cfg,
-                              mask_head=_stage_cfg(vkn, 'KernelUpdateHeadVideo', c, num_proposals=c['N'])))
+                              num_stuff_classes=0, test_cfg=test_cfg, query_merge_method=merge,
+                              mask_head=_stage_cfg(vkn, 'KernelUpdateHeadVideo', c, num_proposals=c['N'], query_merge_method=merge)))
     return g, c, roi, trk
 
 
-@pytest.mark.parametrize('name', ['vis_tiny', 'vis_cfg'])
+@pytest.mark.parametrize('name', VIS_CASES)
 def test_vis_heads_state_dict_matches_reference(vkn, name):
     """CPU: same keys and shapes as the reference's knet_vis modules (with_cls=False stages have no classification branch)."""
     g, c, roi, trk = _build(vkn, name)
@@ -49,7 +51,7 @@ def _unpack(bits, n, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['vis_tiny', 'vis_cfg'])
+@pytest.mark.parametrize('name', VIS_CASES)
 def test_vis_pipeline_vs_reference_golden(vkn, name):
     g, c, roi, trk = _build(vkn, name)
     for mod, seed in ((roi, c['seed']), (trk, c['seed'] + 1)):
@@ -65,6 +67,9 @@ def test_vis_pipeline_vs_reference_golden(vkn, name):
         res, feats = roi.simple_test(x, pf, mp, None, img_metas, ref_img_metas, rescale=True)
         tres, tfeats = trk.simple_test(x=feats['x_feats'], img_metas=img_metas, ref_img_metas=ref_img_metas,
                                        cls_scores=feats['cls_scores'], masks=feats['masks'], obj_feats=feats['obj_feats'])
+    if 'trk_query_fusion' in g:   # the attention query merge alone, on the reference's own per-frame object features
+        fused = trk._query_fusion(torch.from_numpy(g['roi_obj_feats']).to(DEV), c['bs'], c['nf'])
+        assert maxabs(fused, g['trk_query_fusion']) < 2e-4
     # ---- per-frame roi head
     assert maxabs(feats['obj_feats'], g['roi_obj_feats']) < 2e-4 and maxabs(feats['cls_scores'], g['roi_cls_scores']) < 1e-5
     assert maxabs(feats['masks'], g['roi_masks']) < 1e-3
@@ -88,3 +93,31 @@ def test_vis_pipeline_vs_reference_golden(vkn, name):
             assert np.max(np.abs(rows[:, 5] - ref[:, 5])) < 1e-5                                       # scores
             masks = np.stack([m for per in mask_results for m in per]).astype(bool)
             assert np.mean(masks != _unpack(g[f'trk_masks{b}_{f}'], int(g[f'trk_nmask{b}_{f}']), oshape)) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,N,C,F,with_pos', [(2, 20, 64, 3, False), (1, 100, 256, 3, True), (2, 100, 256, 5, False), (1, 128, 128, 8, True),
+                                              (3, 50, 256, 1, True)])
+def test_query_merge_op_vs_oracle(vkn, B, N, C, F, with_pos):
+    """`vkn_query_merge_f32` against the oracle's restatement: <= 256 keys (the LDS-staged attention kernel) and more (keys from
+    global memory, scores in LDS), with and without the position table.  fp32 tolerance of the bf16x3 GEMMs."""
+    from oracle.knet_oracle import query_merge
+    g = torch.Generator().manual_seed(1000 + N + F)
+    shapes = {'query_merge_attn.attn.in_proj_weight': (3 * C, C), 'query_merge_attn.attn.in_proj_bias': (3 * C,),
+              'query_merge_attn.attn.out_proj.weight': (C, C), 'query_merge_attn.attn.out_proj.bias': (C,),
+              'query_merge_norm.weight': (C,), 'query_merge_norm.bias': (C,),
+              'query_merge_ffn.layers.0.0.weight': (8 * C, C), 'query_merge_ffn.layers.0.0.bias': (8 * C,),
+              'query_merge_ffn.layers.1.weight': (C, 8 * C), 'query_merge_ffn.layers.1.bias': (C,),
+              'query_merge_ffn_norm.weight': (C,), 'query_merge_ffn_norm.bias': (C,)}
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, 77 + C).items()}
+    query = torch.randn(B, N, C, generator=g)
+    keys = torch.randn(B, F * N, C, generator=g)
+    pos = torch.randn(N, C, generator=g) if with_pos else None
+    ref = query_merge(sd, '', query, keys, pos)
+    named = {k: v.to(DEV) for k, v in sd.items()}
+    pack = vkn.ops.link_pack(named, torch.device(DEV), None, 'query_merge_attn', 'query_merge_norm', 'query_merge_ffn', 'query_merge_ffn_norm')
+    dims = vkn.ops.make_dims(B, N, C, 8, 8, 8, 8 * C, 1, 0, 0)
+    out = vkn.ops.query_merge(dims, pack, query.to(DEV), keys.to(DEV), pos.to(DEV) if with_pos else None)
+    assert maxabs(out, ref) < 2e-4, maxabs(out, ref)
+    with pytest.raises(ValueError):
+        vkn.ops.query_merge(dims, pack, query.to(DEV), keys.to(DEV)[:, :-1], None)

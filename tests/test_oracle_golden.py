@@ -168,3 +168,24 @@ def test_tracker_oracle_ids_bit_exact_vs_reference():
             b, l_, ids = trk.step(torch.from_numpy(bb), torch.from_numpy(lab), torch.from_numpy(em), t)
             assert np.array_equal(ids.numpy(), g[f'{name}_ids{t}']), (name, t)
             assert np.array_equal(l_.numpy(), g[f'{name}_labels{t}']) and np.array_equal(b.numpy(), g[f'{name}_bboxes{t}'])
+
+
+@pytest.mark.parametrize('name', ['vis_attn_tiny', 'vis_attnpos_tiny', 'vis_attnpos_cfg'])
+def test_query_merge_oracle_matches_reference_golden(name):
+    """The clip-level attention query merge (query_merge_method 'attention' / 'attention_pos'): the oracle's restatement on the
+    reference roi head's object features reproduces the reference tracker's own `_query_fusion` output."""
+    import ast
+    from oracle import synth
+    from oracle.knet_oracle import query_merge
+    g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+    C, N, bs, nf, seed = (int(g['case'][i]) for i in (0, 4, 9, 10, 11))
+    shapes = {str(k): ast.literal_eval(str(v)) for k, v in zip(g['trk_keys'], g['trk_shapes'])}
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, seed + 1).items()}
+    keys = torch.from_numpy(g['roi_obj_feats']).reshape(bs, nf * N, C)
+    query = sd['init_query.weight'].expand(bs, N, C)
+    pos = sd['query_pos.weight'] if str(g['merge']) == 'attention_pos' else None
+    assert ('query_pos.weight' in sd) == (pos is not None)
+    out = query_merge(sd, '', query, keys, pos)
+    ref = g['trk_query_fusion']
+    assert tuple(ref.shape) == (bs, N, C, 1, 1)
+    assert maxabs(out[..., None, None], ref) < 2e-5

@@ -21,6 +21,7 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_w
            'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_kernel_updator_f32',
            'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_stage_chain_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32',
            'vkn_head_forward_prof_f32', 'vkn_head_forward_link_f32', 'vkn_stage_forward_link_f32', 'vkn_link_block_f32',
+           'vkn_query_merge_workspace_bytes', 'vkn_query_merge_f32',
            'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32',
            'vkn_sizeof_panoptic_cfg', 'vkn_panoptic_workspace_bytes', 'vkn_panoptic_joint_f32',
            'vkn_merge_workspace_bytes', 'vkn_panoptic_thing_first_u8',
@@ -226,6 +227,10 @@ def lib():
     L.vkn_stage_forward_link_f32.argtypes = [pD, pW, pW, pW, c_int] + [_fp] * 9 + [_fp, c_size, c_uint, _fp]
     L.vkn_link_block_f32.restype = c_int
     L.vkn_link_block_f32.argtypes = [pD, pW, _fp, _fp, _fp, _fp, _fp, c_size, _fp]
+    L.vkn_query_merge_workspace_bytes.restype = c_size
+    L.vkn_query_merge_workspace_bytes.argtypes = [pD, c_int]
+    L.vkn_query_merge_f32.restype = c_int
+    L.vkn_query_merge_f32.argtypes = [pD, c_int, pW, _fp, _fp, _fp, _fp, _fp, c_size, _fp]
     L.vkn_kernel_init_workspace_bytes.restype = c_size
     L.vkn_kernel_init_workspace_bytes.argtypes = [c_int] * 5
     L.vkn_kernel_init_f32.restype = c_int

@@ -967,6 +967,78 @@ int vkn_link_block_f32(const VknDims* d, const VknStageWeights* w, const float* 
     return run_link(d, w, pw, cur, prev, out, s, static_cast<hipStream_t>(stream), update_feature);
 }
 
+// Clip-level query merge of the VIS heads ('attention' / 'attention_pos'):
+//   out = LN2(FFN(LN1(query + MHA8(query + pos, keys + pos, keys))))
+// kernel_frame_iter_head.py:142-160 (fusing the per-frame object features) and tracker/kernel_update_head.py:244-263 (fusing the
+// per-frame gathers).  d: B = clips, N = queries per clip, ff = the merge FFN's width; keys [B][frames * N][C], key f*N + n takes
+// pos[n] (key_pos = query_pos.repeat(1, frames, 1)).  `w` carries the pa_* (query_merge_attn + query_merge_norm) and lffn*
+// (query_merge_ffn + query_merge_ffn_norm) members.
+namespace {
+struct MergeWs { float *qp, *kp, *kv, *kv2; };
+size_t carve_merge(const VknDims* d, int frames, char* base, StageWs* s, MergeWs* m) {
+    const size_t st = carve_stage(d, base, s);
+    Carver c{base ? base + st : nullptr, 0};
+    const size_t Mq = (size_t)d->B * d->N, Mk = Mq * frames, C = d->C;
+    m->qp = c.take<float>(Mq * C);
+    m->kp = c.take<float>(Mk * C);
+    m->kv = c.take<float>(Mk * 2 * C);
+    m->kv2 = c.take<float>(Mk * 2 * C);
+    return st + ((c.off + 255) & ~(size_t)255);
+}
+}  // namespace
+
+size_t vkn_query_merge_workspace_bytes(const VknDims* d, int num_frames) {
+    if (check_dims(d) != VKN_OK || num_frames <= 0) return 0;
+    StageWs s;
+    MergeWs m;
+    return carve_merge(d, num_frames, nullptr, &s, &m);
+}
+
+int vkn_query_merge_f32(const VknDims* d, int num_frames, const VknStageWeights* w, const float* query, const float* keys,
+                        const float* pos, float* out, void* ws, size_t ws_bytes, void* stream) {
+    VKN_TRY(check_dims(d));
+    if (!w || !query || !keys || !out || num_frames <= 0) return VKN_E_ARG;
+    if (!w->pa_in_w || !w->pa_in_b || !w->pa_out_w || !w->pa_norm_w || !w->lffn1_w || !w->lffn2_w || !w->lffn_norm_w) return VKN_E_ARG;
+    if (!aligned16(query) || !aligned16(keys) || !aligned16(pos) || !aligned16(out)) return VKN_E_ALIGN;
+    StageWs s;
+    MergeWs m;
+    const size_t need = carve_merge(d, num_frames, nullptr, &s, &m);
+    if (!ws || ws_bytes < need || !aligned16(ws)) return VKN_E_WORKSPACE;
+    carve_merge(d, num_frames, static_cast<char*>(ws), &s, &m);
+    PrepW pw;
+    VKN_TRY(carve_pw(d, w, 0, &pw));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int C = d->C, Mq = d->B * d->N, Nk = d->N * num_frames, Mk = d->B * Nk, hd = C / 8;
+    const float* qsrc = query;
+    const float* ksrc = keys;
+    if (pos) {
+        VKN_TRY(vkn_launch_add_rows(query, pos, m.qp, (size_t)Mq, C, d->N, st));
+        VKN_TRY(vkn_launch_add_rows(keys, pos, m.kp, (size_t)Mk, C, d->N, st));
+        qsrc = m.qp;
+        ksrc = m.kp;
+    }
+    VknEpi e = mk_epi(d);
+    e.bias = w->pa_in_b; e.out = s.lq; e.ldo = C;
+    VKN_TRY(vkn_launch_gemm(qsrc, nullptr, C, w->pa_in_w, pw.pa_in, Mq, C, C, 1, nullptr, e, st));
+    // k | v rows of the packed in_proj as ONE [2C]-column GEMM (the prepared tile image covers both); with a position table the
+    // k columns come from keys + pos and the v columns from keys: the same GEMM on both operands, each read for its half
+    e = mk_epi(d);
+    e.bias = w->pa_in_b + C; e.out = m.kv; e.ldo = 2 * C;
+    VKN_TRY(vkn_launch_gemm(ksrc, nullptr, C, w->pa_in_w + (size_t)C * C, pw.pa_in_kv, Mk, C, 2 * C, 1, nullptr, e, st));
+    const float* vsrc = m.kv + C;
+    if (pos) {
+        e.out = m.kv2;
+        VKN_TRY(vkn_launch_gemm(keys, nullptr, C, w->pa_in_w + (size_t)C * C, pw.pa_in_kv, Mk, C, 2 * C, 1, nullptr, e, st));
+        vsrc = m.kv2 + C;
+    }
+    VKN_TRY(vkn_launch_attn(s.lq, C, m.kv, vsrc, 2 * C, s.ao, C, d->B, d->N, Nk, 8, hd, st));
+    e = mk_epi(d);   // the residual is the query WITHOUT its position (mmcv: identity = query before `query + query_pos`)
+    e.bias = w->pa_out_b; e.resid = query; e.ldr = C; e.ln_w = w->pa_norm_w; e.ln_b = w->pa_norm_b; e.out = s.t1; e.ldo = C;
+    VKN_TRY(vkn_launch_gemm(s.ao, nullptr, C, w->pa_out_w, pw.pa_out, Mq, C, C, 1, nullptr, e, st));
+    return run_ffn(d, s, s.t1, w->lffn1_w, pw.lffn1, w->lffn1_b, w->lffn2_w, pw.lffn2, w->lffn2_b, w->lffn_norm_w,
+                   w->lffn_norm_b, out, st);
+}
+
 int vkn_stage_chain_f32(const VknDims* d, const VknStageWeights* w, const float* x_feat, const float* obj_in, float* cls_logits,
                         float* kernels_out, float* kb_out, float* obj_out, void* ws, size_t ws_bytes, unsigned flags,
                         void* stream) {

@@ -866,6 +866,86 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int l
     }
 }
 
+// Attention with MORE than 256 keys per query (the clip-level query merge of the VIS heads: Nk = frames * kernels, a query row
+// attends to every frame's kernels — knet_vis/tracker/kernel_frame_iter_head.py:142-160).  One wave per query row, grid
+// (heads, B, ceil(Nq / 4)); K / V stay in global memory (B * Nk * hd floats per head: cache-resident), the row's scores live in
+// LDS ([4][Nk] floats).  Same lane roles as k_attn: a lane owns keys lane, lane + 64, .. for q.K and 4 output channels of a key
+// group for P.V.  Runs once per clip, not per stage — not a hot kernel.
+template <int HD4>
+__global__ __launch_bounds__(256) void k_attn_long(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
+                                                   const float* __restrict__ Vp, int ldkv, float* __restrict__ out, int ldo,
+                                                   int Nq, int Nk, float scale) {
+    constexpr int hd = HD4 * 4;
+    constexpr int NGRP = 64 / HD4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sc = reinterpret_cast<float*>(smem_raw) + (size_t)wave * Nk;
+    const int i = blockIdx.z * 4 + wave;
+    if (i >= Nq) return;  // (no workgroup-level barrier below: a wave only reads its own LDS rows)
+    f32x4 qv[HD4];
+#pragma unroll
+    for (int u = 0; u < HD4; ++u) qv[u] = *reinterpret_cast<const f32x4*>(Q + ((size_t)b * Nq + i) * ldq + h * hd + 4 * u) * scale;
+    const float* Kb = Kp + (size_t)b * Nk * ldkv + h * hd;
+    const float* Vb = Vp + (size_t)b * Nk * ldkv + h * hd;
+    float mx = -INFINITY;
+    for (int j = lane; j < Nk; j += 64) {
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < HD4; ++u) acc4 += qv[u] * *reinterpret_cast<const f32x4*>(Kb + (size_t)j * ldkv + 4 * u);
+        const float a = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = vkn_wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < Nk; j += 64) {  // (each lane re-reads only what it wrote)
+        const float ev = expf(sc[j] - mx);
+        sc[j] = ev;
+        sum += ev;
+    }
+    sum = vkn_wave_sum(sum);
+    const float inv = 1.0f / sum;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int grp = lane / HD4, dl4 = lane - grp * HD4;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int j = grp; j < Nk; j += NGRP) o += (sc[j] * inv) * *reinterpret_cast<const f32x4*>(Vb + (size_t)j * ldkv + 4 * dl4);
+#pragma unroll
+    for (int off = HD4; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = o[e];
+            o[e] = t + __shfl_xor(t, off, 64);
+        }
+    }
+    if (grp == 0) *reinterpret_cast<f32x4*>(out + ((size_t)b * Nq + i) * ldo + h * hd + 4 * dl4) = o;
+}
+
+// out[r][c] = a[r][c] + pos[r % period][c]   (query_pos / key_pos of the 'attention_pos' query merge: one [Np][C] table, repeated
+// per clip and per frame — kernel_frame_iter_head.py:154-155); C % 4 == 0
+__global__ __launch_bounds__(256) void k_add_rows(const float* __restrict__ a, const float* __restrict__ pos,
+                                                  float* __restrict__ out, size_t rows, int C4, int period) {
+    const size_t n = rows * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / C4;
+        const int c = (int)(i - r * C4);
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] +
+                                           reinterpret_cast<const f32x4*>(pos)[(r % period) * C4 + c];
+    }
+}
+
+int vkn_launch_add_rows(const float* a, const float* pos, float* out, size_t rows, int C, int period, hipStream_t st) {
+    if ((C & 3) || period <= 0) return VKN_E_SHAPE;
+    if (rows == 0) return VKN_OK;
+    const size_t n = rows * (C / 4);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_add_rows, dim3(grid), dim3(256), 0, st, a, pos, out, rows, C / 4, period);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
 // Bilinear upsample by integer factor S, align_corners=False (F.interpolate(scale_factor=S, mode='bilinear')):
 // src = (dst + 0.5) / S - 0.5 clamped at 0; neighbours clamped at the border.
 // Write-bound (S*S outputs per input): one workgroup = one input row of one plane -> its S output rows; a thread owns 4
@@ -1049,7 +1129,25 @@ int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig,
 
 int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* out, int ldo, int B, int Nq,
                     int Nk, int heads, int hd, hipStream_t stream) {
-    if (Nk > 256 || hd > 64 || hd < 4 || (hd & (hd - 1)) != 0 || (ldq % 4) || (ldkv % 4) || (ldo % 4)) return VKN_E_SHAPE;
+    if (hd > 64 || hd < 4 || (hd & (hd - 1)) != 0 || (ldq % 4) || (ldkv % 4) || (ldo % 4)) return VKN_E_SHAPE;
+    if (Nk > 256) {  // clip-level query merge: scores in LDS, K / V from global
+        const size_t ldsl = (size_t)4 * Nk * sizeof(float);
+        if (ldsl > 160 * 1024) return VKN_E_SHAPE;
+        dim3 gl(heads, B, (Nq + 3) / 4);
+        const float scl = 1.0f / sqrtf((float)hd);
+#define ATTL_CASE(H4)                                                                                                     \
+    case H4:                                                                                                              \
+        if (ldsl > 64 * 1024) VKN_ALLOW_FULL_LDS(k_attn_long<H4>);                                                        \
+        hipLaunchKernelGGL(k_attn_long<H4>, gl, dim3(256), ldsl, stream, Q, ldq, K, V, ldkv, out, ldo, Nq, Nk, scl);      \
+        break;
+        switch (hd / 4) {
+            ATTL_CASE(1) ATTL_CASE(2) ATTL_CASE(4) ATTL_CASE(8) ATTL_CASE(16)
+            default: return VKN_E_SHAPE;
+        }
+#undef ATTL_CASE
+        VKN_CHECK_LAUNCH();
+        return VKN_OK;
+    }
     // 16 query rows per workgroup.  64 (K / V of a (frame, head) staged twice instead of eight times) was measured at 32 frames
     // per call: 36 us instead of 30 — the kernel is bound by the serial per-row chain of a wave, not by the staging
     const int rpw = 16;

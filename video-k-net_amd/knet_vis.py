@@ -16,21 +16,53 @@ import torch.nn as nn
 
 from . import ops
 from .kernel_iter_head import KernelIterHead
-from .kernel_update_head import KernelUpdateHead
+from .kernel_update_head import KernelUpdateHead, _FFNParams, _MHAParams
 from .registry import BaseRoIHead, build_head, register_head
 
 
+class _QueryMerge:
+    """query_merge_method 'attention' / 'attention_pos' of both clip-level classes (tracker/kernel_update_head.py:153-179,
+    tracker/kernel_frame_iter_head.py:47-75): the modules (same state-dict keys) and the one HIP entry point that runs them
+    (`vkn_query_merge_f32`: 8 heads, FFN of 8 C, two LayerNorms)."""
+    MERGE_NAMES = (None, 'query_merge_attn', 'query_merge_norm', 'query_merge_ffn', 'query_merge_ffn_norm')
+
+    def _build_query_merge(self, channels):
+        self.query_merge_attn = _MHAParams(channels, 8, 0.0)
+        self.query_merge_norm = nn.LayerNorm(channels)
+        self.query_merge_ffn = _FFNParams(channels, channels * 8, 2, 0.0)
+        self.query_merge_ffn_norm = nn.LayerNorm(channels)
+        self._merge_pack = None
+
+    def invalidate_pack(self):
+        self._merge_pack = None
+        if hasattr(super(), 'invalidate_pack'):
+            super().invalidate_pack()
+
+    def _query_merge(self, query, keys, pos):
+        """query [B,N,C], keys [B,F*N,C], pos [N,C] | None -> [B,N,C] on the GPU (no autograd)."""
+        named = {k: v.detach() for k, v in self.named_parameters() if k.startswith('query_merge_')}
+        sig = ops.StagePack.signature(named, query.device)
+        if getattr(self, '_merge_pack', None) is None or self._merge_pack[0] != sig:
+            self._merge_pack = (sig, ops.link_pack(named, query.device, *self.MERGE_NAMES))
+        B, N, C = query.shape
+        dims = ops.make_dims(B, N, C, 8, 8, 8, 8 * C, 1, 0, 0, 0.5, self.query_merge_norm.eps)
+        return ops.query_merge(dims, self._merge_pack[1], query, keys, pos)
+
+
 @register_head
-class KernelUpdateHeadVideo(KernelUpdateHead):
+class KernelUpdateHeadVideo(_QueryMerge, KernelUpdateHead):
 
     def __init__(self, with_cls=True, num_proposals=100, query_merge_method='mean', **kwargs):
         super().__init__(**kwargs)
         self.with_cls = with_cls
         self.num_proposals = num_proposals
         self.query_merge_method = query_merge_method
-        if query_merge_method != 'mean' and with_cls:
-            raise NotImplementedError("query_merge_method must be 'mean' (the shipped knet_track configs); the attention merge "
-                                      '(knet_vis/tracker/kernel_update_head.py:244-263) is not built')
+        if query_merge_method not in ('mean', 'attention', 'attention_pos'):
+            raise NotImplementedError(query_merge_method)                                       # as the reference's forward (:264)
+        if query_merge_method != 'mean' and with_cls:                                           # :155-179
+            if self.conv_kernel_size != 1:
+                raise NotImplementedError('Only supporting kernel size = 1')                    # :246
+            self._build_query_merge(self.in_channels)
         if not with_cls:                       # the reference builds no classification branch then (:133-146): same state dict
             del self.cls_fcs
             del self.fc_cls
@@ -76,7 +108,13 @@ class KernelUpdateHeadVideo(KernelUpdateHead):
             x_feat = x_feat + cnt.unsqueeze(-1) * self.feat_transform.conv.bias.detach()
         else:
             x_feat = xraw
-        x_feat = x_feat.reshape(B, F, N, C).mean(1)                                            # query_merge_method == 'mean' :243
+        if self.query_merge_method == 'mean':
+            x_feat = x_feat.reshape(B, F, N, C).mean(1)                                        # :243
+        else:                                                                                  # :244-263
+            if self.query_merge_method == 'attention_pos' and pos is None:
+                raise ValueError("query_merge_method='attention_pos' needs `pos` (the tracker head's query_pos.weight)")
+            x_feat = self._query_merge(proposal_feat.reshape(B, N, C), x_feat.reshape(B, F * N, C),
+                                       pos.detach() if self.query_merge_method == 'attention_pos' else None)
         dims = self.make_dims(B, N, H, W)
         cls, kern, kb, obj = ops.stage_chain(dims, self.stage_pack(x.device), x_feat, proposal_feat.reshape(B, N, C))
         # every frame of a clip is decoded with the clip's kernels (:318-330)
@@ -151,8 +189,8 @@ class KernelIterHeadVideo(KernelIterHead):
 
 
 @register_head
-class KernelFrameIterHeadVideo(BaseRoIHead):
-    """knet_vis/tracker/kernel_frame_iter_head.py:15-383 (inference; `query_merge_method='mean'`, `with_mask_init` optional)."""
+class KernelFrameIterHeadVideo(_QueryMerge, BaseRoIHead):
+    """knet_vis/tracker/kernel_frame_iter_head.py:15-383 (inference; every `query_merge_method`, `with_mask_init` optional)."""
 
     def __init__(self, mask_head=None, with_mask_init=False, num_stages=3, stage_loss_weights=(1, 1, 1), proposal_feature_channel=256,
                  assign_stages=5, num_proposals=100, num_thing_classes=80, num_stuff_classes=53, query_merge_method='mean',
@@ -166,9 +204,14 @@ class KernelFrameIterHeadVideo(BaseRoIHead):
         self.num_stuff_classes = num_stuff_classes
         self.query_merge_method = query_merge_method
         self.proposal_feature_channel = proposal_feature_channel
-        if query_merge_method != 'mean':
-            raise NotImplementedError("query_merge_method must be 'mean' (the shipped knet_track configs)")
+        if query_merge_method not in ('mean', 'attention', 'attention_pos'):
+            raise NotImplementedError(query_merge_method)
         super().__init__(mask_head=mask_head, train_cfg=train_cfg, test_cfg=test_cfg, **kwargs)
+        if query_merge_method != 'mean':                                                        # :47-75
+            self.init_query = nn.Embedding(num_proposals, proposal_feature_channel)
+            if query_merge_method == 'attention_pos':
+                self.query_pos = nn.Embedding(num_proposals, proposal_feature_channel)
+            self._build_query_merge(proposal_feature_channel)
         self.with_mask_init = with_mask_init
         if self.with_mask_init:
             self.fc_mask = nn.Linear(proposal_feature_channel, proposal_feature_channel)
@@ -198,7 +241,8 @@ class KernelFrameIterHeadVideo(BaseRoIHead):
 
     def _mask_forward(self, stage, x, object_feats, mask_preds):
         mask_head = self.mask_head[stage]
-        cls_score, mask_preds, object_feats = mask_head(x, object_feats, mask_preds, img_metas=None)
+        pos = self.query_pos.weight if self.query_merge_method == 'attention_pos' else None     # :117
+        cls_score, mask_preds, object_feats = mask_head(x, object_feats, mask_preds, img_metas=None, pos=pos)
         if mask_head.mask_upsample_stride > 1 and (stage == self.num_stages - 1 or self.training):
             B, F, N, H, W = mask_preds.shape
             s = mask_head.mask_upsample_stride
@@ -208,7 +252,15 @@ class KernelFrameIterHeadVideo(BaseRoIHead):
         return dict(cls_score=cls_score, mask_preds=mask_preds, scaled_mask_preds=scaled, object_feats=object_feats)
 
     def _query_fusion(self, obj_feats, num_imgs, num_frames):
-        return obj_feats.mean(1)                                                               # :140-141
+        if self.query_merge_method == 'mean':
+            return obj_feats.mean(1)                                                           # :140-141
+        if tuple(obj_feats.shape[-2:]) != (1, 1):
+            raise NotImplementedError('Only supporting kernel size = 1')                       # :143
+        C, N = self.proposal_feature_channel, self.num_proposals                                # :142-160
+        keys = obj_feats.reshape(num_imgs, num_frames * N, C)
+        query = self.init_query.weight.detach().expand(num_imgs, N, C).contiguous()
+        pos = self.query_pos.weight.detach() if self.query_merge_method == 'attention_pos' else None
+        return self._query_merge(query, keys, pos)[..., None, None]
 
     def _mask_init(self, object_feats, x_feats, num_imgs):
         """:163-178: mask_preds = conv2d(x_feats[i], fc_mask(object_feats)[i]) for all frames of clip i."""

@@ -314,6 +314,26 @@ def link_block(dims: VknDims, pack: StagePack, cur, prev, update_feature=None):
     return out
 
 
+def query_merge(dims: VknDims, pack: StagePack, query, keys, pos=None):
+    """Clip-level attention query merge (include/vkn.h: vkn_query_merge_f32): query [B,N,C], keys [B,F*N,C] frame-major, pos [N,C] | None
+    -> [B,N,C].  `pack`: `link_pack(named, dev, None, 'query_merge_attn', 'query_merge_norm', 'query_merge_ffn',
+    'query_merge_ffn_norm')`; dims.ff is the merge FFN's width."""
+    query, keys = _req(query, 'query'), _req(keys, 'keys')
+    pos = _req(pos, 'pos') if pos is not None else None
+    B, N, C = query.shape
+    if keys.shape[0] != B or keys.shape[2] != C or keys.shape[1] % N or (pos is not None and tuple(pos.shape) != (N, C)):
+        raise ValueError(f'query {tuple(query.shape)}, keys {tuple(keys.shape)}, pos {None if pos is None else tuple(pos.shape)}')
+    F = keys.shape[1] // N
+    L = _lib.lib()
+    pack.ensure_prepared(dims)
+    out = torch.empty_like(query)
+    ws = _workspace(max(L.vkn_query_merge_workspace_bytes(ctypes.byref(dims), F), 256), query.device)
+    with torch.cuda.device(query.device):
+        check(L.vkn_query_merge_f32(ctypes.byref(dims), F, ctypes.byref(pack.w), _ptr(query), _ptr(keys), _ptr(pos), _ptr(out),
+                                    _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
 def make_dims(B, N, C, H, W, heads, ff, ncls, n_cls_fcs, n_mask_fcs, hard_mask_thr=0.5, ln_eps=1e-5):
     return VknDims(B, N, C, H, W, heads, ff, ncls, n_cls_fcs, n_mask_fcs, thr_logit(hard_mask_thr), ln_eps)
 
