@@ -375,6 +375,9 @@ typedef struct VknAssignCfg {
     float cls_weight, dice_weight, mask_weight; /* the three `weight=` of train_cfg.assigner */
     float focal_alpha, focal_gamma, focal_eps;  /* FocalLossCost defaults: 0.25, 2, 1e-12 */
     float dice_eps;                             /* DiceCost eps: 1e-3 */
+    float dice_pred_min, mask_pred_min;         /* lower clamp of sigmoid(mask logits) inside DiceCost / MaskCost: knet/det/
+                                                   mask_hungarian_assigner.py:69,101 clamp at 1e-3 / 1e-2; the knet_vis copies of the
+                                                   same classes (knet_vis/det/mask_hungarian_assigner.py:69,100) do not clamp: 0 / 0 */
 } VknAssignCfg;
 size_t vkn_sizeof_assign_cfg(void);
 size_t vkn_assign_workspace_bytes(int N, int G, int P);

@@ -7,6 +7,7 @@ and `mmdet.datasets.coco_panoptic` stand-ins).  Only outputs are stored.
 
     python oracle/gen_golden_vis.py        # writes tests/golden/vis_*.npz
 
+  vis_train_* `forward_train` of the tracker head: clip-level assignment (MaskHungarianAssignerVideo), losses, gradients
   vis_attn_* the same pipeline with query_merge_method = 'attention' / 'attention_pos' in the tracker and its clip-level stages
   vis_tiny   KernelIterHeadVideo (per-frame roi head, instance results + features) -> KernelFrameIterHeadVideo (clip-level tracker:
              query fusion 'mean', 3 stages with assign_stages = 2: two clip-level `with_cls` stages, one per-frame stage)
@@ -109,6 +110,69 @@ def run(name, C, heads, ffn, ncls, N, H, W, up, S, bs, nf, seed, kmax, merge='me
     print(f'{name}: ok  roi instances/frame = {[int(out[f"roi_nmask{i}"]) for i in range(B)]}, tracker instances = {int(out["trk_nmask0_0"])}')
 
 
+TRAIN_GRAD_KEYS = ('mask_head.0.kernel_update_conv.dynamic_layer.weight', 'mask_head.0.attention.attn.in_proj_weight',
+                   'mask_head.0.ffn.layers.1.weight', 'mask_head.0.fc_cls.weight', 'mask_head.0.feat_transform.conv.weight',
+                   'mask_head.1.fc_mask.weight', 'mask_head.2.kernel_update_conv.fc_layer.weight', 'mask_head.2.fc_mask.bias',
+                   'init_query.weight', 'query_pos.weight', 'query_merge_attn.attn.in_proj_weight', 'query_merge_ffn.layers.0.0.weight',
+                   'mask_head.0.query_merge_attn.attn.out_proj.weight', 'mask_head.1.query_merge_ffn_norm.weight', 'fc_mask.weight')
+
+
+def run_train(name, C, heads, ffn, ncls, N, H, W, up, bs, nf, seed, merge='mean', mask_init=False):
+    """`KernelFrameIterHeadVideo.forward_train` of the reference (knet_vis/tracker/kernel_frame_iter_head.py:182-312) with the shipped
+    `train_cfg.tracker` (MaskHungarianAssignerVideo + MaskPseudoSampler): losses, the per-stage clip assignments, gradients w.r.t.
+    x / the per-frame object features and a sample of the parameters."""
+    import knet_vis.det.mask_hungarian_assigner  # noqa: F401  (registers DiceCost / MaskCost)
+    import knet_vis.tracker.mask_hungarian_assigner  # noqa: F401  (registers MaskHungarianAssignerVideo)
+    import knet_vis.det.mask_pseudo_sampler  # noqa: F401
+    train_cfg = AttrDict(assigner=dict(type='MaskHungarianAssignerVideo', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                       dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                       mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)),
+                         sampler=dict(type='MaskPseudoSampler'), pos_weight=1)
+    trk = build_head(dict(type='KernelFrameIterHeadVideo', num_proposals=N, num_stages=3, assign_stages=2, proposal_feature_channel=C,
+                          stage_loss_weights=(1., 1., 1.), num_thing_classes=ncls, num_stuff_classes=0, train_cfg=train_cfg,
+                          query_merge_method=merge, with_mask_init=mask_init,
+                          mask_head=stage_cfg('KernelUpdateHeadVideo', C, heads, ffn, ncls, up, num_proposals=N, query_merge_method=merge)))
+    trk.train()
+    shapes = {k: tuple(v.shape) for k, v in trk.state_dict().items()}
+    trk.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, seed + 1).items()}, strict=True)
+    B = bs * nf
+    x, pf, mp = (torch.from_numpy(a) for a in synth.head_inputs(B, N, C, H, W, seed))
+    x = x.reshape(bs, nf, C, H, W).requires_grad_(True)
+    obj = pf.reshape(bs, nf, N, C, 1, 1).requires_grad_(True)
+    masks = mp.reshape(bs, nf, N, H, W)
+    tg = synth.clip_targets(bs, nf, ncls, H * up, W * up, seed)
+    gt_masks = [[torch.from_numpy(m) for m in t['gt_masks']] for t in tg]
+    gt_labels = [torch.from_numpy(t['gt_labels']) for t in tg]
+    gt_ids = [torch.from_numpy(t['gt_instance_ids']) for t in tg]
+    ref_img_metas = [[dict()] * nf for _ in range(bs)]
+    assigned = []
+    for a in trk.mask_assigner:
+        orig = a.assign
+
+        def rec(*args, _orig=orig, **kw):
+            r = _orig(*args, **kw)
+            assigned.append(r[0].gt_inds.clone())
+            return r
+        a.assign = rec
+    losses, feats = trk.forward_train(x, ref_img_metas, None, masks, obj, gt_masks, gt_labels, gt_ids)
+    total = sum(v for k, v in losses.items() if 'loss' in k) + 0.01 * (feats['obj_feats'] ** 2).sum()
+    total.backward()
+    out = dict(case=np.array([C, heads, ffn, ncls, N, H, W, up, bs, nf, seed, int(mask_init)], dtype=np.int64), merge=np.array(merge),
+               keys=np.array(sorted(shapes)), shapes=np.array([str(shapes[k]) for k in sorted(shapes)]),
+               loss_keys=np.array(sorted(losses)), loss_vals=np.array([float(losses[k]) for k in sorted(losses)], dtype=np.float64),
+               total=np.float64(float(total)), assigned=torch.stack(assigned).numpy(), feat_obj=feats['obj_feats'].detach().numpy(),
+               feat_masks=feats['masks'].detach().numpy(), grad_x=x.grad.numpy(), grad_obj=obj.grad.numpy())
+    named = dict(trk.named_parameters())
+    gk = [k for k in TRAIN_GRAD_KEYS if k in named]
+    out['grad_keys'] = np.array(gk)
+    for i, k in enumerate(gk):
+        out[f'grad_{i}'] = named[k].grad.numpy()
+    out['all_keys'] = np.array(sorted(named))
+    out['all_gnorm'] = np.array([float(named[k].grad.double().norm()) if named[k].grad is not None else -1.0 for k in sorted(named)])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(f'{name}: ok  total={float(total):.5f}  ' + ' '.join(f'{k}={float(v):.4f}' for k, v in sorted(losses.items())[:6]))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -118,3 +182,7 @@ if __name__ == '__main__':
     run('vis_attn_tiny', C=64, heads=8, ffn=128, ncls=7, N=20, H=8, W=16, up=2, S=2, bs=2, nf=3, seed=95, kmax=10, merge='attention')
     run('vis_attnpos_tiny', C=64, heads=8, ffn=128, ncls=7, N=20, H=8, W=16, up=2, S=2, bs=2, nf=3, seed=96, kmax=10, merge='attention_pos')
     run('vis_attnpos_cfg', C=256, heads=8, ffn=2048, ncls=40, N=100, H=12, W=20, up=2, S=3, bs=1, nf=3, seed=97, kmax=10, merge='attention_pos')
+    # clip-level training of the tracker head (MaskHungarianAssignerVideo)
+    run_train('vis_train_tiny', C=64, heads=8, ffn=128, ncls=7, N=20, H=8, W=16, up=2, bs=2, nf=3, seed=101)
+    run_train('vis_train_attnpos', C=64, heads=8, ffn=128, ncls=7, N=20, H=8, W=16, up=2, bs=2, nf=3, seed=102, merge='attention_pos',
+              mask_init=True)

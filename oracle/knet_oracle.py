@@ -410,19 +410,21 @@ def panoptic_joint(cls_scores, mask_logits, num_proposals, num_thing_classes, ma
 
 
 def assign_costs(mask_preds, cls_pred, gt_masks, gt_labels, cls_weight=2.0, dice_weight=4.0, mask_weight=1.0,
-                 focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3):
+                 focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3, dice_pred_min=0.001, mask_pred_min=0.01):
     """Cost matrix of MaskHungarianAssigner.assign (knet/det/mask_hungarian_assigner.py:222-241) with FocalLossCost
-    (mmdet 2.18, restated), DiceCost(pred_act=True) (:37-74) and MaskCost(pred_act=True) (:87-113).  -> [N, G] fp32."""
+    (mmdet 2.18, restated), DiceCost(pred_act=True) (:37-74) and MaskCost(pred_act=True) (:87-113).  -> [N, G] fp32.
+    The knet_vis copies of the two cost classes take the plain sigmoid (knet_vis/det/mask_hungarian_assigner.py:69,100):
+    dice_pred_min = mask_pred_min = 0."""
     p = cls_pred.sigmoid()                                                                            # FocalLossCost
     neg = -(1 - p + focal_eps).log() * (1 - focal_alpha) * p.pow(focal_gamma)
     pos = -(p + focal_eps).log() * focal_alpha * (1 - p).pow(focal_gamma)
     cls_cost = (pos[:, gt_labels] - neg[:, gt_labels]) * cls_weight
-    mp = mask_preds.sigmoid().clamp(min=0.01, max=1.0)                                                # MaskCost :104-113
+    mp = mask_preds.sigmoid().clamp(min=mask_pred_min, max=1.0)                                                # MaskCost :104-113
     H, W = gt_masks.shape[-2:]
     pos_c = torch.einsum('nhw,mhw->nm', mp, gt_masks)
     neg_c = torch.einsum('nhw,mhw->nm', 1 - mp, 1 - gt_masks)
     reg_cost = -(pos_c + neg_c) / (H * W) * mask_weight
-    dp = mask_preds.sigmoid().clamp(min=0.001, max=1.0)                                               # DiceCost :48-74
+    dp = mask_preds.sigmoid().clamp(min=dice_pred_min, max=1.0)                                               # DiceCost :48-74
     inp = dp.reshape(dp.shape[0], -1)
     tgt = gt_masks.reshape(gt_masks.shape[0], -1).float()
     a = torch.einsum('nh,mh->nm', inp, tgt)

@@ -139,6 +139,42 @@ def train_targets(B, n_thing, n_stuff, Hs, Ws, seed, gmin=2, gmax=5, soft=True):
     return out
 
 
+def clip_targets(num_clips, num_frames, n_cls, Hs, Ws, seed, gmin=2, gmax=4):
+    """Ground truth of the clip-level VIS training (knet_vis: ref_gt_masks / ref_gt_labels / ref_gt_instance_ids): per clip a few
+    instances (drifting soft elliptic blobs with one label each), every instance visible in a subset of the frames (always in at
+    least one), listed per frame in a shuffled order.  Per clip: gt_masks = list over frames of [n_f, Hs, Ws] float32;
+    gt_labels [M, 2] = (frame, label); gt_instance_ids [M, 2] = (frame, instance id) — the rows of a frame in its masks' order."""
+    ys = ((np.arange(Hs) + 0.5) / Hs)[:, None]
+    xs = ((np.arange(Ws) + 0.5) / Ws)[None, :]
+    out = []
+    for b in range(num_clips):
+        sd = 9101 + 211 * seed + 29 * b
+        G = gmin + int(uniform((1,), sd, 0.0, 1.0)[0] * (gmax - gmin + 1) * 0.999)
+        ids = 3 + 2 * np.arange(G) + int(uniform((1,), sd + 1, 0.0, 1.0)[0] * 5)        # sparse, ascending instance ids
+        labels = (uniform((G,), sd + 2, 0.0, 1.0).astype(np.float64) * n_cls).astype(np.int64)
+        c0 = uniform((G, 2), sd + 3, 0.2, 0.8).astype(np.float64)
+        vel = uniform((G, 2), sd + 4, -0.06, 0.06).astype(np.float64)
+        rad = uniform((G, 2), sd + 5, 0.08, 0.28).astype(np.float64)
+        vis = uniform((G, num_frames), sd + 6, 0.0, 1.0) < 0.75
+        vis[np.arange(G), (uniform((G,), sd + 7, 0.0, 1.0).astype(np.float64) * num_frames).astype(np.int64)] = True
+        gt_masks, lab_rows, id_rows = [], [], []
+        for f in range(num_frames):
+            present = np.nonzero(vis[:, f])[0]
+            order = np.argsort(uniform((len(present),), sd + 40 + f, 0.0, 1.0), kind='stable')
+            present = present[order]
+            fm = []
+            for g in present:
+                cx, cy = c0[g] + vel[g] * f
+                d = np.sqrt(((xs - cx) / rad[g, 0]) ** 2 + ((ys - cy) / rad[g, 1]) ** 2)
+                fm.append(np.clip((1.0 - d) * 4.0 + 0.5, 0.0, 1.0).astype(np.float32))
+                lab_rows.append((f, labels[g]))
+                id_rows.append((f, ids[g]))
+            gt_masks.append(np.stack(fm) if fm else np.zeros((0, Hs, Ws), np.float32))
+        out.append(dict(gt_masks=gt_masks, gt_labels=np.array(lab_rows, dtype=np.int64).reshape(-1, 2),
+                        gt_instance_ids=np.array(id_rows, dtype=np.int64).reshape(-1, 2)))
+    return out
+
+
 def tracker_sequence(T, n_obj, emb, n_cls, seed):
     """A synthetic video for the quasi-dense tracker: `n_obj` objects drift over T frames (some disappear / reappear), each frame
     lists detections in shuffled order: boxes [n,5] (x1,y1,x2,y2,score), labels [n], embeddings [n,emb] = object code + noise, plus

@@ -857,6 +857,36 @@ def test_assignment_full_resolution(vkn):
     assert np.array_equal(res.gt_inds.cpu().numpy(), inds)
 
 
+def test_clip_level_assigner_costs_and_layout(vkn):
+    """`MaskHungarianAssignerVideo` (knet_vis): costs on the tall [Q, F*H, W] layout WITHOUT the sigmoid clamps of knet's cost classes,
+    against the oracle's cost restatement in that flavour; the assignment equals scipy's on the oracle costs."""
+    from oracle.knet_oracle import assign_costs
+    F, Q, H, W, ncls = 3, 40, 16, 24, 5
+    tg = synth.clip_targets(1, F, ncls, H, W, 5, gmin=4, gmax=6)[0]
+    logits = torch.from_numpy(synth.normalish((F, Q, H, W), 321, 6.0))          # |z| up to ~12: sigmoid far below both clamps
+    cls = torch.from_numpy(synth.normalish((Q, ncls), 322, 2.0))
+    a = vkn.MaskHungarianAssignerVideo(cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                       dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                       mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    masks = [torch.from_numpy(m).to(DEV) for m in tg['gt_masks']]
+    lab, ids = torch.from_numpy(tg['gt_labels']).to(DEV), torch.from_numpy(tg['gt_instance_ids']).to(DEV)
+    res, gt_tall = a.assign(logits.to(DEV), cls.to(DEV), masks, lab, ids)
+    clip, labels, inst = a.clip_instances(F, [m.cpu() for m in masks], lab.cpu(), ids.cpu())
+    assert torch.equal(gt_tall.cpu(), clip.reshape(len(inst), F * H, W))
+    tall = a.tall(logits)
+    want = assign_costs(tall, cls, clip.reshape(len(inst), F * H, W), labels, dice_pred_min=0.0, mask_pred_min=0.0)
+    got = a.cost_matrix(tall.to(DEV), cls.to(DEV), gt_tall, labels.to(DEV))
+    assert maxabs(got, want) < 2e-5
+    clamped = assign_costs(tall, cls, clip.reshape(len(inst), F * H, W), labels)
+    assert maxabs(clamped, want) > 1e-4                                         # the two flavours really differ on these inputs
+    from scipy.optimize import linear_sum_assignment
+    r0, c0 = linear_sum_assignment(want.numpy())
+    inds = np.zeros(Q, dtype=np.int64)
+    inds[r0] = c0 + 1
+    assert np.array_equal(res.gt_inds.cpu().numpy(), inds)
+    assert np.array_equal(res.labels.cpu().numpy()[r0], labels.numpy()[c0])
+
+
 @pytest.mark.parametrize('name', ['pan_tiny', 'pan_cfg'])
 def test_segment_boxes_for_tracking(vkn, name):
     """bbox output of the panoptic pipeline == tensor_mask2box(panoptic_seg == id) on the reference's panoptic map for every

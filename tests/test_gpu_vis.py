@@ -121,3 +121,110 @@ def test_query_merge_op_vs_oracle(vkn, B, N, C, F, with_pos):
     assert maxabs(out, ref) < 2e-4, maxabs(out, ref)
     with pytest.raises(ValueError):
         vkn.ops.query_merge(dims, pack, query.to(DEV), keys.to(DEV)[:, :-1], None)
+
+
+VIS_TRAIN_FIELDS = ('C', 'heads', 'ffn', 'ncls', 'N', 'H', 'W', 'up', 'bs', 'nf', 'seed', 'mask_init')
+
+
+def _build_train(vkn, name):
+    g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+    c = dict(zip(VIS_TRAIN_FIELDS, (int(v) for v in g['case'])))
+    merge = str(g['merge'])
+    train_cfg = dict(assigner=dict(type='MaskHungarianAssignerVideo', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                   dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                   mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)),
+                     sampler=dict(type='MaskPseudoSampler'), pos_weight=1)
+    trk = vkn.build_head(dict(type='KernelFrameIterHeadVideo', num_proposals=c['N'], num_stages=3, assign_stages=2,
+                              proposal_feature_channel=c['C'], stage_loss_weights=(1., 1., 1.), num_thing_classes=c['ncls'],
+                              num_stuff_classes=0, train_cfg=train_cfg, query_merge_method=merge, with_mask_init=bool(c['mask_init']),
+                              mask_head=_stage_cfg(vkn, 'KernelUpdateHeadVideo', c, num_proposals=c['N'], query_merge_method=merge)))
+    return g, c, trk
+
+
+@pytest.mark.parametrize('name', ['vis_train_tiny', 'vis_train_attnpos'])
+def test_vis_train_state_dict_matches_reference(vkn, name):
+    g, c, trk = _build_train(vkn, name)
+    sd = trk.state_dict()
+    assert sorted(sd) == list(g['keys']) and [str(tuple(sd[k].shape)) for k in sorted(sd)] == list(g['shapes'])
+
+
+def test_clip_instances_of_the_video_assigner(vkn):
+    """CPU: the clip-instance table (instances in ascending id order; a frame where an instance is absent is a zero mask; one
+    label per instance) against a direct per-instance / per-frame construction."""
+    tg = synth.clip_targets(3, 4, 5, 6, 10, 7)
+    for t in tg:
+        masks = [torch.from_numpy(m) for m in t['gt_masks']]
+        clip, labels, inst = vkn.MaskHungarianAssignerVideo.clip_instances(4, masks, torch.from_numpy(t['gt_labels']),
+                                                                           torch.from_numpy(t['gt_instance_ids']))
+        ids, lab = t['gt_instance_ids'], t['gt_labels']
+        assert list(inst) == sorted(set(ids[:, 1].tolist())) and clip.shape == (len(inst), 4, 6, 10)
+        for gi, iid in enumerate(inst):
+            for f in range(4):
+                rows = ids[ids[:, 0] == f, 1]
+                hit = np.nonzero(rows == iid)[0]
+                want = masks[f][hit[0]] if len(hit) else torch.zeros(6, 10)
+                assert torch.equal(clip[gi, f], want)
+                if len(hit):
+                    assert int(labels[gi]) == int(lab[lab[:, 0] == f, 1][hit[0]])
+    with pytest.raises(ValueError):
+        bad = tg[0]['gt_labels'].copy()
+        bad[0, 1] = (bad[0, 1] + 1) % 5
+        first = tg[0]['gt_instance_ids'][0, 1]
+        if (tg[0]['gt_instance_ids'][:, 1] == first).sum() < 2:
+            raise ValueError('instance visible once: nothing to clash with')
+        vkn.MaskHungarianAssignerVideo.clip_instances(4, [torch.from_numpy(m) for m in tg[0]['gt_masks']], torch.from_numpy(bad),
+                                                      torch.from_numpy(tg[0]['gt_instance_ids']))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['vis_train_tiny', 'vis_train_attnpos'])
+def test_vis_clip_training_vs_reference_golden(vkn, name):
+    """`KernelFrameIterHeadVideo.forward_train` (clip-level assignment with MaskHungarianAssignerVideo, per-stage losses, gradients)
+    against the reference's own forward_train: assignments bit-exact, losses 1e-4 relative, gradients 2e-3 of the tensor's max."""
+    g, c, trk = _build_train(vkn, name)
+    shapes = {k: tuple(v.shape) for k, v in trk.state_dict().items()}
+    trk.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, c['seed'] + 1).items()}, strict=True)
+    trk = trk.to(DEV).train()
+    bs, nf, N, C, H, W = c['bs'], c['nf'], c['N'], c['C'], c['H'], c['W']
+    x, pf, mp = (torch.from_numpy(a) for a in synth.head_inputs(bs * nf, N, C, H, W, c['seed']))
+    x = x.reshape(bs, nf, C, H, W).to(DEV).requires_grad_(True)
+    obj = pf.reshape(bs, nf, N, C, 1, 1).to(DEV).requires_grad_(True)
+    masks = mp.reshape(bs, nf, N, H, W).to(DEV)
+    tg = synth.clip_targets(bs, nf, c['ncls'], H * c['up'], W * c['up'], c['seed'])
+    gt_masks = [[torch.from_numpy(m).to(DEV) for m in t['gt_masks']] for t in tg]
+    gt_labels = [torch.from_numpy(t['gt_labels']).to(DEV) for t in tg]
+    gt_ids = [torch.from_numpy(t['gt_instance_ids']).to(DEV) for t in tg]
+    assigned = []
+    for a in trk.mask_assigner:
+        orig = a.assign
+
+        def rec(*args, _orig=orig, **kw):
+            r = _orig(*args, **kw)
+            assigned.append(r[0].gt_inds.clone())
+            return r
+        a.assign = rec
+    losses, feats = trk.forward_train(x, [[dict()] * nf for _ in range(bs)], None, masks, obj, gt_masks, gt_labels, gt_ids)
+    assert sorted(losses) == list(g['loss_keys'])
+    assert np.array_equal(torch.stack(assigned).cpu().numpy(), g['assigned']), 'clip-level Hungarian assignments must be bit-exact'
+    for k, ref in zip(g['loss_keys'], g['loss_vals']):
+        assert abs(float(losses[k].detach()) - ref) < 1e-4 * max(1.0, abs(ref)), (k, float(losses[k].detach()), ref)
+    assert feats['cls_scores'] is None                       # the last (per-frame) stage has no classification branch
+    assert maxabs(feats['obj_feats'], g['feat_obj']) < 1e-3 and maxabs(feats['masks'], g['feat_masks']) < 2e-3
+    total = sum(v for k, v in losses.items() if 'loss' in k) + 0.01 * (feats['obj_feats'] ** 2).sum()
+    assert abs(float(total.detach()) - float(g['total'])) < 1e-4 * abs(float(g['total']))
+    total.backward()
+
+    def close(got, ref, tag, tol=2e-3):
+        ref = torch.from_numpy(ref)
+        assert maxabs(got.detach().cpu(), ref) < tol * max(float(ref.abs().max()), 1e-12), tag
+    close(x.grad, g['grad_x'], 'grad_x')
+    close(obj.grad, g['grad_obj'], 'grad_obj')
+    named = dict(trk.named_parameters())
+    for i, k in enumerate(g['grad_keys']):
+        close(named[str(k)].grad, g[f'grad_{i}'], str(k))
+    for k, ref in zip(g['all_keys'], g['all_gnorm']):       # every parameter's gradient norm
+        p = named[str(k)]
+        if ref < 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, str(k)
+        else:
+            assert p.grad is not None and abs(float(p.grad.double().norm()) - ref) < 5e-3 * max(ref, 1e-6), (str(k), ref)

@@ -12,7 +12,7 @@ from .kernel_update_head import KernelUpdateHead, VideoKernelUpdateHead  # noqa:
 from .kernel_iter_head import KernelIterHead, VideoKernelIterHead  # noqa: F401
 from .kernel_head import ConvKernelHead  # noqa: F401
 from .knet_vis import KernelFrameIterHeadVideo, KernelIterHeadVideo, KernelUpdateHeadVideo  # noqa: F401
-from .mask_hungarian_assigner import MaskHungarianAssigner  # noqa: F401
+from .mask_hungarian_assigner import MaskHungarianAssigner, MaskHungarianAssignerVideo  # noqa: F401
 from .qd_tracker import QuasiDenseEmbedTracker, build_tracker  # noqa: F401
 from .registry import HEADS, TRANSFORMER_LAYER, build_head, build_transformer_layer  # noqa: F401
 from . import autograd, losses  # noqa: F401
@@ -20,6 +20,6 @@ from .mask_pseudo_sampler import MaskPseudoSampler  # noqa: F401
 
 registry._register_training_components()
 
-__all__ = ['KernelUpdator', 'KernelUpdateHead', 'VideoKernelUpdateHead', 'KernelIterHead', 'VideoKernelIterHead', 'ConvKernelHead', 'MaskHungarianAssigner',
+__all__ = ['KernelUpdator', 'KernelUpdateHead', 'VideoKernelUpdateHead', 'KernelIterHead', 'VideoKernelIterHead', 'ConvKernelHead', 'MaskHungarianAssigner', 'MaskHungarianAssignerVideo',
            'HEADS', 'TRANSFORMER_LAYER', 'build_head', 'build_transformer_layer', 'ops', 'build', 'VknError',
            'VknLibraryError']

@@ -42,7 +42,7 @@ class VknAssignCfg(ctypes.Structure):
     """Mirror of include/vkn.h: VknAssignCfg."""
     _fields_ = [('cls_weight', ctypes.c_float), ('dice_weight', ctypes.c_float), ('mask_weight', ctypes.c_float),
                 ('focal_alpha', ctypes.c_float), ('focal_gamma', ctypes.c_float), ('focal_eps', ctypes.c_float),
-                ('dice_eps', ctypes.c_float)]
+                ('dice_eps', ctypes.c_float), ('dice_pred_min', ctypes.c_float), ('mask_pred_min', ctypes.c_float)]
 
 
 class VknTrackerCfg(ctypes.Structure):

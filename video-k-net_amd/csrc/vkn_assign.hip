@@ -3,8 +3,8 @@
 // Reference, per image: MaskHungarianAssigner.assign (knet/det/mask_hungarian_assigner.py:160-274) with the shipped costs
 // (configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:143-160):
 //     cost[n][g] = w_cls  * FocalLossCost(cls_logits)[n][label_g]                       (mmdet 2.18 match cost, restated below)
-//                + w_dice * DiceCost  = -2 a / (sum_p p1^2 + eps + sum_p g^2 + eps),   a = sum_p p1 g,  p1 = clamp(sigmoid z, 1e-3, 1)   (:37-74)
-//                + w_mask * MaskCost  = -(sum_p p2 g + sum_p (1 - p2)(1 - g)) / (H W),                p2 = clamp(sigmoid z, 1e-2, 1)   (:87-113)
+//                + w_dice * DiceCost  = -2 a / (sum_p p1^2 + eps + sum_p g^2 + eps),   a = sum_p p1 g,  p1 = clamp(sigmoid z, dice_pred_min, 1)   (:37-74)
+//                + w_mask * MaskCost  = -(sum_p p2 g + sum_p (1 - p2)(1 - g)) / (H W),                p2 = clamp(sigmoid z, mask_pred_min, 1)   (:87-113)
 // then scipy.optimize.linear_sum_assignment on the host and assigned_gt_inds[row] = col + 1                                  (:244-271).
 //
 // The two [N x P] . [P x G] contractions are the gather kernel with the roles swapped: the left operand is the ground truth
@@ -30,7 +30,8 @@
 
 // act[0 .. Npad) = p1 rows, act[Npad .. 2 Npad) = p2 rows (rows >= N zero); rowsum[n][chunk][2] = partial (sum p1^2, sum p2)
 __global__ __launch_bounds__(256) void k_assign_act(const float* __restrict__ logits, float* __restrict__ act,
-                                                    float* __restrict__ rowsum, int N, int Npad, int P, int nchunk) {
+                                                    float* __restrict__ rowsum, int N, int Npad, int P, int nchunk, float lo1,
+                                                    float lo2) {
     __shared__ float red[2][4];
     const int n = blockIdx.y, ck = blockIdx.x;
     const int p_lo = ck * AS_CHUNK, p_hi = min(P, p_lo + AS_CHUNK);
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void k_assign_act(const float* __restrict__ lo
         const float* z = logits + (size_t)n * P;
         for (int p = p_lo + threadIdx.x; p < p_hi; p += 256) {
             const float s = 1.0f / (1.0f + expf(-z[p]));
-            const float p1 = fminf(fmaxf(s, 0.001f), 1.0f), p2 = fminf(fmaxf(s, 0.01f), 1.0f);
+            const float p1 = fminf(fmaxf(s, lo1), 1.0f), p2 = fminf(fmaxf(s, lo2), 1.0f);
             a1[p] = p1;
             a2[p] = p2;
             s1 += p1 * p1;
@@ -160,7 +161,8 @@ int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, cons
     carve_assign(N, G, P, static_cast<char*>(ws), &w);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nchunk = (P + AS_CHUNK - 1) / AS_CHUNK;
-    hipLaunchKernelGGL(k_assign_act, dim3(nchunk, Npad), dim3(256), 0, st, mask_logits, w.act, w.rowsum, N, Npad, P, nchunk);
+    hipLaunchKernelGGL(k_assign_act, dim3(nchunk, Npad), dim3(256), 0, st, mask_logits, w.act, w.rowsum, N, Npad, P, nchunk,
+                       cfg->dice_pred_min, cfg->mask_pred_min);
     VKN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_assign_gtsq, dim3(nchunk, G), dim3(256), 0, st, gt_masks, w.gsq, P, nchunk);
     VKN_CHECK_LAUNCH();

@@ -221,23 +221,23 @@ class KernelUpdateHead(nn.Module):
         identity = query if identity is None else identity
         return identity + mod.attn(query, key, key, need_weights=False)[0]
 
-    def _forward_autograd(self, x, proposal_feat, mask_preds, previous_obj_feats=None):
-        """Differentiable stage (training): the two x-streaming ops are the HIP kernels behind autograd Functions
-        (video-k-net_amd/autograd.py: their backward passes are the same kernels with transposed operands), the [B*N, C] chain
-        runs as torch ops on this module's own parameters.  `feat_transform` stays folded: x_feat = xraw W^T + cnt b,
-        Z = (mask_feat W) x + mask_feat . b — its weight / bias gradients come out of the two small matmuls.
-        Line-by-line counterpart of knet/det/kernel_update_head.py:170-277 (video: knet/video/kernel_update_head.py:281-541)."""
+    def _xfeat_autograd(self, x, mask_preds):
+        """Differentiable gather: x [B,C,H,W], mask_preds [B,N,H,W] -> x_feat [B,N,C] with `feat_transform` folded
+        (x_feat = xraw W^T + cnt b; reference :179-180, :190-195)."""
         if x.dtype != torch.float32:
             raise TypeError('the autograd (training) path reads fp32 features; half-storage x is an inference option')
+        C = self.in_channels
+        xraw, cnt = vag.mask_gather(x, mask_preds.detach(), self.hard_mask_thr)
+        if self.feat_transform is None:
+            return xraw
+        return xraw @ self.feat_transform.conv.weight.reshape(C, C).t() + cnt.unsqueeze(-1) * self.feat_transform.conv.bias
+
+    def _chain_autograd(self, x_feat, proposal_feat, previous_obj_feats=None):
+        """The [B*N, C] chain as torch ops on this module's own parameters (reference :198-227; video :324-476):
+        x_feat [B,N,C], proposal_feat [B,N,C,K,K] -> (cls_score | None, decode kernels [B,N,C], decode bias [B,N] | None,
+        obj_feat [B,N,C,K,K], track | None).  `feat_transform` is folded into the decode kernels: Z = (mask_feat W) x + mask_feat . b."""
         B, N = proposal_feat.shape[:2]
         C, K = self.in_channels, self.conv_kernel_size
-        xraw, cnt = vag.mask_gather(x, mask_preds.detach(), self.hard_mask_thr)                        # :190-195
-        if self.feat_transform is not None:
-            w_ft = self.feat_transform.conv.weight.reshape(C, C)
-            b_ft = self.feat_transform.conv.bias
-            x_feat = xraw @ w_ft.t() + cnt.unsqueeze(-1) * b_ft                                         # :179-180 folded
-        else:
-            x_feat = xraw
         pf = proposal_feat.reshape(B, N, C, -1).permute(0, 1, 3, 2)                                     # :198-199
         if previous_obj_feats is not None and getattr(self, 'previous_link', None) is not None:         # video :324-372
             pf = self._link_autograd(self._link_names('link'), x_feat, pf.reshape(B, N, C), previous_obj_feats,
@@ -249,24 +249,36 @@ class KernelUpdateHead(nn.Module):
         if self.with_ffn:
             obj_feat = self.ffn_norm(obj_feat + self.ffn.layers(obj_feat))                              # :214-215
         track = None
-        if previous_obj_feats is not None and self.previous is not None and self.previous_type is not None:   # video :394-476
+        if previous_obj_feats is not None and getattr(self, 'previous', None) is not None and self.previous_type is not None:   # video :394-476
             uf = {'ffn': None, 'update': x_feat, 'update_obj': obj_feat.reshape(B, N, C)}[self.previous_type]
             t = self._link_autograd(self._link_names('track'), uf, obj_feat.reshape(B, N, C), previous_obj_feats, False)
             track = t.reshape(B, N, C, K, K)
-        cls_feat = obj_feat.sum(-2)                                                                     # :217-221
+        cls_score = None
+        if getattr(self, 'fc_cls', None) is not None:
+            cls_feat = obj_feat.sum(-2)                                                                 # :217-221
+            for layer in self.cls_fcs:
+                cls_feat = layer(cls_feat)
+            cls_score = self.fc_cls(cls_feat).view(B, N, -1)
         mask_feat = obj_feat
-        for layer in self.cls_fcs:
-            cls_feat = layer(cls_feat)
-        cls_score = self.fc_cls(cls_feat).view(B, N, -1)
         for layer in self.mask_fcs:                                                                     # :223-227
             mask_feat = layer(mask_feat)
         mask_feat = self.fc_mask(mask_feat).reshape(B, N, C)
-        if self.feat_transform is not None:
-            kern, kb = mask_feat @ w_ft, mask_feat @ b_ft                                               # K (W x + b) = (K W) x + K.b
+        if self.feat_transform is not None:                                                             # K (W x + b) = (K W) x + K.b
+            kern = mask_feat @ self.feat_transform.conv.weight.reshape(C, C)
+            kb = mask_feat @ self.feat_transform.conv.bias
         else:
             kern, kb = mask_feat, None
+        return cls_score, kern, kb, obj_feat.permute(0, 1, 3, 2).reshape(B, N, C, K, K), track
+
+    def _forward_autograd(self, x, proposal_feat, mask_preds, previous_obj_feats=None):
+        """Differentiable stage (training): the two x-streaming ops are the HIP kernels behind autograd Functions
+        (video-k-net_amd/autograd.py: their backward passes are the same kernels with transposed operands), the [B*N, C] chain
+        runs as torch ops on this module's own parameters.
+        Counterpart of knet/det/kernel_update_head.py:170-277 (video: knet/video/kernel_update_head.py:281-541)."""
+        x_feat = self._xfeat_autograd(x, mask_preds)
+        cls_score, kern, kb, obj_feat, track = self._chain_autograd(x_feat, proposal_feat, previous_obj_feats)
         new_mask_preds = vag.mask_decode(x, kern, kb)                                                   # :247-260
-        return cls_score, new_mask_preds, obj_feat.permute(0, 1, 3, 2).reshape(B, N, C, K, K), x_feat, track
+        return cls_score, new_mask_preds, obj_feat, x_feat, track
 
     def _link_names(self, which):
         raise NotImplementedError
@@ -354,7 +366,7 @@ class KernelUpdateHead(nn.Module):
         num_pos = pos_inds.sum().float()
         avg_factor = reduce_mean(num_pos).clamp_(min=1.0)
         num_preds = mask_pred.shape[0] * mask_pred.shape[1]
-        assert mask_pred.shape[0] == cls_score.shape[0] and mask_pred.shape[1] == cls_score.shape[1]
+        assert cls_score is None or (mask_pred.shape[0] == cls_score.shape[0] and mask_pred.shape[1] == cls_score.shape[1])
         if cls_score is not None and cls_score.numel() > 0:
             losses['loss_cls'] = self.loss_cls(cls_score.view(num_preds, -1), labels, label_weights, avg_factor=avg_factor,
                                                reduction_override=reduction_override)

@@ -14,10 +14,11 @@ gather `einsum('bfnhw,bfchw->bfnc')` is `vkn_mask_gather_f32` on B * F frames, t
 import torch
 import torch.nn as nn
 
+from . import autograd as vag
 from . import ops
 from .kernel_iter_head import KernelIterHead
 from .kernel_update_head import KernelUpdateHead, _FFNParams, _MHAParams
-from .registry import BaseRoIHead, build_head, register_head
+from .registry import BaseRoIHead, build_assigner, build_head, build_sampler, register_head
 
 
 class _QueryMerge:
@@ -37,6 +38,16 @@ class _QueryMerge:
         self._merge_pack = None
         if hasattr(super(), 'invalidate_pack'):
             super().invalidate_pack()
+
+    def _query_merge_autograd(self, query, keys, pos):
+        """The same block as torch ops on this module's parameters (training): mmcv's MultiheadAttention adds the positions to
+        query / key only; value and the residual are `keys` / `query` themselves."""
+        F = keys.shape[1] // query.shape[1]
+        q = query if pos is None else query + pos
+        k = keys if pos is None else keys + pos.repeat(F, 1)
+        att = self.query_merge_attn.attn(q.transpose(0, 1), k.transpose(0, 1), keys.transpose(0, 1), need_weights=False)[0]
+        t = self.query_merge_norm(query + att.transpose(0, 1))
+        return self.query_merge_ffn_norm(t + self.query_merge_ffn.layers(t))
 
     def _query_merge(self, query, keys, pos):
         """query [B,N,C], keys [B,F*N,C], pos [N,C] | None -> [B,N,C] on the GPU (no autograd)."""
@@ -88,6 +99,8 @@ class KernelUpdateHeadVideo(_QueryMerge, KernelUpdateHead):
         B, F, C, H, W = x.shape
         if mask_preds.shape[-2:] != (H, W):
             raise NotImplementedError('mask_preds at another resolution than x is dead in shipped configs (:227-231)')
+        if self._needs_grad(x, proposal_feat):
+            return self._forward_clip_autograd(x, proposal_feat, mask_preds, pos)
         if proposal_feat.dim() == 6:
             assert not self.with_cls
             N = proposal_feat.shape[2]
@@ -120,6 +133,39 @@ class KernelUpdateHeadVideo(_QueryMerge, KernelUpdateHead):
         # every frame of a clip is decoded with the clip's kernels (:318-330)
         masks = ops.mask_decode(xf, kern.repeat_interleave(F, dim=0), kb.repeat_interleave(F, dim=0))
         return cls, masks.reshape(B, F, N, H, W), obj.reshape(B, N, C, 1, 1)
+
+    def _forward_clip_autograd(self, x, proposal_feat, mask_preds, pos):
+        """Training counterpart of `forward`: the gather / decode over the B * F frames are the HIP kernels behind their autograd
+        Functions, the merge and the [N x C] chain torch ops on this module's parameters (base class `_xfeat_autograd` /
+        `_chain_autograd`)."""
+        B, F, C, H, W = x.shape
+        xf = x.reshape(B * F, C, H, W)
+        if proposal_feat.dim() == 6:                                                           # per-frame kernels (:266-267, :276-279)
+            assert not self.with_cls
+            N = proposal_feat.shape[2]
+            assert self.num_proposals == N
+            x_feat = self._xfeat_autograd(xf, mask_preds.reshape(B * F, N, H, W))
+            _, kern, kb, obj, _ = self._chain_autograd(x_feat, proposal_feat.reshape(B * F, N, C, 1, 1))
+            masks = vag.mask_decode(xf, kern, kb)
+            return None, masks.reshape(B, F, N, H, W), obj.reshape(B, F, N, C, 1, 1)
+        assert self.with_cls
+        N = proposal_feat.shape[1]
+        assert self.num_proposals == N
+        x_feat = self._xfeat_autograd(xf, mask_preds.reshape(B * F, N, H, W)).reshape(B, F, N, C)
+        if self.query_merge_method == 'mean':
+            x_feat = x_feat.mean(1)                                                            # :243
+        else:                                                                                  # :244-263 (init_query is detached there)
+            if self.query_merge_method == 'attention_pos' and pos is None:
+                raise ValueError("query_merge_method='attention_pos' needs `pos` (the tracker head's query_pos.weight)")
+            x_feat = self._query_merge_autograd(proposal_feat.reshape(B, N, C).detach(), x_feat.reshape(B, F * N, C),
+                                                pos if self.query_merge_method == 'attention_pos' else None)
+        cls, kern, kb, obj, _ = self._chain_autograd(x_feat, proposal_feat.reshape(B, N, C, 1, 1))
+        masks = vag.mask_decode(xf, kern.repeat_interleave(F, dim=0), kb.repeat_interleave(F, dim=0) if kb is not None else None)
+        return cls, masks.reshape(B, F, N, H, W), obj
+
+    def get_targets(self, sampling_results, rcnn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None):
+        """knet_vis's signature (tracker/kernel_update_head.py:504-530): no gt_mask / gt_labels arguments."""
+        return KernelUpdateHead.get_targets(self, sampling_results, None, None, rcnn_train_cfg, concat, gt_sem_seg, gt_sem_cls)
 
     def get_seg_masks_tracking(self, masks_per_img, labels_per_img, scores_per_img, ids_per_img, test_cfg, img_meta):
         """knet_vis/det/kernel_update_head.py:484-500: masks + mmtrack's `outs2results` packing (ids instead of boxes)."""
@@ -165,6 +211,12 @@ def outs2results(bboxes=None, labels=None, masks=None, ids=None, num_classes=Non
 @register_head
 class KernelIterHeadVideo(KernelIterHead):
     """knet_vis/tracker/kernel_iter_head.py: the per-frame roi head of the VIS model.  x holds bs * num_frames frames."""
+
+    def init_assigner_sampler(self):
+        super().init_assigner_sampler()
+        for a in self.mask_assigner:       # knet_vis's DiceCost / MaskCost do not clamp the sigmoid (knet_vis/det/mask_hungarian_assigner.py:69,100)
+            if hasattr(a, 'pred_clamp'):
+                a.pred_clamp = (0.0, 0.0)
 
     def simple_test(self, x, proposal_feats, mask_preds, cls_score, img_metas, ref_img_metas, imgs_whwh=None, rescale=False):
         """-> (results: per frame `(bbox_result, segm_result)`, features: the tracker's inputs)            reference :243-313"""
@@ -228,9 +280,13 @@ class KernelFrameIterHeadVideo(_QueryMerge, BaseRoIHead):
             self.mask_head.append(build_head(head))
 
     def init_assigner_sampler(self):
+        """One assigner + sampler per stage, all from the ONE `train_cfg.tracker` dict (:92-103)."""
         self.mask_assigner, self.mask_sampler = [], []
         if self.train_cfg is not None:
-            raise NotImplementedError('training of the clip-level tracker head (MaskHungarianAssignerVideo) is not built')
+            for i in range(self.num_stages):
+                self.mask_assigner.append(build_assigner(self._cfg(self.train_cfg, 'assigner')))
+                self.current_stage = i
+                self.mask_sampler.append(build_sampler(self._cfg(self.train_cfg, 'sampler'), context=self))
 
     def init_bbox_head(self, mask_roi_extractor, mask_head):
         raise NotImplementedError
@@ -244,12 +300,21 @@ class KernelFrameIterHeadVideo(_QueryMerge, BaseRoIHead):
         pos = self.query_pos.weight if self.query_merge_method == 'attention_pos' else None     # :117
         cls_score, mask_preds, object_feats = mask_head(x, object_feats, mask_preds, img_metas=None, pos=pos)
         if mask_head.mask_upsample_stride > 1 and (stage == self.num_stages - 1 or self.training):
-            B, F, N, H, W = mask_preds.shape
-            s = mask_head.mask_upsample_stride
-            scaled = ops.upsample_bilinear(mask_preds.reshape(B * F, N, H, W), s).reshape(B, F, N, H * s, W * s)   # :121-130
+            scaled = self._upsample_clip(mask_preds, mask_head.mask_upsample_stride)                              # :121-130
         else:
             scaled = mask_preds
         return dict(cls_score=cls_score, mask_preds=mask_preds, scaled_mask_preds=scaled, object_feats=object_feats)
+
+    @staticmethod
+    def _upsample_clip(mask_preds, s):
+        """[B,F,N,H,W] -> [B,F,N,sH,sW] bilinear: the HIP kernel at inference, torch's op (for its backward) under autograd."""
+        B, F, N, H, W = mask_preds.shape
+        flat = mask_preds.reshape(B * F, N, H, W)
+        if mask_preds.requires_grad and torch.is_grad_enabled():
+            up = torch.nn.functional.interpolate(flat, scale_factor=s, mode='bilinear', align_corners=False)
+        else:
+            up = ops.upsample_bilinear(flat, s)
+        return up.reshape(B, F, N, H * s, W * s)
 
     def _query_fusion(self, obj_feats, num_imgs, num_frames):
         if self.query_merge_method == 'mean':
@@ -258,6 +323,9 @@ class KernelFrameIterHeadVideo(_QueryMerge, BaseRoIHead):
             raise NotImplementedError('Only supporting kernel size = 1')                       # :143
         C, N = self.proposal_feature_channel, self.num_proposals                                # :142-160
         keys = obj_feats.reshape(num_imgs, num_frames * N, C)
+        if torch.is_grad_enabled() and (keys.requires_grad or self.init_query.weight.requires_grad):
+            pos = self.query_pos.weight if self.query_merge_method == 'attention_pos' else None
+            return self._query_merge_autograd(self.init_query.weight.expand(num_imgs, N, C), keys, pos)[..., None, None]
         query = self.init_query.weight.detach().expand(num_imgs, N, C).contiguous()
         pos = self.query_pos.weight.detach() if self.query_merge_method == 'attention_pos' else None
         return self._query_merge(query, keys, pos)[..., None, None]
@@ -266,12 +334,72 @@ class KernelFrameIterHeadVideo(_QueryMerge, BaseRoIHead):
         """:163-178: mask_preds = conv2d(x_feats[i], fc_mask(object_feats)[i]) for all frames of clip i."""
         B, F, C, H, W = x_feats.shape
         N = object_feats.shape[1]
+        if torch.is_grad_enabled() and (object_feats.requires_grad or x_feats.requires_grad or self.fc_mask.weight.requires_grad):
+            k = self.fc_mask(object_feats.reshape(B, N, C))
+            return vag.mask_decode(x_feats.reshape(B * F, C, H, W), k.repeat_interleave(F, dim=0), None).reshape(B, F, N, H, W)
         k = ops.linear(object_feats.reshape(B * N, C), self.fc_mask.weight.detach(), self.fc_mask.bias.detach()).reshape(B, N, C)
         return ops.mask_decode(x_feats.reshape(B * F, C, H, W), k.repeat_interleave(F, dim=0)).reshape(B, F, N, H, W)
 
     @staticmethod
     def _cfg(cfg, key):
         return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
+
+    def _clip_losses(self, stage, prefix, object_feats, cls_score, scaled, assigned, ref_gt_masks, ref_gt_labels, ref_gt_instance_ids,
+                     cls_for_assign, out):
+        """Assign (or re-use `assigned`, the (AssignResult, gt tall masks) pairs of the last assigning stage), sample, build the
+        targets and add this stage's losses to `out` under `prefix`.  A clip's masks are handled in the "tall" layout
+        ([Q, F*H, W]: frames stacked along the rows) — losses and costs then are the per-frame ones, unchanged.  Returns `assigned`."""
+        assigner, sampler, head = self.mask_assigner[stage], self.mask_sampler[stage], self.mask_head[stage]
+        num_imgs = scaled.shape[0]
+        if assigned is None:
+            assigned = []
+            det = scaled.detach()
+            for i in range(num_imgs):
+                r = assigner.assign(det[i][:, :self.num_proposals], cls_for_assign[i] if cls_for_assign is not None else None,
+                                    ref_gt_masks[i], ref_gt_labels[i], ref_gt_instance_ids[i])
+                if not isinstance(r, tuple):   # a clip without ground truth
+                    F, _, H, W = det[i].shape
+                    r = (r, det.new_zeros((0, F * H, W)))
+                assigned.append(r)
+        tall = torch.stack([assigner.tall(scaled[i]) for i in range(num_imgs)])                          # [B, Q, F*H, W]
+        sampling = [sampler.sample(assigned[i][0], tall[i], assigned[i][1]) for i in range(num_imgs)]
+        targets = head.get_targets(sampling, self.train_cfg, True, gt_sem_seg=None, gt_sem_cls=None)
+        for key, value in head.loss(object_feats, cls_score, tall, *targets).items():
+            out[f'{prefix}_{key}'] = value * self.stage_loss_weights[stage]
+        return assigned
+
+    def forward_train(self, x, ref_img_metas, cls_scores, masks, obj_feats, ref_gt_masks, ref_gt_labels, ref_gt_instance_ids, **kwargs):
+        """Clip-level training of the tracker head (reference :182-312): x [B,F,C,H,W]; ref_gt_masks[i][f] = [n_f, sH, sW] masks of
+        frame f of clip i, ref_gt_labels[i] / ref_gt_instance_ids[i] = [M, 2] rows (frame, label) / (frame, instance id).
+        -> (losses `tracker_s{stage}_*` (+ `tracker_init_*` with `with_mask_init`), features).  Stages < assign_stages assign on their
+        own predictions; the per-frame stages after them re-use the last assignment (:270-283)."""
+        if not self.mask_assigner:
+            raise RuntimeError('forward_train needs train_cfg (assigner / sampler / pos_weight of the tracker head)')
+        num_imgs, num_frames = len(ref_img_metas), len(ref_img_metas[0])
+        object_feats = self._query_fusion(obj_feats, num_imgs, num_frames) if obj_feats.dim() == 6 else obj_feats
+        losses = {}
+        if self.with_mask_init:                                                                          # :196-246
+            mask_preds = self._mask_init(object_feats, x, num_imgs)
+            s = self.mask_head[0].mask_upsample_stride
+            scaled = self._upsample_clip(mask_preds, s) if s > 1 else mask_preds
+            self._clip_losses(0, 'tracker_init', object_feats, None, scaled, None, ref_gt_masks, ref_gt_labels, ref_gt_instance_ids,
+                              None, losses)
+        else:
+            mask_preds = masks
+        assigned, cls_score = None, None
+        for stage in range(self.num_stages):
+            if stage == self.assign_stages:
+                object_feats = object_feats[:, None].repeat(1, num_frames, 1, 1, 1, 1)
+            r = self._mask_forward(stage, x, object_feats, mask_preds)
+            mask_preds, cls_score, object_feats = r['mask_preds'], r['cls_score'], r['object_feats']
+            cls_for_assign = None
+            if stage < self.assign_stages:
+                assigned = None
+                if cls_score is not None:
+                    cls_for_assign = cls_score.detach()[:, :self.num_proposals, :self.num_thing_classes]
+            assigned = self._clip_losses(stage, f'tracker_s{stage}', object_feats, cls_score, r['scaled_mask_preds'], assigned,
+                                         ref_gt_masks, ref_gt_labels, ref_gt_instance_ids, cls_for_assign, losses)
+        return losses, dict(obj_feats=object_feats, x_feats=x, cls_scores=cls_score, masks=mask_preds)
 
     def simple_test(self, x, img_metas, ref_img_metas, cls_scores, masks, obj_feats, **kwargs):
         """-> (results[img][frame] = (bbox_results with ids, mask_results), features)                      reference :313-372"""

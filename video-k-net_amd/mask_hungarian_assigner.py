@@ -37,6 +37,9 @@ def _cost_cfg(cfg, kind, allowed, defaults):
 
 
 class MaskHungarianAssigner:
+    # lower clamp of sigmoid(mask logits) inside (DiceCost, MaskCost): knet/det/mask_hungarian_assigner.py:69,101.  The knet_vis copies
+    # of the two cost classes (same registry names) do not clamp — `pred_clamp = (0.0, 0.0)` selects that flavour
+    pred_clamp = (1e-3, 1e-2)
 
     def __init__(self, cls_cost=dict(type='ClassificationCost', weight=1.), mask_cost=dict(type='SigmoidCost', weight=1.0),
                  dice_cost=dict(), boundary_cost=None, topk=1):
@@ -58,7 +61,8 @@ class MaskHungarianAssigner:
         return ops.assign_costs(bbox_pred, cls_pred if use_cls else None, gt_bboxes, gt_labels,
                                 cls_weight=self.cls['weight'] if use_cls else 0.0, dice_weight=self.dice['weight'],
                                 mask_weight=self.mask['weight'], focal_alpha=self.cls['alpha'], focal_gamma=self.cls['gamma'],
-                                focal_eps=self.cls['eps'], dice_eps=self.dice['eps'])
+                                focal_eps=self.cls['eps'], dice_eps=self.dice['eps'], dice_pred_min=self.pred_clamp[0],
+                                mask_pred_min=self.pred_clamp[1])
 
     def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta=None, gt_bboxes_ignore=None, eps=1e-7):
         """bbox_pred = mask logits [N,H,W], gt_bboxes = gt masks [G,H,W] (the reference's argument names).
@@ -84,8 +88,74 @@ class MaskHungarianAssigner:
         return res
 
 
+class MaskHungarianAssignerVideo(MaskHungarianAssigner):
+    """Clip-level assigner of the VIS tracker head (knet_vis/tracker/mask_hungarian_assigner.py:17-190): one ground-truth unit is
+    an INSTANCE OF THE CLIP — its masks in the frames where it appears, zeros elsewhere — and the costs are those of the per-frame
+    assigner on "tall" masks, the F frames of a clip stacked along the row axis ([Q, F*H, W] against [G, F*H, W]).  So this is the
+    same GPU cost kernel and the same LSAP on a different layout; what is added is the construction of the clip instances.
+    knet_vis's DiceCost / MaskCost take the plain sigmoid (knet_vis/det/mask_hungarian_assigner.py:69,100): no clamp."""
+    pred_clamp = (0.0, 0.0)
+
+    @staticmethod
+    def clip_instances(num_frames, gt_masks, gt_labels, gt_instance_ids):
+        """gt_masks: per frame [n_f, H, W]; gt_labels / gt_instance_ids: [M, 2] rows (frame, label) / (frame, instance id), the rows
+        of one frame in the order of that frame's masks.  -> (clip masks [G, F, H, W] float, labels [G] long, instance ids [G]),
+        instances in ascending id order (reference :104-128).  The bookkeeping runs on the host on the two tiny id tables; the
+        masks move with ONE gather on their own device."""
+        ids = np.asarray(gt_instance_ids.detach().cpu().numpy(), dtype=np.int64).reshape(-1, 2)
+        lab = np.asarray(gt_labels.detach().cpu().numpy(), dtype=np.int64).reshape(-1, 2)
+        dev = gt_masks[0].device
+        H, W = gt_masks[0].shape[-2:]
+        inst = np.unique(ids[:, 1])
+        G = len(inst)
+        if G == 0:
+            return gt_masks[0].new_zeros((0, num_frames, H, W), dtype=torch.float32), torch.zeros(0, dtype=torch.long, device=dev), inst
+        base = np.concatenate([[0], np.cumsum([int(m.shape[0]) for m in gt_masks])])       # row of a frame's first mask in the stack
+        src, dst = [], []
+        labels = np.full(G, -1, dtype=np.int64)
+        for f in range(num_frames):
+            rows = np.nonzero(ids[:, 0] == f)[0]
+            lrows = np.nonzero(lab[:, 0] == f)[0]
+            if len(rows) != int(gt_masks[f].shape[0]) or len(lrows) != len(rows):
+                raise ValueError(f'frame {f}: {gt_masks[f].shape[0]} masks, {len(rows)} instance ids, {len(lrows)} labels')
+            g = np.searchsorted(inst, ids[rows, 1])
+            if len(np.unique(g)) != len(g):
+                raise ValueError(f'frame {f}: an instance id appears twice')
+            src.append(base[f] + np.arange(len(rows)))
+            dst.append(g * num_frames + f)
+            fl = lab[lrows, 1]
+            clash = (labels[g] >= 0) & (labels[g] != fl)
+            if clash.any():
+                raise ValueError(f'instance {inst[g[clash][0]]} changes its label inside the clip')
+            labels[g] = np.where(labels[g] >= 0, labels[g], fl)
+        src, dst = np.concatenate(src), np.concatenate(dst)
+        clip = gt_masks[0].new_zeros((G * num_frames, H, W), dtype=torch.float32)
+        if len(src):
+            stack = torch.cat([m.to(torch.float32) for m in gt_masks])
+            clip[torch.from_numpy(dst).to(dev)] = stack[torch.from_numpy(src).to(dev)]
+        return clip.view(G, num_frames, H, W), torch.from_numpy(labels).to(dev), inst
+
+    @staticmethod
+    def tall(masks):
+        """[F, Q, H, W] (a clip's frames) -> [Q, F*H, W]: the frames of a kernel stacked along the row axis (reference :147)."""
+        F, Q, H, W = masks.shape
+        return masks.permute(1, 0, 2, 3).reshape(Q, F * H, W)
+
+    def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_instance_ids, img_meta=None, gt_bboxes_ignore=None, eps=1e-7):
+        """bbox_pred = mask logits of one clip [F, Q, H, W]; cls_pred [Q, ncls] | None -> (AssignResult, gt tall masks [G, F*H, W])."""
+        assert gt_bboxes_ignore is None, 'Only case when gt_bboxes_ignore is None is supported.'
+        F, Q, H, W = bbox_pred.shape
+        clip, labels, _ = self.clip_instances(F, gt_bboxes, gt_labels, gt_instance_ids)
+        gt_tall = clip.reshape(clip.shape[0], F * H, W)
+        res = MaskHungarianAssigner.assign(self, self.tall(bbox_pred), cls_pred, gt_tall, labels, img_meta=img_meta)
+        if gt_tall.shape[0] == 0:
+            return res      # (the reference returns the bare AssignResult here as well, :137-142)
+        return res, gt_tall
+
+
 try:  # register beside the reference's class when mmdet is importable (same `type` name, force=True)
     from mmdet.core.bbox.builder import BBOX_ASSIGNERS  # type: ignore
     BBOX_ASSIGNERS.register_module(force=True)(MaskHungarianAssigner)
+    BBOX_ASSIGNERS.register_module(force=True)(MaskHungarianAssignerVideo)
 except Exception:  # noqa: BLE001
     pass

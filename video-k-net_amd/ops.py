@@ -636,8 +636,9 @@ def panoptic_thing_first(thing_masks, thing_scores, thing_labels, thing_order, s
 
 
 def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, dice_weight=4.0, mask_weight=1.0,
-                 focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3):
-    """Cost matrix [N, G] of `MaskHungarianAssigner.assign` (knet/det/mask_hungarian_assigner.py:222-241) on the GPU."""
+                 focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3, dice_pred_min=1e-3, mask_pred_min=1e-2):
+    """Cost matrix [N, G] of `MaskHungarianAssigner.assign` (knet/det/mask_hungarian_assigner.py:222-241) on the GPU.
+    dice_pred_min / mask_pred_min: the lower clamp of sigmoid(logits) in DiceCost / MaskCost (knet: 1e-3 / 1e-2; knet_vis: none)."""
     m = _req(mask_logits.reshape(mask_logits.shape[0], -1), 'mask_preds')
     g = _req(gt_masks.reshape(gt_masks.shape[0], -1).float(), 'gt_masks')
     N, P = m.shape
@@ -656,7 +657,7 @@ def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, d
         if lo < 0 or hi >= ncls:
             raise IndexError(f'gt_labels outside [0, {ncls}): {lo} .. {hi}')
     cfg = _lib.VknAssignCfg(float(cls_weight), float(dice_weight), float(mask_weight), float(focal_alpha), float(focal_gamma),
-                            float(focal_eps), float(dice_eps))
+                            float(focal_eps), float(dice_eps), float(dice_pred_min), float(mask_pred_min))
     L = _lib.lib()
     cost = torch.empty((N, G), dtype=torch.float32, device=m.device)
     nb = L.vkn_assign_workspace_bytes(N, G, P)

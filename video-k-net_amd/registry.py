@@ -99,11 +99,12 @@ def _register_training_components():
     if HAVE_MM:
         return
     from . import losses
-    from .mask_hungarian_assigner import MaskHungarianAssigner
+    from .mask_hungarian_assigner import MaskHungarianAssigner, MaskHungarianAssignerVideo
     from .mask_pseudo_sampler import MaskPseudoSampler
     for cls in (losses.FocalLoss, losses.CrossEntropyLoss, losses.DiceLoss):
         LOSSES.register_module(force=True)(cls)
     BBOX_ASSIGNERS.register_module(force=True)(MaskHungarianAssigner)
+    BBOX_ASSIGNERS.register_module(force=True)(MaskHungarianAssignerVideo)
     BBOX_SAMPLERS.register_module(force=True)(MaskPseudoSampler)
 
 
