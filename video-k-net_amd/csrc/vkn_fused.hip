@@ -815,7 +815,7 @@ template <int NB, int C, int XH = 0, int PF = 0>
 __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restrict__ x, const _Float16* __restrict__ kfh,
                                                              const _Float16* __restrict__ kfl, const float* __restrict__ kb,
                                                              float thr, float* __restrict__ part, float* __restrict__ cntp,
-                                                             int N, int NPT, int n0, int P) {
+                                                             int N, int NPT, int n0_in, int P, int NZ) {
     constexpr int KS = C / 16;
     // 16-channel fragments of a tile per loader wave: the decode waves (128 + 16 + 24 registers of operands) take NFD each, the gather
     // waves (128 + 32 + 24) NFG — at C = 256 3 + 1 (with two tiles in flight: 48 + 16 registers), else all of them go to the decode waves
@@ -834,7 +834,11 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
     unsigned* wbits = reinterpret_cast<unsigned*>(lut + 256);   // [2 buffers][128 rows]
     float* kbs = reinterpret_cast<float*>(wbits + 256);         // [128]
 
-    const int b = blockIdx.y, gidx = blockIdx.x, G = gridDim.x;
+    // NZ > 1 (more than 128 kernel rows): NZ workgroups with ADJACENT block indices walk the same pixel tiles at the same time, each on
+    // its own chunk of NB * 32 rows — the feature map is fetched from HBM once (the second reader hits the memory-side cache) instead
+    // of once per chunk as with one launch per chunk
+    const int b = blockIdx.y, gidx = blockIdx.x / NZ, G = gridDim.x / NZ;
+    const int n0 = n0_in + (blockIdx.x - gidx * NZ) * (NB * 32);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
@@ -1065,7 +1069,7 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
             if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0)
                 for (int k = 0; k < 8; ++k) g_fs_prof[wave][k] = prof[k];
 #endif
-        if (has_dec && lane < 32) cntp[((size_t)b * G + gidx) * NPT + n0 + wave * 32 + lane] = (float)cnt_i;
+        if (has_dec && lane < 32 && n0 + wave * 32 + lane < NPT) cntp[((size_t)b * G + gidx) * NPT + n0 + wave * 32 + lane] = (float)cnt_i;
     } else {
         // =============================================================== gather role: channel blocks wave - 4 (+ 4)
         const int gw = wave - 4;
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int n = n0 + nb * 32 + vkn_cd_row(r, lane);
-                        pp[(size_t)n * C + cb * 32 + li] = accg[j][nb][r];
+                        if (n < NPT) pp[(size_t)n * C + cb * 32 + li] = accg[j][nb][r];
                     }
             }
         }
@@ -1577,9 +1581,17 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
 #else
     const size_t lds = fuseds_lds_bytes(C);
 #endif
-    for (int n0 = 0; n0 < NPT; n0 += 128) {
-        const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
-        dim3 grid(G, B, 1);
+#ifdef VKN_DEBUG
+    const bool one_pass = (variant == 10 || variant == 11) && !vkn_dbg_env("VKN_FUSED_CHUNK_LOOP", 0);
+#else
+    const bool one_pass = true;
+#endif
+    // more than 128 rows: NZ equal chunks handled by NZ adjacent workgroups of ONE launch (k_fused_il), see the kernel
+    const int NZ = one_pass ? (NPT + 127) / 128 : 1;
+    const int nb_one = (NPT / 32 + NZ - 1) / NZ;
+    for (int n0 = 0; n0 < (one_pass ? 1 : NPT); n0 += 128) {
+        const int nb = one_pass ? nb_one : ((NPT - n0 >= 128) ? 4 : (NPT - n0) / 32);
+        dim3 grid(G * NZ, B, 1);
 #define FU_LAUNCH_XV(NBV, CV, XHV, VV)                                                                                         \
     do {                                                                                                                       \
         VKN_ALLOW_FULL_LDS((k_fused_dgs<NBV, CV, XHV, VV>));                                                                   \
@@ -1596,7 +1608,7 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
     do {                                                                                                                       \
         VKN_ALLOW_FULL_LDS((k_fused_il<NBV, CV, XHV, PFV>));                                                                   \
         hipLaunchKernelGGL((k_fused_il<NBV, CV, XHV, PFV>), grid, dim3(FS_THREADS), lds, stream, x, kfh, kfl, kb, thr, part,   \
-                           cntp, N, NPT, n0, P);                                                                               \
+                           cntp, N, NPT, n0, P, NZ);                                                                           \
     } while (0)
 #define FU_LAUNCH_PP(NBV, CV, XHV, PFV)                                                                                        \
     do {                                                                                                                       \
