@@ -386,6 +386,22 @@ int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, cons
                          void* stream);
 /*      cost: HOST fp32 [nr][nc]; writes min(nr, nc) (row, col) pairs sorted by row; returns their number or a negative code */
 int vkn_lsap_f32(const float* cost, int nr, int nc, int* row_ind, int* col_ind);
+/*      The same algorithm ON THE DEVICE, one wavefront per problem, a batch of problems (the images of a training batch) per launch:
+ *      the assignment then needs no device -> host copy at all.  cost: DEVICE fp32 [nr][nc] row-major (nr = predictions, nc = ground
+ *      truths; nr, nc <= 256); outputs (DEVICE, each may be NULL): gt_inds int64 [nr] = matched col + 1 or 0 — the reference's
+ *      `assigned_gt_inds` (:262-271) — and the min(nr, nc) (row, col) pairs sorted by row, exactly scipy's return value.
+ *      status (DEVICE int [nprob], may be NULL): 0 ok, 1 the matrix holds NaN / -inf, 2 infeasible (gt_inds = -1 then).
+ *      Results are identical to vkn_lsap_f32 / scipy including tied matrices (same scan order and tie rule, fp64). */
+#define VKN_LSAP_MAX_BATCH 64
+typedef struct VknLsapProblem {
+    const float* cost;
+    int nr, nc;
+    long long* gt_inds;
+    int* row_ind;
+    int* col_ind;
+} VknLsapProblem;
+size_t vkn_sizeof_lsap_problem(void);
+int vkn_lsap_batch_f32(const VknLsapProblem* probs, int nprob, int* status, void* stream);
 
 /* ---- quasi-dense embedding association (the `tracker=dict(type='QuasiDenseEmbedTracker', ...)` of the video configs).  Replaces
  *      `QuasiDenseEmbedTracker.match(bboxes, labels, track_feats, frame_id) -> (bboxes, labels, ids)` together with the `update_memo`

@@ -857,6 +857,70 @@ def test_assignment_full_resolution(vkn):
     assert np.array_equal(res.gt_inds.cpu().numpy(), inds)
 
 
+def test_device_lsap_equals_host_solver_and_scipy(vkn):
+    """`vkn_lsap_batch_f32` (one wavefront per matrix, batches of 64 per launch) against the host solver `vkn_lsap_f32` and scipy on 300
+    matrices: wide, tall (transposed inside), square, 1 x n, continuous costs, and small-integer costs whose optimum is massively tied
+    — the tie rule and scan order decide there, and the results must still be IDENTICAL (integer assignments: bit-exact)."""
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(5)
+    mats = []
+    for k in range(300):
+        nr, nc = int(rng.integers(1, 129)), int(rng.integers(1, 257))
+        if k % 7 == 0:
+            nr = nc = int(rng.integers(1, 129))
+        if k % 11 == 0:
+            nr = 1
+        if k % 3 == 0:
+            m = rng.integers(0, 4, (nr, nc)).astype(np.float32)                  # ties everywhere
+        elif k % 3 == 1:
+            m = rng.standard_normal((nr, nc)).astype(np.float32)
+        else:
+            m = (rng.standard_normal((nr, nc)) * 3).round(1).astype(np.float32)   # some ties
+        mats.append(m)
+    gts, rows, cols, status = vkn.ops.lsap_device([torch.from_numpy(m).to(DEV) for m in mats])
+    assert status.cpu().tolist() == [0] * len(mats)
+    for m, g, r, c in zip(mats, gts, rows, cols):
+        hr, hc = vkn.ops.lsap(m)
+        sr, sc = linear_sum_assignment(m)
+        assert np.array_equal(hr, sr) and np.array_equal(hc, sc)
+        assert np.array_equal(r.cpu().numpy(), sr) and np.array_equal(c.cpu().numpy(), sc), m.shape
+        want = np.zeros(m.shape[0], dtype=np.int64)
+        want[sr] = sc + 1
+        assert np.array_equal(g.cpu().numpy(), want)
+    # status words instead of exceptions: NaN / -inf entries (scipy: ValueError), infeasible (all +inf)
+    bad = np.ones((3, 5), np.float32)
+    bad[1, 2] = np.nan
+    inf = np.full((4, 6), np.inf, np.float32)
+    ok = np.arange(12, dtype=np.float32).reshape(3, 4)
+    g, _, _, st = vkn.ops.lsap_device([torch.from_numpy(a).to(DEV) for a in (bad, inf, ok)])
+    assert st.cpu().tolist() == [1, 2, 0] and g[0].cpu().tolist() == [-1] * 3 and g[1].cpu().tolist() == [-1] * 4
+    a = vkn.MaskHungarianAssigner(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                  mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    a.pending_status.append(st)
+    with pytest.raises(ValueError):
+        a.check_status()
+    a.check_status()   # (drained)
+
+
+def test_device_and_host_assignment_paths_agree(vkn):
+    """The assigner with the device LSAP (default) and with the host LSAP: same AssignResult, and the sampler's index sets built from
+    the device tensors equal the ones built from the host copy."""
+    N, G, ncls, H, W = 100, 23, 4, 32, 64
+    lo, cl, gt, lab = (torch.from_numpy(a).to(DEV) for a in synth.assign_inputs(N, G, ncls, H, W, 4))
+    kw = dict(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+              mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    ad, ah = vkn.MaskHungarianAssigner(**kw), vkn.MaskHungarianAssigner(**kw)
+    ah.lsap = 'host'
+    rd, rh = ad.assign(lo, cl, gt, lab), ah.assign(lo, cl, gt, lab)
+    assert rd.device_pos_inds is not None and rd.host_pos_inds is None and rh.host_pos_inds is not None
+    assert torch.equal(rd.gt_inds, rh.gt_inds) and torch.equal(rd.labels, rh.labels)
+    sam = vkn.MaskPseudoSampler()
+    sd, sh = sam.sample(rd, lo, gt), sam.sample(rh, lo, gt)
+    assert torch.equal(sd.pos_inds, sh.pos_inds) and torch.equal(sd.neg_inds, sh.neg_inds)
+    assert torch.equal(sd.pos_assigned_gt_inds, sh.pos_assigned_gt_inds) and torch.equal(sd.pos_gt_labels, sh.pos_gt_labels)
+    ad.check_status()
+
+
 def test_clip_level_assigner_costs_and_layout(vkn):
     """`MaskHungarianAssignerVideo` (knet_vis): costs on the tall [Q, F*H, W] layout WITHOUT the sigmoid clamps of knet's cost classes,
     against the oracle's cost restatement in that flavour; the assignment equals scipy's on the oracle costs."""

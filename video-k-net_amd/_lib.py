@@ -26,6 +26,7 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_w
            'vkn_sizeof_panoptic_cfg', 'vkn_panoptic_workspace_bytes', 'vkn_panoptic_joint_f32',
            'vkn_merge_workspace_bytes', 'vkn_panoptic_thing_first_u8',
            'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_lsap_f32',
+           'vkn_sizeof_lsap_problem', 'vkn_lsap_batch_f32',
            'vkn_sizeof_tracker_cfg', 'vkn_qd_tracker_state_bytes', 'vkn_qd_tracker_workspace_bytes', 'vkn_qd_tracker_state_layout',
            'vkn_qd_tracker_reset', 'vkn_qd_tracker_match_f32')
 
@@ -43,6 +44,12 @@ class VknAssignCfg(ctypes.Structure):
     _fields_ = [('cls_weight', ctypes.c_float), ('dice_weight', ctypes.c_float), ('mask_weight', ctypes.c_float),
                 ('focal_alpha', ctypes.c_float), ('focal_gamma', ctypes.c_float), ('focal_eps', ctypes.c_float),
                 ('dice_eps', ctypes.c_float), ('dice_pred_min', ctypes.c_float), ('mask_pred_min', ctypes.c_float)]
+
+
+class VknLsapProblem(ctypes.Structure):
+    """Mirror of include/vkn.h: VknLsapProblem (device pointers as integers)."""
+    _fields_ = [('cost', ctypes.c_void_p), ('nr', ctypes.c_int), ('nc', ctypes.c_int), ('gt_inds', ctypes.c_void_p),
+                ('row_ind', ctypes.c_void_p), ('col_ind', ctypes.c_void_p)]
 
 
 class VknTrackerCfg(ctypes.Structure):
@@ -258,6 +265,12 @@ def lib():
     L.vkn_assign_workspace_bytes.argtypes = [c_int] * 3
     L.vkn_assign_costs_f32.restype = c_int
     L.vkn_assign_costs_f32.argtypes = [pA, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp, _fp, c_size, _fp]
+    L.vkn_sizeof_lsap_problem.restype = c_size
+    L.vkn_sizeof_lsap_problem.argtypes = []
+    if L.vkn_sizeof_lsap_problem() != ctypes.sizeof(VknLsapProblem):
+        raise VknLibraryError('VknLsapProblem layout mismatch between include/vkn.h and _lib.py')
+    L.vkn_lsap_batch_f32.restype = c_int
+    L.vkn_lsap_batch_f32.argtypes = [ctypes.POINTER(VknLsapProblem), c_int, _fp, _fp]
     L.vkn_lsap_f32.restype = c_int
     L.vkn_lsap_f32.argtypes = [_fp, c_int, c_int, _fp, _fp]
     pT = ctypes.POINTER(VknTrackerCfg)

@@ -137,9 +137,177 @@ size_t carve_assign(int N, int G, int P, char* base, AssignWs* w) {
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Device linear sum assignment: the SAME shortest-augmenting-path algorithm as vkn_lsap_f32 below (scipy's), one WAVEFRONT per
+// problem, all state in LDS, fp64 arithmetic — so the train-time assignment needs no device -> host copy of the cost matrix.
+// Identical results, including degenerate (tied) matrices, need the identical scan: scipy walks `remaining` (filled in reverse,
+// shrunk by swap-removal) position by position and keeps
+//      index = it   whenever  spc[j] < lowest  ||  (spc[j] == lowest && row4col[j] == -1).
+// In closed form: with m the minimum of spc over the remaining columns and T the positions that reach it, the scan ends at
+// max{it in T : column still free} if that set is non-empty, else at min T.  The 64 lanes own the positions it = lane, lane + 64, ..;
+// the order-free parts (relaxation of spc / path, minimum, the two position reductions, dual updates) run lane-parallel, the
+// order-dependent bookkeeping (swap-removal, augmentation along `path`) on lane 0.  The expression order of every fp64 sum is the
+// host function's (no multiplications: nothing to contract).
+#define LS_MAXDIM 256
+struct VknLsapBatch {
+    VknLsapProblem p[VKN_LSAP_MAX_BATCH];
+};
+
+__device__ __forceinline__ double ls_wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int ls_wave_min_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int ls_wave_max_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+#define LS_SYNC()                                  \
+    do {                                           \
+        __builtin_amdgcn_s_waitcnt(0xc07f);        \
+        __builtin_amdgcn_wave_barrier();           \
+    } while (0)
+
+__global__ __launch_bounds__(64) void k_lsap(VknLsapBatch batch, int* __restrict__ status) {
+    __shared__ double u[LS_MAXDIM], v[LS_MAXDIM], spc[LS_MAXDIM];
+    __shared__ int path[LS_MAXDIM], col4row[LS_MAXDIM], row4col[LS_MAXDIM], remaining[LS_MAXDIM];
+    __shared__ unsigned char SR[LS_MAXDIM], SC[LS_MAXDIM];
+    const VknLsapProblem pb = batch.p[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int nr = pb.nr, nc = pb.nc;
+    const bool transpose = nc < nr;
+    const int R = transpose ? nc : nr, Cn = transpose ? nr : nc;  // R <= Cn
+    const float* __restrict__ cost = pb.cost;
+    const double INF = __builtin_huge_val();
+    // element (i, j) of the R x Cn problem
+    auto c = [&](int i, int j) -> double { return (double)(transpose ? cost[(size_t)j * nc + i] : cost[(size_t)i * nc + j]); };
+    int bad = 0;
+    for (int e = lane; e < nr * nc; e += 64) {
+        const double x = (double)cost[e];
+        if (x != x || x == -INF) bad = 1;  // scipy: "matrix contains invalid numeric entries"
+    }
+    bad = ls_wave_max_i(bad);
+    for (int j = lane; j < Cn; j += 64) { v[j] = 0.0; path[j] = -1; row4col[j] = -1; }
+    for (int i = lane; i < R; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+    LS_SYNC();
+    int st = bad ? 1 : 0;
+    for (int cur = 0; cur < R && st == 0; ++cur) {
+        double minVal = 0.0;
+        int num_remaining = Cn;
+        for (int j = lane; j < Cn; j += 64) { remaining[j] = Cn - j - 1; SC[j] = 0; spc[j] = INF; }
+        for (int i = lane; i < R; i += 64) SR[i] = 0;
+        LS_SYNC();
+        int sink = -1, i = cur;
+        while (sink == -1) {
+            if (lane == 0) SR[i] = 1;
+            const double ui = u[i];
+            double sv[LS_MAXDIM / 64];
+            int jv[LS_MAXDIM / 64];
+            double lmin = INF;
+#pragma unroll
+            for (int t = 0; t < LS_MAXDIM / 64; ++t) {
+                const int it = lane + 64 * t;
+                sv[t] = INF;
+                jv[t] = -1;
+                if (it < num_remaining) {
+                    const int j = remaining[it];
+                    const double r = minVal + c(i, j) - ui - v[j];
+                    double sj = spc[j];
+                    if (r < sj) { path[j] = i; spc[j] = r; sj = r; }
+                    sv[t] = sj;
+                    jv[t] = j;
+                    lmin = fmin(lmin, sj);
+                }
+            }
+            const double lowest = ls_wave_min(lmin);
+            if (lowest == INF) { st = 2; break; }  // infeasible
+            int first = 0x7fffffff, lastfree = -1;
+#pragma unroll
+            for (int t = 0; t < LS_MAXDIM / 64; ++t) {
+                const int it = lane + 64 * t;
+                if (jv[t] >= 0 && sv[t] == lowest) {
+                    first = min(first, it);
+                    if (row4col[jv[t]] == -1) lastfree = max(lastfree, it);
+                }
+            }
+            first = ls_wave_min_i(first);
+            lastfree = ls_wave_max_i(lastfree);
+            const int index = lastfree >= 0 ? lastfree : first;
+            minVal = lowest;
+            const int j = remaining[index];
+            const int owner = row4col[j];
+            if (owner == -1) sink = j;
+            else i = owner;
+            LS_SYNC();   // every lane has read remaining[index] / row4col[j] before lane 0 rewrites the list
+            --num_remaining;
+            if (lane == 0) {
+                SC[j] = 1;
+                remaining[index] = remaining[num_remaining];
+            }
+            LS_SYNC();
+        }
+        if (st != 0) break;
+        // dual updates (host function: u[cur] += minVal; u[r] += minVal - spc[col4row[r]]; v[j] -= minVal - spc[j])
+        for (int r2 = lane; r2 < R; r2 += 64) {
+            if (r2 == cur) u[r2] += minVal;
+            else if (SR[r2]) u[r2] += minVal - spc[col4row[r2]];
+        }
+        for (int j = lane; j < Cn; j += 64)
+            if (SC[j]) v[j] -= minVal - spc[j];
+        LS_SYNC();
+        if (lane == 0) {  // augment along the alternating path
+            int j = sink;
+            while (true) {
+                const int r2 = path[j];
+                row4col[j] = r2;
+                const int t = col4row[r2];
+                col4row[r2] = j;
+                j = t;
+                if (r2 == cur) break;
+            }
+        }
+        LS_SYNC();
+    }
+    if (lane == 0 && status) status[blockIdx.x] = st;
+    // outputs in terms of the ORIGINAL matrix (rows = nr): gt_inds[row] = col + 1 or 0; (row_ind, col_ind) pairs sorted by row
+    if (st != 0) {
+        for (int r = lane; r < nr; r += 64)
+            if (pb.gt_inds) pb.gt_inds[r] = -1;
+        return;
+    }
+    if (!transpose) {
+        for (int r = lane; r < nr; r += 64) {
+            if (pb.gt_inds) pb.gt_inds[r] = (long long)col4row[r] + 1;
+            if (pb.row_ind) pb.row_ind[r] = r;
+            if (pb.col_ind) pb.col_ind[r] = col4row[r];
+        }
+    } else {
+        int base = 0;
+        for (int j0 = 0; j0 < Cn; j0 += 64) {
+            const int j = j0 + lane;
+            const int g = j < Cn ? row4col[j] : -1;
+            const unsigned long long m = __ballot(g != -1);
+            if (j < Cn && pb.gt_inds) pb.gt_inds[j] = (long long)g + 1;
+            if (g != -1) {
+                const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (pb.row_ind) pb.row_ind[k] = j;
+                if (pb.col_ind) pb.col_ind[k] = g;
+            }
+            base += __popcll(m);
+        }
+    }
+}
+
 extern "C" {
 
 size_t vkn_sizeof_assign_cfg(void) { return sizeof(VknAssignCfg); }
+size_t vkn_sizeof_lsap_problem(void) { return sizeof(VknLsapProblem); }
 
 size_t vkn_assign_workspace_bytes(int N, int G, int P) {
     if (N <= 0 || G <= 0 || P <= 0) return 0;
@@ -251,5 +419,25 @@ int vkn_lsap_f32(const float* cost, int nr, int nc, int* row_ind, int* col_ind) 
     }
     return n;
 }
+
+// One launch, one wavefront per problem (vkn.h).  `probs` is a HOST array; it travels as a kernel argument.
+int vkn_lsap_batch_f32(const VknLsapProblem* probs, int nprob, int* status, void* stream) {
+    if (!probs || nprob < 0) return VKN_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int b0 = 0; b0 < nprob; b0 += VKN_LSAP_MAX_BATCH) {
+        const int nb = (nprob - b0 < VKN_LSAP_MAX_BATCH) ? nprob - b0 : VKN_LSAP_MAX_BATCH;
+        VknLsapBatch batch;
+        for (int k = 0; k < nb; ++k) {
+            const VknLsapProblem& p = probs[b0 + k];
+            if (!p.cost || p.nr <= 0 || p.nc <= 0) return VKN_E_ARG;
+            if (p.nr > LS_MAXDIM || p.nc > LS_MAXDIM) return VKN_E_SHAPE;
+            batch.p[k] = p;
+        }
+        hipLaunchKernelGGL(k_lsap, dim3(nb), dim3(64), 0, st, batch, status ? status + b0 : nullptr);
+        VKN_CHECK_LAUNCH();
+    }
+    return VKN_OK;
+}
+
 
 }  // extern "C"

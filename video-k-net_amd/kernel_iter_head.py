@@ -209,6 +209,9 @@ class KernelIterHead(BaseRoIHead):
                 all_stage_loss[f's{stage}_{key}'] = value * self.stage_loss_weights[stage]
             if not self.post_assign:
                 prev_mask_preds, prev_cls_score = scaled_mask_preds.detach(), cls_score.detach()
+        for a in self.mask_assigner:       # device assignments report invalid cost matrices through status words: one read per step
+            if hasattr(a, 'check_status'):
+                a.check_status()
         return all_stage_loss, mask_results
 
     def forward_train(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, gt_bboxes_ignore=None,

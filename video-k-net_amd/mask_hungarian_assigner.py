@@ -21,6 +21,8 @@ class AssignResult:
         self.max_overlaps = max_overlaps
         self.labels = labels
         self.host_pos_inds = None   # sorted numpy array of the matched prediction indices when the assigner knows them on the host
+        self.device_pos_inds = None # the same as a device tensor (device LSAP): its length is min(N, G), no synchronisation needed
+        self.status = None
 
 
 def _cost_cfg(cfg, kind, allowed, defaults):
@@ -54,6 +56,8 @@ class MaskHungarianAssigner:
             if not c['pred_act'] or c['act_mode'] != 'sigmoid':
                 raise NotImplementedError(f'{name} needs pred_act=True, act_mode="sigmoid" (every shipped config)')
         self.topk = topk
+        self.lsap = 'device'        # 'host': copy the cost matrix to the host and run vkn_lsap_f32 there (the round-1/2 path)
+        self.pending_status = []
 
     def cost_matrix(self, bbox_pred, cls_pred, gt_bboxes, gt_labels):
         """[N, G] device tensor: cls_cost + mask_cost + dice_cost (reference :222-241)."""
@@ -76,6 +80,18 @@ class MaskHungarianAssigner:
                 gt_inds[:] = 0
             return AssignResult(num_gts, gt_inds, None, labels=labels)
         cost = self.cost_matrix(bbox_pred, cls_pred, gt_bboxes, gt_labels)
+        if self.lsap == 'device' and num_gts <= 256 and num_bboxes <= 256:
+            # the whole assignment stays on the device and on the stream: no copy, no synchronisation (vkn_lsap_batch_f32)
+            gts, rows, cols, status = ops.lsap_device([cost])
+            rows, cols = rows[0].long(), cols[0].long()
+            gt_inds = gts[0]
+            labels[rows] = gt_labels.to(device=labels.device, dtype=labels.dtype)[cols]
+            res = AssignResult(num_gts, gt_inds, None, labels=labels)
+            res.device_pos_inds = rows                        # sorted; their number min(N, G) is known without asking the device
+            res.status = status
+            self.pending_status.append(status)
+            del self.pending_status[:-64]
+            return res
         rows, cols = ops.lsap(cost)                       # one D2H copy of [N, G] floats, C++ solver on the host
         rows_host = rows
         rows = torch.from_numpy(rows).to(bbox_pred.device)
@@ -86,6 +102,15 @@ class MaskHungarianAssigner:
         res = AssignResult(num_gts, gt_inds, None, labels=labels)
         res.host_pos_inds = np.sort(np.asarray(rows_host, dtype=np.int64))   # the LSAP ran on the host: the sampler needs no device nonzero
         return res
+
+    def check_status(self):
+        """Read the status words of the device assignments issued since the last call (ONE synchronisation): raises like the host
+        solver does for NaN / -inf entries or an infeasible matrix.  Call it once per step, not per image."""
+        pend, self.pending_status = self.pending_status, []
+        if pend:
+            bad = torch.cat(pend).nonzero()
+            if bad.numel():
+                raise ValueError('linear sum assignment: the cost matrix holds invalid entries or is infeasible')
 
 
 class MaskHungarianAssignerVideo(MaskHungarianAssigner):

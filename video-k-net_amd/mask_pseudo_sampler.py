@@ -41,7 +41,14 @@ class MaskPseudoSampler:
 
     def sample(self, assign_result, masks, gt_masks, **kwargs):
         host_pos = getattr(assign_result, 'host_pos_inds', None)
-        if host_pos is not None:
+        dev_pos = getattr(assign_result, 'device_pos_inds', None)
+        if dev_pos is not None:
+            # device assignment: the matched predictions are already a sorted device tensor of KNOWN length min(N, G); the unmatched
+            # ones are the first N - K entries of a stable sort on "is matched" — fixed shapes, no nonzero(), no synchronisation
+            n = assign_result.gt_inds.shape[0]
+            pos_inds = dev_pos
+            neg_inds = torch.sort((assign_result.gt_inds > 0).to(torch.uint8), stable=True)[1][:n - dev_pos.shape[0]]
+        elif host_pos is not None:
             # same index sets as the reference's `nonzero(gt_inds > 0 / == 0).unique()` (:197-200), built from the host copy of
             # the assignment: four device -> host synchronisations fewer per image and stage
             import numpy as np

@@ -668,6 +668,36 @@ def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, d
     return cost
 
 
+def lsap_device(costs):
+    """`scipy.optimize.linear_sum_assignment` for a batch of DEVICE cost matrices [nr_b, nc_b] (fp32) without leaving the device:
+    one launch, one wavefront per matrix (include/vkn.h: vkn_lsap_batch_f32).  -> (gt_inds, row_ind, col_ind, status):
+    per matrix gt_inds int64 [nr] (matched column + 1, 0 = unmatched: the reference's `assigned_gt_inds`), the min(nr, nc) matched
+    (row, col) pairs sorted by row (int32), and ONE int32 status tensor [batch] (0 ok, 1 invalid entries, 2 infeasible) that
+    the caller may read whenever it wants to pay for the synchronisation."""
+    if not costs:
+        return [], [], [], None
+    dev = costs[0].device
+    probs = (_lib.VknLsapProblem * len(costs))()
+    gts, rows, cols, keep = [], [], [], []
+    for b, c in enumerate(costs):
+        c = _req(c, 'cost')
+        if c.dim() != 2 or c.shape[0] == 0 or c.shape[1] == 0:
+            raise ValueError(f'cost {b}: expected a non-empty 2-D matrix, got {tuple(c.shape)}')
+        nr, nc = c.shape
+        k = min(nr, nc)
+        g = torch.empty(nr, dtype=torch.int64, device=dev)
+        r = torch.empty(k, dtype=torch.int32, device=dev)
+        cc = torch.empty(k, dtype=torch.int32, device=dev)
+        probs[b] = _lib.VknLsapProblem(c.data_ptr(), nr, nc, g.data_ptr(), r.data_ptr(), cc.data_ptr())
+        gts.append(g); rows.append(r); cols.append(cc); keep.append(c)
+    status = torch.empty(len(costs), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().vkn_lsap_batch_f32(probs, len(costs), status.data_ptr(), _stream()))
+    for c in keep:                       # the launch is asynchronous: the matrices must outlive it on this stream
+        c.record_stream(torch.cuda.current_stream(dev))
+    return gts, rows, cols, status
+
+
 def lsap(cost):
     """`scipy.optimize.linear_sum_assignment(cost)` on a host fp32 matrix through libvkn's C++ solver -> (row_ind, col_ind)
     int64 numpy arrays (knet/det/mask_hungarian_assigner.py:244-251)."""
