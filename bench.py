@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 CFG2 = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-PMC_SIDECAR = 'profiles/r02_pmc.json'   # HBM counters of this same command (tools/gpu_profile.sh); `roofline.traffic` is read from it
+PMC_SIDECAR = 'profiles/r03_pmc.json'   # HBM counters of this same command (tools/gpu_profile.sh); `roofline.traffic` is read from it
 
 
 def build_head(vkn, device, seed=0):
@@ -400,7 +400,7 @@ def main():
                                      isolated_loop_launch_ms=round(dec_iso_ms, 4),
                                      isolated_loop_frac=round(B * P * (C * xeb + N * 4) / (dec_iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      frames_per_launch=Bl)
-            # the fused decode(s) -> gather(s+1) pass alone (k_fused_dgs + reduce): it reads x once; reported both against the
+            # the fused decode(s) -> gather(s+1) pass alone (k_fused_il + reduce): it reads x once; reported both against the
             # bytes it actually moves and against the algorithmic bytes of the two ops it replaces (decode: x + logits written,
             # gather: x + logits read — SURVEY.md §8(d)); co-bound by the matrix pipe, see DESIGN.md
             for _ in range(5):
@@ -546,8 +546,17 @@ def main():
                                         decode_algorithmic_bytes=algh)
                     del xh, o_
             per_call['x_storage_variants'] = variants
+            fused_traffic = None
+            try:   # counter traffic of the fused kernel from the same sidecar as roofline.traffic (x once + partials written)
+                side = json.load(open(os.path.join(ROOT, PMC_SIDECAR)))
+                if Bl == side.get('_frames_per_launch') and xeb == 4:
+                    fused_traffic = side['k_fused_il']['hbm_bytes_per_launch']
+            except Exception:  # noqa: BLE001
+                pass
             extra['breakdown'] = dict(**per_call, fused_decode_gather_ms=round(fu_ms, 4),
                                       fused_x_GBps=round(B * P * C * xeb / (fu_ms * 1e-3) / 1e9, 1),
+                                      fused_frac_of_hbm_peak=(round(fused_traffic / (fu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                              if fused_traffic else None),   # counter bytes / isolated-loop time
                                       fused_replaces_algorithmic_GBps=round(2 * alg / (fu_ms * 1e-3) / 1e9, 1),
                                       decode_ms=round(dec_ms, 4), gather_plus_reduce_ms=round(ga_ms, 4),
                                       kernel_init_pass0_ms=round(init_ms, 4), panoptic_joint_1024x2048_ms=round(pan_ms, 4),

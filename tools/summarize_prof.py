@@ -29,9 +29,17 @@ def short(n):
             import re
             m = re.search(r'k_fused_dgsILi(\d+)ELi(\d+)ELi(\d+)E', n)
             return 'k_fused_dgs<x16>' if (m and m.group(3) != '0') else 'k_fused_dgs'
-        for key in ('k_split_planes', 'k_gemm_s3', 'k_fused_dgs', 'k_ffn_fused', 'k_gather_bits_w'):
+        if 'k_fused_il' in n:   # round 3: the shipped fused pass
+            import re
+            m = re.search(r'k_fused_ilILi(\d+)ELi(\d+)ELi(\d+)E', n)
+            return 'k_fused_il<x16>' if (m and m.group(3) != '0') else 'k_fused_il'
+        for key in ('k_split_planes', 'k_gemm_s3', 'k_fused_dgs', 'k_fused_il', 'k_ffn_fused', 'k_gather_bits_w', 'k_attn_long', 'k_attn', 'k_rowepi', 'k_gather_reduce', 'k_upsample_s', 'k_gather_mfma'):
             if key in n:
                 return key
+    import re
+    m = re.match(r'k_fused_il<(\d+), (\d+), (\d+)', n)      # demangled: <NB, C, XH, PF>
+    if m:
+        return 'k_fused_il<x16>' if m.group(3) != '0' else 'k_fused_il'
     return n.split('(')[0][:48]
 
 
@@ -47,7 +55,7 @@ if con:
     print('== x-streaming kernels by frames per launch (grid_y) ==')
     for n, gy, c, avg, mn, mx in con.execute(
             "select name, grid_y, count(*), avg(end - start), min(end - start), max(end - start) from kernels where name like "
-            "'%k_decode_mfma%' or name like '%k_fused_dgs%' or name like '%k_gather_mfma%' or name like '%k_upsample_s%' "
+            "'%k_decode_mfma%' or name like '%k_fused_dgs%' or name like '%k_fused_il%' or name like '%k_gather_mfma%' or name like '%k_upsample_s%' "
             "group by name, grid_y order by name, grid_y"):
         print(f'{short(n):28s} frames/launch={gy:5d} calls={c:4d} avg_us={avg / 1e3:9.2f} min_us={mn / 1e3:9.2f} max_us={mx / 1e3:9.2f}')
     print()
@@ -134,12 +142,14 @@ for tag, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
 if len(sys.argv) > 2 and pmc:
     import json
     side = {}
-    for k in ('k_decode_mfma', 'k_decode_mfma<x16>', 'k_fused_dgs', 'k_fused_dgs<x16>', 'k_gather_mfma<4>', 'k_upsample'):
+    for k in ('k_decode_mfma', 'k_decode_mfma<x16>', 'k_fused_il', 'k_fused_il<x16>', 'k_fused_dgs', 'k_fused_dgs<x16>', 'k_gather_mfma', 'k_gather_mfma<4>', 'k_upsample_s', 'k_upsample'):
         if k in pmc and 'FETCH_SIZE_KB' in pmc[k] and 'WRITE_SIZE_KB' in pmc[k]:
             side[k] = dict(fetch_size_kb=pmc[k]['FETCH_SIZE_KB'], write_size_kb=pmc[k]['WRITE_SIZE_KB'],
                            hbm_bytes_per_launch=int((2 * pmc[k]['FETCH_SIZE_KB'] + pmc[k]['WRITE_SIZE_KB']) * 1024))
             if k in mfma_util:  # SQ_VALU_MFMA_BUSY_CYCLES / (32 SIMDs x GRBM_GUI_ACTIVE), all launches of the kernel
                 side[k]['mfma_util'] = round(mfma_util[k], 4)
+    # matrix-pipe utilisation of every kernel of the step ('MFMA-util per kernel in profiles/r03_pmc.json')
+    side['_mfma_util_per_kernel'] = {k: round(v, 4) for k, v in sorted(mfma_util.items(), key=lambda kv: -kv[1]) if v > 0.0005}
     try:  # frames per launch of the profiled run, from the bench line rocprofv3 passed through
         import re
         log = open(os.path.join(out, 'bench_trace.log')).read()
