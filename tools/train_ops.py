@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Which torch ops the training bench step issues, by count and host time (steady state): torch.profiler over 5 steps after warm-up.
+usage (GPU box): python tools/train_ops.py [top]"""
+import os, sys, argparse
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+import vkn_import
+from importlib import import_module
+vkn = vkn_import.load()
+vkn_dist = import_module('video_k_net_amd.dist')
+device = torch.device('cuda', 0)
+src = open(os.path.join(ROOT, 'bench.py')).read()
+args = argparse.Namespace(frames=32, warmup=3, steps=10)
+body = src[src.index('def train_main('):src.index('    def step():', src.index('def train_main('))]
+ns = dict(bench.__dict__)
+exec(body + '    return locals()\n', ns)
+L = ns['train_main'](args, vkn, vkn_dist, device, 1, 0)
+head, reducer, opt, x, pf, mp, metas = L['head'], L['reducer'], L['opt'], L['x'], L['pf'], L['mp'], L['metas']
+gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, prev = L['gt_masks'], L['gt_labels'], L['gt_sem_seg'], L['gt_sem_cls'], L['prev']
+
+
+def step():
+    reducer.zero_grad(); x.grad = None
+    out = head.forward_train_with_previous(x, pf, mp, None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls,
+                                           previous_obj_feats=prev)
+    loss = sum(v for k, v in out[0].items() if 'loss' in k) + 1e-3 * (out[5] ** 2).mean()
+    loss.backward()
+    reducer.finalize(); opt.step()
+
+
+for _ in range(8):
+    step()
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+top = int(sys.argv[1]) if len(sys.argv) > 1 else 45
+print(prof.key_averages().table(sort_by=os.environ.get('SORT', 'self_cpu_time_total'), row_limit=top, max_name_column_width=60))
+ev = prof.key_averages()
+print('total op calls per step:', sum(e.count for e in ev) / 5)
+print('kernel launches per step (hipLaunchKernel + ExtLaunch):', sum(e.count for e in ev if 'aunch' in e.key) / 5)
+print('\nsynchronising ops per step:')
+for e in ev:
+    if any(k in e.key for k in ('item', '_local_scalar_dense', 'nonzero', 'is_nonzero', 'hipMemcpy', 'hipStreamSynchronize', 'hipDeviceSynchronize', 'hipEventSynchronize', '_to_copy', 'aten::to')):
+        print(f'  {e.key:40s} {e.count / 5:8.1f} calls  {e.self_cpu_time_total / 5 / 1e3:8.3f} ms self cpu')
+if os.environ.get('STACKS'):
+    with profile(activities=[ProfilerActivity.CPU], with_stack=True) as p2:
+        step()
+        torch.cuda.synchronize()
+    for e in p2.events():
+        if e.name in ('aten::_local_scalar_dense', 'aten::nonzero') or 'hipMemcpyWithStream' in e.name:
+            st = [s for s in (e.stack or []) if 'video-k-net_amd' in s or 'bench' in s or 'train_ops' in s][:3]
+            print(e.name, '<-', ' | '.join(st))

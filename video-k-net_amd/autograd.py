@@ -10,6 +10,8 @@ hi/lo split's range first (exact in fp32) and the result is scaled back.  Dynami
 max|g| at ~2^10; an element more than ~2^34 below the tensor's maximum falls under the smallest f16 subnormal of the low half
 (2^-24) and contributes zero — irrelevant for loss gradients (their spread inside one tensor is far smaller) but it is a limit.
 """
+import math
+
 import torch
 
 from . import ops
@@ -19,7 +21,7 @@ def _pow2_scale(t, target=1024.0):
     """Power of two s (device scalar tensor) with max|t| * s in [target / 2, target]; 1 for an all-zero tensor."""
     m = t.detach().abs().amax()
     e = torch.floor(torch.log2(torch.clamp(m, min=1e-30)))
-    s = torch.exp2(torch.clamp(torch.floor(torch.log2(torch.tensor(target, device=t.device))) - e, -100.0, 100.0))
+    s = torch.exp2(torch.clamp(math.floor(math.log2(target)) - e, -100.0, 100.0))   # (no host tensor: a tiny H2D copy is a stream sync)
     return torch.where(m > 0, s, torch.ones_like(s))
 
 

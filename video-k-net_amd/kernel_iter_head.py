@@ -181,6 +181,9 @@ class KernelIterHead(BaseRoIHead):
             gt_masks = [g.bool().float() for g in gt_masks]
         object_feats = proposal_feats
         all_stage_loss, assign_results, mask_results = {}, [], None
+        if self.mask_assigner and hasattr(self.mask_assigner[0], 'validate_labels'):
+            # the labels do not change between stages: one range check (one host read) for the whole step
+            self.mask_assigner[0].validate_labels(gt_labels, self.num_thing_classes)
         for stage in range(self.num_stages):
             extra = stage_kwargs(stage) if stage_kwargs is not None else {}
             mask_results = self._mask_forward(stage, x, object_feats, mask_preds, img_metas, **extra)
@@ -209,9 +212,9 @@ class KernelIterHead(BaseRoIHead):
                 all_stage_loss[f's{stage}_{key}'] = value * self.stage_loss_weights[stage]
             if not self.post_assign:
                 prev_mask_preds, prev_cls_score = scaled_mask_preds.detach(), cls_score.detach()
-        for a in self.mask_assigner:       # device assignments report invalid cost matrices through status words: one read per step
-            if hasattr(a, 'check_status'):
-                a.check_status()
+        if self.mask_assigner and hasattr(self.mask_assigner[0], 'check_status'):
+            # device assignments report invalid cost matrices through status words: ONE read per step for all stages
+            self.mask_assigner[0].check_status(*self.mask_assigner[1:])
         return all_stage_loss, mask_results
 
     def forward_train(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, gt_bboxes_ignore=None,

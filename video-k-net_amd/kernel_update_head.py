@@ -360,23 +360,30 @@ class KernelUpdateHead(nn.Module):
     # ---- training: knet/det/kernel_update_head.py:279-441
     def loss(self, object_feats, cls_score, mask_pred, labels, label_weights, mask_targets, mask_weights, imgs_whwh=None,
              reduction_override=None, **kwargs):
+        """Losses of one stage (reference :279-330).  Positives are the rows with a real class label.  When `labels` is the tensor
+        `get_targets` just built, their flat indices are already known as a device tensor of STATIC length (matched predictions +
+        present stuff rows): rows are then taken by index — no boolean-mask indexing, i.e. no `nonzero` and no device -> host
+        synchronisation anywhere in the loss.  Foreign `labels` take the boolean path (same values)."""
         losses = dict()
         bg_class_ind = self.num_classes
+        stash = getattr(self, '_targets_stash', None)
+        pos_index = stash[1] if (stash is not None and stash[0] is labels) else None
         pos_inds = (labels >= 0) & (labels < bg_class_ind)
         num_pos = pos_inds.sum().float()
         avg_factor = reduce_mean(num_pos).clamp_(min=1.0)
         num_preds = mask_pred.shape[0] * mask_pred.shape[1]
         assert cls_score is None or (mask_pred.shape[0] == cls_score.shape[0] and mask_pred.shape[1] == cls_score.shape[1])
+        take = (lambda t: t.index_select(0, pos_index)) if pos_index is not None else (lambda t: t[pos_inds])
         if cls_score is not None and cls_score.numel() > 0:
-            losses['loss_cls'] = self.loss_cls(cls_score.view(num_preds, -1), labels, label_weights, avg_factor=avg_factor,
-                                               reduction_override=reduction_override)
-            losses['pos_acc'] = accuracy(cls_score.view(num_preds, -1)[pos_inds], labels[pos_inds])
+            flat_cls = cls_score.view(num_preds, -1)
+            losses['loss_cls'] = self.loss_cls(flat_cls, labels, label_weights, avg_factor=avg_factor, reduction_override=reduction_override)
+            losses['pos_acc'] = accuracy(take(flat_cls), take(labels))
         if mask_pred is not None:
-            bool_pos_inds = pos_inds.type(torch.bool)
             H, W = mask_pred.shape[-2:]
-            if pos_inds.any():
-                pos_mask_pred = mask_pred.reshape(num_preds, H, W)[bool_pos_inds]
-                pos_mask_targets = mask_targets[bool_pos_inds]
+            any_pos = (pos_index.numel() > 0) if pos_index is not None else bool(pos_inds.any())
+            if any_pos:
+                pos_mask_pred = take(mask_pred.reshape(num_preds, H, W))
+                pos_mask_targets = take(mask_targets)
                 losses['loss_mask'] = self.loss_mask(pos_mask_pred, pos_mask_targets)
                 losses['loss_dice'] = self.loss_dice(pos_mask_pred, pos_mask_targets)
                 if self.loss_rank is not None:
@@ -434,16 +441,74 @@ class KernelUpdateHead(nn.Module):
         return labels, label_weights, mask_targets, mask_weights
 
     def get_targets(self, sampling_results, gt_mask, gt_labels, rcnn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None):
+        """(labels, label_weights, mask_targets, mask_weights) of a batch (reference :396-441).  `concat=True` (every caller in the
+        reference): built for the WHOLE batch at once by `_batch_targets`; `concat=False`: per-image lists through
+        `_get_target_single`, as the reference does."""
         n = len(sampling_results)
+        self._targets_stash = None
+        if concat and n > 0:
+            return self._batch_targets(sampling_results, rcnn_train_cfg, gt_sem_seg, gt_sem_cls)
         if gt_sem_seg is None:
             gt_sem_seg, gt_sem_cls = [None] * n, [None] * n      # (the reference hard-codes 2 here, :417-418: batch of 2 only)
         out = [self._get_target_single(r.pos_inds, r.neg_inds, r.pos_masks, r.neg_masks, r.pos_gt_masks, r.pos_gt_labels,
                                        gt_sem_seg[i], gt_sem_cls[i], rcnn_train_cfg) for i, r in enumerate(sampling_results)]
         labels, label_weights, mask_targets, mask_weights = (list(t) for t in zip(*out))
-        if concat:
-            labels, label_weights = torch.cat(labels, 0), torch.cat(label_weights, 0)
-            mask_targets, mask_weights = torch.cat(mask_targets, 0), torch.cat(mask_weights, 0)
         return labels, label_weights, mask_targets, mask_weights
+
+    def _batch_targets(self, sampling_results, cfg, gt_sem_seg, gt_sem_cls):
+        """The concatenated targets of `_get_target_single` over the images of a batch, written directly in the batch layout
+        [B, N + S] (N predictions, then the S stuff rows of that image) with a handful of scatters instead of ~25 small ops per
+        image — and with the flat indices of the positive rows as a by-product (`loss` takes rows by them).  Same values:
+          labels        num_classes, matched predictions <- their gt label, present stuff rows <- their class
+          label_weights matched / unmatched predictions 1 (matched: pos_weight if > 0) over the thing columns only when stuff targets
+                        exist (:388), stuff rows the identity over the stuff columns
+          mask_targets  zeros, matched <- their gt mask, present stuff rows <- gt_sem_seg;  mask_weights 1 on exactly those rows."""
+        r0 = sampling_results[0]
+        B = len(sampling_results)
+        dev, dt = r0.pos_masks.device, r0.pos_masks.dtype
+        H, W = r0.pos_masks.shape[-2:]
+        N = int(r0.pos_inds.shape[0]) + r0.num_neg
+        with_sem = gt_sem_seg is not None and gt_sem_cls is not None and all(g is not None for g in gt_sem_seg) \
+            and all(g is not None for g in gt_sem_cls)
+        S, T = (self.num_stuff_classes, self.num_thing_classes) if with_sem else (0, 0)
+        Ns, ncls = N + S, self.num_classes
+        pw = cfg['pos_weight'] if isinstance(cfg, dict) else cfg.pos_weight
+        pw = 1.0 if pw <= 0 else float(pw)
+        pos_rows, pos_lab, pos_msk, sem_rows, sem_lab, sem_msk = [], [], [], [], [], []
+        for i, r in enumerate(sampling_results):
+            if int(r.pos_inds.shape[0]) + r.num_neg != N:
+                raise ValueError('all images of a batch must carry the same number of predictions')
+            pos_rows.append(r.pos_inds + i * Ns)
+            pos_lab.append(r.pos_gt_labels)
+            pos_msk.append(r.pos_gt_masks)
+            if with_sem and gt_sem_cls[i].numel() > 0:
+                cls_i = gt_sem_cls[i].to(dev).long()
+                sem_rows.append(cls_i - T + (i * Ns + N))
+                sem_lab.append(cls_i)
+                sem_msk.append(gt_sem_seg[i])
+        pos_rows = torch.cat(pos_rows)
+        labels = torch.full((B * Ns,), ncls, dtype=torch.long, device=dev)
+        label_weights = torch.zeros((B, Ns, ncls), dtype=dt, device=dev)
+        mask_targets = torch.zeros((B * Ns, H, W), dtype=dt, device=dev)
+        row_weight = torch.zeros((B * Ns,), dtype=dt, device=dev)
+        label_weights[:, :N, :(T if with_sem else ncls)] = 1.0
+        if pos_rows.numel() > 0:
+            labels[pos_rows] = torch.cat(pos_lab)
+            mask_targets[pos_rows] = torch.cat(pos_msk).to(dt)
+            row_weight[pos_rows] = 1.0
+            if pw != 1.0:
+                label_weights.view(B * Ns, ncls)[:, :(T if with_sem else ncls)][pos_rows] = pw
+        if with_sem:
+            label_weights[:, N:, T:] = torch.eye(S, dtype=dt, device=dev)
+            if sem_rows:
+                sem_rows = torch.cat(sem_rows)
+                labels[sem_rows] = torch.cat(sem_lab)
+                mask_targets[sem_rows] = torch.cat(sem_msk).to(dt)
+                row_weight[sem_rows] = 1.0
+                pos_rows = torch.sort(torch.cat([pos_rows, sem_rows]))[0]
+        mask_weights = row_weight.view(-1, 1, 1).expand(-1, H, W)      # (a view: the reference fills a second [B*Ns, H, W] tensor)
+        self._targets_stash = (labels, pos_rows)
+        return labels, label_weights.view(B * Ns, ncls), mask_targets, mask_weights
 
 
 @register_head

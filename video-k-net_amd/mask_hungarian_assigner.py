@@ -59,10 +59,32 @@ class MaskHungarianAssigner:
         self.lsap = 'device'        # 'host': copy the cost matrix to the host and run vkn_lsap_f32 there (the round-1/2 path)
         self.pending_status = []
 
+    @staticmethod
+    def _label_key(gt_labels, ncls):
+        return (gt_labels.data_ptr(), gt_labels._version, tuple(gt_labels.shape), str(gt_labels.device), int(ncls))
+
+    @classmethod
+    def validate_labels(cls, label_tensors, ncls):
+        """Range-check the ground-truth labels of a whole batch against the `ncls` class logits with ONE device -> host read, and
+        remember them (by storage, version and class count): `assign` skips its own per-image check — one synchronisation per step
+        instead of one per image and stage.  Raises the IndexError the reference's `cls_pred[:, gt_labels]` would raise."""
+        cls._validated.clear()        # (keys name storage: they are only trusted for the step that read them)
+        todo = [t for t in label_tensors if torch.is_tensor(t) and t.numel()]
+        if not todo:
+            return
+        ext = torch.stack([torch.stack(torch.aminmax(t)).to(torch.int64) for t in todo]).tolist()    # (CPU tensors: no sync at all)
+        for t, (lo, hi) in zip(todo, ext):
+            if lo < 0 or hi >= ncls:
+                raise IndexError(f'gt_labels outside [0, {ncls}): {lo} .. {hi}')
+            cls._validated[cls._label_key(t, ncls)] = True
+
+    _validated = {}
+
     def cost_matrix(self, bbox_pred, cls_pred, gt_bboxes, gt_labels):
         """[N, G] device tensor: cls_cost + mask_cost + dice_cost (reference :222-241)."""
         use_cls = self.cls['weight'] != 0 and cls_pred is not None
-        return ops.assign_costs(bbox_pred, cls_pred if use_cls else None, gt_bboxes, gt_labels,
+        checked = use_cls and torch.is_tensor(gt_labels) and self._label_key(gt_labels, cls_pred.shape[1]) in self._validated
+        return ops.assign_costs(bbox_pred, cls_pred if use_cls else None, gt_bboxes, gt_labels, labels_checked=checked,
                                 cls_weight=self.cls['weight'] if use_cls else 0.0, dice_weight=self.dice['weight'],
                                 mask_weight=self.mask['weight'], focal_alpha=self.cls['alpha'], focal_gamma=self.cls['gamma'],
                                 focal_eps=self.cls['eps'], dice_eps=self.dice['eps'], dice_pred_min=self.pred_clamp[0],
@@ -103,14 +125,17 @@ class MaskHungarianAssigner:
         res.host_pos_inds = np.sort(np.asarray(rows_host, dtype=np.int64))   # the LSAP ran on the host: the sampler needs no device nonzero
         return res
 
-    def check_status(self):
-        """Read the status words of the device assignments issued since the last call (ONE synchronisation): raises like the host
-        solver does for NaN / -inf entries or an infeasible matrix.  Call it once per step, not per image."""
-        pend, self.pending_status = self.pending_status, []
-        if pend:
-            bad = torch.cat(pend).nonzero()
-            if bad.numel():
-                raise ValueError('linear sum assignment: the cost matrix holds invalid entries or is infeasible')
+    def check_status(self, *others):
+        """Read the status words of the device assignments issued since the last call by this assigner (and `others`: the per-stage
+        assigners of a head) with ONE synchronisation: raises like the host solver does for NaN / -inf entries or an infeasible
+        matrix.  Call it once per step, not per image."""
+        pend = []
+        for a in (self,) + tuple(others):
+            if hasattr(a, 'pending_status'):
+                pend += a.pending_status
+                a.pending_status = []
+        if pend and bool(torch.cat(pend).any()):
+            raise ValueError('linear sum assignment: the cost matrix holds invalid entries or is infeasible')
 
 
 class MaskHungarianAssignerVideo(MaskHungarianAssigner):

@@ -10,7 +10,11 @@ class MaskSamplingResult:
         self.pos_inds = pos_inds
         self.neg_inds = neg_inds
         self.pos_masks = masks[pos_inds]
-        self.neg_masks = masks[neg_inds]
+        # `neg_masks` (reference :33) is a copy of every UNMATCHED prediction — ~100 full-resolution masks per image and stage that
+        # nothing downstream reads (target building only asks for their number).  Same field, materialised on first access.
+        self._all_masks = masks
+        self._neg_masks = None
+        self.num_neg = int(neg_inds.shape[0])
         self.pos_is_gt = gt_flags[pos_inds]
         self.num_gts = gt_masks.shape[0]
         self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
@@ -22,6 +26,12 @@ class MaskSamplingResult:
         self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
         extra = getattr(assign_result, '_extra_properties', {})
         self.pos_gt_pids = extra['pids'][pos_inds] if 'pids' in extra else None
+
+    @property
+    def neg_masks(self):
+        if self._neg_masks is None:
+            self._neg_masks = self._all_masks[self.neg_inds]
+        return self._neg_masks
 
     @property
     def masks(self):

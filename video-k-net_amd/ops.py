@@ -636,7 +636,8 @@ def panoptic_thing_first(thing_masks, thing_scores, thing_labels, thing_order, s
 
 
 def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, dice_weight=4.0, mask_weight=1.0,
-                 focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3, dice_pred_min=1e-3, mask_pred_min=1e-2):
+                 focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3, dice_pred_min=1e-3, mask_pred_min=1e-2,
+                 labels_checked=False):
     """Cost matrix [N, G] of `MaskHungarianAssigner.assign` (knet/det/mask_hungarian_assigner.py:222-241) on the GPU.
     dice_pred_min / mask_pred_min: the lower clamp of sigmoid(logits) in DiceCost / MaskCost (knet: 1e-3 / 1e-2; knet_vis: none)."""
     m = _req(mask_logits.reshape(mask_logits.shape[0], -1), 'mask_preds')
@@ -648,7 +649,7 @@ def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, d
     cls = _req(cls_logits, 'cls_pred') if cls_logits is not None else None
     ncls = cls.shape[1] if cls is not None else 0
     lab = gt_labels.to(device=m.device, dtype=torch.int32).contiguous()
-    if cls is not None and lab.numel():
+    if cls is not None and lab.numel() and not labels_checked:
         # the reference's `cls_pred[:, gt_labels]` raises an IndexError for labels outside the logits (ignore label 255, stuff label
         # against thing-only logits); an unchecked device read would silently produce garbage costs.  Host labels are checked on the
         # host; device labels cost ONE combined read (the cost matrix itself goes to the host for the LSAP right after)
