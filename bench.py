@@ -136,6 +136,17 @@ def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
     head.init_weights()
     head = head.to(device).train()
     reducer = vkn_dist.BucketedGradAllReducer(head, force_collectives=dist_on)
+    if not getattr(args, 'no_tune_gemms', False):
+        # the chain's Linear layers run on the library GEMMs (rocBLAS / hipBLASLt); their default heuristic picks a 256x256 macro-tile
+        # for the 468-row problems of a 4-frame step (8 workgroups, 114 us per call: 15 % of the step's GPU time).  PyTorch's
+        # TunableOp times the libraries' solutions once per shape (during the first, untimed steps) and keeps the fastest
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(True)
+        torch.cuda.tunable.set_max_tuning_duration(10)
+        torch.cuda.tunable.set_max_tuning_iterations(10)
+        torch.cuda.tunable.set_filename(os.path.join('/tmp', 'vkn_tunableop_%d.csv' % rank))
+    if not getattr(args, 'no_chain_graphs', False):
+        head.enable_chain_graphs()                        # every stage's [B*N, C] chain, forward and backward, as captured hipGraphs
     opt = torch.optim.SGD(head.parameters(), lr=1e-4, momentum=0.9)
     x, pf, mp = synth_inputs(B, device, rank)
     x.requires_grad_(True)                                 # gradients flow on into the backbone in the real model
@@ -190,8 +201,12 @@ def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
                               ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
                               dtype='f32', data='synthetic',
                               config=dict(workload='cfg3 video_knet_s3_r50 head training: forward_train_with_previous (losses, GPU '
-                                                   'cost matrices + host LSAP), backward through the HIP gather / decode kernels, '
-                                                   'per-stage bucketed RCCL gradient all-reduce overlapped with backward, SGD step',
+                                                   'cost matrices + device LSAP), backward through the HIP gather / decode kernels, '
+                                                   'the [B*N, C] chains as ' + ('eager torch ops' if getattr(args, 'no_chain_graphs', False)
+                                                                               else 'captured hipGraphs (forward + backward)')
+                                                   + ', library GEMMs ' + ('with default heuristics' if getattr(args, 'no_tune_gemms', False)
+                                                                           else 'picked by TunableOp')
+                                                   + ', per-stage bucketed RCCL gradient all-reduce overlapped with backward, SGD step',
                                           frames_per_gpu_per_step=B, parallelism=f'frame-sharded dp{world}',
                                           head_parameters=nparam, last_loss=round(float(loss), 4)))))
     if dist_on:
@@ -215,6 +230,9 @@ def main():
     ap.add_argument('--x-storage', default='fp32', choices=['fp32', 'fp16', 'bf16'],
                     help='storage type of the feature map x (the head computes in fp32 either way; fp32 = the parity-exact headline)')
     ap.add_argument('--train', action='store_true', help='training step (cfg3) instead of the inference headline; see the docstring')
+    ap.add_argument('--no-tune-gemms', action='store_true', help='--train: keep the BLAS libraries\' default GEMM heuristics instead of TunableOp (A/B)')
+    ap.add_argument('--no-chain-graphs', action='store_true',
+                    help='--train: run the [B*N, C] chains as eager torch ops instead of captured hipGraphs (A/B)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group and take the multi-rank code path even with ONE rank (tests/test_gpu_rccl.py: '
                          'the distributed step on a 1-GPU box)')

@@ -128,6 +128,48 @@ def test_forward_train_vs_reference_golden(vkn, name):
             assert p.grad is not None and abs(float(p.grad.double().norm()) - ref) < 5e-3 * max(ref, 1e-6), (k, ref)
 
 
+@pytest.mark.parametrize('name', ['train_tiny', 'train_video_upd'])
+def test_chain_as_hipgraphs_equals_eager_chain(vkn, name):
+    """`enable_chain_graphs()`: every stage's [B*N, C] chain (forward and backward) replayed from captured hipGraphs gives the losses
+    and gradients of the eager chain — over several steps (the first captures, the later ones replay into the same static buffers),
+    with `zero_grad` between them, and still against the reference golden."""
+    g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, name)
+    metas = [dict() for _ in range(case['B'])]
+
+    def run(h, scale):
+        xd = (x * scale).to(DEV).requires_grad_(True)
+        pfd = pf.to(DEV).requires_grad_(True)
+        for p in h.parameters():
+            p.grad = None
+        if case['video']:
+            out = h.forward_train_with_previous(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                                gt_sem_cls=gt_sem_cls, previous_obj_feats=prev.to(DEV))
+            losses, total = out[0], 0.01 * (out[5] ** 2).sum()
+        else:
+            losses = h.forward_train(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+            total = 0.0
+        total = total + sum(v for k, v in losses.items() if 'loss' in k)
+        total.backward()
+        return ({k: float(v.detach()) for k, v in losses.items()}, xd.grad.clone(), pfd.grad.clone(),
+                {k: p.grad.clone() for k, p in h.named_parameters() if p.grad is not None})
+
+    eager = [run(head, sc) for sc in (1.0, 0.9, 1.0)]
+    head.enable_chain_graphs()
+    graphed = [run(head, sc) for sc in (1.0, 0.9, 1.0)]
+    assert all(len(h._chain_graphs) >= 1 for h in head.mask_head)
+    for (le, gxe, gpe, pe), (lg, gxg, gpg, pg) in zip(eager, graphed):
+        assert le.keys() == lg.keys() and pe.keys() == pg.keys()
+        for k in le:
+            assert abs(le[k] - lg[k]) <= 1e-6 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+        assert maxabs(gxe, gxg) <= 1e-6 * float(gxe.abs().max()) and maxabs(gpe, gpg) <= 1e-6 * float(gpe.abs().max())
+        for k in pe:
+            assert maxabs(pe[k], pg[k]) <= 1e-6 * max(float(pe[k].abs().max()), 1e-12), k
+    for k, ref in zip(g['loss_keys'], g['loss_vals']):           # and the graphed step is still the reference's step
+        assert abs(graphed[0][0][str(k)] - ref) < 1e-4 * max(1.0, abs(ref)), k
+    head.enable_chain_graphs(False)
+    assert all(h._chain_graphs is None for h in head.mask_head)
+
+
 def test_soft_gt_assignment_vs_reference(vkn):
     """Soft (bilinearly down-sampled) ground-truth masks: DiceCost / MaskCost use the REAL target values."""
     g = dict(np.load(f'{__import__("helpers").GOLDEN}/assign_soft.npz', allow_pickle=False))

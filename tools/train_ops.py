@@ -12,11 +12,11 @@ vkn = vkn_import.load()
 vkn_dist = import_module('video_k_net_amd.dist')
 device = torch.device('cuda', 0)
 src = open(os.path.join(ROOT, 'bench.py')).read()
-args = argparse.Namespace(frames=32, warmup=3, steps=10)
+args = argparse.Namespace(frames=32, warmup=3, steps=10, no_chain_graphs=bool(os.environ.get('NOGRAPH')), no_tune_gemms=bool(os.environ.get('NOTUNE')))
 body = src[src.index('def train_main('):src.index('    def step():', src.index('def train_main('))]
 ns = dict(bench.__dict__)
 exec(body + '    return locals()\n', ns)
-L = ns['train_main'](args, vkn, vkn_dist, device, 1, 0)
+L = ns['train_main'](args, vkn, vkn_dist, device, 1, 0)  # (chain graphs on unless NOGRAPH=1)
 head, reducer, opt, x, pf, mp, metas = L['head'], L['reducer'], L['opt'], L['x'], L['pf'], L['mp'], L['metas']
 gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, prev = L['gt_masks'], L['gt_labels'], L['gt_sem_seg'], L['gt_sem_cls'], L['prev']
 

@@ -73,6 +73,13 @@ class KernelIterHead(BaseRoIHead):
         for i in range(self.num_stages):
             self.mask_head[i].init_weights()
 
+    def enable_chain_graphs(self, on=True):
+        """Training: run every stage's [B*N, C] chain (forward and backward) as captured hipGraphs — see
+        `KernelUpdateHead.enable_chain_graphs`.  The gather / decode kernels, the assignment and the losses stay as they are."""
+        for h in self.mask_head:
+            h.enable_chain_graphs(on)
+        return self
+
     def init_mask_head(self, mask_roi_extractor, mask_head):
         self.mask_head = nn.ModuleList()
         if not isinstance(mask_head, list):

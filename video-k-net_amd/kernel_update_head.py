@@ -55,6 +55,28 @@ class _ConvParams(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 1)
 
 
+class _ChainGraphModule(nn.Module):
+    """The [B*N, C] chain of one stage (`KernelUpdateHead._chain_autograd`) as a callable for `torch.cuda.make_graphed_callables`:
+    its forward and backward become TWO hipGraph launches instead of ~150 + ~300 eager torch launches per stage.  The chain's shapes
+    are static ([B, N, C] whatever the ground truth looks like), unlike the losses behind it, so this is the part of a training
+    step that can be captured.  The head is held WITHOUT registering it as a sub-module (the head owns this object); `parameters()`
+    hands the head's parameters to the capture so that their gradients are part of the backward graph."""
+
+    def __init__(self, head, has_prev):
+        super().__init__()
+        object.__setattr__(self, 'head', head)
+        self.has_prev = has_prev
+        self.pattern = None          # which of the five outputs exist (cls_score / bias / track may be None)
+
+    def parameters(self, recurse=True):
+        return iter(list(self.head.parameters()))
+
+    def forward(self, x_feat, proposal_feat, prev=None):
+        out = self.head._chain_autograd(x_feat, proposal_feat, prev if self.has_prev else None)
+        self.pattern = tuple(o is not None for o in out)
+        return tuple(o for o in out if o is not None)
+
+
 @register_head
 class KernelUpdateHead(nn.Module):
 
@@ -143,6 +165,7 @@ class KernelUpdateHead(nn.Module):
             self.mask_fcs.append(nn.ReLU(inplace=True))
         self.fc_mask = nn.Linear(in_channels, out_channels)
         self._init_video(num_ffn_fcs=num_ffn_fcs, **video_kwargs)
+        self._chain_graphs = None      # see enable_chain_graphs()
         self._pack = None
         self._pack_sig = None
 
@@ -275,10 +298,46 @@ class KernelUpdateHead(nn.Module):
         (video-k-net_amd/autograd.py: their backward passes are the same kernels with transposed operands), the [B*N, C] chain
         runs as torch ops on this module's own parameters.
         Counterpart of knet/det/kernel_update_head.py:170-277 (video: knet/video/kernel_update_head.py:281-541)."""
+        if getattr(self, '_chain_graphs', None) is not None and x.is_cuda:
+            # capture (first use of a shape) BEFORE this step's autograd graph touches the head's parameters: a live eager graph
+            # through them at capture time takes the capture down (hipStreamEndCapture faults; measured, tools/scratch/graph_probe.py)
+            xf_rg = x.requires_grad or (self.feat_transform is not None and any(p.requires_grad for p in self.feat_transform.parameters()))
+            B, N = proposal_feat.shape[:2]
+            self._chain_graph_for(x.new_empty((B, N, self.in_channels)).requires_grad_(xf_rg), proposal_feat, previous_obj_feats)
         x_feat = self._xfeat_autograd(x, mask_preds)
-        cls_score, kern, kb, obj_feat, track = self._chain_autograd(x_feat, proposal_feat, previous_obj_feats)
+        cls_score, kern, kb, obj_feat, track = self._chain(x_feat, proposal_feat, previous_obj_feats)
         new_mask_preds = vag.mask_decode(x, kern, kb)                                                   # :247-260
         return cls_score, new_mask_preds, obj_feat, x_feat, track
+
+    # ---- hipGraph capture of the chain (training): opt-in, `enable_chain_graphs()`
+    def enable_chain_graphs(self, on=True):
+        """Run the chain's forward and backward as captured hipGraphs (`torch.cuda.make_graphed_callables`): one graph pair per
+        (shapes, requires-grad pattern, train / eval mode), captured at first use.  The values are those of the eager chain (same
+        kernels, same order).  Parameters may be UPDATED in place (optimizers do) but not REPLACED: after `load_state_dict` with
+        `assign=True`, `.to()` or re-initialisation call `enable_chain_graphs()` again (it drops the captured graphs)."""
+        self._chain_graphs = {} if on else None
+        return self
+
+    def _chain_graph_for(self, x_feat, proposal_feat, previous_obj_feats):
+        """(graphed callable, module, contiguous args) for these shapes / requires-grad flags / mode; captures at first use."""
+        import gc
+        args = [x_feat, proposal_feat] + ([previous_obj_feats] if previous_obj_feats is not None else [])
+        args = [a.contiguous() for a in args]
+        key = (self.training,) + tuple((tuple(a.shape), a.dtype, a.requires_grad) for a in args)
+        graphs = self._chain_graphs
+        if key not in graphs:
+            gc.collect()                    # dead autograd graphs held by reference cycles count as "live" for the fault above
+            mod = _ChainGraphModule(self, previous_obj_feats is not None)
+            samples = tuple(torch.randn_like(a).requires_grad_(a.requires_grad) for a in args)
+            graphs[key] = (torch.cuda.make_graphed_callables(mod, samples, allow_unused_input=True), mod)
+        return graphs[key] + (args,)
+
+    def _chain(self, x_feat, proposal_feat, previous_obj_feats=None):
+        if getattr(self, '_chain_graphs', None) is None or not x_feat.is_cuda or not torch.is_grad_enabled():
+            return self._chain_autograd(x_feat, proposal_feat, previous_obj_feats)
+        fn, mod, args = self._chain_graph_for(x_feat, proposal_feat, previous_obj_feats)
+        outs = iter(fn(*args))
+        return tuple(next(outs) if present else None for present in mod.pattern)
 
     def _link_names(self, which):
         raise NotImplementedError
