@@ -59,7 +59,7 @@ def main():
             base = None
             for v in [int(t) for t in args.variants.split(',')]:
                 # v < 100: k_fused_dgs variant bits; 100 / 101 = k_fused_pp / its profile build; 200 / 201 = k_fused_pq (shipped) / its profile build
-                os.environ['VKN_FUSED'] = {100: '3', 101: '4', 200: '5', 201: '6', 202: '7', 203: '8', 204: '9', 300: '10', 301: '11', 302: '10'}.get(v, '2')
+                os.environ['VKN_FUSED'] = {100: '3', 101: '4', 200: '5', 201: '6', 202: '7', 203: '8', 204: '9', 300: '10', 301: '11', 302: '10', 400: '12', 401: '13', 402: '14', 403: '15', 404: '16'}.get(v, '2')
                 os.environ['VKN_FUSED_CHUNK_LOOP'] = '1' if v == 302 else '0'   # 302: k_fused_il with one launch per 128-row chunk (N > 128)
                 os.environ['VKN_FUSED_V'] = str(v)
                 out = vkn.ops.decode_gather(x, hi, lo, N, kb)
@@ -71,17 +71,25 @@ def main():
                 t = timeit(lambda: vkn.ops.decode_gather(x, hi, lo, N, kb))
                 print(f'fused B={B} N={N} C={C} {H}x{W} V={v}: {t:8.1f} us  x-bytes {B * C * P * 4 / t / 1e6:6.2f} TB/s  '
                       f'bit-identical to V=first: {same0}, to decode->gather: {same_ref}', flush=True)
-            for pv in [t for t in args.variants.split(',') if t in ('15', '101', '201', '202', '203', '204', '301')]:
+            for pv in [t for t in args.variants.split(',') if t in ('15', '101', '201', '202', '203', '204', '301', '401', '402', '403', '404')]:
                 import ctypes
                 L = vkn._lib.lib()
                 buf = (ctypes.c_ulonglong * 64)()
-                os.environ['VKN_FUSED'] = {'15': '2', '101': '4', '201': '6', '202': '7', '203': '8', '204': '9', '301': '11'}[pv]
+                os.environ['VKN_FUSED'] = {'15': '2', '101': '4', '201': '6', '202': '7', '203': '8', '204': '9', '301': '11', '401': '13', '402': '14', '403': '15', '404': '16'}[pv]
                 os.environ['VKN_FUSED_V'] = '15'
                 vkn.ops.decode_gather(x, hi, lo, N, kb)
                 torch.cuda.synchronize()
                 L.vkn_dbg_fused_prof.argtypes = [ctypes.c_void_p]
                 assert L.vkn_dbg_fused_prof(buf) == 0
                 ntile = 2 * (((P >> 6) + (256 // B if B <= 256 else 1) - 1) // max(256 // B, 1))
+                if pv in ('401', '402', '403', '404'):
+                    if pv != '401':
+                        print('ABLATION (wrong results): ' + {'402': 'no loader micro-ops in phase D', '403': 'no ballots / writelanes', '404': 'no B-fragment LDS reads after k-step 1'}[pv])
+                    print(f'k_fused_w4: cycles per 64-px super-tile, workgroup (0,0), ~{ntile // 2} of them.  slots: 0 phase D (decode + ballots + loader share), 1 barrier A, 2 phase G (gather + loader share), 3 barrier B')
+                    for w in range(4):
+                        v = [buf[w * 8 + k] / max(ntile // 2, 1) for k in range(4)]
+                        print(f'  wave {w}: ' + ' '.join(f'{t:8.0f}' for t in v) + f'   sum {sum(v):8.0f}')
+                    continue
                 if pv in ('15', '301'):
                     print(f'k_fused_dgs: phase cycles per tile, workgroup (0,0), ~{ntile} tiles: [role work | wait loads | split+LDS write | issue | barrier]')
                     ns = 5
@@ -101,7 +109,7 @@ def main():
                 head = bench.build_head(vkn, dev)
                 xx, pf, mp = bench.synth_inputs(B, dev, 0)
                 for v in [int(t) for t in args.variants.split(',')]:
-                    os.environ['VKN_FUSED'] = {100: '3', 101: '4', 200: '5', 201: '6', 202: '7', 203: '8', 204: '9', 300: '10', 301: '11'}.get(v, '2')
+                    os.environ['VKN_FUSED'] = {100: '3', 101: '4', 200: '5', 201: '6', 202: '7', 203: '8', 204: '9', 300: '10', 301: '11', 400: '12', 401: '13'}.get(v, '2')
                     os.environ['VKN_FUSED_V'] = str(v)
                     with torch.no_grad():
                         t = timeit(lambda: head._head_forward(xx, pf, mp, want_scaled=False), reps=20)

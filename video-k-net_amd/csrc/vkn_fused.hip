@@ -823,6 +823,10 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
     static_assert(KS % 4 == 0 && 4 * (NFD + NFG) == KS, "C must be a multiple of 64");
     constexpr int NCB = C / 32;
     constexpr int CBW = (NCB + 3) / 4;
+    // straight-line role loops: a branch per MFMA group costs accumulator copies at its join, so conditions that hold for every wave are
+    // compile-time (all four n-blocks live / every gather wave owns CBW channel blocks), and the gather of "tile -1" in the first
+    // iteration runs on a zeroed image and zero bit words instead of being branched around
+    constexpr bool ALLDEC = (NB == 4), ALLCB = (NCB % 4) == 0;
     constexpr int LDK = C + 8;
     constexpr int PLANE = FS_TILE * LDK;
     constexpr int IMG = 2 * PLANE;
@@ -858,7 +862,10 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
     if (tid < 128) {
         const int n = n0 + tid;
         kbs[tid] = (kb && tid < NB * 32 && n < N) ? kb[(size_t)b * N + n] : 0.f;
+        wbits[128 + tid] = 0u;                                   // bit words of "tile -1"
     }
+    for (int v = tid; v < IMG / 8; v += FS_THREADS)              // image of "tile -1" (buffer 2): finite values for its 0 x x products
+        reinterpret_cast<half8*>(dimg + 2 * IMG)[v] = half8{0, 0, 0, 0, 0, 0, 0, 0};
 
     const __amdgpu_buffer_rsrc_t xrs =
         XH ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * C * P), 0,
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         if (ks + 2 < KS) ldb((ks + 2) % 3, ks + 2);
-                        if (has_dec) {
+                        if (ALLDEC || has_dec) {
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], rbh[ks % 3], acc, 0, 0, 0);
                             if (!XH) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], rbl[ks % 3], acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[ks], rbh[ks % 3], acc, 0, 0, 0);
@@ -1028,7 +1035,7 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (has_dec) {
+                if (ALLDEC || has_dec) {
                     unsigned long long m[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) m[r] = __ballot(acc[r] >= thr);  // bit 32 g' + li' : row (r) + 4 g', image row li'
@@ -1101,7 +1108,7 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
         const int toff = (4 * (tg >> 1) + (ta >> 1) + 16 * (ta & 1)) * LDK + 16 * (tg & 1) + 4 * tq;
         auto ldf = [&](int slot, int st, const _Float16* dh) {
             const int cb = gw + 4 * (st >> 1);
-            if (cb < NCB) {
+            if (ALLCB || cb < NCB) {
                 const _Float16* cp = dh + toff + (8 * (st & 1)) * LDK + cb * 32;
                 const fs_short4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(cp));
                 const fs_short4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(cp + 2 * LDK));
@@ -1113,11 +1120,11 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
                 }
             }
         };
-        auto prep = [&](int t) {   // tile t: its bit words are complete (written in phase A of iteration t, two barriers ago)
-            const _Float16* dh = dimg + (size_t)(t % 3) * IMG;
+        auto prep = [&](int img, int wb) {   // image / bit-word buffer of the tile to gather (its bit words were written two barriers ago)
+            const _Float16* dh = dimg + (size_t)img * IMG;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const unsigned wv = wbits[(t & 1) * 128 + nb * 32 + li];
+                const unsigned wv = wbits[wb * 128 + nb * 32 + li];
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps)
                     a[ps][nb] = lut[((wv >> (8 * ps + 4 * g)) & 0xFu) | (((wv >> (16 + 8 * ps + 4 * g)) & 0xFu) << 4)];
@@ -1131,7 +1138,7 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
             for (int st = 0; st < NSTEP; ++st) {
                 if (st + 2 < NSTEP) ldf((st + 2) % 3, st + 2, dh);
                 const int j = st >> 1, ps = st & 1, cb = gw + 4 * j;
-                if (cb < NCB) {
+                if (ALLCB || cb < NCB) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         accg[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ps][nb], fbh[st % 3], accg[j][nb], 0, 0, 0);
@@ -1149,18 +1156,18 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
                 const int i = i0 + u;
                 // the gather of tile i - 1 with this wave's loader units in the gaps of its MFMA stream (two units behind every group of
                 // four MFMAs), fenced against re-clustering
-                if (i >= 1) prep(i - 1);
+                prep((i + 2) % 3, (i + 1) & 1);   // tile i - 1 (i = 0: the zeroed image and bit words)
                 {
                     const _Float16* dh = dimg + (size_t)((i + 2) % 3) * IMG;   // image of tile i - 1
                     constexpr int NUNIT = 2 * NFG * 4, NCH = NSTEP * (XH ? 1 : 2);
                     int ch = 0;
 #pragma unroll
                     for (int st = 0; st < NSTEP; ++st) {
-                        if (i >= 1 && st + 2 < NSTEP) ldf((st + 2) % 3, st + 2, dh);
+                        if (st + 2 < NSTEP) ldf((st + 2) % 3, st + 2, dh);
                         const int j = st >> 1, ps = st & 1, cb = gw + 4 * j;
 #pragma unroll
                         for (int pl = 0; pl < (XH ? 1 : 2); ++pl) {
-                            if (i >= 1 && cb < NCB) {
+                            if (ALLCB || cb < NCB) {
 #pragma unroll
                                 for (int nb = 0; nb < NB; ++nb)
                                     accg[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ps][nb], pl ? fbl[st % 3] : fbh[st % 3], accg[j][nb], 0, 0, 0);
@@ -1179,7 +1186,7 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
             }
         }
         if (T >= 1) {   // the last tile (the decode waves are done)
-            prep(T - 1);
+            prep((T - 1) % 3, (T - 1) & 1);
             gather(T - 1);
         }
 #ifdef VKN_DEBUG
@@ -1202,6 +1209,10 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
         }
     }
 }
+
+#ifdef VKN_DEBUG  // k_fused_w4 (one wave per SIMD, 64-px super-tiles; measured slower): tools/experiments/fused_w4.inc
+#include "../../tools/experiments/fused_w4.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_fused_pq — ping-pong phases over 64-px PAIRS of strips (round 3, the shipped variant).  What the stamps of k_fused_pp added to
@@ -1552,6 +1563,9 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_pq(const float* __restr
 
 static size_t fusedq_lds_bytes(int C) { return (size_t)4 * 2 * FS_TILE * (C + 8) * sizeof(_Float16) + 256 * 16 + 256 * 4 + 128 * 4; }
 
+#ifdef VKN_DEBUG
+static size_t fusedw4_lds_bytes(int C) { return (size_t)4 * 2 * FS_TILE * (C + 8) * sizeof(_Float16) + 256 * 16 + 256 * 4 + 128 * 4; }
+#endif
 static size_t fuseds_lds_bytes(int C) { return (size_t)3 * 2 * FS_TILE * (C + 8) * sizeof(_Float16) + 256 * 16 + 256 * 4 + 128 * 4; }
 
 #ifdef VKN_DEBUG
@@ -1582,7 +1596,7 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
     const size_t lds = fuseds_lds_bytes(C);
 #endif
 #ifdef VKN_DEBUG
-    const bool one_pass = (variant == 10 || variant == 11) && !vkn_dbg_env("VKN_FUSED_CHUNK_LOOP", 0);
+    const bool one_pass = (variant >= 10 && variant <= 16) && !vkn_dbg_env("VKN_FUSED_CHUNK_LOOP", 0);
 #else
     const bool one_pass = true;
 #endif
@@ -1610,6 +1624,14 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
         hipLaunchKernelGGL((k_fused_il<NBV, CV, XHV, PFV>), grid, dim3(FS_THREADS), lds, stream, x, kfh, kfl, kb, thr, part,   \
                            cntp, N, NPT, n0, P, NZ);                                                                           \
     } while (0)
+#ifdef VKN_DEBUG
+#define FU_LAUNCH_W4(NBV, CV, XHV, PFV)                                                                                        \
+    do {                                                                                                                       \
+        VKN_ALLOW_FULL_LDS((k_fused_w4<NBV, CV, XHV, PFV>));                                                                   \
+        hipLaunchKernelGGL((k_fused_w4<NBV, CV, XHV, PFV>), grid, dim3(W4_THREADS), fusedw4_lds_bytes(C), stream, x, kfh, kfl,  \
+                           kb, thr, part, cntp, N, NPT, n0, P, NZ);                                                            \
+    } while (0)
+#endif
 #define FU_LAUNCH_PP(NBV, CV, XHV, PFV)                                                                                        \
     do {                                                                                                                       \
         VKN_ALLOW_FULL_LDS((k_fused_pp<NBV, CV, XHV, PFV>));                                                                   \
@@ -1628,6 +1650,11 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
         else if (variant == 9 && cfg2) FU_LAUNCH_PQ(4, 256, 0, 4);                         \
         else if (variant == 3) FU_LAUNCH_PP(NBV, CV, XHV, 0);                              \
         else if (variant == 10) FU_LAUNCH_IL(NBV, CV, XHV, 0);                             \
+        else if (variant == 12) FU_LAUNCH_W4(NBV, CV, XHV, 0);                             \
+        else if (variant == 13 && cfg2) FU_LAUNCH_W4(4, 256, 0, 1);                        \
+        else if (variant == 14 && cfg2) FU_LAUNCH_W4(4, 256, 0, 2);                        \
+        else if (variant == 15 && cfg2) FU_LAUNCH_W4(4, 256, 0, 3);                        \
+        else if (variant == 16 && cfg2) FU_LAUNCH_W4(4, 256, 0, 4);                        \
         else if (variant == 11 && cfg2) FU_LAUNCH_IL(4, 256, 0, 1);                        \
         else if (variant == 5) FU_LAUNCH_PQ(NBV, CV, XHV, 0);                              \
         else if (cfg2 && vv != FS_V_DEFAULT) {                                             \
@@ -1690,6 +1717,9 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
 #undef FU_LAUNCH_XV
 #undef FU_LAUNCH_PP
 #undef FU_LAUNCH_IL
+#ifdef VKN_DEBUG
+#undef FU_LAUNCH_W4
+#endif
 #undef FU_LAUNCH_PQ
         VKN_CHECK_LAUNCH();
     }
