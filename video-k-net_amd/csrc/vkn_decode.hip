@@ -234,6 +234,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
             const int p0_ = p_begin + (wave + DEC_WAVES * c_sl) * DEC_TILE;                                       \
             const int px_ = p0_ + 2 * li;                                                                         \
             const int vst_ = ((4 * g) * P + 2 * li) << 2;                                                         \
+            /* the 64 row offsets row * P * 4 are loop invariants the compiler would keep in 64 SGPRs (-> 230 SGPR spills as   */ \
+            /* v_writelane / v_readlane pairs in this loop); an opaque copy of P makes it recompute them per store: one s_mul   */ \
+            int Pq_ = P;                                                                                          \
+            asm volatile("" : "+s"(Pq_));                                                                         \
             if (BITS) { /* P % 64 == 0 (launcher): every tile is whole */                                        \
                 dec_emit_bits<NB>(acc, thr, bits_out + ((size_t)b * (P >> 5) + ((p0_ >> 6) << 1)) * NPT + n0, NPT, lane);   \
             } else if (ABL != 3 || acc[0][0][0] == 12345.678f) {                                                  \
@@ -255,25 +259,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
                                 v_[1] = q_ ? (unsigned)t1_ : __float_as_uint(e1_);                                \
                                 v_[2] = q_ ? __float_as_uint(o0_) : (unsigned)t0_;                                \
                                 v_[3] = q_ ? __float_as_uint(o1_) : (unsigned)t1_;                                \
-                                __builtin_amdgcn_raw_buffer_store_b128(v_, ors, vw_, (row_ * P + p0_) << 2, 0);   \
+                                __builtin_amdgcn_raw_buffer_store_b128(v_, ors, vw_, (row_ * Pq_ + p0_) << 2, 0);   \
                             }                                                                                     \
-                        } else if (n0 + nb * 32 + 32 <= N) { /* full n-block (uniform): no per-row guard */       \
+                        } else { /* no per-row guard: `ors` covers exactly the frame's N rows, so the stores of rows >= N */ \
+                                 /* (ragged last n-block) are dropped by the buffer's range check — no exec branches in the loop */ \
                             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
                                 const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                           \
                                 const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
                                 const u32x2 v_ = {__float_as_uint(a0_), __float_as_uint(a1_)};                    \
                                 if (ABL == 5)                                                                     \
-                                    __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * P + p0_) << 2, 2); \
+                                    __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * Pq_ + p0_) << 2, 2); \
                                 else                                                                              \
-                                    __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * P + p0_) << 2, 0); \
-                            }                                                                                     \
-                        } else {                                                                                  \
-                            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
-                                const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                           \
-                                const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
-                                const u32x2 v_ = {__float_as_uint(a0_), __float_as_uint(a1_)};                    \
-                                if (row_ + 4 * g < N)                                                             \
-                                    __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * P + p0_) << 2, 0); \
+                                    __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * Pq_ + p0_) << 2, 0); \
                             }                                                                                     \
                         }                                                                                         \
                     }                                                                                             \
@@ -281,7 +278,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
                     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                           \
                         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
                             const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                               \
-                            const int so_ = (row_ * P + p0_) << 2;                                                \
+                            const int so_ = (row_ * Pq_ + p0_) << 2;                                                \
                             if (row_ + 4 * g < N) {                                                               \
                                 const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
                                 if (px_ < p_end)                                                                  \
