@@ -1234,6 +1234,9 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
                     for (int i = 0; i < NTAP; ++i) pre[sb][r][i] = ip[(size_t)y * W + cx[i]];
                 }
         }
+        // (unrolled on purpose: the SUBS copies keep their 16 rows' offsets and blend weights in SGPRs at once — 498 SGPR spills as
+        //  v_writelane / v_readlane — but `#pragma unroll 1` (33 spills, 65 instead of 200 VGPRs) was measured 4 % SLOWER: 1.53-1.54 ms
+        //  against 1.48 ms per 32-frame launch; the spill code is scalar work beside a store-bound stream)
 #pragma unroll
         for (int sub = 0; sub < SUBS; ++sub) {
             const int yb = yb0 + sub * UP_ROWS;
