@@ -120,6 +120,14 @@ CASES = {
                               seed=12, plink='update_dynamic_cov', ptype='ffn'),
     'video_upd_cfg': dict(video=True, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=16, W=32, B=2,
                           seed=13, plink='update_dynamic_cov', ptype='update'),
+    # the link combinations no shipped config uses (the ctor accepts them): attention-only previous link (`link_atten`, :350-372) with the
+    # updator tracking link, and the `update_obj` tracking link (:446-476) without / with a previous link
+    'video_latt_upd_tiny': dict(video=True, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=2, nprop=12, N=15, H=8, W=16, B=3,
+                                seed=15, plink='link_atten', ptype='update'),
+    'video_updobj_tiny': dict(video=True, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=2, nprop=12, N=15, H=8, W=16, B=3,
+                              seed=16, plink=None, ptype='update_obj'),
+    'video_latt_updobj_tiny': dict(video=True, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=2, nprop=12, N=15, H=8, W=16,
+                                   B=2, seed=17, plink='link_atten', ptype='update_obj'),
     # BASELINE cfg5 as literally worded: 150 proposals + 66 stuff kernels = 216 rows (the reference's VIP-Seg config has 100 + 66)
     'video_vipseg_n216': dict(video=True, C=256, heads=8, ffn=2048, ncls=124, n_thing=58, n_stuff=66, S=3, up=4, nprop=150, N=216, H=46, W=80,
                               B=1, seed=14),
@@ -139,8 +147,8 @@ def run_case(name, p):
     out = dict(case=np.array([p['C'], p['heads'], p['ffn'], p['ncls'], p['n_thing'], p['n_stuff'], p['S'], p['up'],
                               p['nprop'], N, H, W, B, seed, int(video)], dtype=np.int64),
                keys=np.array(sorted(shapes)), shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
-    if p.get('plink') is not None:
-        out['plink'], out['ptype'] = np.array(p['plink']), np.array(p['ptype'])
+    if p.get('plink') is not None or p.get('ptype', 'ffn') != 'ffn':
+        out['plink'], out['ptype'] = np.array(p['plink'] or ''), np.array(p['ptype'])
     with torch.no_grad():
         # per-stage intermediates straight from the reference's stage modules
         obj, masks = pf, mp
@@ -159,7 +167,7 @@ def run_case(name, p):
                 obj2, masks2 = mr['object_feats'], mr['mask_preds']
             out['track'] = mr['object_feats_track'].numpy()
             assert torch.equal(masks2, m)
-            if p.get('plink') is not None:
+            if p.get('plink') is not None or p.get('ptype', 'ffn') != 'ffn':
                 # the B frames as CONSECUTIVE frames of one video, walked the way the detector does
                 # (knet/video/knet_quansi_dense_embed_fc_joint_train.py:505-525): frame 0 has no previous kernels, frame t > 0 gets
                 # frame t - 1's last-stage object_feats — with previous_link the masks of frame t depend on frame t - 1
@@ -497,8 +505,8 @@ def run_train_case(name, p):
                               W, B, seed, int(video)], dtype=np.int64),
                loss_keys=np.array(sorted(losses)), loss_vals=np.array([float(losses[k]) for k in sorted(losses)], dtype=np.float64),
                total=np.float64(float(total)), assigned=torch.stack(assigned).numpy())
-    if p.get('plink') is not None:
-        out['plink'], out['ptype'] = np.array(p['plink']), np.array(p['ptype'])
+    if p.get('plink') is not None or p.get('ptype', 'ffn') != 'ffn':
+        out['plink'], out['ptype'] = np.array(p['plink'] or ''), np.array(p['ptype'])
     big = p['C'] > 64
 
     def put(tag, t):

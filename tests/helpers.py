@@ -15,14 +15,14 @@ def load_golden(name):
     g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
     case = dict(zip(CASE_FIELDS, (int(v) for v in g['case'])))
     if 'plink' in g:   # the "update" video heads (previous_link / previous_type of the swin configs)
-        case['plink'], case['ptype'] = str(g['plink']), str(g['ptype'])
+        case['plink'], case['ptype'] = (str(g['plink']) or None), str(g['ptype'])   # ('' = no previous_link, a non-'ffn' tracking link)
     return g, case
 
 
 def cfg_of(case) -> HeadCfg:
     return HeadCfg(num_stages=case['S'], in_channels=case['C'], num_heads=case['heads'], num_classes=case['ncls'],
                    mask_upsample_stride=case['up'], feat_channels=case['C'],
-                   previous_type=case.get('ptype', 'ffn') if case['video'] else '', previous_link=case.get('plink', ''),
+                   previous_type=case.get('ptype', 'ffn') if case['video'] else '', previous_link=case.get('plink') or '',
                    extra=dict(feedforward_channels=case['ffn']))
 
 

@@ -18,7 +18,7 @@ from test_gpu_parity import _build_head, _cuda
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-CASES = ['video_upd_tiny', 'video_updffn_tiny', 'video_upd_cfg']
+CASES = ['video_upd_tiny', 'video_updffn_tiny', 'video_upd_cfg', 'video_latt_upd_tiny', 'video_updobj_tiny', 'video_latt_updobj_tiny']
 
 
 def _rand(shape, salt, std=1.0):
@@ -159,3 +159,29 @@ def test_link_block_vs_oracle(vkn, with_updator):
     pfx = f'mask_head.{case["S"] - 1}'
     ref = O.link_block(sd, pfx, '_link', with_updator, uf, cur, prev, cfg)
     assert maxabs(out, ref) < 1e-4
+
+
+@pytest.mark.parametrize('ptype', ['ffn', 'update', 'update_obj'])
+@pytest.mark.parametrize('plink', [None, 'update_dynamic_cov', 'link_atten'])
+def test_every_link_combination_clip_equals_frame_by_frame(vkn, plink, ptype):
+    """All nine (previous_link, previous_type) combinations the reference's ctor accepts — only three are shipped configs and have
+    goldens — through the in-call clip (frame-sequential last stage, batched tracking link) and frame by frame: every output
+    bit-identical.  (A soak run found the unshipped `link_atten` + `update` pair reading an x_feat the clip path had not written.)"""
+    torch.manual_seed(3)
+    for C in (64, 128):
+        head = vkn.build_head(vkn.configs.roi_head_cfg(True, C=C, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=2, nprop=20,
+                                                       mask_over=dict(previous_link=plink, previous_type=ptype)))
+        head.init_weights()
+        head = head.to(DEV).eval()
+        for T, H, W in ((2, 8, 8), (3, 16, 16), (4, 8, 16)):
+            N = 23
+            x, pf = torch.randn(T, C, H, W, device=DEV), torch.randn(T, N, C, 1, 1, device=DEV)
+            mp, first = torch.randn(T, N, H, W, device=DEV) * 3, torch.randn(1, N, C, 1, 1, device=DEV)
+            with torch.no_grad():
+                clip = head.clip_forward(x, pf, mp, first)
+                prev = first
+                for t in range(T):
+                    one = head.clip_forward(x[t:t + 1], pf[t:t + 1], mp[t:t + 1], prev)
+                    for name, u, v in zip(('obj', 'cls', 'masks', 'scaled', 'track'), one, clip):
+                        assert torch.equal(u[0], v[t]), (plink, ptype, C, T, t, name)
+                    prev = one[0][0:1]

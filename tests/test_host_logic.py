@@ -33,9 +33,11 @@ def test_reference_config_builds_and_state_dict_matches_reference(vkn, video):
     head.load_state_dict({k: torch.zeros(tuple(v.shape)) for k, v in sd.items()}, strict=True)
 
 
-@pytest.mark.parametrize('name', ['video_upd_tiny', 'video_updffn_tiny', 'video_upd_cfg'])
+@pytest.mark.parametrize('name', ['video_upd_tiny', 'video_updffn_tiny', 'video_upd_cfg', 'video_latt_upd_tiny', 'video_updobj_tiny',
+                                  'video_latt_updobj_tiny'])
 def test_update_link_configs_build_and_state_dict_matches_reference(vkn, name):
-    """previous_link='update_dynamic_cov' + previous_type='update' | 'ffn' (three shipped swin configs): same module tree / keys."""
+    """previous_link='update_dynamic_cov' + previous_type='update' | 'ffn' (three shipped swin configs) and the combinations nobody
+    ships (`link_atten`, `update_obj`): same module tree / keys."""
     g, case = load_golden(name)
     head = vkn.build_head(_cfg(True, C=case['C'], heads=case['heads'], ffn=case['ffn'], ncls=case['ncls'], n_thing=case['n_thing'],
                                n_stuff=case['n_stuff'], S=case['S'], up=case['up'], nprop=case['nprop'],
@@ -44,7 +46,8 @@ def test_update_link_configs_build_and_state_dict_matches_reference(vkn, name):
     assert sorted(sd) == list(g['keys'])
     assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == list(g['shapes'])
     last = head.mask_head[-1]
-    assert last._link_names('link')[0] == 'attention_previous_update_link'
+    if case['plink'] is not None:   # the pre-link's updator exists only for `update_dynamic_cov` (`link_atten`: attention + FFN only)
+        assert last._link_names('link')[0] == ('attention_previous_update_link' if case['plink'] == 'update_dynamic_cov' else None)
     assert (last._link_names('track')[0] is None) == (case['ptype'] == 'ffn')
 
 

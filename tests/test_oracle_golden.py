@@ -36,7 +36,8 @@ def test_oracle_matches_reference_golden(name):
         assert track is None
 
 
-@pytest.mark.parametrize('name', ['video_upd_tiny', 'video_updffn_tiny', 'video_upd_cfg'])
+@pytest.mark.parametrize('name', ['video_upd_tiny', 'video_updffn_tiny', 'video_upd_cfg', 'video_latt_upd_tiny', 'video_updobj_tiny',
+                                  'video_latt_updobj_tiny'])
 def test_oracle_update_link_heads_match_reference_golden(name):
     """previous_link='update_dynamic_cov' / previous_type='update' (knet/video/kernel_update_head.py:324-348, 417-445), incl. the
     frame-by-frame walk of a video where frame t's last stage is linked to frame t-1's final kernels."""

@@ -228,13 +228,79 @@ def t_xhalf():
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), tag
 
 
+def t_lsap():
+    """device LSAP (one wavefront per matrix) vs the host solver (== scipy): identical pairs on random / tied matrices."""
+    mats = []
+    for _ in range(48):
+        nr, nc = int(rng.integers(1, 129)), int(rng.integers(1, 257))
+        kind = int(rng.integers(0, 3))
+        m = (rng.integers(0, 5, (nr, nc)).astype(np.float32) if kind == 0 else
+             rng.standard_normal((nr, nc)).astype(np.float32) if kind == 1 else (rng.standard_normal((nr, nc)) * 2).round(1).astype(np.float32))
+        mats.append(m)
+    gts, rows, cols, st = vkn.ops.lsap_device([torch.from_numpy(m).to(dev) for m in mats])
+    assert not bool(st.any())
+    for m, g, r, c in zip(mats, gts, rows, cols):
+        hr, hc = vkn.ops.lsap(m)
+        assert np.array_equal(r.cpu().numpy(), hr) and np.array_equal(c.cpu().numpy(), hc), ('lsap', m.shape)
+        want = np.zeros(m.shape[0], dtype=np.int64)
+        want[hr] = hc + 1
+        assert np.array_equal(g.cpu().numpy(), want), ('lsap gt_inds', m.shape)
+
+
+def t_tracker():
+    """device quasi-dense tracker vs the flat-table oracle on random videos: survivors, labels, ids of every frame."""
+    from oracle.tracker_oracle import TrackerOracle, random_video
+    metric = str(rng.choice(['bisoftmax', 'softmax', 'cosine']))
+    cfg = dict(init_score_thr=0.5, obj_score_thr=0.35, match_score_thr=0.5, memo_tracklet_frames=int(rng.integers(2, 6)),
+               memo_backdrop_frames=int(rng.integers(0, 4)), memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3,
+               nms_class_iou_thr=0.7, with_cats=bool(rng.integers(0, 2)), match_metric=metric)
+    emb = int(rng.choice([32, 64, 256]))
+    trk = vkn.build_tracker(dict(cfg, type='QuasiDenseEmbedTracker', max_tracklets=1024))
+    ora = TrackerOracle(**cfg)
+    for t, (bb, lab, em) in enumerate(random_video(8, int(rng.integers(5, 100)), emb, 3, int(rng.integers(0, 1 << 30)))):
+        b, l_, ids = trk.match(torch.from_numpy(bb).to(dev), torch.from_numpy(lab).to(dev), torch.from_numpy(em).to(dev), t)
+        rb, rl, rids = ora.step(torch.from_numpy(bb), torch.from_numpy(lab), torch.from_numpy(em), t)
+        assert np.array_equal(b.cpu().numpy(), rb.numpy()) and np.array_equal(l_.cpu().numpy(), rl.numpy()), ('tracker', metric, t)
+        assert np.array_equal(ids.cpu().numpy(), rids.numpy()), ('tracker ids', metric, t)
+
+
+def t_link_heads():
+    """previous_link / previous_type video heads: one in-call clip == frame-by-frame calls, bit for bit (frame-sequential last stage)."""
+    plink = [None, 'update_dynamic_cov', 'link_atten'][int(rng.integers(0, 3))]
+    ptype = ['ffn', 'update', 'update_obj'][int(rng.integers(0, 3))]
+    C = int(rng.choice([64, 128]))
+    key = ('link', C, plink, ptype)
+    if key not in _heads:
+        cfgd = vkn.configs.roi_head_cfg(True, C=C, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=2, nprop=20,
+                                        mask_over=dict(previous_link=plink, previous_type=ptype))
+        h = vkn.build_head(cfgd)
+        h.init_weights()
+        _heads[key] = h.to(dev).eval()
+    head = _heads[key]
+    T, N = int(rng.integers(2, 5)), 23
+    H, W = int(rng.choice([8, 16])), int(rng.choice([8, 16]))
+    x, pf = torch.randn(T, C, H, W, device=dev), torch.randn(T, N, C, 1, 1, device=dev)
+    mp = torch.randn(T, N, H, W, device=dev) * 3
+    first = torch.randn(1, N, C, 1, 1, device=dev)
+    clip = head.clip_forward(x, pf, mp, first)
+    prev = first
+    for t in range(T):
+        one = head.clip_forward(x[t:t + 1], pf[t:t + 1], mp[t:t + 1], prev)
+        for u, v in zip(one, clip):
+            if torch.is_tensor(u):
+                assert torch.equal(u[0], v[t]), ('link heads', plink, ptype, t)
+        prev = one[0][0:1]
+
+
 _heads = {}
 only = sys.argv[2:]
 with torch.no_grad():
     for name, fn in (('gather / decode', t_gather_decode), ('upsample', t_upsample), ('panoptic joint', t_panoptic),
                      ('head bit vs logits hand-off', t_head_handoff), ('assignment costs', t_assign),
                      ('kernel init', t_kernel_init), ('head C=256 split vs exact GEMMs', t_head_c256),
-                     ('head fused / bits / logits / side stream', t_head_fused), ('half-storage x', t_xhalf)):
+                     ('head fused / bits / logits / side stream', t_head_fused), ('half-storage x', t_xhalf),
+                     ('device LSAP vs host solver', t_lsap), ('device tracker vs oracle', t_tracker),
+                     ('link heads clip vs frame-by-frame', t_link_heads)):
         if not only or any(o in name for o in only):
             section(name, fn)
 print('soak: OK')

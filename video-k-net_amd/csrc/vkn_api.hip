@@ -40,6 +40,7 @@ struct StageOpts {
     const VknStageWeights* link_track = nullptr;  // previous_type "update" / "update_obj" block (NULL: the stage's own "ffn" link)
     int track_src = 0;                            // update feature of link_track's updator: 1 = x_feat, 2 = the stage's obj_out
     bool skip_decode = false;                     // stop after the decode kernels (planes / kern32, kb) are written
+    bool keep_xfeat = false;                      // materialise x_feat in the workspace: a caller-side link reads it after the stage
 };
 
 // pre-split (bf16x3) copies of the Linear weights, carved from VknStageWeights.prepared in a fixed order
@@ -370,7 +371,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     const int xdt = xdt_of(flags);
     const bool skip_decode = so && so->skip_decode;
     const bool pre_link = so && so->link_pre && so->prev_pre;
-    const bool need_xfeat = (pre_link && so->link_pre->dyn_w) || (so && so->link_track && so->track_src == 1);  // (the link may run after the stage: side stream)
+    const bool need_xfeat = (pre_link && so->link_pre->dyn_w) || (so && so->link_track && so->track_src == 1) || (so && so->keep_xfeat);  // (the link may run after the stage: side stream)
     auto decode_final = [&](const float* kb) -> int {
         return final_decode(d, x, s, kb, masks_out, flags, st, prof0, prof1, up_out, up_stride, up_chunk, up_done);
     };
@@ -1209,6 +1210,7 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
             VknDims d1 = *d;
             d1.B = 1;
             so.skip_decode = true;
+            so.keep_xfeat = so.link_track && so.track_src == 1;   // ... and reads every frame's x_feat ("update") from the workspace:
             so.link_track = nullptr;  // the tracking link runs batched behind the loop (every frame's kernels are known then)
             for (int b = 0; b < B; ++b) {
                 const size_t r = (size_t)b * N;

@@ -464,8 +464,11 @@ class VideoKernelIterHead(KernelIterHead):
         (no previous kernels) runs without the link, exactly like the reference's first `simple_test_with_previous` call.
         -> (object_feats [T,N,C,1,1], cls [T,N,ncls], mask_preds, scaled_mask_preds, object_feats_track [T,N,C,1,1])"""
         last = self.mask_head[-1]
-        if getattr(last, 'previous', None) is not None and getattr(last, 'previous_link', None) is not None \
-                and first_previous_obj_feats is None:
+        in_call_only = getattr(last, 'previous', None) is not None and (
+            getattr(last, 'previous_link', None) is not None or getattr(last, 'previous_type', None) in ('update', 'update_obj'))
+        if in_call_only and first_previous_obj_feats is None:
+            # (previous_link rewrites the last stage's kernels; the "update" / "update_obj" tracking links need the stage's x_feat /
+            #  their own updator: both exist only inside the head call)
             # frame 0 has nothing to link to; frames 1.. form a clip whose first previous kernels are frame 0's
             o0, c0, m0, s0, _ = self._head_forward(x[:1], proposal_feats[:1], mask_preds[:1], want_scaled=want_scaled)
             if x.shape[0] == 1:
