@@ -292,6 +292,31 @@ def t_link_heads():
         prev = one[0][0:1]
 
 
+def t_query_merge():
+    """clip-level attention query merge (<= 256 keys: LDS-staged attention; more: k_attn_long) vs the oracle's restatement."""
+    C = int(rng.choice([64, 128, 256]))
+    B, N, Fr = int(rng.integers(1, 4)), int(rng.integers(4, 120)), int(rng.integers(1, 7))
+    with_pos = bool(rng.integers(0, 2))
+    key = ('qm', C)
+    if key not in _heads:
+        shapes = {'query_merge_attn.attn.in_proj_weight': (3 * C, C), 'query_merge_attn.attn.in_proj_bias': (3 * C,),
+                  'query_merge_attn.attn.out_proj.weight': (C, C), 'query_merge_attn.attn.out_proj.bias': (C,),
+                  'query_merge_norm.weight': (C,), 'query_merge_norm.bias': (C,),
+                  'query_merge_ffn.layers.0.0.weight': (8 * C, C), 'query_merge_ffn.layers.0.0.bias': (8 * C,),
+                  'query_merge_ffn.layers.1.weight': (C, 8 * C), 'query_merge_ffn.layers.1.bias': (C,),
+                  'query_merge_ffn_norm.weight': (C,), 'query_merge_ffn_norm.bias': (C,)}
+        sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, 5 + C).items()}
+        named = {k: v.to(dev) for k, v in sd.items()}
+        _heads[key] = (sd, vkn.ops.link_pack(named, torch.device(dev), None, 'query_merge_attn', 'query_merge_norm', 'query_merge_ffn',
+                                             'query_merge_ffn_norm'), named)
+    sd, pack, _ = _heads[key]
+    q, k = torch.randn(B, N, C), torch.randn(B, Fr * N, C)
+    pos = torch.randn(N, C) if with_pos else None
+    ref = O.query_merge(sd, '', q, k, pos)
+    out = vkn.ops.query_merge(vkn.ops.make_dims(B, N, C, 8, 8, 8, 8 * C, 1, 0, 0), pack, q.to(dev), k.to(dev), pos.to(dev) if with_pos else None)
+    assert float((out.cpu() - ref).abs().max()) < 3e-4, ('query_merge', B, N, C, Fr, with_pos)
+
+
 _heads = {}
 only = sys.argv[2:]
 with torch.no_grad():
@@ -300,7 +325,7 @@ with torch.no_grad():
                      ('kernel init', t_kernel_init), ('head C=256 split vs exact GEMMs', t_head_c256),
                      ('head fused / bits / logits / side stream', t_head_fused), ('half-storage x', t_xhalf),
                      ('device LSAP vs host solver', t_lsap), ('device tracker vs oracle', t_tracker),
-                     ('link heads clip vs frame-by-frame', t_link_heads)):
+                     ('link heads clip vs frame-by-frame', t_link_heads), ('VIS attention query merge', t_query_merge)):
         if not only or any(o in name for o in only):
             section(name, fn)
 print('soak: OK')
