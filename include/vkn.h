@@ -403,6 +403,26 @@ typedef struct VknLsapProblem {
 size_t vkn_sizeof_lsap_problem(void);
 int vkn_lsap_batch_f32(const VknLsapProblem* probs, int nprob, int* status, void* stream);
 
+/* ---- the three MASK losses of a training stage, forward and backward (replaces the torch op sequence of
+ *      `KernelUpdateHead.loss`, knet/det/kernel_update_head.py:303-322, for the shipped loss objects):
+ *        loss_mask  CrossEntropyLoss(use_sigmoid=True)   mean BCE-with-logits over the K positive rows' pixels
+ *        loss_dice  DiceLoss(use_sigmoid, activate, eps)  mean over the K rows of 1 - 2 a / (b + eps + c + eps)
+ *        loss_rank  CrossEntropyLoss over the kernel axis, target = largest positive row whose mask target covers the pixel (:311-322)
+ *      pred, target: [R = B * Ns][P] fp32 (the up-scaled mask logits and the mask targets of `get_targets`), P % 4 == 0;
+ *      pos_rows int64 [K] (ascending positive rows), rowk int32 [R] (index among the positives or -1).
+ *      fwd out: row_partial [K][vkn_mask_losses_chunks(P)][4] = partial (sum bce, sum p t, sum p^2, sum t^2);
+ *               with_rank: lse [B][P], top int32 [B][P] (covering row or -1), rank_partial [B][vkn_mask_losses_blocks(P)]
+ *               (fixed-order partial sums: the caller adds them up and applies weights / means — a handful of K-sized ops).
+ *      bwd: grad [R][P] = coef[1] [covered] (softmax_n - onehot) + [row positive] (coef[0] (p - t) + (rowcoef[k][0] t + rowcoef[k][1] p) p (1 - p));
+ *           coef (device float[2]) = {g_mask w_mask / (K P), g_rank w_rank / (B P)}, rowcoef (device [K][2]) = the dice chain rule
+ *           per row {-2 / (b + c), 4 a / (b + c)^2} x g_dice w_dice / K.  One pass writes the gradient of all three losses. */
+int vkn_mask_losses_chunks(int P);
+int vkn_mask_losses_blocks(int P);
+int vkn_mask_losses_fwd_f32(const float* pred, const float* target, const long long* pos_rows, const int* rowk, int K, int B, int Ns,
+                            int P, int with_rank, float* row_partial, float* lse, int* top, float* rank_partial, void* stream);
+int vkn_mask_losses_bwd_f32(const float* pred, const float* target, const int* rowk, const float* rowcoef, const float* coef,
+                            const float* lse, const int* top, int B, int Ns, int P, int with_rank, float* grad, void* stream);
+
 /* ---- quasi-dense embedding association (the `tracker=dict(type='QuasiDenseEmbedTracker', ...)` of the video configs).  Replaces
  *      `QuasiDenseEmbedTracker.match(bboxes, labels, track_feats, frame_id) -> (bboxes, labels, ids)` together with the `update_memo`
  *      and `memo` it calls: knet/video/qdtrack/trackers/quasi_dense_embed_tracker.py:137-207, :47-103, :105-135 (ctor kwargs :11-38).

@@ -170,6 +170,51 @@ def test_chain_as_hipgraphs_equals_eager_chain(vkn, name):
     assert all(h._chain_graphs is None for h in head.mask_head)
 
 
+@pytest.mark.parametrize('B,Ns,H,W,K,with_rank', [(2, 17, 16, 24, 7, True), (4, 117, 32, 64, 40, True), (1, 20, 8, 12, 3, False),
+                                                 (3, 33, 24, 20, 33, True)])
+def test_fused_mask_losses_vs_torch_ops(vkn, B, Ns, H, W, K, with_rank):
+    """`vkn_mask_losses_*` (BCE + dice over the positive rows, rank loss over the kernel axis; one backward pass) against the torch op
+    sequence of `KernelUpdateHead.loss` on the same tensors: losses 1e-5 relative, gradient 1e-5 of its maximum."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(100 + Ns)
+    R = B * Ns
+    pred = (torch.randn(B, Ns, H, W, generator=g) * 3).to(DEV)
+    pos_rows = torch.sort(torch.randperm(R, generator=g)[:K])[0].to(DEV)
+    targets = torch.zeros(R, H, W)
+    soft = torch.rand(K, H, W, generator=g)
+    targets[pos_rows.cpu()] = torch.where(soft > 0.6, soft, torch.zeros(()))          # soft targets with holes (zeros = not covered)
+    targets = targets.to(DEV)
+    w_mask, w_dice, eps, w_rank = 1.0, 4.0, 1e-3, (0.1 if with_rank else None)
+
+    def torch_losses(p):
+        pp, tt = p.reshape(R, H, W)[pos_rows], targets[pos_rows]
+        lm = w_mask * F.binary_cross_entropy_with_logits(pp, tt, reduction='mean')
+        sp = pp.sigmoid().flatten(1)
+        a, b_, c = (sp * tt.flatten(1)).sum(1), (sp * sp).sum(1) + eps, (tt.flatten(1) ** 2).sum(1) + eps
+        ld = w_dice * (1 - 2 * a / (b_ + c)).mean()
+        lr = p.new_zeros(())
+        if with_rank:
+            pos = torch.zeros(R, dtype=torch.bool, device=DEV)
+            pos[pos_rows] = True
+            covered = targets.view(B, Ns, H, W).bool() & pos.view(B, Ns, 1, 1)
+            idx = torch.arange(Ns, device=DEV).view(1, Ns, 1, 1)
+            top = torch.where(covered, idx, idx.new_full((), -1)).amax(dim=1)
+            tgt = torch.where(top >= 0, top, top.new_full((), 255))
+            lr = w_rank * F.cross_entropy(p, tgt, reduction='none', ignore_index=255).mean()
+        return lm, ld, lr
+
+    pa = pred.clone().requires_grad_(True)
+    la = vkn.autograd.mask_losses(pa, targets, pos_rows, w_mask, w_dice, eps, w_rank)
+    pb = pred.clone().requires_grad_(True)
+    lb = torch_losses(pb)
+    for u, v in zip(la, lb):
+        assert abs(float(u.detach()) - float(v.detach())) <= 1e-5 * max(1.0, abs(float(v.detach()))), (float(u.detach()), float(v.detach()))
+    ws = (0.7, 1.3, 2.1)
+    sum(w * l for w, l in zip(ws, la)).backward()
+    sum(w * l for w, l in zip(ws, lb)).backward()
+    assert maxabs(pa.grad, pb.grad) <= 1e-5 * float(pb.grad.abs().max()), (maxabs(pa.grad, pb.grad), float(pb.grad.abs().max()))
+
+
 def test_soft_gt_assignment_vs_reference(vkn):
     """Soft (bilinearly down-sampled) ground-truth masks: DiceCost / MaskCost use the REAL target values."""
     g = dict(np.load(f'{__import__("helpers").GOLDEN}/assign_soft.npz', allow_pickle=False))

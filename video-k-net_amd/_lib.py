@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
-SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_tracker.hip', 'vkn_api.hip')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_tracker.hip', 'vkn_loss.hip', 'vkn_api.hip')
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares
@@ -27,6 +27,7 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_w
            'vkn_merge_workspace_bytes', 'vkn_panoptic_thing_first_u8',
            'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_lsap_f32',
            'vkn_sizeof_lsap_problem', 'vkn_lsap_batch_f32',
+           'vkn_mask_losses_chunks', 'vkn_mask_losses_blocks', 'vkn_mask_losses_fwd_f32', 'vkn_mask_losses_bwd_f32',
            'vkn_sizeof_tracker_cfg', 'vkn_qd_tracker_state_bytes', 'vkn_qd_tracker_workspace_bytes', 'vkn_qd_tracker_state_layout',
            'vkn_qd_tracker_reset', 'vkn_qd_tracker_match_f32')
 
@@ -265,6 +266,14 @@ def lib():
     L.vkn_assign_workspace_bytes.argtypes = [c_int] * 3
     L.vkn_assign_costs_f32.restype = c_int
     L.vkn_assign_costs_f32.argtypes = [pA, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp, _fp, c_size, _fp]
+    L.vkn_mask_losses_chunks.restype = c_int
+    L.vkn_mask_losses_chunks.argtypes = [c_int]
+    L.vkn_mask_losses_blocks.restype = c_int
+    L.vkn_mask_losses_blocks.argtypes = [c_int]
+    L.vkn_mask_losses_fwd_f32.restype = c_int
+    L.vkn_mask_losses_fwd_f32.argtypes = [_fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _fp, _fp, _fp, _fp, _fp]
+    L.vkn_mask_losses_bwd_f32.restype = c_int
+    L.vkn_mask_losses_bwd_f32.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp, _fp]
     L.vkn_sizeof_lsap_problem.restype = c_size
     L.vkn_sizeof_lsap_problem.argtypes = []
     if L.vkn_sizeof_lsap_problem() != ctypes.sizeof(VknLsapProblem):

@@ -112,3 +112,46 @@ def mask_gather(x, mask_logits, hard_mask_thr=0.5):
 
 def mask_decode(x, kernels, bias=None):
     return MaskDecodeFn.apply(x, kernels, bias)
+
+
+class MaskLossesFn(torch.autograd.Function):
+    """(loss_mask, loss_dice, loss_rank | 0) of one training stage from the up-scaled mask logits: two HIP passes forward, one
+    backward that writes the gradient of all three into one tensor (csrc/vkn_loss.hip).  Values: those of CrossEntropyLoss(
+    use_sigmoid=True), DiceLoss(use_sigmoid, activate) and CrossEntropyLoss over the kernel axis with the masked-max rank target
+    (`KernelUpdateHead.loss`); the mask targets carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, mask_pred, mask_targets, pos_rows, B, w_mask, w_dice, dice_eps, w_rank):
+        R, P = mask_pred.shape[0] * mask_pred.shape[1], mask_pred.shape[2] * mask_pred.shape[3]
+        pred = mask_pred.reshape(R, P)
+        target = mask_targets.reshape(R, P)
+        K = int(pos_rows.shape[0])
+        dev = pred.device
+        rowk = torch.full((R,), -1, dtype=torch.int32, device=dev)
+        rowk[pos_rows] = torch.arange(K, dtype=torch.int32, device=dev)
+        with_rank = w_rank is not None
+        stats, lse, top, rank_sum = ops.mask_losses_fwd(pred, target, pos_rows, rowk, B, with_rank)
+        bce, a, b, c = stats.unbind(1)
+        bc = (b + dice_eps) + (c + dice_eps)
+        loss_mask = w_mask * (bce.sum() / (K * P))
+        loss_dice = w_dice * (1.0 - (2.0 * a) / bc).mean()
+        loss_rank = (w_rank * (rank_sum / (B * P))) if with_rank else pred.new_zeros(())
+        ctx.save_for_backward(pred, target, rowk, a, bc, lse if with_rank else pred.new_empty(0), top if with_rank else rowk.new_empty(0))
+        ctx.meta = (B, K, P, w_mask, w_dice, w_rank, tuple(mask_pred.shape))
+        return loss_mask, loss_dice, loss_rank
+
+    @staticmethod
+    def backward(ctx, g_mask, g_dice, g_rank):
+        pred, target, rowk, a, bc, lse, top = ctx.saved_tensors
+        B, K, P, w_mask, w_dice, w_rank, shape = ctx.meta
+        with_rank = w_rank is not None
+        gd = g_dice * (w_dice / K)
+        rowcoef = torch.stack([gd * (-2.0 / bc), gd * (4.0 * a / (bc * bc))], dim=1).contiguous()
+        coef = torch.stack([g_mask * (w_mask / (K * P)), (g_rank * (w_rank / (B * P))) if with_rank else g_mask * 0.0]).float().contiguous()
+        grad = ops.mask_losses_bwd(pred, target, rowk, rowcoef.float(), coef, lse, top, B, with_rank)
+        return grad.reshape(shape), None, None, None, None, None, None, None
+
+
+def mask_losses(mask_pred, mask_targets, pos_rows, w_mask, w_dice, dice_eps, w_rank=None):
+    """mask_pred [B, Ns, H, W] logits, mask_targets [B*Ns, H, W], pos_rows int64 [K > 0] ascending -> (loss_mask, loss_dice, loss_rank)."""
+    return MaskLossesFn.apply(mask_pred.contiguous(), mask_targets.contiguous(), pos_rows, mask_pred.shape[0], w_mask, w_dice, dice_eps, w_rank)

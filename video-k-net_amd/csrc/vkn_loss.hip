@@ -1,0 +1,170 @@
+// vkn_loss.hip — the three MASK losses of a training stage in two passes over the up-scaled predictions instead of ~60 element-wise /
+// reduction launches (knet/det/kernel_update_head.py:303-322 with the shipped loss objects):
+//   loss_mask  CrossEntropyLoss(use_sigmoid=True): mean over the K positive rows' pixels of BCE-with-logits(z, t)      (knet/cross_entropy_loss.py:61-101)
+//   loss_dice  DiceLoss(use_sigmoid, activate, eps): mean over the K rows of 1 - 2 a / (b + c), a = sum p t, b = sum p^2 + eps,
+//              c = sum t^2 + eps, p = sigmoid(z)                                                                        (mmdet 2.18 dice_loss)
+//   loss_rank  CrossEntropyLoss over the kernel axis: per pixel, target = the LARGEST positive row whose mask target covers it
+//              (:311-322), ignored where none does; mean over ALL B H W pixels of logsumexp_n z - z[target]            (knet/cross_entropy_loss.py:8-43)
+// Forward: k_ml_rows (one workgroup per (positive row, pixel chunk): four partial sums) + k_ml_rank_fwd (a thread owns 4 pixels of a
+// frame and walks the Ns rows: online logsumexp, the covering row, per-block partial loss; lse and target are kept for backward).
+// Backward: ONE kernel writes the gradient of all three losses into one [R][P] tensor (no zero-fill + add of the sparse mask / dice
+// gradients into the dense rank gradient).  Fixed-order reductions, no atomics: deterministic.
+#include <hip/hip_runtime.h>
+
+#include "../../include/vkn.h"
+#include "vkn_common.h"
+#include "vkn_launch.h"
+
+namespace {
+
+constexpr int ML_CHUNK = 8192;   // pixels per workgroup of k_ml_rows
+
+// partial [K][nchunk][4] = (sum bce, sum p t, sum p^2, sum t^2) of row pos_rows[k] over pixels [chunk * ML_CHUNK, ...)
+__global__ __launch_bounds__(256) void k_ml_rows(const float* __restrict__ pred, const float* __restrict__ target,
+                                                 const long long* __restrict__ pos_rows, int P, int nchunk, float* __restrict__ partial) {
+    __shared__ float red[4][4];
+    const int k = blockIdx.y, ck = blockIdx.x;
+    const size_t row = (size_t)pos_rows[k];
+    const float* z = pred + row * P;
+    const float* t = target + row * P;
+    const int p_lo = ck * ML_CHUNK, p_hi = min(P, p_lo + ML_CHUNK);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int p = p_lo + threadIdx.x; p < p_hi; p += 256) {
+        const float zz = z[p], tt = t[p];
+        // F.binary_cross_entropy_with_logits: max(z, 0) - z t + log(1 + exp(-|z|))
+        s0 += fmaxf(zz, 0.f) - zz * tt + log1pf(expf(-fabsf(zz)));
+        const float pp = 1.0f / (1.0f + expf(-zz));
+        s1 += pp * tt;
+        s2 += pp * pp;
+        s3 += tt * tt;
+    }
+    s0 = vkn_wave_sum(s0); s1 = vkn_wave_sum(s1); s2 = vkn_wave_sum(s2); s3 = vkn_wave_sum(s3);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = s0; red[1][w] = s1; red[2][w] = s2; red[3][w] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float* r = red[threadIdx.x];
+        partial[((size_t)k * nchunk + ck) * 4 + threadIdx.x] = (r[0] + r[1]) + (r[2] + r[3]);
+    }
+}
+
+// frame b, pixels 4 * (blockIdx.x * 256 + tid) .. + 3: walk the Ns rows.  rowk [R]: index of a row among the positives or -1.
+__global__ __launch_bounds__(256) void k_ml_rank_fwd(const float* __restrict__ pred, const float* __restrict__ target,
+                                                     const int* __restrict__ rowk, int Ns, int P, float* __restrict__ lse,
+                                                     int* __restrict__ top, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int p = 4 * (blockIdx.x * 256 + threadIdx.x);
+    float loss = 0.f;
+    if (p < P) {
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s = {0.f, 0.f, 0.f, 0.f}, zt = {0.f, 0.f, 0.f, 0.f};
+        int tp[4] = {-1, -1, -1, -1};
+        for (int n = 0; n < Ns; ++n) {
+            const size_t off = ((size_t)b * Ns + n) * P + p;
+            const f32x4 z = *reinterpret_cast<const f32x4*>(pred + off);
+            const bool pos = rowk[b * Ns + n] >= 0;   // uniform
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (pos) t = *reinterpret_cast<const f32x4*>(target + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float mn = fmaxf(m[e], z[e]);
+                s[e] = s[e] * expf(m[e] - mn) + expf(z[e] - mn);
+                m[e] = mn;
+                if (pos && t[e] != 0.f) { tp[e] = n; zt[e] = z[e]; }
+            }
+        }
+        f32x4 l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            l[e] = m[e] + logf(s[e]);
+            if (tp[e] >= 0) loss += l[e] - zt[e];
+        }
+        *reinterpret_cast<f32x4*>(lse + (size_t)b * P + p) = l;
+        *reinterpret_cast<int4*>(top + (size_t)b * P + p) = make_int4(tp[0], tp[1], tp[2], tp[3]);
+    }
+    loss = vkn_wave_sum(loss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// grad[row][p] = coef[1] * [covered] (softmax_n - onehot) + [row positive] (coef[0] (p - t) + (rowcoef[k][0] t + rowcoef[k][1] p) p (1 - p))
+// coef (device): [0] = g_mask w_mask / (K P), [1] = g_rank w_rank / (B P);  rowcoef [K][2]: the dice chain rule per row
+__global__ __launch_bounds__(256) void k_ml_bwd(const float* __restrict__ pred, const float* __restrict__ target,
+                                                const int* __restrict__ rowk, const float* __restrict__ rowcoef,
+                                                const float* __restrict__ coef, const float* __restrict__ lse,
+                                                const int* __restrict__ top, int Ns, int P, int with_rank, float* __restrict__ grad) {
+    const int b = blockIdx.y;
+    const int p = 4 * (blockIdx.x * 256 + threadIdx.x);
+    if (p >= P) return;
+    const float cm = coef[0], cr = with_rank ? coef[1] : 0.f;
+    f32x4 l = {0.f, 0.f, 0.f, 0.f};
+    int4 tp = make_int4(-1, -1, -1, -1);
+    if (with_rank) {
+        l = *reinterpret_cast<const f32x4*>(lse + (size_t)b * P + p);
+        tp = *reinterpret_cast<const int4*>(top + (size_t)b * P + p);
+    }
+    const int tpv[4] = {tp.x, tp.y, tp.z, tp.w};
+    for (int n = 0; n < Ns; ++n) {
+        const size_t off = ((size_t)b * Ns + n) * P + p;
+        const f32x4 z = *reinterpret_cast<const f32x4*>(pred + off);
+        const int k = rowk[b * Ns + n];   // uniform
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (with_rank) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (tpv[e] >= 0) g[e] = cr * (expf(z[e] - l[e]) - (tpv[e] == n ? 1.f : 0.f));
+        }
+        if (k >= 0) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(target + off);
+            const float ca = rowcoef[2 * k], cb = rowcoef[2 * k + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pp = 1.0f / (1.0f + expf(-z[e]));
+                g[e] += cm * (pp - t[e]) + (ca * t[e] + cb * pp) * pp * (1.f - pp);
+            }
+        }
+        *reinterpret_cast<f32x4*>(grad + off) = g;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vkn_mask_losses_chunks(int P) { return P > 0 ? (P + ML_CHUNK - 1) / ML_CHUNK : 0; }
+int vkn_mask_losses_blocks(int P) { return P > 0 ? (P / 4 + 255) / 256 : 0; }
+
+int vkn_mask_losses_fwd_f32(const float* pred, const float* target, const long long* pos_rows, const int* rowk, int K, int B, int Ns,
+                            int P, int with_rank, float* row_partial, float* lse, int* top, float* rank_partial, void* stream) {
+    if (!pred || !target || B <= 0 || Ns <= 0 || P <= 0 || K < 0) return VKN_E_ARG;
+    if ((P & 3) || ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target)) & 15)) return VKN_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (K > 0) {
+        if (!pos_rows || !row_partial) return VKN_E_ARG;
+        hipLaunchKernelGGL(k_ml_rows, dim3(vkn_mask_losses_chunks(P), K), dim3(256), 0, st, pred, target, pos_rows, P,
+                           vkn_mask_losses_chunks(P), row_partial);
+        VKN_CHECK_LAUNCH();
+    }
+    if (with_rank) {
+        if (!rowk || !lse || !top || !rank_partial) return VKN_E_ARG;
+        hipLaunchKernelGGL(k_ml_rank_fwd, dim3(vkn_mask_losses_blocks(P), B), dim3(256), 0, st, pred, target, rowk, Ns, P, lse, top,
+                           rank_partial);
+        VKN_CHECK_LAUNCH();
+    }
+    return VKN_OK;
+}
+
+int vkn_mask_losses_bwd_f32(const float* pred, const float* target, const int* rowk, const float* rowcoef, const float* coef,
+                            const float* lse, const int* top, int B, int Ns, int P, int with_rank, float* grad, void* stream) {
+    if (!pred || !target || !rowk || !rowcoef || !coef || !grad || B <= 0 || Ns <= 0 || P <= 0) return VKN_E_ARG;
+    if (with_rank && (!lse || !top)) return VKN_E_ARG;
+    if ((P & 3) || ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(grad)) & 15))
+        return VKN_E_ALIGN;
+    hipLaunchKernelGGL(k_ml_bwd, dim3(vkn_mask_losses_blocks(P), B), dim3(256), 0, static_cast<hipStream_t>(stream), pred, target, rowk,
+                       rowcoef, coef, lse, top, Ns, P, with_rank, grad);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+}  // extern "C"

@@ -440,7 +440,15 @@ class KernelUpdateHead(nn.Module):
         if mask_pred is not None:
             H, W = mask_pred.shape[-2:]
             any_pos = (pos_index.numel() > 0) if pos_index is not None else bool(pos_inds.any())
-            if any_pos:
+            if any_pos and pos_index is not None and self._fused_mask_losses_ok(mask_pred, reduction_override):
+                # the three mask losses in two HIP passes forward and one backward (csrc/vkn_loss.hip) instead of ~60 element-wise /
+                # reduction launches over [K, H, W] and [B, Ns, H, W] tensors; same values (tests/test_gpu_train.py)
+                lm, ld, lr = vag.mask_losses(mask_pred, mask_targets, pos_index, self.loss_mask.loss_weight, self.loss_dice.loss_weight,
+                                             self.loss_dice.eps, self.loss_rank.loss_weight if self.loss_rank is not None else None)
+                losses['loss_mask'], losses['loss_dice'] = lm, ld
+                if self.loss_rank is not None:
+                    losses['loss_rank'] = lr
+            elif any_pos:
                 pos_mask_pred = take(mask_pred.reshape(num_preds, H, W))
                 pos_mask_targets = take(mask_targets)
                 losses['loss_mask'] = self.loss_mask(pos_mask_pred, pos_mask_targets)
@@ -463,6 +471,18 @@ class KernelUpdateHead(nn.Module):
                 if self.loss_rank is not None:
                     losses['loss_rank'] = mask_pred.sum() * 0
         return losses
+
+    fused_mask_losses = True     # False: the torch op sequence (A/B; also taken whenever a loss object is not the shipped one)
+
+    def _fused_mask_losses_ok(self, mask_pred, reduction_override):
+        from . import losses as L
+        lm, ld, lr = self.loss_mask, self.loss_dice, self.loss_rank
+        return (self.fused_mask_losses and reduction_override is None and mask_pred.is_cuda and mask_pred.dtype == torch.float32
+                and (mask_pred.shape[-1] * mask_pred.shape[-2]) % 4 == 0 and mask_pred.dim() == 4
+                and type(lm) is L.CrossEntropyLoss and lm.use_sigmoid and lm.reduction == 'mean' and lm.class_weight is None
+                and type(ld) is L.DiceLoss and ld.use_sigmoid and ld.activate and ld.reduction == 'mean'
+                and (lr is None or (type(lr) is L.CrossEntropyLoss and not lr.use_sigmoid and not lr.use_mask and lr.reduction == 'mean'
+                                    and lr.class_weight is None)))
 
     def _get_target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls,
                            cfg):

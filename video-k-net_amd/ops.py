@@ -669,6 +669,39 @@ def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, d
     return cost
 
 
+def mask_losses_fwd(pred, target, pos_rows, rowk, B, with_rank):
+    """Forward sums of the three mask losses (include/vkn.h: vkn_mask_losses_fwd_f32).  pred, target [R, P]; pos_rows int64 [K]; rowk
+    int32 [R].  -> (rowstats [K, 4] = (sum bce, sum p t, sum p^2, sum t^2), lse [B, P] | None, top int32 [B, P] | None,
+    rank_sum scalar tensor | None)."""
+    pred, target = _req(pred, 'pred'), _req(target, 'target')
+    R, P = pred.shape
+    K, Ns = int(pos_rows.shape[0]), R // B
+    L = _lib.lib()
+    nch, nbl = L.vkn_mask_losses_chunks(P), L.vkn_mask_losses_blocks(P)
+    dev = pred.device
+    rp = torch.empty((K, nch, 4), dtype=torch.float32, device=dev)
+    lse = torch.empty((B, P), dtype=torch.float32, device=dev) if with_rank else None
+    top = torch.empty((B, P), dtype=torch.int32, device=dev) if with_rank else None
+    rkp = torch.empty((B, nbl), dtype=torch.float32, device=dev) if with_rank else None
+    with torch.cuda.device(dev):
+        check(L.vkn_mask_losses_fwd_f32(_ptr(pred), _ptr(target), pos_rows.data_ptr() if K else None, rowk.data_ptr(), K, B, Ns, P,
+                                        1 if with_rank else 0, _ptr(rp) if K else None, _ptr(lse), top.data_ptr() if with_rank else None,
+                                        _ptr(rkp), _stream()))
+    return rp.sum(dim=1), lse, top, (rkp.sum() if with_rank else None)
+
+
+def mask_losses_bwd(pred, target, rowk, rowcoef, coef, lse, top, B, with_rank):
+    """Gradient of the three mask losses w.r.t. pred [R, P] in one pass (vkn_mask_losses_bwd_f32)."""
+    pred, target = _req(pred, 'pred'), _req(target, 'target')
+    R, P = pred.shape
+    grad = torch.empty_like(pred)
+    with torch.cuda.device(pred.device):
+        check(_lib.lib().vkn_mask_losses_bwd_f32(_ptr(pred), _ptr(target), rowk.data_ptr(), _ptr(rowcoef), _ptr(coef), _ptr(lse),
+                                                 top.data_ptr() if with_rank else None, B, R // B, P, 1 if with_rank else 0,
+                                                 _ptr(grad), _stream()))
+    return grad
+
+
 def lsap_device(costs):
     """`scipy.optimize.linear_sum_assignment` for a batch of DEVICE cost matrices [nr_b, nc_b] (fp32) without leaving the device:
     one launch, one wavefront per matrix (include/vkn.h: vkn_lsap_batch_f32).  -> (gt_inds, row_ind, col_ind, status):
