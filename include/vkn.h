@@ -165,6 +165,8 @@ int vkn_decode_gather_x(const void* x, int x_dtype, const void* kf_hi, const voi
 /* ---- `F.interpolate(mask_preds, scale_factor=S, mode='bilinear', align_corners=False)`
  *      knet/det/kernel_iter_head.py:122-130.  in [planes][H][W] -> out [planes][H*S][W*S]. */
 int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, int W, int S, void* stream);
+/*      its adjoint (training: the losses act on the up-scaled predictions): grad_out [planes][H*S][W*S] -> grad_in [planes][H][W] */
+int vkn_upsample_bilinear_bwd_f32(const float* grad_out, float* grad_in, int planes, int H, int W, int S, void* stream);
 
 /* ---- weight preparation for the bf16x3 split-MFMA GEMMs: splits every non-NULL Linear weight of `w` (w->prepared is ignored)
  *      into `prepared` (device buffer, >= vkn_prepared_bytes(d, w) bytes, 256-B aligned).  Afterwards set

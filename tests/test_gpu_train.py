@@ -215,6 +215,22 @@ def test_fused_mask_losses_vs_torch_ops(vkn, B, Ns, H, W, K, with_rank):
     assert maxabs(pa.grad, pb.grad) <= 1e-5 * float(pb.grad.abs().max()), (maxabs(pa.grad, pb.grad), float(pb.grad.abs().max()))
 
 
+@pytest.mark.parametrize('shape,S', [((2, 5, 8, 12), 2), ((1, 3, 7, 9), 4), ((3, 4, 16, 32), 2), ((1, 2, 5, 3), 3)])
+def test_upsample_backward_vs_torch_autograd(vkn, shape, S):
+    """The adjoint of the bilinear xS upsample (HIP, gather form, deterministic) against torch's autograd of F.interpolate."""
+    import torch.nn.functional as F
+    x = _rand(shape, 700 + S).to(DEV)
+    g = _rand(shape[:2] + (shape[2] * S, shape[3] * S), 701 + S).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = vkn.autograd.upsample_bilinear(xa, S)
+    ya.backward(g)
+    xb = x.clone().requires_grad_(True)
+    yb = F.interpolate(xb, scale_factor=S, mode='bilinear', align_corners=False)
+    yb.backward(g)
+    assert maxabs(ya, yb) < 1e-6 * max(1.0, float(yb.abs().max()))
+    assert maxabs(xa.grad, xb.grad) < 1e-5 * float(xb.grad.abs().max())
+
+
 def test_soft_gt_assignment_vs_reference(vkn):
     """Soft (bilinearly down-sampled) ground-truth masks: DiceCost / MaskCost use the REAL target values."""
     g = dict(np.load(f'{__import__("helpers").GOLDEN}/assign_soft.npz', allow_pickle=False))

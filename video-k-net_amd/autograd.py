@@ -155,3 +155,20 @@ class MaskLossesFn(torch.autograd.Function):
 def mask_losses(mask_pred, mask_targets, pos_rows, w_mask, w_dice, dice_eps, w_rank=None):
     """mask_pred [B, Ns, H, W] logits, mask_targets [B*Ns, H, W], pos_rows int64 [K > 0] ascending -> (loss_mask, loss_dice, loss_rank)."""
     return MaskLossesFn.apply(mask_pred.contiguous(), mask_targets.contiguous(), pos_rows, mask_pred.shape[0], w_mask, w_dice, dice_eps, w_rank)
+
+
+class UpsampleBilinearFn(torch.autograd.Function):
+    """`F.interpolate(x, scale_factor=S, mode='bilinear', align_corners=False)` on the HIP kernels, forward and adjoint."""
+
+    @staticmethod
+    def forward(ctx, masks, scale):
+        ctx.scale = int(scale)
+        return ops.upsample_bilinear(masks, ctx.scale)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ops.upsample_bilinear_bwd(grad_out.contiguous(), ctx.scale), None
+
+
+def upsample_bilinear(masks, scale):
+    return UpsampleBilinearFn.apply(masks, scale)

@@ -128,9 +128,56 @@ __global__ __launch_bounds__(256) void k_ml_bwd(const float* __restrict__ pred, 
     }
 }
 
+// Adjoint of the xS bilinear upsample (F.interpolate(scale_factor=S, bilinear, align_corners=False)): gin[y][x] = sum over the
+// output pixels whose two source rows / columns include (y, x) of their weights x gout.  Gather form: a thread owns one input pixel
+// and visits the <= 3 S x 3 S output pixels around it, testing each one's own (y0, y1, ly) — the same clamped source-index formula
+// as the forward kernels, so forward and backward agree on every border case.  Deterministic (torch's kernel scatters with atomics).
+__global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ gout, float* __restrict__ gin, int H, int W, int S) {
+    const int plane = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W;
+    const int OH = H * S, OW = W * S;
+    const float rs = 1.0f / (float)S;
+    const float* gp = gout + (size_t)plane * OH * OW;
+    float acc = 0.f;
+    const int oy_lo = max(S * (y - 1), 0), oy_hi = min(S * (y + 2) - 1, OH - 1);
+    const int ox_lo = max(S * (x - 1), 0), ox_hi = min(S * (x + 2) - 1, OW - 1);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f);
+        const int y0 = min((int)sy, H - 1), y1 = min(y0 + 1, H - 1);
+        const float ly = sy - (float)y0;
+        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const float sx = fmaxf(((float)ox + 0.5f) * rs - 0.5f, 0.f);
+            const int x0 = min((int)sx, W - 1), x1 = min(x0 + 1, W - 1);
+            const float lx = sx - (float)x0;
+            const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+            if (wx != 0.f) row += wx * gp[(size_t)oy * OW + ox];
+        }
+        acc += wy * row;
+    }
+    gin[(size_t)plane * H * W + idx] = acc;
+}
+
 }  // namespace
 
 extern "C" {
+
+int vkn_upsample_bilinear_bwd_f32(const float* grad_out, float* grad_in, int planes, int H, int W, int S, void* stream) {
+    if (!grad_out || !grad_in || planes <= 0 || H <= 0 || W <= 0 || S < 1) return VKN_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int done = 0; done < planes; done += 32768) {  // gridDim.y <= 65535
+        const int chunk = (planes - done > 32768) ? 32768 : planes - done;
+        hipLaunchKernelGGL(k_upsample_bwd, dim3((H * W + 255) / 256, chunk), dim3(256), 0, st, grad_out + (size_t)done * H * S * W * S,
+                           grad_in + (size_t)done * H * W, H, W, S);
+        VKN_CHECK_LAUNCH();
+    }
+    return VKN_OK;
+}
+
 
 int vkn_mask_losses_chunks(int P) { return P > 0 ? (P + ML_CHUNK - 1) / ML_CHUNK : 0; }
 int vkn_mask_losses_blocks(int P) { return P > 0 ? (P / 4 + 255) / 256 : 0; }

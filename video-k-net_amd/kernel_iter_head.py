@@ -104,9 +104,12 @@ class KernelIterHead(BaseRoIHead):
 
     @staticmethod
     def _upsample(mask_preds, stride):
-        """`F.interpolate(mask_preds, scale_factor=stride, bilinear, align_corners=False)` (reference :122-130): the HIP kernel at
-        inference; under autograd torch's own op (its backward is needed, the upsample is write-bound either way)."""
+        """`F.interpolate(mask_preds, scale_factor=stride, bilinear, align_corners=False)` (reference :122-130): the HIP kernel; under
+        autograd the same kernel with its adjoint as backward."""
         if mask_preds.requires_grad and torch.is_grad_enabled():
+            from . import autograd as vag
+            if mask_preds.is_cuda and mask_preds.dtype == torch.float32 and mask_preds.dim() == 4:
+                return vag.upsample_bilinear(mask_preds, stride)       # HIP forward + its adjoint (csrc/vkn_loss.hip)
             return torch.nn.functional.interpolate(mask_preds, scale_factor=stride, mode='bilinear', align_corners=False)
         return ops.upsample_bilinear(mask_preds, stride)
 

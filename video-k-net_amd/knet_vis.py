@@ -311,7 +311,7 @@ class KernelFrameIterHeadVideo(_QueryMerge, BaseRoIHead):
         B, F, N, H, W = mask_preds.shape
         flat = mask_preds.reshape(B * F, N, H, W)
         if mask_preds.requires_grad and torch.is_grad_enabled():
-            up = torch.nn.functional.interpolate(flat, scale_factor=s, mode='bilinear', align_corners=False)
+            up = vag.upsample_bilinear(flat.contiguous(), s)
         else:
             up = ops.upsample_bilinear(flat, s)
         return up.reshape(B, F, N, H * s, W * s)

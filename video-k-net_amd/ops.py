@@ -179,6 +179,17 @@ def upsample_bilinear(masks, scale):
     return out
 
 
+def upsample_bilinear_bwd(grad_out, scale):
+    """Adjoint of `upsample_bilinear`: grad_out [B, N, H*scale, W*scale] -> [B, N, H, W] (vkn_upsample_bilinear_bwd_f32)."""
+    g = _req(grad_out, 'grad_out')
+    B, N, OH, OW = g.shape
+    H, W = OH // scale, OW // scale
+    out = torch.empty((B, N, H, W), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        check(_lib.lib().vkn_upsample_bilinear_bwd_f32(_ptr(g), _ptr(out), B * N, H, W, int(scale), _stream()))
+    return out
+
+
 class StagePack:
     """Device pointers of one stage's parameters in the C-ABI struct, plus the derived folded tensor `ft_wT`.
     Holds references to every tensor it points to.  Rebuilt when any parameter is replaced or modified in place
