@@ -55,3 +55,26 @@ if os.environ.get('STACKS'):
         if e.name in ('aten::_local_scalar_dense', 'aten::nonzero') or 'hipMemcpyWithStream' in e.name:
             st = [s for s in (e.stack or []) if 'video-k-net_amd' in s or 'bench' in s or 'train_ops' in s][:3]
             print(e.name, '<-', ' | '.join(st))
+if os.environ.get('CPROFILE'):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    pr.enable()
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats('cumulative').print_stats('video-k-net_amd|train_ops|torch/autograd/function|torch/cuda/graphs', 45)
+    st.sort_stats('tottime').print_stats(25)
+if os.environ.get('FINDSYNC'):
+    import traceback
+    for name in ('item', '__bool__', 'tolist', '__int__', '__float__', 'cpu', 'numpy', 'nonzero', '__index__'):
+        orig = getattr(torch.Tensor, name)
+        def wrap(self, *a, _orig=orig, _name=name, **k):
+            if self.is_cuda:
+                fr = [f for f in traceback.extract_stack()[:-1] if 'video-k-net_amd' in f.filename or 'train_ops' in f.filename or 'torch/optim' in f.filename][-2:]
+                print('SYNC', _name, ' <- ', ' | '.join(f'{os.path.basename(f.filename)}:{f.lineno} {f.name}' for f in fr))
+            return _orig(self, *a, **k)
+        setattr(torch.Tensor, name, wrap)
+    step()

@@ -224,7 +224,7 @@ class KernelIterHead(BaseRoIHead):
                 prev_mask_preds, prev_cls_score = scaled_mask_preds.detach(), cls_score.detach()
         if self.mask_assigner and hasattr(self.mask_assigner[0], 'check_status'):
             # device assignments report invalid cost matrices through status words: ONE read per step for all stages
-            self.mask_assigner[0].check_status(*self.mask_assigner[1:])
+            self.mask_assigner[0].check_status(*self.mask_assigner[1:], wait=False)   # (reported at a later poll: no stall)
         return all_stage_loss, mask_results
 
     def forward_train(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, gt_bboxes_ignore=None,

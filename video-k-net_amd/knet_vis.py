@@ -399,7 +399,7 @@ class KernelFrameIterHeadVideo(_QueryMerge, BaseRoIHead):
                     cls_for_assign = cls_score.detach()[:, :self.num_proposals, :self.num_thing_classes]
             assigned = self._clip_losses(stage, f'tracker_s{stage}', object_feats, cls_score, r['scaled_mask_preds'], assigned,
                                          ref_gt_masks, ref_gt_labels, ref_gt_instance_ids, cls_for_assign, losses)
-        self.mask_assigner[0].check_status(*self.mask_assigner[1:])
+        self.mask_assigner[0].check_status(*self.mask_assigner[1:], wait=False)
         return losses, dict(obj_feats=object_feats, x_feats=x, cls_scores=cls_score, masks=mask_preds)
 
     def simple_test(self, x, img_metas, ref_img_metas, cls_scores, masks, obj_feats, **kwargs):

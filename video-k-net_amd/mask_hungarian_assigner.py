@@ -25,6 +25,41 @@ class AssignResult:
         self.status = None
 
 
+class _AsyncFlags:
+    """Error flags computed on the device and read WITHOUT stalling the stream: `push` enqueues a copy of the flag into pinned host
+    memory and records an event; `poll` looks only at flags whose event has completed (`wait=True`: all of them).  The training loop
+    polls at the start of the next step — an invalid cost matrix or label is reported one step late instead of costing a
+    synchronisation per step."""
+
+    def __init__(self):
+        self.items = []
+
+    def push(self, flag, message):
+        host = torch.empty((), dtype=torch.int32).pin_memory()
+        host.copy_(flag.to(torch.int32).reshape(()), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.items.append((ev, host, message))
+        del self.items[:-256]
+
+    def poll(self, wait=False):
+        keep, bad = [], None
+        for ev, host, message in self.items:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                if int(host) != 0 and bad is None:
+                    bad = message
+            else:
+                keep.append((ev, host, message))
+        self.items = keep
+        if bad is not None:
+            raise (IndexError if 'gt_labels' in bad else ValueError)(bad)
+
+
+FLAGS = _AsyncFlags()     # one queue per process: the assigners of all stages share it
+
+
 def _cost_cfg(cfg, kind, allowed, defaults):
     cfg = dict(cfg or {})
     typ = cfg.pop('type', None)
@@ -65,18 +100,26 @@ class MaskHungarianAssigner:
 
     @classmethod
     def validate_labels(cls, label_tensors, ncls):
-        """Range-check the ground-truth labels of a whole batch against the `ncls` class logits with ONE device -> host read, and
-        remember them (by storage, version and class count): `assign` skips its own per-image check — one synchronisation per step
-        instead of one per image and stage.  Raises the IndexError the reference's `cls_pred[:, gt_labels]` would raise."""
-        cls._validated.clear()        # (keys name storage: they are only trusted for the step that read them)
-        todo = [t for t in label_tensors if torch.is_tensor(t) and t.numel()]
-        if not todo:
-            return
-        ext = torch.stack([torch.stack(torch.aminmax(t)).to(torch.int64) for t in todo]).tolist()    # (CPU tensors: no sync at all)
-        for t, (lo, hi) in zip(todo, ext):
-            if lo < 0 or hi >= ncls:
-                raise IndexError(f'gt_labels outside [0, {ncls}): {lo} .. {hi}')
+        """Range-check the ground-truth labels of a whole batch against the `ncls` class logits ONCE per step, on the device: the result
+        goes to the asynchronous flag queue (`FLAGS`), `assign` skips its own per-image check.  An out-of-range label is what makes the
+        reference's `cls_pred[:, gt_labels]` raise an IndexError; here the cost kernel clamps the index (no stray read) and the error
+        surfaces at the next `FLAGS.poll()` — one step later, without a device -> host synchronisation in the step.  CPU label
+        tensors are checked on the spot."""
+        cls._validated.clear()        # (keys name storage: they are only trusted for the step that checked them)
+        dev_bad = []
+        for t in label_tensors:
+            if not torch.is_tensor(t) or t.numel() == 0:
+                continue
+            if t.is_cuda:
+                lo, hi = torch.aminmax(t)
+                dev_bad.append((lo < 0) | (hi >= ncls))
+            else:
+                lo, hi = int(t.min()), int(t.max())
+                if lo < 0 or hi >= ncls:
+                    raise IndexError(f'gt_labels outside [0, {ncls}): {lo} .. {hi}')
             cls._validated[cls._label_key(t, ncls)] = True
+        if dev_bad:
+            FLAGS.push(torch.stack(dev_bad).any(), f'gt_labels outside [0, {ncls})')
 
     _validated = {}
 
@@ -125,17 +168,19 @@ class MaskHungarianAssigner:
         res.host_pos_inds = np.sort(np.asarray(rows_host, dtype=np.int64))   # the LSAP ran on the host: the sampler needs no device nonzero
         return res
 
-    def check_status(self, *others):
-        """Read the status words of the device assignments issued since the last call by this assigner (and `others`: the per-stage
-        assigners of a head) with ONE synchronisation: raises like the host solver does for NaN / -inf entries or an infeasible
-        matrix.  Call it once per step, not per image."""
+    def check_status(self, *others, wait=True):
+        """Hand the status words of the device assignments issued since the last call by this assigner (and `others`: the per-stage
+        assigners of a head) to the asynchronous flag queue and poll it.  `wait=True` (default): block until every queued flag is
+        known — raises like the host solver does for NaN / -inf entries or an infeasible matrix.  `wait=False` (the training loop):
+        only flags that are already on the host are looked at; nothing stalls, an error surfaces at a later poll."""
         pend = []
         for a in (self,) + tuple(others):
             if hasattr(a, 'pending_status'):
                 pend += a.pending_status
                 a.pending_status = []
-        if pend and bool(torch.cat(pend).any()):
-            raise ValueError('linear sum assignment: the cost matrix holds invalid entries or is infeasible')
+        if pend:
+            FLAGS.push(torch.cat(pend).any(), 'linear sum assignment: the cost matrix holds invalid entries or is infeasible')
+        FLAGS.poll(wait=wait)
 
 
 class MaskHungarianAssignerVideo(MaskHungarianAssigner):
