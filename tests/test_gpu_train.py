@@ -96,6 +96,14 @@ def test_forward_train_vs_reference_golden(vkn, name):
             assigned.append(r.gt_inds.clone())
             return r
         a.assign = rec
+        origb = a.assign_batch      # (the training loop assigns a whole batch per stage: one LSAP launch)
+
+        def recb(*args, _orig=origb, **kw):
+            rs = _orig(*args, **kw)
+            if _orig.__self__.lsap == 'device':        # (the host path goes through `assign`, recorded above)
+                assigned.extend(r.gt_inds.clone() for r in rs)
+            return rs
+        a.assign_batch = recb
     track = None
     if case['video']:
         out = head.forward_train_with_previous(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,

@@ -181,51 +181,51 @@ class KernelIterHead(BaseRoIHead):
         wrappers.  `stage_kwargs(stage)` gives extra keyword arguments of `_mask_forward` (the last stage's previous-frame link)."""
         if not self.mask_assigner:
             raise RuntimeError('forward_train needs train_cfg (one dict per stage with assigner / sampler / pos_weight)')
-        import torch.nn.functional as F
         num_imgs = len(img_metas)
         up = self.mask_head[0].mask_upsample_stride
-        prev_mask_preds = (F.interpolate(mask_preds.detach(), scale_factor=up, mode='bilinear', align_corners=False)
-                           if up > 1 else mask_preds.detach())
-        prev_cls_score = cls_score.detach() if cls_score is not None else [None] * num_imgs
+        # what stage s is assigned on: the predictions it RECEIVES (reference :150-156, :225-226) — or, with `post_assign`, its own
+        assign_masks = self._upsample(mask_preds.detach(), up) if up > 1 else mask_preds.detach()
+        assign_cls = cls_score.detach() if cls_score is not None else None
         if self.hard_target:
             gt_masks = [g.bool().float() for g in gt_masks]
         object_feats = proposal_feats
-        all_stage_loss, assign_results, mask_results = {}, [], None
+        all_stage_loss, assign_results, mask_results = {}, None, None
         if self.mask_assigner and hasattr(self.mask_assigner[0], 'validate_labels'):
-            # the labels do not change between stages: one range check (one host read) for the whole step
+            # the labels do not change between stages: one range check for the whole step (on the device, reported asynchronously)
             self.mask_assigner[0].validate_labels(gt_labels, self.num_thing_classes)
         for stage in range(self.num_stages):
             extra = stage_kwargs(stage) if stage_kwargs is not None else {}
             mask_results = self._mask_forward(stage, x, object_feats, mask_preds, img_metas, **extra)
-            mask_preds = mask_results['mask_preds']
-            scaled_mask_preds = mask_results['scaled_mask_preds']
-            cls_score = mask_results['cls_score']
-            object_feats = mask_results['object_feats']
+            mask_preds, scaled_mask_preds = mask_results['mask_preds'], mask_results['scaled_mask_preds']
+            cls_score, object_feats = mask_results['cls_score'], mask_results['object_feats']
             if self.post_assign:
-                prev_mask_preds, prev_cls_score = scaled_mask_preds.detach(), cls_score.detach()
-            sampling_results = []
-            if stage < self.assign_stages:
-                assign_results = []
-            for i in range(num_imgs):
-                if stage < self.assign_stages:
-                    mask_for_assign = prev_mask_preds[i][:self.num_proposals]
-                    cls_for_assign = (prev_cls_score[i][:self.num_proposals, :self.num_thing_classes]
-                                      if prev_cls_score[i] is not None else None)
-                    assign_results.append(self.mask_assigner[stage].assign(mask_for_assign, cls_for_assign, gt_masks[i],
-                                                                           gt_labels[i], img_meta=img_metas[i]))
-                sampling_results.append(self.mask_sampler[stage].sample(assign_results[i], scaled_mask_preds[i], gt_masks[i]))
-            mask_targets = self.mask_head[stage].get_targets(sampling_results, gt_masks, gt_labels, self.train_cfg[stage], True,
-                                                             gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
-            single_stage_loss = self.mask_head[stage].loss(object_feats, cls_score, scaled_mask_preds, *mask_targets,
-                                                           imgs_whwh=imgs_whwh)
-            for key, value in single_stage_loss.items():
+                assign_masks, assign_cls = scaled_mask_preds.detach(), cls_score.detach()
+            if stage < self.assign_stages:       # later stages keep the last assignment (:196)
+                assign_results = self._assign_batch(stage, assign_masks, assign_cls, gt_masks, gt_labels, img_metas)
+            sampler = self.mask_sampler[stage]
+            sampling_results = [sampler.sample(assign_results[i], scaled_mask_preds[i], gt_masks[i]) for i in range(num_imgs)]
+            head = self.mask_head[stage]
+            mask_targets = head.get_targets(sampling_results, gt_masks, gt_labels, self.train_cfg[stage], True,
+                                            gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+            for key, value in head.loss(object_feats, cls_score, scaled_mask_preds, *mask_targets, imgs_whwh=imgs_whwh).items():
                 all_stage_loss[f's{stage}_{key}'] = value * self.stage_loss_weights[stage]
             if not self.post_assign:
-                prev_mask_preds, prev_cls_score = scaled_mask_preds.detach(), cls_score.detach()
+                assign_masks, assign_cls = scaled_mask_preds.detach(), cls_score.detach()
         if self.mask_assigner and hasattr(self.mask_assigner[0], 'check_status'):
             # device assignments report invalid cost matrices through status words: ONE read per step for all stages
             self.mask_assigner[0].check_status(*self.mask_assigner[1:], wait=False)   # (reported at a later poll: no stall)
         return all_stage_loss, mask_results
+
+    def _assign_batch(self, stage, masks, cls, gt_masks, gt_labels, img_metas):
+        """One-to-one assignment of a stage for every image of the batch: proposals only (the stuff kernels have fixed targets), thing
+        logits only.  One LSAP launch for the batch when the assigner offers it (`MaskHungarianAssigner.assign_batch`)."""
+        a, Np, T = self.mask_assigner[stage], self.num_proposals, self.num_thing_classes
+        n = masks.shape[0]
+        m = [masks[i][:Np] for i in range(n)]
+        c = [cls[i][:Np, :T] if cls is not None else None for i in range(n)]
+        if hasattr(a, 'assign_batch'):
+            return a.assign_batch(m, c, gt_masks, gt_labels, img_metas)
+        return [a.assign(m[i], c[i], gt_masks[i], gt_labels[i], img_meta=img_metas[i]) for i in range(n)]
 
     def forward_train(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, gt_bboxes_ignore=None,
                       imgs_whwh=None, gt_bboxes=None, gt_sem_seg=None, gt_sem_cls=None):

@@ -168,6 +168,29 @@ class MaskHungarianAssigner:
         res.host_pos_inds = np.sort(np.asarray(rows_host, dtype=np.int64))   # the LSAP ran on the host: the sampler needs no device nonzero
         return res
 
+    def assign_batch(self, bbox_preds, cls_preds, gt_bboxes, gt_labels, img_metas=None):
+        """`assign` for the images of a batch (lists of per-image tensors; `cls_preds` entries may be None): the cost matrices are
+        computed image by image, ALL linear sum assignments run in ONE launch (one wavefront per image, vkn_lsap_batch_f32).
+        -> list of AssignResult, identical to calling `assign` per image."""
+        n = len(bbox_preds)
+        if self.lsap != 'device' or any(g.size(0) == 0 or g.size(0) > 256 or p.size(0) == 0 or p.size(0) > 256
+                                        for g, p in zip(gt_bboxes, bbox_preds)):
+            return [self.assign(bbox_preds[i], cls_preds[i], gt_bboxes[i], gt_labels[i],
+                                img_meta=img_metas[i] if img_metas is not None else None) for i in range(n)]
+        costs = [self.cost_matrix(bbox_preds[i], cls_preds[i], gt_bboxes[i], gt_labels[i]) for i in range(n)]
+        gts, rows, cols, status = ops.lsap_device(costs)
+        self.pending_status.append(status)
+        del self.pending_status[:-64]
+        out = []
+        for i in range(n):
+            r, c = rows[i].long(), cols[i].long()
+            labels = bbox_preds[i].new_full((bbox_preds[i].size(0),), -1, dtype=torch.long)
+            labels[r] = gt_labels[i].to(device=labels.device, dtype=labels.dtype)[c]
+            res = AssignResult(gt_bboxes[i].size(0), gts[i], None, labels=labels)
+            res.device_pos_inds, res.status = r, status
+            out.append(res)
+        return out
+
     def check_status(self, *others, wait=True):
         """Hand the status words of the device assignments issued since the last call by this assigner (and `others`: the per-stage
         assigners of a head) to the asynchronous flag queue and poll it.  `wait=True` (default): block until every queued flag is
