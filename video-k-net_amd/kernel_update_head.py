@@ -544,9 +544,9 @@ class KernelUpdateHead(nn.Module):
           mask_targets  zeros, matched <- their gt mask, present stuff rows <- gt_sem_seg;  mask_weights 1 on exactly those rows."""
         r0 = sampling_results[0]
         B = len(sampling_results)
-        dev, dt = r0.pos_masks.device, r0.pos_masks.dtype
-        H, W = r0.pos_masks.shape[-2:]
-        N = int(r0.pos_inds.shape[0]) + r0.num_neg
+        dev, dt = r0.device, r0.mask_dtype
+        H, W = r0.mask_shape[-2:]
+        N = r0.num_pos + r0.num_neg
         with_sem = gt_sem_seg is not None and gt_sem_cls is not None and all(g is not None for g in gt_sem_seg) \
             and all(g is not None for g in gt_sem_cls)
         S, T = (self.num_stuff_classes, self.num_thing_classes) if with_sem else (0, 0)
@@ -555,7 +555,7 @@ class KernelUpdateHead(nn.Module):
         pw = 1.0 if pw <= 0 else float(pw)
         pos_rows, pos_lab, pos_msk, sem_rows, sem_lab, sem_msk = [], [], [], [], [], []
         for i, r in enumerate(sampling_results):
-            if int(r.pos_inds.shape[0]) + r.num_neg != N:
+            if r.num_pos + r.num_neg != N:
                 raise ValueError('all images of a batch must carry the same number of predictions')
             pos_rows.append(r.pos_inds + i * Ns)
             pos_lab.append(r.pos_gt_labels)
