@@ -574,7 +574,7 @@ class KernelUpdateHead(nn.Module):
         if pos_rows.numel() > 0:
             labels[pos_rows] = torch.cat(pos_lab)
             mask_targets[pos_rows] = torch.cat(pos_msk).to(dt)
-            row_weight[pos_rows] = 1.0
+            row_weight.index_fill_(0, pos_rows, 1.0)        # (x[idx] = python scalar would copy the scalar host -> device: a stall)
             if pw != 1.0:
                 label_weights.view(B * Ns, ncls)[:, :(T if with_sem else ncls)][pos_rows] = pw
         if with_sem:
@@ -583,7 +583,7 @@ class KernelUpdateHead(nn.Module):
                 sem_rows = torch.cat(sem_rows)
                 labels[sem_rows] = torch.cat(sem_lab)
                 mask_targets[sem_rows] = torch.cat(sem_msk).to(dt)
-                row_weight[sem_rows] = 1.0
+                row_weight.index_fill_(0, sem_rows, 1.0)
                 pos_rows = torch.sort(torch.cat([pos_rows, sem_rows]))[0]
         mask_weights = row_weight.view(-1, 1, 1).expand(-1, H, W)      # (a view: the reference fills a second [B*Ns, H, W] tensor)
         self._targets_stash = (labels, pos_rows)
