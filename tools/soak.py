@@ -177,7 +177,7 @@ def t_head_fused():
     """fused decode->gather pass vs bit words vs fp32 logits between stages, side-stream vs serial link: bit-identical outputs."""
     from test_host_logic import _cfg
     C = int(rng.choice([64, 128, 256]))
-    N = int(rng.integers(3, 170))
+    N = int(rng.integers(3, 257))                                      # (> 128: two row chunks in one fused launch)
     H, W = int(rng.choice([8, 16, 32])), int(rng.choice([8, 16, 64]))   # H * W % 64 == 0: the fused pass is eligible
     B = int(rng.integers(1, 6))
     S = int(rng.integers(2, 4))
