@@ -59,7 +59,7 @@ def main():
             base = None
             for v in [int(t) for t in args.variants.split(',')]:
                 # v < 100: k_fused_dgs variant bits; 100 / 101 = k_fused_pp / its profile build; 200 / 201 = k_fused_pq (shipped) / its profile build
-                os.environ['VKN_FUSED'] = {100: '3', 101: '4', 200: '5', 201: '6', 202: '7', 203: '8', 204: '9', 300: '10', 301: '11', 302: '10', 400: '12', 401: '13', 402: '14', 403: '15', 404: '16'}.get(v, '2')
+                os.environ['VKN_FUSED'] = {100: '3', 101: '4', 200: '5', 201: '6', 202: '7', 203: '8', 204: '9', 300: '10', 301: '11', 302: '10', 400: '12', 401: '13', 402: '14', 403: '15', 404: '16', 305: '17', 306: '18'}.get(v, '2')
                 os.environ['VKN_FUSED_CHUNK_LOOP'] = '1' if v == 302 else '0'   # 302: k_fused_il with one launch per 128-row chunk (N > 128)
                 os.environ['VKN_FUSED_V'] = str(v)
                 out = vkn.ops.decode_gather(x, hi, lo, N, kb)

@@ -969,6 +969,7 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
 
     if (wave < 4) {
         // =============================================================== decode role: n-block `wave`
+        if constexpr (PF == 2) __builtin_amdgcn_s_setprio(2);   // (debug A/B: decode waves first at the issue arbiter)
         const bool has_dec = wave < NB;
         half8 Ah[KS], Al[KS];
         {
@@ -1079,6 +1080,7 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
         if (has_dec && lane < 32 && n0 + wave * 32 + lane < NPT) cntp[((size_t)b * G + gidx) * NPT + n0 + wave * 32 + lane] = (float)cnt_i;
     } else {
         // =============================================================== gather role: channel blocks wave - 4 (+ 4)
+        if constexpr (PF == 3) __builtin_amdgcn_s_setprio(2);   // (debug A/B: gather waves first)
         const int gw = wave - 4;
         f32x16 accg[CBW][NB];
 #pragma unroll
@@ -1596,7 +1598,7 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
     const size_t lds = fuseds_lds_bytes(C);
 #endif
 #ifdef VKN_DEBUG
-    const bool one_pass = (variant >= 10 && variant <= 16) && !vkn_dbg_env("VKN_FUSED_CHUNK_LOOP", 0);
+    const bool one_pass = (variant >= 10 && variant <= 18) && !vkn_dbg_env("VKN_FUSED_CHUNK_LOOP", 0);
 #else
     const bool one_pass = true;
 #endif
@@ -1656,6 +1658,8 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
         else if (variant == 15 && cfg2) FU_LAUNCH_W4(4, 256, 0, 3);                        \
         else if (variant == 16 && cfg2) FU_LAUNCH_W4(4, 256, 0, 4);                        \
         else if (variant == 11 && cfg2) FU_LAUNCH_IL(4, 256, 0, 1);                        \
+        else if (variant == 17 && cfg2) FU_LAUNCH_IL(4, 256, 0, 2);                        \
+        else if (variant == 18 && cfg2) FU_LAUNCH_IL(4, 256, 0, 3);                        \
         else if (variant == 5) FU_LAUNCH_PQ(NBV, CV, XHV, 0);                              \
         else if (cfg2 && vv != FS_V_DEFAULT) {                                             \
             switch (vv) {                                                                  \
