@@ -763,11 +763,11 @@ __global__ __launch_bounds__(256) void k_ku_mix(const float* __restrict__ params
 // Nk <= 256, hd <= 64, hd % 4 == 0.  The kernel is LDS-bandwidth bound (45 KB of LDS reads per query row with scalar reads),
 // so every LDS access is 16 bytes: K/V rows padded to hd+4 floats (conflict-free ds_read_b128), the query row is held in
 // registers, the P.V product gives each lane 4 output channels and splits the keys over 64/(hd/4) lane groups.
-template <int HD4>  // hd / 4
-__global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
+template <int HD4, int NW = 4>  // hd / 4; waves per workgroup
+__global__ __launch_bounds__(64 * NW) void k_attn(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
                                               const float* __restrict__ Vp, int ldkv, float* __restrict__ out, int ldo,
                                               int Nq, int Nk, float scale, int rpw) {
-    // rpw: query rows per workgroup (a multiple of 4: rpw / 4 consecutive rows per wave)
+    // rpw: query rows per workgroup (a multiple of NW: rpw / NW consecutive rows per wave)
     constexpr int hd = HD4 * 4, ldh = hd + 4;
     constexpr int NGRP = 64 / HD4;  // lane groups of the P.V product (HD4 is a power of two <= 16)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -775,18 +775,19 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int l
     float* Ks = smem;             // [Nk][hd+4]
     float* Vs = Ks + Nk * ldh;    // [Nk][hd+4]
     float* qs = Vs + Nk * ldh;    // [rpw][hd]  (pre-scaled query rows of this workgroup)
-    float* ps = qs + rpw * hd;    // [4][256]
+    float* ps = qs + rpw * hd;    // [NW][256]
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.z * rpw;
     // K/V staging: one float4 per thread per step, 4 steps batched (8 independent 16-B loads in flight before the LDS writes)
     const int nvec = Nk * HD4;
-    for (int i0 = tid; i0 < nvec; i0 += 256 * 4) {
+    constexpr int NT = 64 * NW;
+    for (int i0 = tid; i0 < nvec; i0 += NT * 4) {
         f32x4 kv[4], vv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = min(i0 + u * 256, nvec - 1);
+            const int i = min(i0 + u * NT, nvec - 1);
             const int j = i / HD4, q4 = i - j * HD4;
             const size_t off = ((size_t)b * Nk + j) * ldkv + h * hd + 4 * q4;
             kv[u] = *reinterpret_cast<const f32x4*>(Kp + off);
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int l
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 256;
+            const int i = i0 + u * NT;
             if (i < nvec) {
                 const int j = i / HD4, q4 = i - j * HD4;
                 *reinterpret_cast<f32x4*>(Ks + j * ldh + 4 * q4) = kv[u];
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int l
             }
         }
     }
-    for (int i = tid; i < rpw * HD4; i += 256) {
+    for (int i = tid; i < rpw * HD4; i += NT) {
         const int r = i / HD4, q4 = i - r * HD4;
         if (row0 + r < Nq) {
             f32x4 v = *reinterpret_cast<const f32x4*>(Q + ((size_t)b * Nq + row0 + r) * ldq + h * hd + 4 * q4);
@@ -812,8 +813,8 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ Q, int l
     __syncthreads();
     const int grp = lane / HD4, dl4 = lane - grp * HD4;
     float* myp = ps + wave * 256;
-    const int i_begin = row0 + wave * (rpw >> 2);
-    const int i_end = min(Nq, i_begin + (rpw >> 2));
+    const int i_begin = row0 + wave * (rpw / NW);
+    const int i_end = min(Nq, i_begin + (rpw / NW));
     for (int i = i_begin; i < i_end; ++i) {
         f32x4 qv[HD4];
 #pragma unroll
@@ -1151,14 +1152,16 @@ int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int
     // 16 query rows per workgroup.  64 (K / V of a (frame, head) staged twice instead of eight times) was measured at 32 frames
     // per call: 36 us instead of 30 — the kernel is bound by the serial per-row chain of a wave, not by the staging
     const int rpw = 16;
-    const size_t lds = ((size_t)2 * Nk * (hd + 4) + (size_t)rpw * hd + 4 * 256) * sizeof(float);
+    // (8 waves x 2 rows instead of 4 x 4 — template parameter NW — was measured: 28-31 us at 32 frames either way)
+    const int nw = 4;
+    const size_t lds = ((size_t)2 * Nk * (hd + 4) + (size_t)rpw * hd + (size_t)nw * 256) * sizeof(float);
     if (lds > 160 * 1024) return VKN_E_SHAPE;   // (N = 216 kernels of 32-wide heads: 68 KB — beyond the 64 KB default limit)
     dim3 grid(heads, B, (Nq + rpw - 1) / rpw);
     const float scale = 1.0f / sqrtf((float)hd);
 #define ATT_CASE(H4)                                                                                                      \
     case H4:                                                                                                              \
-        if (lds > 64 * 1024) VKN_ALLOW_FULL_LDS(k_attn<H4>);                                                              \
-        hipLaunchKernelGGL(k_attn<H4>, grid, dim3(256), lds, stream, Q, ldq, K, V, ldkv, out, ldo, Nq, Nk, scale, rpw);   \
+        if (lds > 64 * 1024) VKN_ALLOW_FULL_LDS((k_attn<H4, 4>));                                                         \
+        hipLaunchKernelGGL((k_attn<H4, 4>), grid, dim3(256), lds, stream, Q, ldq, K, V, ldkv, out, ldo, Nq, Nk, scale, rpw); \
         break;
     switch (hd / 4) {
         ATT_CASE(1) ATT_CASE(2) ATT_CASE(4) ATT_CASE(8) ATT_CASE(16)
