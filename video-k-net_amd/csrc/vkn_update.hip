@@ -867,6 +867,168 @@ __global__ __launch_bounds__(64 * NW) void k_attn(const float* __restrict__ Q, i
     }
 }
 
+// Attention on the matrix cores (north_star: "MFMA only for the dense N x C kernel-attention contraction"): one workgroup per
+// (frame, head), one wave per block of 32 queries; both contractions are 32x32x16 f16 MFMAs on hi + lo split operands
+// (hi hi + hi lo + lo hi, products exact in fp32 — the split of the gather / decode kernels, same fp32-class accuracy):
+//   S^T = K . Q^T      A = K rows from LDS (hi / lo planes), B = the wave's 32 scaled queries, split in registers.  The accumulator
+//                      layout puts a QUERY on a lane column, so the softmax over the keys is a reduction over a lane's own registers
+//                      plus one exchange with lane ^ 32 — no row-wise cross-lane reductions;
+//   O   = P . V        A = P: the normalised probabilities ARE already an A fragment (row = query = lane column) if the contraction
+//                      index walks the keys in the order the accumulator holds them; B = V^T from LDS, stored transposed with exactly
+//                      that key permutation (position of key 32 kb + jj: 32 kb + 16 (jj >> 4) + 8 ((jj >> 2) & 1) + 4 ((jj >> 3) & 1)
+//                      + (jj & 3)), so a B fragment is one 16-byte LDS read.  Output rows = queries, lane = channel: coalesced stores.
+// HD: head width (16 / 32 / 64), NKB: 32-key blocks (keys >= Nk are masked to -inf / zero).  Replaces k_attn's VALU loops
+// (one wave per query row: 28-31 us per launch at 32 frames).
+template <int HD, int NKB>
+__global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
+                                                   const float* __restrict__ Vp, int ldkv, float* __restrict__ out, int ldo,
+                                                   int Nq, int Nk, float scale) {
+    constexpr int NKP = NKB * 32;            // padded key count
+    constexpr int KLD = HD + 8;              // halfs per K row (16-byte aligned rows, conflict-free 16-B reads)
+    constexpr int VLD = NKP + 8;             // halfs per V^T row
+    constexpr int DP = HD < 32 ? 32 : HD;    // channel rows of V^T (one or two 32-column blocks of O)
+    constexpr int NDB = DP / 32;
+    constexpr int KS = HD / 16;              // k-steps of K . Q^T
+    extern __shared__ __attribute__((aligned(16))) char smem_am[];
+    _Float16* Kh = reinterpret_cast<_Float16*>(smem_am);   // [NKP][KLD]
+    _Float16* Kl = Kh + NKP * KLD;
+    _Float16* Vh = Kl + NKP * KLD;                          // [DP][VLD]  (V^T, keys permuted)
+    _Float16* Vl = Vh + DP * VLD;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    // ---- stage K (rows) and V (transposed, permuted) as f16 hi / lo
+    for (int i = tid; i < NKP * (HD / 4); i += 256) {
+        const int j = i / (HD / 4), d4 = i - j * (HD / 4);
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (j < Nk) {
+            const size_t off = ((size_t)b * Nk + j) * ldkv + h * HD + 4 * d4;
+            kv = *reinterpret_cast<const f32x4*>(Kp + off);
+            vv = *reinterpret_cast<const f32x4*>(Vp + off);
+        }
+        half4 kh, kl;
+        const int jj = j & 31;
+        const int pos = (j & ~31) + 16 * (jj >> 4) + 8 * ((jj >> 2) & 1) + 4 * ((jj >> 3) & 1) + (jj & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 hh, ll;
+            vkn_split_f16(kv[e], hh, ll);
+            kh[e] = hh;
+            kl[e] = ll;
+            vkn_split_f16(vv[e], hh, ll);
+            Vh[(4 * d4 + e) * VLD + pos] = hh;
+            Vl[(4 * d4 + e) * VLD + pos] = ll;
+        }
+        *reinterpret_cast<half4*>(Kh + j * KLD + 4 * d4) = kh;
+        *reinterpret_cast<half4*>(Kl + j * KLD + 4 * d4) = kl;
+    }
+    if (HD < 32)   // channel rows HD .. 31 of V^T: zeros (they feed output columns nobody stores, but must be finite)
+        for (int i = tid; i < (DP - HD) * NKP; i += 256) {
+            const int d = HD + i / NKP, k = i - (i / NKP) * NKP;
+            Vh[d * VLD + k] = (_Float16)0.f;
+            Vl[d * VLD + k] = (_Float16)0.f;
+        }
+    __syncthreads();
+    const int qb = blockIdx.z * 4 + wave;
+    if (qb * 32 >= Nq) return;   // (no barrier below)
+    // ---- the wave's 32 queries as B fragments: lane (g, li) = query li, channels 16 ks + 8 g .. + 7, scaled, split
+    half8 qh[KS], ql[KS];
+    {
+        const int q = min(qb * 32 + li, Nq - 1);
+        const float* qp = Q + ((size_t)b * Nq + q) * ldq + h * HD + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 hh, ll;
+                vkn_split_f16((e < 4 ? a0[e] : a1[e - 4]) * scale, hh, ll);
+                qh[ks][e] = hh;
+                ql[ks][e] = ll;
+            }
+        }
+    }
+    // ---- S^T = K . Q^T: acc[kb][r] at lane (g, li) = score of key 32 kb + cd_row(r, lane) for query li
+    f32x16 acc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const half8 ah = *reinterpret_cast<const half8*>(Kh + (kb * 32 + li) * KLD + 16 * ks + 8 * g);
+            const half8 al = *reinterpret_cast<const half8*>(Kl + (kb * 32 + li) * KLD + 16 * ks + 8 * g);
+            acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], acc[kb], 0, 0, 0);
+            acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], acc[kb], 0, 0, 0);
+            acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], acc[kb], 0, 0, 0);
+        }
+    }
+    // ---- softmax over the keys of this lane's query (its own registers + the other half-wave)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = (kb * 32 + vkn_cd_row(r, lane)) < Nk;
+            acc[kb][r] = ok ? acc[kb][r] : -INFINITY;
+            mx = fmaxf(mx, acc[kb][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ev = expf(acc[kb][r] - mx);   // (-inf -> 0)
+            acc[kb][r] = ev;
+            sum += ev;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    // ---- O = P . V: k-step t = (kb, half): the lane's registers 8 half .. 8 half + 7 of acc[kb] ARE the A fragment
+    f32x16 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            half8 ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 hh, ll;
+                vkn_split_f16(acc[kb][8 * hf + e] * inv, hh, ll);
+                ph[e] = hh;
+                pl[e] = ll;
+            }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const int voff = (db * 32 + li) * VLD + kb * 32 + 16 * hf + 8 * g;
+                const half8 vh = *reinterpret_cast<const half8*>(Vh + voff);
+                const half8 vl = *reinterpret_cast<const half8*>(Vl + voff);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o[db], 0, 0, 0);
+            }
+        }
+    // ---- o[db][r] at lane (g, li) = output of query 32 qb + cd_row(r, lane), channel 32 db + li
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+        const int d = db * 32 + li;
+        if (d < HD) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qb * 32 + vkn_cd_row(r, lane);
+                if (q < Nq) out[((size_t)b * Nq + q) * ldo + h * HD + d] = o[db][r];
+            }
+        }
+    }
+}
+
 // Attention with MORE than 256 keys per query (the clip-level query merge of the VIS heads: Nk = frames * kernels, a query row
 // attends to every frame's kernels — knet_vis/tracker/kernel_frame_iter_head.py:142-160).  One wave per query row, grid
 // (heads, B, ceil(Nq / 4)); K / V stay in global memory (B * Nk * hd floats per head: cache-resident), the row's scores live in
@@ -1149,6 +1311,37 @@ int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int
         VKN_CHECK_LAUNCH();
         return VKN_OK;
     }
+    if ((hd == 16 || hd == 32 || hd == 64) && Nk <= 256 && !vkn_dbg_env("VKN_ATTN_VALU", 0)) {   // matrix-core attention
+        const int nkb = (Nk + 31) / 32;
+        const int nkbt = nkb <= 1 ? 1 : nkb <= 2 ? 2 : nkb <= 4 ? 4 : nkb <= 6 ? 6 : 8;
+        const int dp = hd < 32 ? 32 : hd;
+        const size_t ldsm = ((size_t)2 * nkbt * 32 * (hd + 8) + (size_t)2 * dp * (nkbt * 32 + 8)) * sizeof(_Float16);
+        dim3 gm(heads, B, (Nq + 127) / 128);
+        const float sc = 1.0f / sqrtf((float)hd);
+#define ATTM_LAUNCH(HDV, NKBV)                                                                                            \
+    do {                                                                                                                  \
+        if (ldsm > 64 * 1024) VKN_ALLOW_FULL_LDS((k_attn_mfma<HDV, NKBV>));                                               \
+        hipLaunchKernelGGL((k_attn_mfma<HDV, NKBV>), gm, dim3(256), ldsm, stream, Q, ldq, K, V, ldkv, out, ldo, Nq, Nk, sc); \
+    } while (0)
+#define ATTM_HD(HDV)                                       \
+    do {                                                   \
+        switch (nkbt) {                                    \
+            case 1: ATTM_LAUNCH(HDV, 1); break;            \
+            case 2: ATTM_LAUNCH(HDV, 2); break;            \
+            case 4: ATTM_LAUNCH(HDV, 4); break;            \
+            case 6: ATTM_LAUNCH(HDV, 6); break;            \
+            default: ATTM_LAUNCH(HDV, 8); break;           \
+        }                                                  \
+    } while (0)
+        if (hd == 16) ATTM_HD(16);
+        else if (hd == 32) ATTM_HD(32);
+        else ATTM_HD(64);
+#undef ATTM_HD
+#undef ATTM_LAUNCH
+        VKN_CHECK_LAUNCH();
+        return VKN_OK;
+    }
+    // (head widths 4 / 8: the VALU kernel)
     // 16 query rows per workgroup.  64 (K / V of a (frame, head) staged twice instead of eight times) was measured at 32 frames
     // per call: 36 us instead of 30 — the kernel is bound by the serial per-row chain of a wave, not by the staging
     const int rpw = 16;
