@@ -165,8 +165,20 @@ def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
     prev = torch.randn(B, N, C, 1, 1, generator=g).to(device)
     metas = [dict() for _ in range(B)]
 
+    # the step runs on a stream of its own: the chain graphs are captured on the stream the step runs on, so no parameter gradient
+    # crosses streams in backward (KernelUpdateHead.enable_chain_graphs); gradients arrive as tensors and fill their bucket with one
+    # multi-tensor copy (BucketedGradAllReducer.zero_grad(set_to_none=True)) instead of one add_ per parameter
+    torch.cuda.synchronize()
+    train_stream = torch.cuda.Stream(device=device)
+
     def step():
-        reducer.zero_grad()
+        if getattr(args, 'train_default_stream', False):    # A/B
+            return step_()
+        with torch.cuda.stream(train_stream):
+            return step_()
+
+    def step_():
+        reducer.zero_grad(set_to_none=not getattr(args, 'train_add_grads', False))
         if x.grad is not None:
             x.grad = None
         out = head.forward_train_with_previous(x, pf, mp, None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
@@ -225,6 +237,8 @@ def main():
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the extra data points of `breakdown` that launch other batch sizes / several clips (profiling runs)')
     ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
+    ap.add_argument('--train-default-stream', action='store_true', help='--train A/B: run the step on the default stream (chain graphs captured on a side stream)')
+    ap.add_argument('--train-add-grads', action='store_true', help='--train A/B: zero the gradient buckets and add into their views instead of set_to_none + one batched copy')
     ap.add_argument('--streams', type=int, default=1,
                     help='frame groups of the clip processed on separate HIP streams (measured: no gain, 1 is fastest)')
     ap.add_argument('--x-storage', default='fp32', choices=['fp32', 'fp16', 'bf16'],

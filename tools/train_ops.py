@@ -22,7 +22,14 @@ gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, prev = L['gt_masks'], L['gt_labels'
 
 
 def step():
-    reducer.zero_grad(); x.grad = None
+    if os.environ.get('DEFSTREAM'):
+        return step_()
+    with torch.cuda.stream(L['train_stream']):
+        return step_()
+
+
+def step_():
+    reducer.zero_grad(set_to_none=not os.environ.get('ADDGRADS')); x.grad = None
     out = head.forward_train_with_previous(x, pf, mp, None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls,
                                            previous_obj_feats=prev)
     loss = sum(v for k, v in out[0].items() if 'loss' in k) + 1e-3 * (out[5] ** 2).mean()

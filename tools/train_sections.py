@@ -25,7 +25,7 @@ def sync():
     torch.cuda.synchronize(); return time.perf_counter()
 tot = [0.0, 0.0, 0.0]
 for it in range(13):
-    reducer.zero_grad(); x.grad = None
+    reducer.zero_grad(set_to_none=not os.environ.get('ADDGRADS')); x.grad = None
     t0 = sync()
     out = head.forward_train_with_previous(x, pf, mp, None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls,
                                            previous_obj_feats=prev)

@@ -94,9 +94,14 @@ class BucketedGradAllReducer:
     * one synchronised backward per step: `zero_grad -> backward -> finalize -> optimizer.step`.  Gradient accumulation: run the
       earlier backward passes under `with reducer.no_sync():` — nothing is launched there, gradients just add up in the buckets.
       A second backward outside `no_sync()` before `finalize()` would add to a buffer that is already being reduced: it raises.
-    * ANY `zero_grad` is fine.  `reducer.zero_grad()` zeroes the flat buffers.  torch's default `optimizer.zero_grad()` /
-      `module.zero_grad()` (set_to_none=True) DROPS the `.grad` views; the hook notices (`p.grad` is no longer the bucket's view),
-      copies the fresh gradient into the view and re-attaches it, so the collective always reduces the real gradients.
+    * ANY `zero_grad` is fine.  `reducer.zero_grad()` zeroes the flat buffers: backward then ADDS every gradient into its view
+      (one `add_` launch per parameter).  `reducer.zero_grad(set_to_none=True)` — or torch's default `optimizer.zero_grad()` /
+      `module.zero_grad()` — DROPS the `.grad` views instead: autograd then hands each parameter the gradient tensor itself (no
+      kernel), the hook notes it, and the moment a bucket is complete its gradients are copied into the flat buffer by ONE
+      multi-tensor launch (`torch._foreach_copy_`) and the views are re-attached, so the collective always reduces the real
+      gradients.  This is the cheap mode for a step with one backward (~150 launches and dispatcher calls less per step of the
+      K-Net head); the gradient tensors may alias a captured graph's static buffers (`enable_chain_graphs`), which is fine because
+      they are consumed before the next replay.  Under `no_sync()` a dropped view is filled and re-attached at once.
     * parameters that take part in no backward (the video head builds its link modules in every stage but uses the last stage's
       only) are learned during the first synchronised step: from the second step on a bucket waits only for the parameters that
       did fire, so stage buckets with unused members also overlap with backward.  When the set of used parameters changes
@@ -124,7 +129,7 @@ class BucketedGradAllReducer:
         self.buckets = []
         for (key, dev, dt), params in groups.items():
             flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=dt)
-            b = dict(key=key, flat=flat, params=params, views=[], fired=set(), expect=None, handle=None, grew=False)
+            b = dict(key=key, flat=flat, params=params, views=[], fired=set(), expect=None, handle=None, grew=False, pending=set())
             off = 0
             for i, p in enumerate(params):
                 v = flat[off:off + p.numel()].view_as(p)
@@ -134,7 +139,18 @@ class BucketedGradAllReducer:
                 p.register_post_accumulate_grad_hook(self._make_hook(b, i))
             self.buckets.append(b)
 
+    @staticmethod
+    def _flush(b):
+        """Gradients that arrived as tensors of their own (dropped views): into the flat buffer with one multi-tensor copy."""
+        if b['pending']:
+            idx = sorted(b['pending'])
+            torch._foreach_copy_([b['views'][i] for i in idx], [b['params'][i].grad for i in idx])
+            for i in idx:
+                b['params'][i].grad = b['views'][i]
+            b['pending'] = set()
+
     def _launch(self, b):
+        self._flush(b)
         b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _make_hook(self, b, i):
@@ -142,10 +158,13 @@ class BucketedGradAllReducer:
             view = b['views'][i]
             g = p.grad
             if g is not view and (g is None or g.data_ptr() != view.data_ptr()):
-                # `zero_grad(set_to_none=True)` (torch's default) or an external `p.grad = ...` dropped the view
-                if g is not None:
-                    view.copy_(g)
-                p.grad = view
+                # `zero_grad(set_to_none=True)` or an external `p.grad = ...` dropped the view
+                if g is not None and self._sync:
+                    b['pending'].add(i)              # stays `p.grad` (a second use of the parameter adds into it) until the bucket is flushed
+                else:
+                    if g is not None:
+                        view.copy_(g)
+                    p.grad = view
             if b['handle'] is not None:
                 raise RuntimeError(f"BucketedGradAllReducer: a gradient arrived in bucket '{b['key']}' while its all-reduce is in "
                                    'flight (a second backward before finalize() — wrap the earlier ones in no_sync() — or the set '
@@ -180,19 +199,26 @@ class BucketedGradAllReducer:
         for b in self.buckets:
             b['expect'] = None
 
-    def zero_grad(self):
-        """Zero the flat buffers, (re-)attach the parameters' `.grad` views and re-arm the hooks."""
+    def zero_grad(self, set_to_none=False):
+        """Re-arm the hooks and either zero the flat buffers and (re-)attach the parameters' `.grad` views (gradients are added
+        into the buckets), or — `set_to_none=True` — drop the views (gradients arrive as tensors, one batched copy per bucket)."""
         for b in self.buckets:
-            b['flat'].zero_()
-            for p, v in zip(b['params'], b['views']):
-                if p.grad is not v:
-                    p.grad = v
-            b['fired'], b['handle'], b['grew'] = set(), None, False
+            if set_to_none:
+                for p in b['params']:
+                    p.grad = None
+            else:
+                b['flat'].zero_()
+                for p, v in zip(b['params'], b['views']):
+                    if p.grad is not v:
+                        p.grad = v
+            b['fired'], b['handle'], b['grew'], b['pending'] = set(), None, False, set()
 
     def finalize(self):
         """Launch the collectives of the buckets that are not in flight yet (first step, unused members, accumulation), wait for
         all of them, then average.  Call after the step's last `backward()` and before `optimizer.step()`."""
         for b in self.buckets:
+            if b['handle'] is None:
+                self._flush(b)
             for p, v in zip(b['params'], b['views']):
                 # `p.grad is None`: the parameter took no part in this step after a set_to_none zero_grad — it stays None (the
                 # optimizer skips it; whatever its slot of the flat buffer holds is reduced along and never read)

@@ -314,7 +314,13 @@ class KernelUpdateHead(nn.Module):
         """Run the chain's forward and backward as captured hipGraphs (`torch.cuda.make_graphed_callables`): one graph pair per
         (shapes, requires-grad pattern, train / eval mode), captured at first use.  The values are those of the eager chain (same
         kernels, same order).  Parameters may be UPDATED in place (optimizers do) but not REPLACED: after `load_state_dict` with
-        `assign=True`, `.to()` or re-initialisation call `enable_chain_graphs()` again (it drops the captured graphs)."""
+        `assign=True`, `.to()` or re-initialisation call `enable_chain_graphs()` again (it drops the captured graphs).
+
+        Streams: autograd binds a parameter's gradient-accumulation node to the stream it was created on, and the captured
+        forward keeps those nodes alive.  When the training step runs on a NON-default stream (`with torch.cuda.stream(s):` around
+        forward, backward and the optimizer), the capture happens on that same stream and nothing crosses streams afterwards.  On
+        the default stream the capture needs a side stream, and every parameter gradient of the chains then pays an event
+        record / wait pair per backward (~150 per step of the K-Net head; torch warns about the mismatch once)."""
         self._chain_graphs = {} if on else None
         return self
 
@@ -329,7 +335,27 @@ class KernelUpdateHead(nn.Module):
             gc.collect()                    # dead autograd graphs held by reference cycles count as "live" for the fault above
             mod = _ChainGraphModule(self, previous_obj_feats is not None)
             samples = tuple(torch.randn_like(a).requires_grad_(a.requires_grad) for a in args)
-            graphs[key] = (torch.cuda.make_graphed_callables(mod, samples, allow_unused_input=True), mod)
+            cur = torch.cuda.current_stream(x_feat.device)
+            own = cur != torch.cuda.default_stream(x_feat.device)
+            # our own warm-up (lazy library initialisation, TunableOp's timing runs) instead of make_graphed_callables': that one
+            # runs on an anonymous stream and its last outputs stay alive through the capture, so the parameters' accumulation
+            # nodes would be the ones created THERE — bound to a stream nobody uses again — whatever stream the capture is on
+            torch.cuda.synchronize()
+            with torch.cuda.stream(cur if own else torch.cuda.Stream(device=x_feat.device)):
+                surface = [t for t in samples if t.requires_grad] + [p for p in mod.parameters() if p.requires_grad]
+                for _ in range(3):
+                    outs = [o for o in mod(*samples) if o.requires_grad]
+                    grads = torch.autograd.grad(outs, surface, [torch.empty_like(o) for o in outs], allow_unused=True)
+                del outs, grads, surface
+            torch.cuda.synchronize()
+            gc.collect()
+            keep = torch.cuda.graph.default_capture_stream
+            if own:
+                torch.cuda.graph.default_capture_stream = cur           # capture where the step runs (see enable_chain_graphs)
+            try:
+                graphs[key] = (torch.cuda.make_graphed_callables(mod, samples, num_warmup_iters=0, allow_unused_input=True), mod)
+            finally:
+                torch.cuda.graph.default_capture_stream = keep
         return graphs[key] + (args,)
 
     def _chain(self, x_feat, proposal_feat, previous_obj_feats=None):
