@@ -165,8 +165,18 @@ int vkn_decode_gather_x(const void* x, int x_dtype, const void* kf_hi, const voi
 /* ---- `F.interpolate(mask_preds, scale_factor=S, mode='bilinear', align_corners=False)`
  *      knet/det/kernel_iter_head.py:122-130.  in [planes][H][W] -> out [planes][H*S][W*S]. */
 int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, int W, int S, void* stream);
-/*      its adjoint (training: the losses act on the up-scaled predictions): grad_out [planes][H*S][W*S] -> grad_in [planes][H][W] */
+/*      its adjoint (training: the losses act on the up-scaled predictions): grad_out [planes][H*S][W*S] -> grad_in [planes][H][W];
+ *      S in {1, 2, 3, 4, 8} (VKN_E_SHAPE otherwise) */
 int vkn_upsample_bilinear_bwd_f32(const float* grad_out, float* grad_in, int planes, int H, int W, int S, void* stream);
+
+/* ---- sigmoid focal loss of the classification branch (mmdet FocalLoss(use_sigmoid=True), the `loss_cls` of every shipped config:
+ *      configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:131-136; call site knet/det/kernel_update_head.py:296-300).
+ *      logits [M][ncls], labels int64 [M] (ncls or anything outside [0, ncls) = background), row_weight [M] or NULL.
+ *      partial [vkn_focal_loss_blocks(M, ncls)]: block sums of the weighted element losses (fixed order; the caller adds them and
+ *      applies loss_weight / avg_factor); grad [M][ncls] = d(sum of the element losses) / d logits. */
+int vkn_focal_loss_blocks(int M, int ncls);
+int vkn_focal_loss_f32(const float* logits, const long long* labels, const float* row_weight, int M, int ncls, float alpha,
+                       float gamma, float* partial, float* grad, void* stream);
 
 /* ---- weight preparation for the bf16x3 split-MFMA GEMMs: splits every non-NULL Linear weight of `w` (w->prepared is ignored)
  *      into `prepared` (device buffer, >= vkn_prepared_bytes(d, w) bytes, 256-B aligned).  Afterwards set

@@ -223,7 +223,28 @@ def test_fused_mask_losses_vs_torch_ops(vkn, B, Ns, H, W, K, with_rank):
     assert maxabs(pa.grad, pb.grad) <= 1e-5 * float(pb.grad.abs().max()), (maxabs(pa.grad, pb.grad), float(pb.grad.abs().max()))
 
 
-@pytest.mark.parametrize('shape,S', [((2, 5, 8, 12), 2), ((1, 3, 7, 9), 4), ((3, 4, 16, 32), 2), ((1, 2, 5, 3), 3)])
+@pytest.mark.parametrize('M,ncls,weighted', [(468, 124, True), (117, 19, False), (7, 3, True), (3744, 124, True)])
+def test_fused_focal_loss_vs_torch_formula(vkn, M, ncls, weighted):
+    """`FocalLoss` on CUDA tensors runs ONE HIP pass (vkn_focal_loss_f32) — value and gradient against the torch restatement of
+    mmdet's py_sigmoid_focal_loss (losses.py, `fused=False`), with a device-tensor avg_factor, background and weighted rows."""
+    g = torch.Generator().manual_seed(900 + M)
+    z = (torch.randn(M, ncls, generator=g) * 4).to(DEV)
+    labels = torch.randint(0, ncls + 1, (M,), generator=g).to(DEV)          # ncls = background
+    w = (torch.rand(M, generator=g) > 0.2).float().to(DEV) if weighted else None
+    avg = torch.tensor(17.0, device=DEV)
+    loss = vkn.losses.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0)
+    za, zb = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    la = loss(za, labels, w, avg_factor=avg)
+    loss.fused = False
+    lb = loss(zb, labels, w, avg_factor=avg)
+    (la * 1.7).backward()
+    (lb * 1.7).backward()
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)), (float(la), float(lb))
+    assert maxabs(za.grad, zb.grad) <= 1e-5 * float(zb.grad.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize('shape,S', [((2, 5, 8, 12), 2), ((1, 3, 7, 9), 4), ((3, 4, 16, 32), 2), ((1, 2, 5, 3), 3), ((1, 2, 4, 6), 8),
+                                     ((2, 3, 5, 7), 1)])
 def test_upsample_backward_vs_torch_autograd(vkn, shape, S):
     """The adjoint of the bilinear xS upsample (HIP, gather form, deterministic) against torch's autograd of F.interpolate."""
     import torch.nn.functional as F

@@ -19,7 +19,7 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_w
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
            'vkn_decode_gather_supported', 'vkn_decode_gather_f32', 'vkn_mask_decode_planes_x', 'vkn_decode_gather_x',
            'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_upsample_bilinear_bwd_f32', 'vkn_kernel_updator_f32',
-           'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_stage_chain_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32',
+           'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_stage_chain_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32', 'vkn_focal_loss_blocks', 'vkn_focal_loss_f32',
            'vkn_head_forward_prof_f32', 'vkn_head_forward_link_f32', 'vkn_stage_forward_link_f32', 'vkn_link_block_f32',
            'vkn_query_merge_workspace_bytes', 'vkn_query_merge_f32',
            'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32',
@@ -225,6 +225,10 @@ def lib():
     L.vkn_stage_chain_f32.argtypes = [pD, pW] + [_fp] * 6 + [_fp, c_size, c_uint, _fp]
     L.vkn_head_workspace_bytes.restype = c_size
     L.vkn_head_workspace_bytes.argtypes = [pD]
+    L.vkn_focal_loss_blocks.restype = c_int
+    L.vkn_focal_loss_blocks.argtypes = [c_int, c_int]
+    L.vkn_focal_loss_f32.restype = c_int
+    L.vkn_focal_loss_f32.argtypes = [_fp, _fp, _fp, c_int, c_int, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp]
     L.vkn_head_forward_f32.restype = c_int
     L.vkn_head_forward_f32.argtypes = [pD, c_int, pW] + [_fp] * 8 + [c_int, _fp, _fp, c_size, c_uint, _fp]
     L.vkn_head_forward_prof_f32.restype = c_int

@@ -129,37 +129,85 @@ __global__ __launch_bounds__(256) void k_ml_bwd(const float* __restrict__ pred, 
 }
 
 // Adjoint of the xS bilinear upsample (F.interpolate(scale_factor=S, bilinear, align_corners=False)): gin[y][x] = sum over the
-// output pixels whose two source rows / columns include (y, x) of their weights x gout.  Gather form: a thread owns one input pixel
-// and visits the <= 3 S x 3 S output pixels around it, testing each one's own (y0, y1, ly) — the same clamped source-index formula
-// as the forward kernels, so forward and backward agree on every border case.  Deterministic (torch's kernel scatters with atomics).
-__global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ gout, float* __restrict__ gin, int H, int W, int S) {
+// output pixels whose two source rows / columns include (y, x) of their weights x gout.  Gather form: a thread owns one input pixel.
+// Source row sy(oy) = max((oy + 0.5) / S - 0.5, 0) touches input row y iff sy is in (y - 1, y + 1), i.e. oy in
+// [S y - S/2, S y - S/2 + 2 S): 2 S candidate rows (and columns) per input pixel, each tested with its own (y0, y1, ly) — the same
+// clamped source-index formula as the forward kernels, so forward and backward agree on every border case.  The 2 S column
+// weights are computed once per thread; terms are added in raster order.  Deterministic (torch's kernel scatters with atomics).
+template <int S>
+__global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ gout, float* __restrict__ gin, int H, int W) {
+    constexpr int R = 2 * S;
     const int plane = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= H * W) return;
     const int y = idx / W, x = idx - y * W;
     const int OH = H * S, OW = W * S;
-    const float rs = 1.0f / (float)S;
+    constexpr float rs = 1.0f / (float)S;
     const float* gp = gout + (size_t)plane * OH * OW;
+    const int oy0 = S * y - S / 2, ox0 = S * x - S / 2;
+    float wxs[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int ox = ox0 + j;
+        const float sx = fmaxf(((float)ox + 0.5f) * rs - 0.5f, 0.f);
+        const int x0 = min((int)sx, W - 1), x1 = min(x0 + 1, W - 1);
+        const float lx = sx - (float)x0;
+        const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+        wxs[j] = (ox >= 0 && ox < OW) ? wx : 0.f;
+    }
     float acc = 0.f;
-    const int oy_lo = max(S * (y - 1), 0), oy_hi = min(S * (y + 2) - 1, OH - 1);
-    const int ox_lo = max(S * (x - 1), 0), ox_hi = min(S * (x + 2) - 1, OW - 1);
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int oy = oy0 + i;
+        if (oy < 0 || oy >= OH) continue;
         const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f);
         const int y0 = min((int)sy, H - 1), y1 = min(y0 + 1, H - 1);
         const float ly = sy - (float)y0;
         const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
         if (wy == 0.f) continue;
+        const float* rp = gp + (size_t)oy * OW + ox0;
         float row = 0.f;
-        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-            const float sx = fmaxf(((float)ox + 0.5f) * rs - 0.5f, 0.f);
-            const int x0 = min((int)sx, W - 1), x1 = min(x0 + 1, W - 1);
-            const float lx = sx - (float)x0;
-            const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
-            if (wx != 0.f) row += wx * gp[(size_t)oy * OW + ox];
-        }
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (wxs[j] != 0.f) row += wxs[j] * rp[j];
         acc += wy * row;
     }
     gin[(size_t)plane * H * W + idx] = acc;
+}
+
+// Sigmoid focal loss (mmdet FocalLoss(use_sigmoid=True): py_sigmoid_focal_loss, the classification loss of every shipped config) over
+// logits [M][ncls] with integer labels [M] (label == ncls or out of range = background: an all-zero target row) and optional
+// per-row weights: element loss = w_row * bce(z, t) * (alpha t + (1 - alpha)(1 - t)) * pt^gamma, pt = (1 - p) t + p (1 - t).
+// One pass writes the block partial sums of the loss AND d(sum of losses)/dz per element, so backward is one scaling.
+__global__ __launch_bounds__(256) void k_focal(const float* __restrict__ z, const long long* __restrict__ labels,
+                                               const float* __restrict__ roww, int M, int ncls, float alpha, float gamma,
+                                               float* __restrict__ partial, float* __restrict__ grad) {
+    const size_t n = (size_t)M * ncls;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int row = (int)(i / ncls), c = (int)(i - (size_t)row * ncls);
+        const float v = z[i];
+        const float t = (labels[row] == (long long)c) ? 1.f : 0.f;
+        const float w = roww ? roww[row] : 1.f;
+        const float e = expf(-fabsf(v));
+        const float p = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        const float bce = fmaxf(v, 0.f) - v * t + log1pf(e);
+        const float pt = (1.f - p) * t + p * (1.f - t);
+        const float at = alpha * t + (1.f - alpha) * (1.f - t);
+        const float ptg = powf(pt, gamma);
+        acc += w * bce * at * ptg;
+        // d/dz: bce' = p - t; pt' = p (1 - p) (1 - 2 t)
+        const float dptg = pt > 0.f ? gamma * powf(pt, gamma - 1.f) * p * (1.f - p) * (1.f - 2.f * t) : 0.f;
+        grad[i] = w * at * ((p - t) * ptg + bce * dptg);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {   // fixed tree: deterministic
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
 }  // namespace
@@ -168,16 +216,39 @@ extern "C" {
 
 int vkn_upsample_bilinear_bwd_f32(const float* grad_out, float* grad_in, int planes, int H, int W, int S, void* stream) {
     if (!grad_out || !grad_in || planes <= 0 || H <= 0 || W <= 0 || S < 1) return VKN_E_ARG;
+    if (S > 4 && S != 8) return VKN_E_SHAPE;   // scale factors of the shipped configs: 2 (training), 4 (inference), 8 (semantic branch)
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (int done = 0; done < planes; done += 32768) {  // gridDim.y <= 65535
         const int chunk = (planes - done > 32768) ? 32768 : planes - done;
-        hipLaunchKernelGGL(k_upsample_bwd, dim3((H * W + 255) / 256, chunk), dim3(256), 0, st, grad_out + (size_t)done * H * S * W * S,
-                           grad_in + (size_t)done * H * W, H, W, S);
+        const float* go = grad_out + (size_t)done * H * S * W * S;
+        float* gi = grad_in + (size_t)done * H * W;
+        const dim3 grid((H * W + 255) / 256, chunk);
+        switch (S) {
+#define UB_CASE(SV) case SV: hipLaunchKernelGGL(k_upsample_bwd<SV>, grid, dim3(256), 0, st, go, gi, H, W); break;
+            UB_CASE(1) UB_CASE(2) UB_CASE(3) UB_CASE(4) UB_CASE(8)
+#undef UB_CASE
+            default: return VKN_E_SHAPE;
+        }
         VKN_CHECK_LAUNCH();
     }
     return VKN_OK;
 }
 
+
+int vkn_focal_loss_blocks(int M, int ncls) {
+    if (M <= 0 || ncls <= 0) return 0;
+    const size_t nb = ((size_t)M * ncls + 255) / 256;
+    return (int)(nb < 512 ? nb : 512);
+}
+
+int vkn_focal_loss_f32(const float* logits, const long long* labels, const float* row_weight, int M, int ncls, float alpha,
+                       float gamma, float* partial, float* grad, void* stream) {
+    if (!logits || !labels || !partial || !grad || M <= 0 || ncls <= 0) return VKN_E_ARG;
+    hipLaunchKernelGGL(k_focal, dim3(vkn_focal_loss_blocks(M, ncls)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, labels,
+                       row_weight, M, ncls, alpha, gamma, partial, grad);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
 
 int vkn_mask_losses_chunks(int P) { return P > 0 ? (P + ML_CHUNK - 1) / ML_CHUNK : 0; }
 int vkn_mask_losses_blocks(int P) { return P > 0 ? (P / 4 + 255) / 256 : 0; }

@@ -73,6 +73,7 @@ def py_sigmoid_focal_loss(pred, target, weight=None, gamma=2.0, alpha=0.25, redu
 
 
 class FocalLoss(nn.Module):
+    fused = True      # CUDA tensors with reduction 'mean' and an avg_factor: the fused HIP kernel (False: the torch formula, A/B)
 
     def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0):
         super().__init__()
@@ -84,6 +85,11 @@ class FocalLoss(nn.Module):
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
         num_classes = pred.size(1)
+        if (self.fused and pred.is_cuda and pred.dtype == torch.float32 and reduction == 'mean' and avg_factor is not None
+                and pred.dim() == 2 and target.dim() == 1 and (weight is None or weight.numel() == pred.size(0))):
+            # one HIP pass for the element losses and their derivative (csrc/vkn_loss.hip); same values (tests/test_gpu_train.py)
+            from . import autograd as vag
+            return vag.focal_loss(pred, target, weight, self.loss_weight, avg_factor, self.alpha, self.gamma)
         target = F.one_hot(target, num_classes=num_classes + 1)[:, :num_classes]   # label == num_classes is background
         return self.loss_weight * py_sigmoid_focal_loss(pred, target, weight, gamma=self.gamma, alpha=self.alpha,
                                                         reduction=reduction, avg_factor=avg_factor)

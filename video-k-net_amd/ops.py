@@ -680,6 +680,22 @@ def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, d
     return cost
 
 
+def focal_loss_fwd(logits, labels, row_weight, alpha, gamma):
+    """Sigmoid focal loss in one pass (include/vkn.h: vkn_focal_loss_f32).  logits [M, ncls] fp32, labels int64 [M], row_weight [M] |
+    None -> (sum of the weighted element losses: 0-d tensor, d sum / d logits [M, ncls])."""
+    z = _req(logits, 'cls_score')
+    M, ncls = z.shape
+    lab = labels.to(device=z.device, dtype=torch.int64).contiguous()
+    w = _req(row_weight.reshape(M).float(), 'label_weights') if row_weight is not None else None
+    L = _lib.lib()
+    part = torch.empty((L.vkn_focal_loss_blocks(M, ncls),), dtype=torch.float32, device=z.device)
+    grad = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        check(L.vkn_focal_loss_f32(_ptr(z), lab.data_ptr(), _ptr(w), M, ncls, float(alpha), float(gamma), _ptr(part), _ptr(grad),
+                                   _stream()))
+    return part.sum(), grad
+
+
 def mask_losses_fwd(pred, target, pos_rows, rowk, B, with_rank):
     """Forward sums of the three mask losses (include/vkn.h: vkn_mask_losses_fwd_f32).  pred, target [R, P]; pos_rows int64 [K]; rowk
     int32 [R].  -> (rowstats [K, 4] = (sum bce, sum p t, sum p^2, sum t^2), lse [B, P] | None, top int32 [B, P] | None,
