@@ -171,12 +171,13 @@ int vkn_upsample_bilinear_bwd_f32(const float* grad_out, float* grad_in, int pla
 
 /* ---- sigmoid focal loss of the classification branch (mmdet FocalLoss(use_sigmoid=True), the `loss_cls` of every shipped config:
  *      configs/det/_base_/models/knet_kitti_step_s3_r50_fpn.py:131-136; call site knet/det/kernel_update_head.py:296-300).
- *      logits [M][ncls], labels int64 [M] (ncls or anything outside [0, ncls) = background), row_weight [M] or NULL.
+ *      logits [M][ncls], labels int64 [M] (ncls or anything outside [0, ncls) = background); weight: NULL, [M] (per row,
+ *      weight_elementwise = 0) or [M][ncls] (weight_elementwise = 1: `label_weights` of KernelUpdateHead.get_targets, :396-441).
  *      partial [vkn_focal_loss_blocks(M, ncls)]: block sums of the weighted element losses (fixed order; the caller adds them and
  *      applies loss_weight / avg_factor); grad [M][ncls] = d(sum of the element losses) / d logits. */
 int vkn_focal_loss_blocks(int M, int ncls);
-int vkn_focal_loss_f32(const float* logits, const long long* labels, const float* row_weight, int M, int ncls, float alpha,
-                       float gamma, float* partial, float* grad, void* stream);
+int vkn_focal_loss_f32(const float* logits, const long long* labels, const float* weight, int weight_elementwise, int M, int ncls,
+                       float alpha, float gamma, float* partial, float* grad, void* stream);
 
 /* ---- weight preparation for the bf16x3 split-MFMA GEMMs: splits every non-NULL Linear weight of `w` (w->prepared is ignored)
  *      into `prepared` (device buffer, >= vkn_prepared_bytes(d, w) bytes, 256-B aligned).  Afterwards set
@@ -396,6 +397,19 @@ size_t vkn_assign_workspace_bytes(int N, int G, int P);
 int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, const float* cls_logits, const float* gt_masks,
                          const int* gt_labels, int N, int G, int ncls, int P, float* cost_out, void* ws, size_t ws_bytes,
                          void* stream);
+/*      The images of a training batch in ONE call (HOST array of per-image problems, same N / ncls / P, each its own G): the kernels
+ *      of image b run behind those of image b - 1 on `stream` and share `ws` (>= vkn_assign_workspace_bytes(N, max G, P)). */
+typedef struct VknAssignProblem {
+    const float* mask_logits; /* [N][P] */
+    const float* cls_logits;  /* [N][ncls] or NULL */
+    const float* gt_masks;    /* [G][P] */
+    const int* gt_labels;     /* [G] */
+    int G;
+    float* cost_out;          /* [N][G] */
+} VknAssignProblem;
+size_t vkn_sizeof_assign_problem(void);
+int vkn_assign_costs_batch_f32(const VknAssignCfg* cfg, const VknAssignProblem* probs, int nprob, int N, int ncls, int P, void* ws,
+                               size_t ws_bytes, void* stream);
 /*      cost: HOST fp32 [nr][nc]; writes min(nr, nc) (row, col) pairs sorted by row; returns their number or a negative code */
 int vkn_lsap_f32(const float* cost, int nr, int nc, int* row_ind, int* col_ind);
 /*      The same algorithm ON THE DEVICE, one wavefront per problem, a batch of problems (the images of a training batch) per launch:

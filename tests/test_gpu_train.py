@@ -223,14 +223,15 @@ def test_fused_mask_losses_vs_torch_ops(vkn, B, Ns, H, W, K, with_rank):
     assert maxabs(pa.grad, pb.grad) <= 1e-5 * float(pb.grad.abs().max()), (maxabs(pa.grad, pb.grad), float(pb.grad.abs().max()))
 
 
-@pytest.mark.parametrize('M,ncls,weighted', [(468, 124, True), (117, 19, False), (7, 3, True), (3744, 124, True)])
+@pytest.mark.parametrize('M,ncls,weighted', [(468, 124, 2), (117, 19, 0), (7, 3, 1), (3744, 124, 1), (50, 1, 2)])
 def test_fused_focal_loss_vs_torch_formula(vkn, M, ncls, weighted):
     """`FocalLoss` on CUDA tensors runs ONE HIP pass (vkn_focal_loss_f32) — value and gradient against the torch restatement of
     mmdet's py_sigmoid_focal_loss (losses.py, `fused=False`), with a device-tensor avg_factor, background and weighted rows."""
     g = torch.Generator().manual_seed(900 + M)
     z = (torch.randn(M, ncls, generator=g) * 4).to(DEV)
     labels = torch.randint(0, ncls + 1, (M,), generator=g).to(DEV)          # ncls = background
-    w = (torch.rand(M, generator=g) > 0.2).float().to(DEV) if weighted else None
+    # 0: no weight, 1: per row [M], 2: per element [M, ncls] (the head's label_weights)
+    w = None if not weighted else (torch.rand((M,) if weighted == 1 else (M, ncls), generator=g) > 0.2).float().to(DEV)
     avg = torch.tensor(17.0, device=DEV)
     loss = vkn.losses.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0)
     za, zb = z.clone().requires_grad_(True), z.clone().requires_grad_(True)

@@ -25,7 +25,7 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_sizeof_dims', 'vkn_sizeof_stage_w
            'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32',
            'vkn_sizeof_panoptic_cfg', 'vkn_panoptic_workspace_bytes', 'vkn_panoptic_joint_f32',
            'vkn_merge_workspace_bytes', 'vkn_panoptic_thing_first_u8',
-           'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_lsap_f32',
+           'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_sizeof_assign_problem', 'vkn_assign_costs_batch_f32', 'vkn_lsap_f32',
            'vkn_sizeof_lsap_problem', 'vkn_lsap_batch_f32',
            'vkn_mask_losses_chunks', 'vkn_mask_losses_blocks', 'vkn_mask_losses_fwd_f32', 'vkn_mask_losses_bwd_f32',
            'vkn_sizeof_tracker_cfg', 'vkn_qd_tracker_state_bytes', 'vkn_qd_tracker_workspace_bytes', 'vkn_qd_tracker_state_layout',
@@ -45,6 +45,12 @@ class VknAssignCfg(ctypes.Structure):
     _fields_ = [('cls_weight', ctypes.c_float), ('dice_weight', ctypes.c_float), ('mask_weight', ctypes.c_float),
                 ('focal_alpha', ctypes.c_float), ('focal_gamma', ctypes.c_float), ('focal_eps', ctypes.c_float),
                 ('dice_eps', ctypes.c_float), ('dice_pred_min', ctypes.c_float), ('mask_pred_min', ctypes.c_float)]
+
+
+class VknAssignProblem(ctypes.Structure):
+    """Mirror of include/vkn.h: VknAssignProblem (device pointers as integers)."""
+    _fields_ = [('mask_logits', ctypes.c_void_p), ('cls_logits', ctypes.c_void_p), ('gt_masks', ctypes.c_void_p),
+                ('gt_labels', ctypes.c_void_p), ('G', ctypes.c_int), ('cost_out', ctypes.c_void_p)]
 
 
 class VknLsapProblem(ctypes.Structure):
@@ -228,7 +234,7 @@ def lib():
     L.vkn_focal_loss_blocks.restype = c_int
     L.vkn_focal_loss_blocks.argtypes = [c_int, c_int]
     L.vkn_focal_loss_f32.restype = c_int
-    L.vkn_focal_loss_f32.argtypes = [_fp, _fp, _fp, c_int, c_int, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp]
+    L.vkn_focal_loss_f32.argtypes = [_fp, _fp, _fp, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp]
     L.vkn_head_forward_f32.restype = c_int
     L.vkn_head_forward_f32.argtypes = [pD, c_int, pW] + [_fp] * 8 + [c_int, _fp, _fp, c_size, c_uint, _fp]
     L.vkn_head_forward_prof_f32.restype = c_int
@@ -280,6 +286,12 @@ def lib():
     L.vkn_mask_losses_fwd_f32.argtypes = [_fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _fp, _fp, _fp, _fp, _fp]
     L.vkn_mask_losses_bwd_f32.restype = c_int
     L.vkn_mask_losses_bwd_f32.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp, _fp]
+    L.vkn_sizeof_assign_problem.restype = c_size
+    L.vkn_sizeof_assign_problem.argtypes = []
+    if L.vkn_sizeof_assign_problem() != ctypes.sizeof(VknAssignProblem):
+        raise VknLibraryError('VknAssignProblem layout mismatch between include/vkn.h and _lib.py')
+    L.vkn_assign_costs_batch_f32.restype = c_int
+    L.vkn_assign_costs_batch_f32.argtypes = [pA, ctypes.POINTER(VknAssignProblem), c_int, c_int, c_int, c_int, _fp, c_size, _fp]
     L.vkn_sizeof_lsap_problem.restype = c_size
     L.vkn_sizeof_lsap_problem.argtypes = []
     if L.vkn_sizeof_lsap_problem() != ctypes.sizeof(VknLsapProblem):

@@ -343,6 +343,20 @@ int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, cons
     return VKN_OK;
 }
 
+size_t vkn_sizeof_assign_problem(void) { return sizeof(VknAssignProblem); }
+
+int vkn_assign_costs_batch_f32(const VknAssignCfg* cfg, const VknAssignProblem* probs, int nprob, int N, int ncls, int P, void* ws,
+                               size_t ws_bytes, void* stream) {
+    if (!cfg || !probs || nprob <= 0) return VKN_E_ARG;
+    for (int b = 0; b < nprob; ++b) {
+        const VknAssignProblem& pb = probs[b];
+        const int rc = vkn_assign_costs_f32(cfg, pb.mask_logits, pb.cls_logits, pb.gt_masks, pb.gt_labels, N, pb.G, ncls, P, pb.cost_out,
+                                            ws, ws_bytes, stream);
+        if (rc != VKN_OK) return rc;
+    }
+    return VKN_OK;
+}
+
 // Rectangular linear sum assignment (minimisation), HOST function: the shortest augmenting path algorithm of
 // scipy.optimize.linear_sum_assignment (D. F. Crouse, "On implementing 2D rectangular assignment algorithms", IEEE TAES 2016).
 // ATTRIBUTION: this function restates scipy/optimize/rectangular_lsap/rectangular_lsap.cpp (SciPy 1.x; Copyright (c) 2019,

@@ -177,18 +177,18 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
 
 // Sigmoid focal loss (mmdet FocalLoss(use_sigmoid=True): py_sigmoid_focal_loss, the classification loss of every shipped config) over
 // logits [M][ncls] with integer labels [M] (label == ncls or out of range = background: an all-zero target row) and optional
-// per-row weights: element loss = w_row * bce(z, t) * (alpha t + (1 - alpha)(1 - t)) * pt^gamma, pt = (1 - p) t + p (1 - t).
+// per-row [M] or per-element [M][ncls] weights: element loss = w_row * bce(z, t) * (alpha t + (1 - alpha)(1 - t)) * pt^gamma, pt = (1 - p) t + p (1 - t).
 // One pass writes the block partial sums of the loss AND d(sum of losses)/dz per element, so backward is one scaling.
 __global__ __launch_bounds__(256) void k_focal(const float* __restrict__ z, const long long* __restrict__ labels,
-                                               const float* __restrict__ roww, int M, int ncls, float alpha, float gamma,
-                                               float* __restrict__ partial, float* __restrict__ grad) {
+                                               const float* __restrict__ roww, int elementwise, int M, int ncls, float alpha,
+                                               float gamma, float* __restrict__ partial, float* __restrict__ grad) {
     const size_t n = (size_t)M * ncls;
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int row = (int)(i / ncls), c = (int)(i - (size_t)row * ncls);
         const float v = z[i];
         const float t = (labels[row] == (long long)c) ? 1.f : 0.f;
-        const float w = roww ? roww[row] : 1.f;
+        const float w = roww ? (elementwise ? roww[i] : roww[row]) : 1.f;
         const float e = expf(-fabsf(v));
         const float p = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
         const float bce = fmaxf(v, 0.f) - v * t + log1pf(e);
@@ -241,11 +241,11 @@ int vkn_focal_loss_blocks(int M, int ncls) {
     return (int)(nb < 512 ? nb : 512);
 }
 
-int vkn_focal_loss_f32(const float* logits, const long long* labels, const float* row_weight, int M, int ncls, float alpha,
-                       float gamma, float* partial, float* grad, void* stream) {
+int vkn_focal_loss_f32(const float* logits, const long long* labels, const float* weight, int weight_elementwise, int M, int ncls,
+                       float alpha, float gamma, float* partial, float* grad, void* stream) {
     if (!logits || !labels || !partial || !grad || M <= 0 || ncls <= 0) return VKN_E_ARG;
     hipLaunchKernelGGL(k_focal, dim3(vkn_focal_loss_blocks(M, ncls)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, labels,
-                       row_weight, M, ncls, alpha, gamma, partial, grad);
+                       weight, weight_elementwise, M, ncls, alpha, gamma, partial, grad);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -86,7 +86,7 @@ class FocalLoss(nn.Module):
         reduction = reduction_override if reduction_override else self.reduction
         num_classes = pred.size(1)
         if (self.fused and pred.is_cuda and pred.dtype == torch.float32 and reduction == 'mean' and avg_factor is not None
-                and pred.dim() == 2 and target.dim() == 1 and (weight is None or weight.numel() == pred.size(0))):
+                and pred.dim() == 2 and target.dim() == 1 and (weight is None or weight.numel() in (pred.size(0), pred.numel()))):
             # one HIP pass for the element losses and their derivative (csrc/vkn_loss.hip); same values (tests/test_gpu_train.py)
             from . import autograd as vag
             return vag.focal_loss(pred, target, weight, self.loss_weight, avg_factor, self.alpha, self.gamma)

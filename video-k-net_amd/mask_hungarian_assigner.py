@@ -177,7 +177,18 @@ class MaskHungarianAssigner:
                                         for g, p in zip(gt_bboxes, bbox_preds)):
             return [self.assign(bbox_preds[i], cls_preds[i], gt_bboxes[i], gt_labels[i],
                                 img_meta=img_metas[i] if img_metas is not None else None) for i in range(n)]
-        costs = [self.cost_matrix(bbox_preds[i], cls_preds[i], gt_bboxes[i], gt_labels[i]) for i in range(n)]
+        use_cls = self.cls['weight'] != 0 and all(c is not None for c in cls_preds)
+        same = len({p.shape for p in bbox_preds}) == 1 and (not use_cls or len({c.shape for c in cls_preds}) == 1)
+        checked = not use_cls or all(torch.is_tensor(l) and self._label_key(l, cls_preds[0].shape[1]) in self._validated for l in gt_labels)
+        if same and checked and (use_cls or all(c is None for c in cls_preds) or self.cls['weight'] == 0):
+            # every image's cost matrix from ONE C call (the labels were range-checked by validate_labels)
+            costs = ops.assign_costs_batch(bbox_preds, cls_preds if use_cls else None, gt_bboxes, gt_labels,
+                                           cls_weight=self.cls['weight'] if use_cls else 0.0, dice_weight=self.dice['weight'],
+                                           mask_weight=self.mask['weight'], focal_alpha=self.cls['alpha'], focal_gamma=self.cls['gamma'],
+                                           focal_eps=self.cls['eps'], dice_eps=self.dice['eps'], dice_pred_min=self.pred_clamp[0],
+                                           mask_pred_min=self.pred_clamp[1])
+        else:
+            costs = [self.cost_matrix(bbox_preds[i], cls_preds[i], gt_bboxes[i], gt_labels[i]) for i in range(n)]
         gts, rows, cols, status = ops.lsap_device(costs)
         self.pending_status.append(status)
         del self.pending_status[:-64]

@@ -680,18 +680,61 @@ def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, d
     return cost
 
 
+def assign_costs_batch(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, dice_weight=4.0, mask_weight=1.0,
+                       focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3, dice_pred_min=1e-3, mask_pred_min=1e-2):
+    """`assign_costs` for the images of a batch in ONE C call (vkn_assign_costs_batch_f32): lists of per-image [N, H, W] logits,
+    [N, ncls] class logits (or None for all), [G_b, H, W] float ground-truth masks and [G_b] labels — ALREADY range-checked (the
+    per-image entry point checks; this one is the training loop's).  -> list of [N, G_b] cost matrices (views of one allocation)."""
+    n = len(mask_logits)
+    N = mask_logits[0].shape[0]
+    P = mask_logits[0][0].numel()
+    dev = mask_logits[0].device
+    use_cls = cls_logits is not None and cls_logits[0] is not None and cls_weight != 0
+    ncls = cls_logits[0].shape[1] if use_cls else 0
+    Gs = [int(g.shape[0]) for g in gt_masks]
+    labs = torch.cat([l.reshape(-1) for l in gt_labels]).to(device=dev, dtype=torch.int32) if use_cls else None
+    cost = torch.empty((N * sum(Gs),), dtype=torch.float32, device=dev)
+    probs = (_lib.VknAssignProblem * n)()
+    keep, out, off = [], [], 0
+    for b in range(n):
+        m = _req(mask_logits[b].reshape(N, P), 'mask_preds')
+        g = gt_masks[b].reshape(Gs[b], -1)
+        if g.dtype != torch.float32:
+            g = g.float()
+        g = _req(g, 'gt_masks')
+        if g.shape[1] != P or m.shape[0] != N:
+            raise ValueError('mask_preds and gt_masks must have the same spatial size, and every image the same number of predictions')
+        c = _req(cls_logits[b], 'cls_pred') if use_cls else None
+        cb = cost[N * off:N * (off + Gs[b])].view(N, Gs[b])
+        probs[b] = _lib.VknAssignProblem(m.data_ptr(), c.data_ptr() if use_cls else None, g.data_ptr(),
+                                         labs.data_ptr() + 4 * off if use_cls else None, Gs[b], cb.data_ptr())
+        keep += [m, g, c]
+        out.append(cb)
+        off += Gs[b]
+    cfg = _lib.VknAssignCfg(float(cls_weight if use_cls else 0.0), float(dice_weight), float(mask_weight), float(focal_alpha),
+                            float(focal_gamma), float(focal_eps), float(dice_eps), float(dice_pred_min), float(mask_pred_min))
+    L = _lib.lib()
+    ws = _workspace(max(L.vkn_assign_workspace_bytes(N, max(Gs), P), 256), dev)
+    with torch.cuda.device(dev):
+        check(L.vkn_assign_costs_batch_f32(ctypes.byref(cfg), probs, n, N, ncls, P, _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
 def focal_loss_fwd(logits, labels, row_weight, alpha, gamma):
     """Sigmoid focal loss in one pass (include/vkn.h: vkn_focal_loss_f32).  logits [M, ncls] fp32, labels int64 [M], row_weight [M] |
-    None -> (sum of the weighted element losses: 0-d tensor, d sum / d logits [M, ncls])."""
+    [M, ncls] | None -> (sum of the weighted element losses: 0-d tensor, d sum / d logits [M, ncls])."""
     z = _req(logits, 'cls_score')
     M, ncls = z.shape
     lab = labels.to(device=z.device, dtype=torch.int64).contiguous()
-    w = _req(row_weight.reshape(M).float(), 'label_weights') if row_weight is not None else None
+    ew = row_weight is not None and row_weight.numel() == M * ncls and ncls > 1
+    w = None
+    if row_weight is not None:
+        w = _req(row_weight.reshape((M, ncls) if ew else (M,)).float(), 'label_weights')
     L = _lib.lib()
     part = torch.empty((L.vkn_focal_loss_blocks(M, ncls),), dtype=torch.float32, device=z.device)
     grad = torch.empty_like(z)
     with torch.cuda.device(z.device):
-        check(L.vkn_focal_loss_f32(_ptr(z), lab.data_ptr(), _ptr(w), M, ncls, float(alpha), float(gamma), _ptr(part), _ptr(grad),
+        check(L.vkn_focal_loss_f32(_ptr(z), lab.data_ptr(), _ptr(w), int(ew), M, ncls, float(alpha), float(gamma), _ptr(part), _ptr(grad),
                                    _stream()))
     return part.sum(), grad
 
