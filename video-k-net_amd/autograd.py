@@ -18,31 +18,31 @@ from . import ops
 
 
 def _pow2_scale(t, target=1024.0):
-    """Power of two s (device scalar tensor) with max|t| * s in [target / 2, target]; 1 for an all-zero tensor."""
-    m = t.detach().abs().amax()
-    e = torch.floor(torch.log2(torch.clamp(m, min=1e-30)))
-    s = torch.exp2(torch.clamp(math.floor(math.log2(target)) - e, -100.0, 100.0))   # (no host tensor: a tiny H2D copy is a stream sync)
-    return torch.where(m > 0, s, torch.ones_like(s))
+    """Power of two s (device scalar tensor) with max|t| * s in [target / 2, target) (2^10-ish for an all-zero tensor: harmless).
+    One reduction pass (`max |t|` as the infinity norm, no |t| temporary) and three scalar ops; nothing touches the host."""
+    m = torch.linalg.vector_norm(t.detach(), ord=float('inf'))
+    e = torch.frexp(m)[1]                                              # m = mantissa * 2^e, mantissa in [0.5, 1)
+    return torch.ldexp(torch.ones_like(m), (int(math.floor(math.log2(target))) - e).clamp_(-100, 100))
 
 
-def _pad_rows(t, mult):
-    """[B, R, ...] -> rows padded with zeros to a multiple of `mult`."""
+def _scaled_rows(t, s, mult=32):
+    """t [B, R, ...] * s with the rows zero-padded to a multiple of `mult`: one pass over t (no concatenation)."""
     r = t.shape[1]
     rp = (r + mult - 1) // mult * mult
-    if rp == r:
+    out = torch.empty((t.shape[0], rp) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
+    torch.mul(t, s, out=out[:, :r])
+    if rp != r:
+        out[:, r:].zero_()
+    return out
+
+
+def _pad_last(t, n):
+    """[..., m] -> [..., n] zero-padded (n >= m), contiguous."""
+    if t.shape[-1] == n:
         return t.contiguous()
-    pad = t.new_zeros((t.shape[0], rp - r) + tuple(t.shape[2:]))
-    return torch.cat([t, pad], dim=1).contiguous()
-
-
-def _decode_transposed(rows, kern_t):
-    """out[b, c, p] = sum_n kern_t[b, c, n] rows[b, n, p]: the decode kernel with `rows` [B, R, H, W] as its feature map
-    (R padded to the kernel's 16-channel contraction step) and `kern_t` [B, C, R] as its kernels."""
-    rows_p = _pad_rows(rows, 32)
-    k = kern_t
-    if rows_p.shape[1] != kern_t.shape[2]:
-        k = torch.cat([kern_t, kern_t.new_zeros(kern_t.shape[0], kern_t.shape[1], rows_p.shape[1] - kern_t.shape[2])], dim=2)
-    return ops.mask_decode(rows_p, k.contiguous())
+    out = t.new_zeros(tuple(t.shape[:-1]) + (n,))
+    out[..., :t.shape[-1]] = t
+    return out
 
 
 class MaskGatherFn(torch.autograd.Function):
@@ -66,19 +66,17 @@ class MaskGatherFn(torch.autograd.Function):
         (bits,) = ctx.saved_tensors                                     # [B, N, H, W] bool
         B, N, H, W = bits.shape
         s = _pow2_scale(dxraw)
-        kt = (dxraw * s).transpose(1, 2)                                # [B, C, N]
-        if (H * W) % 64 == 0:
-            # the decode kernel with the bit rows as a HALF-STORAGE feature map (fp16 {0, 1} is exact, its low half is zero: one MFMA
-            # per operand pair instead of three, half the bytes of an fp32 bit tensor), rows padded to the 32-row contraction step
-            Np = (N + 31) // 32 * 32
-            rows = torch.zeros((B, Np, H, W), dtype=torch.float16, device=bits.device)
-            rows[:, :N] = bits
-            if Np != N:
-                kt = torch.cat([kt, kt.new_zeros(B, kt.shape[1], Np - N)], dim=2)
-            dx = ops.mask_decode(rows, kt.contiguous()) / s             # [B, C, H, W]
-        else:
-            dx = _decode_transposed(bits.to(torch.float32), kt) / s
-        return dx, None, None
+        Np = (N + 31) // 32 * 32
+        kt = _pad_last((dxraw * s).transpose(1, 2), Np)                 # [B, C, Np]
+        # the decode kernel with the bit rows as its feature map, rows padded to the 32-row contraction step.  fp16 {0, 1} is exact
+        # and its low half is zero: with H*W % 64 == 0 the rows travel as a HALF-STORAGE map (one MFMA per operand pair instead of
+        # three, half the bytes of an fp32 bit tensor)
+        rows = torch.empty((B, Np, H, W), dtype=torch.float16 if (H * W) % 64 == 0 else torch.float32, device=bits.device)
+        rows[:, :N] = bits
+        if Np != N:
+            rows[:, N:].zero_()
+        dx = ops.mask_decode(rows, kt)                                  # [B, C, H, W]
+        return dx.mul_(1.0 / s), None, None
 
 
 class MaskDecodeFn(torch.autograd.Function):
@@ -96,13 +94,21 @@ class MaskDecodeFn(torch.autograd.Function):
         x, kernels = ctx.saved_tensors
         dz = dz.contiguous()
         s = _pow2_scale(dz)
-        dzs = dz * s
+        inv = 1.0 / s
+        need_k = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        N = dz.shape[1]
         dk = dkb = dx = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dk, dkb = ops.mask_gather_real(x, dzs)
-            dk, dkb = dk / s, dkb / s
         if ctx.needs_input_grad[0]:
-            dx = _decode_transposed(dzs, kernels.transpose(1, 2)) / s
+            # dx[b, c, p] = sum_n K[b, n, c] dz[b, n, p]: the decode kernel with the (scaled, row-padded) dz as its feature map and
+            # K^T as its kernels; the padded rows are zero, so the gather below may run over them too
+            dzs = _scaled_rows(dz, s)
+            dx = ops.mask_decode(dzs, _pad_last(kernels.reshape(kernels.shape[0], N, -1).transpose(1, 2), dzs.shape[1])).mul_(inv)
+            if need_k:
+                dk, dkb = ops.mask_gather_real(x, dzs)
+                dk, dkb = dk[:, :N].mul(inv), dkb[:, :N].mul(inv)
+        elif need_k:
+            dk, dkb = ops.mask_gather_real(x, dz * s)
+            dk, dkb = dk.mul_(inv), dkb.mul_(inv)
         return dx, dk if ctx.needs_input_grad[1] else None, dkb if (ctx.has_bias and ctx.needs_input_grad[2]) else None
 
 
