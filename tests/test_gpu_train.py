@@ -178,6 +178,44 @@ def test_chain_as_hipgraphs_equals_eager_chain(vkn, name):
     assert all(h._chain_graphs is None for h in head.mask_head)
 
 
+@pytest.mark.parametrize('set_to_none', [False, True])
+def test_chain_graphs_deliver_gradients_to_the_bucketed_reducer(vkn, set_to_none):
+    """Captured chains hand their parameter gradients over in bulk (no autograd accumulation nodes): through
+    `BucketedGradAllReducer.params_ready` they must land in the buckets exactly like eager gradients do, in both zero_grad modes,
+    step after step (the delivered tensors alias the graphs' static buffers)."""
+    from importlib import import_module
+    vdist = import_module('video_k_net_amd.dist')
+    g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, 'train_video')
+    metas = [dict() for _ in range(case['B'])]
+
+    def grads(h, red, scale):
+        xd = (x * scale).to(DEV).requires_grad_(True)
+        if red is None:
+            for p in h.parameters():
+                p.grad = None
+        else:
+            red.zero_grad(set_to_none=set_to_none)
+        out = h.forward_train_with_previous(xd, pf.to(DEV), mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                            gt_sem_cls=gt_sem_cls, previous_obj_feats=prev.to(DEV))
+        (sum(v for k, v in out[0].items() if 'loss' in k) + 0.01 * (out[5] ** 2).sum()).backward()
+        if red is not None:
+            red.finalize()
+        return {k: p.grad.clone() for k, p in h.named_parameters() if p.grad is not None}
+
+    eager = [grads(head, None, sc) for sc in (1.0, 0.9)]
+    red = vdist.BucketedGradAllReducer(head)
+    head.enable_chain_graphs()
+    assert all(h.on_param_grads is not None for h in head.mask_head)
+    for e, sc in zip(eager, (1.0, 0.9)):
+        got = grads(head, red, sc)
+        for k in e:
+            assert k in got and maxabs(e[k], got[k]) <= 1e-6 * max(float(e[k].abs().max()), 1e-12), k
+        for b in red.buckets:                                     # every delivered gradient now lives in its bucket's flat buffer
+            for p, v in zip(b['params'], b['views']):
+                assert p.grad is None or p.grad.data_ptr() == v.data_ptr()
+    head.enable_chain_graphs(False)
+
+
 @pytest.mark.parametrize('B,Ns,H,W,K,with_rank', [(2, 17, 16, 24, 7, True), (4, 117, 32, 64, 40, True), (1, 20, 8, 12, 3, False),
                                                  (3, 33, 24, 20, 33, True)])
 def test_fused_mask_losses_vs_torch_ops(vkn, B, Ns, H, W, K, with_rank):

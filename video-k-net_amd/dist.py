@@ -102,9 +102,10 @@ class BucketedGradAllReducer:
       gradients.  This is the cheap mode for a step with one backward (~150 launches and dispatcher calls less per step of the
       K-Net head); the gradient tensors may alias a captured graph's static buffers (`enable_chain_graphs`), which is fine because
       they are consumed before the next replay.  Under `no_sync()` a dropped view is filled and re-attached at once.
-    * parameters that take part in no backward (the video head builds its link modules in every stage but uses the last stage's
-      only) are learned during the first synchronised step: from the second step on a bucket waits only for the parameters that
-      did fire, so stage buckets with unused members also overlap with backward.  When the set of used parameters changes
+    * which parameters take part in backward (the video head builds its link modules in every stage but uses the last stage's
+      only), and how often each one reports per step, is learned during the first synchronised step (reduced in `finalize()`):
+      from the second step on a bucket is launched the moment its expected reports are in, so stage buckets with unused members
+      also overlap with backward.  When the set of used parameters changes
       (e.g. switching between `forward_train` and `forward_train_with_previous`), call `reset_usage()`; a gradient arriving in a
       bucket that is already in flight raises instead of being silently lost."""
 
@@ -121,6 +122,7 @@ class BucketedGradAllReducer:
                 return f'stage{m.group(1)}' if m else 'rest'
         groups = {}
         seen = set()
+        self._hook_of = {}
         for name, p in module.named_parameters():
             if not p.requires_grad or id(p) in seen:        # shared parameters (recursive heads) are bucketed once
                 continue
@@ -129,15 +131,29 @@ class BucketedGradAllReducer:
         self.buckets = []
         for (key, dev, dt), params in groups.items():
             flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=dt)
-            b = dict(key=key, flat=flat, params=params, views=[], fired=set(), expect=None, handle=None, grew=False, pending=set())
+            b = dict(key=key, flat=flat, params=params, views=[], fired={}, nfired=0, expect=None, expect_total=0, handle=None, grew=False, pending=set())
             off = 0
             for i, p in enumerate(params):
                 v = flat[off:off + p.numel()].view_as(p)
                 b['views'].append(v)
                 p.grad = v
                 off += p.numel()
-                p.register_post_accumulate_grad_hook(self._make_hook(b, i))
+                hook = self._make_hook(b, i)
+                self._hook_of[id(p)] = hook
+                p.register_post_accumulate_grad_hook(hook)
             self.buckets.append(b)
+        # heads whose captured chain graphs deliver parameter gradients in bulk (KernelUpdateHead.enable_chain_graphs) report here
+        for m in module.modules():
+            if hasattr(m, 'on_param_grads'):
+                m.on_param_grads = self.params_ready
+
+    def params_ready(self, params):
+        """The gradients of `params` have been written to their `.grad` outside autograd's accumulation nodes (a captured backward
+        graph): the same bookkeeping as the post-accumulate hook."""
+        for p in params:
+            hook = self._hook_of.get(id(p))
+            if hook is not None:
+                hook(p)
 
     @staticmethod
     def _flush(b):
@@ -171,11 +187,17 @@ class BucketedGradAllReducer:
                                    'of used parameters changed — call reset_usage())')
             if not self._sync:
                 return
-            b['fired'].add(i)
-            if b['expect'] is not None and i not in b['expect']:
-                b['grew'] = True                                  # a parameter we did not expect: reduce this bucket in finalize()
-            want = b['expect'] if b['expect'] is not None else range(len(b['params']))
-            if self._coll and not b['grew'] and len(b['fired']) == len(want):
+            # a parameter may report more than once per backward (a captured chain delivers its share in bulk, an eager use of the same
+            # parameter reports through autograd later): the bucket is complete when every member has reported as often as it did
+            # in the steps seen so far.  The first synchronised step only learns (everything is reduced in finalize()).
+            n = b['fired'][i] = b['fired'].get(i, 0) + 1
+            b['nfired'] += 1
+            exp = b['expect']
+            if exp is None:
+                return
+            if n > exp.get(i, 0):
+                b['grew'] = True                                  # more than we expected: reduce this bucket in finalize()
+            if self._coll and not b['grew'] and b['nfired'] == b['expect_total']:
                 self._launch(b)
         return hook
 
@@ -211,7 +233,7 @@ class BucketedGradAllReducer:
                 for p, v in zip(b['params'], b['views']):
                     if p.grad is not v:
                         p.grad = v
-            b['fired'], b['handle'], b['grew'], b['pending'] = set(), None, False, set()
+            b['fired'], b['nfired'], b['handle'], b['grew'], b['pending'] = {}, 0, None, False, set()
 
     def finalize(self):
         """Launch the collectives of the buckets that are not in flight yet (first step, unused members, accumulation), wait for
@@ -219,13 +241,17 @@ class BucketedGradAllReducer:
         for b in self.buckets:
             if b['handle'] is None:
                 self._flush(b)
+            late = []
             for p, v in zip(b['params'], b['views']):
                 # `p.grad is None`: the parameter took no part in this step after a set_to_none zero_grad — it stays None (the
                 # optimizer skips it; whatever its slot of the flat buffer holds is reduced along and never read)
                 if p.grad is not None and p.grad is not v and p.grad.data_ptr() != v.data_ptr():
                     if b['handle'] is not None:   # a gradient assigned behind the hooks' back
                         raise RuntimeError(f"BucketedGradAllReducer: bucket '{b['key']}' was reduced without a member's gradient")
-                    v.copy_(p.grad)
+                    late.append((p, v))
+            if late:
+                torch._foreach_copy_([v for _, v in late], [p.grad for p, _ in late])
+                for p, v in late:
                     p.grad = v
         if self._coll:
             for b in self.buckets:
@@ -236,5 +262,8 @@ class BucketedGradAllReducer:
                 b['flat'].div_(self.world)
         for b in self.buckets:
             if self._sync and b['fired']:
-                b['expect'] = set(b['fired']) if b['expect'] is None else (b['expect'] | b['fired'])
-            b['fired'], b['handle'], b['grew'] = set(), None, False
+                exp = b['expect'] if b['expect'] is not None else {}
+                for i, n in b['fired'].items():
+                    exp[i] = max(exp.get(i, 0), n)
+                b['expect'], b['expect_total'] = exp, sum(exp.values())
+            b['fired'], b['nfired'], b['handle'], b['grew'] = {}, 0, None, False

@@ -80,6 +80,11 @@ class KernelIterHead(BaseRoIHead):
             h.enable_chain_graphs(on)
         return self
 
+    def _chain_graphs_new_step(self):
+        for h in self.mask_head:
+            if hasattr(h, 'chain_graphs_new_step'):
+                h.chain_graphs_new_step()
+
     def init_mask_head(self, mask_roi_extractor, mask_head):
         self.mask_head = nn.ModuleList()
         if not isinstance(mask_head, list):
@@ -182,6 +187,7 @@ class KernelIterHead(BaseRoIHead):
         if not self.mask_assigner:
             raise RuntimeError('forward_train needs train_cfg (one dict per stage with assigner / sampler / pos_weight)')
         num_imgs = len(img_metas)
+        self._chain_graphs_new_step()
         up = self.mask_head[0].mask_upsample_stride
         # what stage s is assigned on: the predictions it RECEIVES (reference :150-156, :225-226) — or, with `post_assign`, its own
         assign_masks = self._upsample(mask_preds.detach(), up) if up > 1 else mask_preds.detach()

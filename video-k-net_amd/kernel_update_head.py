@@ -77,6 +77,83 @@ class _ChainGraphModule(nn.Module):
         return tuple(o for o in out if o is not None)
 
 
+class _ChainGraphRunner:
+    """One captured (forward, backward) hipGraph pair of a stage's chain for fixed shapes.
+
+    `torch.cuda.make_graphed_callables` would do the capture too, but it returns every parameter gradient as an autograd output:
+    ~150 `detach` + accumulation nodes + per-parameter hooks per stage and backward — a third of the host time of a step that is
+    host-bound.  Here the parameters are constants of the captured graphs as far as autograd is concerned: the backward graph
+    computes their gradients into static buffers and `_deliver` hands them over in bulk — `p.grad = buffer` when the parameter has
+    no gradient yet (the buffer is consumed before the next replay: optimizer step / bucket copy), ONE multi-tensor add otherwise —
+    and then tells whoever registered `head.on_param_grads` (the bucketed all-reducer) which parameters are ready."""
+
+    def __init__(self, head, mod, samples, stream):
+        self.head, self.mod = head, mod
+        self.params = [p for p in mod.parameters() if p.requires_grad]
+        self.static_in = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in samples)
+        pool = torch.cuda.graph_pool_handle()
+        self.fwd, self.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd, pool=pool, stream=stream):
+            outs = mod(*self.static_in)
+        self.static_out = tuple(outs)
+        self.static_gout = tuple(torch.empty_like(o) if o.requires_grad else None for o in outs)
+        self.in_rg = [i for i, t in enumerate(self.static_in) if t.requires_grad]
+        surface = [self.static_in[i] for i in self.in_rg] + self.params
+        diff = [o for o in outs if o.requires_grad]
+        grads = ()
+        if diff and surface:
+            with torch.cuda.graph(self.bwd, pool=pool, stream=stream):
+                grads = torch.autograd.grad(diff, surface, [g for g in self.static_gout if g is not None], allow_unused=True)
+        self.has_bwd = len(grads) > 0
+        self.static_gin = [None] * len(self.static_in)
+        for i, g in zip(self.in_rg, grads[:len(self.in_rg)]):
+            self.static_gin[i] = g
+        pg = grads[len(self.in_rg):]
+        self.used = [(p, g) for p, g in zip(self.params, pg) if g is not None]      # parameters the chain really uses
+        self.in_flight = False        # a forward whose backward has not run yet
+
+    def _deliver(self):
+        fresh = [(p, g) for p, g in self.used if p.grad is None]
+        more = [(p, g) for p, g in self.used if p.grad is not None]
+        for p, g in fresh:
+            p.grad = g
+        if more:
+            torch._foreach_add_([p.grad for p, _ in more], [g for _, g in more])
+        cb = getattr(self.head, 'on_param_grads', None)
+        if cb is not None:
+            cb([p for p, _ in self.used])
+
+
+class _ChainGraphFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, runner, *inputs):
+        for st, t in zip(runner.static_in, inputs):
+            if st.data_ptr() != t.data_ptr():
+                st.detach().copy_(t)
+        runner.fwd.replay()
+        runner.in_flight = runner.has_bwd
+        ctx.runner = runner
+        return tuple(o.detach() for o in runner.static_out)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gouts):
+        r = ctx.runner
+        if not r.has_bwd:
+            return (None,) * (1 + len(r.static_in))
+        for st, g in zip(r.static_gout, gouts):
+            if st is not None:
+                if g is None:
+                    st.zero_()
+                elif st.data_ptr() != g.data_ptr():
+                    st.copy_(g)
+        r.bwd.replay()
+        r.in_flight = False
+        r._deliver()
+        return (None,) + tuple(g.detach() if g is not None else None for g in r.static_gin)
+
+
 @register_head
 class KernelUpdateHead(nn.Module):
 
@@ -318,14 +395,26 @@ class KernelUpdateHead(nn.Module):
 
         Streams: autograd binds a parameter's gradient-accumulation node to the stream it was created on, and the captured
         forward keeps those nodes alive.  When the training step runs on a NON-default stream (`with torch.cuda.stream(s):` around
-        forward, backward and the optimizer), the capture happens on that same stream and nothing crosses streams afterwards.  On
-        the default stream the capture needs a side stream, and every parameter gradient of the chains then pays an event
-        record / wait pair per backward (~150 per step of the K-Net head; torch warns about the mismatch once)."""
+        forward, backward and the optimizer), the capture happens on that same stream; on the default stream it needs a side stream.
+        Either way the replays run on the current stream.
+
+        Gradients: the parameters are constants of the captured graphs as far as autograd is concerned (`_ChainGraphRunner`): after
+        a stage's backward replay their gradients are in `p.grad` (set, or added to an existing one) without per-parameter autograd
+        nodes; `torch.autograd.grad(loss, parameters)` therefore does not see the chain's parameters.  A module may be in ONE
+        forward at a time: a second forward before the first one's backward (recursive heads, the frame-sequential last stage of
+        the previous_link heads) runs eagerly."""
         self._chain_graphs = {} if on else None
         return self
 
+    on_param_grads = None     # callable(list of parameters): set by BucketedGradAllReducer; called when a captured backward has delivered
+
+    def chain_graphs_new_step(self):
+        """Forget forwards whose backward never ran (a training step that was abandoned): their graphs are usable again."""
+        for runner, _ in (getattr(self, '_chain_graphs', None) or {}).values():
+            runner.in_flight = False
+
     def _chain_graph_for(self, x_feat, proposal_feat, previous_obj_feats):
-        """(graphed callable, module, contiguous args) for these shapes / requires-grad flags / mode; captures at first use."""
+        """(captured graph pair, module, contiguous args) for these shapes / requires-grad flags / mode; captures at first use."""
         import gc
         args = [x_feat, proposal_feat] + ([previous_obj_feats] if previous_obj_feats is not None else [])
         args = [a.contiguous() for a in args]
@@ -349,20 +438,19 @@ class KernelUpdateHead(nn.Module):
                 del outs, grads, surface
             torch.cuda.synchronize()
             gc.collect()
-            keep = torch.cuda.graph.default_capture_stream
-            if own:
-                torch.cuda.graph.default_capture_stream = cur           # capture where the step runs (see enable_chain_graphs)
-            try:
-                graphs[key] = (torch.cuda.make_graphed_callables(mod, samples, num_warmup_iters=0, allow_unused_input=True), mod)
-            finally:
-                torch.cuda.graph.default_capture_stream = keep
+            # capture on the stream the step runs on when that is not the default stream (a capture cannot use the default one)
+            graphs[key] = (_ChainGraphRunner(self, mod, samples, cur if own else None), mod)
         return graphs[key] + (args,)
 
     def _chain(self, x_feat, proposal_feat, previous_obj_feats=None):
         if getattr(self, '_chain_graphs', None) is None or not x_feat.is_cuda or not torch.is_grad_enabled():
             return self._chain_autograd(x_feat, proposal_feat, previous_obj_feats)
-        fn, mod, args = self._chain_graph_for(x_feat, proposal_feat, previous_obj_feats)
-        outs = iter(fn(*args))
+        runner, mod, args = self._chain_graph_for(x_feat, proposal_feat, previous_obj_feats)
+        if runner.in_flight or not any(a.requires_grad for a in args):
+            # a second forward of the same module before its backward (recursive heads, frame-sequential previous_link stages) would
+            # overwrite the activations the captured backward reads; inputs without gradients would cut the parameters off
+            return self._chain_autograd(x_feat, proposal_feat, previous_obj_feats)
+        outs = iter(_ChainGraphFn.apply(runner, *args))
         return tuple(next(outs) if present else None for present in mod.pattern)
 
     def _link_names(self, which):
