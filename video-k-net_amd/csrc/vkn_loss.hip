@@ -29,14 +29,20 @@ __global__ __launch_bounds__(256) void k_ml_rows(const float* __restrict__ pred,
     const float* t = target + row * P;
     const int p_lo = ck * ML_CHUNK, p_hi = min(P, p_lo + ML_CHUNK);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int p = p_lo + threadIdx.x; p < p_hi; p += 256) {
-        const float zz = z[p], tt = t[p];
-        // F.binary_cross_entropy_with_logits: max(z, 0) - z t + log(1 + exp(-|z|))
-        s0 += fmaxf(zz, 0.f) - zz * tt + log1pf(expf(-fabsf(zz)));
-        const float pp = 1.0f / (1.0f + expf(-zz));
-        s1 += pp * tt;
-        s2 += pp * pp;
-        s3 += tt * tt;
+    // 16-byte loads, two of each operand in flight per thread (P % 4 == 0 and 16-byte aligned rows: checked by the entry point)
+#pragma unroll 2
+    for (int p = p_lo + 4 * threadIdx.x; p < p_hi; p += 1024) {
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + p), tv = *reinterpret_cast<const f32x4*>(t + p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float zz = zv[e], tt = tv[e];
+            // F.binary_cross_entropy_with_logits: max(z, 0) - z t + log(1 + exp(-|z|))
+            s0 += fmaxf(zz, 0.f) - zz * tt + log1pf(expf(-fabsf(zz)));
+            const float pp = 1.0f / (1.0f + expf(-zz));
+            s1 += pp * tt;
+            s2 += pp * pp;
+            s3 += tt * tt;
+        }
     }
     s0 = vkn_wave_sum(s0); s1 = vkn_wave_sum(s1); s2 = vkn_wave_sum(s2); s3 = vkn_wave_sum(s3);
     const int w = threadIdx.x >> 6;
@@ -59,12 +65,13 @@ __global__ __launch_bounds__(256) void k_ml_rank_fwd(const float* __restrict__ p
     if (p < P) {
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s = {0.f, 0.f, 0.f, 0.f}, zt = {0.f, 0.f, 0.f, 0.f};
         int tp[4] = {-1, -1, -1, -1};
+#pragma unroll 4
         for (int n = 0; n < Ns; ++n) {
             const size_t off = ((size_t)b * Ns + n) * P + p;
             const f32x4 z = *reinterpret_cast<const f32x4*>(pred + off);
             const bool pos = rowk[b * Ns + n] >= 0;   // uniform
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (pos) t = *reinterpret_cast<const f32x4*>(target + off);
+            // (no branch around the second load, so that the loads of several rows can be in flight: a non-positive row re-reads z)
+            const f32x4 t = *reinterpret_cast<const f32x4*>((pos ? target : pred) + off);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float mn = fmaxf(m[e], z[e]);
@@ -210,6 +217,68 @@ __global__ __launch_bounds__(256) void k_focal(const float* __restrict__ z, cons
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// The same adjoint for S = 2 and rows that are whole multiples of a wavefront (W % 64 == 0): a thread owns one input column and UB2_R
+// consecutive input rows.  Per output row it loads ONE aligned float2 (columns 2x, 2x + 1) and takes columns 2x - 1 / 2x + 2 from
+// its lane neighbours' pairs (wave-edge lanes fetch theirs), forms the horizontal sum once — adjacent input rows share two of their
+// four output rows — and blends vertically.  Same weights, same order of additions as k_upsample_bwd<2>: bit-identical, a quarter
+// of the load instructions and every output element fetched ~1.25 times instead of 4.
+#define UB2_R 4
+__global__ __launch_bounds__(256) void k_upsample_bwd2(const float* __restrict__ gout, float* __restrict__ gin, int H, int W) {
+    const int plane = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y0 = blockIdx.y * UB2_R;
+    if (x >= W) return;   // (whole waves: W % 64 == 0)
+    const int lane = threadIdx.x & 63;
+    const int OH = 2 * H, OW = 2 * W;
+    const float* gp = gout + (size_t)plane * OH * OW;
+    float wxs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ox = 2 * x - 1 + j;
+        const float sx = fmaxf(((float)ox + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int x0 = min((int)sx, W - 1), x1 = min(x0 + 1, W - 1);
+        const float lx = sx - (float)x0;
+        const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+        wxs[j] = (ox >= 0 && ox < OW) ? wx : 0.f;
+    }
+    float hs[2 * UB2_R + 2];   // horizontal sums of output rows 2 y0 - 1 .. 2 y0 + 2 R
+#pragma unroll
+    for (int i = 0; i < 2 * UB2_R + 2; ++i) {
+        const int oy = 2 * y0 - 1 + i;
+        float h = 0.f;
+        if (oy >= 0 && oy < OH) {   // uniform
+            const float* rp = gp + (size_t)oy * OW + 2 * x;
+            const float2 v = *reinterpret_cast<const float2*>(rp);
+            float vm = __shfl_up(v.y, 1), vp = __shfl_down(v.x, 1);
+            if (lane == 0 && x > 0) vm = rp[-1];
+            if (lane == 63 && x + 1 < W) vp = rp[2];
+            if (wxs[0] != 0.f) h += wxs[0] * vm;
+            if (wxs[1] != 0.f) h += wxs[1] * v.x;
+            if (wxs[2] != 0.f) h += wxs[2] * v.y;
+            if (wxs[3] != 0.f) h += wxs[3] * vp;
+        }
+        hs[i] = h;
+    }
+#pragma unroll
+    for (int r = 0; r < UB2_R; ++r) {
+        const int y = y0 + r;
+        if (y >= H) break;   // uniform
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = 2 * y - 1 + i;
+            if (oy < 0 || oy >= OH) continue;
+            const float sy = fmaxf(((float)oy + 0.5f) * 0.5f - 0.5f, 0.f);
+            const int yy0 = min((int)sy, H - 1), yy1 = min(yy0 + 1, H - 1);
+            const float ly = sy - (float)yy0;
+            const float wy = (yy0 == y ? 1.f - ly : 0.f) + (yy1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            acc += wy * hs[2 * r + i];
+        }
+        gin[((size_t)plane * H + y) * W + x] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -218,6 +287,15 @@ int vkn_upsample_bilinear_bwd_f32(const float* grad_out, float* grad_in, int pla
     if (!grad_out || !grad_in || planes <= 0 || H <= 0 || W <= 0 || S < 1) return VKN_E_ARG;
     if (S > 4 && S != 8) return VKN_E_SHAPE;   // scale factors of the shipped configs: 2 (training), 4 (inference), 8 (semantic branch)
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (S == 2 && (W % 64) == 0 && ((reinterpret_cast<uintptr_t>(grad_out) & 7) == 0)) {   // the training configs' scale
+        for (int done = 0; done < planes; done += 32768) {  // gridDim.z <= 65535
+            const int chunk = (planes - done > 32768) ? 32768 : planes - done;
+            hipLaunchKernelGGL(k_upsample_bwd2, dim3((W + 255) / 256, (H + UB2_R - 1) / UB2_R, chunk), dim3(256), 0, st,
+                               grad_out + (size_t)done * H * S * W * S, grad_in + (size_t)done * H * W, H, W);
+            VKN_CHECK_LAUNCH();
+        }
+        return VKN_OK;
+    }
     for (int done = 0; done < planes; done += 32768) {  // gridDim.y <= 65535
         const int chunk = (planes - done > 32768) ? 32768 : planes - done;
         const float* go = grad_out + (size_t)done * H * S * W * S;
