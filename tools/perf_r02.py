@@ -171,10 +171,12 @@ def main():
             wb = B * N * P * 16 * 4
             print(f'upsample x4 B={B}: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s of writes', flush=True)
             if not args.release:
-                for mode in (24, 11, 64, 74, 34):   # plain stores, one row group per WG, nontemporal input loads, all loads up front, write-only   # 2x plain stores, x1 one row group, x8 / x9 = 8 / 32 groups per WG, 3x write-only
+                ref = vkn.ops.upsample_bilinear(m, 4)
+                for mode in tuple(int(v) for v in os.environ.get('UPMODES', '24,11,64,74,34').split(',')):   # 1RX: k_upsample_f (fill pattern), R code 0/1/2 = 2/4/8 rows, X = 2*xmap + nt;  plain stores, one row group per WG, nontemporal input loads, all loads up front, write-only   # 2x plain stores, x1 one row group, x8 / x9 = 8 / 32 groups per WG, 3x write-only
                     os.environ['VKN_UPSAMPLE'] = str(mode)
                     t = timeit(lambda: vkn.ops.upsample_bilinear(m, 4), reps=10, warm=3)
-                    print(f'upsample x4 B={B} mode={mode}: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s of writes', flush=True)
+                    same = bool(torch.equal(vkn.ops.upsample_bilinear(m, 4), ref)) if mode >= 100 else None
+                    print(f'upsample x4 B={B} mode={mode}: {t:8.1f} us  {wb / t / 1e6:7.3f} TB/s of writes' + ('' if same is None else f'  bit-identical to the shipped kernel: {same}'), flush=True)
                 os.environ.pop('VKN_UPSAMPLE')
             o = torch.empty(B, N, H * 4, W * 4, device=dev)
             t = timeit(lambda: o.fill_(1.0), reps=10, warm=3)

@@ -1491,6 +1491,10 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
     }
 }
 
+#ifdef VKN_DEBUG  // k_upsample_f (fill-pattern x4 upsample; measured slower): tools/experiments/upsample_fill.inc
+#include "../../tools/experiments/upsample_fill.inc"
+#endif
+
 int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream) {
     if (S < 1) return VKN_E_SHAPE;
     int done = 0;
@@ -1500,6 +1504,19 @@ int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, i
         float* op = out + (size_t)done * H * S * W * S;
         const int mode = vkn_dbg_env("VKN_UPSAMPLE", 14);  // debug build only: 0 = generic kernel; 1x/2x = staged nt/plain stores, x = 1|4 groups
         const bool staged = mode != 0 && (S == 2 || S == 4) && ((W * S) % 4) == 0 && (reinterpret_cast<uintptr_t>(op) & 15) == 0;
+#ifdef VKN_DEBUG
+        if (mode >= 100 && S == 4 && (W % 64) == 0 && (reinterpret_cast<uintptr_t>(op) & 15) == 0) {   // k_upsample_f A/B: 1 <R code> <xmap*2 + nt>
+            const int rc = (mode / 10) % 10, xm = (mode % 10) >> 1, ntv = mode & 1;
+            const int R = rc == 0 ? 2 : rc == 1 ? 4 : 8;
+            const int ngroups = (H * 4 + 8 * R - 1) / (8 * R);
+            dim3 grid(xm ? ((ngroups + 7) / 8) * 64 : ngroups * 8, chunk);
+#define UF_LAUNCH(RV, XV, NV) hipLaunchKernelGGL((k_upsample_f<RV, XV, NV>), grid, dim3(256), 0, stream, ip, op, H, W)
+            if (R == 2) { if (xm) { if (ntv) UF_LAUNCH(2, 1, 1); else UF_LAUNCH(2, 1, 0); } else { if (ntv) UF_LAUNCH(2, 0, 1); else UF_LAUNCH(2, 0, 0); } }
+            else if (R == 4) { if (xm) { if (ntv) UF_LAUNCH(4, 1, 1); else UF_LAUNCH(4, 1, 0); } else { if (ntv) UF_LAUNCH(4, 0, 1); else UF_LAUNCH(4, 0, 0); } }
+            else { if (xm) { if (ntv) UF_LAUNCH(8, 1, 1); else UF_LAUNCH(8, 1, 0); } else { if (ntv) UF_LAUNCH(8, 0, 1); else UF_LAUNCH(8, 0, 0); } }
+#undef UF_LAUNCH
+        } else
+#endif
         if (staged) {
             const bool nt = mode / 10 != 2;
             const int subs = (mode % 10 == 1) ? 1 : 4;
