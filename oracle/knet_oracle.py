@@ -122,7 +122,7 @@ def link_block(sd, pfx, sfx, with_updator, update_feature, cur, prev, cfg: HeadC
     return _ln(sd, f'{pfx}.link_ffn_norm{sfx}', ffn(sd, f'{pfx}.link_ffn{sfx}', t, cfg.num_ffn_fcs), cfg.ln_eps)
 
 
-def query_merge(sd, pfx, query, keys, pos=None, ln_eps=1e-5):
+def query_merge(sd, pfx, query, keys, pos=None, ln_eps=1e-5, heads=8):
     """Clip-level attention query merge of the VIS heads (knet_vis/tracker/kernel_frame_iter_head.py:142-160,
     knet_vis/tracker/kernel_update_head.py:244-263):
          t   = query_merge_norm(query_merge_attn(query=query, key=keys, value=keys, query_pos=pos, key_pos=pos per frame))   (8 heads)
@@ -137,7 +137,7 @@ def query_merge(sd, pfx, query, keys, pos=None, ln_eps=1e-5):
         q = query + pos[None]
         k = keys + pos[None].repeat(1, F_, 1)
     t = multihead_attention(sd, p + 'query_merge_attn', q.permute(1, 0, 2), k.permute(1, 0, 2), keys.permute(1, 0, 2),
-                            query.permute(1, 0, 2), 8).permute(1, 0, 2)
+                            query.permute(1, 0, 2), heads).permute(1, 0, 2)   # (the reference builds it with 8 heads)
     t = _ln(sd, p + 'query_merge_norm', t, ln_eps)
     return _ln(sd, p + 'query_merge_ffn_norm', ffn(sd, p + 'query_merge_ffn', t, 2), ln_eps)
 

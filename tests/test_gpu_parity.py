@@ -819,6 +819,30 @@ def test_head_vipseg_kernel_count_vs_oracle(vkn, hw):
     assert maxabs(m1, rm) < TOL_LOGIT and maxabs(cls1, traces[1]['cls_score']) < 1e-4
 
 
+@pytest.mark.parametrize('C,heads,N', [(256, 4, 40), (256, 4, 166), (256, 8, 20), (256, 8, 60), (256, 8, 230), (128, 8, 117),
+                                       (256, 16, 100), (128, 2, 33)])
+def test_stage_attention_head_widths_and_key_blocks_vs_oracle(vkn, C, heads, N):
+    """The kernel-to-kernel attention on the matrix cores (k_attn_mfma) for every head width it takes (16 / 32 / 64 channels) and
+    every key-block count (N = 20 .. 230 kernels -> 1, 2, 4, 6, 8 blocks of 32 keys): one stage, same inputs, against the oracle."""
+    from test_host_logic import _cfg
+    H, W = 8, 16
+    kw = dict(C=C, heads=heads, ffn=2 * C, ncls=19, n_thing=8, n_stuff=11, S=1, up=1, nprop=N - 11)
+    case = dict(kw, N=N, H=H, W=W, B=2, seed=300 + N + heads, video=0)
+    head = vkn.build_head(_cfg(False, **kw))
+    cfg, sd, x, pf, mp, _ = make_case(case)
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV).eval()
+    with torch.no_grad():
+        traces = []
+        O.iter_head_mask_preds(sd, x, pf, mp, cfg, traces=traces)
+    dims = head.mask_head[0].make_dims(2, N, H, W)
+    pack = head.mask_head[0].stage_pack(torch.device(DEV))
+    cls0, m0, o0, _, _ = vkn.ops.stage_forward(dims, pack, x.to(DEV), pf.reshape(2, N, C).to(DEV), mp.to(DEV))
+    t0 = traces[0]
+    assert maxabs(o0, t0['obj_feat'].reshape(2, N, C)) < 2e-4
+    assert maxabs(m0, t0['new_mask_preds']) < TOL_LOGIT and maxabs(cls0, t0['cls_score']) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------ train-time assignment
 @pytest.mark.parametrize('name', ['assign_tiny', 'assign_cfg', 'assign_odd'])
 def test_assignment_vs_reference(vkn, name):

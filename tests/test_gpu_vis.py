@@ -96,12 +96,17 @@ def test_vis_pipeline_vs_reference_golden(vkn, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,N,C,F,with_pos', [(2, 20, 64, 3, False), (1, 100, 256, 3, True), (2, 100, 256, 5, False), (1, 128, 128, 8, True),
-                                              (3, 50, 256, 1, True)])
-def test_query_merge_op_vs_oracle(vkn, B, N, C, F, with_pos):
+@pytest.mark.parametrize('case', [(2, 20, 64, 3, False), (1, 100, 256, 3, True), (2, 100, 256, 5, False), (1, 128, 128, 8, True),
+                                              (3, 50, 256, 1, True),
+                                              # the matrix-core attention (k_attn_mfma: <= 256 keys, head width 16 / 32 / 64), every key-block count
+                                              (2, 10, 256, 2, True), (1, 60, 256, 2, False), (1, 90, 256, 2, True), (2, 128, 256, 2, True),
+                                              (1, 33, 128, 3, True), (2, 7, 128, 1, False), (1, 117, 256, 1, False), (2, 100, 256, 2, False)])
+def test_query_merge_op_vs_oracle(vkn, case):
     """`vkn_query_merge_f32` against the oracle's restatement: <= 256 keys (the LDS-staged attention kernel) and more (keys from
     global memory, scores in LDS), with and without the position table.  fp32 tolerance of the bf16x3 GEMMs."""
     from oracle.knet_oracle import query_merge
+    B, N, C, F, with_pos = case[:5]
+    heads = 8                                        # (the merge attention is built with 8 heads whatever the stages use: the reference's)
     g = torch.Generator().manual_seed(1000 + N + F)
     shapes = {'query_merge_attn.attn.in_proj_weight': (3 * C, C), 'query_merge_attn.attn.in_proj_bias': (3 * C,),
               'query_merge_attn.attn.out_proj.weight': (C, C), 'query_merge_attn.attn.out_proj.bias': (C,),
@@ -113,7 +118,7 @@ def test_query_merge_op_vs_oracle(vkn, B, N, C, F, with_pos):
     query = torch.randn(B, N, C, generator=g)
     keys = torch.randn(B, F * N, C, generator=g)
     pos = torch.randn(N, C, generator=g) if with_pos else None
-    ref = query_merge(sd, '', query, keys, pos)
+    ref = query_merge(sd, '', query, keys, pos, heads=heads)
     named = {k: v.to(DEV) for k, v in sd.items()}
     pack = vkn.ops.link_pack(named, torch.device(DEV), None, 'query_merge_attn', 'query_merge_norm', 'query_merge_ffn', 'query_merge_ffn_norm')
     dims = vkn.ops.make_dims(B, N, C, 8, 8, 8, 8 * C, 1, 0, 0)
