@@ -54,40 +54,49 @@ __global__ __launch_bounds__(256) void k_ml_rows(const float* __restrict__ pred,
     }
 }
 
-// frame b, pixels 4 * (blockIdx.x * 256 + tid) .. + 3: walk the Ns rows.  rowk [R]: index of a row among the positives or -1.
+// frame b, pixels ML_PX * (blockIdx.x * ML_PXB + tid) .. : walk the Ns rows.  rowk [R]: index of a row among the positives or -1.
+// Two pixels per thread (8-byte loads): twice the waves of the 4-pixel version for the serial online-softmax walk over the rows.
+// partial [B][vkn_mask_losses_blocks(P)]: one value per workgroup (512 pixels of a frame).
+constexpr int ML_PX = 2;
+typedef float ml_vec __attribute__((ext_vector_type(ML_PX)));
+typedef int ml_ivec __attribute__((ext_vector_type(ML_PX)));
 __global__ __launch_bounds__(256) void k_ml_rank_fwd(const float* __restrict__ pred, const float* __restrict__ target,
                                                      const int* __restrict__ rowk, int Ns, int P, float* __restrict__ lse,
                                                      int* __restrict__ top, float* __restrict__ partial) {
     __shared__ float red[4];
     const int b = blockIdx.y;
-    const int p = 4 * (blockIdx.x * 256 + threadIdx.x);
+    const int p = ML_PX * (blockIdx.x * 256 + threadIdx.x);
     float loss = 0.f;
     if (p < P) {
-        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s = {0.f, 0.f, 0.f, 0.f}, zt = {0.f, 0.f, 0.f, 0.f};
-        int tp[4] = {-1, -1, -1, -1};
+        float m[ML_PX], s[ML_PX], zt[ML_PX];
+        int tp[ML_PX];
+#pragma unroll
+        for (int e = 0; e < ML_PX; ++e) { m[e] = -INFINITY; s[e] = 0.f; zt[e] = 0.f; tp[e] = -1; }
 #pragma unroll 4
         for (int n = 0; n < Ns; ++n) {
             const size_t off = ((size_t)b * Ns + n) * P + p;
-            const f32x4 z = *reinterpret_cast<const f32x4*>(pred + off);
+            const ml_vec z = *reinterpret_cast<const ml_vec*>(pred + off);
             const bool pos = rowk[b * Ns + n] >= 0;   // uniform
             // (no branch around the second load, so that the loads of several rows can be in flight: a non-positive row re-reads z)
-            const f32x4 t = *reinterpret_cast<const f32x4*>((pos ? target : pred) + off);
+            const ml_vec t = *reinterpret_cast<const ml_vec*>((pos ? target : pred) + off);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < ML_PX; ++e) {
                 const float mn = fmaxf(m[e], z[e]);
                 s[e] = s[e] * expf(m[e] - mn) + expf(z[e] - mn);
                 m[e] = mn;
                 if (pos && t[e] != 0.f) { tp[e] = n; zt[e] = z[e]; }
             }
         }
-        f32x4 l;
+        ml_vec l;
+        ml_ivec tv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < ML_PX; ++e) {
             l[e] = m[e] + logf(s[e]);
+            tv[e] = tp[e];
             if (tp[e] >= 0) loss += l[e] - zt[e];
         }
-        *reinterpret_cast<f32x4*>(lse + (size_t)b * P + p) = l;
-        *reinterpret_cast<int4*>(top + (size_t)b * P + p) = make_int4(tp[0], tp[1], tp[2], tp[3]);
+        *reinterpret_cast<ml_vec*>(lse + (size_t)b * P + p) = l;
+        *reinterpret_cast<ml_ivec*>(top + (size_t)b * P + p) = tv;
     }
     loss = vkn_wave_sum(loss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = loss;
@@ -112,7 +121,12 @@ __global__ __launch_bounds__(256) void k_ml_bwd(const float* __restrict__ pred, 
         tp = *reinterpret_cast<const int4*>(top + (size_t)b * P + p);
     }
     const int tpv[4] = {tp.x, tp.y, tp.z, tp.w};
-    for (int n = 0; n < Ns; ++n) {
+    // the rows are independent here: gridDim.z workgroups share a pixel range's rows (more waves in flight per CU than the 8 a
+    // [P / 1024, B] grid gives at training sizes)
+    const int rpz = (Ns + gridDim.z - 1) / gridDim.z;
+    const int n_hi = min(Ns, (int)(blockIdx.z + 1) * rpz);
+#pragma unroll 2
+    for (int n = blockIdx.z * rpz; n < n_hi; ++n) {
         const size_t off = ((size_t)b * Ns + n) * P + p;
         const f32x4 z = *reinterpret_cast<const f32x4*>(pred + off);
         const int k = rowk[b * Ns + n];   // uniform
@@ -329,7 +343,7 @@ int vkn_focal_loss_f32(const float* logits, const long long* labels, const float
 }
 
 int vkn_mask_losses_chunks(int P) { return P > 0 ? (P + ML_CHUNK - 1) / ML_CHUNK : 0; }
-int vkn_mask_losses_blocks(int P) { return P > 0 ? (P / 4 + 255) / 256 : 0; }
+int vkn_mask_losses_blocks(int P) { return P > 0 ? (P / ML_PX + 255) / 256 : 0; }   // workgroups per frame of k_ml_rank_fwd
 
 int vkn_mask_losses_fwd_f32(const float* pred, const float* target, const long long* pos_rows, const int* rowk, int K, int B, int Ns,
                             int P, int with_rank, float* row_partial, float* lse, int* top, float* rank_partial, void* stream) {
@@ -357,7 +371,7 @@ int vkn_mask_losses_bwd_f32(const float* pred, const float* target, const int* r
     if (with_rank && (!lse || !top)) return VKN_E_ARG;
     if ((P & 3) || ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(grad)) & 15))
         return VKN_E_ALIGN;
-    hipLaunchKernelGGL(k_ml_bwd, dim3(vkn_mask_losses_blocks(P), B), dim3(256), 0, static_cast<hipStream_t>(stream), pred, target, rowk,
+    hipLaunchKernelGGL(k_ml_bwd, dim3((P / 4 + 255) / 256, B, 4), dim3(256), 0, static_cast<hipStream_t>(stream), pred, target, rowk,
                        rowcoef, coef, lse, top, Ns, P, with_rank, grad);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
