@@ -41,12 +41,12 @@ for _ in range(8):
     step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=bool(os.environ.get('SHAPES'))) as prof:
     for _ in range(5):
         step()
     torch.cuda.synchronize()
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 45
-print(prof.key_averages().table(sort_by=os.environ.get('SORT', 'self_cpu_time_total'), row_limit=top, max_name_column_width=60))
+print(prof.key_averages(group_by_input_shape=bool(os.environ.get('SHAPES'))).table(sort_by=os.environ.get('SORT', 'self_cpu_time_total'), row_limit=top, max_name_column_width=60))
 ev = prof.key_averages()
 print('total op calls per step:', sum(e.count for e in ev) / 5)
 print('kernel launches per step (hipLaunchKernel + ExtLaunch):', sum(e.count for e in ev if 'aunch' in e.key) / 5)

