@@ -317,6 +317,57 @@ def t_query_merge():
     assert float((out.cpu() - ref).abs().max()) < 3e-4, ('query_merge', B, N, C, Fr, with_pos)
 
 
+def t_train_ops():
+    """round-3 training kernels against torch: focal loss (value + gradient, per-row / per-element weights), the upsample adjoint
+    (every scale the entry takes, the S = 2 lane-exchange kernel when W % 64 == 0), the fused mask losses' gradient."""
+    with torch.enable_grad():
+        M, ncls = int(rng.integers(1, 700)), int(rng.integers(1, 140))
+        z = (torch.randn(M, ncls, device=dev) * 4)
+        lab = torch.randint(0, ncls + 1, (M,), device=dev)
+        wk = int(rng.integers(0, 3))
+        w = None if wk == 0 else (torch.rand((M,) if wk == 1 else (M, ncls), device=dev) > 0.3).float()
+        avg = torch.tensor(float(rng.integers(1, 50)), device=dev)
+        loss = vkn.losses.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=float(rng.uniform(0.5, 3)))
+        za, zb = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+        la = loss(za, lab, w, avg_factor=avg)
+        loss.fused = False
+        lb = loss(zb, lab, w, avg_factor=avg)
+        la.backward(); lb.backward()
+        assert abs(float(la) - float(lb)) <= 2e-5 * max(abs(float(lb)), 1e-6), ('focal', M, ncls, wk)
+        assert float((za.grad - zb.grad).abs().max()) <= 2e-5 * float(zb.grad.abs().max()) + 1e-9, ('focal grad', M, ncls, wk)
+        S = int(rng.choice([1, 2, 2, 2, 3, 4, 8]))
+        H, W = int(rng.integers(1, 24)), int(rng.choice([int(rng.integers(1, 80)), 64, 128, 192]))
+        x = torch.randn(int(rng.integers(1, 3)), int(rng.integers(1, 5)), H, W, device=dev)
+        g = torch.randn(x.shape[0], x.shape[1], H * S, W * S, device=dev)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        vkn.autograd.upsample_bilinear(xa, S).backward(g)
+        F.interpolate(xb, scale_factor=S, mode='bilinear', align_corners=False).backward(g)
+        assert float((xa.grad - xb.grad).abs().max()) < 2e-5 * float(xb.grad.abs().max()), ('upsample adjoint', S, tuple(x.shape))
+
+
+def t_attn_widths():
+    """one stage through k_attn_mfma for head widths 16 / 32 / 64 and 1 .. 8 key blocks (N <= 256) against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_host_logic import _cfg
+    from helpers import make_case
+    C, heads = [(256, 4), (256, 8), (128, 8), (256, 16), (128, 4), (64, 4)][int(rng.integers(0, 6))]
+    N = int(rng.integers(13, 250))
+    kw = dict(C=C, heads=heads, ffn=2 * C, ncls=19, n_thing=8, n_stuff=11, S=1, up=1, nprop=N - 11)
+    case = dict(kw, N=N, H=4, W=8, B=int(rng.integers(1, 3)), seed=int(rng.integers(0, 1 << 20)), video=0)
+    key = ('aw', C, heads, N)
+    head = vkn.build_head(_cfg(False, **kw))
+    cfg, sd, x, pf, mp, _ = make_case(case)
+    head.load_state_dict(sd, strict=True)
+    head = head.to(dev).eval()
+    traces = []
+    O.iter_head_mask_preds(sd, x, pf, mp, cfg, traces=traces)
+    B = case['B']
+    dims = head.mask_head[0].make_dims(B, N, 4, 8)
+    pack = head.mask_head[0].stage_pack(torch.device(dev))
+    _, _, o0, _, _ = vkn.ops.stage_forward(dims, pack, x.to(dev), pf.reshape(B, N, C).to(dev), mp.to(dev))
+    assert float((o0.cpu() - traces[0]['obj_feat'].reshape(B, N, C)).abs().max()) < 3e-4, ('attention widths', C, heads, N, B)
+
+
 _heads = {}
 only = sys.argv[2:]
 with torch.no_grad():
@@ -325,7 +376,8 @@ with torch.no_grad():
                      ('kernel init', t_kernel_init), ('head C=256 split vs exact GEMMs', t_head_c256),
                      ('head fused / bits / logits / side stream', t_head_fused), ('half-storage x', t_xhalf),
                      ('device LSAP vs host solver', t_lsap), ('device tracker vs oracle', t_tracker),
-                     ('link heads clip vs frame-by-frame', t_link_heads), ('VIS attention query merge', t_query_merge)):
+                     ('link heads clip vs frame-by-frame', t_link_heads), ('VIS attention query merge', t_query_merge),
+                     ('training ops vs torch', t_train_ops), ('attention head widths / key blocks', t_attn_widths)):
         if not only or any(o in name for o in only):
             section(name, fn)
 print('soak: OK')
