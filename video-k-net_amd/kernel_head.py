@@ -290,39 +290,54 @@ class ConvKernelHead(nn.Module):
                 losses['loss_rpn_seg'] = self.loss_seg(flat, tgt, ignore_index=self.num_classes)
         return losses
 
-    def _get_target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls, cfg):
-        """:427-466.  `seg_targets`: the dense semantic target — stuff classes first, then every positive instance's label painted
-        over its ground-truth mask in sample order."""
-        num_pos, num_neg = pos_mask.size(0), neg_mask.size(0)
-        n = num_pos + num_neg
-        H, W = pos_mask.shape[-2:]
-        labels = pos_mask.new_full((n,), self.num_classes, dtype=torch.long)
-        label_weights = pos_mask.new_zeros(n)
-        mask_targets = pos_mask.new_zeros(n, H, W)
-        mask_weights = pos_mask.new_zeros(n, H, W)
-        seg_targets = pos_mask.new_full((H, W), self.num_classes, dtype=torch.long)
-        if gt_sem_cls is not None and gt_sem_seg is not None:
-            for sem_mask, sem_cls in zip(gt_sem_seg.bool(), gt_sem_cls):
-                seg_targets[sem_mask] = sem_cls.long()
-        if num_pos > 0:
-            labels[pos_inds] = pos_gt_labels
+    def _image_targets(self, n, shape, dtype, dev, pos_inds, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls, cfg):
+        """Targets of one image (reference :427-466) from what defines them — the matched rows with their ground truth — without the
+        matched / unmatched mask copies the reference passes around:
+          labels [n] (background = num_classes), label_weights [n] (matched: pos_weight if > 0, everything else 1),
+          mask_targets [n, H, W] and mask_weights (1 on the matched rows; an expanded view of a [n] vector),
+          seg_targets [H, W]: the dense semantic target.  The reference PAINTS it — the stuff masks in order, then every matched
+          instance's label over its mask in sample order — so a pixel ends up with the label of the LAST layer covering it; here
+          that is one masked arg-max over the stacked layers (no per-instance boolean-mask writes, each of which synchronises)."""
+        H, W = shape
+        k = int(pos_inds.shape[0])
+        labels = torch.full((n,), self.num_classes, dtype=torch.long, device=dev)
+        label_weights = torch.ones((n,), dtype=dtype, device=dev)       # unmatched rows weigh 1, matched ones pos_weight
+        mask_targets = torch.zeros((n, H, W), dtype=dtype, device=dev)
+        row_w = torch.zeros((n,), dtype=dtype, device=dev)
+        layers, layer_labels = [], []
+        if gt_sem_cls is not None and gt_sem_seg is not None and len(gt_sem_cls) > 0:
+            layers.append(gt_sem_seg.to(dev).bool())
+            layer_labels.append(gt_sem_cls.to(dev).long())
+        if k > 0:
             pw = self._cfg(cfg, 'pos_weight')
-            label_weights[pos_inds] = 1.0 if pw <= 0 else pw
-            mask_targets[pos_inds, ...] = pos_gt_mask
-            mask_weights[pos_inds, ...] = 1
-            for i in range(num_pos):
-                seg_targets[pos_gt_mask[i].bool()] = pos_gt_labels[i]
-        if num_neg > 0:
-            label_weights[neg_inds] = 1.0
-        return labels, label_weights, mask_targets, mask_weights, seg_targets
+            labels[pos_inds] = pos_gt_labels
+            if pw > 0 and pw != 1:
+                label_weights.index_fill_(0, pos_inds, float(pw))
+            mask_targets[pos_inds] = pos_gt_mask.to(dtype)
+            row_w.index_fill_(0, pos_inds, 1.0)
+            layers.append(pos_gt_mask.bool())
+            layer_labels.append(pos_gt_labels.long())
+        if layers:
+            stack, lab = torch.cat(layers), torch.cat(layer_labels)
+            order = torch.arange(stack.shape[0], device=dev, dtype=torch.int32).view(-1, 1, 1)
+            top = torch.where(stack, order, order.new_full((), -1)).amax(dim=0).long()
+            seg_targets = torch.where(top >= 0, lab[top.clamp(min=0)], lab.new_full((), self.num_classes))
+        else:
+            seg_targets = torch.full((H, W), self.num_classes, dtype=torch.long, device=dev)
+        return labels, label_weights, mask_targets, row_w.view(-1, 1, 1).expand(-1, H, W), seg_targets
+
+    def _get_target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls, cfg):
+        """The reference's per-image entry point (:427-466), kept for callers that hold its argument list."""
+        return self._image_targets(pos_mask.size(0) + neg_mask.size(0), tuple(pos_mask.shape[-2:]), pos_mask.dtype, pos_mask.device,
+                                   pos_inds, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls, cfg)
 
     def get_targets(self, sampling_results, gt_mask, rpn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None):
         """:468-504"""
         n = len(sampling_results)
         if gt_sem_seg is None:
             gt_sem_seg, gt_sem_cls = [None] * n, [None] * n      # (the reference hard-codes 2, :480-481)
-        out = [self._get_target_single(r.pos_inds, r.neg_inds, r.pos_masks, r.neg_masks, r.pos_gt_masks, r.pos_gt_labels,
-                                       gt_sem_seg[i], gt_sem_cls[i], rpn_train_cfg) for i, r in enumerate(sampling_results)]
+        out = [self._image_targets(r.num_pos + r.num_neg, r.mask_shape[-2:], r.mask_dtype, r.device, r.pos_inds, r.pos_gt_masks, r.pos_gt_labels, gt_sem_seg[i], gt_sem_cls[i], rpn_train_cfg)
+               for i, r in enumerate(sampling_results)]
         labels, label_weights, mask_targets, mask_weights, seg_targets = (list(t) for t in zip(*out))
         if concat:
             labels, label_weights = torch.cat(labels, 0), torch.cat(label_weights, 0)

@@ -598,58 +598,22 @@ class KernelUpdateHead(nn.Module):
                 and (lr is None or (type(lr) is L.CrossEntropyLoss and not lr.use_sigmoid and not lr.use_mask and lr.reduction == 'mean'
                                     and lr.class_weight is None)))
 
-    def _get_target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls,
-                           cfg):
-        num_pos, num_neg = pos_mask.size(0), neg_mask.size(0)
-        num_samples = num_pos + num_neg
-        H, W = pos_mask.shape[-2:]
-        labels = pos_mask.new_full((num_samples,), self.num_classes, dtype=torch.long)
-        label_weights = pos_mask.new_zeros((num_samples, self.num_classes))
-        mask_targets = pos_mask.new_zeros(num_samples, H, W)
-        mask_weights = pos_mask.new_zeros(num_samples, H, W)
-        if num_pos > 0:
-            labels[pos_inds] = pos_gt_labels
-            pw = cfg['pos_weight'] if isinstance(cfg, dict) else cfg.pos_weight
-            label_weights[pos_inds] = 1.0 if pw <= 0 else pw
-            mask_targets[pos_inds, ...] = pos_gt_mask
-            mask_weights[pos_inds, ...] = 1
-        if num_neg > 0:
-            label_weights[neg_inds] = 1.0
-        if gt_sem_cls is not None and gt_sem_seg is not None:
-            S, T = self.num_stuff_classes, self.num_thing_classes
-            sem_labels = pos_mask.new_full((S,), self.num_classes, dtype=torch.long)
-            sem_targets = pos_mask.new_zeros(S, H, W)
-            sem_weights = pos_mask.new_zeros(S, H, W)
-            sem_label_weights = torch.cat([pos_mask.new_zeros((S, T)), torch.eye(S, device=pos_mask.device)], dim=-1)
-            if len(gt_sem_cls > 0):
-                sem_inds = (gt_sem_cls - T).long()
-                sem_labels[sem_inds] = gt_sem_cls.long()
-                sem_targets[sem_inds] = gt_sem_seg
-                sem_weights[sem_inds] = 1
-            label_weights[:, T:] = 0
-            labels = torch.cat([labels, sem_labels])
-            label_weights = torch.cat([label_weights, sem_label_weights])
-            mask_targets = torch.cat([mask_targets, sem_targets])
-            mask_weights = torch.cat([mask_weights, sem_weights])
-        return labels, label_weights, mask_targets, mask_weights
-
     def get_targets(self, sampling_results, gt_mask, gt_labels, rcnn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None):
         """(labels, label_weights, mask_targets, mask_weights) of a batch (reference :396-441).  `concat=True` (every caller in the
-        reference): built for the WHOLE batch at once by `_batch_targets`; `concat=False`: per-image lists through
-        `_get_target_single`, as the reference does."""
+        reference): built for the WHOLE batch at once by `_batch_targets`; `concat=False`: per-image lists (the same builder, one
+        image at a time)."""
         n = len(sampling_results)
         self._targets_stash = None
         if concat and n > 0:
             return self._batch_targets(sampling_results, rcnn_train_cfg, gt_sem_seg, gt_sem_cls)
-        if gt_sem_seg is None:
-            gt_sem_seg, gt_sem_cls = [None] * n, [None] * n      # (the reference hard-codes 2 here, :417-418: batch of 2 only)
-        out = [self._get_target_single(r.pos_inds, r.neg_inds, r.pos_masks, r.neg_masks, r.pos_gt_masks, r.pos_gt_labels,
-                                       gt_sem_seg[i], gt_sem_cls[i], rcnn_train_cfg) for i, r in enumerate(sampling_results)]
-        labels, label_weights, mask_targets, mask_weights = (list(t) for t in zip(*out))
-        return labels, label_weights, mask_targets, mask_weights
+        sem = gt_sem_seg is not None and gt_sem_cls is not None
+        out = [self._batch_targets([r], rcnn_train_cfg, [gt_sem_seg[i]] if sem else None, [gt_sem_cls[i]] if sem else None)
+               for i, r in enumerate(sampling_results)]
+        self._targets_stash = None
+        return tuple(list(t) for t in zip(*out)) if out else ([], [], [], [])
 
     def _batch_targets(self, sampling_results, cfg, gt_sem_seg, gt_sem_cls):
-        """The concatenated targets of `_get_target_single` over the images of a batch, written directly in the batch layout
+        """The targets of the images of a batch (reference :332-441), written directly in the batch layout
         [B, N + S] (N predictions, then the S stuff rows of that image) with a handful of scatters instead of ~25 small ops per
         image — and with the flat indices of the positive rows as a by-product (`loss` takes rows by them).  Same values:
           labels        num_classes, matched predictions <- their gt label, present stuff rows <- their class
