@@ -381,7 +381,8 @@ int vkn_panoptic_thing_first_u8(const unsigned char* thing_masks, const float* t
  *      vkn_assign_costs_f32 computes the cost matrix on the GPU (the two [N x P].[P x G] contractions run on the gather kernel);
  *      vkn_lsap_f32 is a HOST function: scipy.optimize.linear_sum_assignment's algorithm (same scan order and tie rule).
  *      in : mask_logits [N][P] (the kernels' mask predictions at the assign resolution), cls_logits [N][ncls] or NULL,
- *           gt_masks [G][P] with values 0 / 1, gt_labels int32 [G]; N <= 128, G <= 256.
+ *           gt_masks [G][P] with values 0 / 1, gt_labels int32 [G]; N <= 256, G <= 256 (more than 128
+ *           predictions: the two activations take one gather launch each instead of sharing one).
  *      out: cost [N][G] fp32 (device).  The caller copies it to the host, runs vkn_lsap_f32 and sets
  *           assigned_gt_inds[row] = col + 1 (0 = background), as the reference does (:262-271). */
 typedef struct VknAssignCfg {

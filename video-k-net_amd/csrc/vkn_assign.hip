@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void k_assign_gtsq(const float* __restrict__ g
 }
 
 // S [G][2 Npad] from the gather (S[g][n] = sum p1 g, S[g][Npad + n] = sum p2 g), cnt [G] = sum g -> cost [N][G]
-__global__ __launch_bounds__(256) void k_assign_cost(VknAssignCfg c, const float* __restrict__ S, const float* __restrict__ cnt,
+__global__ __launch_bounds__(256) void k_assign_cost(VknAssignCfg c, const float* __restrict__ S1, const float* __restrict__ S2, int lds,
+                                                     const float* __restrict__ cnt,
                                                      const float* __restrict__ rowsum, const float* __restrict__ gsq,
                                                      const float* __restrict__ cls, const int* __restrict__ labels, int N,
                                                      int Npad, int G, int ncls, int P, int nchunk, float* __restrict__ cost) {
@@ -93,11 +94,11 @@ __global__ __launch_bounds__(256) void k_assign_cost(VknAssignCfg c, const float
     for (int k = 0; k < nchunk; ++k) sgsq += (double)gsq[(size_t)g * nchunk + k];
     double total = 0.0;
     if (c.dice_weight != 0.f) {
-        const double a = (double)S[(size_t)g * 2 * Npad + n];
+        const double a = (double)S1[(size_t)g * lds + n];
         total += (double)c.dice_weight * (-(2.0 * a) / ((sp1sq + (double)c.dice_eps) + (sgsq + (double)c.dice_eps)));
     }
     if (c.mask_weight != 0.f) {
-        const double pos = (double)S[(size_t)g * 2 * Npad + Npad + n];
+        const double pos = (double)S2[(size_t)g * lds + n];
         const double neg = (double)P - sp2 - sg + pos;  // sum (1 - p2)(1 - g)
         total += (double)c.mask_weight * (-(pos + neg) / (double)P);
     }
@@ -321,7 +322,8 @@ int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, cons
     if (!cfg || !mask_logits || !gt_masks || !cost_out || N <= 0 || G <= 0 || P <= 0) return VKN_E_ARG;
     if (cfg->cls_weight != 0.f && cls_logits && (!gt_labels || ncls <= 0)) return VKN_E_ARG;
     const int Npad = (N + 31) / 32 * 32;
-    if (2 * Npad > 256 || G > 256) return VKN_E_SHAPE;  // both activations ride one gather launch as 2 Npad channels
+    if (Npad > 256 || G > 256) return VKN_E_SHAPE;
+    const bool one = 2 * Npad <= 256;   // both activations ride ONE gather launch as 2 Npad channels; more than 128 predictions: two
     if ((reinterpret_cast<uintptr_t>(mask_logits) | reinterpret_cast<uintptr_t>(gt_masks) | reinterpret_cast<uintptr_t>(ws)) & 15)
         return VKN_E_ALIGN;
     AssignWs w;
@@ -335,10 +337,19 @@ int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, cons
     hipLaunchKernelGGL(k_assign_gtsq, dim3(nchunk, G), dim3(256), 0, st, gt_masks, w.gsq, P, nchunk);
     VKN_CHECK_LAUNCH();
     // "x" = the activations [1][2 Npad][P], left operand = the (possibly soft) ground truth [G][P]
-    const int rc = vkn_launch_gather_real(w.act, gt_masks, w.S, w.cnt, w.part, w.cntp, 1, G, 2 * Npad, P, G, st);
+    const float* S2 = w.S + (one ? (size_t)Npad : (size_t)G * Npad);
+    int rc;
+    if (one) {
+        rc = vkn_launch_gather_real(w.act, gt_masks, w.S, w.cnt, w.part, w.cntp, 1, G, 2 * Npad, P, G, st);
+    } else {   // [G][Npad] sums of p1, then of p2 (cnt = sum_p g either time)
+        rc = vkn_launch_gather_real(w.act, gt_masks, w.S, w.cnt, w.part, w.cntp, 1, G, Npad, P, G, st);
+        if (rc == VKN_OK)
+            rc = vkn_launch_gather_real(w.act + (size_t)Npad * P, gt_masks, w.S + (size_t)G * Npad, w.cnt, w.part, w.cntp, 1, G, Npad,
+                                        P, G, st);
+    }
     if (rc != VKN_OK) return rc;
-    hipLaunchKernelGGL(k_assign_cost, dim3((N * G + 255) / 256), dim3(256), 0, st, *cfg, w.S, w.cnt, w.rowsum, w.gsq, cls_logits,
-                       gt_labels, N, Npad, G, ncls, P, nchunk, cost_out);
+    hipLaunchKernelGGL(k_assign_cost, dim3((N * G + 255) / 256), dim3(256), 0, st, *cfg, w.S, S2, one ? 2 * Npad : Npad, w.cnt,
+                       w.rowsum, w.gsq, cls_logits, gt_labels, N, Npad, G, ncls, P, nchunk, cost_out);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
