@@ -318,6 +318,65 @@ def test_soft_gt_assignment_vs_reference(vkn):
         a.cost_matrix(logits.to(DEV), cls.to(DEV), gt.to(DEV), torch.full_like(labels, 255).to(DEV))
 
 
+def test_conv_kernel_head_video_is_the_image_head_over_flattened_clips(vkn):
+    """`ConvKernelHeadVideo` (knet_vis/tracker/kernel_head.py, the VIS models' rpn_head): B clips of T frames arrive as B*T frames;
+    per-frame metas / masks / (frame, label) rows are flattened and everything else is `ConvKernelHead` — same kernel-init outputs,
+    same losses and gradients as the image head on the flattened batch, same state-dict keys."""
+    from helpers import GOLDEN, INIT_FIELDS, make_init_case
+    g = dict(np.load(f'{GOLDEN}/rpn_train_tiny.npz', allow_pickle=False))
+    p = dict(zip(INIT_FIELDS, (int(v) for v in g['case'])))
+    assert p['B'] % 2 == 0
+    loc, sem, iw, sw, sb = make_init_case(p)
+    kw = dict(num_proposals=p['nprop'], in_channels=p['C'], out_channels=p['C'], num_loc_convs=0, num_seg_convs=0,
+              localization_fpn=None, conv_kernel_size=1, semantic_fpn=True, num_classes=p['ncls'], use_binary=True,
+              proposal_feats_with_obj=True, feat_downsample_stride=2, feat_refine=False, num_thing_classes=p['n_thing'],
+              num_stuff_classes=p['ncls'] - p['n_thing'], cat_stuff_mask=True,
+              loss_rank=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=0.1),
+              loss_seg=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+              loss_mask=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0), loss_dice=dict(type='DiceLoss', loss_weight=4.0),
+              train_cfg=dict(assigner=dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                           dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                           mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)),
+                             sampler=dict(type='MaskPseudoSampler'), pos_weight=1))
+    heads = [vkn.build_head(dict(type=t, **kw)) for t in ('ConvKernelHead', 'ConvKernelHeadVideo')]
+    assert sorted(heads[0].state_dict()) == sorted(heads[1].state_dict())
+    tg = synth.train_targets(p['B'], p['n_thing'], p['ncls'] - p['n_thing'], 2 * p['H'], 2 * p['W'], p['seed'])
+    t = lambda key: [torch.from_numpy(e[key]).to(DEV) for e in tg]  # noqa: E731
+    T, nclip = 2, p['B'] // 2
+    outs = []
+    for video, head in enumerate(heads):
+        head.load_state_dict({'init_kernels.weight': iw, 'conv_seg.weight': sw, 'conv_seg.bias': sb}, strict=True)
+        head = head.to(DEV).train()
+        head._upstream_feats = lambda img: img
+        locd, semd = loc.to(DEV).requires_grad_(True), sem.to(DEV).requires_grad_(True)
+        if video:
+            masks, labels = t('gt_masks'), t('gt_labels')
+            ref_metas = [[dict() for _ in range(T)] for _ in range(nclip)]
+            clip_masks = [[masks[c * T + j] for j in range(T)] for c in range(nclip)]
+            clip_labels = [torch.cat([torch.stack([torch.full_like(labels[c * T + j], j), labels[c * T + j]], dim=1) for j in range(T)])
+                           for c in range(nclip)]
+            res = head.forward_train((locd, semd), [dict()] * nclip, ref_metas, clip_masks, clip_labels, gt_sem_seg=t('gt_sem_seg'),
+                                     gt_sem_cls=t('gt_sem_cls'))
+            with torch.no_grad():
+                inf = head.eval().simple_test_rpn((locd, semd), [dict()] * nclip, ref_metas)
+        else:
+            res = head.forward_train((locd, semd), [dict() for _ in range(p['B'])], t('gt_masks'), t('gt_labels'),
+                                     gt_sem_seg=t('gt_sem_seg'), gt_sem_cls=t('gt_sem_cls'))
+            with torch.no_grad():
+                inf = head.eval().simple_test_rpn((locd, semd), [dict() for _ in range(p['B'])])
+        sum(v for k, v in res[0].items() if 'loss' in k).backward()
+        outs.append((res, inf, locd.grad.clone(), head.init_kernels.weight.grad.clone()))
+    (ra, ia, ga, wa), (rb, ib, gb, wb) = outs
+    assert ra[0].keys() == rb[0].keys()
+    for k in ra[0]:
+        assert torch.equal(ra[0][k], rb[0][k]), k
+    for u, v in zip(ra[1:4], rb[1:4]):
+        assert torch.equal(u, v)
+    for u, v in zip(ia, ib):
+        assert (u is None and v is None) or torch.equal(u, v)
+    assert torch.equal(ga, gb) and torch.equal(wa, wb)
+
+
 @pytest.mark.parametrize('name', ['rpn_train_tiny', 'rpn_train_cfg'])
 def test_conv_kernel_head_forward_train_vs_reference_golden(vkn, name):
     """`ConvKernelHead.forward_train` (knet/det/kernel_head.py:267-336) with the shipped rpn losses / train_cfg: losses, Hungarian

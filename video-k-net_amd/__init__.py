@@ -10,7 +10,7 @@ from ._lib import VknError, VknLibraryError, build  # noqa: F401
 from .kernel_updator import KernelUpdator  # noqa: F401
 from .kernel_update_head import KernelUpdateHead, VideoKernelUpdateHead  # noqa: F401
 from .kernel_iter_head import KernelIterHead, VideoKernelIterHead  # noqa: F401
-from .kernel_head import ConvKernelHead  # noqa: F401
+from .kernel_head import ConvKernelHead, ConvKernelHeadVideo  # noqa: F401
 from .knet_vis import KernelFrameIterHeadVideo, KernelIterHeadVideo, KernelUpdateHeadVideo  # noqa: F401
 from .mask_hungarian_assigner import MaskHungarianAssigner, MaskHungarianAssignerVideo  # noqa: F401
 from .qd_tracker import QuasiDenseEmbedTracker, build_tracker  # noqa: F401

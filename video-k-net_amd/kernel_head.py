@@ -344,3 +344,48 @@ class ConvKernelHead(nn.Module):
             mask_targets, mask_weights = torch.cat(mask_targets, 0), torch.cat(mask_weights, 0)
             seg_targets = torch.stack(seg_targets, 0)
         return labels, label_weights, mask_targets, mask_weights, seg_targets
+
+
+@register_head
+class ConvKernelHeadVideo(ConvKernelHead):
+    """knet_vis/tracker/kernel_head.py:12-512 — the kernel-initialisation head of the VIS models (`rpn_head` of
+    configs/video_knet_vis/video_knet_vis/knet_track_*_youtubevis.py).  It is `ConvKernelHead` over the `B * T` frames of a batch of
+    `B` clips: `img` / the feature maps arrive flattened to `[B*T, ...]`, every frame gets the same initial kernels, and what
+    differs from the per-image head is bookkeeping only — per-frame metas come as `ref_img_metas[clip][frame]`, ground-truth masks
+    as `gt_masks[clip][frame]` and labels as `gt_labels[clip]` rows `(frame index, label)` (:303-317).  So the frames are
+    flattened here and everything — HIP kernel-init pass, assignment, targets, losses — is the base class's."""
+
+    def _init_layers(self):
+        super()._init_layers()
+        if self.semantic_fpn and not self.loss_seg.use_sigmoid:
+            # the reference gives the semantic branch a background channel then (:131-136); no shipped config does
+            raise NotImplementedError('ConvKernelHeadVideo with a soft-max semantic loss (num_classes + 1 channels) is not built')
+
+    @staticmethod
+    def _frame_metas(img_metas, ref_img_metas):
+        if ref_img_metas is None:
+            return img_metas
+        return [m for clip in ref_img_metas for m in clip]
+
+    def _decode_init_proposals(self, img, img_metas, ref_img_metas=None):
+        return super()._decode_init_proposals(img, self._frame_metas(img_metas, ref_img_metas))
+
+    def simple_test_rpn(self, img, img_metas, ref_img_metas=None):
+        with torch.no_grad():
+            return self._decode_init_proposals(img, img_metas, ref_img_metas)
+
+    def forward_dummy(self, img, img_metas, ref_img_metas=None):
+        return self._decode_init_proposals(img, img_metas, ref_img_metas)
+
+    def forward_train(self, img, img_metas, ref_img_metas, gt_masks, gt_labels, gt_instance_ids=None, gt_sem_seg=None,
+                      gt_sem_cls=None):
+        """-> (losses, proposal_feats, x_feats, mask_preds, cls_scores) over the B*T frames (:267-334)."""
+        metas = self._frame_metas(img_metas, ref_img_metas)
+        flat_masks, flat_labels = [], []
+        for i, clip in enumerate(ref_img_metas):
+            rows = gt_labels[i]
+            for j in range(len(clip)):
+                flat_masks.append(gt_masks[i][j])
+                flat_labels.append(rows[:, 1][rows[:, 0] == j])
+        return super().forward_train(img, metas, flat_masks, flat_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+
