@@ -153,6 +153,40 @@ def test_vis_train_state_dict_matches_reference(vkn, name):
     assert sorted(sd) == list(g['keys']) and [str(tuple(sd[k].shape)) for k in sorted(sd)] == list(g['shapes'])
 
 
+@pytest.mark.gpu
+def test_vis_roi_head_forward_train_is_the_stage_loop_over_flattened_clips(vkn):
+    """`KernelIterHeadVideo.forward_train` (knet_vis/tracker/kernel_iter_head.py:139-242, the per-frame roi head of the VIS model):
+    clip-shaped ground truth (`gt_masks[clip][frame]`, `(frame, label)` rows) flattened onto the image head's stage loop — same
+    losses as the loop called on the flat lists — and the clip-shaped `features` it hands to the clip-level tracker head."""
+    c = dict(C=32, heads=4, ffn=64, ncls=5, N=10, H=8, W=12, up=2, S=2)
+    train_cfg = [dict(assigner=dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                    dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                                    mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)),
+                      sampler=dict(type='MaskPseudoSampler'), pos_weight=1) for _ in range(c['S'])]
+    roi = vkn.build_head(dict(type='KernelIterHeadVideo', num_stages=c['S'], stage_loss_weights=[1] * c['S'], assign_stages=c['S'],
+                              proposal_feature_channel=c['C'], num_thing_classes=c['ncls'], num_stuff_classes=0, num_proposals=c['N'],
+                              train_cfg=train_cfg, mask_head=[_stage_cfg(vkn, 'KernelUpdateHead', c) for _ in range(c['S'])]))
+    shapes = {k: tuple(v.shape) for k, v in roi.state_dict().items()}
+    roi.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, 91).items()}, strict=True)
+    roi = roi.to(DEV).train()
+    bs, nf = 2, 3
+    x, pf, mp = (torch.from_numpy(a).to(DEV) for a in synth.head_inputs(bs * nf, c['N'], c['C'], c['H'], c['W'], 17))
+    tg = synth.clip_targets(bs, nf, c['ncls'], c['H'] * c['up'], c['W'] * c['up'], 17)
+    gt_masks = [[torch.from_numpy(m).to(DEV) for m in t['gt_masks']] for t in tg]
+    gt_labels = [torch.from_numpy(t['gt_labels']).to(DEV) for t in tg]
+    metas = [[dict() for _ in range(nf)] for _ in range(bs)]
+    losses, feats = roi.forward_train(x, pf, mp, None, metas, gt_masks, gt_labels)
+    flat_masks = [gt_masks[i][j] for i in range(bs) for j in range(nf)]
+    flat_labels = [gt_labels[i][:, 1][gt_labels[i][:, 0] == j] for i in range(bs) for j in range(nf)]
+    want, last = roi._train_stages(x, pf, mp, None, [dict()] * (bs * nf), flat_masks, flat_labels)
+    assert sorted(losses) == sorted(want) and all(torch.equal(losses[k], want[k]) for k in want)
+    assert tuple(feats['obj_feats'].shape) == (bs, nf, c['N'], c['C'], 1, 1) and tuple(feats['x_feats'].shape) == (bs, nf, c['C'], c['H'], c['W'])
+    assert torch.equal(feats['masks'].reshape(bs * nf, c['N'], c['H'], c['W']), last['mask_preds'])
+    assert tuple(feats['cls_scores'].shape) == (bs, nf, c['N'], c['ncls'])
+    got = vkn.HEADS.get('VideoKernelIterHead').get_masked_feature(roi, x, mp)     # (the video panoptic head's helper: the HIP gather)
+    assert torch.equal(got, vkn.ops.mask_gather(x, mp, 0.5)[0])
+
+
 def test_clip_instances_of_the_video_assigner(vkn):
     """CPU: the clip-instance table (instances in ascending id order; a frame where an instance is absent is a zero mask; one
     label per instance) against a direct per-instance / per-frame construction."""

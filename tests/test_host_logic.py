@@ -247,3 +247,92 @@ def test_quasi_dense_tracker_surface(vkn):
     assert L.vkn_qd_tracker_state_bytes(ctypes.byref(c)) > 0 and L.vkn_qd_tracker_workspace_bytes(ctypes.byref(c)) > 0
     c.max_dets = 1024                                        # outside the envelope: size queries answer 0, calls VKN_E_SHAPE
     assert L.vkn_qd_tracker_state_bytes(ctypes.byref(c)) == 0
+
+
+def test_joint_merge_helpers_follow_the_rule(vkn):
+    """`merge_stuff_thing_stuff_joint` (image and video signatures) and the VIS `merge_stuff_thing`: the vectorised merge against a
+    plain loop over the masks in descending score order (the rule of knet/det/kernel_iter_head.py:467-524), on soft masks with
+    ties in neither scores nor products; CPU tensors (the helpers are host-side torch)."""
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(5)
+    T, Sn, H, W = 3, 4, 12, 18
+    head = vkn.build_head(_cfg(True, n_thing=T, n_stuff=Sn, ncls=T + Sn, nprop=6, C=32, heads=4, ffn=64))
+    Kt, Ks = 6, Sn
+    # every mask owns a column stripe (p = 0.9 there, noise elsewhere); masks 1 and 2 share a stripe (the weaker one keeps too little
+    # of its area and is dropped), thing 4 scores below the instance threshold
+    base = torch.rand(Kt + Ks, H, W, generator=g) * 0.2
+    stripe = [0, 1, 1, 2, 3, 4, 5, 6, 7, 8]
+    for k, c in enumerate(stripe):
+        base[k, :, 2 * c:2 * c + 2] = 0.9 + 0.05 * torch.rand(H, 2, generator=g)
+    tm, sm = base[:Kt], base[Kt:]
+    tl, sl = torch.randint(0, T, (Kt,), generator=g), torch.arange(Ks) + T
+    ts = torch.tensor([0.91, 0.83, 0.62, 0.77, 0.12, 0.55])
+    ss = torch.tensor([0.71, 0.64, 0.93, 0.48])
+    cfgm = SimpleNamespace(instance_score_thr=0.3, overlap_thr=0.5, iou_thr=0.5, stuff_max_area=4)
+    masks, labels, scores = torch.cat([tm, sm]), torch.cat([tl, sl]), torch.cat([ts, ss])
+    win = (scores.view(-1, 1, 1) * masks).argmax(0)
+    want, info, things, sid = torch.zeros(H, W, dtype=torch.int32), [], [], 0
+    for k in torch.argsort(-scores).tolist():
+        thing = int(labels[k]) < T
+        if thing and float(scores[k]) < cfgm.instance_score_thr:
+            continue
+        a, o = int((win == k).sum()), int((masks[k] >= 0.5).sum())
+        if a == 0 or o == 0 or a / o < cfgm.overlap_thr:
+            continue
+        sid += 1
+        want[win == k] = sid
+        info.append((sid, thing, int(labels[k]) if thing else int(labels[k]) - T + 1, k if thing else a))
+        if thing:
+            things.append(k)
+    assert sid >= 3
+    pan, segs = super(type(head), head).merge_stuff_thing_stuff_joint(tm, tl, ts, sm, sl, ss, cfgm)
+    assert np.array_equal(pan, want.numpy()) and pan.dtype == np.int32
+    assert [(s_['id'], s_['isthing'], s_['category_id'], s_['instance_id'] if s_['isthing'] else s_['area']) for s_ in segs] == info
+    obj_t, obj_s = torch.randn(Kt, 8, generator=g), torch.randn(Ks, 8, generator=g)
+    (pan2, segs2), feats = head.merge_stuff_thing_stuff_joint(tm, tl, ts, sm, sl, ss, cfgm, thing_obj=obj_t, stuff_obj=obj_s)
+    assert np.array_equal(pan2, pan) and segs2 == segs and torch.equal(feats, torch.cat([obj_t, obj_s])[things])
+    assert [torch.equal(u, v) for u, v in zip(head.split_thing_stuff(masks, torch.cat([tl, sl]), scores),
+                                              (masks[:6], labels[:6], scores[:6], masks[6:], labels[6:] - T + 1, scores[6:]))] == [True] * 6
+    vis = vkn.HEADS.get('KernelIterHeadVideo')
+    code = vis.merge_stuff_thing(head, masks, labels, scores, cfgm)
+    exp = np.full((H, W), head.num_classes, dtype=np.int64)
+    order = [k for k in torch.argsort(-scores).tolist()]
+    seg_of = {}
+    for k in order:
+        v = int(want[win == k].max()) if bool((win == k).any()) else 0
+        if v > 0:
+            seg_of[k] = v
+    for k, v in seg_of.items():
+        exp[(win == k).numpy()] = int(labels[k]) + (v - 1) * 1000
+    assert np.array_equal(code, exp) and code.dtype == np.int64
+
+
+def test_update_head_single_image_targets_equal_the_batch_builder(vkn):
+    """`KernelUpdateHead._get_target_single` (the reference's per-image argument list) and `get_targets(concat=False)` are the batch
+    builder on one image: same tensors as slicing the concatenated result."""
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(11)
+    head = vkn.build_head(_cfg(False, n_thing=3, n_stuff=2, ncls=5, nprop=7, C=32, heads=4, ffn=64)).mask_head[0]
+    N, H, W = 7, 6, 10
+    res, segs, clss = [], [], []
+    for i in range(2):
+        k = 3 - i
+        pos = torch.sort(torch.randperm(N, generator=g)[:k])[0]
+        res.append(SimpleNamespace(pos_inds=pos, pos_gt_masks=(torch.rand(k, H, W, generator=g) > 0.5).float(),
+                                   pos_gt_labels=torch.randint(0, 3, (k,), generator=g), num_pos=k, num_neg=N - k,
+                                   device=torch.device('cpu'), mask_dtype=torch.float32, mask_shape=(H, W)))
+        clss.append(torch.tensor([3, 4][:2 - i]))
+        segs.append((torch.rand(2 - i, H, W, generator=g) > 0.5).float())
+    cfg = dict(pos_weight=1)
+    whole = head.get_targets(res, None, None, cfg, True, gt_sem_seg=segs, gt_sem_cls=clss)
+    lists = head.get_targets(res, None, None, cfg, False, gt_sem_seg=segs, gt_sem_cls=clss)
+    Ns = N + 2
+    for i in range(2):
+        for a, b in zip(whole, (t[i] for t in lists)):
+            assert torch.equal(a[i * Ns:(i + 1) * Ns], b)
+        r = res[i]
+        one = head._get_target_single(r.pos_inds, None, torch.zeros(r.num_pos, H, W), torch.zeros(r.num_neg, H, W), r.pos_gt_masks,
+                                      r.pos_gt_labels, segs[i], clss[i], cfg)
+        for a, b in zip(one, (t[i] for t in lists)):
+            assert torch.equal(a, b)
+

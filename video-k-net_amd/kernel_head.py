@@ -238,7 +238,7 @@ class ConvKernelHead(nn.Module):
         for i in range(num_imgs):
             assign_result = self.assigner.assign(scaled_mask_preds[i].detach(), None, gt_masks[i], gt_labels[i], img_metas[i])
             sampling_results.append(self.sampler.sample(assign_result, scaled_mask_preds[i], gt_masks[i]))
-        mask_targets = self.get_targets(sampling_results, gt_masks, self.train_cfg, True, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+        mask_targets = self._targets(sampling_results, self.train_cfg, True, gt_sem_seg, gt_sem_cls)
         losses = self.loss(scaled_mask_preds, cls_scores, scaled_seg_preds, proposal_feats, *mask_targets)
         if self.cat_stuff_mask and self.training:
             mask_preds = torch.cat([mask_preds, seg_preds[:, self.num_thing_classes:]], dim=1)
@@ -332,7 +332,10 @@ class ConvKernelHead(nn.Module):
                                    pos_inds, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls, cfg)
 
     def get_targets(self, sampling_results, gt_mask, rpn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None):
-        """:468-504"""
+        """:468-504 (`gt_mask` is not read there either: the sampling results carry the matched ground truth)"""
+        return self._targets(sampling_results, rpn_train_cfg, concat, gt_sem_seg, gt_sem_cls)
+
+    def _targets(self, sampling_results, rpn_train_cfg, concat, gt_sem_seg, gt_sem_cls):
         n = len(sampling_results)
         if gt_sem_seg is None:
             gt_sem_seg, gt_sem_cls = [None] * n, [None] * n      # (the reference hard-codes 2, :480-481)
@@ -373,6 +376,10 @@ class ConvKernelHeadVideo(ConvKernelHead):
     def simple_test_rpn(self, img, img_metas, ref_img_metas=None):
         with torch.no_grad():
             return self._decode_init_proposals(img, img_metas, ref_img_metas)
+
+    def get_targets(self, sampling_results, rpn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None):
+        """(:466-501: the VIS head's signature has no `gt_mask`.)"""
+        return self._targets(sampling_results, rpn_train_cfg, concat, gt_sem_seg, gt_sem_cls)
 
     def forward_dummy(self, img, img_metas, ref_img_metas=None):
         return self._decode_init_proposals(img, img_metas, ref_img_metas)

@@ -309,6 +309,55 @@ class KernelIterHead(BaseRoIHead):
                 segments_info.append(dict(id=int(row[0]), isthing=False, category_id=int(row[2]), area=int(row[3])))
         return seg.cpu().numpy(), segments_info
 
+    # ---- the reference's merge helpers under their own names, for callers that hold MASKS (the fused `get_panoptic` path above
+    #      goes from class scores + logits to the map in one kernel and never materialises them)
+    def split_thing_stuff(self, mask_preds, det_labels, cls_scores):
+        """Rows [0, num_proposals) are things, the rest stuff with labels renumbered from 1 (reference :372-384)."""
+        n, first_stuff = self.num_proposals, self.num_thing_classes - 1
+        return (mask_preds[:n], det_labels[:n], cls_scores[:n], mask_preds[n:], det_labels[n:] - first_stuff, cls_scores[n:])
+
+    def _joint_merge(self, total_masks, total_labels, total_scores, merge_cfg):
+        """The joint merge rule (reference :467-524) without its per-mask loop: a pixel belongs to the mask with the largest
+        score * probability; a mask survives if it wins pixels, covers any at p >= 0.5, keeps at least `overlap_thr` of that
+        area, and — for things — scores at least `instance_score_thr`; survivors are numbered 1.. in descending score order.
+        -> (winner [H, W], segment id per mask [K] (0 = dropped), won pixels per mask [K])."""
+        K = total_masks.shape[0]
+        winner = (total_scores.view(-1, 1, 1) * total_masks).argmax(0)
+        area = torch.bincount(winner.flatten(), minlength=K)
+        solid = (total_masks >= 0.5).flatten(1).sum(1)
+        keep = (area > 0) & (solid > 0) & (area.double() / solid.clamp(min=1).double() >= float(self._cfg(merge_cfg, 'overlap_thr')))
+        keep &= ~((total_labels < self.num_thing_classes) & (total_scores < self._cfg(merge_cfg, 'instance_score_thr')))
+        order = torch.argsort(-total_scores, stable=True)
+        kept_in_order = keep[order]
+        seg_id = torch.zeros(K, dtype=torch.long, device=total_masks.device)
+        seg_id[order] = torch.where(kept_in_order, torch.cumsum(kept_in_order.long(), 0), seg_id)
+        return winner, seg_id, area
+
+    def _joint_segments(self, seg_id, total_labels, total_scores, area):
+        """segments_info in segment order + the mask index of every accepted thing, from ONE device -> host copy."""
+        table = torch.stack([seg_id, total_labels.long(), area]).cpu().numpy()
+        scores = total_scores.detach().cpu().numpy()
+        T = self.num_thing_classes
+        rows = [k for k in np.argsort(table[0], kind='stable') if table[0][k] > 0]
+        info, things = [], []
+        for k in rows:
+            sid, lab = int(table[0][k]), int(table[1][k])
+            if lab < T:
+                info.append(dict(id=sid, isthing=True, score=float(scores[k]), category_id=lab, instance_id=int(k)))
+                things.append(int(k))
+            else:
+                info.append(dict(id=sid, isthing=False, category_id=lab - T + 1, area=int(table[2][k])))
+        return info, things
+
+    def merge_stuff_thing_stuff_joint(self, thing_masks, thing_labels, thing_scores, stuff_masks, stuff_labels, stuff_scores,
+                                      merge_cfg=None):
+        """-> (panoptic_seg int32 ndarray, segments_info) from SOFT masks (probabilities), things and stuff competing per pixel."""
+        masks, labels = torch.cat([thing_masks, stuff_masks]), torch.cat([thing_labels, stuff_labels])
+        scores = torch.cat([thing_scores, stuff_scores])
+        winner, seg_id, area = self._joint_merge(masks, labels, scores, merge_cfg)
+        info, _ = self._joint_segments(seg_id, labels, scores, area)
+        return seg_id[winner].to(torch.int32).cpu().numpy(), info
+
     def _get_panoptic_thing_first(self, cls_scores, mask_preds, test_cfg, img_meta):
         """reference :332-370 with merge_joint=False: top-k things and score-sorted stuff, rescaled and thresholded, then merged."""
         Np, T = self.num_proposals, self.num_thing_classes
@@ -502,6 +551,34 @@ class VideoKernelIterHead(KernelIterHead):
         if first_previous_obj_feats is None:
             track[0] = cur[0]
         return obj, cls, masks, scaled, track.reshape(obj.shape)
+
+    def get_masked_feature(self, x, mask_pred):
+        """`einsum('bnhw,bchw->bnc', (sigmoid(mask_pred) > 0.5).float(), x)` (knet/video/kernel_iter_head.py:566-571): the HIP gather."""
+        return ops.mask_gather(x, mask_pred, 0.5)[0]
+
+    def merge_stuff_thing_stuff_joint(self, thing_masks, thing_labels, thing_scores, stuff_masks, stuff_labels, stuff_scores,
+                                      merge_cfg=None, thing_obj=None, stuff_obj=None):
+        """The joint merge plus the tracking embeddings of the accepted things in segment order (:832-905)."""
+        masks, labels = torch.cat([thing_masks, stuff_masks]), torch.cat([thing_labels, stuff_labels])
+        scores = torch.cat([thing_scores, stuff_scores])
+        winner, seg_id, area = self._joint_merge(masks, labels, scores, merge_cfg)
+        info, things = self._joint_segments(seg_id, labels, scores, area)
+        feats = None
+        if thing_obj is not None:
+            obj = torch.cat([thing_obj, stuff_obj]) if stuff_obj is not None else thing_obj
+            feats = obj[torch.as_tensor(things, dtype=torch.long, device=obj.device)]
+        return (seg_id[winner].to(torch.int32).cpu().numpy(), info), feats
+
+    def merge_stuff_thing_thing_first(self, thing_masks, thing_labels, thing_scores, stuff_masks, stuff_labels, stuff_scores,
+                                      merge_cfg=None, thing_obj_feat=None, stuff_obj_feat=None):
+        """Things pasted first in score order, then stuff (:656-742) = the image head's `merge_stuff_thing`, plus the embeddings of
+        the accepted things, which the reference indexes in score-sorted order."""
+        pan = self.merge_stuff_thing(thing_masks, thing_labels, thing_scores, stuff_masks, stuff_labels, stuff_scores, merge_cfg)
+        feats = None
+        if thing_obj_feat is not None:
+            ids = [s_['instance_id'] for s_ in pan[1] if s_['isthing']]
+            feats = thing_obj_feat[torch.argsort(-thing_scores)][torch.as_tensor(ids, dtype=torch.long, device=thing_obj_feat.device)]
+        return pan, feats
 
     def get_panoptic(self, cls_scores, mask_preds, test_cfg, img_meta, obj_feat=None):
         """Video signature (knet/video/kernel_iter_head.py:591-640): 5-tuple

@@ -598,6 +598,18 @@ class KernelUpdateHead(nn.Module):
                 and (lr is None or (type(lr) is L.CrossEntropyLoss and not lr.use_sigmoid and not lr.use_mask and lr.reduction == 'mean'
                                     and lr.class_weight is None)))
 
+    def _get_target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls, cfg):
+        """The reference's per-image entry point (:332-394) for callers that hold its argument list: the batch builder on one image
+        (the matched rows and their ground truth are all it needs; the mask copies only give the sizes)."""
+        from types import SimpleNamespace
+        one = SimpleNamespace(pos_inds=pos_inds, pos_gt_masks=pos_gt_mask, pos_gt_labels=pos_gt_labels, num_pos=int(pos_mask.size(0)),
+                              num_neg=int(neg_mask.size(0)), device=pos_mask.device, mask_dtype=pos_mask.dtype,
+                              mask_shape=tuple(pos_mask.shape[1:]))
+        sem = gt_sem_seg is not None and gt_sem_cls is not None
+        out = self._batch_targets([one], cfg, [gt_sem_seg] if sem else None, [gt_sem_cls] if sem else None)
+        self._targets_stash = None
+        return out
+
     def get_targets(self, sampling_results, gt_mask, gt_labels, rcnn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None):
         """(labels, label_weights, mask_targets, mask_weights) of a batch (reference :396-441).  `concat=True` (every caller in the
         reference): built for the WHOLE batch at once by `_batch_targets`; `concat=False`: per-image lists (the same builder, one

@@ -218,6 +218,39 @@ class KernelIterHeadVideo(KernelIterHead):
             if hasattr(a, 'pred_clamp'):
                 a.pred_clamp = (0.0, 0.0)
 
+    def forward_train(self, x, proposal_feats, mask_preds, cls_score, ref_img_metas, gt_masks, gt_labels, gt_bboxes_ignore=None,
+                      imgs_whwh=None, gt_bboxes=None, gt_sem_seg=None, gt_sem_cls=None):
+        """-> (losses, features) over the bs * num_frames frames (reference :139-242): per-frame ground truth arrives as
+        `gt_masks[clip][frame]` and `gt_labels[clip]` rows (frame, label) and is flattened to the frame list the image head's stage
+        loop takes; `features` are the clip-shaped views the clip-level tracker head reads."""
+        num_imgs, num_frames = len(ref_img_metas), len(ref_img_metas[0])
+        metas = [m for clip in ref_img_metas for m in clip]
+        flat_masks, flat_labels = [], []
+        for i in range(num_imgs):
+            rows = gt_labels[i]
+            for j in range(num_frames):
+                flat_masks.append(gt_masks[i][j])
+                flat_labels.append(rows[:, 1][rows[:, 0] == j])
+        losses, last = self._train_stages(x, proposal_feats, mask_preds, cls_score, metas, flat_masks, flat_labels, imgs_whwh=imgs_whwh,
+                                          gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+        object_feats, cls_last, masks_last = last['object_feats'], last['cls_score'], last['mask_preds']
+        nq, c = object_feats.shape[1:3]
+        h, w = x.shape[-2:]
+        assert object_feats.shape[0] == x.shape[0] == num_imgs * num_frames and c == x.shape[1]
+        features = dict(obj_feats=object_feats.reshape((num_imgs, num_frames) + tuple(object_feats.shape[1:])),
+                        x_feats=x.reshape(num_imgs, num_frames, c, h, w),
+                        cls_scores=cls_last.reshape(num_imgs, num_frames, nq, self.num_classes),
+                        masks=masks_last.reshape(num_imgs, num_frames, nq, h, w))
+        return losses, features
+
+    def merge_stuff_thing(self, total_masks, total_labels, total_scores, merge_cfg=None):
+        """The joint merge of SOFT masks with the VIS encoding (reference :352-388): a pixel carries `label + segment * 1000`
+        (mmdet's INSTANCE_OFFSET; segments counted from 0 in descending score order), `num_classes` where nothing survives.
+        -> int64 ndarray [H, W]."""
+        winner, seg_id, _ = self._joint_merge(total_masks, total_labels, total_scores, merge_cfg)
+        code = torch.where(seg_id > 0, total_labels.long() + (seg_id - 1) * 1000, seg_id.new_full((), self.num_classes))
+        return code[winner].cpu().numpy()
+
     def simple_test(self, x, proposal_feats, mask_preds, cls_score, img_metas, ref_img_metas, imgs_whwh=None, rescale=False):
         """-> (results: per frame `(bbox_result, segm_result)`, features: the tracker's inputs)            reference :243-313"""
         if self.do_panoptic:
