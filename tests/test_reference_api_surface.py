@@ -30,6 +30,8 @@ PAIRS = {
     'knet_vis.tracker.kernel_iter_head:KernelIterHeadVideo': 'KernelIterHeadVideo',
     'knet_vis.tracker.kernel_frame_iter_head:KernelFrameIterHeadVideo': 'KernelFrameIterHeadVideo',
     'knet_vis.tracker.mask_hungarian_assigner:MaskHungarianAssignerVideo': 'MaskHungarianAssignerVideo',
+    'knet.video.qdtrack.trackers.quasi_dense_embed_tracker:QuasiDenseEmbedTracker': 'QuasiDenseEmbedTracker',
+    'knet.cross_entropy_loss:CrossEntropyLoss': 'losses.CrossEntropyLoss',
 }
 
 CHILD = r'''
@@ -39,10 +41,15 @@ root = sys.argv[1]
 sys.path.insert(0, os.path.join(root, 'oracle', 'standins'))
 sys.path.insert(1, '/root/reference')
 out = {}
-for key in json.loads(sys.argv[2]):
+for key in sorted(json.loads(sys.argv[2]), key=lambda k: 'QuasiDenseEmbedTracker' in k):
     mod, cls = key.split(':')
     try:
-        c = getattr(importlib.import_module(mod), cls)
+        if cls == 'QuasiDenseEmbedTracker':      # its package __init__ needs cv2: loaded by path, as the golden generator does (last: it
+            sys.path.insert(0, root)             # replaces the `knet` package entries in sys.modules)
+            from oracle.gen_golden_tracker import load_reference_tracker
+            c = load_reference_tracker()
+        else:
+            c = getattr(importlib.import_module(mod), cls)
     except Exception as e:            # a module the stand-ins cannot carry
         out[key] = {'__error__': type(e).__name__ + ': ' + str(e)[:200]}
         continue
@@ -65,6 +72,7 @@ NOT_BUILT = {
                             'merge_stuff_thing_stuff_first'},       # dead code in the reference: nothing calls it
     'KernelIterHead': {'forward_dummy', 'aug_test', 'get_panoptic'},    # test-time augmentation raises in the reference too; get_panoptic lives on the detector here
     'KernelIterHeadVideo': {'forward_dummy', 'aug_test'},
+    'QuasiDenseEmbedTracker': {'update_memo'},     # the memo lives in the device state buffer; the match kernel updates it in the same launch
     'KernelFrameIterHeadVideo': {'forward_dummy', 'aug_test'},
 }
 
@@ -85,7 +93,10 @@ def test_methods_and_parameter_names_follow_the_reference(vkn):
         if '__error__' in ref:
             problems.append(f'{key}: reference class not importable: {ref["__error__"]}')
             continue
-        cls = getattr(vkn, here, None) or vkn.HEADS.get(here)
+        cls = vkn
+        for part in here.split('.'):
+            cls = getattr(cls, part, None) if cls is not None else None
+        cls = cls or vkn.HEADS.get(here)
         assert cls is not None, here
         for name, rparams in sorted(ref.items()):
             if name in NOT_BUILT.get(here, ()):
