@@ -9,6 +9,8 @@ and `mmdet.datasets.coco_panoptic` stand-ins).  Only outputs are stored.
 
   vis_train_* `forward_train` of the tracker head: clip-level assignment (MaskHungarianAssignerVideo), losses, gradients
   vis_attn_* the same pipeline with query_merge_method = 'attention' / 'attention_pos' in the tracker and its clip-level stages
+  vis_rpn_train  `ConvKernelHeadVideo.forward_train` (knet_vis/tracker/kernel_head.py:267-334) and `KernelIterHeadVideo.forward_train`
+             (knet_vis/tracker/kernel_iter_head.py:139-242) on the heads it feeds: clip-shaped ground truth, losses, assignments
   vis_tiny   KernelIterHeadVideo (per-frame roi head, instance results + features) -> KernelFrameIterHeadVideo (clip-level tracker:
              query fusion 'mean', 3 stages with assign_stages = 2: two clip-level `with_cls` stages, one per-frame stage)
 """
@@ -35,6 +37,9 @@ import knet_vis.det.kernel_update_head  # noqa: E402,F401
 import knet_vis.tracker.kernel_iter_head  # noqa: E402,F401
 import knet_vis.tracker.kernel_update_head  # noqa: E402,F401
 import knet_vis.tracker.kernel_frame_iter_head  # noqa: E402,F401
+import knet_vis.tracker.kernel_head  # noqa: E402,F401  (ConvKernelHeadVideo: the VIS models' rpn_head)
+import knet_vis.det.mask_hungarian_assigner  # noqa: E402,F401
+import knet_vis.det.mask_pseudo_sampler  # noqa: E402,F401
 import knet.cross_entropy_loss  # noqa: E402,F401
 from mmdet.models.builder import build_head  # noqa: E402
 
@@ -173,6 +178,73 @@ def run_train(name, C, heads, ffn, ncls, N, H, W, up, bs, nf, seed, merge='mean'
     print(f'{name}: ok  total={float(total):.5f}  ' + ' '.join(f'{k}={float(v):.4f}' for k, v in sorted(losses.items())[:6]))
 
 
+def run_rpn_roi_train(name, C, heads, ffn, ncls, nprop, H, W, up, S, bs, nf, seed):
+    """The VIS model's rpn_head -> roi_head training hand-over on bs clips of nf frames: ConvKernelHeadVideo.forward_train behind a
+    pass-through neck (things only, sigmoid focal semantic loss as in configs/video_knet_vis/.../knet_track_r50_1x_youtubevis.py),
+    then KernelIterHeadVideo.forward_train on its outputs.  Stored: both loss dicts, every Hungarian assignment, the roi head's
+    clip-shaped features."""
+    from mmdet.models.builder import NECKS
+
+    if 'PassThroughNeckVis' not in NECKS._module_dict:
+        @NECKS.register_module()
+        class PassThroughNeckVis(torch.nn.Module):
+            def forward(self, feats):
+                return [feats[0], feats[1]] if len(feats) == 2 else feats[0]
+    assign = dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                  dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True), mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    rpn = build_head(dict(type='ConvKernelHeadVideo', num_proposals=nprop, in_channels=C, out_channels=C, num_loc_convs=0,
+                          num_seg_convs=0, localization_fpn=dict(type='PassThroughNeckVis'), conv_kernel_size=1, semantic_fpn=True,
+                          num_classes=ncls, use_binary=True, proposal_feats_with_obj=True, feat_downsample_stride=up, feat_refine=False,
+                          num_thing_classes=ncls, num_stuff_classes=0, cat_stuff_mask=False,
+                          loss_seg=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                          loss_mask=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                          loss_dice=dict(type='DiceLoss', loss_weight=4.0),
+                          train_cfg=AttrDict(assigner=assign, sampler=dict(type='MaskPseudoSampler'), pos_weight=1)))
+    roi = build_head(dict(type='KernelIterHeadVideo', num_stages=S, stage_loss_weights=[1] * S, assign_stages=S, proposal_feature_channel=C,
+                          num_thing_classes=ncls, num_stuff_classes=0, num_proposals=nprop,
+                          train_cfg=[AttrDict(assigner=assign, sampler=dict(type='MaskPseudoSampler'), pos_weight=1) for _ in range(S)],
+                          mask_head=[stage_cfg('KernelUpdateHead', C, heads, ffn, ncls, up) for _ in range(S)]))
+    for m, sd_seed in ((rpn, seed), (roi, seed + 1)):
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, sd_seed).items()}, strict=True)
+        m.train()
+    F = bs * nf
+    loc = torch.from_numpy(synth.uniform((F, C, H, W), seed + 2, -1.0, 1.0)).requires_grad_(True)
+    sem = torch.from_numpy(synth.uniform((F, C, H, W), seed + 3, -1.0, 1.0)).requires_grad_(True)
+    tg = synth.clip_targets(bs, nf, ncls, H * up, W * up, seed)
+    gt_masks = [[torch.from_numpy(m) for m in t['gt_masks']] for t in tg]
+    gt_labels = [torch.from_numpy(t['gt_labels']) for t in tg]
+    metas = [[dict() for _ in range(nf)] for _ in range(bs)]
+    assigned = []
+
+    def hook(a):
+        orig = a.assign
+
+        def rec(*args, **kw):
+            r = orig(*args, **kw)
+            assigned.append(r.gt_inds.clone())
+            return r
+        a.assign = rec
+    hook(rpn.assigner)
+    for a in roi.mask_assigner:
+        hook(a)
+    rl, prop, x_feats, masks, cls = rpn.forward_train((loc, sem), [dict()] * bs, metas, gt_masks, gt_labels)
+    n_rpn = len(assigned)
+    ll, feats = roi.forward_train(x_feats, prop, masks, cls, metas, gt_masks, gt_labels)
+    total = sum(v for k, v in rl.items() if 'loss' in k) + sum(v for k, v in ll.items() if 'loss' in k)
+    total.backward()
+    out = dict(case=np.array([C, heads, ffn, ncls, nprop, H, W, up, S, bs, nf, seed], dtype=np.int64),
+               rpn_keys=np.array(sorted(rl)), rpn_vals=np.array([float(rl[k].detach()) for k in sorted(rl)], dtype=np.float64),
+               roi_keys=np.array(sorted(ll)), roi_vals=np.array([float(ll[k].detach()) for k in sorted(ll)], dtype=np.float64),
+               assigned_rpn=torch.stack(assigned[:n_rpn]).numpy(), assigned_roi=torch.stack(assigned[n_rpn:]).numpy(),
+               proposal_feats=prop.detach().numpy(), feat_obj=feats['obj_feats'].detach().numpy(),
+               feat_cls=feats['cls_scores'].detach().numpy(), feat_mask_rowsum=feats['masks'].detach().double().sum(dim=(-1, -2)).numpy(),
+               grad_loc_norm=np.float64(float(loc.grad.double().norm())), grad_sem_norm=np.float64(float(sem.grad.double().norm())),
+               rpn_keys_sd=np.array(sorted(rpn.state_dict())), total=np.float64(float(total.detach())))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(f'{name}: ok  total={float(total):.5f}  rpn ' + ' '.join(f'{k}={float(v):.4f}' for k, v in sorted(rl.items())))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -186,3 +258,4 @@ if __name__ == '__main__':
     run_train('vis_train_tiny', C=64, heads=8, ffn=128, ncls=7, N=20, H=8, W=16, up=2, bs=2, nf=3, seed=101)
     run_train('vis_train_attnpos', C=64, heads=8, ffn=128, ncls=7, N=20, H=8, W=16, up=2, bs=2, nf=3, seed=102, merge='attention_pos',
               mask_init=True)
+    run_rpn_roi_train('vis_rpn_train', C=64, heads=8, ffn=128, ncls=7, nprop=20, H=8, W=16, up=2, S=2, bs=2, nf=3, seed=111)

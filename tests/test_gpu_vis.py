@@ -187,6 +187,76 @@ def test_vis_roi_head_forward_train_is_the_stage_loop_over_flattened_clips(vkn):
     assert torch.equal(got, vkn.ops.mask_gather(x, mp, 0.5)[0])
 
 
+@pytest.mark.gpu
+def test_vis_rpn_and_roi_training_vs_reference_golden(vkn):
+    """The VIS model's rpn_head -> roi_head training hand-over against the REFERENCE's own classes (oracle/gen_golden_vis.py:
+    run_rpn_roi_train): `ConvKernelHeadVideo.forward_train` behind a pass-through neck, then `KernelIterHeadVideo.forward_train` on
+    its outputs, clip-shaped ground truth — both loss dicts 1e-4 relative, every Hungarian assignment bit-exact, the clip-shaped
+    features the tracker head receives."""
+    g = dict(np.load(os.path.join(GOLDEN, 'vis_rpn_train.npz'), allow_pickle=False))
+    C, heads, ffn, ncls, nprop, H, W, up, S, bs, nf, seed = (int(v) for v in g['case'])
+    c = dict(C=C, heads=heads, ffn=ffn, ncls=ncls, up=up)
+    assign = dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                  dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True), mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    tc = dict(assigner=assign, sampler=dict(type='MaskPseudoSampler'), pos_weight=1)
+    rpn = vkn.build_head(dict(type='ConvKernelHeadVideo', num_proposals=nprop, in_channels=C, out_channels=C, num_loc_convs=0,
+                              num_seg_convs=0, localization_fpn=None, conv_kernel_size=1, semantic_fpn=True, num_classes=ncls,
+                              use_binary=True, proposal_feats_with_obj=True, feat_downsample_stride=up, feat_refine=False,
+                              num_thing_classes=ncls, num_stuff_classes=0, cat_stuff_mask=False,
+                              loss_seg=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                              loss_mask=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                              loss_dice=dict(type='DiceLoss', loss_weight=4.0), train_cfg=tc))
+    roi = vkn.build_head(dict(type='KernelIterHeadVideo', num_stages=S, stage_loss_weights=[1] * S, assign_stages=S,
+                              proposal_feature_channel=C, num_thing_classes=ncls, num_stuff_classes=0, num_proposals=nprop,
+                              train_cfg=[tc for _ in range(S)], mask_head=[_stage_cfg(vkn, 'KernelUpdateHead', c) for _ in range(S)]))
+    assert sorted(rpn.state_dict()) == list(g['rpn_keys_sd'])
+    for m, sd_seed in ((rpn, seed), (roi, seed + 1)):
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_like(shapes, sd_seed).items()}, strict=True)
+        m.to(DEV).train()
+    rpn._upstream_feats = lambda img: img
+    F_ = bs * nf
+    loc = torch.from_numpy(synth.uniform((F_, C, H, W), seed + 2, -1.0, 1.0)).to(DEV).requires_grad_(True)
+    sem = torch.from_numpy(synth.uniform((F_, C, H, W), seed + 3, -1.0, 1.0)).to(DEV).requires_grad_(True)
+    tg = synth.clip_targets(bs, nf, ncls, H * up, W * up, seed)
+    gt_masks = [[torch.from_numpy(m).to(DEV) for m in t['gt_masks']] for t in tg]
+    gt_labels = [torch.from_numpy(t['gt_labels']).to(DEV) for t in tg]
+    metas = [[dict() for _ in range(nf)] for _ in range(bs)]
+    assigned = []
+
+    def hook(a):
+        for meth in ('assign', 'assign_batch'):
+            if hasattr(a, meth):
+                orig = getattr(a, meth)
+
+                def rec(*args, _orig=orig, **kw):
+                    r = _orig(*args, **kw)
+                    assigned.extend(x.gt_inds.clone() for x in (r if isinstance(r, list) else [r]))
+                    return r
+                setattr(a, meth, rec)
+    hook(rpn.assigner)
+    for a in roi.mask_assigner:
+        hook(a)
+    rl, prop, x_feats, masks, cls = rpn.forward_train((loc, sem), [dict()] * bs, metas, gt_masks, gt_labels)
+    n_rpn = len(assigned)
+    ll, feats = roi.forward_train(x_feats, prop, masks, cls, metas, gt_masks, gt_labels)
+    assert sorted(rl) == list(g['rpn_keys']) and sorted(ll) == list(g['roi_keys'])
+    got = torch.stack(assigned).cpu().numpy()
+    assert np.array_equal(got[:n_rpn], g['assigned_rpn']) and np.array_equal(got[n_rpn:], g['assigned_roi'])
+    for keys, vals, d in ((g['rpn_keys'], g['rpn_vals'], rl), (g['roi_keys'], g['roi_vals'], ll)):
+        for k, ref in zip(keys, vals):
+            assert abs(float(d[str(k)].detach()) - ref) < 1e-4 * max(1.0, abs(ref)), (str(k), float(d[str(k)].detach()), ref)
+    assert maxabs(prop, g['proposal_feats']) < 1e-3 * (1 + float(np.abs(g['proposal_feats']).max()))
+    assert maxabs(feats['obj_feats'], g['feat_obj']) < 1e-3 and maxabs(feats['cls_scores'], g['feat_cls']) < 1e-3
+    rs = feats['masks'].detach().double().sum(dim=(-1, -2)).cpu().numpy()
+    assert np.abs(rs - g['feat_mask_rowsum']).max() < 2e-3 * max(1.0, float(np.abs(g['feat_mask_rowsum']).max()))
+    total = sum(v for k, v in rl.items() if 'loss' in k) + sum(v for k, v in ll.items() if 'loss' in k)
+    assert abs(float(total.detach()) - float(g['total'])) < 1e-4 * abs(float(g['total']))
+    total.backward()
+    assert abs(float(loc.grad.double().norm()) - float(g['grad_loc_norm'])) < 5e-3 * float(g['grad_loc_norm'])
+    assert abs(float(sem.grad.double().norm()) - float(g['grad_sem_norm'])) < 5e-3 * float(g['grad_sem_norm'])
+
+
 def test_clip_instances_of_the_video_assigner(vkn):
     """CPU: the clip-instance table (instances in ascending id order; a frame where an instance is absent is a zero mask; one
     label per instance) against a direct per-instance / per-frame construction."""
