@@ -868,9 +868,12 @@ __global__ __launch_bounds__(64 * NW) void k_attn(const float* __restrict__ Q, i
 }
 
 // Attention on the matrix cores (north_star: "MFMA only for the dense N x C kernel-attention contraction"): one workgroup per
-// (frame, head), one wave per block of 32 queries; both contractions are 32x32x16 f16 MFMAs on hi + lo split operands
-// (hi hi + hi lo + lo hi, products exact in fp32 — the split of the gather / decode kernels, same fp32-class accuracy):
-//   S^T = K . Q^T      A = K rows from LDS (hi / lo planes), B = the wave's 32 scaled queries, split in registers.  The accumulator
+// (frame, head), one wave per block of 32 queries; both contractions are 32x32x16 bf16 MFMAs on operands split into THREE bf16
+// planes (hi + mid + lo = the fp32 value to 24 bits) with the six cross products of the [N x C] GEMMs (hi lo, lo hi, mid mid,
+// hi mid, mid hi, hi hi; smallest first) — fp32-class accuracy.  (A first version used the f16 hi + lo split of the gather / decode
+// kernels, three products: ~2^-21 per term, 1e-5 on the output — 20x the error of an fp32 loop and enough to move a near-threshold
+// pixel of the free-running head; the bf16x3 form costs 2x the MFMAs of a kernel that is latency-bound.)
+//   S^T = K . Q^T      A = K rows from LDS (three planes), B = the wave's 32 scaled queries, split in registers.  The accumulator
 //                      layout puts a QUERY on a lane column, so the softmax over the keys is a reduction over a lane's own registers
 //                      plus one exchange with lane ^ 32 — no row-wise cross-lane reductions;
 //   O   = P . V        A = P: the normalised probabilities ARE already an A fragment (row = query = lane column) if the contraction
@@ -879,26 +882,33 @@ __global__ __launch_bounds__(64 * NW) void k_attn(const float* __restrict__ Q, i
 //                      + (jj & 3)), so a B fragment is one 16-byte LDS read.  Output rows = queries, lane = channel: coalesced stores.
 // HD: head width (16 / 32 / 64), NKB: 32-key blocks (keys >= Nk are masked to -inf / zero).  Replaces k_attn's VALU loops
 // (one wave per query row: 28-31 us per launch at 32 frames).
+#define ATTM_MFMA6(ACC, AH, AM, AL, BH, BM, BL)                                   \
+    do {                                                                          \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BM, ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BM, ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BH, ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, ACC, 0, 0, 0);      \
+    } while (0)
 template <int HD, int NKB>
 __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
                                                    const float* __restrict__ Vp, int ldkv, float* __restrict__ out, int ldo,
                                                    int Nq, int Nk, float scale) {
     constexpr int NKP = NKB * 32;            // padded key count
-    constexpr int KLD = HD + 8;              // halfs per K row (16-byte aligned rows, conflict-free 16-B reads)
-    constexpr int VLD = NKP + 8;             // halfs per V^T row
+    constexpr int KLD = HD + 8;              // bf16 per K row (16-byte aligned rows, conflict-free 16-B reads)
+    constexpr int VLD = NKP + 8;             // bf16 per V^T row
     constexpr int DP = HD < 32 ? 32 : HD;    // channel rows of V^T (one or two 32-column blocks of O)
     constexpr int NDB = DP / 32;
     constexpr int KS = HD / 16;              // k-steps of K . Q^T
     extern __shared__ __attribute__((aligned(16))) char smem_am[];
-    _Float16* Kh = reinterpret_cast<_Float16*>(smem_am);   // [NKP][KLD]
-    _Float16* Kl = Kh + NKP * KLD;
-    _Float16* Vh = Kl + NKP * KLD;                          // [DP][VLD]  (V^T, keys permuted)
-    _Float16* Vl = Vh + DP * VLD;
+    __bf16* Kpl = reinterpret_cast<__bf16*>(smem_am);      // [3][NKP][KLD]: hi, mid, lo planes of the K rows
+    __bf16* Vpl = Kpl + 3 * NKP * KLD;                      // [3][DP][VLD]: planes of V^T, keys permuted
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
-    // ---- stage K (rows) and V (transposed, permuted) as f16 hi / lo
+    // ---- stage K (rows) and V (transposed, permuted) as three bf16 planes
     for (int i = tid; i < NKP * (HD / 4); i += 256) {
         const int j = i / (HD / 4), d4 = i - j * (HD / 4);
         f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
@@ -907,33 +917,37 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
             kv = *reinterpret_cast<const f32x4*>(Kp + off);
             vv = *reinterpret_cast<const f32x4*>(Vp + off);
         }
-        half4 kh, kl;
+        bf16x4 kh, km, kl;
         const int jj = j & 31;
         const int pos = (j & ~31) + 16 * (jj >> 4) + 8 * ((jj >> 2) & 1) + 4 * ((jj >> 3) & 1) + (jj & 3);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            _Float16 hh, ll;
-            vkn_split_f16(kv[e], hh, ll);
+            __bf16 hh, mm, ll;
+            vkn_split_bf16x3(kv[e], hh, mm, ll);
             kh[e] = hh;
+            km[e] = mm;
             kl[e] = ll;
-            vkn_split_f16(vv[e], hh, ll);
-            Vh[(4 * d4 + e) * VLD + pos] = hh;
-            Vl[(4 * d4 + e) * VLD + pos] = ll;
+            vkn_split_bf16x3(vv[e], hh, mm, ll);
+            __bf16* vd = Vpl + (4 * d4 + e) * VLD + pos;
+            vd[0] = hh;
+            vd[DP * VLD] = mm;
+            vd[2 * DP * VLD] = ll;
         }
-        *reinterpret_cast<half4*>(Kh + j * KLD + 4 * d4) = kh;
-        *reinterpret_cast<half4*>(Kl + j * KLD + 4 * d4) = kl;
+        __bf16* kd = Kpl + j * KLD + 4 * d4;
+        *reinterpret_cast<bf16x4*>(kd) = kh;
+        *reinterpret_cast<bf16x4*>(kd + NKP * KLD) = km;
+        *reinterpret_cast<bf16x4*>(kd + 2 * NKP * KLD) = kl;
     }
     if (HD < 32)   // channel rows HD .. 31 of V^T: zeros (they feed output columns nobody stores, but must be finite)
-        for (int i = tid; i < (DP - HD) * NKP; i += 256) {
-            const int d = HD + i / NKP, k = i - (i / NKP) * NKP;
-            Vh[d * VLD + k] = (_Float16)0.f;
-            Vl[d * VLD + k] = (_Float16)0.f;
+        for (int i = tid; i < 3 * (DP - HD) * NKP; i += 256) {
+            const int pl = i / ((DP - HD) * NKP), r = i - pl * (DP - HD) * NKP;
+            Vpl[(pl * DP + HD + r / NKP) * VLD + (r - (r / NKP) * NKP)] = (__bf16)0.f;
         }
     __syncthreads();
     const int qb = blockIdx.z * 4 + wave;
     if (qb * 32 >= Nq) return;   // (no barrier below)
     // ---- the wave's 32 queries as B fragments: lane (g, li) = query li, channels 16 ks + 8 g .. + 7, scaled, split
-    half8 qh[KS], ql[KS];
+    bf16x8 qh[KS], qm[KS], ql[KS];
     {
         const int q = min(qb * 32 + li, Nq - 1);
         const float* qp = Q + ((size_t)b * Nq + q) * ldq + h * HD + 8 * g;
@@ -943,9 +957,10 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                _Float16 hh, ll;
-                vkn_split_f16((e < 4 ? a0[e] : a1[e - 4]) * scale, hh, ll);
+                __bf16 hh, mm, ll;
+                vkn_split_bf16x3((e < 4 ? a0[e] : a1[e - 4]) * scale, hh, mm, ll);
                 qh[ks][e] = hh;
+                qm[ks][e] = mm;
                 ql[ks][e] = ll;
             }
         }
@@ -958,11 +973,11 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
         for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const half8 ah = *reinterpret_cast<const half8*>(Kh + (kb * 32 + li) * KLD + 16 * ks + 8 * g);
-            const half8 al = *reinterpret_cast<const half8*>(Kl + (kb * 32 + li) * KLD + 16 * ks + 8 * g);
-            acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], acc[kb], 0, 0, 0);
-            acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], acc[kb], 0, 0, 0);
-            acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], acc[kb], 0, 0, 0);
+            const __bf16* kp = Kpl + (kb * 32 + li) * KLD + 16 * ks + 8 * g;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kp);
+            const bf16x8 am = *reinterpret_cast<const bf16x8*>(kp + NKP * KLD);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(kp + 2 * NKP * KLD);
+            ATTM_MFMA6(acc[kb], ah, am, al, qh[ks], qm[ks], ql[ks]);
         }
     }
     // ---- softmax over the keys of this lane's query (its own registers + the other half-wave)
@@ -997,22 +1012,22 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            half8 ph, pl;
+            bf16x8 ph, pm, pl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                _Float16 hh, ll;
-                vkn_split_f16(acc[kb][8 * hf + e] * inv, hh, ll);
+                __bf16 hh, mm, ll;
+                vkn_split_bf16x3(acc[kb][8 * hf + e] * inv, hh, mm, ll);
                 ph[e] = hh;
+                pm[e] = mm;
                 pl[e] = ll;
             }
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
-                const int voff = (db * 32 + li) * VLD + kb * 32 + 16 * hf + 8 * g;
-                const half8 vh = *reinterpret_cast<const half8*>(Vh + voff);
-                const half8 vl = *reinterpret_cast<const half8*>(Vl + voff);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o[db], 0, 0, 0);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o[db], 0, 0, 0);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o[db], 0, 0, 0);
+                const __bf16* vp = Vpl + (db * 32 + li) * VLD + kb * 32 + 16 * hf + 8 * g;
+                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vp);
+                const bf16x8 vm = *reinterpret_cast<const bf16x8*>(vp + DP * VLD);
+                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vp + 2 * DP * VLD);
+                ATTM_MFMA6(o[db], ph, pm, pl, vh, vm, vl);
             }
         }
     // ---- o[db][r] at lane (g, li) = output of query 32 qb + cd_row(r, lane), channel 32 db + li
@@ -1028,6 +1043,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
         }
     }
 }
+#undef ATTM_MFMA6
 
 // Attention with MORE than 256 keys per query (the clip-level query merge of the VIS heads: Nk = frames * kernels, a query row
 // attends to every frame's kernels — knet_vis/tracker/kernel_frame_iter_head.py:142-160).  One wave per query row, grid
@@ -1311,11 +1327,12 @@ int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int
         VKN_CHECK_LAUNCH();
         return VKN_OK;
     }
-    if ((hd == 16 || hd == 32 || hd == 64) && Nk <= 256 && !vkn_dbg_env("VKN_ATTN_VALU", 0)) {   // matrix-core attention
+    // matrix-core attention: head widths 16 / 32 with up to 256 keys, 64 with up to 128 (three bf16 planes of K and V^T in <= 160 KB)
+    if ((hd == 16 || hd == 32 || (hd == 64 && Nk <= 128)) && Nk <= 256 && !vkn_dbg_env("VKN_ATTN_VALU", 0)) {
         const int nkb = (Nk + 31) / 32;
         const int nkbt = nkb <= 1 ? 1 : nkb <= 2 ? 2 : nkb <= 4 ? 4 : nkb <= 6 ? 6 : 8;
         const int dp = hd < 32 ? 32 : hd;
-        const size_t ldsm = ((size_t)2 * nkbt * 32 * (hd + 8) + (size_t)2 * dp * (nkbt * 32 + 8)) * sizeof(_Float16);
+        const size_t ldsm = ((size_t)3 * nkbt * 32 * (hd + 8) + (size_t)3 * dp * (nkbt * 32 + 8)) * sizeof(__bf16);   // three planes of K and V^T
         dim3 gm(heads, B, (Nq + 127) / 128);
         const float sc = 1.0f / sqrtf((float)hd);
 #define ATTM_LAUNCH(HDV, NKBV)                                                                                            \
