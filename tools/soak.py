@@ -168,8 +168,7 @@ def t_head_c256():
     # one stage (no intermediate binarisation): the two GEMM paths must agree to fp32 rounding on every output
     assert float((a[1] - e[1]).abs().max()) < 1e-5, tag                                                   # cls probabilities
     assert float((a[0] - e[0]).abs().max()) < 1e-4 * max(1.0, float(e[0].abs().max())), tag              # kernels
-    # mask logits: a 256-term dot product of kernels that agree to ~1e-5 relative: 400 trials at N < 40 reached 0.83e-3 at |logit| ~ 42
-    assert float((a[2] - e[2]).abs().max()) < 2e-3 * max(1.0, float(e[2].abs().max()) / 50), tag
+    assert float((a[2] - e[2]).abs().max()) < 1e-3 * max(1.0, float(e[2].abs().max()) / 50), tag          # mask logits
     if video:
         assert float((a[4] - e[4]).abs().max()) < 1e-4 * max(1.0, float(e[4].abs().max())), tag
 
