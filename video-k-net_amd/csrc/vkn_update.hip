@@ -908,18 +908,12 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
-    // ---- stage K (rows) and V (transposed, permuted) as three bf16 planes
+    // ---- stage K (rows) as three bf16 planes: a thread owns 4 channels of a key
     for (int i = tid; i < NKP * (HD / 4); i += 256) {
         const int j = i / (HD / 4), d4 = i - j * (HD / 4);
-        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-        if (j < Nk) {
-            const size_t off = ((size_t)b * Nk + j) * ldkv + h * HD + 4 * d4;
-            kv = *reinterpret_cast<const f32x4*>(Kp + off);
-            vv = *reinterpret_cast<const f32x4*>(Vp + off);
-        }
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f};
+        if (j < Nk) kv = *reinterpret_cast<const f32x4*>(Kp + ((size_t)b * Nk + j) * ldkv + h * HD + 4 * d4);
         bf16x4 kh, km, kl;
-        const int jj = j & 31;
-        const int pos = (j & ~31) + 16 * (jj >> 4) + 8 * ((jj >> 2) & 1) + 4 * ((jj >> 3) & 1) + (jj & 3);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             __bf16 hh, mm, ll;
@@ -927,16 +921,32 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
             kh[e] = hh;
             km[e] = mm;
             kl[e] = ll;
-            vkn_split_bf16x3(vv[e], hh, mm, ll);
-            __bf16* vd = Vpl + (4 * d4 + e) * VLD + pos;
-            vd[0] = hh;
-            vd[DP * VLD] = mm;
-            vd[2 * DP * VLD] = ll;
         }
         __bf16* kd = Kpl + j * KLD + 4 * d4;
         *reinterpret_cast<bf16x4*>(kd) = kh;
         *reinterpret_cast<bf16x4*>(kd + NKP * KLD) = km;
         *reinterpret_cast<bf16x4*>(kd + 2 * NKP * KLD) = kl;
+    }
+    // ---- ... and V transposed with the keys permuted: a thread owns ONE channel of 4 consecutive keys — the permutation keeps
+    // such a group contiguous, so each plane takes one 8-byte store (lanes = channels: the four row loads are coalesced)
+    for (int i = tid; i < (NKP / 4) * HD; i += 256) {
+        const int j4 = i / HD, d = i - j4 * HD;
+        const int j = 4 * j4, jj = j & 31;
+        const int pos = (j & ~31) + 16 * (jj >> 4) + 8 * ((jj >> 2) & 1) + 4 * ((jj >> 3) & 1);
+        bf16x4 vh, vm, vl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = (j + e < Nk) ? Vp[((size_t)b * Nk + j + e) * ldkv + h * HD + d] : 0.f;
+            __bf16 hh, mm, ll;
+            vkn_split_bf16x3(v, hh, mm, ll);
+            vh[e] = hh;
+            vm[e] = mm;
+            vl[e] = ll;
+        }
+        __bf16* vd = Vpl + d * VLD + pos;
+        *reinterpret_cast<bf16x4*>(vd) = vh;
+        *reinterpret_cast<bf16x4*>(vd + DP * VLD) = vm;
+        *reinterpret_cast<bf16x4*>(vd + 2 * DP * VLD) = vl;
     }
     if (HD < 32)   // channel rows HD .. 31 of V^T: zeros (they feed output columns nobody stores, but must be finite)
         for (int i = tid; i < 3 * (DP - HD) * NKP; i += 256) {
