@@ -221,3 +221,96 @@ def test_reducer_survives_default_zero_grad_accumulation_and_unused_members():
         assert p.exitcode == 0
     assert res['default_zero_grad'] < 1e-5 and res['step2'] < 1e-5 and res['accumulate'] < 1e-5, res
     assert res['overlap'] and res['misuse_raises'], res
+
+
+def _bulk_worker(rank, world, port, q):
+    """Parameter gradients delivered OUTSIDE autograd's accumulation nodes (what a captured chain graph does: `_ChainGraphRunner`)
+    mixed with eager ones in the same bucket, one parameter reporting both ways — through `BucketedGradAllReducer.params_ready`:
+    averaged gradients equal the plain computation, in both zero_grad modes, and the buckets are launched inside backward from the
+    second step on (report counts were learned in the first)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import vkn_import
+    vkn_import.load()
+    from importlib import import_module
+    d = import_module('video_k_net_amd.dist')
+    torch.manual_seed(0)
+
+    class Outside(torch.autograd.Function):          # y = x @ w.T + b with w, b NOT inputs of the function
+        @staticmethod
+        def forward(ctx, x, stage):
+            ctx.stage = stage
+            ctx.save_for_backward(x)
+            return x @ stage.w.detach().t() + stage.b.detach()
+
+        @staticmethod
+        def backward(ctx, gy):
+            (x,) = ctx.saved_tensors
+            st = ctx.stage
+            for p, g in ((st.w, gy.t() @ x), (st.b, gy.sum(0))):
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+            st.on_param_grads([st.w, st.b])
+            return gy @ st.w.detach(), None
+
+    class Stage(torch.nn.Module):
+        on_param_grads = None
+
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(8, 8) * 0.3)
+            self.b = torch.nn.Parameter(torch.zeros(8))
+            self.eager = torch.nn.Linear(8, 8)
+
+        def forward(self, x):
+            h = torch.tanh(Outside.apply(x, self))
+            return torch.tanh(self.eager(h)) + 0.1 * (h @ self.w.t())      # `w` is ALSO used eagerly: it reports twice
+
+        def plain(self, x):
+            h = torch.tanh(x @ self.w.t() + self.b)
+            return torch.tanh(self.eager(h)) + 0.1 * (h @ self.w.t())
+
+    net = torch.nn.ModuleDict({'mask_head': torch.nn.ModuleList([Stage(), Stage()])})
+    red = d.BucketedGradAllReducer(net)
+    assert all(st.on_param_grads is not None for st in net['mask_head'])
+    g = torch.Generator().manual_seed(5)
+    data = torch.randn(4, world * 6, 8, generator=g)
+
+    def run(xb, plain):
+        h = xb.clone().requires_grad_(True)          # (a function none of whose inputs needs a gradient is never differentiated: the
+        for st in net['mask_head']:                  #  chain graphs fall back to the eager chain in that case, KernelUpdateHead._chain)
+            h = st.plain(h) if plain else st(h)
+        return (h ** 2).sum()
+
+    res = dict(err=0.0, overlap=True)
+    for step, mode in enumerate((False, True, True, False)):
+        params = [p for _, p in net.named_parameters()]
+        ref = [gi / world for gi in torch.autograd.grad(run(data[step], True), params)]
+        red.zero_grad(set_to_none=mode)
+        run(data[step][rank * 6:(rank + 1) * 6], False).backward()
+        if step >= 1:
+            res['overlap'] = res['overlap'] and all(b['handle'] is not None for b in red.buckets)
+        red.finalize()
+        res['err'] = max([res['err']] + [float((p.grad - r).abs().max()) for p, r in zip(params, ref)])
+        assert all(p.grad.data_ptr() == v.data_ptr() for b in red.buckets for p, v in zip(b['params'], b['views']))
+    if rank == 0:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_takes_gradients_delivered_outside_autograd():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bulk_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res['err'] < 1e-5 and res['overlap'], res
