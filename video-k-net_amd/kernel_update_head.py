@@ -377,7 +377,7 @@ class KernelUpdateHead(nn.Module):
         Counterpart of knet/det/kernel_update_head.py:170-277 (video: knet/video/kernel_update_head.py:281-541)."""
         if getattr(self, '_chain_graphs', None) is not None and x.is_cuda:
             # capture (first use of a shape) BEFORE this step's autograd graph touches the head's parameters: a live eager graph
-            # through them at capture time takes the capture down (hipStreamEndCapture faults; measured, tools/scratch/graph_probe.py)
+            # through them at capture time takes the capture down (hipStreamEndCapture faults; measured, tools/micro/graph_capture_probe.py)
             xf_rg = x.requires_grad or (self.feat_transform is not None and any(p.requires_grad for p in self.feat_transform.parameters()))
             B, N = proposal_feat.shape[:2]
             self._chain_graph_for(x.new_empty((B, N, self.in_channels)).requires_grad_(xf_rg), proposal_feat, previous_obj_feats)
