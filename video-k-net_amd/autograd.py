@@ -21,6 +21,8 @@ def _pow2_scale(t, target=1024.0):
     """Power of two s (device scalar tensor) with max|t| * s in [target / 2, target) (2^10-ish for an all-zero tensor: harmless).
     One reduction pass (`max |t|` as the infinity norm, no |t| temporary) and three scalar ops; nothing touches the host."""
     t = t.detach()
+    if t.numel() == 0:
+        return torch.ones((), dtype=torch.float32, device=t.device)
     # (measured: vector_norm(inf) takes 34 us whatever the size — right for the 61 MB logit gradients, 6x slower than abs + amax on
     #  the [B, N, C] kernel gradients)
     m = torch.linalg.vector_norm(t, ord=float('inf')) if t.numel() > (1 << 22) else t.abs().amax()
