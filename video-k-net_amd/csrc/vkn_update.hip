@@ -585,6 +585,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __rest
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    const bool pre_ok = (ABL == 0) && (kt1 & 1) == 0;   // first tiles of the next GEMM requested one iteration early (they land in buffer 0)
 
     for (int cc = 0; cc < cps; ++cc) {
         const int c = hs * cps + cc;  // hidden chunk = column tile of W1 = K-tiles 8c .. 8c+7 of W2
@@ -593,7 +594,9 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
         const __bf16* w1t = W1p + (size_t)c * kt1 * GS_WTILE;
-        FF_DMA(w1t, 0);
+        const __bf16* w2t = W2p + (size_t)c * 8 * GS_WTILE;
+        // (chunks after the first: their first W1 tile was requested during the previous chunk's last GEMM-2 iteration)
+        if (cc == 0 || !pre_ok) FF_DMA(w1t, 0);
         ra = *reinterpret_cast<const f32x4*>(X + aoff);
         FF_ASTASH(0);
         __syncthreads();
@@ -603,6 +606,10 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __rest
             if (more) {
                 FF_DMA(w1t + (size_t)(kt + 1) * GS_WTILE, cur ^ 1);
                 ra = *reinterpret_cast<const f32x4*>(X + aoff + (size_t)(kt + 1) * 32);
+            } else if (pre_ok) {
+                // last K-tile of GEMM 1: buffer 0 was last read one iteration ago (every wave is past that barrier), so GEMM 2's
+                // first weight tile can travel under these MFMAs and the hidden-image conversion instead of after them
+                FF_DMA(w2t, 0);
             }
             {
                 const __bf16* Ab = Al + (size_t)cur * GS_ATILE;
@@ -637,14 +644,15 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __rest
             }
         }
         // ---- GEMM 2: acc2 [32 x C] += hidden [32 x 256] . W2[:, chunk]^T   (the barrier below also publishes the hidden image)
-        const __bf16* w2t = W2p + (size_t)c * 8 * GS_WTILE;
-        FF_DMA(w2t, 0);
+        if (!pre_ok) FF_DMA(w2t, 0);
         FF_VMCNT0();
         __syncthreads();
         for (int kt = 0; kt < (ABL == 2 ? 0 : 8); ++kt) {
             const int cur = kt & 1;
             const bool more = (kt + 1 < 8);
             if (more) FF_DMA(w2t + (size_t)(kt + 1) * GS_WTILE, cur ^ 1);
+            else if (pre_ok && cc + 1 < cps)   // ... and the next chunk's first W1 tile under the last GEMM-2 iteration (buffer 0 is free again)
+                FF_DMA(W1p + (size_t)(c + 1) * kt1 * GS_WTILE, 0);
             {
                 const __bf16* Wb = Wl + (size_t)cur * GS_WTILE;
 #pragma unroll
