@@ -336,3 +336,27 @@ def test_update_head_single_image_targets_equal_the_batch_builder(vkn):
         for a, b in zip(one, (t[i] for t in lists)):
             assert torch.equal(a, b)
 
+
+
+def test_release_sources_hold_no_debug_only_kernels():
+    """The product sources define ONE kernel per job: everything rejected or superseded lives in tools/experiments/*.inc and enters
+    only the -DVKN_DEBUG build through #include.  No `__global__` definition may sit inside an `#ifdef VKN_DEBUG` block of csrc/, and
+    the release build reads no environment variable (vkn_dbg_env is a constant there)."""
+    import glob
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'video-k-net_amd', 'csrc')
+    files = sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')))
+    assert len(files) >= 12
+    for f in files:
+        stack = []
+        for i, line in enumerate(open(f), 1):
+            t = line.strip()
+            if t.startswith('#if'):
+                stack.append('VKN_DEBUG' in t and not t.startswith('#ifndef'))
+            elif t.startswith('#else') and stack:
+                stack[-1] = False
+            elif t.startswith('#endif') and stack:
+                stack.pop()
+            elif any(stack):
+                assert '__global__' not in t, f'{os.path.basename(f)}:{i}: a kernel inside #ifdef VKN_DEBUG'
+            else:
+                assert 'getenv' not in t or 'VKN_DEBUG' in t or t.startswith('//'), f'{os.path.basename(f)}:{i}: environment read in the release build'
