@@ -68,12 +68,8 @@ print('@@' + json.dumps(out))
 
 # methods of the reference this package deliberately does not carry (reason beside each)
 NOT_BUILT = {
-    'VideoKernelIterHead': {'forward_dummy',                        # FLOPs counting hook of mmdet's tools
-                            'merge_stuff_thing_stuff_first'},       # dead code in the reference: nothing calls it
-    'KernelIterHead': {'forward_dummy', 'aug_test', 'get_panoptic'},    # test-time augmentation raises in the reference too; get_panoptic lives on the detector here
-    'KernelIterHeadVideo': {'forward_dummy', 'aug_test'},
+    'VideoKernelIterHead': {'merge_stuff_thing_stuff_first'},      # dead code in the reference: nothing calls it
     'QuasiDenseEmbedTracker': {'update_memo'},     # the memo lives in the device state buffer; the match kernel updates it in the same launch
-    'KernelFrameIterHeadVideo': {'forward_dummy', 'aug_test'},
 }
 
 
