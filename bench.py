@@ -72,6 +72,32 @@ def panoptic_inputs(B, N, Np, ncls, H, W, device, seed=7):
     return cls.to(device), logits.to(device)
 
 
+def _cpu_identity():
+    """(CPU model string, physical core count) of this host from /proc/cpuinfo — BASELINE.md §3 asks for both beside the thread
+    count the baseline actually used."""
+    model, cores = 'unknown', set()
+    try:
+        phys = core = None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                k, _, v = line.partition(':')
+                k, v = k.strip(), v.strip()
+                if k == 'model name' and model == 'unknown':
+                    model = v
+                elif k == 'physical id':
+                    phys = v
+                elif k == 'core id':
+                    core = v
+                elif not k and phys is not None and core is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or None)
+
+
 def cpu_baseline(head_sd, sample_frames=1, runs=6):
     """The CPU oracle (same ATen op sequence as the reference) on this host's cores — kind 'port'."""
     from oracle.knet_oracle import HeadCfg, iter_head_mask_preds
@@ -117,7 +143,9 @@ def cpu_baseline(head_sd, sample_frames=1, runs=6):
             if i >= 1:
                 t1.append(time.perf_counter() - t0)
     t1.sort()
+    model, phys = _cpu_identity()
     return dict(value=round(sample_frames / med, 4), unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                cpu_model=model, physical_cores=phys, logical_cores=ncpu, threads_used=torch.get_num_threads(),
                 cfg1_size_value=round(sample_frames / t1[len(t1) // 2], 4),
                 sample=f'{runs} timed runs (2 warm-up) of {sample_frames} frame(s) of the same workload, fp32, median, '
                        f'{best} intra-op threads (fastest of 8/16/32/64 on {ncpu} logical CPUs); '
@@ -512,7 +540,7 @@ def main():
             per_call[f'frames_per_s_at_{B}_frames_per_call'] = round(frames / dt, 1)
             if world == 1 and NS == 1 and not args.no_extras:
                 # several independent clips in flight (step i on HIP stream i % 4, e.g. one video per stream): the latency-bound update
-                # chain of one clip runs while another clip's HBM-bound kernels stream (tools/inflight_test.py: 1 / 3 / 4 / 6 streams ->
+                # chain of one clip runs while another clip's HBM-bound kernels stream (tools/inflight_probe.py: 1 / 3 / 4 / 6 streams ->
                 # 8.66 / 9.13 / 9.62 / 9.64 k frames/s).  For the record only: `value` is ONE step at a time on one stream, and the
                 # roofline kernel is timed without a concurrent clip.
                 sts = [torch.cuda.Stream(device=device) for _ in range(4)]

@@ -9,8 +9,14 @@
  *     (16-byte aligned); nothing is allocated or freed inside; work is enqueued asynchronously on `stream`
  *     (a `hipStream_t`, passed as void*; NULL = the default stream); no host synchronisation.
  *   - return value: 0 = VKN_OK, < 0 = error (vkn_strerror); never throws, never aborts.
- *   - re-entrant and thread-safe: no global mutable state; scratch memory is the caller's `ws` buffer
- *     (size from vkn_stage_workspace_bytes / vkn_head_workspace_bytes).
+ *   - re-entrant and thread-safe; scratch memory is the caller's `ws` buffer (size from vkn_stage_workspace_bytes /
+ *     vkn_head_workspace_bytes).  Library-owned state, all of it idempotent and per (host thread, device) or per device:
+ *       (1) one non-blocking side stream + two events per (host thread, device), created on first use by vkn_head_forward_* /
+ *           vkn_head_forward_link_f32 when a tracking link is requested WITHOUT VKN_FLAG_SERIAL_LINK, never destroyed (process
+ *           lifetime) and shared by every caller stream of that thread (calls of one thread are host-ordered, so their side-stream
+ *           work is ordered too; it does not overlap ACROSS caller streams of one thread).  VKN_FLAG_SERIAL_LINK: nothing is created;
+ *       (2) a per-kernel "dynamic LDS limit raised on device d" bit mask (hipFuncSetAttribute once per process and device).
+ *     Nothing else is kept between calls; two threads may call concurrently with different workspaces.
  *   - layouts: x [B][C][P] fp32 (NCHW, P = H*W); mask logits [B][N][P] fp32; kernels / object features [B][N][C] fp32
  *     (the reference's [B,N,C,1,1] with conv_kernel_size K = 1, the only value in any shipped config).
  *   - arithmetic: fp32 storage; gather / decode contract on MFMA with an f16 hi+lo operand split and fp32 accumulation
@@ -417,7 +423,9 @@ int vkn_lsap_f32(const float* cost, int nr, int nc, int* row_ind, int* col_ind);
  *      the assignment then needs no device -> host copy at all.  cost: DEVICE fp32 [nr][nc] row-major (nr = predictions, nc = ground
  *      truths; nr, nc <= 256); outputs (DEVICE, each may be NULL): gt_inds int64 [nr] = matched col + 1 or 0 — the reference's
  *      `assigned_gt_inds` (:262-271) — and the min(nr, nc) (row, col) pairs sorted by row, exactly scipy's return value.
- *      status (DEVICE int [nprob], may be NULL): 0 ok, 1 the matrix holds NaN / -inf, 2 infeasible (gt_inds = -1 then).
+ *      status (DEVICE int [nprob], may be NULL): 0 ok, 1 the matrix holds NaN / -inf, 2 infeasible.  On failure the outputs are a
+ *      VALID dummy assignment (pair k = (row k, column 0), gt_inds = 1 for the first min(nr, nc) rows, 0 beyond): a caller that
+ *      reads the status asynchronously can index with them in bounds until it raises.
  *      Results are identical to vkn_lsap_f32 / scipy including tied matrices (same scan order and tie rule, fp64). */
 #define VKN_LSAP_MAX_BATCH 64
 typedef struct VknLsapProblem {
@@ -459,7 +467,8 @@ int vkn_mask_losses_bwd_f32(const float* pred, const float* target, const int* r
  *      in : bboxes [n][5] (x1, y1, x2, y2, score) fp32, labels [n] int64, embeds [n][embed_dim] fp32 — device pointers, n <= max_dets
  *      out: out_bboxes [max_dets][5], out_labels [max_dets], out_ids [max_dets] — the SURVIVING detections in score order (the
  *           reference returns exactly these rows), ids: >= 0 track id, -1 unmatched (kept as backdrop candidate), -2 suppressed;
- *           out_count[0] = number of surviving detections, out_count[1] = status bits (1: tracklet table full, a birth was dropped).
+ *           out_count[0] = number of surviving detections, out_count[1] = status bits OF THIS CALL (1: tracklet table full, a birth
+ *           was dropped — its id is still consumed); the state header keeps the union over all calls since the reset.
  *      Equal scores are ordered by input row (torch's unstable sort leaves that order unspecified).  memo_keep = float(1.0 -
  *      double(memo_momentum)): Python evaluates `1 - self.memo_momentum` in double before it meets the fp32 tensor. */
 typedef struct VknTrackerCfg {

@@ -930,8 +930,12 @@ def test_device_lsap_equals_host_solver_and_scipy(vkn):
     bad[1, 2] = np.nan
     inf = np.full((4, 6), np.inf, np.float32)
     ok = np.arange(12, dtype=np.float32).reshape(3, 4)
-    g, _, _, st = vkn.ops.lsap_device([torch.from_numpy(a).to(DEV) for a in (bad, inf, ok)])
-    assert st.cpu().tolist() == [1, 2, 0] and g[0].cpu().tolist() == [-1] * 3 and g[1].cpu().tolist() == [-1] * 4
+    g, r, c, st = vkn.ops.lsap_device([torch.from_numpy(a).to(DEV) for a in (bad, inf, ok)])
+    assert st.cpu().tolist() == [1, 2, 0]
+    # a failed problem still returns an IN-BOUNDS dummy assignment (row k <-> column 0): the status is read one step late, the
+    # indices are used at once
+    assert g[0].cpu().tolist() == [1, 1, 1] and r[0].cpu().tolist() == [0, 1, 2] and c[0].cpu().tolist() == [0, 0, 0]
+    assert g[1].cpu().tolist() == [1, 1, 1, 1] and r[1].cpu().tolist() == [0, 1, 2, 3] and c[1].cpu().tolist() == [0] * 4
     a = vkn.MaskHungarianAssigner(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
                                   mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
     a.pending_status.append(st)

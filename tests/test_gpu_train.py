@@ -178,6 +178,40 @@ def test_chain_as_hipgraphs_equals_eager_chain(vkn, name):
     assert all(h._chain_graphs is None for h in head.mask_head)
 
 
+@pytest.mark.parametrize('mode', ['zero_in_place', 'accumulate'])
+def test_chain_graphs_without_reducer_zero_in_place_and_accumulation(vkn, mode):
+    """the captured chains' static gradient buffers become `p.grad`; `optimizer.zero_grad(set_to_none=False)` and
+    gradient accumulation over two micro-batches (no reducer) must still give the eager chain's gradients."""
+    g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, 'train_tiny')
+    metas = [dict() for _ in range(case['B'])]
+
+    def step(h, scale):
+        xd = (x * scale).to(DEV)
+        losses = h.forward_train(xd, pf.to(DEV), mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                 gt_sem_cls=gt_sem_cls)
+        sum(v for k, v in losses.items() if 'loss' in k).backward()
+
+    def run(h):
+        for p in h.parameters():
+            p.grad = None
+        step(h, 1.0)
+        if mode == 'zero_in_place':
+            for p in h.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
+        step(h, 0.9)
+        return {k: p.grad.clone() for k, p in h.named_parameters() if p.grad is not None}
+
+    eager = run(head)
+    head.enable_chain_graphs()
+    run(head)                       # captures
+    graphed = run(head)             # replays into the same static buffers
+    head.enable_chain_graphs(False)
+    assert eager.keys() == graphed.keys()
+    for k in eager:
+        assert maxabs(eager[k], graphed[k]) <= 2e-6 * max(float(eager[k].abs().max()), 1e-12), k
+
+
 @pytest.mark.parametrize('set_to_none', [False, True])
 def test_chain_graphs_deliver_gradients_to_the_bucketed_reducer(vkn, set_to_none):
     """Captured chains hand their parameter gradients over in bulk (no autograd accumulation nodes): through

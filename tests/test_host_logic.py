@@ -360,3 +360,31 @@ def test_release_sources_hold_no_debug_only_kernels():
                 assert '__global__' not in t, f'{os.path.basename(f)}:{i}: a kernel inside #ifdef VKN_DEBUG'
             else:
                 assert 'getenv' not in t or 'VKN_DEBUG' in t or t.startswith('//'), f'{os.path.basename(f)}:{i}: environment read in the release build'
+
+
+def test_chain_graph_gradient_delivery_survives_inplace_zero_and_accumulation(vkn):
+    """`_ChainGraphRunner._deliver` hands the captured backward graph's STATIC gradient buffers over as `p.grad`.  With
+    `zero_grad(set_to_none=False)` or a second micro-batch (no zeroing at all) that buffer is still `p.grad` when the next replay
+    overwrites it — the replay is simulated here by writing into the buffers, which is all a graph replay does to them."""
+    from importlib import import_module
+    kuh = import_module('video_k_net_amd.kernel_update_head')
+    p = torch.nn.Parameter(torch.zeros(3))
+    buf = torch.zeros(3)
+    r = kuh._ChainGraphRunner.__new__(kuh._ChainGraphRunner)
+    r.used, r.head = [(p, buf)], object()
+
+    def backward(vals):
+        r._unalias()                      # what _ChainGraphFn.backward does around the replay
+        buf.copy_(torch.tensor(vals))     # "replay"
+        r._deliver()
+
+    backward([1., 2., 3.])
+    assert p.grad.tolist() == [1., 2., 3.]
+    p.grad.zero_()                        # optimizer.zero_grad(set_to_none=False)
+    backward([1., 2., 3.])
+    assert p.grad.tolist() == [1., 2., 3.]            # was [2, 4, 6]: the buffer added to itself
+    backward([10., 10., 10.])             # gradient accumulation: no zeroing between two backwards
+    assert p.grad.tolist() == [11., 12., 13.]         # was [20, 20, 20]: the first micro-batch lost
+    p.grad = None                         # the usual loop
+    backward([5., 6., 7.])
+    assert p.grad.tolist() == [5., 6., 7.] and p.grad.data_ptr() == buf.data_ptr()   # fast path still hands the buffer itself over

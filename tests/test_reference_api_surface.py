@@ -69,7 +69,6 @@ print('@@' + json.dumps(out))
 # methods of the reference this package deliberately does not carry (reason beside each)
 NOT_BUILT = {
     'VideoKernelIterHead': {'merge_stuff_thing_stuff_first'},      # dead code in the reference: nothing calls it
-    'QuasiDenseEmbedTracker': {'update_memo'},     # the memo lives in the device state buffer; the match kernel updates it in the same launch
 }
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Consecutive clip steps in flight on K HIP streams (step i on stream i % K): does the latency-bound update chain of one step hide
-under the HBM-bound upsample of another?   python tools/inflight_test.py [--frames 32]"""
+under the HBM-bound upsample of another?   python tools/inflight_probe.py [--frames 32]"""
 import argparse
 import os
 import sys

@@ -278,8 +278,16 @@ __global__ __launch_bounds__(64) void k_lsap(VknLsapBatch batch, int* __restrict
     if (lane == 0 && status) status[blockIdx.x] = st;
     // outputs in terms of the ORIGINAL matrix (rows = nr): gt_inds[row] = col + 1 or 0; (row_ind, col_ind) pairs sorted by row
     if (st != 0) {
+        // failed (NaN / -inf entries, infeasible): the status word reports it, but the caller reads it asynchronously — one step
+        // later — and indexes with these outputs at once.  So they are a VALID dummy assignment (row k <-> column 0 for the
+        // min(nr, nc) pairs the caller expects): every downstream gather stays in bounds until the flag is raised.
+        const int K = nr < nc ? nr : nc;
         for (int r = lane; r < nr; r += 64)
-            if (pb.gt_inds) pb.gt_inds[r] = -1;
+            if (pb.gt_inds) pb.gt_inds[r] = r < K ? 1 : 0;
+        for (int k = lane; k < K; k += 64) {
+            if (pb.row_ind) pb.row_ind[k] = k;
+            if (pb.col_ind) pb.col_ind[k] = 0;
+        }
         return;
     }
     if (!transpose) {

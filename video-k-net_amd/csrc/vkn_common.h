@@ -23,6 +23,14 @@ static inline int vkn_dbg_env(const char* name, int dflt) {
 #else
 #define vkn_dbg_env(name, dflt) (dflt)
 #endif
+// Time-attribution / ablation arms of the shipped kernels (template parameter ABL, upsample NT 2 / 3): `VKN_ABL_IS(ABL, k)` is the
+// comparison in the debug build and the literal `false` in the release build — the preprocessor removes the arms from the
+// release kernels instead of leaving dead template branches in the product.
+#ifdef VKN_DEBUG
+#define VKN_ABL_IS(param, k) ((param) == (k))
+#else
+#define VKN_ABL_IS(param, k) false
+#endif
 
 // ---- MFMA 32x32 C/D fragment map (dtype independent on gfx950): lane l, register r ->
 //      col = l & 31 ; row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)

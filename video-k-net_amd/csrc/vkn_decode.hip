@@ -159,15 +159,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
         } else if (XH) { /* half storage: the pixel pair is one dword */                                         \
             _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                        \
                 REG[e] = u32x2{__builtin_amdgcn_raw_buffer_load_b32(xrs, voff_, soff_ + ((e * P) << 1), 3), 0u}; \
-        } else if (ABL == 2) {                                                                                          \
+        } else if (VKN_ABL_IS(ABL, 2)) {                                                                                    \
             _Pragma("unroll") for (int e = 0; e < 8; ++e) REG[e] = u32x2{(unsigned)(voff_ + e), (unsigned)soff_}; \
         } else {                                                                                                 \
             _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                        \
                 /* aux = 2 (nt): x is streamed once per launch; measured +9 % (92 -> 84 us, cfg2 B = 8).  ABL 4 = plain */ \
                 /* cache policy aux = 3 (sc0 | nt): x is streamed once per launch.  tools/decode_sweep.py, cfg2 B = 8:        */ \
                 /* plain 88.7-94.6 us, nt 81.9-86.2 us, sc0|nt 78.3-82.7 us.  ABL 4 = plain, ABL 6 = nt only (A/B)     */ \
-                REG[e] = (ABL == 4)   ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 0) \
-                         : (ABL == 6) ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 2) \
+                REG[e] = VKN_ABL_IS(ABL, 4) ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 0) \
+                         : VKN_ABL_IS(ABL, 6) ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 2) \
                                       : __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 3); \
         }                                                                                                        \
         const bool adv_ = (ld_cnt + 1 < total);                                                                  \
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
             const _Float16* ap_ = ldsH + (nb * 32 + li) * LDK + cb_;                                              \
             const half8 ah = *reinterpret_cast<const half8*>(ap_);                                                \
             const half8 al = *reinterpret_cast<const half8*>(ap_ + NB * 32 * LDK);                                \
-            if (ABL == 1) {                                                                                       \
+            if (VKN_ABL_IS(ABL, 1)) {                                                                                   \
                 asm volatile("" ::"v"(ah), "v"(al), "v"(bh0), "v"(bl0), "v"(bh1), "v"(bl1));                      \
             } else { /* alternate the two accumulators so dependent MFMAs are never back to back */               \
                 acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, acc[0][nb], 0, 0, 0);                \
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
             asm volatile("" : "+s"(Pq_));                                                                         \
             if (BITS) { /* P % 64 == 0 (launcher): every tile is whole */                                        \
                 dec_emit_bits<NB>(acc, thr, bits_out + ((size_t)b * (P >> 5) + ((p0_ >> 6) << 1)) * NPT + n0, NPT, lane);   \
-            } else if (ABL != 3 || acc[0][0][0] == 12345.678f) {                                                  \
+            } else if (!VKN_ABL_IS(ABL, 3) || acc[0][0][0] == 12345.678f) {                                                  \
                 if (p0_ + DEC_TILE <= p_end) { /* whole tile in range (uniform): 8-byte stores, 256 B per row */  \
                     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                           \
                         if ((OPT & 4) && n0 + nb * 32 + 32 <= N) { /* 16-byte stores: lanes 2j / 2j+1 swap halves */ \
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
                                 const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                           \
                                 const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
                                 const u32x2 v_ = {__float_as_uint(a0_), __float_as_uint(a1_)};                    \
-                                if (ABL == 5)                                                                     \
+                                if (VKN_ABL_IS(ABL, 5))                                                              \
                                     __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * Pq_ + p0_) << 2, 2); \
                                 else                                                                              \
                                     __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * Pq_ + p0_) << 2, 0); \

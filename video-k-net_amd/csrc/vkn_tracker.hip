@@ -495,7 +495,15 @@ __global__ __launch_bounds__(TRK_THREADS) void k_qd_match(VknTrackerCfg cfg, cha
         ntrk = s_total;
     }
     // any thread may have seen the overflow
-    if (status) atomicOr(&st.hdr[H_STATUS], status);
+    // out_count[1] reports THIS call's status; the header keeps the sticky union for introspection (`tracker.status`).  Reporting
+    // the sticky word made every later match() raise until reset().
+    __shared__ int s_call_status;
+    if (tid == 0) s_call_status = 0;
+    __syncthreads();
+    if (status) {
+        atomicOr(&s_call_status, status);
+        atomicOr(&st.hdr[H_STATUS], status);
+    }
     __syncthreads();
     if (tid == 0) {
         st.hdr[H_NEXT_ID] = next_id + total_new;
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_qd_match(VknTrackerCfg cfg, cha
         st.hdr[H_LAST_NV] = nv;
         st.hdr[H_CALLS] += 1;
         out_count[0] = nv;
-        out_count[1] = st.hdr[H_STATUS];
+        out_count[1] = s_call_status;
     }
 }
 

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
     // BAR: this wave's LDS writes are done (lgkmcnt) + workgroup barrier, as ONE asm statement: behind a __syncthreads() hipcc
     // strengthens the wait to vmcnt(0) (its workgroup release fence), which would drain the prefetch.
 #define GS_BAR(VM) asm volatile("s_waitcnt " VM "lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    const int nkt = (ABL == 1) ? 0 : kt_end - kt_begin;
+    const int nkt = VKN_ABL_IS(ABL, 1) ? 0 : kt_end - kt_begin;
     if (nkt > 0) {
         const int klast = kt_end - 1;
         if (a_role) {
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(GM_THREADS) void k_gemm_s3(VknGemmProb p0, VknGemmP
 #pragma unroll
     for (int r = 0; r < 16; ++r) T[vkn_cd_row(r, lane) * GM_LDT + wave * 32 + li] = active ? acc[r] : 0.f;
     __syncthreads();
-    if (ABL == 2) {
+    if (VKN_ABL_IS(ABL, 2)) {
         if (T[tid] == 12345.678f) partial[0] = cols.bias[0];  // keep the loads alive
         return;
     }
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __rest
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-    const bool pre_ok = (ABL == 0) && (kt1 & 1) == 0;   // first tiles of the next GEMM requested one iteration early (they land in buffer 0)
+    const bool pre_ok = !VKN_ABL_IS(ABL, 1) && !VKN_ABL_IS(ABL, 2) && (kt1 & 1) == 0;   // first tiles of the next GEMM requested one iteration early (they land in buffer 0)
 
     for (int cc = 0; cc < cps; ++cc) {
         const int c = hs * cps + cc;  // hidden chunk = column tile of W1 = K-tiles 8c .. 8c+7 of W2
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __rest
         if (!pre_ok) FF_DMA(w2t, 0);
         FF_VMCNT0();
         __syncthreads();
-        for (int kt = 0; kt < (ABL == 2 ? 0 : 8); ++kt) {
+        for (int kt = 0; kt < (VKN_ABL_IS(ABL, 2) ? 0 : 8); ++kt) {
             const int cur = kt & 1;
             const bool more = (kt + 1 < 8);
             if (more) FF_DMA(w2t + (size_t)(kt + 1) * GS_WTILE, cur ^ 1);
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void k_ffn_fused(const float* __rest
                     FF_MFMA6(acc2, ah, am, al, bp);
                 }
             }
-            if (ABL != 1) FF_VMCNT0();
+            if (!VKN_ABL_IS(ABL, 1)) FF_VMCNT0();
             __syncthreads();
         }
     }
@@ -1450,7 +1450,7 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
             const int y = min(max(yb0 - 1 + r, 0), H - 1);
             float v[NTAP];
 #pragma unroll
-            for (int i = 0; i < NTAP; ++i) v[i] = (NT == 2) ? (float)(y + cx[i]) : (NT == 3) ? __builtin_nontemporal_load(ip + (size_t)y * W + cx[i]) : ip[(size_t)y * W + cx[i]];  // NT == 2: write-only ablation, 3: nontemporal input loads (debug A/B)
+            for (int i = 0; i < NTAP; ++i) v[i] = VKN_ABL_IS(NT, 2) ? (float)(y + cx[i]) : VKN_ABL_IS(NT, 3) ? __builtin_nontemporal_load(ip + (size_t)y * W + cx[i]) : ip[(size_t)y * W + cx[i]];  // NT == 2: write-only ablation, 3: nontemporal input loads (debug A/B)
             hinterp(v, hrow[r]);
         }
         // NT == 4: ALL input rows of the workgroup are requested up front — no load sits between store bursts
@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
                 for (int r = 0; r < UP_ROWS; ++r) {
                     const int y = min(yb + UP_ROWS + 1 + r, H - 1);
 #pragma unroll
-                    for (int i = 0; i < NTAP; ++i) nv[r][i] = (NT == 2) ? (float)(y + cx[i]) : (NT == 3) ? __builtin_nontemporal_load(ip + (size_t)y * W + cx[i]) : ip[(size_t)y * W + cx[i]];
+                    for (int i = 0; i < NTAP; ++i) nv[r][i] = VKN_ABL_IS(NT, 2) ? (float)(y + cx[i]) : VKN_ABL_IS(NT, 3) ? __builtin_nontemporal_load(ip + (size_t)y * W + cx[i]) : ip[(size_t)y * W + cx[i]];
                 }
             }
             // vertical blend + store: output rows S * yb .. S * (yb + UP_ROWS) - 1

@@ -167,6 +167,13 @@ class BucketedGradAllReducer:
 
     def _launch(self, b):
         self._flush(b)
+        # members without a gradient in this step (`zero_grad(set_to_none=True)` and no use): their slots of the flat buffer still
+        # hold a previous step's averaged gradient — they must contribute ZERO to the sum, as DDP's unused parameters do.
+        # Parameter usage is expected to be the same on every rank (the launch points are learned per rank: rank-divergent usage
+        # would order the collectives differently); with identical usage this zeroing is what keeps the slot clean everywhere.
+        stale = [v for p, v in zip(b['params'], b['views']) if p.grad is None]
+        if stale:
+            torch._foreach_zero_(stale)
         b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _make_hook(self, b, i):
@@ -244,7 +251,7 @@ class BucketedGradAllReducer:
             late = []
             for p, v in zip(b['params'], b['views']):
                 # `p.grad is None`: the parameter took no part in this step after a set_to_none zero_grad — it stays None (the
-                # optimizer skips it; whatever its slot of the flat buffer holds is reduced along and never read)
+                # optimizer skips it; its slot of the flat buffer is zeroed before the reduction, see _launch)
                 if p.grad is not None and p.grad is not v and p.grad.data_ptr() != v.data_ptr():
                     if b['handle'] is not None:   # a gradient assigned behind the hooks' back
                         raise RuntimeError(f"BucketedGradAllReducer: bucket '{b['key']}' was reduced without a member's gradient")

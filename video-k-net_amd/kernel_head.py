@@ -240,6 +240,8 @@ class ConvKernelHead(nn.Module):
             sampling_results.append(self.sampler.sample(assign_result, scaled_mask_preds[i], gt_masks[i]))
         mask_targets = self._targets(sampling_results, self.train_cfg, True, gt_sem_seg, gt_sem_cls)
         losses = self.loss(scaled_mask_preds, cls_scores, scaled_seg_preds, proposal_feats, *mask_targets)
+        if hasattr(self.assigner, 'check_status'):
+            self.assigner.check_status(wait=False)     # device LSAP status words -> the asynchronous flag queue (no stall)
         if self.cat_stuff_mask and self.training:
             mask_preds = torch.cat([mask_preds, seg_preds[:, self.num_thing_classes:]], dim=1)
             stuff_kernels = self.conv_seg.weight[self.num_thing_classes:].clone()

@@ -112,6 +112,16 @@ class _ChainGraphRunner:
         self.used = [(p, g) for p, g in zip(self.params, pg) if g is not None]      # parameters the chain really uses
         self.in_flight = False        # a forward whose backward has not run yet
 
+    def _unalias(self):
+        """Before a backward replay overwrites the static gradient buffers: a parameter whose `.grad` still IS its buffer (handed
+        over by the previous `_deliver` and neither consumed nor replaced since — `zero_grad(set_to_none=False)`, or a second
+        micro-batch of gradient accumulation) gets a private copy, so that the replay cannot overwrite the accumulated value and
+        `_deliver` never adds a buffer to itself.  The usual loops (`set_to_none=True`, the bucketed reducer) never
+        take this branch."""
+        for p, g in self.used:
+            if p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                p.grad = g.clone()
+
     def _deliver(self):
         fresh = [(p, g) for p, g in self.used if p.grad is None]
         more = [(p, g) for p, g in self.used if p.grad is not None]
@@ -148,6 +158,7 @@ class _ChainGraphFn(torch.autograd.Function):
                     st.zero_()
                 elif st.data_ptr() != g.data_ptr():
                     st.copy_(g)
+        r._unalias()
         r.bwd.replay()
         r.in_flight = False
         r._deliver()

@@ -6,6 +6,8 @@ shortest-augmenting-path solver (`vkn_lsap_f32`, the algorithm scipy uses) — s
 Supported: the costs every shipped config uses — `FocalLossCost` (mmdet 2.18 defaults), `DiceCost(pred_act=True)`,
 `MaskCost(pred_act=True)`, `topk=1`, no boundary cost.  Anything else raises NotImplementedError.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -40,7 +42,12 @@ class _AsyncFlags:
         ev = torch.cuda.Event()
         ev.record()
         self.items.append((ev, host, message))
-        del self.items[:-256]
+        if len(self.items) > 256:            # never drop an unread flag silently: read the oldest ones now (their events are long done)
+            old, self.items = self.items[:-256], self.items[-256:]
+            for ev_o, host_o, msg_o in old:
+                ev_o.synchronize()
+                if int(host_o) != 0:
+                    raise (IndexError if 'gt_labels' in msg_o else ValueError)(msg_o)
 
     def poll(self, wait=False):
         keep, bad = [], None
@@ -117,16 +124,21 @@ class MaskHungarianAssigner:
                 lo, hi = int(t.min()), int(t.max())
                 if lo < 0 or hi >= ncls:
                     raise IndexError(f'gt_labels outside [0, {ncls}): {lo} .. {hi}')
-            cls._validated[cls._label_key(t, ncls)] = True
+            cls._validated[cls._label_key(t, ncls)] = weakref.ref(t)    # identity, not address: a recycled allocation must not match
         if dev_bad:
             FLAGS.push(torch.stack(dev_bad).any(), f'gt_labels outside [0, {ncls})')
 
     _validated = {}
 
+    @classmethod
+    def _is_validated(cls, t, ncls):
+        r = cls._validated.get(cls._label_key(t, ncls)) if torch.is_tensor(t) else None
+        return r is not None and r() is t
+
     def cost_matrix(self, bbox_pred, cls_pred, gt_bboxes, gt_labels):
         """[N, G] device tensor: cls_cost + mask_cost + dice_cost (reference :222-241)."""
         use_cls = self.cls['weight'] != 0 and cls_pred is not None
-        checked = use_cls and torch.is_tensor(gt_labels) and self._label_key(gt_labels, cls_pred.shape[1]) in self._validated
+        checked = use_cls and self._is_validated(gt_labels, cls_pred.shape[1])
         return ops.assign_costs(bbox_pred, cls_pred if use_cls else None, gt_bboxes, gt_labels, labels_checked=checked,
                                 cls_weight=self.cls['weight'] if use_cls else 0.0, dice_weight=self.dice['weight'],
                                 mask_weight=self.mask['weight'], focal_alpha=self.cls['alpha'], focal_gamma=self.cls['gamma'],
@@ -154,8 +166,7 @@ class MaskHungarianAssigner:
             res = AssignResult(num_gts, gt_inds, None, labels=labels)
             res.device_pos_inds = rows                        # sorted; their number min(N, G) is known without asking the device
             res.status = status
-            self.pending_status.append(status)
-            del self.pending_status[:-64]
+            self._remember(status)
             return res
         rows, cols = ops.lsap(cost)                       # one D2H copy of [N, G] floats, C++ solver on the host
         rows_host = rows
@@ -179,7 +190,7 @@ class MaskHungarianAssigner:
                                 img_meta=img_metas[i] if img_metas is not None else None) for i in range(n)]
         use_cls = self.cls['weight'] != 0 and all(c is not None for c in cls_preds)
         same = len({p.shape for p in bbox_preds}) == 1 and (not use_cls or len({c.shape for c in cls_preds}) == 1)
-        checked = not use_cls or all(torch.is_tensor(l) and self._label_key(l, cls_preds[0].shape[1]) in self._validated for l in gt_labels)
+        checked = not use_cls or all(self._is_validated(l, cls_preds[0].shape[1]) for l in gt_labels)
         if same and checked and (use_cls or all(c is None for c in cls_preds) or self.cls['weight'] == 0):
             # every image's cost matrix from ONE C call (the labels were range-checked by validate_labels)
             costs = ops.assign_costs_batch(bbox_preds, cls_preds if use_cls else None, gt_bboxes, gt_labels,
@@ -190,8 +201,7 @@ class MaskHungarianAssigner:
         else:
             costs = [self.cost_matrix(bbox_preds[i], cls_preds[i], gt_bboxes[i], gt_labels[i]) for i in range(n)]
         gts, rows, cols, status = ops.lsap_device(costs)
-        self.pending_status.append(status)
-        del self.pending_status[:-64]
+        self._remember(status)
         out = []
         for i in range(n):
             r, c = rows[i].long(), cols[i].long()
@@ -201,6 +211,14 @@ class MaskHungarianAssigner:
             res.device_pos_inds, res.status = r, status
             out.append(res)
         return out
+
+    def _remember(self, status):
+        """Queue a device status tensor for the next `check_status`.  The list is bounded by FOLDING the oldest entries into one
+        `any()` word, never by dropping them: a head that polls rarely still sees every failure."""
+        self.pending_status.append(status)
+        if len(self.pending_status) > 64:
+            head, self.pending_status = self.pending_status[:-32], self.pending_status[-32:]
+            self.pending_status.insert(0, torch.cat([h.reshape(-1) for h in head]).any().to(torch.int32).reshape(1))
 
     def check_status(self, *others, wait=True):
         """Hand the status words of the device assignments issued since the last call by this assigner (and `others`: the per-stage

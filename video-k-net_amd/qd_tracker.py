@@ -116,8 +116,35 @@ class QuasiDenseEmbedTracker:
         host = self._tail.cpu()                                           # ONE small copy: ids + count + status
         k, status = (int(v) for v in host[self.max_dets:].view(torch.int32)[:2])
         if status & 1:
-            raise RuntimeError(f'QuasiDenseEmbedTracker: more than max_tracklets = {self.max_tracklets} live tracks')
+            # reported for THIS frame only (the device state has already advanced: the dropped birth's id is consumed); later
+            # frames run normally.  The reference has no cap — raise max_tracklets if this fires.
+            raise RuntimeError(f'QuasiDenseEmbedTracker: more than max_tracklets = {self.max_tracklets} live tracks in frame '
+                               f'{int(frame_id)}: a birth was dropped')
         return out_b[:k], out_l[:k].to(labels.dtype), host[:k].clone()
+
+    # ------------------------------------------------------------------ the reference's memo surface (host-side views)
+    @property
+    def memo(self):
+        """The reference's `memo` property (:105-135) as a HOST snapshot: dict(bboxes, labels, embeds, ids, vs) over the tracklets in
+        creation order followed by the backdrops (ids -1) — what `match` scores detections against.  Introspection only: the match
+        kernel reads the device-resident table, never this copy."""
+        tr, bd = self.tracklets, self.backdrops
+        E = self._cfg.embed_dim if self._cfg is not None else 0
+        boxes = [t['bbox'][None] for t in tr.values()] + [b['bboxes'] for b in bd]
+        embs = [t['embed'][None] for t in tr.values()] + [b['embeds'] for b in bd]
+        labs = [torch.tensor([t['label']]) for t in tr.values()] + [b['labels'].long() for b in bd]
+        nb = sum(int(b['bboxes'].shape[0]) for b in bd)
+        ids = torch.tensor(list(tr.keys()) + [-1] * nb, dtype=torch.long)
+        vs = [t['velocity'][None] for t in tr.values()] + [torch.zeros(nb, 5)]
+        cat = lambda xs, shape: torch.cat(xs) if xs else torch.zeros(shape)
+        return dict(bboxes=cat(boxes, (0, 5)), labels=cat(labs, (0,)).long(), embeds=cat(embs, (0, E)), ids=ids,
+                    vs=cat(vs, (0, 5)))
+
+    def update_memo(self, ids, bboxes, embeds, labels, frame_id):
+        """The reference's host-side memo update (:47-103) is part of `vkn_qd_tracker_match_f32` here (births, momentum embeddings,
+        velocities, backdrops and expiry happen inside the match kernel, on the device table).  Calling it separately would apply
+        the update twice."""
+        raise NotImplementedError('update_memo is fused into match(): the memo lives in the device state buffer')
 
     # ------------------------------------------------------------------ introspection (host copies; not on the hot path)
     def _view(self, idx, dtype, shape):
