@@ -59,6 +59,9 @@ extern "C" {
 #define VKN_X_BF16 2
 #define VKN_FLAG_X_F16 64u    /* x is [B][C][H*W] fp16 */
 #define VKN_FLAG_X_BF16 128u  /* x is [B][C][H*W] bf16 */
+#define VKN_FLAG_CHAIN_LAUNCHES 256u /* the [N x C] chain as one launch per GEMM (k_gemm_s3 ...) instead of the two persistent row-owner
+                                    * kernels (k_chain_a / k_chain_c); A/B and the path of every shape the latter do not cover.  Same
+                                    * arithmetic (bf16x3 MFMA, fp32 LayerNorm), different summation order: agrees to fp32 rounding */
 #define VKN_FLAG_SERIAL_LINK 32u   /* vkn_head_forward_f32: run the tracking link on the caller's stream instead of the library's side
                                     * stream (A/B, or callers that must see ONE stream; same results) */
 #define VKN_FLAG_CLIP_LINK 8u      /* vkn_head_forward_f32: the B frames are CONSECUTIVE frames of one video: prev_obj is [1][N][C] (the

@@ -843,6 +843,49 @@ def test_stage_attention_head_widths_and_key_blocks_vs_oracle(vkn, C, heads, N):
     assert maxabs(m0, t0['new_mask_preds']) < TOL_LOGIT and maxabs(cls0, t0['cls_score']) < 1e-4
 
 
+@pytest.mark.parametrize('B,N,ff,ncls,video', [(1, 117, 2048, 19, 0), (3, 117, 2048, 19, 1), (2, 166, 1024, 124, 0), (5, 20, 512, 40, 0),
+                                                (1, 32, 256, 3, 0), (8, 100, 2048, 40, 1)])
+def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, video):
+    """The [N x C] chain as two persistent row-owner kernels (k_chain_a / k_chain_c, the default at C = 256) against the same chain as
+    one launch per GEMM (VKN_FLAG_CHAIN_LAUNCHES) and against the exact-fp32 GEMM chain (VKN_FLAG_EXACT_GEMM): one stage, same
+    inputs — ragged last row tile (B*N % 32 != 0), one / many workgroups, 1 .. 8 hidden chunks, class counts below and above one
+    column block, with and without the video link.  Same bf16x3 arithmetic, different summation order: fp32 rounding apart."""
+    from test_host_logic import _cfg
+    C, heads, H, W = 256, 8, 8, 16
+    n_stuff = 11 if (N > 11 and ncls > 11) else 1
+    kw = dict(C=C, heads=heads, ffn=ff, ncls=ncls, n_thing=ncls - n_stuff, n_stuff=n_stuff, S=1, up=1, nprop=N - n_stuff)
+    case = dict(kw, N=N, H=H, W=W, B=B, seed=700 + B + N, video=video)
+    head = vkn.build_head(_cfg(bool(video), **kw))
+    cfg, sd, x, pf, mp, prev = make_case(case)
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV).eval()
+    dims = head.mask_head[0].make_dims(B, N, H, W)
+    pack = head.mask_head[0].stage_pack(torch.device(DEV))
+    args = (dims, pack, x.to(DEV), pf.reshape(B, N, C).to(DEV), mp.to(DEV))
+    kwd = dict(prev_obj=prev.reshape(B, N, C).to(DEV), want_track=True) if video else {}
+    new = vkn.ops.stage_forward(*args, **kwd)
+    old = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_CHAIN_LAUNCHES, **kwd)
+    exact = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_EXACT_GEMM, **kwd)
+    names = ('cls', 'masks', 'obj', 'x_feat', 'track')
+    for nm, a, b, e in zip(names, new, old, exact):
+        if a is None:
+            assert b is None
+            continue
+        scale = max(1.0, float(e.abs().max()))
+        d_old, d_exact, d_base = maxabs(a, b), maxabs(a, e), maxabs(b, e)
+        assert torch.isfinite(a).all(), nm
+        # the two bf16x3 chains sit equally close to the exact-fp32 chain (both ~1e-6 on O(1) values)
+        assert d_old < 2e-5 * scale and d_exact < 2e-5 * scale, (nm, d_old, d_exact, d_base, scale)
+    with torch.no_grad():
+        traces = []
+        O.iter_head_mask_preds(sd, x, pf, mp, cfg, traces=traces, **(dict(previous_obj_feats=prev) if video else {}))
+    t0 = traces[0]
+    assert maxabs(new[2], t0['obj_feat'].reshape(B, N, C)) < 2e-4
+    assert maxabs(new[1], t0['new_mask_preds']) < TOL_LOGIT and maxabs(new[0], t0['cls_score']) < 1e-4
+    again = vkn.ops.stage_forward(*args, **kwd)
+    assert all(a is None or torch.equal(a, b) for a, b in zip(new, again)), 'deterministic'
+
+
 # ------------------------------------------------------------------------------------------ train-time assignment
 @pytest.mark.parametrize('name', ['assign_tiny', 'assign_cfg', 'assign_odd'])
 def test_assignment_vs_reference(vkn, name):

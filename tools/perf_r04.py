@@ -1,0 +1,66 @@
+"""Round-4 measurements of the [N x C] chain: the persistent row-owner kernels (k_chain_a + attention + k_chain_c, default) against
+the launch-per-GEMM chain (VKN_FLAG_CHAIN_LAUNCHES), chain alone (`vkn_stage_chain_f32`: x_feat in, decode kernels out) and whole
+head steps, at several frames per call.   python tools/perf_r04.py [--what chain|head|all]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import vkn_import  # noqa: E402
+
+vkn = vkn_import.load()
+DEV = 'cuda:0'
+
+
+def timeit(fn, iters=50, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--what', default='all')
+    args = ap.parse_args()
+    N, C, H, W = 117, 256, 128, 256
+    cfg = vkn.configs.roi_head_cfg(True, C=C, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100)
+    head = vkn.build_head(cfg)
+    torch.manual_seed(0)
+    head.init_weights()
+    head = head.to(DEV).eval()
+    g = torch.Generator(device='cpu').manual_seed(1)
+    if args.what in ('chain', 'all'):
+        print('== chain alone (vkn_stage_chain_f32), us per stage ==')
+        for B in (1, 2, 4, 8, 16, 32, 64):
+            dims = head.mask_head[0].make_dims(B, N, H, W)
+            pack = head.mask_head[0].stage_pack(torch.device(DEV))
+            xf = (torch.randn(B, N, C, generator=g) * 50).to(DEV)
+            ob = torch.randn(B, N, C, generator=g).to(DEV)
+            t_new = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob))
+            t_old = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob, flags=vkn.ops.FLAG_CHAIN_LAUNCHES))
+            print(f'B={B:3d} rows={B * N:5d}  persistent {t_new:8.1f}   launch-per-GEMM {t_old:8.1f}   ratio {t_old / t_new:5.2f}')
+    if args.what in ('head', 'all'):
+        print('== whole head step (3 stages + link + x4 upsample), ms per call ==')
+        for B in (1, 8, 32):
+            x = torch.randn(B, C, H, W, generator=g).to(DEV)
+            pf = torch.randn(B, N, C, 1, 1, generator=g).to(DEV)
+            mp = (torch.randn(B, N, H, W, generator=g) * 4).to(DEV)
+            prev = torch.randn(B, N, C, 1, 1, generator=g).to(DEV)
+            for nm, fl in (('persistent', 0), ('launch-per-GEMM', vkn.ops.FLAG_CHAIN_LAUNCHES)):
+                with torch.no_grad():
+                    t = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True, flags=fl), iters=30, warm=5)
+                print(f'B={B:3d} {nm:16s} {t / 1e3:8.3f} ms  -> {B / t * 1e6:8.1f} frames/s')
+
+
+if __name__ == '__main__':
+    main()

@@ -33,7 +33,7 @@ def short(n):
             import re
             m = re.search(r'k_fused_ilILi(\d+)ELi(\d+)ELi(\d+)E', n)
             return 'k_fused_il<x16>' if (m and m.group(3) != '0') else 'k_fused_il'
-        for key in ('k_split_planes', 'k_gemm_s3', 'k_fused_dgs', 'k_fused_il', 'k_ffn_fused', 'k_gather_bits_w', 'k_attn_long', 'k_attn_mfma', 'k_attn', 'k_rowepi', 'k_gather_reduce', 'k_upsample_s', 'k_gather_mfma'):
+        for key in ('k_chain_a', 'k_chain_c', 'k_split_planes', 'k_gemm_s3', 'k_fused_dgs', 'k_fused_il', 'k_ffn_fused', 'k_gather_bits_w', 'k_attn_long', 'k_attn_mfma', 'k_attn', 'k_rowepi', 'k_gather_reduce', 'k_upsample_s', 'k_gather_mfma'):
             if key in n:
                 return key
     import re

@@ -347,6 +347,63 @@ int final_decode(const VknDims* d, const float* x, const StageWs& s, const float
     return VKN_OK;
 }
 
+// The persistent row-owner chain (vkn_chain.hip) covers the shipped shape: C == 256, one cls / mask FC, an FFN whose width is a
+// multiple of 256 (<= 2048), composite (feat_transform-folded) pre-split weights.  Everything else — and VKN_FLAG_CHAIN_LAUNCHES
+// (A/B) — takes the launch-per-GEMM path below.
+inline unsigned pw_off(const VknStageWeights* w, const void* p) {
+    return (unsigned)(static_cast<const char*>(p) - static_cast<const char*>(w->prepared));
+}
+bool chain_fast_ok(const VknDims* d, const VknStageWeights* w, const PrepW& pw, unsigned flags, bool have_cls) {
+    if (flags & (VKN_FLAG_CHAIN_LAUNCHES | VKN_FLAG_EXACT_GEMM)) return false;
+    if (vkn_dbg_env("VKN_CHAIN_LAUNCHES", 0)) return false;
+    if (d->C != 256 || d->n_cls_fcs != 1 || d->n_mask_fcs != 1 || d->ff % 256 != 0 || d->ff > 2048) return false;
+    if (!w->prepared || w->prepared_bytes >= (1ull << 31)) return false;
+    if (!pw.dynft || !pw.dyn || !pw.dec || !pw.inp || !pw.ig || !pw.ug || !pw.fc || !pw.attn_in || !pw.attn_out || !pw.ffn1 ||
+        !pw.ffn2 || !pw.cls_fc[0] || !pw.mask_fc[0])
+        return false;
+    if (have_cls && !pw.fc_cls) return false;
+    if (!w->ffn1_w || !w->cls_ln_w[0] || !w->mask_ln_w[0]) return false;
+    return true;
+}
+
+// (ii) + the FC branches as three launches: k_chain_a, the attention, k_chain_c.  `a0` / `rowscale`: the raw gather + pixel counts
+// (composite dynamic weights) or x_feat (rowscale NULL).  The decode kernels leave as f16 planes (s.kfh / s.kfl) or as fp32 (kern32_out).
+int run_chain_fast(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* a0, bool a0_raw, const float* cnt,
+                   const float* obj_in, float* obj_out, float* cls_logits, bool cls_sigmoid, float* kern32_out, const StageWs& s,
+                   hipStream_t st) {
+    const int M = d->B * d->N, C = d->C;
+    VknChainA a{};
+    a.a0 = a0; a.obj_in = obj_in; a.rowscale = a0_raw ? cnt : nullptr;
+    a.wbase = w->prepared; a.wbytes = w->prepared_bytes;
+    a.off_dyn = pw_off(w, a0_raw ? pw.dynft : pw.dyn);
+    a.off_inp = pw_off(w, pw.inp); a.off_ig = pw_off(w, pw.ig); a.off_ug = pw_off(w, pw.ug); a.off_fc = pw_off(w, pw.fc);
+    a.off_in = pw_off(w, pw.attn_in);
+    a.dyn_bias = a0_raw ? pw.bcnt : w->dyn_b; a.dyn_bias2 = a0_raw ? w->dyn_b : nullptr;
+    a.norm_out_w = w->norm_out_w; a.norm_out_b = w->norm_out_b; a.inp_b = w->inp_b;
+    a.inorm_out_w = w->inorm_out_w; a.inorm_out_b = w->inorm_out_b;
+    a.ig_b = w->ig_b; a.inorm_in_w = w->inorm_in_w; a.inorm_in_b = w->inorm_in_b;
+    a.ug_b = w->ug_b; a.norm_in_w = w->norm_in_w; a.norm_in_b = w->norm_in_b;
+    a.fc_b = w->fc_b; a.fc_norm_w = w->fc_norm_w; a.fc_norm_b = w->fc_norm_b; a.in_b = w->attn_in_b;
+    a.eps = d->ln_eps; a.M = M; a.obj1 = s.obj1; a.qkv = s.qkv;
+    VKN_TRY(vkn_launch_chain_a(a, st));
+    VKN_TRY(vkn_launch_attn(s.qkv, 3 * C, s.qkv + C, s.qkv + 2 * C, 3 * C, s.ao, C, d->B, d->N, d->N, d->heads, C / d->heads, st));
+    VknChainC c{};
+    c.ao = s.ao; c.obj1 = s.obj1; c.wbase = w->prepared; c.wbytes = w->prepared_bytes;
+    c.off_out = pw_off(w, pw.attn_out); c.off_ffn1 = pw_off(w, pw.ffn1); c.off_ffn2 = pw_off(w, pw.ffn2);
+    c.off_clsfc = pw_off(w, pw.cls_fc[0]); c.off_maskfc = pw_off(w, pw.mask_fc[0]);
+    c.off_fccls = pw.fc_cls ? pw_off(w, pw.fc_cls) : 0u; c.off_dec = pw_off(w, pw.dec);
+    c.out_b = w->attn_out_b; c.attn_norm_w = w->attn_norm_w; c.attn_norm_b = w->attn_norm_b;
+    c.ffn1_b = w->ffn1_b; c.ffn2_b = w->ffn2_b; c.ffn_norm_w = w->ffn_norm_w; c.ffn_norm_b = w->ffn_norm_b;
+    c.cls_ln_w = w->cls_ln_w[0]; c.cls_ln_b = w->cls_ln_b[0]; c.mask_ln_w = w->mask_ln_w[0]; c.mask_ln_b = w->mask_ln_b[0];
+    c.dvec = pw.dvec; c.kb0 = pw.kb0; c.fc_cls_b = w->fc_cls_b; c.dec_b = pw.decb;
+    c.ff = d->ff; c.ncls = d->ncls; c.cls_sigmoid = cls_sigmoid ? 1 : 0; c.eps = d->ln_eps; c.M = M;
+    c.obj_out = obj_out; c.cls_out = (w->fc_cls_w && cls_logits) ? cls_logits : nullptr; c.kb_out = s.kb;
+    if (kern32_out) c.kern_out = kern32_out;
+    else { c.plane_hi = s.kfh; c.plane_lo = s.kfl; }
+    c.rows_per_frame = d->N; c.NPT = npt_of(d->N);
+    return vkn_launch_chain_c(c, st);
+}
+
 int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in, const float* masks_in,
               const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out, float* x_feat_out,
               float* track_out, const StageWs& s, unsigned flags, hipStream_t st, const unsigned* bits_in = nullptr,
@@ -419,6 +476,35 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         obj_in = s.lobj;
     }
 
+    const float* kb = has_ft ? s.kb : nullptr;
+    const bool fast = comp && chain_fast_ok(d, w, pw, flags, w->fc_cls_w && cls_logits);
+    if (fast) {
+        // (ii) + FC branches: k_chain_a -> attention -> k_chain_c (vkn_chain.hip); obj_out, cls, kb and the decode kernels are final
+        const bool raw = !xfeat_in;
+        VKN_TRY(run_chain_fast(d, w, pw, raw ? s.xraw : xfeat, raw, s.cnt, obj_in, obj_out, cls_logits, cls_sigmoid,
+                               ref_decode ? (chain_only ? kern_out : s.kern32) : nullptr, s, st));
+        if (obj_ready && hipEventRecord(obj_ready, st) != hipSuccess) return VKN_E_LAUNCH;
+        if (chain_only) {
+            if (kb_out && hipMemcpyAsync(kb_out, s.kb, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return VKN_E_LAUNCH;
+        } else if (skip_decode) {
+        } else if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
+        else if (gather_out)
+            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt));
+        else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
+        else VKN_TRY(decode_final(kb));
+        if (prev_obj && track_out) {
+            if (so && so->link_track) {
+                PrepW pt;
+                VKN_TRY(carve_pw(d, so->link_track, flags, &pt));
+                VKN_TRY(run_link(d, so->link_track, pt, obj_out, prev_obj, track_out, s, st, so->track_src == 2 ? obj_out : xfeat));
+            } else {
+                VKN_TRY(run_link(d, w, pw, obj_out, prev_obj, track_out, s, st));
+            }
+        }
+        return VKN_OK;
+    }
+
     // (ii-a) KernelUpdator                                    knet/kernel_updator.py:56-93
     VKN_TRY(run_updator(d, w, pw, xfeat, (comp && !xfeat_in) ? s.xraw : nullptr, s.cnt, obj_in, s.obj1, s, st));
 
@@ -463,7 +549,6 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         }
         VKN_TRY(vkn_launch_gemm_group(pr, np, M, C, 1, nullptr, st));
     }
-    const float* kb = has_ft ? s.kb : nullptr;
     if (comp) {
         // fc_cls, and the decode kernels Kf = fc_mask(.) . W_ft in ONE GEMM from the composite weight          (:221, :227, :247)
         VknGemmProb pr[2];

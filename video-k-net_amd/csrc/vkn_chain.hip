@@ -1,0 +1,734 @@
+// vkn_chain.hip — the [B*N, C] "kernel update + interaction" chain of one stage as TWO persistent row-owner kernels around the
+// attention (C == 256, the shipped shape).  Replaces the ten k_gemm_s3 / k_ffn_fused / k_rowepi launches per stage of vkn_update.hip
+// on the fast path; that file keeps the generic path (any C, exact-fp32 GEMMs, split-K) and the link blocks.
+//
+// Covers (reference file:line):
+//   KernelUpdator.forward                      knet/kernel_updator.py:56-93                 -> k_chain_a (+ in_proj of the attention)
+//   attention_norm(attention(obj))             knet/det/kernel_update_head.py:204-208       in_proj: k_chain_a; softmax(QK^T)V: k_attn_mfma;
+//                                                                                           out_proj + residual + LayerNorm: k_chain_c
+//   ffn_norm(ffn(obj))                         knet/det/kernel_update_head.py:214-215       -> k_chain_c
+//   cls_fcs / fc_cls / mask_fcs / fc_mask      knet/det/kernel_update_head.py:217-227       -> k_chain_c (fc_mask folded with feat_transform)
+//
+// Design (DESIGN.md §5 "chain"):
+//   * A workgroup (8 waves) OWNS 32 rows (kernels) for the whole launch.  Activations never leave the CU between GEMMs: they live in
+//     LDS as bf16x3 "images" [plane 3][row 32][k 256] (16-byte chunk j of row r stored at chunk j ^ r: conflict-free ds_read_b128) and,
+//     where a later epilogue needs them elementwise, in registers.
+//   * Weights are the pre-split bf16x3 tile images of vkn_prepare_stage_f32 ([plane][q][row 256][8] per 256-col x 32-k tile = already
+//     the MFMA fragment layout).  Wave w is the only consumer of column block w, so every wave streams ITS six fragments per K-tile
+//     straight from global memory (L2 / MALL resident: 12 MB per stage, read by all workgroups in near lock-step) into a 4-deep
+//     register ring with buffer loads — no LDS traffic for weights, no barrier inside a GEMM, and the stream never stops: the ring is
+//     refilled with the NEXT GEMM's first tiles while the current epilogue runs (the address sequence is static).
+//   * MFMA operand roles are swapped against k_gemm_s3: D^T = W . A^T, i.e. the weight fragment is the first operand and the
+//     activation fragment the second.  A lane then owns ONE activation row (lane & 31) and sixteen output columns in four groups of four
+//     consecutive columns: LayerNorm needs a 16-value in-lane sum + one exchange of 16 partials per row through 2 KB of LDS (no
+//     output tile round trip, no per-row wave reductions), every elementwise combination of the updator (gates, mix) is a register
+//     operation, image writes are 8-byte packed stores and global stores are float4.
+//   * Six significant cross products of the bf16x3 split per operand pair, fp32 accumulation, smallest terms first — the arithmetic
+//     of k_gemm_s3 (2^-24 relative); LayerNorm two-pass in fp32.  Summation order differs from the launch-per-GEMM path (the
+//     LayerNorm partials, the FFN's hidden chunks in sequence instead of four split sums): results agree to fp32 rounding, not bit
+//     for bit; everything is deterministic.
+#include "vkn_common.h"
+#include "vkn_launch.h"
+
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
+
+#define CH_THREADS 512
+#define CH_ROWS 32
+#define CH_C 256
+#define CH_WTILE 49152u                 // bytes of one weight tile image (256 cols x 32 k x 3 planes bf16)
+#define CH_IMG (3 * CH_ROWS * CH_C)     // bf16 elements of one activation image (48 KB)
+#define CH_PLANE (CH_ROWS * CH_C)       // bf16 elements of one plane of an image
+#define CH_SBUF (2 * 16 * 32)           // floats of one row-statistics exchange buffer: [value 2][partial 16][row 32]
+
+// this wave's LDS operations are done + workgroup barrier, as ONE asm statement: behind a __syncthreads() hipcc strengthens the wait
+// to vmcnt(0) (workgroup release fence), which would drain the weight ring at every epilogue
+#define CH_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+namespace {
+
+__device__ __forceinline__ void ch_split3(float v, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+// lane coordinates of a workgroup thread
+struct ChLane {
+    int wave, g, li;
+    unsigned woff;   // byte offset of this lane's fragment inside a weight tile image: plane 0, ks 0
+    unsigned abase;  // byte offset of this lane's activation fragment inside an image plane for chunk pair 0: row li, 16-byte chunk
+                     // (g ^ li); the fragment of (kt, ks) is at abase ^ ((4 kt + 2 ks) << 4) — the swizzle is an XOR of chunk bits
+};
+__device__ __forceinline__ ChLane ch_lane(int tid) {
+    ChLane L;
+    const int lane = tid & 63;
+    L.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    L.g = lane >> 5;
+    L.li = lane & 31;
+    L.woff = (unsigned)(L.g * 4096 + (L.wave * 32 + L.li) * 16);
+    L.abase = (unsigned)(L.li * (CH_C * 2) + (((L.g ^ L.li) & 31) << 4));
+    return L;
+}
+
+struct ChRing {
+    cu32x4 r[4][6];  // [slot][ks * 3 + plane]
+};
+
+// the six fragments (2 k-steps x 3 planes) of this wave's column block of the tile at byte offset `toff` of the weight buffer
+__device__ __forceinline__ void ch_wload(ChRing& R, const int slot, const __amdgpu_buffer_rsrc_t wrs, const ChLane& L, unsigned toff) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            R.r[slot][ks * 3 + p] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)L.woff, (int)(toff + (unsigned)((p * 4 + 2 * ks) * 4096)), 0);
+}
+
+// activation fragments (3 planes) of K-tile kt, k-step ks from an image
+__device__ __forceinline__ void ch_afrag(const __bf16* img, const ChLane& L, int kt, int ks, cbf16x8& h, cbf16x8& m, cbf16x8& l) {
+    const char* pb = reinterpret_cast<const char*>(img) + (L.abase ^ (unsigned)(((kt << 2) + (ks << 1)) << 4));
+    const __bf16* p = reinterpret_cast<const __bf16*>(pb);
+    h = *reinterpret_cast<const cbf16x8*>(p);
+    m = *reinterpret_cast<const cbf16x8*>(p + CH_PLANE);
+    l = *reinterpret_cast<const cbf16x8*>(p + 2 * CH_PLANE);
+}
+
+// acc (transposed tile: lane = activation row li, register r = output column 8 (r >> 2) + 4 g + (r & 3) of the wave's block) +=
+// W-fragments (slot) x activation fragments, the six significant products, smallest first
+__device__ __forceinline__ void ch_mfma6(f32x16& acc, const ChRing& R, const int slot, const int ks, const cbf16x8& ah, const cbf16x8& am,
+                                         const cbf16x8& al) {
+    const cbf16x8 wh = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 0]);
+    const cbf16x8 wm = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 1]);
+    const cbf16x8 wl = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 2]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, am, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
+}
+
+// what the ring is refilled with once the current GEMM has no tiles left to request: the first three units of the next GEMM
+struct ChNext {
+    unsigned base0, base1;  // tile-image byte offsets of the next GEMM's accumulator 0 / 1 (column tiles or weights)
+    int nacc;               // 1 or 2; 0 = nothing follows
+    __device__ __forceinline__ unsigned off(int j) const {  // unit j (0..2) of the next GEMM
+        if (nacc == 2) return ((j & 1) ? base1 : base0) + (unsigned)(j >> 1) * CH_WTILE;
+        return base0 + (unsigned)j * CH_WTILE;
+    }
+};
+
+// One GEMM of the chain over K = 256 (8 K-tiles): NACC accumulators (column tiles or independent weights) fed from the unit stream
+//   unit u = kt * NACC + a  ->  tile image at base[a] + kt * CH_WTILE, accumulator a, activation image img[a].
+// The ring slot of unit u is u & 3 (every GEMM has a multiple of four units); on entry units 0..2 are in flight (requested by the
+// previous GEMM's tail or by the kernel prologue), on exit the next GEMM's units 0..2 are.
+template <int NACC, bool SAMEA>
+__device__ __forceinline__ void ch_gemm(f32x16 (&acc)[NACC], const __bf16* img0, const __bf16* img1, unsigned base0, unsigned base1,
+                                        const ChNext nx, ChRing& R, const __amdgpu_buffer_rsrc_t wrs, const ChLane& L) {
+    constexpr int NU = 8 * NACC;
+    cbf16x8 ah[2], am[2], al[2];
+#pragma unroll 1
+    for (int u0 = 0; u0 < NU; u0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = u0 + j;
+            // request unit u + 3 into the slot unit u - 1 has left
+            const int un = u + 3;
+            if (un < NU) {
+                const int an = (NACC == 2) ? (un & 1) : 0, ktn = (NACC == 2) ? (un >> 1) : un;
+                ch_wload(R, (j + 3) & 3, wrs, L, ((NACC == 2 && an) ? base1 : base0) + (unsigned)ktn * CH_WTILE);
+            } else if (nx.nacc) {
+                ch_wload(R, (j + 3) & 3, wrs, L, nx.off(un - NU));
+            }
+            // the request stays HERE, three units ahead of its use: without the fence the machine scheduler sinks every load to just
+            // before its MFMA (load, s_waitcnt vmcnt(0), mfma) to save registers — the whole point of the ring
+            __builtin_amdgcn_sched_barrier(0);
+            const int a = (NACC == 2) ? (j & 1) : 0, kt = (NACC == 2) ? (u >> 1) : u;
+            if (a == 0 || !SAMEA) {
+                const __bf16* img = (a == 0) ? img0 : img1;
+                ch_afrag(img, L, kt, 0, ah[0], am[0], al[0]);
+                ch_afrag(img, L, kt, 1, ah[1], am[1], al[1]);
+            }
+            ch_mfma6(acc[a], R, j, 0, ah[0], am[0], al[0]);
+            ch_mfma6(acc[a], R, j, 1, ah[1], am[1], al[1]);
+        }
+    }
+}
+
+__device__ __forceinline__ void ch_zero(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// this lane's sixteen column constants of a [256]-float vector in LDS (columns wave * 32 + 8 q + 4 g + e)
+__device__ __forceinline__ void ch_cols(const float* vec, const ChLane& L, float (&c)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(vec + L.wave * 32 + 8 * q + 4 * L.g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[4 * q + e] = t[e];
+    }
+}
+
+// sum over the 256 columns of a row for NV per-lane partials: 16 partials per row (8 waves x 2 column halves) through LDS, summed in
+// fixed order by every lane of the row.  One barrier.
+template <int NV>
+__device__ __forceinline__ void ch_rowsum(float (&p)[NV], float* Sbuf, const ChLane& L) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) Sbuf[v * 512 + (L.wave * 2 + L.g) * 32 + L.li] = p[v];
+    CH_BAR();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += Sbuf[v * 512 + k * 32 + L.li];
+        p[v] = s;
+    }
+}
+
+// LayerNorm over the 256 columns of NV independent row sets held in registers (v[i][16]); weights / biases from LDS vectors.
+// Two-pass (mean, centred variance), 1 / sqrtf, as the row epilogue of vkn_update.hip.  Two barriers; `sb` toggles the exchange buffer.
+template <int NV>
+__device__ __forceinline__ void ch_layernorm(float (&v)[NV][16], const float* const (&lw)[NV], const float* const (&lb)[NV], float eps,
+                                             float* S, int& sb, const ChLane& L) {
+    float p[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += v[i][r];
+        p[i] = s;
+    }
+    ch_rowsum<NV>(p, S + sb * CH_SBUF, L);
+    sb ^= 1;
+    float mean[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        mean[i] = p[i] / 256.f;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = v[i][r] - mean[i];
+            s += d * d;
+        }
+        p[i] = s;
+    }
+    ch_rowsum<NV>(p, S + sb * CH_SBUF, L);
+    sb ^= 1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float rstd = 1.0f / sqrtf(p[i] / 256.f + eps);
+        float w[16], b[16];
+        ch_cols(lw[i], L, w);
+        ch_cols(lb[i], L, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[i][r] = (v[i][r] - mean[i]) * rstd * w[r] + b[r];
+    }
+}
+
+// registers (transposed tile) -> bf16x3 image: 8-byte packed stores, chunk (wave * 4 + q) of row li, half g
+__device__ __forceinline__ void ch_img_write(__bf16* img, const float (&v)[16], const ChLane& L) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        cbf16x4 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 hh, mm, ll;
+            ch_split3(v[4 * q + e], hh, mm, ll);
+            h[e] = hh;
+            m[e] = mm;
+            l[e] = ll;
+        }
+        __bf16* d = img + L.li * CH_C + ((((L.wave << 2) + q) ^ L.li) & 31) * 8 + 4 * L.g;
+        *reinterpret_cast<cbf16x4*>(d) = h;
+        *reinterpret_cast<cbf16x4*>(d + CH_PLANE) = m;
+        *reinterpret_cast<cbf16x4*>(d + 2 * CH_PLANE) = l;
+    }
+}
+
+// fp32 rows [M][ld] (32 rows from m0, 256 columns) -> image; rows >= M repeat the last row (never stored)
+__device__ __forceinline__ void ch_img_load(__bf16* img, const float* __restrict__ src, int ld, int m0, int M, int tid) {
+    const int row = tid >> 4, c4 = (tid & 15) << 2;
+    const float* s = src + (size_t)min(m0 + row, M - 1) * ld + c4;
+    f32x4 t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const f32x4*>(s + 64 * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = c4 + 64 * j;
+        cbf16x4 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 hh, mm, ll;
+            ch_split3(t[j][e], hh, mm, ll);
+            h[e] = hh;
+            m[e] = mm;
+            l[e] = ll;
+        }
+        __bf16* d = img + row * CH_C + ((((col >> 3) ^ row) & 31) << 3) + (col & 7);
+        *reinterpret_cast<cbf16x4*>(d) = h;
+        *reinterpret_cast<cbf16x4*>(d + CH_PLANE) = m;
+        *reinterpret_cast<cbf16x4*>(d + 2 * CH_PLANE) = l;
+    }
+}
+
+// registers (transposed tile) -> fp32 rows [M][ld] at column tile offset col0: four float4 stores per lane
+__device__ __forceinline__ void ch_store_rows(float* __restrict__ dst, int ld, int col0, int row, bool ok, const float (&v)[16],
+                                              const ChLane& L) {
+    if (!ok) return;
+    float* d = dst + (size_t)row * ld + col0 + L.wave * 32 + 4 * L.g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(d + 8 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+
+// a lane's sixteen values parked in LDS across a GEMM (register pressure): private slots [q][thread] float4, no barrier needed
+__device__ __forceinline__ void ch_park(float* P, const float (&v)[16], int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(P + (q * CH_THREADS + tid) * 4) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+__device__ __forceinline__ void ch_unpark(const float* P, float (&v)[16], int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(P + (q * CH_THREADS + tid) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+    }
+}
+
+// constant vectors -> LDS: entry i copies n[i] floats from src[i] (NULL: fill with fill[i]) to cst + dst[i]
+#define CH_MAXTAB 20
+struct ChConstTab {
+    const float* src[CH_MAXTAB];
+    short dst[CH_MAXTAB], n[CH_MAXTAB];
+    float fill[CH_MAXTAB];
+    int count;
+};
+__device__ __forceinline__ void ch_stage_consts(float* cst, const ChConstTab& T, int tid) {
+    for (int i = 0; i < T.count; ++i) {
+        const float* s = T.src[i];
+        for (int k = tid; k < T.n[i]; k += CH_THREADS) cst[T.dst[i] + k] = s ? s[k] : T.fill[i];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ kernel A: updator + in_proj
+// LDS constant map of k_chain_a (floats)
+enum {
+    CA_DYN_B = 0,      // [512] dynamic_layer bias (scaled per row by `rowscale` when the folded feat_transform bias is used)
+    CA_DYN_B2 = 512,   // [512] second, unscaled bias (dyn_b beside the folded W_dyn.b_ft) or zeros
+    CA_NO_W = 1024, CA_NO_B = 1280,    // norm_out
+    CA_INP_B = 1536,   // [512]
+    CA_INO_W = 2048, CA_INO_B = 2304,  // input_norm_out
+    CA_IG_B = 2560, CA_INI_W = 2816, CA_INI_B = 3072,   // input_gate bias, input_norm_in
+    CA_UG_B = 3328, CA_NI_W = 3584, CA_NI_B = 3840,     // update_gate bias, norm_in
+    CA_FC_B = 4096, CA_FCN_W = 4352, CA_FCN_B = 4608,   // fc_layer bias, fc_norm
+    CA_IN_B = 4864,    // [768] attention in_proj bias
+    CA_TOTAL = 5632
+};
+
+struct ChainAArgs {
+    const float* a0;        // [M][256] update feature: the raw gather (composite dynamic weights) or x_feat
+    const float* obj_in;    // [M][256] incoming kernels
+    const float* rowscale;  // [M] pixel counts (scale of CA_DYN_B) or NULL
+    const void* wbase;      // prepared weight buffer
+    unsigned wbytes;
+    unsigned off_dyn, off_inp, off_ig, off_ug, off_fc, off_in;  // tile images (byte offsets in wbase)
+    float eps;
+    int M;
+    float* obj1;  // [M][256] out: updated kernels (residual of the attention block)
+    float* qkv;   // [M][768] out: packed q | k | v
+    ChConstTab consts;
+};
+
+__global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_ca[];
+    __bf16* IMG0 = reinterpret_cast<__bf16*>(smem_ca);
+    __bf16* IMG1 = IMG0 + CH_IMG;
+    float* S = reinterpret_cast<float*>(IMG1 + CH_IMG);  // [2][CH_SBUF]
+    float* CST = S + 2 * CH_SBUF;
+    float* PARK = CST + CA_TOTAL;                        // [4][512] float4: parameters_in, later input_out, parked across a GEMM
+
+    const int tid = threadIdx.x;
+    const ChLane L = ch_lane(tid);
+    const int m0 = blockIdx.x * CH_ROWS, M = A.M;
+    const int row = m0 + L.li;
+    const bool row_ok = row < M;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.wbase), 0, (int)A.wbytes, 0x00020000);
+
+    ChRing R;
+    ch_wload(R, 0, wrs, L, A.off_dyn);                    // unit 0: (kt 0, column tile 0)
+    ch_wload(R, 1, wrs, L, A.off_dyn + 8u * CH_WTILE);    // unit 1: (kt 0, column tile 1)
+    ch_wload(R, 2, wrs, L, A.off_dyn + CH_WTILE);         // unit 2: (kt 1, column tile 0)
+    ch_stage_consts(CST, A.consts, tid);
+    ch_img_load(IMG0, A.a0, CH_C, m0, M, tid);
+    ch_img_load(IMG1, A.obj_in, CH_C, m0, M, tid);
+    const float bs = A.rowscale ? A.rowscale[min(row, M - 1)] : 1.f;
+    CH_BAR();
+
+    int sb = 0;
+    f32x16 acc[2];
+    float pout[1][16];
+    // ---- dynamic_layer(update feature): parameters_in | LN(parameters_out)                        knet/kernel_updator.py:59-62, :79
+    ch_zero(acc[0]);
+    ch_zero(acc[1]);
+    ch_gemm<2, true>(acc, IMG0, IMG0, A.off_dyn, A.off_dyn + 8u * CH_WTILE, ChNext{A.off_inp, A.off_inp + 8u * CH_WTILE, 2}, R, wrs, L);
+    {
+        float b[16], b2[16], pin[16];
+        ch_cols(CST + CA_DYN_B, L, b);
+        ch_cols(CST + CA_DYN_B2, L, b2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pin[r] = acc[0][r] + b[r] * bs + b2[r];
+        ch_park(PARK, pin, tid);
+        ch_cols(CST + CA_DYN_B + 256, L, b);
+        ch_cols(CST + CA_DYN_B2 + 256, L, b2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pout[0][r] = acc[1][r] + b[r] * bs + b2[r];
+        const float* const lw[1] = {CST + CA_NO_W};
+        const float* const lb[1] = {CST + CA_NO_B};
+        ch_layernorm<1>(pout, lw, lb, A.eps, S, sb, L);
+    }
+    // ---- input_layer(kernels): input_in | LN(input_out); gate = input_in * parameters_in -> image             :65-70, :80
+    ch_zero(acc[0]);
+    ch_zero(acc[1]);
+    ch_gemm<2, true>(acc, IMG1, IMG1, A.off_inp, A.off_inp + 8u * CH_WTILE, ChNext{A.off_ig, A.off_ug, 2}, R, wrs, L);
+    {
+        float b[16], gate[16], iout[1][16];
+        ch_cols(CST + CA_INP_B, L, b);
+        ch_unpark(PARK, gate, tid);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gate[r] = (acc[0][r] + b[r]) * gate[r];
+        ch_img_write(IMG0, gate, L);   // IMG0 was last read by the first GEMM: every wave is past that epilogue's barriers
+        ch_cols(CST + CA_INP_B + 256, L, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) iout[0][r] = acc[1][r] + b[r];
+        const float* const lw[1] = {CST + CA_INO_W};
+        const float* const lb[1] = {CST + CA_INO_B};
+        ch_layernorm<1>(iout, lw, lb, A.eps, S, sb, L);   // (its barriers publish the gate image)
+        ch_park(PARK, iout[0], tid);
+    }
+    // ---- input_gate / update_gate = sigmoid(LN(linear(gate))); features = update_gate * param_out + input_gate * input_out   :72-88
+    ch_zero(acc[0]);
+    ch_zero(acc[1]);
+    ch_gemm<2, true>(acc, IMG0, IMG0, A.off_ig, A.off_ug, ChNext{A.off_fc, 0u, 1}, R, wrs, L);
+    {
+        float gt[2][16], b[16];
+        ch_cols(CST + CA_IG_B, L, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gt[0][r] = acc[0][r] + b[r];
+        ch_cols(CST + CA_UG_B, L, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gt[1][r] = acc[1][r] + b[r];
+        const float* const lw[2] = {CST + CA_INI_W, CST + CA_NI_W};
+        const float* const lb[2] = {CST + CA_INI_B, CST + CA_NI_B};
+        ch_layernorm<2>(gt, lw, lb, A.eps, S, sb, L);
+        float f[16];
+        ch_unpark(PARK, f, tid);      // input_out
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ig = 1.0f / (1.0f + expf(-gt[0][r]));
+            const float ug = 1.0f / (1.0f + expf(-gt[1][r]));
+            f[r] = ug * pout[0][r] + ig * f[r];
+        }
+        ch_img_write(IMG1, f, L);   // IMG1 was last read by the input_layer GEMM
+        CH_BAR();
+    }
+    // ---- fc_layer + fc_norm + ReLU -> updated kernels (obj1)                                                      :90-92
+    f32x16 acc1[1];
+    ch_zero(acc1[0]);
+    ch_gemm<1, true>(acc1, IMG1, IMG1, A.off_fc, 0u, ChNext{A.off_in, 0u, 1}, R, wrs, L);
+    {
+        float o[1][16], b[16];
+        ch_cols(CST + CA_FC_B, L, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[0][r] = acc1[0][r] + b[r];
+        const float* const lw[1] = {CST + CA_FCN_W};
+        const float* const lb[1] = {CST + CA_FCN_B};
+        ch_layernorm<1>(o, lw, lb, A.eps, S, sb, L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[0][r] = fmaxf(o[0][r], 0.f);
+        ch_store_rows(A.obj1, CH_C, 0, row, row_ok, o[0], L);
+        ch_img_write(IMG0, o[0], L);   // IMG0 was last read by the gate GEMM
+        CH_BAR();
+    }
+    // ---- attention in_proj: q | k | v = obj1 . W_in^T + b_in                                     knet/det/kernel_update_head.py:206
+#pragma unroll 1
+    for (int t = 0; t < 3; ++t) {
+        asm volatile("" ::: "memory");   // the image reads are loop invariant: keep hipcc from hoisting all 48 fragments (192 VGPRs) out of the loop
+        ch_zero(acc1[0]);
+        const ChNext nx = (t < 2) ? ChNext{A.off_in + (unsigned)(t + 1) * 8u * CH_WTILE, 0u, 1} : ChNext{0u, 0u, 0};
+        ch_gemm<1, true>(acc1, IMG0, IMG0, A.off_in + (unsigned)t * 8u * CH_WTILE, 0u, nx, R, wrs, L);
+        float o[16], b[16];
+        ch_cols(CST + CA_IN_B + 256 * t, L, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = acc1[0][r] + b[r];
+        ch_store_rows(A.qkv, 3 * CH_C, 256 * t, row, row_ok, o, L);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel C: out_proj .. decode kernels
+enum {
+    CC_OUT_B = 0, CC_AN_W = 256, CC_AN_B = 512,       // attention out_proj bias, attention_norm
+    CC_B2 = 768, CC_FN_W = 1024, CC_FN_B = 1280,      // ffn second bias, ffn_norm
+    CC_CLN_W = 1536, CC_CLN_B = 1792,                 // cls_fcs LayerNorm
+    CC_MLN_W = 2048, CC_MLN_B = 2304,                 // mask_fcs LayerNorm
+    CC_DVEC = 2560,                                   // W_fm^T . b_ft (decode-bias dot vector)
+    CC_CLS_B = 2816,                                  // fc_cls bias, zero padded to 256
+    CC_DEC_B = 3072,                                  // bias of the folded decode kernels
+    CC_B1 = 3328,                                     // [ff <= 2048] ffn first bias
+    CC_TOTAL = 3328 + 2048
+};
+
+struct ChainCArgs {
+    const float* ao;     // [M][256] attention output (before out_proj)
+    const float* obj1;   // [M][256] residual of the attention block
+    const void* wbase;
+    unsigned wbytes;
+    unsigned off_out, off_ffn1, off_ffn2, off_clsfc, off_maskfc, off_fccls, off_dec;
+    int nchunks;         // ff / 256
+    int has_cls;         // fc_cls is computed
+    int cls_sigmoid;
+    int ncls;
+    float eps;
+    int M;
+    const float* kb0;    // device scalar b_fm . b_ft (added to the decode bias) or NULL
+    float* obj_out;      // [M][256] the stage's output kernels
+    float* cls_out;      // [M][ncls] or NULL
+    float* kb_out;       // [M] folded decode bias
+    _Float16* plane_hi;  // f16 split planes [B][NPT][256] of the folded decode kernels, or NULL ->
+    _Float16* plane_lo;
+    float* kern_out;     // ... fp32 [M][256]
+    int rows_per_frame, NPT;
+    ChConstTab consts;
+};
+
+__global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_cc[];
+    __bf16* IMG0 = reinterpret_cast<__bf16*>(smem_cc);
+    __bf16* HID = IMG0 + CH_IMG;
+    float* S = reinterpret_cast<float*>(HID + CH_IMG);
+    float* CST = S + 2 * CH_SBUF;
+
+    const int tid = threadIdx.x;
+    const ChLane L = ch_lane(tid);
+    const int m0 = blockIdx.x * CH_ROWS, M = A.M;
+    const int row = m0 + L.li;
+    const bool row_ok = row < M;
+    const int rowc = min(row, M - 1);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.wbase), 0, (int)A.wbytes, 0x00020000);
+
+    ChRing R;
+    ch_wload(R, 0, wrs, L, A.off_out);
+    ch_wload(R, 1, wrs, L, A.off_out + CH_WTILE);
+    ch_wload(R, 2, wrs, L, A.off_out + 2u * CH_WTILE);
+    ch_stage_consts(CST, A.consts, tid);
+    ch_img_load(IMG0, A.ao, CH_C, m0, M, tid);
+    float obj[1][16];   // residual rows in the transposed-tile layout
+    {
+        const float* s = A.obj1 + (size_t)rowc * CH_C + L.wave * 32 + 4 * L.g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(s + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) obj[0][4 * q + e] = t[e];
+        }
+    }
+    CH_BAR();
+
+    int sb = 0;
+    f32x16 acc1[1];
+    // ---- attention out_proj + identity + attention_norm                                           knet/det/kernel_update_head.py:206-208
+    ch_zero(acc1[0]);
+    ch_gemm<1, true>(acc1, IMG0, IMG0, A.off_out, 0u, ChNext{A.off_ffn1, 0u, 1}, R, wrs, L);
+    {
+        float b[16];
+        ch_cols(CST + CC_OUT_B, L, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) obj[0][r] = acc1[0][r] + b[r] + obj[0][r];
+        const float* const lw[1] = {CST + CC_AN_W};
+        const float* const lb[1] = {CST + CC_AN_B};
+        ch_layernorm<1>(obj, lw, lb, A.eps, S, sb, L);
+        ch_img_write(IMG0, obj[0], L);   // every wave has finished the out_proj reads of IMG0 (the LayerNorm barriers)
+        CH_BAR();
+    }
+    // ---- FFN: obj + W2 relu(W1 obj + b1) + b2, hidden chunks of 256 in sequence; the hidden activations live in ONE image     :214-215
+    f32x16 acc2[1];
+    ch_zero(acc2[0]);
+#pragma unroll 1
+    for (int c = 0; c < A.nchunks; ++c) {
+        ch_zero(acc1[0]);
+        ch_gemm<1, true>(acc1, IMG0, IMG0, A.off_ffn1 + (unsigned)c * 8u * CH_WTILE, 0u,
+                         ChNext{A.off_ffn2 + (unsigned)c * 8u * CH_WTILE, 0u, 1}, R, wrs, L);
+        float h[16], b[16];
+        ch_cols(CST + CC_B1 + 256 * c, L, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[r] = fmaxf(acc1[0][r] + b[r], 0.f);
+        CH_BAR();                      // the previous chunk's second GEMM has finished reading the hidden image (all waves)
+        ch_img_write(HID, h, L);
+        CH_BAR();
+        const bool lastc = (c + 1 == A.nchunks);
+        const ChNext nx = lastc ? ChNext{A.off_clsfc, A.off_maskfc, 2} : ChNext{A.off_ffn1 + (unsigned)(c + 1) * 8u * CH_WTILE, 0u, 1};
+        ch_gemm<1, true>(acc2, HID, HID, A.off_ffn2 + (unsigned)c * 8u * CH_WTILE, 0u, nx, R, wrs, L);
+    }
+    {
+        float b[16];
+        ch_cols(CST + CC_B2, L, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) obj[0][r] = obj[0][r] + acc2[0][r] + b[r];
+        const float* const lw[1] = {CST + CC_FN_W};
+        const float* const lb[1] = {CST + CC_FN_B};
+        ch_layernorm<1>(obj, lw, lb, A.eps, S, sb, L);
+        ch_store_rows(A.obj_out, CH_C, 0, row, row_ok, obj[0], L);
+        ch_img_write(IMG0, obj[0], L);   // IMG0's last reader was the last chunk's first GEMM (barriers since)
+        CH_BAR();
+    }
+    // ---- cls_fcs[0] / mask_fcs[0]: Linear (no bias) + LN + ReLU, one pass over the obj image                      :217-226
+    f32x16 acc[2];
+    ch_zero(acc[0]);
+    ch_zero(acc[1]);
+    const ChNext nfin = A.has_cls ? ChNext{A.off_fccls, A.off_dec, 2} : ChNext{A.off_dec, 0u, 1};
+    ch_gemm<2, true>(acc, IMG0, IMG0, A.off_clsfc, A.off_maskfc, nfin, R, wrs, L);
+    {
+        float t[2][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            t[0][r] = acc[0][r];
+            t[1][r] = acc[1][r];
+        }
+        const float* const lw[2] = {CST + CC_CLN_W, CST + CC_MLN_W};
+        const float* const lb[2] = {CST + CC_CLN_B, CST + CC_MLN_B};
+        ch_layernorm<2>(t, lw, lb, A.eps, S, sb, L);
+        float dv[16], kd[1];
+        ch_cols(CST + CC_DVEC, L, dv);
+        kd[0] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            t[0][r] = fmaxf(t[0][r], 0.f);
+            t[1][r] = fmaxf(t[1][r], 0.f);
+            kd[0] += t[1][r] * dv[r];
+        }
+        ch_img_write(IMG0, t[0], L);   // cls branch input of fc_cls
+        ch_img_write(HID, t[1], L);    // mask branch input of the folded fc_mask
+        ch_rowsum<1>(kd, S + sb * CH_SBUF, L);   // folded decode bias kb = mask_feat . b_ft; its barrier publishes both images
+        sb ^= 1;
+        if (row_ok && L.wave == 0 && L.g == 0 && A.kb_out) A.kb_out[row] = kd[0] + (A.kb0 ? *A.kb0 : 0.f);
+    }
+    // ---- fc_cls (+ sigmoid on the last stage) and the folded decode kernels Kf = fc_mask(.) . W_ft                 :221, :227, :247
+    ch_zero(acc[0]);
+    ch_zero(acc[1]);
+    if (A.has_cls) {
+        ch_gemm<2, false>(acc, IMG0, HID, A.off_fccls, A.off_dec, ChNext{0u, 0u, 0}, R, wrs, L);
+        if (L.wave * 32 < A.ncls && row_ok && A.cls_out) {
+            float b[16];
+            ch_cols(CST + CC_CLS_B, L, b);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = L.wave * 32 + 8 * (r >> 2) + 4 * L.g + (r & 3);
+                float v = acc[0][r] + b[r];
+                if (A.cls_sigmoid) v = 1.0f / (1.0f + expf(-v));
+                if (col < A.ncls) A.cls_out[(size_t)row * A.ncls + col] = v;
+            }
+        }
+    } else {
+        f32x16 accd[1];
+        ch_zero(accd[0]);
+        ch_gemm<1, true>(accd, HID, HID, A.off_dec, 0u, ChNext{0u, 0u, 0}, R, wrs, L);
+        acc[1] = accd[0];
+    }
+    {
+        float k[16], b[16];
+        ch_cols(CST + CC_DEC_B, L, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) k[r] = acc[1][r] + b[r];
+        if (A.plane_hi) {
+            if (row_ok) {
+                const int fb = row / A.rows_per_frame, n = row - fb * A.rows_per_frame;
+                const size_t base = ((size_t)fb * A.NPT + n) * CH_C + L.wave * 32 + 4 * L.g;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    half4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 hh, ll;
+                        vkn_split_f16(k[4 * q + e], hh, ll);
+                        h[e] = hh;
+                        l[e] = ll;
+                    }
+                    *reinterpret_cast<half4*>(A.plane_hi + base + 8 * q) = h;
+                    *reinterpret_cast<half4*>(A.plane_lo + base + 8 * q) = l;
+                }
+            }
+        } else {
+            ch_store_rows(A.kern_out, CH_C, 0, row, row_ok, k, L);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host launchers
+static void ch_tab_add(ChConstTab& T, const float* src, int dst, int n, float fill) {
+    const int i = T.count++;
+    T.src[i] = src;
+    T.dst[i] = (short)dst;
+    T.n[i] = (short)n;
+    T.fill[i] = fill;
+}
+
+int vkn_launch_chain_a(const VknChainA& p, hipStream_t stream) {
+    if (!p.a0 || !p.obj_in || !p.wbase || !p.obj1 || !p.qkv || p.M <= 0 || p.wbytes >= (1ull << 31)) return VKN_E_ARG;
+    ChainAArgs A{};
+    A.a0 = p.a0; A.obj_in = p.obj_in; A.rowscale = p.rowscale; A.wbase = p.wbase; A.wbytes = (unsigned)p.wbytes;
+    A.off_dyn = p.off_dyn; A.off_inp = p.off_inp; A.off_ig = p.off_ig; A.off_ug = p.off_ug; A.off_fc = p.off_fc; A.off_in = p.off_in;
+    A.eps = p.eps; A.M = p.M; A.obj1 = p.obj1; A.qkv = p.qkv;
+    ChConstTab& T = A.consts;
+    T.count = 0;
+    ch_tab_add(T, p.dyn_bias, CA_DYN_B, 512, 0.f);
+    ch_tab_add(T, p.dyn_bias2, CA_DYN_B2, 512, 0.f);
+    ch_tab_add(T, p.norm_out_w, CA_NO_W, 256, 1.f);   ch_tab_add(T, p.norm_out_b, CA_NO_B, 256, 0.f);
+    ch_tab_add(T, p.inp_b, CA_INP_B, 512, 0.f);
+    ch_tab_add(T, p.inorm_out_w, CA_INO_W, 256, 1.f); ch_tab_add(T, p.inorm_out_b, CA_INO_B, 256, 0.f);
+    ch_tab_add(T, p.ig_b, CA_IG_B, 256, 0.f);
+    ch_tab_add(T, p.inorm_in_w, CA_INI_W, 256, 1.f);  ch_tab_add(T, p.inorm_in_b, CA_INI_B, 256, 0.f);
+    ch_tab_add(T, p.ug_b, CA_UG_B, 256, 0.f);
+    ch_tab_add(T, p.norm_in_w, CA_NI_W, 256, 1.f);    ch_tab_add(T, p.norm_in_b, CA_NI_B, 256, 0.f);
+    ch_tab_add(T, p.fc_b, CA_FC_B, 256, 0.f);
+    ch_tab_add(T, p.fc_norm_w, CA_FCN_W, 256, 1.f);   ch_tab_add(T, p.fc_norm_b, CA_FCN_B, 256, 0.f);
+    ch_tab_add(T, p.in_b, CA_IN_B, 768, 0.f);
+    const size_t lds = (size_t)2 * CH_IMG * sizeof(__bf16) + (size_t)(2 * CH_SBUF + CA_TOTAL + 16 * CH_THREADS) * sizeof(float);
+    VKN_ALLOW_FULL_LDS(k_chain_a);
+    hipLaunchKernelGGL(k_chain_a, dim3((p.M + CH_ROWS - 1) / CH_ROWS), dim3(CH_THREADS), lds, stream, A);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_launch_chain_c(const VknChainC& p, hipStream_t stream) {
+    if (!p.ao || !p.obj1 || !p.wbase || !p.obj_out || p.M <= 0 || p.wbytes >= (1ull << 31)) return VKN_E_ARG;
+    if (p.ff <= 0 || p.ff % 256 != 0 || p.ff > 2048 || p.ncls > 256) return VKN_E_SHAPE;
+    if (!p.plane_hi == !p.kern_out || (p.plane_hi && !p.plane_lo)) return VKN_E_ARG;   // exactly one output form of the decode kernels
+    ChainCArgs A{};
+    A.ao = p.ao; A.obj1 = p.obj1; A.wbase = p.wbase; A.wbytes = (unsigned)p.wbytes;
+    A.off_out = p.off_out; A.off_ffn1 = p.off_ffn1; A.off_ffn2 = p.off_ffn2; A.off_clsfc = p.off_clsfc; A.off_maskfc = p.off_maskfc;
+    A.off_fccls = p.off_fccls; A.off_dec = p.off_dec;
+    A.nchunks = p.ff / 256; A.has_cls = (p.cls_out != nullptr) ? 1 : 0; A.cls_sigmoid = p.cls_sigmoid; A.ncls = p.ncls;
+    A.eps = p.eps; A.M = p.M; A.kb0 = p.kb0; A.obj_out = p.obj_out; A.cls_out = p.cls_out; A.kb_out = p.kb_out;
+    A.plane_hi = p.plane_hi; A.plane_lo = p.plane_lo; A.kern_out = p.kern_out; A.rows_per_frame = p.rows_per_frame; A.NPT = p.NPT;
+    ChConstTab& T = A.consts;
+    T.count = 0;
+    ch_tab_add(T, p.out_b, CC_OUT_B, 256, 0.f);
+    ch_tab_add(T, p.attn_norm_w, CC_AN_W, 256, 1.f);  ch_tab_add(T, p.attn_norm_b, CC_AN_B, 256, 0.f);
+    ch_tab_add(T, p.ffn2_b, CC_B2, 256, 0.f);
+    ch_tab_add(T, p.ffn_norm_w, CC_FN_W, 256, 1.f);   ch_tab_add(T, p.ffn_norm_b, CC_FN_B, 256, 0.f);
+    ch_tab_add(T, p.cls_ln_w, CC_CLN_W, 256, 1.f);    ch_tab_add(T, p.cls_ln_b, CC_CLN_B, 256, 0.f);
+    ch_tab_add(T, p.mask_ln_w, CC_MLN_W, 256, 1.f);   ch_tab_add(T, p.mask_ln_b, CC_MLN_B, 256, 0.f);
+    ch_tab_add(T, p.dvec, CC_DVEC, 256, 0.f);
+    ch_tab_add(T, nullptr, CC_CLS_B, 256, 0.f);                                   // zero pad, then the ncls real entries
+    if (p.fc_cls_b && p.cls_out) ch_tab_add(T, p.fc_cls_b, CC_CLS_B, p.ncls, 0.f);
+    ch_tab_add(T, p.dec_b, CC_DEC_B, 256, 0.f);
+    ch_tab_add(T, p.ffn1_b, CC_B1, p.ff, 0.f);
+    const size_t lds = (size_t)2 * CH_IMG * sizeof(__bf16) + (size_t)(2 * CH_SBUF + CC_TOTAL) * sizeof(float);
+    VKN_ALLOW_FULL_LDS(k_chain_c);
+    hipLaunchKernelGGL(k_chain_c, dim3((p.M + CH_ROWS - 1) / CH_ROWS), dim3(CH_THREADS), lds, stream, A);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}

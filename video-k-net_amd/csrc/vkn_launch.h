@@ -104,3 +104,42 @@ struct VknPanopticCfg;
 size_t vkn_panoptic_ws_bytes(int B, int K);
 int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const float* masks, int B, int N, int ncls,
                               int* panoptic_seg, int* info, int* nseg, int* bbox, void* ws, size_t ws_bytes, hipStream_t st);
+
+// ---- persistent row-owner chain kernels (vkn_chain.hip): C == 256, pre-split weights.  `off_*` are byte offsets of tile images
+// inside the prepared weight buffer `wbase` (vkn_prepare_stage_f32).
+struct VknChainA {   // KernelUpdator + attention in_proj
+    const float* a0;        // [M][256] update feature (raw gather with composite weights, else x_feat)
+    const float* obj_in;    // [M][256]
+    const float* rowscale;  // [M] or NULL: scales dyn_bias per row (pixel count x folded feat_transform bias)
+    const void* wbase;
+    size_t wbytes;
+    unsigned off_dyn, off_inp, off_ig, off_ug, off_fc, off_in;
+    const float *dyn_bias, *dyn_bias2;                    // [512] (scaled), [512] or NULL
+    const float *norm_out_w, *norm_out_b, *inp_b, *inorm_out_w, *inorm_out_b;
+    const float *ig_b, *inorm_in_w, *inorm_in_b, *ug_b, *norm_in_w, *norm_in_b;
+    const float *fc_b, *fc_norm_w, *fc_norm_b, *in_b;     // in_b [768]
+    float eps;
+    int M;
+    float* obj1;  // [M][256]
+    float* qkv;   // [M][768]
+};
+struct VknChainC {   // attention out_proj + LN, FFN + LN, cls / mask FCs, fc_cls, folded decode kernels
+    const float* ao;      // [M][256]
+    const float* obj1;    // [M][256]
+    const void* wbase;
+    size_t wbytes;
+    unsigned off_out, off_ffn1, off_ffn2, off_clsfc, off_maskfc, off_fccls, off_dec;
+    const float *out_b, *attn_norm_w, *attn_norm_b, *ffn1_b, *ffn2_b, *ffn_norm_w, *ffn_norm_b;
+    const float *cls_ln_w, *cls_ln_b, *mask_ln_w, *mask_ln_b, *dvec, *kb0, *fc_cls_b, *dec_b;
+    int ff, ncls, cls_sigmoid;
+    float eps;
+    int M;
+    float* obj_out;   // [M][256]
+    float* cls_out;   // [M][ncls] or NULL (no classification branch)
+    float* kb_out;    // [M]
+    _Float16 *plane_hi, *plane_lo;   // f16 planes [B][NPT][256] ...
+    float* kern_out;                 // ... or fp32 [M][256] (exactly one of the two forms)
+    int rows_per_frame, NPT;
+};
+int vkn_launch_chain_a(const VknChainA& p, hipStream_t stream);
+int vkn_launch_chain_c(const VknChainC& p, hipStream_t stream);

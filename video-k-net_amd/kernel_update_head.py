@@ -113,11 +113,13 @@ class _ChainGraphRunner:
         self.in_flight = False        # a forward whose backward has not run yet
 
     def _unalias(self):
-        """Before a backward replay overwrites the static gradient buffers: a parameter whose `.grad` still IS its buffer (handed
-        over by the previous `_deliver` and neither consumed nor replaced since — `zero_grad(set_to_none=False)`, or a second
-        micro-batch of gradient accumulation) gets a private copy, so that the replay cannot overwrite the accumulated value and
-        `_deliver` never adds a buffer to itself.  The usual loops (`set_to_none=True`, the bucketed reducer) never
-        take this branch."""
+        """Before ANY replay of this runner's graphs: a parameter whose `.grad` still IS its static buffer (handed over by the
+        previous `_deliver` and neither consumed nor replaced since — `zero_grad(set_to_none=False)`, or a second micro-batch of
+        gradient accumulation) gets a private copy.  The buffers live in the graphs' private pool, where the FORWARD graph's
+        intermediates share their memory: the next forward replay already scribbles over them, the backward replay rewrites them,
+        and `_deliver` would add a buffer to itself (found as garbage gradients by
+        `test_chain_graphs_without_reducer_zero_in_place_and_accumulation`).  The usual loops (`set_to_none=True`, the bucketed
+        reducer) never take this branch."""
         for p, g in self.used:
             if p.grad is not None and p.grad.data_ptr() == g.data_ptr():
                 p.grad = g.clone()
@@ -141,6 +143,7 @@ class _ChainGraphFn(torch.autograd.Function):
         for st, t in zip(runner.static_in, inputs):
             if st.data_ptr() != t.data_ptr():
                 st.detach().copy_(t)
+        runner._unalias()
         runner.fwd.replay()
         runner.in_flight = runner.has_bwd
         ctx.runner = runner
