@@ -59,9 +59,13 @@ extern "C" {
 #define VKN_X_BF16 2
 #define VKN_FLAG_X_F16 64u    /* x is [B][C][H*W] fp16 */
 #define VKN_FLAG_X_BF16 128u  /* x is [B][C][H*W] bf16 */
-#define VKN_FLAG_CHAIN_LAUNCHES 256u /* the [N x C] chain as one launch per GEMM (k_gemm_s3 ...) instead of the two persistent row-owner
-                                    * kernels (k_chain_a / k_chain_c); A/B and the path of every shape the latter do not cover.  Same
-                                    * arithmetic (bf16x3 MFMA, fp32 LayerNorm), different summation order: agrees to fp32 rounding */
+/* The [N x C] chain of a stage runs either as one launch per GEMM (k_gemm_s3 ...: the tile stream of every GEMM spread over the chip,
+ * best for few rows) or as two persistent row-owner kernels around the attention (k_chain_a / k_chain_c, vkn_chain.hip: C == 256,
+ * num_cls_fcs == num_mask_fcs == 1, ff % 256 == 0, pre-split composite weights; best from ~2048 rows = 17 frames of 117 kernels on).
+ * Default: by row count.  Same arithmetic (bf16x3 MFMA, fp32 two-pass LayerNorm), different summation order: the two agree to fp32
+ * rounding (tests/test_gpu_parity.py::test_persistent_chain_equals_launch_per_gemm_chain), each is deterministic. */
+#define VKN_FLAG_CHAIN_LAUNCHES 256u   /* always one launch per GEMM */
+#define VKN_FLAG_CHAIN_PERSISTENT 512u /* always the persistent kernels (where the shape allows them) */
 #define VKN_FLAG_SERIAL_LINK 32u   /* vkn_head_forward_f32: run the tracking link on the caller's stream instead of the library's side
                                     * stream (A/B, or callers that must see ONE stream; same results) */
 #define VKN_FLAG_CLIP_LINK 8u      /* vkn_head_forward_f32: the B frames are CONSECUTIVE frames of one video: prev_obj is [1][N][C] (the

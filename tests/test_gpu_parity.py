@@ -175,7 +175,7 @@ def test_stage_by_stage_vs_oracle_and_reference(vkn, name):
             assert maxabs(r['object_feats_track'], g['track']) < 1e-4
 
 
-@pytest.mark.parametrize('flags', [0, 1, 2, 3], ids=['mfma', 'refkernels', 'exactgemm', 'allexact'])
+@pytest.mark.parametrize('flags', [0, 1, 2, 3, 512, 513], ids=['mfma', 'refkernels', 'exactgemm', 'allexact', 'persistent', 'persistent_ref'])
 @pytest.mark.parametrize('name', ['det_tiny', 'det_odd', 'det_cfg', 'video_tiny', 'video_cfg'])
 def test_head_vs_reference_golden(vkn, name, flags):
     """The fused S-stage call (`simple_test_mask_preds[_plus_previous]`) against the REFERENCE's own outputs."""
@@ -374,8 +374,10 @@ def test_cfg2_size_properties(vkn):
     assert maxabs(d1, refd) < 2e-4
 
 
-def test_cfg2_size_head_vs_oracle(vkn):
-    """One 1024x2048 frame through the video head (S=3, N=117, link + x4 upsample) against the CPU oracle.
+@pytest.mark.parametrize('chain', ['launches', 'persistent'])
+def test_cfg2_size_head_vs_oracle(vkn, chain):
+    """(Both forms of the [N x C] chain: one launch per GEMM — the default at one frame — and the persistent row-owner kernels.)
+    One 1024x2048 frame through the video head (S=3, N=117, link + x4 upsample) against the CPU oracle.
 
     At this size (3.8 M logits per stage) a few logits lie within 1e-5 of the binarisation flip point, and ANY change of
     fp32 summation order flips them (SURVEY.md §7 'Threshold semantics'; with i.i.d. random features one flipped pixel moves
@@ -385,6 +387,8 @@ def test_cfg2_size_head_vs_oracle(vkn):
     case = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256,
                 B=1, seed=11, video=1)
     head, (x, pf, mp, prev) = _build_head(vkn, case)
+    for h in head.mask_head:
+        h.vkn_flags = vkn.ops.FLAG_CHAIN_PERSISTENT if chain == 'persistent' else vkn.ops.FLAG_CHAIN_LAUNCHES
     traces = []
     obj_r, cls_r, masks_r, scaled_r, track_r = run_oracle(case, traces=traces)
     xd, prevd = _cuda(x, prev)
@@ -844,7 +848,7 @@ def test_stage_attention_head_widths_and_key_blocks_vs_oracle(vkn, C, heads, N):
 
 
 @pytest.mark.parametrize('B,N,ff,ncls,video', [(1, 117, 2048, 19, 0), (3, 117, 2048, 19, 1), (2, 166, 1024, 124, 0), (5, 20, 512, 40, 0),
-                                                (1, 32, 256, 3, 0), (8, 100, 2048, 40, 1)])
+                                                (1, 32, 256, 3, 0), (8, 100, 2048, 40, 1), (18, 117, 2048, 19, 1)])
 def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, video):
     """The [N x C] chain as two persistent row-owner kernels (k_chain_a / k_chain_c, the default at C = 256) against the same chain as
     one launch per GEMM (VKN_FLAG_CHAIN_LAUNCHES) and against the exact-fp32 GEMM chain (VKN_FLAG_EXACT_GEMM): one stage, same
@@ -863,7 +867,7 @@ def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, vide
     pack = head.mask_head[0].stage_pack(torch.device(DEV))
     args = (dims, pack, x.to(DEV), pf.reshape(B, N, C).to(DEV), mp.to(DEV))
     kwd = dict(prev_obj=prev.reshape(B, N, C).to(DEV), want_track=True) if video else {}
-    new = vkn.ops.stage_forward(*args, **kwd)
+    new = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_CHAIN_PERSISTENT, **kwd)
     old = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_CHAIN_LAUNCHES, **kwd)
     exact = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_EXACT_GEMM, **kwd)
     names = ('cls', 'masks', 'obj', 'x_feat', 'track')
@@ -882,8 +886,11 @@ def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, vide
     t0 = traces[0]
     assert maxabs(new[2], t0['obj_feat'].reshape(B, N, C)) < 2e-4
     assert maxabs(new[1], t0['new_mask_preds']) < TOL_LOGIT and maxabs(new[0], t0['cls_score']) < 1e-4
-    again = vkn.ops.stage_forward(*args, **kwd)
+    again = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_CHAIN_PERSISTENT, **kwd)
     assert all(a is None or torch.equal(a, b) for a, b in zip(new, again)), 'deterministic'
+    auto = vkn.ops.stage_forward(*args, **kwd)     # default policy: by row count (64 row tiles)
+    pick = new if (B * N + 31) // 32 >= 64 else old
+    assert all(a is None or torch.equal(a, b) for a, b in zip(auto, pick)), 'default policy picks by row count'
 
 
 # ------------------------------------------------------------------------------------------ train-time assignment

@@ -13,6 +13,10 @@ import vkn_import  # noqa: E402
 
 vkn = vkn_import.load()
 DEV = 'cuda:0'
+if '--debug-lib' in sys.argv:       # time-attribution variants (VKN_CHAIN_ABL ...) exist only in lib/libvkn_debug.so
+    sys.argv.remove('--debug-lib')
+    vkn._lib.build_debug()
+    vkn._lib.use_debug()
 
 
 def timeit(fn, iters=50, warm=10):
@@ -49,6 +53,18 @@ def main():
             t_new = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob))
             t_old = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob, flags=vkn.ops.FLAG_CHAIN_LAUNCHES))
             print(f'B={B:3d} rows={B * N:5d}  persistent {t_new:8.1f}   launch-per-GEMM {t_old:8.1f}   ratio {t_old / t_new:5.2f}')
+    if args.what == 'abl':           # needs --debug-lib
+        print('== chain alone, time attribution (VKN_CHAIN_ABL: 1 no MFMA, 2 no weight loads, 3 no fragment reads, 4 neither, 5|6|7 no MFMA + ring 2 | ring 8 | nt loads), us per stage ==')
+        for B in (1, 32):
+            dims = head.mask_head[0].make_dims(B, N, H, W)
+            pack = head.mask_head[0].stage_pack(torch.device(DEV))
+            xf = (torch.randn(B, N, C, generator=g) * 50).to(DEV)
+            ob = torch.randn(B, N, C, generator=g).to(DEV)
+            for abl in (0, 1, 2, 4, 8, 9, 10, 0):
+                os.environ['VKN_CHAIN_ABL'] = str(abl)
+                t = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob))
+                print(f'B={B:3d} ABL={abl}  {t:8.1f}')
+        os.environ['VKN_CHAIN_ABL'] = '0'
     if args.what in ('head', 'all'):
         print('== whole head step (3 stages + link + x4 upsample), ms per call ==')
         for B in (1, 8, 32):

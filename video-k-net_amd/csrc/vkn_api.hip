@@ -53,6 +53,7 @@ struct PrepW {
     //   dvec = W_fm^T.b_ft [C], kb0 = b_fm.b_ft                   -> decode bias
     const void *dynft, *dec;
     float *dynft32, *bcnt, *dec32, *decb, *dvec, *kb0, *fmT;
+    float* chain_consts;   // packed bias / LayerNorm vectors of the persistent chain kernels (vkn_chain.hip), C == 256 only
 };
 
 inline bool has_composites(const VknDims* d, const VknStageWeights* w) {
@@ -95,7 +96,7 @@ size_t carve_prepared(const VknDims* d, const VknStageWeights* w, char* base, Pr
     Carver c{base, 0};
     for (int i = 0; i < n; ++i) *it[i].dst = c.take<char>(vkn_split_w3_bytes(it[i].nout, it[i].k));
     p->dynft = p->dec = nullptr;
-    p->dynft32 = p->bcnt = p->dec32 = p->decb = p->dvec = p->kb0 = p->fmT = nullptr;
+    p->dynft32 = p->bcnt = p->dec32 = p->decb = p->dvec = p->kb0 = p->fmT = p->chain_consts = nullptr;
     if (has_composites(d, w)) {
         const size_t C = d->C;
         p->dynft = c.take<char>(vkn_split_w3_bytes(2 * d->C, d->C));
@@ -107,6 +108,7 @@ size_t carve_prepared(const VknDims* d, const VknStageWeights* w, char* base, Pr
         p->dvec = c.take<float>(C);
         p->kb0 = c.take<float>(4);
         p->fmT = c.take<float>(C * C);
+        if (d->C == 256 && d->ff <= 2048) p->chain_consts = c.take<float>(vkn_chain_consts_floats());
     }
     if (n_out) *n_out = n;
     return (c.off + 255) & ~(size_t)255;
@@ -356,9 +358,13 @@ inline unsigned pw_off(const VknStageWeights* w, const void* p) {
 bool chain_fast_ok(const VknDims* d, const VknStageWeights* w, const PrepW& pw, unsigned flags, bool have_cls) {
     if (flags & (VKN_FLAG_CHAIN_LAUNCHES | VKN_FLAG_EXACT_GEMM)) return false;
     if (vkn_dbg_env("VKN_CHAIN_LAUNCHES", 0)) return false;
+    // Policy (profiles/r04_chain_ab.txt): a row-owner workgroup streams ALL of a stage's weights (12 MB) through its CU, ~160 us per
+    // stage however many rows there are, while the launch-per-GEMM chain spreads the tile stream over the chip and costs
+    // 124 / 149 / 202 / 341 us at 117 / 1872 / 3744 / 7488 rows: the persistent kernels win from ~64 row tiles (2048 rows) on.
+    if (!(flags & VKN_FLAG_CHAIN_PERSISTENT) && !vkn_dbg_env("VKN_CHAIN_PERSISTENT", 0) && (d->B * d->N + 31) / 32 < 64) return false;
     if (d->C != 256 || d->n_cls_fcs != 1 || d->n_mask_fcs != 1 || d->ff % 256 != 0 || d->ff > 2048) return false;
     if (!w->prepared || w->prepared_bytes >= (1ull << 31)) return false;
-    if (!pw.dynft || !pw.dyn || !pw.dec || !pw.inp || !pw.ig || !pw.ug || !pw.fc || !pw.attn_in || !pw.attn_out || !pw.ffn1 ||
+    if (!pw.chain_consts || !pw.dynft || !pw.dyn || !pw.dec || !pw.inp || !pw.ig || !pw.ug || !pw.fc || !pw.attn_in || !pw.attn_out || !pw.ffn1 ||
         !pw.ffn2 || !pw.cls_fc[0] || !pw.mask_fc[0])
         return false;
     if (have_cls && !pw.fc_cls) return false;
@@ -378,12 +384,7 @@ int run_chain_fast(const VknDims* d, const VknStageWeights* w, const PrepW& pw, 
     a.off_dyn = pw_off(w, a0_raw ? pw.dynft : pw.dyn);
     a.off_inp = pw_off(w, pw.inp); a.off_ig = pw_off(w, pw.ig); a.off_ug = pw_off(w, pw.ug); a.off_fc = pw_off(w, pw.fc);
     a.off_in = pw_off(w, pw.attn_in);
-    a.dyn_bias = a0_raw ? pw.bcnt : w->dyn_b; a.dyn_bias2 = a0_raw ? w->dyn_b : nullptr;
-    a.norm_out_w = w->norm_out_w; a.norm_out_b = w->norm_out_b; a.inp_b = w->inp_b;
-    a.inorm_out_w = w->inorm_out_w; a.inorm_out_b = w->inorm_out_b;
-    a.ig_b = w->ig_b; a.inorm_in_w = w->inorm_in_w; a.inorm_in_b = w->inorm_in_b;
-    a.ug_b = w->ug_b; a.norm_in_w = w->norm_in_w; a.norm_in_b = w->norm_in_b;
-    a.fc_b = w->fc_b; a.fc_norm_w = w->fc_norm_w; a.fc_norm_b = w->fc_norm_b; a.in_b = w->attn_in_b;
+    a.consts = pw.chain_consts;
     a.eps = d->ln_eps; a.M = M; a.obj1 = s.obj1; a.qkv = s.qkv;
     VKN_TRY(vkn_launch_chain_a(a, st));
     VKN_TRY(vkn_launch_attn(s.qkv, 3 * C, s.qkv + C, s.qkv + 2 * C, 3 * C, s.ao, C, d->B, d->N, d->N, d->heads, C / d->heads, st));
@@ -392,10 +393,7 @@ int run_chain_fast(const VknDims* d, const VknStageWeights* w, const PrepW& pw, 
     c.off_out = pw_off(w, pw.attn_out); c.off_ffn1 = pw_off(w, pw.ffn1); c.off_ffn2 = pw_off(w, pw.ffn2);
     c.off_clsfc = pw_off(w, pw.cls_fc[0]); c.off_maskfc = pw_off(w, pw.mask_fc[0]);
     c.off_fccls = pw.fc_cls ? pw_off(w, pw.fc_cls) : 0u; c.off_dec = pw_off(w, pw.dec);
-    c.out_b = w->attn_out_b; c.attn_norm_w = w->attn_norm_w; c.attn_norm_b = w->attn_norm_b;
-    c.ffn1_b = w->ffn1_b; c.ffn2_b = w->ffn2_b; c.ffn_norm_w = w->ffn_norm_w; c.ffn_norm_b = w->ffn_norm_b;
-    c.cls_ln_w = w->cls_ln_w[0]; c.cls_ln_b = w->cls_ln_b[0]; c.mask_ln_w = w->mask_ln_w[0]; c.mask_ln_b = w->mask_ln_b[0];
-    c.dvec = pw.dvec; c.kb0 = pw.kb0; c.fc_cls_b = w->fc_cls_b; c.dec_b = pw.decb;
+    c.consts = pw.chain_consts; c.kb0 = pw.kb0;
     c.ff = d->ff; c.ncls = d->ncls; c.cls_sigmoid = cls_sigmoid ? 1 : 0; c.eps = d->ln_eps; c.M = M;
     c.obj_out = obj_out; c.cls_out = (w->fc_cls_w && cls_logits) ? cls_logits : nullptr; c.kb_out = s.kb;
     if (kern32_out) c.kern_out = kern32_out;
@@ -952,6 +950,21 @@ int vkn_prepare_stage_f32(const VknDims* d, const VknStageWeights* w, void* prep
         VKN_TRY(mm(w->fc_mask_b, w->ft_b, pw.kb0, 1, 1));            // b_fm.b_ft
         VKN_TRY(vkn_launch_split_w3(pw.dynft32, const_cast<void*>(pw.dynft), 2 * C, C, st));
         VKN_TRY(vkn_launch_split_w3(pw.dec32, const_cast<void*>(pw.dec), C, C, st));
+        if (pw.chain_consts) {
+            VknChainConsts cc{};
+            cc.bcnt = pw.bcnt; cc.dyn_b = w->dyn_b;
+            cc.norm_out_w = w->norm_out_w; cc.norm_out_b = w->norm_out_b; cc.inp_b = w->inp_b;
+            cc.inorm_out_w = w->inorm_out_w; cc.inorm_out_b = w->inorm_out_b;
+            cc.ig_b = w->ig_b; cc.inorm_in_w = w->inorm_in_w; cc.inorm_in_b = w->inorm_in_b;
+            cc.ug_b = w->ug_b; cc.norm_in_w = w->norm_in_w; cc.norm_in_b = w->norm_in_b;
+            cc.fc_b = w->fc_b; cc.fc_norm_w = w->fc_norm_w; cc.fc_norm_b = w->fc_norm_b; cc.in_b = w->attn_in_b;
+            cc.out_b = w->attn_out_b; cc.attn_norm_w = w->attn_norm_w; cc.attn_norm_b = w->attn_norm_b;
+            cc.ffn1_b = w->ffn1_b; cc.ffn2_b = w->ffn2_b; cc.ffn_norm_w = w->ffn_norm_w; cc.ffn_norm_b = w->ffn_norm_b;
+            cc.cls_ln_w = w->cls_ln_w[0]; cc.cls_ln_b = w->cls_ln_b[0]; cc.mask_ln_w = w->mask_ln_w[0]; cc.mask_ln_b = w->mask_ln_b[0];
+            cc.dvec = pw.dvec; cc.fc_cls_b = w->fc_cls_w ? w->fc_cls_b : nullptr; cc.dec_b = pw.decb;
+            cc.ff = d->ff; cc.ncls = d->ncls;
+            VKN_TRY(vkn_chain_pack_consts(cc, pw.chain_consts, st));
+        }
     }
     return VKN_OK;
 }

@@ -73,17 +73,32 @@ __device__ __forceinline__ ChLane ch_lane(int tid) {
     return L;
 }
 
+// ring depth and cache policy: 4 units, default policy; the debug build's stream probes (VKN_CHAIN_ABL 5 / 6 / 7, all without MFMAs)
+// change them to tell a latency-bound weight stream from a bandwidth-bound one
+#ifdef VKN_DEBUG
+#define CH_RING_OF(ABL) ((ABL) == 5 ? 2 : (ABL) == 6 ? 8 : 4)
+#define CH_AUX_OF(ABL) ((ABL) == 7 ? 2 : (ABL) == 8 ? 16 : (ABL) == 9 ? 17 : (ABL) == 10 ? 1 : 0)   /* 8 / 9 / 10: the FULL kernel with sc1 / sc0 sc1 / sc0 loads */
+#define CH_NOMFMA(ABL) ((ABL) == 1 || (ABL) == 4 || (ABL) == 5 || (ABL) == 6 || (ABL) == 7)
+#define CH_NOLOAD(ABL) ((ABL) == 2 || (ABL) == 4)
+#else
+#define CH_RING_OF(ABL) 4
+#define CH_AUX_OF(ABL) 0
+#define CH_NOMFMA(ABL) false
+#define CH_NOLOAD(ABL) false
+#endif
+template <int RING>
 struct ChRing {
-    cu32x4 r[4][6];  // [slot][ks * 3 + plane]
+    cu32x4 r[RING][6];  // [slot][ks * 3 + plane]
 };
 
 // the six fragments (2 k-steps x 3 planes) of this wave's column block of the tile at byte offset `toff` of the weight buffer
-__device__ __forceinline__ void ch_wload(ChRing& R, const int slot, const __amdgpu_buffer_rsrc_t wrs, const ChLane& L, unsigned toff) {
+template <int RING, int AUX = 0>
+__device__ __forceinline__ void ch_wload(ChRing<RING>& R, const int slot, const __amdgpu_buffer_rsrc_t wrs, const ChLane& L, unsigned toff) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            R.r[slot][ks * 3 + p] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)L.woff, (int)(toff + (unsigned)((p * 4 + 2 * ks) * 4096)), 0);
+            R.r[slot][ks * 3 + p] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)L.woff, (int)(toff + (unsigned)((p * 4 + 2 * ks) * 4096)), AUX);
 }
 
 // activation fragments (3 planes) of K-tile kt, k-step ks from an image
@@ -97,7 +112,8 @@ __device__ __forceinline__ void ch_afrag(const __bf16* img, const ChLane& L, int
 
 // acc (transposed tile: lane = activation row li, register r = output column 8 (r >> 2) + 4 g + (r & 3) of the wave's block) +=
 // W-fragments (slot) x activation fragments, the six significant products, smallest first
-__device__ __forceinline__ void ch_mfma6(f32x16& acc, const ChRing& R, const int slot, const int ks, const cbf16x8& ah, const cbf16x8& am,
+template <int RING>
+__device__ __forceinline__ void ch_mfma6(f32x16& acc, const ChRing<RING>& R, const int slot, const int ks, const cbf16x8& ah, const cbf16x8& am,
                                          const cbf16x8& al) {
     const cbf16x8 wh = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 0]);
     const cbf16x8 wm = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 1]);
@@ -114,7 +130,7 @@ __device__ __forceinline__ void ch_mfma6(f32x16& acc, const ChRing& R, const int
 struct ChNext {
     unsigned base0, base1;  // tile-image byte offsets of the next GEMM's accumulator 0 / 1 (column tiles or weights)
     int nacc;               // 1 or 2; 0 = nothing follows
-    __device__ __forceinline__ unsigned off(int j) const {  // unit j (0..2) of the next GEMM
+    __device__ __forceinline__ unsigned off(int j) const {  // unit j (0 .. RING-2) of the next GEMM
         if (nacc == 2) return ((j & 1) ? base1 : base0) + (unsigned)(j >> 1) * CH_WTILE;
         return base0 + (unsigned)j * CH_WTILE;
     }
@@ -122,37 +138,48 @@ struct ChNext {
 
 // One GEMM of the chain over K = 256 (8 K-tiles): NACC accumulators (column tiles or independent weights) fed from the unit stream
 //   unit u = kt * NACC + a  ->  tile image at base[a] + kt * CH_WTILE, accumulator a, activation image img[a].
-// The ring slot of unit u is u & 3 (every GEMM has a multiple of four units); on entry units 0..2 are in flight (requested by the
-// previous GEMM's tail or by the kernel prologue), on exit the next GEMM's units 0..2 are.
-template <int NACC, bool SAMEA>
+// The ring slot of unit u is u % RING (every GEMM's unit count is a multiple of RING); on entry units 0 .. RING-2 are in flight
+// (requested by the previous GEMM's tail or by the kernel prologue), on exit the next GEMM's first RING-1 units are.
+// ABL (debug build only, VKN_CHAIN_ABL; WRONG results by construction, time attribution): 1 = no MFMAs, 2 = no weight loads,
+// 3 = no activation-fragment reads, 4 = neither MFMAs nor loads (epilogues alone), 5 / 6 / 7 = no MFMAs with a ring of 2 / 8 units /
+// non-temporal loads
+template <int NACC, bool SAMEA, int ABL>
 __device__ __forceinline__ void ch_gemm(f32x16 (&acc)[NACC], const __bf16* img0, const __bf16* img1, unsigned base0, unsigned base1,
-                                        const ChNext nx, ChRing& R, const __amdgpu_buffer_rsrc_t wrs, const ChLane& L) {
-    constexpr int NU = 8 * NACC;
+                                        const ChNext nx, ChRing<CH_RING_OF(ABL)>& R, const __amdgpu_buffer_rsrc_t wrs, const ChLane& L) {
+    constexpr int NU = 8 * NACC, RING = CH_RING_OF(ABL), AUX = CH_AUX_OF(ABL);
+    static_assert(NU % RING == 0, "unit count must be a multiple of the ring depth");
     cbf16x8 ah[2], am[2], al[2];
 #pragma unroll 1
-    for (int u0 = 0; u0 < NU; u0 += 4) {
+    for (int u0 = 0; u0 < NU; u0 += RING) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RING; ++j) {
             const int u = u0 + j;
-            // request unit u + 3 into the slot unit u - 1 has left
-            const int un = u + 3;
-            if (un < NU) {
+            // request unit u + RING - 1 into the slot unit u - 1 has left
+            const int un = u + RING - 1;
+            if (CH_NOLOAD(ABL)) {
+            } else if (un < NU) {
                 const int an = (NACC == 2) ? (un & 1) : 0, ktn = (NACC == 2) ? (un >> 1) : un;
-                ch_wload(R, (j + 3) & 3, wrs, L, ((NACC == 2 && an) ? base1 : base0) + (unsigned)ktn * CH_WTILE);
+                ch_wload<RING, AUX>(R, (j + RING - 1) % RING, wrs, L, ((NACC == 2 && an) ? base1 : base0) + (unsigned)ktn * CH_WTILE);
             } else if (nx.nacc) {
-                ch_wload(R, (j + 3) & 3, wrs, L, nx.off(un - NU));
+                ch_wload<RING, AUX>(R, (j + RING - 1) % RING, wrs, L, nx.off(un - NU));
             }
-            // the request stays HERE, three units ahead of its use: without the fence the machine scheduler sinks every load to just
+            // the request stays HERE, RING - 1 units ahead of its use: without the fence the machine scheduler sinks every load to just
             // before its MFMA (load, s_waitcnt vmcnt(0), mfma) to save registers — the whole point of the ring
             __builtin_amdgcn_sched_barrier(0);
-            const int a = (NACC == 2) ? (j & 1) : 0, kt = (NACC == 2) ? (u >> 1) : u;
-            if (a == 0 || !SAMEA) {
+            const int a = (NACC == 2) ? (u & 1) : 0, kt = (NACC == 2) ? (u >> 1) : u;
+            if ((a == 0 || !SAMEA) && !(VKN_ABL_IS(ABL, 3) && u > 0)) {
                 const __bf16* img = (a == 0) ? img0 : img1;
                 ch_afrag(img, L, kt, 0, ah[0], am[0], al[0]);
                 ch_afrag(img, L, kt, 1, ah[1], am[1], al[1]);
             }
-            ch_mfma6(acc[a], R, j, 0, ah[0], am[0], al[0]);
-            ch_mfma6(acc[a], R, j, 1, ah[1], am[1], al[1]);
+            if (CH_NOMFMA(ABL)) {   // keep the loads and reads alive without the matrix pipe
+#pragma unroll
+                for (int f = 0; f < 6; ++f) asm volatile("" ::"v"(R.r[j][f]));
+                asm volatile("" ::"v"(ah[0]), "v"(am[0]), "v"(al[0]), "v"(ah[1]), "v"(am[1]), "v"(al[1]));
+            } else {
+                ch_mfma6(acc[a], R, j, 0, ah[0], am[0], al[0]);
+                ch_mfma6(acc[a], R, j, 1, ah[1], am[1], al[1]);
+            }
         }
     }
 }
@@ -297,18 +324,21 @@ __device__ __forceinline__ void ch_unpark(const float* P, float (&v)[16], int ti
     }
 }
 
-// constant vectors -> LDS: entry i copies n[i] floats from src[i] (NULL: fill with fill[i]) to cst + dst[i]
-#define CH_MAXTAB 20
-struct ChConstTab {
-    const float* src[CH_MAXTAB];
-    short dst[CH_MAXTAB], n[CH_MAXTAB];
-    float fill[CH_MAXTAB];
-    int count;
-};
-__device__ __forceinline__ void ch_stage_consts(float* cst, const ChConstTab& T, int tid) {
-    for (int i = 0; i < T.count; ++i) {
-        const float* s = T.src[i];
-        for (int k = tid; k < T.n[i]; k += CH_THREADS) cst[T.dst[i] + k] = s ? s[k] : T.fill[i];
+// the kernel's constant vectors -> LDS: ONE contiguous, 16-byte aligned block packed at prepare time (k_chain_pack), copied with all
+// loads in flight at once (a table of separate vectors cost one global round trip per vector: ~7 us per launch)
+template <int NF>  // floats, multiple of 4
+__device__ __forceinline__ void ch_stage_consts(float* cst, const float* __restrict__ src, int tid) {
+    constexpr int NV = NF / 4, PER = (NV + CH_THREADS - 1) / CH_THREADS;
+    f32x4 t[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = tid + i * CH_THREADS;
+        t[i] = *reinterpret_cast<const f32x4*>(src + 4 * min(k, NV - 1));
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = tid + i * CH_THREADS;
+        if (k < NV) *reinterpret_cast<f32x4*>(cst + 4 * k) = t[i];
     }
 }
 
@@ -340,9 +370,10 @@ struct ChainAArgs {
     int M;
     float* obj1;  // [M][256] out: updated kernels (residual of the attention block)
     float* qkv;   // [M][768] out: packed q | k | v
-    ChConstTab consts;
+    const float* consts;   // [CA_TOTAL] packed block (vkn_chain_pack_consts)
 };
 
+template <int ABL>
 __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_ca[];
     __bf16* IMG0 = reinterpret_cast<__bf16*>(smem_ca);
@@ -358,11 +389,15 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     const bool row_ok = row < M;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.wbase), 0, (int)A.wbytes, 0x00020000);
 
-    ChRing R;
-    ch_wload(R, 0, wrs, L, A.off_dyn);                    // unit 0: (kt 0, column tile 0)
-    ch_wload(R, 1, wrs, L, A.off_dyn + 8u * CH_WTILE);    // unit 1: (kt 0, column tile 1)
-    ch_wload(R, 2, wrs, L, A.off_dyn + CH_WTILE);         // unit 2: (kt 1, column tile 0)
-    ch_stage_consts(CST, A.consts, tid);
+    constexpr int RING = CH_RING_OF(ABL);
+    ChRing<RING> R;
+    {   // the first RING - 1 units of the dynamic_layer GEMM (unit u = column tile u & 1 of K-tile u >> 1)
+        const ChNext first{A.off_dyn, A.off_dyn + 8u * CH_WTILE, 2};
+#pragma unroll
+        for (int j = 0; j < RING - 1; ++j) ch_wload<RING, CH_AUX_OF(ABL)>(R, j, wrs, L, first.off(j));
+        if (CH_NOLOAD(ABL)) ch_wload<RING>(R, RING - 1, wrs, L, A.off_dyn);   // (ablation: the ring is never refilled; defined contents)
+    }
+    ch_stage_consts<CA_TOTAL>(CST, A.consts, tid);
     ch_img_load(IMG0, A.a0, CH_C, m0, M, tid);
     ch_img_load(IMG1, A.obj_in, CH_C, m0, M, tid);
     const float bs = A.rowscale ? A.rowscale[min(row, M - 1)] : 1.f;
@@ -374,7 +409,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     // ---- dynamic_layer(update feature): parameters_in | LN(parameters_out)                        knet/kernel_updator.py:59-62, :79
     ch_zero(acc[0]);
     ch_zero(acc[1]);
-    ch_gemm<2, true>(acc, IMG0, IMG0, A.off_dyn, A.off_dyn + 8u * CH_WTILE, ChNext{A.off_inp, A.off_inp + 8u * CH_WTILE, 2}, R, wrs, L);
+    ch_gemm<2, true, ABL>(acc, IMG0, IMG0, A.off_dyn, A.off_dyn + 8u * CH_WTILE, ChNext{A.off_inp, A.off_inp + 8u * CH_WTILE, 2}, R, wrs, L);
     {
         float b[16], b2[16], pin[16];
         ch_cols(CST + CA_DYN_B, L, b);
@@ -393,7 +428,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     // ---- input_layer(kernels): input_in | LN(input_out); gate = input_in * parameters_in -> image             :65-70, :80
     ch_zero(acc[0]);
     ch_zero(acc[1]);
-    ch_gemm<2, true>(acc, IMG1, IMG1, A.off_inp, A.off_inp + 8u * CH_WTILE, ChNext{A.off_ig, A.off_ug, 2}, R, wrs, L);
+    ch_gemm<2, true, ABL>(acc, IMG1, IMG1, A.off_inp, A.off_inp + 8u * CH_WTILE, ChNext{A.off_ig, A.off_ug, 2}, R, wrs, L);
     {
         float b[16], gate[16], iout[1][16];
         ch_cols(CST + CA_INP_B, L, b);
@@ -412,7 +447,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     // ---- input_gate / update_gate = sigmoid(LN(linear(gate))); features = update_gate * param_out + input_gate * input_out   :72-88
     ch_zero(acc[0]);
     ch_zero(acc[1]);
-    ch_gemm<2, true>(acc, IMG0, IMG0, A.off_ig, A.off_ug, ChNext{A.off_fc, 0u, 1}, R, wrs, L);
+    ch_gemm<2, true, ABL>(acc, IMG0, IMG0, A.off_ig, A.off_ug, ChNext{A.off_fc, 0u, 1}, R, wrs, L);
     {
         float gt[2][16], b[16];
         ch_cols(CST + CA_IG_B, L, b);
@@ -438,7 +473,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     // ---- fc_layer + fc_norm + ReLU -> updated kernels (obj1)                                                      :90-92
     f32x16 acc1[1];
     ch_zero(acc1[0]);
-    ch_gemm<1, true>(acc1, IMG1, IMG1, A.off_fc, 0u, ChNext{A.off_in, 0u, 1}, R, wrs, L);
+    ch_gemm<1, true, ABL>(acc1, IMG1, IMG1, A.off_fc, 0u, ChNext{A.off_in, 0u, 1}, R, wrs, L);
     {
         float o[1][16], b[16];
         ch_cols(CST + CA_FC_B, L, b);
@@ -459,7 +494,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
         asm volatile("" ::: "memory");   // the image reads are loop invariant: keep hipcc from hoisting all 48 fragments (192 VGPRs) out of the loop
         ch_zero(acc1[0]);
         const ChNext nx = (t < 2) ? ChNext{A.off_in + (unsigned)(t + 1) * 8u * CH_WTILE, 0u, 1} : ChNext{0u, 0u, 0};
-        ch_gemm<1, true>(acc1, IMG0, IMG0, A.off_in + (unsigned)t * 8u * CH_WTILE, 0u, nx, R, wrs, L);
+        ch_gemm<1, true, ABL>(acc1, IMG0, IMG0, A.off_in + (unsigned)t * 8u * CH_WTILE, 0u, nx, R, wrs, L);
         float o[16], b[16];
         ch_cols(CST + CA_IN_B + 256 * t, L, b);
 #pragma unroll
@@ -501,9 +536,10 @@ struct ChainCArgs {
     _Float16* plane_lo;
     float* kern_out;     // ... fp32 [M][256]
     int rows_per_frame, NPT;
-    ChConstTab consts;
+    const float* consts;   // [CC_TOTAL] packed block
 };
 
+template <int ABL>
 __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_cc[];
     __bf16* IMG0 = reinterpret_cast<__bf16*>(smem_cc);
@@ -519,11 +555,15 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     const int rowc = min(row, M - 1);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.wbase), 0, (int)A.wbytes, 0x00020000);
 
-    ChRing R;
-    ch_wload(R, 0, wrs, L, A.off_out);
-    ch_wload(R, 1, wrs, L, A.off_out + CH_WTILE);
-    ch_wload(R, 2, wrs, L, A.off_out + 2u * CH_WTILE);
-    ch_stage_consts(CST, A.consts, tid);
+    constexpr int RING = CH_RING_OF(ABL);
+    ChRing<RING> R;
+    {
+        const ChNext first{A.off_out, 0u, 1};
+#pragma unroll
+        for (int j = 0; j < RING - 1; ++j) ch_wload<RING, CH_AUX_OF(ABL)>(R, j, wrs, L, first.off(j));
+        if (CH_NOLOAD(ABL)) ch_wload<RING>(R, RING - 1, wrs, L, A.off_out);
+    }
+    ch_stage_consts<CC_TOTAL>(CST, A.consts, tid);
     ch_img_load(IMG0, A.ao, CH_C, m0, M, tid);
     float obj[1][16];   // residual rows in the transposed-tile layout
     {
@@ -541,7 +581,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     f32x16 acc1[1];
     // ---- attention out_proj + identity + attention_norm                                           knet/det/kernel_update_head.py:206-208
     ch_zero(acc1[0]);
-    ch_gemm<1, true>(acc1, IMG0, IMG0, A.off_out, 0u, ChNext{A.off_ffn1, 0u, 1}, R, wrs, L);
+    ch_gemm<1, true, ABL>(acc1, IMG0, IMG0, A.off_out, 0u, ChNext{A.off_ffn1, 0u, 1}, R, wrs, L);
     {
         float b[16];
         ch_cols(CST + CC_OUT_B, L, b);
@@ -559,7 +599,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
 #pragma unroll 1
     for (int c = 0; c < A.nchunks; ++c) {
         ch_zero(acc1[0]);
-        ch_gemm<1, true>(acc1, IMG0, IMG0, A.off_ffn1 + (unsigned)c * 8u * CH_WTILE, 0u,
+        ch_gemm<1, true, ABL>(acc1, IMG0, IMG0, A.off_ffn1 + (unsigned)c * 8u * CH_WTILE, 0u,
                          ChNext{A.off_ffn2 + (unsigned)c * 8u * CH_WTILE, 0u, 1}, R, wrs, L);
         float h[16], b[16];
         ch_cols(CST + CC_B1 + 256 * c, L, b);
@@ -570,7 +610,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
         CH_BAR();
         const bool lastc = (c + 1 == A.nchunks);
         const ChNext nx = lastc ? ChNext{A.off_clsfc, A.off_maskfc, 2} : ChNext{A.off_ffn1 + (unsigned)(c + 1) * 8u * CH_WTILE, 0u, 1};
-        ch_gemm<1, true>(acc2, HID, HID, A.off_ffn2 + (unsigned)c * 8u * CH_WTILE, 0u, nx, R, wrs, L);
+        ch_gemm<1, true, ABL>(acc2, HID, HID, A.off_ffn2 + (unsigned)c * 8u * CH_WTILE, 0u, nx, R, wrs, L);
     }
     {
         float b[16];
@@ -589,7 +629,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     ch_zero(acc[0]);
     ch_zero(acc[1]);
     const ChNext nfin = A.has_cls ? ChNext{A.off_fccls, A.off_dec, 2} : ChNext{A.off_dec, 0u, 1};
-    ch_gemm<2, true>(acc, IMG0, IMG0, A.off_clsfc, A.off_maskfc, nfin, R, wrs, L);
+    ch_gemm<2, true, ABL>(acc, IMG0, IMG0, A.off_clsfc, A.off_maskfc, nfin, R, wrs, L);
     {
         float t[2][16];
 #pragma unroll
@@ -619,7 +659,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     ch_zero(acc[0]);
     ch_zero(acc[1]);
     if (A.has_cls) {
-        ch_gemm<2, false>(acc, IMG0, HID, A.off_fccls, A.off_dec, ChNext{0u, 0u, 0}, R, wrs, L);
+        ch_gemm<2, false, ABL>(acc, IMG0, HID, A.off_fccls, A.off_dec, ChNext{0u, 0u, 0}, R, wrs, L);
         if (L.wave * 32 < A.ncls && row_ok && A.cls_out) {
             float b[16];
             ch_cols(CST + CC_CLS_B, L, b);
@@ -634,7 +674,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     } else {
         f32x16 accd[1];
         ch_zero(accd[0]);
-        ch_gemm<1, true>(accd, HID, HID, A.off_dec, 0u, ChNext{0u, 0u, 0}, R, wrs, L);
+        ch_gemm<1, true, ABL>(accd, HID, HID, A.off_dec, 0u, ChNext{0u, 0u, 0}, R, wrs, L);
         acc[1] = accd[0];
     }
     {
@@ -667,43 +707,106 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ host launchers
-static void ch_tab_add(ChConstTab& T, const float* src, int dst, int n, float fill) {
+// constant blocks: packed once per weight update into the prepared buffer (vkn_prepare_stage_f32)
+#define CH_PACK_MAX 64
+struct ChPackTab {
+    const float* src[CH_PACK_MAX];
+    int dst[CH_PACK_MAX], n[CH_PACK_MAX];
+    float fill[CH_PACK_MAX];
+    int count;
+};
+__global__ __launch_bounds__(256) void k_chain_pack(const ChPackTab T, float* __restrict__ out) {
+    const int i = blockIdx.x;
+    const float* s = T.src[i];
+    for (int k = threadIdx.x; k < T.n[i]; k += 256) out[T.dst[i] + k] = s ? s[k] : T.fill[i];
+}
+static void ch_tab_add(ChPackTab& T, const float* src, int dst, int n, float fill) {
+    if (T.count >= CH_PACK_MAX) return;   // (50 entries today; the launcher checks the count)
     const int i = T.count++;
     T.src[i] = src;
-    T.dst[i] = (short)dst;
-    T.n[i] = (short)n;
+    T.dst[i] = dst;
+    T.n[i] = n;
     T.fill[i] = fill;
 }
 
+size_t vkn_chain_consts_floats() { return (size_t)2 * CA_TOTAL + CC_TOTAL; }
+
+// out: [A block, raw-gather mode (dyn bias = bcnt scaled per row + dyn_b) | A block, x_feat mode (dyn bias = dyn_b) | C block]
+int vkn_chain_pack_consts(const VknChainConsts& c, float* out, hipStream_t stream) {
+    if (!out || c.ff <= 0 || c.ff > 2048 || c.ncls < 0 || c.ncls > 256) return VKN_E_ARG;
+    ChPackTab T;
+    T.count = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+        const int o = mode * CA_TOTAL;
+        ch_tab_add(T, mode == 0 ? c.bcnt : c.dyn_b, o + CA_DYN_B, 512, 0.f);
+        ch_tab_add(T, mode == 0 ? c.dyn_b : nullptr, o + CA_DYN_B2, 512, 0.f);
+        ch_tab_add(T, c.norm_out_w, o + CA_NO_W, 256, 1.f);   ch_tab_add(T, c.norm_out_b, o + CA_NO_B, 256, 0.f);
+        ch_tab_add(T, c.inp_b, o + CA_INP_B, 512, 0.f);
+        ch_tab_add(T, c.inorm_out_w, o + CA_INO_W, 256, 1.f); ch_tab_add(T, c.inorm_out_b, o + CA_INO_B, 256, 0.f);
+        ch_tab_add(T, c.ig_b, o + CA_IG_B, 256, 0.f);
+        ch_tab_add(T, c.inorm_in_w, o + CA_INI_W, 256, 1.f);  ch_tab_add(T, c.inorm_in_b, o + CA_INI_B, 256, 0.f);
+        ch_tab_add(T, c.ug_b, o + CA_UG_B, 256, 0.f);
+        ch_tab_add(T, c.norm_in_w, o + CA_NI_W, 256, 1.f);    ch_tab_add(T, c.norm_in_b, o + CA_NI_B, 256, 0.f);
+        ch_tab_add(T, c.fc_b, o + CA_FC_B, 256, 0.f);
+        ch_tab_add(T, c.fc_norm_w, o + CA_FCN_W, 256, 1.f);   ch_tab_add(T, c.fc_norm_b, o + CA_FCN_B, 256, 0.f);
+        ch_tab_add(T, c.in_b, o + CA_IN_B, 768, 0.f);
+    }
+    const int o = 2 * CA_TOTAL;
+    ch_tab_add(T, c.out_b, o + CC_OUT_B, 256, 0.f);
+    ch_tab_add(T, c.attn_norm_w, o + CC_AN_W, 256, 1.f);  ch_tab_add(T, c.attn_norm_b, o + CC_AN_B, 256, 0.f);
+    ch_tab_add(T, c.ffn2_b, o + CC_B2, 256, 0.f);
+    ch_tab_add(T, c.ffn_norm_w, o + CC_FN_W, 256, 1.f);   ch_tab_add(T, c.ffn_norm_b, o + CC_FN_B, 256, 0.f);
+    ch_tab_add(T, c.cls_ln_w, o + CC_CLN_W, 256, 1.f);    ch_tab_add(T, c.cls_ln_b, o + CC_CLN_B, 256, 0.f);
+    ch_tab_add(T, c.mask_ln_w, o + CC_MLN_W, 256, 1.f);   ch_tab_add(T, c.mask_ln_b, o + CC_MLN_B, 256, 0.f);
+    ch_tab_add(T, c.dvec, o + CC_DVEC, 256, 0.f);
+    ch_tab_add(T, c.fc_cls_b, o + CC_CLS_B, c.fc_cls_b ? c.ncls : 0, 0.f);
+    ch_tab_add(T, nullptr, o + CC_CLS_B + (c.fc_cls_b ? c.ncls : 0), 256 - (c.fc_cls_b ? c.ncls : 0), 0.f);   // zero pad
+    ch_tab_add(T, c.dec_b, o + CC_DEC_B, 256, 0.f);
+    ch_tab_add(T, c.ffn1_b, o + CC_B1, c.ff, 0.f);
+    ch_tab_add(T, nullptr, o + CC_B1 + c.ff, 2048 - c.ff, 0.f);
+    if (T.count >= CH_PACK_MAX) return VKN_E_ARG;
+    hipLaunchKernelGGL(k_chain_pack, dim3(T.count), dim3(256), 0, stream, T, out);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
 int vkn_launch_chain_a(const VknChainA& p, hipStream_t stream) {
-    if (!p.a0 || !p.obj_in || !p.wbase || !p.obj1 || !p.qkv || p.M <= 0 || p.wbytes >= (1ull << 31)) return VKN_E_ARG;
+    if (!p.a0 || !p.obj_in || !p.wbase || !p.obj1 || !p.qkv || !p.consts || p.M <= 0 || p.wbytes >= (1ull << 31)) return VKN_E_ARG;
     ChainAArgs A{};
     A.a0 = p.a0; A.obj_in = p.obj_in; A.rowscale = p.rowscale; A.wbase = p.wbase; A.wbytes = (unsigned)p.wbytes;
     A.off_dyn = p.off_dyn; A.off_inp = p.off_inp; A.off_ig = p.off_ig; A.off_ug = p.off_ug; A.off_fc = p.off_fc; A.off_in = p.off_in;
     A.eps = p.eps; A.M = p.M; A.obj1 = p.obj1; A.qkv = p.qkv;
-    ChConstTab& T = A.consts;
-    T.count = 0;
-    ch_tab_add(T, p.dyn_bias, CA_DYN_B, 512, 0.f);
-    ch_tab_add(T, p.dyn_bias2, CA_DYN_B2, 512, 0.f);
-    ch_tab_add(T, p.norm_out_w, CA_NO_W, 256, 1.f);   ch_tab_add(T, p.norm_out_b, CA_NO_B, 256, 0.f);
-    ch_tab_add(T, p.inp_b, CA_INP_B, 512, 0.f);
-    ch_tab_add(T, p.inorm_out_w, CA_INO_W, 256, 1.f); ch_tab_add(T, p.inorm_out_b, CA_INO_B, 256, 0.f);
-    ch_tab_add(T, p.ig_b, CA_IG_B, 256, 0.f);
-    ch_tab_add(T, p.inorm_in_w, CA_INI_W, 256, 1.f);  ch_tab_add(T, p.inorm_in_b, CA_INI_B, 256, 0.f);
-    ch_tab_add(T, p.ug_b, CA_UG_B, 256, 0.f);
-    ch_tab_add(T, p.norm_in_w, CA_NI_W, 256, 1.f);    ch_tab_add(T, p.norm_in_b, CA_NI_B, 256, 0.f);
-    ch_tab_add(T, p.fc_b, CA_FC_B, 256, 0.f);
-    ch_tab_add(T, p.fc_norm_w, CA_FCN_W, 256, 1.f);   ch_tab_add(T, p.fc_norm_b, CA_FCN_B, 256, 0.f);
-    ch_tab_add(T, p.in_b, CA_IN_B, 768, 0.f);
+    A.consts = p.consts + (p.rowscale ? 0 : CA_TOTAL);
     const size_t lds = (size_t)2 * CH_IMG * sizeof(__bf16) + (size_t)(2 * CH_SBUF + CA_TOTAL + 16 * CH_THREADS) * sizeof(float);
-    VKN_ALLOW_FULL_LDS(k_chain_a);
-    hipLaunchKernelGGL(k_chain_a, dim3((p.M + CH_ROWS - 1) / CH_ROWS), dim3(CH_THREADS), lds, stream, A);
+#define CHA_LAUNCH(ABLV)                                                                                            \
+    do {                                                                                                            \
+        VKN_ALLOW_FULL_LDS(k_chain_a<ABLV>);                                                                        \
+        hipLaunchKernelGGL(k_chain_a<ABLV>, dim3((p.M + CH_ROWS - 1) / CH_ROWS), dim3(CH_THREADS), lds, stream, A); \
+    } while (0)
+#ifdef VKN_DEBUG
+    switch (vkn_dbg_env("VKN_CHAIN_ABL", 0)) {
+        case 1: CHA_LAUNCH(1); break;
+        case 2: CHA_LAUNCH(2); break;
+        case 3: CHA_LAUNCH(3); break;
+        case 4: CHA_LAUNCH(4); break;
+        case 5: CHA_LAUNCH(5); break;
+        case 6: CHA_LAUNCH(6); break;
+        case 7: CHA_LAUNCH(7); break;
+        case 8: CHA_LAUNCH(8); break;
+        case 9: CHA_LAUNCH(9); break;
+        case 10: CHA_LAUNCH(10); break;
+        default: CHA_LAUNCH(0); break;
+    }
+#else
+    CHA_LAUNCH(0);
+#endif
+#undef CHA_LAUNCH
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
 
 int vkn_launch_chain_c(const VknChainC& p, hipStream_t stream) {
-    if (!p.ao || !p.obj1 || !p.wbase || !p.obj_out || p.M <= 0 || p.wbytes >= (1ull << 31)) return VKN_E_ARG;
+    if (!p.ao || !p.obj1 || !p.wbase || !p.obj_out || !p.consts || p.M <= 0 || p.wbytes >= (1ull << 31)) return VKN_E_ARG;
     if (p.ff <= 0 || p.ff % 256 != 0 || p.ff > 2048 || p.ncls > 256) return VKN_E_SHAPE;
     if (!p.plane_hi == !p.kern_out || (p.plane_hi && !p.plane_lo)) return VKN_E_ARG;   // exactly one output form of the decode kernels
     ChainCArgs A{};
@@ -713,22 +816,31 @@ int vkn_launch_chain_c(const VknChainC& p, hipStream_t stream) {
     A.nchunks = p.ff / 256; A.has_cls = (p.cls_out != nullptr) ? 1 : 0; A.cls_sigmoid = p.cls_sigmoid; A.ncls = p.ncls;
     A.eps = p.eps; A.M = p.M; A.kb0 = p.kb0; A.obj_out = p.obj_out; A.cls_out = p.cls_out; A.kb_out = p.kb_out;
     A.plane_hi = p.plane_hi; A.plane_lo = p.plane_lo; A.kern_out = p.kern_out; A.rows_per_frame = p.rows_per_frame; A.NPT = p.NPT;
-    ChConstTab& T = A.consts;
-    T.count = 0;
-    ch_tab_add(T, p.out_b, CC_OUT_B, 256, 0.f);
-    ch_tab_add(T, p.attn_norm_w, CC_AN_W, 256, 1.f);  ch_tab_add(T, p.attn_norm_b, CC_AN_B, 256, 0.f);
-    ch_tab_add(T, p.ffn2_b, CC_B2, 256, 0.f);
-    ch_tab_add(T, p.ffn_norm_w, CC_FN_W, 256, 1.f);   ch_tab_add(T, p.ffn_norm_b, CC_FN_B, 256, 0.f);
-    ch_tab_add(T, p.cls_ln_w, CC_CLN_W, 256, 1.f);    ch_tab_add(T, p.cls_ln_b, CC_CLN_B, 256, 0.f);
-    ch_tab_add(T, p.mask_ln_w, CC_MLN_W, 256, 1.f);   ch_tab_add(T, p.mask_ln_b, CC_MLN_B, 256, 0.f);
-    ch_tab_add(T, p.dvec, CC_DVEC, 256, 0.f);
-    ch_tab_add(T, nullptr, CC_CLS_B, 256, 0.f);                                   // zero pad, then the ncls real entries
-    if (p.fc_cls_b && p.cls_out) ch_tab_add(T, p.fc_cls_b, CC_CLS_B, p.ncls, 0.f);
-    ch_tab_add(T, p.dec_b, CC_DEC_B, 256, 0.f);
-    ch_tab_add(T, p.ffn1_b, CC_B1, p.ff, 0.f);
+    A.consts = p.consts + 2 * CA_TOTAL;
     const size_t lds = (size_t)2 * CH_IMG * sizeof(__bf16) + (size_t)(2 * CH_SBUF + CC_TOTAL) * sizeof(float);
-    VKN_ALLOW_FULL_LDS(k_chain_c);
-    hipLaunchKernelGGL(k_chain_c, dim3((p.M + CH_ROWS - 1) / CH_ROWS), dim3(CH_THREADS), lds, stream, A);
+#define CHC_LAUNCH(ABLV)                                                                                            \
+    do {                                                                                                            \
+        VKN_ALLOW_FULL_LDS(k_chain_c<ABLV>);                                                                        \
+        hipLaunchKernelGGL(k_chain_c<ABLV>, dim3((p.M + CH_ROWS - 1) / CH_ROWS), dim3(CH_THREADS), lds, stream, A); \
+    } while (0)
+#ifdef VKN_DEBUG
+    switch (vkn_dbg_env("VKN_CHAIN_ABL", 0)) {
+        case 1: CHC_LAUNCH(1); break;
+        case 2: CHC_LAUNCH(2); break;
+        case 3: CHC_LAUNCH(3); break;
+        case 4: CHC_LAUNCH(4); break;
+        case 5: CHC_LAUNCH(5); break;
+        case 6: CHC_LAUNCH(6); break;
+        case 7: CHC_LAUNCH(7); break;
+        case 8: CHC_LAUNCH(8); break;
+        case 9: CHC_LAUNCH(9); break;
+        case 10: CHC_LAUNCH(10); break;
+        default: CHC_LAUNCH(0); break;
+    }
+#else
+    CHC_LAUNCH(0);
+#endif
+#undef CHC_LAUNCH
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

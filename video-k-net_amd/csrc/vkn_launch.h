@@ -106,18 +106,26 @@ int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const f
                               int* panoptic_seg, int* info, int* nseg, int* bbox, void* ws, size_t ws_bytes, hipStream_t st);
 
 // ---- persistent row-owner chain kernels (vkn_chain.hip): C == 256, pre-split weights.  `off_*` are byte offsets of tile images
-// inside the prepared weight buffer `wbase` (vkn_prepare_stage_f32).
-struct VknChainA {   // KernelUpdator + attention in_proj
-    const float* a0;        // [M][256] update feature (raw gather with composite weights, else x_feat)
-    const float* obj_in;    // [M][256]
-    const float* rowscale;  // [M] or NULL: scales dyn_bias per row (pixel count x folded feat_transform bias)
-    const void* wbase;
-    size_t wbytes;
-    unsigned off_dyn, off_inp, off_ig, off_ug, off_fc, off_in;
-    const float *dyn_bias, *dyn_bias2;                    // [512] (scaled), [512] or NULL
+// inside the prepared weight buffer `wbase` (vkn_prepare_stage_f32); `consts` is the packed constant block (vkn_chain_pack_consts).
+struct VknChainConsts {   // every bias / LayerNorm vector the two kernels read (NULL: zeros / ones)
+    const float *bcnt, *dyn_b;                            // [512]: W_dyn.b_ft (scaled by the pixel count), dynamic_layer bias
     const float *norm_out_w, *norm_out_b, *inp_b, *inorm_out_w, *inorm_out_b;
     const float *ig_b, *inorm_in_w, *inorm_in_b, *ug_b, *norm_in_w, *norm_in_b;
     const float *fc_b, *fc_norm_w, *fc_norm_b, *in_b;     // in_b [768]
+    const float *out_b, *attn_norm_w, *attn_norm_b, *ffn1_b, *ffn2_b, *ffn_norm_w, *ffn_norm_b;
+    const float *cls_ln_w, *cls_ln_b, *mask_ln_w, *mask_ln_b, *dvec, *fc_cls_b, *dec_b;
+    int ff, ncls;
+};
+size_t vkn_chain_consts_floats();
+int vkn_chain_pack_consts(const VknChainConsts& c, float* out, hipStream_t stream);
+struct VknChainA {   // KernelUpdator + attention in_proj
+    const float* a0;        // [M][256] update feature (raw gather with composite weights, else x_feat)
+    const float* obj_in;    // [M][256]
+    const float* rowscale;  // [M] pixel counts: a0 is the RAW gather (dynamic bias = bcnt x count + dyn_b); NULL: a0 is x_feat
+    const void* wbase;
+    size_t wbytes;
+    unsigned off_dyn, off_inp, off_ig, off_ug, off_fc, off_in;
+    const float* consts;
     float eps;
     int M;
     float* obj1;  // [M][256]
@@ -129,8 +137,8 @@ struct VknChainC {   // attention out_proj + LN, FFN + LN, cls / mask FCs, fc_cl
     const void* wbase;
     size_t wbytes;
     unsigned off_out, off_ffn1, off_ffn2, off_clsfc, off_maskfc, off_fccls, off_dec;
-    const float *out_b, *attn_norm_w, *attn_norm_b, *ffn1_b, *ffn2_b, *ffn_norm_w, *ffn_norm_b;
-    const float *cls_ln_w, *cls_ln_b, *mask_ln_w, *mask_ln_b, *dvec, *kb0, *fc_cls_b, *dec_b;
+    const float* consts;
+    const float* kb0;     // device scalar b_fm . b_ft
     int ff, ncls, cls_sigmoid;
     float eps;
     int M;

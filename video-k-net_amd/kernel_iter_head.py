@@ -143,7 +143,7 @@ class KernelIterHead(BaseRoIHead):
         link_pre, link_track, track_src = hl.link_packs(x.device) if (prev is not None or clip_first_prev is not None) else (None, None, 0)
         obj, cls, masks, scaled, track = ops.head_forward(dims, packs, x, proposal_feats.reshape(B, N, C), mask_preds, prev,
                                                           hl.mask_upsample_stride, want_track=want_track, want_scaled=want_scaled,
-                                                          flags=flags, clip_first_prev=clip_first_prev, link_pre=link_pre,
+                                                          flags=flags | getattr(h0, 'vkn_flags', 0), clip_first_prev=clip_first_prev, link_pre=link_pre,
                                                           link_track=link_track, track_src=track_src)
         if not hl.loss_cls.use_sigmoid:
             raise NotImplementedError('softmax cls activation (reference :309-310): every shipped config uses sigmoid')

@@ -257,6 +257,7 @@ class KernelUpdateHead(nn.Module):
         self.fc_mask = nn.Linear(in_channels, out_channels)
         self._init_video(num_ffn_fcs=num_ffn_fcs, **video_kwargs)
         self._chain_graphs = None      # see enable_chain_graphs()
+        self.vkn_flags = 0             # extra VKN_FLAG_* bits of every C call of this stage (e.g. ops.FLAG_CHAIN_PERSISTENT: A/B, tests)
         self._pack = None
         self._pack_sig = None
 
@@ -493,7 +494,7 @@ class KernelUpdateHead(nn.Module):
         link_pre, link_track, track_src = self.link_packs(x.device) if prev is not None else (None, None, 0)
         cls, masks, obj, xfeat, track = ops.stage_forward(dims, self.stage_pack(x.device), x, obj_in, mask_preds, prev,
                                                           want_track=prev is not None and self.previous_type is not None,
-                                                          flags=flags, link_pre=link_pre, link_track=link_track, track_src=track_src)
+                                                          flags=flags | getattr(self, 'vkn_flags', 0), link_pre=link_pre, link_track=link_track, track_src=track_src)
         obj = obj.reshape(B, N, C, K, K)
         if track is not None:
             track = track.reshape(B, N, C, K, K)

@@ -17,7 +17,8 @@ FLAG_REF_KERNELS = 1
 FLAG_EXACT_GEMM = 2
 FLAG_LOGITS_HANDOFF = 4
 FLAG_BITS_HANDOFF = 16
-FLAG_CHAIN_LAUNCHES = 256  # the [N x C] chain as one launch per GEMM instead of the persistent row-owner kernels (A/B)
+FLAG_CHAIN_LAUNCHES = 256    # the [N x C] chain always as one launch per GEMM (default: by row count, include/vkn.h)
+FLAG_CHAIN_PERSISTENT = 512  # ... always as the two persistent row-owner kernels (vkn_chain.hip)
 FLAG_SERIAL_LINK = 32   # tracking link on the caller's stream instead of the library's side stream (A/B; same results)
 
 _tls = threading.local()
