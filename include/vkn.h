@@ -20,7 +20,7 @@
  *   - layouts: x [B][C][P] fp32 (NCHW, P = H*W); mask logits [B][N][P] fp32; kernels / object features [B][N][C] fp32
  *     (the reference's [B,N,C,1,1] with conv_kernel_size K = 1, the only value in any shipped config).
  *   - arithmetic: fp32 storage; gather / decode contract on MFMA with an f16 hi+lo operand split and fp32 accumulation
- *     (2^-22 relative operand error, requires |x| < 65504); the [N x C] GEMMs are exact-fp32 MFMA, or bf16 MFMA on a
+ *     (2^-22 relative operand error, requires |x| < 65504: watched by the workspace status word, VKN_STATUS_RANGE); the [N x C] GEMMs are exact-fp32 MFMA, or bf16 MFMA on a
  *     three-term operand split (2^-24 relative, full fp32 range) when pre-split weights are supplied (VknStageWeights.prepared).
  *     flags & VKN_FLAG_REF_KERNELS selects plain fp32 FMA kernels for gather / decode (slow, exact; debugging).
  */
@@ -41,6 +41,16 @@ extern "C" {
 #define VKN_E_WORKSPACE (-3) /* ws too small or NULL */
 #define VKN_E_LAUNCH (-4)    /* HIP launch error */
 #define VKN_E_ALIGN (-5)     /* pointer not 16-byte aligned */
+#define VKN_E_RANGE (-6)     /* vkn_workspace_status: the feature map left the f16-split envelope (|x| >= 65504 or non-finite) */
+
+/* Status word = the first four bytes of every stage / head / chain workspace (`ws`).  Kernels only ever OR bits into it; the CALLER
+ * zeroes it once (vkn_workspace_init, or a memset of the first 256 bytes) and reads it when it wants to pay for a synchronisation
+ * (vkn_workspace_status).  Bits: */
+#define VKN_STATUS_RANGE 1u  /* a mask gather of a vkn_stage_* / vkn_head_* call produced a non-finite sum: some |x| >= 65504 (the f16
+                              * hi/lo split turns it into inf, and inf x {0,1} reaches EVERY kernel row of that frame) or x itself was
+                              * non-finite.  The outputs of that call are garbage.  Checked in the fixed-order reduction that ends
+                              * every gather (one compare per [B][N][C] output value: free); the stand-alone op entry points
+                              * (vkn_mask_gather_f32, vkn_mask_decode_f32 ...) do not check. */
 
 #define VKN_FLAG_REF_KERNELS 1u /* exact-fp32 FMA gather/decode kernels instead of the MFMA ones */
 #define VKN_FLAG_EXACT_GEMM 2u  /* exact-fp32 MFMA for the [N x C] GEMMs even when pre-split weights are supplied */
@@ -123,6 +133,10 @@ typedef struct VknStageWeights {
 
 int vkn_version(void);
 const char* vkn_strerror(int code);
+/* zero the 256-byte header of a workspace (asynchronous on `stream`) / synchronise `stream`, read AND CLEAR the status word:
+ * VKN_OK, or VKN_E_RANGE when VKN_STATUS_RANGE was set since the last clear */
+int vkn_workspace_init(void* ws, size_t ws_bytes, void* stream);
+int vkn_workspace_status(void* ws, size_t ws_bytes, void* stream);
 /* sizeof(VknDims) / sizeof(VknStageWeights) as compiled — lets a foreign-language binding verify its struct mirror */
 size_t vkn_sizeof_dims(void);
 size_t vkn_sizeof_stage_weights(void);

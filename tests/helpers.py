@@ -8,6 +8,7 @@ from oracle import synth
 from oracle.knet_oracle import HeadCfg, head_param_shapes, iter_head_mask_preds
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASE_FIELDS = ('C', 'heads', 'ffn', 'ncls', 'n_thing', 'n_stuff', 'S', 'up', 'nprop', 'N', 'H', 'W', 'B', 'seed', 'video')
 
 
@@ -112,3 +113,26 @@ def load_assign_golden(name):
 
 def make_assign_case(case):
     return tuple(torch.from_numpy(a) for a in synth.assign_inputs(case['N'], case['G'], case['ncls'], case['H'], case['W'], case['seed']))
+
+
+# ---- measured parity margins: the free-running tests record WHAT they measured, not only pass / fail; the file is
+# rewritten after every record so that a partial run still leaves evidence.  Copied to profiles/r04_parity_margins.json by hand.
+_MARGINS = {}
+
+
+def record_margins(test_id, values):
+    import json
+    _MARGINS[test_id] = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v) for k, v in values.items()}
+    path = os.environ.get('VKN_MARGINS_JSON', os.path.join(ROOT, 'gpurun_out', 'parity_margins.json'))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(_MARGINS)
+        with open(path, 'w') as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print(f'[margins] {test_id}: ' + ', '.join(f'{k}={v:.3g}' if isinstance(v, float) else f'{k}={v}' for k, v in _MARGINS[test_id].items()))

@@ -25,6 +25,7 @@ struct StageWs {
     float *part, *cntp, *xraw, *cnt, *xfeat, *params, *inputf, *ig, *ug, *f, *obj1, *qkv, *ao, *obj2, *h, *partial, *t1, *t2,
         *maskfeat, *kb, *kern32, *lq, *lkv, *lobj, *lupd, *lf;
     _Float16 *kfh, *kfl;
+    int* status;   // the workspace's status word: its FIRST four bytes (include/vkn.h: vkn_workspace_status)
 };
 
 // Optional previous-frame blocks of the video head's LAST stage (knet/video/kernel_update_head.py:192-236).  A "link block" is
@@ -136,6 +137,7 @@ size_t carve_stage(const VknDims* d, char* base, StageWs* s) {
     Carver c{base, 0};
     const size_t B = d->B, N = d->N, C = d->C, P = (size_t)d->H * d->W, M = B * N, FF = d->ff;
     const size_t G = vkn_gather_groups(d->B, (int)P), NPT = npt_of(d->N);
+    s->status = c.take<int>(64);   // offset 0 of every stage / head / chain workspace (256-byte header)
     s->part = c.take<float>(B * G * NPT * C);
     s->cntp = c.take<float>(B * G * NPT);
     s->xraw = c.take<float>(M * C);
@@ -445,9 +447,9 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     } else if (ref)
         VKN_TRY(vkn_launch_gather_ref(x, masks_in, d->thr_logit, s.xraw, s.cnt, B, N, C, P, st));
     else if (bits_in)
-        VKN_TRY(vkn_launch_gather_bits(x, bits_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt));
+        VKN_TRY(vkn_launch_gather_bits(x, bits_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status));
     else
-        VKN_TRY(vkn_launch_gather(x, masks_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt));
+        VKN_TRY(vkn_launch_gather(x, masks_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status));
 
     // folded feat_transform: x_feat = xraw . W_ft^T + cnt (x) b_ft             (:179-180 folded).  With the
     // composite weights x_feat itself is only materialised when the caller asks for it.
@@ -488,7 +490,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         } else if (skip_decode) {
         } else if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
         else if (gather_out)
-            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt));
+            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status));
         else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
         else VKN_TRY(decode_final(kb));
         if (prev_obj && track_out) {
@@ -568,7 +570,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             // the caller decodes all frames at once (frame-sequential last stage)
         } else if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
         else if (gather_out)
-            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt));
+            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status));
         else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
         else VKN_TRY(decode_final(kb));
     } else {
@@ -616,7 +618,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             if (skip_decode) {
             } else if (gather_out)
                 VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P,
-                                                       st, xdt));
+                                                       st, xdt, s.status));
             else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
             else VKN_TRY(decode_final(kb));
         }
@@ -684,6 +686,8 @@ const char* vkn_strerror(int code) {
         case VKN_E_WORKSPACE: return "workspace missing or too small";
         case VKN_E_LAUNCH: return "HIP launch failed";
         case VKN_E_ALIGN: return "pointer not 16-byte aligned";
+        case VKN_E_RANGE:
+            return "feature map outside the f16-split envelope: |x| >= 65504 or a non-finite x reached a mask gather (its sums are not finite)";
         default: return "unknown error";
     }
 }
@@ -1003,6 +1007,22 @@ int vkn_kernel_updator_f32(const VknDims* d, const VknStageWeights* w, const flo
     return run_updator(d, w, pw, update_feature, nullptr, nullptr, input_feature, out, s, static_cast<hipStream_t>(stream));
 }
 
+int vkn_workspace_init(void* ws, size_t ws_bytes, void* stream) {
+    if (!ws || ws_bytes < 256) return VKN_E_WORKSPACE;
+    return hipMemsetAsync(ws, 0, 256, static_cast<hipStream_t>(stream)) == hipSuccess ? VKN_OK : VKN_E_LAUNCH;
+}
+
+int vkn_workspace_status(void* ws, size_t ws_bytes, void* stream) {
+    if (!ws || ws_bytes < 256) return VKN_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int word = 0;
+    if (hipMemcpyAsync(&word, ws, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return VKN_E_LAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return VKN_E_LAUNCH;
+    if (word == 0) return VKN_OK;
+    if (hipMemsetAsync(ws, 0, sizeof(int), st) != hipSuccess) return VKN_E_LAUNCH;   // read-and-clear
+    return (word & VKN_STATUS_RANGE) ? VKN_E_RANGE : VKN_E_LAUNCH;
+}
+
 size_t vkn_stage_workspace_bytes(const VknDims* d) {
     if (check_dims(d) != VKN_OK) return 0;
     StageWs s;
@@ -1302,8 +1322,8 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
             const int B = d->B, N = d->N, C = d->C, P = d->H * d->W;
             if (!(use_fused && sidx > 0)) {  // the stage's gather for all frames (run_stage's step (i))
                 if (flags & VKN_FLAG_REF_KERNELS) VKN_TRY(vkn_launch_gather_ref(x, m_in, d->thr_logit, s.xraw, s.cnt, B, N, C, P, st));
-                else if (b_in) VKN_TRY(vkn_launch_gather_bits(x, b_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt_of(flags)));
-                else VKN_TRY(vkn_launch_gather(x, m_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt_of(flags)));
+                else if (b_in) VKN_TRY(vkn_launch_gather_bits(x, b_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt_of(flags), s.status));
+                else VKN_TRY(vkn_launch_gather(x, m_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt_of(flags), s.status));
             }
             VknDims d1 = *d;
             d1.B = 1;

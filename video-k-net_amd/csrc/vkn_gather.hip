@@ -485,9 +485,12 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_bits_w(const float* __
 // (chain k = groups k, k+4, ...; a remainder of G % 4 groups continues chain 0), combined as (s0 + s1) + (s2 + s3) -> deterministic.
 // One wave per chain, 8 independent 16-byte loads in flight per lane: with few frames G is large (256 partials per frame at B = 1)
 // and a serial walk over g is pure load latency (73 us per call at B = 1 before this layout; the sums are bit-identical to it).
+// `status` (or NULL): VKN_STATUS_RANGE is OR-ed in when a gathered sum is not finite — what |x| >= 65504 or a non-finite x turns
+// into once it has been through the f16 split (inf x 0 = NaN, inf x 1 = inf: EVERY kernel row of the frame sees the pixel), so one
+// compare per OUTPUT value of this small kernel watches the whole feature map for free (include/vkn.h: VKN_E_RANGE).
 __global__ __launch_bounds__(256) void k_gather_reduce(const float* __restrict__ part, const float* __restrict__ cntp,
                                                         float* __restrict__ xraw, float* __restrict__ cnt, int N, int NPT,
-                                                        int C, int G) {
+                                                        int C, int G, int* __restrict__ status) {
     __shared__ f32x4 comb[3][64];
     const int row = blockIdx.x;  // b*N + n
     const int b = row / N, n = row - b * N;
@@ -515,7 +518,12 @@ __global__ __launch_bounds__(256) void k_gather_reduce(const float* __restrict__
         if (c0) __syncthreads();
         if (k) comb[k - 1][lane] = s;
         __syncthreads();
-        if (k == 0 && ok) *reinterpret_cast<f32x4*>(xraw + (size_t)row * C + c4) = (s + comb[0][lane]) + (comb[1][lane] + comb[2][lane]);
+        if (k == 0 && ok) {
+            const f32x4 r = (s + comb[0][lane]) + (comb[1][lane] + comb[2][lane]);
+            *reinterpret_cast<f32x4*>(xraw + (size_t)row * C + c4) = r;
+            if (status && !(fabsf(r[0]) <= 3.0e38f && fabsf(r[1]) <= 3.0e38f && fabsf(r[2]) <= 3.0e38f && fabsf(r[3]) <= 3.0e38f))
+                atomicOr(status, 1);   // VKN_STATUS_RANGE (rare: no contention)
+        }
     }
     if (k == 1) {  // lane l sums groups l, l + 64, ... in order, then a fixed butterfly (binary counts: exact in any order)
         const float* cp = cntp + (size_t)b * G * NPT + n;
@@ -548,8 +556,8 @@ __global__ __launch_bounds__(256) void k_gather_ref(const float* __restrict__ x,
 }
 
 int vkn_launch_gather_reduce(const float* part, const float* cntp, float* xraw, float* cnt, int B, int N, int C, int G,
-                             hipStream_t stream) {
-    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, (N + 31) / 32 * 32, C, G);
+                             hipStream_t stream, int* status) {
+    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, (N + 31) / 32 * 32, C, G, status);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
@@ -565,17 +573,17 @@ int vkn_gather_groups(int B, int P) {
 
 // part: [B][G][NPT][C] f32, cntp: [B][G][NPT] f32 (workspace); xraw [B][N][C], cnt [B][N] outputs.
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                      int B, int N, int C, int P, hipStream_t stream, int xdt) {
-    return vkn_launch_gather_ex(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, N, stream, xdt);
+                      int B, int N, int C, int P, hipStream_t stream, int xdt, int* status) {
+    return vkn_launch_gather_ex(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, N, stream, xdt, status);
 }
 
 // mask_rows: rows per frame of the logits tensor the N gathered rows live in (>= N; `masks` points at the first of them)
 static int gather_launch(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
-                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt = 0);
+                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt = 0, int* status = nullptr);
 
 int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                         int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt) {
-    return gather_launch(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 0, stream, xdt);
+                         int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt, int* status) {
+    return gather_launch(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 0, stream, xdt, status);
 }
 
 // REAL-valued left operand a [B][mask_rows][P] (first N rows used): xraw = sum_p a x, cnt = sum_p a
@@ -592,13 +600,13 @@ int vkn_launch_gather_soft(const float* x, const float* masks, float thr, float*
 
 // binary operand given as bit words [B][P/64][2][roundup(N,32)] (vkn_launch_decode_bits); P % 64 == 0
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
-                           int C, int P, hipStream_t stream, int xdt) {
+                           int C, int P, hipStream_t stream, int xdt, int* status) {
     if ((P % 64) != 0) return VKN_E_SHAPE;
-    return gather_launch(x, reinterpret_cast<const float*>(bits), 0.f, xraw, cnt, part, cntp, B, N, C, P, N, 1, stream, xdt);
+    return gather_launch(x, reinterpret_cast<const float*>(bits), 0.f, xraw, cnt, part, cntp, B, N, C, P, N, 1, stream, xdt, status);
 }
 
 static int gather_launch(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
-                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt) {
+                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt, int* status) {
     if (B <= 0 || N <= 0 || P <= 0 || mask_rows < N) return VKN_E_ARG;
     if (xdt < 0 || xdt > 2) return VKN_E_ARG;
     if (xdt && (bits >= 2 || (P % 64) != 0)) return VKN_E_SHAPE;  // half-storage x: binary operands, whole 16-byte aligned tiles
@@ -666,7 +674,7 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
 #undef GA_LAUNCH
         VKN_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, NPT, C, G);
+    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, NPT, C, G, status);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -40,8 +40,10 @@ struct VknGemmProb {
 };
 
 int vkn_gather_groups(int B, int P);
+// `status` (last argument of the gather launchers that end in k_gather_reduce; NULL = no check): a device int, VKN_STATUS_RANGE is OR-ed
+// in when a gathered sum is not finite (include/vkn.h: VKN_E_RANGE)
 int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                         int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt = 0);
+                         int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt = 0, int* status = nullptr);
 int vkn_launch_gather_ref_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                              int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C,
@@ -49,16 +51,16 @@ int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* c
 int vkn_launch_gather_soft(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
                            int N, int C, int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
-                           int C, int P, hipStream_t stream, int xdt = 0);
+                           int C, int P, hipStream_t stream, int xdt = 0, int* status = nullptr);
 int vkn_launch_gather_reduce(const float* part, const float* cntp, float* xraw, float* cnt, int B, int N, int C, int G,
-                             hipStream_t stream);
+                             hipStream_t stream, int* status = nullptr);
 // stage s decode fused with the stage s + 1 gather (vkn_fused.hip)
 int vkn_fused_supported(int C, int P);
 int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float thr,
                                    float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C, int P,
-                                   hipStream_t stream, int xdt = 0);
+                                   hipStream_t stream, int xdt = 0, int* status = nullptr);
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                      int B, int N, int C, int P, hipStream_t stream, int xdt = 0);
+                      int B, int N, int C, int P, hipStream_t stream, int xdt = 0, int* status = nullptr);
 int vkn_launch_gather_ref(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                           int P, hipStream_t stream);
 // per-frame element strides of the decode operands (shared kernels: 0)

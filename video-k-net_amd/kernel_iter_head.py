@@ -118,6 +118,11 @@ class KernelIterHead(BaseRoIHead):
             return torch.nn.functional.interpolate(mask_preds, scale_factor=stride, mode='bilinear', align_corners=False)
         return ops.upsample_bilinear(mask_preds, stride)
 
+    def check_status(self, device=None):
+        """Raise `VknError` (VKN_E_RANGE) when a call since the last check fed the kernels features outside the f16-split envelope
+        (|x| >= 65504 or non-finite): `ops.workspace_status`.  One stream synchronisation."""
+        ops.workspace_status(device)
+
     # ---- fused S-stage loop
     def _fused_ok(self, x):
         # the `simple_test*` entry points are INFERENCE APIs: in eval() mode they take the fused C-ABI path and their outputs are

@@ -69,8 +69,25 @@ def _workspace(nbytes, device):
     buf = cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        buf[:256].zero_()          # the workspace header: its first word is the status word the kernels OR into (include/vkn.h)
         cache[key] = buf
     return buf
+
+
+def workspace_status(device=None):
+    """Synchronise the current stream and read-and-clear the status word of this (thread, device, stream)'s workspace: raises
+    `VknError` (VKN_E_RANGE) when a mask gather of a stage / head call since the last check produced non-finite sums — some
+    |x| >= 65504 or a non-finite x entered the f16 split (include/vkn.h: VKN_STATUS_RANGE).  Costs one stream synchronisation: call it
+    when you would look at the results anyway (per video, per evaluation step), not per frame."""
+    device = torch.device(device if device is not None else torch.cuda.current_device())
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    cache = getattr(_tls, 'ws', None) or {}
+    buf = cache.get((device, torch.cuda.current_stream(device).cuda_stream))
+    if buf is None:
+        return
+    with torch.cuda.device(device):
+        check(_lib.lib().vkn_workspace_status(_ptr(buf), buf.numel(), _stream()))
 
 
 _THR_CACHE = {}
