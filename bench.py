@@ -36,10 +36,13 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 PMC_SIDECAR = 'profiles/r03_pmc.json'   # HBM counters of this same command (tools/gpu_profile.sh); `roofline.traffic` is read from it
 
 
-def build_head(vkn, device, seed=0):
+def build_head(vkn, device, seed=0, link='ffn'):
+    # link='update': the `*_joint_update` KITTI-STEP configs (previous_link='update_dynamic_cov', previous_type='update') — the
+    # last stage of frame t depends on frame t-1's final kernels (bench.py --head update; never the headline line)
+    over = dict(previous_link='update_dynamic_cov', previous_type='update') if link == 'update' else None
     head = vkn.build_head(vkn.configs.roi_head_cfg(True, C=CFG2['C'], heads=CFG2['heads'], ffn=CFG2['ffn'], ncls=CFG2['ncls'],
                                n_thing=CFG2['n_thing'], n_stuff=CFG2['n_stuff'], S=CFG2['S'], up=CFG2['up'],
-                               nprop=CFG2['nprop']))
+                               nprop=CFG2['nprop'], mask_over=over))
     torch.manual_seed(seed)
     head.init_weights()                      # xavier-uniform, fc_cls.bias = -log 99 (reference init; no checkpoints offline)
     return head.to(device).eval()
@@ -275,6 +278,9 @@ def main():
     ap.add_argument('--no-tune-gemms', action='store_true', help='--train: keep the BLAS libraries\' default GEMM heuristics instead of TunableOp (A/B)')
     ap.add_argument('--no-chain-graphs', action='store_true',
                     help='--train: run the [B*N, C] chains as eager torch ops instead of captured hipGraphs (A/B)')
+    ap.add_argument('--head', default='ffn', choices=['ffn', 'update'],
+                    help="'update': the previous_link heads (video_knet_s3_swin*_joint_update): a rank's block runs in three phases "
+                         "around one receive / one send (dist.linked_block_forward); extra measurement, not the BASELINE metric")
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group and take the multi-rank code path even with ONE rank (tests/test_gpu_rccl.py: '
                          'the distributed step on a 1-GPU box)')
@@ -301,7 +307,7 @@ def main():
     vkn_dist = import_module('video_k_net_amd.dist')
     if args.train:
         return train_main(args, vkn, vkn_dist, device, world, rank, dist_on)
-    head = build_head(vkn, device)
+    head = build_head(vkn, device, link=args.head)
     B = args.frames
     x, pf, mp = synth_inputs(B, device, rank)
     XDT = {'fp32': torch.float32, 'fp16': torch.float16, 'bf16': torch.bfloat16}
@@ -328,6 +334,12 @@ def main():
     dims1 = last.make_dims(1, N, CFG2['H'], CFG2['W'])
 
     def step(events=None):
+        if args.head == 'update':
+            # previous_link heads: phase A (stages 0..S-2 + last gather) on every rank at once, the frame-sequential last-stage
+            # chains (phase B) handed from rank to rank with ONE 120 KB receive / send per boundary, phase C (decode, upsample,
+            # tracking link) overlapping the next rank's chains
+            out = vkn_dist.linked_block_forward(head.linked_block_phases(x, pf, mp), first_prev)
+            return out, out[4]
         if dist_on and NS == 1:
             # one process per GPU, contiguous blocks of the clip: the whole block — S stages, x4 upsample, the tracking link of
             # frames 1 .. B-1 to their predecessors (VKN_FLAG_CLIP_LINK) — is ONE C-ABI call, as on one GPU; only frame 0 of the
@@ -438,6 +450,8 @@ def main():
             dec_iso_ms = e0.elapsed_time(e1) / reps
             Bl = B // NS if NS > 1 else B                      # frames of the launch the events bracket
             dec_ms = sum(dec_live_ms) / len(dec_live_ms)
+            if args.head == 'update':      # the phased call records no decode events: the isolated loop stands in (extra measurement)
+                dec_ms, dec_live_ms = dec_iso_ms, [dec_iso_ms]
             alg = Bl * P * (C * xeb + N * 4)                   # read x once + write the logits once
             ach = alg / (dec_ms * 1e-3) / 1e9
             # HBM bytes per launch from the committed PMC profile of this same command (tools/gpu_profile.sh ->
@@ -633,8 +647,11 @@ def main():
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                     config=dict(workload='cfg2 video_knet_s3_r50: VideoKernelIterHead S=3, N=100 proposals + 17 stuff = 117 '
-                                         'kernels, C=256, 1024x2048 frame -> 128x256 stride-8 features, ffn tracking link, '
-                                         'x4 bilinear upsample of the final logits' + (' [SKIPPED]' if args.no_upsample else ''),
+                                         'kernels, C=256, 1024x2048 frame -> 128x256 stride-8 features, '
+                                         + ('ffn tracking link, ' if args.head == 'ffn' else
+                                            'previous_link=update_dynamic_cov + previous_type=update (NOT the BASELINE head: the last '
+                                            'stage is frame-sequential, phases A/B/C per rank), ')
+                                         + 'x4 bilinear upsample of the final logits' + (' [SKIPPED]' if args.no_upsample else ''),
                                 frames_per_gpu_per_step=B, streams_per_gpu=NS, parallelism=f'frame-sharded dp{world}',
                                 x_storage=args.x_storage,
                                 arithmetic=('fp32 storage;' if xeb == 4 else args.x_storage + ' storage of x, fp32 everything else;') + ' gather/decode on f16 hi+lo split MFMA, [N x C] GEMMs on bf16x3 split MFMA, '

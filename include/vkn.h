@@ -81,6 +81,16 @@ extern "C" {
 #define VKN_FLAG_CLIP_LINK 8u      /* vkn_head_forward_f32: the B frames are CONSECUTIVE frames of one video: prev_obj is [1][N][C] (the
                                       kernels of the frame before frame 0) and frame b > 0 links to this call's own frame b - 1 */
 
+/* vkn_head_forward_link_f32 with a previous_link block and VKN_FLAG_CLIP_LINK, in phases — for a clip whose frames are sharded over
+ * ranks: rank r runs A at once, B when rank r-1's last kernels have arrived (they are `prev_obj`), sends its own last
+ * kernels (obj_out[B-1]) on, then runs C.  Same arguments, same workspace and same output tensors in all three calls, nothing else
+ * through that workspace in between; no phase bit = the whole call.  A: stages 0 .. S-2 + the last stage's gather; B: the last stage's
+ * frame-sequential [N x C] chains (writes obj_out / cls_prob); C: the last decode, the upsample, the tracking link. */
+#define VKN_FLAG_PHASE_A 1024u
+#define VKN_FLAG_PHASE_B 2048u
+#define VKN_FLAG_PHASE_C 4096u
+#define VKN_FLAG_PHASE_MASK (VKN_FLAG_PHASE_A | VKN_FLAG_PHASE_B | VKN_FLAG_PHASE_C)
+
 #define VKN_MAX_FCS 4
 
 /* Problem dimensions shared by the stage / head entry points. */

@@ -314,3 +314,82 @@ def test_reducer_takes_gradients_delivered_outside_autograd():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res['err'] < 1e-5 and res['overlap'], res
+
+
+# ---- previous_link heads: the phase split of a sharded clip
+def _stub_phases(x_block, log):
+    """A stand-in for `VideoKernelIterHead.linked_block_phases` with the same data flow, in plain torch on the CPU:
+       A: y[t] = tanh(x[t] W)                                  (per frame, no cross-frame input)
+       B: k[t] = tanh(y[t] + 0.5 * roll(k[t-1])) , k[-1] = prev (the frame-sequential last-stage chain)
+       C: out[t] = k[t] * y[t] + k[t-1]                         (per frame + the tracking link to the previous kernels)"""
+    torch.manual_seed(5)
+    Wm = torch.randn(x_block.shape[-1], x_block.shape[-1]) * 0.3
+    st = {}
+
+    def run(name, prev):
+        log.append(name)
+        if name == 'A':
+            assert prev is None
+            st['y'] = torch.tanh(x_block @ Wm)
+            return None
+        if name == 'B':
+            ks, k = [], prev[0]
+            for t in range(x_block.shape[0]):
+                k = torch.tanh(st['y'][t] + 0.5 * torch.roll(k, 1, 0))
+                ks.append(k)
+            st['k'] = torch.stack(ks)
+            return st['k']
+        before = torch.cat([prev, st['k'][:-1]])
+        return st['k'] * st['y'] + before
+    return run
+
+
+def _linked_worker(rank, world, port, T, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import vkn_import
+    vkn_import.load()
+    from importlib import import_module
+    d = import_module('video_k_net_amd.dist')
+    N, C = 5, 8
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(T, N, C, generator=g)
+    first = torch.randn(1, N, C, generator=g)
+    b0, b1 = d.shard_bounds(T, world, rank)
+    log = []
+    out = d.linked_block_forward(_stub_phases(x[b0:b1], log), first)
+    q.put((rank, b0, b1, out, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_previous_link_clip_sharded_in_phases_equals_the_whole_clip():
+    """`dist.linked_block_forward` over 2 and 3 ranks (gloo) with a stub chain of the head's data flow: the sharded clip — phase A on
+    every rank at once, the sequential phase B handed from rank to rank with ONE receive and ONE send per boundary, phase C —
+    equals the single-process clip, and every rank ran A, B, C in that order."""
+    from importlib import import_module
+    sys.path.insert(0, ROOT)
+    import vkn_import
+    vkn_import.load()
+    d = import_module('video_k_net_amd.dist')
+    T, N, C = 7, 5, 8
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(T, N, C, generator=g)
+    first = torch.randn(1, N, C, generator=g)
+    whole = d.linked_block_forward(_stub_phases(x, []), first)       # no process group: one rank
+    for world in (2, 3):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_linked_worker, args=(r, world, port, T, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        got = torch.cat([r[3] for r in res])
+        assert [r[1] for r in res] == [(T * k) // world for k in range(world)] and res[-1][2] == T
+        assert torch.equal(got, whole), f'world {world}: max err {float((got - whole).abs().max())}'
+        assert all(r[4] == ['A', 'B', 'C'] for r in res)

@@ -88,6 +88,42 @@ def test_neighbour_exchange_through_rccl(vkn, rccl_group):
     assert torch.equal(prev[1:], block[:-1]) and float(prev[0].abs().max()) == 0.0
 
 
+def test_previous_link_block_in_phases_through_rccl(vkn, rccl_group):
+    """`dist.linked_block_forward` on a previous_link head with a real RCCL process group (one rank: no neighbour, but the phases run
+    between initialised-communicator calls on the GPU) equals `clip_forward`; the hand-over message itself — the block's last kernels
+    as ONE batched isend / irecv, here to the rank itself — arrives intact and phase B started from it reproduces the clip."""
+    from importlib import import_module
+    from helpers import load_golden
+    from test_gpu_parity import _build_head
+    d = import_module('video_k_net_amd.dist')
+    g, case = load_golden('video_upd_cfg')
+    head, _ = _build_head(vkn, case)
+    T, N, C, H, W = 4, case['N'], case['C'], case['H'], case['W']
+    gen = torch.Generator().manual_seed(3)
+    xs = torch.randn(T, C, H, W, generator=gen).to(DEV)
+    pfs = torch.randn(T, N, C, 1, 1, generator=gen).to(DEV)
+    mps = (torch.randn(T, N, H, W, generator=gen) * 4).to(DEV)
+    first = torch.randn(1, N, C, generator=gen).to(DEV)
+    with torch.no_grad():
+        whole = head.clip_forward(xs, pfs, mps, first_previous_obj_feats=first.reshape(1, N, C, 1, 1))
+        out = d.linked_block_forward(head.linked_block_phases(xs, pfs, mps), first)
+        for k in range(5):
+            assert torch.equal(out[k].reshape(whole[k].shape), whole[k]), k
+        # two blocks, the hand-over travelling through RCCL (send to / receive from rank 0 = this rank)
+        run0 = head.linked_block_phases(xs[:2], pfs[:2], mps[:2])
+        run0('A', None)
+        k0 = run0('B', first)
+        recv = torch.empty(1, N, C, device=DEV)
+        d.exchange(k0[-1:].contiguous().reshape(1, N, C), recv, send_to=0, recv_from=0)
+        out0 = run0('C', first)
+        run1 = head.linked_block_phases(xs[2:], pfs[2:], mps[2:])
+        run1('A', None)
+        run1('B', recv)
+        out1 = run1('C', recv)
+        for k in range(5):
+            assert torch.equal(torch.cat([out0[k], out1[k]], 0).reshape(whole[k].shape), whole[k]), k
+
+
 def _bench(args, launcher=()):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.pop('MASTER_PORT', None)

@@ -185,3 +185,40 @@ def test_every_link_combination_clip_equals_frame_by_frame(vkn, plink, ptype):
                     for name, u, v in zip(('obj', 'cls', 'masks', 'scaled', 'track'), one, clip):
                         assert torch.equal(u[0], v[t]), (plink, ptype, C, T, t, name)
                     prev = one[0][0:1]
+
+
+@pytest.mark.parametrize('name', ['video_upd_tiny', 'video_updffn_tiny', 'video_upd_cfg', 'video_latt_upd_tiny'])
+def test_clip_in_phases_equals_the_whole_call_and_shards_over_blocks(vkn, name):
+    """`vkn_head_forward_link_f32` in phases (VKN_FLAG_PHASE_A / B / C) — what a rank of a frame-sharded clip runs
+    around its ONE receive and ONE send (dist.linked_block_forward).  (1) A, B, C through `linked_block_phases` equal the unphased
+    clip call bit for bit; (2) the clip cut into two blocks, the second one's phase B started from the first one's last kernels —
+    two ranks emulated on one GPU — equals the whole clip bit for bit."""
+    from importlib import import_module
+    d = import_module('video_k_net_amd.dist')
+    g, case = load_golden(name)
+    head, _ = _build_head(vkn, case)
+    T, N, C, H, W = 5, case['N'], case['C'], case['H'], case['W']
+    xs = _rand((T, C, H, W), 1951).to(DEV)
+    pfs = _rand((T, N, C, 1, 1), 1952).to(DEV)
+    mps = _rand((T, N, H, W), 1953, 4.0).to(DEV)
+    first = _rand((1, N, C), 1954).to(DEV)
+    with torch.no_grad():
+        whole = head.clip_forward(xs, pfs, mps, first_previous_obj_feats=first.reshape(1, N, C, 1, 1))
+        phased = d.linked_block_forward(head.linked_block_phases(xs, pfs, mps), first)        # no process group: one rank, three calls
+        for k in range(5):
+            assert torch.equal(phased[k].reshape(whole[k].shape), whole[k]), k
+        # two blocks = two ranks: block 1's phase A may run before block 0 is done (separate output tensors; the workspace is
+        # per (thread, stream), so the emulation runs the blocks one after the other)
+        h = 2
+        run0 = head.linked_block_phases(xs[:h], pfs[:h], mps[:h])
+        run0('A', None)
+        k0 = run0('B', first)
+        out0 = run0('C', first)
+        run1 = head.linked_block_phases(xs[h:], pfs[h:], mps[h:])
+        hand_over = k0[-1:].clone()                                   # what rank 0 sends to rank 1
+        run1('A', None)
+        run1('B', hand_over)
+        out1 = run1('C', hand_over)
+        for k in range(5):
+            got = torch.cat([out0[k], out1[k]], 0)
+            assert torch.equal(got.reshape(whole[k].shape), whole[k]), k

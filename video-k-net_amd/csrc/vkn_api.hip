@@ -1279,12 +1279,28 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
     // keeps the two-kernel bit-word path (A/B; bit-identical results)
     const bool use_fused = use_bits && !(flags & VKN_FLAG_BITS_HANDOFF) && vkn_fused_supported(d->C, d->H * d->W);
 
+    // Phases of a previous_link clip call (VKN_FLAG_PHASE_*; 0 = everything): the frames of a clip sharded over ranks need the
+    // previous rank's final kernels BEFORE their own last-stage chains and should hand their own on BEFORE the HBM-bound tail —
+    //   A: stages 0 .. S-2 and the last stage's gather (no cross-frame dependency),
+    //   B: the last stage's [N x C] chains, frame by frame (frame 0 links to `prev_obj`),
+    //   C: the batched last decode, the upsample and the tracking link.
+    // The state between phases (gather sums, stage S-2's kernels) lives in `ws` and in the caller's output tensors.
+    const unsigned ph = flags & VKN_FLAG_PHASE_MASK;
+    const bool do_a = !ph || (ph & VKN_FLAG_PHASE_A), do_b = !ph || (ph & VKN_FLAG_PHASE_B), do_c = !ph || (ph & VKN_FLAG_PHASE_C);
+    if (ph && !(link_pre && (flags & VKN_FLAG_CLIP_LINK) && prev_obj)) return VKN_E_ARG;   // phases exist for the frame-sequential path only
+
     const float* m_in = mask_preds_in;
     const float* o_in = proposal_feats;
     SideStream* joined = nullptr;
     bool up_done = false;
     for (int sidx = 0; sidx < num_stages; ++sidx) {
         const bool last = (sidx == num_stages - 1);
+        if (!last && !do_a) {   // (a later phase: the stage ran in phase A; follow the buffer alternation only)
+            const bool to_out_s = ((num_stages - 1 - sidx) & 1) == 0;
+            m_in = to_out_s ? mask_preds_out : mtmp;
+            o_in = to_out_s ? obj_out : otmp;
+            continue;
+        }
         // alternate so that the LAST stage writes the caller's buffers
         const bool to_out = ((num_stages - 1 - sidx) & 1) == 0;
         float* m_out = to_out ? mask_preds_out : mtmp;
@@ -1302,7 +1318,7 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
         // chain is frame-sequential: gather (all frames) -> per frame { link, update, interaction, FC branches } -> decode (all
         // frames).  Everything that streams x stays batched; only ~15 small launches per frame are serialised.
         const float* prev_pre = (last && link_pre) ? prev_obj : nullptr;
-        const bool seq = prev_pre && (flags & VKN_FLAG_CLIP_LINK) && d->B > 1;
+        const bool seq = prev_pre && (flags & VKN_FLAG_CLIP_LINK) && (d->B > 1 || ph);
         StageOpts so;
         so.link_pre = prev_pre ? link_pre : nullptr;
         so.prev_pre = prev_pre;
@@ -1320,7 +1336,7 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
         } else {
             const VknStageWeights* w = &stages[sidx];
             const int B = d->B, N = d->N, C = d->C, P = d->H * d->W;
-            if (!(use_fused && sidx > 0)) {  // the stage's gather for all frames (run_stage's step (i))
+            if (do_a && !(use_fused && sidx > 0)) {  // the stage's gather for all frames (run_stage's step (i))
                 if (flags & VKN_FLAG_REF_KERNELS) VKN_TRY(vkn_launch_gather_ref(x, m_in, d->thr_logit, s.xraw, s.cnt, B, N, C, P, st));
                 else if (b_in) VKN_TRY(vkn_launch_gather_bits(x, b_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt_of(flags), s.status));
                 else VKN_TRY(vkn_launch_gather(x, m_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt_of(flags), s.status));
@@ -1330,7 +1346,7 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
             so.skip_decode = true;
             so.keep_xfeat = so.link_track && so.track_src == 1;   // ... and reads every frame's x_feat ("update") from the workspace:
             so.link_track = nullptr;  // the tracking link runs batched behind the loop (every frame's kernels are known then)
-            for (int b = 0; b < B; ++b) {
+            for (int b = 0; b < (do_b ? B : 0); ++b) {
                 const size_t r = (size_t)b * N;
                 const StageWs sb = frame_ws(s, d, b);
                 so.prev_pre = b == 0 ? prev_obj : o_out + (r - N) * C;
@@ -1338,6 +1354,7 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
                                   nullptr, sb, flags, st, nullptr, nullptr, true, true, false, nullptr, nullptr, nullptr, nullptr,
                                   nullptr, nullptr, nullptr, 0, 0, nullptr, &so));
             }
+            if (!do_c) return VKN_OK;   // phases A / B end here: nothing was forked, nothing to join
             if (prev && side && hipEventRecord(side->fork, st) != hipSuccess) return VKN_E_LAUNCH;
             VKN_TRY(final_decode(d, x, s, w->ft_w ? s.kb : nullptr, m_out, flags, st, ev0, ev1, up_out, upsample_stride,
                                  vkn_dbg_env("VKN_LAST_CHUNK", 0), &up_done));

@@ -78,6 +78,39 @@ def previous_kernels_for_block(block_kernels: torch.Tensor, first_previous=None,
     return torch.cat([p0.reshape(1, N, C), block_kernels[:-1]], dim=0)
 
 
+def linked_block_forward(run_phase, first_previous, group=None):
+    """One rank's share of a clip for the heads whose LAST stage rewrites its incoming kernels from the previous frame's final
+    kernels (`previous_link = "update_dynamic_cov" | "link_atten"`, knet/video/kernel_update_head.py:324-372,
+    knet/video/kernel_iter_head.py:454-456).  There the masks of frame t depend on frame t-1 — through [N x C]-sized state only,
+    and only in the last stage — so a rank cannot simply run its block and patch frame 0 afterwards (`neighbour_last_kernels`
+    does that for the heads without previous_link).  The block runs in three phases around ONE receive and ONE send:
+
+        A  `run_phase('A', None)`     stages 0 .. S-2 and the last stage's gather for all frames of the block: no cross-frame input,
+                                      every rank runs it at once (the x-streaming work);
+           receive the final kernels of the frame before the block from rank - 1 (rank 0: `first_previous`);
+        B  `run_phase('B', prev)`     the last stage's [N x C] chains, frame by frame, frame 0 linked to `prev` -> returns the
+                                      block's final kernels [T_r, N, C];
+           send the LAST frame's kernels to rank + 1 — before the HBM-bound tail, so the next rank's chains start while this
+           rank decodes and upsamples;
+        C  `run_phase('C', prev)`     the batched last decode, the upsample, the tracking link -> the block's outputs.
+
+    The last-stage chains of a clip therefore serialise across the ranks (~0.13 ms per frame at one frame per launch) while
+    phases A and C of all ranks overlap; the cross-rank traffic is one 120 KB point-to-point message per rank boundary.
+    `run_phase(name, prev)` is `VideoKernelIterHead.linked_block_phases(...)` on the GPU, any callable with that contract in tests.
+    Every rank must own at least one frame.  -> what phase C returns."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    run_phase('A', None)
+    prev = first_previous
+    if world > 1 and rank > 0:
+        prev = torch.empty_like(first_previous)
+        exchange(None, prev, None, rank - 1, group)
+    kernels = run_phase('B', prev)
+    if world > 1 and rank + 1 < world:
+        exchange(kernels[-1:].contiguous().reshape(first_previous.shape), None, rank + 1, None, group)
+    return run_phase('C', prev)
+
+
 class BucketedGradAllReducer:
     """Data-parallel gradient averaging for the head (BASELINE cfg3: frames of a clip sharded over the GPUs of a node, RCCL
     all-reduce over xGMI; the reference gets this from mmcv's `MMDistributedDataParallel`, external/train.py:53-61).

@@ -557,6 +557,37 @@ class VideoKernelIterHead(KernelIterHead):
             track[0] = cur[0]
         return obj, cls, masks, scaled, track.reshape(obj.shape)
 
+    def linked_block_phases(self, x, proposal_feats, mask_preds, want_scaled=True):
+        """`run_phase` callable for `dist.linked_block_forward`: this head on one rank's contiguous block of a clip, in the three phases
+        of `vkn_head_forward_link_f32` (VKN_FLAG_PHASE_A / B / C).  Only for heads with a `previous_link` block (the others shard
+        without phases).  Phase 'B' returns the block's final kernels [T, N, C]; phase 'C' the five outputs of `clip_forward`."""
+        last = self.mask_head[-1]
+        if getattr(last, 'previous', None) is None or getattr(last, 'previous_link', None) is None:
+            raise ValueError('linked_block_phases: the last stage has no previous_link block — shard the clip with clip_forward + '
+                             'dist.neighbour_last_kernels instead')
+        h0 = self.mask_head[0]
+        T, N = proposal_feats.shape[:2]
+        C, K = h0.in_channels, h0.conv_kernel_size
+        dims = h0.make_dims(T, N, x.shape[-2], x.shape[-1])
+        packs = [h.stage_pack(x.device) for h in self.mask_head]
+        link_pre, link_track, track_src = last.link_packs(x.device)
+        pf = proposal_feats.reshape(T, N, C)
+        state = {}
+
+        def run(name, prev):
+            bit = {'A': ops.PHASE_A, 'B': ops.PHASE_B, 'C': ops.PHASE_C}[name]
+            p = prev if prev is not None else pf.new_zeros(1, N, C)      # (phase A never reads it: no cross-frame input yet)
+            state['out'] = ops.head_forward(dims, packs, x, pf, mask_preds, None, last.mask_upsample_stride, want_scaled=want_scaled,
+                                            flags=getattr(h0, 'vkn_flags', 0), clip_first_prev=p.reshape(1, N, C), link_pre=link_pre,
+                                            link_track=link_track, track_src=track_src, phase=bit, out=state.get('out'))
+            obj, cls, masks, scaled, track = state['out']
+            if name == 'B':
+                return obj
+            if name == 'C':
+                return obj.reshape(T, N, C, K, K), cls, masks, scaled, track.reshape(T, N, C, K, K)
+            return None
+        return run
+
     def get_masked_feature(self, x, mask_pred):
         """`einsum('bnhw,bchw->bnc', (sigmoid(mask_pred) > 0.5).float(), x)` (knet/video/kernel_iter_head.py:566-571): the HIP gather."""
         return ops.mask_gather(x, mask_pred, 0.5)[0]

@@ -428,8 +428,12 @@ def stage_chain(dims: VknDims, pack: StagePack, x_feat, obj_in, want_cls=True, f
     return cls, kern, kb, obj
 
 
+PHASE_A, PHASE_B, PHASE_C = 1024, 2048, 4096     # VKN_FLAG_PHASE_*: include/vkn.h
+
+
 def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=None, upsample_stride=1, want_track=False,
-                 want_scaled=True, flags=0, clip_first_prev=None, decode_events=None, link_pre=None, link_track=None, track_src=0):
+                 want_scaled=True, flags=0, clip_first_prev=None, decode_events=None, link_pre=None, link_track=None, track_src=0,
+                 phase=0, out=None):
     """The S-stage loop in one C call.  Returns (obj [B,N,C], cls_prob [B,N,ncls], mask_preds [B,N,H,W],
     scaled_mask_preds [B,N,H*s,W*s] | None, track [B,N,C] | None).  link_pre / link_track / track_src: the LAST stage's
     previous_link / previous_type="update" blocks (`link_pack`; vkn_head_forward_link_f32) — they need prev_obj / clip_first_prev."""
@@ -442,18 +446,26 @@ def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=N
     for p in packs:
         p.ensure_prepared(dims)
     arr = (VknStageWeights * S)(*[p.w for p in packs])
-    obj = torch.empty((B, N, C), dtype=torch.float32, device=dev)
-    cls = torch.empty((B, N, dims.ncls), dtype=torch.float32, device=dev)
-    masks = torch.empty((B, N, H, W), dtype=torch.float32, device=dev)
-    scaled = None
-    if want_scaled and upsample_stride > 1:
-        scaled = torch.empty((B, N, H * upsample_stride, W * upsample_stride), dtype=torch.float32, device=dev)
-    track = None
+    # `phase` (PHASE_A | PHASE_B | PHASE_C, previous_link heads in clip mode only) runs a part of the call; `out` = the tuple a previous
+    # phase returned: the later phases write the SAME tensors and continue from the state the earlier ones left in the workspace
+    if out is not None:
+        obj, cls, masks, scaled, track = out
+        scaled = scaled if (want_scaled and upsample_stride > 1) else None
+    else:
+        obj = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        cls = torch.empty((B, N, dims.ncls), dtype=torch.float32, device=dev)
+        masks = torch.empty((B, N, H, W), dtype=torch.float32, device=dev)
+        scaled = None
+        if want_scaled and upsample_stride > 1:
+            scaled = torch.empty((B, N, H * upsample_stride, W * upsample_stride), dtype=torch.float32, device=dev)
+        track = None
+    flags |= int(phase)
     if clip_first_prev is not None:
         # the B frames are consecutive frames of one video: frame b links to frame b - 1 of this call, frame 0 to `clip_first_prev`
         # [1,N,C] (VKN_FLAG_CLIP_LINK) — the whole clip step is one C call
         prev_obj = _req(clip_first_prev.reshape(1, N, C), 'clip_first_prev')
-        track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        if track is None:
+            track = torch.empty((B, N, C), dtype=torch.float32, device=dev)
         flags |= 8
     elif prev_obj is not None and (want_track or link_pre is not None):
         prev_obj = _req(prev_obj, 'previous_obj_feats')
