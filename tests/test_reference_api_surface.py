@@ -32,6 +32,7 @@ PAIRS = {
     'knet_vis.tracker.mask_hungarian_assigner:MaskHungarianAssignerVideo': 'MaskHungarianAssignerVideo',
     'knet.video.qdtrack.trackers.quasi_dense_embed_tracker:QuasiDenseEmbedTracker': 'QuasiDenseEmbedTracker',
     'knet.cross_entropy_loss:CrossEntropyLoss': 'losses.CrossEntropyLoss',
+    'knet.video.track_heads:QuasiDenseMaskEmbedHeadGTMask': 'QuasiDenseMaskEmbedHeadGTMask',
 }
 
 CHILD = r'''
@@ -41,13 +42,17 @@ root = sys.argv[1]
 sys.path.insert(0, os.path.join(root, 'oracle', 'standins'))
 sys.path.insert(1, '/root/reference')
 out = {}
-for key in sorted(json.loads(sys.argv[2]), key=lambda k: 'QuasiDenseEmbedTracker' in k):
+for key in sorted(json.loads(sys.argv[2]), key=lambda k: ('QuasiDenseEmbedTracker' in k) + 2 * ('QuasiDenseMaskEmbedHeadGTMask' in k)):
     mod, cls = key.split(':')
     try:
         if cls == 'QuasiDenseEmbedTracker':      # its package __init__ needs cv2: loaded by path, as the golden generator does (last: it
             sys.path.insert(0, root)             # replaces the `knet` package entries in sys.modules)
             from oracle.gen_golden_tracker import load_reference_tracker
             c = load_reference_tracker()
+        elif cls == 'QuasiDenseMaskEmbedHeadGTMask':   # knet/video/track_heads.py also holds RoI-based heads: loaded by path with name shims
+            sys.path.insert(0, root)
+            from oracle.gen_golden_tracker import load_reference_embed_head
+            c = load_reference_embed_head()
         else:
             c = getattr(importlib.import_module(mod), cls)
     except Exception as e:            # a module the stand-ins cannot carry

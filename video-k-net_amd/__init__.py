@@ -14,6 +14,7 @@ from .kernel_head import ConvKernelHead, ConvKernelHeadVideo  # noqa: F401
 from .knet_vis import KernelFrameIterHeadVideo, KernelIterHeadVideo, KernelUpdateHeadVideo  # noqa: F401
 from .mask_hungarian_assigner import MaskHungarianAssigner, MaskHungarianAssignerVideo  # noqa: F401
 from .qd_tracker import QuasiDenseEmbedTracker, build_tracker  # noqa: F401
+from .track_heads import QuasiDenseMaskEmbedHeadGTMask  # noqa: F401
 from .registry import HEADS, TRANSFORMER_LAYER, build_head, build_transformer_layer  # noqa: F401
 from . import autograd, losses  # noqa: F401
 from .mask_pseudo_sampler import MaskPseudoSampler  # noqa: F401
