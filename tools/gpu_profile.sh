@@ -7,7 +7,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --settle 3 --no-cpu-baseline --no-extras $*"
+# (0) the un-profiled bench line of THIS box, same session (profiled passes run at lower clocks: never compare across the two)
+python $R/bench.py --no-cpu-baseline $* > $OUT/bench_default.json 2> $OUT/bench_default.err
+ARGS="--steps 20 --warmup 4 --settle 12 --no-cpu-baseline --no-extras $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with sys-trace)
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python $R/bench.py $ARGS > $OUT/bench_fetch.log 2>&1

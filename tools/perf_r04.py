@@ -65,6 +65,26 @@ def main():
                 t = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob))
                 print(f'B={B:3d} ABL={abl}  {t:8.1f}')
         os.environ['VKN_CHAIN_ABL'] = '0'
+    if args.what == 'decpol':        # needs --debug-lib: cache policy of the decode's x loads / output stores (VKN_DECODE_ABL 4..9)
+        B = 32
+        x = torch.randn(B, C, H, W, generator=g).to(DEV)
+        pf = torch.randn(B, N, C, 1, 1, generator=g).to(DEV)
+        mp = (torch.randn(B, N, H, W, generator=g) * 4).to(DEV)
+        prev = torch.randn(B, N, C, 1, 1, generator=g).to(DEV)
+        kern = torch.randn(B, N, C, generator=g).to(DEV)
+        hi, lo = vkn.ops.split_planes(kern)
+        kb = torch.randn(B, N, generator=g).to(DEV)
+        out = torch.empty(B, N, H, W, device=DEV)
+        alg = B * H * W * (C * 4 + N * 4)
+        names = {0: 'sc0 nt (shipped)', 4: 'plain', 6: 'nt', 7: 'sc1', 8: 'sc1 nt', 9: 'sc0 sc1 nt', 5: 'shipped loads, nt stores'}
+        for rep in range(2):
+            for abl in (0, 4, 6, 7, 8, 9, 5, 0):
+                os.environ['VKN_DECODE_ABL'] = str(abl)
+                t = timeit(lambda: vkn.ops.mask_decode_planes(x, hi, lo, N, kb, out), iters=40, warm=10)
+                with torch.no_grad():
+                    th = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True), iters=15, warm=4)
+                print(f'decode x-load policy {names[abl]:26s} isolated loop {t:7.1f} us = {alg / t / 1e6 / 8:.3f} of 8 TB/s   head step {th / 1e3:7.3f} ms')
+        os.environ['VKN_DECODE_ABL'] = '0'
     if args.what in ('head', 'all'):
         print('== whole head step (3 stages + link + x4 upsample), ms per call ==')
         for B in (1, 8, 32):

@@ -33,7 +33,7 @@ def short(n):
             import re
             m = re.search(r'k_fused_ilILi(\d+)ELi(\d+)ELi(\d+)E', n)
             return 'k_fused_il<x16>' if (m and m.group(3) != '0') else 'k_fused_il'
-        for key in ('k_chain_a', 'k_chain_c', 'k_split_planes', 'k_gemm_s3', 'k_fused_dgs', 'k_fused_il', 'k_ffn_fused', 'k_gather_bits_w', 'k_attn_long', 'k_attn_mfma', 'k_attn', 'k_rowepi', 'k_gather_reduce', 'k_upsample_s', 'k_gather_mfma'):
+        for key in ('k_chain_a', 'k_chain_c', 'k_chain_pack', 'k_split_planes', 'k_gemm_s3', 'k_fused_dgs', 'k_fused_il', 'k_ffn_fused', 'k_gather_bits_w', 'k_attn_long', 'k_attn_mfma', 'k_attn', 'k_rowepi', 'k_gather_reduce', 'k_upsample_s', 'k_gather_mfma'):
             if key in n:
                 return key
     import re
@@ -69,6 +69,34 @@ if con:
     if instep:
         print(f'k_decode_mfma at {full_y} frames per launch: inside head steps n={len(instep)} avg_us={sum(instep) / len(instep):.2f} '
               f'min={min(instep):.2f} max={max(instep):.2f}; back-to-back loop n={len(loop)} avg_us={sum(loop) / max(len(loop), 1):.2f}')
+        # the roofline line recomputed from THIS trace, and the traced run's own bench line beside it (same process: must agree)
+        try:
+            import json
+            import re
+            log = open(os.path.join(out, 'bench_trace.log')).read()
+            line = json.loads(re.findall(r'^\{.*\}$', log, flags=re.M)[-1])
+            rl = line['roofline']
+            alg = rl['algorithmic_bytes_per_launch']
+            t_in, t_loop = sum(instep) / len(instep), sum(loop) / max(len(loop), 1)
+            # bench.py times the last `steps` head steps: the in-step launches of the warm-up / settle steps are in the trace as well
+            timed = instep[-line['steps']:]
+            t_timed = sum(timed) / len(timed)
+            print(f'roofline recomputed from this trace: algorithmic {alg / 1e6:.1f} MB per launch; in-step (all {len(instep)}) '
+                  f'{alg / t_in / 1e6 / 8000:.4f}, in-step (the {len(timed)} timed steps) {alg / t_timed / 1e6 / 8000:.4f}, '
+                  f'back-to-back loop {alg / t_loop / 1e6 / 8000 if loop else 0:.4f} of 8 TB/s')
+            print(f'bench line of the SAME traced process: avg_launch_ms={rl["avg_launch_ms"]} (HIP events) frac={rl["frac"]} '
+                  f'isolated_loop_launch_ms={rl["isolated_loop_launch_ms"]} isolated_loop_frac={rl["isolated_loop_frac"]} '
+                  f'-> events / trace = {rl["avg_launch_ms"] * 1e3 / t_timed:.3f} (in-step), '
+                  f'{rl["isolated_loop_launch_ms"] * 1e3 / t_loop if loop else 0:.3f} (loop)')
+        except Exception as e:  # noqa: BLE001
+            print('(no bench line beside the trace:', e, ')')
+        try:
+            d = json.loads(open(os.path.join(out, 'bench_default.json')).read().strip().splitlines()[-1])
+            print(f'un-profiled bench line, same box and session: {d["value"]} frames/s, {d["ms_per_step"]} ms per step, decode '
+                  f'avg_launch_ms={d["roofline"]["avg_launch_ms"]} frac={d["roofline"]["frac"]} '
+                  f'isolated_loop_frac={d["roofline"]["isolated_loop_frac"]}')
+        except Exception as e:  # noqa: BLE001
+            print('(no un-profiled bench line:', e, ')')
         print()
     agg = defaultdict(lambda: [0, 0.0])
     for n, s, e in rows:

@@ -42,6 +42,8 @@ struct StageOpts {
     int track_src = 0;                            // update feature of link_track's updator: 1 = x_feat, 2 = the stage's obj_out
     bool skip_decode = false;                     // stop after the decode kernels (planes / kern32, kb) are written
     bool keep_xfeat = false;                      // materialise x_feat in the workspace: a caller-side link reads it after the stage
+    const void* touch_next = nullptr;             // the NEXT stage's prepared weights: warmed by the reduction that ends this stage's
+    size_t touch_next_bytes = 0;                  // fused decode -> gather pass (k_gather_reduce)
 };
 
 // pre-split (bf16x3) copies of the Linear weights, carved from VknStageWeights.prepared in a fixed order
@@ -441,15 +443,21 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             return VKN_E_WORKSPACE;
     }
 
+    // the gather's reduction warms the memory-side cache with the weights of the persistent chain that follows it
+    const bool will_fast = !xfeat_in && pw.dynft && chain_fast_ok(d, w, pw, flags, w->fc_cls_w && cls_logits) && vkn_dbg_env("VKN_CHAIN_TOUCH", 1);
+    const void* touch_own = will_fast ? w->prepared : nullptr;
+    const size_t touch_own_bytes = will_fast ? w->prepared_bytes : 0;
+    const void* touch_nx = (so && vkn_dbg_env("VKN_CHAIN_TOUCH", 1)) ? so->touch_next : nullptr;
+    const size_t touch_nx_bytes = touch_nx ? so->touch_next_bytes : 0;
     // (i) mask gather                                        knet/det/kernel_update_head.py:190-195
     if (gathered_in || xfeat_in) {
         // s.xraw / s.cnt were produced by the previous stage's fused decode -> gather pass (or x_feat is given)
     } else if (ref)
         VKN_TRY(vkn_launch_gather_ref(x, masks_in, d->thr_logit, s.xraw, s.cnt, B, N, C, P, st));
     else if (bits_in)
-        VKN_TRY(vkn_launch_gather_bits(x, bits_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status));
+        VKN_TRY(vkn_launch_gather_bits(x, bits_in, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status, touch_own, touch_own_bytes));
     else
-        VKN_TRY(vkn_launch_gather(x, masks_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status));
+        VKN_TRY(vkn_launch_gather(x, masks_in, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status, touch_own, touch_own_bytes));
 
     // folded feat_transform: x_feat = xraw . W_ft^T + cnt (x) b_ft             (:179-180 folded).  With the
     // composite weights x_feat itself is only materialised when the caller asks for it.
@@ -490,7 +498,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         } else if (skip_decode) {
         } else if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
         else if (gather_out)
-            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status));
+            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status, touch_nx, touch_nx_bytes));
         else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
         else VKN_TRY(decode_final(kb));
         if (prev_obj && track_out) {
@@ -570,7 +578,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             // the caller decodes all frames at once (frame-sequential last stage)
         } else if (ref_decode) VKN_TRY(vkn_launch_decode_ref(x, s.kern32, kb, masks_out, B, N, C, P, st));
         else if (gather_out)
-            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status));
+            VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P, st, xdt, s.status, touch_nx, touch_nx_bytes));
         else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
         else VKN_TRY(decode_final(kb));
     } else {
@@ -618,7 +626,7 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             if (skip_decode) {
             } else if (gather_out)
                 VKN_TRY(vkn_launch_fused_decode_gather(x, s.kfh, s.kfl, kb, d->thr_logit, s.xraw, s.cnt, s.part, s.cntp, B, N, C, P,
-                                                       st, xdt, s.status));
+                                                       st, xdt, s.status, touch_nx, touch_nx_bytes));
             else if (bits_out) VKN_TRY(vkn_launch_decode_bits(x, s.kfh, s.kfl, kb, bits_out, d->thr_logit, B, N, C, P, st, xdt));
             else VKN_TRY(decode_final(kb));
         }
@@ -1324,6 +1332,11 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
         so.prev_pre = prev_pre;
         so.link_track = (last && track_out) ? link_track : nullptr;
         so.track_src = track_src;
+        if (!last && use_fused && !(flags & (VKN_FLAG_CHAIN_LAUNCHES | VKN_FLAG_EXACT_GEMM)) &&
+            ((flags & VKN_FLAG_CHAIN_PERSISTENT) || (d->B * d->N + 31) / 32 >= 64)) {   // the fused pass of this stage ends in the next stage's gather reduction
+            so.touch_next = stages[sidx + 1].prepared;
+            so.touch_next_bytes = stages[sidx + 1].prepared_bytes;
+        }
         hipEvent_t ev0 = last ? static_cast<hipEvent_t>(ev_decode_start) : nullptr;
         hipEvent_t ev1 = last ? static_cast<hipEvent_t>(ev_decode_stop) : nullptr;
         float* up_out = (last && scaled_out && upsample_stride > 1) ? scaled_out : nullptr;

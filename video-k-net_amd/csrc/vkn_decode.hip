@@ -168,6 +168,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
                 /* plain 88.7-94.6 us, nt 81.9-86.2 us, sc0|nt 78.3-82.7 us.  ABL 4 = plain, ABL 6 = nt only (A/B)     */ \
                 REG[e] = VKN_ABL_IS(ABL, 4) ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 0) \
                          : VKN_ABL_IS(ABL, 6) ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 2) \
+                         : VKN_ABL_IS(ABL, 7) ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 16) /* sc1 */ \
+                         : VKN_ABL_IS(ABL, 8) ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 18) /* sc1 nt */ \
+                         : VKN_ABL_IS(ABL, 9) ? __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 19) /* sc0 sc1 nt */ \
                                       : __builtin_amdgcn_raw_buffer_load_b64(xrs, voff_, soff_ + ((e * P) << 2), 3); \
         }                                                                                                        \
         const bool adv_ = (ld_cnt + 1 < total);                                                                  \
@@ -500,6 +503,9 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
         else if (NBV == 4 && abl == 4) DEC_LAUNCH(4, 4, 3, 0);  \
         else if (NBV == 4 && abl == 5) DEC_LAUNCH(4, 5, 3, 0);  \
         else if (NBV == 4 && abl == 6) DEC_LAUNCH(4, 6, 3, 0);  \
+        else if (NBV == 4 && abl == 7) DEC_LAUNCH(4, 7, 3, 0);  \
+        else if (NBV == 4 && abl == 8) DEC_LAUNCH(4, 8, 3, 0);  \
+        else if (NBV == 4 && abl == 9) DEC_LAUNCH(4, 9, 3, 0);  \
         else DEC_LAUNCH(NBV, 0, 3, 0);                          \
         break;
 #else

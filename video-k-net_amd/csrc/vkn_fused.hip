@@ -514,7 +514,7 @@ int vkn_fused_supported(int C, int P) {
 // cnt [B][N]; part / cntp: the gather's workspace ([B][G][NPT][C], [B][G][NPT], G = vkn_gather_groups(B, P)).
 int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float thr,
                                    float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C, int P,
-                                   hipStream_t stream, int xdt, int* status) {
+                                   hipStream_t stream, int xdt, int* status, const void* touch, size_t touch_bytes) {
     if (B <= 0 || N <= 0 || P <= 0 || xdt < 0 || xdt > 2) return VKN_E_ARG;
     if (!vkn_fused_supported(C, P)) return VKN_E_SHAPE;
     const int NPT = (N + 31) / 32 * 32;
@@ -660,7 +660,7 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
 #endif
         VKN_CHECK_LAUNCH();
     }
-    return vkn_launch_gather_reduce(part, cntp, xraw, cnt, B, N, C, G, stream, status);  // the unfused path's fixed-order second pass
+    return vkn_launch_gather_reduce(part, cntp, xraw, cnt, B, N, C, G, stream, status, touch, touch_bytes);  // the unfused path's fixed-order second pass
 }
 
 #ifdef VKN_DEBUG

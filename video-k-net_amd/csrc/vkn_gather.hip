@@ -490,7 +490,20 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_bits_w(const float* __
 // compare per OUTPUT value of this small kernel watches the whole feature map for free (include/vkn.h: VKN_E_RANGE).
 __global__ __launch_bounds__(256) void k_gather_reduce(const float* __restrict__ part, const float* __restrict__ cntp,
                                                         float* __restrict__ xraw, float* __restrict__ cnt, int N, int NPT,
-                                                        int C, int G, int* __restrict__ status) {
+                                                        int C, int G, int* __restrict__ status, const char* __restrict__ touch,
+                                                        unsigned touch_bytes) {
+    // `touch` (or NULL): the pre-split weights of the [N x C] chain that runs right behind this kernel.  Between two stages the
+    // x-streaming passes push > 1 GB through the memory-side cache, so the chain's 117 workgroups — all streaming the same 12 MB in
+    // lock-step — would take every tile's first touch from HBM; this latency-bound kernel has the bandwidth to spare and pulls them
+    // into the memory-side cache on the way (one 16-byte load per thread and 64 KB step; the values are discarded).
+    if (touch) {
+        const unsigned per = (touch_bytes / gridDim.x + 15u) & ~15u;
+        const unsigned t0 = blockIdx.x * per, t1 = min(t0 + per, touch_bytes & ~15u);
+        for (unsigned o = t0 + threadIdx.x * 16u; o < t1; o += 256u * 16u) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(touch + o);
+            asm volatile("" ::"v"(v));
+        }
+    }
     __shared__ f32x4 comb[3][64];
     const int row = blockIdx.x;  // b*N + n
     const int b = row / N, n = row - b * N;
@@ -556,8 +569,10 @@ __global__ __launch_bounds__(256) void k_gather_ref(const float* __restrict__ x,
 }
 
 int vkn_launch_gather_reduce(const float* part, const float* cntp, float* xraw, float* cnt, int B, int N, int C, int G,
-                             hipStream_t stream, int* status) {
-    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, (N + 31) / 32 * 32, C, G, status);
+                             hipStream_t stream, int* status, const void* touch, size_t touch_bytes) {
+    if (touch_bytes >= (1ull << 31)) touch = nullptr;
+    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, (N + 31) / 32 * 32, C, G, status,
+                       static_cast<const char*>(touch), (unsigned)touch_bytes);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
@@ -573,17 +588,19 @@ int vkn_gather_groups(int B, int P) {
 
 // part: [B][G][NPT][C] f32, cntp: [B][G][NPT] f32 (workspace); xraw [B][N][C], cnt [B][N] outputs.
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                      int B, int N, int C, int P, hipStream_t stream, int xdt, int* status) {
-    return vkn_launch_gather_ex(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, N, stream, xdt, status);
+                      int B, int N, int C, int P, hipStream_t stream, int xdt, int* status, const void* touch, size_t touch_bytes) {
+    return vkn_launch_gather_ex(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, N, stream, xdt, status, touch, touch_bytes);
 }
 
 // mask_rows: rows per frame of the logits tensor the N gathered rows live in (>= N; `masks` points at the first of them)
 static int gather_launch(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
-                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt = 0, int* status = nullptr);
+                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt = 0, int* status = nullptr,
+                         const void* touch = nullptr, size_t touch_bytes = 0);
 
 int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                         int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt, int* status) {
-    return gather_launch(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 0, stream, xdt, status);
+                         int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt, int* status, const void* touch,
+                         size_t touch_bytes) {
+    return gather_launch(x, masks, thr, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 0, stream, xdt, status, touch, touch_bytes);
 }
 
 // REAL-valued left operand a [B][mask_rows][P] (first N rows used): xraw = sum_p a x, cnt = sum_p a
@@ -600,13 +617,15 @@ int vkn_launch_gather_soft(const float* x, const float* masks, float thr, float*
 
 // binary operand given as bit words [B][P/64][2][roundup(N,32)] (vkn_launch_decode_bits); P % 64 == 0
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
-                           int C, int P, hipStream_t stream, int xdt, int* status) {
+                           int C, int P, hipStream_t stream, int xdt, int* status, const void* touch, size_t touch_bytes) {
     if ((P % 64) != 0) return VKN_E_SHAPE;
-    return gather_launch(x, reinterpret_cast<const float*>(bits), 0.f, xraw, cnt, part, cntp, B, N, C, P, N, 1, stream, xdt, status);
+    return gather_launch(x, reinterpret_cast<const float*>(bits), 0.f, xraw, cnt, part, cntp, B, N, C, P, N, 1, stream, xdt, status, touch,
+                         touch_bytes);
 }
 
 static int gather_launch(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
-                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt, int* status) {
+                         int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt, int* status, const void* touch,
+                         size_t touch_bytes) {
     if (B <= 0 || N <= 0 || P <= 0 || mask_rows < N) return VKN_E_ARG;
     if (xdt < 0 || xdt > 2) return VKN_E_ARG;
     if (xdt && (bits >= 2 || (P % 64) != 0)) return VKN_E_SHAPE;  // half-storage x: binary operands, whole 16-byte aligned tiles
@@ -674,7 +693,8 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
 #undef GA_LAUNCH
         VKN_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, NPT, C, G, status);
+    hipLaunchKernelGGL(k_gather_reduce, dim3(B * N), dim3(256), 0, stream, part, cntp, xraw, cnt, N, NPT, C, G, status,
+                       static_cast<const char*>(touch), (unsigned)(touch_bytes < (1ull << 31) ? touch_bytes : 0));
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -41,9 +41,11 @@ struct VknGemmProb {
 
 int vkn_gather_groups(int B, int P);
 // `status` (last argument of the gather launchers that end in k_gather_reduce; NULL = no check): a device int, VKN_STATUS_RANGE is OR-ed
-// in when a gathered sum is not finite (include/vkn.h: VKN_E_RANGE)
+// in when a gathered sum is not finite (include/vkn.h: VKN_E_RANGE).  `touch` / `touch_bytes` (or NULL): memory the reduction pulls into the
+// memory-side cache on the way — the weights of the chain that follows (k_gather_reduce)
 int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                         int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt = 0, int* status = nullptr);
+                         int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt = 0, int* status = nullptr,
+                         const void* touch = nullptr, size_t touch_bytes = 0);
 int vkn_launch_gather_ref_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                              int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C,
@@ -51,16 +53,19 @@ int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* c
 int vkn_launch_gather_soft(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
                            int N, int C, int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
-                           int C, int P, hipStream_t stream, int xdt = 0, int* status = nullptr);
+                           int C, int P, hipStream_t stream, int xdt = 0, int* status = nullptr, const void* touch = nullptr,
+                           size_t touch_bytes = 0);
 int vkn_launch_gather_reduce(const float* part, const float* cntp, float* xraw, float* cnt, int B, int N, int C, int G,
-                             hipStream_t stream, int* status = nullptr);
+                             hipStream_t stream, int* status = nullptr, const void* touch = nullptr, size_t touch_bytes = 0);
 // stage s decode fused with the stage s + 1 gather (vkn_fused.hip)
 int vkn_fused_supported(int C, int P);
 int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float thr,
                                    float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C, int P,
-                                   hipStream_t stream, int xdt = 0, int* status = nullptr);
+                                   hipStream_t stream, int xdt = 0, int* status = nullptr, const void* touch = nullptr,
+                                   size_t touch_bytes = 0);
 int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
-                      int B, int N, int C, int P, hipStream_t stream, int xdt = 0, int* status = nullptr);
+                      int B, int N, int C, int P, hipStream_t stream, int xdt = 0, int* status = nullptr, const void* touch = nullptr,
+                      size_t touch_bytes = 0);
 int vkn_launch_gather_ref(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                           int P, hipStream_t stream);
 // per-frame element strides of the decode operands (shared kernels: 0)
