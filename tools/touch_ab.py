@@ -1,3 +1,6 @@
+"""In-step A/B of the two weight-latency measures of the persistent chain (debug library): VKN_CHAIN_TOUCH (the gather reduction warms the
+memory-side cache with the next chain's weights) and the per-unit cache-line prefetch distance (VKN_CHAIN_ABL 11 / 12 / 13 = 0 / 4 / 12 units).
+    python tools/touch_ab.py"""
 import os, sys, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import vkn_import
@@ -22,10 +25,12 @@ def timeit(fn, iters=30, warm=6):
 with torch.no_grad():
     ref = None
     for rep in range(3):
-        for t in (1, 0):
+        for t, abl in ((1, 0), (0, 0)):
             os.environ['VKN_CHAIN_TOUCH'] = str(t)
+            os.environ['VKN_CHAIN_ABL'] = str(abl)
             ms = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True))
             out = head._head_forward(x, pf, mp, prev, want_track=True)
             if ref is None: ref = out
             same = all(torch.equal(a, b) for a, b in zip(out, ref))
-            print(f'touch={t}: {ms:.3f} ms per 32-frame step -> {B / ms * 1e3:.0f} frames/s  identical outputs: {same}')
+            pfd = 0
+            print(f'touch={t} line-prefetch {pfd:2d} units ahead: {ms:.3f} ms per 32-frame step -> {B / ms * 1e3:.0f} frames/s  identical outputs: {same}')

@@ -163,6 +163,10 @@ __device__ __forceinline__ void ch_gemm(f32x16 (&acc)[NACC], const __bf16* img0,
             } else if (nx.nacc) {
                 ch_wload<RING, AUX>(R, (j + RING - 1) % RING, wrs, L, nx.off(un - NU));
             }
+            // (Measured and dropped, round 4: one extra dword load per unit that touches the 48 cache lines of the unit 4 / 8 / 12 ahead,
+            //  to cover the memory-side latency inside a head step — 3.44 / 3.42-3.53 / 3.49 ms per 32-frame step against 3.38 without:
+            //  the stream is bound by the CU's L2 -> L1 path, and a line prefetch moves every byte over that path twice.  Warming the
+            //  memory-side cache from the gather reduction (k_gather_reduce `touch`) is what helps: 3.45 -> 3.38 ms.)
             // the request stays HERE, RING - 1 units ahead of its use: without the fence the machine scheduler sinks every load to just
             // before its MFMA (load, s_waitcnt vmcnt(0), mfma) to save registers — the whole point of the ring
             __builtin_amdgcn_sched_barrier(0);
