@@ -82,8 +82,8 @@ if con:
             timed = instep[-line['steps']:]
             t_timed = sum(timed) / len(timed)
             print(f'roofline recomputed from this trace: algorithmic {alg / 1e6:.1f} MB per launch; in-step (all {len(instep)}) '
-                  f'{alg / t_in / 1e6 / 8000:.4f}, in-step (the {len(timed)} timed steps) {alg / t_timed / 1e6 / 8000:.4f}, '
-                  f'back-to-back loop {alg / t_loop / 1e6 / 8000 if loop else 0:.4f} of 8 TB/s')
+                  f'{alg / t_in / 1e3 / 8000:.4f}, in-step (the {len(timed)} timed steps) {alg / t_timed / 1e3 / 8000:.4f}, '
+                  f'back-to-back loop {alg / t_loop / 1e3 / 8000 if loop else 0:.4f} of 8 TB/s')
             print(f'bench line of the SAME traced process: avg_launch_ms={rl["avg_launch_ms"]} (HIP events) frac={rl["frac"]} '
                   f'isolated_loop_launch_ms={rl["isolated_loop_launch_ms"]} isolated_loop_frac={rl["isolated_loop_frac"]} '
                   f'-> events / trace = {rl["avg_launch_ms"] * 1e3 / t_timed:.3f} (in-step), '
