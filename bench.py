@@ -539,7 +539,7 @@ def main():
             # frame per call; `value` above is at `--frames` per call
             per_call = {}
             for b_ in (1, 8):
-                if b_ >= B:
+                if b_ >= B or args.head != 'ffn':     # (the previous_link head needs its link packs: only its headline step is timed)
                     continue
                 dims_b = last.make_dims(b_, N, CFG2['H'], CFG2['W'])
                 xb, pfb, mpb = x[:b_], pf[:b_].reshape(b_, N, C), mp[:b_]
@@ -596,7 +596,7 @@ def main():
             # the same step with x STORED as fp16 / bf16 (VKN_FLAG_X_F16 / _BF16: fp32 compute, half the x bytes; bit-identical to
             # the fp32 path on the rounded x, tests/test_gpu_xhalf.py) — reported next to the fp32 headline, never as `value`
             variants = {}
-            if xeb == 4 and world == 1 and NS == 1:
+            if xeb == 4 and world == 1 and NS == 1 and args.head == 'ffn':
                 del loc, sem
                 for nm in ('fp16', 'bf16'):
                     xh = x.to(XDT[nm])

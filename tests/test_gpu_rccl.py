@@ -155,3 +155,15 @@ def test_bench_under_torchrun_one_rank_matches_plain_run():
                    launcher=['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
                              '--master-port', str(_free_port())])
     assert train['n_gpus'] == 1 and train['value'] > 0
+
+
+def test_bench_previous_link_head_under_torchrun_one_rank():
+    """`bench.py --head update` (the previous_link heads: phases A / B / C around one receive / one send per rank boundary) as the driver
+    would launch it on N GPUs — here one rank, RCCL initialised: it runs and reports the metric of the phased clip step."""
+    port = _free_port()
+    line = _bench(['--force-dist', '--head', 'update', '--frames', '8'],
+                  launcher=['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                            '--master-port', str(port)])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and 'previous_link=update_dynamic_cov' in line['config']['workload']
+    assert line['config']['frames_per_gpu_per_step'] == 8
+

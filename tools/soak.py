@@ -173,6 +173,49 @@ def t_head_c256():
         assert float((a[4] - e[4]).abs().max()) < 1e-4 * max(1.0, float(e[4].abs().max())), tag
 
 
+def t_chain_persistent():
+    """The persistent row-owner chain (k_chain_a / k_chain_c, forced) against the launch-per-GEMM chain and the exact-fp32 GEMM chain:
+    random row counts (ragged last tile, 1 .. 20 row tiles), hidden widths 256 .. 2048, class counts 1 .. 200, S = 1..3 stages, with /
+    without the video link, whole-head calls (so the fused hand-off and the weight warm-up in the gather reduction are in the loop)."""
+    from test_host_logic import _cfg
+    N = int(rng.integers(2, 200))
+    B = int(rng.integers(1, 5))
+    H, W = int(rng.choice([4, 8])), int(rng.choice([8, 16]))
+    video = bool(rng.integers(0, 2))
+    ff = int(rng.choice([256, 512, 1024, 2048]))
+    ncls = int(rng.choice([1, 3, 19, 40, 124, 200]))
+    S = int(rng.integers(1, 4))
+    key = ('chain', video, ff, ncls, S)
+    if key not in _heads:
+        n_stuff = 1 if ncls < 3 else 2
+        h = vkn.build_head(_cfg(video, C=256, heads=8, ffn=ff, ncls=ncls, n_thing=max(ncls - n_stuff, 0) or 1, n_stuff=n_stuff if ncls > 1 else 0,
+                                S=S, up=2, nprop=100))
+        h.init_weights()
+        _heads[key] = h.to(dev).eval()
+    head = _heads[key]
+    x, pf = torch.randn(B, 256, H, W, device=dev), torch.randn(B, N, 256, device=dev)
+    mp = torch.randn(B, N, H, W, device=dev) * 3
+    first = torch.randn(1, N, 256, device=dev)
+    dims = head.mask_head[0].make_dims(B, N, H, W)
+    packs = [h.stage_pack(torch.device(dev)) for h in head.mask_head]
+    kw = dict(clip_first_prev=first) if video else {}
+    tag = ('chain', video, B, N, H, W, ff, ncls, S)
+    p = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=vkn.ops.FLAG_CHAIN_PERSISTENT, **kw)
+    p2 = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=vkn.ops.FLAG_CHAIN_PERSISTENT, **kw)
+    assert all(a is None or torch.equal(a, b) for a, b in zip(p, p2)), ('not deterministic',) + tag
+    assert all(a is None or bool(torch.isfinite(a).all()) for a in p), ('non-finite',) + tag
+    if S == 1:      # one stage: no binarisation between the chains -> fp32-rounding agreement on every output
+        q = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=vkn.ops.FLAG_CHAIN_LAUNCHES, **kw)
+        e = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=2, **kw)
+        for other in (q, e):
+            assert float((p[1] - other[1]).abs().max()) < 1e-5, tag
+            assert float((p[0] - other[0]).abs().max()) < 1e-4 * max(1.0, float(other[0].abs().max())), tag
+            assert float((p[2] - other[2]).abs().max()) < 1e-3 * max(1.0, float(other[2].abs().max()) / 50), tag
+            if video:
+                assert float((p[4] - other[4]).abs().max()) < 1e-4 * max(1.0, float(other[4].abs().max())), tag
+    vkn.ops.workspace_status()
+
+
 def t_head_fused():
     """fused decode->gather pass vs bit words vs fp32 logits between stages, side-stream vs serial link: bit-identical outputs."""
     from test_host_logic import _cfg
@@ -374,6 +417,7 @@ with torch.no_grad():
     for name, fn in (('gather / decode', t_gather_decode), ('upsample', t_upsample), ('panoptic joint', t_panoptic),
                      ('head bit vs logits hand-off', t_head_handoff), ('assignment costs', t_assign),
                      ('kernel init', t_kernel_init), ('head C=256 split vs exact GEMMs', t_head_c256),
+                     ('persistent chain vs launch chain vs exact', t_chain_persistent),
                      ('head fused / bits / logits / side stream', t_head_fused), ('half-storage x', t_xhalf),
                      ('device LSAP vs host solver', t_lsap), ('device tracker vs oracle', t_tracker),
                      ('link heads clip vs frame-by-frame', t_link_heads), ('VIS attention query merge', t_query_merge),
