@@ -388,3 +388,20 @@ def test_chain_graph_gradient_delivery_survives_inplace_zero_and_accumulation(vk
     p.grad = None                         # the usual loop
     backward([5., 6., 7.])
     assert p.grad.tolist() == [5., 6., 7.] and p.grad.data_ptr() == buf.data_ptr()   # fast path still hands the buffer itself over
+
+
+def test_python_flag_constants_match_the_header(vkn):
+    """`ops.FLAG_*` / `ops.PHASE_*` are typed by hand: they must equal include/vkn.h's VKN_FLAG_* values (and no two flags may share a bit)."""
+    import re
+    text = open(os.path.join(ROOT, 'include', 'vkn.h')).read()
+    hdr = {m.group(1): int(m.group(2)) for m in re.finditer(r'#define VKN_FLAG_(\w+) (\d+)u', text)}
+    assert len(hdr) >= 12 and len(set(hdr.values())) == len(hdr)
+    assert all(v & (v - 1) == 0 for v in hdr.values()), 'every flag is one bit'
+    py = dict(REF_KERNELS=vkn.ops.FLAG_REF_KERNELS, EXACT_GEMM=vkn.ops.FLAG_EXACT_GEMM, LOGITS_HANDOFF=vkn.ops.FLAG_LOGITS_HANDOFF,
+              BITS_HANDOFF=vkn.ops.FLAG_BITS_HANDOFF, SERIAL_LINK=vkn.ops.FLAG_SERIAL_LINK, X_F16=vkn.ops.FLAG_X_F16,
+              X_BF16=vkn.ops.FLAG_X_BF16, CHAIN_LAUNCHES=vkn.ops.FLAG_CHAIN_LAUNCHES, CHAIN_PERSISTENT=vkn.ops.FLAG_CHAIN_PERSISTENT,
+              PHASE_A=vkn.ops.PHASE_A, PHASE_B=vkn.ops.PHASE_B, PHASE_C=vkn.ops.PHASE_C, CLIP_LINK=8)
+    for k, v in py.items():
+        assert hdr[k] == v, (k, hdr[k], v)
+    assert int(re.search(r'#define VKN_E_RANGE \((-\d+)\)', text).group(1)) == -6
+    assert vkn._lib.lib().vkn_strerror(-6).decode().startswith('feature map outside')
