@@ -227,19 +227,19 @@ def test_head_cfg1_size_vs_reference_golden(vkn):
     assert np.all((bits ^ g['sign_bits']) & g['sign_valid'] == 0), 'binary masks (|logit| > 2e-3) must be bit-exact'
 
 
-# Measured on MI355X in round 4 (profiles/r04_parity_margins.json, both forms of the [N x C] chain), then given 2x head-room: errors
-# may double, a share may lose as many rows again as it has lost (at least two), flipped bits may double (at least two).
-#   video_vipseg_big  (166 rows): 165 rows clean (one kernel sits on the threshold), 3 wrong off-threshold bits, clean kernels 2.1e-5,
-#                                 sampled clean logits 2.6e-4
-#   det_ytvis         (200 rows): every row clean, 0 wrong bits, kernels 5.8e-6, logits 4.8e-5
-#   video_vipseg_n216 (216 rows): every row clean, 0 wrong bits, kernels 7.4e-6, logits 6.1e-5
+# Measured on MI355X in round 4 (profiles/r04_parity_margins.json) over FOUR realisations of the [N x C] chain's fp32 summation order
+# (launch-per-GEMM on k_gemm_s3 / on k_gemm_t3, the persistent kernels, the persistent kernels with a split FFN), then given 2x
+# head-room: errors may double (capped by the hard tolerance), a share may lose as many rows again as it has lost (at least two),
+# flipped bits may double (at least two).  Each of the two VIP-Seg cases has ONE kernel whose hand-over mask sits on the threshold: it
+# flips in some realisations and not in others (worst seen: 1 row, 7 off-threshold bits, clean kernels 4.9e-5, clean logits 6.6e-4;
+# best: every row clean, 0 bits, 7.0e-6 / 5.9e-5).  YouTube-VIS: every row clean in every realisation.
 FREE_RUN_LIMITS = {
     'video_vipseg_big': dict(clean_share_of_stable=0.985, share_rows_kernels_within_2e4=1 - 3 / 166, share_rows_sampled_logits_within_1e3=1 - 3 / 166,
-                             wrong_bits_off_threshold=6, worst_clean_kernel_err=4.3e-5, worst_clean_sampled_logit_err=5.2e-4),
+                             wrong_bits_off_threshold=14, worst_clean_kernel_err=1.0e-4, worst_clean_sampled_logit_err=1.0e-3),
     'det_ytvis': dict(clean_share_of_stable=0.99, share_rows_kernels_within_2e4=1 - 2 / 200, share_rows_sampled_logits_within_1e3=1 - 2 / 200,
                       wrong_bits_off_threshold=2, worst_clean_kernel_err=1.2e-5, worst_clean_sampled_logit_err=1.0e-4),
-    'video_vipseg_n216': dict(clean_share_of_stable=0.99, share_rows_kernels_within_2e4=1 - 2 / 216, share_rows_sampled_logits_within_1e3=1 - 2 / 216,
-                              wrong_bits_off_threshold=2, worst_clean_kernel_err=1.5e-5, worst_clean_sampled_logit_err=1.3e-4),
+    'video_vipseg_n216': dict(clean_share_of_stable=0.99, share_rows_kernels_within_2e4=1 - 3 / 216, share_rows_sampled_logits_within_1e3=1 - 3 / 216,
+                              wrong_bits_off_threshold=14, worst_clean_kernel_err=1.0e-4, worst_clean_sampled_logit_err=1.0e-3),
 }
 
 

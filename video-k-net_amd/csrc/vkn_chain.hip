@@ -710,6 +710,227 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ one GEMM per launch on the same engine
+// k_gemm_t3: out = epi((A (.* A2) (+ A3 .* A4)) . W^T) for K == 256 with the row epilogue of k_gemm_s3 (vkn_update.hip: VknEpi) — the
+// launch-per-GEMM chain of few-row calls (frame-by-frame video inference: 117 rows), the link blocks and the stand-alone linear entry
+// points.  Same tile (32 rows x 256 columns per workgroup, wave = column block), same six products per operand pair, but the K loop is
+// the chain kernels': the A tile is split ONCE into a resident LDS image (K = 256 whole), the weight fragments go straight from
+// global memory into the consumer wave's register ring, no barrier and no LDS-DMA inside the loop, the epilogue runs in registers
+// (LayerNorm through the 16-partial exchange).  k_gemm_s3's loop cost 0.87 us per K-tile with a barrier each (7 us of a 13.8 us
+// launch at 117 rows); this one streams at ~0.5 us per tile.  Up to two problems per launch (blockIdx.z), as k_gemm_s3.
+template <int ABL>
+__global__ __launch_bounds__(CH_THREADS) void k_gemm_t3(const VknGemmProb p0, const VknGemmProb p1, int nprob, int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem_t3[];
+    __bf16* IMG = reinterpret_cast<__bf16*>(smem_t3);
+    float* S = reinterpret_cast<float*>(IMG + CH_IMG);
+    const bool second = (nprob > 1) && (blockIdx.z == 1);
+    const VknGemmProb& P = second ? p1 : p0;
+    const VknEpi& E = P.epi;
+    const int Nout = P.Nout;
+    const int m0 = blockIdx.y * CH_ROWS, n0 = blockIdx.x * 256;
+    if (n0 >= Nout) return;   // grouped launch: the grid is sized for the wider problem (uniform exit before any barrier)
+
+    const int tid = threadIdx.x;
+    const ChLane L = ch_lane(tid);
+    const int ntiles = (Nout + 255) / 256;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.Wsplit), 0, (int)((unsigned)ntiles * 8u * CH_WTILE), 0x00020000);
+    const unsigned wbase = (unsigned)blockIdx.x * 8u * CH_WTILE;
+    constexpr int RING = CH_RING_OF(ABL);
+    ChRing<RING> R;
+#pragma unroll
+    for (int j = 0; j < RING - 1; ++j) ch_wload<RING, CH_AUX_OF(ABL)>(R, j, wrs, L, wbase + (unsigned)j * CH_WTILE);
+
+    // ---- the A tile -> bf16x3 image (optional elementwise prologue: A .* A2 + A3 .* A4, the updator's gate / mix)
+    {
+        const int row = tid >> 4, c4 = (tid & 15) << 2;
+        const size_t ro = (size_t)min(m0 + row, M - 1) * P.lda + c4;
+        f32x4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const f32x4*>(P.A + ro + 64 * j);
+        if (P.A2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] *= *reinterpret_cast<const f32x4*>(P.A2 + ro + 64 * j);
+        }
+        if (P.A3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                t[j] += *reinterpret_cast<const f32x4*>(P.A3 + ro + 64 * j) * *reinterpret_cast<const f32x4*>(P.A4 + ro + 64 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c4 + 64 * j;
+            cbf16x4 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 hh, mm, ll;
+                ch_split3(t[j][e], hh, mm, ll);
+                h[e] = hh;
+                m[e] = mm;
+                l[e] = ll;
+            }
+            __bf16* d = IMG + row * CH_C + ((((col >> 3) ^ row) & 31) << 3) + (col & 7);
+            *reinterpret_cast<cbf16x4*>(d) = h;
+            *reinterpret_cast<cbf16x4*>(d + CH_PLANE) = m;
+            *reinterpret_cast<cbf16x4*>(d + 2 * CH_PLANE) = l;
+        }
+    }
+    // ---- the lane's sixteen columns and their epilogue constants (requested before the K loop: their round trips ride under it)
+    const int row = m0 + L.li;
+    const bool row_ok = row < M;
+    const int rowc = min(row, M - 1);
+    const int ncols = min(256, Nout - n0);
+    const bool do_ln = (E.ln_w != nullptr) && (n0 >= E.ln_from_col);
+    float bias[16], lnw[16], lnb[16], rv[16];
+    bool okc[16];
+    const float bscale = (E.bias && E.rowscale) ? E.rowscale[rowc] : 1.f;
+    // a full, 16-byte aligned tile (every chain GEMM but fc_cls): four float4 loads per vector instead of sixteen dword loads
+    const bool vec4 = ncols == 256 && ((reinterpret_cast<uintptr_t>(E.bias) | reinterpret_cast<uintptr_t>(E.bias2) | reinterpret_cast<uintptr_t>(E.ln_w) |
+                                        reinterpret_cast<uintptr_t>(E.ln_b) | reinterpret_cast<uintptr_t>(E.resid)) & 15) == 0 && (E.ldr & 3) == 0;
+    if (vec4) {
+        const int cb = n0 + L.wave * 32 + 4 * L.g;
+        auto ld4 = [&](const float* p, float dflt, float (&o)[16]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t = p ? *reinterpret_cast<const f32x4*>(p + 8 * q) : f32x4{dflt, dflt, dflt, dflt};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * q + e] = t[e];
+            }
+        };
+        float b2[16];
+        ld4(E.bias ? E.bias + cb : nullptr, 0.f, bias);
+        ld4(E.bias2 ? E.bias2 + cb : nullptr, 0.f, b2);
+        ld4(do_ln ? E.ln_w + (cb - E.ln_from_col) : nullptr, 1.f, lnw);
+        ld4(do_ln ? E.ln_b + (cb - E.ln_from_col) : nullptr, 0.f, lnb);
+        ld4(E.resid ? E.resid + (size_t)rowc * E.ldr + cb : nullptr, 0.f, rv);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            okc[r] = true;
+            bias[r] = bias[r] * bscale + b2[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = L.wave * 32 + 8 * (r >> 2) + 4 * L.g + (r & 3);   // column inside the tile
+            okc[r] = cl < ncols;
+            const int c = n0 + min(cl, ncols - 1);
+            float b = E.bias ? E.bias[c] * bscale : 0.f;
+            if (E.bias2) b += E.bias2[c];
+            bias[r] = b;
+            lnw[r] = do_ln ? E.ln_w[c - E.ln_from_col] : 1.f;
+            lnb[r] = do_ln ? E.ln_b[c - E.ln_from_col] : 0.f;
+            rv[r] = E.resid ? E.resid[(size_t)rowc * E.ldr + c] : 0.f;
+        }
+    }
+    CH_BAR();
+
+    f32x16 acc[1];
+    ch_zero(acc[0]);
+    ch_gemm<1, true, ABL>(acc, IMG, IMG, wbase, 0u, ChNext{0u, 0u, 0}, R, wrs, L);
+
+    float v[1][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[0][r] = okc[r] ? (acc[0][r] + bias[r] + rv[r]) : 0.f;
+    if (do_ln) {   // LayerNorm over the tile's ncols columns (two-pass), as vkn_row_epilogue
+        float pr[1];
+        pr[0] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[0] += v[0][r];
+        ch_rowsum<1>(pr, S, L);
+        const float mean = pr[0] / (float)ncols;
+        pr[0] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dlt = okc[r] ? (v[0][r] - mean) : 0.f;
+            pr[0] += dlt * dlt;
+        }
+        ch_rowsum<1>(pr, S + CH_SBUF, L);
+        const float rstd = 1.0f / sqrtf(pr[0] / (float)ncols + E.eps);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[0][r] = (v[0][r] - mean) * rstd * lnw[r] + lnb[r];
+    }
+    if (E.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[0][r] = fmaxf(v[0][r], 0.f);
+    } else if (E.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[0][r] = 1.0f / (1.0f + expf(-v[0][r]));
+    }
+    if (E.out && row_ok) {
+        float* o = E.out + (size_t)row * E.ldo + n0 + L.wave * 32 + 4 * L.g;
+        const bool vec = ((E.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.out) & 15) == 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (vec && okc[4 * q + 3]) {
+                *reinterpret_cast<f32x4*>(o + 8 * q) = f32x4{v[0][4 * q], v[0][4 * q + 1], v[0][4 * q + 2], v[0][4 * q + 3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (okc[4 * q + e]) o[8 * q + e] = v[0][4 * q + e];
+            }
+        }
+    }
+    if (E.dot_vec) {   // (uniform) side output: dot_out[row] = sum_col v * dot_vec[col] (+ *dot_bias) — the folded decode bias
+        float pr[1];
+        pr[0] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = L.wave * 32 + 8 * (r >> 2) + 4 * L.g + (r & 3);
+            pr[0] += okc[r] ? v[0][r] * E.dot_vec[n0 + cl] : 0.f;
+        }
+        CH_BAR();                       // (the exchange buffer may still be read by a slower wave of the LayerNorm above)
+        ch_rowsum<1>(pr, S, L);
+        if (row_ok && L.wave == 0 && L.g == 0) E.dot_out[row] = pr[0] + (E.dot_bias ? *E.dot_bias : 0.f);
+    }
+    if (E.plane_hi && row_ok) {
+        const int fb = row / E.rows_per_frame, n = row - fb * E.rows_per_frame;
+        const size_t base = ((size_t)fb * E.NPT + n) * E.ldo + n0 + L.wave * 32 + 4 * L.g;
+        const bool vec = ((E.ldo & 3) == 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            half4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 hh, ll;
+                vkn_split_f16(v[0][4 * q + e], hh, ll);
+                h[e] = hh;
+                l[e] = ll;
+            }
+            if (vec && okc[4 * q + 3]) {
+                *reinterpret_cast<half4*>(E.plane_hi + base + 8 * q) = h;
+                *reinterpret_cast<half4*>(E.plane_lo + base + 8 * q) = l;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (okc[4 * q + e]) {
+                        E.plane_hi[base + 8 * q + e] = h[e];
+                        E.plane_lo[base + 8 * q + e] = l[e];
+                    }
+            }
+        }
+    }
+}
+
+// K == 256, pre-split weights, no split-K: the problems of one launch (same M).  Returns VKN_E_SHAPE when the kernel does not apply
+// (the caller then takes k_gemm_s3).
+int vkn_launch_gemm_t3(const VknGemmProb* probs, int nprob, int M, hipStream_t stream) {
+    if (nprob < 1 || nprob > 2 || M <= 0) return VKN_E_ARG;
+    int nmax = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const VknGemmProb& p = probs[i];
+        if (!p.Wsplit || (p.lda & 3) || (reinterpret_cast<uintptr_t>(p.A) & 15) || (p.A2 && (reinterpret_cast<uintptr_t>(p.A2) & 15)) ||
+            (p.A3 && ((reinterpret_cast<uintptr_t>(p.A3) & 15) || !p.A4 || (reinterpret_cast<uintptr_t>(p.A4) & 15))))
+            return VKN_E_SHAPE;
+        if ((size_t)((p.Nout + 255) / 256) * 8 * CH_WTILE >= (1ull << 31)) return VKN_E_SHAPE;
+        nmax = p.Nout > nmax ? p.Nout : nmax;
+    }
+    const size_t lds = (size_t)CH_IMG * sizeof(__bf16) + (size_t)2 * CH_SBUF * sizeof(float);
+    dim3 grid((nmax + 255) / 256, (M + CH_ROWS - 1) / CH_ROWS, nprob);
+    VKN_ALLOW_FULL_LDS(k_gemm_t3<0>);
+    hipLaunchKernelGGL(k_gemm_t3<0>, grid, dim3(CH_THREADS), lds, stream, probs[0], probs[nprob > 1 ? 1 : 0], nprob, M);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ host launchers
 // constant blocks: packed once per weight update into the prepared buffer (vkn_prepare_stage_f32)
 #define CH_PACK_MAX 64
