@@ -229,6 +229,53 @@ int vkn_split_weight_f32(const float* W, void* w_split, int Nout, int K, void* s
 int vkn_linear_f32(const float* A, const float* W, const void* w_split, const float* bias, float* out, int M, int K, int Nout,
                    int act, int ksplit, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- BACKWARD building blocks of the [B*N x C] chain (training).  With these the chain of a training step — every nn.Linear,
+ *      nn.LayerNorm (+ ReLU / sigmoid, + residual) and the attention core of `KernelUpdator.forward` (knet/kernel_updator.py:56-93) and
+ *      `KernelUpdateHead.forward` (knet/det/kernel_update_head.py:198-227; the video links knet/video/kernel_update_head.py:324-476) —
+ *      runs on this library's kernels in both directions (host side: video-k-net_amd/chain_train.py); csrc/vkn_train.hip.
+ *
+ *      vkn_split_weight_t_f32: the bf16x3 tile images of the TRANSPOSE of a stored matrix.  W is [K][Nout] row-major (a torch Linear
+ *      weight [out = K][in = Nout]); the images describe Wt [Nout][K], so that `vkn_linear_f32(dY, ., images, ...)` with M rows,
+ *      K = out features, Nout = in features computes dA = dY . W.  K % 32 == 0; 6 * roundup(Nout, 256) * K bytes.
+ *      vkn_linear_dw_f32: dW[n][k] (+)= sum_m dY[m][n] A[m][k]  ([Nout][K], the weight gradient of Y = A W^T),
+ *      db[n] (+)= sum_m dY[m][n] (or NULL); ldy / lda = row strides of dY / A in floats; accumulate != 0 adds to dW / db.  Exact-fp32
+ *      MFMA (v_mfma_f32_32x32x2_f32), deterministic. */
+int vkn_split_weight_t_f32(const float* W, void* w_split_t, int Nout, int K, void* stream);
+/*      ... of MANY matrices in ONE launch (training: the images of both orientations of every Linear weight of a stage are rebuilt every
+ *      step).  An item describes the matrix Wm [Nout][K] the images stand for through strides into the stored tensor: element (n, k)
+ *      is W[n * ldn + k * ldk] for k < kvalid and 0 for kvalid <= k < K (K % 32 == 0: zero padding of a short contraction).
+ *      A Linear weight [Nout][K]: ldn = K, ldk = 1, kvalid = K; its transpose, W stored [R][Cc]: Nout = Cc, K = roundup(R, 32), ldn = 1,
+ *      ldk = Cc, kvalid = R.  images: 6 * roundup(Nout, 256) * K bytes each, 16-byte aligned.  `items` is a HOST array. */
+#define VKN_SPLIT_MAX_ITEMS 64
+typedef struct VknSplitItem {
+    const float* W;
+    void* images;
+    long long ldn, ldk;
+    int Nout, K, kvalid, reserved;
+} VknSplitItem;
+size_t vkn_sizeof_split_item(void);
+int vkn_split_weights_batch_f32(const VknSplitItem* items, int nitems, void* stream);
+int vkn_linear_dw_f32(const float* dY, int ldy, const float* A, int lda, float* dW, float* db, int M, int K, int Nout, int accumulate,
+                      void* stream);
+/*      out = act(LayerNorm_C(in + resid) * gamma + beta) per row (resid / gamma / beta may be NULL), act 0 none / 1 ReLU / 2 sigmoid;
+ *      stats [M][2] = (mean, 1 / sqrt(var + eps)) for the backward (may be NULL).  C <= 256.  ld* = row strides in floats. */
+int vkn_layernorm_act_fwd_f32(const float* in, int ldi, const float* resid, int ldr, const float* gamma, const float* beta, float eps,
+                              int act, float* out, int ldo, float* stats, int M, int C, void* stream);
+/*      its backward: dx = d loss / d (in + resid) (the same tensor is the gradient of both), dgamma / dbeta [C] (may be NULL; written,
+ *      not accumulated; fixed summation order).  `in`, `resid`, `gamma`, `beta`, `stats`: as in the forward call.  One launch. */
+int vkn_layernorm_act_bwd_f32(const float* dy, int lddy, const float* in, int ldi, const float* resid, int ldr, const float* gamma,
+                              const float* beta, const float* stats, int act, float* dx, int lddx, float* dgamma, float* dbeta, int M,
+                              int C, void* stream);
+/*      the attention core of nn.MultiheadAttention: out[b][i][h] = softmax_j(q_i . k_j / sqrt(hd)) v_j per frame b and head h.
+ *      Q rows b * Nq + i, K / V rows b * Nk + j; head h = columns [h * hd, (h + 1) * hd) of every operand; ld* = row strides
+ *      (q, k, v may be column slices of one packed in_proj output).  hd in {4, 8, 16, 32, 64} for the backward, Nk <= 256.
+ *      Backward: dQ, dK, dV from dO and the forward's O (the softmax is recomputed in fp32 from q, k). */
+int vkn_attention_f32(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* out, int ldo, int B, int Nq, int Nk,
+                      int heads, int hd, void* stream);
+int vkn_attention_bwd_f32(const float* Q, int ldq, const float* K, const float* V, int ldkv, const float* O, int ldo, const float* dO,
+                          int lddo, float* dQ, int lddq, float* dK, float* dV, int lddkv, int B, int Nq, int Nk, int heads, int hd,
+                          void* stream);
+
 /* ---- the gated kernel update alone.  Replaces `KernelUpdator.forward(update_feature, input_feature)`
  *      knet/kernel_updator.py:56-93 (gate_sigmoid=True, gate_norm_act=False, activate_out=False — the defaults, :15-17).
  *      update_feature [B][N][C] (= x_feat), input_feature [B][N][C] (= kernels, K*K = 1) -> out [B][N][C].

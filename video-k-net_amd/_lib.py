@@ -11,14 +11,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
-SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_tracker.hip', 'vkn_loss.hip', 'vkn_chain.hip', 'vkn_api.hip')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_tracker.hip', 'vkn_loss.hip', 'vkn_chain.hip', 'vkn_train.hip', 'vkn_api.hip')
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares
 SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_workspace_init', 'vkn_workspace_status', 'vkn_sizeof_dims', 'vkn_sizeof_stage_weights', 'vkn_gather_workspace_bytes', 'vkn_mask_gather_f32', 'vkn_mask_gather_real_f32',
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
            'vkn_decode_gather_supported', 'vkn_decode_gather_f32', 'vkn_mask_decode_planes_x', 'vkn_decode_gather_x',
-           'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_upsample_bilinear_f32', 'vkn_upsample_bilinear_bwd_f32', 'vkn_kernel_updator_f32',
+           'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_split_weight_t_f32', 'vkn_sizeof_split_item', 'vkn_split_weights_batch_f32', 'vkn_linear_dw_f32', 'vkn_layernorm_act_fwd_f32', 'vkn_layernorm_act_bwd_f32', 'vkn_attention_f32', 'vkn_attention_bwd_f32', 'vkn_upsample_bilinear_f32', 'vkn_upsample_bilinear_bwd_f32', 'vkn_kernel_updator_f32',
            'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_stage_chain_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32', 'vkn_focal_loss_blocks', 'vkn_focal_loss_f32',
            'vkn_head_forward_prof_f32', 'vkn_head_forward_link_f32', 'vkn_stage_forward_link_f32', 'vkn_link_block_f32',
            'vkn_query_merge_workspace_bytes', 'vkn_query_merge_f32',
@@ -78,6 +78,14 @@ class VknError(RuntimeError):
 
 
 _fp = ctypes.c_void_p  # device pointers travel as integers
+
+
+class VknSplitItem(ctypes.Structure):
+    """include/vkn.h: one matrix of vkn_split_weights_batch_f32"""
+    _fields_ = [('W', ctypes.c_void_p), ('images', ctypes.c_void_p), ('ldn', ctypes.c_longlong), ('ldk', ctypes.c_longlong),
+                ('Nout', ctypes.c_int), ('K', ctypes.c_int), ('kvalid', ctypes.c_int), ('reserved', ctypes.c_int)]
+
+SPLIT_MAX_ITEMS = 64
 
 
 class VknDims(ctypes.Structure):
@@ -224,6 +232,23 @@ def lib():
     L.vkn_split_weight_f32.argtypes = [_fp, _fp, c_int, c_int, _fp]
     L.vkn_linear_f32.restype = c_int
     L.vkn_linear_f32.argtypes = [_fp, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _fp, c_size, _fp]
+    L.vkn_split_weight_t_f32.restype = c_int
+    L.vkn_split_weight_t_f32.argtypes = [_fp, _fp, c_int, c_int, _fp]
+    L.vkn_sizeof_split_item.restype = c_size
+    L.vkn_sizeof_split_item.argtypes = []
+    L.vkn_split_weights_batch_f32.restype = c_int
+    L.vkn_split_weights_batch_f32.argtypes = [ctypes.POINTER(VknSplitItem), c_int, _fp]
+    L.vkn_linear_dw_f32.restype = c_int
+    L.vkn_linear_dw_f32.argtypes = [_fp, c_int, _fp, c_int, _fp, _fp, c_int, c_int, c_int, c_int, _fp]
+    L.vkn_layernorm_act_fwd_f32.restype = c_int
+    L.vkn_layernorm_act_fwd_f32.argtypes = [_fp, c_int, _fp, c_int, _fp, _fp, c_float, c_int, _fp, c_int, _fp, c_int, c_int, _fp]
+    L.vkn_layernorm_act_bwd_f32.restype = c_int
+    L.vkn_layernorm_act_bwd_f32.argtypes = [_fp, c_int, _fp, c_int, _fp, c_int, _fp, _fp, _fp, c_int, _fp, c_int, _fp, _fp, c_int, c_int, _fp]
+    L.vkn_attention_f32.restype = c_int
+    L.vkn_attention_f32.argtypes = [_fp, c_int, _fp, _fp, c_int, _fp, c_int, c_int, c_int, c_int, c_int, c_int, _fp]
+    L.vkn_attention_bwd_f32.restype = c_int
+    L.vkn_attention_bwd_f32.argtypes = [_fp, c_int, _fp, _fp, c_int, _fp, c_int, _fp, c_int, _fp, c_int, _fp, _fp, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, _fp]
     L.vkn_kernel_updator_f32.restype = c_int
     L.vkn_kernel_updator_f32.argtypes = [pD, pW, _fp, _fp, _fp, _fp, c_size, _fp]
     L.vkn_stage_workspace_bytes.restype = c_size

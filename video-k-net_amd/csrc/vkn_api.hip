@@ -986,6 +986,11 @@ int vkn_split_weight_f32(const float* W, void* w_split, int Nout, int K, void* s
     return vkn_launch_split_w3(W, w_split, Nout, K, static_cast<hipStream_t>(stream));
 }
 
+int vkn_split_weight_t_f32(const float* W, void* w_split_t, int Nout, int K, void* stream) {
+    if (!W || !w_split_t) return VKN_E_ARG;
+    return vkn_launch_split_w3_t(W, w_split_t, Nout, K, static_cast<hipStream_t>(stream));
+}
+
 int vkn_linear_f32(const float* A, const float* W, const void* w_split, const float* bias, float* out, int M, int K, int Nout,
                    int act, int ksplit, void* ws, size_t ws_bytes, void* stream) {
     if (!A || !W || !out || M <= 0 || K <= 0 || Nout <= 0) return VKN_E_ARG;

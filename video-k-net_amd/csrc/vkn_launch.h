@@ -99,6 +99,7 @@ int vkn_launch_ffn_fused(const float* X, int ldx, const void* W1s, const float* 
                          float* partial, const VknEpi& epi2, hipStream_t stream);
 int vkn_launch_transpose(const float* src, float* dst, int R, int Cc, hipStream_t st);  // dst[c][r] = src[r][c]
 int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream);
+int vkn_launch_split_w3_t(const float* W, void* Wp, int Nout, int K, hipStream_t stream);  // images of W^T, W stored [K][Nout]
 int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig, const float* ug, const float* no_w,
                       const float* no_b, const float* ino_w, const float* ino_b, float eps, float* f, int M, int C,
                       hipStream_t stream);

@@ -1,0 +1,589 @@
+// vkn_train.hip — the BACKWARD building blocks of the [B*N, C] chain (training): with these the chain of a training
+// step runs on this library's kernels in both directions instead of torch autograd on library GEMMs.
+//   reference ops differentiated here                                        reference
+//   nn.Linear (every layer of the chain)                                    knet/kernel_updator.py:36-54, knet/det/kernel_update_head.py:93-134
+//   nn.LayerNorm (+ ReLU / sigmoid behind it, + the residual before it)     knet/kernel_updator.py:74-93, knet/det/kernel_update_head.py:206-227
+//   nn.MultiheadAttention's softmax(q k^T / sqrt(d)) v                      knet/det/kernel_update_head.py:203-206 (mmcv MultiheadAttention)
+// Kernels:
+//   k_gemm_tn     dW[n][k] = sum_m dY[m][n] A[m][k], db[n] = sum_m dY[m][n]: the contraction runs over the ROWS of both operands, which is
+//                 what v_mfma_f32_32x32x2_f32 wants straight from memory (lane = column, two rows per instruction: both operand loads
+//                 are coalesced 128-byte row segments, no LDS staging, exact fp32 products).  A 32 x 32 tile of dW per workgroup of
+//                 16 waves = 16 row slices, summed through LDS in fixed order (deterministic).
+//   k_ln_fwd      y = act(LayerNorm(in + resid)) per row, (mean, rstd) kept for the backward; a wave per row.
+//   k_ln_bwd      dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dz gamma, dz = act'(z) dy (row workgroups) and dgamma = sum dz xhat,
+//                 dbeta = sum dz (column workgroups of the same launch; fixed order, no atomics).
+//   k_attn_bwd    one workgroup per (frame, head): K, V resident in LDS, a tile of 64 query rows at a time: P recomputed from q, k
+//                 (fp32 VALU: exact softmax, the forward's MFMA rounding does not enter), dV += P^T dO, dS = P (dO v^T - D) / sqrt(d),
+//                 dK += dS^T q, dQ = dS k; D = dO . O from the saved forward output.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/vkn.h"
+#include "vkn_common.h"
+#include "vkn_launch.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------ k_gemm_tn
+// Every dependent memory round trip of these few-row kernels costs ~1 us (the operands were just written by workgroups on other
+// XCDs: nothing is in this XCD's L2), so the kernels below are built to need ONE: all loads of a workgroup are requested before the
+// first use.  Here: a 32 x 32 tile of dW per workgroup, its 16 waves are 16 row slices (wave s owns rows 32 u + 2 s, + 1); two
+// register sets of 8 row pairs each are requested up front (512 rows: the whole contraction of a 4-frame step), longer
+// contractions keep two sets in flight.  The slices are summed through LDS in fixed order (deterministic).
+constexpr int TN_THREADS = 1024;
+constexpr int TN_U = 8;
+constexpr size_t TN_LDS = (size_t)(16 * 32 * 32 + 16 * 32) * sizeof(float);
+
+__global__ __launch_bounds__(TN_THREADS) void k_gemm_tn(const float* __restrict__ Y, int ldy, const float* __restrict__ A, int lda,
+                                                        float* __restrict__ dW, int ldw, float* __restrict__ db, int M, int Nout, int K,
+                                                        int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float smem_tn[];
+    float (*red)[32][32] = reinterpret_cast<float (*)[32][32]>(smem_tn);             // [row slice][n][k]: 64 KB
+    float (*redb)[32] = reinterpret_cast<float (*)[32]>(smem_tn + 16 * 32 * 32);     // [row slice][n]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int slice = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int li = lane & 31, half = lane >> 5;
+    const int n = n0 + li, k = k0 + li;
+    const bool okn = n < Nout, okk = k < K;
+    const float* yp = Y + (okn ? n : 0);
+    const float* ap = A + (okk ? k : 0);
+    const float keepn = okn ? 1.f : 0.f, keepk = okk ? 1.f : 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float asum = 0.f;
+    float a[TN_U], b[TN_U], an[TN_U], bn[TN_U];
+    // rows beyond M are read from row M - 1 (a valid address) and multiplied by zero at use: no divergent branches around the loads
+    auto fetch = [&](int mb, float (&fa)[TN_U], float (&fb)[TN_U]) {
+#pragma unroll
+        for (int u = 0; u < TN_U; ++u) {
+            const int mc = min(mb + 32 * u + 2 * slice + half, M - 1);
+            fa[u] = yp[(size_t)mc * ldy];
+            fb[u] = ap[(size_t)mc * lda];
+        }
+    };
+    auto consume = [&](int mb, const float (&fa)[TN_U], const float (&fb)[TN_U]) {
+#pragma unroll
+        for (int u = 0; u < TN_U; ++u) {
+            const float keep = (mb + 32 * u + 2 * slice + half) < M ? 1.f : 0.f;
+            const float av = fa[u] * (keep * keepn), bv = fb[u] * (keep * keepk);
+            asum += av;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    };
+    constexpr int SET = 32 * TN_U;   // rows per register set
+    fetch(0, a, b);
+    fetch(SET, an, bn);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int mb = 0; mb < M; mb += 2 * SET) {
+        consume(mb, a, b);
+        __builtin_amdgcn_sched_barrier(0);
+        // unconditional (clamped addresses; the last two are wasted): a branch here makes the compiler drain every load at the merge
+        fetch(mb + 2 * SET, a, b);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(mb + SET, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(mb + 3 * SET, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[slice][vkn_cd_row(r, lane)][li] = acc[r];
+    asum += __shfl_xor(asum, 32);
+    if (half == 0) redb[slice][li] = asum;
+    __syncthreads();
+    {
+        const int rn = tid >> 5, rk = tid & 31;
+        if (n0 + rn < Nout && k0 + rk < K) {
+            float v = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) v += red[sl][rn][rk];
+            float* o = dW + (size_t)(n0 + rn) * ldw + k0 + rk;
+            *o = accumulate ? *o + v : v;
+        }
+    }
+    if (db && blockIdx.y == 0 && tid < 32 && n0 + tid < Nout) {
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) v += redb[sl][tid];
+        db[n0 + tid] = accumulate ? db[n0 + tid] + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ k_split_batch
+// The bf16x3 tile images of MANY weights in one launch (both orientations of every Linear weight of a stage: the weights change every
+// training step).  Image layout as k_split_w3 (vkn_update.hip): [ceil(Nout/256)][K/32][plane 3][q 4][row 256][8] bf16.  A workgroup writes
+// one 48-KB tile: thread = row, 32 k values -> twelve 16-byte stores, consecutive threads consecutive 16 bytes.
+struct SplitTab {
+    const float* W[VKN_SPLIT_MAX_ITEMS];
+    __bf16* dst[VKN_SPLIT_MAX_ITEMS];
+    long long ldn[VKN_SPLIT_MAX_ITEMS], ldk[VKN_SPLIT_MAX_ITEMS];
+    int nout[VKN_SPLIT_MAX_ITEMS], k[VKN_SPLIT_MAX_ITEMS], kvalid[VKN_SPLIT_MAX_ITEMS];
+    int tile0[VKN_SPLIT_MAX_ITEMS + 1];
+};
+
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 bh = (__bf16)v;
+    const float r1 = v - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    const __bf16 bl = (__bf16)(r1 - (float)bm);
+    h = __builtin_bit_cast(unsigned short, bh);
+    m = __builtin_bit_cast(unsigned short, bm);
+    l = __builtin_bit_cast(unsigned short, bl);
+}
+
+__global__ __launch_bounds__(256) void k_split_batch(const SplitTab T, int nitems) {
+    const int b = blockIdx.x;
+    int it = 0;
+    while (it + 1 < nitems && b >= T.tile0[it + 1]) ++it;   // block-uniform
+    const int tl = b - T.tile0[it];
+    const int K = T.k[it], Nout = T.nout[it], kvalid = T.kvalid[it];
+    const int ktiles = K >> 5;
+    const int nt = tl / ktiles, kt = tl - nt * ktiles;
+    const float* __restrict__ W = T.W[it];
+    const long long ldn = T.ldn[it], ldk = T.ldk[it];
+    const int row = threadIdx.x, n = nt * 256 + row;
+    float v[32];
+    if (n < Nout) {
+        if (ldk == 1 && kt * 32 + 32 <= kvalid && (ldn & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(W + (size_t)n * ldn + kt * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 t = src[j];
+                v[4 * j] = t[0]; v[4 * j + 1] = t[1]; v[4 * j + 2] = t[2]; v[4 * j + 3] = t[3];
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                const int k = kt * 32 + kk;
+                v[kk] = k < kvalid ? W[(size_t)n * ldn + (size_t)k * ldk] : 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) v[kk] = 0.f;
+    }
+    u16x8* dst = reinterpret_cast<u16x8*>(T.dst[it] + ((size_t)nt * ktiles + kt) * (3 * 4 * 256 * 8));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        u16x8 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            unsigned short a, c, d;
+            split3(v[8 * q + e], a, c, d);
+            h[e] = a; m[e] = c; l[e] = d;
+        }
+        dst[(0 * 4 + q) * 256 + row] = h;
+        dst[(1 * 4 + q) * 256 + row] = m;
+        dst[(2 * 4 + q) * 256 + row] = l;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ LayerNorm
+constexpr int LN_MAXV = 4;   // C <= 256: up to four elements per lane
+
+__device__ __forceinline__ float ln_act(float z, int act) {
+    if (act == 1) return z > 0.f ? z : 0.f;
+    if (act == 2) return 1.f / (1.f + expf(-z));
+    return z;
+}
+
+// grid = ceil(M / 4), 256 threads: a wave per row
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ in, int ldi, const float* __restrict__ resid, int ldr,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
+                                                float* __restrict__ out, int ldo, float* __restrict__ stats, int M, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float x[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int c = lane + 64 * j;
+        x[j] = 0.f;
+        if (c < C) {
+            x[j] = in[(size_t)row * ldi + c];
+            if (resid) x[j] += resid[(size_t)row * ldr + c];
+        }
+        s += x[j];
+    }
+    const float mean = vkn_wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const float dlt = (lane + 64 * j < C) ? x[j] - mean : 0.f;
+        q += dlt * dlt;
+    }
+    const float rstd = 1.0f / sqrtf(vkn_wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) {
+            const float z = (x[j] - mean) * rstd * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+            out[(size_t)row * ldo + c] = ln_act(z, act);
+        }
+    }
+    if (stats && lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+constexpr int LNB_ROWS = 16;      // rows per row-block of k_ln_bwd: a wave per row
+constexpr int LNB_THREADS = 1024;
+
+__device__ __forceinline__ float ln_dz(float dy, float z, int act) {
+    if (act == 1) return z > 0.f ? dy : 0.f;
+    if (act == 2) {
+        const float sg = 1.f / (1.f + expf(-z));
+        return dy * sg * (1.f - sg);
+    }
+    return dy;
+}
+
+// ONE launch, two kinds of workgroups, each with a single memory round trip:
+//   blocks [0, nrb)        16 rows each, a wave per row: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dz gamma
+//   blocks [nrb, nrb + ncb) 32 columns each, 32 row slices: dgamma[c] = sum_m dz xhat, dbeta[c] = sum_m dz (recomputed from the same
+//                          inputs — cheaper than a partial buffer and a second, dependent launch), fixed summation order
+__global__ __launch_bounds__(LNB_THREADS) void k_ln_bwd(const float* __restrict__ dy, int lddy, const float* __restrict__ in, int ldi,
+                                                        const float* __restrict__ resid, int ldr, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ stats, int act,
+                                                        float* __restrict__ dx, int lddx, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int M, int C, int nrb) {
+    __shared__ float red[2][32][33];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if ((int)blockIdx.x < nrb) {
+        const int row = blockIdx.x * LNB_ROWS + (tid >> 6);
+        if (row >= M) return;
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        float xv[LN_MAXV], dv[LN_MAXV], gam[LN_MAXV], bet[LN_MAXV];
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = lane + 64 * j;
+            const bool ok = c < C;
+            const int cc = ok ? c : 0;
+            xv[j] = in[(size_t)row * ldi + cc];
+            if (resid) xv[j] += resid[(size_t)row * ldr + cc];
+            dv[j] = dy[(size_t)row * lddy + cc];
+            gam[j] = gamma ? gamma[cc] : 1.f;
+            bet[j] = beta ? beta[cc] : 0.f;
+        }
+        float xh[LN_MAXV], g[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const bool ok = lane + 64 * j < C;
+            xh[j] = (xv[j] - mean) * rstd;
+            const float dz = ln_dz(dv[j], xh[j] * gam[j] + bet[j], act);
+            g[j] = ok ? dz * gam[j] : 0.f;
+            s1 += g[j];
+            s2 += g[j] * xh[j];
+        }
+        const float invC = 1.0f / (float)C;
+        s1 = vkn_wave_sum(s1) * invC;
+        s2 = vkn_wave_sum(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) dx[(size_t)row * lddx + c] = rstd * (g[j] - s1 - xh[j] * s2);
+        }
+        return;
+    }
+    // ---- column gradients
+    const int cb = blockIdx.x - nrb;
+    const int cl = tid & 31, sl = tid >> 5;          // column of the block, row slice
+    const int c = cb * 32 + cl;
+    const bool okc = c < C;
+    const int cc = okc ? c : 0;
+    const float gam = gamma ? gamma[cc] : 1.f, bet = beta ? beta[cc] : 0.f;
+    float pg = 0.f, pb = 0.f;
+    constexpr int CU = 8;                             // rows per step: all their loads are requested together
+    for (int m0 = sl; m0 < M; m0 += 32 * CU) {
+        float xv[CU], dv[CU], mu[CU], rs[CU];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const int m = min(m0 + 32 * u, M - 1);
+            mu[u] = stats[2 * m];
+            rs[u] = stats[2 * m + 1];
+            xv[u] = in[(size_t)m * ldi + cc];
+            if (resid) xv[u] += resid[(size_t)m * ldr + cc];
+            dv[u] = dy[(size_t)m * lddy + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const float xh = (xv[u] - mu[u]) * rs[u];
+            float dz = ln_dz(dv[u], xh * gam + bet, act);
+            dz = (m0 + 32 * u < M) ? dz : 0.f;
+            pg += dz * xh;
+            pb += dz;
+        }
+    }
+    red[0][sl][cl] = pg;
+    red[1][sl][cl] = pb;
+    __syncthreads();
+    if (tid < 64) {
+        const int which = tid >> 5;
+        float v = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) v += red[which][s2][cl];
+        float* o = which ? dbeta : dgamma;
+        if (o && okc) o[c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ attention
+constexpr int AB_THREADS = 512;
+
+// grid = (heads, B).  LDS: Ks, Vs [Nk][HD+1]; Qt, dOt [TQ][HD+1]; Pt [TQ][Nk+1]; Dt [TQ]
+template <int HD, int TQ>
+__global__ __launch_bounds__(AB_THREADS) void k_attn_bwd(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
+                                                         const float* __restrict__ Vp, int ldkv, const float* __restrict__ O, int ldo,
+                                                         const float* __restrict__ dO, int lddo, float* __restrict__ dQ, int lddq,
+                                                         float* __restrict__ dK, float* __restrict__ dV, int lddkv, int Nq, int Nk,
+                                                         float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem_ab[];
+    constexpr int LD = HD + 1;
+    float* Ks = smem_ab;
+    float* Vs = Ks + (size_t)Nk * LD;
+    float* Qt = Vs + (size_t)Nk * LD;
+    float* dOt = Qt + (size_t)TQ * LD;
+    float* Pt = dOt + (size_t)TQ * LD;
+    float* Dt = Pt + (size_t)TQ * (Nk + 1);
+    const int LP = Nk + 1;
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const size_t qrow0 = (size_t)b * Nq, krow0 = (size_t)b * Nk;
+    const int col0 = h * HD;
+
+    for (int idx = tid; idx < Nk * HD; idx += AB_THREADS) {
+        const int j = idx / HD, d = idx - j * HD;
+        Ks[j * LD + d] = Kp[(krow0 + j) * ldkv + col0 + d];
+        Vs[j * LD + d] = Vp[(krow0 + j) * ldkv + col0 + d];
+    }
+    // (j, half of the head width) accumulators of dK / dV
+    constexpr int HH = HD / 2;
+    const int aj = tid >> 1, ah = tid & 1;
+    float dk[HH], dv[HH];
+#pragma unroll
+    for (int d = 0; d < HH; ++d) dk[d] = dv[d] = 0.f;
+    // (query row of the tile, 1 of NP column parts)
+    constexpr int NP = AB_THREADS / TQ;      // 8 / 16 / 32 parts for TQ = 64 / 32 / 16
+    constexpr int PER = HD / NP > 0 ? HD / NP : 1;   // head-width columns of dQ per part (parts beyond the head width idle)
+    const int ti = tid / NP, tp = tid - ti * NP;
+
+    for (int i0 = 0; i0 < Nq; i0 += TQ) {
+        __syncthreads();   // the previous tile's readers are done (first round: K / V staged)
+        for (int idx = tid; idx < TQ * HD; idx += AB_THREADS) {
+            const int i = idx / HD, d = idx - i * HD;
+            const bool ok = i0 + i < Nq;
+            Qt[i * LD + d] = ok ? Q[(qrow0 + i0 + i) * ldq + col0 + d] : 0.f;
+            dOt[i * LD + d] = ok ? dO[(qrow0 + i0 + i) * lddo + col0 + d] : 0.f;
+        }
+        if (tid < TQ) {
+            float s = 0.f;
+            if (i0 + tid < Nq)
+                for (int d = 0; d < HD; ++d) s += dO[(qrow0 + i0 + tid) * lddo + col0 + d] * O[(qrow0 + i0 + tid) * ldo + col0 + d];
+            Dt[tid] = s;
+        }
+        __syncthreads();
+        // ---- scores, softmax: P into Pt
+        {
+            const bool ok = i0 + ti < Nq;
+            float q[HD];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) q[d] = Qt[ti * LD + d];
+            float mx = -INFINITY;
+            for (int j = tp; j < Nk; j += NP) {
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) s += q[d] * Ks[j * LD + d];
+                s *= scale;
+                Pt[ti * LP + j] = s;
+                mx = fmaxf(mx, s);
+            }
+            for (int o = 1; o < NP; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float sum = 0.f;
+            for (int j = tp; j < Nk; j += NP) {
+                const float e = expf(Pt[ti * LP + j] - mx);
+                Pt[ti * LP + j] = e;
+                sum += e;
+            }
+            for (int o = 1; o < NP; o <<= 1) sum += __shfl_xor(sum, o);
+            const float inv = ok ? 1.0f / sum : 0.f;   // rows beyond Nq contribute nothing
+            for (int j = tp; j < Nk; j += NP) Pt[ti * LP + j] *= inv;
+        }
+        __syncthreads();
+        // ---- dV += P^T dO
+        if (aj < Nk) {
+            for (int i = 0; i < TQ; ++i) {
+                const float p = Pt[i * LP + aj];
+#pragma unroll
+                for (int d = 0; d < HH; ++d) dv[d] += p * dOt[i * LD + ah * HH + d];
+            }
+        }
+        __syncthreads();
+        // ---- dS = P (dO v^T - D) scale, in place
+        {
+            float g[HD];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) g[d] = dOt[ti * LD + d];
+            const float Di = Dt[ti];
+            for (int j = tp; j < Nk; j += NP) {
+                float dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) dp += g[d] * Vs[j * LD + d];
+                Pt[ti * LP + j] = Pt[ti * LP + j] * (dp - Di) * scale;
+            }
+        }
+        __syncthreads();
+        // ---- dK += dS^T q ; dQ = dS k
+        if (aj < Nk) {
+            for (int i = 0; i < TQ; ++i) {
+                const float s = Pt[i * LP + aj];
+#pragma unroll
+                for (int d = 0; d < HH; ++d) dk[d] += s * Qt[i * LD + ah * HH + d];
+            }
+        }
+        if (i0 + ti < Nq) {
+            // the NP parts of a row split the head width; with NP > HD the surplus parts idle
+            const int d0 = tp * PER;
+            if (d0 < HD) {
+                float accq[PER];
+#pragma unroll
+                for (int d = 0; d < PER; ++d) accq[d] = 0.f;
+                for (int j = 0; j < Nk; ++j) {
+                    const float s = Pt[ti * LP + j];
+#pragma unroll
+                    for (int d = 0; d < PER; ++d) accq[d] += s * Ks[j * LD + d0 + d];
+                }
+#pragma unroll
+                for (int d = 0; d < PER; ++d) dQ[(qrow0 + i0 + ti) * lddq + col0 + d0 + d] = accq[d];
+            }
+        }
+    }
+    if (aj < Nk) {
+#pragma unroll
+        for (int d = 0; d < HH; ++d) {
+            dK[(krow0 + aj) * lddkv + col0 + ah * HH + d] = dk[d];
+            dV[(krow0 + aj) * lddkv + col0 + ah * HH + d] = dv[d];
+        }
+    }
+}
+
+template <int HD, int TQ>
+int attn_bwd_launch_tq(size_t lds, const float* Q, int ldq, const float* K, const float* V, int ldkv, const float* O, int ldo,
+                       const float* dO, int lddo, float* dQ, int lddq, float* dK, float* dV, int lddkv, int B, int Nq, int Nk, int heads,
+                       hipStream_t st) {
+    if (lds > 64 * 1024) VKN_ALLOW_FULL_LDS((k_attn_bwd<HD, TQ>));
+    hipLaunchKernelGGL((k_attn_bwd<HD, TQ>), dim3(heads, B), dim3(AB_THREADS), lds, st, Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq,
+                       dK, dV, lddkv, Nq, Nk, 1.0f / sqrtf((float)HD));
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+template <int HD>
+int attn_bwd_launch(const float* Q, int ldq, const float* K, const float* V, int ldkv, const float* O, int ldo, const float* dO,
+                    int lddo, float* dQ, int lddq, float* dK, float* dV, int lddkv, int B, int Nq, int Nk, int heads,
+                    hipStream_t st) {
+    auto lds_of = [&](int tq) {
+        return ((size_t)2 * Nk * (HD + 1) + (size_t)2 * tq * (HD + 1) + (size_t)tq * (Nk + 1) + tq) * sizeof(float);
+    };
+    const size_t cap = 160 * 1024;
+    if (lds_of(64) <= cap)
+        return attn_bwd_launch_tq<HD, 64>(lds_of(64), Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+    if (lds_of(32) <= cap)
+        return attn_bwd_launch_tq<HD, 32>(lds_of(32), Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+    if (lds_of(16) <= cap)
+        return attn_bwd_launch_tq<HD, 16>(lds_of(16), Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+    return VKN_E_SHAPE;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vkn_linear_dw_f32(const float* dY, int ldy, const float* A, int lda, float* dW, float* db, int M, int K, int Nout, int accumulate,
+                      void* stream) {
+    if (!dY || !A || !dW || M <= 0 || K <= 0 || Nout <= 0 || ldy < Nout || lda < K) return VKN_E_ARG;
+    VKN_ALLOW_FULL_LDS(k_gemm_tn);
+    hipLaunchKernelGGL(k_gemm_tn, dim3((Nout + 31) / 32, (K + 31) / 32), dim3(TN_THREADS), TN_LDS, static_cast<hipStream_t>(stream), dY,
+                       ldy, A, lda, dW, K, db, M, Nout, K, accumulate);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_split_weights_batch_f32(const VknSplitItem* items, int nitems, void* stream) {
+    if (!items || nitems <= 0 || nitems > VKN_SPLIT_MAX_ITEMS) return VKN_E_ARG;
+    SplitTab T;
+    int tiles = 0;
+    for (int i = 0; i < nitems; ++i) {
+        const VknSplitItem& it = items[i];
+        if (!it.W || !it.images || it.Nout <= 0 || it.K <= 0 || it.kvalid < 0 || it.kvalid > it.K) return VKN_E_ARG;
+        if (it.K % 32 != 0 || (reinterpret_cast<uintptr_t>(it.images) & 15) != 0) return VKN_E_SHAPE;
+        T.W[i] = it.W;
+        T.dst[i] = static_cast<__bf16*>(it.images);
+        T.ldn[i] = it.ldn;
+        T.ldk[i] = it.ldk;
+        T.nout[i] = it.Nout;
+        T.k[i] = it.K;
+        T.kvalid[i] = it.kvalid;
+        T.tile0[i] = tiles;
+        tiles += ((it.Nout + 255) / 256) * (it.K / 32);
+    }
+    T.tile0[nitems] = tiles;
+    hipLaunchKernelGGL(k_split_batch, dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), T, nitems);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+size_t vkn_sizeof_split_item(void) { return sizeof(VknSplitItem); }
+
+int vkn_layernorm_act_fwd_f32(const float* in, int ldi, const float* resid, int ldr, const float* gamma, const float* beta, float eps,
+                              int act, float* out, int ldo, float* stats, int M, int C, void* stream) {
+    if (!in || !out || M <= 0 || C <= 0 || ldi < C || ldo < C || (resid && ldr < C) || act < 0 || act > 2) return VKN_E_ARG;
+    if (C > 64 * LN_MAXV) return VKN_E_SHAPE;
+    hipLaunchKernelGGL(k_ln_fwd, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in, ldi, resid, ldr, gamma, beta,
+                       eps, act, out, ldo, stats, M, C);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_layernorm_act_bwd_f32(const float* dy, int lddy, const float* in, int ldi, const float* resid, int ldr, const float* gamma,
+                              const float* beta, const float* stats, int act, float* dx, int lddx, float* dgamma, float* dbeta, int M,
+                              int C, void* stream) {
+    if (!dy || !in || !stats || !dx || M <= 0 || C <= 0 || lddy < C || ldi < C || lddx < C || (resid && ldr < C) || act < 0 || act > 2)
+        return VKN_E_ARG;
+    if (C > 64 * LN_MAXV) return VKN_E_SHAPE;
+    const int nrb = (M + LNB_ROWS - 1) / LNB_ROWS;
+    const int ncb = (dgamma || dbeta) ? (C + 31) / 32 : 0;
+    hipLaunchKernelGGL(k_ln_bwd, dim3(nrb + ncb), dim3(LNB_THREADS), 0, static_cast<hipStream_t>(stream), dy, lddy, in, ldi, resid, ldr,
+                       gamma, beta, stats, act, dx, lddx, dgamma, dbeta, M, C, nrb);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_attention_f32(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* out, int ldo, int B, int Nq, int Nk,
+                      int heads, int hd, void* stream) {
+    if (!Q || !K || !V || !out || B <= 0 || Nq <= 0 || Nk <= 0 || heads <= 0) return VKN_E_ARG;
+    return vkn_launch_attn(Q, ldq, K, V, ldkv, out, ldo, B, Nq, Nk, heads, hd, static_cast<hipStream_t>(stream));
+}
+
+int vkn_attention_bwd_f32(const float* Q, int ldq, const float* K, const float* V, int ldkv, const float* O, int ldo, const float* dO,
+                          int lddo, float* dQ, int lddq, float* dK, float* dV, int lddkv, int B, int Nq, int Nk, int heads, int hd,
+                          void* stream) {
+    if (!Q || !K || !V || !O || !dO || !dQ || !dK || !dV || B <= 0 || Nq <= 0 || Nk <= 0 || heads <= 0) return VKN_E_ARG;
+    if (Nk > AB_THREADS / 2) return VKN_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (hd) {
+        case 4: return attn_bwd_launch<4>(Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+        case 8: return attn_bwd_launch<8>(Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+        case 16: return attn_bwd_launch<16>(Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+        case 32: return attn_bwd_launch<32>(Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+        case 64: return attn_bwd_launch<64>(Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+        default: return VKN_E_SHAPE;
+    }
+}
+
+}  // extern "C"

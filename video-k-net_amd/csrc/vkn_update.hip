@@ -286,13 +286,16 @@ __device__ __forceinline__ void vkn_split_bf16x3(float v, __bf16& h, __bf16& m, 
 }
 
 // fp32 W [Nout][K] -> tile images Wp[ceil(Nout/256)][K/32][3][4][256][8] (rows >= Nout zero).  grid = (K/32, ceil(Nout/256)).
-__global__ __launch_bounds__(256) void k_split_w3(const float* __restrict__ W, __bf16* __restrict__ Wp, int Nout, int K) {
+// Element (n, k) of the weight is read at W[n * ldn + k * ldk]: (K, 1) for a torch Linear weight, (1, Nout) for the images of its
+// TRANSPOSE (the dA = dY . W GEMM of the backward pass: "weight" [K_fwd][Nout_fwd] read from the same storage).
+__global__ __launch_bounds__(256) void k_split_w3(const float* __restrict__ W, __bf16* __restrict__ Wp, int Nout, int K, size_t ldn,
+                                                  size_t ldk) {
     const int kt = blockIdx.x, nt = blockIdx.y;
     __bf16* dst = Wp + ((size_t)nt * gridDim.x + kt) * GS_WTILE;
     const int row = threadIdx.x, n = nt * 256 + row;
     for (int k = 0; k < 32; ++k) {
         __bf16 h = (__bf16)0.f, m = (__bf16)0.f, l = (__bf16)0.f;
-        if (n < Nout) vkn_split_bf16x3(W[(size_t)n * K + kt * 32 + k], h, m, l);
+        if (n < Nout) vkn_split_bf16x3(W[(size_t)n * ldn + (size_t)(kt * 32 + k) * ldk], h, m, l);
         const int q = k >> 3, e = k & 7;
         dst[((0 * 4 + q) * 256 + row) * 8 + e] = h;
         dst[((1 * 4 + q) * 256 + row) * 8 + e] = m;
@@ -1315,7 +1318,17 @@ int vkn_launch_transpose(const float* src, float* dst, int R, int Cc, hipStream_
 // fp32 W [Nout][K] -> tile images (K % 32 == 0)
 int vkn_launch_split_w3(const float* W, void* Wp, int Nout, int K, hipStream_t stream) {
     if (Nout <= 0 || K <= 0 || K % 32 != 0) return VKN_E_SHAPE;
-    hipLaunchKernelGGL(k_split_w3, dim3(K / 32, (Nout + 255) / 256), dim3(256), 0, stream, W, static_cast<__bf16*>(Wp), Nout, K);
+    hipLaunchKernelGGL(k_split_w3, dim3(K / 32, (Nout + 255) / 256), dim3(256), 0, stream, W, static_cast<__bf16*>(Wp), Nout, K,
+                       (size_t)K, (size_t)1);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+// tile images of the TRANSPOSE of a stored matrix: Wt [Nout][K] with Wt[n][k] = W[k * Nout + n] (W is [K][Nout] row-major)
+int vkn_launch_split_w3_t(const float* W, void* Wp, int Nout, int K, hipStream_t stream) {
+    if (Nout <= 0 || K <= 0 || K % 32 != 0) return VKN_E_SHAPE;
+    hipLaunchKernelGGL(k_split_w3, dim3(K / 32, (Nout + 255) / 256), dim3(256), 0, stream, W, static_cast<__bf16*>(Wp), Nout, K,
+                       (size_t)1, (size_t)Nout);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import autograd as vag
+from . import chain_train
 from . import ops
 from .losses import accuracy, reduce_mean
 from .registry import build_loss, build_transformer_layer, register_head
@@ -72,7 +73,7 @@ class _ChainGraphModule(nn.Module):
         return iter(list(self.head.parameters()))
 
     def forward(self, x_feat, proposal_feat, prev=None):
-        out = self.head._chain_autograd(x_feat, proposal_feat, prev if self.has_prev else None)
+        out = self.head._chain_impl(x_feat, proposal_feat, prev if self.has_prev else None)
         self.pattern = tuple(o is not None for o in out)
         return tuple(o for o in out if o is not None)
 
@@ -345,7 +346,12 @@ class KernelUpdateHead(nn.Module):
         xraw, cnt = vag.mask_gather(x, mask_preds.detach(), self.hard_mask_thr)
         if self.feat_transform is None:
             return xraw
-        return xraw @ self.feat_transform.conv.weight.reshape(C, C).t() + cnt.unsqueeze(-1) * self.feat_transform.conv.bias
+        if self.device_chain:
+            B, N = xraw.shape[:2]
+            folded = chain_train.linear(xraw.reshape(B * N, C), self.feat_transform.conv.weight.reshape(C, C)).view(B, N, C)
+        else:
+            folded = xraw @ self.feat_transform.conv.weight.reshape(C, C).t()
+        return folded + cnt.unsqueeze(-1) * self.feat_transform.conv.bias
 
     def _chain_autograd(self, x_feat, proposal_feat, previous_obj_feats=None):
         """The [B*N, C] chain as torch ops on this module's own parameters (reference :198-227; video :324-476):
@@ -384,6 +390,22 @@ class KernelUpdateHead(nn.Module):
         else:
             kern, kb = mask_feat, None
         return cls_score, kern, kb, obj_feat.permute(0, 1, 3, 2).reshape(B, N, C, K, K), track
+
+    device_chain = True     # the training chain on the library's kernels (chain_train.py); False: torch autograd on library GEMMs
+
+    def enable_device_chain(self, on=True):
+        """Training: run the [B*N, C] chain — forward AND backward — on this library's kernels (`chain_train.chain_forward`, the
+        default) or as torch autograd ops on the BLAS libraries' GEMMs (`_chain_autograd`: the A/B and the test oracle of the
+        former).  Captured chain graphs are dropped (they hold the kernels of the previous setting)."""
+        self.device_chain = bool(on)
+        if getattr(self, '_chain_graphs', None) is not None:
+            self._chain_graphs = {}
+        return self
+
+    def _chain_impl(self, x_feat, proposal_feat, previous_obj_feats=None):
+        if self.device_chain and x_feat.is_cuda:
+            return chain_train.chain_forward(self, x_feat, proposal_feat, previous_obj_feats)
+        return self._chain_autograd(x_feat, proposal_feat, previous_obj_feats)
 
     def _forward_autograd(self, x, proposal_feat, mask_preds, previous_obj_feats=None):
         """Differentiable stage (training): the two x-streaming ops are the HIP kernels behind autograd Functions
@@ -459,12 +481,12 @@ class KernelUpdateHead(nn.Module):
 
     def _chain(self, x_feat, proposal_feat, previous_obj_feats=None):
         if getattr(self, '_chain_graphs', None) is None or not x_feat.is_cuda or not torch.is_grad_enabled():
-            return self._chain_autograd(x_feat, proposal_feat, previous_obj_feats)
+            return self._chain_impl(x_feat, proposal_feat, previous_obj_feats)
         runner, mod, args = self._chain_graph_for(x_feat, proposal_feat, previous_obj_feats)
         if runner.in_flight or not any(a.requires_grad for a in args):
             # a second forward of the same module before its backward (recursive heads, frame-sequential previous_link stages) would
             # overwrite the activations the captured backward reads; inputs without gradients would cut the parameters off
-            return self._chain_autograd(x_feat, proposal_feat, previous_obj_feats)
+            return self._chain_impl(x_feat, proposal_feat, previous_obj_feats)
         outs = iter(_ChainGraphFn.apply(runner, *args))
         return tuple(next(outs) if present else None for present in mod.pattern)
 
