@@ -257,6 +257,19 @@ size_t vkn_sizeof_split_item(void);
 int vkn_split_weights_batch_f32(const VknSplitItem* items, int nitems, void* stream);
 int vkn_linear_dw_f32(const float* dY, int ldy, const float* A, int lda, float* dW, float* db, int M, int K, int Nout, int accumulate,
                       void* stream);
+/*      ... MANY weight gradients (same M) in ONE launch, each written (not accumulated) into dW [Nout][K] (row stride K) and db [Nout]
+ *      (or NULL).  The weight gradients of a chain are off its backward's critical path: the host side queues them and runs them
+ *      together at the end (chain_train.py).  `items` is a HOST array. */
+#define VKN_DW_MAX_ITEMS 48
+typedef struct VknDwItem {
+    const float* dY;
+    const float* A;
+    float* dW;
+    float* db;
+    int ldy, lda, Nout, K;
+} VknDwItem;
+size_t vkn_sizeof_dw_item(void);
+int vkn_linear_dw_batch_f32(const VknDwItem* items, int nitems, int M, void* stream);
 /*      out = act(LayerNorm_C(in + resid) * gamma + beta) per row (resid / gamma / beta may be NULL), act 0 none / 1 ReLU / 2 sigmoid;
  *      stats [M][2] = (mean, 1 / sqrt(var + eps)) for the backward (may be NULL).  C <= 256.  ld* = row strides in floats. */
 int vkn_layernorm_act_fwd_f32(const float* in, int ldi, const float* resid, int ldr, const float* gamma, const float* beta, float eps,
@@ -266,6 +279,28 @@ int vkn_layernorm_act_fwd_f32(const float* in, int ldi, const float* resid, int 
 int vkn_layernorm_act_bwd_f32(const float* dy, int lddy, const float* in, int ldi, const float* resid, int ldr, const float* gamma,
                               const float* beta, const float* stats, int act, float* dx, int lddx, float* dgamma, float* dbeta, int M,
                               int C, void* stream);
+/*      the element-wise core of `KernelUpdator.forward` between its GEMMs (knet/kernel_updator.py:70-90), both directions.
+ *      params / inputs: the packed outputs [M][2C] of dynamic_layer / input_layer (first half *_in, second half *_out);
+ *      gate_feats [M][C] = param_in * input_in (:70); gates [M][2C] = [input_gate(gate_feats) | update_gate(gate_feats)] before their norms;
+ *      features [M][C] = sigmoid(norm_in(update gate)) norm_out(param_out) + sigmoid(input_norm_in(input gate)) input_norm_out(input_out)
+ *      (:74-90; gate_sigmoid=True, gate_norm_act=False — the shipped defaults); stats [M][8] for the backward.  C <= 256, C % 4 == 0.
+ *      Backward: vkn_updator_mix_bwd_f32 writes d_gates [M][2C], the SECOND halves of d_params / d_inputs [M][2C] and the eight
+ *      LayerNorm parameter gradients (d_norms may be NULL); vkn_updator_gate_product_bwd_f32 writes their FIRST halves from d_gate_feats. */
+typedef struct VknUpdatorNorms {
+    const float *norm_in_w, *norm_in_b, *norm_out_w, *norm_out_b, *input_norm_in_w, *input_norm_in_b, *input_norm_out_w, *input_norm_out_b;
+    const float *input_gate_b, *update_gate_b;   /* the gate layers' biases (or NULL): `gates` is the bias-free GEMM output, they are added here */
+} VknUpdatorNorms;
+typedef struct VknUpdatorNormGrads {
+    float *norm_in_w, *norm_in_b, *norm_out_w, *norm_out_b, *input_norm_in_w, *input_norm_in_b, *input_norm_out_w, *input_norm_out_b;
+} VknUpdatorNormGrads;
+int vkn_updator_gate_product_f32(const float* params, const float* inputs, float* gate_feats, int M, int C, void* stream);
+int vkn_updator_gate_product_bwd_f32(const float* d_gate_feats, const float* params, const float* inputs, float* d_params, float* d_inputs,
+                                     int M, int C, void* stream);
+int vkn_updator_mix_fwd_f32(const float* gates, const float* params, const float* inputs, const VknUpdatorNorms* norms, float eps,
+                            float* features, float* stats, int M, int C, void* stream);
+int vkn_updator_mix_bwd_f32(const float* d_features, const float* gates, const float* params, const float* inputs,
+                            const VknUpdatorNorms* norms, const float* stats, float* d_gates, float* d_params, float* d_inputs,
+                            const VknUpdatorNormGrads* d_norms, int M, int C, void* stream);
 /*      the attention core of nn.MultiheadAttention: out[b][i][h] = softmax_j(q_i . k_j / sqrt(hd)) v_j per frame b and head h.
  *      Q rows b * Nq + i, K / V rows b * Nk + j; head h = columns [h * hd, (h + 1) * hd) of every operand; ld* = row strides
  *      (q, k, v may be column slices of one packed in_proj output).  hd in {4, 8, 16, 32, 64} for the backward, Nk <= 256.

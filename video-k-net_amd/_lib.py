@@ -18,7 +18,7 @@ MAX_FCS = 4
 SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_workspace_init', 'vkn_workspace_status', 'vkn_sizeof_dims', 'vkn_sizeof_stage_weights', 'vkn_gather_workspace_bytes', 'vkn_mask_gather_f32', 'vkn_mask_gather_real_f32',
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
            'vkn_decode_gather_supported', 'vkn_decode_gather_f32', 'vkn_mask_decode_planes_x', 'vkn_decode_gather_x',
-           'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_split_weight_t_f32', 'vkn_sizeof_split_item', 'vkn_split_weights_batch_f32', 'vkn_linear_dw_f32', 'vkn_layernorm_act_fwd_f32', 'vkn_layernorm_act_bwd_f32', 'vkn_attention_f32', 'vkn_attention_bwd_f32', 'vkn_upsample_bilinear_f32', 'vkn_upsample_bilinear_bwd_f32', 'vkn_kernel_updator_f32',
+           'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_split_weight_t_f32', 'vkn_sizeof_split_item', 'vkn_split_weights_batch_f32', 'vkn_linear_dw_f32', 'vkn_sizeof_dw_item', 'vkn_linear_dw_batch_f32', 'vkn_layernorm_act_fwd_f32', 'vkn_layernorm_act_bwd_f32', 'vkn_updator_gate_product_f32', 'vkn_updator_gate_product_bwd_f32', 'vkn_updator_mix_fwd_f32', 'vkn_updator_mix_bwd_f32', 'vkn_attention_f32', 'vkn_attention_bwd_f32', 'vkn_upsample_bilinear_f32', 'vkn_upsample_bilinear_bwd_f32', 'vkn_kernel_updator_f32',
            'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_stage_chain_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32', 'vkn_focal_loss_blocks', 'vkn_focal_loss_f32',
            'vkn_head_forward_prof_f32', 'vkn_head_forward_link_f32', 'vkn_stage_forward_link_f32', 'vkn_link_block_f32',
            'vkn_query_merge_workspace_bytes', 'vkn_query_merge_f32',
@@ -86,6 +86,25 @@ class VknSplitItem(ctypes.Structure):
                 ('Nout', ctypes.c_int), ('K', ctypes.c_int), ('kvalid', ctypes.c_int), ('reserved', ctypes.c_int)]
 
 SPLIT_MAX_ITEMS = 64
+
+
+class VknDwItem(ctypes.Structure):
+    """include/vkn.h: one weight gradient of vkn_linear_dw_batch_f32"""
+    _fields_ = [('dY', ctypes.c_void_p), ('A', ctypes.c_void_p), ('dW', ctypes.c_void_p), ('db', ctypes.c_void_p),
+                ('ldy', ctypes.c_int), ('lda', ctypes.c_int), ('Nout', ctypes.c_int), ('K', ctypes.c_int)]
+
+DW_MAX_ITEMS = 48
+
+
+class VknUpdatorNorms(ctypes.Structure):
+    """include/vkn.h: LayerNorm vectors (and gate biases) of vkn_updator_mix_*"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('norm_in_w', 'norm_in_b', 'norm_out_w', 'norm_out_b', 'input_norm_in_w', 'input_norm_in_b',
+                                               'input_norm_out_w', 'input_norm_out_b', 'input_gate_b', 'update_gate_b')]
+
+
+class VknUpdatorNormGrads(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ('norm_in_w', 'norm_in_b', 'norm_out_w', 'norm_out_b', 'input_norm_in_w', 'input_norm_in_b',
+                                               'input_norm_out_w', 'input_norm_out_b')]
 
 
 class VknDims(ctypes.Structure):
@@ -238,12 +257,25 @@ def lib():
     L.vkn_sizeof_split_item.argtypes = []
     L.vkn_split_weights_batch_f32.restype = c_int
     L.vkn_split_weights_batch_f32.argtypes = [ctypes.POINTER(VknSplitItem), c_int, _fp]
+    L.vkn_sizeof_dw_item.restype = c_size
+    L.vkn_sizeof_dw_item.argtypes = []
+    L.vkn_linear_dw_batch_f32.restype = c_int
+    L.vkn_linear_dw_batch_f32.argtypes = [ctypes.POINTER(VknDwItem), c_int, c_int, _fp]
     L.vkn_linear_dw_f32.restype = c_int
     L.vkn_linear_dw_f32.argtypes = [_fp, c_int, _fp, c_int, _fp, _fp, c_int, c_int, c_int, c_int, _fp]
     L.vkn_layernorm_act_fwd_f32.restype = c_int
     L.vkn_layernorm_act_fwd_f32.argtypes = [_fp, c_int, _fp, c_int, _fp, _fp, c_float, c_int, _fp, c_int, _fp, c_int, c_int, _fp]
     L.vkn_layernorm_act_bwd_f32.restype = c_int
     L.vkn_layernorm_act_bwd_f32.argtypes = [_fp, c_int, _fp, c_int, _fp, c_int, _fp, _fp, _fp, c_int, _fp, c_int, _fp, _fp, c_int, c_int, _fp]
+    L.vkn_updator_gate_product_f32.restype = c_int
+    L.vkn_updator_gate_product_f32.argtypes = [_fp, _fp, _fp, c_int, c_int, _fp]
+    L.vkn_updator_gate_product_bwd_f32.restype = c_int
+    L.vkn_updator_gate_product_bwd_f32.argtypes = [_fp, _fp, _fp, _fp, _fp, c_int, c_int, _fp]
+    L.vkn_updator_mix_fwd_f32.restype = c_int
+    L.vkn_updator_mix_fwd_f32.argtypes = [_fp, _fp, _fp, ctypes.POINTER(VknUpdatorNorms), c_float, _fp, _fp, c_int, c_int, _fp]
+    L.vkn_updator_mix_bwd_f32.restype = c_int
+    L.vkn_updator_mix_bwd_f32.argtypes = [_fp, _fp, _fp, _fp, ctypes.POINTER(VknUpdatorNorms), _fp, _fp, _fp, _fp,
+                                          ctypes.POINTER(VknUpdatorNormGrads), c_int, c_int, _fp]
     L.vkn_attention_f32.restype = c_int
     L.vkn_attention_f32.argtypes = [_fp, c_int, _fp, _fp, c_int, _fp, c_int, c_int, c_int, c_int, c_int, c_int, _fp]
     L.vkn_attention_bwd_f32.restype = c_int

@@ -13,8 +13,8 @@ x-streaming ops on either side of it were already HIP in both directions (`autog
 
 and `chain_forward` composes them exactly like `KernelUpdateHead._chain_autograd` (reference: knet/kernel_updator.py:56-93,
 knet/det/kernel_update_head.py:198-227, the video links knet/video/kernel_update_head.py:324-476) — the torch chain stays as the A/B
-and as the test oracle of this one (`tests/test_gpu_chain_train.py`).  What is left to torch inside the chain: reshapes, four
-element-wise products / sums of the gated update, the `mask_feat . b_ft` row dot.  No BLAS call, no TunableOp.
+and as the test oracle of this one (`tests/test_gpu_chain_train.py`).  What is left to torch inside the chain: reshapes, the ReLU
+mask of the FFN's hidden gradient, autograd's own additions where a tensor feeds two consumers.  No BLAS call, no TunableOp.
 
 Every Function allocates its scratch with `torch.empty` (never the cached `ops._workspace`): the chain is captured into hipGraphs
 (`KernelUpdateHead.enable_chain_graphs`), and a captured pointer into a cache that is re-grown later would dangle.
@@ -60,8 +60,9 @@ class WeightImages:
       N = the images of W itself   ([Nout = R][K = Cc]):               y = a . W^T  (nn.Linear forward)    /  da = dy . W^T (wt)
       T = the images of W^T        ([Nout = Cc][K = roundup(R, 32)]):  da = dy . W  (nn.Linear backward)   /  y = a . W     (wt)"""
 
-    def __init__(self, weights):
+    def __init__(self, weights, queue=None):
         self.map = {}
+        self.queue = queue            # a `DwQueue`: the Linear layers built on these images defer their weight gradients to it
         todo = []
         for w in weights:
             key = (w.data_ptr(), tuple(w.shape))
@@ -78,14 +79,19 @@ class WeightImages:
             sizes.append((6 * _rup(R, 256) * Cc, 6 * _rup(Cc, 256) * _rup(R, 32)))
         total = sum(_rup(a, 256) + _rup(b, 256) for a, b in sizes)
         buf = torch.empty(total, dtype=torch.uint8, device=dev)
-        items, off = [], 0
+        # all N images first, then all T images, each group in list order: the images of consecutive weights are adjacent in memory,
+        # which makes the N (T) images of two [C, C] layers the images of their row-wise (column-wise) concatenation (`pair`)
+        items, off_n = [], 0
+        off_t = sum(_rup(a, 256) for a, _ in sizes)
         for (key, w), (sn, st) in zip(todo, sizes):
             R, Cc = w.shape
-            imgn, imgt = buf[off:off + sn], buf[off + _rup(sn, 256):off + _rup(sn, 256) + st]
-            off += _rup(sn, 256) + _rup(st, 256)
+            imgn, imgt = buf[off_n:off_n + sn], buf[off_t:off_t + st]
+            off_n += _rup(sn, 256)
+            off_t += _rup(st, 256)
             items.append(_lib.VknSplitItem(w.data_ptr(), imgn.data_ptr(), Cc, 1, R, Cc, Cc, 0))
             items.append(_lib.VknSplitItem(w.data_ptr(), imgt.data_ptr(), 1, Cc, Cc, _rup(R, 32), R, 0))
             self.map[key] = (imgn, imgt, w)            # (w: keeps a non-contiguous source's copy alive until the launch has run)
+        self.buf = buf
         L = _lib.lib()
         with torch.cuda.device(dev):
             for i in range(0, len(items), _lib.SPLIT_MAX_ITEMS):
@@ -95,6 +101,25 @@ class WeightImages:
 
     def get(self, w):
         return self.map.get((w.data_ptr(), tuple(w.shape)), (None, None))[:2]
+
+    def pair(self, w1, w2):
+        """(N, T) images of the stacked layer [w1; w2] (two [C, C] weights, C % 32 == 0) when this set holds them back to back:
+        N = the images of the [2C, C] weight (needs C % 256 == 0: whole 256-row tiles), T = those of its transpose [C, 2C]
+        (one row tile, the K tiles of w1^T followed by those of w2^T).  None where that does not hold."""
+        n1, t1 = self.get(w1)
+        n2, t2 = self.get(w2)
+        if n1 is None or n2 is None or w1.shape != w2.shape or w1.shape[0] != w1.shape[1] or w1.shape[0] > 256:
+            return None, None
+        C = w1.shape[0]
+        b0 = self.buf.data_ptr()
+
+        def joined(a, b):
+            if a.data_ptr() + a.numel() != b.data_ptr():
+                return None
+            o = a.data_ptr() - b0
+            return self.buf[o:o + a.numel() + b.numel()]
+
+        return (joined(n1, n2) if C % 256 == 0 else None), joined(t1, t2)
 
 
 def _gemm(a, weight, images, bias, act, K, Nout):
@@ -112,10 +137,11 @@ def _gemm(a, weight, images, bias, act, K, Nout):
 
 class LinearFn(torch.autograd.Function):
     """y = act(a . W^T + b) (wt=False, nn.Linear) or y = a . W + b (wt=True: the folded `feat_transform` weight, used as is).
-    img_n / img_t: this weight's tile images from a `WeightImages` (None: built here)."""
+    img_n / img_t: this weight's tile images from a `WeightImages` (None: built here).  queue: a `DwQueue` — backward then only
+    computes da and leaves (dy, a) in the queue; the weight / bias gradients come out of `ChainEntryFn.backward` in one launch."""
 
     @staticmethod
-    def forward(ctx, a, weight, bias, act, wt, img_n, img_t):
+    def forward(ctx, a, weight, bias, act, wt, img_n, img_t, queue):
         a, weight = _f32c(a, 'a'), _f32c(weight, 'weight')
         if a.dim() != 2 or weight.dim() != 2:
             raise ValueError('LinearFn: a [M, K], weight [Nout, K] (or [K, Nout] with wt)')
@@ -130,17 +156,17 @@ class LinearFn(torch.autograd.Function):
             img_n, img_t = WeightImages([weight]).get(weight)
         with torch.cuda.device(a.device):
             y = _gemm(a, weight, img_t if wt else img_n, bias, act, K, Nout)
-        ctx.act, ctx.wt, ctx.has_bias = act, wt, bias is not None
-        ctx.save_for_backward(a, weight, y if act else None, img_n if wt else img_t)
+        ctx.act, ctx.wt, ctx.has_bias, ctx.queue = act, wt, bias is not None, queue
+        ctx.save_for_backward(a, weight, y if act else None, img_n if wt else img_t, bias if queue is not None else None)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        a, weight, y, img_b = ctx.saved_tensors
+        a, weight, y, img_b, bias = ctx.saved_tensors
         dy = _f32c(dy, 'dy')
         if ctx.act == 1:
-            dy = dy * (y > 0)
+            dy = torch.ops.aten.threshold_backward(dy, y, 0)          # ReLU: one element-wise launch
         elif ctx.act:
             raise NotImplementedError
         M, K = a.shape
@@ -153,6 +179,10 @@ class LinearFn(torch.autograd.Function):
                 # contraction length is the out-feature count rounded up to 32 (fc_cls: 19 classes) — dy is zero-padded to match
                 g = dy if Nout % 32 == 0 else F.pad(dy, (0, 32 - Nout % 32))
                 da = _gemm(g, weight, img_b, None, 0, g.shape[1], K)
+            if ctx.queue is not None and not ctx.queue.closed:
+                if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                    ctx.queue.items.append((dy, a, weight, bias, ctx.wt))
+                return da, None, None, None, None, None, None, None
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(weight)
                 db = torch.empty(Nout, dtype=torch.float32, device=a.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
@@ -164,7 +194,78 @@ class LinearFn(torch.autograd.Function):
                     check(L.vkn_linear_dw_f32(_ptr(dy), Nout, _ptr(a), K, _ptr(dw), _ptr(db), M, K, Nout, 0, _stream()))
             elif ctx.has_bias and ctx.needs_input_grad[2]:
                 db = dy.sum(0)
-        return da, dw, db, None, None, None, None
+        return da, dw, db, None, None, None, None, None
+
+
+class DwQueue:
+    """(dy, a, weight view, bias view, wt) of every Linear layer whose backward has run; `flush` computes all their weight / bias
+    gradients with one `vkn_linear_dw_batch_f32` launch per 48 layers — the dW GEMMs are off the backward's critical path."""
+
+    def __init__(self):
+        self.items = []
+        self.closed = False       # flushed: a Linear backward that still arrives computes its own gradients
+
+    def flush(self, params):
+        """-> gradients aligned with `params` (None where no queued layer touched the parameter)"""
+        items, self.items, self.closed = self.items, [], True
+        spans = [(p.data_ptr(), p.data_ptr() + p.numel() * p.element_size(), i) for i, p in enumerate(params)]
+        bufs, cover = {}, {}
+
+        def slot(view):
+            ptr = view.data_ptr()
+            i = next((k for lo, hi, k in spans if lo <= ptr < hi), None)     # the parameter this (view of a) tensor lives in
+            if i is None or not params[i].requires_grad:
+                return None
+            base, off = params[i], (ptr - params[i].data_ptr()) // 4
+            if i not in bufs:
+                bufs[i] = torch.empty_like(base, memory_format=torch.contiguous_format)
+                cover[i] = 0
+            cover[i] += view.numel()
+            return bufs[i].data_ptr() + off * 4
+
+        by_m = {}
+        for dy, a, w, b, wt in items:
+            pw = slot(w)
+            pb = slot(b) if b is not None else None
+            if pw is None and pb is None:
+                continue
+            if pw is None:
+                raise NotImplementedError('a bias gradient without its weight gradient')
+            M = a.shape[0]
+            K, Nout = a.shape[1], dy.shape[1]
+            it = (_lib.VknDwItem(a.data_ptr(), dy.data_ptr(), pw, None, a.stride(0), dy.stride(0), K, Nout) if wt else
+                  _lib.VknDwItem(dy.data_ptr(), a.data_ptr(), pw, pb, dy.stride(0), a.stride(0), Nout, K))
+            by_m.setdefault(M, []).append(it)
+            if wt and pb is not None:
+                raise NotImplementedError('bias of an untransposed-weight layer')
+        for i, n in cover.items():
+            if n < bufs[i].numel():                  # a parameter only partly written by the queued layers: the rest is zero
+                raise NotImplementedError('partially used packed parameter')
+        L = _lib.lib()
+        for M, its in by_m.items():
+            for j in range(0, len(its), _lib.DW_MAX_ITEMS):
+                chunk = its[j:j + _lib.DW_MAX_ITEMS]
+                arr = (_lib.VknDwItem * len(chunk))(*chunk)
+                check(L.vkn_linear_dw_batch_f32(arr, len(chunk), M, _stream()))
+        return [bufs.get(i) for i in range(len(params))]
+
+
+class ChainEntryFn(torch.autograd.Function):
+    """Identity on the chain's inputs whose backward — by construction the LAST node of the chain's backward: it needs the gradients of
+    all chain inputs — flushes the `DwQueue` and hands out every Linear weight / bias gradient of the chain."""
+
+    @staticmethod
+    def forward(ctx, queue, n_in, *args):
+        ctx.queue, ctx.n_in, ctx.params = queue, n_in, args[n_in:]
+        return tuple(a.view_as(a) for a in args[:n_in])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gin):
+        with torch.cuda.device(ctx.params[0].device):
+            grads = ctx.queue.flush(ctx.params)
+        grads = [g if (g is not None and ctx.needs_input_grad[2 + ctx.n_in + i]) else None for i, g in enumerate(grads)]
+        return (None, None) + tuple(gin) + tuple(grads)
 
 
 class LayerNormActFn(torch.autograd.Function):
@@ -249,10 +350,70 @@ class AttentionFn(torch.autograd.Function):
         return dq, (None if packed else dsrc), None, None
 
 
+_NORM_NAMES = ('norm_in', 'norm_out', 'input_norm_in', 'input_norm_out')
+
+
+class UpdatorCoreFn(torch.autograd.Function):
+    """`KernelUpdator.forward` between dynamic_layer / input_layer and fc_layer (knet/kernel_updator.py:70-90) as three launches in
+    each direction: gate product, ONE GEMM for both gate layers (the stacked weight's images, `WeightImages.pair`), the mix kernel
+    (four LayerNorms, two sigmoids, the gated sum).  params, inputs [M, 2C] -> features [M, C]."""
+
+    @staticmethod
+    def forward(ctx, params, inputs, wig, big, wug, bug, eps, img_n, img_t, queue, *norms):
+        params, inputs = _f32c(params, 'params'), _f32c(inputs, 'inputs')
+        M, C = params.shape[0], params.shape[1] // 2
+        L = _lib.lib()
+        dev = params.device
+        G = torch.empty((M, C), dtype=torch.float32, device=dev)
+        F_ = torch.empty((M, C), dtype=torch.float32, device=dev)
+        stats = torch.empty((M, 8), dtype=torch.float32, device=dev)
+        nw = _lib.VknUpdatorNorms(*[t.data_ptr() for t in norms], big.data_ptr() if big is not None else None,
+                                  bug.data_ptr() if bug is not None else None)
+        with torch.cuda.device(dev):
+            check(L.vkn_updator_gate_product_f32(_ptr(params), _ptr(inputs), _ptr(G), M, C, _stream()))
+            GT = _gemm(G, wig, img_n, None, 0, C, 2 * C)
+            check(L.vkn_updator_mix_fwd_f32(_ptr(GT), _ptr(params), _ptr(inputs), ctypes.byref(nw), float(eps), _ptr(F_), _ptr(stats), M, C,
+                                            _stream()))
+        ctx.queue = queue
+        ctx.save_for_backward(params, inputs, G, GT, stats, wig, big, wug, bug, img_t, *norms)
+        return F_
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dF):
+        params, inputs, G, GT, stats, wig, big, wug, bug, img_t, *norms = ctx.saved_tensors
+        dF = _f32c(dF, 'dF')
+        M, C = G.shape
+        L = _lib.lib()
+        dev = G.device
+        dGT, dP, dI = torch.empty_like(GT), torch.empty_like(params), torch.empty_like(inputs)
+        dn = [torch.empty_like(t) for t in norms]
+        nw = _lib.VknUpdatorNorms(*[t.data_ptr() for t in norms], big.data_ptr() if big is not None else None,
+                                  bug.data_ptr() if bug is not None else None)
+        gw = _lib.VknUpdatorNormGrads(*[t.data_ptr() for t in dn])
+        with torch.cuda.device(dev):
+            check(L.vkn_updator_mix_bwd_f32(_ptr(dF), _ptr(GT), _ptr(params), _ptr(inputs), ctypes.byref(nw), _ptr(stats), _ptr(dGT), _ptr(dP),
+                                            _ptr(dI), ctypes.byref(gw), M, C, _stream()))
+            dG = _gemm(dGT, wig, img_t, None, 0, 2 * C, C)           # [dIG | dUG] . [W_ig ; W_ug]
+            check(L.vkn_updator_gate_product_bwd_f32(_ptr(dG), _ptr(params), _ptr(inputs), _ptr(dP), _ptr(dI), M, C, _stream()))
+            dwi = dbi = dwu = dbu = None
+            if ctx.queue is not None and not ctx.queue.closed:
+                ctx.queue.items.append((dGT[:, :C], G, wig, big, False))
+                ctx.queue.items.append((dGT[:, C:], G, wug, bug, False))
+            else:
+                dwi, dwu = torch.empty_like(wig), torch.empty_like(wug)
+                dbi = torch.empty_like(big) if big is not None else None
+                dbu = torch.empty_like(bug) if bug is not None else None
+                check(L.vkn_linear_dw_f32(_ptr(dGT), 2 * C, _ptr(G), C, _ptr(dwi), _ptr(dbi), M, C, C, 0, _stream()))
+                check(L.vkn_linear_dw_f32(ctypes.c_void_p(dGT.data_ptr() + 4 * C), 2 * C, _ptr(G), C, _ptr(dwu), _ptr(dbu), M, C, C, 0,
+                                          _stream()))
+        return (dP, dI, dwi, dbi, dwu, dbu, None, None, None, None) + tuple(dn)
+
+
 # ---- functional forms
 def linear(a, weight, bias=None, act=0, wt=False, images=None):
     img_n, img_t = images.get(weight) if images is not None else (None, None)
-    return LinearFn.apply(a, weight, bias, act, wt, img_n, img_t)
+    return LinearFn.apply(a, weight, bias, act, wt, img_n, img_t, images.queue if images is not None else None)
 
 
 def layernorm(x, norm: nn.LayerNorm, act=0, resid=None):
@@ -291,12 +452,19 @@ def kernel_updator(ku, update_feature, input_feature, imgs=None):
         raise NotImplementedError('KernelUpdator: gate_sigmoid=True, gate_norm_act=False, activate_out=False (every shipped config)')
     params = linear(update_feature, ku.dynamic_layer.weight, ku.dynamic_layer.bias, images=imgs)      # :58-63
     inputs = linear(input_feature, ku.input_layer.weight, ku.input_layer.bias, images=imgs)           # :65-68
-    gate_feats = inputs[:, :C] * params[:, :C]                                                        # :70
-    input_gate = layernorm(linear(gate_feats, ku.input_gate.weight, ku.input_gate.bias, images=imgs), ku.input_norm_in, act=2)   # :74, :79
-    update_gate = layernorm(linear(gate_feats, ku.update_gate.weight, ku.update_gate.bias, images=imgs), ku.norm_in, act=2)      # :75, :80
-    param_out = layernorm(params[:, C:], ku.norm_out)                                                 # :82
-    input_out = layernorm(inputs[:, C:], ku.input_norm_out)                                           # :83
-    features = update_gate * param_out + input_gate * input_out                                       # :89-90
+    img_n, img_t = imgs.pair(ku.input_gate.weight, ku.update_gate.weight) if imgs is not None else (None, None)
+    if img_n is not None and img_t is not None and all(getattr(ku, n).elementwise_affine for n in _NORM_NAMES):
+        # :70-90 as three launches each way (gate product, one GEMM for both gate layers, the mix kernel)
+        norms = [t for n in _NORM_NAMES for t in (getattr(ku, n).weight, getattr(ku, n).bias)]
+        features = UpdatorCoreFn.apply(params, inputs, ku.input_gate.weight, ku.input_gate.bias, ku.update_gate.weight, ku.update_gate.bias,
+                                       ku.norm_in.eps, img_n, img_t, imgs.queue, *norms)
+    else:
+        gate_feats = inputs[:, :C] * params[:, :C]                                                    # :70
+        input_gate = layernorm(linear(gate_feats, ku.input_gate.weight, ku.input_gate.bias, images=imgs), ku.input_norm_in, act=2)   # :74, :79
+        update_gate = layernorm(linear(gate_feats, ku.update_gate.weight, ku.update_gate.bias, images=imgs), ku.norm_in, act=2)      # :75, :80
+        param_out = layernorm(params[:, C:], ku.norm_out)                                             # :82
+        input_out = layernorm(inputs[:, C:], ku.input_norm_out)                                       # :83
+        features = update_gate * param_out + input_gate * input_out                                   # :89-90
     return layernorm(linear(features, ku.fc_layer.weight, ku.fc_layer.bias, images=imgs), ku.fc_norm, act=1)   # :92-93
 
 
@@ -324,39 +492,61 @@ def link_block(head, names, update_feature, cur, prev, B, imgs=None):
     return layernorm(_ffn(ffn, t, imgs), ffn_norm, resid=t)
 
 
-# ---- the Linear weights a chain uses, in the order it uses them (one `WeightImages` per chain forward)
-def _updator_weights(ku):
-    return [ku.dynamic_layer.weight, ku.input_layer.weight, ku.input_gate.weight, ku.update_gate.weight, ku.fc_layer.weight]
+# ---- the Linear layers a chain uses as (weight, bias | None), in the order it uses them (one `WeightImages` per chain forward)
+def _lin(m):
+    return (m.weight, m.bias)
 
 
-def _ffn_weights(ffn):
-    return [m[0].weight if isinstance(m, nn.Sequential) else m.weight for m in ffn.layers if isinstance(m, (nn.Sequential, nn.Linear))]
+def _updator_linears(ku):
+    return [_lin(ku.dynamic_layer), _lin(ku.input_layer), _lin(ku.input_gate), _lin(ku.update_gate), _lin(ku.fc_layer)]
 
 
-def _link_weights(head, names):
+def _ffn_linears(ffn):
+    return [_lin(m[0]) if isinstance(m, nn.Sequential) else _lin(m) for m in ffn.layers if isinstance(m, (nn.Sequential, nn.Linear))]
+
+
+def _link_linears(head, names):
     upd, att, _, ffn, _ = (getattr(head, n) if n is not None else None for n in names)
     C = head.in_channels
-    w = att.attn.in_proj_weight
-    return (_updator_weights(upd) if upd is not None else []) + [w[:C], w[C:], att.attn.out_proj.weight] + _ffn_weights(ffn)
+    w, b = att.attn.in_proj_weight, att.attn.in_proj_bias
+    return ((_updator_linears(upd) if upd is not None else []) + [(w[:C], b[:C]), (w[C:], b[C:]), _lin(att.attn.out_proj)]
+            + _ffn_linears(ffn))
 
 
-def chain_weights(head, has_prev):
+def chain_linears(head, has_prev):
     C = head.in_channels
-    ws = []
+    ls = []
     if has_prev and getattr(head, 'previous_link', None) is not None:
-        ws += _link_weights(head, head._link_names('link'))
-    ws += _updator_weights(head.kernel_update_conv) + [head.attention.attn.in_proj_weight, head.attention.attn.out_proj.weight]
+        ls += _link_linears(head, head._link_names('link'))
+    a = head.attention.attn
+    ls += _updator_linears(head.kernel_update_conv) + [(a.in_proj_weight, a.in_proj_bias), _lin(a.out_proj)]
     if head.with_ffn:
-        ws += _ffn_weights(head.ffn)
+        ls += _ffn_linears(head.ffn)
     if has_prev and getattr(head, 'previous', None) is not None and head.previous_type is not None:
-        ws += _link_weights(head, head._link_names('track'))
-    ws += [m.weight for m in list(head.cls_fcs) + list(head.mask_fcs) if isinstance(m, nn.Linear)]
+        ls += _link_linears(head, head._link_names('track'))
+    ls += [_lin(m) for m in list(head.cls_fcs) + list(head.mask_fcs) if isinstance(m, nn.Linear)]
     if getattr(head, 'fc_cls', None) is not None:
-        ws.append(head.fc_cls.weight)
-    ws.append(head.fc_mask.weight)
+        ls.append(_lin(head.fc_cls))
+    ls.append(_lin(head.fc_mask))
     if head.feat_transform is not None:
-        ws.append(head.feat_transform.conv.weight.reshape(C, C))
-    return ws
+        ls.append((head.feat_transform.conv.weight.reshape(C, C), None))
+        ls.append((head.feat_transform.conv.bias.view(1, C), None))
+    return ls
+
+
+def _owners(linears, named_params):
+    """The distinct parameters the (views of) weights and biases live in, as `ChainEntryFn` inputs."""
+    spans = [(p.data_ptr(), p.data_ptr() + p.numel() * p.element_size(), p) for p in named_params]
+    out, seen = [], set()
+    for w, b in linears:
+        for t in (w, b):
+            if t is None:
+                continue
+            p = next((q for lo, hi, q in spans if lo <= t.data_ptr() < hi), None)
+            if p is not None and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+    return out
 
 
 def chain_forward(head, x_feat, proposal_feat, previous_obj_feats=None):
@@ -367,7 +557,20 @@ def chain_forward(head, x_feat, proposal_feat, previous_obj_feats=None):
     xf = x_feat.reshape(M, C)
     pf = proposal_feat.reshape(M, C)                                                                  # K*K == 1
     prev = previous_obj_feats.reshape(M, C) if previous_obj_feats is not None else None
-    imgs = WeightImages(chain_weights(head, prev is not None))       # every weight's tile images, both orientations: one launch
+    linears = chain_linears(head, prev is not None)
+    queue = DwQueue() if torch.is_grad_enabled() else None
+    imgs = WeightImages([w for w, _ in linears], queue)              # every weight's tile images, both orientations: one launch
+    if queue is not None:
+        # the entry node: its backward runs when the gradients of ALL chain inputs are there, i.e. last — it computes every queued
+        # weight / bias gradient in one launch and returns them as the gradients of the parameters it was given
+        owners = _owners(linears, [p for p in head.parameters() if p.requires_grad])
+        if owners:
+            ins = [xf, pf] + ([prev] if prev is not None else [])
+            outs = ChainEntryFn.apply(queue, len(ins), *ins, *owners)
+            xf, pf = outs[0], outs[1]
+            prev = outs[2] if prev is not None else None
+        else:
+            imgs.queue = None
     if prev is not None and getattr(head, 'previous_link', None) is not None:                          # video :324-372
         p = prev.detach() if (head.training and head.previous_detach_link) else prev
         pf = link_block(head, head._link_names('link'), xf, pf, p, B, imgs)
@@ -389,7 +592,7 @@ def chain_forward(head, x_feat, proposal_feat, previous_obj_feats=None):
     if head.feat_transform is not None:                                                               # K (W x + b) = (K W) x + K.b
         ft = head.feat_transform.conv
         kern = linear(mask_feat, ft.weight.reshape(C, C), wt=True, images=imgs)
-        kb = (mask_feat * ft.bias).sum(-1).view(B, N)
+        kb = linear(mask_feat, ft.bias.view(1, C), images=imgs).view(B, N)         # a one-row layer: mask_feat . b_ft
     else:
         kern, kb = mask_feat, None
     return cls_score, kern.view(B, N, C), kb, obj.reshape(B, N, C, K, K), track

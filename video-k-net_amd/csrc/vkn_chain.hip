@@ -711,18 +711,18 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ one GEMM per launch on the same engine
-// k_gemm_t3: out = epi((A (.* A2) (+ A3 .* A4)) . W^T) for K == 256 with the row epilogue of k_gemm_s3 (vkn_update.hip: VknEpi) — the
+// k_gemm_t3: out = epi((A (.* A2) (+ A3 .* A4)) . W^T) for K == 256 KC (KC <= 3: the backward GEMMs of the training chain contract over 512 / 768) with the row epilogue of k_gemm_s3 (vkn_update.hip: VknEpi) — the
 // launch-per-GEMM chain of few-row calls (frame-by-frame video inference: 117 rows), the link blocks and the stand-alone linear entry
 // points.  Same tile (32 rows x 256 columns per workgroup, wave = column block), same six products per operand pair, but the K loop is
 // the chain kernels': the A tile is split ONCE into a resident LDS image (K = 256 whole), the weight fragments go straight from
 // global memory into the consumer wave's register ring, no barrier and no LDS-DMA inside the loop, the epilogue runs in registers
 // (LayerNorm through the 16-partial exchange).  k_gemm_s3's loop cost 0.87 us per K-tile with a barrier each (7 us of a 13.8 us
 // launch at 117 rows); this one streams at ~0.5 us per tile.  Up to two problems per launch (blockIdx.z), as k_gemm_s3.
-template <int ABL>
+template <int ABL, int KC>
 __global__ __launch_bounds__(CH_THREADS) void k_gemm_t3(const VknGemmProb p0, const VknGemmProb p1, int nprob, int M) {
     extern __shared__ __attribute__((aligned(16))) char smem_t3[];
     __bf16* IMG = reinterpret_cast<__bf16*>(smem_t3);
-    float* S = reinterpret_cast<float*>(IMG + CH_IMG);
+    float* S = reinterpret_cast<float*>(IMG + KC * CH_IMG);   // KC images of 256 K-columns each (K = 256 KC <= 768: 144 KB + S)
     const bool second = (nprob > 1) && (blockIdx.z == 1);
     const VknGemmProb& P = second ? p1 : p0;
     const VknEpi& E = P.epi;
@@ -733,17 +733,18 @@ __global__ __launch_bounds__(CH_THREADS) void k_gemm_t3(const VknGemmProb p0, co
     const int tid = threadIdx.x;
     const ChLane L = ch_lane(tid);
     const int ntiles = (Nout + 255) / 256;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.Wsplit), 0, (int)((unsigned)ntiles * 8u * CH_WTILE), 0x00020000);
-    const unsigned wbase = (unsigned)blockIdx.x * 8u * CH_WTILE;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.Wsplit), 0, (int)((unsigned)ntiles * (8u * KC) * CH_WTILE), 0x00020000);
+    const unsigned wbase = (unsigned)blockIdx.x * (8u * KC) * CH_WTILE;
     constexpr int RING = CH_RING_OF(ABL);
     ChRing<RING> R;
 #pragma unroll
     for (int j = 0; j < RING - 1; ++j) ch_wload<RING, CH_AUX_OF(ABL)>(R, j, wrs, L, wbase + (unsigned)j * CH_WTILE);
 
-    // ---- the A tile -> bf16x3 image (optional elementwise prologue: A .* A2 + A3 .* A4, the updator's gate / mix)
-    {
+    // ---- the A tile -> bf16x3 images (optional elementwise prologue: A .* A2 + A3 .* A4, the updator's gate / mix)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
         const int row = tid >> 4, c4 = (tid & 15) << 2;
-        const size_t ro = (size_t)min(m0 + row, M - 1) * P.lda + c4;
+        const size_t ro = (size_t)min(m0 + row, M - 1) * P.lda + c4 + 256 * kc;
         f32x4 t[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const f32x4*>(P.A + ro + 64 * j);
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_gemm_t3(const VknGemmProb p0, co
                 m[e] = mm;
                 l[e] = ll;
             }
-            __bf16* d = IMG + row * CH_C + ((((col >> 3) ^ row) & 31) << 3) + (col & 7);
+            __bf16* d = IMG + kc * CH_IMG + row * CH_C + ((((col >> 3) ^ row) & 31) << 3) + (col & 7);
             *reinterpret_cast<cbf16x4*>(d) = h;
             *reinterpret_cast<cbf16x4*>(d + CH_PLANE) = m;
             *reinterpret_cast<cbf16x4*>(d + 2 * CH_PLANE) = l;
@@ -825,7 +826,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_gemm_t3(const VknGemmProb p0, co
 
     f32x16 acc[1];
     ch_zero(acc[0]);
-    ch_gemm<1, true, ABL>(acc, IMG, IMG, wbase, 0u, ChNext{0u, 0u, 0}, R, wrs, L);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)   // the weight stream runs on across the K chunks
+        ch_gemm<1, true, ABL>(acc, IMG + kc * CH_IMG, IMG + kc * CH_IMG, wbase + (unsigned)kc * 8u * CH_WTILE, 0u,
+                              ChNext{kc + 1 < KC ? wbase + (unsigned)(kc + 1) * 8u * CH_WTILE : 0u, 0u, kc + 1 < KC ? 1 : 0}, R, wrs, L);
 
     float v[1][16];
 #pragma unroll
@@ -910,23 +914,32 @@ __global__ __launch_bounds__(CH_THREADS) void k_gemm_t3(const VknGemmProb p0, co
     }
 }
 
-// K == 256, pre-split weights, no split-K: the problems of one launch (same M).  Returns VKN_E_SHAPE when the kernel does not apply
-// (the caller then takes k_gemm_s3).
-int vkn_launch_gemm_t3(const VknGemmProb* probs, int nprob, int M, hipStream_t stream) {
+// K in {256, 512, 768}, pre-split weights, no split-K: the problems of one launch (same M, same K).  Returns VKN_E_SHAPE when the kernel
+// does not apply (the caller then takes k_gemm_s3).
+int vkn_launch_gemm_t3(const VknGemmProb* probs, int nprob, int M, int K, hipStream_t stream) {
     if (nprob < 1 || nprob > 2 || M <= 0) return VKN_E_ARG;
+    if (K != 256 && K != 512 && K != 768) return VKN_E_SHAPE;
+    const int kc = K / 256;
     int nmax = 0;
     for (int i = 0; i < nprob; ++i) {
         const VknGemmProb& p = probs[i];
         if (!p.Wsplit || (p.lda & 3) || (reinterpret_cast<uintptr_t>(p.A) & 15) || (p.A2 && (reinterpret_cast<uintptr_t>(p.A2) & 15)) ||
             (p.A3 && ((reinterpret_cast<uintptr_t>(p.A3) & 15) || !p.A4 || (reinterpret_cast<uintptr_t>(p.A4) & 15))))
             return VKN_E_SHAPE;
-        if ((size_t)((p.Nout + 255) / 256) * 8 * CH_WTILE >= (1ull << 31)) return VKN_E_SHAPE;
+        if ((size_t)((p.Nout + 255) / 256) * 8 * kc * CH_WTILE >= (1ull << 31)) return VKN_E_SHAPE;
         nmax = p.Nout > nmax ? p.Nout : nmax;
     }
-    const size_t lds = (size_t)CH_IMG * sizeof(__bf16) + (size_t)2 * CH_SBUF * sizeof(float);
+    const size_t lds = (size_t)kc * CH_IMG * sizeof(__bf16) + (size_t)2 * CH_SBUF * sizeof(float);
     dim3 grid((nmax + 255) / 256, (M + CH_ROWS - 1) / CH_ROWS, nprob);
-    VKN_ALLOW_FULL_LDS(k_gemm_t3<0>);
-    hipLaunchKernelGGL(k_gemm_t3<0>, grid, dim3(CH_THREADS), lds, stream, probs[0], probs[nprob > 1 ? 1 : 0], nprob, M);
+#define T3_LAUNCH(KCV)                                                                                                                  \
+    do {                                                                                                                                \
+        VKN_ALLOW_FULL_LDS((k_gemm_t3<0, KCV>));                                                                                        \
+        hipLaunchKernelGGL((k_gemm_t3<0, KCV>), grid, dim3(CH_THREADS), lds, stream, probs[0], probs[nprob > 1 ? 1 : 0], nprob, M);     \
+    } while (0)
+    if (kc == 1) T3_LAUNCH(1);
+    else if (kc == 2) T3_LAUNCH(2);
+    else T3_LAUNCH(3);
+#undef T3_LAUNCH
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -159,6 +159,6 @@ struct VknChainC {   // attention out_proj + LN, FFN + LN, cls / mask FCs, fc_cl
 };
 // one GEMM (or two grouped ones) per launch on the chain kernels' register-streaming engine: K == 256, pre-split weights, no split-K
 // (vkn_chain.hip: k_gemm_t3); VKN_E_SHAPE = not applicable, take k_gemm_s3
-int vkn_launch_gemm_t3(const VknGemmProb* probs, int nprob, int M, hipStream_t stream);
+int vkn_launch_gemm_t3(const VknGemmProb* probs, int nprob, int M, int K, hipStream_t stream);
 int vkn_launch_chain_a(const VknChainA& p, hipStream_t stream);
 int vkn_launch_chain_c(const VknChainC& p, hipStream_t stream);

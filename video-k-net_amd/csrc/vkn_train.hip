@@ -34,17 +34,25 @@ constexpr int TN_THREADS = 1024;
 constexpr int TN_U = 8;
 constexpr size_t TN_LDS = (size_t)(16 * 32 * 32 + 16 * 32) * sizeof(float);
 
-__global__ __launch_bounds__(TN_THREADS) void k_gemm_tn(const float* __restrict__ Y, int ldy, const float* __restrict__ A, int lda,
-                                                        float* __restrict__ dW, int ldw, float* __restrict__ db, int M, int Nout, int K,
-                                                        int accumulate) {
+// 16 waves = QN x QK quadrants (32 x 32 outputs each) x NSL row slices.  <1, 1, 16>: the latency form above (one round trip at
+// M <= 512).  <2, 4, 2>: a 64 x 128 tile — the batched launch, where the operand traffic (every tile re-reads its M x 32 column
+// blocks: 117 bytes per output for 32 x 32 tiles, 44 for 64 x 128) and not the latency of one workgroup is what costs.
+template <int QN, int QK, int NSL>
+__device__ __forceinline__ void tn_tile(const float* __restrict__ Y, int ldy, const float* __restrict__ A, int lda,
+                                        float* __restrict__ dW, int ldw, float* __restrict__ db, int M, int Nout, int K, int accumulate,
+                                        int bx, int by) {
+    static_assert(QN * QK * NSL == 16, "16 waves");
+    constexpr int TNN = 32 * QN, TNK = 32 * QK;
     extern __shared__ __attribute__((aligned(16))) float smem_tn[];
-    float (*red)[32][32] = reinterpret_cast<float (*)[32][32]>(smem_tn);             // [row slice][n][k]: 64 KB
-    float (*redb)[32] = reinterpret_cast<float (*)[32]>(smem_tn + 16 * 32 * 32);     // [row slice][n]
+    float (*red)[TNN][TNK] = reinterpret_cast<float (*)[TNN][TNK]>(smem_tn);            // [row slice][n][k]: 64 KB
+    float (*redb)[TNN] = reinterpret_cast<float (*)[TNN]>(smem_tn + NSL * TNN * TNK);   // [row slice][n]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int slice = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quad = wave % (QN * QK), slice = wave / (QN * QK);
+    const int qn = quad / QK, qk = quad % QK;
+    const int n0 = bx * TNN, k0 = by * TNK;
     const int li = lane & 31, half = lane >> 5;
-    const int n = n0 + li, k = k0 + li;
+    const int n = n0 + 32 * qn + li, k = k0 + 32 * qk + li;
     const bool okn = n < Nout, okk = k < K;
     const float* yp = Y + (okn ? n : 0);
     const float* ap = A + (okk ? k : 0);
@@ -54,11 +62,12 @@ __global__ __launch_bounds__(TN_THREADS) void k_gemm_tn(const float* __restrict_
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float asum = 0.f;
     float a[TN_U], b[TN_U], an[TN_U], bn[TN_U];
+    constexpr int RS = 2 * NSL;      // rows per step over the workgroup
     // rows beyond M are read from row M - 1 (a valid address) and multiplied by zero at use: no divergent branches around the loads
     auto fetch = [&](int mb, float (&fa)[TN_U], float (&fb)[TN_U]) {
 #pragma unroll
         for (int u = 0; u < TN_U; ++u) {
-            const int mc = min(mb + 32 * u + 2 * slice + half, M - 1);
+            const int mc = min(mb + RS * u + 2 * slice + half, M - 1);
             fa[u] = yp[(size_t)mc * ldy];
             fb[u] = ap[(size_t)mc * lda];
         }
@@ -66,13 +75,13 @@ __global__ __launch_bounds__(TN_THREADS) void k_gemm_tn(const float* __restrict_
     auto consume = [&](int mb, const float (&fa)[TN_U], const float (&fb)[TN_U]) {
 #pragma unroll
         for (int u = 0; u < TN_U; ++u) {
-            const float keep = (mb + 32 * u + 2 * slice + half) < M ? 1.f : 0.f;
+            const float keep = (mb + RS * u + 2 * slice + half) < M ? 1.f : 0.f;
             const float av = fa[u] * (keep * keepn), bv = fb[u] * (keep * keepk);
             asum += av;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
     };
-    constexpr int SET = 32 * TN_U;   // rows per register set
+    constexpr int SET = RS * TN_U;   // rows per register set
     fetch(0, a, b);
     fetch(SET, an, bn);
     __builtin_amdgcn_sched_barrier(0);
@@ -88,26 +97,62 @@ __global__ __launch_bounds__(TN_THREADS) void k_gemm_tn(const float* __restrict_
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[slice][vkn_cd_row(r, lane)][li] = acc[r];
-    asum += __shfl_xor(asum, 32);
-    if (half == 0) redb[slice][li] = asum;
+    for (int r = 0; r < 16; ++r) red[slice][32 * qn + vkn_cd_row(r, lane)][32 * qk + li] = acc[r];
+    if (qk == 0) {
+        asum += __shfl_xor(asum, 32);
+        if (half == 0) redb[slice][32 * qn + li] = asum;
+    }
     __syncthreads();
-    {
-        const int rn = tid >> 5, rk = tid & 31;
+#pragma unroll
+    for (int j = 0; j < TNN * TNK / TN_THREADS; ++j) {
+        const int idx = tid + TN_THREADS * j;
+        const int rn = idx / TNK, rk = idx % TNK;
         if (n0 + rn < Nout && k0 + rk < K) {
             float v = 0.f;
 #pragma unroll
-            for (int sl = 0; sl < 16; ++sl) v += red[sl][rn][rk];
+            for (int sl = 0; sl < NSL; ++sl) v += red[sl][rn][rk];
             float* o = dW + (size_t)(n0 + rn) * ldw + k0 + rk;
             *o = accumulate ? *o + v : v;
         }
     }
-    if (db && blockIdx.y == 0 && tid < 32 && n0 + tid < Nout) {
+    if (db && by == 0 && tid < TNN && n0 + tid < Nout) {
         float v = 0.f;
 #pragma unroll
-        for (int sl = 0; sl < 16; ++sl) v += redb[sl][tid];
+        for (int sl = 0; sl < NSL; ++sl) v += redb[sl][tid];
         db[n0 + tid] = accumulate ? db[n0 + tid] + v : v;
     }
+}
+
+__global__ __launch_bounds__(TN_THREADS) void k_gemm_tn(const float* __restrict__ Y, int ldy, const float* __restrict__ A, int lda,
+                                                        float* __restrict__ dW, int ldw, float* __restrict__ db, int M, int Nout, int K,
+                                                        int accumulate) {
+    tn_tile<1, 1, 16>(Y, ldy, A, lda, dW, ldw, db, M, Nout, K, accumulate, blockIdx.x, blockIdx.y);
+}
+
+// every weight gradient of a chain's backward in ONE launch: the dW GEMMs are off the critical path (nothing downstream reads them),
+// so the host side queues them (chain_train.py) and runs them together when the chain's backward is through
+struct TnTab {
+    const float* Y[VKN_DW_MAX_ITEMS];
+    const float* A[VKN_DW_MAX_ITEMS];
+    float* dW[VKN_DW_MAX_ITEMS];
+    float* db[VKN_DW_MAX_ITEMS];
+    int ldy[VKN_DW_MAX_ITEMS], lda[VKN_DW_MAX_ITEMS], nout[VKN_DW_MAX_ITEMS], k[VKN_DW_MAX_ITEMS];
+    int tile0[VKN_DW_MAX_ITEMS + 1];
+};
+
+__global__ __launch_bounds__(TN_THREADS) void k_gemm_tn_batch(const TnTab T, int nitems, int M, int ntiles) {
+    // workgroup i runs on XCD i % 8: give every XCD a CONTIGUOUS range of tiles, so that the tiles which share operand columns (same
+    // layer, neighbouring tiles) pull them through the same L2 instead of through all eight
+    const int per = gridDim.x >> 3;
+    const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (b >= ntiles) return;
+    int it = 0;
+    while (it + 1 < nitems && b >= T.tile0[it + 1]) ++it;   // block-uniform
+    const int tl = b - T.tile0[it];
+    const int K = T.k[it], Nout = T.nout[it];
+    const int tk = (K + 127) >> 7;
+    const int bx = tl / tk, by = tl - bx * tk;
+    tn_tile<2, 4, 2>(T.Y[it], T.ldy[it], T.A[it], T.lda[it], T.dW[it], K, T.db[it], M, Nout, K, 0, bx, by);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ k_split_batch
@@ -333,6 +378,221 @@ __global__ __launch_bounds__(LNB_THREADS) void k_ln_bwd(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ gated update
+// The element-wise core of `KernelUpdator.forward` (knet/kernel_updator.py:70-90) between its GEMMs, as three kernels in each direction:
+//   gate product    G = param_in * input_in                                   (the first halves of the packed [M][2C] layer outputs)
+//   mix             F = sigmoid(LN_norm_in(UG)) LN_norm_out(param_out) + sigmoid(LN_input_norm_in(IG)) LN_input_norm_out(input_out)
+// with GT = [IG | UG] the packed output of the two gate layers.  Everything row-local: a wave per row, four LayerNorms = eight wave
+// reductions; the backward's eight parameter-gradient vectors are column sums computed by extra workgroups of the same launch.
+struct UpdNorms {   // gamma / beta of norm_in (update gate), norm_out (param_out), input_norm_in (input gate), input_norm_out (input_out)
+    const float *in_w, *in_b, *out_w, *out_b, *iin_w, *iin_b, *iout_w, *iout_b;
+    const float *ig_b, *ug_b;   // biases of input_gate / update_gate (or null), added to the packed gate GEMM output here
+};
+struct UpdNormGrads {
+    float *in_w, *in_b, *out_w, *out_b, *iin_w, *iin_b, *iout_w, *iout_b;
+};
+
+__global__ __launch_bounds__(256) void k_gprod_fwd(const float* __restrict__ P, const float* __restrict__ I, int ld, float* __restrict__ G,
+                                                   int M, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;     // one float4
+    const int c4 = C >> 2;
+    if (idx >= M * c4) return;
+    const int m = idx / c4, c = (idx - m * c4) * 4;
+    const f32x4 p = *reinterpret_cast<const f32x4*>(P + (size_t)m * ld + c), i = *reinterpret_cast<const f32x4*>(I + (size_t)m * ld + c);
+    *reinterpret_cast<f32x4*>(G + (size_t)m * C + c) = p * i;
+}
+
+// dP[:, :C] = dG * I[:, :C], dI[:, :C] = dG * P[:, :C]  (the second halves are written by k_mix_bwd)
+__global__ __launch_bounds__(256) void k_gprod_bwd(const float* __restrict__ dG, const float* __restrict__ P, const float* __restrict__ I,
+                                                   int ld, float* __restrict__ dP, float* __restrict__ dI, int M, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C >> 2;
+    if (idx >= M * c4) return;
+    const int m = idx / c4, c = (idx - m * c4) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dG + (size_t)m * C + c);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(P + (size_t)m * ld + c), i = *reinterpret_cast<const f32x4*>(I + (size_t)m * ld + c);
+    *reinterpret_cast<f32x4*>(dP + (size_t)m * ld + c) = g * i;
+    *reinterpret_cast<f32x4*>(dI + (size_t)m * ld + c) = g * p;
+}
+
+__device__ __forceinline__ void ln_stats(const float (&x)[LN_MAXV], int lane, int C, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) s += (lane + 64 * j < C) ? x[j] : 0.f;
+    mean = vkn_wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const float d = (lane + 64 * j < C) ? x[j] - mean : 0.f;
+        q += d * d;
+    }
+    rstd = 1.0f / sqrtf(vkn_wave_sum(q) / (float)C + eps);
+}
+
+// stats [M][8] = (mean, rstd) of norm_in(UG), norm_out(param_out), input_norm_in(IG), input_norm_out(input_out)
+__global__ __launch_bounds__(256) void k_mix_fwd(const float* __restrict__ GT, const float* __restrict__ P, const float* __restrict__ I,
+                                                 int ld, UpdNorms nw, float eps, float* __restrict__ F, float* __restrict__ stats, int M,
+                                                 int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float ig[LN_MAXV], ug[LN_MAXV], po[LN_MAXV], io[LN_MAXV];
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int c = min(lane + 64 * j, C - 1);
+        ig[j] = GT[(size_t)row * ld + c] + (nw.ig_b ? nw.ig_b[c] : 0.f);
+        ug[j] = GT[(size_t)row * ld + C + c] + (nw.ug_b ? nw.ug_b[c] : 0.f);
+        po[j] = P[(size_t)row * ld + C + c];
+        io[j] = I[(size_t)row * ld + C + c];
+    }
+    float mu[4], rs[4];
+    ln_stats(ug, lane, C, eps, mu[0], rs[0]);
+    ln_stats(po, lane, C, eps, mu[1], rs[1]);
+    ln_stats(ig, lane, C, eps, mu[2], rs[2]);
+    ln_stats(io, lane, C, eps, mu[3], rs[3]);
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) {
+            const float u = 1.f / (1.f + expf(-((ug[j] - mu[0]) * rs[0] * nw.in_w[c] + nw.in_b[c])));
+            const float o = (po[j] - mu[1]) * rs[1] * nw.out_w[c] + nw.out_b[c];
+            const float g = 1.f / (1.f + expf(-((ig[j] - mu[2]) * rs[2] * nw.iin_w[c] + nw.iin_b[c])));
+            const float q = (io[j] - mu[3]) * rs[3] * nw.iout_w[c] + nw.iout_b[c];
+            F[(size_t)row * C + c] = u * o + g * q;
+        }
+    }
+    if (lane < 4) {
+        stats[(size_t)row * 8 + 2 * lane] = mu[lane];
+        stats[(size_t)row * 8 + 2 * lane + 1] = rs[lane];
+    }
+}
+
+// per element: the four normalised values, the two gates, and the four dz (gradients at the LayerNorm outputs)
+struct MixElem {
+    float xh[4], dz[4];
+};
+__device__ __forceinline__ MixElem mix_elem(float dF, float ugr, float por, float igr, float ior, const float* st, const float (&w)[4],
+                                            const float (&b)[4]) {
+    MixElem e;
+    e.xh[0] = (ugr - st[0]) * st[1];
+    e.xh[1] = (por - st[2]) * st[3];
+    e.xh[2] = (igr - st[4]) * st[5];
+    e.xh[3] = (ior - st[6]) * st[7];
+    const float u = 1.f / (1.f + expf(-(e.xh[0] * w[0] + b[0])));
+    const float o = e.xh[1] * w[1] + b[1];
+    const float g = 1.f / (1.f + expf(-(e.xh[2] * w[2] + b[2])));
+    const float q = e.xh[3] * w[3] + b[3];
+    e.dz[0] = dF * o * u * (1.f - u);
+    e.dz[1] = dF * u;
+    e.dz[2] = dF * q * g * (1.f - g);
+    e.dz[3] = dF * g;
+    return e;
+}
+
+// blocks [0, nrb): 16 rows each (a wave per row) -> dGT [M][2C] = [dIG | dUG], dP[:, C:], dI[:, C:];  blocks [nrb, ..): 32 columns each ->
+// the eight parameter gradients (fixed summation order)
+__global__ __launch_bounds__(LNB_THREADS) void k_mix_bwd(const float* __restrict__ dF, const float* __restrict__ GT,
+                                                         const float* __restrict__ P, const float* __restrict__ I, int ld, UpdNorms nw,
+                                                         const float* __restrict__ stats, float* __restrict__ dGT, float* __restrict__ dP,
+                                                         float* __restrict__ dI, UpdNormGrads gw, int M, int C, int nrb) {
+    __shared__ float red[8][32][33];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if ((int)blockIdx.x < nrb) {
+        const int row = blockIdx.x * LNB_ROWS + (tid >> 6);
+        if (row >= M) return;
+        float st[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st[k] = stats[(size_t)row * 8 + k];
+        float g[4][LN_MAXV], xh[4][LN_MAXV];
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = lane + 64 * j;
+            const bool ok = c < C;
+            const int cc = ok ? c : 0;
+            const float w[4] = {nw.in_w[cc], nw.out_w[cc], nw.iin_w[cc], nw.iout_w[cc]};
+            const float b[4] = {nw.in_b[cc], nw.out_b[cc], nw.iin_b[cc], nw.iout_b[cc]};
+            const MixElem e = mix_elem(dF[(size_t)row * C + cc], GT[(size_t)row * ld + C + cc] + (nw.ug_b ? nw.ug_b[cc] : 0.f),
+                                       P[(size_t)row * ld + C + cc], GT[(size_t)row * ld + cc] + (nw.ig_b ? nw.ig_b[cc] : 0.f),
+                                       I[(size_t)row * ld + C + cc], st, w, b);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                xh[k][j] = e.xh[k];
+                g[k][j] = ok ? e.dz[k] * w[k] : 0.f;
+                s1[k] += g[k][j];
+                s2[k] += g[k][j] * e.xh[k];
+            }
+        }
+        const float invC = 1.0f / (float)C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s1[k] = vkn_wave_sum(s1[k]) * invC;
+            s2[k] = vkn_wave_sum(s2[k]) * invC;
+        }
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) {
+                dGT[(size_t)row * ld + C + c] = st[1] * (g[0][j] - s1[0] - xh[0][j] * s2[0]);   // d UG
+                dP[(size_t)row * ld + C + c] = st[3] * (g[1][j] - s1[1] - xh[1][j] * s2[1]);    // d param_out
+                dGT[(size_t)row * ld + c] = st[5] * (g[2][j] - s1[2] - xh[2][j] * s2[2]);       // d IG
+                dI[(size_t)row * ld + C + c] = st[7] * (g[3][j] - s1[3] - xh[3][j] * s2[3]);    // d input_out
+            }
+        }
+        return;
+    }
+    // ---- column gradients
+    const int cb = blockIdx.x - nrb;
+    const int cl = tid & 31, sl = tid >> 5;
+    const int c = cb * 32 + cl;
+    const bool okc = c < C;
+    const int cc = okc ? c : 0;
+    const float w[4] = {nw.in_w[cc], nw.out_w[cc], nw.iin_w[cc], nw.iout_w[cc]};
+    const float b[4] = {nw.in_b[cc], nw.out_b[cc], nw.iin_b[cc], nw.iout_b[cc]};
+    const float gbi = nw.ig_b ? nw.ig_b[cc] : 0.f, gbu = nw.ug_b ? nw.ug_b[cc] : 0.f;
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int CU = 4;
+    for (int m0 = sl; m0 < M; m0 += 32 * CU) {
+        float vF[CU], vu[CU], vo[CU], vi[CU], vq[CU], st[CU][8];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const int m = min(m0 + 32 * u, M - 1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st[u][k] = stats[(size_t)m * 8 + k];
+            vF[u] = dF[(size_t)m * C + cc];
+            vu[u] = GT[(size_t)m * ld + C + cc] + gbu;
+            vo[u] = P[(size_t)m * ld + C + cc];
+            vi[u] = GT[(size_t)m * ld + cc] + gbi;
+            vq[u] = I[(size_t)m * ld + C + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const MixElem e = mix_elem(vF[u], vu[u], vo[u], vi[u], vq[u], st[u], w, b);
+            const float keep = (m0 + 32 * u < M) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pg[k] += keep * e.dz[k] * e.xh[k];
+                pb[k] += keep * e.dz[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[2 * k][sl][cl] = pg[k];
+        red[2 * k + 1][sl][cl] = pb[k];
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int which = tid >> 5;
+        float v = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) v += red[which][s2][cl];
+        float* outs[8] = {gw.in_w, gw.in_b, gw.out_w, gw.out_b, gw.iin_w, gw.iin_b, gw.iout_w, gw.iout_b};
+        float* o = outs[which];
+        if (o && okc) o[c] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ attention
 constexpr int AB_THREADS = 512;
 
@@ -540,6 +800,28 @@ int vkn_split_weights_batch_f32(const VknSplitItem* items, int nitems, void* str
 
 size_t vkn_sizeof_split_item(void) { return sizeof(VknSplitItem); }
 
+size_t vkn_sizeof_dw_item(void) { return sizeof(VknDwItem); }
+
+int vkn_linear_dw_batch_f32(const VknDwItem* items, int nitems, int M, void* stream) {
+    if (!items || nitems <= 0 || nitems > VKN_DW_MAX_ITEMS || M <= 0) return VKN_E_ARG;
+    TnTab T;
+    int tiles = 0;
+    for (int i = 0; i < nitems; ++i) {
+        const VknDwItem& it = items[i];
+        if (!it.dY || !it.A || !it.dW || it.Nout <= 0 || it.K <= 0 || it.ldy < it.Nout || it.lda < it.K) return VKN_E_ARG;
+        T.Y[i] = it.dY; T.A[i] = it.A; T.dW[i] = it.dW; T.db[i] = it.db;
+        T.ldy[i] = it.ldy; T.lda[i] = it.lda; T.nout[i] = it.Nout; T.k[i] = it.K;
+        T.tile0[i] = tiles;
+        tiles += ((it.Nout + 63) / 64) * ((it.K + 127) / 128);
+    }
+    T.tile0[nitems] = tiles;
+    VKN_ALLOW_FULL_LDS(k_gemm_tn_batch);
+    hipLaunchKernelGGL(k_gemm_tn_batch, dim3((tiles + 7) / 8 * 8), dim3(TN_THREADS), TN_LDS, static_cast<hipStream_t>(stream), T, nitems, M,
+                       tiles);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
 int vkn_layernorm_act_fwd_f32(const float* in, int ldi, const float* resid, int ldr, const float* gamma, const float* beta, float eps,
                               int act, float* out, int ldo, float* stats, int M, int C, void* stream) {
     if (!in || !out || M <= 0 || C <= 0 || ldi < C || ldo < C || (resid && ldr < C) || act < 0 || act > 2) return VKN_E_ARG;
@@ -560,6 +842,63 @@ int vkn_layernorm_act_bwd_f32(const float* dy, int lddy, const float* in, int ld
     const int ncb = (dgamma || dbeta) ? (C + 31) / 32 : 0;
     hipLaunchKernelGGL(k_ln_bwd, dim3(nrb + ncb), dim3(LNB_THREADS), 0, static_cast<hipStream_t>(stream), dy, lddy, in, ldi, resid, ldr,
                        gamma, beta, stats, act, dx, lddx, dgamma, dbeta, M, C, nrb);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_updator_gate_product_f32(const float* params, const float* inputs, float* gate_feats, int M, int C, void* stream) {
+    if (!params || !inputs || !gate_feats || M <= 0 || C <= 0) return VKN_E_ARG;
+    if (C % 4) return VKN_E_SHAPE;
+    hipLaunchKernelGGL(k_gprod_fwd, dim3((M * (C / 4) + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), params, inputs, 2 * C,
+                       gate_feats, M, C);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_updator_gate_product_bwd_f32(const float* d_gate_feats, const float* params, const float* inputs, float* d_params, float* d_inputs,
+                                     int M, int C, void* stream) {
+    if (!d_gate_feats || !params || !inputs || !d_params || !d_inputs || M <= 0 || C <= 0) return VKN_E_ARG;
+    if (C % 4) return VKN_E_SHAPE;
+    hipLaunchKernelGGL(k_gprod_bwd, dim3((M * (C / 4) + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), d_gate_feats, params,
+                       inputs, 2 * C, d_params, d_inputs, M, C);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+static bool upd_norms_ok(const VknUpdatorNorms* n) {
+    return n && n->norm_in_w && n->norm_in_b && n->norm_out_w && n->norm_out_b && n->input_norm_in_w && n->input_norm_in_b &&
+           n->input_norm_out_w && n->input_norm_out_b;
+}
+
+int vkn_updator_mix_fwd_f32(const float* gates, const float* params, const float* inputs, const VknUpdatorNorms* norms, float eps,
+                            float* features, float* stats, int M, int C, void* stream) {
+    if (!gates || !params || !inputs || !features || !stats || !upd_norms_ok(norms) || M <= 0 || C <= 0) return VKN_E_ARG;
+    if (C > 64 * LN_MAXV) return VKN_E_SHAPE;
+    const UpdNorms nw{norms->norm_in_w, norms->norm_in_b, norms->norm_out_w, norms->norm_out_b, norms->input_norm_in_w,
+                      norms->input_norm_in_b, norms->input_norm_out_w, norms->input_norm_out_b, norms->input_gate_b, norms->update_gate_b};
+    hipLaunchKernelGGL(k_mix_fwd, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), gates, params, inputs, 2 * C, nw, eps,
+                       features, stats, M, C);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_updator_mix_bwd_f32(const float* d_features, const float* gates, const float* params, const float* inputs,
+                            const VknUpdatorNorms* norms, const float* stats, float* d_gates, float* d_params, float* d_inputs,
+                            const VknUpdatorNormGrads* d_norms, int M, int C, void* stream) {
+    if (!d_features || !gates || !params || !inputs || !stats || !d_gates || !d_params || !d_inputs || !upd_norms_ok(norms) || M <= 0 ||
+        C <= 0)
+        return VKN_E_ARG;
+    if (C > 64 * LN_MAXV) return VKN_E_SHAPE;
+    const UpdNorms nw{norms->norm_in_w, norms->norm_in_b, norms->norm_out_w, norms->norm_out_b, norms->input_norm_in_w,
+                      norms->input_norm_in_b, norms->input_norm_out_w, norms->input_norm_out_b, norms->input_gate_b, norms->update_gate_b};
+    UpdNormGrads gw{};
+    if (d_norms)
+        gw = UpdNormGrads{d_norms->norm_in_w, d_norms->norm_in_b, d_norms->norm_out_w, d_norms->norm_out_b, d_norms->input_norm_in_w,
+                          d_norms->input_norm_in_b, d_norms->input_norm_out_w, d_norms->input_norm_out_b};
+    const int nrb = (M + LNB_ROWS - 1) / LNB_ROWS;
+    const int ncb = d_norms ? (C + 31) / 32 : 0;
+    hipLaunchKernelGGL(k_mix_bwd, dim3(nrb + ncb), dim3(LNB_THREADS), 0, static_cast<hipStream_t>(stream), d_features, gates, params,
+                       inputs, 2 * C, nw, stats, d_gates, d_params, d_inputs, gw, M, C, nrb);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

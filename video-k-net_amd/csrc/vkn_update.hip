@@ -1228,10 +1228,10 @@ int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int
         if (rc != VKN_OK) return rc;
         split = split && probs[i].Wsplit && (probs[i].lda % 4) == 0;
     }
-    if (split && K == 256 && ksplit == 1 && vkn_dbg_env("VKN_GEMM_T3", 1) != 0) {
+    if (split && (K == 256 || K == 512 || K == 768) && ksplit == 1 && vkn_dbg_env("VKN_GEMM_T3", 1) != 0) {
         // the register-streaming kernel (vkn_chain.hip): resident A image, no barrier in the K loop — ~0.5 us per K-tile where the
         // LDS-DMA loop below costs 0.87 (13.8 -> 9 us per launch at 117 rows)
-        const int rc = vkn_launch_gemm_t3(probs, nprob, M, stream);
+        const int rc = vkn_launch_gemm_t3(probs, nprob, M, K, stream);
         if (rc != VKN_E_SHAPE) return rc;
     }
     if (split) {
