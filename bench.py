@@ -167,10 +167,12 @@ def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
     head.init_weights()
     head = head.to(device).train()
     reducer = vkn_dist.BucketedGradAllReducer(head, force_collectives=dist_on)
-    if not getattr(args, 'no_tune_gemms', False):
-        # the chain's Linear layers run on the library GEMMs (rocBLAS / hipBLASLt); their default heuristic picks a 256x256 macro-tile
-        # for the 468-row problems of a 4-frame step (8 workgroups, 114 us per call: 15 % of the step's GPU time).  PyTorch's
-        # TunableOp times the libraries' solutions once per shape (during the first, untimed steps) and keeps the fastest
+    torch_chain = getattr(args, 'torch_chain', False)
+    if torch_chain:
+        # A/B: the round-3 chain — torch autograd on the BLAS libraries' GEMMs.  Their default heuristic runs the 468-row problems of a
+        # 4-frame step on a 256x256 macro-tile (8 workgroups, 114 us per call), so that arm lets PyTorch's TunableOp pick per shape.
+        for stage in head.mask_head:
+            stage.enable_device_chain(False)
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(True)
         torch.cuda.tunable.set_max_tuning_duration(10)
@@ -245,10 +247,11 @@ def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
                               dtype='f32', data='synthetic',
                               config=dict(workload='cfg3 video_knet_s3_r50 head training: forward_train_with_previous (losses, GPU '
                                                    'cost matrices + device LSAP), backward through the HIP gather / decode kernels, '
-                                                   'the [B*N, C] chains as ' + ('eager torch ops' if getattr(args, 'no_chain_graphs', False)
-                                                                               else 'captured hipGraphs (forward + backward)')
-                                                   + ', library GEMMs ' + ('with default heuristics' if getattr(args, 'no_tune_gemms', False)
-                                                                           else 'picked by TunableOp')
+                                                   'the [B*N, C] chains '
+                                                   + ('as torch autograd on library GEMMs picked by TunableOp (A/B)' if torch_chain else
+                                                      'on the library\'s own kernels in both directions (chain_train.py, vkn_train.hip)')
+                                                   + (', launched eagerly' if getattr(args, 'no_chain_graphs', False)
+                                                      else ', captured as hipGraphs (forward + backward)')
                                                    + ', per-stage bucketed RCCL gradient all-reduce overlapped with backward, SGD step',
                                           frames_per_gpu_per_step=B, parallelism=f'frame-sharded dp{world}',
                                           head_parameters=nparam, last_loss=round(float(loss), 4)))))
@@ -275,7 +278,7 @@ def main():
     ap.add_argument('--x-storage', default='fp32', choices=['fp32', 'fp16', 'bf16'],
                     help='storage type of the feature map x (the head computes in fp32 either way; fp32 = the parity-exact headline)')
     ap.add_argument('--train', action='store_true', help='training step (cfg3) instead of the inference headline; see the docstring')
-    ap.add_argument('--no-tune-gemms', action='store_true', help='--train: keep the BLAS libraries\' default GEMM heuristics instead of TunableOp (A/B)')
+    ap.add_argument('--torch-chain', action='store_true', help='--train A/B: the [B*N, C] chains as torch autograd on library GEMMs (TunableOp) instead of the library\'s own kernels')
     ap.add_argument('--no-chain-graphs', action='store_true',
                     help='--train: run the [B*N, C] chains as eager torch ops instead of captured hipGraphs (A/B)')
     ap.add_argument('--head', default='ffn', choices=['ffn', 'update'],

@@ -12,7 +12,7 @@ vkn = vkn_import.load()
 vkn_dist = import_module('video_k_net_amd.dist')
 device = torch.device('cuda', 0)
 src = open(os.path.join(ROOT, 'bench.py')).read()
-args = argparse.Namespace(frames=32, warmup=3, steps=10, no_chain_graphs=bool(os.environ.get('NOGRAPH')), no_tune_gemms=bool(os.environ.get('NOTUNE')))
+args = argparse.Namespace(frames=32, warmup=3, steps=10, no_chain_graphs=bool(os.environ.get('NOGRAPH')), torch_chain=bool(os.environ.get('TORCHCHAIN')))
 body = src[src.index('def train_main('):src.index('    def step():', src.index('def train_main('))]
 ns = dict(bench.__dict__)
 exec(body + '    return locals()\n', ns)

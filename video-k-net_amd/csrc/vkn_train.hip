@@ -34,9 +34,8 @@ constexpr int TN_THREADS = 1024;
 constexpr int TN_U = 8;
 constexpr size_t TN_LDS = (size_t)(16 * 32 * 32 + 16 * 32) * sizeof(float);
 
-// 16 waves = QN x QK quadrants (32 x 32 outputs each) x NSL row slices.  <1, 1, 16>: the latency form above (one round trip at
-// M <= 512).  <2, 4, 2>: a 64 x 128 tile — the batched launch, where the operand traffic (every tile re-reads its M x 32 column
-// blocks: 117 bytes per output for 32 x 32 tiles, 44 for 64 x 128) and not the latency of one workgroup is what costs.
+// 16 waves = QN x QK quadrants (32 x 32 outputs each) x NSL row slices; <1, 1, 16> is the latency form described above (one round
+// trip at M <= 512), the only one instantiated.
 template <int QN, int QK, int NSL>
 __device__ __forceinline__ void tn_tile(const float* __restrict__ Y, int ldy, const float* __restrict__ A, int lda,
                                         float* __restrict__ dW, int ldw, float* __restrict__ db, int M, int Nout, int K, int accumulate,
@@ -140,19 +139,138 @@ struct TnTab {
     int tile0[VKN_DW_MAX_ITEMS + 1];
 };
 
-__global__ __launch_bounds__(TN_THREADS) void k_gemm_tn_batch(const TnTab T, int nitems, int M, int ntiles) {
-    // workgroup i runs on XCD i % 8: give every XCD a CONTIGUOUS range of tiles, so that the tiles which share operand columns (same
-    // layer, neighbouring tiles) pull them through the same L2 instead of through all eight
-    const int per = gridDim.x >> 3;
-    const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (b >= ntiles) return;
+// The batched form stages its operands through LDS instead: a 64 x 128 tile of one dW per workgroup of 4 waves (32 x 64 outputs
+// each), the rows in chunks of 32 — float4 global loads, 24 KB per chunk, the next chunk in flight (registers) while the MFMAs of
+// this one run.  48 KB of LDS, 2 waves per SIMD: two or three workgroups per CU, so that the matrix pipe has work while a workgroup waits
+// for its chunk (one workgroup per CU with 64-row chunks: 67 us for the 412 tiles of a stage with its link — the fetch latency under
+// load, 3 us, is twice the 1.7 us of MFMAs it was to hide behind; the register-operand form above with 64 x 128 tiles: 78 us).
+// No row slices, so no reduction: the accumulators go straight to global memory.
+constexpr int TL_THREADS = 256;
+constexpr int TL_MC = 32;                       // rows per chunk
+constexpr int TL_BN = 64, TL_BK = 128;
+constexpr int TL_CHUNK = TL_MC * (TL_BN + TL_BK);   // floats per chunk: Y part [64][64] then A part [64][128]
+constexpr size_t TL_LDS = (size_t)2 * TL_CHUNK * sizeof(float);
+constexpr int TL_F4 = TL_CHUNK / 4 / TL_THREADS;    // float4 per thread and chunk (12)
+
+__global__ __launch_bounds__(TL_THREADS, 2) void k_gemm_tn_batch(const TnTab T, int nitems, int M, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem_tl[];
+    const int b = blockIdx.x;
     int it = 0;
     while (it + 1 < nitems && b >= T.tile0[it + 1]) ++it;   // block-uniform
     const int tl = b - T.tile0[it];
     const int K = T.k[it], Nout = T.nout[it];
-    const int tk = (K + 127) >> 7;
+    const int tk = (K + TL_BK - 1) / TL_BK;
     const int bx = tl / tk, by = tl - bx * tk;
-    tn_tile<2, 4, 2>(T.Y[it], T.ldy[it], T.A[it], T.lda[it], T.dW[it], K, T.db[it], M, Nout, K, 0, bx, by);
+    const float* __restrict__ Y = T.Y[it];
+    const float* __restrict__ A = T.A[it];
+    const int ldy = T.ldy[it], lda = T.lda[it];
+    float* __restrict__ dW = T.dW[it];
+    float* __restrict__ db = T.db[it];
+    const int n0 = bx * TL_BN, k0 = by * TL_BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qn = wave >> 1, qk = wave & 1;
+    const int li = lane & 31, hf = lane >> 5;
+    // 16-byte loads where the operand allows them (base, row stride and column count multiples of four floats: uniform per layer);
+    // rows / columns outside the matrix are read from a clamped address and multiplied by zero — no branches around the loads
+    const bool vy = ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) && ((Nout & 3) == 0);
+    const bool va = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((K & 3) == 0);
+
+    f32x4 st[TL_F4];
+    // PART(op): float4 slot f of operand `op` ([64][wcols] block): element e = tid + 256 f: row e / (wcols / 4), col 4 (e % (wcols / 4)).
+    // fetch = raw loads only (a use right behind a load would wait for it); the keep masks are recomputed when the values go to LDS.
+    auto fetch_part = [&](const float* __restrict__ src, int ld, int c0, int lim, bool vec, int m0, int fbeg, int nf, int wcols) {
+        if (vec) {
+#pragma unroll
+            for (int f = 0; f < nf; ++f) {
+                const int e = tid + TL_THREADS * f;
+                const int m = m0 + e / (wcols / 4), c = c0 + 4 * (e % (wcols / 4));
+                st[fbeg + f] = *reinterpret_cast<const f32x4*>(src + (size_t)min(m, M - 1) * ld + (c < lim ? c : 0));
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < nf; ++f) {
+                const int e = tid + TL_THREADS * f;
+                const int m = m0 + e / (wcols / 4), c = c0 + 4 * (e % (wcols / 4));
+                const float* p = src + (size_t)min(m, M - 1) * ld;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st[fbeg + f][q] = p[min(c + q, lim - 1)];
+            }
+        }
+    };
+    auto commit_part = [&](float* buf, int c0, int lim, int m0, int fbeg, int nf, int wcols) {
+#pragma unroll
+        for (int f = 0; f < nf; ++f) {
+            const int e = tid + TL_THREADS * f;
+            const int m = m0 + e / (wcols / 4), c = c0 + 4 * (e % (wcols / 4));
+            f32x4 v = st[fbeg + f];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (m < M && c + q < lim) ? v[q] : 0.f;
+            *reinterpret_cast<f32x4*>(buf + 4 * e) = v;
+        }
+    };
+    constexpr int NFY = TL_MC * TL_BN / 4 / TL_THREADS, NFA = TL_MC * TL_BK / 4 / TL_THREADS;
+    auto fetch = [&](int m0) {
+        fetch_part(Y, ldy, n0, Nout, vy, m0, 0, NFY, TL_BN);
+        fetch_part(A, lda, k0, K, va, m0, NFY, NFA, TL_BK);
+    };
+    auto commit = [&](float* buf, int m0) {
+        commit_part(buf, n0, Nout, m0, 0, NFY, TL_BN);
+        commit_part(buf + TL_MC * TL_BN, k0, K, m0, NFY, NFA, TL_BK);
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+    float asum = 0.f;
+    fetch(0);
+    commit(smem_tl, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int m0 = 0; m0 < M; m0 += TL_MC) {
+        const bool more = m0 + TL_MC < M;
+        if (more) fetch(m0 + TL_MC);                   // in flight under the MFMAs below
+        const float* yb = smem_tl + cur * TL_CHUNK + 32 * qn + li;
+        const float* ab = smem_tl + cur * TL_CHUNK + TL_MC * TL_BN + 64 * qk + li;
+        // operands of 8 steps per group, the next group's LDS reads issued before this group's MFMAs
+        constexpr int TG = 8;
+        float oa[2][TG], ob0[2][TG], ob1[2][TG];
+        auto lread = [&](int g, float (&xa)[TG], float (&x0)[TG], float (&x1)[TG]) {
+#pragma unroll
+            for (int u = 0; u < TG; ++u) {
+                const int rr = 2 * (g * TG + u) + hf;
+                xa[u] = yb[rr * TL_BN];
+                x0[u] = ab[rr * TL_BK];
+                x1[u] = ab[rr * TL_BK + 32];
+            }
+        };
+        lread(0, oa[0], ob0[0], ob1[0]);
+#pragma unroll
+        for (int g = 0; g < TL_MC / 2 / TG; ++g) {
+            if (g + 1 < TL_MC / 2 / TG) lread(g + 1, oa[(g + 1) & 1], ob0[(g + 1) & 1], ob1[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);    // the reads stay ahead of this group's MFMAs
+#pragma unroll
+            for (int u = 0; u < TG; ++u) {
+                asum += oa[g & 1][u];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[g & 1][u], ob0[g & 1][u], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[g & 1][u], ob1[g & 1][u], acc[1], 0, 0, 0);
+            }
+        }
+        if (more) commit(smem_tl + (cur ^ 1) * TL_CHUNK, m0 + TL_MC);
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + 32 * qn + vkn_cd_row(r, lane), k = k0 + 64 * qk + 32 * blk + li;
+            if (n < Nout && k < K) dW[(size_t)n * K + k] = acc[blk][r];
+        }
+    if (db && by == 0 && qk == 0) {
+        asum += __shfl_xor(asum, 32);
+        const int n = n0 + 32 * qn + li;
+        if (hf == 0 && n < Nout) db[n] = asum;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ k_split_batch
@@ -732,6 +850,216 @@ __global__ __launch_bounds__(AB_THREADS) void k_attn_bwd(const float* __restrict
     }
 }
 
+// ---- the same on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 products): a wave owns a block of 32 query rows and walks the
+// key blocks.  Scores are formed TRANSPOSED (rows = keys in the accumulator registers, lane = query), so that the softmax statistics of a
+// query are a reduction over registers (+ one half-wave exchange) and dQ += dS^T-block^T . K contracts over accumulator ROWS, which is
+// what an accumulator register fed back as the A operand does (register r of lane l is element (row(r, l), l % 32): its two halves are
+// the two k-steps of one MFMA).  dV += P^T dO and dK += dS^T Q contract over the other index: P and dS go through a 4-KB wave-private
+// LDS transpose first.  dK / dV blocks are accumulated in LDS; wave w visits key block (w + step) % S, with a workgroup barrier per
+// step, so no two waves touch a block at the same time and the order of additions is fixed (deterministic).
+// Pass 1 computes the statistics online (nothing kept), pass 2 recomputes each score block: 96 MFMAs per (query block, key block) at
+// hd = 32 — 10 us per (frame, head) at N = 117 where the VALU kernel above takes 75.
+template <int HD>
+__global__ __launch_bounds__(512) void k_attn_bwd_mfma(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
+                                                       const float* __restrict__ Vp, int ldkv, const float* __restrict__ O, int ldo,
+                                                       const float* __restrict__ dO, int lddo, float* __restrict__ dQ, int lddq,
+                                                       float* __restrict__ dK, float* __restrict__ dV, int lddkv, int Nq, int Nk,
+                                                       float scale, int QB, int KB) {
+    extern __shared__ __attribute__((aligned(16))) float smem_am[];
+    constexpr int LD = HD + 1;
+    constexpr int DB = (HD + 31) / 32;
+    const int NW = blockDim.x >> 6;
+    float* Ks = smem_am;
+    float* Vs = Ks + (size_t)KB * 32 * LD;
+    float* Qs = Vs + (size_t)KB * 32 * LD;
+    float* Gs = Qs + (size_t)QB * 32 * LD;            // dO
+    float* aK = Gs + (size_t)QB * 32 * LD;            // [KB*32][HD] accumulators
+    float* aV = aK + (size_t)KB * 32 * HD;
+    float* Ts = aV + (size_t)KB * 32 * HD;            // [NW][32][33]
+    float* Ds = Ts + (size_t)NW * 32 * 33;            // [QB*32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hf = lane >> 5;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const size_t qrow0 = (size_t)b * Nq, krow0 = (size_t)b * Nk;
+    const int col0 = h * HD;
+
+    for (int idx = tid; idx < KB * 32 * HD; idx += blockDim.x) {
+        const int j = idx / HD, d = idx - j * HD;
+        const bool ok = j < Nk;
+        Ks[j * LD + d] = ok ? Kp[(krow0 + j) * ldkv + col0 + d] : 0.f;
+        Vs[j * LD + d] = ok ? Vp[(krow0 + j) * ldkv + col0 + d] : 0.f;
+        aK[idx] = 0.f;
+        aV[idx] = 0.f;
+    }
+    // (the HD lanes of a row sit in one wave, and a wave's last iteration runs whole rows or nothing)
+    for (int idx = tid; idx < QB * 32 * HD; idx += blockDim.x) {
+        const int i = idx / HD, d = idx - i * HD;
+        const bool ok = i < Nq;
+        const float g = ok ? dO[(qrow0 + i) * lddo + col0 + d] : 0.f;
+        Qs[i * LD + d] = ok ? Q[(qrow0 + i) * ldq + col0 + d] : 0.f;
+        Gs[i * LD + d] = g;
+        float pd = ok ? g * O[(qrow0 + i) * ldo + col0 + d] : 0.f;      // D_i = dO_i . O_i: summed over the row's HD lanes
+#pragma unroll
+        for (int o = 1; o < HD; o <<= 1) pd += __shfl_xor(pd, o);
+        if (d == 0) Ds[i] = pd;
+    }
+    __syncthreads();
+
+    const int i0 = 32 * w;
+    const bool mine = w < QB;
+    float* T = Ts + (size_t)w * 32 * 33;
+    // ---- pass 1: per query (lane column) max and sum of exp over all keys, online over the key blocks; the two half-waves hold
+    // different key rows of the same query and are merged at the end
+    float mx = -INFINITY, sm = 0.f;
+    if (mine) {
+        for (int jb = 0; jb < KB; ++jb) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < HD / 2; ++t)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(32 * jb + li) * LD + 2 * t + hf], Qs[(i0 + li) * LD + 2 * t + hf], acc, 0, 0, 0);
+            float bm = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * jb + vkn_cd_row(r, lane);
+                acc[r] = j < Nk ? acc[r] * scale : -INFINITY;
+                bm = fmaxf(bm, acc[r]);
+            }
+            const float mn = fmaxf(mx, bm);
+            if (mn > -INFINITY) {
+                float add = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) add += __expf(acc[r] - mn);
+                sm = sm * __expf(mx - mn) + add;
+                mx = mn;
+            }
+        }
+        const float mo = __shfl_xor(mx, 32), so = __shfl_xor(sm, 32);
+        const float mn = fmaxf(mx, mo);
+        sm = (mx > -INFINITY ? sm * __expf(mx - mn) : 0.f) + (mo > -INFINITY ? so * __expf(mo - mn) : 0.f);
+        mx = mn;
+    }
+    const float inv = (mine && sm > 0.f) ? 1.0f / sm : 0.f;
+    const float Di = mine ? Ds[i0 + li] : 0.f;
+    f32x16 dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+
+    // ---- pass 2
+    const int S = NW;
+    for (int step = 0; step < S; ++step) {
+        int jb = w + step;
+        if (jb >= S) jb -= S;
+        if (mine && jb < KB) {
+            f32x16 pt, dpt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pt[r] = dpt[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < HD / 2; ++t) {
+                const float qv = Qs[(i0 + li) * LD + 2 * t + hf], gv = Gs[(i0 + li) * LD + 2 * t + hf];
+                pt = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(32 * jb + li) * LD + 2 * t + hf], qv, pt, 0, 0, 0);
+                dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(32 * jb + li) * LD + 2 * t + hf], gv, dpt, 0, 0, 0);
+            }
+            f32x16 dst;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * jb + vkn_cd_row(r, lane);
+                pt[r] = j < Nk ? __expf(pt[r] * scale - mx) * inv : 0.f;
+                dst[r] = pt[r] * (dpt[r] - Di) * scale;
+            }
+            // dQ_i += dS-block (as stored: rows = keys) fed back as A, K rows as B
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jr = 32 * jb + vkn_cd_row(r, lane);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const float kv = (32 * db + li < HD) ? Ks[jr * LD + 32 * db + li] : 0.f;
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(dst[r], kv, dq[db], 0, 0, 0);
+                }
+            }
+            // P^T-block -> P-block (rows = queries) through the wave's scratch, then dV_j += P^T dO
+            f32x16 ps;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[vkn_cd_row(r, lane) * 33 + li] = pt[r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ps[r] = T[li * 33 + vkn_cd_row(r, lane)];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bool okd = 32 * db + li < HD;
+                f32x16 av;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[r] = okd ? aV[(32 * jb + vkn_cd_row(r, lane)) * HD + 32 * db + li] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float gv = okd ? Gs[(i0 + vkn_cd_row(r, lane)) * LD + 32 * db + li] : 0.f;
+                    av = __builtin_amdgcn_mfma_f32_32x32x2f32(ps[r], gv, av, 0, 0, 0);
+                }
+                if (okd) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) aV[(32 * jb + vkn_cd_row(r, lane)) * HD + 32 * db + li] = av[r];
+                }
+            }
+            // the same for dS: dK_j += dS^T Q
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[vkn_cd_row(r, lane) * 33 + li] = dst[r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ps[r] = T[li * 33 + vkn_cd_row(r, lane)];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bool okd = 32 * db + li < HD;
+                f32x16 av;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[r] = okd ? aK[(32 * jb + vkn_cd_row(r, lane)) * HD + 32 * db + li] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float qv = okd ? Qs[(i0 + vkn_cd_row(r, lane)) * LD + 32 * db + li] : 0.f;
+                    av = __builtin_amdgcn_mfma_f32_32x32x2f32(ps[r], qv, av, 0, 0, 0);
+                }
+                if (okd) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) aK[(32 * jb + vkn_cd_row(r, lane)) * HD + 32 * db + li] = av[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (mine) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + vkn_cd_row(r, lane), d = 32 * db + li;
+                if (i < Nq && d < HD) dQ[(qrow0 + i) * lddq + col0 + d] = dq[db][r];
+            }
+    }
+    for (int idx = tid; idx < Nk * HD; idx += blockDim.x) {
+        const int j = idx / HD, d = idx - j * HD;
+        dK[(krow0 + j) * lddkv + col0 + d] = aK[idx];
+        dV[(krow0 + j) * lddkv + col0 + d] = aV[idx];
+    }
+}
+
+template <int HD>
+int attn_bwd_mfma_launch(const float* Q, int ldq, const float* K, const float* V, int ldkv, const float* O, int ldo, const float* dO,
+                         int lddo, float* dQ, int lddq, float* dK, float* dV, int lddkv, int B, int Nq, int Nk, int heads,
+                         hipStream_t st) {
+    const int QB = (Nq + 31) / 32, KB = (Nk + 31) / 32;
+    const int NW = QB > KB ? QB : KB;
+    if (NW > 8) return VKN_E_SHAPE;
+    const size_t lds = ((size_t)2 * KB * 32 * (HD + 1) + (size_t)2 * QB * 32 * (HD + 1) + (size_t)2 * KB * 32 * HD + (size_t)NW * 32 * 33 +
+                        (size_t)QB * 32) * sizeof(float);
+    if (lds > 160 * 1024) return VKN_E_SHAPE;
+    if (lds > 64 * 1024) VKN_ALLOW_FULL_LDS(k_attn_bwd_mfma<HD>);
+    hipLaunchKernelGGL(k_attn_bwd_mfma<HD>, dim3(heads, B), dim3(64 * NW), lds, st, Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV,
+                       lddkv, Nq, Nk, 1.0f / sqrtf((float)HD), QB, KB);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
 template <int HD, int TQ>
 int attn_bwd_launch_tq(size_t lds, const float* Q, int ldq, const float* K, const float* V, int ldkv, const float* O, int ldo,
                        const float* dO, int lddo, float* dQ, int lddq, float* dK, float* dV, int lddkv, int B, int Nq, int Nk, int heads,
@@ -816,8 +1144,7 @@ int vkn_linear_dw_batch_f32(const VknDwItem* items, int nitems, int M, void* str
     }
     T.tile0[nitems] = tiles;
     VKN_ALLOW_FULL_LDS(k_gemm_tn_batch);
-    hipLaunchKernelGGL(k_gemm_tn_batch, dim3((tiles + 7) / 8 * 8), dim3(TN_THREADS), TN_LDS, static_cast<hipStream_t>(stream), T, nitems, M,
-                       tiles);
+    hipLaunchKernelGGL(k_gemm_tn_batch, dim3(tiles), dim3(TL_THREADS), TL_LDS, static_cast<hipStream_t>(stream), T, nitems, M, tiles);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
@@ -915,6 +1242,13 @@ int vkn_attention_bwd_f32(const float* Q, int ldq, const float* K, const float* 
     if (!Q || !K || !V || !O || !dO || !dQ || !dK || !dV || B <= 0 || Nq <= 0 || Nk <= 0 || heads <= 0) return VKN_E_ARG;
     if (Nk > AB_THREADS / 2) return VKN_E_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    {   // the matrix-core kernel where its LDS footprint fits (every shipped shape up to N = 128 at hd = 32, N = 224 at hd = 16)
+        int rc = VKN_E_SHAPE;
+        if (hd == 16) rc = attn_bwd_mfma_launch<16>(Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+        else if (hd == 32) rc = attn_bwd_mfma_launch<32>(Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+        else if (hd == 64) rc = attn_bwd_mfma_launch<64>(Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
+        if (rc != VKN_E_SHAPE) return rc;
+    }
     switch (hd) {
         case 4: return attn_bwd_launch<4>(Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
         case 8: return attn_bwd_launch<8>(Q, ldq, K, V, ldkv, O, ldo, dO, lddo, dQ, lddq, dK, dV, lddkv, B, Nq, Nk, heads, st);
