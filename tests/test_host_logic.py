@@ -102,6 +102,8 @@ def test_library_exports_every_declared_symbol(vkn):
     assert L2.vkn_strerror(0) == b'ok' and b'workspace' in L2.vkn_strerror(-3)
     assert L2.vkn_sizeof_dims() == ctypes.sizeof(vkn._lib.VknDims)
     assert L2.vkn_sizeof_stage_weights() == ctypes.sizeof(vkn._lib.VknStageWeights)
+    assert L2.vkn_sizeof_split_item() == ctypes.sizeof(vkn._lib.VknSplitItem)      # the batched training-chain tables (round 4)
+    assert L2.vkn_sizeof_dw_item() == ctypes.sizeof(vkn._lib.VknDwItem)
 
 
 def test_workspace_queries_are_pure_host(vkn):
@@ -405,3 +407,23 @@ def test_python_flag_constants_match_the_header(vkn):
         assert hdr[k] == v, (k, hdr[k], v)
     assert int(re.search(r'#define VKN_E_RANGE \((-\d+)\)', text).group(1)) == -6
     assert vkn._lib.lib().vkn_strerror(-6).decode().startswith('feature map outside')
+
+
+@pytest.mark.parametrize('kind', ['image', 'video_ffn', 'video_update', 'video_update_obj'])
+def test_training_chain_enumerates_every_linear_parameter_of_a_stage(vkn, kind):
+    """`chain_train.chain_linears` lists the Linear layers whose tile images are built (and whose weight gradients are batched) per chain
+    forward; a layer missing from it would still train — through the per-layer path — but slowly and unnoticed.  Host logic only: the
+    owners of the listed (views of) weights and biases are exactly the stage's parameters that are not LayerNorm vectors."""
+    import torch.nn as nn
+    over = {'video_update': dict(previous_link='update_dynamic_cov', previous_type='update'),
+            'video_update_obj': dict(previous_link='link_atten', previous_type='update_obj')}.get(kind)
+    cfgd = vkn.configs.roi_head_cfg(kind != 'image', C=64, heads=8, ffn=128, ncls=19, n_thing=8, n_stuff=11, S=1, up=2, nprop=20,
+                                    train_cfg=vkn.configs.rcnn_train_cfg(1), mask_over=over)
+    stage = vkn.build_head(cfgd).mask_head[0]
+    ct = vkn.chain_train
+    linears = ct.chain_linears(stage, kind != 'image')
+    owners = {id(p) for p in ct._owners(linears, list(stage.parameters()))}
+    norm_params = {id(p) for m in stage.modules() if isinstance(m, nn.LayerNorm) for p in m.parameters()}
+    expected = {id(p) for p in stage.parameters()} - norm_params
+    names = {id(p): n for n, p in stage.named_parameters()}
+    assert owners == expected, sorted(names[i] for i in owners ^ expected)

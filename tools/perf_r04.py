@@ -85,6 +85,18 @@ def main():
                     th = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True), iters=15, warm=4)
                 print(f'decode x-load policy {names[abl]:26s} isolated loop {t:7.1f} us = {alg / t / 1e6 / 8:.3f} of 8 TB/s   head step {th / 1e3:7.3f} ms')
         os.environ['VKN_DECODE_ABL'] = '0'
+    if args.what == 'fused':         # needs --debug-lib: the fused decode -> gather pass, packed f16 split (shipped) vs the round-3 split (VKN_FUSED=19)
+        B = 32
+        x = torch.randn(B, C, H, W, generator=g).to(DEV)
+        kern = torch.randn(B, N, C, generator=g).to(DEV)
+        hi, lo = vkn.ops.split_planes(kern)
+        kb = torch.randn(B, N, generator=g).to(DEV)
+        for rep in range(3):
+            for var, nm in ((10, 'vkn_split_f16x2 (shipped)'), (19, 'two vkn_split_f16 per pixel pair (round 3)')):
+                os.environ['VKN_FUSED'] = str(var)
+                t = timeit(lambda: vkn.ops.decode_gather(x, hi, lo, N, kb), iters=40, warm=10)
+                print(f'fused pass, {nm:44s} {t:7.1f} us = {B * C * H * W * 4 / t / 1e6 / 8:.3f} of 8 TB/s by x bytes')
+        os.environ['VKN_FUSED'] = '10'
     if args.what in ('head', 'all'):
         print('== whole head step (3 stages + link + x4 upsample), ms per call ==')
         for B in (1, 8, 32):

@@ -43,6 +43,20 @@ __device__ __forceinline__ void vkn_split_f16(float v, _Float16& hi, _Float16& l
     lo = (_Float16)(v - (float)hi);
 }
 
+// The same split for TWO values in four VALU operations instead of eight: v_cvt_pk_f16_f32 (RNE, both highs in one dword),
+// two v_fma_mix_f32 (r = v - float(hi): the f16 half is an operand, no separate conversion; exact like the subtraction),
+// v_cvt_pk_f16_f32 again.  Bit-identical to two vkn_split_f16 calls.
+typedef _Float16 vkn_half2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void vkn_split_f16x2(float a, float b, vkn_half2& hi, vkn_half2& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_convertvector(v, vkn_half2);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(b));
+    const f32x2 r = {r0, r1};
+    lo = __builtin_convertvector(r, vkn_half2);
+}
+
 // Wave-wide sum / max, the same value in every lane.  DPP row shifts inside the 16-lane rows, then the two row broadcasts (gfx9):
 // six dependent VALU operations (~60 cycles) instead of six ds_bpermute round trips (~700 cycles) — the row epilogue of every
 // [N x C] GEMM runs eight of these reductions back to back (LayerNorm of four rows per wave), 2.4 of its 3.4 us before this.

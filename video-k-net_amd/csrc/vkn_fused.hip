@@ -203,7 +203,27 @@ __global__ __launch_bounds__(FS_THREADS, 2) void k_fused_il(const float* __restr
     half4 ch0, cl0, ch1, cl1;
     auto loader_unit = [&](int nf, int slot, int buf, int tnext, int u) {
         const int NU = nf * 4;
-        if (u < NU) {
+        if (!XH && !VKN_ABL_IS(PF, 4) && u < NU) {   // (debug arm PF == 4: the round-3 split, one channel's pixel pair per unit)
+            // fp32 x: unit j of a fragment = pixel j >> 1, channel pair j & 1 — the two channels of ONE pixel are split together
+            // (vkn_split_f16x2: four VALU operations per pair, and the packed results are already the dwords of the pixel's half4)
+            const int ff = u >> 2, j = u & 3, px = j >> 1, ep = j & 1, ks = frag_ks(ff);
+            vkn_half2 h2, l2;
+            vkn_split_f16x2(__uint_as_float(raw[slot][ff][2 * ep][px]), __uint_as_float(raw[slot][ff][2 * ep + 1][px]), h2, l2);
+            if (px == 0) {
+                ch0[2 * ep] = h2[0]; ch0[2 * ep + 1] = h2[1];
+                cl0[2 * ep] = l2[0]; cl0[2 * ep + 1] = l2[1];
+            } else {
+                ch1[2 * ep] = h2[0]; ch1[2 * ep + 1] = h2[1];
+                cl1[2 * ep] = l2[0]; cl1[2 * ep + 1] = l2[1];
+            }
+            if (j == 3) {
+                _Float16* dh = dimg + (size_t)buf * IMG + lp * LDK + (ks << 4) + (lq << 2);
+                *reinterpret_cast<half4*>(dh) = ch0;
+                *reinterpret_cast<half4*>(dh + 16 * LDK) = ch1;
+                *reinterpret_cast<half4*>(dh + PLANE) = cl0;
+                *reinterpret_cast<half4*>(dh + 16 * LDK + PLANE) = cl1;
+            }
+        } else if (u < NU) {
             const int ff = u >> 2, e = u & 3, ks = frag_ks(ff);
             {
                 const unsigned u0 = raw[slot][ff][e][0], u1 = raw[slot][ff][e][1];
@@ -527,7 +547,7 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
     const size_t lds = fuseds_lds_bytes(C);
 #endif
 #ifdef VKN_DEBUG
-    const bool one_pass = (variant >= 10 && variant <= 18) && !vkn_dbg_env("VKN_FUSED_CHUNK_LOOP", 0);
+    const bool one_pass = (variant >= 10 && variant <= 19) && !vkn_dbg_env("VKN_FUSED_CHUNK_LOOP", 0);
 #else
     const bool one_pass = true;
 #endif
@@ -593,6 +613,7 @@ int vkn_launch_fused_decode_gather(const float* x, const _Float16* kfh, const _F
         else if (variant == 11 && cfg2) FU_LAUNCH_IL(4, 256, 0, 1);                        \
         else if (variant == 17 && cfg2) FU_LAUNCH_IL(4, 256, 0, 2);                        \
         else if (variant == 18 && cfg2) FU_LAUNCH_IL(4, 256, 0, 3);                        \
+        else if (variant == 19 && cfg2) FU_LAUNCH_IL(4, 256, 0, 4);                        \
         else if (variant == 5) FU_LAUNCH_PQ(NBV, CV, XHV, 0);                              \
         else if (cfg2 && vv != FS_V_DEFAULT) {                                             \
             switch (vv) {                                                                  \
