@@ -103,9 +103,12 @@ def _attn_ref(q, k, v, B, heads):
     return (p @ vh).transpose(1, 2).reshape(Mq, C)
 
 
-@pytest.mark.parametrize('B,N,C,heads', [(4, 117, 256, 8), (1, 166, 256, 8), (2, 216, 128, 8), (3, 20, 64, 4), (1, 256, 256, 8)],
+@pytest.mark.parametrize('B,N,C,heads', [(4, 117, 256, 8), (1, 166, 256, 8), (2, 216, 128, 8), (3, 20, 64, 4), (1, 256, 256, 8), (2, 70, 256, 4),
+                                         (2, 33, 64, 8)],
                          ids=lambda v: str(v))
 def test_attention_packed_forward_backward_vs_fp64(vkn, B, N, C, heads):
+    """Head widths 8 (VALU backward), 16 / 32 / 64 (matrix-core backward where its LDS footprint fits: N = 166 and 256 at width 32 fall
+    back to the VALU kernel), ragged last blocks."""
     ct = vkn.chain_train
     qkv = _rand((B * N, 3 * C), 41, 0.7).requires_grad_(True)
     go = _rand((B * N, C), 42, 1e-2)
