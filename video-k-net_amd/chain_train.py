@@ -4,11 +4,16 @@ Until round 4 the chain of a training step was torch autograd on the BLAS librar
 x-streaming ops on either side of it were already HIP in both directions (`autograd.py`).  Here every layer of the chain is an
 `autograd.Function` over the C ABI:
 
-  nn.Linear              forward   bf16x3 split-MFMA GEMM on the weight's tile images (`vkn_linear_f32`; the images are split from
-                                   the CURRENT weights inside the call — weights change every step)
-                         backward  dA = dY . W: the same GEMM kernel on the images of the TRANSPOSE (`vkn_split_weight_t_f32`);
-                                   dW = dY^T . A, db = column sums of dY: `vkn_linear_dw_f32` (exact-fp32 MFMA, deterministic)
+  nn.Linear              forward   bf16x3 split-MFMA GEMM on the weight's tile images (`vkn_linear_f32`); the images of BOTH orientations of
+                                   every Linear weight of the chain are rebuilt from the CURRENT values by one launch at the start of the
+                                   chain forward (`WeightImages`, `vkn_split_weights_batch_f32` — the weights change every step)
+                         backward  dA = dY . W: the same GEMM kernel on the images of the TRANSPOSE;
+                                   dW = dY^T . A, db = column sums of dY (exact-fp32 MFMA, deterministic): queued (`DwQueue`) and
+                                   computed for the whole chain by ONE launch when its backward is through (`ChainEntryFn`,
+                                   `vkn_linear_dw_batch_f32`) — nothing downstream in the chain reads them
   nn.LayerNorm (+ ReLU / sigmoid behind it, + the residual added before it)       `vkn_layernorm_act_{fwd,bwd}_f32`
+  the gated update of KernelUpdator.forward between its GEMMs (:70-90)             `UpdatorCoreFn`: `vkn_updator_gate_product_*`, one GEMM
+                                                                                   for both gate layers, `vkn_updator_mix_{fwd,bwd}_f32`
   the attention core of nn.MultiheadAttention                                     `vkn_attention_f32` / `vkn_attention_bwd_f32`
 
 and `chain_forward` composes them exactly like `KernelUpdateHead._chain_autograd` (reference: knet/kernel_updator.py:56-93,
