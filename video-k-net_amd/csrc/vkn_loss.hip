@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256) void k_focal(const float* __restrict__ z, cons
 }
 
 // The same adjoint for S = 2 and rows that are whole multiples of a wavefront (W % 64 == 0): a thread owns one input column and UB2_R
-// consecutive input rows.  Per output row it loads ONE aligned float2 (columns 2x, 2x + 1) and takes columns 2x - 1 / 2x + 2 from
-// its lane neighbours' pairs (wave-edge lanes fetch theirs), forms the horizontal sum once — adjacent input rows share two of their
+// consecutive input rows.  Per output row it loads ONE aligned float2 (columns 2x, 2x + 1) and the columns 2x - 1 / 2x + 2 beside it
+// (the neighbours' cache lines), forms the horizontal sum once — adjacent input rows share two of their
 // four output rows — and blends vertically.  Same weights, same order of additions as k_upsample_bwd<2>: bit-identical, a quarter
 // of the load instructions and every output element fetched ~1.25 times instead of 4.
 #define UB2_R 4
@@ -242,7 +242,6 @@ __global__ __launch_bounds__(256) void k_upsample_bwd2(const float* __restrict__
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y0 = blockIdx.y * UB2_R;
     if (x >= W) return;   // (whole waves: W % 64 == 0)
-    const int lane = threadIdx.x & 63;
     const int OH = 2 * H, OW = 2 * W;
     const float* gp = gout + (size_t)plane * OH * OW;
     float wxs[4];
@@ -255,21 +254,30 @@ __global__ __launch_bounds__(256) void k_upsample_bwd2(const float* __restrict__
         const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
         wxs[j] = (ox >= 0 && ox < OW) ? wx : 0.f;
     }
-    float hs[2 * UB2_R + 2];   // horizontal sums of output rows 2 y0 - 1 .. 2 y0 + 2 R
+    // ALL loads of the thread first (ten rows: one aligned float2 + the two outer columns each, from clamped addresses — a use right
+    // behind a load, or a branch around one, costs a memory round trip per row: 113 us for the 468 planes of a training stage), then
+    // the arithmetic in the order of k_upsample_bwd<2>.  The outer columns hit the cache lines of the neighbours' float2.
+    constexpr int NR = 2 * UB2_R + 2;
+    float2 vv[NR];
+    float vms[NR], vps[NR];
 #pragma unroll
-    for (int i = 0; i < 2 * UB2_R + 2; ++i) {
+    for (int i = 0; i < NR; ++i) {
+        const int oy = min(max(2 * y0 - 1 + i, 0), OH - 1);
+        const float* rp = gp + (size_t)oy * OW + 2 * x;
+        vv[i] = *reinterpret_cast<const float2*>(rp);
+        vms[i] = rp[x > 0 ? -1 : 0];
+        vps[i] = rp[x + 1 < W ? 2 : 1];
+    }
+    float hs[NR];   // horizontal sums of output rows 2 y0 - 1 .. 2 y0 + 2 R
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
         const int oy = 2 * y0 - 1 + i;
         float h = 0.f;
         if (oy >= 0 && oy < OH) {   // uniform
-            const float* rp = gp + (size_t)oy * OW + 2 * x;
-            const float2 v = *reinterpret_cast<const float2*>(rp);
-            float vm = __shfl_up(v.y, 1), vp = __shfl_down(v.x, 1);
-            if (lane == 0 && x > 0) vm = rp[-1];
-            if (lane == 63 && x + 1 < W) vp = rp[2];
-            if (wxs[0] != 0.f) h += wxs[0] * vm;
-            if (wxs[1] != 0.f) h += wxs[1] * v.x;
-            if (wxs[2] != 0.f) h += wxs[2] * v.y;
-            if (wxs[3] != 0.f) h += wxs[3] * vp;
+            if (wxs[0] != 0.f) h += wxs[0] * vms[i];
+            if (wxs[1] != 0.f) h += wxs[1] * vv[i].x;
+            if (wxs[2] != 0.f) h += wxs[2] * vv[i].y;
+            if (wxs[3] != 0.f) h += wxs[3] * vps[i];
         }
         hs[i] = h;
     }
