@@ -17,6 +17,8 @@
 
 namespace {
 
+// (The exponentials of the three kernels are v_exp_f32 (`__expf`, ~2 ulp): the precise expf was a third of their time — 10^8 calls per
+// stage — and its last bits do not reach the losses' 1e-4 / the gradients' 2e-3 tolerances.)
 constexpr int ML_CHUNK = 8192;   // pixels per workgroup of k_ml_rows
 
 // partial [K][nchunk][4] = (sum bce, sum p t, sum p^2, sum t^2) of row pos_rows[k] over pixels [chunk * ML_CHUNK, ...)
@@ -37,8 +39,8 @@ __global__ __launch_bounds__(256) void k_ml_rows(const float* __restrict__ pred,
         for (int e = 0; e < 4; ++e) {
             const float zz = zv[e], tt = tv[e];
             // F.binary_cross_entropy_with_logits: max(z, 0) - z t + log(1 + exp(-|z|))
-            s0 += fmaxf(zz, 0.f) - zz * tt + log1pf(expf(-fabsf(zz)));
-            const float pp = 1.0f / (1.0f + expf(-zz));
+            s0 += fmaxf(zz, 0.f) - zz * tt + log1pf(__expf(-fabsf(zz)));
+            const float pp = 1.0f / (1.0f + __expf(-zz));
             s1 += pp * tt;
             s2 += pp * pp;
             s3 += tt * tt;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void k_ml_rank_fwd(const float* __restrict__ p
 #pragma unroll
             for (int e = 0; e < ML_PX; ++e) {
                 const float mn = fmaxf(m[e], z[e]);
-                s[e] = s[e] * expf(m[e] - mn) + expf(z[e] - mn);
+                s[e] = s[e] * __expf(m[e] - mn) + __expf(z[e] - mn);
                 m[e] = mn;
                 if (pos && t[e] != 0.f) { tp[e] = n; zt[e] = z[e]; }
             }
@@ -134,14 +136,14 @@ __global__ __launch_bounds__(256) void k_ml_bwd(const float* __restrict__ pred, 
         if (with_rank) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (tpv[e] >= 0) g[e] = cr * (expf(z[e] - l[e]) - (tpv[e] == n ? 1.f : 0.f));
+                if (tpv[e] >= 0) g[e] = cr * (__expf(z[e] - l[e]) - (tpv[e] == n ? 1.f : 0.f));
         }
         if (k >= 0) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(target + off);
             const float ca = rowcoef[2 * k], cb = rowcoef[2 * k + 1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pp = 1.0f / (1.0f + expf(-z[e]));
+                const float pp = 1.0f / (1.0f + __expf(-z[e]));
                 g[e] += cm * (pp - t[e]) + (ca * t[e] + cb * pp) * pp * (1.f - pp);
             }
         }
