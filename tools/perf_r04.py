@@ -85,6 +85,19 @@ def main():
                     th = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True), iters=15, warm=4)
                 print(f'decode x-load policy {names[abl]:26s} isolated loop {t:7.1f} us = {alg / t / 1e6 / 8:.3f} of 8 TB/s   head step {th / 1e3:7.3f} ms')
         os.environ['VKN_DECODE_ABL'] = '0'
+    if args.what == 'upsample':      # needs --debug-lib: x4 upsample, taps from global (shipped, VKN_UPSAMPLE=14) vs input rows through LDS (54)
+        B = 32
+        z = (torch.randn(B, N, H, W, generator=g) * 4).to(DEV)
+        outs = {}
+        for rep in range(3):
+            for mode in (14, 54, 74, 34):
+                os.environ['VKN_UPSAMPLE'] = str(mode)
+                t = timeit(lambda: vkn.ops.upsample_bilinear(z, 4), iters=20, warm=5)
+                outs[mode] = vkn.ops.upsample_bilinear(z, 4)
+                nm = {14: 'taps from global (shipped)', 54: 'input rows through LDS', 74: 'all rows requested up front', 34: 'write-only ablation'}[mode]
+                print(f'upsample x4, {nm:30s} {t:8.1f} us = {B * N * H * W * 16 * 4 / t / 1e6:.2f} TB/s of writes')
+        print('bit-identical to the shipped kernel:', bool(torch.equal(outs[14], outs[54])))
+        os.environ['VKN_UPSAMPLE'] = '14'
     if args.what == 'fused':         # needs --debug-lib: the fused decode -> gather pass, packed f16 split (shipped) vs the round-3 split (VKN_FUSED=19)
         B = 32
         x = torch.randn(B, C, H, W, generator=g).to(DEV)

@@ -1435,6 +1435,18 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
     const float rs = 1.0f / (float)S;
     const float* ip = in + (size_t)plane * H * W;
     float* op = out + (size_t)plane * OH * OW;
+    // NT == 5 (debug A/B, round 4; measured SLOWER: 1555 vs 1470 us per 32-frame launch): the workgroup's UP_ROWS * SUBS + 2 input rows
+    // go through LDS once — 18 load instructions per thread instead of 66 (three overlapping tap loads per row) — and the taps come
+    // from LDS.  Fewer vector-memory instructions do not help: the staging phase + barrier in front of a workgroup's first store costs
+    // more than the tap loads that ride between the store bursts.  Slot r holds input row clamp(yb0 - 1 + r).
+    extern __shared__ __attribute__((aligned(16))) float up_rows[];
+    if (VKN_ABL_IS(NT, 5)) {
+        for (int idx = threadIdx.x; idx < (UP_ROWS * SUBS + 2) * W; idx += 256) {
+            const int r = idx / W, c = idx - r * W;
+            up_rows[idx] = ip[(size_t)min(max(yb0 - 1 + r, 0), H - 1) * W + c];
+        }
+        __syncthreads();
+    }
     for (int q = threadIdx.x; q * 4 < OW; q += 256) {
         const int jb = (q * 4) / S;  // first input column under the quad
         // horizontal coefficients of the quad's 4 output columns, local tap indices
@@ -1469,7 +1481,7 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
             const int y = min(max(yb0 - 1 + r, 0), H - 1);
             float v[NTAP];
 #pragma unroll
-            for (int i = 0; i < NTAP; ++i) v[i] = VKN_ABL_IS(NT, 2) ? (float)(y + cx[i]) : VKN_ABL_IS(NT, 3) ? __builtin_nontemporal_load(ip + (size_t)y * W + cx[i]) : ip[(size_t)y * W + cx[i]];  // NT == 2: write-only ablation, 3: nontemporal input loads (debug A/B)
+            for (int i = 0; i < NTAP; ++i) v[i] = VKN_ABL_IS(NT, 5) ? up_rows[r * W + cx[i]] : VKN_ABL_IS(NT, 2) ? (float)(y + cx[i]) : VKN_ABL_IS(NT, 3) ? __builtin_nontemporal_load(ip + (size_t)y * W + cx[i]) : ip[(size_t)y * W + cx[i]];  // NT == 2: write-only ablation, 3: nontemporal input loads (debug A/B)
             hinterp(v, hrow[r]);
         }
         // NT == 4: ALL input rows of the workgroup are requested up front — no load sits between store bursts
@@ -1506,7 +1518,7 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
                 for (int r = 0; r < UP_ROWS; ++r) {
                     const int y = min(yb + UP_ROWS + 1 + r, H - 1);
 #pragma unroll
-                    for (int i = 0; i < NTAP; ++i) nv[r][i] = VKN_ABL_IS(NT, 2) ? (float)(y + cx[i]) : VKN_ABL_IS(NT, 3) ? __builtin_nontemporal_load(ip + (size_t)y * W + cx[i]) : ip[(size_t)y * W + cx[i]];
+                    for (int i = 0; i < NTAP; ++i) nv[r][i] = VKN_ABL_IS(NT, 5) ? up_rows[(sub * UP_ROWS + UP_ROWS + 2 + r) * W + cx[i]] : VKN_ABL_IS(NT, 2) ? (float)(y + cx[i]) : VKN_ABL_IS(NT, 3) ? __builtin_nontemporal_load(ip + (size_t)y * W + cx[i]) : ip[(size_t)y * W + cx[i]];
                 }
             }
             // vertical blend + store: output rows S * yb .. S * (yb + UP_ROWS) - 1
@@ -1577,7 +1589,8 @@ int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, i
             dim3 grid((H + UP_ROWS * subs - 1) / (UP_ROWS * subs), chunk);
 #define UP_LAUNCH(SV, NTV, SUBV) hipLaunchKernelGGL((k_upsample_s<SV, NTV, SUBV>), grid, dim3(256), 0, stream, ip, op, H, W)
 #ifdef VKN_DEBUG
-            if (S == 4 && mode / 10 == 6) { UP_LAUNCH(4, 3, 4); }  // nontemporal input loads (A/B)
+            if (S == 4 && mode / 10 == 5) { hipLaunchKernelGGL((k_upsample_s<4, 5, 4>), grid, dim3(256), (size_t)(UP_ROWS * 4 + 2) * W * sizeof(float), stream, ip, op, H, W); }  // input rows through LDS (A/B)
+            else if (S == 4 && mode / 10 == 6) { UP_LAUNCH(4, 3, 4); }  // nontemporal input loads (A/B)
             else if (S == 4 && mode / 10 == 7) { UP_LAUNCH(4, 4, 4); }  // all input rows requested up front (A/B)
             else if (S == 4 && mode / 10 == 3) { UP_LAUNCH(4, 2, 4); }  // write-only ablation: the store pattern's own ceiling
             else if (S == 4 && (mode % 10 == 8 || mode % 10 == 9)) {  // 8 / 32 row groups per workgroup (quarter / whole plane)
