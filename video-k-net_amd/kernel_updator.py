@@ -55,7 +55,8 @@ class KernelUpdator(nn.Module):
 
     def forward_autograd(self, update_feature, input_feature):
         """The same arithmetic as plain torch ops on this module's own Linear / LayerNorm parameters — the differentiable
-        path used in training (knet/kernel_updator.py:56-93 line by line; rocBLAS GEMMs on [B*N, C] rows)."""
+        path of a standalone updator in training and the A/B / test oracle of `chain_train.kernel_updator`, which is what a training head
+        runs (knet/kernel_updator.py:56-93 line by line; rocBLAS GEMMs on [B*N, C] rows)."""
         C = self.in_channels
         u = update_feature.reshape(-1, C)
         num = u.size(0)
