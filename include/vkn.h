@@ -436,6 +436,9 @@ int vkn_head_forward_prof_f32(const VknDims* d, int num_stages, const VknStageWe
  *           use_binary=True, 2 = on with use_binary=False (weights (sigmoid(z) > 0.5) * sigmoid(z), :246-247); thr_logit as in VknDims.
  *      out: x_feats [B][C][P]; mask_preds [B][N][P] and proposal_feats [B][N][C] with N = Np + (cat_stuff ? ncls -
  *           num_thing_classes : 0); seg_preds [B][ncls][P] or NULL (kept in the workspace).
+ *      flags: VKN_FLAG_X_F16 / VKN_FLAG_X_BF16 — loc_feats, sem_feats AND x_feats are 2-byte elements (the head then reads x_feats with the
+ *           same flag): mask_preds / seg_preds are the bits of the fp32 pass on the widened features, x_feats = half(float(sem) +
+ *           float(loc)) (one more rounding), proposal_feats the bits of the fp32 gather on that x_feats.  Needs P % 64 == 0, with_obj != 2.
  */
 size_t vkn_kernel_init_workspace_bytes(int B, int Np, int ncls, int C, int P);
 int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const float* init_w, const float* seg_w,

@@ -866,13 +866,18 @@ int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const fl
     carve_init(B, Np, ncls, C, P, sem && !seg_preds, static_cast<char*>(ws), &s);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool ref = (flags & VKN_FLAG_REF_KERNELS) != 0, ref_decode = ref || (P & 1);
+    // 2-byte feature storage (VKN_FLAG_X_F16 / _BF16, round 4): loc_feats, sem_feats and x_feats point at 2-byte elements; the decodes and
+    // the gather read them like the head's passes do, x_feats = half(float(sem) + float(loc))
+    const int xdt = xdt_of(flags);
+    if (xdt && (ref || (P % 64) != 0 || with_obj == 2)) return VKN_E_SHAPE;
+    const size_t xes = xdt ? 2 : 4;
 
     // mask_preds[:, :Np] = init_kernels(loc_feats): 1x1 conv, no bias, the same kernels for every frame          (:222)
     if (ref_decode) {
         VKN_TRY(vkn_launch_decode_ref_ex(loc_feats, init_w, nullptr, mask_preds, B, Np, C, P, 1, N, st));
     } else {
         VKN_TRY(vkn_launch_split_planes(init_w, s.ih, s.il, 1, Np, C, st));
-        VKN_TRY(vkn_launch_decode_ex(loc_feats, s.ih, s.il, nullptr, mask_preds, B, Np, C, P, 1, N, st));
+        VKN_TRY(vkn_launch_decode_ex(loc_feats, s.ih, s.il, nullptr, mask_preds, B, Np, C, P, 1, N, st, xdt));
     }
     const float* xf = loc_feats;
     if (sem) {
@@ -882,7 +887,7 @@ int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const fl
             VKN_TRY(vkn_launch_decode_ref_ex(sem_feats, seg_w, seg_b, seg, B, ncls, C, P, 1, ncls, st));
         } else {
             VKN_TRY(vkn_launch_split_planes(seg_w, s.sh, s.sl, 1, ncls, C, st));
-            VKN_TRY(vkn_launch_decode_ex(sem_feats, s.sh, s.sl, seg_b, seg, B, ncls, C, P, 1, ncls, st));
+            VKN_TRY(vkn_launch_decode_ex(sem_feats, s.sh, s.sl, seg_b, seg, B, ncls, C, P, 1, ncls, st, xdt));
         }
         // mask_preds[:, Np:] = seg_preds[:, num_thing_classes:]  (cat_stuff_mask, inference)                      (:255-257)
         if (nstuff > 0) {
@@ -892,10 +897,11 @@ int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const fl
                 return VKN_E_LAUNCH;
         }
         // x_feats = semantic_feats + loc_feats                                                                   (:238-241)
-        VKN_TRY(vkn_launch_add2(sem_feats, loc_feats, x_feats, (size_t)B * C * P, st));
+        if (xdt) VKN_TRY(vkn_launch_add2_half(sem_feats, loc_feats, x_feats, (size_t)B * C * P, xdt, st));
+        else VKN_TRY(vkn_launch_add2(sem_feats, loc_feats, x_feats, (size_t)B * C * P, st));
         xf = x_feats;
     } else if (x_feats && x_feats != loc_feats) {
-        if (hipMemcpyAsync(x_feats, loc_feats, (size_t)B * C * P * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        if (hipMemcpyAsync(x_feats, loc_feats, (size_t)B * C * P * xes, hipMemcpyDeviceToDevice, st) != hipSuccess)
             return VKN_E_LAUNCH;
     }
     // obj_feats = einsum('bnhw,bchw->bnc', (sigmoid(mask_preds) > 0.5).float(), x_feats)   (use_binary)           (:243-250)
@@ -905,7 +911,7 @@ int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const fl
             if (ref) return VKN_E_SHAPE;  // no exact-fp32 reference kernel for the soft weights
             VKN_TRY(vkn_launch_gather_soft(xf, mask_preds, thr_logit, s.obj, s.cnt, s.part, s.cntp, B, Np, C, P, N, st));
         } else if (ref) VKN_TRY(vkn_launch_gather_ref_ex(xf, mask_preds, thr_logit, s.obj, s.cnt, B, Np, C, P, N, st));
-        else VKN_TRY(vkn_launch_gather_ex(xf, mask_preds, thr_logit, s.obj, s.cnt, s.part, s.cntp, B, Np, C, P, N, st));
+        else VKN_TRY(vkn_launch_gather_ex(xf, mask_preds, thr_logit, s.obj, s.cnt, s.part, s.cntp, B, Np, C, P, N, st, xdt));
         obj = s.obj;
     }
     // proposal_feats = init_kernels.weight (+ obj_feats), then the stuff kernels conv_seg.weight[num_thing:]      (:234-263)

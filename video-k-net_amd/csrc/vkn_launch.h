@@ -92,6 +92,7 @@ int vkn_launch_gemm(const float* A, const float* A2, int lda, const float* W, co
 int vkn_launch_gemm_group(const VknGemmProb* probs, int nprob, int M, int K, int ksplit, float* partial, hipStream_t stream);
 size_t vkn_split_w3_bytes(int Nout, int K);
 int vkn_launch_add2(const float* a, const float* b, float* out, size_t n, hipStream_t st);
+int vkn_launch_add2_half(const void* a, const void* b, void* out, size_t n, int xdt, hipStream_t st);  // 2-byte features (xdt 1 fp16, 2 bf16)
 int vkn_launch_add_rows(const float* a, const float* pos, float* out, size_t rows, int C, int period, hipStream_t st);
 int vkn_launch_init_finish(const float* init_w, const float* obj, const float* seg_w, float* out, int B, int Np, int N, int nth,
                            int C, hipStream_t st);

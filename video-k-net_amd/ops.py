@@ -583,7 +583,8 @@ def kernel_init(loc_feats, semantic_feats, init_w, seg_w=None, seg_b=None, num_t
     """Kernel initialisation ("pass 0"), `ConvKernelHead._decode_init_proposals` after its loc / seg convs
     (knet/det/kernel_head.py:204-263), use_binary semantics.  Returns (proposal_feats [B,N,C], x_feats [B,C,H,W],
     mask_preds [B,N,H,W], seg_preds [B,ncls,H,W] | None)."""
-    loc = _req(loc_feats, 'loc_feats')
+    loc, xdt = _req_x(loc_feats, 'loc_feats')       # fp32, or fp16 / bf16 STORAGE (x_feats then has the same type; the head reads it as is)
+    flags = int(flags) | {1: FLAG_X_F16, 2: FLAG_X_BF16}.get(xdt, 0)
     B, C, H, W = loc.shape
     P = H * W
     dev = loc.device
@@ -594,9 +595,9 @@ def kernel_init(loc_feats, semantic_feats, init_w, seg_w=None, seg_b=None, num_t
     sem = sw = sb = None
     ncls = 0
     if semantic_feats is not None:
-        sem = _req(semantic_feats, 'semantic_feats')
-        if sem.shape != loc.shape:
-            raise ValueError('semantic_feats and loc_feats must have the same shape')
+        sem, sdt = _req_x(semantic_feats, 'semantic_feats')
+        if sem.shape != loc.shape or sdt != xdt:
+            raise ValueError('semantic_feats and loc_feats must have the same shape and storage type')
         sw = _req(seg_w.reshape(seg_w.shape[0], -1), 'conv_seg.weight')
         sb = _req(seg_b, 'conv_seg.bias') if seg_b is not None else None
         ncls = sw.shape[0]
