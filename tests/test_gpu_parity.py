@@ -1284,3 +1284,34 @@ def test_block_step_with_neighbour_link_equals_whole_clip(vkn):
         blocks.append(out)
     for k in range(5):
         assert torch.equal(torch.cat([b[k] for b in blocks], 0), whole[k]), k
+
+
+def test_softmax_classification_head_runs_stage_by_stage_vs_oracle(vkn):
+    """`loss_cls.use_sigmoid=False` (reference knet/det/kernel_iter_head.py:309-310: `cls_score.softmax(-1)[..., :-1]`, `fc_cls` with
+    one more output; no shipped config): the reference entry point works — stage by stage, because the fused call applies the sigmoid
+    in its last epilogue — and matches the oracle; the fused extension API refuses loudly."""
+    import dataclasses
+    from helpers import cfg_of
+    from oracle import synth
+    from oracle.knet_oracle import head_param_shapes, iter_head_mask_preds
+    from test_host_logic import _cfg
+    _, case = load_golden('det_tiny')
+    ocfg = dataclasses.replace(cfg_of(case), use_sigmoid_cls=False)
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_like(head_param_shapes(ocfg), case['seed']).items()}
+    x, pf, mp = (torch.from_numpy(a) for a in synth.head_inputs(case['B'], case['N'], case['C'], case['H'], case['W'], case['seed']))
+    with torch.no_grad():
+        r_obj, r_cls, r_masks, _, _ = iter_head_mask_preds(sd, x, pf, mp, ocfg)
+    head = vkn.build_head(_cfg(False, C=case['C'], heads=case['heads'], ffn=case['ffn'], ncls=case['ncls'], n_thing=case['n_thing'],
+                               n_stuff=case['n_stuff'], S=case['S'], up=case['up'], nprop=case['nprop'],
+                               mask_over=dict(loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))))
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV).eval()
+    xd, pfd, mpd = _cuda(x, pf, mp)
+    with torch.no_grad():
+        obj, cls, masks, scaled = head.simple_test_mask_preds(xd, pfd, mpd, None, [dict()] * case['B'])
+    assert tuple(cls.shape) == (case['B'], case['N'], case['ncls'])
+    assert maxabs(cls, r_cls) < 1e-5
+    assert maxabs(obj, r_obj) < 1e-4
+    assert maxabs(masks, r_masks) < TOL_LOGIT
+    with pytest.raises(NotImplementedError):
+        head._head_forward(xd, pfd, mpd)

@@ -128,8 +128,11 @@ class KernelIterHead(BaseRoIHead):
         # the `simple_test*` entry points are INFERENCE APIs: in eval() mode they take the fused C-ABI path and their outputs are
         # detached from autograd whatever the grad mode (mmdet calls them under no_grad); gradients flow through `forward_train`
         # and through the stage modules' `forward` (KernelUpdateHead._needs_grad)
+        # (a softmax classification head — `loss_cls.use_sigmoid=False`, reference :309-310, no shipped config — runs stage by stage:
+        #  the fused call applies the sigmoid in its last epilogue)
         return (x.is_cuda and not self.training
                 and all(isinstance(h, KernelUpdateHead) for h in self.mask_head)
+                and self.mask_head[-1].loss_cls.use_sigmoid
                 and len({(h.in_channels, h.num_heads, h.feedforward_channels, h.fc_cls.out_features, h.num_cls_fcs,
                           h.num_mask_fcs, h.hard_mask_thr, h.with_ffn, h.feat_transform is None) for h in self.mask_head}) == 1)
 
@@ -151,7 +154,10 @@ class KernelIterHead(BaseRoIHead):
                                                           flags=flags | getattr(h0, 'vkn_flags', 0), clip_first_prev=clip_first_prev, link_pre=link_pre,
                                                           link_track=link_track, track_src=track_src)
         if not hl.loss_cls.use_sigmoid:
-            raise NotImplementedError('softmax cls activation (reference :309-310): every shipped config uses sigmoid')
+            # (the reference entry points never get here: `_fused_ok` sends a softmax head through the stage-by-stage path; the
+            #  clip-batched extensions have no such path)
+            raise NotImplementedError('the fused head call applies sigmoid to the class logits; a softmax head (reference :309-310) '
+                                      'runs through simple_test_mask_preds*')
         obj = obj.reshape(B, N, C, K, K)
         if track is not None:
             track = track.reshape(B, N, C, K, K)
