@@ -1315,3 +1315,26 @@ def test_softmax_classification_head_runs_stage_by_stage_vs_oracle(vkn):
     assert maxabs(masks, r_masks) < TOL_LOGIT
     with pytest.raises(NotImplementedError):
         head._head_forward(xd, pfd, mpd)
+
+
+def test_masks_at_another_resolution_are_resized_like_the_reference(vkn):
+    """Reference knet/det/kernel_update_head.py:182-188 (incoming masks at another resolution than x are resized bilinearly before the
+    gather) and :268-273 (`mask_shape` resizes the new logits): dead in shipped configs, built since round 4.  Fused call and
+    stage-by-stage path against the oracle on half-resolution incoming masks."""
+    import torch.nn.functional as F
+    from helpers import cfg_of, make_case
+    from oracle.knet_oracle import iter_head_mask_preds
+    _, case = load_golden('det_tiny')
+    head, (x, pf, mp, _) = _build_head(vkn, case)
+    cfg, sd, *_ = make_case(case)
+    mp_small = F.avg_pool2d(mp, 2) * 3.0                      # a different tensor at half the resolution
+    with torch.no_grad():
+        r_obj, r_cls, r_masks, _, _ = iter_head_mask_preds(sd, x, pf, mp_small, cfg_of(case))
+    xd, pfd, mpd = _cuda(x, pf, mp_small)
+    with torch.no_grad():
+        obj, cls, masks, scaled = head.simple_test_mask_preds(xd, pfd, mpd, None, [dict()] * case['B'])
+        r = head._mask_forward(0, xd, pfd, mpd, [dict()] * case['B'])
+        cls1, m1, obj1 = head.mask_head[0](xd, pfd, mpd, mask_shape=(2 * case['H'], 2 * case['W']))
+    assert maxabs(obj, r_obj) < 1e-4 and maxabs(cls, r_cls) < 1e-5 and maxabs(masks, r_masks) < TOL_LOGIT
+    assert tuple(m1.shape[-2:]) == (2 * case['H'], 2 * case['W'])
+    assert maxabs(m1, F.interpolate(r['mask_preds'], scale_factor=2, mode='bilinear', align_corners=False)) < 1e-5

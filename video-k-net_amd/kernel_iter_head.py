@@ -141,6 +141,7 @@ class KernelIterHead(BaseRoIHead):
         h0, hl = self.mask_head[0], self.mask_head[-1]
         for h in self.mask_head:
             h._check_inputs(x, proposal_feats, mask_preds, None)
+        mask_preds = h0._gather_masks(x, mask_preds)       # (reference kernel_update_head.py:182-188: only the incoming masks can differ)
         B, N = proposal_feats.shape[:2]
         C, K = h0.in_channels, h0.conv_kernel_size
         H, W = x.shape[-2:]

@@ -319,11 +319,21 @@ class KernelUpdateHead(nn.Module):
             pass  # handled by the library (ffn pointers NULL)
         if x.dim() != 4 or mask_preds.dim() != 4:
             raise ValueError('x must be [B,C,H,W] and mask_preds [B,N,H,W]')
+
+    @staticmethod
+    def _gather_masks(x, mask_preds):
+        """Reference :182-188: masks at another resolution than x are resized (bilinear, align_corners=False) before they are binarised
+        for the gather.  No shipped config gets here; the resize is a torch op in front of the C call."""
         if tuple(mask_preds.shape[-2:]) != tuple(x.shape[-2:]):
-            raise NotImplementedError('mask_preds at a different resolution than x (bilinear pre-resize, reference :183-186) '
-                                      'never happens in shipped configs and is not built')
+            mask_preds = torch.nn.functional.interpolate(mask_preds, tuple(x.shape[-2:]), mode='bilinear', align_corners=False)
+        return mask_preds
+
+    @staticmethod
+    def _to_mask_shape(x, new_mask_preds, mask_shape):
+        """Reference :268-273: `mask_shape` (a caller-given output size) resizes the NEW mask logits when its height differs from x's."""
         if mask_shape is not None and mask_shape[0] != x.shape[-2]:
-            raise NotImplementedError('mask_shape resize (reference :268-273) is dead in shipped configs and is not built')
+            new_mask_preds = torch.nn.functional.interpolate(new_mask_preds, tuple(mask_shape), mode='bilinear', align_corners=False)
+        return new_mask_preds
 
     def _needs_grad(self, x, proposal_feat):
         """Autograd is wanted whenever grad mode is on and an input or any parameter requires grad — in train() AND eval() mode
@@ -525,11 +535,12 @@ class KernelUpdateHead(nn.Module):
     def forward(self, x, proposal_feat, mask_preds, prev_cls_score=None, mask_shape=None, img_metas=None):
         """-> (cls_score [B,N,ncls], new_mask_preds [B,N,H,W], obj_feat [B,N,C,K,K])   reference :170-277"""
         self._check_inputs(x, proposal_feat, mask_preds, mask_shape)
+        mask_preds = self._gather_masks(x, mask_preds)
         if self._needs_grad(x, proposal_feat):
             cls, masks, obj, _, _ = self._forward_autograd(x, proposal_feat, mask_preds)
-            return cls, masks, obj
-        cls, masks, obj, _, _ = self._run(x, proposal_feat, mask_preds)
-        return cls, masks, obj
+        else:
+            cls, masks, obj, _, _ = self._run(x, proposal_feat, mask_preds)
+        return cls, self._to_mask_shape(x, masks, mask_shape), obj
 
     # ---- instance-only results: knet/det/kernel_update_head.py:443-481 (result formatting: K <= max_per_img masks per image)
     @staticmethod
@@ -796,7 +807,9 @@ class VideoKernelUpdateHead(KernelUpdateHead):
             previous_obj_feats = None      # no link modules were built (reference would fail on attribute access)
         if previous_obj_feats is not None and self.training and self.previous_detach:
             previous_obj_feats = previous_obj_feats.detach()                                               # :317-318
+        mask_preds = self._gather_masks(x, mask_preds)
         if self._needs_grad(x, proposal_feat):
-            return self._forward_autograd(x, proposal_feat, mask_preds, previous_obj_feats)
-        cls, masks, obj, xfeat, track = self._run(x, proposal_feat, mask_preds, previous_obj_feats)
-        return cls, masks, obj, xfeat, track
+            cls, masks, obj, xfeat, track = self._forward_autograd(x, proposal_feat, mask_preds, previous_obj_feats)
+        else:
+            cls, masks, obj, xfeat, track = self._run(x, proposal_feat, mask_preds, previous_obj_feats)
+        return cls, self._to_mask_shape(x, masks, mask_shape), obj, xfeat, track

@@ -97,8 +97,10 @@ class KernelUpdateHeadVideo(_QueryMerge, KernelUpdateHead):
         """x [B,F,C,H,W], mask_preds [B,F,N,H,W]; proposal_feat [B,N,C,1,1] (clip-level kernels, `with_cls` stages) or
         [B,F,N,C,1,1] (per-frame kernels) -> (cls_score | None, new_mask_preds [B,F,N,H,W], obj_feat)      reference :209-374"""
         B, F, C, H, W = x.shape
-        if mask_preds.shape[-2:] != (H, W):
-            raise NotImplementedError('mask_preds at another resolution than x is dead in shipped configs (:227-231)')
+        if mask_preds.shape[-2:] != (H, W):      # reference :227-231: bilinear pre-resize of the incoming masks (no shipped config)
+            N_ = mask_preds.shape[2]
+            mask_preds = torch.nn.functional.interpolate(mask_preds.reshape(B * F, N_, *mask_preds.shape[-2:]), (H, W), mode='bilinear',
+                                                         align_corners=False).reshape(B, F, N_, H, W)
         if self._needs_grad(x, proposal_feat):
             return self._forward_clip_autograd(x, proposal_feat, mask_preds, pos)
         if proposal_feat.dim() == 6:
