@@ -467,3 +467,21 @@ def test_conv_kernel_head_forward_train_vs_reference_golden(vkn, name):
     assert sorted(named) == list(g['grad_keys'])
     for i, k in enumerate(g['grad_keys']):
         _check_grad(g, f'grad_{i}', named[str(k)].grad)
+
+
+def test_soft_gather_forward_backward_vs_fp64_autograd(vkn):
+    """`use_binary=False` (knet/det/kernel_head.py:246-249): xraw = ([sigmoid(z) > 0.5] sigmoid(z)) x^T with gradients to x AND to the
+    mask logits, against torch fp64 autograd of the same expression (a reference dead branch in shipped configs; built in round 4)."""
+    B, N, C, H, W = 2, 21, 64, 16, 32
+    x = _rand((B, C, H, W), 601).to(DEV).requires_grad_(True)
+    z = _rand((B, N, H, W), 602, 2.0).to(DEV).requires_grad_(True)
+    g = (_rand((B, N, C), 603) * 1e-3).to(DEV)
+    out = vkn.autograd.mask_gather_soft(x, z, 0.5)
+    out.backward(g)
+    xd, zd = x.detach().double().requires_grad_(True), z.detach().double().requires_grad_(True)
+    sg = torch.sigmoid(zd)
+    ref = torch.einsum('bnhw,bchw->bnc', sg * (z.detach() >= vkn.ops.thr_logit(0.5)).double(), xd)
+    ref.backward(g.double())
+    assert maxabs(out, ref) < 2e-5 * float(ref.detach().abs().max())
+    assert maxabs(x.grad, xd.grad) < 2e-5 * float(xd.grad.abs().max())
+    assert maxabs(z.grad, zd.grad) < 2e-5 * float(zd.grad.abs().max())

@@ -84,6 +84,40 @@ class MaskGatherFn(torch.autograd.Function):
         return dx.mul_(1.0 / s), None, None
 
 
+class SoftMaskGatherFn(torch.autograd.Function):
+    """xraw = w x^T with the SOFT weights w = [z >= thr] sigmoid(z) (`use_binary=False`, knet/det/kernel_head.py:243-249): differentiable
+    w.r.t. x and — unlike the binarised gather — w.r.t. the mask logits z.  Forward: the real-operand gather kernel; backward: two
+    decode-shaped launches, dx = w^T dxraw and dz = [z >= thr] sigmoid'(z) (dxraw x)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_logits, hard_mask_thr):
+        on = mask_logits >= ops.thr_logit(hard_mask_thr)
+        w = torch.sigmoid(mask_logits) * on
+        xraw, _ = ops.mask_gather_real(x, w)
+        ctx.save_for_backward(x, mask_logits)
+        ctx.thr = hard_mask_thr
+        return xraw
+
+    @staticmethod
+    def backward(ctx, dxraw):
+        x, z = ctx.saved_tensors
+        B, N, H, W = z.shape
+        sg = torch.sigmoid(z)
+        on = z >= ops.thr_logit(ctx.thr)
+        s = _pow2_scale(dxraw)
+        inv = 1.0 / s
+        dxs = (dxraw * s).contiguous()                                    # [B, N, C]
+        dx = dz = None
+        if ctx.needs_input_grad[0]:
+            Np = (N + 31) // 32 * 32
+            rows = torch.zeros((B, Np, H, W), dtype=torch.float32, device=z.device)
+            rows[:, :N] = sg * on
+            dx = ops.mask_decode(rows, _pad_last(dxs.transpose(1, 2), Np)).mul_(inv)       # [B, C, H, W]
+        if ctx.needs_input_grad[1]:
+            dz = ops.mask_decode(x, dxs).mul_(inv) * (sg * (1.0 - sg)) * on                # [B, N, H, W]
+        return dx, dz, None
+
+
 class MaskDecodeFn(torch.autograd.Function):
     """Z = decode(x, K, kb); backward: dK = dZ x^T, dkb = sum_p dZ, dx = K^T dZ."""
 
@@ -123,6 +157,10 @@ def mask_gather(x, mask_logits, hard_mask_thr=0.5):
 
 def mask_decode(x, kernels, bias=None):
     return MaskDecodeFn.apply(x, kernels, bias)
+
+
+def mask_gather_soft(x, mask_logits, hard_mask_thr=0.5):
+    return SoftMaskGatherFn.apply(x, mask_logits, hard_mask_thr)
 
 
 class MaskLossesFn(torch.autograd.Function):

@@ -209,9 +209,10 @@ class ConvKernelHead(nn.Module):
         proposal_feats = self.init_kernels.weight[None].expand(B, Np, C, 1, 1)                             # :234-236
         x_feats = semantic_feats + loc_feats if semantic_feats is not None else loc_feats                  # :238-241
         if self.proposal_feats_with_obj:
-            if not self.use_binary:
-                raise NotImplementedError('training with use_binary=False (soft gather weights) is not built (no shipped config)')
-            obj, _ = vag.mask_gather(x_feats, mask_preds.detach(), 0.5)                                    # :243-250 (bool mask: no grad)
+            if self.use_binary:
+                obj, _ = vag.mask_gather(x_feats, mask_preds.detach(), 0.5)                                # :243-250 (bool mask: no grad)
+            else:
+                obj = vag.mask_gather_soft(x_feats, mask_preds, 0.5)                                       # :246-249: gradients reach the logits
             proposal_feats = proposal_feats + obj.view(B, Np, C, 1, 1)                                     # :252-254
         if self.cat_stuff_mask and not self.training:                                                       # :255-263
             mask_preds = torch.cat([mask_preds, seg_preds[:, self.num_thing_classes:]], dim=1)
