@@ -411,6 +411,92 @@ def t_attn_widths():
     assert float((o0.cpu() - traces[0]['obj_feat'].reshape(B, N, C)).abs().max()) < 3e-4, ('attention widths', C, heads, N, B)
 
 
+def t_chain_train():
+    """round-4 training-chain kernels (csrc/vkn_train.hip) at random shapes against torch fp64 autograd: Linear (forward, dA on the
+    transposed images incl. K = 512 / 768 and ragged out-feature counts, dW / db), LayerNorm + activation + residual (row and column
+    workgroups), the attention core (packed and cross, every head width, ragged key / query blocks: matrix-core and VALU backward)."""
+    ct = vkn.chain_train
+
+    def rel(a, b):
+        return float((a.double() - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+    with torch.enable_grad():
+        M = int(rng.integers(1, 700))
+        K = 32 * int(rng.integers(1, 25)) if rng.random() < 0.7 else 2048
+        Nout = int(rng.choice([int(rng.integers(1, 300)), 256, 512, 768, 2048]))
+        act, bias = int(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        a = torch.randn(M, K, device=dev).requires_grad_(True)
+        w = (torch.randn(Nout, K, device=dev) * 0.05).requires_grad_(True)
+        b = (torch.randn(Nout, device=dev) * 0.1).requires_grad_(True) if bias else None
+        gy = torch.randn(M, Nout, device=dev) * 1e-2
+        y = ct.linear(a, w, b, act=act)
+        y.backward(gy)
+        ad, wd = a.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+        bd = b.detach().double().requires_grad_(True) if bias else None
+        yr = F.linear(ad, wd, bd)
+        yr = torch.relu(yr) if act else yr
+        yr.backward(gy.double())
+        tag = ('linear', M, K, Nout, act, bias)
+        assert rel(y.detach(), yr.detach()) < 2e-5, tag
+        # (a ReLU within fp32 rounding of zero flips in fp32: compare the gradients where the two forwards agree on the sign)
+        if not act or bool(((y.detach() > 0) == (yr.detach() > 0)).all()):
+            assert rel(a.grad, ad.grad) < 5e-5 and rel(w.grad, wd.grad) < 5e-5, tag
+            assert (not bias) or rel(b.grad, bd.grad) < 5e-5, tag
+
+        M, C = int(rng.integers(1, 700)), 32 * int(rng.integers(1, 9))
+        act, resid, sliced = int(rng.integers(0, 3)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        wide = (torch.randn(M, 2 * C, device=dev) * 2).requires_grad_(True)
+        x = wide[:, C:] if sliced else wide[:, :C].contiguous()
+        r = torch.randn(M, C, device=dev).requires_grad_(True) if resid else None
+        ln = torch.nn.LayerNorm(C).to(dev)
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(C, device=dev) * 0.5 + 1.0)
+            ln.bias.copy_(torch.randn(C, device=dev) * 0.3)
+        gy = torch.randn(M, C, device=dev) * 1e-2
+        y = ct.layernorm(x, ln, act=act, resid=r)
+        y.backward(gy)
+        wdd = wide.detach().double().requires_grad_(True)
+        xd = wdd[:, C:] if sliced else wdd[:, :C]
+        rd = r.detach().double().requires_grad_(True) if resid else None
+        gd, bd = ln.weight.detach().double().requires_grad_(True), ln.bias.detach().double().requires_grad_(True)
+        zz = F.layer_norm(xd + rd if resid else xd, (C,), gd, bd, ln.eps)
+        yr = torch.relu(zz) if act == 1 else torch.sigmoid(zz) if act == 2 else zz
+        yr.backward(gy.double())
+        tag = ('layernorm', M, C, act, resid, sliced)
+        assert rel(y.detach(), yr.detach()) < 1e-5, tag
+        if act != 1 or bool(((y.detach() > 0) == (yr.detach() > 0)).all()):
+            assert rel(wide.grad, wdd.grad) < 5e-5 and rel(ln.weight.grad, gd.grad) < 5e-5 and rel(ln.bias.grad, bd.grad) < 5e-5, tag
+            assert (not resid) or rel(r.grad, rd.grad) < 5e-5, tag
+
+        hd = int(rng.choice([4, 8, 16, 32, 64]))
+        heads = int(rng.choice([h for h in (1, 2, 4, 8) if h * hd <= 256]))
+        C, B = heads * hd, int(rng.integers(1, 4))
+        Nq, Nk = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        packed = bool(rng.integers(0, 2))
+        if packed:
+            Nk = Nq
+            q = (torch.randn(B * Nq, 3 * C, device=dev) * 0.7).requires_grad_(True)
+            kv = None
+        else:
+            q = (torch.randn(B * Nq, C, device=dev) * 0.7).requires_grad_(True)
+            kv = (torch.randn(B * Nk, 2 * C, device=dev) * 0.7).requires_grad_(True)
+        go = torch.randn(B * Nq, C, device=dev) * 1e-2
+        o = ct.attention(q, kv, B, heads)
+        o.backward(go)
+        qd = q.detach().double().requires_grad_(True)
+        kvd = kv.detach().double().requires_grad_(True) if kv is not None else None
+        qq, kk, vv = (qd[:, :C], qd[:, C:2 * C], qd[:, 2 * C:]) if packed else (qd, kvd[:, :C], kvd[:, C:])
+        qh, kh, vh = (t.reshape(B, -1, heads, hd).transpose(1, 2) for t in (qq, kk, vv))
+        orf = (torch.softmax(qh @ kh.transpose(-1, -2) / hd ** 0.5, -1) @ vh).transpose(1, 2).reshape(B * Nq, C)
+        orf.backward(go.double())
+        tag = ('attention', B, Nq, Nk, heads, hd, packed)
+        assert rel(o.detach(), orf.detach()) < 2e-5, tag
+        if Nk == 1:     # one key: P = 1, dS = 0 — the exact gradients of q and k are ZERO; ours are rounding noise of dO . (v - O)
+            assert float(q.grad[:, :C].abs().max()) < 1e-6 and bool(torch.isfinite(q.grad).all()), tag
+        else:
+            assert rel(q.grad, qd.grad) < 5e-5 and (packed or rel(kv.grad, kvd.grad) < 5e-5), tag
+
+
 _heads = {}
 only = sys.argv[2:]
 with torch.no_grad():
@@ -421,7 +507,8 @@ with torch.no_grad():
                      ('head fused / bits / logits / side stream', t_head_fused), ('half-storage x', t_xhalf),
                      ('device LSAP vs host solver', t_lsap), ('device tracker vs oracle', t_tracker),
                      ('link heads clip vs frame-by-frame', t_link_heads), ('VIS attention query merge', t_query_merge),
-                     ('training ops vs torch', t_train_ops), ('attention head widths / key blocks', t_attn_widths)):
+                     ('training ops vs torch', t_train_ops), ('attention head widths / key blocks', t_attn_widths),
+                     ('training chain kernels vs torch fp64', t_chain_train)):
         if not only or any(o in name for o in only):
             section(name, fn)
 print('soak: OK')
