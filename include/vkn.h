@@ -175,6 +175,11 @@ int vkn_mask_gather_real_f32(const float* x, const float* a, float* out, float* 
 size_t vkn_decode_workspace_bytes(int B, int N, int C);
 int vkn_mask_decode_f32(const float* x, const float* kernels, const float* bias, float* out, int B, int N, int C, int P,
                         void* ws, size_t ws_bytes, unsigned flags, void* stream);
+/*      ... with every output multiplied by a DEVICE scalar before it is stored: out = *out_scale * (kernels x + bias).  The backward passes
+ *      of a training step scale their gradient operand by a power of two into the f16 split's range; this undoes it inside the
+ *      kernel instead of in a second pass over the [B][N][P] result.  MFMA kernel only (even P, no VKN_FLAG_REF_KERNELS). */
+int vkn_mask_decode_scaled_f32(const float* x, const float* kernels, const float* bias, const float* out_scale, float* out, int B,
+                               int N, int C, int P, void* ws, size_t ws_bytes, unsigned flags, void* stream);
 
 /* ---- the same decode on PRE-SPLIT kernels: kf_hi / kf_lo are f16 planes [B][roundup(N,32)][C] with hi + lo ~= K (rows >= N
  *      are ignored), exactly what the update kernels hand to the decode inside a stage.  Launches the MFMA kernel only

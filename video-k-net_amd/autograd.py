@@ -50,6 +50,13 @@ def _pad_last(t, n):
     return out
 
 
+def _decode_unscaled(x, kernels, inv):
+    """decode(x, kernels) * inv with the multiplication inside the decode kernel where it applies (MFMA kernel: even H*W), else behind it."""
+    if (x.shape[-1] * x.shape[-2]) % 2 == 0:
+        return ops.mask_decode(x, kernels, out_scale=inv)
+    return ops.mask_decode(x, kernels).mul_(inv)
+
+
 class MaskGatherFn(torch.autograd.Function):
     """(xraw, cnt) = gather(x, bit(mask_logits)); backward: dx = bit^T dxraw."""
 
@@ -80,8 +87,8 @@ class MaskGatherFn(torch.autograd.Function):
         rows[:, :N] = bits
         if Np != N:
             rows[:, N:].zero_()
-        dx = ops.mask_decode(rows, kt)                                  # [B, C, H, W]
-        return dx.mul_(1.0 / s), None, None
+        # [B, C, H, W]; the 1 / s is applied inside the kernel (no second pass over dx)
+        return _decode_unscaled(rows, kt, 1.0 / s), None, None
 
 
 class SoftMaskGatherFn(torch.autograd.Function):
@@ -112,9 +119,9 @@ class SoftMaskGatherFn(torch.autograd.Function):
             Np = (N + 31) // 32 * 32
             rows = torch.zeros((B, Np, H, W), dtype=torch.float32, device=z.device)
             rows[:, :N] = sg * on
-            dx = ops.mask_decode(rows, _pad_last(dxs.transpose(1, 2), Np)).mul_(inv)       # [B, C, H, W]
+            dx = _decode_unscaled(rows, _pad_last(dxs.transpose(1, 2), Np), inv)           # [B, C, H, W]
         if ctx.needs_input_grad[1]:
-            dz = ops.mask_decode(x, dxs).mul_(inv) * (sg * (1.0 - sg)) * on                # [B, N, H, W]
+            dz = _decode_unscaled(x, dxs, inv) * (sg * (1.0 - sg)) * on                    # [B, N, H, W]
         return dx, dz, None
 
 
@@ -141,7 +148,7 @@ class MaskDecodeFn(torch.autograd.Function):
             # dx[b, c, p] = sum_n K[b, n, c] dz[b, n, p]: the decode kernel with the (scaled, row-padded) dz as its feature map and
             # K^T as its kernels; the padded rows are zero, so the gather below may run over them too
             dzs = _scaled_rows(dz, s)
-            dx = ops.mask_decode(dzs, _pad_last(kernels.reshape(kernels.shape[0], N, -1).transpose(1, 2), dzs.shape[1])).mul_(inv)
+            dx = _decode_unscaled(dzs, _pad_last(kernels.reshape(kernels.shape[0], N, -1).transpose(1, 2), dzs.shape[1]), inv)
             if need_k:
                 dk, dkb = ops.mask_gather_real(x, dzs)
                 dk, dkb = dk[:, :N].mul(inv), dkb[:, :N].mul(inv)

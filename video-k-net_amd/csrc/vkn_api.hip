@@ -771,6 +771,21 @@ int vkn_mask_decode_f32(const float* x, const float* kernels, const float* bias,
     return vkn_launch_decode(x, kfh, kfl, bias, out, B, N, C, P, st, xdt_of(flags));
 }
 
+int vkn_mask_decode_scaled_f32(const float* x, const float* kernels, const float* bias, const float* out_scale, float* out, int B,
+                               int N, int C, int P, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    if (!x || !kernels || !out || !out_scale || B <= 0 || N <= 0 || C <= 0 || P <= 0) return VKN_E_ARG;
+    if (!aligned16(x) || !aligned16(kernels) || !aligned16(out)) return VKN_E_ALIGN;
+    if (C % 32 != 0 || C > 256 || N > 256) return VKN_E_SHAPE;
+    if ((flags & VKN_FLAG_REF_KERNELS) || (P & 1)) return VKN_E_SHAPE;
+    if (!ws || ws_bytes < vkn_decode_workspace_bytes(B, N, C)) return VKN_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver c{static_cast<char*>(ws), 0};
+    _Float16* kfh = c.take<_Float16>((size_t)B * npt_of(N) * C);
+    _Float16* kfl = c.take<_Float16>((size_t)B * npt_of(N) * C);
+    VKN_TRY(vkn_launch_split_planes(kernels, kfh, kfl, B, N, C, st));
+    return vkn_launch_decode_ex(x, kfh, kfl, bias, out, B, N, C, P, 0, N, st, xdt_of(flags), out_scale);
+}
+
 int vkn_split_planes_f32(const float* kernels, void* kf_hi, void* kf_lo, int B, int N, int C, void* stream) {
     if (!kernels || !kf_hi || !kf_lo || B <= 0 || N <= 0 || C <= 0) return VKN_E_ARG;
     if (!aligned16(kf_hi) || !aligned16(kf_lo)) return VKN_E_ALIGN;

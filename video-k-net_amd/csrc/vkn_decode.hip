@@ -73,11 +73,16 @@ __device__ __forceinline__ void dec_emit_bits(const f32x16 (&acc)[2][NB], float 
 // exact for 2^-14 <= |x| < 65504): x IS its own high half, the low half is zero — a lane loads its pixel pair as ONE dword, and the
 // two MFMAs against x_lo disappear.  The remaining sequence (K_hi x, K_lo x per pixel) is the fp32 kernel's with the zero terms
 // removed, so on x' = float(half(x)) both kernels return the same bits.
-template <int NB, int ABL, int RING, int BITS, int OPT, int XH = 0>
+// OSC = 1 (the backward passes of the training step: gradients are scaled by a power of two into the f16 range and back): every output is
+// multiplied by the device scalar *oscale before it is stored — instead of a second pass over the result.  The inference
+// instantiations (OSC = 0) are the kernels they were.
+template <int NB, int ABL, int RING, int BITS, int OPT, int XH = 0, int OSC = 0>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     const float* __restrict__ x, const _Float16* __restrict__ kfh, const _Float16* __restrict__ kfl,
     const float* __restrict__ kb, float* __restrict__ out, int N, int NPT, int n0, int C, int P, int px_per_wg,
-    int xcd_remap, VknDecodeStrides fs, unsigned* __restrict__ bits_out, float thr) {
+    int xcd_remap, VknDecodeStrides fs, unsigned* __restrict__ bits_out, float thr, const float* __restrict__ oscale) {
+    const float osc_ = OSC ? *oscale : 1.f;
+#define DEC_V(v) (OSC ? (v) * osc_ : (v))
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LDK = C + 8;  // halfs per LDS row; (C+8)*2 B = odd multiple of 16 B -> b128 reads conflict-free
     _Float16* ldsH = reinterpret_cast<_Float16*>(smem);
@@ -251,8 +256,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
                             const int vw_ = ((4 * g + q_) * P + 2 * (li - q_)) << 2;                              \
                             _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                   \
                                 const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2); /* even lanes: row_, odd: row_ + 1 */ \
-                                const float e0_ = acc[0][nb][r], e1_ = acc[1][nb][r];         /* row_     : this lane's px pair */ \
-                                const float o0_ = acc[0][nb][r + 1], o1_ = acc[1][nb][r + 1]; /* row_ + 1 */      \
+                                const float e0_ = DEC_V(acc[0][nb][r]), e1_ = DEC_V(acc[1][nb][r]); /* row_: this lane's px pair */ \
+                                const float o0_ = DEC_V(acc[0][nb][r + 1]), o1_ = DEC_V(acc[1][nb][r + 1]); /* row_ + 1 */ \
                                 /* send what the partner stores: the even lane its row_+1 pair, the odd lane its row_ pair */ \
                                 const int s0_ = __float_as_int(q_ ? e0_ : o0_), s1_ = __float_as_int(q_ ? e1_ : o1_); \
                                 const int t0_ = __builtin_amdgcn_mov_dpp(s0_, 0xB1, 0xF, 0xF, true); /* quad_perm [1,0,3,2] */ \
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
                                  /* (ragged last n-block) are dropped by the buffer's range check — no exec branches in the loop */ \
                             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
                                 const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                           \
-                                const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
+                                const float a0_ = DEC_V(acc[0][nb][r]), a1_ = DEC_V(acc[1][nb][r]);               \
                                 const u32x2 v_ = {__float_as_uint(a0_), __float_as_uint(a1_)};                    \
                                 if (VKN_ABL_IS(ABL, 5))                                                              \
                                     __builtin_amdgcn_raw_buffer_store_b64(v_, ors, vst_, (row_ * Pq_ + p0_) << 2, 2); \
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
                             const int row_ = n0 + nb * 32 + (r & 3) + 8 * (r >> 2);                               \
                             const int so_ = (row_ * Pq_ + p0_) << 2;                                                \
                             if (row_ + 4 * g < N) {                                                               \
-                                const float a0_ = acc[0][nb][r], a1_ = acc[1][nb][r];                             \
+                                const float a0_ = DEC_V(acc[0][nb][r]), a1_ = DEC_V(acc[1][nb][r]);               \
                                 if (px_ < p_end)                                                                  \
                                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a0_), ors, vst_, so_, 0); \
                                 if (px_ + 1 < p_end)                                                              \
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     }
 #undef DEC_LOAD
 #undef DEC_COMPUTE
+#undef DEC_V
 }
 
 // NOTE (negative result, round 1): a software-pipelined variant that parked a finished strip's accumulators in a second
@@ -383,12 +389,13 @@ int vkn_launch_decode(const float* x, const _Float16* kfh, const _Float16* kfl, 
 // shared != 0: ONE set of kernels / bias for every frame (planes [NPT][C], kb [N]); out_rows: rows per frame of the output
 // tensor the N decoded rows are written into (>= N: the caller points `out` at the first of its rows).
 static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
-                         int C, int P, int shared, int out_rows, unsigned* bits_out, float thr, hipStream_t stream, int xdt);
+                         int C, int P, int shared, int out_rows, unsigned* bits_out, float thr, hipStream_t stream, int xdt,
+                         const float* oscale = nullptr);
 
 // xdt: storage type of x (VKN_X_F32 / VKN_X_F16 / VKN_X_BF16); for the half types `x` points at 2-byte elements
 int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B,
-                         int N, int C, int P, int shared, int out_rows, hipStream_t stream, int xdt) {
-    return decode_launch(x, kfh, kfl, kb, out, B, N, C, P, shared, out_rows, nullptr, 0.f, stream, xdt);
+                         int N, int C, int P, int shared, int out_rows, hipStream_t stream, int xdt, const float* oscale) {
+    return decode_launch(x, kfh, kfl, kb, out, B, N, C, P, shared, out_rows, nullptr, 0.f, stream, xdt, oscale);
 }
 
 // bit-packed variant: words [B][P/64][2][roundup(N,32)] (even / odd pixels of each 64-px tile) of bit(logit >= thr)
@@ -400,7 +407,9 @@ int vkn_launch_decode_bits(const float* x, const _Float16* kfh, const _Float16* 
 }
 
 static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
-                         int C, int P, int shared, int out_rows, unsigned* bits_out, float thr, hipStream_t stream, int xdt) {
+                         int C, int P, int shared, int out_rows, unsigned* bits_out, float thr, hipStream_t stream, int xdt,
+                         const float* oscale) {
+    if (oscale && bits_out) return VKN_E_ARG;
     if (B <= 0 || N <= 0 || P <= 0 || out_rows < N) return VKN_E_ARG;
     if (xdt < 0 || xdt > 2) return VKN_E_ARG;
     if (C % 16 != 0 || C > 512 || P < 2 || (P & 1)) return VKN_E_SHAPE;  // odd P: rows not 8-byte aligned (use the ref kernel)
@@ -454,7 +463,7 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
     do {                                                                                                       \
         VKN_ALLOW_FULL_LDS((k_decode_mfma<NBV, ABLV, RINGV, BITSV, OPTV, XHV>));                               \
         hipLaunchKernelGGL((k_decode_mfma<NBV, ABLV, RINGV, BITSV, OPTV, XHV>), grid, block, lds, stream, x, kfh, kfl, kb, out, \
-                           N, NPT, n0, C, P, px_per_wg, xcd, fs, bits_out, thr);                               \
+                           N, NPT, n0, C, P, px_per_wg, xcd, fs, bits_out, thr, (const float*)nullptr);        \
     } while (0)
 #ifdef VKN_DEBUG
 #define DEC_LAUNCH_XP() DEC_LAUNCH_X(4, 0, 3, 0, (DEC_OPT_DEFAULT | 8), 2)
@@ -515,6 +524,30 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
         else DEC_LAUNCH(NBV, 0, 3, 0);          \
         break;
 #endif
+        if (oscale) {   // outputs times a device scalar (training backward passes): the shipped variant of each storage type
+#define DEC_LAUNCH_SC(NBV, XHV)                                                                                        \
+    do {                                                                                                               \
+        VKN_ALLOW_FULL_LDS((k_decode_mfma<NBV, 0, 3, 0, DEC_OPT_DEFAULT, XHV, 1>));                                    \
+        hipLaunchKernelGGL((k_decode_mfma<NBV, 0, 3, 0, DEC_OPT_DEFAULT, XHV, 1>), grid, block, lds, stream, x, kfh, kfl, kb, out, \
+                           N, NPT, n0, C, P, px_per_wg, xcd, fs, bits_out, thr, oscale);                               \
+    } while (0)
+#define DEC_CASE_SC(NBV)                          \
+    case NBV:                                     \
+        if (xdt == 0) DEC_LAUNCH_SC(NBV, 0);      \
+        else if (xdt == 1) DEC_LAUNCH_SC(NBV, 1); \
+        else DEC_LAUNCH_SC(NBV, 2);               \
+        break;
+            switch (nb) {
+                DEC_CASE_SC(1)
+                DEC_CASE_SC(2)
+                DEC_CASE_SC(3)
+                DEC_CASE_SC(4)
+                default:
+                    return VKN_E_SHAPE;
+            }
+#undef DEC_CASE_SC
+#undef DEC_LAUNCH_SC
+        } else
         switch (nb) {
             DEC_CASE(1)
             DEC_CASE(2)

@@ -77,7 +77,7 @@ struct VknDecodeStrides {
 // xdt (last argument of the x-streaming launchers): storage type of x — 0 fp32, 1 fp16, 2 bf16 (VKN_X_* in include/vkn.h); for the
 // half types `x` points at 2-byte elements
 int vkn_launch_decode_ex(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, float* out, int B, int N,
-                         int C, int P, int shared, int out_rows, hipStream_t stream, int xdt = 0);
+                         int C, int P, int shared, int out_rows, hipStream_t stream, int xdt = 0, const float* oscale = nullptr);
 int vkn_launch_decode_ref_ex(const float* x, const float* kern, const float* kb, float* out, int B, int N, int C, int P,
                              int shared, int out_rows, hipStream_t stream);
 int vkn_launch_decode_bits(const float* x, const _Float16* kfh, const _Float16* kfl, const float* kb, unsigned* bits_out,

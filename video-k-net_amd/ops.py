@@ -168,9 +168,10 @@ def mask_gather_real(x, a):
     return out, asum
 
 
-def mask_decode(x, kernels, bias=None, flags=0):
+def mask_decode(x, kernels, bias=None, flags=0, out_scale=None):
     """out[b,n,h,w] = sum_c kernels[b,n,c] x[b,c,h,w] (+ bias[b,n]).
-    Replaces the per-image `F.conv2d(x[i:i+1], mask_feat[i])`, K=1 (knet/det/kernel_update_head.py:247-260)."""
+    Replaces the per-image `F.conv2d(x[i:i+1], mask_feat[i])`, K=1 (knet/det/kernel_update_head.py:247-260).
+    `out_scale` (a DEVICE scalar tensor): every output times it, inside the kernel (the backward passes' power-of-two unscaling)."""
     (x, xdt), k = _req_x(x), _req(kernels.reshape(kernels.shape[0], kernels.shape[1], -1), 'kernels')
     flags |= (0, FLAG_X_F16, FLAG_X_BF16)[xdt]
     B, C, H, W = x.shape
@@ -183,8 +184,13 @@ def mask_decode(x, kernels, bias=None, flags=0):
     nb = L.vkn_decode_workspace_bytes(B, N, C)
     ws = _workspace(nb, x.device)
     with torch.cuda.device(x.device):
-        check(L.vkn_mask_decode_f32(_ptr(x), _ptr(k), _ptr(bias), _ptr(out), B, N, C, H * W, _ptr(ws), ws.numel(), flags,
-                                    _stream()))
+        if out_scale is not None:
+            sc = _req(out_scale.reshape(1), 'out_scale')
+            check(L.vkn_mask_decode_scaled_f32(_ptr(x), _ptr(k), _ptr(bias), _ptr(sc), _ptr(out), B, N, C, H * W, _ptr(ws), ws.numel(),
+                                               flags, _stream()))
+        else:
+            check(L.vkn_mask_decode_f32(_ptr(x), _ptr(k), _ptr(bias), _ptr(out), B, N, C, H * W, _ptr(ws), ws.numel(), flags,
+                                        _stream()))
     return out
 
 
