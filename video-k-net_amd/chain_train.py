@@ -244,8 +244,8 @@ class DwQueue:
             if wt and pb is not None:
                 raise NotImplementedError('bias of an untransposed-weight layer')
         for i, n in cover.items():
-            if n < bufs[i].numel():                  # a parameter only partly written by the queued layers: the rest is zero
-                raise NotImplementedError('partially used packed parameter')
+            if n < bufs[i].numel():                  # a packed parameter only partly used by the queued layers: the rest of its
+                bufs[i].zero_()                      # gradient is zero (enqueued before the launch below, same stream)
         L = _lib.lib()
         for M, its in by_m.items():
             for j in range(0, len(its), _lib.DW_MAX_ITEMS):
