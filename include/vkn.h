@@ -144,7 +144,12 @@ typedef struct VknStageWeights {
 int vkn_version(void);
 const char* vkn_strerror(int code);
 /* zero the 256-byte header of a workspace (asynchronous on `stream`) / synchronise `stream`, read AND CLEAR the status word:
- * VKN_OK, or VKN_E_RANGE when VKN_STATUS_RANGE was set since the last clear */
+ * VKN_OK, or VKN_E_RANGE when VKN_STATUS_RANGE was set since the last clear.
+ * The header exists in the workspaces of the STAGE-SHAPED entry points only (vkn_stage_*, vkn_head_*, vkn_link_block_f32,
+ * vkn_track_link_f32, vkn_kernel_updator_f32, vkn_query_merge_f32: they reserve the first 256 bytes and only ever OR into the first
+ * word).  Every other entry point with a `ws` argument (gather / decode / kernel-init / panoptic / merge / assignment / linear) uses its
+ * workspace from offset 0: a caller that shares ONE buffer between the two kinds hands those `ws + 256` (what the Python binding
+ * does), or the status word reads their scratch data. */
 int vkn_workspace_init(void* ws, size_t ws_bytes, void* stream);
 int vkn_workspace_status(void* ws, size_t ws_bytes, void* stream);
 /* sizeof(VknDims) / sizeof(VknStageWeights) as compiled — lets a foreign-language binding verify its struct mirror */

@@ -1338,3 +1338,31 @@ def test_masks_at_another_resolution_are_resized_like_the_reference(vkn):
     assert maxabs(obj, r_obj) < 1e-4 and maxabs(cls, r_cls) < 1e-5 and maxabs(masks, r_masks) < TOL_LOGIT
     assert tuple(m1.shape[-2:]) == (2 * case['H'], 2 * case['W'])
     assert maxabs(m1, F.interpolate(r['mask_preds'], scale_factor=2, mode='bilinear', align_corners=False)) < 1e-5
+
+
+def test_status_word_survives_the_ops_that_share_the_workspace(vkn):
+    """The stage-shaped entry points keep a status word in the first 256 bytes of their workspace; gather / decode / kernel-init /
+    assignment calls use THEIR workspace from offset 0.  The binding shares one buffer per stream between both kinds — it has to hand
+    the second kind the part behind the header (found by the soak in round 4: `check_status` raised after a kernel-init pass)."""
+    _, case = load_golden('det_tiny')
+    head, (x, pf, mp, _) = _build_head(vkn, case)
+    xd, pfd, mpd = _cuda(x, pf, mp)
+    B, N, C, H, W = case['B'], case['N'], case['C'], case['H'], case['W']
+    with torch.no_grad():
+        head.simple_test_mask_preds(xd, pfd, mpd, None, [dict()] * B)
+        head.check_status()
+        for _ in range(3):      # scratch-heavy ops between two head calls, on the same stream
+            vkn.ops.kernel_init(xd, xd * 0.5, torch.randn(N, C, 1, 1, device=DEV), torch.randn(5, C, 1, 1, device=DEV), torch.randn(5, device=DEV))
+            vkn.ops.mask_decode(xd, torch.randn(B, N, C, device=DEV))
+            vkn.ops.mask_gather(xd, mpd, 0.5)
+            vkn.ops.mask_gather_real(xd, torch.rand(B, N, H, W, device=DEV))
+            vkn.ops.linear(torch.randn(64, 256, device=DEV), torch.randn(32, 256, device=DEV), ksplit=4)
+        head.check_status()                                  # must not see their scratch data
+        head.simple_test_mask_preds(xd, pfd, mpd, None, [dict()] * B)
+        head.check_status()
+        bad = xd.clone()
+        bad[0, 0, 0, 0] = float('inf')
+        head.simple_test_mask_preds(bad, pfd, mpd, None, [dict()] * B)
+        with pytest.raises(vkn._lib.VknError):
+            head.check_status()                              # ... and still reports a real one
+        head.check_status()                                  # read-and-clear

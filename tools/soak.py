@@ -22,10 +22,17 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 rng = np.random.default_rng(12345)
 
 
+LAST = {}   # the case a section is working on (printed when it dies)
+
+
 def section(name, fn):
     t0, n = time.time(), 0
     while time.time() - t0 < budget:
-        fn()
+        try:
+            fn()
+        except BaseException:
+            print(f'{name}: FAILED in trial {n}, case {LAST.get("tag")}', flush=True)
+            raise
         n += 1
     print(f'{name:28s} {n:5d} random trials OK')
 
@@ -200,6 +207,7 @@ def t_chain_persistent():
     packs = [h.stage_pack(torch.device(dev)) for h in head.mask_head]
     kw = dict(clip_first_prev=first) if video else {}
     tag = ('chain', video, B, N, H, W, ff, ncls, S)
+    LAST['tag'] = tag
     p = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=vkn.ops.FLAG_CHAIN_PERSISTENT, **kw)
     p2 = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=vkn.ops.FLAG_CHAIN_PERSISTENT, **kw)
     assert all(a is None or torch.equal(a, b) for a, b in zip(p, p2)), ('not deterministic',) + tag

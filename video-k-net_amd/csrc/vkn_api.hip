@@ -1054,7 +1054,8 @@ int vkn_workspace_status(void* ws, size_t ws_bytes, void* stream) {
     if (hipStreamSynchronize(st) != hipSuccess) return VKN_E_LAUNCH;
     if (word == 0) return VKN_OK;
     if (hipMemsetAsync(ws, 0, sizeof(int), st) != hipSuccess) return VKN_E_LAUNCH;   // read-and-clear
-    return (word & VKN_STATUS_RANGE) ? VKN_E_RANGE : VKN_E_LAUNCH;
+    // any other bit: the header holds foreign data (an entry point without a header was given this buffer from offset 0: include/vkn.h)
+    return (word & VKN_STATUS_RANGE) ? VKN_E_RANGE : VKN_E_WORKSPACE;
 }
 
 size_t vkn_stage_workspace_bytes(const VknDims* d) {

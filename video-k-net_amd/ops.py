@@ -59,19 +59,24 @@ def _req_x(t, name='x'):
     return t, _X_DTYPES[t.dtype]
 
 
-def _workspace(nbytes, device):
+def _workspace(nbytes, device, scratch=False):
     """Grow-only per-(thread, device, stream) scratch buffer handed to the C ABI (the library never allocates).  Keyed by the
-    current stream so that calls enqueued on different streams never share scratch memory."""
+    current stream so that calls enqueued on different streams never share scratch memory.
+    The first 256 bytes are the HEADER of the stage / head / chain entry points (their status word, include/vkn.h: they carve it
+    first and only ever OR into it).  Every other entry point uses its workspace from offset 0 — `scratch=True` hands those the
+    buffer BEHIND the header, so that a gather / decode / kernel-init / assignment call between two head calls cannot leave its
+    scratch data where `workspace_status` reads the status word (found by the soak: a spurious error after the kernel-init pass)."""
     cache = getattr(_tls, 'ws', None)
     if cache is None:
         cache = _tls.ws = {}
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    need = int(nbytes) + 256
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 512), dtype=torch.uint8, device=device)
         buf[:256].zero_()          # the workspace header: its first word is the status word the kernels OR into (include/vkn.h)
         cache[key] = buf
-    return buf
+    return buf[256:] if scratch else buf
 
 
 def workspace_status(device=None):
@@ -143,7 +148,7 @@ def mask_gather(x, mask_logits, hard_mask_thr=0.5, flags=0):
     xraw = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
     cnt = torch.empty((B, N), dtype=torch.float32, device=x.device)
     nb = L.vkn_gather_workspace_bytes(B, N, C, P)
-    ws = _workspace(nb, x.device)
+    ws = _workspace(nb, x.device, scratch=True)
     with torch.cuda.device(x.device):
         check(L.vkn_mask_gather_f32(_ptr(x), _ptr(m), thr_logit(hard_mask_thr), _ptr(xraw), _ptr(cnt), B, N, C, P, _ptr(ws),
                                     ws.numel(), flags, _stream()))
@@ -162,7 +167,7 @@ def mask_gather_real(x, a):
     L = _lib.lib()
     out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
     asum = torch.empty((B, N), dtype=torch.float32, device=x.device)
-    ws = _workspace(L.vkn_gather_workspace_bytes(B, N, C, P), x.device)
+    ws = _workspace(L.vkn_gather_workspace_bytes(B, N, C, P), x.device, scratch=True)
     with torch.cuda.device(x.device):
         check(L.vkn_mask_gather_real_f32(_ptr(x), _ptr(a), _ptr(out), _ptr(asum), B, N, C, P, _ptr(ws), ws.numel(), _stream()))
     return out, asum
@@ -182,7 +187,7 @@ def mask_decode(x, kernels, bias=None, flags=0, out_scale=None):
     L = _lib.lib()
     out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
     nb = L.vkn_decode_workspace_bytes(B, N, C)
-    ws = _workspace(nb, x.device)
+    ws = _workspace(nb, x.device, scratch=True)
     with torch.cuda.device(x.device):
         if out_scale is not None:
             sc = _req(out_scale.reshape(1), 'out_scale')
@@ -539,7 +544,7 @@ def decode_gather(x, hi, lo, N, bias=None, hard_mask_thr=0.5):
     L = _lib.lib()
     xraw = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
     cnt = torch.empty((B, N), dtype=torch.float32, device=x.device)
-    ws = _workspace(L.vkn_gather_workspace_bytes(B, N, C, P), x.device)
+    ws = _workspace(L.vkn_gather_workspace_bytes(B, N, C, P), x.device, scratch=True)
     with torch.cuda.device(x.device):
         check(L.vkn_decode_gather_x(_ptr(x), xdt, _ptr(hi), _ptr(lo), _ptr(bias), thr_logit(hard_mask_thr), _ptr(xraw), _ptr(cnt),
                                     B, N, C, P, _ptr(ws), ws.numel(), _stream()))
@@ -577,7 +582,7 @@ def linear(A, W, bias=None, w_split=None, act=0, ksplit=1):
     M, K = A.shape
     Nout = W.shape[0]
     out = torch.empty((M, Nout), dtype=torch.float32, device=A.device)
-    ws = _workspace(max(ksplit * M * Nout * 4, 256), A.device)
+    ws = _workspace(max(ksplit * M * Nout * 4, 256), A.device, scratch=True)
     with torch.cuda.device(A.device):
         check(_lib.lib().vkn_linear_f32(_ptr(A), _ptr(W), _ptr(w_split), _ptr(bias), _ptr(out), M, K, Nout, int(act), int(ksplit),
                                         _ptr(ws), ws.numel(), _stream()))
@@ -617,7 +622,7 @@ def kernel_init(loc_feats, semantic_feats, init_w, seg_w=None, seg_b=None, num_t
     seg = torch.empty((B, ncls, H, W), dtype=torch.float32, device=dev) if (sem is not None and want_seg_preds) else None
     prop = torch.empty((B, N, C), dtype=torch.float32, device=dev)
     nb = L.vkn_kernel_init_workspace_bytes(B, Np, ncls, C, P)
-    ws = _workspace(max(nb, 256), dev)
+    ws = _workspace(max(nb, 256), dev, scratch=True)
     with torch.cuda.device(dev):
         check(L.vkn_kernel_init_f32(_ptr(loc), _ptr(sem), _ptr(iw), _ptr(sw), _ptr(sb), int(num_thing_classes),
                                     int(bool(cat_stuff_mask)), (1 if use_binary else 2) if proposal_feats_with_obj else 0,
@@ -650,7 +655,7 @@ def panoptic_joint(cls_prob, mask_logits, num_proposals, num_thing_classes, max_
     nseg = torch.empty((B,), dtype=torch.int32, device=dev)
     bbox = torch.empty((B, K, 4), dtype=torch.int32, device=dev) if want_bbox else None
     nb = L.vkn_panoptic_workspace_bytes(ctypes.byref(cfg), B, N)
-    ws = _workspace(max(nb, 256), dev)
+    ws = _workspace(max(nb, 256), dev, scratch=True)
     with torch.cuda.device(dev):
         check(L.vkn_panoptic_joint_f32(ctypes.byref(cfg), _ptr(cls), _ptr(m), B, N, ncls, seg.data_ptr(), info.data_ptr(),
                                        nseg.data_ptr(), bbox.data_ptr() if want_bbox else None, _ptr(ws), ws.numel(), _stream()))
@@ -676,7 +681,7 @@ def panoptic_thing_first(thing_masks, thing_scores, thing_labels, thing_order, s
     seg = torch.empty((H, W), dtype=torch.int32, device=dev)
     info = torch.zeros((Kt + Ks, 5), dtype=torch.int32, device=dev)
     nseg = torch.zeros((1,), dtype=torch.int32, device=dev)
-    ws = _workspace(max(L.vkn_merge_workspace_bytes(Kt, Ks), 256), dev)
+    ws = _workspace(max(L.vkn_merge_workspace_bytes(Kt, Ks), 256), dev, scratch=True)
     with torch.cuda.device(dev):
         check(L.vkn_panoptic_thing_first_u8(_ptr(tm), _ptr(ts), tl.data_ptr(), to.data_ptr(), Kt, _ptr(sm), sl.data_ptr(), so.data_ptr(),
                                             Ks, HW, float(instance_score_thr), float(iou_thr), int(stuff_max_area), seg.data_ptr(),
@@ -711,7 +716,7 @@ def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, d
     L = _lib.lib()
     cost = torch.empty((N, G), dtype=torch.float32, device=m.device)
     nb = L.vkn_assign_workspace_bytes(N, G, P)
-    ws = _workspace(max(nb, 256), m.device)
+    ws = _workspace(max(nb, 256), m.device, scratch=True)
     with torch.cuda.device(m.device):
         check(L.vkn_assign_costs_f32(ctypes.byref(cfg), _ptr(m), _ptr(cls), _ptr(g), lab.data_ptr(), N, G, ncls, P, _ptr(cost),
                                      _ptr(ws), ws.numel(), _stream()))
@@ -752,7 +757,7 @@ def assign_costs_batch(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=
     cfg = _lib.VknAssignCfg(float(cls_weight if use_cls else 0.0), float(dice_weight), float(mask_weight), float(focal_alpha),
                             float(focal_gamma), float(focal_eps), float(dice_eps), float(dice_pred_min), float(mask_pred_min))
     L = _lib.lib()
-    ws = _workspace(max(L.vkn_assign_workspace_bytes(N, max(Gs), P), 256), dev)
+    ws = _workspace(max(L.vkn_assign_workspace_bytes(N, max(Gs), P), 256), dev, scratch=True)
     with torch.cuda.device(dev):
         check(L.vkn_assign_costs_batch_f32(ctypes.byref(cfg), probs, n, N, ncls, P, _ptr(ws), ws.numel(), _stream()))
     return out
