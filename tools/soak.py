@@ -19,7 +19,7 @@ from oracle import synth  # noqa: E402
 vkn = vkn_import.load()
 dev = 'cuda:0'
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(os.environ.get('VKN_SOAK_SEED', '12345')))   # (tools only: another seed = other shapes)
 
 
 LAST = {}   # the case a section is working on (printed when it dies)
