@@ -427,3 +427,20 @@ def test_training_chain_enumerates_every_linear_parameter_of_a_stage(vkn, kind):
     expected = {id(p) for p in stage.parameters()} - norm_params
     names = {id(p): n for n, p in stage.named_parameters()}
     assert owners == expected, sorted(names[i] for i in owners ^ expected)
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/vkn.h is the drop-in boundary: a C99 translation unit that only includes it (and names the structs the bindings mirror)
+    must compile — no C++-isms, no torch / HIP types in the signatures."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc in this environment')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "include/vkn.h"\n'
+                   'int main(void) { VknDims d; VknStageWeights w; VknSplitItem a; VknDwItem b; VknUpdatorNorms c; VknUpdatorNormGrads g;\n'
+                   '  (void)d; (void)w; (void)a; (void)b; (void)c; (void)g; return vkn_version() == 0; }\n')
+    r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-Werror', '-fsyntax-only', '-I', root, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
