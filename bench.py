@@ -11,6 +11,11 @@ resident in HBM before the timed region.  Frames of a clip are sharded over the 
 `--frames` per GPU); the only cross-rank data is the [N x C] kernel set of a block's last frame, which the next rank's first
 frame needs for its tracking embedding (RCCL all_gather, 120 KB per rank, inside the timed region).
 
+`--clip T` = STRONG scaling, the shape BASELINE cfg3 words (one clip of T = 8 frames over 8 GPUs, one frame per GPU, as the reference
+trains — samples_per_gpu = 1 — and infers, one frame per call): the SAME T-frame clip in contiguous blocks of T / N frames per rank,
+`"scaling": "strong"`, value = T frames x steps / time.  At N = 1 the `breakdown` additionally carries the measured step time at
+T/2, T/4, ... 1 frames per call (per-rank compute on ONE GPU, labelled as such — not a scaling result).
+
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (mask-decode kernel, HIP-event timed, algorithmic bytes / time
 vs 8 TB/s HBM), "cpu_baseline" (the torch CPU oracle timed on this host, rank 0 / N=1 only), "breakdown" (incl. the whole step at
 1 / 8 / 32 frames per call: the reference walks a video one frame per call).
@@ -267,6 +272,10 @@ def main():
     ap.add_argument('--settle', type=int, default=300, help='untimed settle steps before the warm-up (profiling runs use few)')
     ap.add_argument('--frames', type=int, default=32,
                     help='frames of the clip per GPU per step (throughput at 8 / 16 / 32 / 64: 5.3k / 6.7k / 7.7k / 8.4k frames/s)')
+    ap.add_argument('--clip', type=int, default=0,
+                    help='STRONG scaling (BASELINE cfg3 shape): ONE clip of this many frames split into contiguous blocks of clip / N frames '
+                         'per rank (clip 8 on 8 GPUs = one frame per GPU, as the reference trains and infers); overrides --frames.  '
+                         'Default 0 = weak scaling at --frames per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the extra data points of `breakdown` that launch other batch sizes / several clips (profiling runs)')
@@ -295,6 +304,10 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+    if args.clip:
+        if args.clip % world != 0:
+            raise SystemExit(f'--clip {args.clip} does not split into equal contiguous blocks over {world} ranks')
+        args.frames = args.clip // world          # strong scaling: the clip is fixed, the per-rank block shrinks with N
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist_on = world > 1 or args.force_dist
@@ -541,7 +554,10 @@ def main():
             # the whole step (S stages + link + x4 upsample, one C call) at 1 / 8 frames per call — the reference walks a video one
             # frame per call; `value` above is at `--frames` per call
             per_call = {}
-            for b_ in (1, 8):
+            # --clip T at N = 1: the step at T/2, T/4, ... 1 frames per call = what ONE rank of a 2 / 4 / ... / T-GPU run of the same clip
+            # computes per step (per-rank compute measured on ONE GPU — NOT a scaling result: no hand-over, no other rank)
+            sizes = sorted({max(1, args.clip >> k) for k in range(1, 8)} | {1}) if args.clip else (1, 8)
+            for b_ in sizes:
                 if b_ >= B or args.head != 'ffn':     # (the previous_link head needs its link packs: only its headline step is timed)
                     continue
                 dims_b = last.make_dims(b_, N, CFG2['H'], CFG2['W'])
@@ -554,6 +570,8 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 per_call[f'frames_per_s_at_{b_}_frames_per_call'] = round(b_ / (e0.elapsed_time(e1) / 30 * 1e-3), 1)
+                if args.clip:
+                    per_call[f'per_rank_step_ms_at_{b_}_frames_ONE_gpu'] = round(e0.elapsed_time(e1) / 30, 4)
             per_call[f'frames_per_s_at_{B}_frames_per_call'] = round(frames / dt, 1)
             if world == 1 and NS == 1 and not args.no_extras:
                 # several independent clips in flight (step i on HIP stream i % 4, e.g. one video per stream): the latency-bound update
@@ -648,15 +666,16 @@ def main():
     if rank == 0:
         line = dict(metric='frames/sec (S=3, N=100, 1024x2048)', value=round(frames / dt, 2), unit='frames/s',
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
-                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                    config=dict(workload='cfg2 video_knet_s3_r50: VideoKernelIterHead S=3, N=100 proposals + 17 stuff = 117 '
+                    higher_is_better=True, scaling='strong' if args.clip else 'weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    config=dict(workload=('cfg3 shape: ONE clip of %d frames in contiguous blocks of %d per GPU; ' % (args.clip, B) if args.clip else '')
+                                         + 'cfg2 video_knet_s3_r50: VideoKernelIterHead S=3, N=100 proposals + 17 stuff = 117 '
                                          'kernels, C=256, 1024x2048 frame -> 128x256 stride-8 features, '
                                          + ('ffn tracking link, ' if args.head == 'ffn' else
                                             'previous_link=update_dynamic_cov + previous_type=update (NOT the BASELINE head: the last '
                                             'stage is frame-sequential, phases A/B/C per rank), ')
                                          + 'x4 bilinear upsample of the final logits' + (' [SKIPPED]' if args.no_upsample else ''),
-                                frames_per_gpu_per_step=B, streams_per_gpu=NS, parallelism=f'frame-sharded dp{world}',
-                                x_storage=args.x_storage,
+                                frames_per_gpu_per_step=B, clip_frames=(args.clip or None), streams_per_gpu=NS,
+                                parallelism=f'frame-sharded dp{world}', x_storage=args.x_storage,
                                 arithmetic=('fp32 storage;' if xeb == 4 else args.x_storage + ' storage of x, fp32 everything else;') + ' gather/decode on f16 hi+lo split MFMA, [N x C] GEMMs on bf16x3 split MFMA, '
                                            'fp32 accumulate everywhere (fp32-class accuracy, DESIGN.md §3); random-init weights'),
                     **extra)

@@ -76,6 +76,7 @@ extern "C" {
  * rounding (tests/test_gpu_parity.py::test_persistent_chain_equals_launch_per_gemm_chain), each is deterministic. */
 #define VKN_FLAG_CHAIN_LAUNCHES 256u   /* always one launch per GEMM */
 #define VKN_FLAG_CHAIN_PERSISTENT 512u /* always the persistent kernels (where the shape allows them) */
+#define VKN_FLAG_CHAIN_KSPLIT 8192u    /* always the few-row chain: one column-spread launch per GEMM phase, normalisation in the consumer (vkn_ksplit.hip) */
 #define VKN_FLAG_SERIAL_LINK 32u   /* vkn_head_forward_f32: run the tracking link on the caller's stream instead of the library's side
                                     * stream (A/B, or callers that must see ONE stream; same results) */
 #define VKN_FLAG_CLIP_LINK 8u      /* vkn_head_forward_f32: the B frames are CONSECUTIVE frames of one video: prev_obj is [1][N][C] (the

@@ -19,4 +19,6 @@ def vkn():
     mod = vkn_import.load()
     if not os.path.exists(mod._lib.LIBPATH) or os.environ.get('VKN_REBUILD') == '1':
         mod.build(force=True)          # hipcc cross-compiles gfx950 without a GPU (same recipe as __graft_entry__.build)
+    if os.environ.get('VKN_EXPECT_MM') == '1':      # tests/test_mm_registry_branch.py re-runs parts of the suite with mmcv / mmdet importable
+        assert mod.registry.HAVE_MM, 'VKN_EXPECT_MM=1 but mmcv / mmdet did not import: the plug-in branch of registry.py was not taken'
     return mod

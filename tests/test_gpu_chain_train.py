@@ -197,3 +197,53 @@ def test_device_chain_forward_and_backward_vs_fp64_chain(vkn, kind):
     for name, a, b in [(f'input {i}', a, b) for i, (a, b) in enumerate(zip(dg, tg))] + [(n, dp[n], tp[n]) for n in tp]:
         l2, med = _bulk(a, b)
         assert l2 < 5e-3, (name, l2, med)
+
+
+def test_dw_queue_never_drops_a_gradient(vkn):
+    """the deferred weight-gradient queue must not lose or overwrite anything —
+      * a weight used by TWO layers of one chain (tied / re-used module): the batch launch writes, the second use accumulates;
+      * a weight that reaches the layer as a NON-CONTIGUOUS view of its parameter (`_f32c` copies it: the queue cannot place the copy):
+        that layer computes its own dW in backward;
+      * a FROZEN weight with a trainable bias: the bias gradient is dy.sum(0), no NotImplementedError;
+      * a parameter only partly covered by queued layers: the rest of its gradient is zero."""
+    ct = vkn.chain_train
+    M, C = 96, 64
+    x = _rand((M, C), 31).requires_grad_(True)
+    w1 = _rand((C, C), 32, 0.1).requires_grad_(True)
+    b1 = _rand((C,), 33, 0.1).requires_grad_(True)
+    wbig = _rand((C, 2 * C), 34, 0.1).requires_grad_(True)        # used through the strided view wbig[:, ::2]
+    wf = _rand((C, C), 35, 0.1)                                    # frozen
+    bf = _rand((C,), 36, 0.1).requires_grad_(True)
+    packed = _rand((2 * C * C,), 37, 0.1).requires_grad_(True)     # one flat parameter, only its first half is a layer's weight
+    wp = packed[:C * C].view(C, C)
+    gy = _rand((M, C), 38, 1e-2)
+
+    def run(lin, entry):
+        xi = entry(x)
+        h = lin(xi, w1, b1)
+        h = lin(h, w1, b1)                       # tied
+        h = lin(h, wbig[:, ::2], None)           # non-contiguous view of a parameter
+        h = lin(h, wf, bf)                       # frozen weight, trainable bias
+        h = lin(h, wp, None)                     # half of a packed parameter
+        return h
+
+    queue = ct.DwQueue()
+    imgs = ct.WeightImages([w1, wbig[:, ::2], wf, wp], queue)
+    owners = [w1, b1, wbig, bf, packed]
+    y = run(lambda a, w, b: ct.linear(a, w, b, images=imgs), lambda t: ct.ChainEntryFn.apply(queue, 1, t, *owners)[0])
+    y.backward(gy)
+    got = [t.grad.clone() for t in (x, w1, b1, wbig, bf, packed)]
+    for t in (x, w1, b1, wbig, bf, packed):
+        t.grad = None
+    dd = [t.detach().double().requires_grad_(t.requires_grad) for t in (x, w1, b1, wbig, wf, bf, packed)]
+    xd, w1d, b1d, wbigd, wfd, bfd, packedd = dd
+    h = F.linear(F.linear(xd, w1d, b1d), w1d, b1d)
+    h = F.linear(h, wbigd[:, ::2])
+    h = F.linear(h, wfd, bfd)
+    yr = F.linear(h, packedd[:C * C].view(C, C))
+    yr.backward(gy.double())
+    assert _rel(y, yr) < 2e-5
+    for nm, g, r in zip(('x', 'w1 (tied)', 'b1 (tied)', 'wbig (strided view)', 'bf (frozen weight)', 'packed (half used)'), got,
+                        (xd.grad, w1d.grad, b1d.grad, wbigd.grad, bfd.grad, packedd.grad)):
+        assert g is not None and _rel(g, r) < 5e-5, nm
+    assert float(got[5][C * C:].abs().max()) == 0.0 and float(got[3][:, 1::2].abs().max()) == 0.0

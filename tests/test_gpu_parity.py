@@ -175,7 +175,7 @@ def test_stage_by_stage_vs_oracle_and_reference(vkn, name):
             assert maxabs(r['object_feats_track'], g['track']) < 1e-4
 
 
-@pytest.mark.parametrize('flags', [0, 1, 2, 3, 512, 513], ids=['mfma', 'refkernels', 'exactgemm', 'allexact', 'persistent', 'persistent_ref'])
+@pytest.mark.parametrize('flags', [0, 1, 2, 3, 512, 513, 256, 8192], ids=['mfma', 'refkernels', 'exactgemm', 'allexact', 'persistent', 'persistent_ref', 'launches', 'ksplit'])
 @pytest.mark.parametrize('name', ['det_tiny', 'det_odd', 'det_cfg', 'video_tiny', 'video_cfg'])
 def test_head_vs_reference_golden(vkn, name, flags):
     """The fused S-stage call (`simple_test_mask_preds[_plus_previous]`) against the REFERENCE's own outputs."""
@@ -233,9 +233,17 @@ def test_head_cfg1_size_vs_reference_golden(vkn):
 # flipped bits may double (at least two).  Each of the two VIP-Seg cases has ONE kernel whose hand-over mask sits on the threshold: it
 # flips in some realisations and not in others (worst seen: 1 row, 7 off-threshold bits, clean kernels 4.9e-5, clean logits 6.6e-4;
 # best: every row clean, 0 bits, 7.0e-6 / 5.9e-5).  YouTube-VIS: every row clean in every realisation.
+# Round 5: the limits are anchored on the REFERENCE ALGORITHM'S OWN re-ordering noise (tools/oracle_reorder_noise.py ->
+# profiles/r05_oracle_reorder_noise.json: the CPU oracle against the reference goldens with nothing changed but the fp32 summation
+# order — permuted input channels of the 1x1 conv, 1 / 16 intra-op threads).  video_vipseg_big: the oracle itself lands at 0.964 of the
+# rows within 2e-4 and 39 wrong off-threshold bits with ONE thread (1.000 / 0 with eight); video_vipseg_n216: 0.662 / 30 bits.  Round 4
+# had set "2 x what our two chain forms happened to measure" (14 bits), which the third form (few-row chain: 0.958 / 45 bits, worst
+# clean-row errors 5.8e-5 / 5.7e-4 — and the smallest error of all forms against fp64, tools/chain_accuracy.py) missed by chance, exactly
+# like the reference with another thread count would.  Limits = the worse of (our forms, the oracle's re-orderings) with ~2x head-room
+# on counts; the clean-row error limits stay at the parity tolerances.
 FREE_RUN_LIMITS = {
-    'video_vipseg_big': dict(clean_share_of_stable=0.985, share_rows_kernels_within_2e4=1 - 3 / 166, share_rows_sampled_logits_within_1e3=1 - 3 / 166,
-                             wrong_bits_off_threshold=14, worst_clean_kernel_err=1.0e-4, worst_clean_sampled_logit_err=1.0e-3),
+    'video_vipseg_big': dict(clean_share_of_stable=0.985, share_rows_kernels_within_2e4=0.93, share_rows_sampled_logits_within_1e3=0.93,
+                             wrong_bits_off_threshold=90, worst_clean_kernel_err=1.2e-4, worst_clean_sampled_logit_err=1.0e-3),
     'det_ytvis': dict(clean_share_of_stable=0.99, share_rows_kernels_within_2e4=1 - 2 / 200, share_rows_sampled_logits_within_1e3=1 - 2 / 200,
                       wrong_bits_off_threshold=2, worst_clean_kernel_err=1.2e-5, worst_clean_sampled_logit_err=1.0e-4),
     'video_vipseg_n216': dict(clean_share_of_stable=0.99, share_rows_kernels_within_2e4=1 - 3 / 216, share_rows_sampled_logits_within_1e3=1 - 3 / 216,
@@ -243,7 +251,7 @@ FREE_RUN_LIMITS = {
 }
 
 
-@pytest.mark.parametrize('chain', ['auto', 'persistent'])
+@pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent'])
 @pytest.mark.parametrize('name', ['video_vipseg_big', 'det_ytvis', 'video_vipseg_n216'])
 def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name, chain):
     """(`video_vipseg_n216`: BASELINE cfg5 as LITERALLY worded — 150 proposals + 66 stuff kernels = 216 rows, 46x80 features.)
@@ -252,9 +260,9 @@ def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name, chain):
     stuff, x2, 2 frames): the free-running 3-stage fused head against the REFERENCE's own outputs."""
     g, case = load_golden(name)
     head, (x, pf, mp, prev) = _build_head(vkn, case)
-    if chain == 'persistent':          # (default at these sizes: one launch per GEMM; both forms of the chain are held to the same bounds)
+    if chain != 'auto':          # (default at these sizes: the few-row chain, vkn_ksplit.hip; all three forms of the chain are held to the same bounds)
         for h in head.mask_head:
-            h.vkn_flags = vkn.ops.FLAG_CHAIN_PERSISTENT
+            h.vkn_flags = vkn.ops.FLAG_CHAIN_PERSISTENT if chain == 'persistent' else vkn.ops.FLAG_CHAIN_LAUNCHES
     metas = [dict()] * case['B']
     B, N, P = case['B'], case['N'], case['H'] * case['W']
     # kernels whose hand-over masks stay clear of the binarisation threshold in EVERY stage of the reference cannot flip a bit under
@@ -322,12 +330,15 @@ def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name, chain):
     assert m['worst_clean_kernel_err'] <= lim['worst_clean_kernel_err'] and m['worst_clean_sampled_logit_err'] <= lim['worst_clean_sampled_logit_err']
 
 
-# measured (profiles/r04_parity_margins.json): 9 / 13 flipped bits over the three stages and 108 / 104 of 117 rows clean at the end
-# (launch-per-GEMM / persistent chain), worst clean-row logit error 3.7e-4 / 4.9e-4 -> 2x head-room
-CFG2_FLIP_LIMIT, CFG2_CLEAN_ROWS_MIN, CFG2_CLEAN_LOGIT_ERR = 26, 100, 9.8e-4
+# measured, round 4 (profiles/r04_parity_margins.json): 9 / 13 flipped bits over the three stages and 108 / 104 of 117 rows clean at the
+# end (launch-per-GEMM / persistent chain), worst clean-row logit error 3.7e-4 / 4.9e-4.  Round 5 measured the REFERENCE ALGORITHM against
+# itself on this very case (tools/oracle_reorder_noise.py, profiles/r05_oracle_reorder_noise.json): three channel permutations of the 1x1
+# conv and 1 / 16 threads give 5 .. 24 flipped bits, 93 .. 112 clean rows, worst clean-row logit error 3.2e-4 .. 8.3e-4 — our forms sit
+# INSIDE the band a re-ordered reference spans.  Limits: 2 x the oracle's worst flip count, its worst clean-row count minus head-room.
+CFG2_FLIP_LIMIT, CFG2_CLEAN_ROWS_MIN, CFG2_CLEAN_LOGIT_ERR = 48, 88, 1.0e-3
 
 
-@pytest.mark.parametrize('chain', ['auto', 'persistent'])
+@pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent'])
 def test_cfg2_size_free_running_vs_oracle_flip_budget(vkn, chain):
     """The FREE-RUNNING 3-stage head at BASELINE cfg2 size against the free-running oracle, with the chaos argument measured
     instead of assumed: per stage, the binarised masks may differ from the oracle's only where the oracle's logit
@@ -337,9 +348,9 @@ def test_cfg2_size_free_running_vs_oracle_flip_budget(vkn, chain):
     case = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256,
                 B=1, seed=12, video=0)
     head, (x, pf, mp, _) = _build_head(vkn, case)
-    if chain == 'persistent':
+    if chain != 'auto':        # (auto at one frame: the few-row chain, vkn_ksplit.hip)
         for h in head.mask_head:
-            h.vkn_flags = vkn.ops.FLAG_CHAIN_PERSISTENT
+            h.vkn_flags = vkn.ops.FLAG_CHAIN_PERSISTENT if chain == 'persistent' else vkn.ops.FLAG_CHAIN_LAUNCHES
     traces = []
     run_oracle(case, traces=traces)
     thr = vkn.ops.thr_logit(0.5)
@@ -372,8 +383,8 @@ def test_cfg2_size_free_running_vs_oracle_flip_budget(vkn, chain):
             clean = clean & ~flip.flatten(1).any(dim=1)   # the next stage gathers with these masks
     rec.update(clean_rows_out=int(clean.sum()), total_flipped_bits_clean=total_flips)
     record_margins(f'cfg2_free_running_vs_oracle[{chain}]', rec)
-    assert int(clean.sum()) >= 100, f'{int(clean.sum())} clean rows, {total_flips} flips'
-    # tightened to the measured values with 2x head-room (profiles/r04_parity_margins.json)
+    assert int(clean.sum()) >= CFG2_CLEAN_ROWS_MIN, f'{int(clean.sum())} clean rows, {total_flips} flips'   # (the re-ordered oracle itself: 93 .. 112)
+    # anchored on the reference's own re-ordering noise (profiles/r05_oracle_reorder_noise.json)
     assert total_flips <= CFG2_FLIP_LIMIT and int(clean.sum()) >= CFG2_CLEAN_ROWS_MIN
     assert all(rec[f's{s}_worst_clean_logit_err'] <= CFG2_CLEAN_LOGIT_ERR for s in range(3))
 
@@ -440,9 +451,10 @@ def test_cfg2_size_properties(vkn):
     assert maxabs(d1, refd) < 2e-4
 
 
-@pytest.mark.parametrize('chain', ['launches', 'persistent'])
+@pytest.mark.parametrize('chain', ['ksplit', 'launches', 'persistent'])
 def test_cfg2_size_head_vs_oracle(vkn, chain):
-    """(Both forms of the [N x C] chain: one launch per GEMM — the default at one frame — and the persistent row-owner kernels.)
+    """(All three forms of the [N x C] chain: the few-row chain — the default at one frame —, one launch per GEMM with the row epilogue
+    in the producer, and the persistent row-owner kernels.)
     One 1024x2048 frame through the video head (S=3, N=117, link + x4 upsample) against the CPU oracle.
 
     At this size (3.8 M logits per stage) a few logits lie within 1e-5 of the binarisation flip point, and ANY change of
@@ -454,7 +466,7 @@ def test_cfg2_size_head_vs_oracle(vkn, chain):
                 B=1, seed=11, video=1)
     head, (x, pf, mp, prev) = _build_head(vkn, case)
     for h in head.mask_head:
-        h.vkn_flags = vkn.ops.FLAG_CHAIN_PERSISTENT if chain == 'persistent' else vkn.ops.FLAG_CHAIN_LAUNCHES
+        h.vkn_flags = dict(persistent=vkn.ops.FLAG_CHAIN_PERSISTENT, launches=vkn.ops.FLAG_CHAIN_LAUNCHES, ksplit=vkn.ops.FLAG_CHAIN_KSPLIT)[chain]
     traces = []
     obj_r, cls_r, masks_r, scaled_r, track_r = run_oracle(case, traces=traces)
     xd, prevd = _cuda(x, prev)
@@ -935,17 +947,19 @@ def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, vide
     kwd = dict(prev_obj=prev.reshape(B, N, C).to(DEV), want_track=True) if video else {}
     new = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_CHAIN_PERSISTENT, **kwd)
     old = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_CHAIN_LAUNCHES, **kwd)
+    few = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_CHAIN_KSPLIT, **kwd)      # the few-row chain (vkn_ksplit.hip), forced at any row count
     exact = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_EXACT_GEMM, **kwd)
     names = ('cls', 'masks', 'obj', 'x_feat', 'track')
-    for nm, a, b, e in zip(names, new, old, exact):
+    for nm, a, b, f, e in zip(names, new, old, few, exact):
         if a is None:
-            assert b is None
+            assert b is None and f is None
             continue
         scale = max(1.0, float(e.abs().max()))
         d_old, d_exact, d_base = maxabs(a, b), maxabs(a, e), maxabs(b, e)
-        assert torch.isfinite(a).all(), nm
-        # the two bf16x3 chains sit equally close to the exact-fp32 chain (both ~1e-6 on O(1) values)
+        assert torch.isfinite(a).all() and torch.isfinite(f).all(), nm
+        # the bf16x3 chains sit equally close to the exact-fp32 chain (all ~1e-6 on O(1) values)
         assert d_old < 2e-5 * scale and d_exact < 2e-5 * scale, (nm, d_old, d_exact, d_base, scale)
+        assert maxabs(f, b) < 2e-5 * scale and maxabs(f, e) < 2e-5 * scale, (nm, maxabs(f, b), maxabs(f, e), scale)
     with torch.no_grad():
         traces = []
         O.iter_head_mask_preds(sd, x, pf, mp, cfg, traces=traces, **(dict(previous_obj_feats=prev) if video else {}))
@@ -954,8 +968,13 @@ def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, vide
     assert maxabs(new[1], t0['new_mask_preds']) < TOL_LOGIT and maxabs(new[0], t0['cls_score']) < 1e-4
     again = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_CHAIN_PERSISTENT, **kwd)
     assert all(a is None or torch.equal(a, b) for a, b in zip(new, again)), 'deterministic'
-    auto = vkn.ops.stage_forward(*args, **kwd)     # default policy: by row count (64 row tiles)
-    pick = new if (B * N + 31) // 32 >= 64 else old
+    again = vkn.ops.stage_forward(*args, flags=vkn.ops.FLAG_CHAIN_KSPLIT, **kwd)
+    assert all(a is None or torch.equal(a, b) for a, b in zip(few, again)), 'deterministic (few-row chain)'
+    assert maxabs(few[2], t0['obj_feat'].reshape(B, N, C)) < 2e-4
+    assert maxabs(few[1], t0['new_mask_preds']) < TOL_LOGIT and maxabs(few[0], t0['cls_score']) < 1e-4
+    auto = vkn.ops.stage_forward(*args, **kwd)     # default policy by row tiles: few-row <= 19, launch-per-GEMM <= 63, persistent from 64 on
+    rt = (B * N + 31) // 32
+    pick = new if rt >= 64 else (few if rt <= 19 else old)
     assert all(a is None or torch.equal(a, b) for a, b in zip(auto, pick)), 'default policy picks by row count'
 
 
@@ -1258,10 +1277,13 @@ def test_side_stream_link_equals_serial_link(vkn):
                 assert (u is None and v is None) or torch.equal(u, v)
 
 
-def test_block_step_with_neighbour_link_equals_whole_clip(vkn):
+@pytest.mark.parametrize('chain', ['ksplit', 'launches', 'policy'])
+def test_block_step_with_neighbour_link_equals_whole_clip(vkn, chain):
     """bench.py --gpus N: every rank runs its contiguous block of the clip as ONE call with the in-call clip link and re-links only
     its frame 0 to the previous rank's last kernels (dist.neighbour_last_kernels).  Emulated on one GPU with two blocks: every
-    output of the two block steps equals the whole-clip call."""
+    output of the two block steps equals the whole-clip call — BIT FOR BIT when both run the same form of the [N x C] chain (every
+    form is row-independent with a fixed summation order: batch-invariant), to fp32 rounding when the row-count policy gives the
+    blocks (11 row tiles: few-row chain) another form than the whole clip (22 row tiles: one launch per GEMM)."""
     _, case = load_golden('video_cfg')
     head, _ = _build_head(vkn, case)
     T, N, C, H, W = 6, case['N'], case['C'], case['H'], case['W']
@@ -1271,19 +1293,32 @@ def test_block_step_with_neighbour_link_equals_whole_clip(vkn):
     first = _rand((1, N, C), 954).to(DEV)
     packs = [h.stage_pack(torch.device(DEV)) for h in head.mask_head]
     mk = head.mask_head[0].make_dims
-    whole = vkn.ops.head_forward(mk(T, N, H, W), packs, xs, pfs, mps, None, case['up'], clip_first_prev=first)
+    fl = dict(ksplit=vkn.ops.FLAG_CHAIN_KSPLIT, launches=vkn.ops.FLAG_CHAIN_LAUNCHES, policy=0)[chain]
+    whole = vkn.ops.head_forward(mk(T, N, H, W), packs, xs, pfs, mps, None, case['up'], clip_first_prev=first, flags=fl)
     h = T // 2
     blocks = []
     prev_last = None
     for r, (b0, b1) in enumerate(((0, h), (h, T))):
         out = vkn.ops.head_forward(mk(b1 - b0, N, H, W), packs, xs[b0:b1], pfs[b0:b1], mps[b0:b1], None, case['up'],
-                                   clip_first_prev=first)
+                                   clip_first_prev=first, flags=fl)
         if r > 0:   # what rank r does after the neighbour hand-over
             out[4][0:1].copy_(vkn.ops.track_link(mk(1, N, H, W), packs[-1], out[0][0:1], prev_last))
         prev_last = out[0][-1:].clone()
         blocks.append(out)
     for k in range(5):
-        assert torch.equal(torch.cat([b[k] for b in blocks], 0), whole[k]), k
+        got = torch.cat([b[k] for b in blocks], 0)
+        if chain == 'policy' and (T * N + 31) // 32 > 19 >= (h * N + 31) // 32:
+            # two forms of the chain: the teacher-forced distance (2e-5 relative per stage) grows through three free-running stages only
+            # where a near-threshold mask bit flips; this small case (16x32 features) has none
+            assert maxabs(got, whole[k]) < 2e-4 * max(1.0, float(whole[k].abs().max())), k
+        elif chain == 'launches' and k == 4:
+            # vkn_track_link_f32 carries no flags: the one-frame re-link of block 1's first frame follows the row-count policy (few-row
+            # kernels) while the whole clip's in-call link was forced onto the launch-per-GEMM kernels — that frame to fp32 rounding
+            keep = torch.ones(T, dtype=torch.bool)
+            keep[h] = False
+            assert torch.equal(got[keep], whole[k][keep]) and maxabs(got[h], whole[k][h]) < 2e-5 * max(1.0, float(whole[k].abs().max())), k
+        else:
+            assert torch.equal(got, whole[k]), k
 
 
 def test_softmax_classification_head_runs_stage_by_stage_vs_oracle(vkn):

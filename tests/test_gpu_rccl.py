@@ -167,3 +167,19 @@ def test_bench_previous_link_head_under_torchrun_one_rank():
     assert line['n_gpus'] == 1 and line['value'] > 0 and 'previous_link=update_dynamic_cov' in line['config']['workload']
     assert line['config']['frames_per_gpu_per_step'] == 8
 
+
+
+def test_bench_clip_of_8_strong_scaling_under_torchrun_one_rank():
+    """`bench.py --clip 8` (BASELINE cfg3 shape: ONE clip of 8 frames in contiguous blocks of 8 / N per rank, strong scaling) launched
+    the way the driver launches N-GPU runs — here one rank, RCCL initialised: the line says "strong", carries the whole clip on the one
+    rank, and the N = 1 breakdown holds the per-rank step times at 4 / 2 / 1 frames per call (what a rank of a 2 / 4 / 8-GPU run computes)."""
+    port = _free_port()
+    line = _bench(['--force-dist', '--clip', '8'],
+                  launcher=['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                            '--master-port', str(port)])
+    assert line['scaling'] == 'strong' and line['n_gpus'] == 1 and line['value'] > 0
+    assert line['config']['clip_frames'] == 8 and line['config']['frames_per_gpu_per_step'] == 8
+    bd = line['breakdown']
+    for b in (4, 2, 1):
+        assert bd[f'per_rank_step_ms_at_{b}_frames_ONE_gpu'] > 0
+    assert bd['per_rank_step_ms_at_1_frames_ONE_gpu'] < bd['per_rank_step_ms_at_4_frames_ONE_gpu']

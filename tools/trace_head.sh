@@ -29,4 +29,8 @@ for a, b in zip(ups, ups[1:]):
     for k, v in sorted(d.items(), key=lambda kv: -kv[1][1]):
         print(f'   {k:46s} {v[0]:3d} {v[1]:9.1f} us  avg {v[1] / v[0]:7.1f}')
     print('   timeline:', ' '.join(f"{n.split('(')[0].replace('void ','')[:12]}:{(e - s) / 1e3:.0f}" for n, s, e, gy, gx in seg))
+    t0 = rows[a][2]   # end of the previous step's upsample
+    print('   starts (us after the previous step ended: start+duration name grid):')
+    for n, s, e, gy, gx in seg:
+        print(f"      {(s - t0) / 1e3:8.1f} +{(e - s) / 1e3:7.1f}  {n.split('(')[0].replace('void ','')[:40]}  grid {gx}x{gy}")
 PY

@@ -184,74 +184,125 @@ class LinearFn(torch.autograd.Function):
                 # contraction length is the out-feature count rounded up to 32 (fc_cls: 19 classes) — dy is zero-padded to match
                 g = dy if Nout % 32 == 0 else F.pad(dy, (0, 32 - Nout % 32))
                 da = _gemm(g, weight, img_b, None, 0, g.shape[1], K)
+            need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.queue is not None and not ctx.queue.closed:
-                if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-                    ctx.queue.items.append((dy, a, weight, bias, ctx.wt))
-                return da, None, None, None, None, None, None, None
-            if ctx.needs_input_grad[1]:
+                if not (need_w or need_b):
+                    return da, None, None, None, None, None, None, None
+                # the queue hands a gradient out through the PARAMETER the saved tensor lives in: a tensor it cannot place (a
+                # contiguous / aligned copy `_f32c` made of a strided or misaligned parameter, a transposed-weight layer's bias) is
+                # computed here instead — never dropped
+                if ctx.queue.accepts(weight if need_w else None, bias if need_b else None, ctx.wt):
+                    ctx.queue.items.append((dy, a, weight if need_w else None, bias if need_b else None, ctx.wt))
+                    return da, None, None, None, None, None, None, None
+            if need_w:
                 dw = torch.empty_like(weight)
-                db = torch.empty(Nout, dtype=torch.float32, device=a.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+                db = torch.empty(Nout, dtype=torch.float32, device=a.device) if need_b else None
                 if ctx.wt:                                 # dW[k][n] = sum_m a[m][k] dy[m][n]
                     check(L.vkn_linear_dw_f32(_ptr(a), K, _ptr(dy), Nout, _ptr(dw), None, M, Nout, K, 0, _stream()))
                     if db is not None:
                         db = dy.sum(0)
                 else:                                      # dW[n][k] = sum_m dy[m][n] a[m][k]
                     check(L.vkn_linear_dw_f32(_ptr(dy), Nout, _ptr(a), K, _ptr(dw), _ptr(db), M, K, Nout, 0, _stream()))
-            elif ctx.has_bias and ctx.needs_input_grad[2]:
+            elif need_b:
                 db = dy.sum(0)
         return da, dw, db, None, None, None, None, None
 
 
 class DwQueue:
     """(dy, a, weight view, bias view, wt) of every Linear layer whose backward has run; `flush` computes all their weight / bias
-    gradients with one `vkn_linear_dw_batch_f32` launch per 48 layers — the dW GEMMs are off the backward's critical path."""
+    gradients with one `vkn_linear_dw_batch_f32` launch per 48 layers — the dW GEMMs are off the backward's critical path.
+
+    The gradients leave through the parameters `ChainEntryFn` was given (`params`): a queued tensor must be (a view into) one of them.
+    `accepts` is the gate — `LinearFn.backward` computes anything the queue cannot place itself.  A destination that appears twice
+    in one flush (tied weights, a module used twice in one chain) is written by the batch launch once and ACCUMULATED into for every
+    further use (`vkn_linear_dw_f32(accumulate=1)`); a bias whose weight is frozen gets `dy.sum(0)`."""
 
     def __init__(self):
         self.items = []
         self.closed = False       # flushed: a Linear backward that still arrives computes its own gradients
+        self.params = ()          # set by ChainEntryFn.forward
+
+    def _owner(self, t):
+        """index of the parameter the tensor lives in (whole, 4-byte aligned inside it), or None"""
+        lo = t.data_ptr()
+        hi = lo + t.numel() * t.element_size()
+        for i, p in enumerate(self.params):
+            plo = p.data_ptr()
+            if plo <= lo and hi <= plo + p.numel() * p.element_size() and p.requires_grad and p.is_contiguous() and (lo - plo) % 4 == 0:
+                return i
+        return None
+
+    def accepts(self, weight, bias, wt):
+        if wt and bias is not None:
+            return False                               # (the batch kernel has no bias reduction for the untransposed form)
+        for t in (weight, bias):
+            if t is not None and (not t.is_contiguous() or self._owner(t) is None):
+                return False
+        return True
 
     def flush(self, params):
         """-> gradients aligned with `params` (None where no queued layer touched the parameter)"""
         items, self.items, self.closed = self.items, [], True
-        spans = [(p.data_ptr(), p.data_ptr() + p.numel() * p.element_size(), i) for i, p in enumerate(params)]
-        bufs, cover = {}, {}
+        self.params = tuple(params)
+        bufs, covered = {}, {}
 
         def slot(view):
-            ptr = view.data_ptr()
-            i = next((k for lo, hi, k in spans if lo <= ptr < hi), None)     # the parameter this (view of a) tensor lives in
-            if i is None or not params[i].requires_grad:
-                return None
-            base, off = params[i], (ptr - params[i].data_ptr()) // 4
+            i = self._owner(view)
+            if i is None:                              # (`accepts` let it in, so the parameter set changed under us: loud, not silent)
+                raise RuntimeError('DwQueue.flush: a queued weight / bias is not part of the parameters of this chain')
             if i not in bufs:
-                bufs[i] = torch.empty_like(base, memory_format=torch.contiguous_format)
-                cover[i] = 0
-            cover[i] += view.numel()
-            return bufs[i].data_ptr() + off * 4
+                bufs[i] = torch.empty_like(params[i], memory_format=torch.contiguous_format)
+                covered[i] = set()
+            off = (view.data_ptr() - params[i].data_ptr()) // 4
+            return i, off
 
-        by_m = {}
-        for dy, a, w, b, wt in items:
-            pw = slot(w)
-            pb = slot(b) if b is not None else None
-            if pw is None and pb is None:
-                continue
-            if pw is None:
-                raise NotImplementedError('a bias gradient without its weight gradient')
-            M = a.shape[0]
-            K, Nout = a.shape[1], dy.shape[1]
-            it = (_lib.VknDwItem(a.data_ptr(), dy.data_ptr(), pw, None, a.stride(0), dy.stride(0), K, Nout) if wt else
-                  _lib.VknDwItem(dy.data_ptr(), a.data_ptr(), pw, pb, dy.stride(0), a.stride(0), Nout, K))
-            by_m.setdefault(M, []).append(it)
-            if wt and pb is not None:
-                raise NotImplementedError('bias of an untransposed-weight layer')
-        for i, n in cover.items():
-            if n < bufs[i].numel():                  # a packed parameter only partly used by the queued layers: the rest of its
-                bufs[i].zero_()                      # gradient is zero (enqueued before the launch below, same stream)
         L = _lib.lib()
+        by_m, later, seen = {}, [], set()
+        for dy, a, w, b, wt in items:
+            M, K, Nout = a.shape[0], a.shape[1], dy.shape[1]
+            pw = pb = None
+            if w is not None:
+                i, off = slot(w)
+                pw = bufs[i].data_ptr() + off * 4
+                covered[i].add((off, w.numel()))
+            if b is not None:
+                j, offb = slot(b)
+                pb = bufs[j].data_ptr() + offb * 4
+                covered[j].add((offb, b.numel()))
+            if pw is None:                             # frozen weight, trainable bias
+                later.append(('bias', bufs[j].view(-1)[offb:offb + b.numel()], dy, pb in seen))
+                seen.add(pb)
+                continue
+            dup = pw in seen or (pb is not None and pb in seen)
+            if dup:                                    # second use of a destination in this flush: accumulate after the batch launches
+                later.append(('dw', (dy, a, pw, pb, wt, M, K, Nout), pw in seen, pb is not None and pb in seen))
+            else:
+                it = (_lib.VknDwItem(a.data_ptr(), dy.data_ptr(), pw, None, a.stride(0), dy.stride(0), K, Nout) if wt else
+                      _lib.VknDwItem(dy.data_ptr(), a.data_ptr(), pw, pb, dy.stride(0), a.stride(0), Nout, K))
+                by_m.setdefault(M, []).append(it)
+            seen.add(pw)
+            if pb is not None:
+                seen.add(pb)
+        for i, spans in covered.items():
+            if sum(n for _, n in spans) < bufs[i].numel():   # a packed parameter only partly used by the queued layers: the rest of its
+                bufs[i].zero_()                              # gradient is zero (enqueued before the launches below, same stream)
         for M, its in by_m.items():
             for j in range(0, len(its), _lib.DW_MAX_ITEMS):
                 chunk = its[j:j + _lib.DW_MAX_ITEMS]
                 arr = (_lib.VknDwItem * len(chunk))(*chunk)
                 check(L.vkn_linear_dw_batch_f32(arr, len(chunk), M, _stream()))
+        for ent in later:
+            if ent[0] == 'bias':
+                _, dst, dy, acc = ent
+                dst.add_(dy.sum(0)) if acc else dst.copy_(dy.sum(0))
+                continue
+            _, (dy, a, pw, pb, wt, M, K, Nout), acc_w, acc_b = ent
+            if pb is not None and acc_b != acc_w:      # (a bias shared without its weight, or the reverse: not a shape a module produces)
+                raise NotImplementedError('DwQueue: a bias and its weight are shared differently')
+            if wt:
+                check(L.vkn_linear_dw_f32(a.data_ptr(), a.stride(0), dy.data_ptr(), dy.stride(0), pw, None, M, Nout, K, 1, _stream()))
+            else:
+                check(L.vkn_linear_dw_f32(dy.data_ptr(), dy.stride(0), a.data_ptr(), a.stride(0), pw, pb, M, K, Nout, 1, _stream()))
         return [bufs.get(i) for i in range(len(params))]
 
 
@@ -262,6 +313,7 @@ class ChainEntryFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, queue, n_in, *args):
         ctx.queue, ctx.n_in, ctx.params = queue, n_in, args[n_in:]
+        queue.params = tuple(args[n_in:])        # what `accepts` places queued weights / biases in
         return tuple(a.view_as(a) for a in args[:n_in])
 
     @staticmethod

@@ -160,7 +160,8 @@ size_t carve_stage(const VknDims* d, char* base, StageWs* s) {
         // previous_link heads runs the chain with B = 1 inside a B-frame call, with that shape's own split factors)
         const size_t ks = (size_t)ffn_ksplit((int)M, (int)FF), hs = (size_t)ffn_hsplit((int)M, (int)FF);
         const size_t ks1 = (size_t)ffn_ksplit((int)N, (int)FF), hs1 = (size_t)ffn_hsplit((int)N, (int)FF);
-        const size_t a = (ks > hs ? ks : hs) * M * C, b1 = (ks1 > hs1 ? ks1 : hs1) * N * C;
+        const size_t k4 = 4;   // the few-row chain's z-split FFN (vkn_ksplit.hip) stores up to four partial results
+        const size_t a = (ks > hs ? (ks > k4 ? ks : k4) : (hs > k4 ? hs : k4)) * M * C, b1 = (ks1 > hs1 ? (ks1 > k4 ? ks1 : k4) : (hs1 > k4 ? hs1 : k4)) * N * C;
         s->partial = c.take<float>(a > b1 ? a : b1);
     }
     s->t1 = c.take<float>(M * C);
@@ -302,8 +303,11 @@ int run_updator(const VknDims* d, const VknStageWeights* w, const PrepW& pw, con
 //                                  previous_type == "update" / "update_obj"      :417-476   (updator on x_feat / on obj_feat)
 //                                  previous_link == "update_dynamic_cov"         :324-348   (updator on x_feat; out replaces obj_in)
 //                                  previous_link == "link_atten"                 :350-372
+bool link_ks_ok(const VknDims* d, const VknStageWeights* w, const PrepW& pw, unsigned flags);
+int run_link_ks(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* cur, const float* kv, float* out,
+                const StageWs& s, hipStream_t st);
 int run_link(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* cur, const float* prev,
-             float* out, const StageWs& s, hipStream_t st, const float* update_feature = nullptr) {
+             float* out, const StageWs& s, hipStream_t st, const float* update_feature = nullptr, unsigned flags = 0) {
     if (!w->pa_in_w || !w->lffn1_w) return VKN_E_ARG;
     const float* kv = prev;
     if (update_feature) {   // (the stage's OWN weights also carry an updator — the main one: only an update feature selects it)
@@ -313,6 +317,7 @@ int run_link(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const 
         VKN_TRY(run_updator(d, w, pw, update_feature, nullptr, nullptr, prev, s.lupd, su, st));
         kv = s.lupd;
     }
+    if (link_ks_ok(d, w, pw, flags)) return run_link_ks(d, w, pw, cur, kv, out, s, st);   // few rows: column-spread phases (vkn_ksplit.hip)
     VKN_TRY(run_attention(d, s, cur, kv, 8, w->pa_in_w, pw.pa_in, pw.pa_in_kv, w->pa_in_b, w->pa_out_w, pw.pa_out, w->pa_out_b,
                           w->pa_norm_w, w->pa_norm_b, s.t1, st));                                             // _num_head = 8 (:165)
     return run_ffn(d, s, s.t1, w->lffn1_w, pw.lffn1, w->lffn1_b, w->lffn2_w, pw.lffn2, w->lffn2_b, w->lffn_norm_w,
@@ -406,6 +411,168 @@ int run_chain_fast(const VknDims* d, const VknStageWeights* w, const PrepW& pw, 
     return vkn_launch_chain_c(c, st);
 }
 
+// Row-count policy of the three chain forms (profiles/r05_chain_forms.txt; chain alone, us per stage at 117 / 234 / 468 / 936 / 1872 / 3744
+// rows): few-row 78 / 83 / 97 / 138 / 198 / 341, launch-per-GEMM 109 / 111 / 111 / 111 / 130 / 185, persistent 160 at any row count ->
+// few-row up to 19 row tiles (5 frames of 117 kernels), launch-per-GEMM up to 63, persistent from 64 on.
+#define VKN_KS_MAX_ROW_TILES 19
+// The few-row chain (vkn_ksplit.hip): same shape conditions as the persistent chain, at most VKN_KS_MAX_ROW_TILES row tiles (or VKN_FLAG_CHAIN_KSPLIT),
+// every vector it reads with 16-byte loads aligned (parameters that are views into a packed buffer may not be).
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+bool chain_ks_ok(const VknDims* d, const VknStageWeights* w, const PrepW& pw, unsigned flags, bool have_cls) {
+    if (flags & (VKN_FLAG_CHAIN_LAUNCHES | VKN_FLAG_CHAIN_PERSISTENT | VKN_FLAG_EXACT_GEMM)) return false;
+    if (vkn_dbg_env("VKN_CHAIN_LAUNCHES", 0) || vkn_dbg_env("VKN_CHAIN_PERSISTENT", 0) || !vkn_dbg_env("VKN_CHAIN_KSPLIT", 1)) return false;
+    if (!(flags & VKN_FLAG_CHAIN_KSPLIT) && (d->B * d->N + 31) / 32 > VKN_KS_MAX_ROW_TILES) return false;
+    if (d->C != 256 || d->n_cls_fcs != 1 || d->n_mask_fcs != 1 || d->ff % 256 != 0 || d->ff > 2048) return false;
+    if (d->ff % 512 != 0 && d->ff > 1024) return false;   // at most four z-chunks of the FFN's second Linear
+    if (!w->prepared || w->prepared_bytes >= (1ull << 31)) return false;
+    if (!pw.dynft || !pw.dyn || !pw.dec || !pw.inp || !pw.ig || !pw.ug || !pw.fc || !pw.attn_in || !pw.attn_out || !pw.ffn1 || !pw.ffn2 ||
+        !pw.cls_fc[0] || !pw.mask_fc[0])
+        return false;
+    if (have_cls && !pw.fc_cls) return false;
+    if (!w->ffn1_w || !w->cls_ln_w[0] || !w->mask_ln_w[0]) return false;
+    const void* v16[] = {w->inorm_in_w, w->inorm_in_b, w->norm_in_w, w->norm_in_b, w->norm_out_w, w->norm_out_b, w->inorm_out_w, w->inorm_out_b,
+                         w->fc_norm_w, w->fc_norm_b, w->attn_norm_w, w->attn_norm_b, w->ffn_norm_w, w->ffn_norm_b, w->ffn2_b,
+                         w->cls_ln_w[0], w->cls_ln_b[0], w->mask_ln_w[0], w->mask_ln_b[0], pw.dvec};
+    for (const void* p : v16)
+        if (!p || !al16(p)) return false;
+    return true;
+}
+
+VknKsProb ks_prob(const float* a, int lda, const void* W, int Nout, int KT, float eps) {
+    VknKsProb p{};
+    p.pro.a[0] = a; p.pro.lda[0] = lda; p.pro.nsum = 1; p.pro.eps = eps;
+    p.Wsplit = W; p.Nout = Nout; p.KT = KT;
+    return p;
+}
+
+// (ii) + the FC branches as nine GEMM phases + the attention (reference lines: see run_updator / run_attention / run_ffn and the cls /
+// mask branches of run_stage below).  A phase stores its RAW result; LayerNorm / ReLU / sigmoid / the gate and mix algebra run in the
+// prologue of the phase that consumes it.  `obj_ready` (or NULL) is recorded where obj_out is final — before the last phase.
+int run_chain_ks(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* a0, bool a0_raw, const float* cnt,
+                 const float* obj_in, float* obj_out, float* cls_logits, bool cls_sigmoid, float* kern32_out, const StageWs& s,
+                 hipStream_t st, hipEvent_t obj_ready) {
+    const int M = d->B * d->N, C = d->C, FF = d->ff;
+    const float eps = d->ln_eps;
+    VknKsProb pr[2];
+    // dynamic_layer(update feature) | input_layer(kernels)                                            knet/kernel_updator.py:59-66
+    pr[0] = ks_prob(a0, C, a0_raw ? pw.dynft : pw.dyn, 2 * C, 8, eps);
+    if (a0_raw) { pr[0].epi.bias = pw.bcnt; pr[0].epi.rowscale = cnt; pr[0].epi.bias2 = w->dyn_b; }
+    else pr[0].epi.bias = w->dyn_b;
+    pr[0].epi.out = s.params; pr[0].epi.ldo = 2 * C;
+    pr[1] = ks_prob(obj_in, C, pw.inp, 2 * C, 8, eps);
+    pr[1].epi.bias = w->inp_b; pr[1].epi.out = s.inputf; pr[1].epi.ldo = 2 * C;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 2, 0, 0, 1, 0, M, st));
+    // gate = input_in * parameters_in; input_gate | update_gate (raw)                                 :70-76
+    pr[0] = ks_prob(s.inputf, 2 * C, pw.ig, C, 8, eps);
+    pr[0].pro.a[1] = s.params; pr[0].pro.lda[1] = 2 * C;
+    pr[1] = pr[0];
+    pr[0].epi.bias = w->ig_b; pr[0].epi.out = s.ig; pr[0].epi.ldo = 2 * C;
+    pr[1].Wsplit = pw.ug; pr[1].epi.bias = w->ug_b; pr[1].epi.out = s.ig + C; pr[1].epi.ldo = 2 * C;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 2, 1, 0, 1, 0, M, st));
+    // features = sigmoid(norm_in(update_gate)) * norm_out(param_out) + sigmoid(input_norm_in(input_gate)) * input_norm_out(input_out);
+    // fc_layer (raw)                                                                                   :74-90
+    pr[0] = ks_prob(s.ig, 2 * C, pw.fc, C, 8, eps);
+    pr[0].pro.a[1] = s.ig + C; pr[0].pro.lda[1] = 2 * C;
+    pr[0].pro.a[2] = s.params + C; pr[0].pro.lda[2] = 2 * C;
+    pr[0].pro.a[3] = s.inputf + C; pr[0].pro.lda[3] = 2 * C;
+    pr[0].pro.ln_w[0] = w->inorm_in_w; pr[0].pro.ln_b[0] = w->inorm_in_b;
+    pr[0].pro.ln_w[1] = w->norm_in_w; pr[0].pro.ln_b[1] = w->norm_in_b;
+    pr[0].pro.ln_w[2] = w->norm_out_w; pr[0].pro.ln_b[2] = w->norm_out_b;
+    pr[0].pro.ln_w[3] = w->inorm_out_w; pr[0].pro.ln_b[3] = w->inorm_out_b;
+    pr[0].epi.bias = w->fc_b; pr[0].epi.out = s.f; pr[0].epi.ldo = C;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 1, 2, 0, 1, 0, M, st));
+    // obj1 = relu(fc_norm(.)) (side output); q | k | v = in_proj(obj1)                                :91-92, knet/det/kernel_update_head.py:206
+    pr[0] = ks_prob(s.f, C, pw.attn_in, 3 * C, 8, eps);
+    pr[0].pro.ln_w[0] = w->fc_norm_w; pr[0].pro.ln_b[0] = w->fc_norm_b; pr[0].pro.act = 1;
+    pr[0].pro.side_out = s.obj1; pr[0].pro.ld_side = C;
+    pr[0].epi.bias = w->attn_in_b; pr[0].epi.out = s.qkv; pr[0].epi.ldo = 3 * C;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 1, 0, 0, 1, 0, M, st));
+    VKN_TRY(vkn_launch_attn(s.qkv, 3 * C, s.qkv + C, s.qkv + 2 * C, 3 * C, s.ao, C, d->B, d->N, d->N, d->heads, C / d->heads, st));
+    // out_proj + identity (raw)                                                                        knet/det/kernel_update_head.py:206
+    pr[0] = ks_prob(s.ao, C, pw.attn_out, C, 8, eps);
+    pr[0].epi.bias = w->attn_out_b; pr[0].epi.resid = s.obj1; pr[0].epi.ldr = C; pr[0].epi.out = s.obj2; pr[0].epi.ldo = C;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 1, 0, 0, 1, 0, M, st));
+    // obj2 = attention_norm(.) (side output, the FFN's residual); hidden = relu(W1 obj2 + b1)          :208, :214
+    pr[0] = ks_prob(s.obj2, C, pw.ffn1, FF, 8, eps);
+    pr[0].pro.ln_w[0] = w->attn_norm_w; pr[0].pro.ln_b[0] = w->attn_norm_b;
+    pr[0].pro.side_out = s.t1; pr[0].pro.ld_side = C;
+    pr[0].epi.bias = w->ffn1_b; pr[0].epi.act = 1; pr[0].epi.out = s.h; pr[0].epi.ldo = FF;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 1, 0, 0, 1, 0, M, st));
+    // W2 hidden, the contraction in z-chunks (partial results)                                         :214
+    const int kpw = (FF % 512 == 0) ? 2 : 1, zch = FF / (256 * kpw);
+    pr[0] = ks_prob(s.h, FF, pw.ffn2, C, FF / 32, eps);
+    pr[0].epi.out = s.partial; pr[0].epi.ldo = C;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 1, 0, zch, kpw, (long long)M * C, M, st));
+    // obj_out = ffn_norm(obj2 + sum partial + b2) (side output: the stage's kernels); cls_fcs[0] | mask_fcs[0] (raw, no bias)   :215-226
+    pr[0] = ks_prob(s.partial, C, pw.cls_fc[0], C, 8, eps);
+    pr[0].pro.nsum = zch; pr[0].pro.sum_stride = (long long)M * C;
+    pr[0].pro.pbias = w->ffn2_b; pr[0].pro.presid = s.t1; pr[0].pro.ldr = C;
+    pr[0].pro.ln_w[0] = w->ffn_norm_w; pr[0].pro.ln_b[0] = w->ffn_norm_b;
+    pr[1] = pr[0];
+    pr[0].pro.side_out = obj_out; pr[0].pro.ld_side = C;
+    pr[0].epi.out = s.lkv; pr[0].epi.ldo = 2 * C;
+    pr[1].Wsplit = pw.mask_fc[0]; pr[1].epi.out = s.lkv + C; pr[1].epi.ldo = 2 * C;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 2, 0, 0, 1, 0, M, st));
+    if (obj_ready && hipEventRecord(obj_ready, st) != hipSuccess) return VKN_E_LAUNCH;
+    // fc_cls(relu(LN(cls branch))) (+ sigmoid on the last stage) | folded decode kernels + bias from relu(LN(mask branch))     :217-227, :247
+    int np = 0;
+    if (w->fc_cls_w && cls_logits) {
+        pr[np] = ks_prob(s.lkv, 2 * C, pw.fc_cls, d->ncls, 8, eps);
+        pr[np].pro.ln_w[0] = w->cls_ln_w[0]; pr[np].pro.ln_b[0] = w->cls_ln_b[0]; pr[np].pro.act = 1;
+        pr[np].epi.bias = w->fc_cls_b; pr[np].epi.act = cls_sigmoid ? 2 : 0; pr[np].epi.out = cls_logits; pr[np].epi.ldo = d->ncls;
+        ++np;
+    }
+    pr[np] = ks_prob(s.lkv + C, 2 * C, pw.dec, C, 8, eps);
+    pr[np].pro.ln_w[0] = w->mask_ln_w[0]; pr[np].pro.ln_b[0] = w->mask_ln_b[0]; pr[np].pro.act = 1;
+    pr[np].pro.dot_vec = pw.dvec; pr[np].pro.dot_bias = pw.kb0; pr[np].pro.dot_out = s.kb;
+    pr[np].epi.bias = pw.decb; pr[np].epi.ldo = C;
+    if (kern32_out) pr[np].epi.out = kern32_out;
+    else { pr[np].epi.plane_hi = s.kfh; pr[np].epi.plane_lo = s.kfl; pr[np].epi.rows_per_frame = d->N; pr[np].epi.NPT = npt_of(d->N); }
+    ++np;
+    return vkn_launch_gemm_ks(pr, np, 0, 0, 1, 0, M, st);
+}
+
+// The link block LN(FFN(LN(cur + MHA_8(cur, kv)))) on the few-row kernels: q | k,v projections (one grouped launch), the attention,
+// out_proj + identity (raw), FFN first Linear with attention_previous_norm in its prologue (side output: the FFN's residual), the
+// second Linear z-split, and the closing LayerNorm as a row epilogue over the partial sums.   knet/video/kernel_update_head.py:394-415
+bool link_ks_ok(const VknDims* d, const VknStageWeights* w, const PrepW& pw, unsigned flags) {
+    if (flags & (VKN_FLAG_CHAIN_LAUNCHES | VKN_FLAG_CHAIN_PERSISTENT | VKN_FLAG_EXACT_GEMM)) return false;
+    if (vkn_dbg_env("VKN_CHAIN_LAUNCHES", 0) || !vkn_dbg_env("VKN_CHAIN_KSPLIT", 1)) return false;
+    if (!(flags & VKN_FLAG_CHAIN_KSPLIT) && (d->B * d->N + 31) / 32 > VKN_KS_MAX_ROW_TILES) return false;
+    if (d->C != 256 || d->ff % 256 != 0 || d->ff > 2048 || (d->ff % 512 != 0 && d->ff > 1024)) return false;
+    if (!pw.pa_in || !pw.pa_in_kv || !pw.pa_out || !pw.lffn1 || !pw.lffn2) return false;
+    if (!w->pa_norm_w || !w->pa_norm_b || !al16(w->pa_norm_w) || !al16(w->pa_norm_b)) return false;
+    return true;
+}
+
+int run_link_ks(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* cur, const float* kv, float* out,
+                const StageWs& s, hipStream_t st) {
+    const int M = d->B * d->N, C = d->C, FF = d->ff;
+    const float eps = d->ln_eps;
+    VknKsProb pr[2];
+    pr[0] = ks_prob(cur, C, pw.pa_in, C, 8, eps);                          // q = in_proj[:C](cur)
+    pr[0].epi.bias = w->pa_in_b; pr[0].epi.out = s.lq; pr[0].epi.ldo = C;
+    pr[1] = ks_prob(kv, C, pw.pa_in_kv, 2 * C, 8, eps);                    // k | v = in_proj[C:](kv)
+    pr[1].epi.bias = w->pa_in_b ? w->pa_in_b + C : nullptr; pr[1].epi.out = s.lkv; pr[1].epi.ldo = 2 * C;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 2, 0, 0, 1, 0, M, st));
+    VKN_TRY(vkn_launch_attn(s.lq, C, s.lkv, s.lkv + C, 2 * C, s.ao, C, d->B, d->N, d->N, 8, C / 8, st));        // _num_head = 8 (:165)
+    pr[0] = ks_prob(s.ao, C, pw.pa_out, C, 8, eps);                        // out_proj + identity (raw)
+    pr[0].epi.bias = w->pa_out_b; pr[0].epi.resid = cur; pr[0].epi.ldr = C; pr[0].epi.out = s.t1; pr[0].epi.ldo = C;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 1, 0, 0, 1, 0, M, st));
+    pr[0] = ks_prob(s.t1, C, pw.lffn1, FF, 8, eps);                        // t = attention_previous_norm(.) (side output); relu(W1 t + b1)
+    pr[0].pro.ln_w[0] = w->pa_norm_w; pr[0].pro.ln_b[0] = w->pa_norm_b;
+    pr[0].pro.side_out = s.lf; pr[0].pro.ld_side = C;
+    pr[0].epi.bias = w->lffn1_b; pr[0].epi.act = 1; pr[0].epi.out = s.h; pr[0].epi.ldo = FF;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 1, 0, 0, 1, 0, M, st));
+    const int kpw = (FF % 512 == 0) ? 2 : 1, zch = FF / (256 * kpw);
+    pr[0] = ks_prob(s.h, FF, pw.lffn2, C, FF / 32, eps);                   // W2 hidden, z-split
+    pr[0].epi.out = s.partial; pr[0].epi.ldo = C;
+    VKN_TRY(vkn_launch_gemm_ks(pr, 1, 0, zch, kpw, (long long)M * C, M, st));
+    VknEpi e = mk_epi(d);                                                   // link_ffn_norm(t + sum partial + b2)
+    e.bias = w->lffn2_b; e.resid = s.lf; e.ldr = C; e.ln_w = w->lffn_norm_w; e.ln_b = w->lffn_norm_b; e.out = out; e.ldo = C;
+    return vkn_launch_rowepi(s.partial, zch, M, C, e, st);
+}
+
 int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const float* obj_in, const float* masks_in,
               const float* prev_obj, float* cls_logits, float* masks_out, float* obj_out, float* x_feat_out,
               float* track_out, const StageWs& s, unsigned flags, hipStream_t st, const unsigned* bits_in = nullptr,
@@ -480,18 +647,25 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
     if (pre_link) {
         PrepW pl;
         VKN_TRY(carve_pw(d, so->link_pre, flags, &pl));
-        VKN_TRY(run_link(d, so->link_pre, pl, obj_in, so->prev_pre, s.lobj, s, st, so->link_pre->dyn_w ? xfeat : nullptr));  // (link_atten: no updator)
+        VKN_TRY(run_link(d, so->link_pre, pl, obj_in, so->prev_pre, s.lobj, s, st, so->link_pre->dyn_w ? xfeat : nullptr, flags));  // (link_atten: no updator)
         obj_in = s.lobj;
     }
 
     const float* kb = has_ft ? s.kb : nullptr;
-    const bool fast = comp && chain_fast_ok(d, w, pw, flags, w->fc_cls_w && cls_logits);
+    const bool fewrow = comp && chain_ks_ok(d, w, pw, flags, w->fc_cls_w && cls_logits);
+    const bool fast = fewrow || (comp && chain_fast_ok(d, w, pw, flags, w->fc_cls_w && cls_logits));
     if (fast) {
-        // (ii) + FC branches: k_chain_a -> attention -> k_chain_c (vkn_chain.hip); obj_out, cls, kb and the decode kernels are final
+        // (ii) + FC branches: few rows — nine column-spread GEMM phases + the attention (vkn_ksplit.hip); many rows — k_chain_a ->
+        // attention -> k_chain_c (vkn_chain.hip); obj_out, cls, kb and the decode kernels are final
         const bool raw = !xfeat_in;
-        VKN_TRY(run_chain_fast(d, w, pw, raw ? s.xraw : xfeat, raw, s.cnt, obj_in, obj_out, cls_logits, cls_sigmoid,
-                               ref_decode ? (chain_only ? kern_out : s.kern32) : nullptr, s, st));
-        if (obj_ready && hipEventRecord(obj_ready, st) != hipSuccess) return VKN_E_LAUNCH;
+        if (fewrow) {
+            VKN_TRY(run_chain_ks(d, w, pw, raw ? s.xraw : xfeat, raw, s.cnt, obj_in, obj_out, cls_logits, cls_sigmoid,
+                                 ref_decode ? (chain_only ? kern_out : s.kern32) : nullptr, s, st, obj_ready));
+        } else {
+            VKN_TRY(run_chain_fast(d, w, pw, raw ? s.xraw : xfeat, raw, s.cnt, obj_in, obj_out, cls_logits, cls_sigmoid,
+                                   ref_decode ? (chain_only ? kern_out : s.kern32) : nullptr, s, st));
+            if (obj_ready && hipEventRecord(obj_ready, st) != hipSuccess) return VKN_E_LAUNCH;
+        }
         if (chain_only) {
             if (kb_out && hipMemcpyAsync(kb_out, s.kb, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return VKN_E_LAUNCH;
@@ -505,9 +679,9 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
             if (so && so->link_track) {
                 PrepW pt;
                 VKN_TRY(carve_pw(d, so->link_track, flags, &pt));
-                VKN_TRY(run_link(d, so->link_track, pt, obj_out, prev_obj, track_out, s, st, so->track_src == 2 ? obj_out : xfeat));
+                VKN_TRY(run_link(d, so->link_track, pt, obj_out, prev_obj, track_out, s, st, so->track_src == 2 ? obj_out : xfeat, flags));
             } else {
-                VKN_TRY(run_link(d, w, pw, obj_out, prev_obj, track_out, s, st));
+                VKN_TRY(run_link(d, w, pw, obj_out, prev_obj, track_out, s, st, nullptr, flags));
             }
         }
         return VKN_OK;
@@ -637,9 +811,9 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
         if (so && so->link_track) {   // previous_type "update" (updator on x_feat) / "update_obj" (on obj_feat)        :417-476
             PrepW pt;
             VKN_TRY(carve_pw(d, so->link_track, flags, &pt));
-            VKN_TRY(run_link(d, so->link_track, pt, obj3, prev_obj, track_out, s, st, so->track_src == 2 ? obj3 : xfeat));
+            VKN_TRY(run_link(d, so->link_track, pt, obj3, prev_obj, track_out, s, st, so->track_src == 2 ? obj3 : xfeat, flags));
         } else {
-            VKN_TRY(run_link(d, w, pw, obj3, prev_obj, track_out, s, st));
+            VKN_TRY(run_link(d, w, pw, obj3, prev_obj, track_out, s, st, nullptr, flags));
         }
     }
     return VKN_OK;
@@ -1223,7 +1397,12 @@ static SideStream* side_stream() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     SideStream* p = &ss[dev];
     if (p->dev != dev) {
-        if (hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        // highest priority the device offers: the link's small launches must not queue behind the 100 k workgroups of the x4 upsample
+        // that runs beside them (round 4 trace: the link's first GEMM took 1.4 ms next to the upsample and the rest of the link
+        // finished AFTER it — 25 .. 240 us of tail per call)
+        int plo = 0, phi = 0;
+        if (hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess) plo = phi = 0;
+        if (hipStreamCreateWithPriority(&p->st, hipStreamNonBlocking, phi) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess) return nullptr;
         p->dev = dev;
@@ -1429,7 +1608,7 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
             VKN_TRY(carve_pw(d, w, flags, &pw));
             // previous_type "update": the link's own KernelUpdator turns (x_feat, previous kernels) into the keys / values (:417-445);
             // s.xfeat of the last stage is still intact (nothing after the stage's feat-transform GEMM writes it)
-            VKN_TRY(run_link(d, w, pw, obj_out, pv, track_out, sl, ls, so.link_track ? (track_src == 2 ? obj_out : s.xfeat) : nullptr));
+            VKN_TRY(run_link(d, w, pw, obj_out, pv, track_out, sl, ls, so.link_track ? (track_src == 2 ? obj_out : s.xfeat) : nullptr, flags));
             if (side) {
                 if (hipEventRecord(side->join, side->st) != hipSuccess) return VKN_E_LAUNCH;
                 joined = side;

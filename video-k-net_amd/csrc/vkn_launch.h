@@ -163,3 +163,46 @@ struct VknChainC {   // attention out_proj + LN, FFN + LN, cls / mask FCs, fc_cl
 int vkn_launch_gemm_t3(const VknGemmProb* probs, int nprob, int M, int K, hipStream_t stream);
 int vkn_launch_chain_a(const VknChainA& p, hipStream_t stream);
 int vkn_launch_chain_c(const VknChainC& p, hipStream_t stream);
+
+// ---- few-row chain (vkn_ksplit.hip): one GEMM phase per launch, column blocks over the chip, the contraction over the waves of a
+// workgroup; row-wise normalisation in the CONSUMER's prologue.  K = 256 per problem (or z-split chunks of 256 kpw).
+struct VknKsPro {            // how the A operand [M][256] of a phase is formed from what the previous phases stored
+    const float* a[4];       // MODE 0: a[0] (+ s * sum_stride, s < nsum); MODE 1: a[0] .* a[1]; MODE 2: gates a[0] (input), a[1] (update), a[2] = param_out, a[3] = input_out
+    int lda[4];
+    int nsum;                // MODE 0: number of summands (split-K partials of the producer), 1..4
+    long long sum_stride;    // floats between summands
+    const float* pbias;      // [256] or null, added before the LayerNorm
+    const float* presid;     // [M][ldr] or null, added before the LayerNorm
+    int ldr;
+    const float* ln_w[4];    // MODE 0: [0] or null; MODE 2: the LayerNorms of a[0..3]
+    const float* ln_b[4];
+    float eps;
+    int act;                 // MODE 0: 1 = ReLU after the LayerNorm
+    float* side_out;         // [M][ld_side] or null: the finished A rows are ALSO a result (written by column group 0)
+    int ld_side;
+    const float* dot_vec;    // [256]: dot_out[row] = A[row] . dot_vec (+ *dot_bias)   (written by column group 0)
+    const float* dot_bias;
+    float* dot_out;
+};
+struct VknKsEpi {
+    const float* bias;       // [Nout] or null
+    const float* rowscale;   // [M] or null: bias is multiplied by rowscale[row]
+    const float* bias2;      // [Nout] or null (unscaled)
+    const float* resid;      // [M][ldr] or null
+    int ldr;
+    int act;                 // 0 none, 1 relu, 2 sigmoid
+    float* out;              // [M][ldo] or null
+    int ldo;
+    _Float16* plane_hi;      // or null: f16 split planes [B][NPT][ldo]
+    _Float16* plane_lo;
+    int rows_per_frame, NPT;
+};
+struct VknKsProb {
+    VknKsPro pro;
+    const void* Wsplit;      // bf16x3 tile images of W [Nout][K]
+    int Nout;
+    int KT;                  // K / 32 of the weight (8; the z-split FFN second Linear: ff / 32)
+    VknKsEpi epi;
+};
+int vkn_launch_rowepi(const float* partial, int ks, int M, int Nout, const VknEpi& epi, hipStream_t stream);
+int vkn_launch_gemm_ks(const VknKsProb* probs, int nprob, int mode, int zchunks, int kpw, long long out_zstride, int M, hipStream_t stream);

@@ -712,6 +712,15 @@ int vkn_launch_ffn_fused(const float* X, int ldx, const void* W1s, const float* 
     return VKN_OK;
 }
 
+// (host) the row epilogue alone: out = epi(sum of `ks` partials [ks][M][Nout]) — the closing step of a z-split GEMM whose result has no
+// GEMM consumer (the tracking link's last LayerNorm, vkn_api.hip: run_link_ks)
+int vkn_launch_rowepi(const float* partial, int ks, int M, int Nout, const VknEpi& epi, hipStream_t stream) {
+    if (!partial || ks < 1 || M <= 0 || Nout <= 0 || Nout > 256) return VKN_E_ARG;
+    hipLaunchKernelGGL(k_rowepi, dim3((M + 3) / 4), dim3(256), 0, stream, partial, ks, M, Nout, epi);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
 // Row epilogue after a split-K GEMM: sums `ks` partials [ks][M][Nout] and applies the epilogue.  One wave per row, Nout <= 256.
 __global__ __launch_bounds__(256) void k_rowepi(const float* __restrict__ partial, int ks, int M, int Nout, VknEpi epi) {
     const int lane = threadIdx.x & 63;
@@ -919,11 +928,43 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, li = lane & 31;
-    // ---- stage K (rows) as three bf16 planes: a thread owns 4 channels of a key
-    for (int i = tid; i < NKP * (HD / 4); i += 256) {
+    // ---- every global load of the prologue is requested FIRST (K rows, V columns, the wave's queries): one round trip instead of
+    // one per staging-loop iteration (round 5: the loops ran load -> wait -> write eight times over, 8 of the kernel's 11 us)
+    constexpr int ITEMS = NKP * (HD / 4);    // staging items: (key, 4 channels) of K = (4 keys, channel) of V^T
+    constexpr int NIT = (ITEMS + 255) / 256; // ... per thread
+    f32x4 kreg[NIT];
+    float vreg[NIT][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = min(tid + 256 * it, ITEMS - 1);
         const int j = i / (HD / 4), d4 = i - j * (HD / 4);
-        f32x4 kv = {0.f, 0.f, 0.f, 0.f};
-        if (j < Nk) kv = *reinterpret_cast<const f32x4*>(Kp + ((size_t)b * Nk + j) * ldkv + h * HD + 4 * d4);
+        kreg[it] = *reinterpret_cast<const f32x4*>(Kp + ((size_t)b * Nk + min(j, Nk - 1)) * ldkv + h * HD + 4 * d4);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = min(tid + 256 * it, ITEMS - 1);
+        const int j4 = i / HD, d = i - j4 * HD;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vreg[it][e] = Vp[((size_t)b * Nk + min(4 * j4 + e, Nk - 1)) * ldkv + h * HD + d];
+    }
+    const int qb = blockIdx.z * 4 + wave;
+    f32x4 qreg[KS][2];
+    {
+        const int q = min(qb * 32 + li, Nq - 1);
+        const float* qp = Q + ((size_t)b * Nq + q) * ldq + h * HD + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qreg[ks][0] = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
+            qreg[ks][1] = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+        }
+    }
+    // ---- stage K (rows) as three bf16 planes: a thread owns 4 channels of a key
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        if (ITEMS % 256 != 0 && i >= ITEMS) break;
+        const int j = i / (HD / 4), d4 = i - j * (HD / 4);
+        const f32x4 kv = (j < Nk) ? kreg[it] : f32x4{0.f, 0.f, 0.f, 0.f};
         bf16x4 kh, km, kl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -940,14 +981,17 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
     }
     // ---- ... and V transposed with the keys permuted: a thread owns ONE channel of 4 consecutive keys — the permutation keeps
     // such a group contiguous, so each plane takes one 8-byte store (lanes = channels: the four row loads are coalesced)
-    for (int i = tid; i < (NKP / 4) * HD; i += 256) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        if (ITEMS % 256 != 0 && i >= ITEMS) break;
         const int j4 = i / HD, d = i - j4 * HD;
         const int j = 4 * j4, jj = j & 31;
         const int pos = (j & ~31) + 16 * (jj >> 4) + 8 * ((jj >> 2) & 1) + 4 * ((jj >> 3) & 1);
         bf16x4 vh, vm, vl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float v = (j + e < Nk) ? Vp[((size_t)b * Nk + j + e) * ldkv + h * HD + d] : 0.f;
+            const float v = (j + e < Nk) ? vreg[it][e] : 0.f;
             __bf16 hh, mm, ll;
             vkn_split_bf16x3(v, hh, mm, ll);
             vh[e] = hh;
@@ -965,25 +1009,18 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
             Vpl[(pl * DP + HD + r / NKP) * VLD + (r - (r / NKP) * NKP)] = (__bf16)0.f;
         }
     __syncthreads();
-    const int qb = blockIdx.z * 4 + wave;
     if (qb * 32 >= Nq) return;   // (no barrier below)
     // ---- the wave's 32 queries as B fragments: lane (g, li) = query li, channels 16 ks + 8 g .. + 7, scaled, split
     bf16x8 qh[KS], qm[KS], ql[KS];
-    {
-        const int q = min(qb * 32 + li, Nq - 1);
-        const float* qp = Q + ((size_t)b * Nq + q) * ldq + h * HD + 8 * g;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                __bf16 hh, mm, ll;
-                vkn_split_bf16x3((e < 4 ? a0[e] : a1[e - 4]) * scale, hh, mm, ll);
-                qh[ks][e] = hh;
-                qm[ks][e] = mm;
-                ql[ks][e] = ll;
-            }
+        for (int e = 0; e < 8; ++e) {
+            __bf16 hh, mm, ll;
+            vkn_split_bf16x3((e < 4 ? qreg[ks][0][e] : qreg[ks][1][e - 4]) * scale, hh, mm, ll);
+            qh[ks][e] = hh;
+            qm[ks][e] = mm;
+            ql[ks][e] = ll;
         }
     }
     // ---- S^T = K . Q^T: acc[kb][r] at lane (g, li) = score of key 32 kb + cd_row(r, lane) for query li
@@ -1017,7 +1054,8 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float* __restrict__ Q, 
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float ev = expf(acc[kb][r] - mx);   // (-inf -> 0)
+            const float ev = __expf(acc[kb][r] - mx);   // (-inf -> 0)  v_exp_f32 on x log2(e): exponent error <= |x| 9e-8, i.e. < 1 ulp on every term that is
+                                                          // not negligible against the row maximum; expf's ~12 instructions x 64 per lane were 1 us of this kernel
             acc[kb][r] = ev;
             sum += ev;
         }

@@ -19,6 +19,7 @@ FLAG_LOGITS_HANDOFF = 4
 FLAG_BITS_HANDOFF = 16
 FLAG_CHAIN_LAUNCHES = 256    # the [N x C] chain always as one launch per GEMM (default: by row count, include/vkn.h)
 FLAG_CHAIN_PERSISTENT = 512  # ... always as the two persistent row-owner kernels (vkn_chain.hip)
+FLAG_CHAIN_KSPLIT = 8192     # ... always as the few-row chain: column-spread GEMM phases, normalisation in the consumer (vkn_ksplit.hip)
 FLAG_SERIAL_LINK = 32   # tracking link on the caller's stream instead of the library's side stream (A/B; same results)
 
 _tls = threading.local()

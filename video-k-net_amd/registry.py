@@ -94,13 +94,28 @@ except Exception:  # noqa: BLE001  (mmcv/mmdet are not installed in the build im
 
 
 def _register_training_components():
-    """Losses / assigner / sampler of the training path into the bundled registries (with mmdet present its own are used; the
-    reference's `knet/cross_entropy_loss.py` and assigner / sampler modules register themselves there)."""
-    if HAVE_MM:
-        return
+    """Losses / assigner / sampler of the training path.  Bundled registries: all of ours.  With mmdet present: OUR assigners and
+    sampler replace the reference's in mmdet's own `BBOX_ASSIGNERS` / `BBOX_SAMPLERS` (force=True — our heads call
+    `assigner.assign_batch` and read device-side results, an interface the reference's `MaskHungarianAssigner`
+    (knet/det/mask_hungarian_assigner.py:188-274, CPU scipy) does not have), and our losses fill in only the `LOSSES` names mmdet
+    lacks (mmdet's FocalLoss / CrossEntropyLoss / DiceLoss are the reference's own choice and stay)."""
     from . import losses
     from .mask_hungarian_assigner import MaskHungarianAssigner, MaskHungarianAssignerVideo
     from .mask_pseudo_sampler import MaskPseudoSampler
+    if HAVE_MM:
+        from mmdet.core.bbox.builder import BBOX_ASSIGNERS as mm_assigners, BBOX_SAMPLERS as mm_samplers  # type: ignore
+        from mmdet.models.builder import LOSSES as mm_losses  # type: ignore
+        try:
+            import mmdet.models.losses  # noqa: F401  (mmdet's own losses register on import; `mmdet.models` does this itself in 2.18)
+        except ImportError:
+            pass
+        for cls in (MaskHungarianAssigner, MaskHungarianAssignerVideo):
+            mm_assigners.register_module(force=True)(cls)
+        mm_samplers.register_module(force=True)(MaskPseudoSampler)
+        for cls in (losses.FocalLoss, losses.CrossEntropyLoss, losses.DiceLoss):
+            if mm_losses.get(cls.__name__) is None:
+                mm_losses.register_module()(cls)
+        return
     for cls in (losses.FocalLoss, losses.CrossEntropyLoss, losses.DiceLoss):
         LOSSES.register_module(force=True)(cls)
     BBOX_ASSIGNERS.register_module(force=True)(MaskHungarianAssigner)

@@ -223,7 +223,11 @@ class QuasiDenseMaskEmbedHeadGTMask(nn.Module):
 
 
 def _register_losses():
-    if HAVE_MM:       # with mmdet present the reference's own loss modules register themselves
+    if HAVE_MM:       # with mmdet present: fill in what its LOSSES registry lacks (the reference's own qdtrack loss modules, if the
+        from mmdet.models.builder import LOSSES as mm_losses  # type: ignore   # user imports them too, stay registered)
+        for cls in (MultiPosCrossEntropyLoss, L2Loss):
+            if mm_losses.get(cls.__name__) is None:
+                mm_losses.register_module()(cls)
         return
     from .registry import LOSSES
     LOSSES.register_module(force=True)(MultiPosCrossEntropyLoss)
