@@ -304,6 +304,8 @@ typedef struct VknUpdatorNorms {
 typedef struct VknUpdatorNormGrads {
     float *norm_in_w, *norm_in_b, *norm_out_w, *norm_out_b, *input_norm_in_w, *input_norm_in_b, *input_norm_out_w, *input_norm_out_b;
 } VknUpdatorNormGrads;
+size_t vkn_sizeof_updator_norms(void);       /* sizeof(VknUpdatorNorms) / sizeof(VknUpdatorNormGrads) as compiled (binding self-check) */
+size_t vkn_sizeof_updator_norm_grads(void);
 int vkn_updator_gate_product_f32(const float* params, const float* inputs, float* gate_feats, int M, int C, void* stream);
 int vkn_updator_gate_product_bwd_f32(const float* d_gate_feats, const float* params, const float* inputs, float* d_params, float* d_inputs,
                                      int M, int C, void* stream);

@@ -129,7 +129,7 @@ CASES = {
     'video_latt_updobj_tiny': dict(video=True, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=2, nprop=12, N=15, H=8, W=16,
                                    B=2, seed=17, plink='link_atten', ptype='update_obj'),
     # BASELINE cfg5 as literally worded: 150 proposals + 66 stuff kernels = 216 rows (the reference's VIP-Seg config has 100 + 66)
-    'video_vipseg_n216': dict(video=True, C=256, heads=8, ffn=2048, ncls=124, n_thing=58, n_stuff=66, S=3, up=4, nprop=150, N=216, H=46, W=80,
+    'video_vipseg_n216': dict(video=True, C=256, heads=8, ffn=2048, ncls=124, n_thing=58, n_stuff=66, S=3, up=4, nprop=150, N=216, H=92, W=160,
                               B=1, seed=14),
     'det_ytvis': dict(video=False, C=256, heads=8, ffn=2048, ncls=40, n_thing=40, n_stuff=0, S=3, up=2, nprop=100, N=100, H=48, W=80, B=2,
                       seed=9),

@@ -254,7 +254,7 @@ FREE_RUN_LIMITS = {
 @pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent'])
 @pytest.mark.parametrize('name', ['video_vipseg_big', 'det_ytvis', 'video_vipseg_n216'])
 def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name, chain):
-    """(`video_vipseg_n216`: BASELINE cfg5 as LITERALLY worded — 150 proposals + 66 stuff kernels = 216 rows, 46x80 features.)
+    """(`video_vipseg_n216`: BASELINE cfg5 as LITERALLY worded — 150 proposals + 66 stuff kernels = 216 rows, 92x160 features (round 5; 46x80 before).)
     BASELINE cfg5 at its real size (video_knet_s3_swinb VIP-Seg: N = 166 = 100 + 66 kernels -> two n-chunks, C = 256, 92x160
     features, 124 classes, x4, tracking link) and the cfg4 per-frame shape (YouTube-VIS: N = 100, 48x80, 40 thing classes, no
     stuff, x2, 2 frames): the free-running 3-stage fused head against the REFERENCE's own outputs."""
@@ -497,6 +497,71 @@ def test_cfg2_size_head_vs_oracle(vkn, chain):
             o2, m2 = r['object_feats'], r['mask_preds']
     assert torch.equal(masks, m2) and torch.equal(obj, o2) and torch.equal(scaled, r['scaled_mask_preds'])
     assert torch.equal(track, r['object_feats_track']) and torch.equal(cls, r['cls_score'].sigmoid())
+
+
+def test_cfg2_size_batch_of_32_default_policy_vs_oracle(vkn):
+    """the bench's ACTUAL path at BASELINE cfg2 size — 32 frames per call, default policy (3744 rows: the persistent
+    row-owner chain, the fused decode -> gather pass, the in-call clip link) — against the CPU oracle.  Two distinct frames A / B are
+    run through the oracle; the batch holds 16 copies of each (A B A B ...).  Teacher-forced per stage (every stage gets the oracle's
+    previous-stage outputs, tiled over the batch): frames 0 and 1 meet the oracle within the parity tolerances, and every other
+    frame is BIT-IDENTICAL to its twin (batch invariance: the position of a frame in the batch changes nothing).  Then the fused
+    32-frame call is bit-identical to the GPU's own stage-by-stage path."""
+    B = 32
+    base = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256, B=1, video=1)
+    cases = [dict(base, seed=21), dict(base, seed=22)]
+    head, _ = _build_head(vkn, cases[0])                 # (weights depend on the seed: both frames run under frame A's weights)
+    cfg, sd, *_ = make_case(cases[0])
+    ins, traces, tracks = [], [], []
+    for c in cases:
+        _, _, x, pf, mp, prev = make_case(c)
+        tr = []
+        with torch.no_grad():
+            import oracle.knet_oracle as O
+            tracks.append(O.iter_head_mask_preds(sd, x, pf, mp, cfg, previous_obj_feats=prev, traces=tr)[4])
+        ins.append((x, pf, mp, prev))
+        traces.append(tr)
+
+    def tile(a, b):      # [1, ...] x 2 -> [32, ...]: A B A B ...
+        return torch.cat([a, b], 0).repeat(B // 2, *([1] * (a.dim() - 1)))
+
+    xd = tile(ins[0][0], ins[1][0]).to(DEV)
+    prevd = tile(ins[0][3], ins[1][3]).to(DEV)
+    obj_in, m_in = tile(ins[0][1], ins[1][1]), tile(ins[0][2], ins[1][2])
+    metas = [dict()] * B
+    with torch.no_grad():
+        for s in range(3):
+            kw = dict(previous_obj_feats=prevd) if s == 2 else {}
+            r = head._mask_forward(s, xd, obj_in.to(DEV), m_in.to(DEV), metas, **kw)
+            for f in (0, 1):
+                tr = traces[f][s]
+                assert maxabs(r['x_feats'][f:f + 1], tr['x_feat']) < 2e-5 * float(tr['x_feat'].abs().max()), f'stage {s} frame {f} x_feat'
+                assert maxabs(r['object_feats'][f:f + 1], tr['obj_feat']) < 1e-4, f'stage {s} frame {f} obj'
+                assert maxabs(r['cls_score'][f:f + 1], tr['cls_score']) < 1e-4, f'stage {s} frame {f} cls'
+                assert maxabs(r['mask_preds'][f:f + 1], tr['new_mask_preds']) < TOL_LOGIT, f'stage {s} frame {f} mask logits'
+                mr = tr['new_mask_preds'].numpy()
+                margin = np.abs(mr) > 2e-3
+                assert np.array_equal((r['mask_preds'][f:f + 1].cpu().numpy() > 0)[margin], (mr > 0)[margin]), f'stage {s} frame {f} binary masks'
+            for k in ('x_feats', 'object_feats', 'cls_score', 'mask_preds'):
+                t = r[k]
+                assert torch.equal(t[0::2], t[0:1].expand_as(t[0::2])) and torch.equal(t[1::2], t[1:2].expand_as(t[1::2])), f'stage {s} {k}: batch invariance'
+            obj_in = tile(traces[0][s]['obj_feat'], traces[1][s]['obj_feat'])                 # teacher forcing
+            m_in = tile(traces[0][s]['new_mask_preds'], traces[1][s]['new_mask_preds'])
+        for f in (0, 1):
+            assert maxabs(r['object_feats_track'][f:f + 1], tracks[f]) < 1e-4   # (teacher-forced last stage == the free-running oracle's last stage inputs)
+        del r
+        torch.cuda.empty_cache()
+        # the fused 32-frame call (one C call: persistent chain, fused passes, side-stream link) == the GPU's stage-by-stage path, bit for bit
+        x0, pf0, mp0, prev0 = xd, tile(ins[0][1], ins[1][1]).to(DEV), tile(ins[0][2], ins[1][2]).to(DEV), prevd
+        obj, cls, masks, scaled, track = head._head_forward(x0, pf0, mp0, prev0, want_track=True)
+        o2, m2 = pf0, mp0
+        for s in range(3):
+            kw = dict(previous_obj_feats=prev0) if s == 2 else {}
+            r = head._mask_forward(s, x0, o2, m2, metas, **kw)
+            o2, m2 = r['object_feats'], r['mask_preds']
+        assert torch.equal(masks, m2) and torch.equal(obj, o2) and torch.equal(scaled, r['scaled_mask_preds'])
+        assert torch.equal(track, r['object_feats_track']) and torch.equal(cls, r['cls_score'].sigmoid())
+        assert torch.equal(masks[0::2], masks[0:1].expand_as(masks[0::2])) and torch.equal(masks[1::2], masks[1:2].expand_as(masks[1::2]))
+    head.check_status()
 
 
 # ------------------------------------------------------------------------------------------ kernel initialisation ("pass 0")

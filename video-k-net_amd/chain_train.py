@@ -606,6 +606,39 @@ def _owners(linears, named_params):
     return out
 
 
+LN_MAX_WIDTH = 256       # vkn_layernorm_act_*: 64 lanes x LN_MAXV values
+ATTN_BWD_MAX_KEYS = 256  # vkn_attention_bwd_f32: AB_THREADS / 2 keys per query
+
+
+def supported(head, num_kernels=None):
+    """Can `chain_forward` run this head's chain on the library's kernels?  Linear in-features % 32 (tile images), LayerNorm widths <=
+    256, head width a power of two in 4..64, one eps for the updator's norms, at most 256 kernels per frame in the attention
+    backward.  `KernelUpdateHead._chain_impl` asks once per (head, kernel count) and takes the torch autograd chain when this is
+    False instead of raising in the middle of a training step."""
+    C = head.in_channels
+    if head.conv_kernel_size != 1 or C % 32 or C > LN_MAX_WIDTH:
+        return False
+    try:
+        lin = chain_linears(head, hasattr(head, 'attention_previous') and getattr(head, 'attention_previous', None) is not None)
+    except Exception:  # noqa: BLE001  (a module tree this function does not know)
+        return False
+    for w, _ in lin:
+        if w.dim() != 2 or w.shape[1] % 32:
+            return False
+    for m in head.modules():
+        if isinstance(m, nn.LayerNorm) and (len(m.normalized_shape) != 1 or m.normalized_shape[0] > LN_MAX_WIDTH):
+            return False
+    ku = head.kernel_update_conv
+    if len({n.eps for n in (ku.norm_in, ku.norm_out, ku.input_norm_in, ku.input_norm_out)}) != 1:
+        return False
+    hd = C // head.num_heads
+    if C % head.num_heads or hd < 4 or hd > 64 or (hd & (hd - 1)):
+        return False
+    if num_kernels is not None and num_kernels > ATTN_BWD_MAX_KEYS:
+        return False
+    return True
+
+
 def chain_forward(head, x_feat, proposal_feat, previous_obj_feats=None):
     """`KernelUpdateHead._chain_autograd` on the library's kernels: same arguments, same five results."""
     B, N = proposal_feat.shape[:2]

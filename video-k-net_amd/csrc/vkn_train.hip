@@ -1129,6 +1129,8 @@ int vkn_split_weights_batch_f32(const VknSplitItem* items, int nitems, void* str
 size_t vkn_sizeof_split_item(void) { return sizeof(VknSplitItem); }
 
 size_t vkn_sizeof_dw_item(void) { return sizeof(VknDwItem); }
+size_t vkn_sizeof_updator_norms(void) { return sizeof(VknUpdatorNorms); }
+size_t vkn_sizeof_updator_norm_grads(void) { return sizeof(VknUpdatorNormGrads); }
 
 int vkn_linear_dw_batch_f32(const VknDwItem* items, int nitems, int M, void* stream) {
     if (!items || nitems <= 0 || nitems > VKN_DW_MAX_ITEMS || M <= 0) return VKN_E_ARG;

@@ -584,10 +584,17 @@ class VideoKernelIterHead(KernelIterHead):
         def run(name, prev):
             bit = {'A': ops.PHASE_A, 'B': ops.PHASE_B, 'C': ops.PHASE_C}[name]
             p = prev if prev is not None else pf.new_zeros(1, N, C)      # (phase A never reads it: no cross-frame input yet)
+            # the gather sums and stage S-2's kernels live in this (thread, device, stream)'s workspace between the phases: a phase on
+            # another stream, or a larger call in between that re-allocated the buffer, would read garbage — loud instead
+            key = (torch.cuda.current_stream(x.device).cuda_stream, ops.workspace_generation(x.device))
+            if name != 'A' and state.get('ws_key') not in (None, key):
+                raise RuntimeError('linked_block_phases: the workspace that holds the state of phase A was re-allocated (or the stream '
+                                   'changed) before phase %s — run the three phases of a block on one stream, with no larger call between them' % name)
             state['out'] = ops.head_forward(dims, packs, x, pf, mask_preds, None, last.mask_upsample_stride, want_scaled=want_scaled,
                                             flags=getattr(h0, 'vkn_flags', 0), clip_first_prev=p.reshape(1, N, C), link_pre=link_pre,
                                             link_track=link_track, track_src=track_src, phase=bit, out=state.get('out'))
             obj, cls, masks, scaled, track = state['out']
+            state['ws_key'] = (torch.cuda.current_stream(x.device).cuda_stream, ops.workspace_generation(x.device))
             if name == 'B':
                 return obj
             if name == 'C':

@@ -414,7 +414,16 @@ class KernelUpdateHead(nn.Module):
 
     def _chain_impl(self, x_feat, proposal_feat, previous_obj_feats=None):
         if self.device_chain and x_feat.is_cuda:
-            return chain_train.chain_forward(self, x_feat, proposal_feat, previous_obj_feats)
+            # a shape the library's training kernels do not take (odd widths, wide LayerNorms, > 256 kernels per frame) runs the torch
+            # autograd chain instead of raising in the middle of a step; asked once per (head, kernel count)
+            key = int(proposal_feat.shape[1])
+            ok = self._chain_supported.get(key) if hasattr(self, '_chain_supported') else None
+            if ok is None:
+                if not hasattr(self, '_chain_supported'):
+                    self._chain_supported = {}
+                ok = self._chain_supported[key] = chain_train.supported(self, key)
+            if ok:
+                return chain_train.chain_forward(self, x_feat, proposal_feat, previous_obj_feats)
         return self._chain_autograd(x_feat, proposal_feat, previous_obj_feats)
 
     def _forward_autograd(self, x, proposal_feat, mask_preds, previous_obj_feats=None):

@@ -74,10 +74,25 @@ def _workspace(nbytes, device, scratch=False):
     buf = cache.get(key)
     need = int(nbytes) + 256
     if buf is None or buf.numel() < need:
+        old = buf
         buf = torch.empty(max(need, 512), dtype=torch.uint8, device=device)
-        buf[:256].zero_()          # the workspace header: its first word is the status word the kernels OR into (include/vkn.h)
+        if old is None:
+            buf[:256].zero_()      # the workspace header: its first word is the status word the kernels OR into (include/vkn.h)
+        else:
+            buf[:256].copy_(old[:256])   # regrow: a sticky VKN_STATUS_RANGE nobody has read yet moves with the header (same stream: ordered)
         cache[key] = buf
+        gen = getattr(_tls, 'ws_gen', None)
+        if gen is None:
+            gen = _tls.ws_gen = {}
+        gen[key] = gen.get(key, 0) + 1   # `workspace_generation`: state kept in the buffer between calls (PHASE_A/B/C) dies with a regrow
     return buf[256:] if scratch else buf
+
+
+def workspace_generation(device):
+    """How often this (thread, device, stream)'s workspace has been (re)allocated.  The phased clip call (PHASE_A / B / C) keeps state
+    in the workspace between its three calls: a caller compares the generation before B / C with the one after A."""
+    gen = getattr(_tls, 'ws_gen', None) or {}
+    return gen.get((device, torch.cuda.current_stream(device).cuda_stream), 0)
 
 
 def workspace_status(device=None):

@@ -132,11 +132,15 @@ class QuasiDenseEmbedTracker:
         E = self._cfg.embed_dim if self._cfg is not None else 0
         boxes = [t['bbox'][None] for t in tr.values()] + [b['bboxes'] for b in bd]
         embs = [t['embed'][None] for t in tr.values()] + [b['embeds'] for b in bd]
-        labs = [torch.tensor([t['label']]) for t in tr.values()] + [b['labels'].long() for b in bd]
+        ref = next((t['embed'] for t in tr.values()), None)
+        if ref is None:
+            ref = next((b['embeds'] for b in bd), torch.zeros(0))
+        dev, fdt = ref.device, (ref.dtype if ref.is_floating_point() else torch.float32)      # everything on the entries' device / dtype
+        labs = [torch.tensor([t['label']], device=dev) for t in tr.values()] + [b['labels'].long().to(dev) for b in bd]
         nb = sum(int(b['bboxes'].shape[0]) for b in bd)
-        ids = torch.tensor(list(tr.keys()) + [-1] * nb, dtype=torch.long)
-        vs = [t['velocity'][None] for t in tr.values()] + [torch.zeros(nb, 5)]
-        cat = lambda xs, shape: torch.cat(xs) if xs else torch.zeros(shape)
+        ids = torch.tensor(list(tr.keys()) + [-1] * nb, dtype=torch.long, device=dev)
+        vs = [t['velocity'][None] for t in tr.values()] + [torch.zeros(nb, 5, device=dev, dtype=fdt)]
+        cat = lambda xs, shape: torch.cat([x.to(dev) for x in xs]) if xs else torch.zeros(shape, device=dev, dtype=fdt)
         return dict(bboxes=cat(boxes, (0, 5)), labels=cat(labs, (0,)).long(), embeds=cat(embs, (0, E)), ids=ids,
                     vs=cat(vs, (0, 5)))
 

@@ -167,8 +167,9 @@ class QuasiDenseMaskEmbedHeadGTMask(nn.Module):
         if x.numel() == 0:       # a frame without thing segments (the reference's `view(0, -1)` cannot even express this)
             return x.new_zeros((0, self.embed_channels))
         x = x.reshape(x.size(0), -1)
-        if x.requires_grad and torch.is_grad_enabled() or (self.training and torch.is_grad_enabled()
-                                                           and any(p.requires_grad for p in self.parameters())):
+        # the rule of KernelUpdateHead._needs_grad: grad mode on and anything differentiable in sight (input OR parameter) — eval() with
+        # grad enabled and trainable parameters is differentiable too
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             if not x.is_cuda:
                 raise _lib.VknLibraryError('QuasiDenseMaskEmbedHeadGTMask: expected CUDA/HIP tensors — the MI355X path has no CPU fallback')
             for fc in self.fcs:
