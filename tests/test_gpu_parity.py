@@ -236,7 +236,8 @@ def test_head_cfg1_size_vs_reference_golden(vkn):
 # Round 5: the limits are anchored on the REFERENCE ALGORITHM'S OWN re-ordering noise (tools/oracle_reorder_noise.py ->
 # profiles/r05_oracle_reorder_noise.json: the CPU oracle against the reference goldens with nothing changed but the fp32 summation
 # order — permuted input channels of the 1x1 conv, 1 / 16 intra-op threads).  video_vipseg_big: the oracle itself lands at 0.964 of the
-# rows within 2e-4 and 39 wrong off-threshold bits with ONE thread (1.000 / 0 with eight); video_vipseg_n216: 0.662 / 30 bits.  Round 4
+# rows within 2e-4 and 39 wrong off-threshold bits with ONE thread (1.000 / 0 with eight); video_vipseg_n216 (92x160 since round 5):
+# 0.9815 .. 1.0 / 0 .. 41 bits over six re-orderings — our three chain forms measure 0.9815 / 41, the SAME pixels.  Round 4
 # had set "2 x what our two chain forms happened to measure" (14 bits), which the third form (few-row chain: 0.958 / 45 bits, worst
 # clean-row errors 5.8e-5 / 5.7e-4 — and the smallest error of all forms against fp64, tools/chain_accuracy.py) missed by chance, exactly
 # like the reference with another thread count would.  Limits = the worse of (our forms, the oracle's re-orderings) with ~2x head-room
@@ -246,8 +247,8 @@ FREE_RUN_LIMITS = {
                              wrong_bits_off_threshold=90, worst_clean_kernel_err=1.2e-4, worst_clean_sampled_logit_err=1.0e-3),
     'det_ytvis': dict(clean_share_of_stable=0.99, share_rows_kernels_within_2e4=1 - 2 / 200, share_rows_sampled_logits_within_1e3=1 - 2 / 200,
                       wrong_bits_off_threshold=2, worst_clean_kernel_err=1.2e-5, worst_clean_sampled_logit_err=1.0e-4),
-    'video_vipseg_n216': dict(clean_share_of_stable=0.99, share_rows_kernels_within_2e4=1 - 3 / 216, share_rows_sampled_logits_within_1e3=1 - 3 / 216,
-                              wrong_bits_off_threshold=14, worst_clean_kernel_err=1.0e-4, worst_clean_sampled_logit_err=1.0e-3),
+    'video_vipseg_n216': dict(clean_share_of_stable=0.99, share_rows_kernels_within_2e4=0.96, share_rows_sampled_logits_within_1e3=0.96,
+                              wrong_bits_off_threshold=90, worst_clean_kernel_err=1.2e-4, worst_clean_sampled_logit_err=1.0e-3),
 }
 
 

@@ -43,6 +43,8 @@ def test_registry_resolves_our_training_components_under_mmdet():
         'assert type(l).__module__.startswith("mmdet."), "mmdet\'s own FocalLoss stays: " + type(l).__module__\n'
         'h = vkn.build_head(vkn.configs.roi_head_cfg(True, train_cfg=vkn.configs.rcnn_train_cfg(3)))\n'
         'assert all(type(x) is vkn.MaskHungarianAssigner for x in h.mask_assigner)\n'
+        'c = build_loss(dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0))\n'
+        'assert type(c).__module__.startswith("video_k_net_amd"), "the reference overrides mmdet\'s CrossEntropyLoss (force=True): so do we"\n'
         'print("ok")\n') % (STANDINS, ROOT)
     r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))

@@ -60,6 +60,30 @@ def main():
             for rep in range(args.reps):
                 ts = [timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob, flags=getattr(vkn.ops, fl))) for _, fl in FORMS]
                 print(f'B={B:3d} rows={B * N:5d}  ' + '   '.join(f'{nm} {t:7.1f}' for (nm, _), t in zip(FORMS, ts)))
+    if 'abl11' in what:      # needs --debug-lib.  VERDICT r04 item 4, the prize measured before the work: the persistent chain with TWO
+        # split terms per operand (4 bytes / weight, 3 products per operand pair instead of 6 bytes / 6 products) — VKN_CHAIN_ABL=11 keeps
+        # everything else (activation images, epilogues, ring) and produces WRONG numbers (bf16 x 2 precision); only its time counts
+        print('== persistent chain, three-term split (shipped) vs the traffic / MFMA count of a two-term split (VKN_CHAIN_ABL=11) ==')
+        for B in (32, 64):
+            dims = head.mask_head[0].make_dims(B, N, H, W)
+            pack = head.mask_head[0].stage_pack(torch.device(DEV))
+            xf = (torch.randn(B, N, C, generator=g) * 50).to(DEV)
+            ob = torch.randn(B, N, C, generator=g).to(DEV)
+            x = torch.randn(B, C, H, W, generator=g).to(DEV) if B == 32 else None
+            pf = torch.randn(B, N, C, 1, 1, generator=g).to(DEV) if B == 32 else None
+            mp = (torch.randn(B, N, H, W, generator=g) * 4).to(DEV) if B == 32 else None
+            prev = torch.randn(B, N, C, 1, 1, generator=g).to(DEV) if B == 32 else None
+            for rep in range(2):
+                for abl in (0, 11):
+                    os.environ['VKN_CHAIN_ABL'] = str(abl)
+                    t = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob, flags=vkn.ops.FLAG_CHAIN_PERSISTENT))
+                    line = f'B={B:3d} rows={B * N:5d} ABL={abl:2d}  chain alone {t:7.1f} us per stage'
+                    if x is not None:
+                        with torch.no_grad():
+                            th = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True), iters=20, warm=5)
+                        line += f'   head step {th / 1e3:7.3f} ms = {B / th * 1e6:7.0f} frames/s'
+                    print(line)
+        os.environ['VKN_CHAIN_ABL'] = '0'
     if 'head' in what:
         print('== whole head step (3 stages + link + x4 upsample), ms per call ==')
         for B in frames:

@@ -80,7 +80,9 @@ __device__ __forceinline__ ChLane ch_lane(int tid) {
 #define CH_AUX_OF(ABL) ((ABL) == 7 ? 2 : (ABL) == 8 ? 16 : (ABL) == 9 ? 17 : (ABL) == 10 ? 1 : 0)   /* 8 / 9 / 10: the FULL kernel with sc1 / sc0 sc1 / sc0 loads */
 #define CH_NOMFMA(ABL) ((ABL) == 1 || (ABL) == 4 || (ABL) == 5 || (ABL) == 6 || (ABL) == 7)
 #define CH_NOLOAD(ABL) ((ABL) == 2 || (ABL) == 4)
+#define CH_NP_OF(ABL) ((ABL) == 11 ? 2 : 3)   /* 11: the cost of a two-term split (4 B / weight, 3 products): the prize of VERDICT r04 item 4 */
 #else
+#define CH_NP_OF(ABL) 3
 #define CH_RING_OF(ABL) 4
 #define CH_AUX_OF(ABL) 0
 #define CH_NOMFMA(ABL) false
@@ -92,12 +94,13 @@ struct ChRing {
 };
 
 // the six fragments (2 k-steps x 3 planes) of this wave's column block of the tile at byte offset `toff` of the weight buffer
-template <int RING, int AUX = 0>
+// NP (debug build, VKN_CHAIN_ABL 11): planes loaded per fragment — 2 = the traffic of a two-term (4 bytes / weight) split
+template <int RING, int AUX = 0, int NP = 3>
 __device__ __forceinline__ void ch_wload(ChRing<RING>& R, const int slot, const __amdgpu_buffer_rsrc_t wrs, const ChLane& L, unsigned toff) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
             R.r[slot][ks * 3 + p] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)L.woff, (int)(toff + (unsigned)((p * 4 + 2 * ks) * 4096)), AUX);
 }
 
@@ -121,6 +124,15 @@ __device__ __forceinline__ void ch_mfma6(f32x16& acc, const ChRing<RING>& R, con
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, am, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
+}
+// (debug build, VKN_CHAIN_ABL 11: WRONG results by construction — bf16 x 2 precision) the three products of a two-term split
+template <int RING>
+__device__ __forceinline__ void ch_mfma3(f32x16& acc, const ChRing<RING>& R, const int slot, const int ks, const cbf16x8& ah, const cbf16x8& am) {
+    const cbf16x8 wh = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 0]);
+    const cbf16x8 wm = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 1]);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
@@ -159,9 +171,9 @@ __device__ __forceinline__ void ch_gemm(f32x16 (&acc)[NACC], const __bf16* img0,
             if (CH_NOLOAD(ABL)) {
             } else if (un < NU) {
                 const int an = (NACC == 2) ? (un & 1) : 0, ktn = (NACC == 2) ? (un >> 1) : un;
-                ch_wload<RING, AUX>(R, (j + RING - 1) % RING, wrs, L, ((NACC == 2 && an) ? base1 : base0) + (unsigned)ktn * CH_WTILE);
+                ch_wload<RING, AUX, CH_NP_OF(ABL)>(R, (j + RING - 1) % RING, wrs, L, ((NACC == 2 && an) ? base1 : base0) + (unsigned)ktn * CH_WTILE);
             } else if (nx.nacc) {
-                ch_wload<RING, AUX>(R, (j + RING - 1) % RING, wrs, L, nx.off(un - NU));
+                ch_wload<RING, AUX, CH_NP_OF(ABL)>(R, (j + RING - 1) % RING, wrs, L, nx.off(un - NU));
             }
             // (Measured and dropped, round 4: one extra dword load per unit that touches the 48 cache lines of the unit 4 / 8 / 12 ahead,
             //  to cover the memory-side latency inside a head step — 3.44 / 3.42-3.53 / 3.49 ms per 32-frame step against 3.38 without:
@@ -180,6 +192,9 @@ __device__ __forceinline__ void ch_gemm(f32x16 (&acc)[NACC], const __bf16* img0,
 #pragma unroll
                 for (int f = 0; f < 6; ++f) asm volatile("" ::"v"(R.r[j][f]));
                 asm volatile("" ::"v"(ah[0]), "v"(am[0]), "v"(al[0]), "v"(ah[1]), "v"(am[1]), "v"(al[1]));
+            } else if (VKN_ABL_IS(ABL, 11)) {
+                ch_mfma3(acc[a], R, j, 0, ah[0], am[0]);
+                ch_mfma3(acc[a], R, j, 1, ah[1], am[1]);
             } else {
                 ch_mfma6(acc[a], R, j, 0, ah[0], am[0], al[0]);
                 ch_mfma6(acc[a], R, j, 1, ah[1], am[1], al[1]);
@@ -398,7 +413,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     {   // the first RING - 1 units of the dynamic_layer GEMM (unit u = column tile u & 1 of K-tile u >> 1)
         const ChNext first{A.off_dyn, A.off_dyn + 8u * CH_WTILE, 2};
 #pragma unroll
-        for (int j = 0; j < RING - 1; ++j) ch_wload<RING, CH_AUX_OF(ABL)>(R, j, wrs, L, first.off(j));
+        for (int j = 0; j < RING - 1; ++j) ch_wload<RING, CH_AUX_OF(ABL), CH_NP_OF(ABL)>(R, j, wrs, L, first.off(j));
         if (CH_NOLOAD(ABL)) ch_wload<RING>(R, RING - 1, wrs, L, A.off_dyn);   // (ablation: the ring is never refilled; defined contents)
     }
     ch_stage_consts<CA_TOTAL>(CST, A.consts, tid);
@@ -564,7 +579,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     {
         const ChNext first{A.off_out, 0u, 1};
 #pragma unroll
-        for (int j = 0; j < RING - 1; ++j) ch_wload<RING, CH_AUX_OF(ABL)>(R, j, wrs, L, first.off(j));
+        for (int j = 0; j < RING - 1; ++j) ch_wload<RING, CH_AUX_OF(ABL), CH_NP_OF(ABL)>(R, j, wrs, L, first.off(j));
         if (CH_NOLOAD(ABL)) ch_wload<RING>(R, RING - 1, wrs, L, A.off_out);
     }
     ch_stage_consts<CC_TOTAL>(CST, A.consts, tid);
@@ -1033,6 +1048,7 @@ int vkn_launch_chain_a(const VknChainA& p, hipStream_t stream) {
         case 8: CHA_LAUNCH(8); break;
         case 9: CHA_LAUNCH(9); break;
         case 10: CHA_LAUNCH(10); break;
+        case 11: CHA_LAUNCH(11); break;
         default: CHA_LAUNCH(0); break;
     }
 #else
@@ -1073,6 +1089,7 @@ int vkn_launch_chain_c(const VknChainC& p, hipStream_t stream) {
         case 8: CHC_LAUNCH(8); break;
         case 9: CHC_LAUNCH(9); break;
         case 10: CHC_LAUNCH(10); break;
+        case 11: CHC_LAUNCH(11); break;
         default: CHC_LAUNCH(0); break;
     }
 #else

@@ -97,8 +97,8 @@ def _register_training_components():
     """Losses / assigner / sampler of the training path.  Bundled registries: all of ours.  With mmdet present: OUR assigners and
     sampler replace the reference's in mmdet's own `BBOX_ASSIGNERS` / `BBOX_SAMPLERS` (force=True — our heads call
     `assigner.assign_batch` and read device-side results, an interface the reference's `MaskHungarianAssigner`
-    (knet/det/mask_hungarian_assigner.py:188-274, CPU scipy) does not have), and our losses fill in only the `LOSSES` names mmdet
-    lacks (mmdet's FocalLoss / CrossEntropyLoss / DiceLoss are the reference's own choice and stay)."""
+    (knet/det/mask_hungarian_assigner.py:188-274, CPU scipy) does not have); the reference's own CrossEntropyLoss override is
+    mirrored (force=True); FocalLoss / DiceLoss stay mmdet's (registered here only where mmdet lacks the name)."""
     from . import losses
     from .mask_hungarian_assigner import MaskHungarianAssigner, MaskHungarianAssignerVideo
     from .mask_pseudo_sampler import MaskPseudoSampler
@@ -112,7 +112,10 @@ def _register_training_components():
         for cls in (MaskHungarianAssigner, MaskHungarianAssignerVideo):
             mm_assigners.register_module(force=True)(cls)
         mm_samplers.register_module(force=True)(MaskPseudoSampler)
-        for cls in (losses.FocalLoss, losses.CrossEntropyLoss, losses.DiceLoss):
+        # CrossEntropyLoss: the reference overrides mmdet's with its own (knet/cross_entropy_loss.py:139, `register_module(force=True)`)
+        # — so does this package, with its restatement of THAT class; FocalLoss / DiceLoss are mmdet's own in the reference
+        mm_losses.register_module(force=True)(losses.CrossEntropyLoss)
+        for cls in (losses.FocalLoss, losses.DiceLoss):
             if mm_losses.get(cls.__name__) is None:
                 mm_losses.register_module()(cls)
         return
