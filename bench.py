@@ -572,6 +572,27 @@ def main():
                 per_call[f'frames_per_s_at_{b_}_frames_per_call'] = round(b_ / (e0.elapsed_time(e1) / 30 * 1e-3), 1)
                 if args.clip:
                     per_call[f'per_rank_step_ms_at_{b_}_frames_ONE_gpu'] = round(e0.elapsed_time(e1) / 30, 4)
+                if world == 1 and NS == 1 and not args.no_extras:
+                    # the same small calls with FOUR independent videos in flight (call i on HIP stream i % 4): a few-frame call is a
+                    # chain of ~45 latency-bound launches that leaves most of the chip idle — another video's call fills it.  For the
+                    # record only (throughput of a GPU serving several streams; one call's latency is the line above)
+                    sts_b = [torch.cuda.Stream(device=device) for _ in range(4)]
+                    for st in sts_b:
+                        st.wait_stream(torch.cuda.current_stream(device))
+                    keep_b = [None] * 4
+
+                    def run_b(n):
+                        for i_ in range(n):
+                            with torch.cuda.stream(sts_b[i_ % 4]):
+                                keep_b[i_ % 4] = vkn.ops.head_forward(dims_b, packs, xb, pfb, mpb, None, up, clip_first_prev=first_prev)
+                    run_b(16)
+                    torch.cuda.synchronize()
+                    tb_ = time.perf_counter()
+                    run_b(80)
+                    torch.cuda.synchronize()
+                    tb_ = (time.perf_counter() - tb_) / 80
+                    per_call[f'frames_per_s_at_{b_}_frames_per_call_4_videos_in_flight'] = round(b_ / tb_, 1)
+                    del keep_b, sts_b
             per_call[f'frames_per_s_at_{B}_frames_per_call'] = round(frames / dt, 1)
             if world == 1 and NS == 1 and not args.no_extras:
                 # several independent clips in flight (step i on HIP stream i % 4, e.g. one video per stream): the latency-bound update
@@ -641,6 +662,21 @@ def main():
                                         decode_algorithmic_bytes=algh)
                     del xh, o_
             per_call['x_storage_variants'] = variants
+            if xeb == 4 and world == 1 and NS == 1 and args.head == 'ffn' and up > 1:
+                # opt-in: the x4 up-scaled logits stored as fp16 (VKN_FLAG_SCALED_F16: the fp32 interpolation rounded once at the store,
+                # |error| <= 2^-11 |logit|, tests/test_gpu_xhalf.py) — half of the 245 MB per frame the step's largest kernel writes.
+                # Reported here only, never as `value` (the reference returns fp32 scaled_mask_preds).
+                for _ in range(5):
+                    o_ = vkn.ops.head_forward(dims, packs, x, pfs[0], mp, None, up, clip_first_prev=first_prev, flags=vkn.ops.FLAG_SCALED_F16)
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                for _ in range(20):
+                    o_ = vkn.ops.head_forward(dims, packs, x, pfs[0], mp, None, up, clip_first_prev=first_prev, flags=vkn.ops.FLAG_SCALED_F16)
+                torch.cuda.synchronize()
+                th = (time.perf_counter() - th) / 20
+                per_call['scaled_output_fp16_variant'] = dict(ms_per_step=round(th * 1e3, 4), frames_per_s=round(B / th, 1),
+                                                              tolerance='|error| <= 2^-11 |logit| vs the fp32 output (bit-identical to it rounded to fp16)')
+                del o_
             fused_traffic = None
             try:   # counter traffic of the fused kernel from the same sidecar as roofline.traffic (x once + partials written)
                 side = json.load(open(os.path.join(ROOT, PMC_SIDECAR)))

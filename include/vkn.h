@@ -76,6 +76,7 @@ extern "C" {
  * rounding (tests/test_gpu_parity.py::test_persistent_chain_equals_launch_per_gemm_chain), each is deterministic. */
 #define VKN_FLAG_CHAIN_LAUNCHES 256u   /* always one launch per GEMM */
 #define VKN_FLAG_CHAIN_PERSISTENT 512u /* always the persistent kernels (where the shape allows them) */
+#define VKN_FLAG_SCALED_F16 16384u     /* vkn_head_forward_*: `scaled_out` is fp16 [B][N][H*S][W*S] (see vkn_upsample_bilinear_f16out); S in {2, 4} */
 #define VKN_FLAG_CHAIN_KSPLIT 8192u    /* always the few-row chain: one column-spread launch per GEMM phase, normalisation in the consumer (vkn_ksplit.hip) */
 #define VKN_FLAG_SERIAL_LINK 32u   /* vkn_head_forward_f32: run the tracking link on the caller's stream instead of the library's side
                                     * stream (A/B, or callers that must see ONE stream; same results) */
@@ -213,6 +214,11 @@ int vkn_decode_gather_x(const void* x, int x_dtype, const void* kf_hi, const voi
 /* ---- `F.interpolate(mask_preds, scale_factor=S, mode='bilinear', align_corners=False)`
  *      knet/det/kernel_iter_head.py:122-130.  in [planes][H][W] -> out [planes][H*S][W*S]. */
 int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, int W, int S, void* stream);
+/*      ... with the result stored as fp16 (opt-in): the same fp32 interpolation, ONE round-to-nearest at the store; S in {2, 4},
+ *      W * S % 4 == 0, out 8-byte aligned.  Halves the bytes of the largest write of a head step (245 MB per 1024x2048 frame at x4).
+ *      |error| <= 2^-11 |logit| against vkn_upsample_bilinear_f32 (bit-identical to its result rounded to fp16); the sign — the
+ *      binary mask — is preserved for every |logit| >= 6e-8. */
+int vkn_upsample_bilinear_f16out(const float* in, void* out_f16, int planes, int H, int W, int S, void* stream);
 /*      its adjoint (training: the losses act on the up-scaled predictions): grad_out [planes][H*S][W*S] -> grad_in [planes][H][W];
  *      S in {1, 2, 3, 4, 8} (VKN_E_SHAPE otherwise) */
 int vkn_upsample_bilinear_bwd_f32(const float* grad_out, float* grad_in, int planes, int H, int W, int S, void* stream);

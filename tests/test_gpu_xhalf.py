@@ -197,3 +197,37 @@ def test_kernel_init_pass_on_half_storage_features(vkn, dt, sem):
         assert torch.equal(prop[:, Np:], seg_w.reshape(ncls, C)[nth:].unsqueeze(0).expand(B, -1, -1))
     # the head takes that x_feats as is: same bits as on the widened copy
     assert torch.equal(vkn.ops.mask_gather(xf, masks, 0.5)[0], vkn.ops.mask_gather(xf.float(), masks, 0.5)[0])
+
+
+@pytest.mark.parametrize('S,H,W', [(4, 128, 256), (2, 48, 80), (4, 92, 160), (4, 9, 15)])
+def test_upsample_with_fp16_output_is_the_fp32_result_rounded_once(vkn, S, H, W):
+    """VKN_FLAG_SCALED_F16 / vkn_upsample_bilinear_f16out (opt-in, VERDICT r04 item 9: "offer fewer bytes"): the up-scaled logits as
+    fp16.  Stated tolerance: |error| <= 2^-11 |logit| — because the kernel interpolates in fp32 exactly as the fp32 kernel does and
+    rounds once at the store, its output is BIT-IDENTICAL to `upsample_bilinear(z).half()`; the binary mask (sign) is unchanged."""
+    g = torch.Generator().manual_seed(5)
+    z = (torch.randn(2, 7, H, W, generator=g) * 6.0).to(DEV)
+    ref = vkn.ops.upsample_bilinear(z, S)
+    if (W * S) % 4:
+        with pytest.raises(vkn.VknError):
+            vkn.ops.upsample_bilinear(z, S, out_f16=True)
+        return
+    got = vkn.ops.upsample_bilinear(z, S, out_f16=True)
+    assert got.dtype == torch.float16 and got.shape == ref.shape
+    assert torch.equal(got, ref.half())
+    assert float((got.float() - ref).abs().max()) <= 2.0 ** -11 * float(ref.abs().max())
+    assert torch.equal(got > 0, ref > 0)
+
+
+def test_head_forward_with_fp16_scaled_output(vkn):
+    """The fused head call with VKN_FLAG_SCALED_F16: every output but `scaled` is bit-identical to the plain call, `scaled` is the plain
+    call's fp32 result rounded to fp16."""
+    from test_gpu_parity import _build_head, _cuda
+    g, case = load_golden('video_cfg')
+    head, (x, pf, mp, prev) = _build_head(vkn, case)
+    xd, pfd, mpd, prevd = _cuda(x, pf, mp, prev)
+    with torch.no_grad():
+        a = head._head_forward(xd, pfd, mpd, prevd, want_track=True)
+        b = head._head_forward(xd, pfd, mpd, prevd, want_track=True, flags=vkn.ops.FLAG_SCALED_F16)
+    for k in (0, 1, 2, 4):
+        assert torch.equal(a[k], b[k]), k
+    assert b[3].dtype == torch.float16 and torch.equal(b[3], a[3].half())

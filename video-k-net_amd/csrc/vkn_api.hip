@@ -351,8 +351,10 @@ int final_decode(const VknDims* d, const float* x, const StageWs& s, const float
                                   masks_out + (size_t)b0 * N * P, bn, N, C, P, st, xdt_of(flags)));
         if (b0 == 0 && prof1 && hipEventRecord(prof1, st) != hipSuccess) return VKN_E_LAUNCH;
         if (ch < B)
-            VKN_TRY(vkn_launch_upsample(masks_out + (size_t)b0 * N * P, up_out + (size_t)b0 * N * P * up_stride * up_stride, bn * N,
-                                        d->H, d->W, up_stride, st));
+            VKN_TRY(vkn_launch_upsample(masks_out + (size_t)b0 * N * P,
+                                        (flags & VKN_FLAG_SCALED_F16) ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(up_out) + (size_t)b0 * N * P * up_stride * up_stride)
+                                                                      : up_out + (size_t)b0 * N * P * up_stride * up_stride,
+                                        bn * N, d->H, d->W, up_stride, st, (flags & VKN_FLAG_SCALED_F16) ? 1 : 0));
     }
     if (ch < B && up_done) *up_done = true;
     return VKN_OK;
@@ -1029,6 +1031,11 @@ int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, in
     return vkn_launch_upsample(in, out, planes, H, W, S, static_cast<hipStream_t>(stream));
 }
 
+int vkn_upsample_bilinear_f16out(const float* in, void* out_f16, int planes, int H, int W, int S, void* stream) {
+    if (!in || !out_f16 || planes <= 0 || H <= 0 || W <= 0) return VKN_E_ARG;
+    return vkn_launch_upsample(in, static_cast<float*>(out_f16), planes, H, W, S, static_cast<hipStream_t>(stream), 1);
+}
+
 // ---------------------------------------------------------------------------------------------- kernel initialisation
 size_t vkn_kernel_init_workspace_bytes(int B, int Np, int ncls, int C, int P) {
     if (B <= 0 || Np <= 0 || C <= 0 || P <= 0 || ncls < 0) return 0;
@@ -1616,7 +1623,7 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
         }
     }
     if (scaled_out && upsample_stride > 1 && !up_done)                                    // :122-130
-        VKN_TRY(vkn_launch_upsample(mask_preds_out, scaled_out, d->B * d->N, d->H, d->W, upsample_stride, st));
+        VKN_TRY(vkn_launch_upsample(mask_preds_out, scaled_out, d->B * d->N, d->H, d->W, upsample_stride, st, (flags & VKN_FLAG_SCALED_F16) ? 1 : 0));
     // join: everything the call produced (and every use of the workspace) is ordered before later work on the caller's stream
     if (joined && hipStreamWaitEvent(st, joined->join, 0) != hipSuccess) return VKN_E_LAUNCH;
     return VKN_OK;

@@ -106,7 +106,7 @@ int vkn_launch_ku_mix(const float* params, const float* inputf, const float* ig,
                       hipStream_t stream);
 int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* out, int ldo, int B, int Nq,
                     int Nk, int heads, int hd, hipStream_t stream);
-int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream);
+int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream, int out_f16 = 0);   // out_f16: `out` points at fp16 elements
 
 // post-head joint panoptic merge (vkn_panoptic.hip); VknPanopticCfg is declared in include/vkn.h
 struct VknPanopticCfg;

@@ -1464,7 +1464,9 @@ int vkn_launch_attn(const float* Q, int ldq, const float* K, const float* V, int
 // those values per output pixel.  Coefficients come from the same clamped source-index formula as the generic kernel, taps are
 // selected from the staged registers -> the same values enter the same expression.
 #define UP_ROWS 4
-template <int S, int NT, int SUBS>  // SUBS consecutive groups of UP_ROWS input rows per workgroup (contiguous S*UP_ROWS*SUBS output rows)
+// O16 = 1 (opt-in, VKN_FLAG_SCALED_F16 / vkn_upsample_bilinear_f16out): the up-scaled logits leave as fp16 — the SAME fp32 arithmetic,
+// one round-to-nearest at the store (8-byte stores per quad): half of the 245 MB per frame this kernel writes, which is 45 % of a step
+template <int S, int NT, int SUBS, int O16 = 0>  // SUBS consecutive groups of UP_ROWS input rows per workgroup (contiguous S*UP_ROWS*SUBS output rows)
 __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in, float* __restrict__ out, int H, int W) {
     constexpr int NTAP = 4 / S + 2;  // input columns a quad can touch: jb - 1 .. jb + 4 / S
     const int OW = W * S, OH = H * S;
@@ -1473,6 +1475,7 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
     const float rs = 1.0f / (float)S;
     const float* ip = in + (size_t)plane * H * W;
     float* op = out + (size_t)plane * OH * OW;
+    _Float16* op16 = reinterpret_cast<_Float16*>(out) + (size_t)plane * OH * OW;   // (O16: `out` points at 2-byte elements)
     // NT == 5 (debug A/B, round 4; measured SLOWER: 1555 vs 1470 us per 32-frame launch): the workgroup's UP_ROWS * SUBS + 2 input rows
     // go through LDS once — 18 load instructions per thread instead of 66 (three overlapping tap loads per row) — and the taps come
     // from LDS.  Fewer vector-memory instructions do not help: the staging phase + barrier in front of a workgroup's first store costs
@@ -1578,6 +1581,17 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
                         const float bot = low ? hrow[i + 2][k] : hrow[i + 1][k];
                         o[k] = hy * top + ly * bot;
                     }
+                    if (O16) {
+                        // the fp32 result first, THEN one rounding to fp16 (pinned: hipcc otherwise folds the blend into v_fma_mixlo_f16,
+                        // a single rounding from the exact product sum — not the bits of the fp32 kernel's output rounded to fp16)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(o[k]));
+                        const half4 hv = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                        half4* d16 = reinterpret_cast<half4*>(op16 + (size_t)oy * OW + q * 4);
+                        if (NT) __builtin_nontemporal_store(hv, d16);
+                        else *d16 = hv;
+                        continue;
+                    }
                     float* dst = op + (size_t)oy * OW + q * 4;
                     if (NT)
                         __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(dst));
@@ -1599,8 +1613,23 @@ __global__ __launch_bounds__(256) void k_upsample_s(const float* __restrict__ in
 #include "../../tools/experiments/upsample_fill.inc"
 #endif
 
-int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream) {
+int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, int S, hipStream_t stream, int out_f16) {
     if (S < 1) return VKN_E_SHAPE;
+    if (out_f16) {   // fp16 output: the x2 / x4 staged kernels only (what every shipped config uses), 8-byte aligned quads
+        if ((S != 2 && S != 4) || ((W * S) % 4) != 0 || (reinterpret_cast<uintptr_t>(out) & 7)) return VKN_E_SHAPE;
+        int done16 = 0;
+        while (done16 < planes) {
+            const int chunk = (planes - done16 > 32768) ? 32768 : planes - done16;
+            const float* ip = in + (size_t)done16 * H * W;
+            float* op = reinterpret_cast<float*>(reinterpret_cast<_Float16*>(out) + (size_t)done16 * H * S * W * S);
+            dim3 grid((H + UP_ROWS * 4 - 1) / (UP_ROWS * 4), chunk);
+            if (S == 4) hipLaunchKernelGGL((k_upsample_s<4, 1, 4, 1>), grid, dim3(256), 0, stream, ip, op, H, W);
+            else hipLaunchKernelGGL((k_upsample_s<2, 1, 4, 1>), grid, dim3(256), 0, stream, ip, op, H, W);
+            VKN_CHECK_LAUNCH();
+            done16 += chunk;
+        }
+        return VKN_OK;
+    }
     int done = 0;
     while (done < planes) {  // gridDim.y <= 65535
         const int chunk = (planes - done > 32768) ? 32768 : planes - done;

@@ -19,6 +19,7 @@ FLAG_LOGITS_HANDOFF = 4
 FLAG_BITS_HANDOFF = 16
 FLAG_CHAIN_LAUNCHES = 256    # the [N x C] chain always as one launch per GEMM (default: by row count, include/vkn.h)
 FLAG_CHAIN_PERSISTENT = 512  # ... always as the two persistent row-owner kernels (vkn_chain.hip)
+FLAG_SCALED_F16 = 16384     # head_forward: the up-scaled logits as fp16 (vkn_upsample_bilinear_f16out)
 FLAG_CHAIN_KSPLIT = 8192     # ... always as the few-row chain: column-spread GEMM phases, normalisation in the consumer (vkn_ksplit.hip)
 FLAG_SERIAL_LINK = 32   # tracking link on the caller's stream instead of the library's side stream (A/B; same results)
 
@@ -215,13 +216,17 @@ def mask_decode(x, kernels, bias=None, flags=0, out_scale=None):
     return out
 
 
-def upsample_bilinear(masks, scale):
-    """`F.interpolate(masks, scale_factor=scale, mode='bilinear', align_corners=False)` (knet/det/kernel_iter_head.py:122-130)."""
+def upsample_bilinear(masks, scale, out_f16=False):
+    """`F.interpolate(masks, scale_factor=scale, mode='bilinear', align_corners=False)` (knet/det/kernel_iter_head.py:122-130).
+    out_f16 (opt-in; scale 2 / 4): the result as fp16 — the same fp32 interpolation rounded once at the store, half the bytes."""
     m = _req(masks, 'masks')
     B, N, H, W = m.shape
-    out = torch.empty((B, N, H * scale, W * scale), dtype=torch.float32, device=m.device)
+    out = torch.empty((B, N, H * scale, W * scale), dtype=torch.float16 if out_f16 else torch.float32, device=m.device)
     with torch.cuda.device(m.device):
-        check(_lib.lib().vkn_upsample_bilinear_f32(_ptr(m), _ptr(out), B * N, H, W, int(scale), _stream()))
+        if out_f16:
+            check(_lib.lib().vkn_upsample_bilinear_f16out(_ptr(m), _ptr(out), B * N, H, W, int(scale), _stream()))
+        else:
+            check(_lib.lib().vkn_upsample_bilinear_f32(_ptr(m), _ptr(out), B * N, H, W, int(scale), _stream()))
     return out
 
 
@@ -484,7 +489,8 @@ def head_forward(dims: VknDims, packs, x, proposal_feats, mask_preds, prev_obj=N
         masks = torch.empty((B, N, H, W), dtype=torch.float32, device=dev)
         scaled = None
         if want_scaled and upsample_stride > 1:
-            scaled = torch.empty((B, N, H * upsample_stride, W * upsample_stride), dtype=torch.float32, device=dev)
+            scaled = torch.empty((B, N, H * upsample_stride, W * upsample_stride),
+                                 dtype=torch.float16 if (flags & FLAG_SCALED_F16) else torch.float32, device=dev)
         track = None
     flags |= int(phase)
     if clip_first_prev is not None:
