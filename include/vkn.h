@@ -76,6 +76,8 @@ extern "C" {
  * rounding (tests/test_gpu_parity.py::test_persistent_chain_equals_launch_per_gemm_chain), each is deterministic. */
 #define VKN_FLAG_CHAIN_LAUNCHES 256u   /* always one launch per GEMM */
 #define VKN_FLAG_CHAIN_PERSISTENT 512u /* always the persistent kernels (where the shape allows them) */
+#define VKN_FLAG_JOIN_EARLY 32768u     /* vkn_head_forward_*: join the side-stream link BEFORE the x4 upsample instead of behind it (1-3 % slower in back-to-back throughput;
+                                        * the tracking embeddings of a single call are complete as early as its masks) */
 #define VKN_FLAG_SCALED_F16 16384u     /* vkn_head_forward_*: `scaled_out` is fp16 [B][N][H*S][W*S] (see vkn_upsample_bilinear_f16out); S in {2, 4} */
 #define VKN_FLAG_CHAIN_KSPLIT 8192u    /* always the few-row chain: one column-spread launch per GEMM phase, normalisation in the consumer (vkn_ksplit.hip) */
 #define VKN_FLAG_SERIAL_LINK 32u   /* vkn_head_forward_f32: run the tracking link on the caller's stream instead of the library's side

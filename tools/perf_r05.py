@@ -84,6 +84,20 @@ def main():
                         line += f'   head step {th / 1e3:7.3f} ms = {B / th * 1e6:7.0f} frames/s'
                     print(line)
         os.environ['VKN_CHAIN_ABL'] = '0'
+    if 'join' in what:     # where the side-stream link joins the main stream: behind the upsample (default) vs before it (VKN_FLAG_JOIN_EARLY)
+        print('== link join behind (default) vs before (VKN_FLAG_JOIN_EARLY) the x4 upsample, ms per call ==')
+        for B in frames:
+            x = torch.randn(B, C, H, W, generator=g).to(DEV)
+            pf = torch.randn(B, N, C, 1, 1, generator=g).to(DEV)
+            mp = (torch.randn(B, N, H, W, generator=g) * 4).to(DEV)
+            prev = torch.randn(B, N, C, 1, 1, generator=g).to(DEV)
+            for rep in range(args.reps):
+                row = []
+                for nm, fl in (('join behind upsample', 0), ('join before upsample', vkn.ops.FLAG_JOIN_EARLY)):
+                    with torch.no_grad():
+                        t = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True, flags=fl), iters=40, warm=8)
+                    row.append(f'{nm} {t / 1e3:7.3f} ms = {B / t * 1e6:7.0f} f/s')
+                print(f'B={B:3d}  ' + '   '.join(row))
     if 'head' in what:
         print('== whole head step (3 stages + link + x4 upsample), ms per call ==')
         for B in frames:

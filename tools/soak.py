@@ -212,10 +212,15 @@ def t_chain_persistent():
     p2 = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=vkn.ops.FLAG_CHAIN_PERSISTENT, **kw)
     assert all(a is None or torch.equal(a, b) for a, b in zip(p, p2)), ('not deterministic',) + tag
     assert all(a is None or bool(torch.isfinite(a).all()) for a in p), ('non-finite',) + tag
+    # round 5: the few-row chain (vkn_ksplit.hip: column-spread phases, LayerNorm in the consumer, few-row link) — deterministic, finite
+    f = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=vkn.ops.FLAG_CHAIN_KSPLIT, **kw)
+    f2 = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=vkn.ops.FLAG_CHAIN_KSPLIT, **kw)
+    assert all(a is None or torch.equal(a, b) for a, b in zip(f, f2)), ('few-row chain not deterministic',) + tag
+    assert all(a is None or bool(torch.isfinite(a).all()) for a in f), ('few-row chain non-finite',) + tag
     if S == 1:      # one stage: no binarisation between the chains -> fp32-rounding agreement on every output
         q = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=vkn.ops.FLAG_CHAIN_LAUNCHES, **kw)
         e = vkn.ops.head_forward(dims, packs, x, pf, mp, None, 2, flags=2, **kw)
-        for other in (q, e):
+        for other in (q, e, f):
             assert float((p[1] - other[1]).abs().max()) < 1e-5, tag
             assert float((p[0] - other[0]).abs().max()) < 1e-4 * max(1.0, float(other[0].abs().max())), tag
             assert float((p[2] - other[2]).abs().max()) < 1e-3 * max(1.0, float(other[2].abs().max()) / 50), tag

@@ -1622,10 +1622,18 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
             }
         }
     }
+    // Where the side-stream link joins the caller's stream.  Default: BEHIND the upsample — in back-to-back calls the link's tail (its small
+    // launches queue behind the upsample's 100 k workgroups whatever the stream priority: r05 trace, one link GEMM 1.5 ms beside the
+    // upsample, FFN + LayerNorm ~100 us after it) overlaps the next call's first kernels.  VKN_FLAG_JOIN_EARLY joins BEFORE the upsample
+    // (the link then overlaps the cls / mask branches and the decode only, the upsample has the chip to itself): measured 1-3 % SLOWER in
+    // throughput at 1 .. 16 frames per call, equal at 32 (tools/perf_r05.py --what join, docs/LAB_NOTEBOOK.md) — for callers that need the
+    // tracking embeddings of ONE call as early as its masks.  Either way everything the call produced (and every use of the workspace) is
+    // ordered before later work on the caller's stream.
+    const bool join_early = (flags & VKN_FLAG_JOIN_EARLY) != 0;
+    if (joined && join_early && hipStreamWaitEvent(st, joined->join, 0) != hipSuccess) return VKN_E_LAUNCH;
     if (scaled_out && upsample_stride > 1 && !up_done)                                    // :122-130
         VKN_TRY(vkn_launch_upsample(mask_preds_out, scaled_out, d->B * d->N, d->H, d->W, upsample_stride, st, (flags & VKN_FLAG_SCALED_F16) ? 1 : 0));
-    // join: everything the call produced (and every use of the workspace) is ordered before later work on the caller's stream
-    if (joined && hipStreamWaitEvent(st, joined->join, 0) != hipSuccess) return VKN_E_LAUNCH;
+    if (joined && !join_early && hipStreamWaitEvent(st, joined->join, 0) != hipSuccess) return VKN_E_LAUNCH;
     return VKN_OK;
 }
 
