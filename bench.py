@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 CFG2 = dict(C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128, W=256)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-PMC_SIDECAR = 'profiles/r04_pmc.json'   # HBM counters of this same command (tools/gpu_profile.sh); `roofline.traffic` is read from it
+PMC_SIDECAR = 'profiles/r05_pmc.json'   # HBM counters of this same command (tools/gpu_profile.sh); `roofline.traffic` is read from it
 
 
 def build_head(vkn, device, seed=0, link='ffn'):
