@@ -154,8 +154,14 @@ def test_half_x_single_stage_and_class_api(vkn):
         b = head.simple_test_mask_preds(xh.float(), pfs, mps, None, None)
         for u, v in zip(a, b):
             assert (u is None and v is None) or torch.equal(u, v)
-    with pytest.raises(TypeError):   # the autograd (training) path reads fp32 features
-        head.mask_head[0](xh, pfs, mps)
+    # the autograd (training) path takes half-storage features too since round 5 (it raised TypeError before): forward outputs are the
+    # bits of the fp32 path on the rounded x
+    a = head.mask_head[0](xh, pfs, mps)
+    b = head.mask_head[0](xh.float(), pfs, mps)
+    for u, v in zip(a, b):
+        assert (u is None and v is None) or torch.equal(u, v)
+    with pytest.raises(TypeError):
+        head.mask_head[0](xh.double(), pfs, mps)
 
 
 def test_half_x_rejected_by_reference_kernels_and_ragged_sizes(vkn):
@@ -231,3 +237,37 @@ def test_head_forward_with_fp16_scaled_output(vkn):
     for k in (0, 1, 2, 4):
         assert torch.equal(a[k], b[k]), k
     assert b[3].dtype == torch.float16 and torch.equal(b[3], a[3].half())
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])
+def test_forward_train_on_half_storage_features(vkn, dt):
+    """the TRAINING path on fp16 / bf16 feature storage (BASELINE cfg2 words "bf16", cfg5 "fp16").  Same pin as the
+    inference path: on x' = float(half(x)) the fp32 path returns the SAME losses bit for bit (its forward kernels are the half-storage
+    kernels with the all-zero low-half terms), the parameter / kernel gradients are the same bits (dK runs on the widened x in both
+    cases); x.grad arrives in x's storage type (each of the six contributions rounded once from its fp32 value)."""
+    from test_gpu_train import _train_case
+    g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, 'train_cfg')
+    assert (case['H'] * case['W']) % 64 == 0 and case['C'] in (64, 128, 256)
+    metas = [dict() for _ in range(case['B'])]
+    xh = _clamp_tiny(x).to(dt)                      # (bf16 -> f16 inside the kernels is exact in the normal f16 range)
+
+    def run(xin):
+        xd = xin.to(DEV).requires_grad_(True)
+        pfd = pf.to(DEV).requires_grad_(True)
+        for p in head.parameters():
+            p.grad = None
+        losses = head.forward_train(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+        total = sum(v for k, v in losses.items() if 'loss' in k)
+        total.backward()
+        return ({k: float(v) for k, v in losses.items()}, xd.grad.clone(), pfd.grad.clone(),
+                {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None})
+
+    l32, gx32, gpf32, gp32 = run(xh.float())
+    l16, gx16, gpf16, gp16 = run(xh)
+    assert l16 == l32, (l16, l32)
+    # x.grad: x feeds six differentiable ops (a gather and a decode per stage); each hands back its fp32 gradient rounded ONCE to x's
+    # type and autograd accumulates the six in that type — so not the fp32 sum rounded once, but within a few units of x's precision
+    eps = 2.0 ** -11 if dt == torch.float16 else 2.0 ** -8
+    assert gx16.dtype == dt and float((gx16.float() - gx32).abs().max()) <= 6 * eps * float(gx32.abs().max())
+    assert torch.equal(gpf16, gpf32)
+    assert gp16.keys() == gp32.keys() and all(torch.equal(gp16[k], gp32[k]) for k in gp16)

@@ -62,8 +62,9 @@ class MaskGatherFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mask_logits, hard_mask_thr):
-        xraw, cnt = ops.mask_gather(x, mask_logits, hard_mask_thr)
+        xraw, cnt = ops.mask_gather(x, mask_logits, hard_mask_thr)       # (fp16 / bf16 x: the half-storage kernel, VKN_FLAG_X_F16 / _BF16)
         ctx.need_dx = x.requires_grad
+        ctx.x_dtype = x.dtype
         if ctx.need_dx:
             # backward needs nothing but bit(z >= thr): ONE byte per logit is kept for it instead of the fp32 logits
             # (15 MB -> 3.8 MB per frame and stage at cfg2 size)
@@ -87,8 +88,10 @@ class MaskGatherFn(torch.autograd.Function):
         rows[:, :N] = bits
         if Np != N:
             rows[:, N:].zero_()
-        # [B, C, H, W]; the 1 / s is applied inside the kernel (no second pass over dx)
-        return _decode_unscaled(rows, kt, 1.0 / s), None, None
+        # [B, C, H, W]; the 1 / s is applied inside the kernel (no second pass over dx).  Half-storage x: the gradient leaves in x's
+        # storage type (autograd's contract), rounded once from the fp32 result
+        dx = _decode_unscaled(rows, kt, 1.0 / s)
+        return (dx if ctx.x_dtype == torch.float32 else dx.to(ctx.x_dtype)), None, None
 
 
 class SoftMaskGatherFn(torch.autograd.Function):
@@ -144,6 +147,11 @@ class MaskDecodeFn(torch.autograd.Function):
         need_k = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         N = dz.shape[1]
         dk = dkb = dx = None
+        xdt = x.dtype
+        if need_k and xdt != torch.float32:
+            # half-storage x: dK = dZ x^T runs on the real-operand gather kernel, which reads fp32 features — x widened once (exact);
+            # the FORWARD passes are the half-storage kernels (bit-identical to the fp32 ones on the rounded x)
+            x = x.float()
         if ctx.needs_input_grad[0]:
             # dx[b, c, p] = sum_n K[b, n, c] dz[b, n, p]: the decode kernel with the (scaled, row-padded) dz as its feature map and
             # K^T as its kernels; the padded rows are zero, so the gather below may run over them too
@@ -155,6 +163,8 @@ class MaskDecodeFn(torch.autograd.Function):
         elif need_k:
             dk, dkb = ops.mask_gather_real(x, dz * s)
             dk, dkb = dk.mul_(inv), dkb.mul_(inv)
+        if dx is not None and xdt != torch.float32:
+            dx = dx.to(xdt)
         return dx, dk if ctx.needs_input_grad[1] else None, dkb if (ctx.has_bias and ctx.needs_input_grad[2]) else None
 
 

@@ -350,8 +350,10 @@ class KernelUpdateHead(nn.Module):
     def _xfeat_autograd(self, x, mask_preds):
         """Differentiable gather: x [B,C,H,W], mask_preds [B,N,H,W] -> x_feat [B,N,C] with `feat_transform` folded
         (x_feat = xraw W^T + cnt b; reference :179-180, :190-195)."""
-        if x.dtype != torch.float32:
-            raise TypeError('the autograd (training) path reads fp32 features; half-storage x is an inference option')
+        if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            raise TypeError(f'x: expected float32, float16 or bfloat16 features, got {x.dtype}')
+        # (fp16 / bf16 x — BASELINE cfg2 "bf16", cfg5 "fp16": the forward passes are the half-storage kernels, bit-identical to the fp32
+        #  ones on the rounded x; backward: dK on the widened x, dx rounded once to x's type — autograd.py, tests/test_gpu_xhalf.py)
         C = self.in_channels
         xraw, cnt = vag.mask_gather(x, mask_preds.detach(), self.hard_mask_thr)
         if self.feat_transform is None:
