@@ -83,6 +83,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
     int xcd_remap, VknDecodeStrides fs, unsigned* __restrict__ bits_out, float thr, const float* __restrict__ oscale) {
     const float osc_ = OSC ? *oscale : 1.f;
 #define DEC_V(v) (OSC ? (v) * osc_ : (v))
+    n0 += (int)blockIdx.z * NB * 32;   // few frames per launch: the kernel rows are spread over gridDim.z workgroups per pixel range (round 5)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LDK = C + 8;  // halfs per LDS row; (C+8)*2 B = odd multiple of 16 B -> b128 reads conflict-free
     _Float16* ldsH = reinterpret_cast<_Float16*>(smem);
@@ -433,10 +434,19 @@ static int decode_launch(const float* x, const _Float16* kfh, const _Float16* kf
     const bool wide = xdt == 0 && !bits_out && (P % D4_TILE) == 0 && (C % 64) == 0 && vkn_dbg_env("VKN_DECODE4", 0) != 0 &&
                       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
 #endif
+    // One or two frames per launch leave most CUs without a workgroup (64 workgroups per frame of 128x256) and every workgroup stages ALL
+    // kernel rows (120 KB of planes — at one frame as many bytes as the features).  There the rows are spread over blockIdx.z instead:
+    // 1 or 2 n-blocks per workgroup, 4 or 2 workgroups per pixel range (x is re-read from L2 / the memory-side cache by each); the
+    // accumulators of an n-block see the same MFMA sequence: bit-identical output.  Measured at one frame: 27 -> 19 us (profiles/r05_decode_zsplit.txt)
+    int znb = 0;
+    if (!bits_out && NPT <= 128 && (long long)B * G2 <= 128) {
+        znb = ((long long)B * G2 <= 64) ? 1 : 2;
+        if (NPT % (znb * 32) != 0 || NPT / (znb * 32) < 2) znb = 0;
+    }
     for (int n0 = 0; n0 < NPT; n0 += 128) {
-        const int nb = (NPT - n0 >= 128) ? 4 : (NPT - n0) / 32;
+        const int nb = znb ? znb : ((NPT - n0 >= 128) ? 4 : (NPT - n0) / 32);
         const size_t lds = (size_t)2 * nb * 32 * (C + 8) * sizeof(_Float16) + (size_t)nb * 32 * sizeof(float);
-        dim3 grid(G2, B, 1);
+        dim3 grid(G2, B, znb ? NPT / (znb * 32) : 1);
 #ifdef VKN_DEBUG
         if (wide) {
 #define D4_CASE(NBV)                                                                                                       \
