@@ -1038,9 +1038,9 @@ def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, vide
     assert all(a is None or torch.equal(a, b) for a, b in zip(few, again)), 'deterministic (few-row chain)'
     assert maxabs(few[2], t0['obj_feat'].reshape(B, N, C)) < 2e-4
     assert maxabs(few[1], t0['new_mask_preds']) < TOL_LOGIT and maxabs(few[0], t0['cls_score']) < 1e-4
-    auto = vkn.ops.stage_forward(*args, **kwd)     # default policy by row tiles: few-row <= 19, launch-per-GEMM <= 63, persistent from 64 on
+    auto = vkn.ops.stage_forward(*args, **kwd)     # default policy by row tiles: few-row <= 16, launch-per-GEMM <= 63, persistent from 64 on
     rt = (B * N + 31) // 32
-    pick = new if rt >= 64 else (few if rt <= 19 else old)
+    pick = new if rt >= 64 else (few if rt <= 16 else old)
     assert all(a is None or torch.equal(a, b) for a, b in zip(auto, pick)), 'default policy picks by row count'
 
 
@@ -1373,7 +1373,7 @@ def test_block_step_with_neighbour_link_equals_whole_clip(vkn, chain):
         blocks.append(out)
     for k in range(5):
         got = torch.cat([b[k] for b in blocks], 0)
-        if chain == 'policy' and (T * N + 31) // 32 > 19 >= (h * N + 31) // 32:
+        if chain == 'policy' and (T * N + 31) // 32 > 16 >= (h * N + 31) // 32:
             # two forms of the chain: the teacher-forced distance (2e-5 relative per stage) grows through three free-running stages only
             # where a near-threshold mask bit flips; this small case (16x32 features) has none
             assert maxabs(got, whole[k]) < 2e-4 * max(1.0, float(whole[k].abs().max())), k

@@ -60,6 +60,21 @@ def main():
             for rep in range(args.reps):
                 ts = [timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob, flags=getattr(vkn.ops, fl))) for _, fl in FORMS]
                 print(f'B={B:3d} rows={B * N:5d}  ' + '   '.join(f'{nm} {t:7.1f}' for (nm, _), t in zip(FORMS, ts)))
+    if 'wgcap' in what:     # needs --debug-lib: the few-row chain's workgroup-count cap (tile shape heuristic), chain alone
+        print('== few-row chain alone by VKN_KS_WGCAP (workgroups per launch above which tiles get fatter), us per stage ==')
+        for B in frames:
+            dims = head.mask_head[0].make_dims(B, N, H, W)
+            pack = head.mask_head[0].stage_pack(torch.device(DEV))
+            xf = (torch.randn(B, N, C, generator=g) * 50).to(DEV)
+            ob = torch.randn(B, N, C, generator=g).to(DEV)
+            row = []
+            for cap in (256, 192, 128, 96, 256):
+                os.environ['VKN_KS_WGCAP'] = str(cap)
+                t = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob, flags=vkn.ops.FLAG_CHAIN_KSPLIT))
+                row.append(f'cap {cap}: {t:6.1f}')
+            t3 = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob, flags=vkn.ops.FLAG_CHAIN_LAUNCHES))
+            print(f'B={B:3d} rows={B * N:5d}  ' + '   '.join(row) + f'   launch-per-GEMM {t3:6.1f}')
+        os.environ.pop('VKN_KS_WGCAP', None)
     if 'abl11' in what:      # needs --debug-lib.  VERDICT r04 item 4, the prize measured before the work: the persistent chain with TWO
         # split terms per operand (4 bytes / weight, 3 products per operand pair instead of 6 bytes / 6 products) — VKN_CHAIN_ABL=11 keeps
         # everything else (activation images, epilogues, ring) and produces WRONG numbers (bf16 x 2 precision); only its time counts

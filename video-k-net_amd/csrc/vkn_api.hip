@@ -413,10 +413,10 @@ int run_chain_fast(const VknDims* d, const VknStageWeights* w, const PrepW& pw, 
     return vkn_launch_chain_c(c, st);
 }
 
-// Row-count policy of the three chain forms (profiles/r05_chain_forms.txt; chain alone, us per stage at 117 / 234 / 468 / 936 / 1872 / 3744
-// rows): few-row 78 / 83 / 97 / 138 / 198 / 341, launch-per-GEMM 109 / 111 / 111 / 111 / 130 / 185, persistent 160 at any row count ->
-// few-row up to 19 row tiles (5 frames of 117 kernels), launch-per-GEMM up to 63, persistent from 64 on.
-#define VKN_KS_MAX_ROW_TILES 19
+// Row-count policy of the three chain forms (profiles/r05_chain_forms.txt; chain alone, us per stage at 117 / 234 / 351 / 468 / 585 / 936 /
+// 1872 / 3744 rows): few-row 77 / 78 / 87 / 87 / 109 / 117 / 213 / 368, launch-per-GEMM 105 / 108 / 108 / 107 / 107 / 108 / 128 / 174,
+// persistent 158 at any row count -> few-row up to 16 row tiles (4 frames of 117 kernels), launch-per-GEMM up to 63, persistent from 64 on.
+#define VKN_KS_MAX_ROW_TILES 16
 // The few-row chain (vkn_ksplit.hip): same shape conditions as the persistent chain, at most VKN_KS_MAX_ROW_TILES row tiles (or VKN_FLAG_CHAIN_KSPLIT),
 // every vector it reads with 16-byte loads aligned (parameters that are views into a packed buffer may not be).
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -483,12 +483,15 @@ int vkn_launch_gemm_ks(const VknKsProb* probs, int nprob, int mode, int zchunks,
         nmax = p.Nout > nmax ? p.Nout : nmax;
     }
     const int rt = (M + 31) / 32, cbs = (nmax + 31) / 32, nz = zchunks > 0 ? zchunks : nprob;
-    // tile shape: as many workgroups as the chip takes in ~3 waves; beyond that fatter tiles re-read fewer weight bytes per row
+    // tile shape: at most ONE workgroup per CU (256) — a second round of workgroups costs a whole extra round trip, a fatter tile only
+    // more MFMAs behind the same one (chain alone, us per stage at 234 / 351 / 468 / 585 / 936 rows: cap 768: 83 / 101 / 99 / 140 / 142,
+    // cap 256: 78 / 87 / 87 / 109 / 117, cap 128: 83 / 100 / 99 / 117 / 122; profiles/r05_chain_forms.txt)
     int ncb = 1, mt = 1;
     if (mode == 0) {
         auto wgs = [&](int c, int m) { return (long long)((cbs + c - 1) / c) * ((rt + m - 1) / m) * nz; };
-        if (wgs(1, 1) > 768 && cbs >= 2) ncb = 2;
-        if (ncb == 2 && wgs(2, 1) > 768 && ns == 1) mt = 2;
+        const long long cap = vkn_dbg_env("VKN_KS_WGCAP", 256);   // (debug build: A/B of the workgroup-count cap)
+        if (wgs(1, 1) > cap && cbs >= 2) ncb = 2;
+        if (ncb == 2 && wgs(2, 1) > cap && ns == 1) mt = 2;
     }
     const dim3 grid((cbs + ncb - 1) / ncb, (rt + mt - 1) / mt, nz);
     const size_t lds = (size_t)(8 * ncb * mt * 1024 + 10 * 512 + (mode == 2 ? 8 * 256 : 0)) * sizeof(float);
