@@ -47,9 +47,9 @@ def _run(T, world=2):
     procs = [ctx.Process(target=_worker, args=(r, world, port, T, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=60) for _ in range(world))
+    out = sorted(q.get(timeout=240) for _ in range(world))
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=240)
         assert p.exitcode == 0
     return out
 
