@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VKN_VERSION 0x000300 /* 0.3.0: workspace status word (vkn_workspace_init / _status, VKN_E_RANGE), VKN_FLAG_CHAIN_* / VKN_FLAG_PHASE_* */
+#define VKN_VERSION 0x000400 /* 0.4.0: few-row chain (VKN_FLAG_CHAIN_KSPLIT), VKN_FLAG_SCALED_F16 + vkn_upsample_bilinear_f16out, VKN_FLAG_JOIN_EARLY, struct size probes */
 
 #define VKN_OK 0
 #define VKN_E_ARG (-1)       /* null pointer / non-positive size */

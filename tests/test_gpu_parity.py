@@ -42,7 +42,7 @@ SHAPES = [  # B, N, C, H, W
 def test_library_loaded_and_gpu_visible(vkn):
     assert torch.cuda.is_available()
     assert os.path.exists(vkn._lib.LIBPATH)
-    assert vkn._lib.lib().vkn_version() == 0x000300
+    assert vkn._lib.lib().vkn_version() == 0x000400
 
 
 @pytest.mark.parametrize('flags', [0, 1], ids=['mfma', 'refkernels'])
@@ -1042,6 +1042,33 @@ def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, vide
     rt = (B * N + 31) // 32
     pick = new if rt >= 64 else (few if rt <= 16 else old)
     assert all(a is None or torch.equal(a, b) for a, b in zip(auto, pick)), 'default policy picks by row count'
+
+
+def test_few_row_chain_is_tile_shape_and_batch_invariant_bit_for_bit(vkn):
+    """The few-row chain picks its tile shape (32 or 64 rows x 32 or 64 columns per workgroup) by row count; a frame must come out the
+    same bits whether it runs alone, in a block of 2 (8 row tiles: thin tiles) or among 8 (30 row tiles: fat tiles) — the property the
+    sharded clip relies on.  (Round 5: it did not at first — hipcc contracted `bias * count + bias2` into an fma in one instantiation and
+    not in another; floating-point contraction is off in csrc/vkn_ksplit.hip since.)  One stage through the C ABI with the raw-gather
+    path (count-scaled bias), the video link included."""
+    from test_host_logic import _cfg
+    C, heads, H, W, N, ff, ncls, B = 256, 8, 8, 16, 117, 2048, 19, 8
+    kw = dict(C=C, heads=heads, ffn=ff, ncls=ncls, n_thing=2, n_stuff=17, S=1, up=1, nprop=N - 17)
+    case = dict(kw, N=N, H=H, W=W, B=B, seed=4242, video=1)
+    head = vkn.build_head(_cfg(True, **kw))
+    cfg, sd, x, pf, mp, prev = make_case(case)
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV).eval()
+    pack = head.mask_head[0].stage_pack(torch.device(DEV))
+    xd, pfd, mpd, pvd = x.to(DEV), pf.reshape(B, N, C).to(DEV), mp.to(DEV), prev.reshape(B, N, C).to(DEV)
+
+    def run(b0, b1):
+        dims = head.mask_head[0].make_dims(b1 - b0, N, H, W)
+        return vkn.ops.stage_forward(dims, pack, xd[b0:b1], pfd[b0:b1], mpd[b0:b1], prev_obj=pvd[b0:b1], want_track=True, flags=vkn.ops.FLAG_CHAIN_KSPLIT)
+    whole = run(0, B)
+    for step in (1, 2, 4):
+        parts = [run(b, b + step) for b in range(0, B, step)]
+        for k, nm in enumerate(('cls', 'masks', 'obj', 'x_feat', 'track')):
+            assert torch.equal(torch.cat([p[k] for p in parts], 0), whole[k]), (step, nm)
 
 
 def test_range_status_word_reports_features_outside_the_f16_split(vkn):

@@ -34,6 +34,12 @@
 #include "vkn_common.h"
 #include "vkn_launch.h"
 
+// Floating-point contraction is OFF in this file: the same phase runs in several tile shapes (NCB, MT) picked by row count, and hipcc
+// contracts `a * b + c` into an fma in one instantiation and not in another (seen: the count-scaled bias `bias * count + bias2` of the
+// dynamic layer, the decode-bias dot product) — a clip cut into blocks would then differ from the whole clip in the last bit.  Every
+// prologue / epilogue value is the same sequence of individually rounded fp32 operations in every instantiation; the MFMAs are unaffected.
+#pragma clang fp contract(off)
+
 typedef __bf16 kbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int ku32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 khalf2 __attribute__((ext_vector_type(2)));
