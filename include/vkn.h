@@ -595,6 +595,63 @@ int vkn_mask_losses_fwd_f32(const float* pred, const float* target, const long l
 int vkn_mask_losses_bwd_f32(const float* pred, const float* target, const int* rowk, const float* rowcoef, const float* coef,
                             const float* lse, const int* top, int B, int Ns, int P, int with_rank, float* grad, void* stream);
 
+/* ---- the loss tail of a training stage WITHOUT the target tensors (round 5).  `get_targets` + `loss`
+ *      (knet/det/kernel_update_head.py:279-441) build, per stage, labels / label_weights / mask_targets / mask_weights for all
+ *      R = B (N + S) rows — a zero-filled [R][H][W] tensor with the matched ground-truth masks scattered into it — and then take the
+ *      positive rows out again.  Here the ground truth of the batch stays where it is, in one BANK [G_total][P] (every image's thing
+ *      masks and stuff masks, concatenated once per step), and a row's target is named by an index into it:
+ *        vkn_stage_targets              one launch: labels int64 [R] (ncls = background), label_weights [R][ncls] (:384-392),
+ *                                       row_weight [R] (1 on matched predictions and present stuff rows: `mask_weights` of :381,394
+ *                                       as one value per row), rowk int32 [R] (rank among the positives or -1), pos_rows int64 [K]
+ *                                       ascending, tgt_row int32 [R] (bank row of the row's mask target or -1).  `imgs` is a HOST
+ *                                       array: per image the (row, col) pairs of vkn_lsap_batch_f32 (DEVICE), its labels (DEVICE
+ *                                       int64), its present stuff classes (DEVICE int64, values in [T, T + S); anything else sets
+ *                                       bit 0 of *status and is treated as class T) and where its masks sit in the bank.
+ *                                       S = 0: no stuff targets (weights over all ncls columns); S > 0: thing columns [0, T) only.
+ *                                       K = sum_b (k_b + n_sem_b) is known on the host: nothing synchronises.
+ *        vkn_mask_losses_fwd_bank_f32   vkn_mask_losses_fwd_f32 with row r's target = bank[tgt_row[r]]
+ *        vkn_stage_losses_final_f32     one workgroup: the partial sums of vkn_focal_loss_f32 / the two mask-loss passes -> losses[5] =
+ *                                       {loss_cls = w_cls sum / avg_factor, pos_acc (top-1 accuracy of the positive rows in percent,
+ *                                       :300-301), loss_mask, loss_dice, loss_rank} and the per-row dice sums a [K], b + c [K] that
+ *                                       backward needs.  avg_factor_dev (DEVICE scalar, e.g. an all-reduced count) overrides
+ *                                       cfg->avg_factor when not NULL; cls_logits may be NULL (no accuracy).
+ *        vkn_mask_losses_bwd_bank_f32   vkn_mask_losses_bwd_f32 with the coefficients formed in the kernel from the upstream
+ *                                       gradients g_mask / g_dice / g_rank (DEVICE scalars, NULL = 0) and dice_a / dice_bc
+ *        vkn_scale_by_f32               out = in * host_scale * g / d (DEVICE scalars, NULL = 1): backward of sum * weight / avg
+ *        vkn_check_range_i64            *status |= flag if any v[i] lies outside [lo, hi) (label validation without a host read) */
+#define VKN_TAIL_MAX_IMAGES 64
+typedef struct VknTailImage {
+    const int* row_ind;         /* [k] matched predictions, ascending */
+    const int* col_ind;         /* [k] their ground truths */
+    const long long* gt_labels; /* [G] */
+    const long long* sem_cls;   /* [n_sem] or NULL */
+    int k, n_sem;
+    int gt_row0, sem_row0;      /* first bank row of this image's thing / stuff masks */
+    int pos0;                   /* positives of the images before this one */
+    int reserved;
+} VknTailImage;
+typedef struct VknTailCfg {
+    float w_cls, w_mask, w_dice, dice_eps, w_rank, avg_factor;
+    int with_rank;
+} VknTailCfg;
+size_t vkn_sizeof_tail_image(void);
+size_t vkn_sizeof_tail_cfg(void);
+int vkn_stage_targets(const VknTailImage* imgs, int B, int N, int S, int T, int ncls, float pos_weight, long long* labels,
+                      float* label_weights, float* row_weight, int* rowk, long long* pos_rows, int* tgt_row, int* status, void* stream);
+int vkn_mask_losses_fwd_bank_f32(const float* pred, const float* bank, const int* tgt_row, const long long* pos_rows, const int* rowk,
+                                 int K, int B, int Ns, int P, int with_rank, float* row_partial, float* lse, int* top,
+                                 float* rank_partial, void* stream);
+int vkn_stage_losses_final_f32(const VknTailCfg* cfg, const float* avg_factor_dev, const float* focal_partial, int n_focal,
+                               const float* row_partial, int K, int nchunk, const float* rank_partial, int n_rank,
+                               const float* cls_logits, const long long* labels, const long long* pos_rows, int ncls, int B, int P,
+                               float* losses, float* dice_a, float* dice_bc, void* stream);
+int vkn_mask_losses_bwd_bank_f32(const float* pred, const float* bank, const int* tgt_row, const int* rowk, const float* dice_a,
+                                 const float* dice_bc, const float* g_mask, const float* g_dice, const float* g_rank, float w_mask,
+                                 float w_dice, float w_rank, int K, const float* lse, const int* top, int B, int Ns, int P,
+                                 int with_rank, float* grad, void* stream);
+int vkn_scale_by_f32(const float* in, const float* g, const float* d, float host_scale, float* out, size_t n, void* stream);
+int vkn_check_range_i64(const long long* v, size_t n, long long lo, long long hi, int flag, int* status, void* stream);
+
 /* ---- quasi-dense embedding association (the `tracker=dict(type='QuasiDenseEmbedTracker', ...)` of the video configs).  Replaces
  *      `QuasiDenseEmbedTracker.match(bboxes, labels, track_feats, frame_id) -> (bboxes, labels, ids)` together with the `update_memo`
  *      and `memo` it calls: knet/video/qdtrack/trackers/quasi_dense_embed_tracker.py:137-207, :47-103, :105-135 (ctor kwargs :11-38).

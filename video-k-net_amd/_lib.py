@@ -28,6 +28,8 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_workspace_init', 'vkn_workspace_s
            'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_sizeof_assign_problem', 'vkn_assign_costs_batch_f32', 'vkn_lsap_f32',
            'vkn_sizeof_lsap_problem', 'vkn_lsap_batch_f32',
            'vkn_mask_losses_chunks', 'vkn_mask_losses_blocks', 'vkn_mask_losses_fwd_f32', 'vkn_mask_losses_bwd_f32',
+           'vkn_sizeof_tail_image', 'vkn_sizeof_tail_cfg', 'vkn_stage_targets', 'vkn_mask_losses_fwd_bank_f32', 'vkn_stage_losses_final_f32',
+           'vkn_mask_losses_bwd_bank_f32', 'vkn_scale_by_f32', 'vkn_check_range_i64',
            'vkn_sizeof_tracker_cfg', 'vkn_qd_tracker_state_bytes', 'vkn_qd_tracker_workspace_bytes', 'vkn_qd_tracker_state_layout',
            'vkn_qd_tracker_reset', 'vkn_qd_tracker_match_f32')
 
@@ -57,6 +59,18 @@ class VknLsapProblem(ctypes.Structure):
     """Mirror of include/vkn.h: VknLsapProblem (device pointers as integers)."""
     _fields_ = [('cost', ctypes.c_void_p), ('nr', ctypes.c_int), ('nc', ctypes.c_int), ('gt_inds', ctypes.c_void_p),
                 ('row_ind', ctypes.c_void_p), ('col_ind', ctypes.c_void_p)]
+
+
+class VknTailImage(ctypes.Structure):
+    """Mirror of include/vkn.h: VknTailImage (device pointers as integers)."""
+    _fields_ = [('row_ind', ctypes.c_void_p), ('col_ind', ctypes.c_void_p), ('gt_labels', ctypes.c_void_p), ('sem_cls', ctypes.c_void_p),
+                ('k', ctypes.c_int), ('n_sem', ctypes.c_int), ('gt_row0', ctypes.c_int), ('sem_row0', ctypes.c_int),
+                ('pos0', ctypes.c_int), ('reserved', ctypes.c_int)]
+
+
+class VknTailCfg(ctypes.Structure):
+    """Mirror of include/vkn.h: VknTailCfg."""
+    _fields_ = [(n, ctypes.c_float) for n in ('w_cls', 'w_mask', 'w_dice', 'dice_eps', 'w_rank', 'avg_factor')] + [('with_rank', ctypes.c_int)]
 
 
 class VknTrackerCfg(ctypes.Structure):
@@ -359,6 +373,24 @@ def lib():
     L.vkn_mask_losses_fwd_f32.argtypes = [_fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _fp, _fp, _fp, _fp, _fp]
     L.vkn_mask_losses_bwd_f32.restype = c_int
     L.vkn_mask_losses_bwd_f32.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, _fp, _fp]
+    for fn, st in ((L.vkn_sizeof_tail_image, VknTailImage), (L.vkn_sizeof_tail_cfg, VknTailCfg)):
+        fn.restype = c_size
+        fn.argtypes = []
+        if fn() != ctypes.sizeof(st):
+            raise VknLibraryError(f'{st.__name__} layout mismatch between include/vkn.h and _lib.py')
+    L.vkn_stage_targets.restype = c_int
+    L.vkn_stage_targets.argtypes = [ctypes.POINTER(VknTailImage), c_int, c_int, c_int, c_int, c_int, ctypes.c_float] + [_fp] * 8
+    L.vkn_mask_losses_fwd_bank_f32.restype = c_int
+    L.vkn_mask_losses_fwd_bank_f32.argtypes = [_fp] * 5 + [c_int] * 5 + [_fp] * 5
+    L.vkn_stage_losses_final_f32.restype = c_int
+    L.vkn_stage_losses_final_f32.argtypes = [ctypes.POINTER(VknTailCfg), _fp, _fp, c_int, _fp, c_int, c_int, _fp, c_int, _fp, _fp, _fp,
+                                             c_int, c_int, c_int, _fp, _fp, _fp, _fp]
+    L.vkn_mask_losses_bwd_bank_f32.restype = c_int
+    L.vkn_mask_losses_bwd_bank_f32.argtypes = [_fp] * 9 + [ctypes.c_float] * 3 + [c_int, _fp, _fp, c_int, c_int, c_int, c_int, _fp, _fp]
+    L.vkn_scale_by_f32.restype = c_int
+    L.vkn_scale_by_f32.argtypes = [_fp, _fp, _fp, ctypes.c_float, _fp, c_size, _fp]
+    L.vkn_check_range_i64.restype = c_int
+    L.vkn_check_range_i64.argtypes = [_fp, c_size, ctypes.c_longlong, ctypes.c_longlong, c_int, _fp, _fp]
     L.vkn_sizeof_assign_problem.restype = c_size
     L.vkn_sizeof_assign_problem.argtypes = []
     if L.vkn_sizeof_assign_problem() != ctypes.sizeof(VknAssignProblem):

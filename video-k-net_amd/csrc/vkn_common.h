@@ -94,7 +94,9 @@ __device__ __forceinline__ float vkn_wave_max(float v) {
 #define VKN_E_LAUNCH (-4)
 #define VKN_E_ALIGN (-5)
 #define VKN_E_RANGE (-6)
+#ifndef VKN_STATUS_RANGE
 #define VKN_STATUS_RANGE 1
+#endif
 
 // Raise a kernel's dynamic-LDS limit to the whole 160 KB ONCE per (process, device) instead of on every launch.
 static inline int vkn_allow_full_lds(const void* fn, unsigned long long* done_mask) {

@@ -22,13 +22,16 @@ namespace {
 constexpr int ML_CHUNK = 8192;   // pixels per workgroup of k_ml_rows
 
 // partial [K][nchunk][4] = (sum bce, sum p t, sum p^2, sum t^2) of row pos_rows[k] over pixels [chunk * ML_CHUNK, ...)
+// tgt_row != NULL: `target` is a BANK of ground-truth masks and row r's target is its row tgt_row[r] (the training tail: no [R][P] target
+// tensor is ever built); NULL: target is [R][P].
 __global__ __launch_bounds__(256) void k_ml_rows(const float* __restrict__ pred, const float* __restrict__ target,
-                                                 const long long* __restrict__ pos_rows, int P, int nchunk, float* __restrict__ partial) {
+                                                 const int* __restrict__ tgt_row, const long long* __restrict__ pos_rows, int P,
+                                                 int nchunk, float* __restrict__ partial) {
     __shared__ float red[4][4];
     const int k = blockIdx.y, ck = blockIdx.x;
     const size_t row = (size_t)pos_rows[k];
     const float* z = pred + row * P;
-    const float* t = target + row * P;
+    const float* t = target + (tgt_row ? (size_t)tgt_row[row] : row) * P;
     const int p_lo = ck * ML_CHUNK, p_hi = min(P, p_lo + ML_CHUNK);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     // 16-byte loads, two of each operand in flight per thread (P % 4 == 0 and 16-byte aligned rows: checked by the entry point)
@@ -63,7 +66,8 @@ constexpr int ML_PX = 2;
 typedef float ml_vec __attribute__((ext_vector_type(ML_PX)));
 typedef int ml_ivec __attribute__((ext_vector_type(ML_PX)));
 __global__ __launch_bounds__(256) void k_ml_rank_fwd(const float* __restrict__ pred, const float* __restrict__ target,
-                                                     const int* __restrict__ rowk, int Ns, int P, float* __restrict__ lse,
+                                                     const int* __restrict__ tgt_row, const int* __restrict__ rowk, int Ns, int P,
+                                                     float* __restrict__ lse,
                                                      int* __restrict__ top, float* __restrict__ partial) {
     __shared__ float red[4];
     const int b = blockIdx.y;
@@ -80,7 +84,8 @@ __global__ __launch_bounds__(256) void k_ml_rank_fwd(const float* __restrict__ p
             const ml_vec z = *reinterpret_cast<const ml_vec*>(pred + off);
             const bool pos = rowk[b * Ns + n] >= 0;   // uniform
             // (no branch around the second load, so that the loads of several rows can be in flight: a non-positive row re-reads z)
-            const ml_vec t = *reinterpret_cast<const ml_vec*>((pos ? target : pred) + off);
+            const size_t toff = (pos && tgt_row) ? (size_t)tgt_row[b * Ns + n] * P + p : off;
+            const ml_vec t = *reinterpret_cast<const ml_vec*>((pos ? target : pred) + toff);
 #pragma unroll
             for (int e = 0; e < ML_PX; ++e) {
                 const float mn = fmaxf(m[e], z[e]);
@@ -108,14 +113,25 @@ __global__ __launch_bounds__(256) void k_ml_rank_fwd(const float* __restrict__ p
 
 // grad[row][p] = coef[1] * [covered] (softmax_n - onehot) + [row positive] (coef[0] (p - t) + (rowcoef[k][0] t + rowcoef[k][1] p) p (1 - p))
 // coef (device): [0] = g_mask w_mask / (K P), [1] = g_rank w_rank / (B P);  rowcoef [K][2]: the dice chain rule per row
+// The training tail's form (tl.dice_a != NULL): the coefficients are formed HERE from the upstream gradients (device scalars; NULL = 0)
+// and the per-row dice sums the forward kept — rowcoef / coef are not read — and the targets come from the bank (tgt_row).
+struct MlTail {
+    const int* tgt_row;
+    const float *dice_a, *dice_bc, *g_mask, *g_dice, *g_rank;
+    float c_mask, c_dice, c_rank;   // w_mask / (K P), w_dice / K, w_rank / (B P)
+};
 __global__ __launch_bounds__(256) void k_ml_bwd(const float* __restrict__ pred, const float* __restrict__ target,
                                                 const int* __restrict__ rowk, const float* __restrict__ rowcoef,
                                                 const float* __restrict__ coef, const float* __restrict__ lse,
-                                                const int* __restrict__ top, int Ns, int P, int with_rank, float* __restrict__ grad) {
+                                                const int* __restrict__ top, int Ns, int P, int with_rank, float* __restrict__ grad,
+                                                const MlTail tl) {
     const int b = blockIdx.y;
     const int p = 4 * (blockIdx.x * 256 + threadIdx.x);
     if (p >= P) return;
-    const float cm = coef[0], cr = with_rank ? coef[1] : 0.f;
+    const bool tail = tl.dice_a != nullptr;
+    const float cm = tail ? (tl.g_mask ? tl.g_mask[0] * tl.c_mask : 0.f) : coef[0];
+    const float cr = !with_rank ? 0.f : tail ? (tl.g_rank ? tl.g_rank[0] * tl.c_rank : 0.f) : coef[1];
+    const float gd = (tail && tl.g_dice) ? tl.g_dice[0] * tl.c_dice : 0.f;
     f32x4 l = {0.f, 0.f, 0.f, 0.f};
     int4 tp = make_int4(-1, -1, -1, -1);
     if (with_rank) {
@@ -139,8 +155,16 @@ __global__ __launch_bounds__(256) void k_ml_bwd(const float* __restrict__ pred, 
                 if (tpv[e] >= 0) g[e] = cr * (__expf(z[e] - l[e]) - (tpv[e] == n ? 1.f : 0.f));
         }
         if (k >= 0) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(target + off);
-            const float ca = rowcoef[2 * k], cb = rowcoef[2 * k + 1];
+            const f32x4 t = *reinterpret_cast<const f32x4*>(target + (tl.tgt_row ? (size_t)tl.tgt_row[b * Ns + n] * P + p : off));
+            float ca, cb;
+            if (tail) {   // the dice chain rule per row: d/dp of 1 - 2 a / (b + c)
+                const float a = tl.dice_a[k], bc = tl.dice_bc[k];
+                ca = gd * (-2.0f / bc);
+                cb = gd * (4.0f * a / (bc * bc));
+            } else {
+                ca = rowcoef[2 * k];
+                cb = rowcoef[2 * k + 1];
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float pp = 1.0f / (1.0f + __expf(-z[e]));
@@ -303,6 +327,138 @@ __global__ __launch_bounds__(256) void k_upsample_bwd2(const float* __restrict__
     }
 }
 
+
+// ---- the training tail (round 5): what `get_targets` + `loss` do per stage as FOUR small kernels around the three mask-loss passes.
+// k_stage_targets: one workgroup per image writes that image's rows of labels / label_weights / row_weight / rowk / tgt_row and its
+// slice of pos_rows (knet/det/kernel_update_head.py:332-441 — `_get_target_single` per image + the concatenation).
+struct TailBatch { VknTailImage img[VKN_TAIL_MAX_IMAGES]; };
+__global__ __launch_bounds__(256) void k_stage_targets(const TailBatch batch, int b0, int N, int S, int T, int ncls, int wcols, float pw,
+                                                       long long* __restrict__ labels, float* __restrict__ label_weights,
+                                                       float* __restrict__ row_weight, int* __restrict__ rowk,
+                                                       long long* __restrict__ pos_rows, int* __restrict__ tgt_row,
+                                                       int* __restrict__ status) {
+    const VknTailImage& im = batch.img[blockIdx.x];
+    const int Ns = N + S, tid = threadIdx.x;
+    const size_t base = (size_t)(b0 + blockIdx.x) * Ns;
+    for (int i = tid; i < Ns; i += 256) {
+        labels[base + i] = ncls;     // background
+        row_weight[base + i] = 0.f;
+        rowk[base + i] = -1;
+        tgt_row[base + i] = -1;
+    }
+    // prediction rows: 1 over the first `wcols` columns (the thing columns when stuff targets exist, :388; else all); stuff rows: the
+    // identity over the stuff columns (:391)
+    for (int i = tid; i < Ns * ncls; i += 256) {
+        const int r = i / ncls, c = i - r * ncls;
+        label_weights[base * ncls + i] = r < N ? (c < wcols ? 1.f : 0.f) : ((c >= T && c - T == r - N) ? 1.f : 0.f);
+    }
+    int bad = 0;
+    __syncthreads();
+    for (int j = tid; j < im.k; j += 256) {   // matched predictions: ascending rows (vkn_lsap_batch_f32 emits them sorted)
+        const int r = im.row_ind[j], g = im.col_ind[j];
+        const size_t row = base + r;
+        labels[row] = im.gt_labels[g];
+        row_weight[row] = 1.f;
+        tgt_row[row] = im.gt_row0 + g;
+        rowk[row] = im.pos0 + j;
+        pos_rows[im.pos0 + j] = (long long)row;
+        if (pw != 1.f)
+            for (int c = 0; c < wcols; ++c) label_weights[row * ncls + c] = pw;
+    }
+    for (int j = tid; j < im.n_sem; j += 256) {   // present stuff classes: row N + (class - T), positives in ascending row order
+        long long c = im.sem_cls[j];
+        int rank = 0;
+        for (int i = 0; i < im.n_sem; ++i) {
+            const long long ci = im.sem_cls[i];
+            rank += (ci < c || (ci == c && i < j)) ? 1 : 0;
+        }
+        if (c < T || c >= T + S) { bad |= 1; c = T; }   // out of range: a valid dummy row, reported through `status`
+        const size_t row = base + N + (int)(c - T);
+        labels[row] = c;
+        row_weight[row] = 1.f;
+        tgt_row[row] = im.sem_row0 + j;
+        rowk[row] = im.pos0 + im.k + rank;
+        pos_rows[im.pos0 + im.k + rank] = (long long)row;
+    }
+    if (bad && status) atomicOr(status, bad);
+}
+
+// k_tail_final: ONE workgroup turns the partial sums of k_focal / k_ml_rows / k_ml_rank_fwd into the stage's five outputs
+//   out[0] loss_cls = w_cls sum_focal / avg      out[1] pos_acc = 100 #(argmax == label over the K positive rows) / K
+//   out[2] loss_mask = w_mask sum_bce / (K P)    out[3] loss_dice = w_dice mean_k(1 - 2 a / ((b + eps) + (c + eps)))
+//   out[4] loss_rank = w_rank sum_rank / (B P)   and keeps a, bc per positive row for backward.  Fixed-order sums: deterministic.
+__device__ __forceinline__ float tail_block_sum(float v, float* red) {
+    v = vkn_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void k_tail_final(const VknTailCfg cfg, const float* __restrict__ avg_dev,
+                                                    const float* __restrict__ focal_partial, int n_focal,
+                                                    const float* __restrict__ row_partial, int K, int nchunk,
+                                                    const float* __restrict__ rank_partial, int n_rank,
+                                                    const float* __restrict__ cls_logits, const long long* __restrict__ labels,
+                                                    const long long* __restrict__ pos_rows, int ncls, int B, int P,
+                                                    float* __restrict__ out, float* __restrict__ dice_a, float* __restrict__ dice_bc) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    float f = 0.f;
+    for (int i = tid; i < n_focal; i += 256) f += focal_partial[i];
+    f = tail_block_sum(f, red);
+    float bce = 0.f, dice = 0.f, hit = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            const float* q = row_partial + ((size_t)k * nchunk + c) * 4;
+            s0 += q[0]; s1 += q[1]; s2 += q[2]; s3 += q[3];
+        }
+        const float bc = (s2 + cfg.dice_eps) + (s3 + cfg.dice_eps);
+        bce += s0;
+        dice += 1.0f - (2.0f * s1) / bc;
+        dice_a[k] = s1;
+        dice_bc[k] = bc;
+        if (cls_logits) {   // top-1 of the row (first maximum) against its label
+            const size_t row = (size_t)pos_rows[k];
+            const float* z = cls_logits + row * ncls;
+            int am = 0;
+            float mx = z[0];
+            for (int c = 1; c < ncls; ++c)
+                if (z[c] > mx) { mx = z[c]; am = c; }
+            hit += ((long long)am == labels[row]) ? 1.f : 0.f;
+        }
+    }
+    bce = tail_block_sum(bce, red);
+    dice = tail_block_sum(dice, red);
+    hit = tail_block_sum(hit, red);
+    float rk = 0.f;
+    for (int i = tid; i < n_rank; i += 256) rk += rank_partial[i];
+    rk = tail_block_sum(rk, red);
+    if (tid == 0) {
+        const float avg = avg_dev ? avg_dev[0] : cfg.avg_factor;
+        out[0] = f * (cfg.w_cls / avg);
+        out[1] = hit * (100.0f / (float)K);
+        out[2] = cfg.w_mask * (bce / ((float)K * (float)P));
+        out[3] = cfg.w_dice * (dice / (float)K);
+        out[4] = cfg.with_rank ? cfg.w_rank * (rk / ((float)B * (float)P)) : 0.f;
+    }
+}
+
+// out = in * (host_scale * g / d), g and d device scalars (NULL = 1): the backward of a loss that is `sum * weight / avg_factor`
+__global__ __launch_bounds__(256) void k_scale_by(const float* __restrict__ in, const float* __restrict__ g, const float* __restrict__ d,
+                                                  float host_scale, float* __restrict__ out, size_t n) {
+    const float s = host_scale * (g ? g[0] : 1.f) / (d ? d[0] : 1.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i] * s;
+}
+
+// status |= flag when any of v[0 .. n) lies outside [lo, hi)
+__global__ __launch_bounds__(256) void k_check_range(const long long* __restrict__ v, size_t n, long long lo, long long hi, int flag,
+                                                     int* __restrict__ status) {
+    int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) bad |= (v[i] < lo || v[i] >= hi) ? 1 : 0;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, flag);
+}
+
 }  // namespace
 
 extern "C" {
@@ -355,24 +511,29 @@ int vkn_focal_loss_f32(const float* logits, const long long* labels, const float
 int vkn_mask_losses_chunks(int P) { return P > 0 ? (P + ML_CHUNK - 1) / ML_CHUNK : 0; }
 int vkn_mask_losses_blocks(int P) { return P > 0 ? (P / ML_PX + 255) / 256 : 0; }   // workgroups per frame of k_ml_rank_fwd
 
-int vkn_mask_losses_fwd_f32(const float* pred, const float* target, const long long* pos_rows, const int* rowk, int K, int B, int Ns,
-                            int P, int with_rank, float* row_partial, float* lse, int* top, float* rank_partial, void* stream) {
+static int ml_fwd(const float* pred, const float* target, const int* tgt_row, const long long* pos_rows, const int* rowk, int K, int B,
+                  int Ns, int P, int with_rank, float* row_partial, float* lse, int* top, float* rank_partial, void* stream) {
     if (!pred || !target || B <= 0 || Ns <= 0 || P <= 0 || K < 0) return VKN_E_ARG;
     if ((P & 3) || ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target)) & 15)) return VKN_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (K > 0) {
         if (!pos_rows || !row_partial) return VKN_E_ARG;
-        hipLaunchKernelGGL(k_ml_rows, dim3(vkn_mask_losses_chunks(P), K), dim3(256), 0, st, pred, target, pos_rows, P,
+        hipLaunchKernelGGL(k_ml_rows, dim3(vkn_mask_losses_chunks(P), K), dim3(256), 0, st, pred, target, tgt_row, pos_rows, P,
                            vkn_mask_losses_chunks(P), row_partial);
         VKN_CHECK_LAUNCH();
     }
     if (with_rank) {
         if (!rowk || !lse || !top || !rank_partial) return VKN_E_ARG;
-        hipLaunchKernelGGL(k_ml_rank_fwd, dim3(vkn_mask_losses_blocks(P), B), dim3(256), 0, st, pred, target, rowk, Ns, P, lse, top,
-                           rank_partial);
+        hipLaunchKernelGGL(k_ml_rank_fwd, dim3(vkn_mask_losses_blocks(P), B), dim3(256), 0, st, pred, target, tgt_row, rowk, Ns, P, lse,
+                           top, rank_partial);
         VKN_CHECK_LAUNCH();
     }
     return VKN_OK;
+}
+
+int vkn_mask_losses_fwd_f32(const float* pred, const float* target, const long long* pos_rows, const int* rowk, int K, int B, int Ns,
+                            int P, int with_rank, float* row_partial, float* lse, int* top, float* rank_partial, void* stream) {
+    return ml_fwd(pred, target, nullptr, pos_rows, rowk, K, B, Ns, P, with_rank, row_partial, lse, top, rank_partial, stream);
 }
 
 int vkn_mask_losses_bwd_f32(const float* pred, const float* target, const int* rowk, const float* rowcoef, const float* coef,
@@ -381,8 +542,93 @@ int vkn_mask_losses_bwd_f32(const float* pred, const float* target, const int* r
     if (with_rank && (!lse || !top)) return VKN_E_ARG;
     if ((P & 3) || ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(grad)) & 15))
         return VKN_E_ALIGN;
+    MlTail tl = {};
     hipLaunchKernelGGL(k_ml_bwd, dim3((P / 4 + 255) / 256, B, 4), dim3(256), 0, static_cast<hipStream_t>(stream), pred, target, rowk,
-                       rowcoef, coef, lse, top, Ns, P, with_rank, grad);
+                       rowcoef, coef, lse, top, Ns, P, with_rank, grad, tl);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+// ---- the training tail (vkn.h)
+size_t vkn_sizeof_tail_image(void) { return sizeof(VknTailImage); }
+size_t vkn_sizeof_tail_cfg(void) { return sizeof(VknTailCfg); }
+
+int vkn_stage_targets(const VknTailImage* imgs, int B, int N, int S, int T, int ncls, float pos_weight, long long* labels,
+                      float* label_weights, float* row_weight, int* rowk, long long* pos_rows, int* tgt_row, int* status, void* stream) {
+    if (!imgs || B <= 0 || N <= 0 || S < 0 || T < 0 || ncls <= 0 || !labels || !label_weights || !row_weight || !rowk || !pos_rows || !tgt_row)
+        return VKN_E_ARG;
+    if (S > 0 && T + S > ncls) return VKN_E_SHAPE;
+    const float pw = pos_weight <= 0.f ? 1.f : pos_weight;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int b0 = 0; b0 < B; b0 += VKN_TAIL_MAX_IMAGES) {
+        const int nb = (B - b0 < VKN_TAIL_MAX_IMAGES) ? B - b0 : VKN_TAIL_MAX_IMAGES;
+        TailBatch batch;
+        for (int k = 0; k < nb; ++k) {
+            const VknTailImage& im = imgs[b0 + k];
+            if (im.k < 0 || im.k > N || im.n_sem < 0 || im.n_sem > (S > 0 ? 4 * S : 0) || (im.k && (!im.row_ind || !im.col_ind || !im.gt_labels)) ||
+                (im.n_sem && !im.sem_cls))
+                return VKN_E_ARG;
+            batch.img[k] = im;
+        }
+        hipLaunchKernelGGL(k_stage_targets, dim3(nb), dim3(256), 0, st, batch, b0, N, S, T, ncls, S > 0 ? T : ncls, pw, labels, label_weights,
+                           row_weight, rowk, pos_rows, tgt_row, status);
+        VKN_CHECK_LAUNCH();
+    }
+    return VKN_OK;
+}
+
+int vkn_mask_losses_fwd_bank_f32(const float* pred, const float* bank, const int* tgt_row, const long long* pos_rows, const int* rowk,
+                                 int K, int B, int Ns, int P, int with_rank, float* row_partial, float* lse, int* top,
+                                 float* rank_partial, void* stream) {
+    if (!tgt_row) return VKN_E_ARG;
+    return ml_fwd(pred, bank, tgt_row, pos_rows, rowk, K, B, Ns, P, with_rank, row_partial, lse, top, rank_partial, stream);
+}
+
+int vkn_stage_losses_final_f32(const VknTailCfg* cfg, const float* avg_factor_dev, const float* focal_partial, int n_focal,
+                               const float* row_partial, int K, int nchunk, const float* rank_partial, int n_rank,
+                               const float* cls_logits, const long long* labels, const long long* pos_rows, int ncls, int B, int P,
+                               float* losses, float* dice_a, float* dice_bc, void* stream) {
+    if (!cfg || !losses || K <= 0 || !row_partial || !dice_a || !dice_bc || nchunk <= 0 || B <= 0 || P <= 0 || n_focal < 0 || n_rank < 0)
+        return VKN_E_ARG;
+    if ((n_focal && !focal_partial) || (n_rank && !rank_partial) || (cls_logits && (!labels || !pos_rows || ncls <= 0))) return VKN_E_ARG;
+    hipLaunchKernelGGL(k_tail_final, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), *cfg, avg_factor_dev, focal_partial, n_focal,
+                       row_partial, K, nchunk, rank_partial, n_rank, cls_logits, labels, pos_rows, ncls, B, P, losses, dice_a, dice_bc);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_mask_losses_bwd_bank_f32(const float* pred, const float* bank, const int* tgt_row, const int* rowk, const float* dice_a,
+                                 const float* dice_bc, const float* g_mask, const float* g_dice, const float* g_rank, float w_mask,
+                                 float w_dice, float w_rank, int K, const float* lse, const int* top, int B, int Ns, int P,
+                                 int with_rank, float* grad, void* stream) {
+    if (!pred || !bank || !tgt_row || !rowk || !dice_a || !dice_bc || !grad || B <= 0 || Ns <= 0 || P <= 0 || K <= 0) return VKN_E_ARG;
+    if (with_rank && (!lse || !top)) return VKN_E_ARG;
+    if ((P & 3) || ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(bank) | reinterpret_cast<uintptr_t>(grad)) & 15))
+        return VKN_E_ALIGN;
+    MlTail tl = {tgt_row, dice_a, dice_bc, g_mask, g_dice, g_rank, (float)((double)w_mask / ((double)K * (double)P)),
+                 (float)((double)w_dice / (double)K), (float)((double)w_rank / ((double)B * (double)P))};
+    hipLaunchKernelGGL(k_ml_bwd, dim3((P / 4 + 255) / 256, B, 4), dim3(256), 0, static_cast<hipStream_t>(stream), pred, bank, rowk,
+                       (const float*)nullptr, (const float*)nullptr, lse, top, Ns, P, with_rank, grad, tl);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_scale_by_f32(const float* in, const float* g, const float* d, float host_scale, float* out, size_t n, void* stream) {
+    if (!in || !out) return VKN_E_ARG;
+    if (n == 0) return VKN_OK;
+    const size_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_scale_by, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), in, g, d,
+                       host_scale, out, n);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_check_range_i64(const long long* v, size_t n, long long lo, long long hi, int flag, int* status, void* stream) {
+    if (!status || (n && !v)) return VKN_E_ARG;
+    if (n == 0) return VKN_OK;
+    const size_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_check_range, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(256), 0, static_cast<hipStream_t>(stream), v, n, lo, hi,
+                       flag, status);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -190,6 +190,8 @@ class KernelIterHead(BaseRoIHead):
             out.append(r)
         return out
 
+    fused_tail = True     # False: per-image sampler -> get_targets -> loss, op by op (A/B; taken anyway whenever train_tail.TailStep declines)
+
     def _train_stages(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, imgs_whwh=None,
                       gt_sem_seg=None, gt_sem_cls=None, stage_kwargs=None):
         """The per-stage assign -> sample -> targets -> loss loop shared by `forward_train` (reference :139-231) and the video
@@ -208,9 +210,18 @@ class KernelIterHead(BaseRoIHead):
             gt_masks = [g.bool().float() for g in gt_masks]
         object_feats = proposal_feats
         all_stage_loss, assign_results, mask_results = {}, None, None
+        # the fused loss tail (train_tail.py): the batch's ground truth as one bank, targets and losses per stage on the library's
+        # kernels; None whenever a precondition fails — then the op-by-op path below runs (same values)
+        from .train_tail import TailStep
+        tail = TailStep.begin(self, x.device, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls)
+        if tail is not None:
+            gt_masks = tail.gt_views
         if self.mask_assigner and hasattr(self.mask_assigner[0], 'validate_labels'):
             # the labels do not change between stages: one range check for the whole step (on the device, reported asynchronously)
-            self.mask_assigner[0].validate_labels(gt_labels, self.num_thing_classes)
+            if tail is not None:
+                self.mask_assigner[0].validate_labels(gt_labels, self.num_thing_classes, status=tail.status)
+            else:
+                self.mask_assigner[0].validate_labels(gt_labels, self.num_thing_classes)
         for stage in range(self.num_stages):
             extra = stage_kwargs(stage) if stage_kwargs is not None else {}
             mask_results = self._mask_forward(stage, x, object_feats, mask_preds, img_metas, **extra)
@@ -220,15 +231,24 @@ class KernelIterHead(BaseRoIHead):
                 assign_masks, assign_cls = scaled_mask_preds.detach(), cls_score.detach()
             if stage < self.assign_stages:       # later stages keep the last assignment (:196)
                 assign_results = self._assign_batch(stage, assign_masks, assign_cls, gt_masks, gt_labels, img_metas)
-            sampler = self.mask_sampler[stage]
-            sampling_results = [sampler.sample(assign_results[i], scaled_mask_preds[i], gt_masks[i]) for i in range(num_imgs)]
             head = self.mask_head[stage]
-            mask_targets = head.get_targets(sampling_results, gt_masks, gt_labels, self.train_cfg[stage], True,
-                                            gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
-            for key, value in head.loss(object_feats, cls_score, scaled_mask_preds, *mask_targets, imgs_whwh=imgs_whwh).items():
-                all_stage_loss[f's{stage}_{key}'] = value * self.stage_loss_weights[stage]
+            stage_losses = None
+            if tail is not None and scaled_mask_preds.shape[1] == self.num_proposals + (head.num_stuff_classes if tail.with_sem else 0) \
+                    and tail.stage_ok(head, assign_results, cls_score, scaled_mask_preds):
+                stage_losses = tail.stage_losses(head, self.train_cfg[stage], assign_results, cls_score, scaled_mask_preds)
+            if stage_losses is None:
+                sampler = self.mask_sampler[stage]
+                sampling_results = [sampler.sample(assign_results[i], scaled_mask_preds[i], gt_masks[i]) for i in range(num_imgs)]
+                mask_targets = head.get_targets(sampling_results, gt_masks, gt_labels, self.train_cfg[stage], True,
+                                                gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+                stage_losses = head.loss(object_feats, cls_score, scaled_mask_preds, *mask_targets, imgs_whwh=imgs_whwh)
+            w = self.stage_loss_weights[stage]
+            for key, value in stage_losses.items():
+                all_stage_loss[f's{stage}_{key}'] = value if w == 1 else value * w      # (x * 1 == x: no launch, no autograd node)
             if not self.post_assign:
                 assign_masks, assign_cls = scaled_mask_preds.detach(), cls_score.detach()
+        if tail is not None:
+            tail.finish()
         if self.mask_assigner and hasattr(self.mask_assigner[0], 'check_status'):
             # device assignments report invalid cost matrices through status words: ONE read per step for all stages
             self.mask_assigner[0].check_status(*self.mask_assigner[1:], wait=False)   # (reported at a later poll: no stall)

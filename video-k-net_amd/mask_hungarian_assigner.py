@@ -27,6 +27,33 @@ class AssignResult:
         self.status = None
 
 
+class DeviceAssignResult(AssignResult):
+    """The result of a device assignment of `assign_batch`: `gt_inds` (what the reference's loop and its tests read) exists; `labels`
+    (per-prediction label, -1 = none) and `device_pos_inds` (int64) are three small launches per image that only the sampler path
+    reads — built on first access.  `_pairs32` = the LSAP's own (row, col) int32 pairs, what the fused loss tail consumes."""
+
+    def __init__(self, num_gts, gt_inds, pairs32, gt_labels, status):
+        self.num_gts, self.gt_inds, self.max_overlaps = num_gts, gt_inds, None
+        self._pairs32, self._gt_labels = pairs32, gt_labels
+        self._labels = self._pos = None
+        self.host_pos_inds, self.status = None, status
+
+    @property
+    def device_pos_inds(self):
+        if self._pos is None:
+            self._pos = self._pairs32[0].long()
+        return self._pos
+
+    @property
+    def labels(self):
+        if self._labels is None:
+            n = self.gt_inds.shape[0]
+            lab = self.gt_inds.new_full((n,), -1, dtype=torch.long)
+            lab[self.device_pos_inds] = self._gt_labels.to(device=lab.device, dtype=lab.dtype)[self._pairs32[1].long()]
+            self._labels = lab
+        return self._labels
+
+
 class _AsyncFlags:
     """Error flags computed on the device and read WITHOUT stalling the stream: `push` enqueues a copy of the flag into pinned host
     memory and records an event; `poll` looks only at flags whose event has completed (`wait=True`: all of them).  The training loop
@@ -106,27 +133,29 @@ class MaskHungarianAssigner:
         return (gt_labels.data_ptr(), gt_labels._version, tuple(gt_labels.shape), str(gt_labels.device), int(ncls))
 
     @classmethod
-    def validate_labels(cls, label_tensors, ncls):
+    def validate_labels(cls, label_tensors, ncls, status=None):
         """Range-check the ground-truth labels of a whole batch against the `ncls` class logits ONCE per step, on the device: the result
         goes to the asynchronous flag queue (`FLAGS`), `assign` skips its own per-image check.  An out-of-range label is what makes the
         reference's `cls_pred[:, gt_labels]` raise an IndexError; here the cost kernel clamps the index (no stray read) and the error
         surfaces at the next `FLAGS.poll()` — one step later, without a device -> host synchronisation in the step.  CPU label
-        tensors are checked on the spot."""
+        tensors are checked on the spot.  `status` (device int32 [1]): accumulate the verdict there (bit 1) instead of queueing a
+        flag — the caller hands the word to `FLAGS` itself (the fused training tail: one word per step)."""
         cls._validated.clear()        # (keys name storage: they are only trusted for the step that checked them)
-        dev_bad = []
+        word = status
         for t in label_tensors:
             if not torch.is_tensor(t) or t.numel() == 0:
                 continue
             if t.is_cuda:
-                lo, hi = torch.aminmax(t)
-                dev_bad.append((lo < 0) | (hi >= ncls))
+                if word is None:
+                    word = torch.zeros(1, dtype=torch.int32, device=t.device)
+                ops.check_range(t, 0, ncls, 2, word)          # one small launch per tensor: *word |= 2 when a label is out of range
             else:
                 lo, hi = int(t.min()), int(t.max())
                 if lo < 0 or hi >= ncls:
                     raise IndexError(f'gt_labels outside [0, {ncls}): {lo} .. {hi}')
             cls._validated[cls._label_key(t, ncls)] = weakref.ref(t)    # identity, not address: a recycled allocation must not match
-        if dev_bad:
-            FLAGS.push(torch.stack(dev_bad).any(), f'gt_labels outside [0, {ncls})')
+        if word is not None and status is None:
+            FLAGS.push(word, f'gt_labels outside [0, {ncls})')
 
     _validated = {}
 
@@ -202,15 +231,7 @@ class MaskHungarianAssigner:
             costs = [self.cost_matrix(bbox_preds[i], cls_preds[i], gt_bboxes[i], gt_labels[i]) for i in range(n)]
         gts, rows, cols, status = ops.lsap_device(costs)
         self._remember(status)
-        out = []
-        for i in range(n):
-            r, c = rows[i].long(), cols[i].long()
-            labels = bbox_preds[i].new_full((bbox_preds[i].size(0),), -1, dtype=torch.long)
-            labels[r] = gt_labels[i].to(device=labels.device, dtype=labels.dtype)[c]
-            res = AssignResult(gt_bboxes[i].size(0), gts[i], None, labels=labels)
-            res.device_pos_inds, res.status = r, status
-            out.append(res)
-        return out
+        return [DeviceAssignResult(gt_bboxes[i].size(0), gts[i], (rows[i], cols[i]), gt_labels[i], status) for i in range(n)]
 
     def _remember(self, status):
         """Queue a device status tensor for the next `check_status`.  The list is bounded by FOLDING the oldest entries into one

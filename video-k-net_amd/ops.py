@@ -746,6 +746,23 @@ def assign_costs(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, d
     return cost
 
 
+_LABS32 = {}
+
+
+def _labels_i32(gt_labels, dev):
+    """the batch's labels as ONE int32 tensor — the same tensors arrive once per stage: built once per (tensor identities, versions)"""
+    import weakref
+    key = tuple((l.data_ptr(), l._version, tuple(l.shape), str(l.device)) for l in gt_labels) + (str(dev),)
+    hit = _LABS32.get(key)
+    if hit is not None and all(r() is l for r, l in zip(hit[0], gt_labels)):
+        return hit[1]
+    if len(_LABS32) > 16:
+        _LABS32.clear()
+    labs = torch.cat([l.reshape(-1) for l in gt_labels]).to(device=dev, dtype=torch.int32)
+    _LABS32[key] = ([weakref.ref(l) for l in gt_labels], labs)
+    return labs
+
+
 def assign_costs_batch(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=2.0, dice_weight=4.0, mask_weight=1.0,
                        focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3, dice_pred_min=1e-3, mask_pred_min=1e-2):
     """`assign_costs` for the images of a batch in ONE C call (vkn_assign_costs_batch_f32): lists of per-image [N, H, W] logits,
@@ -758,7 +775,7 @@ def assign_costs_batch(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=
     use_cls = cls_logits is not None and cls_logits[0] is not None and cls_weight != 0
     ncls = cls_logits[0].shape[1] if use_cls else 0
     Gs = [int(g.shape[0]) for g in gt_masks]
-    labs = torch.cat([l.reshape(-1) for l in gt_labels]).to(device=dev, dtype=torch.int32) if use_cls else None
+    labs = _labels_i32(gt_labels, dev) if use_cls else None
     cost = torch.empty((N * sum(Gs),), dtype=torch.float32, device=dev)
     probs = (_lib.VknAssignProblem * n)()
     keep, out, off = [], [], 0
@@ -836,6 +853,15 @@ def mask_losses_bwd(pred, target, rowk, rowcoef, coef, lse, top, B, with_rank):
                                                  top.data_ptr() if with_rank else None, B, R // B, P, 1 if with_rank else 0,
                                                  _ptr(grad), _stream()))
     return grad
+
+
+def check_range(values, lo, hi, flag, status):
+    """*status (device int32 [1]) |= flag when an element of the integer tensor `values` lies outside [lo, hi) (vkn_check_range_i64)."""
+    v = values.reshape(-1)
+    if v.dtype != torch.int64 or not v.is_contiguous():
+        v = v.to(torch.int64).contiguous()
+    with torch.cuda.device(v.device):
+        check(_lib.lib().vkn_check_range_i64(v.data_ptr(), v.numel(), int(lo), int(hi), int(flag), status.data_ptr(), _stream()))
 
 
 def lsap_device(costs):
