@@ -652,6 +652,23 @@ int vkn_mask_losses_bwd_bank_f32(const float* pred, const float* bank, const int
 int vkn_scale_by_f32(const float* in, const float* g, const float* d, float host_scale, float* out, size_t n, void* stream);
 int vkn_check_range_i64(const long long* v, size_t n, long long lo, long long hi, int flag, int* status, void* stream);
 
+/* ---- glue of the BACKWARD passes of the two x-streaming ops (training; the passes themselves are vkn_mask_decode_scaled_f32 and
+ *      vkn_mask_gather_real_f32 with transposed operands — knet/det/kernel_update_head.py:190-195, 247-260 differentiated):
+ *        vkn_pow2_scale_f32      scale8[0] = the power of two s with max|t| s in [2^(target_log2 - 1), 2^target_log2) (s = 2^target_log2
+ *                                for an all-zero t; exponent clamped to +-100), scale8[4] = 1 / s (DEVICE float[8]: both 16-byte
+ *                                aligned).  scratch2: DEVICE unsigned[2], zero before the first use; the kernel re-zeroes it (one
+ *                                scratch per stream).  One launch, no host read.
+ *        vkn_scale_pad_rows_f32  out [B][Rp][P] = t [B][R][P] * *scale (NULL = 1), rows R .. Rp zero
+ *        vkn_transpose_pad_f32   out [B][C][Np] = k [B][N][C]^T * *scale (NULL = 1), columns N .. Np zero
+ *        vkn_threshold_rows_f16  rows [B][Np][P] fp16 = (logits [B][N][P] >= thr_logit) ? 1 : 0, rows N .. Np zero
+ *        vkn_unscale_rows_f32    dk [B][N][C] = dk_p [B][Np][C] * *scale over the first N rows; dkb [B][N] likewise (may be NULL) */
+int vkn_pow2_scale_f32(const float* t, size_t n, int target_log2, float* scale8, unsigned int* scratch2, void* stream);
+int vkn_scale_pad_rows_f32(const float* t, const float* scale, int B, int R, int Rp, size_t P, float* out, void* stream);
+int vkn_transpose_pad_f32(const float* k, const float* scale, int B, int N, int C, int Np, float* out, void* stream);
+int vkn_threshold_rows_f16(const float* logits, float thr_logit, int B, int N, int Np, size_t P, void* rows_f16, void* stream);
+int vkn_unscale_rows_f32(const float* dk_p, const float* dkb_p, const float* scale, int B, int N, int Np, int C, float* dk, float* dkb,
+                         void* stream);
+
 /* ---- quasi-dense embedding association (the `tracker=dict(type='QuasiDenseEmbedTracker', ...)` of the video configs).  Replaces
  *      `QuasiDenseEmbedTracker.match(bboxes, labels, track_feats, frame_id) -> (bboxes, labels, ids)` together with the `update_memo`
  *      and `memo` it calls: knet/video/qdtrack/trackers/quasi_dense_embed_tracker.py:137-207, :47-103, :105-135 (ctor kwargs :11-38).

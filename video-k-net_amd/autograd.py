@@ -66,9 +66,15 @@ class MaskGatherFn(torch.autograd.Function):
         ctx.need_dx = x.requires_grad
         ctx.x_dtype = x.dtype
         if ctx.need_dx:
-            # backward needs nothing but bit(z >= thr): ONE byte per logit is kept for it instead of the fp32 logits
-            # (15 MB -> 3.8 MB per frame and stage at cfg2 size)
-            ctx.save_for_backward(mask_logits >= ops.thr_logit(hard_mask_thr))
+            # backward needs nothing but bit(z >= thr) as the decode kernel's feature rows.  With H*W % 64 == 0 they are written HERE,
+            # once, as the fp16 {0, 1} rows that kernel reads (rows padded to its 32-row contraction step; exact, low half zero, so
+            # they travel as a half-storage map): no bool tensor, no conversion pass in backward.  Else: one byte per logit.
+            B, N, H, W = mask_logits.shape
+            ctx.n = N
+            if (H * W) % 64 == 0 and mask_logits.dtype == torch.float32:
+                ctx.save_for_backward(ops.threshold_rows_f16(mask_logits, hard_mask_thr))
+            else:
+                ctx.save_for_backward(mask_logits >= ops.thr_logit(hard_mask_thr))
         ctx.mark_non_differentiable(cnt)
         return xraw, cnt
 
@@ -76,21 +82,22 @@ class MaskGatherFn(torch.autograd.Function):
     def backward(ctx, dxraw, _dcnt):
         if not ctx.need_dx:
             return None, None, None
-        (bits,) = ctx.saved_tensors                                     # [B, N, H, W] bool
-        B, N, H, W = bits.shape
-        s = _pow2_scale(dxraw)
+        (rows,) = ctx.saved_tensors
+        N = ctx.n
         Np = (N + 31) // 32 * 32
-        kt = _pad_last((dxraw * s).transpose(1, 2), Np)                 # [B, C, Np]
-        # the decode kernel with the bit rows as its feature map, rows padded to the 32-row contraction step.  fp16 {0, 1} is exact
-        # and its low half is zero: with H*W % 64 == 0 the rows travel as a HALF-STORAGE map (one MFMA per operand pair instead of
-        # three, half the bytes of an fp32 bit tensor)
-        rows = torch.empty((B, Np, H, W), dtype=torch.float16 if (H * W) % 64 == 0 else torch.float32, device=bits.device)
-        rows[:, :N] = bits
-        if Np != N:
-            rows[:, N:].zero_()
-        # [B, C, H, W]; the 1 / s is applied inside the kernel (no second pass over dx).  Half-storage x: the gradient leaves in x's
-        # storage type (autograd's contract), rounded once from the fp32 result
-        dx = _decode_unscaled(rows, kt, 1.0 / s)
+        if rows.dtype == torch.bool:                                    # [B, N, H, W] bool: the general path
+            B, _, H, W = rows.shape
+            bits, rows = rows, torch.empty((B, Np, H, W), dtype=torch.float32, device=rows.device)
+            rows[:, :N] = bits
+            if Np != N:
+                rows[:, N:].zero_()
+        # dx = bit^T dxraw: the decode kernel with the bit rows as its feature map and the (power-of-two scaled, transposed, padded)
+        # gradient as its kernels — scale, transpose and pad in one launch each (vkn_pow2_scale_f32, vkn_transpose_pad_f32); the
+        # 1 / s is applied inside the decode kernel.  Half-storage x: the gradient leaves in x's storage type (autograd's
+        # contract), rounded once from the fp32 result
+        s8 = ops.pow2_scale(dxraw)
+        kt = ops.transpose_pad(dxraw, ops.scale_of(s8), Np)             # [B, C, Np]
+        dx = _decode_unscaled(rows, kt, ops.inv_of(s8))
         return (dx if ctx.x_dtype == torch.float32 else dx.to(ctx.x_dtype)), None, None
 
 
@@ -142,8 +149,8 @@ class MaskDecodeFn(torch.autograd.Function):
     def backward(ctx, dz):
         x, kernels = ctx.saved_tensors
         dz = dz.contiguous()
-        s = _pow2_scale(dz)
-        inv = 1.0 / s
+        s8 = ops.pow2_scale(dz)                                           # one launch (vkn_pow2_scale_f32)
+        sc, inv = ops.scale_of(s8), ops.inv_of(s8)
         need_k = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         N = dz.shape[1]
         dk = dkb = dx = None
@@ -152,19 +159,17 @@ class MaskDecodeFn(torch.autograd.Function):
             # half-storage x: dK = dZ x^T runs on the real-operand gather kernel, which reads fp32 features — x widened once (exact);
             # the FORWARD passes are the half-storage kernels (bit-identical to the fp32 ones on the rounded x)
             x = x.float()
+        # dzs = dz * s with the rows zero-padded to the 32-row contraction step: one pass (vkn_scale_pad_rows_f32)
+        dzs = ops.scale_pad_rows(dz, sc)
         if ctx.needs_input_grad[0]:
-            # dx[b, c, p] = sum_n K[b, n, c] dz[b, n, p]: the decode kernel with the (scaled, row-padded) dz as its feature map and
-            # K^T as its kernels; the padded rows are zero, so the gather below may run over them too
-            dzs = _scaled_rows(dz, s)
-            dx = _decode_unscaled(dzs, _pad_last(kernels.reshape(kernels.shape[0], N, -1).transpose(1, 2), dzs.shape[1]), inv)
-            if need_k:
-                dk, dkb = ops.mask_gather_real(x, dzs)
-                dk, dkb = dk[:, :N].mul(inv), dkb[:, :N].mul(inv)
-        elif need_k:
-            dk, dkb = ops.mask_gather_real(x, dz * s)
-            dk, dkb = dk.mul_(inv), dkb.mul_(inv)
-        if dx is not None and xdt != torch.float32:
-            dx = dx.to(xdt)
+            # dx[b, c, p] = sum_n K[b, n, c] dz[b, n, p]: the decode kernel with dzs as its feature map and K^T (padded) as its kernels
+            kT = ops.transpose_pad(kernels.reshape(kernels.shape[0], N, -1), None, dzs.shape[1])
+            dx = _decode_unscaled(dzs, kT, inv)
+            if xdt != torch.float32:
+                dx = dx.to(xdt)
+        if need_k:
+            # the padded rows are zero, so the gather may run over them too; 1 / s and the slice in one launch
+            dk, dkb = ops.unscale_rows(*ops.mask_gather_real(x, dzs), inv, N)
         return dx, dk if ctx.needs_input_grad[1] else None, dkb if (ctx.has_bias and ctx.needs_input_grad[2]) else None
 
 

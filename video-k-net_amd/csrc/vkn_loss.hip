@@ -459,6 +459,114 @@ __global__ __launch_bounds__(256) void k_check_range(const long long* __restrict
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, flag);
 }
 
+// ---- glue of the gather / decode BACKWARD passes (autograd.py), each formerly 2 - 8 element-wise torch launches:
+// k_absmax_pow2: s = the power of two that puts max|t| into [2^(tlog2 - 1), 2^tlog2) (what the f16 hi/lo split of the gradient operands
+// wants), out[0] = s, out[4] = 1 / s.  One launch: block maxima meet in scratch[0] (atomicMax on the bit pattern of a non-negative
+// float), the LAST block (ticket in scratch[1]) finishes and re-zeroes the scratch for the next call on the stream.
+__device__ __forceinline__ float tail_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__global__ __launch_bounds__(256) void k_absmax_pow2(const float* __restrict__ t, size_t n, int vec, int tlog2, float* __restrict__ out,
+                                                     unsigned* __restrict__ scratch) {
+    __shared__ float red[4];
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        const f32x4* t4 = reinterpret_cast<const f32x4*>(t);
+        for (size_t i = i0; i < n / 4; i += stride) {
+            const f32x4 v = t4[i];
+            m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+        for (size_t i = (n / 4) * 4 + i0; i < n; i += stride) m = fmaxf(m, fabsf(t[i]));
+    } else {
+        for (size_t i = i0; i < n; i += stride) m = fmaxf(m, fabsf(t[i]));
+    }
+    m = tail_wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(&scratch[0], __float_as_uint(m));
+        __threadfence();
+        if (atomicAdd(&scratch[1], 1u) == gridDim.x - 1) {
+            const float mm = __uint_as_float(atomicMax(&scratch[0], 0u));
+            int e = 0;
+            if (mm > 0.f) (void)frexpf(mm, &e);   // mm = mantissa 2^e, mantissa in [0.5, 1)
+            const int sh = min(max(tlog2 - e, -100), 100);
+            const float sc = ldexpf(1.0f, sh);
+            out[0] = sc;
+            out[4] = 1.0f / sc;
+            scratch[0] = 0u;
+            scratch[1] = 0u;
+        }
+    }
+}
+
+// out [B][Rp][P] = t [B][R][P] * s, rows R .. Rp zero (the decode kernel's 32-row contraction step)
+__global__ __launch_bounds__(256) void k_scale_pad_rows(const float* __restrict__ t, const float* __restrict__ sc, int R, int Rp, size_t P,
+                                                        int vec, float* __restrict__ out) {
+    const int b = blockIdx.y / Rp, r = blockIdx.y - b * Rp;
+    const float s = sc ? sc[0] : 1.f;
+    float* o = out + ((size_t)b * Rp + r) * P;
+    const float* src = t + ((size_t)b * R + r) * P;
+    const size_t lo = (size_t)blockIdx.x * 4096, hi = lo + 4096 < P ? lo + 4096 : P;
+    if (vec) {
+        for (size_t p = lo + 4 * threadIdx.x; p < hi; p += 1024) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < R) { v = *reinterpret_cast<const f32x4*>(src + p); v *= s; }
+            *reinterpret_cast<f32x4*>(o + p) = v;
+        }
+    } else {
+        for (size_t p = lo + threadIdx.x; p < hi; p += 256) o[p] = r < R ? src[p] * s : 0.f;
+    }
+}
+
+// out [B][C][Np] = k [B][N][C]^T * s, columns N .. Np zero
+__global__ __launch_bounds__(256) void k_transpose_pad(const float* __restrict__ k, const float* __restrict__ sc, int N, int C, int Np,
+                                                       float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const float s = sc ? sc[0] : 1.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < C * Np; i += gridDim.x * 256) {
+        const int c = i / Np, n = i - c * Np;
+        out[(size_t)b * C * Np + i] = n < N ? k[((size_t)b * N + n) * C + c] * s : 0.f;
+    }
+}
+
+// rows [B][Np][P] f16 = (logits [B][N][P] >= thr) ? 1 : 0, rows N .. Np zero: what the gather's backward multiplies with, kept by forward
+__global__ __launch_bounds__(256) void k_threshold_rows(const float* __restrict__ z, float thr, int N, int Np, size_t P, int vec,
+                                                        _Float16* __restrict__ out) {
+    const int b = blockIdx.y / Np, r = blockIdx.y - b * Np;
+    _Float16* o = out + ((size_t)b * Np + r) * P;
+    const float* src = z + ((size_t)b * N + r) * P;
+    const size_t lo = (size_t)blockIdx.x * 4096, hi = lo + 4096 < P ? lo + 4096 : P;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    if (vec) {
+        for (size_t p = lo + 4 * threadIdx.x; p < hi; p += 1024) {
+            h4 v = {0, 0, 0, 0};
+            if (r < N) {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(src + p);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = zz[e] >= thr ? (_Float16)1.0f : (_Float16)0.0f;
+            }
+            *reinterpret_cast<h4*>(o + p) = v;
+        }
+    } else {
+        for (size_t p = lo + threadIdx.x; p < hi; p += 256) o[p] = (r < N && src[p] >= thr) ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+}
+
+// dk [B][N][C] = dk_p [B][Np][C][:N] * s, dkb [B][N] = dkb_p [B][Np][:N] * s
+__global__ __launch_bounds__(256) void k_unscale_rows(const float* __restrict__ dkp, const float* __restrict__ dkbp, const float* __restrict__ sc,
+                                                      int N, int Np, int C, float* __restrict__ dk, float* __restrict__ dkb) {
+    const int b = blockIdx.y;
+    const float s = sc[0];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N * C; i += gridDim.x * 256) dk[(size_t)b * N * C + i] = dkp[(size_t)b * Np * C + i] * s;
+    if (blockIdx.x == 0 && dkb)
+        for (int n = threadIdx.x; n < N; n += 256) dkb[(size_t)b * N + n] = dkbp[(size_t)b * Np + n] * s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -629,6 +737,58 @@ int vkn_check_range_i64(const long long* v, size_t n, long long lo, long long hi
     const size_t nb = (n + 255) / 256;
     hipLaunchKernelGGL(k_check_range, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(256), 0, static_cast<hipStream_t>(stream), v, n, lo, hi,
                        flag, status);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+
+// ---- glue of the gather / decode backward passes (vkn.h)
+int vkn_pow2_scale_f32(const float* t, size_t n, int target_log2, float* scale8, unsigned int* scratch2, void* stream) {
+    if (!scale8 || !scratch2 || (n && !t)) return VKN_E_ARG;
+    const size_t nb = (n + 4095) / 4096;
+    const int vec = (reinterpret_cast<uintptr_t>(t) & 15) == 0;
+    hipLaunchKernelGGL(k_absmax_pow2, dim3((unsigned)(nb < 1 ? 1 : (nb < 1024 ? nb : 1024))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       t, n, vec, target_log2, scale8, scratch2);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_scale_pad_rows_f32(const float* t, const float* scale, int B, int R, int Rp, size_t P, float* out, void* stream) {
+    if (!t || !out || B <= 0 || R <= 0 || Rp < R || P == 0) return VKN_E_ARG;
+    if ((size_t)B * Rp > 65535) return VKN_E_SHAPE;
+    const int vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    hipLaunchKernelGGL(k_scale_pad_rows, dim3((unsigned)((P + 4095) / 4096), B * Rp), dim3(256), 0, static_cast<hipStream_t>(stream), t,
+                       scale, R, Rp, P, vec, out);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_transpose_pad_f32(const float* k, const float* scale, int B, int N, int C, int Np, float* out, void* stream) {
+    if (!k || !out || B <= 0 || N <= 0 || C <= 0 || Np < N) return VKN_E_ARG;
+    if (B > 65535) return VKN_E_SHAPE;
+    const int nb = (C * Np + 255) / 256;
+    hipLaunchKernelGGL(k_transpose_pad, dim3(nb < 64 ? nb : 64, B), dim3(256), 0, static_cast<hipStream_t>(stream), k, scale, N, C, Np, out);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_threshold_rows_f16(const float* logits, float thr_logit, int B, int N, int Np, size_t P, void* rows_f16, void* stream) {
+    if (!logits || !rows_f16 || B <= 0 || N <= 0 || Np < N || P == 0) return VKN_E_ARG;
+    if ((size_t)B * Np > 65535) return VKN_E_SHAPE;
+    const int vec = (P % 4 == 0) && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (reinterpret_cast<uintptr_t>(rows_f16) & 7) == 0;
+    hipLaunchKernelGGL(k_threshold_rows, dim3((unsigned)((P + 4095) / 4096), B * Np), dim3(256), 0, static_cast<hipStream_t>(stream), logits,
+                       thr_logit, N, Np, P, vec, static_cast<_Float16*>(rows_f16));
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_unscale_rows_f32(const float* dk_p, const float* dkb_p, const float* scale, int B, int N, int Np, int C, float* dk, float* dkb,
+                         void* stream) {
+    if (!dk_p || !scale || !dk || B <= 0 || N <= 0 || Np < N || C <= 0 || (dkb && !dkb_p)) return VKN_E_ARG;
+    if (B > 65535) return VKN_E_SHAPE;
+    const int nb = (N * C + 255) / 256;
+    hipLaunchKernelGGL(k_unscale_rows, dim3(nb < 64 ? nb : 64, B), dim3(256), 0, static_cast<hipStream_t>(stream), dk_p, dkb_p, scale, N, Np,
+                       C, dk, dkb);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -855,6 +855,77 @@ def mask_losses_bwd(pred, target, rowk, rowcoef, coef, lse, top, B, with_rank):
     return grad
 
 
+_POW2_SCRATCH = {}
+
+
+def pow2_scale(t, target_log2=10):
+    """-> device float32 [8] with [0] = the power of two s putting max|t| into [2^(target_log2 - 1), 2^target_log2) and [4] = 1 / s
+    (vkn_pow2_scale_f32: one launch, nothing read on the host).  `scale_of(s8)` / `inv_of(s8)` give the two as 16-byte aligned views."""
+    t = _req(t.detach(), 't')
+    dev = t.device
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    scr = _POW2_SCRATCH.get(key)
+    if scr is None:
+        scr = _POW2_SCRATCH[key] = torch.zeros(2, dtype=torch.int32, device=dev)     # the kernel leaves it zero again
+    out = torch.empty(8, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().vkn_pow2_scale_f32(_ptr(t), t.numel(), int(target_log2), _ptr(out), scr.data_ptr(), _stream()))
+    return out
+
+
+def scale_of(s8):
+    return s8[0:1]
+
+
+def inv_of(s8):
+    return s8[4:5]
+
+
+def scale_pad_rows(t, scale, mult=32):
+    """t [B, R, ...] * scale (device scalar or None) with the rows zero-padded to a multiple of `mult` (vkn_scale_pad_rows_f32)."""
+    t = _req(t, 't')
+    B, R = t.shape[:2]
+    P = t[0, 0].numel()
+    Rp = (R + mult - 1) // mult * mult
+    out = torch.empty((B, Rp) + tuple(t.shape[2:]), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(_lib.lib().vkn_scale_pad_rows_f32(_ptr(t), _ptr(scale), B, R, Rp, P, _ptr(out), _stream()))
+    return out
+
+
+def transpose_pad(k, scale, Np):
+    """k [B, N, C] -> [B, C, Np] = k^T * scale (device scalar or None), columns N .. Np zero (vkn_transpose_pad_f32)."""
+    k = _req(k, 'k')
+    B, N, C = k.shape
+    out = torch.empty((B, C, Np), dtype=torch.float32, device=k.device)
+    with torch.cuda.device(k.device):
+        check(_lib.lib().vkn_transpose_pad_f32(_ptr(k), _ptr(scale), B, N, C, int(Np), _ptr(out), _stream()))
+    return out
+
+
+def threshold_rows_f16(mask_logits, hard_mask_thr, mult=32):
+    """[B, N, H, W] logits -> fp16 [B, Np, H, W] = (logit >= thr_logit(hard_mask_thr)), rows padded with zeros to a multiple of `mult`."""
+    m = _req(mask_logits, 'mask_logits')
+    B, N = m.shape[:2]
+    P = m[0, 0].numel()
+    Np = (N + mult - 1) // mult * mult
+    out = torch.empty((B, Np) + tuple(m.shape[2:]), dtype=torch.float16, device=m.device)
+    with torch.cuda.device(m.device):
+        check(_lib.lib().vkn_threshold_rows_f16(_ptr(m), thr_logit(hard_mask_thr), B, N, Np, P, _ptr(out), _stream()))
+    return out
+
+
+def unscale_rows(dk_p, dkb_p, scale, N):
+    """(dk_p [B, Np, C], dkb_p [B, Np]) -> (dk [B, N, C], dkb [B, N]) = the first N rows times the device scalar (vkn_unscale_rows_f32)."""
+    dk_p, dkb_p = _req(dk_p, 'dk'), _req(dkb_p, 'dkb')
+    B, Np, C = dk_p.shape
+    dk = torch.empty((B, N, C), dtype=torch.float32, device=dk_p.device)
+    dkb = torch.empty((B, N), dtype=torch.float32, device=dk_p.device)
+    with torch.cuda.device(dk_p.device):
+        check(_lib.lib().vkn_unscale_rows_f32(_ptr(dk_p), _ptr(dkb_p), _ptr(scale), B, int(N), Np, C, _ptr(dk), _ptr(dkb), _stream()))
+    return dk, dkb
+
+
 def check_range(values, lo, hi, flag, status):
     """*status (device int32 [1]) |= flag when an element of the integer tensor `values` lies outside [lo, hi) (vkn_check_range_i64)."""
     v = values.reshape(-1)
