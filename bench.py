@@ -185,7 +185,10 @@ def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
         torch.cuda.tunable.set_filename(os.path.join('/tmp', 'vkn_tunableop_%d.csv' % rank))
     if not getattr(args, 'no_chain_graphs', False):
         head.enable_chain_graphs()                        # every stage's [B*N, C] chain, forward and backward, as captured hipGraphs
-    opt = torch.optim.SGD(head.parameters(), lr=1e-4, momentum=0.9)
+    try:         # one multi-tensor kernel per step instead of the foreach path's three passes over the parameters (same update rule)
+        opt = torch.optim.SGD(head.parameters(), lr=1e-4, momentum=0.9, fused=not getattr(args, 'train_foreach_sgd', False))
+    except (TypeError, RuntimeError, ValueError):
+        opt = torch.optim.SGD(head.parameters(), lr=1e-4, momentum=0.9)
     x, pf, mp = synth_inputs(B, device, rank)
     x.requires_grad_(True)                                 # gradients flow on into the backbone in the real model
     g = torch.Generator(device='cpu').manual_seed(4321 + rank)
@@ -280,6 +283,7 @@ def main():
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the extra data points of `breakdown` that launch other batch sizes / several clips (profiling runs)')
     ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
+    ap.add_argument('--train-foreach-sgd', action='store_true', help='--train A/B: torch.optim.SGD on its foreach path instead of fused=True')
     ap.add_argument('--train-default-stream', action='store_true', help='--train A/B: run the step on the default stream (chain graphs captured on a side stream)')
     ap.add_argument('--train-add-grads', action='store_true', help='--train A/B: zero the gradient buckets and add into their views instead of set_to_none + one batched copy')
     ap.add_argument('--streams', type=int, default=1,

@@ -669,6 +669,11 @@ int vkn_threshold_rows_f16(const float* logits, float thr_logit, int B, int N, i
 int vkn_unscale_rows_f32(const float* dk_p, const float* dkb_p, const float* scale, int B, int N, int Np, int C, float* dk, float* dkb,
                          void* stream);
 
+/*      out [n] = srcs[0] + srcs[1] + ... (HOST array of nsrc <= VKN_SUM_MAX DEVICE pointers), summed in that order, one pass:
+ *      the feature map's gradient is the sum of six contributions per training step (three gathers, three decodes) */
+#define VKN_SUM_MAX 8
+int vkn_sum_n_f32(const float* const* srcs, int nsrc, size_t n, float* out, void* stream);
+
 /* ---- quasi-dense embedding association (the `tracker=dict(type='QuasiDenseEmbedTracker', ...)` of the video configs).  Replaces
  *      `QuasiDenseEmbedTracker.match(bboxes, labels, track_feats, frame_id) -> (bboxes, labels, ids)` together with the `update_memo`
  *      and `memo` it calls: knet/video/qdtrack/trackers/quasi_dense_embed_tracker.py:137-207, :47-103, :105-135 (ctor kwargs :11-38).

@@ -118,3 +118,64 @@ def test_out_of_range_stuff_class_is_reported_not_read(vkn):
         assert all(bool(torch.isfinite(v).all()) for v in losses.values())
         mha.FLAGS.poll(wait=True)
     mha.FLAGS.poll(wait=True)           # nothing is left behind for the next test
+
+
+def test_backward_glue_kernels_vs_torch(vkn):
+    """the single-launch glue of the gather / decode backward passes against the torch expressions they replace: bit for bit"""
+    ops, vag = vkn.ops, vkn.autograd
+    g = torch.Generator(device='cpu').manual_seed(5)
+    for shape, mag in (((4, 117, 64, 96), 3e-5), ((2, 15, 8, 16), 7.0), ((1, 3, 5, 7), 0.0), ((3, 40, 256), 1e-9)):
+        t = (torch.randn(shape, generator=g) * mag).to(DEV)
+        s8 = ops.pow2_scale(t)
+        ref = vag._pow2_scale(t)
+        assert float(ops.scale_of(s8)) == float(ref) and float(ops.inv_of(s8)) == 1.0 / float(ref), shape
+        if t.dim() == 4:
+            got = ops.scale_pad_rows(t, ops.scale_of(s8))
+            assert torch.equal(got, vag._scaled_rows(t, ref))
+            assert torch.equal(ops.scale_pad_rows(t, None)[:, :shape[1]], t)
+            rows = ops.threshold_rows_f16(t, 0.5)
+            want = torch.zeros_like(got, dtype=torch.float16)
+            want[:, :shape[1]] = (t >= ops.thr_logit(0.5)).half()
+            assert torch.equal(rows, want)
+        else:
+            Np = (shape[1] + 31) // 32 * 32
+            assert torch.equal(ops.transpose_pad(t, ops.scale_of(s8), Np), vag._pad_last((t * ref).transpose(1, 2), Np))
+            assert torch.equal(ops.transpose_pad(t, None, shape[1]), t.transpose(1, 2).contiguous())
+            dkb = torch.randn(shape[0], shape[1], generator=g).to(DEV)
+            a, b = ops.unscale_rows(t, dkb, ops.inv_of(s8), shape[1] - 3)
+            assert torch.equal(a, t[:, :shape[1] - 3] * (1.0 / ref)) and torch.equal(b, dkb[:, :shape[1] - 3] * (1.0 / ref))
+    # a second call on the same stream finds the scratch word re-zeroed
+    big, small = torch.full((100000,), 3.0, device=DEV), torch.full((10,), 1e-3, device=DEV)
+    assert float(ops.scale_of(ops.pow2_scale(big))) == 256.0 and float(ops.scale_of(ops.pow2_scale(small))) == float(vag._pow2_scale(small))
+    parts = [torch.randn(3, 5, 11, 13, generator=g).to(DEV) for _ in range(6)]
+    want = parts[0] + parts[1]
+    for p in parts[2:]:
+        want = want + p
+    assert torch.equal(ops.sum_tensors(list(parts)), want)
+    assert torch.equal(ops.sum_tensors(parts[:1]), parts[0])
+    many = [torch.randn(1001, generator=g).to(DEV) for _ in range(11)]     # more than one launch's worth of operands
+    assert maxabs(ops.sum_tensors(list(many)), torch.stack(many).double().sum(0)) < 1e-5
+
+
+def test_x_hub_sums_the_feature_map_gradient_once(vkn):
+    """`autograd.x_hub`: gather + decode consumers park their dx in the hub (no autograd accumulation), an ordinary consumer's gradient
+    joins them, x.grad = the sum — equal to plain autograd's"""
+    vag = vkn.autograd
+    g = torch.Generator(device='cpu').manual_seed(6)
+    B, N, C, H, W = 2, 15, 64, 8, 16
+    x0 = torch.randn(B, C, H, W, generator=g).to(DEV)
+    k = torch.randn(B, N, C, generator=g).to(DEV).requires_grad_(True)
+    m = torch.randn(B, N, H, W, generator=g).to(DEV)
+    gz, gx = torch.randn(B, N, H, W, generator=g).to(DEV) * 1e-3, torch.randn(B, N, C, generator=g).to(DEV) * 1e-2
+
+    def run(hub):
+        x = x0.clone().requires_grad_(True)
+        xs = vag.x_hub(x) if hub else x
+        z1, z2 = vag.mask_decode(xs, k), vag.mask_decode(xs, k * 0.5)
+        xr, _ = vag.mask_gather(xs, m, 0.5)
+        loss = (z1 * gz).sum() + (z2 * gz).sum() + (xr * gx).sum() + (xs * xs).sum() * 1e-3      # the last term: an ordinary consumer
+        k.grad = None
+        loss.backward()
+        return x.grad.clone(), k.grad.clone()
+    (xa, ka), (xb, kb) = run(True), run(False)
+    assert maxabs(xa, xb) < 1e-6 * float(xb.abs().max()) and torch.equal(ka, kb)

@@ -567,6 +567,22 @@ __global__ __launch_bounds__(256) void k_unscale_rows(const float* __restrict__ 
         for (int n = threadIdx.x; n < N; n += 256) dkb[(size_t)b * N + n] = dkbp[(size_t)b * Np + n] * s;
 }
 
+// out = sum of up to VKN_SUM_MAX tensors, one pass (the gradient contributions of the feature map: six per training step, which
+// autograd would add pair by pair — five passes of two reads and one write each)
+struct SumSrc { const float* p[VKN_SUM_MAX]; };
+__global__ __launch_bounds__(256) void k_sum_n(const SumSrc src, int nsrc, size_t n4, size_t n, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = reinterpret_cast<const f32x4*>(src.p[0])[i];
+        for (int k = 1; k < nsrc; ++k) a += reinterpret_cast<const f32x4*>(src.p[k])[i];
+        reinterpret_cast<f32x4*>(out)[i] = a;
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float a = src.p[0][i];
+        for (int k = 1; k < nsrc; ++k) a += src.p[k][i];
+        out[i] = a;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -789,6 +805,24 @@ int vkn_unscale_rows_f32(const float* dk_p, const float* dkb_p, const float* sca
     const int nb = (N * C + 255) / 256;
     hipLaunchKernelGGL(k_unscale_rows, dim3(nb < 64 ? nb : 64, B), dim3(256), 0, static_cast<hipStream_t>(stream), dk_p, dkb_p, scale, N, Np,
                        C, dk, dkb);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+
+int vkn_sum_n_f32(const float* const* srcs, int nsrc, size_t n, float* out, void* stream) {
+    if (!srcs || !out || nsrc <= 0 || nsrc > VKN_SUM_MAX) return VKN_E_ARG;
+    if (n == 0) return VKN_OK;
+    SumSrc src = {};
+    uintptr_t al = reinterpret_cast<uintptr_t>(out);
+    for (int k = 0; k < nsrc; ++k) {
+        if (!srcs[k]) return VKN_E_ARG;
+        src.p[k] = srcs[k];
+        al |= reinterpret_cast<uintptr_t>(srcs[k]);
+    }
+    const size_t n4 = (al & 15) ? 0 : n / 4;
+    const size_t nb = ((n4 ? n4 : n) + 255) / 256;
+    hipLaunchKernelGGL(k_sum_n, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, static_cast<hipStream_t>(stream), src, nsrc, n4, n, out);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

@@ -190,6 +190,7 @@ class KernelIterHead(BaseRoIHead):
             out.append(r)
         return out
 
+    x_hub = not __import__('os').environ.get('VKN_NO_XHUB')     # (A/B switch of autograd.x_hub)
     fused_tail = True     # False: per-image sampler -> get_targets -> loss, op by op (A/B; taken anyway whenever train_tail.TailStep declines)
 
     def _train_stages(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, imgs_whwh=None,
@@ -212,6 +213,9 @@ class KernelIterHead(BaseRoIHead):
         all_stage_loss, assign_results, mask_results = {}, None, None
         # the fused loss tail (train_tail.py): the batch's ground truth as one bank, targets and losses per stage on the library's
         # kernels; None whenever a precondition fails — then the op-by-op path below runs (same values)
+        if self.fused_tail and self.x_hub and torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda and x.requires_grad:
+            from . import autograd as vag
+            x = vag.x_hub(x)        # the six gradient contributions of x (a gather + a decode per stage) are summed in one pass
         from .train_tail import TailStep
         tail = TailStep.begin(self, x.device, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls)
         if tail is not None:

@@ -926,6 +926,30 @@ def unscale_rows(dk_p, dkb_p, scale, N):
     return dk, dkb
 
 
+SUM_MAX = 8
+
+
+def sum_tensors(parts):
+    """parts[0] + parts[1] + ... (same shape; in that order) in ONE pass for fp32 CUDA tensors (vkn_sum_n_f32), else torch adds."""
+    if len(parts) == 1:
+        return parts[0]
+    p0 = parts[0]
+    if not (p0.is_cuda and all(p.dtype == torch.float32 and p.shape == p0.shape and p.device == p0.device for p in parts)):
+        out = parts[0] + parts[1]
+        for p in parts[2:]:
+            out = out + p
+        return out
+    out = None
+    while len(parts) > 1:
+        take = [_req(p, 'part') for p in parts[:SUM_MAX]]
+        arr = (ctypes.c_void_p * len(take))(*[p.data_ptr() for p in take])
+        out = torch.empty_like(take[0])
+        with torch.cuda.device(p0.device):
+            check(_lib.lib().vkn_sum_n_f32(arr, len(take), out.numel(), _ptr(out), _stream()))
+        parts = [out] + list(parts[SUM_MAX:])
+    return out
+
+
 def check_range(values, lo, hi, flag, status):
     """*status (device int32 [1]) |= flag when an element of the integer tensor `values` lies outside [lo, hi) (vkn_check_range_i64)."""
     v = values.reshape(-1)
