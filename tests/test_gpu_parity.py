@@ -175,7 +175,14 @@ def test_stage_by_stage_vs_oracle_and_reference(vkn, name):
             assert maxabs(r['object_feats_track'], g['track']) < 1e-4
 
 
-@pytest.mark.parametrize('flags', [0, 1, 2, 3, 512, 513, 256, 8192], ids=['mfma', 'refkernels', 'exactgemm', 'allexact', 'persistent', 'persistent_ref', 'launches', 'ksplit'])
+def _chain_flags(vkn, chain):
+    """the forms of the [N x C] chain by name; `persistent_h2`: the persistent kernels on the two-term fp16 split (vkn_chain_h2.hip)"""
+    o = vkn.ops
+    return dict(persistent=o.FLAG_CHAIN_PERSISTENT, launches=o.FLAG_CHAIN_LAUNCHES, ksplit=o.FLAG_CHAIN_KSPLIT,
+                persistent_h2=o.FLAG_CHAIN_PERSISTENT | o.FLAG_CHAIN_H2)[chain]
+
+
+@pytest.mark.parametrize('flags', [0, 1, 2, 3, 512, 513, 256, 8192, 512 + 65536], ids=['mfma', 'refkernels', 'exactgemm', 'allexact', 'persistent', 'persistent_ref', 'launches', 'ksplit', 'persistent_h2'])
 @pytest.mark.parametrize('name', ['det_tiny', 'det_odd', 'det_cfg', 'video_tiny', 'video_cfg'])
 def test_head_vs_reference_golden(vkn, name, flags):
     """The fused S-stage call (`simple_test_mask_preds[_plus_previous]`) against the REFERENCE's own outputs."""
@@ -252,7 +259,7 @@ FREE_RUN_LIMITS = {
 }
 
 
-@pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent'])
+@pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent', 'persistent_h2'])
 @pytest.mark.parametrize('name', ['video_vipseg_big', 'det_ytvis', 'video_vipseg_n216'])
 def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name, chain):
     """(`video_vipseg_n216`: BASELINE cfg5 as LITERALLY worded — 150 proposals + 66 stuff kernels = 216 rows, 92x160 features (round 5; 46x80 before).)
@@ -261,9 +268,9 @@ def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name, chain):
     stuff, x2, 2 frames): the free-running 3-stage fused head against the REFERENCE's own outputs."""
     g, case = load_golden(name)
     head, (x, pf, mp, prev) = _build_head(vkn, case)
-    if chain != 'auto':          # (default at these sizes: the few-row chain, vkn_ksplit.hip; all three forms of the chain are held to the same bounds)
+    if chain != 'auto':          # (default at these sizes: the few-row chain, vkn_ksplit.hip; all forms of the chain are held to the same bounds)
         for h in head.mask_head:
-            h.vkn_flags = vkn.ops.FLAG_CHAIN_PERSISTENT if chain == 'persistent' else vkn.ops.FLAG_CHAIN_LAUNCHES
+            h.vkn_flags = _chain_flags(vkn, chain)
     metas = [dict()] * case['B']
     B, N, P = case['B'], case['N'], case['H'] * case['W']
     # kernels whose hand-over masks stay clear of the binarisation threshold in EVERY stage of the reference cannot flip a bit under
@@ -339,7 +346,7 @@ def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name, chain):
 CFG2_FLIP_LIMIT, CFG2_CLEAN_ROWS_MIN, CFG2_CLEAN_LOGIT_ERR = 48, 88, 1.0e-3
 
 
-@pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent'])
+@pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent', 'persistent_h2'])
 def test_cfg2_size_free_running_vs_oracle_flip_budget(vkn, chain):
     """The FREE-RUNNING 3-stage head at BASELINE cfg2 size against the free-running oracle, with the chaos argument measured
     instead of assumed: per stage, the binarised masks may differ from the oracle's only where the oracle's logit
@@ -351,7 +358,7 @@ def test_cfg2_size_free_running_vs_oracle_flip_budget(vkn, chain):
     head, (x, pf, mp, _) = _build_head(vkn, case)
     if chain != 'auto':        # (auto at one frame: the few-row chain, vkn_ksplit.hip)
         for h in head.mask_head:
-            h.vkn_flags = vkn.ops.FLAG_CHAIN_PERSISTENT if chain == 'persistent' else vkn.ops.FLAG_CHAIN_LAUNCHES
+            h.vkn_flags = _chain_flags(vkn, chain)
     traces = []
     run_oracle(case, traces=traces)
     thr = vkn.ops.thr_logit(0.5)
@@ -452,7 +459,7 @@ def test_cfg2_size_properties(vkn):
     assert maxabs(d1, refd) < 2e-4
 
 
-@pytest.mark.parametrize('chain', ['ksplit', 'launches', 'persistent'])
+@pytest.mark.parametrize('chain', ['ksplit', 'launches', 'persistent', 'persistent_h2'])
 def test_cfg2_size_head_vs_oracle(vkn, chain):
     """(All three forms of the [N x C] chain: the few-row chain — the default at one frame —, one launch per GEMM with the row epilogue
     in the producer, and the persistent row-owner kernels.)
@@ -467,7 +474,7 @@ def test_cfg2_size_head_vs_oracle(vkn, chain):
                 B=1, seed=11, video=1)
     head, (x, pf, mp, prev) = _build_head(vkn, case)
     for h in head.mask_head:
-        h.vkn_flags = dict(persistent=vkn.ops.FLAG_CHAIN_PERSISTENT, launches=vkn.ops.FLAG_CHAIN_LAUNCHES, ksplit=vkn.ops.FLAG_CHAIN_KSPLIT)[chain]
+        h.vkn_flags = _chain_flags(vkn, chain)
     traces = []
     obj_r, cls_r, masks_r, scaled_r, track_r = run_oracle(case, traces=traces)
     xd, prevd = _cuda(x, prev)

@@ -4,6 +4,8 @@ knet/det/kernel_iter_head.py:139-231, kernel_update_head.py:279-441): identical 
 identical assignments, gradients to 1e-5 of each tensor's scale.  The op-by-op path is itself checked against the reference goldens
 (test_gpu_train.py::test_forward_train_vs_reference_golden, which now runs THROUGH the fused tail); this file pins the two paths
 to each other, the pieces (`vkn_stage_targets`) to `get_targets` bit for bit, and the error word."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -127,8 +129,11 @@ def test_backward_glue_kernels_vs_torch(vkn):
     for shape, mag in (((4, 117, 64, 96), 3e-5), ((2, 15, 8, 16), 7.0), ((1, 3, 5, 7), 0.0), ((3, 40, 256), 1e-9)):
         t = (torch.randn(shape, generator=g) * mag).to(DEV)
         s8 = ops.pow2_scale(t)
-        ref = vag._pow2_scale(t)
+        # (the torch expression it replaces, `ldexp(1, k)`, is x * pow(2, k) on the device: 4194303.75 for k = 22 — the kernel's scale
+        #  IS the power of two)
+        ref = torch.tensor(2.0 ** (10 - math.frexp(float(t.abs().max()))[1]), device=DEV)
         assert float(ops.scale_of(s8)) == float(ref) and float(ops.inv_of(s8)) == 1.0 / float(ref), shape
+        assert abs(float(vag._pow2_scale(t)) / float(ref) - 1.0) < 1e-6
         if t.dim() == 4:
             got = ops.scale_pad_rows(t, ops.scale_of(s8))
             assert torch.equal(got, vag._scaled_rows(t, ref))
@@ -146,7 +151,7 @@ def test_backward_glue_kernels_vs_torch(vkn):
             assert torch.equal(a, t[:, :shape[1] - 3] * (1.0 / ref)) and torch.equal(b, dkb[:, :shape[1] - 3] * (1.0 / ref))
     # a second call on the same stream finds the scratch word re-zeroed
     big, small = torch.full((100000,), 3.0, device=DEV), torch.full((10,), 1e-3, device=DEV)
-    assert float(ops.scale_of(ops.pow2_scale(big))) == 256.0 and float(ops.scale_of(ops.pow2_scale(small))) == float(vag._pow2_scale(small))
+    assert float(ops.scale_of(ops.pow2_scale(big))) == 256.0 and float(ops.scale_of(ops.pow2_scale(small))) == 2.0 ** 19
     parts = [torch.randn(3, 5, 11, 13, generator=g).to(DEV) for _ in range(6)]
     want = parts[0] + parts[1]
     for p in parts[2:]:

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
-SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_tracker.hip', 'vkn_loss.hip', 'vkn_chain.hip', 'vkn_ksplit.hip', 'vkn_train.hip', 'vkn_api.hip')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_tracker.hip', 'vkn_loss.hip', 'vkn_chain.hip', 'vkn_chain_h2.hip', 'vkn_ksplit.hip', 'vkn_train.hip', 'vkn_api.hip')
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares

@@ -57,6 +57,11 @@ struct PrepW {
     const void *dynft, *dec;
     float *dynft32, *bcnt, *dec32, *decb, *dvec, *kb0, *fmT;
     float* chain_consts;   // packed bias / LayerNorm vectors of the persistent chain kernels (vkn_chain.hip), C == 256 only
+    // the persistent chain's weights once more as fp16 hi / lo tile images (VKN_FLAG_CHAIN_H2, vkn_chain_h2.hip), in VKN_H2_* order;
+    // h2_scale [VKN_H2_COUNT][8]: vkn_pow2_scale_f32's output per matrix ([0] scale, [4] 1 / scale); h2_scratch: its two words
+    const void* h2[VKN_H2_COUNT];
+    float* h2_scale;
+    unsigned* h2_scratch;
 };
 
 inline bool has_composites(const VknDims* d, const VknStageWeights* w) {
@@ -112,6 +117,20 @@ size_t carve_prepared(const VknDims* d, const VknStageWeights* w, char* base, Pr
         p->kb0 = c.take<float>(4);
         p->fmT = c.take<float>(C * C);
         if (d->C == 256 && d->ff <= 2048) p->chain_consts = c.take<float>(vkn_chain_consts_floats());
+    }
+    for (int i = 0; i < VKN_H2_COUNT; ++i) p->h2[i] = nullptr;
+    p->h2_scale = nullptr;
+    p->h2_scratch = nullptr;
+    // (shape conditions only: in a size query — base == NULL — every slot pointer is NULL)
+    if (has_composites(d, w) && d->C == 256 && d->ff <= 2048 && d->ff % 256 == 0 && d->n_cls_fcs == 1 && d->n_mask_fcs == 1 && w->inp_w && w->ig_w && w->ug_w && w->fc_w &&
+        w->attn_in_w && w->attn_out_w && w->ffn1_w && w->ffn2_w && w->cls_fc_w[0] && w->mask_fc_w[0]) {
+        const int C = d->C, FF = d->ff;
+        const int nout[VKN_H2_COUNT] = {2 * C, 2 * C, 2 * C, C, C, C, 3 * C, C, FF, C, C, C, w->fc_cls_w ? d->ncls : 0, C};
+        const int kk[VKN_H2_COUNT] = {C, C, C, C, C, C, C, C, C, FF, C, C, C, C};
+        for (int i = 0; i < VKN_H2_COUNT; ++i)
+            if (nout[i] > 0) p->h2[i] = c.take<char>(vkn_split_h2_bytes(nout[i], kk[i]));
+        p->h2_scale = c.take<float>(VKN_H2_COUNT * 8);
+        p->h2_scratch = c.take<unsigned>(4);
     }
     if (n_out) *n_out = n;
     return (c.off + 255) & ~(size_t)255;
@@ -382,35 +401,51 @@ bool chain_fast_ok(const VknDims* d, const VknStageWeights* w, const PrepW& pw, 
     if (!w->ffn1_w || !w->cls_ln_w[0] || !w->mask_ln_w[0]) return false;
     return true;
 }
+// the persistent chain on the two-term fp16 split (vkn_chain_h2.hip): on request, where its images were prepared
+inline bool chain_h2(const PrepW& pw, unsigned flags, bool have_cls) {
+    return (flags & VKN_FLAG_CHAIN_H2) && pw.h2_scale && pw.h2[VKN_H2_DYNFT] && pw.h2[VKN_H2_DEC] && (!have_cls || pw.h2[VKN_H2_FCCLS]);
+}
 
 // (ii) + the FC branches as three launches: k_chain_a, the attention, k_chain_c.  `a0` / `rowscale`: the raw gather + pixel counts
 // (composite dynamic weights) or x_feat (rowscale NULL).  The decode kernels leave as f16 planes (s.kfh / s.kfl) or as fp32 (kern32_out).
 int run_chain_fast(const VknDims* d, const VknStageWeights* w, const PrepW& pw, const float* a0, bool a0_raw, const float* cnt,
                    const float* obj_in, float* obj_out, float* cls_logits, bool cls_sigmoid, float* kern32_out, const StageWs& s,
-                   hipStream_t st) {
+                   hipStream_t st, bool h2 = false) {
     const int M = d->B * d->N, C = d->C;
     VknChainA a{};
     a.a0 = a0; a.obj_in = obj_in; a.rowscale = a0_raw ? cnt : nullptr;
     a.wbase = w->prepared; a.wbytes = w->prepared_bytes;
-    a.off_dyn = pw_off(w, a0_raw ? pw.dynft : pw.dyn);
-    a.off_inp = pw_off(w, pw.inp); a.off_ig = pw_off(w, pw.ig); a.off_ug = pw_off(w, pw.ug); a.off_fc = pw_off(w, pw.fc);
-    a.off_in = pw_off(w, pw.attn_in);
+    if (h2) {
+        a.off_dyn = pw_off(w, pw.h2[a0_raw ? VKN_H2_DYNFT : VKN_H2_DYN]);
+        a.off_inp = pw_off(w, pw.h2[VKN_H2_INP]); a.off_ig = pw_off(w, pw.h2[VKN_H2_IG]); a.off_ug = pw_off(w, pw.h2[VKN_H2_UG]);
+        a.off_fc = pw_off(w, pw.h2[VKN_H2_FC]); a.off_in = pw_off(w, pw.h2[VKN_H2_IN]);
+    } else {
+        a.off_dyn = pw_off(w, a0_raw ? pw.dynft : pw.dyn);
+        a.off_inp = pw_off(w, pw.inp); a.off_ig = pw_off(w, pw.ig); a.off_ug = pw_off(w, pw.ug); a.off_fc = pw_off(w, pw.fc);
+        a.off_in = pw_off(w, pw.attn_in);
+    }
     a.consts = pw.chain_consts;
     a.eps = d->ln_eps; a.M = M; a.obj1 = s.obj1; a.qkv = s.qkv;
-    VKN_TRY(vkn_launch_chain_a(a, st));
+    VKN_TRY(h2 ? vkn_launch_chain_a_h2(a, st) : vkn_launch_chain_a(a, st));
     VKN_TRY(vkn_launch_attn(s.qkv, 3 * C, s.qkv + C, s.qkv + 2 * C, 3 * C, s.ao, C, d->B, d->N, d->N, d->heads, C / d->heads, st));
     VknChainC c{};
     c.ao = s.ao; c.obj1 = s.obj1; c.wbase = w->prepared; c.wbytes = w->prepared_bytes;
-    c.off_out = pw_off(w, pw.attn_out); c.off_ffn1 = pw_off(w, pw.ffn1); c.off_ffn2 = pw_off(w, pw.ffn2);
-    c.off_clsfc = pw_off(w, pw.cls_fc[0]); c.off_maskfc = pw_off(w, pw.mask_fc[0]);
-    c.off_fccls = pw.fc_cls ? pw_off(w, pw.fc_cls) : 0u; c.off_dec = pw_off(w, pw.dec);
+    if (h2) {
+        c.off_out = pw_off(w, pw.h2[VKN_H2_OUT]); c.off_ffn1 = pw_off(w, pw.h2[VKN_H2_FFN1]); c.off_ffn2 = pw_off(w, pw.h2[VKN_H2_FFN2]);
+        c.off_clsfc = pw_off(w, pw.h2[VKN_H2_CLSFC]); c.off_maskfc = pw_off(w, pw.h2[VKN_H2_MASKFC]);
+        c.off_fccls = pw.h2[VKN_H2_FCCLS] ? pw_off(w, pw.h2[VKN_H2_FCCLS]) : 0u; c.off_dec = pw_off(w, pw.h2[VKN_H2_DEC]);
+    } else {
+        c.off_out = pw_off(w, pw.attn_out); c.off_ffn1 = pw_off(w, pw.ffn1); c.off_ffn2 = pw_off(w, pw.ffn2);
+        c.off_clsfc = pw_off(w, pw.cls_fc[0]); c.off_maskfc = pw_off(w, pw.mask_fc[0]);
+        c.off_fccls = pw.fc_cls ? pw_off(w, pw.fc_cls) : 0u; c.off_dec = pw_off(w, pw.dec);
+    }
     c.consts = pw.chain_consts; c.kb0 = pw.kb0;
     c.ff = d->ff; c.ncls = d->ncls; c.cls_sigmoid = cls_sigmoid ? 1 : 0; c.eps = d->ln_eps; c.M = M;
     c.obj_out = obj_out; c.cls_out = (w->fc_cls_w && cls_logits) ? cls_logits : nullptr; c.kb_out = s.kb;
     if (kern32_out) c.kern_out = kern32_out;
     else { c.plane_hi = s.kfh; c.plane_lo = s.kfl; }
     c.rows_per_frame = d->N; c.NPT = npt_of(d->N);
-    return vkn_launch_chain_c(c, st);
+    return h2 ? vkn_launch_chain_c_h2(c, st) : vkn_launch_chain_c(c, st);
 }
 
 // Row-count policy of the three chain forms (profiles/r05_chain_forms.txt; chain alone, us per stage at 117 / 234 / 351 / 468 / 585 / 936 /
@@ -665,7 +700,8 @@ int run_stage(const VknDims* d, const VknStageWeights* w, const float* x, const 
                                  ref_decode ? (chain_only ? kern_out : s.kern32) : nullptr, s, st, obj_ready));
         } else {
             VKN_TRY(run_chain_fast(d, w, pw, raw ? s.xraw : xfeat, raw, s.cnt, obj_in, obj_out, cls_logits, cls_sigmoid,
-                                   ref_decode ? (chain_only ? kern_out : s.kern32) : nullptr, s, st));
+                                   ref_decode ? (chain_only ? kern_out : s.kern32) : nullptr, s, st,
+                                   chain_h2(pw, flags, w->fc_cls_w && cls_logits)));
             if (obj_ready && hipEventRecord(obj_ready, st) != hipSuccess) return VKN_E_LAUNCH;
         }
         if (chain_only) {
@@ -1164,6 +1200,21 @@ int vkn_prepare_stage_f32(const VknDims* d, const VknStageWeights* w, void* prep
         VKN_TRY(mm(w->fc_mask_b, w->ft_b, pw.kb0, 1, 1));            // b_fm.b_ft
         VKN_TRY(vkn_launch_split_w3(pw.dynft32, const_cast<void*>(pw.dynft), 2 * C, C, st));
         VKN_TRY(vkn_launch_split_w3(pw.dec32, const_cast<void*>(pw.dec), C, C, st));
+        if (pw.h2_scale) {
+            // the fp16-form images: per matrix its power-of-two scale (one launch, on the device), then the split of W * scale
+            const int C2 = d->C, FF = d->ff;
+            const float* src[VKN_H2_COUNT] = {pw.dynft32, w->dyn_w, w->inp_w, w->ig_w, w->ug_w, w->fc_w, w->attn_in_w, w->attn_out_w, w->ffn1_w,
+                                              w->ffn2_w, w->cls_fc_w[0], w->mask_fc_w[0], w->fc_cls_w, pw.dec32};
+            const int nout[VKN_H2_COUNT] = {2 * C2, 2 * C2, 2 * C2, C2, C2, C2, 3 * C2, C2, FF, C2, C2, C2, w->fc_cls_w ? d->ncls : 0, C2};
+            const int kk[VKN_H2_COUNT] = {C2, C2, C2, C2, C2, C2, C2, C2, C2, FF, C2, C2, C2, C2};
+            if (hipMemsetAsync(pw.h2_scratch, 0, 4 * sizeof(unsigned), st) != hipSuccess) return VKN_E_LAUNCH;
+            for (int i = 0; i < VKN_H2_COUNT; ++i) {
+                if (!pw.h2[i]) continue;
+                float* sc = pw.h2_scale + 8 * i;
+                VKN_TRY(vkn_pow2_scale_f32(src[i], (size_t)nout[i] * kk[i], 10, sc, pw.h2_scratch, st));
+                VKN_TRY(vkn_launch_split_h2(src[i], const_cast<void*>(pw.h2[i]), nout[i], kk[i], sc, st));
+            }
+        }
         if (pw.chain_consts) {
             VknChainConsts cc{};
             cc.bcnt = pw.bcnt; cc.dyn_b = w->dyn_b;
@@ -1177,6 +1228,7 @@ int vkn_prepare_stage_f32(const VknDims* d, const VknStageWeights* w, void* prep
             cc.cls_ln_w = w->cls_ln_w[0]; cc.cls_ln_b = w->cls_ln_b[0]; cc.mask_ln_w = w->mask_ln_w[0]; cc.mask_ln_b = w->mask_ln_b[0];
             cc.dvec = pw.dvec; cc.fc_cls_b = w->fc_cls_w ? w->fc_cls_b : nullptr; cc.dec_b = pw.decb;
             cc.ff = d->ff; cc.ncls = d->ncls;
+            for (int i = 0; i < VKN_H2_COUNT; ++i) cc.h2_inv[i] = (pw.h2_scale && pw.h2[i]) ? pw.h2_scale + 8 * i + 4 : nullptr;
             VKN_TRY(vkn_chain_pack_consts(cc, pw.chain_consts, st));
         }
     }

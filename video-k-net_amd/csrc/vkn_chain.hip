@@ -30,16 +30,34 @@
 #include "vkn_common.h"
 #include "vkn_launch.h"
 
-typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
+// This file compiles TWICE: as itself (the three-term bf16 split: 6 bytes and 6 MFMAs per operand pair, 2^-24) and, with CH_H2 defined, from
+// vkn_chain_h2.hip (the TWO-term fp16 split hi + lo of the gather / decode kernels: 4 bytes, 3 MFMAs; VKN_FLAG_CHAIN_H2).  Everything that
+// depends on the split — element type, planes per image / tile, the products — hangs on the macros below; see vkn_chain_h2.hip for the
+// range management of the fp16 form (pre-scaled weight images, per-row scaled activation images of unbounded rows).
+#ifdef CH_H2
+typedef _Float16 ch_e;
+#define CH_NPL 2                        // planes per image / weight tile
+#define CH_WTILE 32768u                 // bytes of one weight tile image (256 cols x 32 k x 2 planes fp16)
+#define k_chain_a k_chain_a_h2
+#define k_chain_c k_chain_c_h2
+#define ChainAArgs ChainAArgsH2
+#define ChainCArgs ChainCArgsH2
+#define vkn_launch_chain_a vkn_launch_chain_a_h2
+#define vkn_launch_chain_c vkn_launch_chain_c_h2
+#else
+typedef __bf16 ch_e;
+#define CH_NPL 3
+#define CH_WTILE 49152u                 // bytes of one weight tile image (256 cols x 32 k x 3 planes bf16)
+#endif
+typedef ch_e ch_ex8 __attribute__((ext_vector_type(8)));
+typedef ch_e ch_ex4 __attribute__((ext_vector_type(4)));
 typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
 
 #define CH_THREADS 512
 #define CH_ROWS 32
 #define CH_C 256
-#define CH_WTILE 49152u                 // bytes of one weight tile image (256 cols x 32 k x 3 planes bf16)
-#define CH_IMG (3 * CH_ROWS * CH_C)     // bf16 elements of one activation image (48 KB)
-#define CH_PLANE (CH_ROWS * CH_C)       // bf16 elements of one plane of an image
+#define CH_IMG (CH_NPL * CH_ROWS * CH_C)   // elements of one activation image (48 KB; fp16 form 32 KB)
+#define CH_PLANE (CH_ROWS * CH_C)       // elements of one plane of an image
 #define CH_SBUF (2 * 16 * 32)           // floats of one row-statistics exchange buffer: [value 2][partial 16][row 32]
 
 // this wave's LDS operations are done + workgroup barrier, as ONE asm statement: behind a __syncthreads() hipcc strengthens the wait
@@ -48,11 +66,33 @@ typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ void ch_split3(float v, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)v;
-    const float r1 = v - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
+// v = p[0] + p[1] (+ p[2]): each term the rounding of what the earlier ones left
+__device__ __forceinline__ void ch_split(float v, ch_e (&p)[CH_NPL]) {
+    float r = v;
+#pragma unroll
+    for (int i = 0; i < CH_NPL; ++i) {
+        p[i] = (ch_e)r;
+        if (i + 1 < CH_NPL) r -= (float)p[i];
+    }
+}
+// four values -> CH_NPL packed 8-byte plane chunks
+__device__ __forceinline__ void ch_split4(const float (&v)[4], ch_ex4 (&o)[CH_NPL]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ch_e t[CH_NPL];
+        ch_split(v[e], t);
+#pragma unroll
+        for (int i = 0; i < CH_NPL; ++i) o[i][e] = t[i];
+    }
+}
+// the power of two that puts a row maximum m at [2^9, 2^10) — the fp16 form's per-row scale of activation rows whose magnitude the
+// chain does not bound (gather sums, incoming kernels, the updator's gate product, attention output); s = 1 for an all-zero row
+__device__ __forceinline__ float ch_row_pow2(float m, float& inv) {
+    int e = 0;
+    if (m > 0.f) (void)frexpf(m, &e); else e = 10;
+    const int sh = min(max(10 - e, -60), 60);
+    inv = ldexpf(1.0f, -sh);
+    return ldexpf(1.0f, sh);
 }
 
 // lane coordinates of a workgroup thread
@@ -80,9 +120,13 @@ __device__ __forceinline__ ChLane ch_lane(int tid) {
 #define CH_AUX_OF(ABL) ((ABL) == 7 ? 2 : (ABL) == 8 ? 16 : (ABL) == 9 ? 17 : (ABL) == 10 ? 1 : 0)   /* 8 / 9 / 10: the FULL kernel with sc1 / sc0 sc1 / sc0 loads */
 #define CH_NOMFMA(ABL) ((ABL) == 1 || (ABL) == 4 || (ABL) == 5 || (ABL) == 6 || (ABL) == 7)
 #define CH_NOLOAD(ABL) ((ABL) == 2 || (ABL) == 4)
-#define CH_NP_OF(ABL) ((ABL) == 11 ? 2 : 3)   /* 11: the cost of a two-term split (4 B / weight, 3 products): the prize of VERDICT r04 item 4 */
+#ifdef CH_H2
+#define CH_NP_OF(ABL) 2
 #else
-#define CH_NP_OF(ABL) 3
+#define CH_NP_OF(ABL) ((ABL) == 11 ? 2 : 3)   /* 11: the cost of a two-term split (4 B / weight, 3 products): the prize of VERDICT r04 item 4 (built since: CH_H2) */
+#endif
+#else
+#define CH_NP_OF(ABL) CH_NPL
 #define CH_RING_OF(ABL) 4
 #define CH_AUX_OF(ABL) 0
 #define CH_NOMFMA(ABL) false
@@ -90,53 +134,61 @@ __device__ __forceinline__ ChLane ch_lane(int tid) {
 #endif
 template <int RING>
 struct ChRing {
-    cu32x4 r[RING][6];  // [slot][ks * 3 + plane]
+    cu32x4 r[RING][2 * CH_NPL];  // [slot][ks * CH_NPL + plane]
 };
 
 // the six fragments (2 k-steps x 3 planes) of this wave's column block of the tile at byte offset `toff` of the weight buffer
 // NP (debug build, VKN_CHAIN_ABL 11): planes loaded per fragment — 2 = the traffic of a two-term (4 bytes / weight) split
-template <int RING, int AUX = 0, int NP = 3>
+template <int RING, int AUX = 0, int NP = CH_NPL>
 __device__ __forceinline__ void ch_wload(ChRing<RING>& R, const int slot, const __amdgpu_buffer_rsrc_t wrs, const ChLane& L, unsigned toff) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-            R.r[slot][ks * 3 + p] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)L.woff, (int)(toff + (unsigned)((p * 4 + 2 * ks) * 4096)), AUX);
+            R.r[slot][ks * CH_NPL + p] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)L.woff, (int)(toff + (unsigned)((p * 4 + 2 * ks) * 4096)), AUX);
 }
 
-// activation fragments (3 planes) of K-tile kt, k-step ks from an image
-__device__ __forceinline__ void ch_afrag(const __bf16* img, const ChLane& L, int kt, int ks, cbf16x8& h, cbf16x8& m, cbf16x8& l) {
+// activation fragments (CH_NPL planes) of K-tile kt, k-step ks from an image
+__device__ __forceinline__ void ch_afrag(const ch_e* img, const ChLane& L, int kt, int ks, ch_ex8 (&a)[CH_NPL]) {
     const char* pb = reinterpret_cast<const char*>(img) + (L.abase ^ (unsigned)(((kt << 2) + (ks << 1)) << 4));
-    const __bf16* p = reinterpret_cast<const __bf16*>(pb);
-    h = *reinterpret_cast<const cbf16x8*>(p);
-    m = *reinterpret_cast<const cbf16x8*>(p + CH_PLANE);
-    l = *reinterpret_cast<const cbf16x8*>(p + 2 * CH_PLANE);
+    const ch_e* p = reinterpret_cast<const ch_e*>(pb);
+#pragma unroll
+    for (int i = 0; i < CH_NPL; ++i) a[i] = *reinterpret_cast<const ch_ex8*>(p + i * CH_PLANE);
 }
 
 // acc (transposed tile: lane = activation row li, register r = output column 8 (r >> 2) + 4 g + (r & 3) of the wave's block) +=
-// W-fragments (slot) x activation fragments, the six significant products, smallest first
+// W-fragments (slot) x activation fragments: the significant cross products, smallest first
 template <int RING>
-__device__ __forceinline__ void ch_mfma6(f32x16& acc, const ChRing<RING>& R, const int slot, const int ks, const cbf16x8& ah, const cbf16x8& am,
-                                         const cbf16x8& al) {
-    const cbf16x8 wh = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 0]);
-    const cbf16x8 wm = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 1]);
-    const cbf16x8 wl = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 2]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, am, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
+__device__ __forceinline__ void ch_mfma(f32x16& acc, const ChRing<RING>& R, const int slot, const int ks, const ch_ex8 (&a)[CH_NPL]) {
+#ifdef CH_H2
+    const ch_ex8 wh = __builtin_bit_cast(ch_ex8, R.r[slot][ks * 2 + 0]);
+    const ch_ex8 wl = __builtin_bit_cast(ch_ex8, R.r[slot][ks * 2 + 1]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, a[0], acc, 0, 0, 0);   // lo x lo is below fp32 resolution
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, a[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, a[0], acc, 0, 0, 0);
+#else
+    const ch_ex8 wh = __builtin_bit_cast(ch_ex8, R.r[slot][ks * 3 + 0]);
+    const ch_ex8 wm = __builtin_bit_cast(ch_ex8, R.r[slot][ks * 3 + 1]);
+    const ch_ex8 wl = __builtin_bit_cast(ch_ex8, R.r[slot][ks * 3 + 2]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, a[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, a[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, a[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, a[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, a[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, a[0], acc, 0, 0, 0);
+#endif
 }
+#if defined(VKN_DEBUG) && !defined(CH_H2)
 // (debug build, VKN_CHAIN_ABL 11: WRONG results by construction — bf16 x 2 precision) the three products of a two-term split
 template <int RING>
-__device__ __forceinline__ void ch_mfma3(f32x16& acc, const ChRing<RING>& R, const int slot, const int ks, const cbf16x8& ah, const cbf16x8& am) {
-    const cbf16x8 wh = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 0]);
-    const cbf16x8 wm = __builtin_bit_cast(cbf16x8, R.r[slot][ks * 3 + 1]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, ah, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, am, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
+__device__ __forceinline__ void ch_mfma3(f32x16& acc, const ChRing<RING>& R, const int slot, const int ks, const ch_ex8 (&a)[CH_NPL]) {
+    const ch_ex8 wh = __builtin_bit_cast(ch_ex8, R.r[slot][ks * 3 + 0]);
+    const ch_ex8 wm = __builtin_bit_cast(ch_ex8, R.r[slot][ks * 3 + 1]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, a[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, a[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, a[0], acc, 0, 0, 0);
 }
+#endif
 
 // what the ring is refilled with once the current GEMM has no tiles left to request: the first three units of the next GEMM
 struct ChNext {
@@ -156,11 +208,11 @@ struct ChNext {
 // 3 = no activation-fragment reads, 4 = neither MFMAs nor loads (epilogues alone), 5 / 6 / 7 = no MFMAs with a ring of 2 / 8 units /
 // non-temporal loads
 template <int NACC, bool SAMEA, int ABL>
-__device__ __forceinline__ void ch_gemm(f32x16 (&acc)[NACC], const __bf16* img0, const __bf16* img1, unsigned base0, unsigned base1,
+__device__ __forceinline__ void ch_gemm(f32x16 (&acc)[NACC], const ch_e* img0, const ch_e* img1, unsigned base0, unsigned base1,
                                         const ChNext nx, ChRing<CH_RING_OF(ABL)>& R, const __amdgpu_buffer_rsrc_t wrs, const ChLane& L) {
     constexpr int NU = 8 * NACC, RING = CH_RING_OF(ABL), AUX = CH_AUX_OF(ABL);
     static_assert(NU % RING == 0, "unit count must be a multiple of the ring depth");
-    cbf16x8 ah[2], am[2], al[2];
+    ch_ex8 af[2][CH_NPL];
 #pragma unroll 1
     for (int u0 = 0; u0 < NU; u0 += RING) {
 #pragma unroll
@@ -184,20 +236,23 @@ __device__ __forceinline__ void ch_gemm(f32x16 (&acc)[NACC], const __bf16* img0,
             __builtin_amdgcn_sched_barrier(0);
             const int a = (NACC == 2) ? (u & 1) : 0, kt = (NACC == 2) ? (u >> 1) : u;
             if ((a == 0 || !SAMEA) && !(VKN_ABL_IS(ABL, 3) && u > 0)) {
-                const __bf16* img = (a == 0) ? img0 : img1;
-                ch_afrag(img, L, kt, 0, ah[0], am[0], al[0]);
-                ch_afrag(img, L, kt, 1, ah[1], am[1], al[1]);
+                const ch_e* img = (a == 0) ? img0 : img1;
+                ch_afrag(img, L, kt, 0, af[0]);
+                ch_afrag(img, L, kt, 1, af[1]);
             }
             if (CH_NOMFMA(ABL)) {   // keep the loads and reads alive without the matrix pipe
 #pragma unroll
-                for (int f = 0; f < 6; ++f) asm volatile("" ::"v"(R.r[j][f]));
-                asm volatile("" ::"v"(ah[0]), "v"(am[0]), "v"(al[0]), "v"(ah[1]), "v"(am[1]), "v"(al[1]));
+                for (int f = 0; f < 2 * CH_NPL; ++f) asm volatile("" ::"v"(R.r[j][f]));
+#pragma unroll
+                for (int f = 0; f < CH_NPL; ++f) asm volatile("" ::"v"(af[0][f]), "v"(af[1][f]));
+#if defined(VKN_DEBUG) && !defined(CH_H2)
             } else if (VKN_ABL_IS(ABL, 11)) {
-                ch_mfma3(acc[a], R, j, 0, ah[0], am[0]);
-                ch_mfma3(acc[a], R, j, 1, ah[1], am[1]);
+                ch_mfma3(acc[a], R, j, 0, af[0]);
+                ch_mfma3(acc[a], R, j, 1, af[1]);
+#endif
             } else {
-                ch_mfma6(acc[a], R, j, 0, ah[0], am[0], al[0]);
-                ch_mfma6(acc[a], R, j, 1, ah[1], am[1], al[1]);
+                ch_mfma(acc[a], R, j, 0, af[0]);
+                ch_mfma(acc[a], R, j, 1, af[1]);
             }
         }
     }
@@ -274,51 +329,87 @@ __device__ __forceinline__ void ch_layernorm(float (&v)[NV][16], const float* co
     }
 }
 
-// registers (transposed tile) -> bf16x3 image: 8-byte packed stores, chunk (wave * 4 + q) of row li, half g
-__device__ __forceinline__ void ch_img_write(__bf16* img, const float (&v)[16], const ChLane& L) {
+// registers (transposed tile) -> image: 8-byte packed stores, chunk (wave * 4 + q) of row li, half g
+__device__ __forceinline__ void ch_img_write(ch_e* img, const float (&v)[16], const ChLane& L) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        cbf16x4 h, m, l;
+        const float t[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        ch_ex4 o[CH_NPL];
+        ch_split4(t, o);
+        ch_e* d = img + L.li * CH_C + ((((L.wave << 2) + q) ^ L.li) & 31) * 8 + 4 * L.g;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            __bf16 hh, mm, ll;
-            ch_split3(v[4 * q + e], hh, mm, ll);
-            h[e] = hh;
-            m[e] = mm;
-            l[e] = ll;
-        }
-        __bf16* d = img + L.li * CH_C + ((((L.wave << 2) + q) ^ L.li) & 31) * 8 + 4 * L.g;
-        *reinterpret_cast<cbf16x4*>(d) = h;
-        *reinterpret_cast<cbf16x4*>(d + CH_PLANE) = m;
-        *reinterpret_cast<cbf16x4*>(d + 2 * CH_PLANE) = l;
+        for (int i = 0; i < CH_NPL; ++i) *reinterpret_cast<ch_ex4*>(d + i * CH_PLANE) = o[i];
     }
 }
+#ifdef CH_H2
+// the same for rows of unbounded magnitude (the updator's gate product): the row maximum over the workgroup's sixteen holders meets in
+// `X` ([16][32] floats, one barrier), the row is written times the power of two that puts it at 2^9 .. 2^10; returns 1 / scale (the
+// consumer GEMM's epilogue multiplies its accumulators by it — exact)
+__device__ __forceinline__ float ch_img_write_rs(ch_e* img, const float (&v)[16], const ChLane& L, float* X) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(v[r]));
+    X[(L.wave * 2 + L.g) * 32 + L.li] = m;
+    CH_BAR();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m = fmaxf(m, X[k * 32 + L.li]);
+    float inv;
+    const float sc = ch_row_pow2(m, inv);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = v[r] * sc;
+    ch_img_write(img, t, L);
+    return inv;
+}
+#endif
 
-// fp32 rows [M][ld] (32 rows from m0, 256 columns) -> image; rows >= M repeat the last row (never stored)
-__device__ __forceinline__ void ch_img_load(__bf16* img, const float* __restrict__ src, int ld, int m0, int M, int tid) {
+// fp32 rows [M][ld] (32 rows from m0, 256 columns) -> image; rows >= M repeat the last row (never stored).  fp16 form: every row times
+// its own power of two (row maximum over the sixteen lanes that hold the row), 1 / scale -> rs[row] (LDS, read behind the next barrier)
+__device__ __forceinline__ void ch_img_load(ch_e* img, const float* __restrict__ src, int ld, int m0, int M, int tid, float* rs = nullptr) {
     const int row = tid >> 4, c4 = (tid & 15) << 2;
     const float* s = src + (size_t)min(m0 + row, M - 1) * ld + c4;
     f32x4 t[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const f32x4*>(s + 64 * j);
+#ifdef CH_H2
+    {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(t[j][e]));
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float inv;
+        const float sc = ch_row_pow2(m, inv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] *= sc;
+        if ((tid & 15) == 0) rs[row] = inv;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = c4 + 64 * j;
-        cbf16x4 h, m, l;
+        const float tv[4] = {t[j][0], t[j][1], t[j][2], t[j][3]};
+        ch_ex4 o[CH_NPL];
+        ch_split4(tv, o);
+        ch_e* d = img + row * CH_C + ((((col >> 3) ^ row) & 31) << 3) + (col & 7);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            __bf16 hh, mm, ll;
-            ch_split3(t[j][e], hh, mm, ll);
-            h[e] = hh;
-            m[e] = mm;
-            l[e] = ll;
-        }
-        __bf16* d = img + row * CH_C + ((((col >> 3) ^ row) & 31) << 3) + (col & 7);
-        *reinterpret_cast<cbf16x4*>(d) = h;
-        *reinterpret_cast<cbf16x4*>(d + CH_PLANE) = m;
-        *reinterpret_cast<cbf16x4*>(d + 2 * CH_PLANE) = l;
+        for (int i = 0; i < CH_NPL; ++i) *reinterpret_cast<ch_ex4*>(d + i * CH_PLANE) = o[i];
     }
 }
+// fp16 form: acc *= u (u = 1 / (weight image scale x activation row scale), powers of two: exact); bf16 form: nothing
+#ifdef CH_H2
+#define CH_UNSCALE(A, U)                                     \
+    do {                                                     \
+        const float u_ = (U);                                \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)(A)[r_] *= u_; \
+    } while (0)
+#else
+#define CH_UNSCALE(A, U) \
+    do {                 \
+    } while (0)
+#endif
 
 // registers (transposed tile) -> fp32 rows [M][ld] at column tile offset col0: four float4 stores per lane
 __device__ __forceinline__ void ch_store_rows(float* __restrict__ dst, int ld, int col0, int row, bool ok, const float (&v)[16],
@@ -375,7 +466,8 @@ enum {
     CA_UG_B = 3328, CA_NI_W = 3584, CA_NI_B = 3840,     // update_gate bias, norm_in
     CA_FC_B = 4096, CA_FCN_W = 4352, CA_FCN_B = 4608,   // fc_layer bias, fc_norm
     CA_IN_B = 4864,    // [768] attention in_proj bias
-    CA_TOTAL = 5632
+    CA_SC = 5632,      // [8] fp16 form: 1 / scale of the weight images dyn (this block's mode), inp, ig, ug, fc, in_proj (1 in the bf16 form)
+    CA_TOTAL = 5640
 };
 
 struct ChainAArgs {
@@ -395,11 +487,14 @@ struct ChainAArgs {
 template <int ABL>
 __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_ca[];
-    __bf16* IMG0 = reinterpret_cast<__bf16*>(smem_ca);
-    __bf16* IMG1 = IMG0 + CH_IMG;
+    ch_e* IMG0 = reinterpret_cast<ch_e*>(smem_ca);
+    ch_e* IMG1 = IMG0 + CH_IMG;
     float* S = reinterpret_cast<float*>(IMG1 + CH_IMG);  // [2][CH_SBUF]
     float* CST = S + 2 * CH_SBUF;
     float* PARK = CST + CA_TOTAL;                        // [4][512] float4: parameters_in, later input_out, parked across a GEMM
+#ifdef CH_H2
+    float* RS = PARK + 16 * CH_THREADS;                  // [2][32] 1 / row scale of the two loaded images; [16][32] row-maximum exchange
+#endif
 
     const int tid = threadIdx.x;
     const ChLane L = ch_lane(tid);
@@ -417,8 +512,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
         if (CH_NOLOAD(ABL)) ch_wload<RING>(R, RING - 1, wrs, L, A.off_dyn);   // (ablation: the ring is never refilled; defined contents)
     }
     ch_stage_consts<CA_TOTAL>(CST, A.consts, tid);
+#ifdef CH_H2
+    ch_img_load(IMG0, A.a0, CH_C, m0, M, tid, RS);
+    ch_img_load(IMG1, A.obj_in, CH_C, m0, M, tid, RS + 32);
+#else
     ch_img_load(IMG0, A.a0, CH_C, m0, M, tid);
     ch_img_load(IMG1, A.obj_in, CH_C, m0, M, tid);
+#endif
     const float bs = A.rowscale ? A.rowscale[min(row, M - 1)] : 1.f;
     CH_BAR();
 
@@ -429,6 +529,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     ch_zero(acc[0]);
     ch_zero(acc[1]);
     ch_gemm<2, true, ABL>(acc, IMG0, IMG0, A.off_dyn, A.off_dyn + 8u * CH_WTILE, ChNext{A.off_inp, A.off_inp + 8u * CH_WTILE, 2}, R, wrs, L);
+    CH_UNSCALE(acc[0], CST[CA_SC + 0] * RS[L.li]);
+    CH_UNSCALE(acc[1], CST[CA_SC + 0] * RS[L.li]);
     {
         float b[16], b2[16], pin[16];
         ch_cols(CST + CA_DYN_B, L, b);
@@ -448,13 +550,22 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     ch_zero(acc[0]);
     ch_zero(acc[1]);
     ch_gemm<2, true, ABL>(acc, IMG1, IMG1, A.off_inp, A.off_inp + 8u * CH_WTILE, ChNext{A.off_ig, A.off_ug, 2}, R, wrs, L);
+    CH_UNSCALE(acc[0], CST[CA_SC + 1] * RS[32 + L.li]);
+    CH_UNSCALE(acc[1], CST[CA_SC + 1] * RS[32 + L.li]);
+#ifdef CH_H2
+    float gate_inv;
+#endif
     {
         float b[16], gate[16], iout[1][16];
         ch_cols(CST + CA_INP_B, L, b);
         ch_unpark(PARK, gate, tid);
 #pragma unroll
         for (int r = 0; r < 16; ++r) gate[r] = (acc[0][r] + b[r]) * gate[r];
+#ifdef CH_H2
+        gate_inv = ch_img_write_rs(IMG0, gate, L, RS + 64);   // (an unnormalised product: its rows are scaled one by one)
+#else
         ch_img_write(IMG0, gate, L);   // IMG0 was last read by the first GEMM: every wave is past that epilogue's barriers
+#endif
         ch_cols(CST + CA_INP_B + 256, L, b);
 #pragma unroll
         for (int r = 0; r < 16; ++r) iout[0][r] = acc[1][r] + b[r];
@@ -467,6 +578,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     ch_zero(acc[0]);
     ch_zero(acc[1]);
     ch_gemm<2, true, ABL>(acc, IMG0, IMG0, A.off_ig, A.off_ug, ChNext{A.off_fc, 0u, 1}, R, wrs, L);
+#ifdef CH_H2
+    CH_UNSCALE(acc[0], CST[CA_SC + 2] * gate_inv);
+    CH_UNSCALE(acc[1], CST[CA_SC + 3] * gate_inv);
+#endif
     {
         float gt[2][16], b[16];
         ch_cols(CST + CA_IG_B, L, b);
@@ -493,6 +608,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
     f32x16 acc1[1];
     ch_zero(acc1[0]);
     ch_gemm<1, true, ABL>(acc1, IMG1, IMG1, A.off_fc, 0u, ChNext{A.off_in, 0u, 1}, R, wrs, L);
+    CH_UNSCALE(acc1[0], CST[CA_SC + 4]);
     {
         float o[1][16], b[16];
         ch_cols(CST + CA_FC_B, L, b);
@@ -514,6 +630,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
         ch_zero(acc1[0]);
         const ChNext nx = (t < 2) ? ChNext{A.off_in + (unsigned)(t + 1) * 8u * CH_WTILE, 0u, 1} : ChNext{0u, 0u, 0};
         ch_gemm<1, true, ABL>(acc1, IMG0, IMG0, A.off_in + (unsigned)t * 8u * CH_WTILE, 0u, nx, R, wrs, L);
+        CH_UNSCALE(acc1[0], CST[CA_SC + 5]);
         float o[16], b[16];
         ch_cols(CST + CA_IN_B + 256 * t, L, b);
 #pragma unroll
@@ -532,7 +649,8 @@ enum {
     CC_CLS_B = 2816,                                  // fc_cls bias, zero padded to 256
     CC_DEC_B = 3072,                                  // bias of the folded decode kernels
     CC_B1 = 3328,                                     // [ff <= 2048] ffn first bias
-    CC_TOTAL = 3328 + 2048
+    CC_SC = 3328 + 2048,                              // [8] fp16 form: 1 / scale of the weight images out, ffn1, ffn2, cls_fc, mask_fc, fc_cls, dec
+    CC_TOTAL = 3328 + 2048 + 8
 };
 
 struct ChainCArgs {
@@ -561,10 +679,13 @@ struct ChainCArgs {
 template <int ABL>
 __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_cc[];
-    __bf16* IMG0 = reinterpret_cast<__bf16*>(smem_cc);
-    __bf16* HID = IMG0 + CH_IMG;
+    ch_e* IMG0 = reinterpret_cast<ch_e*>(smem_cc);
+    ch_e* HID = IMG0 + CH_IMG;
     float* S = reinterpret_cast<float*>(HID + CH_IMG);
     float* CST = S + 2 * CH_SBUF;
+#ifdef CH_H2
+    float* RS = CST + CC_TOTAL;   // [32] 1 / row scale of the attention-output image
+#endif
 
     const int tid = threadIdx.x;
     const ChLane L = ch_lane(tid);
@@ -583,7 +704,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
         if (CH_NOLOAD(ABL)) ch_wload<RING>(R, RING - 1, wrs, L, A.off_out);
     }
     ch_stage_consts<CC_TOTAL>(CST, A.consts, tid);
+#ifdef CH_H2
+    ch_img_load(IMG0, A.ao, CH_C, m0, M, tid, RS);
+#else
     ch_img_load(IMG0, A.ao, CH_C, m0, M, tid);
+#endif
     float obj[1][16];   // residual rows in the transposed-tile layout
     {
         const float* s = A.obj1 + (size_t)rowc * CH_C + L.wave * 32 + 4 * L.g;
@@ -601,6 +726,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     // ---- attention out_proj + identity + attention_norm                                           knet/det/kernel_update_head.py:206-208
     ch_zero(acc1[0]);
     ch_gemm<1, true, ABL>(acc1, IMG0, IMG0, A.off_out, 0u, ChNext{A.off_ffn1, 0u, 1}, R, wrs, L);
+    CH_UNSCALE(acc1[0], CST[CC_SC + 0] * RS[L.li]);
     {
         float b[16];
         ch_cols(CST + CC_OUT_B, L, b);
@@ -620,6 +746,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
         ch_zero(acc1[0]);
         ch_gemm<1, true, ABL>(acc1, IMG0, IMG0, A.off_ffn1 + (unsigned)c * 8u * CH_WTILE, 0u,
                          ChNext{A.off_ffn2 + (unsigned)c * 8u * CH_WTILE, 0u, 1}, R, wrs, L);
+        CH_UNSCALE(acc1[0], CST[CC_SC + 1]);
         float h[16], b[16];
         ch_cols(CST + CC_B1 + 256 * c, L, b);
 #pragma unroll
@@ -631,6 +758,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
         const ChNext nx = lastc ? ChNext{A.off_clsfc, A.off_maskfc, 2} : ChNext{A.off_ffn1 + (unsigned)(c + 1) * 8u * CH_WTILE, 0u, 1};
         ch_gemm<1, true, ABL>(acc2, HID, HID, A.off_ffn2 + (unsigned)c * 8u * CH_WTILE, 0u, nx, R, wrs, L);
     }
+    CH_UNSCALE(acc2[0], CST[CC_SC + 2]);   // (one scale per weight image: the hidden chunks' partial products share it)
     {
         float b[16];
         ch_cols(CST + CC_B2, L, b);
@@ -649,6 +777,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     ch_zero(acc[1]);
     const ChNext nfin = A.has_cls ? ChNext{A.off_fccls, A.off_dec, 2} : ChNext{A.off_dec, 0u, 1};
     ch_gemm<2, true, ABL>(acc, IMG0, IMG0, A.off_clsfc, A.off_maskfc, nfin, R, wrs, L);
+    CH_UNSCALE(acc[0], CST[CC_SC + 3]);
+    CH_UNSCALE(acc[1], CST[CC_SC + 4]);
     {
         float t[2][16];
 #pragma unroll
@@ -679,6 +809,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     ch_zero(acc[1]);
     if (A.has_cls) {
         ch_gemm<2, false, ABL>(acc, IMG0, HID, A.off_fccls, A.off_dec, ChNext{0u, 0u, 0}, R, wrs, L);
+        CH_UNSCALE(acc[0], CST[CC_SC + 5]);
         if (L.wave * 32 < A.ncls && row_ok && A.cls_out) {
             float b[16];
             ch_cols(CST + CC_CLS_B, L, b);
@@ -696,6 +827,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
         ch_gemm<1, true, ABL>(accd, HID, HID, A.off_dec, 0u, ChNext{0u, 0u, 0}, R, wrs, L);
         acc[1] = accd[0];
     }
+    CH_UNSCALE(acc[1], CST[CC_SC + 6]);
     {
         float k[16], b[16];
         ch_cols(CST + CC_DEC_B, L, b);
@@ -725,6 +857,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
     }
 }
 
+#ifndef CH_H2
 // ------------------------------------------------------------------------------------------------ one GEMM per launch on the same engine
 // k_gemm_t3: out = epi((A (.* A2) (+ A3 .* A4)) . W^T) for K == 256 KC (KC <= 3: the backward GEMMs of the training chain contract over 512 / 768) with the row epilogue of k_gemm_s3 (vkn_update.hip: VknEpi) — the
 // launch-per-GEMM chain of few-row calls (frame-by-frame video inference: 117 rows), the link blocks and the stand-alone linear entry
@@ -736,7 +869,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
 template <int ABL, int KC>
 __global__ __launch_bounds__(CH_THREADS) void k_gemm_t3(const VknGemmProb p0, const VknGemmProb p1, int nprob, int M) {
     extern __shared__ __attribute__((aligned(16))) char smem_t3[];
-    __bf16* IMG = reinterpret_cast<__bf16*>(smem_t3);
+    ch_e* IMG = reinterpret_cast<ch_e*>(smem_t3);
     float* S = reinterpret_cast<float*>(IMG + KC * CH_IMG);   // KC images of 256 K-columns each (K = 256 KC <= 768: 144 KB + S)
     const bool second = (nprob > 1) && (blockIdx.z == 1);
     const VknGemmProb& P = second ? p1 : p0;
@@ -775,19 +908,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_gemm_t3(const VknGemmProb p0, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = c4 + 64 * j;
-            cbf16x4 h, m, l;
+            const float tv[4] = {t[j][0], t[j][1], t[j][2], t[j][3]};
+            ch_ex4 o[CH_NPL];
+            ch_split4(tv, o);
+            ch_e* d = IMG + kc * CH_IMG + row * CH_C + ((((col >> 3) ^ row) & 31) << 3) + (col & 7);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __bf16 hh, mm, ll;
-                ch_split3(t[j][e], hh, mm, ll);
-                h[e] = hh;
-                m[e] = mm;
-                l[e] = ll;
-            }
-            __bf16* d = IMG + kc * CH_IMG + row * CH_C + ((((col >> 3) ^ row) & 31) << 3) + (col & 7);
-            *reinterpret_cast<cbf16x4*>(d) = h;
-            *reinterpret_cast<cbf16x4*>(d + CH_PLANE) = m;
-            *reinterpret_cast<cbf16x4*>(d + 2 * CH_PLANE) = l;
+            for (int i = 0; i < CH_NPL; ++i) *reinterpret_cast<ch_ex4*>(d + i * CH_PLANE) = o[i];
         }
     }
     // ---- the lane's sixteen columns and their epilogue constants (requested before the K loop: their round trips ride under it)
@@ -944,7 +1070,7 @@ int vkn_launch_gemm_t3(const VknGemmProb* probs, int nprob, int M, int K, hipStr
         if ((size_t)((p.Nout + 255) / 256) * 8 * kc * CH_WTILE >= (1ull << 31)) return VKN_E_SHAPE;
         nmax = p.Nout > nmax ? p.Nout : nmax;
     }
-    const size_t lds = (size_t)kc * CH_IMG * sizeof(__bf16) + (size_t)2 * CH_SBUF * sizeof(float);
+    const size_t lds = (size_t)kc * CH_IMG * sizeof(ch_e) + (size_t)2 * CH_SBUF * sizeof(float);
     dim3 grid((nmax + 255) / 256, (M + CH_ROWS - 1) / CH_ROWS, nprob);
 #define T3_LAUNCH(KCV)                                                                                                                  \
     do {                                                                                                                                \
@@ -961,7 +1087,7 @@ int vkn_launch_gemm_t3(const VknGemmProb* probs, int nprob, int M, int K, hipStr
 
 // ------------------------------------------------------------------------------------------------ host launchers
 // constant blocks: packed once per weight update into the prepared buffer (vkn_prepare_stage_f32)
-#define CH_PACK_MAX 64
+#define CH_PACK_MAX 96
 struct ChPackTab {
     const float* src[CH_PACK_MAX];
     int dst[CH_PACK_MAX], n[CH_PACK_MAX];
@@ -974,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_chain_pack(const ChPackTab T, float* __
     for (int k = threadIdx.x; k < T.n[i]; k += 256) out[T.dst[i] + k] = s ? s[k] : T.fill[i];
 }
 static void ch_tab_add(ChPackTab& T, const float* src, int dst, int n, float fill) {
-    if (T.count >= CH_PACK_MAX) return;   // (50 entries today; the launcher checks the count)
+    if (T.count >= CH_PACK_MAX) return;   // (83 entries today; the launcher checks the count)
     const int i = T.count++;
     T.src[i] = src;
     T.dst[i] = dst;
@@ -1003,6 +1129,8 @@ int vkn_chain_pack_consts(const VknChainConsts& c, float* out, hipStream_t strea
         ch_tab_add(T, c.fc_b, o + CA_FC_B, 256, 0.f);
         ch_tab_add(T, c.fc_norm_w, o + CA_FCN_W, 256, 1.f);   ch_tab_add(T, c.fc_norm_b, o + CA_FCN_B, 256, 0.f);
         ch_tab_add(T, c.in_b, o + CA_IN_B, 768, 0.f);
+        const float* sc[8] = {mode == 0 ? c.h2_inv[0] : c.h2_inv[1], c.h2_inv[2], c.h2_inv[3], c.h2_inv[4], c.h2_inv[5], c.h2_inv[6], nullptr, nullptr};
+        for (int k = 0; k < 8; ++k) ch_tab_add(T, sc[k], o + CA_SC + k, 1, 1.f);
     }
     const int o = 2 * CA_TOTAL;
     ch_tab_add(T, c.out_b, o + CC_OUT_B, 256, 0.f);
@@ -1017,11 +1145,39 @@ int vkn_chain_pack_consts(const VknChainConsts& c, float* out, hipStream_t strea
     ch_tab_add(T, c.dec_b, o + CC_DEC_B, 256, 0.f);
     ch_tab_add(T, c.ffn1_b, o + CC_B1, c.ff, 0.f);
     ch_tab_add(T, nullptr, o + CC_B1 + c.ff, 2048 - c.ff, 0.f);
+    for (int k = 0; k < 8; ++k) ch_tab_add(T, k < 7 ? c.h2_inv[7 + k] : nullptr, o + CC_SC + k, 1, 1.f);
     if (T.count >= CH_PACK_MAX) return VKN_E_ARG;
     hipLaunchKernelGGL(k_chain_pack, dim3(T.count), dim3(256), 0, stream, T, out);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
+
+#else   // CH_H2: what only the fp16 form needs — its weight images
+// fp32 W [Nout][K] -> fp16 hi / lo tile images Wp[ceil(Nout/256)][K/32][2][4][256][8] of W * *scale (rows >= Nout zero), the layout of
+// k_split_w3 (vkn_update.hip) with two planes.  scale: DEVICE scalar, a power of two (vkn_pow2_scale_f32 of the matrix: its maximum at
+// 2^9 .. 2^10, so that the low half of every weight down to 2^-12 of the maximum keeps its eleven bits); grid = (K/32, ceil(Nout/256)).
+__global__ __launch_bounds__(256) void k_split_h2(const float* __restrict__ W, _Float16* __restrict__ Wp, int Nout, int K,
+                                                  const float* __restrict__ scale) {
+    const int kt = blockIdx.x, nt = blockIdx.y;
+    _Float16* dst = Wp + ((size_t)nt * gridDim.x + kt) * (CH_WTILE / 2);
+    const int row = threadIdx.x, n = nt * 256 + row;
+    const float sc = scale[0];
+    for (int k = 0; k < 32; ++k) {
+        ch_e t[2] = {(ch_e)0.f, (ch_e)0.f};
+        if (n < Nout) ch_split(W[(size_t)n * K + kt * 32 + k] * sc, t);
+        const int q = k >> 3, e = k & 7;
+        dst[((0 * 4 + q) * 256 + row) * 8 + e] = t[0];
+        dst[((1 * 4 + q) * 256 + row) * 8 + e] = t[1];
+    }
+}
+size_t vkn_split_h2_bytes(int Nout, int K) { return (size_t)((Nout + 255) / 256) * (size_t)(K / 32) * CH_WTILE; }
+int vkn_launch_split_h2(const float* W, void* images, int Nout, int K, const float* scale, hipStream_t stream) {
+    if (!W || !images || !scale || Nout <= 0 || K <= 0 || K % 32 != 0) return VKN_E_ARG;
+    hipLaunchKernelGGL(k_split_h2, dim3(K / 32, (Nout + 255) / 256), dim3(256), 0, stream, W, static_cast<_Float16*>(images), Nout, K, scale);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+#endif  // CH_H2
 
 int vkn_launch_chain_a(const VknChainA& p, hipStream_t stream) {
     if (!p.a0 || !p.obj_in || !p.wbase || !p.obj1 || !p.qkv || !p.consts || p.M <= 0 || p.wbytes >= (1ull << 31)) return VKN_E_ARG;
@@ -1030,7 +1186,11 @@ int vkn_launch_chain_a(const VknChainA& p, hipStream_t stream) {
     A.off_dyn = p.off_dyn; A.off_inp = p.off_inp; A.off_ig = p.off_ig; A.off_ug = p.off_ug; A.off_fc = p.off_fc; A.off_in = p.off_in;
     A.eps = p.eps; A.M = p.M; A.obj1 = p.obj1; A.qkv = p.qkv;
     A.consts = p.consts + (p.rowscale ? 0 : CA_TOTAL);
-    const size_t lds = (size_t)2 * CH_IMG * sizeof(__bf16) + (size_t)(2 * CH_SBUF + CA_TOTAL + 16 * CH_THREADS) * sizeof(float);
+#ifdef CH_H2
+    const size_t lds = (size_t)2 * CH_IMG * sizeof(ch_e) + (size_t)(2 * CH_SBUF + CA_TOTAL + 16 * CH_THREADS + 64 + 512) * sizeof(float);
+#else
+    const size_t lds = (size_t)2 * CH_IMG * sizeof(ch_e) + (size_t)(2 * CH_SBUF + CA_TOTAL + 16 * CH_THREADS) * sizeof(float);
+#endif
 #define CHA_LAUNCH(ABLV)                                                                                            \
     do {                                                                                                            \
         VKN_ALLOW_FULL_LDS(k_chain_a<ABLV>);                                                                        \
@@ -1071,7 +1231,11 @@ int vkn_launch_chain_c(const VknChainC& p, hipStream_t stream) {
     A.eps = p.eps; A.M = p.M; A.kb0 = p.kb0; A.obj_out = p.obj_out; A.cls_out = p.cls_out; A.kb_out = p.kb_out;
     A.plane_hi = p.plane_hi; A.plane_lo = p.plane_lo; A.kern_out = p.kern_out; A.rows_per_frame = p.rows_per_frame; A.NPT = p.NPT;
     A.consts = p.consts + 2 * CA_TOTAL;
-    const size_t lds = (size_t)2 * CH_IMG * sizeof(__bf16) + (size_t)(2 * CH_SBUF + CC_TOTAL) * sizeof(float);
+#ifdef CH_H2
+    const size_t lds = (size_t)2 * CH_IMG * sizeof(ch_e) + (size_t)(2 * CH_SBUF + CC_TOTAL + 32) * sizeof(float);
+#else
+    const size_t lds = (size_t)2 * CH_IMG * sizeof(ch_e) + (size_t)(2 * CH_SBUF + CC_TOTAL) * sizeof(float);
+#endif
 #define CHC_LAUNCH(ABLV)                                                                                            \
     do {                                                                                                            \
         VKN_ALLOW_FULL_LDS(k_chain_c<ABLV>);                                                                        \

@@ -124,7 +124,12 @@ struct VknChainConsts {   // every bias / LayerNorm vector the two kernels read 
     const float *out_b, *attn_norm_w, *attn_norm_b, *ffn1_b, *ffn2_b, *ffn_norm_w, *ffn_norm_b;
     const float *cls_ln_w, *cls_ln_b, *mask_ln_w, *mask_ln_b, *dvec, *fc_cls_b, *dec_b;
     int ff, ncls;
+    // fp16-form weight images (VKN_FLAG_CHAIN_H2): DEVICE scalars 1 / scale of the images in the order of VKN_H2_* (NULL: 1)
+    const float* h2_inv[14];
 };
+// the weight matrices of the persistent chain, in the order of VknChainConsts::h2_inv and PrepW::h2
+enum { VKN_H2_DYNFT = 0, VKN_H2_DYN, VKN_H2_INP, VKN_H2_IG, VKN_H2_UG, VKN_H2_FC, VKN_H2_IN, VKN_H2_OUT, VKN_H2_FFN1, VKN_H2_FFN2,
+       VKN_H2_CLSFC, VKN_H2_MASKFC, VKN_H2_FCCLS, VKN_H2_DEC, VKN_H2_COUNT };
 size_t vkn_chain_consts_floats();
 int vkn_chain_pack_consts(const VknChainConsts& c, float* out, hipStream_t stream);
 struct VknChainA {   // KernelUpdator + attention in_proj
@@ -163,6 +168,13 @@ struct VknChainC {   // attention out_proj + LN, FFN + LN, cls / mask FCs, fc_cl
 int vkn_launch_gemm_t3(const VknGemmProb* probs, int nprob, int M, int K, hipStream_t stream);
 int vkn_launch_chain_a(const VknChainA& p, hipStream_t stream);
 int vkn_launch_chain_c(const VknChainC& p, hipStream_t stream);
+// the same two kernels on the two-term fp16 split (vkn_chain_h2.hip): `off_*` then name the fp16 tile images (vkn_launch_split_h2:
+// W times a power of two per matrix, whose inverse sits in the constant block)
+int vkn_launch_chain_a_h2(const VknChainA& p, hipStream_t stream);
+int vkn_launch_chain_c_h2(const VknChainC& p, hipStream_t stream);
+size_t vkn_split_h2_bytes(int Nout, int K);
+int vkn_launch_split_h2(const float* W, void* images, int Nout, int K, const float* scale, hipStream_t stream);
+// vkn_pow2_scale_f32 (vkn_loss.hip) is the C-ABI entry point; the prepare step calls it directly
 
 // ---- few-row chain (vkn_ksplit.hip): one GEMM phase per launch, column blocks over the chip, the contraction over the waves of a
 // workgroup; row-wise normalisation in the CONSUMER's prologue.  K = 256 per problem (or z-split chunks of 256 kpw).
