@@ -79,10 +79,12 @@ extern "C" {
 #define VKN_FLAG_JOIN_EARLY 32768u     /* vkn_head_forward_*: join the side-stream link BEFORE the x4 upsample instead of behind it (1-3 % slower in back-to-back throughput;
                                         * the tracking embeddings of a single call are complete as early as its masks) */
 #define VKN_FLAG_SCALED_F16 16384u     /* vkn_head_forward_*: `scaled_out` is fp16 [B][N][H*S][W*S] (see vkn_upsample_bilinear_f16out); S in {2, 4} */
-#define VKN_FLAG_CHAIN_H2 65536u       /* the persistent kernels on the TWO-term fp16 split (hi + lo, 3 cross products, 4 bytes per weight: vkn_chain_h2.hip) instead of
-                                        * the three-term bf16 split (6 products, 6 bytes): 2^-22 instead of 2^-24 per product — where torch's own fp32 GEMMs sit
-                                        * against fp64 (profiles/r05_chain_two_term_accuracy.txt); same parity bounds.  Takes effect where the persistent form
-                                        * runs (by row count or VKN_FLAG_CHAIN_PERSISTENT) and vkn_prepare_stage_f32 built the fp16 images (C == 256 shapes) */
+/* The persistent kernels run on the TWO-term fp16 split of both operands (hi + lo, 3 cross products, 4 bytes per weight: vkn_chain_h2.hip;
+ * round 5) wherever vkn_prepare_stage_f32 built the fp16 weight images (the C == 256 shapes): 2^-22 per product instead of the 2^-24 of
+ * the three-term bf16 split (6 products, 6 bytes) — against fp64 the chain's outputs sit where torch's own fp32 GEMMs sit
+ * (profiles/r05_chain_two_term_accuracy.txt); same parity bounds (tests/test_gpu_parity.py), 29 % less time per stage
+ * (profiles/r05_chain_two_term_built.txt).  The one-launch-per-GEMM and few-row forms keep the bf16 split. */
+#define VKN_FLAG_CHAIN_BF16X3 65536u   /* the persistent kernels on the three-term bf16 split, as rounds 2-4 ran them (A/B; fp32 exponent range in every operand) */
 #define VKN_FLAG_CHAIN_KSPLIT 8192u    /* always the few-row chain: one column-spread launch per GEMM phase, normalisation in the consumer (vkn_ksplit.hip) */
 #define VKN_FLAG_SERIAL_LINK 32u   /* vkn_head_forward_f32: run the tracking link on the caller's stream instead of the library's side
                                     * stream (A/B, or callers that must see ONE stream; same results) */

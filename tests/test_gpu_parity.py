@@ -176,13 +176,13 @@ def test_stage_by_stage_vs_oracle_and_reference(vkn, name):
 
 
 def _chain_flags(vkn, chain):
-    """the forms of the [N x C] chain by name; `persistent_h2`: the persistent kernels on the two-term fp16 split (vkn_chain_h2.hip)"""
+    """the forms of the [N x C] chain by name; `persistent`: the persistent kernels as shipped (two-term fp16 split, vkn_chain_h2.hip); `persistent_bf16x3`: on the three-term bf16 split"""
     o = vkn.ops
     return dict(persistent=o.FLAG_CHAIN_PERSISTENT, launches=o.FLAG_CHAIN_LAUNCHES, ksplit=o.FLAG_CHAIN_KSPLIT,
-                persistent_h2=o.FLAG_CHAIN_PERSISTENT | o.FLAG_CHAIN_H2)[chain]
+                persistent_bf16x3=o.FLAG_CHAIN_PERSISTENT | o.FLAG_CHAIN_BF16X3)[chain]
 
 
-@pytest.mark.parametrize('flags', [0, 1, 2, 3, 512, 513, 256, 8192, 512 + 65536], ids=['mfma', 'refkernels', 'exactgemm', 'allexact', 'persistent', 'persistent_ref', 'launches', 'ksplit', 'persistent_h2'])
+@pytest.mark.parametrize('flags', [0, 1, 2, 3, 512, 513, 256, 8192, 512 + 65536], ids=['mfma', 'refkernels', 'exactgemm', 'allexact', 'persistent', 'persistent_ref', 'launches', 'ksplit', 'persistent_bf16x3'])
 @pytest.mark.parametrize('name', ['det_tiny', 'det_odd', 'det_cfg', 'video_tiny', 'video_cfg'])
 def test_head_vs_reference_golden(vkn, name, flags):
     """The fused S-stage call (`simple_test_mask_preds[_plus_previous]`) against the REFERENCE's own outputs."""
@@ -259,7 +259,7 @@ FREE_RUN_LIMITS = {
 }
 
 
-@pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent', 'persistent_h2'])
+@pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent', 'persistent_bf16x3'])
 @pytest.mark.parametrize('name', ['video_vipseg_big', 'det_ytvis', 'video_vipseg_n216'])
 def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name, chain):
     """(`video_vipseg_n216`: BASELINE cfg5 as LITERALLY worded — 150 proposals + 66 stuff kernels = 216 rows, 92x160 features (round 5; 46x80 before).)
@@ -346,7 +346,7 @@ def test_head_cfg5_cfg4_size_vs_reference_golden(vkn, name, chain):
 CFG2_FLIP_LIMIT, CFG2_CLEAN_ROWS_MIN, CFG2_CLEAN_LOGIT_ERR = 48, 88, 1.0e-3
 
 
-@pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent', 'persistent_h2'])
+@pytest.mark.parametrize('chain', ['auto', 'launches', 'persistent', 'persistent_bf16x3'])
 def test_cfg2_size_free_running_vs_oracle_flip_budget(vkn, chain):
     """The FREE-RUNNING 3-stage head at BASELINE cfg2 size against the free-running oracle, with the chaos argument measured
     instead of assumed: per stage, the binarised masks may differ from the oracle's only where the oracle's logit
@@ -459,7 +459,7 @@ def test_cfg2_size_properties(vkn):
     assert maxabs(d1, refd) < 2e-4
 
 
-@pytest.mark.parametrize('chain', ['ksplit', 'launches', 'persistent', 'persistent_h2'])
+@pytest.mark.parametrize('chain', ['ksplit', 'launches', 'persistent', 'persistent_bf16x3'])
 def test_cfg2_size_head_vs_oracle(vkn, chain):
     """(All three forms of the [N x C] chain: the few-row chain — the default at one frame —, one launch per GEMM with the row epilogue
     in the producer, and the persistent row-owner kernels.)

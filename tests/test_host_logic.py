@@ -401,7 +401,7 @@ def test_python_flag_constants_match_the_header(vkn):
     assert all(v & (v - 1) == 0 for v in hdr.values()), 'every flag is one bit'
     py = dict(REF_KERNELS=vkn.ops.FLAG_REF_KERNELS, EXACT_GEMM=vkn.ops.FLAG_EXACT_GEMM, LOGITS_HANDOFF=vkn.ops.FLAG_LOGITS_HANDOFF,
               BITS_HANDOFF=vkn.ops.FLAG_BITS_HANDOFF, SERIAL_LINK=vkn.ops.FLAG_SERIAL_LINK, X_F16=vkn.ops.FLAG_X_F16,
-              X_BF16=vkn.ops.FLAG_X_BF16, CHAIN_LAUNCHES=vkn.ops.FLAG_CHAIN_LAUNCHES, CHAIN_PERSISTENT=vkn.ops.FLAG_CHAIN_PERSISTENT, CHAIN_H2=vkn.ops.FLAG_CHAIN_H2,
+              X_BF16=vkn.ops.FLAG_X_BF16, CHAIN_LAUNCHES=vkn.ops.FLAG_CHAIN_LAUNCHES, CHAIN_PERSISTENT=vkn.ops.FLAG_CHAIN_PERSISTENT, CHAIN_BF16X3=vkn.ops.FLAG_CHAIN_BF16X3,
               PHASE_A=vkn.ops.PHASE_A, PHASE_B=vkn.ops.PHASE_B, PHASE_C=vkn.ops.PHASE_C, CLIP_LINK=8)
     for k, v in py.items():
         assert hdr[k] == v, (k, hdr[k], v)

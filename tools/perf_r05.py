@@ -91,16 +91,16 @@ def main():
             for rep in range(2):
                 for abl in (0, 11):
                     os.environ['VKN_CHAIN_ABL'] = str(abl)
-                    t = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob, flags=vkn.ops.FLAG_CHAIN_PERSISTENT))
+                    t = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob, flags=vkn.ops.FLAG_CHAIN_PERSISTENT | vkn.ops.FLAG_CHAIN_BF16X3))
                     line = f'B={B:3d} rows={B * N:5d} ABL={abl:2d}  chain alone {t:7.1f} us per stage'
                     if x is not None:
                         with torch.no_grad():
-                            th = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True), iters=20, warm=5)
+                            th = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True, flags=vkn.ops.FLAG_CHAIN_BF16X3), iters=20, warm=5)
                         line += f'   head step {th / 1e3:7.3f} ms = {B / th * 1e6:7.0f} frames/s'
                     print(line)
         os.environ['VKN_CHAIN_ABL'] = '0'
     if 'h2' in what:       # VERDICT r04 item 4 built: the persistent chain on the two-term fp16 split (vkn_chain_h2.hip) against the bf16 x 3 form
-        print('== persistent chain: three-term bf16 split (6 B / weight, 6 MFMAs) vs two-term fp16 split (VKN_FLAG_CHAIN_H2: 4 B, 3 MFMAs) ==')
+        print('== persistent chain: three-term bf16 split (6 B / weight, 6 MFMAs) vs two-term fp16 split (the default since round 5: 4 B, 3 MFMAs) ==')
         for B in (32, 64):
             dims = head.mask_head[0].make_dims(B, N, H, W)
             pack = head.mask_head[0].stage_pack(torch.device(DEV))
@@ -111,12 +111,12 @@ def main():
             mp = (torch.randn(B, N, H, W, generator=g) * 4).to(DEV) if B == 32 else None
             prev = torch.randn(B, N, C, 1, 1, generator=g).to(DEV) if B == 32 else None
             for rep in range(args.reps):
-                for nm, fl in (('bf16x3', vkn.ops.FLAG_CHAIN_PERSISTENT), ('fp16x2', vkn.ops.FLAG_CHAIN_PERSISTENT | vkn.ops.FLAG_CHAIN_H2)):
+                for nm, fl in (('bf16x3', vkn.ops.FLAG_CHAIN_PERSISTENT | vkn.ops.FLAG_CHAIN_BF16X3), ('fp16x2', vkn.ops.FLAG_CHAIN_PERSISTENT)):
                     t = timeit(lambda: vkn.ops.stage_chain(dims, pack, xf, ob, flags=fl))
                     line = f'B={B:3d} rows={B * N:5d} {nm}  chain alone {t:7.1f} us per stage'
                     if x is not None:
                         with torch.no_grad():
-                            th = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True, flags=fl & vkn.ops.FLAG_CHAIN_H2), iters=20, warm=5)
+                            th = timeit(lambda: head._head_forward(x, pf, mp, prev, want_track=True, flags=fl & vkn.ops.FLAG_CHAIN_BF16X3), iters=20, warm=5)
                         line += f'   head step (default policy) {th / 1e3:7.3f} ms = {B / th * 1e6:7.0f} frames/s'
                     print(line)
     if 'join' in what:     # where the side-stream link joins the main stream: behind the upsample (default) vs before it (VKN_FLAG_JOIN_EARLY)

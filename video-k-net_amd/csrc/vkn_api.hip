@@ -57,7 +57,7 @@ struct PrepW {
     const void *dynft, *dec;
     float *dynft32, *bcnt, *dec32, *decb, *dvec, *kb0, *fmT;
     float* chain_consts;   // packed bias / LayerNorm vectors of the persistent chain kernels (vkn_chain.hip), C == 256 only
-    // the persistent chain's weights once more as fp16 hi / lo tile images (VKN_FLAG_CHAIN_H2, vkn_chain_h2.hip), in VKN_H2_* order;
+    // the persistent chain's weights once more as fp16 hi / lo tile images (vkn_chain_h2.hip: the default of the persistent form), in VKN_H2_* order;
     // h2_scale [VKN_H2_COUNT][8]: vkn_pow2_scale_f32's output per matrix ([0] scale, [4] 1 / scale); h2_scratch: its two words
     const void* h2[VKN_H2_COUNT];
     float* h2_scale;
@@ -382,6 +382,9 @@ int final_decode(const VknDims* d, const float* x, const StageWs& s, const float
 // The persistent row-owner chain (vkn_chain.hip) covers the shipped shape: C == 256, one cls / mask FC, an FFN whose width is a
 // multiple of 256 (<= 2048), composite (feat_transform-folded) pre-split weights.  Everything else — and VKN_FLAG_CHAIN_LAUNCHES
 // (A/B) — takes the launch-per-GEMM path below.
+inline int persistent_min_row_tiles(const PrepW& pw, unsigned flags) {
+    return (!(flags & VKN_FLAG_CHAIN_BF16X3) && pw.h2_scale && pw.h2[VKN_H2_DYNFT]) ? 40 : 64;
+}
 inline unsigned pw_off(const VknStageWeights* w, const void* p) {
     return (unsigned)(static_cast<const char*>(p) - static_cast<const char*>(w->prepared));
 }
@@ -391,7 +394,12 @@ bool chain_fast_ok(const VknDims* d, const VknStageWeights* w, const PrepW& pw, 
     // Policy (profiles/r04_chain_ab.txt): a row-owner workgroup streams ALL of a stage's weights (12 MB) through its CU, ~160 us per
     // stage however many rows there are, while the launch-per-GEMM chain spreads the tile stream over the chip and costs
     // 124 / 149 / 202 / 341 us at 117 / 1872 / 3744 / 7488 rows: the persistent kernels win from ~64 row tiles (2048 rows) on.
-    if (!(flags & VKN_FLAG_CHAIN_PERSISTENT) && !vkn_dbg_env("VKN_CHAIN_PERSISTENT", 0) && (d->B * d->N + 31) / 32 < 64) return false;
+    // Round 5: on the two-term fp16 split the row owners stream 8 MB instead of 12 — 112 us per stage at any row count against
+    // 108 / 124 / 127 / 160 / 175 us of the launch-per-GEMM chain at 936 / 1404 / 1872 / 2340 / 3744 rows (profiles/r05_chain_forms.txt):
+    // they win from ~40 row tiles (11 frames of 117 kernels) on; on the bf16 split (VKN_FLAG_CHAIN_BF16X3) from 64 as before.
+    if (!(flags & VKN_FLAG_CHAIN_PERSISTENT) && !vkn_dbg_env("VKN_CHAIN_PERSISTENT", 0) &&
+        (d->B * d->N + 31) / 32 < persistent_min_row_tiles(pw, flags))
+        return false;
     if (d->C != 256 || d->n_cls_fcs != 1 || d->n_mask_fcs != 1 || d->ff % 256 != 0 || d->ff > 2048) return false;
     if (!w->prepared || w->prepared_bytes >= (1ull << 31)) return false;
     if (!pw.chain_consts || !pw.dynft || !pw.dyn || !pw.dec || !pw.inp || !pw.ig || !pw.ug || !pw.fc || !pw.attn_in || !pw.attn_out || !pw.ffn1 ||
@@ -401,9 +409,9 @@ bool chain_fast_ok(const VknDims* d, const VknStageWeights* w, const PrepW& pw, 
     if (!w->ffn1_w || !w->cls_ln_w[0] || !w->mask_ln_w[0]) return false;
     return true;
 }
-// the persistent chain on the two-term fp16 split (vkn_chain_h2.hip): on request, where its images were prepared
+// the persistent chain runs on the two-term fp16 split (vkn_chain_h2.hip) wherever its images were prepared; VKN_FLAG_CHAIN_BF16X3 opts out
 inline bool chain_h2(const PrepW& pw, unsigned flags, bool have_cls) {
-    return (flags & VKN_FLAG_CHAIN_H2) && pw.h2_scale && pw.h2[VKN_H2_DYNFT] && pw.h2[VKN_H2_DEC] && (!have_cls || pw.h2[VKN_H2_FCCLS]);
+    return !(flags & VKN_FLAG_CHAIN_BF16X3) && pw.h2_scale && pw.h2[VKN_H2_DYNFT] && pw.h2[VKN_H2_DEC] && (!have_cls || pw.h2[VKN_H2_FCCLS]);
 }
 
 // (ii) + the FC branches as three launches: k_chain_a, the attention, k_chain_c.  `a0` / `rowscale`: the raw gather + pixel counts
@@ -1597,10 +1605,21 @@ static int head_forward_impl(const VknDims* d, int num_stages, const VknStageWei
         so.prev_pre = prev_pre;
         so.link_track = (last && track_out) ? link_track : nullptr;
         so.track_src = track_src;
-        if (!last && use_fused && !(flags & (VKN_FLAG_CHAIN_LAUNCHES | VKN_FLAG_EXACT_GEMM)) &&
-            ((flags & VKN_FLAG_CHAIN_PERSISTENT) || (d->B * d->N + 31) / 32 >= 64)) {   // the fused pass of this stage ends in the next stage's gather reduction
-            so.touch_next = stages[sidx + 1].prepared;
-            so.touch_next_bytes = stages[sidx + 1].prepared_bytes;
+        if (!last && use_fused && !(flags & (VKN_FLAG_CHAIN_LAUNCHES | VKN_FLAG_EXACT_GEMM)) && stages[sidx + 1].prepared) {
+            // the fused pass of this stage ends in the next stage's gather reduction: it warms the weight images the persistent kernels
+            // will stream — the fp16 images alone where those run (they sit together in the prepared buffer)
+            PrepW pwn;
+            PrepItem itn[40];
+            carve_prepared(d, &stages[sidx + 1], static_cast<char*>(const_cast<void*>(stages[sidx + 1].prepared)), &pwn, itn, nullptr);
+            if ((flags & VKN_FLAG_CHAIN_PERSISTENT) || (d->B * d->N + 31) / 32 >= persistent_min_row_tiles(pwn, flags)) {
+                if (chain_h2(pwn, flags, false)) {
+                    so.touch_next = pwn.h2[VKN_H2_DYNFT];
+                    so.touch_next_bytes = (size_t)(reinterpret_cast<const char*>(pwn.h2_scale) - static_cast<const char*>(pwn.h2[VKN_H2_DYNFT]));
+                } else {
+                    so.touch_next = stages[sidx + 1].prepared;
+                    so.touch_next_bytes = stages[sidx + 1].prepared_bytes;
+                }
+            }
         }
         hipEvent_t ev0 = last ? static_cast<hipEvent_t>(ev_decode_start) : nullptr;
         hipEvent_t ev1 = last ? static_cast<hipEvent_t>(ev_decode_stop) : nullptr;

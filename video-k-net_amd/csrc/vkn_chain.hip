@@ -31,7 +31,7 @@
 #include "vkn_launch.h"
 
 // This file compiles TWICE: as itself (the three-term bf16 split: 6 bytes and 6 MFMAs per operand pair, 2^-24) and, with CH_H2 defined, from
-// vkn_chain_h2.hip (the TWO-term fp16 split hi + lo of the gather / decode kernels: 4 bytes, 3 MFMAs; VKN_FLAG_CHAIN_H2).  Everything that
+// vkn_chain_h2.hip (the TWO-term fp16 split hi + lo of the gather / decode kernels: 4 bytes, 3 MFMAs: what the persistent form runs unless VKN_FLAG_CHAIN_BF16X3).  Everything that
 // depends on the split — element type, planes per image / tile, the products — hangs on the macros below; see vkn_chain_h2.hip for the
 // range management of the fp16 form (pre-scaled weight images, per-row scaled activation images of unbounded rows).
 #ifdef CH_H2

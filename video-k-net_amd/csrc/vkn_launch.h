@@ -124,7 +124,7 @@ struct VknChainConsts {   // every bias / LayerNorm vector the two kernels read 
     const float *out_b, *attn_norm_w, *attn_norm_b, *ffn1_b, *ffn2_b, *ffn_norm_w, *ffn_norm_b;
     const float *cls_ln_w, *cls_ln_b, *mask_ln_w, *mask_ln_b, *dvec, *fc_cls_b, *dec_b;
     int ff, ncls;
-    // fp16-form weight images (VKN_FLAG_CHAIN_H2): DEVICE scalars 1 / scale of the images in the order of VKN_H2_* (NULL: 1)
+    // fp16-form weight images (vkn_chain_h2.hip): DEVICE scalars 1 / scale of the images in the order of VKN_H2_* (NULL: 1)
     const float* h2_inv[14];
 };
 // the weight matrices of the persistent chain, in the order of VknChainConsts::h2_inv and PrepW::h2
