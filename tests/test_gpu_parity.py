@@ -998,6 +998,37 @@ def test_stage_attention_head_widths_and_key_blocks_vs_oracle(vkn, C, heads, N):
     assert maxabs(m0, t0['new_mask_preds']) < TOL_LOGIT and maxabs(cls0, t0['cls_score']) < 1e-4
 
 
+@pytest.mark.parametrize('xscale,oscale', [(1e-4, 1.0), (1.0, 1e-3), (3e3, 1.0), (40.0, 50.0), (3e3, 1e-3)])
+def test_two_term_chain_range_management(vkn, xscale, oscale):
+    """The persistent chain on the two-term fp16 split (the default of that form) over inputs that leave fp16's exponent range in both
+    directions: update features (gather sums) of magnitude 1e-4 .. 1e5 and incoming kernels of 1e-3 .. 50 — every row of the four
+    unbounded activation images is scaled by its own power of two and every weight image by its matrix', so the results stay at fp32
+    rounding from the bf16 x 3 form and the exact-fp32 chain (no overflow at 65504, no lost low halves below 2^-14)."""
+    from test_host_logic import _cfg
+    B, N, C, ff, ncls = 3, 117, 256, 2048, 19
+    kw = dict(C=C, heads=8, ffn=ff, ncls=ncls, n_thing=2, n_stuff=17, S=1, up=1, nprop=100)
+    head = vkn.build_head(_cfg(False, **kw))
+    cfg, sd, x, pf, mp, prev = make_case(dict(kw, N=N, H=8, W=16, B=B, seed=777, video=0))
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV).eval()
+    dims = head.mask_head[0].make_dims(B, N, 8, 16)
+    pack = head.mask_head[0].stage_pack(torch.device(DEV))
+    g = torch.Generator(device='cpu').manual_seed(31)
+    xf = (torch.randn(B, N, C, generator=g) * 30 * xscale).to(DEV)
+    xf[0, 3] *= 1e-3                                   # rows of very different magnitude inside one tile
+    xf[1, 5] = 0.0                                     # an all-zero row (an empty mask)
+    ob = (torch.randn(B, N, C, generator=g) * oscale).to(DEV)
+    o = vkn.ops
+    h2 = o.stage_chain(dims, pack, xf, ob, flags=o.FLAG_CHAIN_PERSISTENT)
+    b3 = o.stage_chain(dims, pack, xf, ob, flags=o.FLAG_CHAIN_PERSISTENT | o.FLAG_CHAIN_BF16X3)
+    ex = o.stage_chain(dims, pack, xf, ob, flags=o.FLAG_EXACT_GEMM)
+    for nm, a, b, e in zip(('cls', 'kernels', 'bias', 'obj'), h2, b3, ex):
+        assert torch.isfinite(a).all(), nm
+        scale = max(1.0, float(e.abs().max()))
+        assert maxabs(a, e) < 4e-5 * scale and maxabs(a, b) < 4e-5 * scale, (nm, maxabs(a, e), maxabs(a, b), maxabs(b, e), scale)
+    assert not torch.equal(h2[3], b3[3]), 'the flag must select a different arithmetic'
+
+
 @pytest.mark.parametrize('B,N,ff,ncls,video', [(1, 117, 2048, 19, 0), (3, 117, 2048, 19, 1), (2, 166, 1024, 124, 0), (5, 20, 512, 40, 0),
                                                 (1, 32, 256, 3, 0), (8, 100, 2048, 40, 1), (18, 117, 2048, 19, 1)])
 def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, video):

@@ -44,6 +44,10 @@ class DeviceAssignResult(AssignResult):
             self._pos = self._pairs32[0].long()
         return self._pos
 
+    @device_pos_inds.setter
+    def device_pos_inds(self, value):
+        self._pos = value
+
     @property
     def labels(self):
         if self._labels is None:
@@ -52,6 +56,10 @@ class DeviceAssignResult(AssignResult):
             lab[self.device_pos_inds] = self._gt_labels.to(device=lab.device, dtype=lab.dtype)[self._pairs32[1].long()]
             self._labels = lab
         return self._labels
+
+    @labels.setter
+    def labels(self, value):       # (mmdet's AssignResult is a plain attribute bag: callers may overwrite)
+        self._labels = value
 
 
 class _AsyncFlags:
