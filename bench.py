@@ -716,7 +716,7 @@ def main():
                                          + 'x4 bilinear upsample of the final logits' + (' [SKIPPED]' if args.no_upsample else ''),
                                 frames_per_gpu_per_step=B, clip_frames=(args.clip or None), streams_per_gpu=NS,
                                 parallelism=f'frame-sharded dp{world}', x_storage=args.x_storage,
-                                arithmetic=('fp32 storage;' if xeb == 4 else args.x_storage + ' storage of x, fp32 everything else;') + ' gather/decode on f16 hi+lo split MFMA, [N x C] GEMMs on bf16x3 split MFMA, '
+                                arithmetic=('fp32 storage;' if xeb == 4 else args.x_storage + ' storage of x, fp32 everything else;') + ' gather/decode on f16 hi+lo split MFMA, [N x C] GEMMs on the same two-term f16 split in the persistent form (>= 40 row tiles: this workload at >= 11 frames per call) and on bf16x3 split MFMA in the few-row / launch-per-GEMM forms, '
                                            'fp32 accumulate everywhere (fp32-class accuracy, DESIGN.md §3); random-init weights'),
                     **extra)
         print(json.dumps(line))

@@ -17,3 +17,5 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python $R/bench.py $ARG
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o mfma -- python $R/bench.py $ARGS > $OUT/bench_mfma.log 2>&1
 python $R/tools/summarize_prof.py $OUT $OUT/pmc.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt | head -60
+# the trace / counter databases are tens of MB each and gpurun merges at most 64 MiB back: keep the summaries only
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
