@@ -184,3 +184,47 @@ def test_x_hub_sums_the_feature_map_gradient_once(vkn):
         return x.grad.clone(), k.grad.clone()
     (xa, ka), (xb, kb) = run(True), run(False)
     assert maxabs(xa, xb) < 1e-6 * float(xb.abs().max()) and torch.equal(ka, kb)
+
+
+@pytest.mark.parametrize('variant', ['no_stuff_targets', 'pos_weight_stage_weights', 'no_rank_loss', 'one_frame'])
+def test_fused_tail_equals_the_op_by_op_path_on_config_variants(vkn, variant):
+    """the corners of `get_targets` / `loss` the reference goldens do not visit, fused tail against the op-by-op path of this package:
+    a head without stuff kernels (label weights over ALL class columns, :388), pos_weight != 1 with per-stage loss weights != 1,
+    no rank loss, a single frame."""
+    from oracle import synth
+    n_thing, n_stuff = (5, 0) if variant == 'no_stuff_targets' else (2, 3)
+    B, C, H, W, up, nprop, S = (1 if variant == 'one_frame' else 3), 64, 8, 16, 2, 12, 2
+    over = dict(loss_rank=None) if variant == 'no_rank_loss' else None
+    cfgd = vkn.configs.roi_head_cfg(False, C=C, heads=8, ffn=128, ncls=n_thing + n_stuff, n_thing=n_thing, n_stuff=n_stuff, S=S, up=up,
+                                    nprop=nprop, train_cfg=vkn.configs.rcnn_train_cfg(S), mask_over=over)
+    if variant == 'pos_weight_stage_weights':
+        for c in cfgd['train_cfg']:
+            c['pos_weight'] = 2.5
+        cfgd['stage_loss_weights'] = [1, 0.5]
+    tg = synth.train_targets(B, n_thing, n_stuff, H * up, W * up, 91)
+    t = lambda key: [torch.from_numpy(e[key]).to(DEV) for e in tg]  # noqa: E731
+    gt_masks, gt_labels = t('gt_masks'), t('gt_labels')
+    sem = dict(gt_sem_seg=t('gt_sem_seg'), gt_sem_cls=t('gt_sem_cls')) if n_stuff else {}
+    N = nprop + n_stuff
+    g = torch.Generator(device='cpu').manual_seed(17)
+    x0, pf0 = torch.randn(B, C, H, W, generator=g), torch.randn(B, N, C, 1, 1, generator=g)
+    mp = (torch.randn(B, N, H, W, generator=g) * 3).to(DEV)
+    out = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        head = vkn.build_head(cfgd)
+        head.init_weights()
+        head = head.to(DEV).train()
+        head.fused_tail = fused
+        x, pf = x0.to(DEV).requires_grad_(True), pf0.to(DEV).requires_grad_(True)
+        losses = head.forward_train(x, pf, mp, None, [dict() for _ in range(B)], gt_masks, gt_labels, **sem)
+        sum(v for k, v in losses.items() if 'loss' in k).backward()
+        out.append((losses, x.grad, pf.grad, {k: p.grad for k, p in head.named_parameters() if p.grad is not None}))
+    (la, xa, pa, ga), (lb, xb, pb, gb) = out
+    assert sorted(la) == sorted(lb) and (('s0_loss_rank' in la) == (variant != 'no_rank_loss'))
+    for k in lb:
+        assert la[k].shape == lb[k].shape and abs(float(la[k]) - float(lb[k])) < 2e-6 * max(1.0, abs(float(lb[k]))), (k, float(la[k]), float(lb[k]))
+    assert maxabs(xa, xb) < 1e-5 * float(xb.abs().max()) and maxabs(pa, pb) < 1e-5 * float(pb.abs().max())
+    assert sorted(ga) == sorted(gb)
+    for k in gb:
+        assert maxabs(ga[k], gb[k]) < 1e-5 * max(float(gb[k].abs().max()), 1e-12), k
