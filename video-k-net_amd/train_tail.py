@@ -92,8 +92,7 @@ class TailStep:
         as_i64 = lambda t: t.to(device=device, dtype=torch.int64).contiguous().reshape(-1)  # noqa: E731  (no-op for device int64)
         self.labels = [as_i64(l) for l in gt_labels]
         self.sem_cls = [as_i64(c) if self.n_sem[b] else None for b, c in enumerate(gt_sem_cls)] if self.with_sem else [None] * self.B
-        self.status = torch.zeros(1, dtype=torch.int32, device=device)
-        self._zero = None
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)    # bit 0: a stuff class out of range (vkn_stage_targets), bit 1: a thing label (validate_labels)
 
     def stage_ok(self, head, assign_results, cls_score, scaled):
         return (cls_score is not None and cls_score.dtype == torch.float32 and scaled.is_cuda and scaled.dtype == torch.float32
@@ -151,7 +150,7 @@ class TailStep:
     def finish(self):
         """hand the range-error word to the asynchronous flag queue (read without stalling: mask_hungarian_assigner.FLAGS)"""
         from .mask_hungarian_assigner import FLAGS
-        FLAGS.push(self.status, 'gt_sem_cls outside the stuff classes [num_thing_classes, num_classes) (gt_labels of the stuff targets)')
+        FLAGS.push(self.status, 'gt_labels outside [0, num_thing_classes) or gt_sem_cls outside [num_thing_classes, num_classes)')
 
 
 class _StageTargets:
