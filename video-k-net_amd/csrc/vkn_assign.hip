@@ -28,10 +28,12 @@
 
 #define AS_CHUNK 4096  // pixels per workgroup of k_assign_act
 
-// act[0 .. Npad) = p1 rows, act[Npad .. 2 Npad) = p2 rows (rows >= N zero); rowsum[n][chunk][2] = partial (sum p1^2, sum p2)
+// act[0 .. Npad) = p1 rows, act[Npad .. 2 Npad) = p2 rows (rows >= N zero); rowsum[n][chunk][2] = partial (sum p1^2, sum p2).
+// two_planes == 0 (lo2 >= lo1: p2 = max(p1, lo2) exactly): only the p1 plane is written — the gather forms the second one on the way
+// into LDS (vkn_launch_gather_real: x_alias) — half the bytes of the largest tensor of the assignment.
 __global__ __launch_bounds__(256) void k_assign_act(const float* __restrict__ logits, float* __restrict__ act,
                                                     float* __restrict__ rowsum, int N, int Npad, int P, int nchunk, float lo1,
-                                                    float lo2) {
+                                                    float lo2, int two_planes) {
     __shared__ float red[2][4];
     const int n = blockIdx.y, ck = blockIdx.x;
     const int p_lo = ck * AS_CHUNK, p_hi = min(P, p_lo + AS_CHUNK);
@@ -44,12 +46,15 @@ __global__ __launch_bounds__(256) void k_assign_act(const float* __restrict__ lo
             const float s = 1.0f / (1.0f + expf(-z[p]));
             const float p1 = fminf(fmaxf(s, lo1), 1.0f), p2 = fminf(fmaxf(s, lo2), 1.0f);
             a1[p] = p1;
-            a2[p] = p2;
+            if (two_planes) a2[p] = p2;
             s1 += p1 * p1;
             s2 += p2;
         }
     } else {
-        for (int p = p_lo + threadIdx.x; p < p_hi; p += 256) { a1[p] = 0.f; a2[p] = 0.f; }
+        for (int p = p_lo + threadIdx.x; p < p_hi; p += 256) {
+            a1[p] = 0.f;
+            if (two_planes) a2[p] = 0.f;
+        }
     }
     s1 = vkn_wave_sum(s1);
     s2 = vkn_wave_sum(s2);
@@ -339,8 +344,10 @@ int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, cons
     carve_assign(N, G, P, static_cast<char*>(ws), &w);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nchunk = (P + AS_CHUNK - 1) / AS_CHUNK;
+    // MaskCost's activation is DiceCost's clamped higher (every shipped config: 1e-2 against 1e-3; knet_vis: 0 and 0): one stored plane
+    const bool alias = cfg->mask_pred_min >= cfg->dice_pred_min;
     hipLaunchKernelGGL(k_assign_act, dim3(nchunk, Npad), dim3(256), 0, st, mask_logits, w.act, w.rowsum, N, Npad, P, nchunk,
-                       cfg->dice_pred_min, cfg->mask_pred_min);
+                       cfg->dice_pred_min, cfg->mask_pred_min, alias ? 0 : 1);
     VKN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_assign_gtsq, dim3(nchunk, G), dim3(256), 0, st, gt_masks, w.gsq, P, nchunk);
     VKN_CHECK_LAUNCH();
@@ -348,12 +355,15 @@ int vkn_assign_costs_f32(const VknAssignCfg* cfg, const float* mask_logits, cons
     const float* S2 = w.S + (one ? (size_t)Npad : (size_t)G * Npad);
     int rc;
     if (one) {
-        rc = vkn_launch_gather_real(w.act, gt_masks, w.S, w.cnt, w.part, w.cntp, 1, G, 2 * Npad, P, G, st);
+        rc = vkn_launch_gather_real(w.act, gt_masks, w.S, w.cnt, w.part, w.cntp, 1, G, 2 * Npad, P, G, st, alias ? Npad : -1,
+                                    cfg->mask_pred_min);
     } else {   // [G][Npad] sums of p1, then of p2 (cnt = sum_p g either time)
         rc = vkn_launch_gather_real(w.act, gt_masks, w.S, w.cnt, w.part, w.cntp, 1, G, Npad, P, G, st);
         if (rc == VKN_OK)
-            rc = vkn_launch_gather_real(w.act + (size_t)Npad * P, gt_masks, w.S + (size_t)G * Npad, w.cnt, w.part, w.cntp, 1, G, Npad,
-                                        P, G, st);
+            rc = alias ? vkn_launch_gather_real(w.act, gt_masks, w.S + (size_t)G * Npad, w.cnt, w.part, w.cntp, 1, G, Npad, P, G, st, 0,
+                                                cfg->mask_pred_min)
+                       : vkn_launch_gather_real(w.act + (size_t)Npad * P, gt_masks, w.S + (size_t)G * Npad, w.cnt, w.part, w.cntp, 1, G,
+                                                Npad, P, G, st);
     }
     if (rc != VKN_OK) return rc;
     hipLaunchKernelGGL(k_assign_cost, dim3((N * G + 255) / 256), dim3(256), 0, st, *cfg, w.S, S2, one ? 2 * Npad : Npad, w.cnt,

@@ -36,8 +36,11 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
                                                                const float* __restrict__ masks, float thr,
                                                                float* __restrict__ part, float* __restrict__ cntp, int N,
                                                                int NPT, int n0, int C, int P, int px_per_wg,
-                                                               long long mask_fs, int ileave) {
+                                                               long long mask_fs, int ileave, int x_alias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // x_alias >= 0 (BITS == 2 only; the assignment's cost contraction): channels c >= x_alias of the feature operand are not stored —
+    // they are max(x[c - x_alias], thr), formed on the way into LDS (`thr` is otherwise unused by this mode).  The second activation
+    // of MaskCost / DiceCost is the first one clamped higher: one plane written and streamed instead of two.
     // per buffer: xh [C][40], xl [C][40], mk [NB*32][40] (+ ml [NB*32][40]: low half of a REAL mask operand, BITS == 2)
     constexpr bool REAL = (BITS == 2 || BITS == 3);  // 3: real operand = bit(z) * sigmoid(z), activated on the fly
     static_assert(!(XH && REAL), "half-storage x: binary operands only");
@@ -95,7 +98,10 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
             // non-temporal: x is streamed once per launch (same +9 % as in the decode kernel)
             if (XH)  // plain load: the 32-px tile is half a 128-byte line, the next tile of this workgroup takes the other half
                 xr[i] = *reinterpret_cast<const f32x4*>(xb16 + (size_t)(idc >> 2) * P + p0 + ((idc & 3) << 3));
-            else
+            else if (BITS == 2 && x_alias >= 0) {   // (plain loads: every stored row is read twice — once as itself, once as its alias)
+                const int ch = idc >> 3;
+                xr[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(ch >= x_alias ? ch - x_alias : ch) * P + p0 + ((idc & 7) << 2));
+            } else
                 xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)(idc >> 3) * P + p0 + ((idc & 7) << 2)));
         }
         if (BITS == 1) {  // even- and odd-pixel word of this row for the 64-px tile holding p0 (clamped: every thread loads)
@@ -122,7 +128,8 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (idx < nxch) {
                 const int p = p0 + ((idx & 7) << 2);
-                const float* src = xb + (size_t)(idx >> 3) * P + p;
+                const int ch = idx >> 3;
+                const float* src = xb + (size_t)((BITS == 2 && x_alias >= 0 && ch >= x_alias) ? ch - x_alias : ch) * P + p;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (p + k < p_end) v[k] = src[k];
@@ -175,10 +182,13 @@ __global__ __launch_bounds__(GA_THREADS, 2) void k_gather_mfma(const float* __re
             const int idx = tid + i * GA_THREADS;
             if (idx < nxch) {
                 half4 h, l;
+                const bool floor_ch = (BITS == 2) && x_alias >= 0 && (idx >> 3) >= x_alias;   // an aliased channel: max(stored value, thr)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     _Float16 hh, ll;
-                    vkn_split_f16(xr[i][k], hh, ll);
+                    float xv = xr[i][k];
+                    if (BITS == 2) xv = floor_ch ? fmaxf(xv, thr) : xv;
+                    vkn_split_f16(xv, hh, ll);
                     h[k] = hh;
                     l[k] = ll;
                 }
@@ -595,7 +605,7 @@ int vkn_launch_gather(const float* x, const float* masks, float thr, float* xraw
 // mask_rows: rows per frame of the logits tensor the N gathered rows live in (>= N; `masks` points at the first of them)
 static int gather_launch(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
                          int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt = 0, int* status = nullptr,
-                         const void* touch = nullptr, size_t touch_bytes = 0);
+                         const void* touch = nullptr, size_t touch_bytes = 0, int x_alias = -1);
 
 int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp,
                          int B, int N, int C, int P, int mask_rows, hipStream_t stream, int xdt, int* status, const void* touch,
@@ -604,9 +614,13 @@ int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* x
 }
 
 // REAL-valued left operand a [B][mask_rows][P] (first N rows used): xraw = sum_p a x, cnt = sum_p a
+// x_alias >= 0: channels c >= x_alias of x are max(x[c - x_alias], x_floor) and are not stored (x holds x_alias rows — or C when x_alias == 0:
+// every channel floored); -1: off
 int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C,
-                           int P, int mask_rows, hipStream_t stream) {
-    return gather_launch(x, a, 0.f, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 2, stream);
+                           int P, int mask_rows, hipStream_t stream, int x_alias, float x_floor) {
+    if (x_alias > C || (x_alias > 0 && (C - x_alias > x_alias || B != 1))) return VKN_E_ARG;   // (aliased rows: one frame — the frame stride is C rows)
+    return gather_launch(x, a, x_alias >= 0 ? x_floor : 0.f, xraw, cnt, part, cntp, B, N, C, P, mask_rows, 2, stream, 0, nullptr, nullptr, 0,
+                         x_alias);
 }
 
 // soft gather weights: xraw = sum_p [z >= thr] sigmoid(z) x, cnt = the sum of the weights (use_binary=False, knet/det/kernel_head.py:243-249)
@@ -625,7 +639,8 @@ int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, fl
 
 static int gather_launch(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
                          int N, int C, int P, int mask_rows, int bits, hipStream_t stream, int xdt, int* status, const void* touch,
-                         size_t touch_bytes) {
+                         size_t touch_bytes, int x_alias) {
+    if (x_alias >= 0 && bits != 2) return VKN_E_ARG;
     if (B <= 0 || N <= 0 || P <= 0 || mask_rows < N) return VKN_E_ARG;
     if (xdt < 0 || xdt > 2) return VKN_E_ARG;
     if (xdt && (bits >= 2 || (P % 64) != 0)) return VKN_E_SHAPE;  // half-storage x: binary operands, whole 16-byte aligned tiles
@@ -668,7 +683,7 @@ static int gather_launch(const float* x, const float* masks, float thr, float* x
     do {                                                                                                         \
         VKN_ALLOW_FULL_LDS((k_gather_mfma<NBV, BV, XHV>));                                                       \
         hipLaunchKernelGGL((k_gather_mfma<NBV, BV, XHV>), grid, block, lds, stream, x, masks, thr, part, cntp, N, NPT, n0, C, P, \
-                           px_per_wg, mask_fs, ileave);                                                          \
+                           px_per_wg, mask_fs, ileave, x_alias);                                                 \
     } while (0)
 #define GA_CASE(NBV)                                 \
     case NBV:                                        \

@@ -49,7 +49,7 @@ int vkn_launch_gather_ex(const float* x, const float* masks, float thr, float* x
 int vkn_launch_gather_ref_ex(const float* x, const float* masks, float thr, float* xraw, float* cnt, int B, int N, int C,
                              int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_real(const float* x, const float* a, float* xraw, float* cnt, float* part, float* cntp, int B, int N, int C,
-                           int P, int mask_rows, hipStream_t stream);
+                           int P, int mask_rows, hipStream_t stream, int x_alias = -1, float x_floor = 0.f);
 int vkn_launch_gather_soft(const float* x, const float* masks, float thr, float* xraw, float* cnt, float* part, float* cntp, int B,
                            int N, int C, int P, int mask_rows, hipStream_t stream);
 int vkn_launch_gather_bits(const float* x, const unsigned* bits, float* xraw, float* cnt, float* part, float* cntp, int B, int N,
