@@ -1030,7 +1030,7 @@ def test_two_term_chain_range_management(vkn, xscale, oscale):
 
 
 @pytest.mark.parametrize('B,N,ff,ncls,video', [(1, 117, 2048, 19, 0), (3, 117, 2048, 19, 1), (2, 166, 1024, 124, 0), (5, 20, 512, 40, 0),
-                                                (1, 32, 256, 3, 0), (8, 100, 2048, 40, 1), (18, 117, 2048, 19, 1)])
+                                                (1, 32, 256, 3, 0), (8, 100, 2048, 40, 1), (18, 117, 2048, 19, 1), (5, 117, 2048, 19, 0)])
 def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, video):
     """The [N x C] chain as two persistent row-owner kernels (k_chain_a / k_chain_c, the default at C = 256) against the same chain as
     one launch per GEMM (VKN_FLAG_CHAIN_LAUNCHES) and against the exact-fp32 GEMM chain (VKN_FLAG_EXACT_GEMM): one stage, same
@@ -1076,9 +1076,9 @@ def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, vide
     assert all(a is None or torch.equal(a, b) for a, b in zip(few, again)), 'deterministic (few-row chain)'
     assert maxabs(few[2], t0['obj_feat'].reshape(B, N, C)) < 2e-4
     assert maxabs(few[1], t0['new_mask_preds']) < TOL_LOGIT and maxabs(few[0], t0['cls_score']) < 1e-4
-    auto = vkn.ops.stage_forward(*args, **kwd)     # default policy by row tiles: few-row <= 16, launch-per-GEMM <= 63, persistent from 64 on
+    auto = vkn.ops.stage_forward(*args, **kwd)     # default policy by row tiles: few-row <= 16, launch-per-GEMM 17 .. 21, persistent (two-term fp16 split) from 22 on
     rt = (B * N + 31) // 32
-    pick = new if rt >= 64 else (few if rt <= 16 else old)
+    pick = new if rt >= 22 else (few if rt <= 16 else old)
     assert all(a is None or torch.equal(a, b) for a, b in zip(auto, pick)), 'default policy picks by row count'
 
 

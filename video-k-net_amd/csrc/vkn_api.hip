@@ -383,7 +383,7 @@ int final_decode(const VknDims* d, const float* x, const StageWs& s, const float
 // multiple of 256 (<= 2048), composite (feat_transform-folded) pre-split weights.  Everything else — and VKN_FLAG_CHAIN_LAUNCHES
 // (A/B) — takes the launch-per-GEMM path below.
 inline int persistent_min_row_tiles(const PrepW& pw, unsigned flags) {
-    return (!(flags & VKN_FLAG_CHAIN_BF16X3) && pw.h2_scale && pw.h2[VKN_H2_DYNFT]) ? 40 : 64;
+    return (!(flags & VKN_FLAG_CHAIN_BF16X3) && pw.h2_scale && pw.h2[VKN_H2_DYNFT]) ? 22 : 64;
 }
 inline unsigned pw_off(const VknStageWeights* w, const void* p) {
     return (unsigned)(static_cast<const char*>(p) - static_cast<const char*>(w->prepared));
@@ -396,7 +396,10 @@ bool chain_fast_ok(const VknDims* d, const VknStageWeights* w, const PrepW& pw, 
     // 124 / 149 / 202 / 341 us at 117 / 1872 / 3744 / 7488 rows: the persistent kernels win from ~64 row tiles (2048 rows) on.
     // Round 5: on the two-term fp16 split the row owners stream 8 MB instead of 12 — 112 us per stage at any row count against
     // 108 / 124 / 127 / 160 / 175 us of the launch-per-GEMM chain at 936 / 1404 / 1872 / 2340 / 3744 rows (profiles/r05_chain_forms.txt):
-    // they win from ~40 row tiles (11 frames of 117 kernels) on; on the bf16 split (VKN_FLAG_CHAIN_BF16X3) from 64 as before.
+    // chain alone they win from ~40 row tiles on, but inside a head step earlier — two launches instead of ten and the weight warm-up of the
+    // preceding gather reduction: whole steps at 5 / 6 / 7 / 8 / 9 / 10 frames per call 0.857 / 0.947 / 1.057 / 1.156 / 1.192 / 1.285 ms against
+    // 0.845 / 0.953 / 1.061 / 1.187 / 1.262 / 1.370 on the launch-per-GEMM chain (profiles/r05_chain_forms.txt) => from 22 row tiles (6 frames
+    // of 117 kernels) on; on the bf16 split (VKN_FLAG_CHAIN_BF16X3) from 64 as before.
     if (!(flags & VKN_FLAG_CHAIN_PERSISTENT) && !vkn_dbg_env("VKN_CHAIN_PERSISTENT", 0) &&
         (d->B * d->N + 31) / 32 < persistent_min_row_tiles(pw, flags))
         return false;
