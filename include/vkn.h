@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define VKN_VERSION 0x000400 /* 0.4.0: few-row chain (VKN_FLAG_CHAIN_KSPLIT), VKN_FLAG_SCALED_F16 + vkn_upsample_bilinear_f16out, VKN_FLAG_JOIN_EARLY, struct size probes */
+#define VKN_VERSION 0x000500 /* 0.5.0: the persistent chain runs on the two-term fp16 split (VKN_FLAG_CHAIN_BF16X3 opts out; vkn_prepared_bytes grows by the
+                              * fp16 weight images), the loss tail without target tensors (vkn_stage_targets ...), the backward glue entry points,
+                              * vkn_sum_n_f32.  0.4.0: few-row chain (VKN_FLAG_CHAIN_KSPLIT), VKN_FLAG_SCALED_F16 + vkn_upsample_bilinear_f16out,
+                              * VKN_FLAG_JOIN_EARLY, struct size probes */
 
 #define VKN_OK 0
 #define VKN_E_ARG (-1)       /* null pointer / non-positive size */

@@ -42,7 +42,7 @@ SHAPES = [  # B, N, C, H, W
 def test_library_loaded_and_gpu_visible(vkn):
     assert torch.cuda.is_available()
     assert os.path.exists(vkn._lib.LIBPATH)
-    assert vkn._lib.lib().vkn_version() == 0x000400
+    assert vkn._lib.lib().vkn_version() == 0x000500
 
 
 @pytest.mark.parametrize('flags', [0, 1], ids=['mfma', 'refkernels'])
