@@ -444,3 +444,49 @@ def test_public_header_is_plain_c(tmp_path):
                    '  (void)d; (void)w; (void)a; (void)b; (void)c; (void)g; return vkn_version() == 0; }\n')
     r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-Werror', '-fsyntax-only', '-I', root, str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_device_assign_result_is_lazy_and_equal_to_the_eager_fields(vkn):
+    """`DeviceAssignResult` (what `assign_batch` returns on the device path): `labels` and `device_pos_inds` are built on first access
+    from the LSAP's (row, col) pairs and equal the fields the eager construction produced (mask_hungarian_assigner.py, reference
+    :262-274); both can be overwritten like the attributes of mmdet's AssignResult."""
+    from importlib import import_module
+    mha = import_module('video_k_net_amd.mask_hungarian_assigner')
+    N, G = 12, 4
+    rows, cols = torch.tensor([1, 4, 7, 10], dtype=torch.int32), torch.tensor([2, 0, 3, 1], dtype=torch.int32)
+    gt_labels = torch.tensor([5, 6, 7, 8])
+    gt_inds = torch.zeros(N, dtype=torch.int64)
+    gt_inds[rows.long()] = cols.long() + 1
+    r = mha.DeviceAssignResult(G, gt_inds, (rows, cols), gt_labels, None)
+    assert r._labels is None and r._pos is None and r.num_gts == G and r.max_overlaps is None
+    want = torch.full((N,), -1, dtype=torch.long)
+    want[rows.long()] = gt_labels[cols.long()]
+    assert torch.equal(r.labels, want) and r.labels is r.labels
+    assert torch.equal(r.device_pos_inds, rows.long()) and r.device_pos_inds.dtype == torch.int64
+    s = import_module('video_k_net_amd.mask_pseudo_sampler').MaskPseudoSampler().sample(r, torch.zeros(N, 2, 2), torch.zeros(G, 2, 2))
+    assert torch.equal(s.pos_inds, rows.long()) and torch.equal(s.pos_gt_labels, gt_labels[cols.long()]) and s.num_neg == N - G
+    assert torch.equal(s.pos_assigned_gt_inds, cols.long())
+    r.labels = want + 1
+    assert torch.equal(r.labels, want + 1)
+
+
+def test_fused_training_tail_declines_what_it_does_not_cover(vkn):
+    """`TailStep.begin` returns None — the op-by-op path then runs — for CPU tensors, foreign assigners / samplers / loss objects, empty
+    or oversized ground truth; it never raises."""
+    from importlib import import_module
+    tt = import_module('video_k_net_amd.train_tail')
+    head = vkn.build_head(vkn.configs.roi_head_cfg(False, C=64, heads=8, ffn=128, ncls=5, n_thing=2, n_stuff=3, S=2, up=2, nprop=12,
+                                                   train_cfg=vkn.configs.rcnn_train_cfg(2)))
+    gm, gl = [torch.zeros(3, 16, 32)], [torch.zeros(3, dtype=torch.long)]
+    assert tt.TailStep.begin(head, torch.device('cpu'), gm, gl, None, None) is None
+    dev = torch.device('cuda', 0)          # (never touched: every check below fails before a tensor would be moved)
+    assert tt.TailStep.begin(head, dev, gm, gl, None, None) is None                                  # ground truth on another device
+    assert tt.TailStep.begin(head, dev, [], [], None, None) is None
+    head.fused_tail = False
+    assert tt.TailStep.begin(head, dev, gm, gl, None, None) is None
+    head.fused_tail = True
+    head.mask_assigner[0].lsap = 'host'
+    assert tt.TailStep.begin(head, dev, gm, gl, None, None) is None
+    head.mask_assigner[0].lsap = 'device'
+    head.mask_head[1].fused_mask_losses = False
+    assert tt.TailStep.begin(head, dev, gm, gl, None, None) is None
