@@ -169,17 +169,53 @@ def _stale(path=None):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _compile_objects(objdir, extra=(), force=False, verbose=False):
+    """One `hipcc -c` per source, in parallel, re-using objects newer than every header and their own source (no cross-file device
+    symbols exist, so plain separate compilation links)."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(os.path.dirname(HERE), 'include', 'vkn.h')]
+    exp = os.path.join(os.path.dirname(HERE), 'tools', 'experiments')
+    if '-DVKN_DEBUG' in extra and os.path.isdir(exp):
+        hdrs += [os.path.join(exp, f) for f in os.listdir(exp)]
+    hdrs.append(os.path.join(CSRC, 'vkn_chain.hip'))              # vkn_chain_h2.hip #includes it
+    t_h = max(os.path.getmtime(h) for h in hdrs if os.path.exists(h))
+    jobs, objs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s[:-4] + '.o')
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(t_h, os.path.getmtime(src)):
+            jobs.append([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', *extra, '-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise VknLibraryError('hipcc failed:\n' + r.stdout + r.stderr)
+    with ThreadPoolExecutor(max_workers=max(1, min(int(os.environ.get('VKN_BUILD_JOBS', '6')), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    return objs
+
+
+def _link(objs, out, verbose=False):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', out]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise VknLibraryError('hipcc link failed:\n' + r.stdout + r.stderr)
+
+
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into lib/libvkn.so (cross-compiles without a GPU)."""
+    """Compile csrc/*.hip for gfx950 into lib/libvkn.so (cross-compiles without a GPU): one object per source under lib/obj/,
+    compiled in parallel, then one link."""
     os.makedirs(LIBDIR, exist_ok=True)
     if not force and not _stale():
         return LIBPATH
-    cmd = hipcc_command()
-    if verbose:
-        print(' '.join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise VknLibraryError('hipcc failed:\n' + r.stdout + r.stderr)
+    _link(_compile_objects(os.path.join(LIBDIR, 'obj'), force=force, verbose=verbose), LIBPATH, verbose)
     return LIBPATH
 
 
@@ -189,9 +225,7 @@ def build_debug(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     if not force and not _stale(DEBUG_LIBPATH):
         return DEBUG_LIBPATH
-    r = subprocess.run(hipcc_command(out=DEBUG_LIBPATH, extra=('-DVKN_DEBUG',)), capture_output=True, text=True)
-    if r.returncode != 0:
-        raise VknLibraryError('hipcc failed:\n' + r.stdout + r.stderr)
+    _link(_compile_objects(os.path.join(LIBDIR, 'obj_debug'), extra=('-DVKN_DEBUG',), force=force), DEBUG_LIBPATH)
     return DEBUG_LIBPATH
 
 
