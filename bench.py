@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of the Video K-Net kernel-update head on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: re-executes itself under torch.distributed.run, one rank per GPU;
+                                                            also runs when the driver already launched it that way)
 
 A "step" = one pass of the hot path over one clip of `--frames` synthetic 1024x2048 frames per GPU:
 `VideoKernelIterHead` (S=3 stages of gather -> kernel update + interaction -> decode, N = 100 proposals + 17 stuff kernels,
@@ -106,7 +107,7 @@ def _cpu_identity():
     return model, (len(cores) or None)
 
 
-def cpu_baseline(head_sd, sample_frames=1, runs=6):
+def cpu_baseline(head_sd, sample_frames=1, runs=10):
     """The CPU oracle (same ATen op sequence as the reference) on this host's cores — kind 'port'."""
     from oracle.knet_oracle import HeadCfg, iter_head_mask_preds
     cfg = HeadCfg(num_stages=CFG2['S'], in_channels=CFG2['C'], num_heads=CFG2['heads'], num_classes=CFG2['ncls'],
@@ -160,10 +161,23 @@ def cpu_baseline(head_sd, sample_frames=1, runs=6):
                        f'min {sample_frames / ts[-1]:.3f} max {sample_frames / ts[0]:.3f} frames/s')
 
 
+def _max_over_ranks(dt, steps, device, dist_on):
+    """(MAX over ranks of the timed region, ms per step of every rank, the rank count the process group reports)."""
+    if not dist_on:
+        return dt, [round(dt / steps * 1e3, 4)], 1
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    ts = [float(p.item()) for p in parts]
+    return max(ts), [round(v / steps * 1e3, 4) for v in ts], dist.get_world_size()
+
+
 def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
     """BASELINE cfg3: the clip's frames sharded over the ranks, head trained data-parallel (see the module docstring)."""
     B = args.frames if args.frames != 32 else 4            # frames per GPU per step (the inference default of 32 is not a training batch)
-    N, C, H, W, up = CFG2['N'], CFG2['C'], CFG2['H'], CFG2['W'], 2
+    # x4: mask_upsample_stride of the shipped KITTI-STEP video config (configs/det/video_knet_kitti_step/...link_ffn_joint_train.py:102;
+    # mask_assign_stride=2, :22) -> 512x1024 loss / assignment masks for a 1024x2048 frame.  Rounds 2-5 timed x2 (`--train-up 2`).
+    N, C, H, W, up = CFG2['N'], CFG2['C'], CFG2['H'], CFG2['W'], args.train_up
     cfg = vkn.configs.roi_head_cfg(True, C=C, heads=CFG2['heads'], ffn=CFG2['ffn'], ncls=CFG2['ncls'], n_thing=CFG2['n_thing'],
                                    n_stuff=CFG2['n_stuff'], S=CFG2['S'], up=up, nprop=CFG2['nprop'],
                                    train_cfg=vkn.configs.rcnn_train_cfg(CFG2['S']))
@@ -243,14 +257,12 @@ def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, per_rank_ms, ranks_seen = _max_over_ranks(dt, args.steps, device, dist_on)
     if rank == 0:
         nparam = sum(p.numel() for p in head.parameters())
         print(json.dumps(dict(metric='training frames/sec (S=3, N=100, 1024x2048, head only)', value=round(world * B * args.steps / dt, 2),
-                              unit='frames/s', n_gpus=world, steps=args.steps, warmup=max(args.warmup, 3),
+                              unit='frames/s', n_gpus=world, rccl_ranks=(ranks_seen if dist_on else None), per_rank_ms_per_step=per_rank_ms,
+                              steps=args.steps, warmup=max(args.warmup, 3),
                               ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
                               dtype='f32', data='synthetic',
                               config=dict(workload='cfg3 video_knet_s3_r50 head training: forward_train_with_previous (losses, GPU '
@@ -262,7 +274,12 @@ def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
                                                       else ', captured as hipGraphs (forward + backward)')
                                                    + ', per-stage bucketed RCCL gradient all-reduce overlapped with backward, SGD step',
                                           frames_per_gpu_per_step=B, parallelism=f'frame-sharded dp{world}',
-                                          head_parameters=nparam, last_loss=round(float(loss), 4)))))
+                                          mask_upsample_stride=up, loss_mask_size=[Hs, Ws], fused_loss_tail=bool(getattr(head, '_last_tail_fused', False)),
+                                          head_parameters=nparam, last_loss=round(float(loss), 4)),
+                              # the parity pin of THIS step at THIS size: the reference's own forward_train_with_previous on the CPU,
+                              # same head / channel / kernel counts / feature size / x4, two frames (oracle/gen_golden.py)
+                              parity_witness=('tests/golden/train_video_cfg3.npz via tests/test_gpu_train.py::'
+                                              'test_forward_train_at_the_benchmarked_cfg3_size_vs_reference_golden' if up == 4 else None))))
     if dist_on:
         dist.destroy_process_group()
 
@@ -283,6 +300,8 @@ def main():
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the extra data points of `breakdown` that launch other batch sizes / several clips (profiling runs)')
     ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
+    ap.add_argument('--train-up', type=int, default=4, choices=[1, 2, 4],
+                    help='--train: mask_upsample_stride (4 = the shipped video KITTI-STEP config: 512x1024 loss masks; 2 = what rounds 2-5 timed)')
     ap.add_argument('--train-foreach-sgd', action='store_true', help='--train A/B: torch.optim.SGD on its foreach path instead of fused=True')
     ap.add_argument('--train-default-stream', action='store_true', help='--train A/B: run the step on the default stream (chain graphs captured on a side stream)')
     ap.add_argument('--train-add-grads', action='store_true', help='--train A/B: zero the gradient buckets and add into their views instead of set_to_none + one batched copy')
@@ -305,9 +324,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.force_dist):
+        # `python bench.py --gpus N` starts its own N ranks (the reference's launcher does the same from one command:
+        # tools/dist_train.sh:7-9): re-exec under torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1
+        import socket
+        with socket.socket() as s_:
+            s_.bind(('127.0.0.1', 0))
+            port = s_.getsockname()[1]
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]])
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` (self-launching) or with '
+                         f'torch.distributed.run --nproc-per-node equal to --gpus')
     if args.clip:
         if args.clip % world != 0:
             raise SystemExit(f'--clip {args.clip} does not split into equal contiguous blocks over {world} ranks')
@@ -440,10 +469,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         dec_live_ms = sorted(e0_.elapsed_time(e1_) for e0_, e1_ in dec_events)
-    if dist_on:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, per_rank_ms, ranks_seen = _max_over_ranks(dt, args.steps, device, dist_on)
     frames = world * B * args.steps
     ms_per_step = dt / args.steps * 1e3
 
@@ -705,7 +731,8 @@ def main():
 
     if rank == 0:
         line = dict(metric='frames/sec (S=3, N=100, 1024x2048)', value=round(frames / dt, 2), unit='frames/s',
-                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+                    n_gpus=world, rccl_ranks=(ranks_seen if dist_on else None), per_rank_ms_per_step=per_rank_ms,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                     higher_is_better=True, scaling='strong' if args.clip else 'weak', vs_baseline=None, dtype='f32', data='synthetic',
                     config=dict(workload=('cfg3 shape: ONE clip of %d frames in contiguous blocks of %d per GPU; ' % (args.clip, B) if args.clip else '')
                                          + 'cfg2 video_knet_s3_r50: VideoKernelIterHead S=3, N=100 proposals + 17 stuff = 117 '
@@ -716,7 +743,7 @@ def main():
                                          + 'x4 bilinear upsample of the final logits' + (' [SKIPPED]' if args.no_upsample else ''),
                                 frames_per_gpu_per_step=B, clip_frames=(args.clip or None), streams_per_gpu=NS,
                                 parallelism=f'frame-sharded dp{world}', x_storage=args.x_storage,
-                                arithmetic=('fp32 storage;' if xeb == 4 else args.x_storage + ' storage of x, fp32 everything else;') + ' gather/decode on f16 hi+lo split MFMA, [N x C] GEMMs on the same two-term f16 split in the persistent form (>= 40 row tiles: this workload at >= 11 frames per call) and on bf16x3 split MFMA in the few-row / launch-per-GEMM forms, '
+                                arithmetic=('fp32 storage;' if xeb == 4 else args.x_storage + ' storage of x, fp32 everything else;') + ' gather/decode on f16 hi+lo split MFMA, [N x C] GEMMs on the same two-term f16 split in the persistent form (>= 22 row tiles: this workload at >= 6 frames per call) and on bf16x3 split MFMA in the few-row / launch-per-GEMM forms, '
                                            'fp32 accumulate everywhere (fp32-class accuracy, DESIGN.md §3); random-init weights'),
                     **extra)
         print(json.dumps(line))

@@ -53,7 +53,11 @@ extern "C" {
                               * hi/lo split turns it into inf, and inf x {0,1} reaches EVERY kernel row of that frame) or x itself was
                               * non-finite.  The outputs of that call are garbage.  Checked in the fixed-order reduction that ends
                               * every gather (one compare per [B][N][C] output value: free); the stand-alone op entry points
-                              * (vkn_mask_gather_f32, vkn_mask_decode_f32 ...) do not check. */
+                              * (vkn_mask_gather_f32, vkn_mask_decode_f32 ...) do not check.
+                              * Also set by the persistent [N x C] chain on the two-term fp16 split (its default form) when one of the
+                              * activation images it stores UNSCALED — LayerNorm outputs, ReLU / FFN hidden rows, the cls / mask branch
+                              * inputs: O(1) for ordinary weights — holds |v| >= 2^15 or a NaN (a large LayerNorm gain, a fine-tuned W1):
+                              * re-run with VKN_FLAG_CHAIN_BF16X3 (fp32 range). */
 
 #define VKN_FLAG_REF_KERNELS 1u /* exact-fp32 FMA gather/decode kernels instead of the MFMA ones */
 #define VKN_FLAG_EXACT_GEMM 2u  /* exact-fp32 MFMA for the [N x C] GEMMs even when pre-split weights are supplied */

@@ -447,6 +447,13 @@ TRAIN_CASES = {
     # config channels / kernel count
     'train_cfg': dict(video=False, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=2, nprop=100, N=117, H=16, W=32,
                       B=2, seed=73),
+    # video head at config channels / kernel count, x4 (the shipped KITTI-STEP video config: mask_upsample_stride=4,
+    # configs/det/video_knet_kitti_step/...link_ffn_joint_train.py:102), full gradients w.r.t. x and the kernels
+    'train_video_c256': dict(video=True, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=16,
+                             W=32, B=2, seed=75, full_x=True),
+    # BASELINE cfg3 at the size bench.py --train times: 1024x2048 frames -> 128x256 features, 512x1024 loss masks, two frames
+    'train_video_cfg3': dict(video=True, C=256, heads=8, ffn=2048, ncls=19, n_thing=2, n_stuff=17, S=3, up=4, nprop=100, N=117, H=128,
+                             W=256, B=2, seed=76),
 }
 TRAIN_GRAD_KEYS = ('mask_head.0.feat_transform.conv.weight', 'mask_head.0.feat_transform.conv.bias',
                    'mask_head.0.kernel_update_conv.dynamic_layer.weight', 'mask_head.0.attention.attn.in_proj_weight',
@@ -460,6 +467,7 @@ def run_train_case(name, p):
     of the summed loss w.r.t. x, proposal_feats and a sample of the parameters."""
     p = dict(p)
     N, H, W, B, seed = (p.pop(k) for k in ('N', 'H', 'W', 'B', 'seed'))
+    full_x = p.pop('full_x', False)
     video = p['video']
     cfg = head_cfg(**p)
     cfg['train_cfg'] = [AttrDict(assigner=dict(type='MaskHungarianAssigner', cls_cost=dict(type='FocalLossCost', weight=2.0),
@@ -509,17 +517,17 @@ def run_train_case(name, p):
         out['plink'], out['ptype'] = np.array(p['plink'] or ''), np.array(p['ptype'])
     big = p['C'] > 64
 
-    def put(tag, t):
+    def put(tag, t, full=False):
         """full tensor for the small cases; 4096 sampled elements + the norm for the config-size case"""
         t = t.detach()
-        if not big or t.numel() <= 8192:
+        if full or not big or t.numel() <= 8192:
             out[tag] = t.numpy()
         else:
             idx = (synth.uniform((4096,), 5151 + len(tag), 0.0, 1.0).astype(np.float64) * t.numel()).astype(np.int64)
             out[tag + '_idx'], out[tag + '_val'] = idx, t.reshape(-1)[idx].numpy()
             out[tag + '_norm'] = np.float64(float(t.double().norm()))
-    put('grad_x', x.grad)
-    put('grad_pf', pf.grad)
+    put('grad_x', x.grad, full_x)
+    put('grad_pf', pf.grad, full_x)
     named = dict(head.named_parameters())
     gk = [k for k in TRAIN_GRAD_KEYS if k in named]
     if video and p.get('plink') is not None:

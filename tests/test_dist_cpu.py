@@ -80,6 +80,7 @@ def _grad_worker(rank, world, port, q):
     vkn = vkn_import.load()
     from importlib import import_module
     d = import_module('video_k_net_amd.dist')
+    _updator_torch = import_module('video_k_net_amd.kernel_update_head')._updator_torch
     torch.manual_seed(0)                                    # identical replicas
     C, rows = 32, 16
     net = torch.nn.ModuleDict({'mask_head': torch.nn.ModuleList(
@@ -91,8 +92,8 @@ def _grad_worker(rank, world, port, q):
 
     def loss_of(u_, k_):
         h = k_
-        for m in net['mask_head']:                           # the head's own torch chain (KernelUpdator.forward_autograd), CPU
-            h = m.forward_autograd(u_, h)
+        for m in net['mask_head']:                           # the head's own torch chain (kernel_update_head._updator_torch), CPU
+            h = _updator_torch(m, u_, h)
         return (h ** 2).mean()
 
     for _ in range(2):                                       # two steps: zero_grad re-arms the hooks
@@ -106,7 +107,7 @@ def _grad_worker(rank, world, port, q):
         ref_net.load_state_dict(net.state_dict())
         h = k
         for m in ref_net['mask_head']:
-            h = m.forward_autograd(u, h)
+            h = _updator_torch(m, u, h)
         (h ** 2).mean().backward()
         err = max(float((got[n] - p.grad).abs().max() / (p.grad.abs().max() + 1e-12)) for n, p in ref_net.named_parameters())
         q.put(err)

@@ -1029,6 +1029,45 @@ def test_two_term_chain_range_management(vkn, xscale, oscale):
     assert not torch.equal(h2[3], b3[3]), 'the flag must select a different arithmetic'
 
 
+def test_two_term_chain_reports_activations_outside_the_fp16_envelope(vkn):
+    """the persistent chain's UNSCALED activation images (LayerNorm outputs, FFN hidden rows, branch inputs) are O(1) for
+    ordinary weights; a fine-tuned / badly scaled W1 or LayerNorm gain that pushes one beyond 2^15 used to become inf -> NaN silently.
+    Now the write ORs VKN_STATUS_RANGE into the workspace status word (`workspace_status()` raises VKN_E_RANGE); the bf16x3 form
+    (VKN_FLAG_CHAIN_BF16X3: fp32 range) computes the same stage cleanly and is the documented fallback."""
+    from test_host_logic import _cfg
+    B, N, C, ff, ncls = 3, 117, 256, 2048, 19
+    kw = dict(C=C, heads=8, ffn=ff, ncls=ncls, n_thing=2, n_stuff=17, S=1, up=1, nprop=100)
+    cfg, sd, x, pf, mp, prev = make_case(dict(kw, N=N, H=8, W=16, B=B, seed=778, video=0))
+    g = torch.Generator(device='cpu').manual_seed(32)
+    xf = (torch.randn(B, N, C, generator=g) * 30).to(DEV)
+    ob = torch.randn(B, N, C, generator=g).to(DEV)
+    o = vkn.ops
+
+    def run(scale_key, factor, flags):
+        head = vkn.build_head(_cfg(False, **kw))
+        sd2 = {k: (v * factor if k == scale_key else v) for k, v in sd.items()}
+        head.load_state_dict(sd2, strict=True)
+        head = head.to(DEV).eval()
+        dims = head.mask_head[0].make_dims(B, N, 8, 16)
+        return o.stage_chain(dims, head.mask_head[0].stage_pack(torch.device(DEV)), xf, ob, flags=flags)
+
+    o.workspace_status()                                                   # clear whatever an earlier test left
+    out = run(None, 1.0, o.FLAG_CHAIN_PERSISTENT)
+    o.workspace_status()                                                   # ordinary weights: nothing reported
+    assert all(torch.isfinite(t).all() for t in out)
+    for key, factor in (('mask_head.0.ffn.layers.0.0.weight', 3e5), ('mask_head.0.attention_norm.weight', 1e5)):
+        run(key, factor, o.FLAG_CHAIN_PERSISTENT)
+        with pytest.raises(vkn._lib.VknError) as e:
+            o.workspace_status()
+        assert e.value.code == -6, key
+        o.workspace_status()                                               # read-and-clear
+        b3 = run(key, factor, o.FLAG_CHAIN_PERSISTENT | o.FLAG_CHAIN_BF16X3)
+        o.workspace_status()                                               # the fp32-range form does not report ...
+        ex = run(key, factor, o.FLAG_EXACT_GEMM)
+        assert all(torch.isfinite(t).all() for t in b3)                    # ... and computes the stage
+        assert maxabs(b3[3], ex[3]) < 1e-4 * max(1.0, float(ex[3].abs().max()))
+
+
 @pytest.mark.parametrize('B,N,ff,ncls,video', [(1, 117, 2048, 19, 0), (3, 117, 2048, 19, 1), (2, 166, 1024, 124, 0), (5, 20, 512, 40, 0),
                                                 (1, 32, 256, 3, 0), (8, 100, 2048, 40, 1), (18, 117, 2048, 19, 1), (5, 117, 2048, 19, 0)])
 def test_persistent_chain_equals_launch_per_gemm_chain(vkn, B, N, ff, ncls, video):

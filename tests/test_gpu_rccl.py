@@ -42,6 +42,7 @@ def test_bucketed_reducer_through_rccl(vkn, rccl_group):
     finalize -> optimizer works with torch's default zero_grad."""
     from importlib import import_module
     d = import_module('video_k_net_amd.dist')
+    _updator_torch = import_module('video_k_net_amd.kernel_update_head')._updator_torch
     torch.manual_seed(0)
     C, rows = 64, 48
     net = torch.nn.ModuleDict({'mask_head': torch.nn.ModuleList(
@@ -53,7 +54,7 @@ def test_bucketed_reducer_through_rccl(vkn, rccl_group):
     def loss_of():
         h = k
         for m in net['mask_head']:
-            h = m.forward_autograd(u, h)
+            h = _updator_torch(m, u, h)
         return (h ** 2).mean()
 
     ref = torch.autograd.grad(loss_of(), list(net.parameters()))
@@ -183,3 +184,22 @@ def test_bench_clip_of_8_strong_scaling_under_torchrun_one_rank():
     for b in (4, 2, 1):
         assert bd[f'per_rank_step_ms_at_{b}_frames_ONE_gpu'] > 0
     assert bd['per_rank_step_ms_at_1_frames_ONE_gpu'] < bd['per_rank_step_ms_at_4_frames_ONE_gpu']
+
+
+def test_bench_self_launches_its_ranks_from_the_bare_command():
+    """`python bench.py --gpus 1 --force-dist` with no launcher and no WORLD_SIZE in the environment: bench.py re-executes itself
+    under torch.distributed.run (the path `python bench.py --gpus 8` takes; reference: one command starts every rank,
+    tools/dist_train.sh:7-9), RCCL is initialised, and the one JSON line reports the rank count the process group saw and every
+    rank's own step time.  Also `--clip 8` and `--train` through the same path."""
+    env_keys = [k for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR') if k in os.environ]
+    saved = {k: os.environ.pop(k) for k in env_keys}
+    try:
+        line = _bench(['--force-dist'])
+        assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1 and len(line['per_rank_ms_per_step']) == 1 and line['value'] > 0
+        assert abs(line['per_rank_ms_per_step'][0] - line['ms_per_step']) < 1e-3 * line['ms_per_step'] + 1e-3
+        clip = _bench(['--force-dist', '--clip', '8'])
+        assert clip['scaling'] == 'strong' and clip['rccl_ranks'] == 1
+        train = _bench(['--force-dist', '--train', '--steps', '6', '--warmup', '3'])
+        assert train['rccl_ranks'] == 1 and train['value'] > 0 and train['parity_witness']
+    finally:
+        os.environ.update(saved)

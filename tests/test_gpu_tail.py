@@ -1,4 +1,7 @@
-"""GPU (-m gpu): the fused loss tail of the training loop (video-k-net_amd/train_tail.py; include/vkn.h "the loss tail of a training
+"""GPU (-m gpu): SELF-COMPARISON, not parity evidence — the parity pin of the fused tail is
+tests/test_gpu_train.py::test_forward_train_vs_reference_golden (+ the cfg3-size golden), which run THROUGH the fused tail by default.
+
+The fused loss tail of the training loop (video-k-net_amd/train_tail.py; include/vkn.h "the loss tail of a training
 stage") against the op-by-op path it replaces (per-image sampler -> `get_targets` -> `loss`, reference
 knet/det/kernel_iter_head.py:139-231, kernel_update_head.py:279-441): identical loss keys, values to fp32 reduction-order accuracy,
 identical assignments, gradients to 1e-5 of each tensor's scale.  The op-by-op path is itself checked against the reference goldens
@@ -122,6 +125,32 @@ def test_out_of_range_stuff_class_is_reported_not_read(vkn):
     mha.FLAGS.poll(wait=True)           # nothing is left behind for the next test
 
 
+def test_repeated_stuff_class_is_reported_and_too_many_stuff_targets_decline_the_fused_tail(vkn):
+    """a class listed twice in gt_sem_cls (the reference keeps the last mask and counts the class once) would race on one
+    row and over-count the positives: the fused tail reports it through the status word; more stuff targets than stuff kernels cannot
+    be distinct -> `TailStep.begin` declines and the op-by-op path (the reference's semantics) runs."""
+    from importlib import import_module
+    mha = import_module('video_k_net_amd.mask_hungarian_assigner')
+    g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, 'train_cfg')
+    assert gt_sem_cls[0].numel() >= 2
+    dup = [c.clone() for c in gt_sem_cls]
+    dup[0][1] = dup[0][0]
+    mha.FLAGS.poll(wait=True)
+    metas = [dict() for _ in range(case['B'])]
+    with pytest.raises(IndexError):
+        head.forward_train(x.to(DEV), pf.to(DEV), mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=dup)
+        assert head._last_tail_fused
+        mha.FLAGS.poll(wait=True)
+    mha.FLAGS.poll(wait=True)
+    S = head.mask_head[0].num_stuff_classes
+    many_cls = [torch.cat([c, c])[:S + 1] if c.numel() * 2 > S else c for c in gt_sem_cls]
+    many_seg = [torch.cat([m, m])[:S + 1] if m.shape[0] * 2 > S else m for m in gt_sem_seg]
+    assert any(c.numel() > S for c in many_cls)
+    head.forward_train(x.to(DEV), pf.to(DEV), mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=many_seg, gt_sem_cls=many_cls)
+    assert not head._last_tail_fused
+    mha.FLAGS.poll(wait=True)
+
+
 def test_backward_glue_kernels_vs_torch(vkn):
     """the single-launch glue of the gather / decode backward passes against the torch expressions they replace: bit for bit"""
     ops, vag = vkn.ops, vkn.autograd
@@ -184,6 +213,58 @@ def test_x_hub_sums_the_feature_map_gradient_once(vkn):
         return x.grad.clone(), k.grad.clone()
     (xa, ka), (xb, kb) = run(True), run(False)
     assert maxabs(xa, xb) < 1e-6 * float(xb.abs().max()) and torch.equal(ka, kb)
+
+
+def test_x_hub_partial_backward_leaves_no_stale_parts(vkn):
+    """a backward pass that never reaches the hub's node — `torch.autograd.grad(loss, head_params,
+    retain_graph=True)` — parks dx contributions in the hub; they must not be added to the NEXT pass over the same graph.  x.grad of
+    a full backward after a partial one == x.grad of a fresh full backward, bit for bit; also after a pass that raised midway."""
+    vag = vkn.autograd
+    g = torch.Generator(device='cpu').manual_seed(8)
+    B, N, C, H, W = 2, 15, 64, 8, 16
+    x0 = torch.randn(B, C, H, W, generator=g).to(DEV)
+    k0 = torch.randn(B, N, C, generator=g).to(DEV)
+    m = torch.randn(B, N, H, W, generator=g).to(DEV)
+    gz, gx = torch.randn(B, N, H, W, generator=g).to(DEV) * 1e-3, torch.randn(B, N, C, generator=g).to(DEV) * 1e-2
+
+    class Boom(torch.autograd.Function):
+        armed = False
+
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, gt):
+            if Boom.armed:
+                raise RuntimeError('boom')
+            return gt
+
+    def graph():
+        x = x0.clone().requires_grad_(True)
+        k = k0.clone().requires_grad_(True)
+        xs = vag.x_hub(x)
+        z1 = vag.mask_decode(xs, k)
+        xr, _ = vag.mask_gather(xs, m, 0.5)
+        loss = (z1 * gz).sum() + (xr * gx).sum() + (Boom.apply(xs) * xs).sum() * 1e-3
+        return x, k, loss
+
+    x, k, loss = graph()
+    loss.backward()
+    want = x.grad.clone()
+    x, k, loss = graph()
+    (gk,) = torch.autograd.grad(loss, [k], retain_graph=True)          # partial pass: the hub's node never runs
+    assert x.grad is None and gk is not None
+    loss.backward(retain_graph=True)
+    assert torch.equal(x.grad, want), 'stale parts of the partial pass were added to the full pass'
+    x.grad = None
+    Boom.armed = True
+    with pytest.raises(RuntimeError, match='boom'):
+        loss.backward(retain_graph=True)                                # a pass that dies between a consumer and the hub
+    Boom.armed = False
+    x.grad = None
+    loss.backward()
+    assert torch.equal(x.grad, want)
 
 
 @pytest.mark.parametrize('variant', ['no_stuff_targets', 'pos_weight_stage_weights', 'no_rank_loss', 'one_frame'])

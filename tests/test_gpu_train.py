@@ -79,12 +79,10 @@ def _check_grad(g, tag, got, tol=2e-3):
         assert abs(float(got.double().norm()) - float(g[tag + '_norm'])) < tol * float(g[tag + '_norm']), tag
 
 
-@pytest.mark.parametrize('name', ['train_tiny', 'train_video', 'train_video_upd', 'train_cfg'])
-def test_forward_train_vs_reference_golden(vkn, name):
-    """Losses (every `s{stage}_*` key), per-stage assignments and gradients vs the reference's forward_train."""
+def _forward_train_vs_golden(vkn, name, graphs=False, steps=1):
+    """One (or `steps`) training step(s) of the head under its DEFAULT policy (fused loss tail, device chain; `graphs`: the chains as
+    captured hipGraphs, the first step captures and the later ones replay) against the golden `name`."""
     g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, name)
-    xd = x.to(DEV).requires_grad_(True)
-    pfd = pf.to(DEV).requires_grad_(True)
     metas = [dict() for _ in range(case['B'])]
     # record the assignments
     assigned = []
@@ -104,36 +102,73 @@ def test_forward_train_vs_reference_golden(vkn, name):
                 assigned.extend(r.gt_inds.clone() for r in rs)
             return rs
         a.assign_batch = recb
-    track = None
-    if case['video']:
-        out = head.forward_train_with_previous(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
-                                               gt_sem_cls=gt_sem_cls, previous_obj_feats=prev.to(DEV))
-        losses, track = out[0], out[5]
-    else:
-        losses = head.forward_train(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
-                                    gt_sem_cls=gt_sem_cls)
-    assert sorted(losses) == list(g['loss_keys'])
-    assert np.array_equal(torch.stack(assigned).cpu().numpy(), g['assigned']), 'Hungarian assignments must be bit-exact'
-    for k, ref in zip(g['loss_keys'], g['loss_vals']):
-        assert abs(float(losses[k]) - ref) < 1e-4 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
-    total = sum(v for k, v in losses.items() if 'loss' in k)
-    if track is not None:
-        assert maxabs(track, g['track']) < 1e-3
-        total = total + 0.01 * (track ** 2).sum()
-    assert abs(float(total) - float(g['total'])) < 1e-4 * abs(float(g['total']))
-    total.backward()
-    _check_grad(g, 'grad_x', xd.grad)
-    _check_grad(g, 'grad_pf', pfd.grad)
-    named = dict(head.named_parameters())
-    for i, k in enumerate(g['grad_keys']):
-        _check_grad(g, f'grad_{i}', named[str(k)].grad)
-    # every parameter received a gradient of the reference's norm
-    for k, ref in zip(g['all_keys'], g['all_gnorm']):
-        p = named[str(k)]
-        if ref < 0:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+    if graphs:
+        head.enable_chain_graphs()
+    for step in range(steps):
+        del assigned[:]
+        for p in head.parameters():
+            p.grad = None
+        xd = x.to(DEV).requires_grad_(True)
+        pfd = pf.to(DEV).requires_grad_(True)
+        track = None
+        if case['video']:
+            out = head.forward_train_with_previous(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                                   gt_sem_cls=gt_sem_cls, previous_obj_feats=prev.to(DEV))
+            losses, track = out[0], out[5]
         else:
-            assert p.grad is not None and abs(float(p.grad.double().norm()) - ref) < 5e-3 * max(ref, 1e-6), (k, ref)
+            losses = head.forward_train(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                        gt_sem_cls=gt_sem_cls)
+        assert sorted(losses) == list(g['loss_keys'])
+        assert np.array_equal(torch.stack(assigned).cpu().numpy(), g['assigned']), 'Hungarian assignments must be bit-exact'
+        for k, ref in zip(g['loss_keys'], g['loss_vals']):
+            assert abs(float(losses[k]) - ref) < 1e-4 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
+        total = sum(v for k, v in losses.items() if 'loss' in k)
+        if track is not None:
+            assert maxabs(track, g['track']) < 1e-3
+            total = total + 0.01 * (track ** 2).sum()
+        assert abs(float(total) - float(g['total'])) < 1e-4 * abs(float(g['total']))
+        total.backward()
+        _check_grad(g, 'grad_x', xd.grad)
+        _check_grad(g, 'grad_pf', pfd.grad)
+        named = dict(head.named_parameters())
+        for i, k in enumerate(g['grad_keys']):
+            _check_grad(g, f'grad_{i}', named[str(k)].grad)
+        # every parameter received a gradient of the reference's norm
+        for k, ref in zip(g['all_keys'], g['all_gnorm']):
+            p = named[str(k)]
+            if ref < 0:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            else:
+                assert p.grad is not None and abs(float(p.grad.double().norm()) - ref) < 5e-3 * max(ref, 1e-6), (k, ref)
+    if graphs:
+        assert all(len(h._chain_graphs) >= 1 for h in head.mask_head)
+        head.enable_chain_graphs(False)
+    return head
+
+
+@pytest.mark.parametrize('name', ['train_tiny', 'train_video', 'train_video_upd', 'train_cfg', 'train_video_c256'])
+def test_forward_train_vs_reference_golden(vkn, name):
+    """Losses (every `s{stage}_*` key), per-stage assignments and gradients vs the reference's forward_train
+    (knet/det/kernel_iter_head.py:139-231, knet/video/kernel_iter_head.py:255-376, knet/det/kernel_update_head.py:279-441); the head
+    runs its default policy: the fused loss tail (train_tail.py) and the device chain."""
+    head = _forward_train_vs_golden(vkn, name)
+    if name != 'train_video_upd':          # (the previous_link heads run the op-by-op tail)
+        assert head._last_tail_fused, 'the default policy must have taken the fused loss tail'
+
+
+CFG3_GOLDEN = 'train_video_cfg3'   # bench.py --train prints this name as its parity witness
+
+
+@pytest.mark.parametrize('graphs', [False, True], ids=['eager_chain', 'hipgraph_chain'])
+def test_forward_train_at_the_benchmarked_cfg3_size_vs_reference_golden(vkn, graphs):
+    """the training step AT THE SIZE `bench.py --train` TIMES — video head, C = 256, N = 100 + 17, 128x256 features,
+    x4 (512x1024 loss masks: mask_upsample_stride=4 of the shipped KITTI-STEP video config), two frames, ffn link — against the
+    reference's own `forward_train_with_previous` run on the CPU (oracle/gen_golden.py `train_video_cfg3`): every loss 1e-4 relative,
+    the Hungarian assignments of every stage bit-exact, gradients w.r.t. x / the kernels / a sample of the parameters 2e-3 of their
+    maximum (4096 sampled elements + the norm), every parameter's gradient norm.  `hipgraph_chain`: the policy bench.py runs (chains
+    captured as hipGraphs) — capture step and two replays."""
+    head = _forward_train_vs_golden(vkn, CFG3_GOLDEN, graphs=graphs, steps=3 if graphs else 1)
+    assert head._last_tail_fused
 
 
 @pytest.mark.parametrize('name', ['train_tiny', 'train_video_upd'])

@@ -58,10 +58,37 @@ def _decode_unscaled(x, kernels, inv):
 
 
 class _XHub:
-    """Collects the feature map's gradient contributions of one training step (see `x_hub`)."""
+    """Collects the feature map's gradient contributions of ONE backward pass (see `x_hub`).  A pass that never reaches the hub's
+    node — `torch.autograd.grad(loss, head_params, retain_graph=True)`, `backward(inputs=...)`, an exception between a consumer and the
+    hub — must not leave its parts behind for the next pass over the same graph to add again: the first part parked in a pass queues
+    an end-of-backward callback on the engine that drops whatever the hub's node did not take."""
 
     def __init__(self):
         self.parts = []
+        self.task = None          # the engine's id of the backward pass the parked parts belong to
+        self._cb_queued = False
+
+    def _enter(self):
+        """parts of another pass (one that raised before its end-of-backward callbacks ran) are dropped on first touch"""
+        task = torch._C._current_graph_task_id()
+        if task != self.task:
+            self.parts, self.task, self._cb_queued = [], task, False
+
+    def park(self, dx):
+        self._enter()
+        if not self._cb_queued:
+            self._cb_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        self.parts.append(dx)
+
+    def take(self):
+        self._enter()
+        parts, self.parts = self.parts, []
+        return parts
+
+    def _end_of_backward(self):
+        self._cb_queued = False
+        self.parts, self.task = [], None
 
 
 class XHubFn(torch.autograd.Function):
@@ -73,7 +100,7 @@ class XHubFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        parts, ctx.hub.parts = ctx.hub.parts, []
+        parts = ctx.hub.take()
         if g is not None:
             parts.append(g)
         return (ops.sum_tensors(parts) if parts else None), None
@@ -136,7 +163,7 @@ class MaskGatherFn(torch.autograd.Function):
         dx = _decode_unscaled(rows, kt, ops.inv_of(s8))
         dx = dx if ctx.x_dtype == torch.float32 else dx.to(ctx.x_dtype)
         if ctx.hub is not None:           # (x_hub: the contribution is summed with the others in one pass)
-            ctx.hub.parts.append(dx)
+            ctx.hub.park(dx)
             dx = None
         return dx, None, None, None
 
@@ -212,7 +239,7 @@ class MaskDecodeFn(torch.autograd.Function):
             # the padded rows are zero, so the gather may run over them too; 1 / s and the slice in one launch
             dk, dkb = ops.unscale_rows(*ops.mask_gather_real(x, dzs), inv, N)
         if ctx.hub is not None and dx is not None:
-            ctx.hub.parts.append(dx)
+            ctx.hub.park(dx)
             dx = None
         return dx, dk if ctx.needs_input_grad[1] else None, dkb if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None
 

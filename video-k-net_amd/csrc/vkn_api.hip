@@ -436,7 +436,7 @@ int run_chain_fast(const VknDims* d, const VknStageWeights* w, const PrepW& pw, 
         a.off_in = pw_off(w, pw.attn_in);
     }
     a.consts = pw.chain_consts;
-    a.eps = d->ln_eps; a.M = M; a.obj1 = s.obj1; a.qkv = s.qkv;
+    a.eps = d->ln_eps; a.M = M; a.obj1 = s.obj1; a.qkv = s.qkv; a.status = s.status;
     VKN_TRY(h2 ? vkn_launch_chain_a_h2(a, st) : vkn_launch_chain_a(a, st));
     VKN_TRY(vkn_launch_attn(s.qkv, 3 * C, s.qkv + C, s.qkv + 2 * C, 3 * C, s.ao, C, d->B, d->N, d->N, d->heads, C / d->heads, st));
     VknChainC c{};
@@ -455,7 +455,7 @@ int run_chain_fast(const VknDims* d, const VknStageWeights* w, const PrepW& pw, 
     c.obj_out = obj_out; c.cls_out = (w->fc_cls_w && cls_logits) ? cls_logits : nullptr; c.kb_out = s.kb;
     if (kern32_out) c.kern_out = kern32_out;
     else { c.plane_hi = s.kfh; c.plane_lo = s.kfl; }
-    c.rows_per_frame = d->N; c.NPT = npt_of(d->N);
+    c.rows_per_frame = d->N; c.NPT = npt_of(d->N); c.status = s.status;
     return h2 ? vkn_launch_chain_c_h2(c, st) : vkn_launch_chain_c(c, st);
 }
 

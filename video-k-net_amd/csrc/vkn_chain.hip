@@ -101,6 +101,7 @@ struct ChLane {
     unsigned woff;   // byte offset of this lane's fragment inside a weight tile image: plane 0, ks 0
     unsigned abase;  // byte offset of this lane's activation fragment inside an image plane for chunk pair 0: row li, 16-byte chunk
                      // (g ^ li); the fragment of (kt, ks) is at abase ^ ((4 kt + 2 ks) << 4) — the swizzle is an XOR of chunk bits
+    int* status;     // two-term fp16 form: where ch_img_write reports an activation outside the fp16 envelope (or NULL)
 };
 __device__ __forceinline__ ChLane ch_lane(int tid) {
     ChLane L;
@@ -110,6 +111,7 @@ __device__ __forceinline__ ChLane ch_lane(int tid) {
     L.li = lane & 31;
     L.woff = (unsigned)(L.g * 4096 + (L.wave * 32 + L.li) * 16);
     L.abase = (unsigned)(L.li * (CH_C * 2) + (((L.g ^ L.li) & 31) << 4));
+    L.status = nullptr;
     return L;
 }
 
@@ -331,6 +333,19 @@ __device__ __forceinline__ void ch_layernorm(float (&v)[NV][16], const float* co
 
 // registers (transposed tile) -> image: 8-byte packed stores, chunk (wave * 4 + q) of row li, half g
 __device__ __forceinline__ void ch_img_write(ch_e* img, const float (&v)[16], const ChLane& L) {
+#ifdef CH_H2
+    {   // the images written here travel UNSCALED (LayerNorm outputs, ReLU / FFN hidden rows, branch inputs: O(1) for ordinary weights);
+        // a value of 2^15 or more — large LayerNorm gains, a fine-tuned W1 — is one binade from fp16's inf: reported through the status
+        // word instead of silently becoming NaN (the bf16x3 form, VKN_FLAG_CHAIN_BF16X3, has fp32 range).  NaN compares false: !(m < 2^15)
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(v[r]));
+        bool bad = !(m < 32768.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bad |= (v[r] != v[r]);
+        if (bad && L.status) atomicOr(L.status, VKN_STATUS_RANGE);
+    }
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float t[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
@@ -482,6 +497,7 @@ struct ChainAArgs {
     float* obj1;  // [M][256] out: updated kernels (residual of the attention block)
     float* qkv;   // [M][768] out: packed q | k | v
     const float* consts;   // [CA_TOTAL] packed block (vkn_chain_pack_consts)
+    int* status;
 };
 
 template <int ABL>
@@ -497,7 +513,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_a(const ChainAArgs A) {
 #endif
 
     const int tid = threadIdx.x;
-    const ChLane L = ch_lane(tid);
+    ChLane L_ = ch_lane(tid);
+    L_.status = A.status;
+    const ChLane L = L_;
     const int m0 = blockIdx.x * CH_ROWS, M = A.M;
     const int row = m0 + L.li;
     const bool row_ok = row < M;
@@ -674,6 +692,7 @@ struct ChainCArgs {
     float* kern_out;     // ... fp32 [M][256]
     int rows_per_frame, NPT;
     const float* consts;   // [CC_TOTAL] packed block
+    int* status;
 };
 
 template <int ABL>
@@ -688,7 +707,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_c(const ChainCArgs A) {
 #endif
 
     const int tid = threadIdx.x;
-    const ChLane L = ch_lane(tid);
+    ChLane L_ = ch_lane(tid);
+    L_.status = A.status;
+    const ChLane L = L_;
     const int m0 = blockIdx.x * CH_ROWS, M = A.M;
     const int row = m0 + L.li;
     const bool row_ok = row < M;
@@ -1186,6 +1207,7 @@ int vkn_launch_chain_a(const VknChainA& p, hipStream_t stream) {
     A.off_dyn = p.off_dyn; A.off_inp = p.off_inp; A.off_ig = p.off_ig; A.off_ug = p.off_ug; A.off_fc = p.off_fc; A.off_in = p.off_in;
     A.eps = p.eps; A.M = p.M; A.obj1 = p.obj1; A.qkv = p.qkv;
     A.consts = p.consts + (p.rowscale ? 0 : CA_TOTAL);
+    A.status = p.status;
 #ifdef CH_H2
     const size_t lds = (size_t)2 * CH_IMG * sizeof(ch_e) + (size_t)(2 * CH_SBUF + CA_TOTAL + 16 * CH_THREADS + 64 + 512) * sizeof(float);
 #else
@@ -1231,6 +1253,7 @@ int vkn_launch_chain_c(const VknChainC& p, hipStream_t stream) {
     A.eps = p.eps; A.M = p.M; A.kb0 = p.kb0; A.obj_out = p.obj_out; A.cls_out = p.cls_out; A.kb_out = p.kb_out;
     A.plane_hi = p.plane_hi; A.plane_lo = p.plane_lo; A.kern_out = p.kern_out; A.rows_per_frame = p.rows_per_frame; A.NPT = p.NPT;
     A.consts = p.consts + 2 * CA_TOTAL;
+    A.status = p.status;
 #ifdef CH_H2
     const size_t lds = (size_t)2 * CH_IMG * sizeof(ch_e) + (size_t)(2 * CH_SBUF + CC_TOTAL + 32) * sizeof(float);
 #else

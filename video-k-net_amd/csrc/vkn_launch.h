@@ -144,6 +144,8 @@ struct VknChainA {   // KernelUpdator + attention in_proj
     int M;
     float* obj1;  // [M][256]
     float* qkv;   // [M][768]
+    int* status;  // the workspace's status word or NULL: the two-term fp16 form ORs VKN_STATUS_RANGE in when an unscaled activation image
+                  // (LayerNorm outputs, FFN hidden rows, branch inputs) holds |v| >= 2^15 — one binade below where fp16 turns it into inf
 };
 struct VknChainC {   // attention out_proj + LN, FFN + LN, cls / mask FCs, fc_cls, folded decode kernels
     const float* ao;      // [M][256]
@@ -162,6 +164,7 @@ struct VknChainC {   // attention out_proj + LN, FFN + LN, cls / mask FCs, fc_cl
     _Float16 *plane_hi, *plane_lo;   // f16 planes [B][NPT][256] ...
     float* kern_out;                 // ... or fp32 [M][256] (exactly one of the two forms)
     int rows_per_frame, NPT;
+    int* status;                     // as VknChainA::status
 };
 // one GEMM (or two grouped ones) per launch on the chain kernels' register-streaming engine: K == 256, pre-split weights, no split-K
 // (vkn_chain.hip: k_gemm_t3); VKN_E_SHAPE = not applicable, take k_gemm_s3

@@ -373,6 +373,10 @@ __global__ __launch_bounds__(256) void k_stage_targets(const TailBatch batch, in
         for (int i = 0; i < im.n_sem; ++i) {
             const long long ci = im.sem_cls[i];
             rank += (ci < c || (ci == c && i < j)) ? 1 : 0;
+            // a class listed twice: the reference keeps the LAST mask and counts the class once (sem_targets[sem_inds] = gt_sem_seg,
+            // knet/det/kernel_update_head.py:372-378) — the caller's positive count (k + n_sem, known from shapes) would be one too
+            // many and two threads would write one row: reported like an out-of-range class instead of computed wrongly
+            if (ci == c && i != j) bad |= 1;
         }
         if (c < T || c >= T + S) { bad |= 1; c = T; }   // out of range: a valid dummy row, reported through `status`
         const size_t row = base + N + (int)(c - T);

@@ -220,6 +220,7 @@ class KernelIterHead(BaseRoIHead):
         tail = TailStep.begin(self, x.device, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls)
         if tail is not None:
             gt_masks = tail.gt_views
+        self._last_tail_fused = tail is not None     # (tests / bench: did the step's EVERY stage run the fused tail?)
         if self.mask_assigner and hasattr(self.mask_assigner[0], 'validate_labels'):
             # the labels do not change between stages: one range check for the whole step (on the device, reported asynchronously)
             if tail is not None:
@@ -241,6 +242,7 @@ class KernelIterHead(BaseRoIHead):
                     and tail.stage_ok(head, assign_results, cls_score, scaled_mask_preds):
                 stage_losses = tail.stage_losses(head, self.train_cfg[stage], assign_results, cls_score, scaled_mask_preds)
             if stage_losses is None:
+                self._last_tail_fused = False
                 sampler = self.mask_sampler[stage]
                 sampling_results = [sampler.sample(assign_results[i], scaled_mask_preds[i], gt_masks[i]) for i in range(num_imgs)]
                 mask_targets = head.get_targets(sampling_results, gt_masks, gt_labels, self.train_cfg[stage], True,

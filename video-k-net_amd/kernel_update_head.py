@@ -19,6 +19,25 @@ from .losses import accuracy, reduce_mean
 from .registry import build_loss, build_transformer_layer, register_head
 
 
+def _updator_torch(ku, update_feature, input_feature):
+    """The adaptive kernel update on torch ops — only for `_chain_autograd` (the A/B arm of the device chain and the fallback for shapes
+    the library's training kernels decline, `chain_train.supported`) and the CPU-side tests of the gradient reducer.  Laid out the way
+    `chain_train.UpdatorCoreFn` launches it: the dynamic / input projections [rows, 2C] = (gate half | value half), BOTH gate layers
+    as one GEMM on the stacked weights, then the gated mix and the output projection.  [M, C] (or [B, N, C]) x [M, K*K, C] -> [M, K*K, C]."""
+    F = torch.nn.functional
+    C = ku.feat_channels
+    u = update_feature.reshape(-1, ku.in_channels)
+    M = u.shape[0]
+    dyn = F.linear(u, ku.dynamic_layer.weight, ku.dynamic_layer.bias).unsqueeze(1)                       # [M, 1, 2C]
+    inp = F.linear(input_feature.reshape(M, -1, C), ku.input_layer.weight, ku.input_layer.bias)          # [M, K*K, 2C]
+    gates = F.linear(inp[..., :C] * dyn[..., :C], torch.cat([ku.input_gate.weight, ku.update_gate.weight]),
+                     torch.cat([ku.input_gate.bias, ku.update_gate.bias]))                               # [M, K*K, 2C]
+    keep_input = torch.sigmoid(ku.input_norm_in(gates[..., :C]))
+    take_update = torch.sigmoid(ku.norm_in(gates[..., C:]))
+    mixed = take_update * ku.norm_out(dyn[..., C:]) + keep_input * ku.input_norm_out(inp[..., C:])
+    return torch.relu(ku.fc_norm(ku.fc_layer(mixed)))
+
+
 class _MHAParams(nn.Module):
     """mmcv `MultiheadAttention(embed_dims, num_heads, attn_drop)` as a parameter container: `.attn` is a real
     `nn.MultiheadAttention` so parameter names, shapes and default init are torch's own."""
@@ -375,7 +394,7 @@ class KernelUpdateHead(nn.Module):
         if previous_obj_feats is not None and getattr(self, 'previous_link', None) is not None:         # video :324-372
             pf = self._link_autograd(self._link_names('link'), x_feat, pf.reshape(B, N, C), previous_obj_feats,
                                      self.training and self.previous_detach_link).reshape(B, N, -1, C)
-        obj_feat = self.kernel_update_conv.forward_autograd(x_feat, pf)                                 # :200
+        obj_feat = _updator_torch(self.kernel_update_conv, x_feat, pf)                                 # :200
         obj_feat = obj_feat.reshape(B, N, -1).permute(1, 0, 2)                                          # :203-205
         obj_feat = self.attention_norm(self._mha(self.attention, obj_feat))                             # :206
         obj_feat = obj_feat.permute(1, 0, 2).reshape(B, N, -1, C)                                       # :208-211
@@ -522,7 +541,7 @@ class KernelUpdateHead(nn.Module):
         if detach_prev:
             prev = prev.detach()
         if upd is not None:
-            prev = upd.forward_autograd(update_feature, prev.reshape(B, N, 1, C)).reshape(B, N, C)
+            prev = _updator_torch(upd, update_feature, prev.reshape(B, N, 1, C)).reshape(B, N, C)
         q = cur.permute(1, 0, 2)
         t = norm(self._mha(att, q, prev.permute(1, 0, 2), q)).permute(1, 0, 2)
         return ffn_norm(t + ffn.layers(t))
@@ -649,11 +668,12 @@ class KernelUpdateHead(nn.Module):
 
     def _fused_mask_losses_ok(self, mask_pred, reduction_override):
         from . import losses as L
+        from .train_tail import _is_sigmoid_dice
         lm, ld, lr = self.loss_mask, self.loss_dice, self.loss_rank
         return (self.fused_mask_losses and reduction_override is None and mask_pred.is_cuda and mask_pred.dtype == torch.float32
                 and (mask_pred.shape[-1] * mask_pred.shape[-2]) % 4 == 0 and mask_pred.dim() == 4
                 and type(lm) is L.CrossEntropyLoss and lm.use_sigmoid and lm.reduction == 'mean' and lm.class_weight is None
-                and type(ld) is L.DiceLoss and ld.use_sigmoid and ld.activate and ld.reduction == 'mean'
+                and _is_sigmoid_dice(ld)        # (ours or mmdet's own class: checked by value, train_tail.py)
                 and (lr is None or (type(lr) is L.CrossEntropyLoss and not lr.use_sigmoid and not lr.use_mask and lr.reduction == 'mean'
                                     and lr.class_weight is None)))
 

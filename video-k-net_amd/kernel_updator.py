@@ -53,38 +53,19 @@ class KernelUpdator(nn.Module):
         self.fc_layer = nn.Linear(Cf, self.out_channels, 1)
         self.fc_norm = nn.LayerNorm(self.out_channels)
 
-    def forward_autograd(self, update_feature, input_feature):
-        """The same arithmetic as plain torch ops on this module's own Linear / LayerNorm parameters — the differentiable
-        path of a standalone updator in training and the A/B / test oracle of `chain_train.kernel_updator`, which is what a training head
-        runs (knet/kernel_updator.py:56-93 line by line; rocBLAS GEMMs on [B*N, C] rows)."""
-        C = self.in_channels
-        u = update_feature.reshape(-1, C)
-        num = u.size(0)
-        parameters = self.dynamic_layer(u)
-        param_in = parameters[:, :self.num_params_in].view(-1, self.feat_channels)
-        param_out = parameters[:, -self.num_params_out:].view(-1, self.feat_channels)
-        input_feats = self.input_layer(input_feature.reshape(num, -1, self.feat_channels))
-        input_in = input_feats[..., :self.num_params_in]
-        input_out = input_feats[..., -self.num_params_out:]
-        gate_feats = input_in * param_in.unsqueeze(-2)
-        input_gate = self.input_norm_in(self.input_gate(gate_feats)).sigmoid()
-        update_gate = self.norm_in(self.update_gate(gate_feats)).sigmoid()
-        param_out = self.norm_out(param_out)
-        input_out = self.input_norm_out(input_out)
-        features = update_gate * param_out.unsqueeze(-2) + input_gate * input_out
-        return torch.relu(self.fc_norm(self.fc_layer(features)))
-
     def forward(self, update_feature, input_feature):
         """update_feature [B,N,C] (or [B*N,C]); input_feature [B,N,K*K=1,C] -> [B*N, 1, C]  (reference :56-93)."""
-        if torch.is_grad_enabled() and (update_feature.requires_grad or input_feature.requires_grad
-                                        or any(p.requires_grad for p in self.parameters())):
-            return self.forward_autograd(update_feature, input_feature)
         C = self.in_channels
         u = update_feature.reshape(-1, C)
         M = u.shape[0]
         k = input_feature.reshape(M, -1, C)
         if k.shape[1] != 1:
             raise NotImplementedError('conv_kernel_size != 1 is not built (no shipped config uses it)')
+        if torch.is_grad_enabled() and (update_feature.requires_grad or input_feature.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            # differentiable: the library's own kernels in both directions (chain_train.py: LinearFn / UpdatorCoreFn / LayerNormActFn)
+            from . import chain_train
+            return chain_train.kernel_updator(self, ops._req(u, 'update_feature'), ops._req(k.reshape(M, C), 'input_feature')).reshape(M, 1, C)
         u, k = ops._req(u, 'update_feature'), ops._req(k.reshape(M, C), 'input_feature')
         named = {'kernel_update_conv.' + n: p for n, p in self.named_parameters()}
         pack = ops.StagePack(named, u.device)

@@ -23,14 +23,45 @@ from ._lib import check
 from .ops import _ptr, _req, _stream
 
 
+def _is_sigmoid_focal(lc):
+    """A sigmoid focal loss with mean reduction, checked BY VALUE: this package's `losses.FocalLoss` (with its fused kernel on) or
+    mmdet's own `FocalLoss` — under real mmdet the registry keeps mmdet's class (registry.py), and the tail computes the same formula
+    (mmdet/models/losses/focal_loss.py: py_sigmoid_focal_loss + weight_reduce_loss) from gamma / alpha / loss_weight."""
+    from . import losses as L
+    if type(lc) is L.FocalLoss:
+        ours = True
+    else:
+        ours = False
+        if type(lc).__name__ != 'FocalLoss' or not type(lc).__module__.startswith('mmdet.'):
+            return False
+    try:
+        ok = (lc.use_sigmoid is True and lc.reduction == 'mean' and not getattr(lc, 'activated', False)
+              and float(lc.gamma) >= 0.0 and 0.0 <= float(lc.alpha) <= 1.0 and float(lc.loss_weight) == float(lc.loss_weight))
+    except (AttributeError, TypeError, ValueError):
+        return False
+    return ok and (lc.fused if ours else True)
+
+
+def _is_sigmoid_dice(ld):
+    """`DiceLoss(use_sigmoid=True, activate=True, reduction='mean')` — ours or mmdet's (not its later `naive_dice` variant)."""
+    from . import losses as L
+    if type(ld) is not L.DiceLoss and not (type(ld).__name__ == 'DiceLoss' and type(ld).__module__.startswith('mmdet.')):
+        return False
+    try:
+        return bool(ld.use_sigmoid and ld.activate and ld.reduction == 'mean' and not getattr(ld, 'naive_dice', False)
+                    and float(ld.eps) > 0.0 and float(ld.loss_weight) == float(ld.loss_weight))
+    except (AttributeError, TypeError, ValueError):
+        return False
+
+
 def _shipped_losses(head):
     """the loss objects the fused tail restates: FocalLoss(sigmoid, mean) + the three mask losses of `_fused_mask_losses_ok`"""
     from . import losses as L
     lc, lm, ld, lr = head.loss_cls, head.loss_mask, head.loss_dice, head.loss_rank
     return (getattr(head, 'fused_mask_losses', False) and getattr(head, 'fused_tail', True)
-            and type(lc) is L.FocalLoss and lc.fused and lc.use_sigmoid and lc.reduction == 'mean'
+            and _is_sigmoid_focal(lc)
             and type(lm) is L.CrossEntropyLoss and lm.use_sigmoid and lm.reduction == 'mean' and lm.class_weight is None
-            and type(ld) is L.DiceLoss and ld.use_sigmoid and ld.activate and ld.reduction == 'mean'
+            and _is_sigmoid_dice(ld)
             and (lr is None or (type(lr) is L.CrossEntropyLoss and not lr.use_sigmoid and not lr.use_mask and lr.reduction == 'mean'
                                 and lr.class_weight is None)))
 
@@ -66,6 +97,11 @@ class TailStep:
                 if not torch.is_tensor(g) or not torch.is_tensor(c) or c.numel() > 0 and (g.dim() != 3 or tuple(g.shape[1:]) != shape
                                                                                          or g.shape[0] != c.numel() or g.device != device):
                     return None
+        if with_sem:
+            # more stuff targets than stuff kernels cannot be distinct classes: the op-by-op path handles (and the reference defines) that
+            n_stuff = max((getattr(h, 'num_stuff_classes', 0) for h in iter_head.mask_head), default=0)
+            if any(c.numel() > n_stuff for c in gt_sem_cls):
+                return None
         return cls(device, gt_masks, gt_labels, gt_sem_seg if with_sem else None, gt_sem_cls if with_sem else None)
 
     def __init__(self, device, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls):
@@ -92,7 +128,7 @@ class TailStep:
         as_i64 = lambda t: t.to(device=device, dtype=torch.int64).contiguous().reshape(-1)  # noqa: E731  (no-op for device int64)
         self.labels = [as_i64(l) for l in gt_labels]
         self.sem_cls = [as_i64(c) if self.n_sem[b] else None for b, c in enumerate(gt_sem_cls)] if self.with_sem else [None] * self.B
-        self.status = torch.zeros(1, dtype=torch.int32, device=device)    # bit 0: a stuff class out of range (vkn_stage_targets), bit 1: a thing label (validate_labels)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)    # bit 0: a stuff class out of range or listed twice (vkn_stage_targets), bit 1: a thing label (validate_labels)
 
     def stage_ok(self, head, assign_results, cls_score, scaled):
         return (cls_score is not None and cls_score.dtype == torch.float32 and scaled.is_cuda and scaled.dtype == torch.float32
@@ -150,7 +186,7 @@ class TailStep:
     def finish(self):
         """hand the range-error word to the asynchronous flag queue (read without stalling: mask_hungarian_assigner.FLAGS)"""
         from .mask_hungarian_assigner import FLAGS
-        FLAGS.push(self.status, 'gt_labels outside [0, num_thing_classes) or gt_sem_cls outside [num_thing_classes, num_classes)')
+        FLAGS.push(self.status, 'gt_labels outside [0, num_thing_classes), or gt_sem_cls outside [num_thing_classes, num_classes) or listing a class twice')
 
 
 class _StageTargets:
