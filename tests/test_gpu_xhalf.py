@@ -240,13 +240,13 @@ def test_head_forward_with_fp16_scaled_output(vkn):
 
 
 @pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])
-def test_forward_train_on_half_storage_features(vkn, dt):
+def test_forward_train_on_half_storage_features(vkn, dt, name='train_cfg'):
     """the TRAINING path on fp16 / bf16 feature storage (BASELINE cfg2 words "bf16", cfg5 "fp16").  Same pin as the
     inference path: on x' = float(half(x)) the fp32 path returns the SAME losses bit for bit (its forward kernels are the half-storage
     kernels with the all-zero low-half terms), the parameter / kernel gradients are the same bits (dK runs on the widened x in both
     cases); x.grad arrives in x's storage type (each of the six contributions rounded once from its fp32 value)."""
     from test_gpu_train import _train_case
-    g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, 'train_cfg')
+    g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, name)
     assert (case['H'] * case['W']) % 64 == 0 and case['C'] in (64, 128, 256)
     metas = [dict() for _ in range(case['B'])]
     xh = _clamp_tiny(x).to(dt)                      # (bf16 -> f16 inside the kernels is exact in the normal f16 range)
@@ -256,8 +256,13 @@ def test_forward_train_on_half_storage_features(vkn, dt):
         pfd = pf.to(DEV).requires_grad_(True)
         for p in head.parameters():
             p.grad = None
-        losses = head.forward_train(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
-        total = sum(v for k, v in losses.items() if 'loss' in k)
+        if case['video']:
+            out = head.forward_train_with_previous(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                                   gt_sem_cls=gt_sem_cls, previous_obj_feats=prev.to(DEV))
+            losses, extra = out[0], 0.01 * (out[5] ** 2).sum()
+        else:
+            losses, extra = head.forward_train(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls), 0.0
+        total = sum(v for k, v in losses.items() if 'loss' in k) + extra
         total.backward()
         return ({k: float(v) for k, v in losses.items()}, xd.grad.clone(), pfd.grad.clone(),
                 {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None})
@@ -271,3 +276,11 @@ def test_forward_train_on_half_storage_features(vkn, dt):
     assert gx16.dtype == dt and float((gx16.float() - gx32).abs().max()) <= 6 * eps * float(gx32.abs().max())
     assert torch.equal(gpf16, gpf32)
     assert gp16.keys() == gp32.keys() and all(torch.equal(gp16[k], gp32[k]) for k in gp16)
+
+
+def test_forward_train_on_fp16_storage_at_the_benchmarked_cfg3_size(vkn):
+    """the cfg3-size training step (128x256 features, x4, C = 256, N = 117, video head — the golden
+    `train_video_cfg3`) with x STORED as fp16: same losses bit for bit and same parameter / kernel gradients bit for bit as the fp32 path on
+    the rounded x, x.grad in fp16 — the pin that carries the reference golden of the fp32 path over to half storage at this size."""
+    test_forward_train_on_half_storage_features(vkn, torch.float16, name='train_video_cfg3')
+
