@@ -1165,7 +1165,7 @@ size_t vkn_sizeof_panoptic_cfg(void) { return sizeof(VknPanopticCfg); }
 
 size_t vkn_panoptic_workspace_bytes(const VknPanopticCfg* cfg, int B, int N) {
     if (!cfg || B <= 0 || N <= 0 || cfg->num_proposals > N || cfg->max_per_img <= 0) return 0;
-    return vkn_panoptic_ws_bytes(B, cfg->max_per_img + (N - cfg->num_proposals));
+    return vkn_panoptic_ws_bytes(B, cfg->max_per_img + (N - cfg->num_proposals), cfg->Ho, cfg->Wo);
 }
 
 int vkn_panoptic_joint_f32(const VknPanopticCfg* cfg, const float* cls_prob, const float* mask_logits, int B, int N, int ncls,

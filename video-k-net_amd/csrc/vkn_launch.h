@@ -110,7 +110,7 @@ int vkn_launch_upsample(const float* in, float* out, int planes, int H, int W, i
 
 // post-head joint panoptic merge (vkn_panoptic.hip); VknPanopticCfg is declared in include/vkn.h
 struct VknPanopticCfg;
-size_t vkn_panoptic_ws_bytes(int B, int K);
+size_t vkn_panoptic_ws_bytes(int B, int K, int Ho, int Wo);
 int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const float* masks, int B, int N, int ncls,
                               int* panoptic_seg, int* info, int* nseg, int* bbox, void* ws, size_t ws_bytes, hipStream_t st);
 

@@ -26,7 +26,7 @@
 
 #define PAN_TW 64
 #define PAN_TH 16
-#define PAN_PPT (PAN_TH / 4)  // output pixels per thread: rows fy + 4*j
+#define PAN_PPT (PAN_TH / 4)  // output pixels per thread: rows fy * PAN_PPT + j of one column (adjacent rows share their input rows)
 #define PAN_THREADS 256
 #define PAN_KB 4
 
@@ -120,24 +120,111 @@ struct PanTab {  // per-level coefficient tables in LDS (local indices into the 
     float *lx, *ly;
 };
 
-// Workgroup = one 64x16 output tile of one frame (thread = 4 output pixels of one column).
-//  1. coefficient tables of every level for this tile, from the output back to the logits;
-//  2. the logits footprint of ALL K kernels -> LDS in one burst (one global-latency exposure per tile), and per kernel the
-//     footprint's max / min logit.  Bilinear resampling and the sigmoid are monotone convex combinations, so every output value
-//     of kernel k in this tile lies in [sigmoid(min_k), sigmoid(max_k)]:  k can neither win a pixel nor reach prob 0.5 here if
+// Input region of every level for one output tile, from the output back to the logits: a level's input region is spanned by the first
+// tap of the first output pixel and the second tap of the last one (the coordinate maps are monotone).  The SAME function gives
+// k_pan_bounds its footprints and k_pan_argmax its staging regions — the bounds cover exactly the logits the tile reads.
+struct PanRegion { int rx0[3], rw[3], ry0[3], rh[3]; };
+__device__ __forceinline__ void pan_region(const PanGeom& g, int X0, int tw, int Y0, int th, PanRegion& R) {
+    int ox0 = X0, ow = tw, oy0 = Y0, oh = th;
+#pragma unroll
+    for (int l = 2; l >= 0; --l) {
+        if (l >= g.nlev) continue;
+        int a0, a1, b0, b1;
+        float lam;
+        pan_coef(g.lv[l].sx, ox0, g.lv[l].in_w, a0, a1, lam);
+        pan_coef(g.lv[l].sx, ox0 + ow - 1, g.lv[l].in_w, b0, b1, lam);
+        R.rx0[l] = a0; R.rw[l] = b1 - a0 + 1;
+        pan_coef(g.lv[l].sy, oy0, g.lv[l].in_h, a0, a1, lam);
+        pan_coef(g.lv[l].sy, oy0 + oh - 1, g.lv[l].in_h, b0, b1, lam);
+        R.ry0[l] = a0; R.rh[l] = b1 - a0 + 1;
+        ox0 = R.rx0[l]; ow = R.rw[l]; oy0 = R.ry0[l]; oh = R.rh[l];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ footprint bounds (round 6)
+// bounds[b][ty][tx][k] = (min, max) of the logits of selected kernel k over the footprint of output tile (tx, ty): ONE coalesced pass
+// over the K selected planes (each row is read by the two or three tile rows whose footprints hold it: cache hits) instead of every
+// tile workgroup fetching the footprint of all K kernels (4.5x read over-fetch, eight dependent global round trips and a 55-element
+// serial min / max walk per kernel and tile: what made k_pan_argmax a 10 us-per-tile latency chain in round 5).
+// Workgroup = (PANB_KCH kernels) x (a strip of PANB_TR tile rows) x frame; thread = logit column: column-wise min / max over the tile
+// row's footprint rows -> LDS, then one (tile, kernel) pair per thread takes the min / max over the tile's footprint columns.
+#define PANB_KCH 4
+#define PANB_TR 8
+typedef float pan_f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_pan_bounds(PanGeom g, const float* __restrict__ masks, const int* __restrict__ sel_row, int K,
+                                                    int N, int ntx, int nty, pan_f2* __restrict__ bounds) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cmn = reinterpret_cast<float*>(smem);        // [PANB_KCH][Wm] column minima of the current tile row's footprint rows
+    float* cmx = cmn + PANB_KCH * g.Wm;                 // ... maxima
+    const int tid = threadIdx.x, b = blockIdx.z, k0 = blockIdx.x * PANB_KCH;
+    const size_t plane = (size_t)g.Hm * g.Wm;
+    const float* pl[PANB_KCH];
+#pragma unroll
+    for (int kk = 0; kk < PANB_KCH; ++kk)
+        pl[kk] = masks + ((size_t)b * N + sel_row[(size_t)b * K + min(k0 + kk, K - 1)]) * plane;
+    const int ty1 = min(nty, ((int)blockIdx.y + 1) * PANB_TR);
+    for (int ty = blockIdx.y * PANB_TR; ty < ty1; ++ty) {
+        const int Y0 = ty * PAN_TH, th = min(PAN_TH, g.Ho - Y0);
+        PanRegion R;
+        pan_region(g, 0, 1, Y0, th, R);   // (the row footprint does not depend on the tile column)
+        const int ry0 = R.ry0[0], lh = R.rh[0];
+        for (int x = tid; x < g.Wm; x += 256) {
+            float mn[PANB_KCH], mx[PANB_KCH];
+#pragma unroll
+            for (int kk = 0; kk < PANB_KCH; ++kk) { mn[kk] = INFINITY; mx[kk] = -INFINITY; }
+            for (int y8 = 0; y8 < lh; y8 += 8) {   // eight rows x PANB_KCH planes requested before the first use (rows past the footprint: its last row again)
+                float v[8][PANB_KCH];
+#pragma unroll
+                for (int yy = 0; yy < 8; ++yy) {
+                    const size_t o = (size_t)(ry0 + min(y8 + yy, lh - 1)) * g.Wm + x;
+#pragma unroll
+                    for (int kk = 0; kk < PANB_KCH; ++kk) v[yy][kk] = pl[kk][o];
+                }
+#pragma unroll
+                for (int yy = 0; yy < 8; ++yy)
+#pragma unroll
+                    for (int kk = 0; kk < PANB_KCH; ++kk) { mn[kk] = fminf(mn[kk], v[yy][kk]); mx[kk] = fmaxf(mx[kk], v[yy][kk]); }
+            }
+#pragma unroll
+            for (int kk = 0; kk < PANB_KCH; ++kk) { cmn[kk * g.Wm + x] = mn[kk]; cmx[kk * g.Wm + x] = mx[kk]; }
+        }
+        __syncthreads();
+        for (int i = tid; i < ntx * PANB_KCH; i += 256) {
+            const int kk = i & (PANB_KCH - 1), tx = i / PANB_KCH;
+            const int X0 = tx * PAN_TW, tw = min(PAN_TW, g.Wo - X0);
+            pan_region(g, X0, tw, Y0, th, R);
+            float mn = INFINITY, mx = -INFINITY;
+            for (int xx = 0; xx < R.rw[0]; ++xx) {
+                mn = fminf(mn, cmn[kk * g.Wm + R.rx0[0] + xx]);
+                mx = fmaxf(mx, cmx[kk * g.Wm + R.rx0[0] + xx]);
+            }
+            if (k0 + kk < K) bounds[(((size_t)b * nty + ty) * ntx + tx) * K + k0 + kk] = pan_f2{mn, mx};
+        }
+        __syncthreads();
+    }
+}
+
+// Workgroup = one PAN_TW x PAN_TH output tile of one frame (thread = PAN_PPT output pixels of one column).
+//  1. every thread derives the tile's level regions itself (pan_region: no serial section), the coefficient tables of every level are
+//     filled in one go — one barrier;
+//  2. thread k reads kernel k's footprint bounds (one coalesced load of the tile's K (min, max) pairs, k_pan_bounds).  Bilinear
+//     resampling and the sigmoid are monotone convex combinations, so every output value of kernel k in this tile lies in
+//     [sigmoid(min_k), sigmoid(max_k)]:  k can neither win a pixel nor reach prob 0.5 here if
 //         score_k * sigmoid(max_k) < LB := max_j score_j * sigmoid(min_j)   and   sigmoid(max_k) < 0.5
-//     (bounds padded by 1e-5 relative: fp32 rounding of the logits moves a probability by <= 2e-6 relative).  Only the surviving kernels — typically a handful per tile for real
-//     segmentation masks — are resampled; the result is identical to visiting all K;
-//  3. per batch of PAN_KB survivors: wave kk resamples kernel kk's footprint level by level through LDS; then every thread
+//     (bounds padded by 1e-5 relative: fp32 rounding of the logits moves a probability by <= 2e-6 relative).  Only the surviving
+//     kernels — typically a handful per tile for real segmentation masks — are staged and resampled; the result is identical to
+//     visiting all K;
+//  3. the survivors' logits footprints -> LDS, every load of a chunk of KC survivors in flight at once (one global round trip);
+//  4. per batch of PAN_KB survivors: wave kk resamples kernel kk's footprint level by level through LDS; then every thread
 //     evaluates the last level at its output pixels, keeps the running arg-max (strict >, ascending k: first maximum wins,
 //     as torch.argmax) and counts prob >= 0.5.
 __global__ __launch_bounds__(PAN_THREADS) void k_pan_argmax(PanGeom g, const float* __restrict__ masks,
                                                             const int* __restrict__ sel_row,
                                                             const float* __restrict__ sel_score, int K, int N,
                                                             int* __restrict__ ids, int* __restrict__ area,
-                                                            int* __restrict__ orig, int* __restrict__ err, int prune, int KC) {
+                                                            int* __restrict__ orig, int* __restrict__ err, int prune, int KC,
+                                                            const pan_f2* __restrict__ bounds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int rx0[3], ry0[3], rw[3], rh[3];  // input region of each level (absolute origin, extent)
     __shared__ int nact_s;
     __shared__ int lb_bits;
     const int tid = threadIdx.x, b = blockIdx.z, lane = tid & 63;
@@ -166,98 +253,76 @@ __global__ __launch_bounds__(PAN_THREADS) void k_pan_argmax(PanGeom g, const flo
     int* list = take_i(K);     // surviving kernels, ascending
     float* khi = take_f(K);    // score * sigmoid(max logit)  (padded up)
     float* kpm = take_f(K);    // sigmoid(max logit)          (padded up)
+    int* srow = take_i(K);     // mask row of kernel k   } read once per tile: the staging and the arg-max loops index them by survivor,
+    float* ssc = take_f(K);    // score of kernel k      } which from global memory were two more dependent round trips per tile
     const int ln = g.cap_w[0] * g.cap_h[0], lp = g.cap_w[0];
-    const int Lo = take_o(KC * ln);  // word offset of the logits footprints: of every kernel when KC == K, else of one chunk / one batch at a time
+    const int Lo = take_o(KC * ln);  // word offset of the logits footprints of one chunk of KC survivors
     float* const Ls = ldsf + Lo;
     const int b1o = take_o(PAN_KB * g.cap_w[1] * g.cap_h[1]);
     const int b2o = (nl == 3) ? take_o(PAN_KB * g.cap_w[2] * g.cap_h[2]) : 0;
 
     for (int i = tid; i < K; i += PAN_THREADS) { area_s[i] = 0; orig_s[i] = 0; }
+    if (tid == 0) lb_bits = 0;
+    // the tile's only independent global reads — kernel tid's footprint bounds, score and mask row — are requested first: their
+    // latency runs under the region / table arithmetic below
+    const int* rowp = sel_row + (size_t)b * K;
+    const float* scp = sel_score + (size_t)b * K;
+    const pan_f2* bt = bounds + (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * K;
+    const int kpre = min(tid, K - 1);
+    const pan_f2 bd_pre = bt[kpre];
+    const float s_pre = scp[kpre];
+    const int row_pre = rowp[kpre];
 
-    // ---- 1. coefficient tables, from the output tile back to the logits (once per tile)
+    // ---- 1. regions (registers, every thread) and coefficient tables (LDS, local indices) of every level
+    PanRegion R;
+    pan_region(g, X0, tw, Y0, th, R);
+    {
+        bool bad = false;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+            if (l < nl) bad |= (R.rw[l] + 1 > g.cap_w[l]) || (R.rh[l] + 1 > g.cap_h[l]);
+        if (bad) {   // capacity bug: reported through `err`, never silent (uniform over the workgroup)
+            if (tid == 0) atomicExch(err, 1);
+            return;
+        }
+    }
 #pragma unroll
     for (int l = 2; l >= 0; --l) {
         if (l >= nl) continue;
-        const int ox0 = (l == nl - 1) ? X0 : rx0[l + 1], oy0 = (l == nl - 1) ? Y0 : ry0[l + 1];
-        const int ow = (l == nl - 1) ? tw : rw[l + 1], oh = (l == nl - 1) ? th : rh[l + 1];
-        for (int i = tid; i < ow; i += PAN_THREADS) pan_coef(g.lv[l].sx, ox0 + i, g.lv[l].in_w, tab[l].x0[i], tab[l].x1[i], tab[l].lx[i]);
-        for (int i = tid; i < oh; i += PAN_THREADS) pan_coef(g.lv[l].sy, oy0 + i, g.lv[l].in_h, tab[l].y0[i], tab[l].y1[i], tab[l].ly[i]);
-        __syncthreads();
-        if (tid == 0) {
-            rx0[l] = tab[l].x0[0]; rw[l] = tab[l].x1[ow - 1] - tab[l].x0[0] + 1;
-            ry0[l] = tab[l].y0[0]; rh[l] = tab[l].y1[oh - 1] - tab[l].y0[0] + 1;
-            if (rw[l] + 1 > g.cap_w[l] || rh[l] + 1 > g.cap_h[l]) atomicExch(err, 1);
+        const int ox0 = (l == nl - 1) ? X0 : R.rx0[l + 1], oy0 = (l == nl - 1) ? Y0 : R.ry0[l + 1];
+        const int ow = (l == nl - 1) ? tw : R.rw[l + 1], oh = (l == nl - 1) ? th : R.rh[l + 1];
+        for (int i = tid; i < ow; i += PAN_THREADS) {
+            int i0, i1;
+            float lam;
+            pan_coef(g.lv[l].sx, ox0 + i, g.lv[l].in_w, i0, i1, lam);
+            tab[l].x0[i] = i0 - R.rx0[l]; tab[l].x1[i] = i1 - R.rx0[l]; tab[l].lx[i] = lam;
         }
-        __syncthreads();
-        if (rw[l] + 1 > g.cap_w[l] || rh[l] + 1 > g.cap_h[l]) return;  // capacity bug: reported through `err`, never silent
-        for (int i = tid; i < ow; i += PAN_THREADS) { tab[l].x0[i] -= rx0[l]; tab[l].x1[i] -= rx0[l]; }
-        for (int i = tid; i < oh; i += PAN_THREADS) { tab[l].y0[i] -= ry0[l]; tab[l].y1[i] -= ry0[l]; }
-        __syncthreads();
+        for (int i = tid; i < oh; i += PAN_THREADS) {
+            int i0, i1;
+            float lam;
+            pan_coef(g.lv[l].sy, oy0 + i, g.lv[l].in_h, i0, i1, lam);
+            tab[l].y0[i] = i0 - R.ry0[l]; tab[l].y1[i] = i1 - R.ry0[l]; tab[l].ly[i] = lam;
+        }
     }
 
-    // ---- 2. logits footprint of all K kernels -> LDS, bounds, survivor list
-    const int lw = rw[0], lh = rh[0];
-    const int lw1 = lw + 1, lwh = lw1 * (lh + 1);  // staged with the replicated column / row
-    const float inv_lw = 1.0f / (float)lw1;
-    const float* mb = masks + (size_t)b * N * g.Hm * g.Wm;
-    const int* rowp = sel_row + (size_t)b * K;
-    const float* scp = sel_score + (size_t)b * K;
-    const float* lbase = mb + (size_t)ry0[0] * g.Wm + rx0[0];
-    const size_t plane = (size_t)g.Hm * g.Wm;
-    const bool all_fit = KC >= K;
-    // footprint element r of this lane (two per lane cover up to 128 elements; larger footprints loop): source / LDS offsets
-    // are per-tile constants, the kernel's plane base is wave-uniform -> per kernel the staging is 2 loads + 2 LDS stores
-    if (tid == 0) lb_bits = 0;
-    for (int c0 = 0; c0 < K; c0 += KC) {
-        const int nc = min(KC, K - c0);
-        for (int r0 = 0; r0 < lwh; r0 += 128) {
-            int so[2], dof[2];
-            bool okr[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int r = r0 + lane + 64 * u;
-                okr[u] = r < lwh;
-                const int rc = min(r, lwh - 1);
-                const int yy = (int)(((float)rc + 0.5f) * inv_lw), xx = rc - yy * lw1;
-                so[u] = min(yy, lh - 1) * g.Wm + min(xx, lw - 1);
-                dof[u] = yy * lp + xx;
-            }
-            for (int kc0 = wave * 4; kc0 < nc; kc0 += (PAN_THREADS / 64) * 4) {  // 4 kernels x 2 elements in flight per lane
-                float v[4][2];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int kc = min(kc0 + q, nc - 1);
-                    const float* pl = lbase + (size_t)rowp[c0 + kc] * plane;
-                    v[q][0] = pl[so[0]];
-                    v[q][1] = pl[so[1]];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (kc0 + q < nc) {
-                        if (okr[0]) Ls[(kc0 + q) * ln + dof[0]] = v[q][0];
-                        if (okr[1]) Ls[(kc0 + q) * ln + dof[1]] = v[q][1];
-                    }
-                }
-            }
+    // ---- 2. bounds of all K kernels over this tile's footprint, survivor list
+    {
+        float lo_w = 0.f;
+        for (int k = tid; k < K; k += PAN_THREADS) {
+            const bool pre = k == tid;
+            const pan_f2 bd = pre ? bd_pre : bt[k];
+            const float s = pre ? s_pre : scp[k];
+            srow[k] = pre ? row_pre : rowp[k];
+            ssc[k] = s;
+            const float pm = 1.0f / (1.0f + expf(-bd[1])), pn = 1.0f / (1.0f + expf(-bd[0]));
+            khi[k] = s * pm * (1.0f + 1e-5f) + 1e-30f;
+            kpm[k] = pm * (1.0f + 1e-5f);
+            lo_w = fmaxf(lo_w, fmaxf(s * pn * (1.0f - 1e-5f), 0.f));
         }
+        lo_w = vkn_wave_max(lo_w);
+        __syncthreads();   // (lb_bits = 0 and the tables are visible)
+        if (lane == 0 && lo_w > 0.f) atomicMax(&lb_bits, __float_as_int(lo_w));  // lo >= 0: the int order of the bits is the float order
         __syncthreads();
-        // bounds: one thread per kernel walks its footprint (no cross-lane reduction)
-        for (int kc = tid; kc < nc; kc += PAN_THREADS) {
-            const int k = c0 + kc;
-            float mx = -INFINITY, mn = INFINITY;
-            for (int yy = 0; yy < lh; ++yy)
-                for (int xx = 0; xx < lw; ++xx) {
-                    const float v = Ls[kc * ln + yy * lp + xx];
-                    mx = fmaxf(mx, v);
-                    mn = fminf(mn, v);
-                }
-            const float s = scp[k];
-            const float pm = 1.0f / (1.0f + expf(-mx)), pn = 1.0f / (1.0f + expf(-mn));
-            const float hi = s * pm * (1.0f + 1e-5f) + 1e-30f, lo = fmaxf(s * pn * (1.0f - 1e-5f), 0.f);
-            khi[k] = hi; kpm[k] = pm * (1.0f + 1e-5f);
-            atomicMax(&lb_bits, __float_as_int(lo));  // lo >= 0: the int order of the bits is the float order
-        }
-        __syncthreads();  // bounds done (and, when chunked, the next chunk may overwrite Ls)
     }
     if (wave == 0) {
         const float LB = __int_as_float(lb_bits);
@@ -274,94 +339,138 @@ __global__ __launch_bounds__(PAN_THREADS) void k_pan_argmax(PanGeom g, const flo
     __syncthreads();
     const int nact = nact_s;
 
-    // this thread's output pixels: (fx, fy + 4*j), j < PAN_PPT
-    const int fx = tid & 63, fy = tid >> 6;
+    const int lw = R.rw[0], lh = R.rh[0];
+    const int lw1 = lw + 1, lwh = lw1 * (lh + 1);  // staged with the replicated column / row
+    const float inv_lw = 1.0f / (float)lw1, inv_lwh = 1.0f / (float)lwh;
+    const float* lbase = masks + (size_t)b * N * g.Hm * g.Wm + (size_t)R.ry0[0] * g.Wm + R.rx0[0];
+    const size_t plane = (size_t)g.Hm * g.Wm;
+
+    // this thread's output pixels: (fx, fy * PAN_PPT + j), j < PAN_PPT — vertically adjacent, so that consecutive pixels share input rows
+    // of the last level (x2 up-scaling: four output rows read three input rows); fy is the wave index: the row pattern is wave-uniform
+    const int fx = tid & 63, fy = wave;
     const bool okx = fx < tw;
     const PanTab tf = (nl == 3) ? tab[2] : tab[1];
     const int fip = (nl == 3) ? g.cap_w[2] : g.cap_w[1];
     const float flx = tf.lx[okx ? fx : 0];
+    const int fxo = tf.x0[okx ? fx : 0];
     bool okp[PAN_PPT];
-    int foff[PAN_PPT];   // word offset of the pixel's first tap inside a kernel's last-level buffer
+    int fy0[PAN_PPT];    // first input row of the pixel (wave-uniform: SGPR)
     float fly[PAN_PPT];
     float best[PAN_PPT];
     int bid[PAN_PPT];
 #pragma unroll
     for (int j = 0; j < PAN_PPT; ++j) {
-        okp[j] = okx && (fy + 4 * j) < th;
-        const int yy = okp[j] ? fy + 4 * j : 0;
-        foff[j] = tf.y0[yy] * fip + tf.x0[okx ? fx : 0];
+        okp[j] = okx && (fy * PAN_PPT + j) < th;
+        const int yy = min(fy * PAN_PPT + j, th - 1);
+        fy0[j] = __builtin_amdgcn_readfirstlane(tf.y0[yy]);
         fly[j] = tf.ly[yy];
         best[j] = -INFINITY;
         bid[j] = 0;
     }
 
-    // ---- 3. survivors, PAN_KB at a time: wave kk resamples kernel list[a0 + kk] through the intermediate levels
-    for (int a0 = 0; a0 < nact; a0 += PAN_KB) {
-        const int nk = min(PAN_KB, nact - a0);
-        for (int kq = wave; kq < nk; kq += PAN_THREADS / 64) {
-            const int k = list[a0 + kq];
-            const int slot = all_fit ? k : kq;
-            if (!all_fit) {  // footprints did not all fit: this wave re-stages its kernel's footprint (slot = batch position)
-                for (int r = lane; r < lwh; r += 64) {
-                    const int yy = (int)(((float)r + 0.5f) * inv_lw), xx = r - yy * lw1;
-                    Ls[slot * ln + yy * lp + xx] = lbase[(size_t)rowp[k] * plane + (size_t)min(yy, lh - 1) * g.Wm + min(xx, lw - 1)];
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-            }
-            {   // level 0: logits footprint -> x up -> sigmoid                                     (rescale_masks :446)
-                const int ow = rw[1], oh = rh[1], op = g.cap_w[1], ow1 = ow + 1;
-                const float inv_ow = 1.0f / (float)ow1;
-                const int so = Lo + slot * ln, dof = b1o + kq * (g.cap_w[1] * g.cap_h[1]);
-                const PanTab& t = tab[0];
-                for (int r = lane; r < ow1 * (oh + 1); r += 64) {
-                    const int yy = (int)(((float)r + 0.5f) * inv_ow), xx = r - yy * ow1;
-                    const int ys = min(yy, oh - 1), xs = min(xx, ow - 1);
-                    const float v = pan_lerp(ldsf, so, lp, t.y0[ys], t.ly[ys], t.x0[xs], t.lx[xs]);
-                    ldsf[dof + yy * op + xx] = 1.0f / (1.0f + expf(-v));
-                }
-            }
-            if (nl == 3) {  // level 1: -> batch_input_shape (the crop is the domain of level 2)
-                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are visible to its own reads
-                __builtin_amdgcn_wave_barrier();
-                const int ow = rw[2], oh = rh[2], op = g.cap_w[2], ip = g.cap_w[1], ow1 = ow + 1;
-                const float inv_ow = 1.0f / (float)ow1;
-                const int so = b1o + kq * (g.cap_w[1] * g.cap_h[1]), dof = b2o + kq * (g.cap_w[2] * g.cap_h[2]);
-                const PanTab& t = tab[1];
-                for (int r = lane; r < ow1 * (oh + 1); r += 64) {
-                    const int yy = (int)(((float)r + 0.5f) * inv_ow), xx = r - yy * ow1;
-                    const int ys = min(yy, oh - 1), xs = min(xx, ow - 1);
-                    ldsf[dof + yy * op + xx] = pan_lerp(ldsf, so, ip, t.y0[ys], t.ly[ys], t.x0[xs], t.lx[xs]);
-                }
-            }
-        }
-        __syncthreads();
-        // ---- last level per output pixel + score-weighted arg-max + ">= 0.5" count                      :484-486, :499
-        {
-            const int in = fip * ((nl == 3) ? g.cap_h[2] : g.cap_h[1]);
-            const int lasto = (nl == 3) ? b2o : b1o;
-            for (int kk = 0; kk < nk; ++kk) {
-                const int k = list[a0 + kk];
-                const int so = lasto + kk * in;
-                const float s = scp[k];
-                int c = 0;
+    for (int c0 = 0; c0 < nact; c0 += KC) {
+        const int nc = min(KC, nact - c0);
+        // ---- 3. footprints of this chunk's survivors -> LDS: item i = (survivor i / lwh, element i % lwh), four items per thread in
+        //         flight (all of a typical chunk: a handful of survivors x ~70 elements)
+        if (c0) __syncthreads();   // the previous chunk's last batch is done with Ls
+        const int items = nc * lwh;
+        for (int i0 = tid; i0 < items; i0 += 4 * PAN_THREADS) {
+            float v[4];
+            int dst[4];
 #pragma unroll
-                for (int j = 0; j < PAN_PPT; ++j) {
-                    const float v = pan_lerp(ldsf, so + foff[j], fip, 0, fly[j], 0, flx);
-                    const float pj = s * v;
-                    if (pj > best[j]) { best[j] = pj; bid[j] = k; }
-                    c += __popcll(__ballot(okp[j] && v >= 0.5f));
-                }
-                if (lane == 0 && c) atomicAdd(&orig_s[k], c);
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * PAN_THREADS, items - 1);
+                const int a = (int)(((float)i + 0.5f) * inv_lwh), r = i - a * lwh;
+                const int yy = (int)(((float)r + 0.5f) * inv_lw), xx = r - yy * lw1;
+                v[u] = lbase[(size_t)srow[list[c0 + a]] * plane + (size_t)min(yy, lh - 1) * g.Wm + min(xx, lw - 1)];
+                dst[u] = a * ln + yy * lp + xx;
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * PAN_THREADS < items) Ls[dst[u]] = v[u];
         }
         __syncthreads();
+
+        // ---- 4. survivors of the chunk, PAN_KB at a time: wave kk resamples kernel list[c0 + a0 + kk] through the intermediate levels
+        for (int a0 = 0; a0 < nc; a0 += PAN_KB) {
+            const int nk = min(PAN_KB, nc - a0);
+            for (int kq = wave; kq < nk; kq += PAN_THREADS / 64) {
+                const int slot = a0 + kq;
+                {   // level 0: logits footprint -> x up -> sigmoid                                     (rescale_masks :446)
+                    const int ow = R.rw[1], oh = R.rh[1], op = g.cap_w[1], ow1 = ow + 1;
+                    const float inv_ow = 1.0f / (float)ow1;
+                    const int so = Lo + slot * ln, dof = b1o + kq * (g.cap_w[1] * g.cap_h[1]);
+                    const PanTab& t = tab[0];
+                    for (int r = lane; r < ow1 * (oh + 1); r += 64) {
+                        const int yy = (int)(((float)r + 0.5f) * inv_ow), xx = r - yy * ow1;
+                        const int ys = min(yy, oh - 1), xs = min(xx, ow - 1);
+                        const float v = pan_lerp(ldsf, so, lp, t.y0[ys], t.ly[ys], t.x0[xs], t.lx[xs]);
+                        ldsf[dof + yy * op + xx] = 1.0f / (1.0f + expf(-v));
+                    }
+                }
+                if (nl == 3) {  // level 1: -> batch_input_shape (the crop is the domain of level 2)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+                    __builtin_amdgcn_wave_barrier();
+                    const int ow = R.rw[2], oh = R.rh[2], op = g.cap_w[2], ip = g.cap_w[1], ow1 = ow + 1;
+                    const float inv_ow = 1.0f / (float)ow1;
+                    const int so = b1o + kq * (g.cap_w[1] * g.cap_h[1]), dof = b2o + kq * (g.cap_w[2] * g.cap_h[2]);
+                    const PanTab& t = tab[1];
+                    for (int r = lane; r < ow1 * (oh + 1); r += 64) {
+                        const int yy = (int)(((float)r + 0.5f) * inv_ow), xx = r - yy * ow1;
+                        const int ys = min(yy, oh - 1), xs = min(xx, ow - 1);
+                        ldsf[dof + yy * op + xx] = pan_lerp(ldsf, so, ip, t.y0[ys], t.ly[ys], t.x0[xs], t.lx[xs]);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- last level per output pixel + score-weighted arg-max + ">= 0.5" count                      :484-486, :499
+            {
+                const int in = fip * ((nl == 3) ? g.cap_h[2] : g.cap_h[1]);
+                const int lasto = (nl == 3) ? b2o : b1o;
+                for (int kk = 0; kk < nk; ++kk) {
+                    const int k = list[c0 + a0 + kk];
+                    const int so = lasto + kk * in + fxo;
+                    const float s = ssc[k];
+                    int c = 0;
+                    // ATen's order — x first (one horizontal lerp per input row: v0 * (1 - lx) + v1 * lx), then y — with every input row's
+                    // horizontal lerp computed ONCE per thread: the two most recent rows stay in registers (scalar row compares)
+                    const float wx0 = 1.f - flx;
+                    int ya = -2, yb = -2;
+                    float ra = 0.f, rb = 0.f;
+                    auto hl = [&](int y) { const int o = so + y * fip; return ldsf[o] * wx0 + ldsf[o + 1] * flx; };
+#pragma unroll
+                    for (int j = 0; j < PAN_PPT; ++j) {
+                        const int y0 = fy0[j];
+                        float r0, r1;
+                        if (y0 == ya) r0 = ra; else if (y0 == yb) r0 = rb; else r0 = hl(y0);
+                        if (y0 + 1 == yb) r1 = rb; else if (y0 + 1 == ya) r1 = ra; else r1 = hl(y0 + 1);
+                        ya = y0; ra = r0; yb = y0 + 1; rb = r1;
+                        const float v = r0 * (1.f - fly[j]) + r1 * fly[j];
+                        const float pj = s * v;
+                        if (pj > best[j]) { best[j] = pj; bid[j] = k; }
+                        c += __popcll(__ballot(okp[j] && v >= 0.5f));
+                    }
+                    if (lane == 0 && c) atomicAdd(&orig_s[k], c);
+                }
+            }
+            __syncthreads();
+        }
     }
 
     int* idp = ids + (size_t)b * g.Ho * g.Wo;
 #pragma unroll
     for (int j = 0; j < PAN_PPT; ++j)
-        if (okp[j]) { idp[(size_t)(Y0 + fy + 4 * j) * g.Wo + X0 + fx] = bid[j]; atomicAdd(&area_s[bid[j]], 1); }
+    {
+        if (okp[j]) idp[(size_t)(Y0 + fy * PAN_PPT + j) * g.Wo + X0 + fx] = bid[j];
+        // pixel counts: a row of 64 pixels usually has ONE winner — one LDS atomic per wave instead of 64 on the same address
+        const int first = __builtin_amdgcn_readfirstlane(bid[j]);
+        const unsigned long long act = __ballot(okp[j]), same = __ballot(okp[j] && bid[j] == first);
+        if (same == act) {
+            if (lane == 0 && act) atomicAdd(&area_s[first], (int)__popcll(act));
+        } else if (okp[j]) {
+            atomicAdd(&area_s[bid[j]], 1);
+        }
+    }
     __syncthreads();
     for (int i = tid; i < K; i += PAN_THREADS) {
         if (area_s[i]) atomicAdd(&area[(size_t)b * K + i], area_s[i]);
@@ -471,9 +580,14 @@ static int cap_of(int out_extent, float scale, int in_size) {
     return (int)(c < 1 ? 1 : c) + 1;  // + the replicated border column / row
 }
 
-size_t vkn_panoptic_ws_bytes(int B, int K) {
+static size_t pan_tables_bytes(int B, int K) {
     // sel_row, sel_label, order, area, orig, seg_of (int) + sel_score (float) + err
     return ((size_t)B * K * 7 * 4 + 256 + 255) & ~(size_t)255;
+}
+size_t vkn_panoptic_ws_bytes(int B, int K, int Ho, int Wo) {
+    // ... + the footprint bounds [B][tiles][K] (min, max)
+    const size_t tiles = (size_t)((Wo + PAN_TW - 1) / PAN_TW) * (size_t)((Ho + PAN_TH - 1) / PAN_TH);
+    return pan_tables_bytes(B, K) + (((size_t)B * tiles * K * 8 + 255) & ~(size_t)255);
 }
 
 int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const float* masks, int B, int N, int ncls,
@@ -485,7 +599,7 @@ int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const f
     if (c->up < 1 || c->Hm <= 0 || c->Wm <= 0 || c->Hb <= 0 || c->Wb <= 0 || c->h <= 0 || c->w <= 0 || c->Ho <= 0 || c->Wo <= 0)
         return VKN_E_ARG;
     if (c->h > c->Hb || c->w > c->Wb) return VKN_E_ARG;  // img_shape is a crop of batch_input_shape
-    if (ws_bytes < vkn_panoptic_ws_bytes(B, K)) return VKN_E_WORKSPACE;
+    if (ws_bytes < vkn_panoptic_ws_bytes(B, K, c->Ho, c->Wo)) return VKN_E_WORKSPACE;
     int* wsi = static_cast<int*>(ws);
     int* sel_row = wsi;
     int* sel_label = sel_row + (size_t)B * K;
@@ -495,6 +609,7 @@ int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const f
     int* seg_of = orig + (size_t)B * K;
     float* sel_score = reinterpret_cast<float*>(seg_of + (size_t)B * K);
     int* err = reinterpret_cast<int*>(sel_score + (size_t)B * K);
+    pan_f2* bounds = reinterpret_cast<pan_f2*>(static_cast<char*>(ws) + pan_tables_bytes(B, K));
     if (hipMemsetAsync(area, 0, (size_t)B * K * 2 * sizeof(int), st) != hipSuccess) return VKN_E_LAUNCH;
     if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) return VKN_E_LAUNCH;
 
@@ -528,21 +643,26 @@ int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const f
         lds += (size_t)(3 * nw + 3 * nh) * 4;
         if (l > 0) lds += (size_t)PAN_KB * g.cap_w[l] * g.cap_h[l] * 4;
     }
-    lds += (size_t)5 * K * 4;
-    // logits footprints: all K kernels when they fit (<= 64 KB and what the other buffers leave of 150 KB), else chunks for
-    // the bounds pass and one per batch slot for the resampling pass
+    lds += (size_t)7 * K * 4;
+    // logits footprints of the SURVIVORS of a tile, a chunk of KC at a time (a handful survive for segmentation-like masks; an
+    // adversarial input — every kernel everywhere — walks the chunks): 32 footprints keep the workgroup small enough for several per CU
     const size_t ln_bytes = (size_t)g.cap_w[0] * g.cap_h[0] * 4;
     const size_t lds_cap = 150 * 1024;
     if (lds + PAN_KB * ln_bytes > lds_cap) return VKN_E_SHAPE;  // extreme down-scaling: one tile's footprint does not fit LDS
     size_t budget = lds_cap - lds;
-    if (budget > 65536) budget = 65536;
+    if (budget > 32 * ln_bytes) budget = 32 * ln_bytes;
     int KC = (int)(budget / ln_bytes);
     if (KC >= K) KC = K;
+    KC = KC / PAN_KB * PAN_KB;
     lds += (size_t)KC * ln_bytes;
-    VKN_ALLOW_FULL_LDS(k_pan_argmax);
     dim3 grid((c->Wo + PAN_TW - 1) / PAN_TW, (c->Ho + PAN_TH - 1) / PAN_TH, B);
+    if ((size_t)2 * PANB_KCH * g.Wm * 4 > 60 * 1024) return VKN_E_SHAPE;
+    hipLaunchKernelGGL(k_pan_bounds, dim3((K + PANB_KCH - 1) / PANB_KCH, (grid.y + PANB_TR - 1) / PANB_TR, B), dim3(256),
+                       (size_t)2 * PANB_KCH * g.Wm * 4, st, g, masks, sel_row, K, N, (int)grid.x, (int)grid.y, bounds);
+    VKN_CHECK_LAUNCH();
+    VKN_ALLOW_FULL_LDS(k_pan_argmax);
     hipLaunchKernelGGL(k_pan_argmax, grid, dim3(PAN_THREADS), lds, st, g, masks, sel_row, sel_score, K, N, panoptic_seg, area, orig, err,
-                       vkn_dbg_env("VKN_PAN_NOPRUNE", 0) ? 0 : 1, KC);  // debug build only: visit all K kernels in every tile
+                       vkn_dbg_env("VKN_PAN_NOPRUNE", 0) ? 0 : 1, KC, bounds);  // debug build only: visit all K kernels in every tile
     VKN_CHECK_LAUNCH();
 
     hipLaunchKernelGGL(k_pan_merge, dim3(B), dim3(64), (size_t)K * 6 * 4, st, sel_row, sel_label, sel_score, order, area, orig, K, T,
