@@ -148,59 +148,78 @@ __device__ __forceinline__ void pan_region(const PanGeom& g, int X0, int tw, int
 // serial min / max walk per kernel and tile: what made k_pan_argmax a 10 us-per-tile latency chain in round 5).
 // Workgroup = (PANB_KCH kernels) x (a strip of PANB_TR tile rows) x frame; thread = logit column: column-wise min / max over the tile
 // row's footprint rows -> LDS, then one (tile, kernel) pair per thread takes the min / max over the tile's footprint columns.
-#define PANB_KCH 4
+#define PANB_KCH 2
 #define PANB_TR 8
 typedef float pan_f2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_pan_bounds(PanGeom g, const float* __restrict__ masks, const int* __restrict__ sel_row, int K,
                                                     int N, int ntx, int nty, pan_f2* __restrict__ bounds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* cmn = reinterpret_cast<float*>(smem);        // [PANB_KCH][Wm] column minima of the current tile row's footprint rows
-    float* cmx = cmn + PANB_KCH * g.Wm;                 // ... maxima
-    const int tid = threadIdx.x, b = blockIdx.z, k0 = blockIdx.x * PANB_KCH;
+    pan_f2* cmm = reinterpret_cast<pan_f2*>(smem);      // [PANB_TR tile rows][PANB_KCH][Wm] column (min, max) over the tile row's footprint rows
+    const int tid = threadIdx.x, b = blockIdx.z, k0 = blockIdx.x * PANB_KCH, strip = blockIdx.y;
     const size_t plane = (size_t)g.Hm * g.Wm;
     const float* pl[PANB_KCH];
 #pragma unroll
     for (int kk = 0; kk < PANB_KCH; ++kk)
         pl[kk] = masks + ((size_t)b * N + sel_row[(size_t)b * K + min(k0 + kk, K - 1)]) * plane;
-    const int ty1 = min(nty, ((int)blockIdx.y + 1) * PANB_TR);
-    for (int ty = blockIdx.y * PANB_TR; ty < ty1; ++ty) {
-        const int Y0 = ty * PAN_TH, th = min(PAN_TH, g.Ho - Y0);
-        PanRegion R;
-        pan_region(g, 0, 1, Y0, th, R);   // (the row footprint does not depend on the tile column)
-        const int ry0 = R.ry0[0], lh = R.rh[0];
+    const int ty0 = strip * PANB_TR, ntr = min(nty - ty0, PANB_TR);
+    // phase A: every tile row of the strip, no barrier in between; FOUR tile rows' loads (4 x 6 rows x PANB_KCH planes) are requested
+    // before the first use — a wave that waits on 12 loads at a time was the whole cost of this kernel (5120 resident waves x 12 loads
+    // per ~2 us round trip = 185 us for the 5.7 M wave-loads)
+    for (int t0 = 0; t0 < ntr; t0 += 4) {
+        int ry0[4], lh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int Y0 = (ty0 + min(t0 + u, ntr - 1)) * PAN_TH, th = min(PAN_TH, g.Ho - Y0);
+            PanRegion R;
+            pan_region(g, 0, 1, Y0, th, R);   // (the row footprint does not depend on the tile column)
+            ry0[u] = R.ry0[0]; lh[u] = R.rh[0];
+        }
+        const int lhm = max(max(lh[0], lh[1]), max(lh[2], lh[3]));
         for (int x = tid; x < g.Wm; x += 256) {
-            float mn[PANB_KCH], mx[PANB_KCH];
+            float mn[4][PANB_KCH], mx[4][PANB_KCH];
 #pragma unroll
-            for (int kk = 0; kk < PANB_KCH; ++kk) { mn[kk] = INFINITY; mx[kk] = -INFINITY; }
-            for (int y8 = 0; y8 < lh; y8 += 8) {   // eight rows x PANB_KCH planes requested before the first use (rows past the footprint: its last row again)
-                float v[8][PANB_KCH];
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int yy = 0; yy < 8; ++yy) {
-                    const size_t o = (size_t)(ry0 + min(y8 + yy, lh - 1)) * g.Wm + x;
+                for (int kk = 0; kk < PANB_KCH; ++kk) { mn[u][kk] = INFINITY; mx[u][kk] = -INFINITY; }
+            for (int y6 = 0; y6 < lhm; y6 += 6) {   // (rows past a footprint: its last row again)
+                float v[4][6][PANB_KCH];
 #pragma unroll
-                    for (int kk = 0; kk < PANB_KCH; ++kk) v[yy][kk] = pl[kk][o];
-                }
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int yy = 0; yy < 8; ++yy)
+                    for (int yy = 0; yy < 6; ++yy) {
+                        const size_t o = (size_t)(ry0[u] + min(y6 + yy, lh[u] - 1)) * g.Wm + x;
 #pragma unroll
-                    for (int kk = 0; kk < PANB_KCH; ++kk) { mn[kk] = fminf(mn[kk], v[yy][kk]); mx[kk] = fmaxf(mx[kk], v[yy][kk]); }
+                        for (int kk = 0; kk < PANB_KCH; ++kk) v[u][yy][kk] = pl[kk][o];
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int yy = 0; yy < 6; ++yy)
+#pragma unroll
+                        for (int kk = 0; kk < PANB_KCH; ++kk) { mn[u][kk] = fminf(mn[u][kk], v[u][yy][kk]); mx[u][kk] = fmaxf(mx[u][kk], v[u][yy][kk]); }
             }
 #pragma unroll
-            for (int kk = 0; kk < PANB_KCH; ++kk) { cmn[kk * g.Wm + x] = mn[kk]; cmx[kk * g.Wm + x] = mx[kk]; }
+            for (int u = 0; u < 4; ++u)
+                if (t0 + u < ntr)
+#pragma unroll
+                    for (int kk = 0; kk < PANB_KCH; ++kk) cmm[((size_t)(t0 + u) * PANB_KCH + kk) * g.Wm + x] = pan_f2{mn[u][kk], mx[u][kk]};
         }
-        __syncthreads();
-        for (int i = tid; i < ntx * PANB_KCH; i += 256) {
-            const int kk = i & (PANB_KCH - 1), tx = i / PANB_KCH;
-            const int X0 = tx * PAN_TW, tw = min(PAN_TW, g.Wo - X0);
-            pan_region(g, X0, tw, Y0, th, R);
-            float mn = INFINITY, mx = -INFINITY;
-            for (int xx = 0; xx < R.rw[0]; ++xx) {
-                mn = fminf(mn, cmn[kk * g.Wm + R.rx0[0] + xx]);
-                mx = fmaxf(mx, cmx[kk * g.Wm + R.rx0[0] + xx]);
-            }
-            if (k0 + kk < K) bounds[(((size_t)b * nty + ty) * ntx + tx) * K + k0 + kk] = pan_f2{mn, mx};
+    }
+    __syncthreads();
+    // phase B: one (tile row, tile column, kernel) triple per thread
+    for (int i = tid; i < ntr * ntx * PANB_KCH; i += 256) {
+        const int kk = i % PANB_KCH, tx = (i / PANB_KCH) % ntx, t = i / (PANB_KCH * ntx);
+        const int Y0 = (ty0 + t) * PAN_TH, th = min(PAN_TH, g.Ho - Y0);
+        const int X0 = tx * PAN_TW, tw = min(PAN_TW, g.Wo - X0);
+        PanRegion R;
+        pan_region(g, X0, tw, Y0, th, R);
+        float mn = INFINITY, mx = -INFINITY;
+        const pan_f2* c = cmm + ((size_t)t * PANB_KCH + kk) * g.Wm + R.rx0[0];
+        for (int xx = 0; xx < R.rw[0]; ++xx) {
+            mn = fminf(mn, c[xx][0]);
+            mx = fmaxf(mx, c[xx][1]);
         }
-        __syncthreads();
+        if (k0 + kk < K) bounds[(((size_t)b * nty + ty0 + t) * ntx + tx) * K + k0 + kk] = pan_f2{mn, mx};
     }
 }
 
@@ -656,9 +675,10 @@ int vkn_launch_panoptic_joint(const VknPanopticCfg* c, const float* cls, const f
     KC = KC / PAN_KB * PAN_KB;
     lds += (size_t)KC * ln_bytes;
     dim3 grid((c->Wo + PAN_TW - 1) / PAN_TW, (c->Ho + PAN_TH - 1) / PAN_TH, B);
-    if ((size_t)2 * PANB_KCH * g.Wm * 4 > 60 * 1024) return VKN_E_SHAPE;
+    if ((size_t)2 * PANB_KCH * PANB_TR * g.Wm * 4 > 64 * 1024) return VKN_E_SHAPE;
+    // (tried: an XCD-aware unit order that assembles every 128-byte line of `bounds` in one L2 — 168 us against 160: not the limit)
     hipLaunchKernelGGL(k_pan_bounds, dim3((K + PANB_KCH - 1) / PANB_KCH, (grid.y + PANB_TR - 1) / PANB_TR, B), dim3(256),
-                       (size_t)2 * PANB_KCH * g.Wm * 4, st, g, masks, sel_row, K, N, (int)grid.x, (int)grid.y, bounds);
+                       (size_t)2 * PANB_KCH * PANB_TR * g.Wm * 4, st, g, masks, sel_row, K, N, (int)grid.x, (int)grid.y, bounds);
     VKN_CHECK_LAUNCH();
     VKN_ALLOW_FULL_LDS(k_pan_argmax);
     hipLaunchKernelGGL(k_pan_argmax, grid, dim3(PAN_THREADS), lds, st, g, masks, sel_row, sel_score, K, N, panoptic_seg, area, orig, err,
