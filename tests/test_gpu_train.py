@@ -399,7 +399,8 @@ def test_fused_focal_loss_vs_torch_formula(vkn, M, ncls, weighted):
 
 
 @pytest.mark.parametrize('shape,S', [((2, 5, 8, 12), 2), ((1, 3, 7, 9), 4), ((3, 4, 16, 32), 2), ((1, 2, 5, 3), 3), ((1, 2, 4, 6), 8),
-                                     ((2, 3, 5, 7), 1), ((2, 3, 6, 64), 2), ((1, 2, 9, 128), 2), ((1, 1, 5, 320), 2)])
+                                     ((2, 3, 5, 7), 1), ((2, 3, 6, 64), 2), ((1, 2, 9, 128), 2), ((1, 1, 5, 320), 2),
+                                     ((2, 3, 6, 64), 4), ((1, 2, 9, 128), 4), ((1, 1, 5, 320), 4), ((1, 2, 1, 64), 4), ((1, 8, 128, 256), 4)])
 def test_upsample_backward_vs_torch_autograd(vkn, shape, S):
     """The adjoint of the bilinear xS upsample (HIP, gather form, deterministic) against torch's autograd of F.interpolate."""
     import torch.nn.functional as F

@@ -329,6 +329,77 @@ __global__ __launch_bounds__(256) void k_upsample_bwd2(const float* __restrict__
     }
 }
 
+// ... and for S = 4 (mask_upsample_stride of the shipped video configs: the x4 loss masks of a training stage are 981 MB per 4 frames —
+// the generic kernel fetched every element 4 x 4 times with 64 scalar loads per thread: 955 us per stage, 21 % of the x4 training step).
+// A thread owns one input column and UB4_R consecutive input rows; per output row it loads the aligned float4 (columns 4x .. 4x + 3) and
+// the float2 on either side (4x - 2, 4x - 1 / 4x + 4, 4x + 5: the neighbours' lines), forms the horizontal sum once — adjacent input rows
+// share four of their eight output rows — and blends vertically.  Same weights and order of additions as k_upsample_bwd<4>: bit-identical.
+#define UB4_R 2
+__global__ __launch_bounds__(256) void k_upsample_bwd4(const float* __restrict__ gout, float* __restrict__ gin, int H, int W) {
+    const int plane = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y0 = blockIdx.y * UB4_R;
+    if (x >= W) return;   // (whole waves: W % 64 == 0)
+    const int OH = 4 * H, OW = 4 * W;
+    const float* gp = gout + (size_t)plane * OH * OW;
+    float wxs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ox = 4 * x - 2 + j;
+        const float sx = fmaxf(((float)ox + 0.5f) * 0.25f - 0.5f, 0.f);
+        const int x0 = min((int)sx, W - 1), x1 = min(x0 + 1, W - 1);
+        const float lx = sx - (float)x0;
+        const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+        wxs[j] = (ox >= 0 && ox < OW) ? wx : 0.f;
+    }
+    constexpr int NR = 4 * UB4_R + 4;   // output rows 4 y0 - 2 .. 4 (y0 + R - 1) + 5
+    f32x4 vv[NR];
+    float2 vm[NR], vp[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {   // ALL loads first, from clamped addresses (see k_upsample_bwd2)
+        const int oy = min(max(4 * y0 - 2 + i, 0), OH - 1);
+        const float* rp = gp + (size_t)oy * OW + 4 * x;
+        vv[i] = *reinterpret_cast<const f32x4*>(rp);
+        vm[i] = *reinterpret_cast<const float2*>(rp + (x > 0 ? -2 : 0));
+        vp[i] = *reinterpret_cast<const float2*>(rp + (x + 1 < W ? 4 : 2));
+    }
+    float hs[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int oy = 4 * y0 - 2 + i;
+        float h = 0.f;
+        if (oy >= 0 && oy < OH) {   // uniform
+            if (wxs[0] != 0.f) h += wxs[0] * vm[i].x;
+            if (wxs[1] != 0.f) h += wxs[1] * vm[i].y;
+            if (wxs[2] != 0.f) h += wxs[2] * vv[i][0];
+            if (wxs[3] != 0.f) h += wxs[3] * vv[i][1];
+            if (wxs[4] != 0.f) h += wxs[4] * vv[i][2];
+            if (wxs[5] != 0.f) h += wxs[5] * vv[i][3];
+            if (wxs[6] != 0.f) h += wxs[6] * vp[i].x;
+            if (wxs[7] != 0.f) h += wxs[7] * vp[i].y;
+        }
+        hs[i] = h;
+    }
+#pragma unroll
+    for (int r = 0; r < UB4_R; ++r) {
+        const int y = y0 + r;
+        if (y >= H) break;   // uniform
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int oy = 4 * y - 2 + i;
+            if (oy < 0 || oy >= OH) continue;
+            const float sy = fmaxf(((float)oy + 0.5f) * 0.25f - 0.5f, 0.f);
+            const int yy0 = min((int)sy, H - 1), yy1 = min(yy0 + 1, H - 1);
+            const float ly = sy - (float)yy0;
+            const float wy = (yy0 == y ? 1.f - ly : 0.f) + (yy1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            acc += wy * hs[4 * r + i];
+        }
+        gin[((size_t)plane * H + y) * W + x] = acc;
+    }
+}
+
 
 // ---- the training tail (round 5): what `get_targets` + `loss` do per stage as FOUR small kernels around the three mask-loss passes.
 // k_stage_targets: one workgroup per image writes that image's rows of labels / label_weights / row_weight / rowk / tgt_row and its
@@ -601,6 +672,15 @@ int vkn_upsample_bilinear_bwd_f32(const float* grad_out, float* grad_in, int pla
         for (int done = 0; done < planes; done += 32768) {  // gridDim.z <= 65535
             const int chunk = (planes - done > 32768) ? 32768 : planes - done;
             hipLaunchKernelGGL(k_upsample_bwd2, dim3((W + 255) / 256, (H + UB2_R - 1) / UB2_R, chunk), dim3(256), 0, st,
+                               grad_out + (size_t)done * H * S * W * S, grad_in + (size_t)done * H * W, H, W);
+            VKN_CHECK_LAUNCH();
+        }
+        return VKN_OK;
+    }
+    if (S == 4 && (W % 64) == 0 && ((reinterpret_cast<uintptr_t>(grad_out) & 15) == 0)) {   // the video configs' training scale
+        for (int done = 0; done < planes; done += 32768) {
+            const int chunk = (planes - done > 32768) ? 32768 : planes - done;
+            hipLaunchKernelGGL(k_upsample_bwd4, dim3((W + 255) / 256, (H + UB4_R - 1) / UB4_R, chunk), dim3(256), 0, st,
                                grad_out + (size_t)done * H * S * W * S, grad_in + (size_t)done * H * W, H, W);
             VKN_CHECK_LAUNCH();
         }
