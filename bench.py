@@ -581,6 +581,24 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             pan_ms = e0.elapsed_time(e1) / 5
+            # END TO END, what the reference's `simple_test` runs per frame (knet/det/knet.py:161-190; video:
+            # knet/video/knet_quansi_dense_embed_fc_joint_train.py:505-560): kernel initialisation (pass 0: the two 1x1 decodes, x = loc + sem,
+            # the kernel-init gather) -> the S-stage head on pass 0's OWN outputs (+ the tracking link; no x4 tensor: the post-head
+            # kernels resample the low-res logits themselves) -> panoptic merge to the 1024x2048 id map.  Chained on one stream,
+            # inputs resident; the head's masks here are whatever the random-init head makes of pass 0's output (timing, not parity —
+            # the arg-max pruning is data dependent: `panoptic_joint_1024x2048_ms` above is on segmentation-like logits).
+            def pipeline():
+                prop_, xf_, mp_, _ = vkn.ops.kernel_init(loc, sem, iw, sw, sb, 2, True, True, want_seg_preds=False)
+                o_ = vkn.ops.head_forward(dims, packs, xf_, prop_, mp_, None, CFG2['up'], want_scaled=False, clip_first_prev=first_prev)
+                return vkn.ops.panoptic_joint(o_[1], o_[2], P0, 2, P0, 0.25, 0.6, full, full, full, upsample_stride=CFG2['up'])
+            for _ in range(2):
+                pipeline()
+            e0.record()
+            for _ in range(5):
+                pipeline()
+            e1.record()
+            torch.cuda.synchronize()
+            pipe_ms = e0.elapsed_time(e1) / 5
             # the whole step (S stages + link + x4 upsample, one C call) at 1 / 8 frames per call — the reference walks a video one
             # frame per call; `value` above is at `--frames` per call
             per_call = {}
@@ -721,6 +739,8 @@ def main():
                                       fused_replaces_algorithmic_GBps=round(2 * alg / (fu_ms * 1e-3) / 1e9, 1),
                                       decode_ms=round(dec_ms, 4), gather_plus_reduce_ms=round(ga_ms, 4),
                                       kernel_init_pass0_ms=round(init_ms, 4), panoptic_joint_1024x2048_ms=round(pan_ms, 4),
+                                      pipeline_ms=round(pipe_ms, 4), pipeline_frames_per_s=round(B / (pipe_ms * 1e-3), 1),
+                                      pipeline='kernel init (pass 0) -> S-stage head + tracking link -> panoptic merge (1024x2048 id map), chained as simple_test does',
                                       gather_GBps=round(alg / (ga_ms * 1e-3) / 1e9, 1),
                                       head_3stages_no_upsample_ms=round(head_ms, 4),
                                       upsample_x4_ms=round(up_ms, 4),

@@ -103,6 +103,8 @@ extern "C" {
  * kernels (obj_out[B-1]) on, then runs C.  Same arguments, same workspace and same output tensors in all three calls, nothing else
  * through that workspace in between; no phase bit = the whole call.  A: stages 0 .. S-2 + the last stage's gather; B: the last stage's
  * frame-sequential [N x C] chains (writes obj_out / cls_prob); C: the last decode, the upsample, the tracking link. */
+#define VKN_FLAG_INIT_SEPARATE 131072u /* vkn_kernel_init_f32: the round-5 form (two decode launches, a copy, an add pass, a logits gather) instead of the
+                                        * one-pass kernel (A/B, tests: bit-identical outputs) */
 #define VKN_FLAG_PHASE_A 1024u
 #define VKN_FLAG_PHASE_B 2048u
 #define VKN_FLAG_PHASE_C 4096u

@@ -676,6 +676,27 @@ def test_kernel_init_cfg2_size(vkn):
     assert maxabs(prop[:, :Np], want_p) < 2e-5 * float(want_p.abs().max())
 
 
+@pytest.mark.parametrize('B,Np,ncls,nth,C,H,W,cat,seg', [(2, 100, 19, 2, 256, 128, 256, True, True), (3, 100, 19, 2, 256, 16, 32, True, False),
+                                                          (1, 127, 1, 0, 256, 8, 16, False, True), (2, 97, 31, 11, 128, 8, 24, True, True),
+                                                          (2, 12, 5, 2, 64, 8, 16, True, True), (1, 20, 12, 3, 256, 16, 16, False, False)])
+def test_kernel_init_one_pass_equals_the_separate_form_bit_for_bit(vkn, B, Np, ncls, nth, C, H, W, cat, seg):
+    """Round 6: pass 0 as ONE pass over loc and sem (k_init_pass: both 1x1 decodes, x = loc + sem, the stuff rows, the thing bits of
+    the kernel-init gather; knet/det/kernel_head.py:222-257) against the round-5 form (two decode launches, a copy, an add pass, a
+    logits gather; VKN_FLAG_INIT_SEPARATE) — which the reference goldens pin: all four outputs bit for bit, over both built row maps
+    (100 proposals + 19 classes in four n-blocks; everything in one), ragged row counts, with / without stuff rows and seg_preds."""
+    assert vkn._lib.lib().vkn_kernel_init_workspace_bytes(B, Np, ncls, C, H * W) > 0
+    loc, sem = _rand((B, C, H, W), 511).to(DEV), _rand((B, C, H, W), 512).to(DEV)
+    iw = (_rand((Np, C, 1, 1), 513, 0.05)).to(DEV)
+    sw, sb = _rand((ncls, C, 1, 1), 514, 0.05).to(DEV), _rand((ncls,), 515).to(DEV)
+    a = vkn.ops.kernel_init(loc, sem, iw, sw, sb, nth, cat, True, want_seg_preds=seg)
+    b = vkn.ops.kernel_init(loc, sem, iw, sw, sb, nth, cat, True, want_seg_preds=seg, flags=vkn.ops.FLAG_INIT_SEPARATE)
+    for nm, u, v in zip(('proposal_feats', 'x_feats', 'mask_preds', 'seg_preds'), a, b):
+        assert (u is None and v is None) or torch.equal(u, v), nm
+    assert torch.equal(a[1], sem + loc)
+    c = vkn.ops.kernel_init(loc, sem, iw, sw, sb, nth, cat, False, want_seg_preds=seg)         # no object features: no bits, no gather
+    assert torch.equal(c[2], a[2]) and torch.equal(c[0][:, :Np], iw.reshape(1, Np, C).expand(B, -1, -1))
+
+
 def test_conv_kernel_head_class_matches_reference_golden(vkn):
     """The registry class end to end: a pass-through neck, reference-shaped checkpoint, `simple_test_rpn` 5-tuple."""
     from helpers import load_init_golden, make_init_case

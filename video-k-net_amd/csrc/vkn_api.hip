@@ -883,6 +883,8 @@ StageWs frame_ws(const StageWs& s, const VknDims* d, int b) {
 struct InitWs {
     _Float16 *ih, *il, *sh, *sl;
     float *part, *cntp, *cnt, *obj, *seg;
+    _Float16 *ph, *pl;   // one-pass form (k_init_pass): the 128 plane rows init_kernels | conv_seg (+ 32 rows of slack for the second split)
+    unsigned* bits;      // ... and the thing bits [B][P/64][2][npt]
 };
 size_t carve_init(int B, int Np, int ncls, int C, int P, bool need_seg, char* base, InitWs* s) {
     Carver c{base, 0};
@@ -896,6 +898,13 @@ size_t carve_init(int B, int Np, int ncls, int C, int P, bool need_seg, char* ba
     s->cnt = c.take<float>((size_t)B * Np);
     s->obj = c.take<float>((size_t)B * Np * C);
     s->seg = need_seg ? c.take<float>((size_t)B * ncls * P) : nullptr;
+    s->ph = s->pl = nullptr;
+    s->bits = nullptr;
+    if (ncls > 0 && vkn_init_pass_supported(Np, ncls, C, P)) {
+        s->ph = c.take<_Float16>((size_t)160 * C);
+        s->pl = c.take<_Float16>((size_t)160 * C);
+        s->bits = c.take<unsigned>((size_t)B * (P / 32) * NPTp);
+    }
     return (c.off + 255) & ~(size_t)255;
 }
 
@@ -1115,37 +1124,51 @@ int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const fl
     if (xdt && (ref || (P % 64) != 0 || with_obj == 2)) return VKN_E_SHAPE;
     const size_t xes = xdt ? 2 : 4;
 
-    // mask_preds[:, :Np] = init_kernels(loc_feats): 1x1 conv, no bias, the same kernels for every frame          (:222)
-    if (ref_decode) {
-        VKN_TRY(vkn_launch_decode_ref_ex(loc_feats, init_w, nullptr, mask_preds, B, Np, C, P, 1, N, st));
-    } else {
-        VKN_TRY(vkn_launch_split_planes(init_w, s.ih, s.il, 1, Np, C, st));
-        VKN_TRY(vkn_launch_decode_ex(loc_feats, s.ih, s.il, nullptr, mask_preds, B, Np, C, P, 1, N, st, xdt));
-    }
+    // ONE pass over loc and sem (k_init_pass): both decodes, x = loc + sem, the stuff rows, the thing bits of the gather below
+    const bool one_pass = sem && !ref && !xdt && with_obj != 2 && s.ph && !(flags & VKN_FLAG_INIT_SEPARATE) &&
+                          vkn_init_pass_supported(Np, ncls, C, P) != 0;
     const float* xf = loc_feats;
-    if (sem) {
-        // seg_preds = conv_seg(semantic_feats)                                                                   (:231-234)
-        float* seg = seg_preds ? seg_preds : s.seg;
+    if (one_pass) {
+        VKN_TRY(vkn_launch_split_planes(init_w, s.ph, s.pl, 1, Np, C, st));                                   // rows [0, Np) (+ zeros up to 128)
+        VKN_TRY(vkn_launch_split_planes(seg_w, s.ph + (size_t)Np * C, s.pl + (size_t)Np * C, 1, ncls, C, st));  // rows [Np, Np + ncls)
+        InitPassArgs a{};
+        a.loc = loc_feats; a.sem = sem_feats; a.kh = s.ph; a.kl = s.pl; a.seg_b = seg_b; a.x_out = x_feats; a.masks = mask_preds;
+        a.seg = seg_preds; a.bits = with_obj ? s.bits : nullptr; a.thr = thr_logit; a.Np = Np; a.ncls = ncls; a.nth = num_thing_classes;
+        a.cat = nstuff > 0 ? 1 : 0; a.N = N; a.C = C; a.P = P; a.npt = npt_of(Np);
+        VKN_TRY(vkn_launch_init_pass(a, B, st));
+        xf = x_feats;
+    } else {
+        // mask_preds[:, :Np] = init_kernels(loc_feats): 1x1 conv, no bias, the same kernels for every frame          (:222)
         if (ref_decode) {
-            VKN_TRY(vkn_launch_decode_ref_ex(sem_feats, seg_w, seg_b, seg, B, ncls, C, P, 1, ncls, st));
+            VKN_TRY(vkn_launch_decode_ref_ex(loc_feats, init_w, nullptr, mask_preds, B, Np, C, P, 1, N, st));
         } else {
-            VKN_TRY(vkn_launch_split_planes(seg_w, s.sh, s.sl, 1, ncls, C, st));
-            VKN_TRY(vkn_launch_decode_ex(sem_feats, s.sh, s.sl, seg_b, seg, B, ncls, C, P, 1, ncls, st, xdt));
+            VKN_TRY(vkn_launch_split_planes(init_w, s.ih, s.il, 1, Np, C, st));
+            VKN_TRY(vkn_launch_decode_ex(loc_feats, s.ih, s.il, nullptr, mask_preds, B, Np, C, P, 1, N, st, xdt));
         }
-        // mask_preds[:, Np:] = seg_preds[:, num_thing_classes:]  (cat_stuff_mask, inference)                      (:255-257)
-        if (nstuff > 0) {
-            if (hipMemcpy2DAsync(mask_preds + (size_t)Np * P, (size_t)N * P * sizeof(float), seg + (size_t)num_thing_classes * P,
-                                 (size_t)ncls * P * sizeof(float), (size_t)nstuff * P * sizeof(float), B,
-                                 hipMemcpyDeviceToDevice, st) != hipSuccess)
+        if (sem) {
+            // seg_preds = conv_seg(semantic_feats)                                                                   (:231-234)
+            float* seg = seg_preds ? seg_preds : s.seg;
+            if (ref_decode) {
+                VKN_TRY(vkn_launch_decode_ref_ex(sem_feats, seg_w, seg_b, seg, B, ncls, C, P, 1, ncls, st));
+            } else {
+                VKN_TRY(vkn_launch_split_planes(seg_w, s.sh, s.sl, 1, ncls, C, st));
+                VKN_TRY(vkn_launch_decode_ex(sem_feats, s.sh, s.sl, seg_b, seg, B, ncls, C, P, 1, ncls, st, xdt));
+            }
+            // mask_preds[:, Np:] = seg_preds[:, num_thing_classes:]  (cat_stuff_mask, inference)                      (:255-257)
+            if (nstuff > 0) {
+                if (hipMemcpy2DAsync(mask_preds + (size_t)Np * P, (size_t)N * P * sizeof(float), seg + (size_t)num_thing_classes * P,
+                                     (size_t)ncls * P * sizeof(float), (size_t)nstuff * P * sizeof(float), B,
+                                     hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return VKN_E_LAUNCH;
+            }
+            // x_feats = semantic_feats + loc_feats                                                                   (:238-241)
+            if (xdt) VKN_TRY(vkn_launch_add2_half(sem_feats, loc_feats, x_feats, (size_t)B * C * P, xdt, st));
+            else VKN_TRY(vkn_launch_add2(sem_feats, loc_feats, x_feats, (size_t)B * C * P, st));
+            xf = x_feats;
+        } else if (x_feats && x_feats != loc_feats) {
+            if (hipMemcpyAsync(x_feats, loc_feats, (size_t)B * C * P * xes, hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return VKN_E_LAUNCH;
         }
-        // x_feats = semantic_feats + loc_feats                                                                   (:238-241)
-        if (xdt) VKN_TRY(vkn_launch_add2_half(sem_feats, loc_feats, x_feats, (size_t)B * C * P, xdt, st));
-        else VKN_TRY(vkn_launch_add2(sem_feats, loc_feats, x_feats, (size_t)B * C * P, st));
-        xf = x_feats;
-    } else if (x_feats && x_feats != loc_feats) {
-        if (hipMemcpyAsync(x_feats, loc_feats, (size_t)B * C * P * xes, hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return VKN_E_LAUNCH;
     }
     // obj_feats = einsum('bnhw,bchw->bnc', (sigmoid(mask_preds) > 0.5).float(), x_feats)   (use_binary)           (:243-250)
     const float* obj = nullptr;
@@ -1154,6 +1177,7 @@ int vkn_kernel_init_f32(const float* loc_feats, const float* sem_feats, const fl
             if (ref) return VKN_E_SHAPE;  // no exact-fp32 reference kernel for the soft weights
             VKN_TRY(vkn_launch_gather_soft(xf, mask_preds, thr_logit, s.obj, s.cnt, s.part, s.cntp, B, Np, C, P, N, st));
         } else if (ref) VKN_TRY(vkn_launch_gather_ref_ex(xf, mask_preds, thr_logit, s.obj, s.cnt, B, Np, C, P, N, st));
+        else if (one_pass) VKN_TRY(vkn_launch_gather_bits(xf, s.bits, s.obj, s.cnt, s.part, s.cntp, B, Np, C, P, st));
         else VKN_TRY(vkn_launch_gather_ex(xf, mask_preds, thr_logit, s.obj, s.cnt, s.part, s.cntp, B, Np, C, P, N, st, xdt));
         obj = s.obj;
     }

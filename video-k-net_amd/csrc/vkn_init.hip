@@ -94,3 +94,258 @@ int vkn_launch_init_finish(const float* init_w, const float* obj, const float* s
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- pass 0 as ONE pass over loc and sem
+// k_init_pass (round 6): the two 1x1 decodes (init_kernels . loc -> the Np thing logits, conv_seg . sem -> the ncls semantic logits),
+// x = loc + sem, the stuff rows of mask_preds (= seg_preds[num_thing:]) and the thresholded thing bits for the kernel-init gather —
+// one read of loc, one read of sem, one write of x (knet/det/kernel_head.py:222-257).  Before: k_decode_mfma(loc) + k_decode_mfma<NB=1>(sem)
+// + a 2-D copy + k_add2 (which alone moved 3.2 GB per 32 frames) + a logits gather that read x and the logits again: 231 MB per frame;
+// now 118 MB + the bit-word gather's read of x (34 MB).
+//
+// Structure = k_decode_mfma's (persistent 512-thread workgroup, kernel planes in LDS, a wave owns 64-px tiles as two interleaved 32-column
+// MFMA strips, feature fragments straight from global memory in MFMA B layout, 8-byte buffer loads) with a fragment PAIR per k-step:
+// the same 16 channels x 2 pixels of loc and of sem.  The 128 plane rows hold init_kernels in rows [0, Np) and conv_seg in rows
+// [Np, Np + ncls): a row multiplies ONE of the two sources, so n-blocks below SLO see the loc fragments only, and in the mixed n-blocks the
+// A fragment of the other source's rows is zeroed per lane (the accumulator then adds exact zeros: same bits as the separate decodes).
+// x = loc + sem is formed from the pair in registers and stored with the loads' addressing (256-byte segments per channel row).
+// NBL = n-blocks holding thing rows, [SLO, SHI] = n-blocks holding semantic rows — compile time (no branches around accumulators).
+typedef unsigned int ip_u32x2 __attribute__((ext_vector_type(2)));
+#define IP_THREADS 512
+#define IP_WAVES 8
+#define IP_TILE 64
+
+// logits of one 64-px tile -> their tensors: row < Np: mask_preds[b][row]; semantic row j = row - Np: seg_preds[b][j] (when wanted) and,
+// with cat_stuff_mask, mask_preds[b][Np + j - num_thing] for j >= num_thing                    knet/det/kernel_head.py:222, 231-234, 255-257
+// Buffer stores: n-blocks of thing rows only take the row offset in the SGPR operand (an opaque copy of P keeps the 64 row offsets from
+// being hoisted into 64 SGPRs, as in k_decode_mfma); in the mixed n-blocks the destination row is a per-lane byte offset, and a lane
+// whose row has no destination in a tensor stores to an offset past the buffer's range — dropped by the range check, no exec branches.
+template <int NB, int SLO>
+__device__ __forceinline__ void ip_store_tile(const f32x16 (&acc)[2][NB], const InitPassArgs& A, __amdgpu_buffer_rsrc_t mrs,
+                                              __amdgpu_buffer_rsrc_t srs, int p0, int li, int g, int Ntot) {
+    int Pq = A.P;
+    asm volatile("" : "+s"(Pq));
+    const int vst = ((4 * g) * Pq + 2 * li) << 2;
+    const unsigned oor = 0x7FFFFFF0u;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row0 = nb * 32 + (r & 3) + 8 * (r >> 2);   // this lane's row is row0 + 4 g
+            const ip_u32x2 v = {__float_as_uint(acc[0][nb][r]), __float_as_uint(acc[1][nb][r])};
+            if (nb < SLO) {
+                __builtin_amdgcn_raw_buffer_store_b64(v, mrs, vst, (row0 * Pq + p0) << 2, 0);
+            } else {
+                const int row = row0 + 4 * g, j = row - A.Np;
+                const int mrow = row < A.Np ? row : ((A.cat && row < Ntot && j >= A.nth) ? A.Np + j - A.nth : -1);
+                const unsigned vm = mrow >= 0 ? (unsigned)((mrow * Pq + p0 + 2 * li) << 2) : oor;
+                __builtin_amdgcn_raw_buffer_store_b64(v, mrs, (int)vm, 0, 0);
+                const unsigned vs = (j >= 0 && row < Ntot) ? (unsigned)((j * Pq + p0 + 2 * li) << 2) : oor;
+                __builtin_amdgcn_raw_buffer_store_b64(v, srs, (int)vs, 0, 0);
+            }
+        }
+}
+
+template <int NB>
+__device__ __forceinline__ void ip_emit_bits(const f32x16 (&acc)[2][NB], float thr, unsigned* __restrict__ wbase, int NPT, int lane) {
+    // (vkn_decode.hip dec_emit_bits: lane <- the words of its row; even / odd pixels of the 64-px tile)
+    constexpr int NH = (NB * 32 + 63) / 64;
+    int w[2][NH];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) w[t][h] = 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned long long m0 = __ballot(acc[0][nb][r] >= thr);
+            const unsigned long long m1 = __ballot(acc[1][nb][r] >= thr);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int row = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const bool mine = lane == (row & 63);
+                w[0][row >> 6] = mine ? (int)(unsigned)(m0 >> (32 * g)) : w[0][row >> 6];
+                w[1][row >> 6] = mine ? (int)(unsigned)(m1 >> (32 * g)) : w[1][row >> 6];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            if (h * 64 + lane < NB * 32) wbase[(size_t)t * NPT + h * 64 + lane] = (unsigned)w[t][h];
+}
+
+template <int NBL, int SLO, int SHI>
+__global__ __launch_bounds__(IP_THREADS, 2) void k_init_pass(const InitPassArgs A) {
+    constexpr int NB = (NBL > SHI + 1) ? NBL : SHI + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = A.C, P = A.P, LDK = C + 8, KS = C >> 4;
+    _Float16* ldsH = reinterpret_cast<_Float16*>(smem);
+    _Float16* ldsL = ldsH + NB * 32 * LDK;
+    float* kbs = reinterpret_cast<float*>(ldsL + NB * 32 * LDK);
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, li = lane & 31;
+    const int Ntot = A.Np + A.ncls;
+
+    const int p_begin = blockIdx.x * A.px_per_wg, p_end = min(P, p_begin + A.px_per_wg);
+    const int ntile = (p_end > p_begin) ? (p_end - p_begin) / IP_TILE : 0;      // P % 64 == 0, px_per_wg % 512 == 0: whole tiles
+    const int my = (ntile > wave) ? (ntile - wave + IP_WAVES - 1) / IP_WAVES : 0;
+    const int total = my * KS;
+
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.loc + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.sem + (size_t)b * C * P), 0, C * P * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(A.x_out + (size_t)b * C * P, 0, C * P * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(A.masks + (size_t)b * A.N * P, 0, A.N * P * 4, 0x00020000);
+    // (seg_preds not wanted: a zero-sized buffer — every store to it is dropped)
+    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(A.seg ? A.seg + (size_t)b * A.ncls * P : A.masks, 0,
+                                                                         A.seg ? A.ncls * P * 4 : 0, 0x00020000);
+
+    ip_u32x2 L0[8], S0[8], L1[8], S1[8];
+    int ld_ks = 0, ld_sl = 0, ld_cnt = 0, c_ks = 0, c_sl = 0;
+    const int voff = ((g << 3) * P + 2 * li) << 2;
+#define IP_LOAD(LR, SR)                                                                                      \
+    do {                                                                                                     \
+        const int soff_ = ((ld_ks << 4) * P + p_begin + (wave + IP_WAVES * ld_sl) * IP_TILE) << 2;           \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                      \
+            LR[e] = __builtin_amdgcn_raw_buffer_load_b64(lrs, voff, soff_ + ((e * P) << 2), 3);              \
+            SR[e] = __builtin_amdgcn_raw_buffer_load_b64(srs, voff, soff_ + ((e * P) << 2), 3);              \
+        }                                                                                                    \
+        const bool adv_ = (ld_cnt + 1 < total), wrap_ = (ld_ks + 1 == KS);                                   \
+        ld_cnt += adv_ ? 1 : 0;                                                                              \
+        ld_sl += (adv_ && wrap_) ? 1 : 0;                                                                    \
+        ld_ks = adv_ ? (wrap_ ? 0 : ld_ks + 1) : ld_ks;                                                      \
+    } while (0)
+
+    if (total > 0) IP_LOAD(L0, S0);   // the first pair is requested before the planes are staged (its latency runs under the staging)
+    {   // planes -> LDS (rows >= Np + ncls: zero), bias of the semantic rows
+        const int cpr = C >> 3;
+        for (int i = tid; i < NB * 32 * cpr; i += IP_THREADS) {
+            const int r = i / cpr, q = i - r * cpr;
+            half8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (r < Ntot) {
+                vh = *reinterpret_cast<const half8*>(A.kh + (size_t)r * C + q * 8);
+                vl = *reinterpret_cast<const half8*>(A.kl + (size_t)r * C + q * 8);
+            }
+            *reinterpret_cast<half8*>(ldsH + r * LDK + q * 8) = vh;
+            *reinterpret_cast<half8*>(ldsL + r * LDK + q * 8) = vl;
+        }
+        if (tid < NB * 32) kbs[tid] = (A.seg_b && tid >= A.Np && tid < Ntot) ? A.seg_b[tid - A.Np] : 0.f;
+        __syncthreads();
+    }
+    if (total == 0) return;
+
+    f32x16 acc[2][NB];
+    // rows of this lane in the mixed n-blocks: thing (multiplies loc) or semantic (multiplies sem)
+    bool thing_row[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) thing_row[nb] = (nb * 32 + li) < A.Np;
+    const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+
+#define IP_SPLIT(REG)                                                     \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                       \
+        _Float16 h_, l_;                                                  \
+        const unsigned u0_ = REG[e][0], u1_ = REG[e][1];                  \
+        vkn_split_f16(__uint_as_float(u0_), h_, l_);                      \
+        bh0[e] = h_; bl0[e] = l_;                                         \
+        vkn_split_f16(__uint_as_float(u1_), h_, l_);                      \
+        bh1[e] = h_; bl1[e] = l_;                                         \
+    }
+#define IP_MFMA6(AH, AL, NBI)                                                                      \
+    do {                                                                                           \
+        acc[0][NBI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bh0, acc[0][NBI], 0, 0, 0);       \
+        acc[1][NBI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bh1, acc[1][NBI], 0, 0, 0);       \
+        acc[0][NBI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bl0, acc[0][NBI], 0, 0, 0);       \
+        acc[1][NBI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bl1, acc[1][NBI], 0, 0, 0);       \
+        acc[0][NBI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, bh0, acc[0][NBI], 0, 0, 0);       \
+        acc[1][NBI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, bh1, acc[1][NBI], 0, 0, 0);       \
+    } while (0)
+
+#define IP_COMPUTE(LR, SR)                                                                                         \
+    do {                                                                                                           \
+        if (c_ks == 0) {                                                                                           \
+            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                      \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
+                    const float kb_ = kbs[nb * 32 + vkn_cd_row(r, lane)];                                          \
+                    acc[0][nb][r] = kb_;                                                                           \
+                    acc[1][nb][r] = kb_;                                                                           \
+                }                                                                                                  \
+        }                                                                                                          \
+        const int p0_ = p_begin + (wave + IP_WAVES * c_sl) * IP_TILE;                                              \
+        {   /* x = loc + sem for the pair's 16 channels x 2 pixels */                                              \
+            const int soff_ = ((c_ks << 4) * P + p0_) << 2;                                                        \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                        \
+                const ip_u32x2 v_ = {__float_as_uint(__uint_as_float(LR[e][0]) + __uint_as_float(SR[e][0])),       \
+                                     __float_as_uint(__uint_as_float(LR[e][1]) + __uint_as_float(SR[e][1]))};      \
+                __builtin_amdgcn_raw_buffer_store_b64(v_, xrs, voff, soff_ + ((e * P) << 2), 0);                   \
+            }                                                                                                      \
+        }                                                                                                          \
+        const int cb_ = (c_ks << 4) + (g << 3);                                                                    \
+        half8 bh0, bl0, bh1, bl1;                                                                                  \
+        IP_SPLIT(LR)                                                                                               \
+        _Pragma("unroll") for (int nb = 0; nb < NBL; ++nb) {                                                       \
+            const _Float16* ap_ = ldsH + (nb * 32 + li) * LDK + cb_;                                               \
+            half8 ah_ = *reinterpret_cast<const half8*>(ap_);                                                      \
+            half8 al_ = *reinterpret_cast<const half8*>(ap_ + NB * 32 * LDK);                                      \
+            if (nb >= SLO) { ah_ = thing_row[nb] ? ah_ : hz; al_ = thing_row[nb] ? al_ : hz; }                     \
+            IP_MFMA6(ah_, al_, nb);                                                                                \
+        }                                                                                                          \
+        IP_SPLIT(SR)                                                                                               \
+        _Pragma("unroll") for (int nb = SLO; nb <= SHI; ++nb) {                                                    \
+            const _Float16* ap_ = ldsH + (nb * 32 + li) * LDK + cb_;                                               \
+            half8 ah_ = *reinterpret_cast<const half8*>(ap_);                                                      \
+            half8 al_ = *reinterpret_cast<const half8*>(ap_ + NB * 32 * LDK);                                      \
+            ah_ = thing_row[nb] ? hz : ah_; al_ = thing_row[nb] ? hz : al_;                                        \
+            IP_MFMA6(ah_, al_, nb);                                                                                \
+        }                                                                                                          \
+        if (++c_ks == KS) {                                                                                        \
+            ip_store_tile<NB, SLO>(acc, A, mrs, ers, p0_, li, g, Ntot);                                            \
+            if (A.bits) ip_emit_bits<NB>(acc, A.thr, A.bits + ((size_t)b * (P >> 5) + ((p0_ >> 6) << 1)) * A.npt, A.npt, lane); \
+            c_ks = 0;                                                                                              \
+            ++c_sl;                                                                                                \
+        }                                                                                                          \
+    } while (0)
+
+    for (int f = 0; f < total; f += 2) {   // pairs double-buffered: the next pair's 16 loads are in flight behind this pair's 30 MFMA groups
+        IP_LOAD(L1, S1);
+        IP_COMPUTE(L0, S0);
+        if (f + 1 >= total) break;
+        IP_LOAD(L0, S0);
+        IP_COMPUTE(L1, S1);
+    }
+#undef IP_LOAD
+#undef IP_SPLIT
+#undef IP_MFMA6
+#undef IP_COMPUTE
+}
+
+// pass 0 in one pass (see k_init_pass): supported when every thing and semantic row fits the 128 plane rows in one of the built row maps
+int vkn_init_pass_supported(int Np, int ncls, int C, int P) {
+    if (Np <= 0 || ncls <= 0 || C % 16 != 0 || C > 256 || (P % 64) != 0) return 0;
+    if ((size_t)C * P * 4 >= ((size_t)1 << 31)) return 0;
+    const int nbl = (Np + 31) / 32, slo = Np / 32, shi = (Np + ncls - 1) / 32;
+    if (nbl == 4 && slo == 3 && shi == 3) return 1;     // Np in [97, 127], Np + ncls <= 128: 100 proposals + 19 classes (the STEP configs)
+    if (nbl == 1 && slo == 0 && shi == 0) return 2;     // everything in one n-block (the tiny goldens)
+    return 0;
+}
+int vkn_launch_init_pass(const InitPassArgs& a, int B, hipStream_t st) {
+    const int kind = vkn_init_pass_supported(a.Np, a.ncls, a.C, a.P);
+    if (!kind) return VKN_E_SHAPE;
+    InitPassArgs A = a;
+    long long ppx = ((long long)B * a.P + 255) / 256;      // one persistent workgroup per CU over the batch when it is large enough
+    A.px_per_wg = (int)((ppx + 511) / 512 * 512);
+    if (A.px_per_wg < 512) A.px_per_wg = 512;
+    const dim3 grid((a.P + A.px_per_wg - 1) / A.px_per_wg, B);
+    const int NB = kind == 1 ? 4 : 1;
+    const size_t lds = (size_t)2 * NB * 32 * (a.C + 8) * sizeof(_Float16) + (size_t)NB * 32 * sizeof(float);
+    if (kind == 1) {
+        VKN_ALLOW_FULL_LDS((k_init_pass<4, 3, 3>));
+        hipLaunchKernelGGL((k_init_pass<4, 3, 3>), grid, dim3(IP_THREADS), lds, st, A);
+    } else {
+        VKN_ALLOW_FULL_LDS((k_init_pass<1, 0, 0>));
+        hipLaunchKernelGGL((k_init_pass<1, 0, 0>), grid, dim3(IP_THREADS), lds, st, A);
+    }
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}

@@ -94,6 +94,19 @@ size_t vkn_split_w3_bytes(int Nout, int K);
 int vkn_launch_add2(const float* a, const float* b, float* out, size_t n, hipStream_t st);
 int vkn_launch_add2_half(const void* a, const void* b, void* out, size_t n, int xdt, hipStream_t st);  // 2-byte features (xdt 1 fp16, 2 bf16)
 int vkn_launch_add_rows(const float* a, const float* pos, float* out, size_t rows, int C, int period, hipStream_t st);
+// pass 0 in one pass over loc and sem (vkn_init.hip: k_init_pass)
+struct InitPassArgs {
+    const float *loc, *sem;
+    const _Float16 *kh, *kl;   // planes [128][C]: rows [0, Np) init_kernels, [Np, Np + ncls) conv_seg (f16 hi / lo split); the rest is not read
+    const float* seg_b;        // [ncls] or NULL
+    float *x_out, *masks, *seg;   // x [B][C][P]; mask_preds [B][N][P]; seg_preds [B][ncls][P] or NULL
+    unsigned* bits;            // [B][P/64][2][npt] thing bits (z >= thr) or NULL
+    float thr;
+    int Np, ncls, nth, cat, N, C, P, px_per_wg;
+    int npt;                   // row stride of the bit words = roundup(Np, 32)
+};
+int vkn_init_pass_supported(int Np, int ncls, int C, int P);
+int vkn_launch_init_pass(const InitPassArgs& a, int B, hipStream_t st);
 int vkn_launch_init_finish(const float* init_w, const float* obj, const float* seg_w, float* out, int B, int Np, int N, int nth,
                            int C, hipStream_t st);
 int vkn_launch_ffn_fused(const float* X, int ldx, const void* W1s, const float* b1, const void* W2s, int M, int C, int FF, int HS,

@@ -22,6 +22,7 @@ FLAG_CHAIN_PERSISTENT = 512  # ... always as the two persistent row-owner kernel
 FLAG_JOIN_EARLY = 32768     # head_forward: the side-stream link joins BEFORE the upsample (single-call latency; 1-3 % slower in throughput)
 FLAG_SCALED_F16 = 16384     # head_forward: the up-scaled logits as fp16 (vkn_upsample_bilinear_f16out)
 FLAG_CHAIN_BF16X3 = 65536   # ... the persistent kernels on the three-term bf16 split of rounds 2-4 (default since round 5: the two-term fp16 split, vkn_chain_h2.hip)
+FLAG_INIT_SEPARATE = 131072   # vkn_kernel_init_f32: the round-5 form of pass 0 (separate decodes + add + logits gather) instead of the one-pass kernel (A/B)
 FLAG_CHAIN_KSPLIT = 8192     # ... always as the few-row chain: column-spread GEMM phases, normalisation in the consumer (vkn_ksplit.hip)
 FLAG_SERIAL_LINK = 32   # tracking link on the caller's stream instead of the library's side stream (A/B; same results)
 
