@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VKN_VERSION 0x000500 /* 0.5.0: the persistent chain runs on the two-term fp16 split (VKN_FLAG_CHAIN_BF16X3 opts out; vkn_prepared_bytes grows by the
+#define VKN_VERSION 0x000600 /* 0.5.0: the persistent chain runs on the two-term fp16 split (VKN_FLAG_CHAIN_BF16X3 opts out; vkn_prepared_bytes grows by the
                               * fp16 weight images), the loss tail without target tensors (vkn_stage_targets ...), the backward glue entry points,
                               * vkn_sum_n_f32.  0.4.0: few-row chain (VKN_FLAG_CHAIN_KSPLIT), VKN_FLAG_SCALED_F16 + vkn_upsample_bilinear_f16out,
                               * VKN_FLAG_JOIN_EARLY, struct size probes */
@@ -372,6 +372,12 @@ int vkn_stage_forward_f32(const VknDims* d, const VknStageWeights* w, const floa
  *      previous frame), then one link call with prev[b] = cur[b-1].  ws: vkn_stage_workspace_bytes. */
 int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* cur_obj, const float* prev_obj,
                        float* track_out, void* ws, size_t ws_bytes, void* stream);
+/* the same with the CHAIN-FORM flags of the head call it completes (VKN_FLAG_CHAIN_KSPLIT / _LAUNCHES / _EXACT_GEMM): the library picks the
+ * link's arithmetic by row count, so a one-frame re-link after a multi-frame call (a rank's first frame against its neighbour's last
+ * kernels: video_k_net_amd/dist.py) would otherwise run another form than the in-call link of the other frames — fp32 rounding apart.
+ * Pass the flag of the form the B-frame call took (its row count decides: see INTEGRATION.md "batch size and bits"). */
+int vkn_track_link_flags_f32(const VknDims* d, const VknStageWeights* w, const float* cur_obj, const float* prev_obj,
+                             float* track_out, void* ws, size_t ws_bytes, unsigned flags, void* stream);
 
 /* ---- a previous-frame LINK BLOCK of the video head's last stage (knet/video/kernel_update_head.py:192-236, 324-476):
  *        kv  = w has kernel_update_conv.* ? KernelUpdator_w(update_feature, prev) : prev

@@ -42,7 +42,7 @@ SHAPES = [  # B, N, C, H, W
 def test_library_loaded_and_gpu_visible(vkn):
     assert torch.cuda.is_available()
     assert os.path.exists(vkn._lib.LIBPATH)
-    assert vkn._lib.lib().vkn_version() == 0x000500
+    assert vkn._lib.lib().vkn_version() == 0x000600
 
 
 @pytest.mark.parametrize('flags', [0, 1], ids=['mfma', 'refkernels'])
@@ -1473,8 +1473,9 @@ def test_block_step_with_neighbour_link_equals_whole_clip(vkn, chain):
     """bench.py --gpus N: every rank runs its contiguous block of the clip as ONE call with the in-call clip link and re-links only
     its frame 0 to the previous rank's last kernels (dist.neighbour_last_kernels).  Emulated on one GPU with two blocks: every
     output of the two block steps equals the whole-clip call — BIT FOR BIT when both run the same form of the [N x C] chain (every
-    form is row-independent with a fixed summation order: batch-invariant), to fp32 rounding when the row-count policy gives the
-    blocks (11 row tiles: few-row chain) another form than the whole clip (22 row tiles: one launch per GEMM)."""
+    form is row-independent with a fixed summation order: batch-invariant; the one-frame re-link is pinned to the call's form through
+    vkn_track_link_flags_f32), to fp32 rounding when the row-count policy gives the blocks (11 row tiles: few-row chain)
+    another form than the whole clip (22 row tiles: one launch per GEMM)."""
     _, case = load_golden('video_cfg')
     head, _ = _build_head(vkn, case)
     T, N, C, H, W = 6, case['N'], case['C'], case['H'], case['W']
@@ -1493,7 +1494,7 @@ def test_block_step_with_neighbour_link_equals_whole_clip(vkn, chain):
         out = vkn.ops.head_forward(mk(b1 - b0, N, H, W), packs, xs[b0:b1], pfs[b0:b1], mps[b0:b1], None, case['up'],
                                    clip_first_prev=first, flags=fl)
         if r > 0:   # what rank r does after the neighbour hand-over
-            out[4][0:1].copy_(vkn.ops.track_link(mk(1, N, H, W), packs[-1], out[0][0:1], prev_last))
+            out[4][0:1].copy_(vkn.ops.track_link(mk(1, N, H, W), packs[-1], out[0][0:1], prev_last, flags=fl))   # pinned to the call's form
         prev_last = out[0][-1:].clone()
         blocks.append(out)
     for k in range(5):
@@ -1502,12 +1503,6 @@ def test_block_step_with_neighbour_link_equals_whole_clip(vkn, chain):
             # two forms of the chain: the teacher-forced distance (2e-5 relative per stage) grows through three free-running stages only
             # where a near-threshold mask bit flips; this small case (16x32 features) has none
             assert maxabs(got, whole[k]) < 2e-4 * max(1.0, float(whole[k].abs().max())), k
-        elif chain == 'launches' and k == 4:
-            # vkn_track_link_f32 carries no flags: the one-frame re-link of block 1's first frame follows the row-count policy (few-row
-            # kernels) while the whole clip's in-call link was forced onto the launch-per-GEMM kernels — that frame to fp32 rounding
-            keep = torch.ones(T, dtype=torch.bool)
-            keep[h] = False
-            assert torch.equal(got[keep], whole[k][keep]) and maxabs(got[h], whole[k][h]) < 2e-5 * max(1.0, float(whole[k].abs().max())), k
         else:
             assert torch.equal(got, whole[k]), k
 

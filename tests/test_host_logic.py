@@ -98,7 +98,7 @@ def test_library_exports_every_declared_symbol(vkn):
     for sym in declared:
         assert getattr(L, sym) is not None
     L2 = vkn._lib.lib()
-    assert L2.vkn_version() == 0x000500
+    assert L2.vkn_version() == 0x000600
     assert L2.vkn_strerror(0) == b'ok' and b'workspace' in L2.vkn_strerror(-3)
     assert L2.vkn_sizeof_dims() == ctypes.sizeof(vkn._lib.VknDims)
     assert L2.vkn_sizeof_stage_weights() == ctypes.sizeof(vkn._lib.VknStageWeights)

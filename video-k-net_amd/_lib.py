@@ -18,7 +18,7 @@ MAX_FCS = 4
 SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_workspace_init', 'vkn_workspace_status', 'vkn_sizeof_dims', 'vkn_sizeof_stage_weights', 'vkn_gather_workspace_bytes', 'vkn_mask_gather_f32', 'vkn_mask_gather_real_f32',
            'vkn_decode_workspace_bytes', 'vkn_mask_decode_f32', 'vkn_mask_decode_scaled_f32', 'vkn_split_planes_f32', 'vkn_mask_decode_planes_f32',
            'vkn_decode_gather_supported', 'vkn_decode_gather_f32', 'vkn_mask_decode_planes_x', 'vkn_decode_gather_x',
-           'vkn_track_link_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_split_weight_t_f32', 'vkn_sizeof_split_item', 'vkn_split_weights_batch_f32', 'vkn_linear_dw_f32', 'vkn_sizeof_dw_item', 'vkn_sizeof_updator_norms', 'vkn_sizeof_updator_norm_grads', 'vkn_linear_dw_batch_f32', 'vkn_layernorm_act_fwd_f32', 'vkn_layernorm_act_bwd_f32', 'vkn_updator_gate_product_f32', 'vkn_updator_gate_product_bwd_f32', 'vkn_updator_mix_fwd_f32', 'vkn_updator_mix_bwd_f32', 'vkn_attention_f32', 'vkn_attention_bwd_f32', 'vkn_upsample_bilinear_f32', 'vkn_upsample_bilinear_f16out', 'vkn_upsample_bilinear_bwd_f32', 'vkn_kernel_updator_f32',
+           'vkn_track_link_f32', 'vkn_track_link_flags_f32', 'vkn_prepared_bytes', 'vkn_prepare_stage_f32', 'vkn_split_weight_f32', 'vkn_linear_f32', 'vkn_split_weight_t_f32', 'vkn_sizeof_split_item', 'vkn_split_weights_batch_f32', 'vkn_linear_dw_f32', 'vkn_sizeof_dw_item', 'vkn_sizeof_updator_norms', 'vkn_sizeof_updator_norm_grads', 'vkn_linear_dw_batch_f32', 'vkn_layernorm_act_fwd_f32', 'vkn_layernorm_act_bwd_f32', 'vkn_updator_gate_product_f32', 'vkn_updator_gate_product_bwd_f32', 'vkn_updator_mix_fwd_f32', 'vkn_updator_mix_bwd_f32', 'vkn_attention_f32', 'vkn_attention_bwd_f32', 'vkn_upsample_bilinear_f32', 'vkn_upsample_bilinear_f16out', 'vkn_upsample_bilinear_bwd_f32', 'vkn_kernel_updator_f32',
            'vkn_stage_workspace_bytes', 'vkn_stage_forward_f32', 'vkn_stage_chain_f32', 'vkn_head_workspace_bytes', 'vkn_head_forward_f32', 'vkn_focal_loss_blocks', 'vkn_focal_loss_f32',
            'vkn_head_forward_prof_f32', 'vkn_head_forward_link_f32', 'vkn_stage_forward_link_f32', 'vkn_link_block_f32',
            'vkn_query_merge_workspace_bytes', 'vkn_query_merge_f32',
@@ -292,6 +292,8 @@ def lib():
     L.vkn_decode_gather_f32.argtypes = [_fp, _fp, _fp, _fp, c_float, _fp, _fp, c_int, c_int, c_int, c_int, _fp, c_size, _fp]
     L.vkn_track_link_f32.restype = c_int
     L.vkn_track_link_f32.argtypes = [pD, pW, _fp, _fp, _fp, _fp, c_size, _fp]
+    L.vkn_track_link_flags_f32.restype = c_int
+    L.vkn_track_link_flags_f32.argtypes = [pD, pW, _fp, _fp, _fp, _fp, c_size, c_uint, _fp]
     L.vkn_upsample_bilinear_f32.restype = c_int
     L.vkn_upsample_bilinear_f32.argtypes = [_fp, _fp, c_int, c_int, c_int, c_int, _fp]
     L.vkn_upsample_bilinear_f16out.restype = c_int

@@ -1065,6 +1065,11 @@ int vkn_decode_gather_x(const void* xv, int x_dtype, const void* kf_hi, const vo
 
 int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* cur_obj, const float* prev_obj,
                        float* track_out, void* ws, size_t ws_bytes, void* stream) {
+    return vkn_track_link_flags_f32(d, w, cur_obj, prev_obj, track_out, ws, ws_bytes, 0u, stream);
+}
+
+int vkn_track_link_flags_f32(const VknDims* d, const VknStageWeights* w, const float* cur_obj, const float* prev_obj,
+                             float* track_out, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
     VKN_TRY(check_dims(d));
     if (!w || !cur_obj || !prev_obj || !track_out) return VKN_E_ARG;
     if (!aligned16(cur_obj) || !aligned16(prev_obj) || !aligned16(track_out)) return VKN_E_ALIGN;
@@ -1078,7 +1083,7 @@ int vkn_track_link_f32(const VknDims* d, const VknStageWeights* w, const float* 
         if (carve_prepared(d, w, static_cast<char*>(const_cast<void*>(w->prepared)), &pw, items, nullptr) > w->prepared_bytes)
             return VKN_E_WORKSPACE;
     }
-    return run_link(d, w, pw, cur_obj, prev_obj, track_out, s, static_cast<hipStream_t>(stream));
+    return run_link(d, w, pw, cur_obj, prev_obj, track_out, s, static_cast<hipStream_t>(stream), nullptr, flags);
 }
 
 int vkn_upsample_bilinear_f32(const float* in, float* out, int planes, int H, int W, int S, void* stream) {

@@ -576,17 +576,18 @@ def decode_gather(x, hi, lo, N, bias=None, hard_mask_thr=0.5):
     return xraw, cnt
 
 
-def track_link(dims: VknDims, pack: StagePack, cur_obj, prev_obj):
+def track_link(dims: VknDims, pack: StagePack, cur_obj, prev_obj, flags=0):
     """Tracking embedding of the video head's last stage for a batch of (cur, prev) kernel sets:
-    knet/video/kernel_update_head.py:394-415.  cur_obj, prev_obj [B,N,C] -> [B,N,C]."""
+    knet/video/kernel_update_head.py:394-415.  cur_obj, prev_obj [B,N,C] -> [B,N,C].  `flags`: FLAG_CHAIN_KSPLIT / _LAUNCHES pin the
+    link's arithmetic to the form a larger call took (a hand-over re-link of one frame; include/vkn.h: vkn_track_link_flags_f32)."""
     cur, prev = _req(cur_obj, 'cur_obj'), _req(prev_obj, 'prev_obj')
     L = _lib.lib()
     pack.ensure_prepared(dims)
     out = torch.empty_like(cur)
     ws = _workspace(max(L.vkn_stage_workspace_bytes(ctypes.byref(dims)), 256), cur.device)
     with torch.cuda.device(cur.device):
-        check(L.vkn_track_link_f32(ctypes.byref(dims), ctypes.byref(pack.w), _ptr(cur), _ptr(prev), _ptr(out), _ptr(ws),
-                                   ws.numel(), _stream()))
+        check(L.vkn_track_link_flags_f32(ctypes.byref(dims), ctypes.byref(pack.w), _ptr(cur), _ptr(prev), _ptr(out), _ptr(ws),
+                                         ws.numel(), int(flags), _stream()))
     return out
 
 
