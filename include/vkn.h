@@ -670,6 +670,14 @@ int vkn_mask_losses_bwd_bank_f32(const float* pred, const float* bank, const int
                                  const float* dice_bc, const float* g_mask, const float* g_dice, const float* g_rank, float w_mask,
                                  float w_dice, float w_rank, int K, const float* lse, const int* top, int B, int Ns, int P,
                                  int with_rank, float* grad, void* stream);
+/* ... and WITHOUT the up-scaled gradient tensor (round 6): the predictions are the LOW-RES logits `low` [B][Ns][h][w]; the losses were taken on
+ * their xS bilinear up-scaling (S = 2 or 4; F.interpolate(scale_factor=S, bilinear, align_corners=False), knet/det/kernel_iter_head.py:122-130)
+ * against bank masks of [S h][S w]; grad_low [B][Ns][h][w] = d(sum of the weighted losses) / d low — the composition of
+ * vkn_mask_losses_bwd_bank_f32 and vkn_upsample_bilinear_bwd_f32 in one pass (the [B Ns][S h][S w] gradient is never written). */
+int vkn_mask_losses_bwd_lowres_f32(const float* low, const float* bank, const int* tgt_row, const int* rowk, const float* dice_a,
+                                   const float* dice_bc, const float* g_mask, const float* g_dice, const float* g_rank, float w_mask,
+                                   float w_dice, float w_rank, int K, const float* lse, const int* top, int B, int Ns, int h, int w, int S,
+                                   int with_rank, float* grad_low, void* stream);
 int vkn_scale_by_f32(const float* in, const float* g, const float* d, float host_scale, float* out, size_t n, void* stream);
 int vkn_check_range_i64(const long long* v, size_t n, long long lo, long long hi, int flag, int* status, void* stream);
 

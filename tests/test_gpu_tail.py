@@ -82,9 +82,9 @@ def test_stage_targets_equal_get_targets_bit_for_bit(vkn):
     seen = {}
     orig = tt.StageTailFn.apply
 
-    def spy(cls_score, scaled, t):
+    def spy(cls_score, scaled, t, *rest):
         seen['t'] = t
-        return orig(cls_score, scaled, t)
+        return orig(cls_score, scaled, t, *rest)
     tt.StageTailFn.apply = spy
     try:
         assert tail.stage_ok(mh, res, cls, masks)
@@ -149,6 +149,42 @@ def test_repeated_stuff_class_is_reported_and_too_many_stuff_targets_decline_the
     head.forward_train(x.to(DEV), pf.to(DEV), mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=many_seg, gt_sem_cls=many_cls)
     assert not head._last_tail_fused
     mha.FLAGS.poll(wait=True)
+
+
+@pytest.mark.parametrize('name', ['train_video', 'train_cfg', 'train_video_c256'])
+def test_lowres_tail_backward_equals_the_upscaled_gradient_plus_adjoint(vkn, name):
+    """Round 6 (self-comparison): the fused tail's backward straight into the low-res logits (vkn_mask_losses_bwd_lowres_f32: a thread re-forms
+    its S x S block of up-scaled logits, takes the three losses' gradient there and folds it back with the separable adjoint) against the
+    form it replaces — the gradient w.r.t. the up-scaled predictions (vkn_mask_losses_bwd_bank_f32) followed by the upsample's adjoint:
+    same losses bit for bit, gradients to fp32 summation order (x2 and x4, with / without the video link).  Both forms meet the
+    reference goldens in test_gpu_train.py."""
+    outs = []
+    for low in (True, False):
+        g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, name)
+        head.lowres_tail = low
+        xd, pfd = x.to(DEV).requires_grad_(True), pf.to(DEV).requires_grad_(True)
+        metas = [dict() for _ in range(case['B'])]
+        if case['video']:
+            out = head.forward_train_with_previous(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                                   gt_sem_cls=gt_sem_cls, previous_obj_feats=prev.to(DEV))
+            losses, last_scaled = out[0], out[4]
+        else:
+            losses, last_scaled = head.forward_train(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                                     gt_sem_cls=gt_sem_cls), None
+        assert head._last_tail_fused
+        total = sum(v for k, v in losses.items() if 'loss' in k)
+        if last_scaled is not None:      # a consumer of the RETURNED up-scaled tensor still reaches the logits (LazyUpsampleFn)
+            assert last_scaled.requires_grad
+            total = total + 1e-3 * (last_scaled ** 2).mean()
+        total.backward()
+        outs.append(({k: float(v.detach()) for k, v in losses.items()}, xd.grad.clone(), pfd.grad.clone(),
+                     {k: p.grad.clone() for k, p in head.named_parameters() if p.grad is not None}))
+    (la, xa, pa, ga), (lb, xb, pb, gb) = outs
+    assert la == lb
+    assert maxabs(xa, xb) < 2e-5 * float(xb.abs().max()) and maxabs(pa, pb) < 2e-5 * float(pb.abs().max())
+    assert sorted(ga) == sorted(gb)
+    for k in gb:
+        assert maxabs(ga[k], gb[k]) < 2e-5 * max(float(gb[k].abs().max()), 1e-12), k
 
 
 def test_backward_glue_kernels_vs_torch(vkn):

@@ -340,3 +340,27 @@ def focal_loss(logits, labels, row_weight, loss_weight, avg_factor, alpha, gamma
     else:
         scale = torch.full((), float(loss_weight) / float(avg_factor), dtype=torch.float32, device=logits.device)
     return FocalLossFn.apply(logits, labels, row_weight, scale, alpha, gamma)
+
+
+class LazyUpsampleFn(torch.autograd.Function):
+    """`values` ARE upsample_bilinear(x, stride) (computed without a graph); backward = the upsample's adjoint.  Lets a consumer that
+    differentiates w.r.t. x itself (the low-res loss tail) use the values while any other consumer of the returned tensor still
+    back-propagates to x."""
+
+    @staticmethod
+    def forward(ctx, x, values, stride):
+        ctx.stride = stride
+        ctx.set_materialize_grads(False)
+        return values.view_as(values)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        return ops.upsample_bilinear_bwd(g.contiguous(), ctx.stride), None, None
+
+
+def lazy_upsample(x, values, stride):
+    out = LazyUpsampleFn.apply(x, values, stride)
+    out._vkn_lowres = x          # (kernel_iter_head._train_stages: these values belong to exactly this low-res tensor)
+    return out

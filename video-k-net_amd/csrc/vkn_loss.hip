@@ -224,6 +224,142 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
     gin[(size_t)plane * H * W + idx] = acc;
 }
 
+// ---- the mask-loss backward pass WITHOUT the xS gradient tensor (round 6): d(losses) / d(low-res mask logits) in one kernel.
+// k_ml_bwd writes the gradient w.r.t. the up-scaled predictions ([B Ns][S h][S w]: 981 MB per stage at the shipped x4 and four 1024x2048
+// frames) and the upsample adjoint reads it back; here a thread owns one low-res pixel's S x S block of up-scaled pixels: it re-forms
+// their logits from the 3 x 3 low-res neighbourhood (the forward kernel's source-index / weight formulas, so every border case agrees),
+// evaluates the gradient of the three losses there (k_ml_bwd's expressions), and folds the S x S values into the nine low-res
+// neighbours with the SEPARABLE adjoint weights.  The nine partial sums meet their owners through a wave shift (columns) and one LDS
+// exchange per kernel row (block rows = waves): fixed order, deterministic.  lse / top / targets of the block are loaded once and the
+// kernel rows n are walked in registers, so the only x S-sized reads are the rank loss's lse / top (8 bytes per pixel) and the
+// positive rows' targets.  Workgroup = LR_NW waves (block rows i0 - 1 .. i0 + LR_NW - 2) x 64 lanes (columns j0 - 1 .. j0 + 62): the
+// outer ring only feeds its neighbours.
+#define LR_NW 8
+template <int S>
+__global__ __launch_bounds__(64 * LR_NW) void k_ml_bwd_lr(const float* __restrict__ low, const float* __restrict__ bank,
+                                                          const int* __restrict__ rowk, const float* __restrict__ lse,
+                                                          const int* __restrict__ top, int Ns, int h, int w, int with_rank,
+                                                          float* __restrict__ grad_low, const MlTail tl) {
+    __shared__ float xch[2][LR_NW][2][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    const int i = (int)blockIdx.y * (LR_NW - 2) - 1 + wv, j = (int)blockIdx.x * 62 - 1 + lane;
+    const bool blk = i >= 0 && i < h && j >= 0 && j < w;        // this thread's block exists
+    const bool own = blk && wv >= 1 && wv <= LR_NW - 2 && lane >= 1 && lane <= 62;   // ... and its low-res pixel is written here
+    const int H = S * h, W = S * w;
+    const size_t P = (size_t)H * W, lp = (size_t)h * w;
+    const float cm = tl.g_mask ? tl.g_mask[0] * tl.c_mask : 0.f;
+    const float cr = (with_rank && tl.g_rank) ? tl.g_rank[0] * tl.c_rank : 0.f;
+    const float gd = tl.g_dice ? tl.g_dice[0] * tl.c_dice : 0.f;
+    // weights of the block's S output rows / columns on the three low-res rows i - 1, i, i + 1 (columns j - 1, j, j + 1)
+    float wy[S][3], wx[S][3];
+    constexpr float rs = 1.0f / (float)S;
+#pragma unroll
+    for (int a = 0; a < S; ++a) {
+        {
+            const float sy = fmaxf(((float)(S * i + a) + 0.5f) * rs - 0.5f, 0.f);
+            const int y0 = min((int)sy, h - 1), y1 = min(y0 + 1, h - 1);
+            const float ly = sy - (float)y0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) wy[a][r] = (y0 == i - 1 + r ? 1.f - ly : 0.f) + (y1 == i - 1 + r ? ly : 0.f);
+        }
+        {
+            const float sx = fmaxf(((float)(S * j + a) + 0.5f) * rs - 0.5f, 0.f);
+            const int x0 = min((int)sx, w - 1), x1 = min(x0 + 1, w - 1);
+            const float lx = sx - (float)x0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wx[a][c] = (x0 == j - 1 + c ? 1.f - lx : 0.f) + (x1 == j - 1 + c ? lx : 0.f);
+        }
+    }
+    // clamped source coordinates (weights of coordinates outside the map are zero)
+    const int ic = min(max(i, 0), h - 1), jc = min(max(j, 0), w - 1);
+    int ro[3], co[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { ro[r] = min(max(ic - 1 + r, 0), h - 1) * w; co[r] = min(max(jc - 1 + r, 0), w - 1); }
+    // lse / top of the block's pixels (the frame's, shared by every kernel row)
+    float l[S][S];
+    int tp[S][S];
+    const size_t pix0 = (size_t)(S * ic) * W + (size_t)S * jc;
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+        for (int c = 0; c < S; ++c) {
+            l[a][c] = with_rank ? lse[(size_t)b * P + pix0 + (size_t)a * W + c] : 0.f;
+            tp[a][c] = with_rank ? top[(size_t)b * P + pix0 + (size_t)a * W + c] : -1;
+        }
+    for (int n = 0; n < Ns; ++n) {
+        const float* lr = low + ((size_t)b * Ns + n) * lp;
+        float v[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[r][c] = lr[ro[r] + co[c]];
+        const int k = rowk[b * Ns + n];   // uniform
+        float ca = 0.f, cb = 0.f;
+        const float* trow = nullptr;
+        if (k >= 0) {
+            const float a_ = tl.dice_a[k], bc = tl.dice_bc[k];
+            ca = gd * (-2.0f / bc);
+            cb = gd * (4.0f * a_ / (bc * bc));
+            trow = bank + (size_t)tl.tgt_row[b * Ns + n] * P + pix0;
+        }
+        // horizontal pass of the forward interpolation: hx[r][c'] = the three low-res rows at the block's S output columns
+        float hx[3][S];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < S; ++c) hx[r][c] = (v[r][0] * wx[c][0] + v[r][1] * wx[c][1]) + v[r][2] * wx[c][2];
+        float ps[3][3];   // partial sums for low-res (i - 1 + r, j - 1 + c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ps[r][c] = 0.f;
+#pragma unroll
+        for (int a = 0; a < S; ++a) {
+            float g[S];
+#pragma unroll
+            for (int c = 0; c < S; ++c) {
+                const float z = (hx[0][c] * wy[a][0] + hx[1][c] * wy[a][1]) + hx[2][c] * wy[a][2];
+                float gv = 0.f;
+                if (tp[a][c] >= 0) gv = cr * (__expf(z - l[a][c]) - (tp[a][c] == n ? 1.f : 0.f));
+                if (k >= 0) {
+                    const float t = trow[(size_t)a * W + c];
+                    const float pp = 1.0f / (1.0f + __expf(-z));
+                    gv += cm * (pp - t) + (ca * t + cb * pp) * pp * (1.f - pp);
+                }
+                g[c] = blk ? gv : 0.f;
+            }
+            // adjoint, columns first: cs[c3] = sum over the row's S pixels of wx * g; then this output row's share of the three low-res rows
+            float cs[3];
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < S; ++c) acc += wx[c][c3] * g[c];
+                cs[c3] = acc;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) ps[r][c3] += wy[a][r] * cs[c3];
+        }
+        // columns: low-res column j collects ps[.][1] of its own block, ps[.][0] of the block to its right, ps[.][2] of the one to its left
+        float hr[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) hr[r] = (ps[r][1] + __shfl_down(ps[r][0], 1)) + __shfl_up(ps[r][2], 1);
+        // rows: low-res row i collects hr[1] of its own block row, hr[0] of the block row below, hr[2] of the one above
+        float* xb = &xch[n & 1][0][0][0];
+        xb[(wv * 2 + 0) * 64 + lane] = hr[0];
+        xb[(wv * 2 + 1) * 64 + lane] = hr[2];
+        __syncthreads();
+        if (own) {
+            const float out = (hr[1] + xb[((wv + 1) * 2 + 0) * 64 + lane]) + xb[((wv - 1) * 2 + 1) * 64 + lane];
+            grad_low[((size_t)b * Ns + n) * lp + (size_t)i * w + j] = out;
+        }
+    }
+}
+
 // Sigmoid focal loss (mmdet FocalLoss(use_sigmoid=True): py_sigmoid_focal_loss, the classification loss of every shipped config) over
 // logits [M][ncls] with integer labels [M] (label == ncls or out of range = background: an all-zero target row) and optional
 // per-row [M] or per-element [M][ncls] weights: element loss = w_row * bce(z, t) * (alpha t + (1 - alpha)(1 - t)) * pt^gamma, pt = (1 - p) t + p (1 - t).
@@ -819,6 +955,24 @@ int vkn_mask_losses_bwd_bank_f32(const float* pred, const float* bank, const int
                  (float)((double)w_dice / (double)K), (float)((double)w_rank / ((double)B * (double)P))};
     hipLaunchKernelGGL(k_ml_bwd, dim3((P / 4 + 255) / 256, B, 4), dim3(256), 0, static_cast<hipStream_t>(stream), pred, bank, rowk,
                        (const float*)nullptr, (const float*)nullptr, lse, top, Ns, P, with_rank, grad, tl);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_mask_losses_bwd_lowres_f32(const float* low, const float* bank, const int* tgt_row, const int* rowk, const float* dice_a,
+                                   const float* dice_bc, const float* g_mask, const float* g_dice, const float* g_rank, float w_mask,
+                                   float w_dice, float w_rank, int K, const float* lse, const int* top, int B, int Ns, int h, int w, int S,
+                                   int with_rank, float* grad_low, void* stream) {
+    if (!low || !bank || !tgt_row || !rowk || !dice_a || !dice_bc || !grad_low || B <= 0 || Ns <= 0 || h <= 0 || w <= 0 || K <= 0) return VKN_E_ARG;
+    if (with_rank && (!lse || !top)) return VKN_E_ARG;
+    if (S != 2 && S != 4) return VKN_E_SHAPE;
+    const double P = (double)S * h * (double)S * w;
+    MlTail tl = {tgt_row, dice_a, dice_bc, g_mask, g_dice, g_rank, (float)((double)w_mask / ((double)K * P)),
+                 (float)((double)w_dice / (double)K), (float)((double)w_rank / ((double)B * P))};
+    const dim3 grid((w + 61) / 62, (h + LR_NW - 3) / (LR_NW - 2), B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (S == 4) hipLaunchKernelGGL(k_ml_bwd_lr<4>, grid, dim3(64 * LR_NW), 0, st, low, bank, rowk, lse, top, Ns, h, w, with_rank, grad_low, tl);
+    else hipLaunchKernelGGL(k_ml_bwd_lr<2>, grid, dim3(64 * LR_NW), 0, st, low, bank, rowk, lse, top, Ns, h, w, with_rank, grad_low, tl);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }

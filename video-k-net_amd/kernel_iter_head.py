@@ -107,10 +107,17 @@ class KernelIterHead(BaseRoIHead):
         return dict(cls_score=cls_score, mask_preds=mask_preds, scaled_mask_preds=scaled_mask_preds,
                     object_feats=object_feats)
 
-    @staticmethod
-    def _upsample(mask_preds, stride):
+    _lowres_tail_step = False     # set by `_train_stages` for the duration of a step that runs the low-res loss tail
+
+    def _upsample(self, mask_preds, stride):
         """`F.interpolate(mask_preds, scale_factor=stride, bilinear, align_corners=False)` (reference :122-130): the HIP kernel; under
         autograd the same kernel with its adjoint as backward."""
+        if self._lowres_tail_step and mask_preds.requires_grad and torch.is_grad_enabled():
+            # the fused loss tail differentiates w.r.t. the LOW-RES logits itself (train_tail.py, vkn_mask_losses_bwd_lowres_f32): the
+            # up-scaled values carry no graph of their own — but whoever back-propagates through the RETURNED tensor (nobody in the
+            # reference: the detector takes boxes from it) still reaches the logits: `LazyUpsampleFn` = these values + the adjoint
+            from . import autograd as vag
+            return vag.lazy_upsample(mask_preds, ops.upsample_bilinear(mask_preds.detach(), stride), stride)
         if mask_preds.requires_grad and torch.is_grad_enabled():
             from . import autograd as vag
             if mask_preds.is_cuda and mask_preds.dtype == torch.float32 and mask_preds.dim() == 4:
@@ -192,6 +199,7 @@ class KernelIterHead(BaseRoIHead):
 
     x_hub = not __import__('os').environ.get('VKN_NO_XHUB')     # (A/B switch of autograd.x_hub)
     fused_tail = True     # False: per-image sampler -> get_targets -> loss, op by op (A/B; taken anyway whenever train_tail.TailStep declines)
+    lowres_tail = True    # the fused tail's backward pass straight into the low-res logits (False: x`up` gradient + upsample adjoint, A/B)
 
     def _train_stages(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, imgs_whwh=None,
                       gt_sem_seg=None, gt_sem_cls=None, stage_kwargs=None):
@@ -221,6 +229,9 @@ class KernelIterHead(BaseRoIHead):
         if tail is not None:
             gt_masks = tail.gt_views
         self._last_tail_fused = tail is not None     # (tests / bench: did the step's EVERY stage run the fused tail?)
+        # the low-res form of the tail's backward (no x`up` gradient tensor, no upsample adjoint): strides 2 / 4, plain fp32 CUDA logits
+        lowres = tail is not None and self.lowres_tail and up in (2, 4) and mask_preds.is_cuda and mask_preds.dtype == torch.float32
+        self._lowres_tail_step = bool(lowres)
         if self.mask_assigner and hasattr(self.mask_assigner[0], 'validate_labels'):
             # the labels do not change between stages: one range check for the whole step (on the device, reported asynchronously)
             if tail is not None:
@@ -240,7 +251,11 @@ class KernelIterHead(BaseRoIHead):
             stage_losses = None
             if tail is not None and scaled_mask_preds.shape[1] == self.num_proposals + (head.num_stuff_classes if tail.with_sem else 0) \
                     and tail.stage_ok(head, assign_results, cls_score, scaled_mask_preds):
-                stage_losses = tail.stage_losses(head, self.train_cfg[stage], assign_results, cls_score, scaled_mask_preds)
+                if lowres and getattr(scaled_mask_preds, '_vkn_lowres', None) is mask_preds:
+                    stage_losses = tail.stage_losses(head, self.train_cfg[stage], assign_results, cls_score, scaled_mask_preds, lowres=mask_preds,
+                                                     stride=up)
+                else:
+                    stage_losses = tail.stage_losses(head, self.train_cfg[stage], assign_results, cls_score, scaled_mask_preds)
             if stage_losses is None:
                 self._last_tail_fused = False
                 sampler = self.mask_sampler[stage]
@@ -253,6 +268,7 @@ class KernelIterHead(BaseRoIHead):
                 all_stage_loss[f's{stage}_{key}'] = value if w == 1 else value * w      # (x * 1 == x: no launch, no autograd node)
             if not self.post_assign:
                 assign_masks, assign_cls = scaled_mask_preds.detach(), cls_score.detach()
+        self._lowres_tail_step = False
         if tail is not None:
             tail.finish()
         if self.mask_assigner and hasattr(self.mask_assigner[0], 'check_status'):

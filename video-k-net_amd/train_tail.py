@@ -137,8 +137,11 @@ class TailStep:
                 and len(assign_results) == self.B and all(getattr(r, '_pairs32', None) is not None for r in assign_results)
                 and scaled.shape[1] > (head.num_stuff_classes if self.with_sem else 0))
 
-    def stage_losses(self, head, cfg, assign_results, cls_score, scaled):
-        """-> dict(loss_cls, pos_acc, loss_mask, loss_dice[, loss_rank]) of one stage: the values of `head.loss(..., *head.get_targets(...))`."""
+    def stage_losses(self, head, cfg, assign_results, cls_score, scaled, lowres=None, stride=1):
+        """-> dict(loss_cls, pos_acc, loss_mask, loss_dice[, loss_rank]) of one stage: the values of `head.loss(..., *head.get_targets(...))`.
+        `lowres` (round 6): the stage's LOW-RES mask logits [B, Ns, h, w] under autograd, `scaled` their x`stride` up-scaling WITHOUT a graph
+        (ops.upsample_bilinear of the detached logits): the losses are taken on `scaled`, the gradient goes straight to `lowres`
+        (vkn_mask_losses_bwd_lowres_f32) — the up-scaled gradient tensor and the upsample's backward pass do not exist."""
         B, Ns = scaled.shape[:2]
         S, T = (head.num_stuff_classes, head.num_thing_classes) if self.with_sem else (0, 0)
         N, ncls = Ns - S, head.num_classes
@@ -177,7 +180,11 @@ class TailStep:
                                 float(head.loss_dice.eps), float(lr.loss_weight) if lr is not None else 0.0, t.avg_host,
                                 1 if lr is not None else 0)
         t.alpha, t.gamma = float(head.loss_cls.alpha), float(head.loss_cls.gamma)
-        l_cls, acc, l_mask, l_dice, l_rank = StageTailFn.apply(cls_score, scaled, t)
+        if lowres is not None:
+            t.stride = int(stride)
+            l_cls, acc, l_mask, l_dice, l_rank = StageTailFn.apply(cls_score, lowres, t, scaled.detach())
+        else:
+            l_cls, acc, l_mask, l_dice, l_rank = StageTailFn.apply(cls_score, scaled, t, None)
         out = dict(loss_cls=l_cls, pos_acc=acc, loss_mask=l_mask, loss_dice=l_dice)
         if lr is not None:
             out['loss_rank'] = l_rank
@@ -198,13 +205,16 @@ class StageTailFn(torch.autograd.Function):
     [B, Ns, H, W]) and the stage's targets `t`: four launches forward, two backward."""
 
     @staticmethod
-    def forward(ctx, cls_score, mask_pred, t):
+    def forward(ctx, cls_score, mask_pred, t, scaled=None):
+        # scaled is None: `mask_pred` is what the losses are taken on (and what the gradient is w.r.t.); else `mask_pred` are the low-res
+        # logits (gradient target) and `scaled` their up-scaling (values only)
         L = _lib.lib()
         dev = mask_pred.device
         B, Ns, K, ncls = t.B, t.Ns, t.K, t.ncls
-        R, P = B * Ns, mask_pred.shape[2] * mask_pred.shape[3]
+        on = scaled if scaled is not None else mask_pred
+        R, P = B * Ns, on.shape[2] * on.shape[3]
         z = _req(cls_score.reshape(R, ncls), 'cls_score')
-        pred = _req(mask_pred.reshape(R, P), 'mask_pred')
+        pred = _req(on.reshape(R, P), 'mask_pred')
         with_rank = bool(t.cfg.with_rank)
         nbf, nch, nbl = L.vkn_focal_loss_blocks(R, ncls), L.vkn_mask_losses_chunks(P), L.vkn_mask_losses_blocks(P)
         part = torch.empty(nbf, dtype=torch.float32, device=dev)
@@ -226,7 +236,9 @@ class StageTailFn(torch.autograd.Function):
                                                B * nbl if with_rank else 0, _ptr(z), t.labels.data_ptr(), t.pos_rows.data_ptr(), ncls, B, P,
                                                _ptr(out), _ptr(a), _ptr(bc), st))
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(pred, fgrad, a, bc, lse if with_rank else a.new_empty(0), top if with_rank else t.rowk.new_empty(0))
+        ctx.lowres = scaled is not None
+        ctx.save_for_backward(_req(mask_pred, 'mask_pred') if ctx.lowres else pred, fgrad, a, bc, lse if with_rank else a.new_empty(0),
+                              top if with_rank else t.rowk.new_empty(0))
         ctx.t, ctx.shapes = t, (tuple(cls_score.shape), tuple(mask_pred.shape))
         acc = out[1:2]
         ctx.mark_non_differentiable(acc)
@@ -238,7 +250,6 @@ class StageTailFn(torch.autograd.Function):
         t = ctx.t
         L = _lib.lib()
         with_rank = bool(t.cfg.with_rank)
-        R, P = pred.shape
         st = _stream()
 
         def scalar(g):
@@ -255,7 +266,17 @@ class StageTailFn(torch.autograd.Function):
                                          float(t.cfg.w_cls) if t.avg_dev is not None else float(t.cfg.w_cls) / t.avg_host, _ptr(d_cls),
                                          fgrad.numel(), st))
                 d_cls = d_cls.view(ctx.shapes[0])
-            if ctx.needs_input_grad[1] and not (g_mask is None and g_dice is None and (g_rank is None or not with_rank)):
+            if ctx.needs_input_grad[1] and not (g_mask is None and g_dice is None and (g_rank is None or not with_rank)) and ctx.lowres:
+                # the low-res logits: one pass, no up-scaled gradient tensor
+                d_pred = torch.empty_like(pred)
+                h, w = pred.shape[-2:]
+                check(L.vkn_mask_losses_bwd_lowres_f32(_ptr(pred), _ptr(t.bank), t.tgt_row.data_ptr(), t.rowk.data_ptr(), _ptr(a), _ptr(bc),
+                                                       _ptr(g_mask), _ptr(g_dice), _ptr(g_rank), float(t.cfg.w_mask), float(t.cfg.w_dice),
+                                                       float(t.cfg.w_rank), t.K, _ptr(lse) if with_rank else None,
+                                                       top.data_ptr() if with_rank else None, t.B, t.Ns, h, w, t.stride,
+                                                       1 if with_rank else 0, _ptr(d_pred), st))
+            elif ctx.needs_input_grad[1] and not (g_mask is None and g_dice is None and (g_rank is None or not with_rank)):
+                R, P = pred.shape
                 d_pred = torch.empty_like(pred)
                 check(L.vkn_mask_losses_bwd_bank_f32(_ptr(pred), _ptr(t.bank), t.tgt_row.data_ptr(), t.rowk.data_ptr(), _ptr(a), _ptr(bc),
                                                      _ptr(g_mask), _ptr(g_dice), _ptr(g_rank), float(t.cfg.w_mask), float(t.cfg.w_dice),
@@ -263,4 +284,4 @@ class StageTailFn(torch.autograd.Function):
                                                      top.data_ptr() if with_rank else None, t.B, t.Ns, P, 1 if with_rank else 0,
                                                      _ptr(d_pred), st))
                 d_pred = d_pred.view(ctx.shapes[1])
-        return d_cls, d_pred, None
+        return d_cls, d_pred, None, None
