@@ -601,8 +601,8 @@ def main():
                 prop_, xf_, mp_, _ = vkn.ops.kernel_init(loc, sem, iw, sw, sb, 2, True, True, want_seg_preds=False)
                 o_ = vkn.ops.head_forward(dims, packs, xf_, prop_, mp_, None, CFG2['up'], want_scaled=False, clip_first_prev=first_prev)
                 return vkn.ops.panoptic_joint(o_[1], o_[2] if own_logits else pl, P0, 2, P0, 0.25, 0.6, full, full, full, upsample_stride=CFG2['up'])
-            pipe = {}
-            for own in (False, True):
+            pipe = {False: None, True: None}
+            for own in ((False, True) if args.head == 'ffn' else ()):   # (the previous_link head needs its link packs: headline step only)
                 for _ in range(2):
                     pipeline(own)
                 e0.record()
@@ -752,8 +752,8 @@ def main():
                                       fused_replaces_algorithmic_GBps=round(2 * alg / (fu_ms * 1e-3) / 1e9, 1),
                                       decode_ms=round(dec_ms, 4), gather_plus_reduce_ms=round(ga_ms, 4),
                                       kernel_init_pass0_ms=round(init_ms, 4), panoptic_joint_1024x2048_ms=round(pan_ms, 4),
-                                      pipeline_ms=round(pipe_ms, 4), pipeline_frames_per_s=round(B / (pipe_ms * 1e-3), 1),
-                                      pipeline_noise_logits_ms=round(pipe_noise_ms, 4),
+                                      pipeline_ms=pipe_ms and round(pipe_ms, 4), pipeline_frames_per_s=pipe_ms and round(B / (pipe_ms * 1e-3), 1),
+                                      pipeline_noise_logits_ms=pipe_noise_ms and round(pipe_noise_ms, 4),
                                       pipeline='kernel init (pass 0) -> S-stage head + tracking link -> panoptic merge (1024x2048 id map), chained as simple_test does; the merge on segmentation-like logits (pipeline_ms) / on the random-init head\'s own noise logits (pipeline_noise_logits_ms)',
                                       gather_GBps=round(alg / (ga_ms * 1e-3) / 1e9, 1),
                                       head_3stages_no_upsample_ms=round(head_ms, 4),

@@ -235,15 +235,19 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
 // positive rows' targets.  Workgroup = LR_NW waves (block rows i0 - 1 .. i0 + LR_NW - 2) x 64 lanes (columns j0 - 1 .. j0 + 62): the
 // outer ring only feeds its neighbours.
 #define LR_NW 8
+#define LR_NSPLIT 4
 template <int S>
-__global__ __launch_bounds__(64 * LR_NW) void k_ml_bwd_lr(const float* __restrict__ low, const float* __restrict__ bank,
+__global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __restrict__ low, const float* __restrict__ bank,
                                                           const int* __restrict__ rowk, const float* __restrict__ lse,
                                                           const int* __restrict__ top, int Ns, int h, int w, int with_rank,
                                                           float* __restrict__ grad_low, const MlTail tl) {
     __shared__ float xch[2][LR_NW][2][64];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.z;
+    // blockIdx.z = frame x LR_NSPLIT + part: the kernel rows of a frame are shared by LR_NSPLIT workgroups per pixel tile (the rows are
+    // independent; one workgroup per tile left 1.7 workgroups per CU at four frames: every row's load -> shift -> LDS -> barrier chain exposed)
+    const int b = blockIdx.z / LR_NSPLIT, part = blockIdx.z - b * LR_NSPLIT;
+    const int rpp = (Ns + LR_NSPLIT - 1) / LR_NSPLIT, n_lo = part * rpp, n_hi = min(Ns, n_lo + rpp);
     const int i = (int)blockIdx.y * (LR_NW - 2) - 1 + wv, j = (int)blockIdx.x * 62 - 1 + lane;
     const bool blk = i >= 0 && i < h && j >= 0 && j < w;        // this thread's block exists
     const bool own = blk && wv >= 1 && wv <= LR_NW - 2 && lane >= 1 && lane <= 62;   // ... and its low-res pixel is written here
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(64 * LR_NW) void k_ml_bwd_lr(const float* __restric
             l[a][c] = with_rank ? lse[(size_t)b * P + pix0 + (size_t)a * W + c] : 0.f;
             tp[a][c] = with_rank ? top[(size_t)b * P + pix0 + (size_t)a * W + c] : -1;
         }
-    for (int n = 0; n < Ns; ++n) {
+    for (int n = n_lo; n < n_hi; ++n) {
         const float* lr = low + ((size_t)b * Ns + n) * lp;
         float v[3][3];
 #pragma unroll
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(64 * LR_NW) void k_ml_bwd_lr(const float* __restric
                 if (tp[a][c] >= 0) gv = cr * (__expf(z - l[a][c]) - (tp[a][c] == n ? 1.f : 0.f));
                 if (k >= 0) {
                     const float t = trow[(size_t)a * W + c];
-                    const float pp = 1.0f / (1.0f + __expf(-z));
+                    const float pp = __builtin_amdgcn_rcpf(1.0f + __expf(-z));   // (v_rcp_f32: 1 ulp, as k_ml_rows)
                     gv += cm * (pp - t) + (ca * t + cb * pp) * pp * (1.f - pp);
                 }
                 g[c] = blk ? gv : 0.f;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(64 * LR_NW) void k_ml_bwd_lr(const float* __restric
 #pragma unroll
         for (int r = 0; r < 3; ++r) hr[r] = (ps[r][1] + __shfl_down(ps[r][0], 1)) + __shfl_up(ps[r][2], 1);
         // rows: low-res row i collects hr[1] of its own block row, hr[0] of the block row below, hr[2] of the one above
-        float* xb = &xch[n & 1][0][0][0];
+        float* xb = &xch[(n - n_lo) & 1][0][0][0];
         xb[(wv * 2 + 0) * 64 + lane] = hr[0];
         xb[(wv * 2 + 1) * 64 + lane] = hr[2];
         __syncthreads();
@@ -969,7 +973,7 @@ int vkn_mask_losses_bwd_lowres_f32(const float* low, const float* bank, const in
     const double P = (double)S * h * (double)S * w;
     MlTail tl = {tgt_row, dice_a, dice_bc, g_mask, g_dice, g_rank, (float)((double)w_mask / ((double)K * P)),
                  (float)((double)w_dice / (double)K), (float)((double)w_rank / ((double)B * P))};
-    const dim3 grid((w + 61) / 62, (h + LR_NW - 3) / (LR_NW - 2), B);
+    const dim3 grid((w + 61) / 62, (h + LR_NW - 3) / (LR_NW - 2), B * LR_NSPLIT);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (S == 4) hipLaunchKernelGGL(k_ml_bwd_lr<4>, grid, dim3(64 * LR_NW), 0, st, low, bank, rowk, lse, top, Ns, h, w, with_rank, grad_low, tl);
     else hipLaunchKernelGGL(k_ml_bwd_lr<2>, grid, dim3(64 * LR_NW), 0, st, low, bank, rowk, lse, top, Ns, h, w, with_rank, grad_low, tl);
