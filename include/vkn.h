@@ -575,6 +575,16 @@ typedef struct VknAssignProblem {
 size_t vkn_sizeof_assign_problem(void);
 int vkn_assign_costs_batch_f32(const VknAssignCfg* cfg, const VknAssignProblem* probs, int nprob, int N, int ncls, int P, void* ws,
                                size_t ws_bytes, void* stream);
+/*      The same cost matrices straight from the LOW-RES logits (round 6): the reference assigns on
+ *      `F.interpolate(mask_preds, scale_factor=S, mode='bilinear', align_corners=False)` (knet/det/kernel_update_head.py:122-130 ->
+ *      knet/det/kernel_iter_head.py:150-156,225-226); here `mask_logits` of a problem are the stage's [N][h][w] logits BEFORE that
+ *      up-scaling and `gt_masks` [G][S h][S w]: interpolation, activation and both contractions run in ONE kernel for the whole batch
+ *      (the up-scaled prediction and its activation plane are never written).  S = 2 or 4, w % 16 == 0, S h % 8 == 0, N, G <= 256,
+ *      nprob <= 16 — anything else returns VKN_E_SHAPE (the caller up-scales and calls vkn_assign_costs_batch_f32).  Deterministic;
+ *      the partial-sum order does not depend on nprob.  Gmax: the largest of the problems' G. */
+size_t vkn_assign_lowres_workspace_bytes(int nprob, int N, int Gmax, int h, int w, int S);
+int vkn_assign_costs_lowres_batch_f32(const VknAssignCfg* cfg, const VknAssignProblem* probs, int nprob, int N, int ncls, int h, int w,
+                                      int S, void* ws, size_t ws_bytes, void* stream);
 /*      cost: HOST fp32 [nr][nc]; writes min(nr, nc) (row, col) pairs sorted by row; returns their number or a negative code */
 int vkn_lsap_f32(const float* cost, int nr, int nc, int* row_ind, int* col_ind);
 /*      The same algorithm ON THE DEVICE, one wavefront per problem, a batch of problems (the images of a training batch) per launch:

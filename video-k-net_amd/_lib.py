@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libvkn.so')
-SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_tracker.hip', 'vkn_loss.hip', 'vkn_chain.hip', 'vkn_chain_h2.hip', 'vkn_ksplit.hip', 'vkn_train.hip', 'vkn_api.hip')
+SOURCES = ('vkn_gather.hip', 'vkn_update.hip', 'vkn_decode.hip', 'vkn_fused.hip', 'vkn_init.hip', 'vkn_panoptic.hip', 'vkn_merge.hip', 'vkn_assign.hip', 'vkn_assign_lr.hip', 'vkn_tracker.hip', 'vkn_loss.hip', 'vkn_chain.hip', 'vkn_chain_h2.hip', 'vkn_ksplit.hip', 'vkn_train.hip', 'vkn_api.hip')
 MAX_FCS = 4
 
 # every symbol include/vkn.h declares
@@ -25,7 +25,7 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_workspace_init', 'vkn_workspace_s
            'vkn_kernel_init_workspace_bytes', 'vkn_kernel_init_f32',
            'vkn_sizeof_panoptic_cfg', 'vkn_panoptic_workspace_bytes', 'vkn_panoptic_joint_f32',
            'vkn_merge_workspace_bytes', 'vkn_panoptic_thing_first_u8',
-           'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_sizeof_assign_problem', 'vkn_assign_costs_batch_f32', 'vkn_lsap_f32',
+           'vkn_sizeof_assign_cfg', 'vkn_assign_workspace_bytes', 'vkn_assign_costs_f32', 'vkn_sizeof_assign_problem', 'vkn_assign_costs_batch_f32', 'vkn_assign_lowres_workspace_bytes', 'vkn_assign_costs_lowres_batch_f32', 'vkn_lsap_f32',
            'vkn_sizeof_lsap_problem', 'vkn_lsap_batch_f32',
            'vkn_mask_losses_chunks', 'vkn_mask_losses_blocks', 'vkn_mask_losses_fwd_f32', 'vkn_mask_losses_bwd_f32',
            'vkn_sizeof_tail_image', 'vkn_sizeof_tail_cfg', 'vkn_stage_targets', 'vkn_mask_losses_fwd_bank_f32', 'vkn_stage_losses_final_f32',
@@ -448,6 +448,10 @@ def lib():
         raise VknLibraryError('VknAssignProblem layout mismatch between include/vkn.h and _lib.py')
     L.vkn_assign_costs_batch_f32.restype = c_int
     L.vkn_assign_costs_batch_f32.argtypes = [pA, ctypes.POINTER(VknAssignProblem), c_int, c_int, c_int, c_int, _fp, c_size, _fp]
+    L.vkn_assign_lowres_workspace_bytes.restype = c_size
+    L.vkn_assign_lowres_workspace_bytes.argtypes = [c_int] * 6
+    L.vkn_assign_costs_lowres_batch_f32.restype = c_int
+    L.vkn_assign_costs_lowres_batch_f32.argtypes = [pA, ctypes.POINTER(VknAssignProblem)] + [c_int] * 6 + [_fp, c_size, _fp]
     L.vkn_sizeof_lsap_problem.restype = c_size
     L.vkn_sizeof_lsap_problem.argtypes = []
     if L.vkn_sizeof_lsap_problem() != ctypes.sizeof(VknLsapProblem):

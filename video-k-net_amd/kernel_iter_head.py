@@ -121,9 +121,13 @@ class KernelIterHead(BaseRoIHead):
         if mask_preds.requires_grad and torch.is_grad_enabled():
             from . import autograd as vag
             if mask_preds.is_cuda and mask_preds.dtype == torch.float32 and mask_preds.dim() == 4:
-                return vag.upsample_bilinear(mask_preds, stride)       # HIP forward + its adjoint (csrc/vkn_loss.hip)
-            return torch.nn.functional.interpolate(mask_preds, scale_factor=stride, mode='bilinear', align_corners=False)
-        return ops.upsample_bilinear(mask_preds, stride)
+                out = vag.upsample_bilinear(mask_preds, stride)       # HIP forward + its adjoint (csrc/vkn_loss.hip)
+            else:
+                out = torch.nn.functional.interpolate(mask_preds, scale_factor=stride, mode='bilinear', align_corners=False)
+        else:
+            out = ops.upsample_bilinear(mask_preds, stride)
+        out._vkn_lowres = mask_preds     # (witness for `_train_stages`: these values are the bilinear x`stride` up-scaling of exactly this tensor)
+        return out
 
     def check_status(self, device=None):
         """Raise `VknError` (VKN_E_RANGE) when a call since the last check fed the kernels features outside the f16-split envelope
@@ -214,6 +218,9 @@ class KernelIterHead(BaseRoIHead):
         up = self.mask_head[0].mask_upsample_stride
         # what stage s is assigned on: the predictions it RECEIVES (reference :150-156, :225-226) — or, with `post_assign`, its own
         assign_masks = self._upsample(mask_preds.detach(), up) if up > 1 else mask_preds.detach()
+        # ... and the low-res logits those are the x`up` up-scaling of: the assigner's cost kernel interpolates them itself
+        # (vkn_assign_costs_lowres_batch_f32) and never reads `assign_masks`
+        assign_low = mask_preds.detach() if up > 1 else None
         assign_cls = cls_score.detach() if cls_score is not None else None
         if self.hard_target:
             gt_masks = [g.bool().float() for g in gt_masks]
@@ -243,10 +250,12 @@ class KernelIterHead(BaseRoIHead):
             mask_results = self._mask_forward(stage, x, object_feats, mask_preds, img_metas, **extra)
             mask_preds, scaled_mask_preds = mask_results['mask_preds'], mask_results['scaled_mask_preds']
             cls_score, object_feats = mask_results['cls_score'], mask_results['object_feats']
+            stage_low = mask_preds.detach() if up > 1 and getattr(scaled_mask_preds, '_vkn_lowres', None) is mask_preds else None
             if self.post_assign:
-                assign_masks, assign_cls = scaled_mask_preds.detach(), cls_score.detach()
+                assign_masks, assign_cls, assign_low = scaled_mask_preds.detach(), cls_score.detach(), stage_low
             if stage < self.assign_stages:       # later stages keep the last assignment (:196)
-                assign_results = self._assign_batch(stage, assign_masks, assign_cls, gt_masks, gt_labels, img_metas)
+                assign_results = self._assign_batch(stage, assign_masks, assign_cls, gt_masks, gt_labels, img_metas,
+                                                    lowres=(assign_low, up) if assign_low is not None else None)
             head = self.mask_head[stage]
             stage_losses = None
             if tail is not None and scaled_mask_preds.shape[1] == self.num_proposals + (head.num_stuff_classes if tail.with_sem else 0) \
@@ -267,7 +276,7 @@ class KernelIterHead(BaseRoIHead):
             for key, value in stage_losses.items():
                 all_stage_loss[f's{stage}_{key}'] = value if w == 1 else value * w      # (x * 1 == x: no launch, no autograd node)
             if not self.post_assign:
-                assign_masks, assign_cls = scaled_mask_preds.detach(), cls_score.detach()
+                assign_masks, assign_cls, assign_low = scaled_mask_preds.detach(), cls_score.detach(), stage_low
         self._lowres_tail_step = False
         if tail is not None:
             tail.finish()
@@ -276,14 +285,17 @@ class KernelIterHead(BaseRoIHead):
             self.mask_assigner[0].check_status(*self.mask_assigner[1:], wait=False)   # (reported at a later poll: no stall)
         return all_stage_loss, mask_results
 
-    def _assign_batch(self, stage, masks, cls, gt_masks, gt_labels, img_metas):
+    def _assign_batch(self, stage, masks, cls, gt_masks, gt_labels, img_metas, lowres=None):
         """One-to-one assignment of a stage for every image of the batch: proposals only (the stuff kernels have fixed targets), thing
-        logits only.  One LSAP launch for the batch when the assigner offers it (`MaskHungarianAssigner.assign_batch`)."""
+        logits only.  One LSAP launch for the batch when the assigner offers it (`MaskHungarianAssigner.assign_batch`).
+        `lowres = ([B, Ns, h, w] logits, stride)`: `masks` are exactly their bilinear x`stride` up-scaling."""
         a, Np, T = self.mask_assigner[stage], self.num_proposals, self.num_thing_classes
         n = masks.shape[0]
         m = [masks[i][:Np] for i in range(n)]
         c = [cls[i][:Np, :T] if cls is not None else None for i in range(n)]
         if hasattr(a, 'assign_batch'):
+            if lowres is not None and getattr(a, 'lowres_costs', False):
+                return a.assign_batch(m, c, gt_masks, gt_labels, img_metas, lowres=([lowres[0][i][:Np] for i in range(n)], lowres[1]))
             return a.assign_batch(m, c, gt_masks, gt_labels, img_metas)
         return [a.assign(m[i], c[i], gt_masks[i], gt_labels[i], img_meta=img_metas[i]) for i in range(n)]
 

@@ -119,6 +119,7 @@ class MaskHungarianAssigner:
     # lower clamp of sigmoid(mask logits) inside (DiceCost, MaskCost): knet/det/mask_hungarian_assigner.py:69,101.  The knet_vis copies
     # of the two cost classes (same registry names) do not clamp — `pred_clamp = (0.0, 0.0)` selects that flavour
     pred_clamp = (1e-3, 1e-2)
+    lowres_costs = True    # `assign_batch(.., lowres=..)`: costs straight from the low-res logits (False: from the up-scaled tensors, A/B)
 
     def __init__(self, cls_cost=dict(type='ClassificationCost', weight=1.), mask_cost=dict(type='SigmoidCost', weight=1.0),
                  dice_cost=dict(), boundary_cost=None, topk=1):
@@ -216,10 +217,13 @@ class MaskHungarianAssigner:
         res.host_pos_inds = np.sort(np.asarray(rows_host, dtype=np.int64))   # the LSAP ran on the host: the sampler needs no device nonzero
         return res
 
-    def assign_batch(self, bbox_preds, cls_preds, gt_bboxes, gt_labels, img_metas=None):
+    def assign_batch(self, bbox_preds, cls_preds, gt_bboxes, gt_labels, img_metas=None, lowres=None):
         """`assign` for the images of a batch (lists of per-image tensors; `cls_preds` entries may be None): the cost matrices are
         computed image by image, ALL linear sum assignments run in ONE launch (one wavefront per image, vkn_lsap_batch_f32).
-        -> list of AssignResult, identical to calling `assign` per image."""
+        -> list of AssignResult, identical to calling `assign` per image.
+        `lowres = (per-image [N, h, w] logits, stride)`: `bbox_preds` ARE their x`stride` bilinear up-scaling (the caller vouches) —
+        the costs then come from the low-res logits in one kernel for the batch (vkn_assign_costs_lowres_batch_f32) and the up-scaled
+        tensors are not read."""
         n = len(bbox_preds)
         if self.lsap != 'device' or any(g.size(0) == 0 or g.size(0) > 256 or p.size(0) == 0 or p.size(0) > 256
                                         for g, p in zip(gt_bboxes, bbox_preds)):
@@ -228,13 +232,18 @@ class MaskHungarianAssigner:
         use_cls = self.cls['weight'] != 0 and all(c is not None for c in cls_preds)
         same = len({p.shape for p in bbox_preds}) == 1 and (not use_cls or len({c.shape for c in cls_preds}) == 1)
         checked = not use_cls or all(self._is_validated(l, cls_preds[0].shape[1]) for l in gt_labels)
-        if same and checked and (use_cls or all(c is None for c in cls_preds) or self.cls['weight'] == 0):
+        kw = dict(cls_weight=self.cls['weight'] if use_cls else 0.0, dice_weight=self.dice['weight'], mask_weight=self.mask['weight'],
+                  focal_alpha=self.cls['alpha'], focal_gamma=self.cls['gamma'], focal_eps=self.cls['eps'], dice_eps=self.dice['eps'],
+                  dice_pred_min=self.pred_clamp[0], mask_pred_min=self.pred_clamp[1])
+        batched = same and checked and (use_cls or all(c is None for c in cls_preds) or self.cls['weight'] == 0)
+        if batched and lowres is not None and self.lowres_costs and all(g.dim() == 3 for g in gt_bboxes) and \
+                all(l.is_cuda and l.dtype == torch.float32 and l.dim() == 3 for l in lowres[0]) and \
+                ops.assign_costs_lowres_supported(lowres[0][0].shape[0], [int(g.shape[0]) for g in gt_bboxes], lowres[0][0].shape[1],
+                                                  lowres[0][0].shape[2], lowres[1]):
+            costs = ops.assign_costs_lowres_batch(lowres[0], lowres[1], cls_preds if use_cls else None, gt_bboxes, gt_labels, **kw)
+        elif batched:
             # every image's cost matrix from ONE C call (the labels were range-checked by validate_labels)
-            costs = ops.assign_costs_batch(bbox_preds, cls_preds if use_cls else None, gt_bboxes, gt_labels,
-                                           cls_weight=self.cls['weight'] if use_cls else 0.0, dice_weight=self.dice['weight'],
-                                           mask_weight=self.mask['weight'], focal_alpha=self.cls['alpha'], focal_gamma=self.cls['gamma'],
-                                           focal_eps=self.cls['eps'], dice_eps=self.dice['eps'], dice_pred_min=self.pred_clamp[0],
-                                           mask_pred_min=self.pred_clamp[1])
+            costs = ops.assign_costs_batch(bbox_preds, cls_preds if use_cls else None, gt_bboxes, gt_labels, **kw)
         else:
             costs = [self.cost_matrix(bbox_preds[i], cls_preds[i], gt_bboxes[i], gt_labels[i]) for i in range(n)]
         gts, rows, cols, status = ops.lsap_device(costs)

@@ -806,6 +806,55 @@ def assign_costs_batch(mask_logits, cls_logits, gt_masks, gt_labels, cls_weight=
     return out
 
 
+def assign_costs_lowres_supported(N, Gs, h, w, stride):
+    """Does `assign_costs_lowres_batch` take this shape?  (include/vkn.h: vkn_assign_costs_lowres_batch_f32)"""
+    return bool(Gs) and len(Gs) <= 16 and min(Gs) > 0 and \
+        _lib.lib().vkn_assign_lowres_workspace_bytes(len(Gs), int(N), max(Gs), int(h), int(w), int(stride)) > 0
+
+
+def assign_costs_lowres_batch(low_logits, stride, cls_logits, gt_masks, gt_labels, cls_weight=2.0, dice_weight=4.0, mask_weight=1.0,
+                              focal_alpha=0.25, focal_gamma=2.0, focal_eps=1e-12, dice_eps=1e-3, dice_pred_min=1e-3, mask_pred_min=1e-2):
+    """`assign_costs_batch` on the LOW-RES logits: per-image [N, h, w] logits whose x`stride` bilinear up-scaling the reference assigns
+    on, [G_b, stride h, stride w] ground truths — interpolation, activation and contraction in one kernel for the whole batch
+    (vkn_assign_costs_lowres_batch_f32: the up-scaled predictions are never read).  Labels ALREADY range-checked.
+    -> list of [N, G_b] cost matrices (views of one allocation)."""
+    n = len(low_logits)
+    N, h, w = (int(v) for v in low_logits[0].shape)
+    dev = low_logits[0].device
+    use_cls = cls_logits is not None and cls_logits[0] is not None and cls_weight != 0
+    ncls = cls_logits[0].shape[1] if use_cls else 0
+    Gs = [int(g.shape[0]) for g in gt_masks]
+    labs = _labels_i32(gt_labels, dev) if use_cls else None
+    cost = torch.empty((N * sum(Gs),), dtype=torch.float32, device=dev)
+    probs = (_lib.VknAssignProblem * n)()
+    keep, out, off = [], [], 0
+    for b in range(n):
+        m = _req(low_logits[b], 'mask_preds')
+        g = gt_masks[b]
+        if g.dtype != torch.float32:
+            g = g.float()
+        g = _req(g, 'gt_masks')
+        if tuple(m.shape) != (N, h, w) or tuple(g.shape[1:]) != (stride * h, stride * w):
+            raise ValueError('every image needs [N, h, w] logits and [G, stride h, stride w] ground-truth masks')
+        c = _req(cls_logits[b], 'cls_pred') if use_cls else None
+        cb = cost[N * off:N * (off + Gs[b])].view(N, Gs[b])
+        probs[b] = _lib.VknAssignProblem(m.data_ptr(), c.data_ptr() if use_cls else None, g.data_ptr(),
+                                         labs.data_ptr() + 4 * off if use_cls else None, Gs[b], cb.data_ptr())
+        keep += [m, g, c]
+        out.append(cb)
+        off += Gs[b]
+    cfg = _lib.VknAssignCfg(float(cls_weight if use_cls else 0.0), float(dice_weight), float(mask_weight), float(focal_alpha),
+                            float(focal_gamma), float(focal_eps), float(dice_eps), float(dice_pred_min), float(mask_pred_min))
+    L = _lib.lib()
+    nb = L.vkn_assign_lowres_workspace_bytes(n, N, max(Gs), h, w, int(stride))
+    if nb == 0:
+        raise ValueError('shape outside vkn_assign_costs_lowres_batch_f32 (ops.assign_costs_lowres_supported)')
+    ws = _workspace(max(nb, 256), dev, scratch=True)
+    with torch.cuda.device(dev):
+        check(L.vkn_assign_costs_lowres_batch_f32(ctypes.byref(cfg), probs, n, N, ncls, h, w, int(stride), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
 def focal_loss_fwd(logits, labels, row_weight, alpha, gamma):
     """Sigmoid focal loss in one pass (include/vkn.h: vkn_focal_loss_f32).  logits [M, ncls] fp32, labels int64 [M], row_weight [M] |
     [M, ncls] | None -> (sum of the weighted element losses: 0-d tensor, d sum / d logits [M, ncls])."""
