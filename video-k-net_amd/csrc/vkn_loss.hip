@@ -281,32 +281,80 @@ __global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __rest
     int ro[3], co[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) { ro[r] = min(max(ic - 1 + r, 0), h - 1) * w; co[r] = min(max(jc - 1 + r, 0), w - 1); }
-    // lse / top of the block's pixels (the frame's, shared by every kernel row)
+    // lse / top of the block's pixels (the frame's, shared by every kernel row).  top as one byte per pixel (Ns <= 256); a pixel that no
+    // positive row covers (top = -1) carries lse = +inf — its softmax term exp(z - lse) is then exactly 0 — and a byte that equals no
+    // row of THIS workgroup's range [n_lo, n_hi), so that its one-hot term is 0 too: no branch per pixel
     float l[S][S];
-    int tp[S][S];
+    unsigned tpk[S];
     const size_t pix0 = (size_t)(S * ic) * W + (size_t)S * jc;
 #pragma unroll
-    for (int a = 0; a < S; ++a)
+    for (int a = 0; a < S; ++a) {
+        tpk[a] = 0;
 #pragma unroll
         for (int c = 0; c < S; ++c) {
-            l[a][c] = with_rank ? lse[(size_t)b * P + pix0 + (size_t)a * W + c] : 0.f;
-            tp[a][c] = with_rank ? top[(size_t)b * P + pix0 + (size_t)a * W + c] : -1;
+            const int t = with_rank ? top[(size_t)b * P + pix0 + (size_t)a * W + c] : -1;
+            l[a][c] = t >= 0 ? lse[(size_t)b * P + pix0 + (size_t)a * W + c] : INFINITY;
+            tpk[a] |= (unsigned)(t < 0 ? (n_lo == 0 ? n_hi & 255 : 0) : t) << (8 * c);
         }
-    for (int n = n_lo; n < n_hi; ++n) {
-        const float* lr = low + ((size_t)b * Ns + n) * lp;
-        float v[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[r][c] = lr[ro[r] + co[c]];
-        const int k = rowk[b * Ns + n];   // uniform
+    }
+    // this workgroup's kernel rows: (k, target row, dice coefficients) once, through LDS — inside the row loop they were three DEPENDENT
+    // memory round trips per positive row (rowk -> tgt_row / dice_a / dice_bc -> target pixels)
+    __shared__ int mk[128], mt[128];
+    __shared__ float mca[128], mcb[128];
+    for (int q = threadIdx.x; q < n_hi - n_lo; q += 64 * LR_NW) {
+        const int k = rowk[b * Ns + n_lo + q];
+        mk[q] = k;
         float ca = 0.f, cb = 0.f;
-        const float* trow = nullptr;
+        int t = 0;
         if (k >= 0) {
             const float a_ = tl.dice_a[k], bc = tl.dice_bc[k];
             ca = gd * (-2.0f / bc);
             cb = gd * (4.0f * a_ / (bc * bc));
-            trow = bank + (size_t)tl.tgt_row[b * Ns + n] * P + pix0;
+            t = tl.tgt_row[b * Ns + n_lo + q];
+        }
+        mt[q] = t; mca[q] = ca; mcb[q] = cb;
+    }
+    __syncthreads();
+    // the low-res neighbourhood of row n + 1 is requested before row n's arithmetic (one round trip per row was the whole cost of a row)
+    // (buffer loads: nine 32-bit pixel offsets held for the whole kernel + the row's offset in a scalar register — nine 64-bit
+    // addresses per row were 18 registers and, at four waves per SIMD, spilled)
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(low + (size_t)b * Ns * lp), 0, (int)((size_t)Ns * lp * 4), 0x00020000);
+    int po[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) po[r][c] = (ro[r] + co[c]) * 4;
+    float vn[3][3];
+    if (n_lo < n_hi) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vn[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, po[r][c], n_lo * (int)lp * 4, 0));
+    }
+    for (int n = n_lo; n < n_hi; ++n) {
+        float v[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[r][c] = vn[r][c];
+        if (n + 1 < n_hi) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) vn[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, po[r][c], (n + 1) * (int)lp * 4, 0));
+        }
+        const int k = __builtin_amdgcn_readfirstlane(mk[n - n_lo]);   // uniform
+        const float ca = mca[n - n_lo], cb = mcb[n - n_lo];
+        f32x4 tg[S];   // the block's target pixels (positive rows): S rows of 16 bytes (S = 2: the first two elements)
+#pragma unroll
+        for (int a = 0; a < S; ++a) tg[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k >= 0) {
+            const float* trow = bank + (size_t)mt[n - n_lo] * P + pix0;
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                if (S == 4) tg[a] = *reinterpret_cast<const f32x4*>(trow + (size_t)a * W);
+                else { const f32x2 t2 = *reinterpret_cast<const f32x2*>(trow + (size_t)a * W); tg[a][0] = t2[0]; tg[a][1] = t2[1]; }
+            }
         }
         // horizontal pass of the forward interpolation: hx[r][c'] = the three low-res rows at the block's S output columns
         float hx[3][S];
@@ -314,6 +362,28 @@ __global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __rest
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < S; ++c) hx[r][c] = (v[r][0] * wx[c][0] + v[r][1] * wx[c][1]) + v[r][2] * wx[c][2];
+        // the S x S gradient values of the block: the rank term for every row, the mask / dice terms for a positive row — ONE uniform
+        // branch per row (inside the pixel loop it was a branch per pixel)
+        float g[S][S];
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+            for (int c = 0; c < S; ++c) {
+                const float z = (hx[0][c] * wy[a][0] + hx[1][c] * wy[a][1]) + hx[2][c] * wy[a][2];
+                const int tpv = (int)((tpk[a] >> (8 * c)) & 255u);
+                g[a][c] = cr * (__expf(z - l[a][c]) - (tpv == n ? 1.f : 0.f));
+            }
+        if (k >= 0) {
+#pragma unroll
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+                for (int c = 0; c < S; ++c) {
+                    const float z = (hx[0][c] * wy[a][0] + hx[1][c] * wy[a][1]) + hx[2][c] * wy[a][2];
+                    const float t = tg[a][c];
+                    const float pp = __builtin_amdgcn_rcpf(1.0f + __expf(-z));   // (v_rcp_f32: 1 ulp, as k_ml_rows)
+                    g[a][c] += cm * (pp - t) + (ca * t + cb * pp) * pp * (1.f - pp);
+                }
+        }
         float ps[3][3];   // partial sums for low-res (i - 1 + r, j - 1 + c)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -321,26 +391,13 @@ __global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __rest
             for (int c = 0; c < 3; ++c) ps[r][c] = 0.f;
 #pragma unroll
         for (int a = 0; a < S; ++a) {
-            float g[S];
-#pragma unroll
-            for (int c = 0; c < S; ++c) {
-                const float z = (hx[0][c] * wy[a][0] + hx[1][c] * wy[a][1]) + hx[2][c] * wy[a][2];
-                float gv = 0.f;
-                if (tp[a][c] >= 0) gv = cr * (__expf(z - l[a][c]) - (tp[a][c] == n ? 1.f : 0.f));
-                if (k >= 0) {
-                    const float t = trow[(size_t)a * W + c];
-                    const float pp = __builtin_amdgcn_rcpf(1.0f + __expf(-z));   // (v_rcp_f32: 1 ulp, as k_ml_rows)
-                    gv += cm * (pp - t) + (ca * t + cb * pp) * pp * (1.f - pp);
-                }
-                g[c] = blk ? gv : 0.f;
-            }
             // adjoint, columns first: cs[c3] = sum over the row's S pixels of wx * g; then this output row's share of the three low-res rows
             float cs[3];
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) {
                 float acc = 0.f;
 #pragma unroll
-                for (int c = 0; c < S; ++c) acc += wx[c][c3] * g[c];
+                for (int c = 0; c < S; ++c) acc += wx[c][c3] * (blk ? g[a][c] : 0.f);
                 cs[c3] = acc;
             }
 #pragma unroll
@@ -356,7 +413,8 @@ __global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __rest
         float* xb = &xch[(n - n_lo) & 1][0][0][0];
         xb[(wv * 2 + 0) * 64 + lane] = hr[0];
         xb[(wv * 2 + 1) * 64 + lane] = hr[2];
-        __syncthreads();
+        // (LDS-only barrier: __syncthreads() also fences global memory — a wait for the NEXT row's prefetched loads, every row)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (own) {
             const float out = (hr[1] + xb[((wv + 1) * 2 + 0) * 64 + lane]) + xb[((wv - 1) * 2 + 1) * 64 + lane];
             grad_low[((size_t)b * Ns + n) * lp + (size_t)i * w + j] = out;
