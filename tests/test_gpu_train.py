@@ -139,6 +139,13 @@ def _forward_train_vs_golden(vkn, name, graphs=False, steps=1):
                 assigned.extend(r.gt_inds.clone() for r in rs)
             return rs
         a.assign_batch = recb
+        origl = a.assign_batch_lowres     # (... and straight from the low-res logits whenever the up-scaling is the library's own)
+
+        def recl(*args, _orig=origl, **kw):
+            rs = _orig(*args, **kw)
+            assigned.extend(r.gt_inds.clone() for r in rs)
+            return rs
+        a.assign_batch_lowres = recl
     if graphs:
         head.enable_chain_graphs()
     for step in range(steps):

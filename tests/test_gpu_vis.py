@@ -225,7 +225,7 @@ def test_vis_rpn_and_roi_training_vs_reference_golden(vkn):
     assigned = []
 
     def hook(a):
-        for meth in ('assign', 'assign_batch'):
+        for meth in ('assign', 'assign_batch', 'assign_batch_lowres'):
             if hasattr(a, meth):
                 orig = getattr(a, meth)
 

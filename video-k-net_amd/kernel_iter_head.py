@@ -217,10 +217,10 @@ class KernelIterHead(BaseRoIHead):
         self._chain_graphs_new_step()
         up = self.mask_head[0].mask_upsample_stride
         # what stage s is assigned on: the predictions it RECEIVES (reference :150-156, :225-226) — or, with `post_assign`, its own
-        assign_masks = self._upsample(mask_preds.detach(), up) if up > 1 else mask_preds.detach()
-        # ... and the low-res logits those are the x`up` up-scaling of: the assigner's cost kernel interpolates them itself
-        # (vkn_assign_costs_lowres_batch_f32) and never reads `assign_masks`
+        # — as the low-res logits whose x`up` up-scaling the reference assigns on: the assigner's cost kernel interpolates them itself
+        # (vkn_assign_costs_lowres_batch_f32); the up-scaled tensor (`assign_masks`) is formed only if the assigner declines
         assign_low = mask_preds.detach() if up > 1 else None
+        assign_masks = None if up > 1 else mask_preds.detach()
         assign_cls = cls_score.detach() if cls_score is not None else None
         if self.hard_target:
             gt_masks = [g.bool().float() for g in gt_masks]
@@ -288,14 +288,19 @@ class KernelIterHead(BaseRoIHead):
     def _assign_batch(self, stage, masks, cls, gt_masks, gt_labels, img_metas, lowres=None):
         """One-to-one assignment of a stage for every image of the batch: proposals only (the stuff kernels have fixed targets), thing
         logits only.  One LSAP launch for the batch when the assigner offers it (`MaskHungarianAssigner.assign_batch`).
-        `lowres = ([B, Ns, h, w] logits, stride)`: `masks` are exactly their bilinear x`stride` up-scaling."""
+        `lowres = ([B, Ns, h, w] logits, stride)`: what the reference assigns on is exactly their bilinear x`stride` up-scaling;
+        `masks` (that up-scaling) may then be None — it is formed here only if the assigner does not take the low-res logits."""
         a, Np, T = self.mask_assigner[stage], self.num_proposals, self.num_thing_classes
-        n = masks.shape[0]
-        m = [masks[i][:Np] for i in range(n)]
+        n = (masks if masks is not None else lowres[0]).shape[0]
         c = [cls[i][:Np, :T] if cls is not None else None for i in range(n)]
+        if lowres is not None and hasattr(a, 'assign_batch_lowres'):
+            lows = [lowres[0][i][:Np] for i in range(n)]
+            if a.lowres_ready(lows, lowres[1], c, gt_masks, gt_labels):
+                return a.assign_batch_lowres(lows, lowres[1], c, gt_masks, gt_labels)
+        if masks is None:
+            masks = self._upsample(lowres[0], lowres[1])
+        m = [masks[i][:Np] for i in range(n)]
         if hasattr(a, 'assign_batch'):
-            if lowres is not None and getattr(a, 'lowres_costs', False):
-                return a.assign_batch(m, c, gt_masks, gt_labels, img_metas, lowres=([lowres[0][i][:Np] for i in range(n)], lowres[1]))
             return a.assign_batch(m, c, gt_masks, gt_labels, img_metas)
         return [a.assign(m[i], c[i], gt_masks[i], gt_labels[i], img_meta=img_metas[i]) for i in range(n)]
 

@@ -236,10 +236,7 @@ class MaskHungarianAssigner:
                   focal_alpha=self.cls['alpha'], focal_gamma=self.cls['gamma'], focal_eps=self.cls['eps'], dice_eps=self.dice['eps'],
                   dice_pred_min=self.pred_clamp[0], mask_pred_min=self.pred_clamp[1])
         batched = same and checked and (use_cls or all(c is None for c in cls_preds) or self.cls['weight'] == 0)
-        if batched and lowres is not None and self.lowres_costs and all(g.dim() == 3 for g in gt_bboxes) and \
-                all(l.is_cuda and l.dtype == torch.float32 and l.dim() == 3 for l in lowres[0]) and \
-                ops.assign_costs_lowres_supported(lowres[0][0].shape[0], [int(g.shape[0]) for g in gt_bboxes], lowres[0][0].shape[1],
-                                                  lowres[0][0].shape[2], lowres[1]):
+        if lowres is not None and self.lowres_ready(lowres[0], lowres[1], cls_preds, gt_bboxes, gt_labels):
             costs = ops.assign_costs_lowres_batch(lowres[0], lowres[1], cls_preds if use_cls else None, gt_bboxes, gt_labels, **kw)
         elif batched:
             # every image's cost matrix from ONE C call (the labels were range-checked by validate_labels)
@@ -249,6 +246,40 @@ class MaskHungarianAssigner:
         gts, rows, cols, status = ops.lsap_device(costs)
         self._remember(status)
         return [DeviceAssignResult(gt_bboxes[i].size(0), gts[i], (rows[i], cols[i]), gt_labels[i], status) for i in range(n)]
+
+    def lowres_ready(self, lows, stride, cls_preds, gt_bboxes, gt_labels):
+        """Will `assign_batch(.., lowres=(lows, stride))` / `assign_batch_lowres` take the costs from the low-res logits?  (every
+        condition of the batched device path + the kernel's shape gate) — a caller that gets True need not up-scale at all."""
+        if not self.lowres_costs or self.lsap != 'device' or not lows:
+            return False
+        if any(g.dim() != 3 or g.size(0) == 0 or g.size(0) > 256 for g in gt_bboxes) or len(gt_bboxes) != len(lows):
+            return False
+        if any(not (l.is_cuda and l.dtype == torch.float32 and l.dim() == 3) for l in lows) or len({l.shape for l in lows}) != 1:
+            return False
+        N, h, w = lows[0].shape
+        if N == 0 or N > 256 or any(tuple(g.shape[1:]) != (stride * h, stride * w) for g in gt_bboxes):
+            return False
+        use_cls = self.cls['weight'] != 0 and all(c is not None for c in cls_preds)
+        if use_cls and (len({c.shape for c in cls_preds}) != 1 or not all(self._is_validated(l, cls_preds[0].shape[1]) for l in gt_labels)):
+            return False
+        if not use_cls and self.cls['weight'] != 0 and any(c is not None for c in cls_preds):
+            return False
+        return ops.assign_costs_lowres_supported(N, [int(g.shape[0]) for g in gt_bboxes], h, w, stride)
+
+    def assign_batch_lowres(self, lows, stride, cls_preds, gt_bboxes, gt_labels):
+        """`assign_batch` on the low-res logits alone (`lowres_ready(..)` must hold): the x`stride` up-scaled predictions the reference
+        assigns on (knet/det/kernel_iter_head.py:150-156) are never formed."""
+        if not self.lowres_ready(lows, stride, cls_preds, gt_bboxes, gt_labels):
+            raise ValueError('assign_batch_lowres: lowres_ready() does not hold for these inputs')
+        use_cls = self.cls['weight'] != 0 and all(c is not None for c in cls_preds)
+        costs = ops.assign_costs_lowres_batch(lows, stride, cls_preds if use_cls else None, gt_bboxes, gt_labels,
+                                              cls_weight=self.cls['weight'] if use_cls else 0.0, dice_weight=self.dice['weight'],
+                                              mask_weight=self.mask['weight'], focal_alpha=self.cls['alpha'], focal_gamma=self.cls['gamma'],
+                                              focal_eps=self.cls['eps'], dice_eps=self.dice['eps'], dice_pred_min=self.pred_clamp[0],
+                                              mask_pred_min=self.pred_clamp[1])
+        gts, rows, cols, status = ops.lsap_device(costs)
+        self._remember(status)
+        return [DeviceAssignResult(gt_bboxes[i].size(0), gts[i], (rows[i], cols[i]), gt_labels[i], status) for i in range(len(lows))]
 
     def _remember(self, status):
         """Queue a device status tensor for the next `check_status`.  The list is bounded by FOLDING the oldest entries into one
