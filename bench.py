@@ -199,10 +199,13 @@ def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
         torch.cuda.tunable.set_filename(os.path.join('/tmp', 'vkn_tunableop_%d.csv' % rank))
     if not getattr(args, 'no_chain_graphs', False):
         head.enable_chain_graphs()                        # every stage's [B*N, C] chain, forward and backward, as captured hipGraphs
-    try:         # one multi-tensor kernel per step instead of the foreach path's three passes over the parameters (same update rule)
-        opt = torch.optim.SGD(head.parameters(), lr=1e-4, momentum=0.9, fused=not getattr(args, 'train_foreach_sgd', False))
-    except (TypeError, RuntimeError, ValueError):
-        opt = torch.optim.SGD(head.parameters(), lr=1e-4, momentum=0.9)
+    if getattr(args, 'train_torch_sgd', False) or getattr(args, 'train_foreach_sgd', False):     # A/B: torch's optimizer over ~300 tensors
+        try:
+            opt = torch.optim.SGD(head.parameters(), lr=1e-4, momentum=0.9, fused=not getattr(args, 'train_foreach_sgd', False))
+        except (TypeError, RuntimeError, ValueError):
+            opt = torch.optim.SGD(head.parameters(), lr=1e-4, momentum=0.9)
+    else:        # the same update rule in one pass per gradient bucket over flat (parameter, gradient, momentum) ranges (dist.FlatSGD)
+        opt = vkn_dist.FlatSGD(reducer, lr=1e-4, momentum=0.9)
     x, pf, mp = synth_inputs(B, device, rank)
     x.requires_grad_(True)                                 # gradients flow on into the backbone in the real model
     g = torch.Generator(device='cpu').manual_seed(4321 + rank)
@@ -272,7 +275,7 @@ def train_main(args, vkn, vkn_dist, device, world, rank, dist_on=False):
                                                       'on the library\'s own kernels in both directions (chain_train.py, vkn_train.hip)')
                                                    + (', launched eagerly' if getattr(args, 'no_chain_graphs', False)
                                                       else ', captured as hipGraphs (forward + backward)')
-                                                   + ', per-stage bucketed RCCL gradient all-reduce overlapped with backward, SGD step',
+                                                   + ', per-stage bucketed RCCL gradient all-reduce overlapped with backward, SGD step (momentum 0.9) over the flat gradient buckets',
                                           frames_per_gpu_per_step=B, parallelism=f'frame-sharded dp{world}',
                                           mask_upsample_stride=up, loss_mask_size=[Hs, Ws], fused_loss_tail=bool(getattr(head, '_last_tail_fused', False)),
                                           head_parameters=nparam, last_loss=round(float(loss), 4)),
@@ -302,6 +305,7 @@ def main():
     ap.add_argument('--no-upsample', action='store_true', help='skip the x4 upsample output (diagnostic)')
     ap.add_argument('--train-up', type=int, default=4, choices=[1, 2, 4],
                     help='--train: mask_upsample_stride (4 = the shipped video KITTI-STEP config: 512x1024 loss masks; 2 = what rounds 2-5 timed)')
+    ap.add_argument('--train-torch-sgd', action='store_true', help='--train A/B: torch.optim.SGD(fused=True) instead of dist.FlatSGD')
     ap.add_argument('--train-foreach-sgd', action='store_true', help='--train A/B: torch.optim.SGD on its foreach path instead of fused=True')
     ap.add_argument('--train-default-stream', action='store_true', help='--train A/B: run the step on the default stream (chain graphs captured on a side stream)')
     ap.add_argument('--train-add-grads', action='store_true', help='--train A/B: zero the gradient buckets and add into their views instead of set_to_none + one batched copy')

@@ -689,6 +689,13 @@ int vkn_mask_losses_bwd_lowres_f32(const float* low, const float* bank, const in
                                    float w_dice, float w_rank, int K, const float* lse, const int* top, int B, int Ns, int h, int w, int S,
                                    int with_rank, float* grad_low, void* stream);
 int vkn_scale_by_f32(const float* in, const float* g, const float* d, float host_scale, float* out, size_t n, void* stream);
+/*      The optimizer step of the training row over ONE flat range (a gradient bucket of dist.BucketedGradAllReducer and the parameters
+ *      laid out the same way): torch.optim.SGD's rule with momentum (dampening 0, no nesterov) in one pass —
+ *          g' = grad * grad_scale + weight_decay * param;  mom = momentum * mom + g';  param -= lr * mom
+ *      (the reference trains through mmcv's optimizer hook around torch's optimizers, external/train.py; `grad_scale` = 1 / world
+ *      folds the data-parallel mean).  All three pointers 16-byte aligned, DEVICE fp32, n elements. */
+int vkn_sgd_momentum_f32(float* param, const float* grad, float* mom, size_t n, float lr, float momentum, float weight_decay,
+                         float grad_scale, void* stream);
 int vkn_check_range_i64(const long long* v, size_t n, long long lo, long long hi, int flag, int* status, void* stream);
 
 /* ---- glue of the BACKWARD passes of the two x-streaming ops (training; the passes themselves are vkn_mask_decode_scaled_f32 and

@@ -203,3 +203,38 @@ def test_bench_self_launches_its_ranks_from_the_bare_command():
         assert train['rccl_ranks'] == 1 and train['value'] > 0 and train['parity_witness']
     finally:
         os.environ.update(saved)
+
+
+def test_flat_sgd_equals_torch_sgd(vkn):
+    """`dist.FlatSGD` (one `vkn_sgd_momentum_f32` pass per gradient bucket over flat parameter / gradient / momentum ranges) against
+    `torch.optim.SGD(momentum, weight_decay)` on a copy of the same module over four steps: the same parameters to fp32 rounding, the
+    parameters still views of the flat buffers, a parameter without a gradient treated as a zero gradient."""
+    import copy
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.LayerNorm(53), torch.nn.Linear(53, 11, bias=False)).to('cuda:0')
+    ref = copy.deepcopy(net)
+    red = vkn.dist.BucketedGradAllReducer(net, bucket_of=lambda name: 'a' if name.startswith('0') else 'b')
+    opt = vkn.dist.FlatSGD(red, lr=0.05, momentum=0.9, weight_decay=1e-3)
+    topt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(a, b)
+    for step in range(4):
+        x = torch.randn(19, 37, device='cuda:0')
+        red.zero_grad(set_to_none=True)
+        topt.zero_grad(set_to_none=True)
+        net(x).square().mean().backward()
+        ref(x).square().mean().backward()
+        red.finalize()
+        opt.step()
+        topt.step()
+        for a, b in zip(net.parameters(), ref.parameters()):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), step
+    ranges = [(st['param'].data_ptr(), st['param'].data_ptr() + 4 * st['param'].numel()) for st in opt.state]
+    assert all(any(lo <= p.data_ptr() < hi for lo, hi in ranges) for p in net.parameters())
+    # a member without a gradient: zero gradient (momentum decays, weight decay applies) — not skipped
+    red.zero_grad(set_to_none=True)
+    before = [p.detach().clone() for p in net.parameters()]
+    net[0](torch.randn(5, 37, device='cuda:0')).square().mean().backward()        # only the first Linear takes part
+    red.finalize()
+    opt.step()
+    assert not torch.equal(before[-1], list(net.parameters())[-1])

@@ -726,6 +726,33 @@ __global__ __launch_bounds__(256) void k_scale_by(const float* __restrict__ in, 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i] * s;
 }
 
+// SGD with momentum over one FLAT parameter range (torch.optim.SGD's update, dampening 0, no nesterov):
+//   g' = g * grad_scale + weight_decay * p;   m = momentum * m + g';   p -= lr * m          (m starts at zero: the first step gives m = g')
+// One pass over the three arrays (16-byte accesses; the tail element-wise).  grad_scale folds the data-parallel mean (1 / world).
+__global__ __launch_bounds__(256) void k_sgd_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, size_t n,
+                                                  float lr, float momentum, float weight_decay, float grad_scale) {
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gv[e] * grad_scale + weight_decay * pv[e];
+            mv[e] = momentum * mv[e] + ge;
+            pv[e] = pv[e] - lr * mv[e];
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        const float ge = g[i] * grad_scale + weight_decay * p[i];
+        const float mv = momentum * m[i] + ge;
+        m[i] = mv;
+        p[i] = p[i] - lr * mv;
+    }
+}
+
 // status |= flag when any of v[0 .. n) lies outside [lo, hi)
 __global__ __launch_bounds__(256) void k_check_range(const long long* __restrict__ v, size_t n, long long lo, long long hi, int flag,
                                                      int* __restrict__ status) {
@@ -1045,6 +1072,18 @@ int vkn_scale_by_f32(const float* in, const float* g, const float* d, float host
     const size_t nb = (n + 255) / 256;
     hipLaunchKernelGGL(k_scale_by, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), in, g, d,
                        host_scale, out, n);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
+}
+
+int vkn_sgd_momentum_f32(float* param, const float* grad, float* mom, size_t n, float lr, float momentum, float weight_decay,
+                         float grad_scale, void* stream) {
+    if (!param || !grad || !mom) return VKN_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(mom)) & 15) return VKN_E_ALIGN;
+    if (n == 0) return VKN_OK;
+    const size_t nb = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(k_sgd_flat, dim3((unsigned)(nb < 1 ? 1 : (nb < 2048 ? nb : 2048))), dim3(256), 0, static_cast<hipStream_t>(stream), param,
+                       grad, mom, n, lr, momentum, weight_decay, grad_scale);
     VKN_CHECK_LAUNCH();
     return VKN_OK;
 }
