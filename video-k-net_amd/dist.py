@@ -163,14 +163,16 @@ class BucketedGradAllReducer:
             groups.setdefault((bucket_of(name), p.device, p.dtype), []).append(p)
         self.buckets = []
         for (key, dev, dt), params in groups.items():
-            flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=dt)
+            # every slot starts on a 256-byte boundary (the padding stays zero): a view is then as aligned as a tensor of its own —
+            # the kernels' 16-byte accesses, and `FlatSGD`'s parameter views, which the chain kernels read in place
+            flat = torch.zeros(sum(self._slot(p.numel()) for p in params), device=dev, dtype=dt)
             b = dict(key=key, flat=flat, params=params, views=[], fired={}, nfired=0, expect=None, expect_total=0, handle=None, grew=False, pending=set())
             off = 0
             for i, p in enumerate(params):
                 v = flat[off:off + p.numel()].view_as(p)
                 b['views'].append(v)
                 p.grad = v
-                off += p.numel()
+                off += self._slot(p.numel())
                 hook = self._make_hook(b, i)
                 self._hook_of[id(p)] = hook
                 p.register_post_accumulate_grad_hook(hook)
@@ -179,6 +181,10 @@ class BucketedGradAllReducer:
         for m in module.modules():
             if hasattr(m, 'on_param_grads'):
                 m.on_param_grads = self.params_ready
+
+    @staticmethod
+    def _slot(n):
+        return (n + 63) // 64 * 64
 
     def params_ready(self, params):
         """The gradients of `params` have been written to their `.grad` outside autograd's accumulation nodes (a captured backward
@@ -329,12 +335,13 @@ class FlatSGD:
             if not flat.is_cuda or flat.dtype != torch.float32:
                 raise RuntimeError('FlatSGD runs on the GPU kernels: fp32 CUDA parameters only (no CPU fallback)')
             pflat = torch.empty_like(flat)
+            pflat.zero_()
             off = 0
             for p in b['params']:
                 n = p.numel()
                 pflat[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = pflat[off:off + n].view_as(p)
-                off += n
+                off += reducer._slot(n)
             self.state.append(dict(param=pflat, mom=torch.zeros_like(flat)))
 
     def zero_grad(self, set_to_none=True):
