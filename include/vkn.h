@@ -688,6 +688,14 @@ int vkn_mask_losses_bwd_lowres_f32(const float* low, const float* bank, const in
                                    const float* dice_bc, const float* g_mask, const float* g_dice, const float* g_rank, float w_mask,
                                    float w_dice, float w_rank, int K, const float* lse, const int* top, int B, int Ns, int h, int w, int S,
                                    int with_rank, float* grad_low, void* stream);
+/* ... and the FORWARD sums of the same losses straight from the low-res logits: vkn_mask_losses_fwd_bank_f32's outputs for the xS
+ * up-scaling of `low` without that tensor (knet/det/kernel_update_head.py:122-130 -> :279-349 loss_mask / loss_dice / loss_rank):
+ * row_partial [K][vkn_mask_losses_lowres_chunks(h, w)][4], lse / top [B][S h S w], rank_partial [B][vkn_mask_losses_lowres_chunks(h, w)].
+ * S = 2 or 4, Ns <= 256; anything else VKN_E_SHAPE (the caller up-scales and calls vkn_mask_losses_fwd_bank_f32). */
+int vkn_mask_losses_lowres_chunks(int h, int w);
+int vkn_mask_losses_fwd_lowres_f32(const float* low, const float* bank, const int* tgt_row, const int* rowk, int K, int B, int Ns, int h,
+                                   int w, int S, int with_rank, float* row_partial, float* lse, int* top, float* rank_partial,
+                                   void* stream);
 int vkn_scale_by_f32(const float* in, const float* g, const float* d, float host_scale, float* out, size_t n, void* stream);
 /*      The optimizer step of the training row over ONE flat range (a gradient bucket of dist.BucketedGradAllReducer and the parameters
  *      laid out the same way): torch.optim.SGD's rule with momentum (dampening 0, no nesterov) in one pass —

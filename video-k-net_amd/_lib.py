@@ -29,7 +29,7 @@ SYMBOLS = ('vkn_version', 'vkn_strerror', 'vkn_workspace_init', 'vkn_workspace_s
            'vkn_sizeof_lsap_problem', 'vkn_lsap_batch_f32',
            'vkn_mask_losses_chunks', 'vkn_mask_losses_blocks', 'vkn_mask_losses_fwd_f32', 'vkn_mask_losses_bwd_f32',
            'vkn_sizeof_tail_image', 'vkn_sizeof_tail_cfg', 'vkn_stage_targets', 'vkn_mask_losses_fwd_bank_f32', 'vkn_stage_losses_final_f32',
-           'vkn_mask_losses_bwd_bank_f32', 'vkn_mask_losses_bwd_lowres_f32', 'vkn_scale_by_f32', 'vkn_sgd_momentum_f32', 'vkn_check_range_i64',
+           'vkn_mask_losses_bwd_bank_f32', 'vkn_mask_losses_bwd_lowres_f32', 'vkn_mask_losses_lowres_chunks', 'vkn_mask_losses_fwd_lowres_f32', 'vkn_scale_by_f32', 'vkn_sgd_momentum_f32', 'vkn_check_range_i64',
            'vkn_pow2_scale_f32', 'vkn_scale_pad_rows_f32', 'vkn_transpose_pad_f32', 'vkn_threshold_rows_f16', 'vkn_unscale_rows_f32', 'vkn_sum_n_f32',
            'vkn_sizeof_tracker_cfg', 'vkn_qd_tracker_state_bytes', 'vkn_qd_tracker_workspace_bytes', 'vkn_qd_tracker_state_layout',
            'vkn_qd_tracker_reset', 'vkn_qd_tracker_match_f32')
@@ -424,6 +424,10 @@ def lib():
                                              c_int, c_int, c_int, _fp, _fp, _fp, _fp]
     L.vkn_mask_losses_bwd_bank_f32.restype = c_int
     L.vkn_mask_losses_bwd_bank_f32.argtypes = [_fp] * 9 + [ctypes.c_float] * 3 + [c_int, _fp, _fp, c_int, c_int, c_int, c_int, _fp, _fp]
+    L.vkn_mask_losses_lowres_chunks.restype = c_int
+    L.vkn_mask_losses_lowres_chunks.argtypes = [c_int, c_int]
+    L.vkn_mask_losses_fwd_lowres_f32.restype = c_int
+    L.vkn_mask_losses_fwd_lowres_f32.argtypes = [_fp] * 4 + [c_int] * 7 + [_fp] * 5
     L.vkn_mask_losses_bwd_lowres_f32.restype = c_int
     L.vkn_mask_losses_bwd_lowres_f32.argtypes = [_fp] * 9 + [ctypes.c_float] * 3 + [c_int, _fp, _fp] + [c_int] * 6 + [_fp, _fp]
     L.vkn_scale_by_f32.restype = c_int

@@ -422,6 +422,195 @@ __global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __rest
     }
 }
 
+// ---- the mask-loss FORWARD pass without the xS tensor (round 6): the row sums of the positive rows (k_ml_rows), the rank loss's
+// per-pixel logsumexp / covering row / loss (k_ml_rank_fwd) in ONE kernel that re-forms the up-scaled logits from the low-res ones —
+// k_upsample_s's 981 MB write per stage at the shipped x4 and both kernels' reads of it do not exist.
+// A thread owns one S x S block of up-scaled pixels SHIFTED by S / 2 (rows S bi + S / 2 .. + S - 1, bi = -1 .. h - 1): exactly the
+// pixels whose bilinear source lies between low-res rows bi and bi + 1 / columns bj and bj + 1, with the COMPILE-TIME weights
+// (a + 0.5) / S — four low-res loads per kernel row instead of nine, two-tap interpolation (PyTorch's expression
+// h0 (w0 v00 + w1 v01) + h1 (w0 v10 + w1 v11); at the clamped borders both taps read the same value).  Blocks are numbered flat
+// (bi + 1) (w + 1) + bj + 1: no tile of 64 columns is mostly empty.  The kernel rows are walked in registers (online logsumexp with ONE
+// exponential per pixel and row), the next row's four values are requested one row ahead, row metadata comes from LDS; a positive
+// row's four sums meet per wave (DPP) in LDS and are written once per workgroup: row_partial [K][nchunk][4], nchunk =
+// vkn_mask_losses_lowres_chunks(h, w); rank_partial [B][nchunk].
+template <int S>
+__global__ __launch_bounds__(256, 2) void k_ml_fwd_lr(const float* __restrict__ low, const float* __restrict__ bank,
+                                                      const int* __restrict__ tgt_row, const int* __restrict__ rowk, int Ns, int h, int w,
+                                                      int with_rank, float* __restrict__ row_partial, int nchunk,
+                                                      float* __restrict__ lse, int* __restrict__ top, float* __restrict__ rank_partial) {
+    __shared__ int mk[256], mt[256];
+    __shared__ float PS[256][4][4];   // [row][wave][sum]
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.y, wg = blockIdx.x;
+    const int H = S * h, W = S * w;
+    const size_t P = (size_t)H * W, lp = (size_t)h * w;
+    for (int q = tid; q < Ns; q += 256) {
+        const int k = rowk[b * Ns + q];
+        mk[q] = k;
+        mt[q] = k >= 0 ? tgt_row[b * Ns + q] : 0;
+    }
+    const int nblk = (h + 1) * (w + 1);
+    const int idx0 = wg * 256 + tid;
+    const bool live = idx0 < nblk;
+    const int idx = live ? idx0 : nblk - 1;
+    const int bi = idx / (w + 1) - 1, bj = idx - (bi + 1) * (w + 1) - 1;
+    // pixel (a, c) of the block: row S bi + S / 2 + a, column S bj + S / 2 + c; outside the map for the half blocks of the border ring
+    const int Y0 = S * bi + S / 2, X0 = S * bj + S / 2;
+    unsigned vmask = 0;
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+        for (int c = 0; c < S; ++c)
+            if (live && Y0 + a >= 0 && Y0 + a < H && X0 + c >= 0 && X0 + c < W) vmask |= 1u << (a * S + c);
+    // clamped low-res taps, as byte offsets of a buffer load (the row's offset rides in a scalar register)
+    const int r0 = max(bi, 0), r1 = min(bi + 1, h - 1), c0 = max(bj, 0), c1 = min(bj + 1, w - 1);
+    const int o00 = (r0 * w + c0) * 4, o01 = (r0 * w + c1) * 4, o10 = (r1 * w + c0) * 4, o11 = (r1 * w + c1) * 4;
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(low + (size_t)b * Ns * lp), 0, (int)((size_t)Ns * lp * 4), 0x00020000);
+    // the block's pixels in the up-scaled map, rows clamped into it; per row the pixels travel in aligned PAIRS (S / 2 is even for
+    // S = 4: a pair is inside or outside the map as a whole) or singly (S = 2)
+    size_t prow[S];
+#pragma unroll
+    for (int a = 0; a < S; ++a) prow[a] = (size_t)min(max(Y0 + a, 0), H - 1) * W;
+    constexpr int PW = S == 4 ? 2 : 1, NP = S / PW;   // pixels per access, accesses per block row
+    int pcol[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) pcol[q] = min(max(X0 + PW * q, 0), W - PW);
+    float m[S][S], sm[S][S], zt[S][S];
+    unsigned tpk[S];
+#pragma unroll
+    for (int a = 0; a < S; ++a) {
+        tpk[a] = 0;
+#pragma unroll
+        for (int c = 0; c < S; ++c) { m[a][c] = -INFINITY; sm[a][c] = 0.f; zt[a][c] = 0.f; }
+    }
+    unsigned cov = 0;   // bit (a, c): some positive row covers the pixel (its top row is the byte in tpk)
+    __syncthreads();
+    float vn[4];
+    vn[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o00, 0, 0));
+    vn[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o01, 0, 0));
+    vn[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o10, 0, 0));
+    vn[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o11, 0, 0));
+    for (int n = 0; n < Ns; ++n) {
+        const float v00 = vn[0], v01 = vn[1], v10 = vn[2], v11 = vn[3];
+        if (n + 1 < Ns) {
+            const int so = (n + 1) * (int)lp * 4;
+            vn[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o00, so, 0));
+            vn[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o01, so, 0));
+            vn[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o10, so, 0));
+            vn[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o11, so, 0));
+        }
+        const int k = __builtin_amdgcn_readfirstlane(mk[n]);   // uniform
+        float z[S][S];
+        {
+            float h0[S], h1[S];
+#pragma unroll
+            for (int c = 0; c < S; ++c) {
+                constexpr float rs = 1.0f / (float)S;
+                const float lx = ((float)c + 0.5f) * rs;
+                h0[c] = (1.f - lx) * v00 + lx * v01;
+                h1[c] = (1.f - lx) * v10 + lx * v11;
+            }
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                constexpr float rs = 1.0f / (float)S;
+                const float ly = ((float)a + 0.5f) * rs;
+#pragma unroll
+                for (int c = 0; c < S; ++c) z[a][c] = (1.f - ly) * h0[c] + ly * h1[c];
+            }
+        }
+        if (with_rank) {
+            // online logsumexp, one exponential per pixel: e = exp(-|z - m|); z above the running maximum rescales the sum, else adds to it
+#pragma unroll
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+                for (int c = 0; c < S; ++c) {
+                    const float d = z[a][c] - m[a][c];
+                    const float e = __expf(-fabsf(d));
+                    sm[a][c] = d > 0.f ? sm[a][c] * e + 1.f : sm[a][c] + e;
+                    m[a][c] = fmaxf(m[a][c], z[a][c]);
+                }
+        }
+        if (k >= 0) {
+            const float* trow = bank + (size_t)mt[n] * P;
+            float t[S][S];
+#pragma unroll
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    if (PW == 2) {
+                        const f32x2 t2 = *reinterpret_cast<const f32x2*>(trow + prow[a] + pcol[q]);
+                        t[a][2 * q] = t2[0];
+                        t[a][2 * q + 1] = t2[1];
+                    } else {
+                        t[a][q] = trow[prow[a] + pcol[q]];
+                    }
+                }
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+                for (int c = 0; c < S; ++c) {
+                    const bool ok = (vmask >> (a * S + c)) & 1u;
+                    const float zz = z[a][c], tt = ok ? t[a][c] : 0.f;
+                    // (k_ml_rows' expressions)
+                    const float bce = fmaxf(zz, 0.f) - zz * tt + __logf(1.0f + __expf(-fabsf(zz)));
+                    const float pp = __builtin_amdgcn_rcpf(1.0f + __expf(-zz));
+                    s0 += ok ? bce : 0.f;
+                    s1 += ok ? pp * tt : 0.f;
+                    s2 += ok ? pp * pp : 0.f;
+                    s3 += tt * tt;
+                    if (ok && tt != 0.f) {   // the LAST positive row that covers the pixel (k_ml_rank_fwd)
+                        cov |= 1u << (a * S + c);
+                        tpk[a] = (tpk[a] & ~(255u << (8 * c))) | ((unsigned)n << (8 * c));
+                        zt[a][c] = zz;
+                    }
+                }
+            s0 = vkn_wave_sum(s0); s1 = vkn_wave_sum(s1); s2 = vkn_wave_sum(s2); s3 = vkn_wave_sum(s3);
+            if (lane == 0) { PS[n][wv][0] = s0; PS[n][wv][1] = s1; PS[n][wv][2] = s2; PS[n][wv][3] = s3; }
+        }
+    }
+    float loss = 0.f;
+    if (with_rank) {
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                float lv[PW];
+                int tv[PW];
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < PW; ++e) {
+                    const int c = PW * q + e;
+                    const bool ok = (vmask >> (a * S + c)) & 1u, cv = (cov >> (a * S + c)) & 1u;
+                    lv[e] = m[a][c] + __logf(sm[a][c]);
+                    tv[e] = cv ? (int)((tpk[a] >> (8 * c)) & 255u) : -1;
+                    if (ok && cv) loss += lv[e] - zt[a][c];
+                    any |= ok;
+                }
+                if (any) {   // (a pair is inside the map as a whole)
+                    const size_t o = (size_t)b * P + prow[a] + pcol[q];
+                    if (PW == 2) {
+                        *reinterpret_cast<f32x2*>(lse + o) = f32x2{lv[0], lv[PW - 1]};
+                        typedef int i32x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<i32x2*>(top + o) = i32x2{tv[0], tv[PW - 1]};
+                    } else {
+                        lse[o] = lv[0];
+                        top[o] = tv[0];
+                    }
+                }
+            }
+    }
+    loss = vkn_wave_sum(loss);
+    if (lane == 0) red[wv] = loss;
+    __syncthreads();
+    if (with_rank && tid == 0) rank_partial[(size_t)b * nchunk + wg] = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int q = tid; q < Ns * 4; q += 256) {
+        const int n = q >> 2, j = q & 3, k = mk[n];
+        if (k >= 0) row_partial[((size_t)k * nchunk + wg) * 4 + j] = (PS[n][0][j] + PS[n][1][j]) + (PS[n][2][j] + PS[n][3][j]);
+    }
+}
+
 // Sigmoid focal loss (mmdet FocalLoss(use_sigmoid=True): py_sigmoid_focal_loss, the classification loss of every shipped config) over
 // logits [M][ncls] with integer labels [M] (label == ncls or out of range = background: an all-zero target row) and optional
 // per-row [M] or per-element [M][ncls] weights: element loss = w_row * bce(z, t) * (alpha t + (1 - alpha)(1 - t)) * pt^gamma, pt = (1 - p) t + p (1 - t).
@@ -684,8 +873,9 @@ __global__ __launch_bounds__(256) void k_tail_final(const VknTailCfg cfg, const 
     float bce = 0.f, dice = 0.f, hit = 0.f;
     for (int k = tid; k < K; k += 256) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
         for (int c = 0; c < nchunk; ++c) {
-            const float* q = row_partial + ((size_t)k * nchunk + c) * 4;
+            const f32x4 q = *reinterpret_cast<const f32x4*>(row_partial + ((size_t)k * nchunk + c) * 4);
             s0 += q[0]; s1 += q[1]; s2 += q[2]; s3 += q[3];
         }
         const float bc = (s2 + cfg.dice_eps) + (s3 + cfg.dice_eps);
@@ -1017,6 +1207,23 @@ int vkn_mask_losses_fwd_bank_f32(const float* pred, const float* bank, const int
                                  float* rank_partial, void* stream) {
     if (!tgt_row) return VKN_E_ARG;
     return ml_fwd(pred, bank, tgt_row, pos_rows, rowk, K, B, Ns, P, with_rank, row_partial, lse, top, rank_partial, stream);
+}
+
+int vkn_mask_losses_lowres_chunks(int h, int w) { return (h > 0 && w > 0) ? ((h + 1) * (w + 1) + 255) / 256 : 0; }
+
+int vkn_mask_losses_fwd_lowres_f32(const float* low, const float* bank, const int* tgt_row, const int* rowk, int K, int B, int Ns, int h,
+                                   int w, int S, int with_rank, float* row_partial, float* lse, int* top, float* rank_partial,
+                                   void* stream) {
+    if (!low || !bank || !tgt_row || !rowk || !row_partial || B <= 0 || Ns <= 0 || h <= 0 || w <= 0 || K <= 0) return VKN_E_ARG;
+    if (with_rank && (!lse || !top || !rank_partial)) return VKN_E_ARG;
+    if ((S != 2 && S != 4) || Ns > 256 || (size_t)Ns * h * w * sizeof(float) >= (1ull << 31)) return VKN_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(bank) | reinterpret_cast<uintptr_t>(lse) | reinterpret_cast<uintptr_t>(top)) & 7) return VKN_E_ALIGN;
+    const int nchunk = vkn_mask_losses_lowres_chunks(h, w);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (S == 4) hipLaunchKernelGGL(k_ml_fwd_lr<4>, dim3(nchunk, B), dim3(256), 0, st, low, bank, tgt_row, rowk, Ns, h, w, with_rank, row_partial, nchunk, lse, top, rank_partial);
+    else hipLaunchKernelGGL(k_ml_fwd_lr<2>, dim3(nchunk, B), dim3(256), 0, st, low, bank, tgt_row, rowk, Ns, h, w, with_rank, row_partial, nchunk, lse, top, rank_partial);
+    VKN_CHECK_LAUNCH();
+    return VKN_OK;
 }
 
 int vkn_stage_losses_final_f32(const VknTailCfg* cfg, const float* avg_factor_dev, const float* focal_partial, int n_focal,

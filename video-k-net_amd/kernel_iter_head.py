@@ -108,10 +108,42 @@ class KernelIterHead(BaseRoIHead):
                     object_feats=object_feats)
 
     _lowres_tail_step = False     # set by `_train_stages` for the duration of a step that runs the low-res loss tail
+    _defer_scaled = False         # ... and for its stages whose up-scaled logits nobody outside the loop sees (every stage but the last)
+
+    class DeferredScaled:
+        """The x`stride` up-scaling of a stage's low-res mask logits that has NOT been computed: inside the training loop the
+        assignment costs and the loss tail work from the low-res logits (vkn_assign_costs_lowres_batch_f32,
+        vkn_mask_losses_fwd_lowres_f32 / _bwd_lowres_f32), so the [B, Ns, S h, S w] tensor — 981 MB per stage at the shipped x4 —
+        exists only if something asks for it: `materialize()` (values + the adjoint as backward, as `_upsample` returns)."""
+
+        def __init__(self, lowres, stride, make):
+            self._vkn_lowres, self.stride, self._make, self._t = lowres, stride, make, None
+            b, n, h, w = lowres.shape
+            self.shape = torch.Size((b, n, h * stride, w * stride))
+            self.dtype, self.device, self.is_cuda = lowres.dtype, lowres.device, lowres.is_cuda
+
+        def dim(self):
+            return 4
+
+        def detach(self):
+            return self
+
+        def materialize(self):
+            if self._t is None:
+                self._t = self._make(self._vkn_lowres, self.stride)
+            return self._t
+
+        def __getitem__(self, i):
+            return self.materialize()[i]
 
     def _upsample(self, mask_preds, stride):
         """`F.interpolate(mask_preds, scale_factor=stride, bilinear, align_corners=False)` (reference :122-130): the HIP kernel; under
         autograd the same kernel with its adjoint as backward."""
+        if self._lowres_tail_step and self._defer_scaled and mask_preds.requires_grad and torch.is_grad_enabled():
+            return self.DeferredScaled(mask_preds, stride, self._upsample_now)
+        return self._upsample_now(mask_preds, stride)
+
+    def _upsample_now(self, mask_preds, stride):
         if self._lowres_tail_step and mask_preds.requires_grad and torch.is_grad_enabled():
             # the fused loss tail differentiates w.r.t. the LOW-RES logits itself (train_tail.py, vkn_mask_losses_bwd_lowres_f32): the
             # up-scaled values carry no graph of their own — but whoever back-propagates through the RETURNED tensor (nobody in the
@@ -247,12 +279,15 @@ class KernelIterHead(BaseRoIHead):
                 self.mask_assigner[0].validate_labels(gt_labels, self.num_thing_classes)
         for stage in range(self.num_stages):
             extra = stage_kwargs(stage) if stage_kwargs is not None else {}
+            # the up-scaled logits of every stage but the last stay uncomputed unless something below asks for them
+            self._defer_scaled = bool(lowres) and stage < self.num_stages - 1 and getattr(tail, 'lowres_forward', False)
             mask_results = self._mask_forward(stage, x, object_feats, mask_preds, img_metas, **extra)
+            self._defer_scaled = False
             mask_preds, scaled_mask_preds = mask_results['mask_preds'], mask_results['scaled_mask_preds']
             cls_score, object_feats = mask_results['cls_score'], mask_results['object_feats']
             stage_low = mask_preds.detach() if up > 1 and getattr(scaled_mask_preds, '_vkn_lowres', None) is mask_preds else None
             if self.post_assign:
-                assign_masks, assign_cls, assign_low = scaled_mask_preds.detach(), cls_score.detach(), stage_low
+                assign_masks, assign_cls, assign_low = (None if stage_low is not None else scaled_mask_preds.detach()), cls_score.detach(), stage_low
             if stage < self.assign_stages:       # later stages keep the last assignment (:196)
                 assign_results = self._assign_batch(stage, assign_masks, assign_cls, gt_masks, gt_labels, img_metas,
                                                     lowres=(assign_low, up) if assign_low is not None else None)
@@ -267,6 +302,8 @@ class KernelIterHead(BaseRoIHead):
                     stage_losses = tail.stage_losses(head, self.train_cfg[stage], assign_results, cls_score, scaled_mask_preds)
             if stage_losses is None:
                 self._last_tail_fused = False
+                if hasattr(scaled_mask_preds, 'materialize'):
+                    scaled_mask_preds = mask_results['scaled_mask_preds'] = scaled_mask_preds.materialize()
                 sampler = self.mask_sampler[stage]
                 sampling_results = [sampler.sample(assign_results[i], scaled_mask_preds[i], gt_masks[i]) for i in range(num_imgs)]
                 mask_targets = head.get_targets(sampling_results, gt_masks, gt_labels, self.train_cfg[stage], True,
@@ -276,7 +313,7 @@ class KernelIterHead(BaseRoIHead):
             for key, value in stage_losses.items():
                 all_stage_loss[f's{stage}_{key}'] = value if w == 1 else value * w      # (x * 1 == x: no launch, no autograd node)
             if not self.post_assign:
-                assign_masks, assign_cls, assign_low = scaled_mask_preds.detach(), cls_score.detach(), stage_low
+                assign_masks, assign_cls, assign_low = (None if stage_low is not None else scaled_mask_preds.detach()), cls_score.detach(), stage_low
         self._lowres_tail_step = False
         if tail is not None:
             tail.finish()
@@ -298,7 +335,8 @@ class KernelIterHead(BaseRoIHead):
             if a.lowres_ready(lows, lowres[1], c, gt_masks, gt_labels):
                 return a.assign_batch_lowres(lows, lowres[1], c, gt_masks, gt_labels)
         if masks is None:
-            masks = self._upsample(lowres[0], lowres[1])
+            masks = ops.upsample_bilinear(lowres[0], lowres[1]) if lowres[0].is_cuda and lowres[0].dtype == torch.float32 else \
+                torch.nn.functional.interpolate(lowres[0], scale_factor=lowres[1], mode='bilinear', align_corners=False)
         m = [masks[i][:Np] for i in range(n)]
         if hasattr(a, 'assign_batch'):
             return a.assign_batch(m, c, gt_masks, gt_labels, img_metas)

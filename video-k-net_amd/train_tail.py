@@ -130,6 +130,8 @@ class TailStep:
         self.sem_cls = [as_i64(c) if self.n_sem[b] else None for b, c in enumerate(gt_sem_cls)] if self.with_sem else [None] * self.B
         self.status = torch.zeros(1, dtype=torch.int32, device=device)    # bit 0: a stuff class out of range or listed twice (vkn_stage_targets), bit 1: a thing label (validate_labels)
 
+    lowres_forward = True   # the forward sums of the low-res tail from the low-res logits (False: from their up-scaling, A/B)
+
     def stage_ok(self, head, assign_results, cls_score, scaled):
         return (cls_score is not None and cls_score.dtype == torch.float32 and scaled.is_cuda and scaled.dtype == torch.float32
                 and scaled.dim() == 4 and tuple(scaled.shape[-2:]) == self.shape and (self.shape[0] * self.shape[1]) % 4 == 0
@@ -182,7 +184,11 @@ class TailStep:
         t.alpha, t.gamma = float(head.loss_cls.alpha), float(head.loss_cls.gamma)
         if lowres is not None:
             t.stride = int(stride)
-            l_cls, acc, l_mask, l_dice, l_rank = StageTailFn.apply(cls_score, lowres, t, scaled.detach())
+            # forward sums from the low-res logits too (strides 2 / 4, up to 256 rows per frame); else from `scaled`
+            from_low = self.lowres_forward and stride in (2, 4) and Ns <= 256 and lowres.shape[1] * lowres.shape[2] * lowres.shape[3] * 4 < 2 ** 31
+            if not from_low and hasattr(scaled, 'materialize'):
+                scaled = scaled.materialize()
+            l_cls, acc, l_mask, l_dice, l_rank = StageTailFn.apply(cls_score, lowres, t, 'lowres' if from_low else scaled.detach())
         else:
             l_cls, acc, l_mask, l_dice, l_rank = StageTailFn.apply(cls_score, scaled, t, None)
         out = dict(loss_cls=l_cls, pos_acc=acc, loss_mask=l_mask, loss_dice=l_dice)
@@ -211,12 +217,20 @@ class StageTailFn(torch.autograd.Function):
         L = _lib.lib()
         dev = mask_pred.device
         B, Ns, K, ncls = t.B, t.Ns, t.K, t.ncls
-        on = scaled if scaled is not None else mask_pred
-        R, P = B * Ns, on.shape[2] * on.shape[3]
+        # scaled == 'lowres' (round 6): `mask_pred` are the LOW-RES logits and the sums come straight from them
+        # (vkn_mask_losses_fwd_lowres_f32) — their x`t.stride` up-scaling is not read, and need not exist
+        from_low = isinstance(scaled, str)
+        on = mask_pred if (scaled is None or from_low) else scaled
+        R = B * Ns
+        P = on.shape[2] * on.shape[3] * (t.stride ** 2 if from_low else 1)
         z = _req(cls_score.reshape(R, ncls), 'cls_score')
-        pred = _req(on.reshape(R, P), 'mask_pred')
+        pred = _req(on if from_low else on.reshape(R, P), 'mask_pred')
         with_rank = bool(t.cfg.with_rank)
-        nbf, nch, nbl = L.vkn_focal_loss_blocks(R, ncls), L.vkn_mask_losses_chunks(P), L.vkn_mask_losses_blocks(P)
+        nbf = L.vkn_focal_loss_blocks(R, ncls)
+        if from_low:
+            nch = nbl = L.vkn_mask_losses_lowres_chunks(on.shape[2], on.shape[3])
+        else:
+            nch, nbl = L.vkn_mask_losses_chunks(P), L.vkn_mask_losses_blocks(P)
         part = torch.empty(nbf, dtype=torch.float32, device=dev)
         fgrad = torch.empty_like(z)
         rp = torch.empty((K, nch, 4), dtype=torch.float32, device=dev)
@@ -229,15 +243,20 @@ class StageTailFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             check(L.vkn_focal_loss_f32(_ptr(z), t.labels.data_ptr(), _ptr(t.label_weights), 1 if ncls > 1 else 0, R, ncls, t.alpha, t.gamma,
                                        _ptr(part), _ptr(fgrad), st))
-            check(L.vkn_mask_losses_fwd_bank_f32(_ptr(pred), _ptr(t.bank), t.tgt_row.data_ptr(), t.pos_rows.data_ptr(), t.rowk.data_ptr(),
-                                                 K, B, Ns, P, 1 if with_rank else 0, _ptr(rp), _ptr(lse),
-                                                 top.data_ptr() if with_rank else None, _ptr(rkp), st))
+            if from_low:
+                check(L.vkn_mask_losses_fwd_lowres_f32(_ptr(pred), _ptr(t.bank), t.tgt_row.data_ptr(), t.rowk.data_ptr(), K, B, Ns,
+                                                       on.shape[2], on.shape[3], t.stride, 1 if with_rank else 0, _ptr(rp), _ptr(lse),
+                                                       top.data_ptr() if with_rank else None, _ptr(rkp), st))
+            else:
+                check(L.vkn_mask_losses_fwd_bank_f32(_ptr(pred), _ptr(t.bank), t.tgt_row.data_ptr(), t.pos_rows.data_ptr(), t.rowk.data_ptr(),
+                                                     K, B, Ns, P, 1 if with_rank else 0, _ptr(rp), _ptr(lse),
+                                                     top.data_ptr() if with_rank else None, _ptr(rkp), st))
             check(L.vkn_stage_losses_final_f32(ctypes.byref(t.cfg), _ptr(t.avg_dev), _ptr(part), nbf, _ptr(rp), K, nch, _ptr(rkp),
                                                B * nbl if with_rank else 0, _ptr(z), t.labels.data_ptr(), t.pos_rows.data_ptr(), ncls, B, P,
                                                _ptr(out), _ptr(a), _ptr(bc), st))
         ctx.set_materialize_grads(False)
         ctx.lowres = scaled is not None
-        ctx.save_for_backward(_req(mask_pred, 'mask_pred') if ctx.lowres else pred, fgrad, a, bc, lse if with_rank else a.new_empty(0),
+        ctx.save_for_backward(pred if from_low else (_req(mask_pred, 'mask_pred') if ctx.lowres else pred), fgrad, a, bc, lse if with_rank else a.new_empty(0),
                               top if with_rank else t.rowk.new_empty(0))
         ctx.t, ctx.shapes = t, (tuple(cls_score.shape), tuple(mask_pred.shape))
         acc = out[1:2]
