@@ -226,14 +226,17 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float* __restrict__ 
 
 // ---- the mask-loss backward pass WITHOUT the xS gradient tensor (round 6): d(losses) / d(low-res mask logits) in one kernel.
 // k_ml_bwd writes the gradient w.r.t. the up-scaled predictions ([B Ns][S h][S w]: 981 MB per stage at the shipped x4 and four 1024x2048
-// frames) and the upsample adjoint reads it back; here a thread owns one low-res pixel's S x S block of up-scaled pixels: it re-forms
-// their logits from the 3 x 3 low-res neighbourhood (the forward kernel's source-index / weight formulas, so every border case agrees),
-// evaluates the gradient of the three losses there (k_ml_bwd's expressions), and folds the S x S values into the nine low-res
-// neighbours with the SEPARABLE adjoint weights.  The nine partial sums meet their owners through a wave shift (columns) and one LDS
-// exchange per kernel row (block rows = waves): fixed order, deterministic.  lse / top / targets of the block are loaded once and the
-// kernel rows n are walked in registers, so the only x S-sized reads are the rank loss's lse / top (8 bytes per pixel) and the
-// positive rows' targets.  Workgroup = LR_NW waves (block rows i0 - 1 .. i0 + LR_NW - 2) x 64 lanes (columns j0 - 1 .. j0 + 62): the
-// outer ring only feeds its neighbours.
+// frames) and the upsample adjoint reads it back; here a thread owns one S x S block of up-scaled pixels SHIFTED by S / 2 (k_ml_fwd_lr's
+// blocks: rows S bi + S / 2 .., bi = -1 .. h - 1): it re-forms their logits from the FOUR low-res taps (bi, bi + 1) x (bj, bj + 1) with
+// the compile-time weights (a + 0.5) / S, evaluates the gradient of the three losses there (k_ml_bwd's expressions) and folds the
+// S x S values back onto the four taps with the separable adjoint.  A low-res pixel (i, j) collects tap (0, 0) of block (i, j),
+// (0, 1) of (i, j - 1), (1, 0) of (i - 1, j) and (1, 1) of (i - 1, j - 1): columns through one wave shift, rows through ONE LDS value per
+// wave and kernel row (fixed order, deterministic); at the clamped borders a block's two taps of a direction are the same pixel and
+// are summed before the exchange.  Workgroup = LR_NW waves (block rows) x 64 lanes (block columns); the first row / column only feed
+// their neighbours: 7 x 63 pixels per workgroup.  lse / top / validity of the block are loaded once, the kernel rows n are walked in
+// registers with the next row's four taps requested one row ahead, row metadata comes from LDS.
+// (The first form of this kernel — unshifted blocks, a 3 x 3 neighbourhood with per-thread three-tap weights, nine loads and a
+// 6-shuffle + 2-LDS-value exchange per row — took 397 us per stage at cfg3 size.)
 #define LR_NW 8
 #define LR_NSPLIT 4
 template <int S>
@@ -241,66 +244,80 @@ __global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __rest
                                                           const int* __restrict__ rowk, const float* __restrict__ lse,
                                                           const int* __restrict__ top, int Ns, int h, int w, int with_rank,
                                                           float* __restrict__ grad_low, const MlTail tl) {
-    __shared__ float xch[2][LR_NW][2][64];
+    __shared__ float xch[2][LR_NW][64];
+    __shared__ int mk[128], mt[128];
+    __shared__ float mca[128], mcb[128];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // blockIdx.z = frame x LR_NSPLIT + part: the kernel rows of a frame are shared by LR_NSPLIT workgroups per pixel tile (the rows are
-    // independent; one workgroup per tile left 1.7 workgroups per CU at four frames: every row's load -> shift -> LDS -> barrier chain exposed)
+    // blockIdx.z = frame x LR_NSPLIT + part: the kernel rows of a frame are shared by LR_NSPLIT workgroups per pixel tile (independent rows)
     const int b = blockIdx.z / LR_NSPLIT, part = blockIdx.z - b * LR_NSPLIT;
     const int rpp = (Ns + LR_NSPLIT - 1) / LR_NSPLIT, n_lo = part * rpp, n_hi = min(Ns, n_lo + rpp);
-    const int i = (int)blockIdx.y * (LR_NW - 2) - 1 + wv, j = (int)blockIdx.x * 62 - 1 + lane;
-    const bool blk = i >= 0 && i < h && j >= 0 && j < w;        // this thread's block exists
-    const bool own = blk && wv >= 1 && wv <= LR_NW - 2 && lane >= 1 && lane <= 62;   // ... and its low-res pixel is written here
+    const int bi = (int)blockIdx.y * (LR_NW - 1) - 1 + wv, bj = (int)blockIdx.x * 63 - 1 + lane;   // this thread's block
+    const bool blk = bi <= h - 1 && bj <= w - 1;                                       // ... exists
+    const bool own = blk && wv >= 1 && lane >= 1;                                      // ... and low-res pixel (bi, bj) is written here
     const int H = S * h, W = S * w;
     const size_t P = (size_t)H * W, lp = (size_t)h * w;
     const float cm = tl.g_mask ? tl.g_mask[0] * tl.c_mask : 0.f;
     const float cr = (with_rank && tl.g_rank) ? tl.g_rank[0] * tl.c_rank : 0.f;
     const float gd = tl.g_dice ? tl.g_dice[0] * tl.c_dice : 0.f;
-    // weights of the block's S output rows / columns on the three low-res rows i - 1, i, i + 1 (columns j - 1, j, j + 1)
-    float wy[S][3], wx[S][3];
-    constexpr float rs = 1.0f / (float)S;
+    const int Y0 = S * bi + S / 2, X0 = S * bj + S / 2;
+    unsigned vmask = 0;
 #pragma unroll
-    for (int a = 0; a < S; ++a) {
-        {
-            const float sy = fmaxf(((float)(S * i + a) + 0.5f) * rs - 0.5f, 0.f);
-            const int y0 = min((int)sy, h - 1), y1 = min(y0 + 1, h - 1);
-            const float ly = sy - (float)y0;
+    for (int a = 0; a < S; ++a)
 #pragma unroll
-            for (int r = 0; r < 3; ++r) wy[a][r] = (y0 == i - 1 + r ? 1.f - ly : 0.f) + (y1 == i - 1 + r ? ly : 0.f);
-        }
-        {
-            const float sx = fmaxf(((float)(S * j + a) + 0.5f) * rs - 0.5f, 0.f);
-            const int x0 = min((int)sx, w - 1), x1 = min(x0 + 1, w - 1);
-            const float lx = sx - (float)x0;
+        for (int c = 0; c < S; ++c)
+            if (blk && Y0 + a >= 0 && Y0 + a < H && X0 + c >= 0 && X0 + c < W) vmask |= 1u << (a * S + c);
+    // clamped low-res taps (byte offsets of a buffer load; the row's offset rides in a scalar register)
+    const int r0 = min(max(bi, 0), h - 1), r1 = min(max(bi + 1, 0), h - 1), c0 = min(max(bj, 0), w - 1), c1 = min(max(bj + 1, 0), w - 1);
+    const bool rsame = r0 == r1, csame = c0 == c1;   // border ring: both taps of a direction are one pixel
+    const int o00 = (r0 * w + c0) * 4, o01 = (r0 * w + c1) * 4, o10 = (r1 * w + c0) * 4, o11 = (r1 * w + c1) * 4;
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(low + (size_t)b * Ns * lp), 0, (int)((size_t)Ns * lp * 4), 0x00020000);
+    // the block's pixels in the up-scaled map (clamped into it), in aligned pairs for S = 4 (a pair is inside or outside as a whole)
+    size_t prow[S];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) wx[a][c] = (x0 == j - 1 + c ? 1.f - lx : 0.f) + (x1 == j - 1 + c ? lx : 0.f);
-        }
-    }
-    // clamped source coordinates (weights of coordinates outside the map are zero)
-    const int ic = min(max(i, 0), h - 1), jc = min(max(j, 0), w - 1);
-    int ro[3], co[3];
+    for (int a = 0; a < S; ++a) prow[a] = (size_t)min(max(Y0 + a, 0), H - 1) * W;
+    constexpr int PW = S == 4 ? 2 : 1, NP = S / PW;
+    int pcol[NP];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) { ro[r] = min(max(ic - 1 + r, 0), h - 1) * w; co[r] = min(max(jc - 1 + r, 0), w - 1); }
+    for (int q = 0; q < NP; ++q) pcol[q] = min(max(X0 + PW * q, 0), W - PW);
     // lse / top of the block's pixels (the frame's, shared by every kernel row).  top as one byte per pixel (Ns <= 256); a pixel that no
-    // positive row covers (top = -1) carries lse = +inf — its softmax term exp(z - lse) is then exactly 0 — and a byte that equals no
-    // row of THIS workgroup's range [n_lo, n_hi), so that its one-hot term is 0 too: no branch per pixel
+    // positive row covers (top = -1) — or that lies outside the map — carries lse = +inf: its softmax term exp(z - lse) is exactly 0, and
+    // a byte that equals no row of THIS workgroup's range [n_lo, n_hi), so that its one-hot term is 0 too: no branch per pixel
     float l[S][S];
     unsigned tpk[S];
-    const size_t pix0 = (size_t)(S * ic) * W + (size_t)S * jc;
 #pragma unroll
     for (int a = 0; a < S; ++a) {
         tpk[a] = 0;
 #pragma unroll
-        for (int c = 0; c < S; ++c) {
-            const int t = with_rank ? top[(size_t)b * P + pix0 + (size_t)a * W + c] : -1;
-            l[a][c] = t >= 0 ? lse[(size_t)b * P + pix0 + (size_t)a * W + c] : INFINITY;
-            tpk[a] |= (unsigned)(t < 0 ? (n_lo == 0 ? n_hi & 255 : 0) : t) << (8 * c);
+        for (int q = 0; q < NP; ++q) {
+            float lv[PW];
+            int tv[PW];
+            if (with_rank) {
+                const size_t o = (size_t)b * P + prow[a] + pcol[q];
+                if (PW == 2) {
+                    typedef int i32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 l2 = *reinterpret_cast<const f32x2*>(lse + o);
+                    const i32x2 t2 = *reinterpret_cast<const i32x2*>(top + o);
+                    lv[0] = l2[0]; lv[PW - 1] = l2[1]; tv[0] = t2[0]; tv[PW - 1] = t2[1];
+                } else {
+                    lv[0] = lse[o];
+                    tv[0] = top[o];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < PW; ++e) { lv[e] = 0.f; tv[e] = -1; }
+            }
+#pragma unroll
+            for (int e = 0; e < PW; ++e) {
+                const int c = PW * q + e;
+                const bool ok = ((vmask >> (a * S + c)) & 1u) && tv[e] >= 0;
+                l[a][c] = ok ? lv[e] : INFINITY;
+                tpk[a] |= (unsigned)(ok ? tv[e] : (n_lo == 0 ? n_hi & 255 : 0)) << (8 * c);
+            }
         }
     }
     // this workgroup's kernel rows: (k, target row, dice coefficients) once, through LDS — inside the row loop they were three DEPENDENT
     // memory round trips per positive row (rowk -> tgt_row / dice_a / dice_bc -> target pixels)
-    __shared__ int mk[128], mt[128];
-    __shared__ float mca[128], mcb[128];
     for (int q = threadIdx.x; q < n_hi - n_lo; q += 64 * LR_NW) {
         const int k = rowk[b * Ns + n_lo + q];
         mk[q] = k;
@@ -315,110 +332,107 @@ __global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __rest
         mt[q] = t; mca[q] = ca; mcb[q] = cb;
     }
     __syncthreads();
-    // the low-res neighbourhood of row n + 1 is requested before row n's arithmetic (one round trip per row was the whole cost of a row)
-    // (buffer loads: nine 32-bit pixel offsets held for the whole kernel + the row's offset in a scalar register — nine 64-bit
-    // addresses per row were 18 registers and, at four waves per SIMD, spilled)
-    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(low + (size_t)b * Ns * lp), 0, (int)((size_t)Ns * lp * 4), 0x00020000);
-    int po[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) po[r][c] = (ro[r] + co[c]) * 4;
-    float vn[3][3];
+    float vn[4];
     if (n_lo < n_hi) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) vn[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, po[r][c], n_lo * (int)lp * 4, 0));
+        const int so = n_lo * (int)lp * 4;
+        vn[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o00, so, 0));
+        vn[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o01, so, 0));
+        vn[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o10, so, 0));
+        vn[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o11, so, 0));
     }
     for (int n = n_lo; n < n_hi; ++n) {
-        float v[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[r][c] = vn[r][c];
+        const float v00 = vn[0], v01 = vn[1], v10 = vn[2], v11 = vn[3];
         if (n + 1 < n_hi) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) vn[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, po[r][c], (n + 1) * (int)lp * 4, 0));
+            const int so = (n + 1) * (int)lp * 4;
+            vn[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o00, so, 0));
+            vn[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o01, so, 0));
+            vn[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o10, so, 0));
+            vn[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o11, so, 0));
         }
         const int k = __builtin_amdgcn_readfirstlane(mk[n - n_lo]);   // uniform
-        const float ca = mca[n - n_lo], cb = mcb[n - n_lo];
-        f32x4 tg[S];   // the block's target pixels (positive rows): S rows of 16 bytes (S = 2: the first two elements)
-#pragma unroll
-        for (int a = 0; a < S; ++a) tg[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (k >= 0) {
-            const float* trow = bank + (size_t)mt[n - n_lo] * P + pix0;
-#pragma unroll
-            for (int a = 0; a < S; ++a) {
-                if (S == 4) tg[a] = *reinterpret_cast<const f32x4*>(trow + (size_t)a * W);
-                else { const f32x2 t2 = *reinterpret_cast<const f32x2*>(trow + (size_t)a * W); tg[a][0] = t2[0]; tg[a][1] = t2[1]; }
-            }
-        }
-        // horizontal pass of the forward interpolation: hx[r][c'] = the three low-res rows at the block's S output columns
-        float hx[3][S];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < S; ++c) hx[r][c] = (v[r][0] * wx[c][0] + v[r][1] * wx[c][1]) + v[r][2] * wx[c][2];
-        // the S x S gradient values of the block: the rank term for every row, the mask / dice terms for a positive row — ONE uniform
-        // branch per row (inside the pixel loop it was a branch per pixel)
-        float g[S][S];
-#pragma unroll
-        for (int a = 0; a < S; ++a)
+        float z[S][S], g[S][S];
+        {
+            constexpr float rs = 1.0f / (float)S;
+            float h0[S], h1[S];
 #pragma unroll
             for (int c = 0; c < S; ++c) {
-                const float z = (hx[0][c] * wy[a][0] + hx[1][c] * wy[a][1]) + hx[2][c] * wy[a][2];
-                const int tpv = (int)((tpk[a] >> (8 * c)) & 255u);
-                g[a][c] = cr * (__expf(z - l[a][c]) - (tpv == n ? 1.f : 0.f));
+                const float lx = ((float)c + 0.5f) * rs;
+                h0[c] = (1.f - lx) * v00 + lx * v01;
+                h1[c] = (1.f - lx) * v10 + lx * v11;
             }
-        if (k >= 0) {
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                const float ly = ((float)a + 0.5f) * rs;
+#pragma unroll
+                for (int c = 0; c < S; ++c) {
+                    z[a][c] = (1.f - ly) * h0[c] + ly * h1[c];
+                    const int tpv = (int)((tpk[a] >> (8 * c)) & 255u);
+                    g[a][c] = cr * (__expf(z[a][c] - l[a][c]) - (tpv == n ? 1.f : 0.f));
+                }
+            }
+        }
+        if (k >= 0) {   // ONE uniform branch per row: the mask / dice terms of a positive row
+            const float ca = mca[n - n_lo], cb = mcb[n - n_lo];
+            const float* trow = bank + (size_t)mt[n - n_lo] * P;
 #pragma unroll
             for (int a = 0; a < S; ++a)
 #pragma unroll
-                for (int c = 0; c < S; ++c) {
-                    const float z = (hx[0][c] * wy[a][0] + hx[1][c] * wy[a][1]) + hx[2][c] * wy[a][2];
-                    const float t = tg[a][c];
-                    const float pp = __builtin_amdgcn_rcpf(1.0f + __expf(-z));   // (v_rcp_f32: 1 ulp, as k_ml_rows)
-                    g[a][c] += cm * (pp - t) + (ca * t + cb * pp) * pp * (1.f - pp);
+                for (int q = 0; q < NP; ++q) {
+                    float tt[PW];
+                    if (PW == 2) {
+                        const f32x2 t2 = *reinterpret_cast<const f32x2*>(trow + prow[a] + pcol[q]);
+                        tt[0] = t2[0]; tt[PW - 1] = t2[1];
+                    } else {
+                        tt[0] = trow[prow[a] + pcol[q]];
+                    }
+#pragma unroll
+                    for (int e = 0; e < PW; ++e) {
+                        const int c = PW * q + e;
+                        const float t = tt[e];
+                        const float pp = __builtin_amdgcn_rcpf(1.0f + __expf(-z[a][c]));   // (v_rcp_f32: 1 ulp, as k_ml_rows)
+                        const float gm = cm * (pp - t) + (ca * t + cb * pp) * pp * (1.f - pp);
+                        g[a][c] += ((vmask >> (a * S + c)) & 1u) ? gm : 0.f;
+                    }
                 }
         }
-        float ps[3][3];   // partial sums for low-res (i - 1 + r, j - 1 + c)
+        // the adjoint onto the four taps, columns first
+        float p00 = 0.f, p01 = 0.f, p10 = 0.f, p11 = 0.f;
+        {
+            constexpr float rs = 1.0f / (float)S;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int a = 0; a < S; ++a) {
+                const float ly = ((float)a + 0.5f) * rs;
+                float q0 = 0.f, q1 = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) ps[r][c] = 0.f;
-#pragma unroll
-        for (int a = 0; a < S; ++a) {
-            // adjoint, columns first: cs[c3] = sum over the row's S pixels of wx * g; then this output row's share of the three low-res rows
-            float cs[3];
-#pragma unroll
-            for (int c3 = 0; c3 < 3; ++c3) {
-                float acc = 0.f;
-#pragma unroll
-                for (int c = 0; c < S; ++c) acc += wx[c][c3] * (blk ? g[a][c] : 0.f);
-                cs[c3] = acc;
+                for (int c = 0; c < S; ++c) {
+                    const float lx = ((float)c + 0.5f) * rs;
+                    q0 += (1.f - lx) * g[a][c];
+                    q1 += lx * g[a][c];
+                }
+                p00 += (1.f - ly) * q0;
+                p01 += (1.f - ly) * q1;
+                p10 += ly * q0;
+                p11 += ly * q1;
             }
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) ps[r][c3] += wy[a][r] * cs[c3];
         }
-        // columns: low-res column j collects ps[.][1] of its own block, ps[.][0] of the block to its right, ps[.][2] of the one to its left
-        float hr[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) hr[r] = (ps[r][1] + __shfl_down(ps[r][0], 1)) + __shfl_up(ps[r][2], 1);
-        // rows: low-res row i collects hr[1] of its own block row, hr[0] of the block row below, hr[2] of the one above
-        float* xb = &xch[(n - n_lo) & 1][0][0][0];
-        xb[(wv * 2 + 0) * 64 + lane] = hr[0];
-        xb[(wv * 2 + 1) * 64 + lane] = hr[2];
+        // clamped borders: the two taps of a direction are ONE pixel — the tap that the exchange routes to this block's own pixel / row
+        // keeps the sum, the other carries nothing (bi = -1: both rows are pixel row 0 = "row bi + 1"; bi = h - 1: both are row h - 1 = "row bi")
+        if (rsame) {
+            if (bi < 0) { p10 += p00; p11 += p01; p00 = p01 = 0.f; }
+            else { p00 += p10; p01 += p11; p10 = p11 = 0.f; }
+        }
+        if (csame) {
+            if (bj < 0) { p01 += p00; p11 += p10; p00 = p10 = 0.f; }
+            else { p00 += p01; p10 += p11; p01 = p11 = 0.f; }
+        }
+        // columns: pixel column bj collects tap (., 0) of its own block and tap (., 1) of the block to its left
+        const float hA = p00 + __shfl_up(p01, 1);   // -> pixel row bi
+        const float hB = p10 + __shfl_up(p11, 1);   // -> pixel row bi + 1
+        float* xb = &xch[(n - n_lo) & 1][0][0];
+        xb[wv * 64 + lane] = hB;
         // (LDS-only barrier: __syncthreads() also fences global memory — a wait for the NEXT row's prefetched loads, every row)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (own) {
-            const float out = (hr[1] + xb[((wv + 1) * 2 + 0) * 64 + lane]) + xb[((wv - 1) * 2 + 1) * 64 + lane];
-            grad_low[((size_t)b * Ns + n) * lp + (size_t)i * w + j] = out;
-        }
+        if (own) grad_low[((size_t)b * Ns + n) * lp + (size_t)bi * w + bj] = hA + xb[(wv - 1) * 64 + lane];
     }
 }
 
@@ -1265,7 +1279,7 @@ int vkn_mask_losses_bwd_lowres_f32(const float* low, const float* bank, const in
     const double P = (double)S * h * (double)S * w;
     MlTail tl = {tgt_row, dice_a, dice_bc, g_mask, g_dice, g_rank, (float)((double)w_mask / ((double)K * P)),
                  (float)((double)w_dice / (double)K), (float)((double)w_rank / ((double)B * P))};
-    const dim3 grid((w + 61) / 62, (h + LR_NW - 3) / (LR_NW - 2), B * LR_NSPLIT);
+    const dim3 grid((w + 62) / 63, (h + LR_NW - 2) / (LR_NW - 1), B * LR_NSPLIT);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (S == 4) hipLaunchKernelGGL(k_ml_bwd_lr<4>, grid, dim3(64 * LR_NW), 0, st, low, bank, rowk, lse, top, Ns, h, w, with_rank, grad_low, tl);
     else hipLaunchKernelGGL(k_ml_bwd_lr<2>, grid, dim3(64 * LR_NW), 0, st, low, bank, rowk, lse, top, Ns, h, w, with_rank, grad_low, tl);
