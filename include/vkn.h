@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define VKN_VERSION 0x000600 /* 0.5.0: the persistent chain runs on the two-term fp16 split (VKN_FLAG_CHAIN_BF16X3 opts out; vkn_prepared_bytes grows by the
+#define VKN_VERSION 0x000600 /* 0.6.0: the training tail on the LOW-RES logits (vkn_assign_costs_lowres_batch_f32, vkn_mask_losses_fwd_lowres_f32 /
+                              * _bwd_lowres_f32), vkn_sgd_momentum_f32, one-pass kernel initialisation (VKN_FLAG_INIT_SEPARATE opts out),
+                              * vkn_track_link_flags_f32.  0.5.0: the persistent chain runs on the two-term fp16 split (VKN_FLAG_CHAIN_BF16X3 opts out; vkn_prepared_bytes grows by the
                               * fp16 weight images), the loss tail without target tensors (vkn_stage_targets ...), the backward glue entry points,
                               * vkn_sum_n_f32.  0.4.0: few-row chain (VKN_FLAG_CHAIN_KSPLIT), VKN_FLAG_SCALED_F16 + vkn_upsample_bilinear_f16out,
                               * VKN_FLAG_JOIN_EARLY, struct size probes */
