@@ -360,7 +360,7 @@ def _linked_worker(rank, world, port, T, q):
     b0, b1 = d.shard_bounds(T, world, rank)
     log = []
     out = d.linked_block_forward(_stub_phases(x[b0:b1], log), first)
-    q.put((rank, b0, b1, out, log))
+    q.put((rank, b0, b1, out.numpy(), log))     # (by value: a torch tensor travels as a file descriptor the child must outlive)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -390,7 +390,7 @@ def test_previous_link_clip_sharded_in_phases_equals_the_whole_clip():
         for p in procs:
             p.join(timeout=120)
             assert p.exitcode == 0
-        got = torch.cat([r[3] for r in res])
+        got = torch.cat([torch.from_numpy(r[3]) for r in res])
         assert [r[1] for r in res] == [(T * k) // world for k in range(world)] and res[-1][2] == T
         assert torch.equal(got, whole), f'world {world}: max err {float((got - whole).abs().max())}'
         assert all(r[4] == ['A', 'B', 'C'] for r in res)
