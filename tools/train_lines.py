@@ -20,7 +20,7 @@ vkn = vkn_import.load()
 vkn_dist = import_module('video_k_net_amd.dist')
 device = torch.device('cuda', 0)
 src = open(os.path.join(ROOT, 'bench.py')).read()
-args = argparse.Namespace(frames=int(sys.argv[2]) if len(sys.argv) > 2 else 32, warmup=3, steps=10, no_chain_graphs=False, torch_chain=False)
+args = argparse.Namespace(frames=int(sys.argv[2]) if len(sys.argv) > 2 else 32, warmup=3, steps=10, no_chain_graphs=False, torch_chain=False, train_up=4)
 body = src[src.index('def train_main('):src.index('    def step():', src.index('def train_main('))]
 ns = dict(bench.__dict__)
 exec(body + '    return locals()\n', ns)
