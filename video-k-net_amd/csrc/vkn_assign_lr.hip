@@ -17,8 +17,12 @@
 //     PyTorch's source index is); the horizontal interpolation of a lane's 8 pixels is shared by the tile's 8 rows;
 //   * arithmetic: p = clamp(sigmoid(z)) with v_exp_f32 / v_rcp_f32 (1 ulp each), both operands on the two-term f16 split
 //     (g_lo p_hi + g_hi p_lo + g_hi p_hi, fp32 accumulate: 2^-22 relative, exact for 0/1 masks), accumulators flushed into a second
-//     level per tile, row sums of p1^2 and p2 per lane, every partial summed in fixed order (fp64) by the finishing kernel —
-//     deterministic, independent of the batch size (AL_WGS workgroups per image whatever the batch).
+//     level (LDS) per tile, row sums of p1^2 and p2 per lane, sum g / sum g^2 of the ground truth riding along (the active waves share
+//     the steps), every partial summed in fixed order (fp64) by the finishing kernel — deterministic, independent of the batch size
+//     (AL_WGS workgroups per image whatever the batch);
+//   * one block of 32 ground truths per pass (blockIdx.z): an image with more of them recomputes the activations per block (a pass
+//     over two blocks at once needs 128 accumulator registers — one wave per SIMD — and its instantiation with a `sched_barrier` per
+//     step produced wrong sums: docs/LAB_NOTEBOOK.md III.1).
 //   The interpolation is PyTorch's expression h0 (w0 v00 + w1 v01) + h1 (w0 v10 + w1 v11) with its clamped source indices; where the
 //   source coordinate is clamped at the top / left border PyTorch's weights collapse to (1, 0) and ours stay (1 - l, l) on twice the
 //   same value — at most one ulp of the logit.
@@ -29,9 +33,9 @@
 #include "vkn_common.h"
 #include "vkn_launch.h"
 
-// Floating-point contraction is OFF in this file: the kernel is instantiated per stride and per number of ground-truth blocks, and
-// hipcc contracts `a * b + c` in one instantiation and not in another — an image's costs would then depend on the widest ground truth
-// of its batch in the last bit.  The fused multiply-adds below are written out.
+// Floating-point contraction is OFF in this file: hipcc contracts `a * b + c` in one instantiation of a template and not in another
+// (seen here between the one- and two-block forms: an image's costs depended on the widest ground truth of its batch in the last
+// bit).  The fused multiply-adds below are written out.
 #pragma clang fp contract(off)
 
 #define AL_WGS 128     // workgroups per image (fixed: the order of the partial sums does not depend on the batch)
