@@ -581,7 +581,7 @@ int vkn_assign_costs_batch_f32(const VknAssignCfg* cfg, const VknAssignProblem* 
  *      `F.interpolate(mask_preds, scale_factor=S, mode='bilinear', align_corners=False)` (knet/det/kernel_update_head.py:122-130 ->
  *      knet/det/kernel_iter_head.py:150-156,225-226); here `mask_logits` of a problem are the stage's [N][h][w] logits BEFORE that
  *      up-scaling and `gt_masks` [G][S h][S w]: interpolation, activation and both contractions run in ONE kernel for the whole batch
- *      (the up-scaled prediction and its activation plane are never written).  S = 2 or 4, w % 16 == 0, S h % 8 == 0, N, G <= 256,
+ *      (the up-scaled prediction and its activation plane are never written).  S = 2 or 4, S w % 8 == 0, N, G <= 256,
  *      nprob <= 16 — anything else returns VKN_E_SHAPE (the caller up-scales and calls vkn_assign_costs_batch_f32).  Deterministic;
  *      the partial-sum order does not depend on nprob.  Gmax: the largest of the problems' G. */
 size_t vkn_assign_lowres_workspace_bytes(int nprob, int N, int Gmax, int h, int w, int S);

@@ -48,10 +48,13 @@ CASES = [
     (150, [9, 70], 5, 8, 32, 4, True),                 # two groups of 128 kernels; 70 ground truths: two passes of two blocks
     (256, [3], 3, 2, 16, 4, False),                    # one tile row
     (37, [40, 2, 6], 4, 12, 48, 2, True),              # ragged N, stride 2, odd tile count
+    (100, [9, 14], 19, 48, 156, 4, True),              # KITTI-STEP's 384 x 1248 frames: 156 columns = 9.75 tiles, 48 rows
+    (50, [5, 3], 3, 7, 22, 4, False),                  # odd height (a half tile row at the bottom), ragged width
+    (64, [11], 3, 5, 12, 2, True),                     # stride 2: 10 x 24 pixels, both edges ragged
 ]
 
 
-@pytest.mark.parametrize('N,Gs,ncls,h,w,S,soft', CASES, ids=['cfg3', 'stride2', 'n150_g70', 'n256', 'n37'])
+@pytest.mark.parametrize('N,Gs,ncls,h,w,S,soft', CASES, ids=['cfg3', 'stride2', 'n150_g70', 'n256', 'n37', 'kitti_step', 'odd_h', 'ragged_s2'])
 def test_lowres_costs_vs_fp64_and_vs_the_three_pass_form(vkn, N, Gs, ncls, h, w, S, soft):
     lows, clss, gts, labs = _case(N, Gs, ncls, h, w, S, 11, soft)
     dl, dc, dg, dlab = ([t.to(DEV) for t in v] for v in (lows, clss, gts, labs))
@@ -92,14 +95,14 @@ def test_lowres_costs_do_not_depend_on_the_batch(vkn):
 
 
 def test_lowres_shape_gate_and_fallback(vkn):
-    """w % 16 != 0, stride 3 or more than 16 images are not taken: `supported` says so, the C entry point returns VKN_E_SHAPE, and the
+    """S w % 8 != 0, stride 3 or more than 16 images are not taken: `supported` says so, the C entry point returns VKN_E_SHAPE, and the
     assigner computes the same assignment from the up-scaled tensors instead"""
-    assert not vkn.ops.assign_costs_lowres_supported(100, [5], 16, 24, 4)
+    assert vkn.ops.assign_costs_lowres_supported(100, [5], 16, 24, 4)             # (ragged maps run since the RAGGED form)
     assert not vkn.ops.assign_costs_lowres_supported(100, [5], 16, 32, 3)
     assert not vkn.ops.assign_costs_lowres_supported(100, [5] * 17, 16, 32, 4)
-    assert not vkn.ops.assign_costs_lowres_supported(100, [5], 3, 32, 2)          # 6 up-scaled rows: not a whole tile
+    assert not vkn.ops.assign_costs_lowres_supported(100, [5], 3, 31, 2)         # 62 up-scaled columns: a lane's 8 pixels would straddle the edge
     assert vkn.ops.assign_costs_lowres_supported(100, [5] * 16, 16, 32, 4)
-    N, Gs, ncls, h, w, S = 40, [6, 3], 4, 16, 24, 4
+    N, Gs, ncls, h, w, S = 40, [6, 3], 4, 16, 23, 2
     lows, clss, gts, labs = _case(N, Gs, ncls, h, w, S, 3, False)
     dl, dc, dg, dlab = ([t.to(DEV) for t in v] for v in (lows, clss, gts, labs))
     with pytest.raises(ValueError):

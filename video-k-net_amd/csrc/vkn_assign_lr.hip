@@ -77,7 +77,9 @@ __device__ __forceinline__ void al_split8(const float (&p)[8], half8& hi, half8&
     }
 }
 
-template <int S>
+// RAGGED: the map is not a whole number of tiles (w % 16 != 0 or S h % 8 != 0; S w % 8 == 0 still holds, so a lane's 8 pixels are inside
+// or outside the map as a whole): steps beyond the right / bottom edge load a clamped (valid) address and are masked out of every sum.
+template <int S, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void k_assign_lr(const AlArgs A) {
     constexpr int TW = 16 * S, NR = 8 / S + 2, NC = 8 / S + 2, NCL = 18, MS = S, CS = 129;   // (odd stride: the fill's writes and the lanes' reads both walk consecutive banks)
     constexpr int NF = NR * NCL * 128 / 256, NQ = MS * 8;
@@ -91,8 +93,8 @@ __global__ __launch_bounds__(256, 2) void k_assign_lr(const AlArgs A) {
     if (zg * 32 >= I.G) return;   // (uniform: this image has fewer ground truths than the widest of the batch)
     const int H = S * A.h, W = S * A.w;
     const size_t lp = (size_t)A.h * A.w, HP = (size_t)H * W;
-    const int tilesx = W / TW;
-    const float* grow = I.gt + (size_t)min(zg * 32 + li, I.G - 1) * HP + 8 * half;
+    const int tilesx = (W + TW - 1) / TW;
+    const float* grow = I.gt + (size_t)min(zg * 32 + li, I.G - 1) * HP + (RAGGED ? 0 : 8 * half);
     // second-level accumulators (the tile sums are flushed into them once per tile): in LDS — 32 registers per lane that would
     // otherwise live across the whole tile loop
     float* TOT = al_lds + NR * NCL * CS + 4 * 64 + wave * (2 * 16 * 64) + lane;
@@ -142,14 +144,24 @@ __global__ __launch_bounds__(256, 2) void k_assign_lr(const AlArgs A) {
         // before step q's arithmetic; the scheduling barrier between steps keeps hipcc from hoisting EVERY step's loads to the top of
         // the tile (256 registers of ground truth, spills)
         const size_t g0 = (size_t)(8 * ty) * W + TW * tx;
-        f32x4 ga0 = *reinterpret_cast<const f32x4*>(grow + g0), ga1 = *reinterpret_cast<const f32x4*>(grow + g0 + 4);
+        // offset of step q's 8 pixels of this lane (RAGGED: row and column clamped into the map) and whether they exist
+        auto goff = [&](int q) -> size_t {
+            if (!RAGGED) return g0 + (size_t)(q & 7) * W + 16 * (q >> 3);
+            const int yy = min(8 * ty + (q & 7), H - 1), xx = min(TW * tx + 16 * (q >> 3) + 8 * half, W - 8);
+            return (size_t)yy * W + xx;
+        };
+        auto gval = [&](int q) -> float {
+            if (!RAGGED) return 1.f;
+            return (8 * ty + (q & 7) < H && TW * tx + 16 * (q >> 3) + 8 * half < W) ? 1.f : 0.f;
+        };
+        f32x4 ga0 = *reinterpret_cast<const f32x4*>(grow + goff(0)), ga1 = *reinterpret_cast<const f32x4*>(grow + goff(0) + 4);
         float hz[NR][8];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int m = q >> 3, y = q & 7;
             f32x4 gn0, gn1;
             if (q + 1 < NQ) {
-                const size_t gq = g0 + (size_t)((q + 1) & 7) * W + 16 * ((q + 1) >> 3);
+                const size_t gq = goff(q + 1);
                 gn0 = *reinterpret_cast<const f32x4*>(grow + gq);
                 gn1 = *reinterpret_cast<const f32x4*>(grow + gq + 4);
             }
@@ -167,15 +179,26 @@ __global__ __launch_bounds__(256, 2) void k_assign_lr(const AlArgs A) {
                     for (int e = 0; e < 8; ++e)
                         hz[r][e] = __builtin_fmaf(al_l<S>(e), v[r][al_j0<S>(e) + 2], (1.f - al_l<S>(e)) * v[r][al_j0<S>(e) + 1]);
             }
+            const float vq = gval(q);
             float p1[8], p2[8];
+            float q1 = 0.f, q2 = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float z = __builtin_fmaf(al_l<S>(y), hz[al_j0<S>(y) + 2][e], (1.f - al_l<S>(y)) * hz[al_j0<S>(y) + 1][e]);
                 const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
                 p1[e] = fmaxf(s, lo1);
                 p2[e] = fmaxf(s, lo2);
-                ts1 = __builtin_fmaf(p1[e], p1[e], ts1);
-                ts2 += p2[e];
+                if (RAGGED) {
+                    q1 = __builtin_fmaf(p1[e], p1[e], q1);
+                    q2 += p2[e];
+                } else {
+                    ts1 = __builtin_fmaf(p1[e], p1[e], ts1);
+                    ts2 += p2[e];
+                }
+            }
+            if (RAGGED) {
+                ts1 = __builtin_fmaf(vq, q1, ts1);
+                ts2 = __builtin_fmaf(vq, q2, ts2);
             }
             half8 h1, l1, h2, l2;
             al_split8(p1, h1, l1);
@@ -183,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void k_assign_lr(const AlArgs A) {
             float gv[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                gv[e] = ga0[e];
-                gv[4 + e] = ga1[e];
+                gv[e] = RAGGED ? ga0[e] * vq : ga0[e];
+                gv[4 + e] = RAGGED ? ga1[e] * vq : ga1[e];
             }
             {   // (predicated, not branched: a branch per step splits the tile into 64 basic blocks and hipcc spills ~500 registers)
                 const float gm = ((gmask >> q) & 1u) ? 1.f : 0.f;
@@ -309,10 +332,10 @@ struct AlPlan {
 };
 // 0 = this shape runs here
 int al_plan(int nprob, int N, int Gmax, int h, int w, int S, AlPlan* p) {
-    if ((S != 2 && S != 4) || N <= 0 || N > 256 || Gmax <= 0 || Gmax > 256 || h <= 0 || w <= 0 || (w % 16) != 0 || ((S * h) % 8) != 0) return VKN_E_SHAPE;
+    if ((S != 2 && S != 4) || N <= 0 || N > 256 || Gmax <= 0 || Gmax > 256 || h <= 0 || w <= 0 || ((S * w) % 8) != 0) return VKN_E_SHAPE;
     if ((size_t)N * h * w * sizeof(float) >= (1ull << 31)) return VKN_E_SHAPE;   // (the low-res tile is read through 32-bit buffer offsets)
     p->Npad = (N + 31) / 32 * 32;
-    p->ntiles = (S * h / 8) * (w / 16);
+    p->ntiles = ((S * h + 7) / 8) * ((w + 15) / 16);
     p->tpw = (p->ntiles + AL_WGS - 1) / AL_WGS;
     p->nwg = (p->ntiles + p->tpw - 1) / p->tpw;
     p->GBT = (Gmax + 31) / 32;   // one pass over the image per block of 32 ground truths (the activations are recomputed per pass)
@@ -363,12 +386,15 @@ int vkn_assign_costs_lowres_batch_f32(const VknAssignCfg* cfg, const VknAssignPr
     const int ngrp = (p.Npad / 32 + 3) / 4;
     const dim3 grid(p.nwg, nprob, ngrp * p.GBT);
     const size_t lds = ((size_t)(8 / S + 2) * 18 * 129 + 4 * 64 + 4 * 2 * 16 * 64) * sizeof(float);
-    if (lds > 64 * 1024) {
-        if (S == 4) VKN_ALLOW_FULL_LDS((k_assign_lr<4>));
-        else VKN_ALLOW_FULL_LDS((k_assign_lr<2>));
-    }
-    if (S == 4) hipLaunchKernelGGL((k_assign_lr<4>), grid, dim3(256), lds, st, A);
-    else hipLaunchKernelGGL((k_assign_lr<2>), grid, dim3(256), lds, st, A);
+    const bool ragged = (w % 16) != 0 || ((S * h) % 8) != 0;
+#define AL_LAUNCH_(SV, RV)                                                              \
+    do {                                                                                \
+        if (lds > 64 * 1024) VKN_ALLOW_FULL_LDS((k_assign_lr<SV, RV>));                 \
+        hipLaunchKernelGGL((k_assign_lr<SV, RV>), grid, dim3(256), lds, st, A);         \
+    } while (0)
+    if (S == 4) { if (ragged) AL_LAUNCH_(4, true); else AL_LAUNCH_(4, false); }
+    else { if (ragged) AL_LAUNCH_(2, true); else AL_LAUNCH_(2, false); }
+#undef AL_LAUNCH_
     VKN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_assign_cost_lr, dim3((N + 63) / 64, Gmax, nprob), dim3(256), 0, st, A, *cfg, ncls, (double)HP);
     VKN_CHECK_LAUNCH();
