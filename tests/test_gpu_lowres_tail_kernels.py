@@ -70,3 +70,33 @@ def test_lowres_forward_and_backward_on_ragged_maps(vkn, B, Ns, h, w, S, K):
     else:
         torch.cuda.synchronize()
         assert bool(torch.isfinite(out_lr).all())
+
+
+def test_lowres_forward_logsumexp_survives_a_huge_spread(vkn):
+    """k_ml_fwd_lr sums exp(z - Mb) against ONE reference point per block (the maximum of the block's taps over all rows); logits spread
+    over +-600 underflow that sum at pixels far from the maximal tap — those blocks are redone with the online form: the lse must still be
+    torch's logsumexp of the up-scaled logits, with no inf / NaN."""
+    L, ops = vkn._lib.lib(), vkn.ops
+    B, Ns, h, w, S, K = 2, 31, 9, 20, 4, 3
+    g = torch.Generator().manual_seed(9)
+    low = (torch.randn(B, Ns, h, w, generator=g) * 200).to(DEV)
+    H, W = S * h, S * w
+    P = H * W
+    bank = (torch.rand(K, H, W, generator=g) > 0.5).float().to(DEV)
+    rowk = torch.full((B * Ns,), -1, dtype=torch.int32)
+    tgt = torch.zeros(B * Ns, dtype=torch.int32)
+    rowk[[3, 17, 40]] = torch.arange(K, dtype=torch.int32)
+    tgt[[3, 17, 40]] = torch.arange(K, dtype=torch.int32)
+    rowk, tgt = rowk.to(DEV), tgt.to(DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ncl = L.vkn_mask_losses_lowres_chunks(h, w)
+    rp, rk = torch.zeros(K, ncl, 4, device=DEV), torch.zeros(B, ncl, device=DEV)
+    lse, top = torch.full((B, P), float('nan'), device=DEV), torch.full((B, P), -7, dtype=torch.int32, device=DEV)
+    assert L.vkn_mask_losses_fwd_lowres_f32(p(low), p(bank), p(tgt), p(rowk), K, B, Ns, h, w, S, 1, p(rp), p(lse), p(top), p(rk), st) == 0
+    torch.cuda.synchronize()
+    want = torch.logsumexp(ops.upsample_bilinear(low, S).double().reshape(B, Ns, P), 1)
+    assert bool(torch.isfinite(lse).all())
+    assert float((lse.double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+    spread = (ops.upsample_bilinear(low, S).reshape(B, Ns, P).amax(1) - low.reshape(B, Ns, -1).amax((1, 2), keepdim=False)[:, None]).min()
+    assert float(spread) < -100.0          # (some pixel's best row really lies far below the map's largest tap: the case exists in this input)

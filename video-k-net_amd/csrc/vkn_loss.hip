@@ -490,16 +490,39 @@ __global__ __launch_bounds__(256, 2) void k_ml_fwd_lr(const float* __restrict__ 
     int pcol[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) pcol[q] = min(max(X0 + PW * q, 0), W - PW);
-    float m[S][S], sm[S][S], zt[S][S];
+    float sm[S][S], zt[S][S];
     unsigned tpk[S];
 #pragma unroll
     for (int a = 0; a < S; ++a) {
         tpk[a] = 0;
 #pragma unroll
-        for (int c = 0; c < S; ++c) { m[a][c] = -INFINITY; sm[a][c] = 0.f; zt[a][c] = 0.f; }
+        for (int c = 0; c < S; ++c) { sm[a][c] = 0.f; zt[a][c] = 0.f; }
     }
     unsigned cov = 0;   // bit (a, c): some positive row covers the pixel (its top row is the byte in tpk)
     __syncthreads();
+    // the logsumexp's reference point: every logit of the block is a convex combination of its row's four taps, so the maximum of the
+    // taps over ALL rows bounds every logit of the block from above — sum exp(z - Mb) cannot overflow and needs no running maximum
+    // (ONE fused multiply-add + v_exp_f32 + add per pixel and row instead of the online form's eight operations).  A first walk over
+    // the rows (taps only: 4 loads + 4 max per row, eight rows in flight) finds it; a block whose sums underflow all the same (a spread
+    // of ~70 between the taps' maximum and the pixel's best row) is redone with the online form at the end.
+    float Mb = -INFINITY;
+    if (with_rank) {
+        for (int n0 = 0; n0 < Ns; n0 += 8) {
+            float t[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int so = min(n0 + u, Ns - 1) * (int)lp * 4;
+                t[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o00, so, 0));
+                t[u][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o01, so, 0));
+                t[u][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o10, so, 0));
+                t[u][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o11, so, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) Mb = fmaxf(Mb, fmaxf(fmaxf(t[u][0], t[u][1]), fmaxf(t[u][2], t[u][3])));
+        }
+    }
+    constexpr float L2E = 1.4426950408889634f;
+    const float mbl = -Mb * L2E;
     float vn[4];
     vn[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o00, 0, 0));
     vn[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o01, 0, 0));
@@ -534,16 +557,10 @@ __global__ __launch_bounds__(256, 2) void k_ml_fwd_lr(const float* __restrict__ 
             }
         }
         if (with_rank) {
-            // online logsumexp, one exponential per pixel: e = exp(-|z - m|); z above the running maximum rescales the sum, else adds to it
 #pragma unroll
             for (int a = 0; a < S; ++a)
 #pragma unroll
-                for (int c = 0; c < S; ++c) {
-                    const float d = z[a][c] - m[a][c];
-                    const float e = __expf(-fabsf(d));
-                    sm[a][c] = d > 0.f ? sm[a][c] * e + 1.f : sm[a][c] + e;
-                    m[a][c] = fmaxf(m[a][c], z[a][c]);
-                }
+                for (int c = 0; c < S; ++c) sm[a][c] += __builtin_amdgcn_exp2f(__builtin_fmaf(z[a][c], L2E, mbl));
         }
         if (k >= 0) {
             const float* trow = bank + (size_t)mt[n] * P;
@@ -586,6 +603,40 @@ __global__ __launch_bounds__(256, 2) void k_ml_fwd_lr(const float* __restrict__ 
     }
     float loss = 0.f;
     if (with_rank) {
+        float m[S][S];
+        bool redo = false;
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+            for (int c = 0; c < S; ++c) {
+                m[a][c] = Mb;
+                redo |= !(sm[a][c] > 1e-30f);
+            }
+        if (redo) {   // (rare) the online form: a running maximum per pixel, one exponential per pixel and row
+#pragma unroll
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+                for (int c = 0; c < S; ++c) { m[a][c] = -INFINITY; sm[a][c] = 0.f; }
+            for (int n = 0; n < Ns; ++n) {
+                const int so = n * (int)lp * 4;
+                const float v00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o00, so, 0));
+                const float v01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o01, so, 0));
+                const float v10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o10, so, 0));
+                const float v11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, o11, so, 0));
+                constexpr float rs = 1.0f / (float)S;
+#pragma unroll
+                for (int a = 0; a < S; ++a)
+#pragma unroll
+                    for (int c = 0; c < S; ++c) {
+                        const float lx = ((float)c + 0.5f) * rs, ly = ((float)a + 0.5f) * rs;
+                        const float zz = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+                        const float d = zz - m[a][c];
+                        const float e = __expf(-fabsf(d));
+                        sm[a][c] = d > 0.f ? sm[a][c] * e + 1.f : sm[a][c] + e;
+                        m[a][c] = fmaxf(m[a][c], zz);
+                    }
+            }
+        }
 #pragma unroll
         for (int a = 0; a < S; ++a)
 #pragma unroll
