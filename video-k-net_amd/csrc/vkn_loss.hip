@@ -281,7 +281,8 @@ __global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __rest
 #pragma unroll
     for (int q = 0; q < NP; ++q) pcol[q] = min(max(X0 + PW * q, 0), W - PW);
     // lse / top of the block's pixels (the frame's, shared by every kernel row).  top as one byte per pixel (Ns <= 256); a pixel that no
-    // positive row covers (top = -1) — or that lies outside the map — carries lse = +inf: its softmax term exp(z - lse) is exactly 0, and
+    // positive row covers (top = -1) — or that lies outside the map — carries lse = +inf (stored: -lse log2(e) = -inf): its softmax term
+    // exp(z - lse) is exactly 0, and
     // a byte that equals no row of THIS workgroup's range [n_lo, n_hi), so that its one-hot term is 0 too: no branch per pixel
     float l[S][S];
     unsigned tpk[S];
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __rest
             for (int e = 0; e < PW; ++e) {
                 const int c = PW * q + e;
                 const bool ok = ((vmask >> (a * S + c)) & 1u) && tv[e] >= 0;
-                l[a][c] = ok ? lv[e] : INFINITY;
+                l[a][c] = ok ? lv[e] * -1.4426950408889634f : -INFINITY;   // (-lse log2(e): the softmax term is exp2(z log2(e) + this) — one fma + v_exp_f32)
                 tpk[a] |= (unsigned)(ok ? tv[e] : (n_lo == 0 ? n_hi & 255 : 0)) << (8 * c);
             }
         }
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(64 * LR_NW, 2) void k_ml_bwd_lr(const float* __rest
                 for (int c = 0; c < S; ++c) {
                     z[a][c] = (1.f - ly) * h0[c] + ly * h1[c];
                     const int tpv = (int)((tpk[a] >> (8 * c)) & 255u);
-                    g[a][c] = cr * (__expf(z[a][c] - l[a][c]) - (tpv == n ? 1.f : 0.f));
+                    g[a][c] = cr * (__builtin_amdgcn_exp2f(__builtin_fmaf(z[a][c], 1.4426950408889634f, l[a][c])) - (tpv == n ? 1.f : 0.f));
                 }
             }
         }
