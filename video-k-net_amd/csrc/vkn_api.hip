@@ -1290,6 +1290,18 @@ int vkn_linear_f32(const float* A, const float* W, const void* w_split, const fl
     if (!A || !W || !out || M <= 0 || K <= 0 || Nout <= 0) return VKN_E_ARG;
     if (K % 32 != 0) return VKN_E_SHAPE;
     if (ksplit > 1 && (!ws || ws_bytes < (size_t)ksplit * M * Nout * sizeof(float))) return VKN_E_WORKSPACE;
+    if (w_split && K == 256 && ksplit <= 1 && M > 128 && M <= 32 * VKN_KS_MAX_ROW_TILES && aligned16(A) && aligned16(out) &&
+        act >= 0 && act <= 2) {
+        // few hundred rows (the training chain at 2 - 4 frames per step): the column-spread phase kernel of the few-row chain as a
+        // plain GEMM — 32 x 32 output tiles over (row tiles x column blocks) workgroups, each one round trip — instead of one
+        // 512-thread workgroup per 32 rows that streams the whole weight image (k_gemm_t3: 15 workgroups at 468 rows)
+        VknKsProb p{};
+        p.pro.a[0] = A; p.pro.lda[0] = K; p.pro.nsum = 1; p.pro.eps = 1e-5f;
+        p.Wsplit = w_split; p.Nout = Nout; p.KT = 8;
+        p.epi.bias = bias; p.epi.act = act; p.epi.out = out; p.epi.ldo = Nout;
+        const int rc = vkn_launch_gemm_ks(&p, 1, 0, 0, 1, 0, M, static_cast<hipStream_t>(stream));
+        if (rc != VKN_E_SHAPE) return rc;
+    }
     VknEpi e{};
     e.bias = bias; e.act = act; e.out = out; e.ldo = Nout; e.eps = 1e-5f;
     return vkn_launch_gemm(A, nullptr, K, W, w_split, M, K, Nout, ksplit, static_cast<float*>(ws), e,
