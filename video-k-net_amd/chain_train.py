@@ -132,7 +132,12 @@ def _gemm(a, weight, images, bias, act, K, Nout):
     M = a.shape[0]
     out = torch.empty((M, Nout), dtype=torch.float32, device=a.device)
     ksplit, ws = 1, None
-    if K >= 1024 and Nout <= 256:          # long contraction, few row tiles: split K over workgroups (fixed-order row epilogue)
+    if 128 < M <= 512 and K > 256 and K % 256 == 0 and K <= 2048:
+        # a few hundred rows: the contraction in chunks of 256 (512 from K = 1024 on) over blockIdx.z of the few-row phase kernel
+        # (vkn_linear_f32), partial products summed in fixed order by the row epilogue
+        ksplit = K // 256 if K < 1024 else K // 512
+        ws = torch.empty(ksplit * M * Nout, dtype=torch.float32, device=a.device)
+    elif K >= 1024 and Nout <= 256:        # long contraction, few row tiles: split K over workgroups (fixed-order row epilogue)
         ksplit = 8
         ws = torch.empty(ksplit * M * Nout, dtype=torch.float32, device=a.device)
     check(_lib.lib().vkn_linear_f32(_ptr(a), _ptr(weight), _ptr(images), _ptr(bias), _ptr(out), M, K, Nout, int(act), ksplit,

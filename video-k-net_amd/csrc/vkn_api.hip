@@ -1302,6 +1302,22 @@ int vkn_linear_f32(const float* A, const float* W, const void* w_split, const fl
         const int rc = vkn_launch_gemm_ks(&p, 1, 0, 0, 1, 0, M, static_cast<hipStream_t>(stream));
         if (rc != VKN_E_SHAPE) return rc;
     }
+    if (w_split && ksplit > 1 && K % ksplit == 0 && (K / ksplit == 256 || K / ksplit == 512) && M > 128 && M <= 32 * VKN_KS_MAX_ROW_TILES &&
+        aligned16(A) && aligned16(out) && aligned16(ws) && act >= 0 && act <= 2) {
+        // ... and a longer contraction in chunks of 256 / 512 over blockIdx.z of the same kernel (partial products in `ws`), summed in
+        // fixed order with bias and activation by the row epilogue
+        VknKsProb p{};
+        p.pro.a[0] = A; p.pro.lda[0] = K; p.pro.nsum = 1; p.pro.eps = 1e-5f;
+        p.Wsplit = w_split; p.Nout = Nout; p.KT = K / 32;
+        p.epi.out = static_cast<float*>(ws); p.epi.ldo = Nout;
+        const int rc = vkn_launch_gemm_ks(&p, 1, 0, ksplit, K / ksplit / 256, (long long)M * Nout, M, static_cast<hipStream_t>(stream));
+        if (rc == VKN_OK) {
+            VknEpi e{};
+            e.bias = bias; e.act = act; e.out = out; e.ldo = Nout; e.eps = 1e-5f;
+            return vkn_launch_rowepi(static_cast<const float*>(ws), ksplit, M, Nout, e, static_cast<hipStream_t>(stream));
+        }
+        if (rc != VKN_E_SHAPE) return rc;
+    }
     VknEpi e{};
     e.bias = bias; e.act = act; e.out = out; e.ldo = Nout; e.eps = 1e-5f;
     return vkn_launch_gemm(A, nullptr, K, W, w_split, M, K, Nout, ksplit, static_cast<float*>(ws), e,
