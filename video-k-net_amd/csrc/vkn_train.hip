@@ -884,25 +884,56 @@ __global__ __launch_bounds__(512) void k_attn_bwd_mfma(const float* __restrict__
     const size_t qrow0 = (size_t)b * Nq, krow0 = (size_t)b * Nk;
     const int col0 = h * HD;
 
-    for (int idx = tid; idx < KB * 32 * HD; idx += blockDim.x) {
-        const int j = idx / HD, d = idx - j * HD;
-        const bool ok = j < Nk;
-        Ks[j * LD + d] = ok ? Kp[(krow0 + j) * ldkv + col0 + d] : 0.f;
-        Vs[j * LD + d] = ok ? Vp[(krow0 + j) * ldkv + col0 + d] : 0.f;
-        aK[idx] = 0.f;
-        aV[idx] = 0.f;
-    }
-    // (the HD lanes of a row sit in one wave, and a wave's last iteration runs whole rows or nothing)
-    for (int idx = tid; idx < QB * 32 * HD; idx += blockDim.x) {
-        const int i = idx / HD, d = idx - i * HD;
-        const bool ok = i < Nq;
-        const float g = ok ? dO[(qrow0 + i) * lddo + col0 + d] : 0.f;
-        Qs[i * LD + d] = ok ? Q[(qrow0 + i) * ldq + col0 + d] : 0.f;
-        Gs[i * LD + d] = g;
-        float pd = ok ? g * O[(qrow0 + i) * ldo + col0 + d] : 0.f;      // D_i = dO_i . O_i: summed over the row's HD lanes
+    // staging: FOUR iterations' loads are requested before the first LDS store (a rolled load -> store loop is one memory round trip per
+    // iteration: 16 + 16 of them were two thirds of this kernel's 47 us at 117 kernels)
+    for (int base = 0; base < KB * 32 * HD; base += 4 * blockDim.x) {
+        float kv[4], vv[4];
 #pragma unroll
-        for (int o = 1; o < HD; o <<= 1) pd += __shfl_xor(pd, o);
-        if (d == 0) Ds[i] = pd;
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * blockDim.x + tid;
+            const int j = idx / HD, d = idx - j * HD;
+            const bool ok = idx < KB * 32 * HD && j < Nk;
+            kv[u] = ok ? Kp[(krow0 + j) * ldkv + col0 + d] : 0.f;
+            vv[u] = ok ? Vp[(krow0 + j) * ldkv + col0 + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * blockDim.x + tid;
+            if (idx < KB * 32 * HD) {
+                const int j = idx / HD, d = idx - j * HD;
+                Ks[j * LD + d] = kv[u];
+                Vs[j * LD + d] = vv[u];
+                aK[idx] = 0.f;
+                aV[idx] = 0.f;
+            }
+        }
+    }
+    // (the HD lanes of a row sit in one wave, and a wave's last iteration runs whole rows or nothing: QB * 32 * HD and blockDim.x are
+    // multiples of 64, so a wave is inside or outside the range as a whole and the shuffles below see full rows)
+    for (int base = 0; base < QB * 32 * HD; base += 4 * blockDim.x) {
+        float qv[4], gv[4], ov[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * blockDim.x + tid;
+            const int i = idx / HD, d = idx - i * HD;
+            const bool ok = idx < QB * 32 * HD && i < Nq;
+            gv[u] = ok ? dO[(qrow0 + i) * lddo + col0 + d] : 0.f;
+            qv[u] = ok ? Q[(qrow0 + i) * ldq + col0 + d] : 0.f;
+            ov[u] = ok ? O[(qrow0 + i) * ldo + col0 + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * blockDim.x + tid;
+            if (idx < QB * 32 * HD) {
+                const int i = idx / HD, d = idx - i * HD;
+                Qs[i * LD + d] = qv[u];
+                Gs[i * LD + d] = gv[u];
+                float pd = gv[u] * ov[u];                                   // D_i = dO_i . O_i: summed over the row's HD lanes
+#pragma unroll
+                for (int o = 1; o < HD; o <<= 1) pd += __shfl_xor(pd, o);
+                if (d == 0) Ds[i] = pd;
+            }
+        }
     }
     __syncthreads();
 
