@@ -101,15 +101,31 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode_mfma(
             const _Float16* gh = kfh + (size_t)b * fs.plane + (size_t)n0 * C;
             const _Float16* gl = kfl + (size_t)b * fs.plane + (size_t)n0 * C;
             const int cpr = C >> 3;
-            for (int i = threadIdx.x; i < NB * 32 * cpr; i += DEC_THREADS) {
-                const int r = i / cpr, q = i - r * cpr;
-                half8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (n0 + r < N) {  // rows >= N of the planes are never written by the producer: treat as zero
-                    vh = *reinterpret_cast<const half8*>(gh + (size_t)r * C + q * 8);
-                    vl = *reinterpret_cast<const half8*>(gl + (size_t)r * C + q * 8);
+            // FOUR iterations' loads (8 x 16 bytes per thread) are requested before the first LDS store: the rolled load -> store loop
+            // was one memory round trip per iteration — eight in a row at C = 256, most of this kernel's time at one frame per launch
+            const int items = NB * 32 * cpr;
+            for (int i0 = threadIdx.x; i0 < items; i0 += 4 * DEC_THREADS) {
+                half8 vh[4], vl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * DEC_THREADS;
+                    const int r = i / cpr, q = i - r * cpr;
+                    vh[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    vl[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (i < items && n0 + r < N) {  // rows >= N of the planes are never written by the producer: treat as zero
+                        vh[u] = *reinterpret_cast<const half8*>(gh + (size_t)r * C + q * 8);
+                        vl[u] = *reinterpret_cast<const half8*>(gl + (size_t)r * C + q * 8);
+                    }
                 }
-                *reinterpret_cast<half8*>(ldsH + r * LDK + q * 8) = vh;
-                *reinterpret_cast<half8*>(ldsL + r * LDK + q * 8) = vl;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * DEC_THREADS;
+                    if (i < items) {
+                        const int r = i / cpr, q = i - r * cpr;
+                        *reinterpret_cast<half8*>(ldsH + r * LDK + q * 8) = vh[u];
+                        *reinterpret_cast<half8*>(ldsL + r * LDK + q * 8) = vl[u];
+                    }
+                }
             }
         }
         // folded decode bias of the chunk's rows -> LDS (accumulators start from it)

@@ -221,15 +221,31 @@ __global__ __launch_bounds__(IP_THREADS, 2) void k_init_pass(const InitPassArgs 
     if (total > 0) IP_LOAD(L0, S0);   // the first pair is requested before the planes are staged (its latency runs under the staging)
     {   // planes -> LDS (rows >= Np + ncls: zero), bias of the semantic rows
         const int cpr = C >> 3;
-        for (int i = tid; i < NB * 32 * cpr; i += IP_THREADS) {
-            const int r = i / cpr, q = i - r * cpr;
-            half8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (r < Ntot) {
-                vh = *reinterpret_cast<const half8*>(A.kh + (size_t)r * C + q * 8);
-                vl = *reinterpret_cast<const half8*>(A.kl + (size_t)r * C + q * 8);
+        // (four iterations' loads in flight before the first LDS store, as in k_decode_mfma: a rolled load -> store loop is one memory
+        // round trip per iteration)
+        const int items = NB * 32 * cpr;
+        for (int i0 = tid; i0 < items; i0 += 4 * IP_THREADS) {
+            half8 vh[4], vl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * IP_THREADS;
+                const int r = i / cpr, q = i - r * cpr;
+                vh[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                vl[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (i < items && r < Ntot) {
+                    vh[u] = *reinterpret_cast<const half8*>(A.kh + (size_t)r * C + q * 8);
+                    vl[u] = *reinterpret_cast<const half8*>(A.kl + (size_t)r * C + q * 8);
+                }
             }
-            *reinterpret_cast<half8*>(ldsH + r * LDK + q * 8) = vh;
-            *reinterpret_cast<half8*>(ldsL + r * LDK + q * 8) = vl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * IP_THREADS;
+                if (i < items) {
+                    const int r = i / cpr, q = i - r * cpr;
+                    *reinterpret_cast<half8*>(ldsH + r * LDK + q * 8) = vh[u];
+                    *reinterpret_cast<half8*>(ldsL + r * LDK + q * 8) = vl[u];
+                }
+            }
         }
         if (tid < NB * 32) kbs[tid] = (A.seg_b && tid >= A.Np && tid < Ntot) ? A.seg_b[tid - A.Np] : 0.f;
         __syncthreads();
