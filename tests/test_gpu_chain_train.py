@@ -26,7 +26,12 @@ def _rel(got, ref):
 
 
 @pytest.mark.parametrize('M,K,Nout,act,bias', [(468, 256, 512, 0, True), (468, 2048, 256, 0, True), (468, 256, 2048, 1, True),
-                                               (117, 256, 19, 0, True), (33, 64, 64, 0, False), (1000, 256, 768, 0, True)],
+                                               (117, 256, 19, 0, True), (33, 64, 64, 0, False), (1000, 256, 768, 0, True),
+                                               # 129 - 512 rows: the few-row phase kernel as a plain GEMM (K = 256), in chunks over
+                                               # blockIdx.z + the row epilogue (K = 512 / 768 / 2048, at most 256 columns), and what falls
+                                               # back (wider outputs of a long contraction; found by tools/soak.py)
+                                               (468, 256, 19, 1, True), (300, 512, 256, 0, True), (300, 768, 19, 1, True),
+                                               (300, 1024, 300, 0, True), (512, 768, 2048, 1, False), (200, 1536, 64, 0, True), (129, 1280, 256, 0, True)],
                          ids=lambda v: str(v))
 def test_linear_forward_backward_vs_fp64(vkn, M, K, Nout, act, bias):
     ct = vkn.chain_train

@@ -510,6 +510,76 @@ def t_chain_train():
             assert rel(q.grad, qd.grad) < 5e-5 and (packed or rel(kv.grad, kvd.grad) < 5e-5), tag
 
 
+def t_lowres_tail():
+    """round 6: the training tail's low-res kernels at random shapes against the up-scaled forms they replace — assignment costs
+    (vkn_assign_costs_lowres_batch_f32 vs fp64 on the up-scaled logits), forward sums and backward of the mask losses
+    (vkn_mask_losses_{fwd,bwd}_lowres_f32 vs upsample + _bank kernels + the upsample adjoint)."""
+    import ctypes
+    L, ops = vkn._lib.lib(), vkn.ops
+    S = int(rng.choice([2, 4]))
+    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 50))
+    B, Ns, K = int(rng.integers(1, 4)), int(rng.integers(2, 140)), 0
+    H, W = S * h, S * w
+    P = H * W
+    seed = int(rng.integers(0, 100000))
+    LAST['tag'] = ('lowres tail', B, Ns, h, w, S, seed)
+    g = torch.Generator().manual_seed(seed)
+    low = (torch.randn(B, Ns, h, w, generator=g) * float(rng.choice([0.5, 3.0, 12.0]))).to(dev)
+    K = int(rng.integers(1, min(B * Ns, 40) + 1))
+    bank = (torch.rand(K, H, W, generator=g) > 0.6).float().to(dev)
+    rowk = torch.full((B * Ns,), -1, dtype=torch.int32)
+    tgt = torch.zeros(B * Ns, dtype=torch.int32)
+    pos = torch.randperm(B * Ns, generator=g)[:K].sort()[0]
+    rowk[pos] = torch.arange(K, dtype=torch.int32)
+    tgt[pos] = torch.arange(K, dtype=torch.int32)
+    rowk, tgt, posd = rowk.to(dev), tgt.to(dev), pos.to(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scaled = ops.upsample_bilinear(low, S)
+    ncl = L.vkn_mask_losses_lowres_chunks(h, w)
+    rp1, rk1 = torch.zeros(K, ncl, 4, device=dev), torch.zeros(B, ncl, device=dev)
+    lse1, top1 = torch.full((B, P), float('nan'), device=dev), torch.full((B, P), -7, dtype=torch.int32, device=dev)
+    assert L.vkn_mask_losses_fwd_lowres_f32(p(low), p(bank), p(tgt), p(rowk), K, B, Ns, h, w, S, 1, p(rp1), p(lse1), p(top1), p(rk1), st) == 0
+    z = scaled.double().reshape(B, Ns, P)
+    assert float((torch.logsumexp(z, 1) - lse1.double()).abs().max()) < 2e-5 * max(1.0, float(z.abs().max()))
+    if P % 4 == 0:
+        nch, nbl = L.vkn_mask_losses_chunks(P), L.vkn_mask_losses_blocks(P)
+        rp0, rk0 = torch.zeros(K, nch, 4, device=dev), torch.zeros(B, nbl, device=dev)
+        lse0, top0 = torch.zeros(B, P, device=dev), torch.zeros(B, P, dtype=torch.int32, device=dev)
+        assert L.vkn_mask_losses_fwd_bank_f32(p(scaled), p(bank), p(tgt), p(posd), p(rowk), K, B, Ns, P, 1, p(rp0), p(lse0), p(top0), p(rk0), st) == 0
+        a, b_ = rp0.double().sum(1), rp1.double().sum(1)
+        assert float(((a - b_).abs() / a.abs().clamp(min=1.0)).max()) < 3e-6 and torch.equal(top0, top1)
+        a_, bc = (torch.rand(K, generator=g) * 50).to(dev), (torch.rand(K, generator=g) * 50 + 60).to(dev)
+        one = torch.ones(1, device=dev)
+        out_lr, gs = torch.full_like(low, float('nan')), torch.empty_like(scaled)
+        assert L.vkn_mask_losses_bwd_lowres_f32(p(low), p(bank), p(tgt), p(rowk), p(a_), p(bc), p(one), p(one), p(one), 1.0, 4.0, 0.1, K,
+                                                p(lse1), p(top1), B, Ns, h, w, S, 1, p(out_lr), st) == 0
+        assert L.vkn_mask_losses_bwd_bank_f32(p(scaled), p(bank), p(tgt), p(rowk), p(a_), p(bc), p(one), p(one), p(one), 1.0, 4.0, 0.1, K,
+                                              p(lse1), p(top1), B, Ns, P, 1, p(gs), st) == 0
+        ref = ops.upsample_bilinear_bwd(gs, S)
+        assert float((out_lr - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+    # assignment costs
+    N = int(rng.integers(1, min(Ns, 256) + 1))
+    Gs = [int(rng.integers(1, 45)) for _ in range(B)]
+    if ops.assign_costs_lowres_supported(N, Gs, h, w, S):
+        ncls = int(rng.integers(1, 9))
+        gts = [(torch.rand(G, H, W, generator=g) > 0.7).float().to(dev) for G in Gs]
+        if rng.random() < 0.5:
+            gts = [F.avg_pool2d(t[None], 3, 1, 1)[0].contiguous() for t in gts]
+        cls = [torch.randn(N, ncls, generator=g).to(dev) for _ in Gs]
+        labs = [torch.randint(0, ncls, (G,), generator=g).to(dev) for G in Gs]
+        got = ops.assign_costs_lowres_batch([low[b][:N] for b in range(B)], S, cls, gts, labs)
+        for b in range(B):
+            pz = scaled[b][:N].double().sigmoid()
+            p1, p2, gd = pz.clamp(0.001, 1.0).flatten(1), pz.clamp(0.01, 1.0).flatten(1), gts[b].double().flatten(1)
+            dice = -(2 * p1 @ gd.t()) / ((p1 * p1).sum(1, keepdim=True) + 1e-3 + (gd * gd).sum(1)[None] + 1e-3)
+            mcost = -(p2 @ gd.t() + (1 - p2) @ (1 - gd).t()) / P
+            pc = cls[b].double().sigmoid()
+            foc = (-(pc + 1e-12).log() * 0.25 * (1 - pc) ** 2 + (1 - pc + 1e-12).log() * 0.75 * pc ** 2)[:, labs[b]]
+            want = 2.0 * foc + 4.0 * dice + mcost
+            assert float((got[b].double() - want).abs().max()) < 1e-5 * max(2.0, float(want.abs().max())), ('assign', b)
+
+
 _heads = {}
 only = sys.argv[2:]
 with torch.no_grad():
@@ -521,7 +591,7 @@ with torch.no_grad():
                      ('device LSAP vs host solver', t_lsap), ('device tracker vs oracle', t_tracker),
                      ('link heads clip vs frame-by-frame', t_link_heads), ('VIS attention query merge', t_query_merge),
                      ('training ops vs torch', t_train_ops), ('attention head widths / key blocks', t_attn_widths),
-                     ('training chain kernels vs torch fp64', t_chain_train)):
+                     ('training chain kernels vs torch fp64', t_chain_train), ('low-res training tail', t_lowres_tail)):
         if not only or any(o in name for o in only):
             section(name, fn)
 print('soak: OK')

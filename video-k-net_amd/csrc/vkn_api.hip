@@ -1302,7 +1302,7 @@ int vkn_linear_f32(const float* A, const float* W, const void* w_split, const fl
         const int rc = vkn_launch_gemm_ks(&p, 1, 0, 0, 1, 0, M, static_cast<hipStream_t>(stream));
         if (rc != VKN_E_SHAPE) return rc;
     }
-    if (w_split && ksplit > 1 && K % ksplit == 0 && (K / ksplit == 256 || K / ksplit == 512) && M > 128 && M <= 32 * VKN_KS_MAX_ROW_TILES &&
+    if (w_split && ksplit > 1 && Nout <= 256 && K % ksplit == 0 && (K / ksplit == 256 || K / ksplit == 512) && M > 128 && M <= 32 * VKN_KS_MAX_ROW_TILES &&
         aligned16(A) && aligned16(out) && aligned16(ws) && act >= 0 && act <= 2) {
         // ... and a longer contraction in chunks of 256 / 512 over blockIdx.z of the same kernel (partial products in `ws`), summed in
         // fixed order with bias and activation by the row epilogue
