@@ -396,3 +396,41 @@ def test_deferred_upscaling_is_materialised_when_a_stage_falls_back(vkn):
     (la, xa, pa), (lb, xb, pb) = outs
     assert sorted(la) == sorted(lb) and all(abs(la[k] - lb[k]) <= 2e-6 * max(1.0, abs(lb[k])) for k in lb), (la, lb)
     assert maxabs(xa, xb) < 2e-5 * float(xb.abs().max()) and maxabs(pa, pb) < 2e-5 * float(pb.abs().max())
+
+
+@pytest.mark.parametrize('name', ['train_cfg', 'train_video_c256'])
+def test_post_assign_head_low_res_path_equals_the_upscaled_path(vkn, name):
+    """`post_assign=True` (a stage is assigned on its OWN predictions, reference knet/det/kernel_iter_head.py:165-171) through the
+    round-6 path — assignment costs from the low-res logits, no up-scaled tensor for the non-final stages — against the same head with
+    the low-res forms switched off (`lowres_tail = False`, `lowres_costs = False`): identical assignments, losses and gradients to
+    fp32 summation order."""
+    outs = []
+    for low in (True, False):
+        g, case, head, (x, pf, mp, prev), (gt_masks, gt_labels, gt_sem_seg, gt_sem_cls) = _train_case(vkn, name)
+        head.post_assign = True
+        head.lowres_tail = low
+        assigned = []
+        for a in head.mask_assigner:
+            a.lowres_costs = low
+            for meth in ('assign_batch', 'assign_batch_lowres'):
+                orig = getattr(a, meth)
+
+                def rec(*args, _orig=orig, **kw):
+                    rs = _orig(*args, **kw)
+                    assigned.extend(r.gt_inds.clone() for r in rs)
+                    return rs
+                setattr(a, meth, rec)
+        xd, pfd = x.to(DEV).requires_grad_(True), pf.to(DEV).requires_grad_(True)
+        metas = [dict() for _ in range(case['B'])]
+        if case['video']:
+            losses = head.forward_train_with_previous(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg,
+                                                      gt_sem_cls=gt_sem_cls, previous_obj_feats=prev.to(DEV))[0]
+        else:
+            losses = head.forward_train(xd, pfd, mp.to(DEV), None, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls)
+        assert head._last_tail_fused
+        sum(v for k, v in losses.items() if 'loss' in k).backward()
+        outs.append((torch.stack(assigned), {k: float(v.detach()) for k, v in losses.items()}, xd.grad.clone(), pfd.grad.clone()))
+    (aa, la, xa, pa), (ab, lb, xb, pb) = outs
+    assert torch.equal(aa, ab)
+    assert sorted(la) == sorted(lb) and all(abs(la[k] - lb[k]) <= 2e-6 * max(1.0, abs(lb[k])) for k in lb), (la, lb)
+    assert maxabs(xa, xb) < 2e-5 * float(xb.abs().max()) and maxabs(pa, pb) < 2e-5 * float(pb.abs().max())
