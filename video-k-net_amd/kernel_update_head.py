@@ -382,7 +382,7 @@ class KernelUpdateHead(nn.Module):
             folded = chain_train.linear(xraw.reshape(B * N, C), self.feat_transform.conv.weight.reshape(C, C)).view(B, N, C)
         else:
             folded = xraw @ self.feat_transform.conv.weight.reshape(C, C).t()
-        return folded + cnt.unsqueeze(-1) * self.feat_transform.conv.bias
+        return torch.addcmul(folded, cnt.unsqueeze(-1), self.feat_transform.conv.bias)      # (one launch: folded + cnt * bias)
 
     def _chain_autograd(self, x_feat, proposal_feat, previous_obj_feats=None):
         """The [B*N, C] chain as torch ops on this module's own parameters (reference :198-227; video :324-476):
