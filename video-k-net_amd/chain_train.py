@@ -132,8 +132,8 @@ def _gemm(a, weight, images, bias, act, K, Nout):
     M = a.shape[0]
     out = torch.empty((M, Nout), dtype=torch.float32, device=a.device)
     ksplit, ws = 1, None
-    if 128 < M <= 512 and 256 < K <= 2048 and K % (256 if K < 1024 else 512) == 0 and Nout <= 256:   # (the row epilogue's width)
-        # a few hundred rows: the contraction in chunks of 256 (512 from K = 1024 on) over blockIdx.z of the few-row phase kernel
+    if M <= 512 and 256 < K <= 2048 and K % (256 if K < 1024 else 512) == 0 and Nout <= 256:   # (the row epilogue's width)
+        # up to 512 rows: the contraction in chunks of 256 (512 from K = 1024 on) over blockIdx.z of the few-row phase kernel
         # (vkn_linear_f32), partial products summed in fixed order by the row epilogue
         ksplit = K // 256 if K < 1024 else K // 512
         ws = torch.empty(ksplit * M * Nout, dtype=torch.float32, device=a.device)

@@ -1290,9 +1290,9 @@ int vkn_linear_f32(const float* A, const float* W, const void* w_split, const fl
     if (!A || !W || !out || M <= 0 || K <= 0 || Nout <= 0) return VKN_E_ARG;
     if (K % 32 != 0) return VKN_E_SHAPE;
     if (ksplit > 1 && (!ws || ws_bytes < (size_t)ksplit * M * Nout * sizeof(float))) return VKN_E_WORKSPACE;
-    if (w_split && K == 256 && ksplit <= 1 && M > 128 && M <= 32 * VKN_KS_MAX_ROW_TILES && aligned16(A) && aligned16(out) &&
+    if (w_split && K == 256 && ksplit <= 1 && M <= 32 * VKN_KS_MAX_ROW_TILES && aligned16(A) && aligned16(out) &&
         act >= 0 && act <= 2) {
-        // few hundred rows (the training chain at 2 - 4 frames per step): the column-spread phase kernel of the few-row chain as a
+        // up to 512 rows (the training chain at 1 - 4 frames per step): the column-spread phase kernel of the few-row chain as a
         // plain GEMM — 32 x 32 output tiles over (row tiles x column blocks) workgroups, each one round trip — instead of one
         // 512-thread workgroup per 32 rows that streams the whole weight image (k_gemm_t3: 15 workgroups at 468 rows)
         VknKsProb p{};
@@ -1302,7 +1302,7 @@ int vkn_linear_f32(const float* A, const float* W, const void* w_split, const fl
         const int rc = vkn_launch_gemm_ks(&p, 1, 0, 0, 1, 0, M, static_cast<hipStream_t>(stream));
         if (rc != VKN_E_SHAPE) return rc;
     }
-    if (w_split && ksplit > 1 && Nout <= 256 && K % ksplit == 0 && (K / ksplit == 256 || K / ksplit == 512) && M > 128 && M <= 32 * VKN_KS_MAX_ROW_TILES &&
+    if (w_split && ksplit > 1 && Nout <= 256 && K % ksplit == 0 && (K / ksplit == 256 || K / ksplit == 512) && M <= 32 * VKN_KS_MAX_ROW_TILES &&
         aligned16(A) && aligned16(out) && aligned16(ws) && act >= 0 && act <= 2) {
         // ... and a longer contraction in chunks of 256 / 512 over blockIdx.z of the same kernel (partial products in `ws`), summed in
         // fixed order with bias and activation by the row epilogue
